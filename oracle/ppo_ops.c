@@ -1,0 +1,347 @@
+/*
+ * ppo_ops.c -- ORACLE (test infrastructure, NOT product code).
+ *
+ * Pushes, gyro scatter (+ ring map build), density, gather helper and the ps_combo160 pseudo
+ * push, restated from:
+ *   test/ellipticalPush.hpp:10-70          src/pumipic_push.hpp:17-75
+ *   test/pseudoPushAndSearch.cpp:87-119,340-374
+ *   test/gyroScatter.hpp:28-229            test/pseudoXGCm.cpp:102-114
+ *   performance_tests/ps_combo160.cpp:152-178
+ *   src/pumipic_adjacency.hpp:772-790
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <math.h>
+#include "ppo.h"
+#include "ppo_geom.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+static void* xcalloc(size_t n, size_t s) {
+  void* p = calloc(n ? n : 1, s ? s : 1);
+  if (!p) {
+    fprintf(stderr, "ppo: out of memory\n");
+    exit(EXIT_FAILURE);
+  }
+  return p;
+}
+
+#define MD(ps, m) ((double*)(ps)->data[m])
+#define MF(ps, m) ((float*)(ps)->data[m])
+#define MI(ps, m) ((int*)(ps)->data[m])
+#define ML(ps, m) ((long*)(ps)->data[m])
+
+typedef struct {
+  int cap;
+  int* elem;
+  unsigned char* mask;
+} slots;
+static slots get_slots(const ppo_ps* ps) {
+  slots s;
+  s.cap = ps->capacity;
+  s.elem = (int*)xcalloc((size_t)s.cap, sizeof(int));
+  s.mask = (unsigned char*)xcalloc((size_t)s.cap, 1);
+  ppo_ps_slot_info(ps, s.elem, s.mask);
+  if (ps->num_ptcls == 0) /* parallel_for is a no-op then */
+    for (int i = 0; i < s.cap; ++i) {
+      s.elem[i] = -1;
+      s.mask[i] = 0;
+    }
+  return s;
+}
+static void free_slots(slots* s) {
+  free(s->elem);
+  free(s->mask);
+}
+
+/* test/ellipticalPush.hpp:10-33 */
+void ppo_elliptical_setup(ppo_ps* ps, int m_x, int m_b, int m_phi, double h, double k, double d) {
+  slots s = get_slots(ps);
+  const size_t A = (size_t)ps->alloc;
+  for (int pid = 0; pid < s.cap; ++pid) {
+    if (!s.mask[pid]) continue;
+    const double w = MD(ps, m_x)[pid];
+    const double z = MD(ps, m_x)[A + pid];
+    const double phi = atan2(d * (z - k), w - h);
+    const double b = (z - k) / sin(phi);
+    MF(ps, m_phi)[pid] = (float)phi;
+    MF(ps, m_b)[pid] = (float)b;
+  }
+  free_slots(&s);
+}
+
+static void trig(int mode, double x, double* sn, double* cs) {
+  if (mode == 0) {
+    *sn = sin(x);
+    *cs = cos(x);
+  } else {
+    ppo_sincos(x, sn, cs);
+  }
+}
+
+/* test/ellipticalPush.hpp:36-70 */
+void ppo_elliptical_push(ppo_ps* ps, const ppo_mesh* mesh, int m_xtgt, int m_b, int m_phi,
+                         double h, double k, double d, double deg, int trigmode) {
+  slots s = get_slots(ps);
+  const size_t A = (size_t)ps->alloc;
+  for (int pid = 0; pid < s.cap; ++pid) {
+    if (!s.mask[pid]) continue;
+    const int e = s.elem[pid];
+    const double centerFactor = mesh->class_id[e] == 1 ? 0.01 : 1.0;
+    const double distByClass = centerFactor * (double)1.0 / mesh->class_id[e];
+    const double degP = deg * distByClass;
+    const float phi = MF(ps, m_phi)[pid];
+    const float b = MF(ps, m_b)[pid];
+    const double a = b * d;
+    const double rad = phi + degP * M_PI / 180.0;
+    double sn, cs;
+    trig(trigmode, rad, &sn, &cs);
+    const double x = a * cs + h;
+    const double y = b * sn + k;
+    MD(ps, m_xtgt)[pid] = x;
+    MD(ps, m_xtgt)[A + pid] = y;
+    MF(ps, m_phi)[pid] = (float)rad;
+  }
+  free_slots(&s);
+}
+
+/* 3-D tokamak restatement (SURVEY 8(d) "3-D north-star variant"): the same elliptical advance
+ * in the particle's local (R,Z) half-plane, plus a rigid rotation of that half-plane about the
+ * Z axis by the same class-scaled angle.  The toroidal direction is taken from the CURRENT
+ * position (x,y)/hypot so no atan2 is needed and every op is IEEE-exact apart from the shared
+ * sincos: x_tgt = R'*(ux*c - uy*s, ux*s + uy*c), z_tgt = Z'. */
+void ppo_toroidal_push(ppo_ps* ps, const ppo_mesh* mesh, int m_x, int m_xtgt, int m_b, int m_phi,
+                       double h, double k, double d, double deg, int trigmode) {
+  slots s = get_slots(ps);
+  const size_t A = (size_t)ps->alloc;
+  for (int pid = 0; pid < s.cap; ++pid) {
+    if (!s.mask[pid]) continue;
+    const int e = s.elem[pid];
+    const double centerFactor = mesh->class_id[e] == 1 ? 0.01 : 1.0;
+    const double distByClass = centerFactor * (double)1.0 / mesh->class_id[e];
+    const double degP = deg * distByClass;
+    const float phi = MF(ps, m_phi)[pid];
+    const float b = MF(ps, m_b)[pid];
+    const double a = b * d;
+    const double dphi = degP * M_PI / 180.0;
+    const double rad = phi + dphi;
+    double sn, cs, st, ct;
+    trig(trigmode, rad, &sn, &cs);
+    trig(trigmode, dphi, &st, &ct);
+    const double Rn = a * cs + h;
+    const double Zn = b * sn + k;
+    const double x0 = MD(ps, m_x)[pid];
+    const double y0 = MD(ps, m_x)[A + pid];
+    const double r0 = sqrt(x0 * x0 + y0 * y0);
+    const double ux = x0 / r0, uy = y0 / r0;
+    MD(ps, m_xtgt)[pid] = Rn * (ux * ct - uy * st);
+    MD(ps, m_xtgt)[A + pid] = Rn * (ux * st + uy * ct);
+    MD(ps, m_xtgt)[2 * A + pid] = Zn;
+    MF(ps, m_phi)[pid] = (float)rad;
+  }
+  free_slots(&s);
+}
+
+/* test/pseudoPushAndSearch.cpp:104-115 (ptclUnique_d is all zeros) */
+void ppo_linear_push(ppo_ps* ps, int m_x, int m_xtgt, double distance, double dx, double dy,
+                     double dz) {
+  slots s = get_slots(ps);
+  const size_t A = (size_t)ps->alloc;
+  const double disp[4] = {distance, dx, dy, dz};
+  for (int pid = 0; pid < s.cap; ++pid) {
+    if (!s.mask[pid]) continue;
+    double dir[3];
+    dir[0] = disp[0] * disp[1];
+    dir[1] = disp[0] * disp[2];
+    dir[2] = disp[0] * disp[3];
+    for (int i = 0; i < 3; ++i)
+      MD(ps, m_xtgt)[i * A + pid] = MD(ps, m_x)[i * A + pid] + dir[i] + 0.0;
+  }
+  free_slots(&s);
+}
+
+/* src/pumipic_push.hpp:26-71, over n particles */
+void ppo_push_boris(int n, double* x, double* y, double* z, double* xp, double* yp, double* zp,
+                    double* vx, double* vy, double* vz, const double* ex, const double* ey,
+                    const double* ez, const double* br, const double* bt, const double* bz,
+                    double dt) {
+  for (int pid = 0; pid < n; ++pid) {
+    ppo_v3 vel = {{vx[pid], vy[pid], vz[pid]}};
+    const ppo_v3 eField = {{ex[pid], ey[pid], ez[pid]}};
+    const ppo_v3 bField = {{br[pid], bt[pid], bz[pid]}};
+    const double charge = 1, amu = 10;
+    /* osh_mag: Omega_h-side helper not in tree; Euclidean norm */
+    const double bFieldMag = ppo_norm3(bField);
+    const double qPrime = charge * 1.60217662e-19 / (amu * 1.6737236e-27) * dt * 0.5;
+    const double coeff = 2.0 * qPrime / (1.0 + (qPrime * bFieldMag) * (qPrime * bFieldMag));
+    const ppo_v3 qpE = ppo_scale3(eField, qPrime);
+    const ppo_v3 vMinus = ppo_sub3(vel, qpE);
+    const ppo_v3 vmxB = ppo_cross3(vMinus, bField);
+    const ppo_v3 qpVmxB = ppo_scale3(vmxB, qPrime);
+    const ppo_v3 vPrime = ppo_add3(vMinus, qpVmxB);
+    const ppo_v3 vpxB = ppo_cross3(vPrime, bField);
+    const ppo_v3 cVpxB = ppo_scale3(vpxB, coeff);
+    vel = ppo_add3(vMinus, cVpxB);
+    vel = ppo_add3(vel, qpE);
+    const double pre[3] = {xp[pid], yp[pid], zp[pid]};
+    xp[pid] = x[pid];
+    yp[pid] = y[pid];
+    zp[pid] = z[pid];
+    x[pid] = pre[0] + vel.v[0] * dt;
+    y[pid] = pre[1] + vel.v[1] * dt;
+    z[pid] = pre[2] + vel.v[2] * dt;
+    vx[pid] = vel.v[0];
+    vy[pid] = vel.v[1];
+    vz[pid] = vel.v[2];
+  }
+}
+
+/* test/pseudoXGCm.cpp:102-114: every visited slot, masked or not */
+void ppo_update_positions(ppo_ps* ps, int m_x, int m_xtgt) {
+  slots s = get_slots(ps);
+  const size_t A = (size_t)ps->alloc;
+  for (int pid = 0; pid < s.cap; ++pid) {
+    if (s.elem[pid] < 0) continue;
+    for (int i = 0; i < 3; ++i) {
+      MD(ps, m_x)[i * A + pid] = MD(ps, m_xtgt)[i * A + pid];
+      MD(ps, m_xtgt)[i * A + pid] = 0;
+    }
+  }
+  free_slots(&s);
+}
+
+/* performance_tests/ps_combo160.cpp:158-178 */
+void ppo_pseudo_push160(ppo_ps* ps, const double* parentElmData) {
+  slots s = get_slots(ps);
+  const size_t A = (size_t)ps->alloc;
+  for (int p = 0; p < s.cap; ++p) {
+    const int e = s.elem[p];
+    if (e < 0) continue;
+    if (s.mask[p]) {
+      for (int i = 0; i < 17; ++i) {
+        double v = 10.3;
+        v = v * v * v / sqrt((double)p) / sqrt((double)e) + parentElmData[e];
+        MD(ps, 0)[i * A + p] = v;
+      }
+      for (int i = 0; i < 4; ++i) MI(ps, 1)[i * A + p] = 4 * p + i;
+      ML(ps, 2)[p] = p;
+    } else {
+      for (int i = 0; i < 17; ++i) MD(ps, 0)[i * A + p] = 0;
+      for (int i = 0; i < 4; ++i) MI(ps, 1)[i * A + p] = -1;
+      ML(ps, 2)[p] = 0;
+    }
+  }
+  free_slots(&s);
+}
+
+/* test/gyroScatter.hpp:101-166 with searchAndBuildMap :28-95.  The reference loads the ring
+ * points into a scratch SCS and calls search_mesh_2d (maxLoops 100); the per-point walk is the
+ * same function of (start element, target), so the single-point walker (hpp:1160-1252) is used. */
+void ppo_create_gyro_ring_mappings(const ppo_mesh* mesh, double rmax, int gnr, int gppr,
+                                   double theta_deg, int* forward_map, int* backward_map) {
+  const int nverts = mesh->nverts;
+  const long num_points = (long)nverts * gnr * gppr;
+  const double torad = M_PI / 180;
+  const int nvpe = 3;
+  for (long id = 0; id < num_points; ++id) {
+    const int point_id = (int)(id % gppr);
+    const long id2 = id / gppr;
+    const int ring_id = (int)(id2 % gnr);
+    const int vert_id = (int)(id2 / gnr);
+    const double radius = rmax * (ring_id + 1) / gnr;
+    const double deg = theta_deg + (((double)point_id) / gppr * 360);
+    const double rad = deg * torad;
+    double pt[2];
+    pt[0] = mesh->coords[(size_t)vert_id * 2] + radius * cos(rad);
+    pt[1] = mesh->coords[(size_t)vert_id * 2 + 1] + radius * sin(rad);
+    const int start_elem = mesh->vert2elems[mesh->vert2elems_off[vert_id]];
+    /* centroid of the start element = average(vtxCoords) = ((p0+p1)+p2)/3 (unused by the walk) */
+    double orig[2] = {0, 0};
+    for (int c = 0; c < 2; ++c) {
+      double acc = mesh->coords[(size_t)mesh->elem2verts[(size_t)start_elem * 3] * 2 + c];
+      acc = acc + mesh->coords[(size_t)mesh->elem2verts[(size_t)start_elem * 3 + 1] * 2 + c];
+      acc = acc + mesh->coords[(size_t)mesh->elem2verts[(size_t)start_elem * 3 + 2] * 2 + c];
+      orig[c] = acc / 3;
+    }
+    int loops = 0;
+    const int parent = ppo_search_mesh_2d_pt(mesh, orig, pt, (int)id, start_elem, &loops, 100);
+    for (int i = 0; i < nvpe; ++i) {
+      const int v = (parent >= 0) ? mesh->elem2verts[(size_t)parent * nvpe + i] : -1;
+      forward_map[id * nvpe + i] = v;
+      backward_map[id * nvpe + i] = v; /* forward/backward projections are identical (:125-134) */
+    }
+  }
+}
+
+/* test/gyroScatter.hpp:168-229 */
+void ppo_gyro_scatter(const ppo_mesh* mesh, const ppo_ps* ps, const int* v2v, double rmax, int gnr,
+                      int gppr, double* scatter_w) {
+  const int nvpe = mesh->dim + 1; /* 3 = literal; 4 = documented tet variant */
+  const double ringWidth = rmax / gnr;
+  double* ring_accum = (double*)xcalloc((size_t)gnr * mesh->nverts, sizeof(double));
+  slots s = get_slots(ps);
+  for (int pid = 0; pid < s.cap; ++pid) {
+    if (!s.mask[pid]) continue;
+    const int e = s.elem[pid];
+    const double ptclRadius = ringWidth * 1.125;
+    int ringDown = 0;
+    for (int i = 2; i <= gnr; i++) ringDown += (ptclRadius >= ringWidth * i);
+    const int ringUp = ringDown + 1;
+    for (int i = 0; i < nvpe; ++i) {
+      const int v = mesh->elem2verts[(size_t)e * nvpe + i];
+      ring_accum[(size_t)v * gnr + ringUp] += 1;
+      ring_accum[(size_t)v * gnr + ringDown] += 1;
+    }
+  }
+  for (int v = 0; v < mesh->nverts; ++v) scatter_w[v] = 0;
+  for (int v = 0; v < mesh->nverts; ++v) {
+    const long vtxIdx = (long)v * gnr * gppr;
+    for (int ring = 0; ring < gnr; ++ring) {
+      const double accumRingVal = ring_accum[(size_t)v * gnr + ring] / gppr;
+      for (int pt = 0; pt < gppr; ++pt) {
+        const long ptIdx = 3 * (vtxIdx + (long)ring * gppr + pt);
+        for (int elmVtx = 0; elmVtx < 3; ++elmVtx) {
+          const int mappedVtx = v2v[ptIdx + elmVtx];
+          if (mappedVtx >= 0) scatter_w[mappedVtx] += accumRingVal;
+        }
+      }
+    }
+  }
+  free(ring_accum);
+  free_slots(&s);
+}
+
+/* test/pseudoPushAndSearch.cpp:340-374 (counts every visited slot, masked or not) */
+void ppo_avg_ptcl_density(const ppo_mesh* mesh, const ppo_ps* ps, double* elem_cnt,
+                          double* vert_density) {
+  slots s = get_slots(ps);
+  for (int e = 0; e < mesh->nelems; ++e) elem_cnt[e] = 0;
+  for (int pid = 0; pid < s.cap; ++pid)
+    if (s.elem[pid] >= 0 && s.elem[pid] < mesh->nelems) elem_cnt[s.elem[pid]] += 1;
+  for (int v = 0; v < mesh->nverts; ++v) {
+    const int first = mesh->vert2elems_off[v];
+    const int deg = mesh->vert2elems_off[v + 1] - first;
+    double val = 0.00;
+    for (int j = 0; j < deg; ++j) val += elem_cnt[mesh->vert2elems[first + j]];
+    vert_density[v] = val / deg;
+  }
+  free_slots(&s);
+}
+
+/* src/pumipic_adjacency.hpp:772-790.  The reference gathers a 4-vector of field values and
+ * indexes it with d*dof+comp, which is only in range for dof==1; that case is restated. */
+double ppo_interpolate_tet_vtx(const ppo_mesh* mesh, const double* field, int elem,
+                               const double bcc[4], int dof, int comp) {
+  (void)dof;
+  (void)comp;
+  double val = 0;
+  for (int fi = 0; fi < 4; ++fi) {
+    const int d = PPO_TET_OPP[fi];
+    const int v = mesh->elem2verts[(size_t)elem * 4 + d];
+    val = val + bcc[fi] * field[v];
+  }
+  return val;
+}
