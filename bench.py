@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""bench.py -- particles pushed+searched(+scattered+rebuilt) per second on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line (rank 0).
+A "step" is one pass of the hot path over the resident particle population:
+
+  c2 (default, BASELINE.json configs[1]): fused toroidal push + BCC adjacency walk on the
+      100 800-tet tokamak mesh, 10 M particles per GPU, SCS layout (C=64), no rebuild; positions
+      ping-pong x <-> x_tgt and the walk is re-seeded from the previous step's element ids.
+  c3 (configs[2]): c2 + updatePtclPositions + SCS rebuild + gyroScatter x2 every step.
+  2d : the literal 2-D pseudoXGCm step (elliptical push + search_mesh_2d) on 100 352 triangles.
+
+Inputs are synthetic (pumi-pic_amd/synth.py) and resident in HBM before the timed region.
+N > 1: one process per GPU (torch.distributed / RCCL); every rank owns a contiguous block of
+elements and the particles inside it; the full mesh is replicated (reference `Input::FULL`
+buffering), so in c2 no particle leaves its safe zone and there is no data-path collective:
+value = sum over ranks of particles / max-over-ranks time ("weak" scaling).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import pumipic_amd_loader  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+# algorithmic bytes per particle and step (DESIGN.md "roofline")
+BYTES = {
+    # read x(24) b,phi(8) mask(1) seed elem(4) ; write x_tgt(24) phi(4) elem(4)
+    "c2": 69.0,
+    # c2 + rebuild: read all members 60 + new_element 4, write all members 60 + mask 1
+    "c3": 69.0 + 125.0,
+    # read b,phi(8) mask(1) seed(4) ; write x_tgt x,y(16) phi(4) elem(4)
+    "2d": 37.0,
+}
+
+
+def build_workload(pp, capi, name, nptcl, rank, world, deg):
+    synth = pp.synth
+    if name == "2d":
+        coords, e2v, cls = synth.annulus_tri()
+        dim, mdl = 2, 12
+        label = "pseudoXGCm 2-D literal: 100352-tri annulus"
+    else:
+        coords, e2v, cls = synth.torus_tet()
+        dim, mdl = 3, 12
+        label = "pseudoXGCm 100800-tet tokamak mesh"
+    ne = len(e2v)
+    # element-block ownership: rank r owns elements [r*ne/world, (r+1)*ne/world)
+    lo, hi = rank * ne // world, (rank + 1) * ne // world
+    cls_own = np.where((np.arange(ne) >= lo) & (np.arange(ne) < hi), cls, 1 << 20)
+    ppe = synth.xgcm_source_counts(cls_own, nptcl, mdl, seed=synth.ELEMENT_SEED + rank)
+    elem, xyz = synth.particles_in_elements(coords, e2v, ppe, seed=synth.PARTICLE_SEED + rank)
+    R = np.hypot(xyz[0], xyz[1]) if dim == 3 else xyz[0]
+    Z = xyz[2] if dim == 3 else xyz[1]
+    b, phi = synth.elliptical_state(R, Z)
+    info = [xyz, np.zeros_like(xyz), np.arange(nptcl, dtype=np.int32), b, phi]
+    mesh = capi.Mesh(dim, coords, e2v, cls)
+    ps = capi.PS.scs(capi.PARTICLE_XGCM, ne, ppe, C_=64, sigma=2**31 - 1, V=1024, pad_strat=0,
+                     shuffle_padding=0.1, extra_padding=0.0, particle_elements=elem,
+                     particle_info=info)
+    return dict(mesh=mesh, ps=ps, dim=dim, label=label, ne=ne, coords=coords, e2v=e2v, cls=cls,
+                ppe=ppe, elem=elem, info=info)
+
+
+class Stepper:
+    def __init__(self, pp, capi, w, name, deg):
+        self.capi, self.w, self.name, self.deg = capi, w, name, deg
+        s = pp.synth
+        self.h, self.k, self.d = s.XGC_H, s.XGC_K, s.XGC_D
+        self.ps, self.mesh = w["ps"], w["mesh"]
+        cap = max(self.ps.capacity(), 1)
+        self.ids = capi.DevArray.from_host(np.full(cap, -1, dtype=np.int32))
+        self.first = True
+        self.kernel_ms = []
+        if name == "c3":
+            raise SystemExit("workload c3 needs a 3-D gyro map: use --workload 2dc3")
+        if name == "2dc3":
+            self.fwd, self.bkwd = capi.create_gyro_ring_mappings(self.mesh)
+            self.w_f = capi.DevArray(self.mesh.nverts, np.float64)
+            self.w_b = capi.DevArray(self.mesh.nverts, np.float64)
+
+    def step(self, timed=False):
+        capi = self.capi
+        if timed:
+            e0, e1 = capi.Event(), capi.Event()
+            e0.record()
+        if self.name == "c2":
+            capi.push_search(self.mesh, self.ps, self.h, self.k, self.d, self.deg, self.ids,
+                             seeded=not self.first, looplimit=200, want_found=False)
+        else:
+            capi.push_search(self.mesh, self.ps, self.h, self.k, self.d, self.deg, self.ids,
+                             seeded=True, looplimit=200, want_found=False)
+        if timed:
+            e1.record()
+            self.kernel_ms.append((e0, e1))
+        self.first = False
+        if self.name == "c2":
+            self.ps.swap_members(0, 1)  # x <-> x_tgt (O(1)); no rebuild in config 2
+        elif self.name == "2dc3":
+            capi.update_positions(self.ps)
+            capi.check(capi.lib().pp_ps_rebuild(self.ps.p, self.ids.ptr, 0, None, None))
+            capi.gyro_scatter(self.mesh, self.ps, self.fwd, out=self.w_f)
+            capi.gyro_scatter(self.mesh, self.ps, self.bkwd, out=self.w_b)
+            cap = max(self.ps.capacity(), 1)
+            if cap > self.ids.n:
+                self.ids = capi.DevArray(cap, np.int32)
+            self.ids.fill_bytes(0xff)
+        # "2d": search_mesh_2d re-seeds from the previous ids as given
+
+    def kernel_avg_ms(self):
+        return float(np.mean([a.elapsed_ms(b) for a, b in self.kernel_ms])) if self.kernel_ms else None
+
+
+def cpu_baseline(pp, w, name, deg, sample, steps=2):
+    """The oracle (restated reference, Kokkos::Serial semantics: C=1, unfused kernels, one pass
+    per kernel per walk iteration) timed on one host core on a bounded sample of the workload."""
+    ppo = pumipic_amd_loader.load_oracle()
+    s = pp.synth
+    idx = np.sort(np.random.default_rng(0).choice(len(w["elem"]), size=sample, replace=False))
+    elem = w["elem"][idx]
+    ppe = np.bincount(elem, minlength=w["ne"]).astype(np.int32)
+    info = [np.ascontiguousarray(a[..., idx]) for a in w["info"]]
+    mesh = ppo.Mesh(w["dim"], w["coords"], w["e2v"], w["cls"])
+    ps = ppo.PS.scs(ppo.PARTICLE_XGCM, w["ne"], ppe, C_max=1, particle_elements=elem,
+                    particle_info=info)
+    ids = None
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        if w["dim"] == 3:
+            ppo.toroidal_push(ps, mesh, s.XGC_H, s.XGC_K, s.XGC_D, deg, trig=0)
+            ids = ppo.search_mesh(mesh, ps, elem_ids=ids, looplimit=200)["elem_ids"]
+            a, b = ps.member(0), ps.member(1)
+            tmp = a.copy()
+            a[:] = b
+            b[:] = tmp
+        else:
+            ppo.elliptical_push(ps, mesh, s.XGC_H, s.XGC_K, s.XGC_D, deg, trig=0)
+            _, ids, _ = ppo.search_mesh_2d(mesh, ps, elem_ids=ids, looplimit=200)
+    dt = time.perf_counter() - t0
+    return dict(value=sample * steps / dt, unit="particles/s", cores=1, kind="port",
+                sample="%d particles x %d steps of the same mesh/push, oracle (C=1 Serial semantics, "
+                       "libm trig), 1 core" % (sample, steps))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=["c2", "2d", "2dc3"])
+    ap.add_argument("--particles", type=int, default=10_000_000, help="particles per GPU")
+    ap.add_argument("--deg", type=float, default=0.5, help="degrees per push (testing.cmake:117)")
+    ap.add_argument("--cpu-sample", type=int, default=300_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    pp = pumipic_amd_loader.load()
+    from pumipic_amd import capi
+    capi.init(local_rank)  # raises when the HIP library / GPU is missing: no CPU fallback
+
+    w = build_workload(pp, capi, a.workload, a.particles, rank, world, a.deg)
+    st = Stepper(pp, capi, w, a.workload, a.deg)
+
+    def barrier():
+        capi.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        st.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        st.step(timed=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    nlive = w["ps"].nPtcls()
+    total_particles = nlive
+    if dist is not None:
+        t = torch.tensor([nlive], device="cuda", dtype=torch.int64)
+        dist.all_reduce(t)
+        total_particles = int(t.item())
+
+    if rank == 0:
+        kms = st.kernel_avg_ms()
+        bpp = BYTES[{"2dc3": "2d"}.get(a.workload, a.workload)]
+        achieved = bpp * nlive / (kms * 1e-3) / 1e9 if kms else None
+        out = {
+            "metric": "particles pushed+searched+scattered / sec / GPU; achieved HBM GB/s vs peak",
+            "value": total_particles * a.steps / dt,
+            "unit": "particles/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "%s, %d particles/GPU, SCS C=64 sigma=inf V=1024, %s" % (
+                w["label"], a.particles,
+                {"c2": "push+search only (fused toroidal push + BCC walk), deg/push=%g" % a.deg,
+                 "2d": "elliptical push + search_mesh_2d (fused), deg/push=%g" % a.deg,
+                 "2dc3": "push+search+rebuild+gyroScatter x2, deg/push=%g" % a.deg}[a.workload]),
+                "parallelism": "element-block partition, %d rank(s), full-mesh replica" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "kernel": "k_push_walk<%d>" % w["dim"], "kernel_ms": kms,
+                         "bytes_per_particle": bpp},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(pp, w, a.workload, a.deg, min(a.cpu_sample, a.particles))
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

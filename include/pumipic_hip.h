@@ -1,0 +1,236 @@
+/*
+ * pumipic_hip.h -- C-ABI of libpumipic_hip.so: the MI355X (gfx950) implementation of PUMI-PIC's
+ * per-timestep particle hot loop (push -> element-to-element adjacency search -> particle<->mesh
+ * scatter -> Sell-C-sigma / CSR rebuild + migration pack).
+ *
+ * The reference has no FFI: its "API" is C++ templates over Kokkos views.  Each
+ * entry point below names the reference interface it stands in for (file:line under
+ * SCOREC/pumi-pic).  The C++ host mirror of that template API lives in pumi-pic_amd/include/ and
+ * is a thin inline layer over these functions; INTEGRATION.md shows the binding a maintainer adds.
+ *
+ * Conventions
+ *   - all functions are extern "C", take plain pointers/sizes, return 0 on success or a negative
+ *     PP_E* code; pp_last_error() gives a message.  No C++/torch types cross this boundary.
+ *   - *_host pointers are host memory, *_dev pointers are HIP device memory on the current
+ *     device.  Handles own their device memory.  Pointers obtained from pp_ps_member_ptr /
+ *     pp_ps_layout are invalidated by pp_ps_rebuild / pp_ps_migrate_* (same rule as the
+ *     reference's Segment accessors, SURVEY 8(b) "Ownership").
+ *   - work is enqueued on one HIP stream per process (pp_stream()); calls return after enqueue
+ *     unless they produce a host-visible result (found flags, counts, capacities).
+ *   - particle members are SoA, component-major: member m, component c, slot pid lives at
+ *     base_m[c*stride + pid] with stride = pp_ps_member_stride() (reference: pumipic::View is
+ *     LayoutLeft, support/ppView.h:7-10; Segment(pid,i), support/Segment.h:29-98).
+ *   - ids are int32 (lid_t / Omega_h LO), global ids int64 (gid_t), reals are IEEE double.
+ *     Device code is built with -ffp-contract=off: every sign test and arg-min follows the
+ *     reference's operation order so element ids are bit-identical to a Kokkos::Serial run.
+ */
+#ifndef PUMIPIC_HIP_H
+#define PUMIPIC_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  PP_OK = 0,
+  PP_EINVAL = -1,   /* bad argument */
+  PP_EHIP = -2,     /* HIP runtime error (no device, launch failure, OOM) */
+  PP_ENOTIMPL = -3,
+  PP_ESTATE = -4
+};
+enum { PP_SCS = 0, PP_CSR = 1 };
+enum { PP_PAD_EVENLY = 0, PP_PAD_PROPORTIONALLY = 1, PP_PAD_INVERSELY = 2 }; /* scs_input.hpp:4-11 */
+
+typedef struct pp_mesh pp_mesh;
+typedef struct pp_ps pp_ps;
+
+/* ------------------------------------------------------------------ runtime */
+const char* pp_last_error(void);
+const char* pp_version(void);
+/* Select the device and create the library stream. Fails loudly (PP_EHIP) without a GPU. */
+int pp_init(int device);
+void* pp_stream(void); /* hipStream_t */
+int pp_sync(void);
+int pp_device_count(void);
+/* plain device memory helpers so hosts without a HIP toolchain (ctypes, cgo, JNI) can drive it */
+void* pp_malloc(size_t bytes);
+int pp_free(void* dev);
+int pp_memcpy_h2d(void* dev, const void* host, size_t bytes);
+int pp_memcpy_d2h(void* host, const void* dev, size_t bytes);
+int pp_memset(void* dev, int value, size_t bytes);
+/* HIP-event timing on the library stream (bench.py measures kernels with these) */
+void* pp_event_create(void);
+int pp_event_record(void* ev);
+float pp_event_elapsed_ms(void* start, void* stop); /* synchronises on stop */
+int pp_event_destroy(void* ev);
+
+/* ------------------------------------------------------------------ mesh
+ * Replaces the Omega_h mesh queries the hot path makes (adjacency.tpp:238-241,394-396,489,
+ * 497-501; adjacency.hpp:568-574,1030-1036): ask_elem_verts, coords, ask_down(dim,dim-1),
+ * ask_up(dim-1,dim), ask_verts_of(dim-1), mark_exposed_sides, measure_elements_real, ask_dual,
+ * ask_up(0,dim), get_array<ClassId>(dim,"class_id").  Derived once and cached.
+ * Side numbering is this library's canonical one (first-seen order). */
+pp_mesh* pp_mesh_create(int dim, int nverts, const double* coords_host, int nelems,
+                        const int* elem2verts_host, const int* class_id_host);
+int pp_mesh_destroy(pp_mesh* m);
+int pp_mesh_info(const pp_mesh* m, int* dim, int* nverts, int* nelems, int* nsides);
+/* compute_tolerance_from_area, adjacency.tpp:418-428 */
+double pp_mesh_tolerance(const pp_mesh* m);
+enum {
+  PP_MESH_COORDS = 0,      /* double nverts*dim */
+  PP_MESH_ELEM2VERTS = 1,  /* int nelems*(dim+1) */
+  PP_MESH_CLASS_ID = 2,    /* int nelems */
+  PP_MESH_ELEM2SIDES = 3,  /* int nelems*(dim+1) */
+  PP_MESH_SIDE2VERTS = 4,  /* int nsides*dim */
+  PP_MESH_SIDE2ELEMS_OFF = 5, /* int nsides+1 */
+  PP_MESH_SIDE2ELEMS = 6,  /* int */
+  PP_MESH_SIDE_EXPOSED = 7, /* int8 nsides */
+  PP_MESH_ELEM_MEASURE = 8, /* double nelems */
+  PP_MESH_DUAL_OFF = 9,    /* int nelems+1 */
+  PP_MESH_DUAL_ELEMS = 10, /* int */
+  PP_MESH_VERT2ELEMS_OFF = 11, /* int nverts+1 */
+  PP_MESH_VERT2ELEMS = 12, /* int */
+  PP_MESH_ELEM_RECORDS = 13 /* packed per-element walk records (DESIGN.md "data layout") */
+};
+/* device pointer + item count of a mesh array (for user kernels written against the C++ mirror) */
+const void* pp_mesh_array_dev(const pp_mesh* m, int which, size_t* count);
+/* copy a mesh array to host memory (out must hold count items) */
+int pp_mesh_array_to_host(const pp_mesh* m, int which, void* out_host);
+
+/* ------------------------------------------------------------------ particle structures
+ * SellCSigma ctor scs/SellCSigma.h:66-72 + SCS_Input scs_input.hpp:27-36; CSR ctor
+ * csr/CSR.hpp:37-69 + CSR_Input.  member_bytes[m] = sizeof(scalar type), member_ncomp[m] =
+ * number of components (MemberTypes<double[3],double[3],int,float,float> -> bytes {8,8,4,4,4},
+ * ncomp {3,3,1,1,1}).  particle_info_host[m] is [ncomp][np] component-major, or NULL.
+ * C is the chunk height (team size); 64 is native on CDNA wave64. */
+pp_ps* pp_ps_create_scs(int C, int sigma, int V, int num_elems, int num_ptcls,
+                        const int* ppe_host, const int64_t* gids_host, int pad_strat,
+                        double shuffle_padding, double extra_padding, int nmembers,
+                        const int* member_bytes, const int* member_ncomp,
+                        const int* particle_elements_host, const void* const* particle_info_host);
+pp_ps* pp_ps_create_csr(int num_elems, int num_ptcls, const int* ppe_host,
+                        const int64_t* gids_host, double padding_amount, int nmembers,
+                        const int* member_bytes, const int* member_ncomp,
+                        const int* particle_elements_host, const void* const* particle_info_host);
+int pp_ps_destroy(pp_ps* ps);
+typedef struct pp_ps_info_t {
+  int kind, num_elems, num_ptcls, capacity, num_rows;
+  int C, V, sigma, num_chunks, num_slices, nmembers;
+  int64_t stride; /* allocated slots per component */
+} pp_ps_info_t;
+/* nElems/nPtcls/capacity/numRows particle_structure.hpp:80-83 */
+int pp_ps_info(const pp_ps* ps, pp_ps_info_t* out);
+/* ptcls->get<N>() particle_structure.hpp:90-104 */
+void* pp_ps_member_ptr(pp_ps* ps, int m);
+int64_t pp_ps_member_stride(const pp_ps* ps);
+typedef struct pp_ps_layout_t {
+  const int* offsets;        /* SCS: num_slices+1 ; CSR: num_elems+1 */
+  const int* slice_to_chunk; /* SCS only */
+  const int* row_to_element; /* SCS only */
+  const int* element_to_row; /* SCS only */
+  const unsigned char* mask; /* SCS only: particle_mask, 1 byte per slot */
+  const int* slot_elem;      /* capacity: parent element of every slot (-1 = not iterated) */
+} pp_ps_layout_t;
+/* device pointers used by the header-only ps::parallel_for (SellCSigma.h:526-558, CSR.hpp:186-213) */
+int pp_ps_layout(const pp_ps* ps, pp_ps_layout_t* out);
+int pp_ps_layout_to_host(const pp_ps* ps, int* offsets, int* slice_to_chunk, int* row_to_element,
+                         int* element_to_row, unsigned char* mask, int* slot_elem);
+int pp_ps_member_to_host(pp_ps* ps, int m, void* out_host);   /* [ncomp][stride] */
+int pp_ps_member_from_host(pp_ps* ps, int m, const void* in_host);
+/* rebuild(new_element, new_particle_elements, new_particle_info) scs/SCS_rebuild.h:122-314,
+ * csr/CSR_rebuild.hpp:18-118.  new_element_dev has capacity entries (-1 = delete).
+ * new_info_dev[m] is a DEVICE array [ncomp][n_new].  Always a full counting-sort re-layout
+ * (the reference's in-place reshuffle fast path is not observable through id-keyed results). */
+int pp_ps_rebuild(pp_ps* ps, const int* new_element_dev, int n_new, const int* new_elems_dev,
+                  const void* const* new_info_dev);
+/* getPIDs ps_for.hpp:65-85: offsets_dev[ne+1], pids_dev[nPtcls] */
+int pp_ps_get_pids(const pp_ps* ps, int* offsets_dev, int* pids_dev);
+/* printMetrics SellCSigma.h:465-524 */
+int pp_ps_metrics(const pp_ps* ps, int* padded_cells, int* padded_slices, int* empty_rows);
+/* swap which member index two same-typed members refer to (O(1); used to ping-pong x / x_tgt
+ * when a driver skips rebuild -- BASELINE config 2) */
+int pp_ps_swap_members(pp_ps* ps, int m_a, int m_b);
+
+/* ------------------------------------------------------------------ pushes */
+/* ellipticalPush::setup test/ellipticalPush.hpp:10-33 (x: double[3], b/phi: float) */
+int pp_elliptical_setup(pp_ps* ps, int m_x, int m_b, int m_phi, double h, double k, double d);
+/* ellipticalPush::push test/ellipticalPush.hpp:36-70 */
+int pp_elliptical_push(pp_ps* ps, const pp_mesh* mesh, int m_xtgt, int m_b, int m_phi, double h,
+                       double k, double d, double deg);
+/* 3-D tokamak restatement of the same push; see DESIGN.md */
+int pp_toroidal_push(pp_ps* ps, const pp_mesh* mesh, int m_x, int m_xtgt, int m_b, int m_phi,
+                     double h, double k, double d, double deg);
+/* push lambda test/pseudoPushAndSearch.cpp:104-115 */
+int pp_linear_push(pp_ps* ps, int m_x, int m_xtgt, double distance, double dx, double dy,
+                   double dz);
+/* pushBoris src/pumipic_push.hpp:17-75, launched over n (the reference launches over 1) */
+int pp_push_boris(int n, double* x, double* y, double* z, double* xp, double* yp, double* zp,
+                  double* vx, double* vy, double* vz, const double* ex, const double* ey,
+                  const double* ez, const double* br, const double* bt, const double* bz,
+                  double dt);
+/* updatePtclPositions test/pseudoXGCm.cpp:102-114 */
+int pp_update_positions(pp_ps* ps, int m_x, int m_xtgt);
+/* pseudoPush performance_tests/ps_combo160.cpp:158-178 (members double[17], int[4], long) */
+int pp_pseudo_push160(pp_ps* ps, const double* parent_elm_data_dev);
+
+/* ------------------------------------------------------------------ searches
+ * elem_ids_dev: capacity ints, in/out.  The whole walk runs inside one kernel (no per-iteration
+ * host round trip); `found` is the reference's return value. */
+/* search_mesh_2d src/pumipic_adjacency.hpp:1011-1158 */
+int pp_search_mesh_2d(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_pid,
+                      int* elem_ids_dev, int looplimit, int* found);
+/* search_mesh src/pumipic_adjacency.hpp:37-45 / adjacency.tpp:641-654 (2-D and 3-D; BCC when
+ * requireIntersection==0, Moller-Trumbore / 2-D segment otherwise).  elem_ids_seeded==0 behaves
+ * like an empty elem_ids (adjacency.tpp:504-515).  inter_* may be NULL when !requireIntersection */
+int pp_search_mesh(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_pid,
+                   int* elem_ids_dev, int elem_ids_seeded, int requireIntersection,
+                   int* inter_faces_dev, double* inter_points_dev, int looplimit, int* found,
+                   int* num_not_in_elem);
+/* legacy 3-D search_mesh src/pumipic_adjacency.hpp:558-768 */
+int pp_search_mesh_legacy3d(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_pid,
+                            int* elem_ids_dev, int elem_ids_seeded, double* xpoints_dev,
+                            int* xface_dev, int looplimit, int* found);
+/* Fused hot path: elliptical (dim 2) / toroidal (dim 3) push + BCC walk in one kernel: particle
+ * state is read once and x_tgt, phi, elem_ids written once.  Result-identical to
+ * pp_*_push followed by pp_search_mesh_2d (dim 2) / pp_search_mesh BCC with the origin check
+ * skipped (dim 3).  found may be NULL (no host sync). */
+int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b, int m_phi,
+                   double h, double k, double d, double deg, int* elem_ids_dev,
+                   int elem_ids_seeded, int looplimit, int* found);
+
+/* ------------------------------------------------------------------ scatter / gather */
+/* createGyroRingMappings test/gyroScatter.hpp:101-166 (maps: nverts*gnr*gppr*3 ints, device) */
+int pp_create_gyro_ring_mappings(const pp_mesh* mesh, double rmax, int gnr, int gppr,
+                                 double theta_deg, int* forward_map_dev, int* backward_map_dev);
+/* gyroScatter test/gyroScatter.hpp:168-229: scatter_w_dev[nverts] (overwritten) */
+int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, double rmax, int gnr,
+                    int gppr, double* scatter_w_dev);
+/* setSyncArray of gyroSync test/gyroScatter.hpp:245-249: out[2v]=fwd[v], out[2v+1]=bkwd[v];
+ * the SUM all-reduce itself (reduceCommArray, pumipic_comm.cpp:234-246) is RCCL on this buffer */
+int pp_gyro_sync_pack(int nverts, const double* fwd_dev, const double* bkwd_dev, double* out_dev);
+/* computeAvgPtclDensity test/pseudoPushAndSearch.cpp:340-374 */
+int pp_avg_ptcl_density(const pp_mesh* mesh, const pp_ps* ps, double* elem_cnt_dev,
+                        double* vert_density_dev);
+
+/* ------------------------------------------------------------------ migration glue */
+/* setUnsafeProcs src/pumipic_ptcl_ops.hpp:32-52 */
+int pp_set_unsafe_procs(const pp_ps* ps, const int* elems_dev, const unsigned char* safe_dev,
+                        const int* owners_dev, int comm_rank, int* new_elems_dev,
+                        int* new_procs_dev);
+/* SellCSigma::migrate scs/SCS_migrate.h:29-137 send side: count per destination rank
+ * (send_counts_host[nranks]) ... */
+int pp_ps_migrate_count(const pp_ps* ps, const int* new_element_dev, const int* new_process_dev,
+                        int comm_rank, int nranks, int* send_counts_host);
+/* ... then pack (element gid int64 + every member) per destination, rank-major, into
+ * send_gid_dev[total] and send_info_dev[m] = [ncomp][total]; marks sent particles' new_element
+ * as -1 (removeSentParticles, SCS_migrate.h:189-196) */
+int pp_ps_migrate_pack(const pp_ps* ps, int* new_element_dev, const int* new_process_dev,
+                       int comm_rank, int nranks, const int* send_counts_host,
+                       int64_t* send_gid_dev, void* const* send_info_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

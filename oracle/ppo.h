@@ -159,8 +159,10 @@ int ppo_search_mesh_2d_pt(const ppo_mesh* mesh, const double orig[2], const doub
 
 /* ---------------------------------------------------------------- scatter / gather */
 /* test/gyroScatter.hpp:101-166 (+ searchAndBuildMap :28-95); maps are nverts*gnr*gppr*3 ints */
+/* trig: 0 = libm cos/sin (literal reference), 1 = ppo_sincos (shared with the device) */
 void ppo_create_gyro_ring_mappings(const ppo_mesh* mesh, double rmax, int gnr, int gppr,
-                                   double theta_deg, int* forward_map, int* backward_map);
+                                   double theta_deg, int trig, int* forward_map,
+                                   int* backward_map);
 /* test/gyroScatter.hpp:168-229 ; nvpe = dim+1 (3 literal; 4 = documented tet deviation) */
 void ppo_gyro_scatter(const ppo_mesh* mesh, const ppo_ps* ps, const int* v2v, double rmax, int gnr,
                       int gppr, double* scatter_w);

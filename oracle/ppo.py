@@ -108,7 +108,7 @@ def lib():
         L.ppo_search_mesh_2d_pt.argtypes = [C.POINTER(_MeshS), c_double_p, c_double_p, C.c_int,
                                             C.c_int, c_int_p, C.c_int]
         L.ppo_create_gyro_ring_mappings.argtypes = [C.POINTER(_MeshS), C.c_double, C.c_int, C.c_int,
-                                                    C.c_double, c_int_p, c_int_p]
+                                                    C.c_double, C.c_int, c_int_p, c_int_p]
         L.ppo_gyro_scatter.argtypes = [C.POINTER(_MeshS), C.POINTER(_PsS), c_int_p, C.c_double,
                                        C.c_int, C.c_int, c_double_p]
         L.ppo_avg_ptcl_density.argtypes = [C.POINTER(_MeshS), C.POINTER(_PsS), c_double_p,
@@ -429,11 +429,11 @@ def search_mesh_2d_pt(mesh, orig, dest, initial_elem, looplimit=0, pid=0):
     return e, loops.value
 
 
-def create_gyro_ring_mappings(mesh, rmax=0.038, gnr=3, gppr=8, theta=0.0):
+def create_gyro_ring_mappings(mesh, rmax=0.038, gnr=3, gppr=8, theta=0.0, trig=0):
     n = mesh.nverts * gnr * gppr * 3
     f = np.empty(n, dtype=np.int32)
     b = np.empty(n, dtype=np.int32)
-    lib().ppo_create_gyro_ring_mappings(mesh.p, rmax, gnr, gppr, theta, _ip(f), _ip(b))
+    lib().ppo_create_gyro_ring_mappings(mesh.p, rmax, gnr, gppr, theta, trig, _ip(f), _ip(b))
     return f, b
 
 

@@ -241,7 +241,8 @@ void ppo_pseudo_push160(ppo_ps* ps, const double* parentElmData) {
  * points into a scratch SCS and calls search_mesh_2d (maxLoops 100); the per-point walk is the
  * same function of (start element, target), so the single-point walker (hpp:1160-1252) is used. */
 void ppo_create_gyro_ring_mappings(const ppo_mesh* mesh, double rmax, int gnr, int gppr,
-                                   double theta_deg, int* forward_map, int* backward_map) {
+                                   double theta_deg, int trigmode, int* forward_map,
+                                   int* backward_map) {
   const int nverts = mesh->nverts;
   const long num_points = (long)nverts * gnr * gppr;
   const double torad = M_PI / 180;
@@ -254,9 +255,10 @@ void ppo_create_gyro_ring_mappings(const ppo_mesh* mesh, double rmax, int gnr, i
     const double radius = rmax * (ring_id + 1) / gnr;
     const double deg = theta_deg + (((double)point_id) / gppr * 360);
     const double rad = deg * torad;
-    double pt[2];
-    pt[0] = mesh->coords[(size_t)vert_id * 2] + radius * cos(rad);
-    pt[1] = mesh->coords[(size_t)vert_id * 2 + 1] + radius * sin(rad);
+    double pt[2], sn, cs;
+    trig(trigmode, rad, &sn, &cs);
+    pt[0] = mesh->coords[(size_t)vert_id * 2] + radius * cs;
+    pt[1] = mesh->coords[(size_t)vert_id * 2 + 1] + radius * sn;
     const int start_elem = mesh->vert2elems[mesh->vert2elems_off[vert_id]];
     /* centroid of the start element = average(vtxCoords) = ((p0+p1)+p2)/3 (unused by the walk) */
     double orig[2] = {0, 0};

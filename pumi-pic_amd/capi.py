@@ -1,0 +1,527 @@
+"""ctypes binding of libpumipic_hip.so (include/pumipic_hip.h).
+
+Python is only the test/bench harness; this module adds no compute of its own and has NO CPU
+fallback: if the HIP library is missing or no GPU is visible every entry point raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpumipic_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+c_int_p = C.POINTER(C.c_int)
+c_double_p = C.POINTER(C.c_double)
+c_void_pp = C.POINTER(C.c_void_p)
+
+PAD_EVENLY, PAD_PROPORTIONALLY, PAD_INVERSELY = 0, 1, 2
+SCS, CSR = 0, 1
+
+(MESH_COORDS, MESH_ELEM2VERTS, MESH_CLASS_ID, MESH_ELEM2SIDES, MESH_SIDE2VERTS,
+ MESH_SIDE2ELEMS_OFF, MESH_SIDE2ELEMS, MESH_SIDE_EXPOSED, MESH_ELEM_MEASURE, MESH_DUAL_OFF,
+ MESH_DUAL_ELEMS, MESH_VERT2ELEMS_OFF, MESH_VERT2ELEMS, MESH_ELEM_RECORDS) = range(14)
+_MESH_DTYPES = {MESH_COORDS: np.float64, MESH_ELEM2VERTS: np.int32, MESH_CLASS_ID: np.int32,
+                MESH_ELEM2SIDES: np.int32, MESH_SIDE2VERTS: np.int32,
+                MESH_SIDE2ELEMS_OFF: np.int32, MESH_SIDE2ELEMS: np.int32,
+                MESH_SIDE_EXPOSED: np.int8, MESH_ELEM_MEASURE: np.float64, MESH_DUAL_OFF: np.int32,
+                MESH_DUAL_ELEMS: np.int32, MESH_VERT2ELEMS_OFF: np.int32,
+                MESH_VERT2ELEMS: np.int32}
+
+
+class PPError(RuntimeError):
+    pass
+
+
+class PsInfo(C.Structure):
+    _fields_ = [("kind", C.c_int), ("num_elems", C.c_int), ("num_ptcls", C.c_int),
+                ("capacity", C.c_int), ("num_rows", C.c_int), ("C", C.c_int), ("V", C.c_int),
+                ("sigma", C.c_int), ("num_chunks", C.c_int), ("num_slices", C.c_int),
+                ("nmembers", C.c_int), ("stride", C.c_int64)]
+
+
+class PsLayout(C.Structure):
+    _fields_ = [("offsets", C.c_void_p), ("slice_to_chunk", C.c_void_p),
+                ("row_to_element", C.c_void_p), ("element_to_row", C.c_void_p),
+                ("mask", C.c_void_p), ("slot_elem", C.c_void_p)]
+
+
+# every symbol include/pumipic_hip.h declares: name -> (restype, argtypes)
+_V, _I, _D, _S = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+SYMBOLS = {
+    "pp_last_error": (C.c_char_p, []),
+    "pp_version": (C.c_char_p, []),
+    "pp_init": (_I, [_I]),
+    "pp_stream": (_V, []),
+    "pp_sync": (_I, []),
+    "pp_device_count": (_I, []),
+    "pp_malloc": (_V, [_S]),
+    "pp_free": (_I, [_V]),
+    "pp_memcpy_h2d": (_I, [_V, _V, _S]),
+    "pp_memcpy_d2h": (_I, [_V, _V, _S]),
+    "pp_memset": (_I, [_V, _I, _S]),
+    "pp_event_create": (_V, []),
+    "pp_event_record": (_I, [_V]),
+    "pp_event_elapsed_ms": (C.c_float, [_V, _V]),
+    "pp_event_destroy": (_I, [_V]),
+    "pp_mesh_create": (_V, [_I, _I, _V, _I, _V, _V]),
+    "pp_mesh_destroy": (_I, [_V]),
+    "pp_mesh_info": (_I, [_V, c_int_p, c_int_p, c_int_p, c_int_p]),
+    "pp_mesh_tolerance": (_D, [_V]),
+    "pp_mesh_array_dev": (_V, [_V, _I, C.POINTER(_S)]),
+    "pp_mesh_array_to_host": (_I, [_V, _I, _V]),
+    "pp_ps_create_scs": (_V, [_I, _I, _I, _I, _I, _V, _V, _I, _D, _D, _I, _V, _V, _V, _V]),
+    "pp_ps_create_csr": (_V, [_I, _I, _V, _V, _D, _I, _V, _V, _V, _V]),
+    "pp_ps_destroy": (_I, [_V]),
+    "pp_ps_info": (_I, [_V, C.POINTER(PsInfo)]),
+    "pp_ps_member_ptr": (_V, [_V, _I]),
+    "pp_ps_member_stride": (C.c_int64, [_V]),
+    "pp_ps_layout": (_I, [_V, C.POINTER(PsLayout)]),
+    "pp_ps_layout_to_host": (_I, [_V, _V, _V, _V, _V, _V, _V]),
+    "pp_ps_member_to_host": (_I, [_V, _I, _V]),
+    "pp_ps_member_from_host": (_I, [_V, _I, _V]),
+    "pp_ps_rebuild": (_I, [_V, _V, _I, _V, _V]),
+    "pp_ps_get_pids": (_I, [_V, _V, _V]),
+    "pp_ps_metrics": (_I, [_V, c_int_p, c_int_p, c_int_p]),
+    "pp_ps_swap_members": (_I, [_V, _I, _I]),
+    "pp_elliptical_setup": (_I, [_V, _I, _I, _I, _D, _D, _D]),
+    "pp_elliptical_push": (_I, [_V, _V, _I, _I, _I, _D, _D, _D, _D]),
+    "pp_toroidal_push": (_I, [_V, _V, _I, _I, _I, _I, _D, _D, _D, _D]),
+    "pp_linear_push": (_I, [_V, _I, _I, _D, _D, _D, _D]),
+    "pp_push_boris": (_I, [_I] + [_V] * 15 + [_D]),
+    "pp_update_positions": (_I, [_V, _I, _I]),
+    "pp_pseudo_push160": (_I, [_V, _V]),
+    "pp_search_mesh_2d": (_I, [_V, _V, _I, _I, _I, _V, _I, c_int_p]),
+    "pp_search_mesh": (_I, [_V, _V, _I, _I, _I, _V, _I, _I, _V, _V, _I, c_int_p, c_int_p]),
+    "pp_search_mesh_legacy3d": (_I, [_V, _V, _I, _I, _I, _V, _I, _V, _V, _I, c_int_p]),
+    "pp_push_search": (_I, [_V, _V, _I, _I, _I, _I, _D, _D, _D, _D, _V, _I, _I, c_int_p]),
+    "pp_create_gyro_ring_mappings": (_I, [_V, _D, _I, _I, _D, _V, _V]),
+    "pp_gyro_scatter": (_I, [_V, _V, _V, _D, _I, _I, _V]),
+    "pp_gyro_sync_pack": (_I, [_I, _V, _V, _V]),
+    "pp_avg_ptcl_density": (_I, [_V, _V, _V, _V]),
+    "pp_set_unsafe_procs": (_I, [_V, _V, _V, _V, _I, _V, _V]),
+    "pp_ps_migrate_count": (_I, [_V, _V, _V, _I, _I, _V]),
+    "pp_ps_migrate_pack": (_I, [_V, _V, _V, _I, _I, _V, _V, _V]),
+}
+
+
+def build(force=False):
+    """Compile every HIP source for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "clean"])
+    subprocess.check_call(["make", "-C", CSRC, "-s", "-j8"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; loud failure when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PPError("libpumipic_hip.so is not built (run __graft_entry__.build()); "
+                          "there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError = missing export
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise PPError("pumipic_hip error %d: %s" % (rc, lib().pp_last_error().decode()))
+
+
+def init(device=0):
+    check(lib().pp_init(device))
+
+
+def sync():
+    check(lib().pp_sync())
+
+
+# ------------------------------------------------------------------ device arrays
+class DevArray:
+    """Typed device buffer owned by Python (hipMalloc via the C-ABI)."""
+
+    def __init__(self, n, dtype):
+        self.n = int(n)
+        self.dtype = np.dtype(dtype)
+        self.ptr = lib().pp_malloc(max(self.n * self.dtype.itemsize, 1))
+        if not self.ptr:
+            raise PPError("pp_malloc failed: " + lib().pp_last_error().decode())
+
+    @classmethod
+    def from_host(cls, a):
+        a = np.ascontiguousarray(a)
+        d = cls(a.size, a.dtype)
+        if a.size:
+            check(lib().pp_memcpy_h2d(d.ptr, a.ctypes.data, a.nbytes))
+        return d
+
+    def to_host(self):
+        sync()
+        out = np.empty(self.n, dtype=self.dtype)
+        if self.n:
+            check(lib().pp_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def fill_bytes(self, value):
+        check(lib().pp_memset(self.ptr, value, self.n * self.dtype.itemsize))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().pp_free(self.ptr)
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self):
+        self.ev = lib().pp_event_create()
+
+    def record(self):
+        check(lib().pp_event_record(self.ev))
+
+    def elapsed_ms(self, stop):
+        return lib().pp_event_elapsed_ms(self.ev, stop.ev)
+
+    def __del__(self):
+        try:
+            lib().pp_event_destroy(self.ev)
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------ mesh
+class Mesh:
+    def __init__(self, dim, coords, elem2verts, class_id=None):
+        coords = np.ascontiguousarray(coords, dtype=np.float64).reshape(-1, dim)
+        e2v = np.ascontiguousarray(elem2verts, dtype=np.int32).reshape(-1, dim + 1)
+        cid = None if class_id is None else np.ascontiguousarray(class_id, dtype=np.int32)
+        self.p = lib().pp_mesh_create(dim, coords.shape[0], coords.ctypes.data, e2v.shape[0],
+                                      e2v.ctypes.data, cid.ctypes.data if cid is not None else None)
+        if not self.p:
+            raise PPError("pp_mesh_create: " + lib().pp_last_error().decode())
+        d, nv, ne, ns = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(lib().pp_mesh_info(self.p, C.byref(d), C.byref(nv), C.byref(ne), C.byref(ns)))
+        self.dim, self.nverts, self.nelems, self.nsides = d.value, nv.value, ne.value, ns.value
+
+    def tolerance(self):
+        return lib().pp_mesh_tolerance(self.p)
+
+    def array(self, which):
+        cnt = C.c_size_t()
+        lib().pp_mesh_array_dev(self.p, which, C.byref(cnt))
+        out = np.empty(cnt.value, dtype=_MESH_DTYPES[which])
+        if cnt.value:
+            check(lib().pp_mesh_array_to_host(self.p, which, out.ctypes.data))
+        return out
+
+    def __del__(self):
+        try:
+            lib().pp_mesh_destroy(self.p)
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------ particle structure
+PARTICLE_XGCM = [(np.float64, 3), (np.float64, 3), (np.int32, 1), (np.float32, 1), (np.float32, 1)]
+PARTICLE_PUSH = [(np.float64, 3), (np.float64, 3), (np.int32, 1)]
+PERF160 = [(np.float64, 17), (np.int32, 4), (np.int64, 1)]
+
+
+def _meta(members):
+    mb = np.array([np.dtype(d).itemsize for d, _ in members], dtype=np.int32)
+    mc = np.array([n for _, n in members], dtype=np.int32)
+    return mb, mc
+
+
+def _host_info(members, info, n):
+    if info is None:
+        return None, None
+    keep, arr = [], (C.c_void_p * len(members))()
+    for i, ((dt, nc), a) in enumerate(zip(members, info)):
+        a = np.ascontiguousarray(np.asarray(a, dtype=dt).reshape(nc, n))
+        keep.append(a)
+        arr[i] = a.ctypes.data
+    return arr, keep
+
+
+class PS:
+    def __init__(self, p, members):
+        if not p:
+            raise PPError("particle structure creation failed: " + lib().pp_last_error().decode())
+        self.p = p
+        self.members = members
+
+    @classmethod
+    def scs(cls, members, ne, ppe, C_=64, sigma=2**31 - 1, V=1024, gids=None, pad_strat=0,
+            shuffle_padding=0.1, extra_padding=0.05, particle_elements=None, particle_info=None):
+        ppe = np.ascontiguousarray(ppe, dtype=np.int32)
+        np_ = int(ppe.sum())
+        mb, mc = _meta(members)
+        pe = None if particle_elements is None else np.ascontiguousarray(particle_elements, np.int32)
+        arr, keep = _host_info(members, particle_info, np_)
+        g = None if gids is None else np.ascontiguousarray(gids, dtype=np.int64)
+        p = lib().pp_ps_create_scs(C_, sigma, V, ne, np_, ppe.ctypes.data,
+                                   g.ctypes.data if g is not None else None, pad_strat,
+                                   shuffle_padding, extra_padding, len(members), mb.ctypes.data,
+                                   mc.ctypes.data, pe.ctypes.data if pe is not None else None,
+                                   C.cast(arr, C.c_void_p) if arr is not None else None)
+        return cls(p, members)
+
+    @classmethod
+    def csr(cls, members, ne, ppe, gids=None, padding_amount=1.05, particle_elements=None,
+            particle_info=None):
+        ppe = np.ascontiguousarray(ppe, dtype=np.int32)
+        np_ = int(ppe.sum())
+        mb, mc = _meta(members)
+        pe = None if particle_elements is None else np.ascontiguousarray(particle_elements, np.int32)
+        arr, keep = _host_info(members, particle_info, np_)
+        g = None if gids is None else np.ascontiguousarray(gids, dtype=np.int64)
+        p = lib().pp_ps_create_csr(ne, np_, ppe.ctypes.data,
+                                   g.ctypes.data if g is not None else None, padding_amount,
+                                   len(members), mb.ctypes.data, mc.ctypes.data,
+                                   pe.ctypes.data if pe is not None else None,
+                                   C.cast(arr, C.c_void_p) if arr is not None else None)
+        return cls(p, members)
+
+    def info(self):
+        i = PsInfo()
+        check(lib().pp_ps_info(self.p, C.byref(i)))
+        return i
+
+    def capacity(self):
+        return self.info().capacity
+
+    def nPtcls(self):
+        return self.info().num_ptcls
+
+    def nElems(self):
+        return self.info().num_elems
+
+    def numRows(self):
+        return self.info().num_rows
+
+    def member(self, m):
+        """host copy (ncomp, stride) of member m"""
+        dt, nc = self.members[m]
+        st = self.info().stride
+        out = np.empty((nc, st), dtype=dt)
+        check(lib().pp_ps_member_to_host(self.p, m, out.ctypes.data))
+        return out
+
+    def set_member(self, m, a):
+        dt, nc = self.members[m]
+        st = self.info().stride
+        a = np.ascontiguousarray(np.asarray(a, dtype=dt).reshape(nc, st))
+        check(lib().pp_ps_member_from_host(self.p, m, a.ctypes.data))
+
+    def member_ptr(self, m):
+        return lib().pp_ps_member_ptr(self.p, m)
+
+    def swap_members(self, a, b):
+        check(lib().pp_ps_swap_members(self.p, a, b))
+
+    def layout(self):
+        i = self.info()
+        d = dict(kind=i.kind, C=i.C, V=i.V, num_chunks=i.num_chunks, num_slices=i.num_slices,
+                 capacity=i.capacity, num_rows=i.num_rows)
+        noff = (i.num_slices + 1) if i.kind == SCS else (i.num_elems + 1)
+        off = np.zeros(noff, dtype=np.int32)
+        s2c = np.zeros(max(i.num_slices, 1), dtype=np.int32)
+        r2e = np.zeros(max(i.num_rows, 1), dtype=np.int32)
+        e2r = np.zeros(max(i.num_rows, 1), dtype=np.int32)
+        mask = np.zeros(max(i.capacity, 1), dtype=np.uint8)
+        se = np.zeros(max(i.capacity, 1), dtype=np.int32)
+        check(lib().pp_ps_layout_to_host(self.p, off.ctypes.data, s2c.ctypes.data, r2e.ctypes.data,
+                                         e2r.ctypes.data, mask.ctypes.data, se.ctypes.data))
+        d["offsets"] = off
+        d["mask"] = mask[:i.capacity]
+        d["slot_elem"] = se[:i.capacity]
+        if i.kind == SCS:
+            d["slice_to_chunk"] = s2c[:i.num_slices]
+            d["row_to_element"] = r2e[:i.num_rows]
+            d["element_to_row"] = e2r[:i.num_rows]
+        return d
+
+    def slot_info(self):
+        L = self.layout()
+        return L["slot_elem"], L["mask"]
+
+    def rebuild(self, new_element, new_particle_elements=None, new_particle_info=None):
+        """new_element: DevArray(int32, capacity) or host array"""
+        ne = new_element if isinstance(new_element, DevArray) else DevArray.from_host(
+            np.ascontiguousarray(new_element, dtype=np.int32))
+        n_new = 0 if new_particle_elements is None else len(new_particle_elements)
+        keep = []
+        arr = None
+        npe = None
+        if n_new:
+            npe = DevArray.from_host(np.ascontiguousarray(new_particle_elements, dtype=np.int32))
+            arr = (C.c_void_p * len(self.members))()
+            for i, ((dt, nc), a) in enumerate(zip(self.members, new_particle_info)):
+                d = DevArray.from_host(np.ascontiguousarray(np.asarray(a, dtype=dt).reshape(nc, n_new)))
+                keep.append(d)
+                arr[i] = d.ptr
+        check(lib().pp_ps_rebuild(self.p, ne.ptr, n_new, npe.ptr if npe else None,
+                                  C.cast(arr, C.c_void_p) if arr is not None else None))
+        sync()
+
+    def get_pids(self):
+        i = self.info()
+        off = DevArray(i.num_elems + 1, np.int32)
+        pids = DevArray(max(i.num_ptcls, 1), np.int32)
+        check(lib().pp_ps_get_pids(self.p, off.ptr, pids.ptr))
+        return off.to_host(), pids.to_host()[:i.num_ptcls]
+
+    def metrics(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        check(lib().pp_ps_metrics(self.p, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def __del__(self):
+        try:
+            lib().pp_ps_destroy(self.p)
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------ operators
+def elliptical_setup(ps, h, k, d, m_x=0, m_b=3, m_phi=4):
+    check(lib().pp_elliptical_setup(ps.p, m_x, m_b, m_phi, h, k, d))
+
+
+def elliptical_push(ps, mesh, h, k, d, deg, m_xtgt=1, m_b=3, m_phi=4):
+    check(lib().pp_elliptical_push(ps.p, mesh.p, m_xtgt, m_b, m_phi, h, k, d, deg))
+
+
+def toroidal_push(ps, mesh, h, k, d, deg, m_x=0, m_xtgt=1, m_b=3, m_phi=4):
+    check(lib().pp_toroidal_push(ps.p, mesh.p, m_x, m_xtgt, m_b, m_phi, h, k, d, deg))
+
+
+def linear_push(ps, distance, dx, dy, dz, m_x=0, m_xtgt=1):
+    check(lib().pp_linear_push(ps.p, m_x, m_xtgt, distance, dx, dy, dz))
+
+
+def update_positions(ps, m_x=0, m_xtgt=1):
+    check(lib().pp_update_positions(ps.p, m_x, m_xtgt))
+
+
+def pseudo_push160(ps, parent_elm_data_dev):
+    check(lib().pp_pseudo_push160(ps.p, parent_elm_data_dev.ptr))
+
+
+def push_boris(dev_arrays, dt):
+    check(lib().pp_push_boris(dev_arrays[0].n, *[a.ptr for a in dev_arrays], dt))
+
+
+def search_mesh_2d(mesh, ps, elem_ids=None, looplimit=0, m_x=0, m_xtgt=1, m_pid=2):
+    cap = ps.capacity()
+    if elem_ids is None:
+        elem_ids = DevArray.from_host(np.full(max(cap, 1), -1, dtype=np.int32))
+    found = C.c_int()
+    check(lib().pp_search_mesh_2d(mesh.p, ps.p, m_x, m_xtgt, m_pid, elem_ids.ptr, looplimit,
+                                  C.byref(found)))
+    return bool(found.value), elem_ids
+
+
+def search_mesh(mesh, ps, elem_ids=None, require_intersection=False, looplimit=0, m_x=0, m_xtgt=1,
+                m_pid=2):
+    cap = max(ps.capacity(), 1)
+    seeded = elem_ids is not None
+    if elem_ids is None:
+        elem_ids = DevArray(cap, np.int32)
+    inter_faces = DevArray(cap, np.int32)
+    inter_points = DevArray(cap * mesh.dim, np.float64)
+    found, notin = C.c_int(), C.c_int()
+    check(lib().pp_search_mesh(mesh.p, ps.p, m_x, m_xtgt, m_pid, elem_ids.ptr, int(seeded),
+                               int(require_intersection), inter_faces.ptr, inter_points.ptr,
+                               looplimit, C.byref(found), C.byref(notin)))
+    return dict(found=bool(found.value), elem_ids=elem_ids, inter_faces=inter_faces,
+                inter_points=inter_points, not_in_elem=notin.value)
+
+
+def search_mesh_legacy3d(mesh, ps, elem_ids=None, looplimit=0, m_x=0, m_xtgt=1, m_pid=2):
+    cap = max(ps.capacity(), 1)
+    seeded = elem_ids is not None
+    if elem_ids is None:
+        elem_ids = DevArray(cap, np.int32)
+    xface = DevArray.from_host(np.full(cap, -1, dtype=np.int32))
+    xpoints = DevArray.from_host(np.zeros(cap * 3))
+    found = C.c_int()
+    check(lib().pp_search_mesh_legacy3d(mesh.p, ps.p, m_x, m_xtgt, m_pid, elem_ids.ptr,
+                                        int(seeded), xpoints.ptr, xface.ptr, looplimit,
+                                        C.byref(found)))
+    return dict(found=found.value, elem_ids=elem_ids, xface=xface, xpoints=xpoints)
+
+
+def push_search(mesh, ps, h, k, d, deg, elem_ids, seeded=True, looplimit=0, want_found=True,
+                m_x=0, m_xtgt=1, m_b=3, m_phi=4):
+    found = C.c_int(1)
+    check(lib().pp_push_search(mesh.p, ps.p, m_x, m_xtgt, m_b, m_phi, h, k, d, deg, elem_ids.ptr,
+                               int(seeded), looplimit, C.byref(found) if want_found else None))
+    return bool(found.value)
+
+
+def create_gyro_ring_mappings(mesh, rmax=0.038, gnr=3, gppr=8, theta=0.0):
+    n = max(mesh.nverts * gnr * gppr * 3, 1)
+    f, b = DevArray(n, np.int32), DevArray(n, np.int32)
+    check(lib().pp_create_gyro_ring_mappings(mesh.p, rmax, gnr, gppr, theta, f.ptr, b.ptr))
+    return f, b
+
+
+def gyro_scatter(mesh, ps, v2v_dev, rmax=0.038, gnr=3, gppr=8, out=None):
+    if out is None:
+        out = DevArray(max(mesh.nverts, 1), np.float64)
+    check(lib().pp_gyro_scatter(mesh.p, ps.p, v2v_dev.ptr, rmax, gnr, gppr, out.ptr))
+    return out
+
+
+def gyro_sync_pack(nverts, fwd, bkwd, out=None):
+    if out is None:
+        out = DevArray(max(2 * nverts, 1), np.float64)
+    check(lib().pp_gyro_sync_pack(nverts, fwd.ptr, bkwd.ptr, out.ptr))
+    return out
+
+
+def avg_ptcl_density(mesh, ps):
+    ec = DevArray(max(mesh.nelems, 1), np.float64)
+    vd = DevArray(max(mesh.nverts, 1), np.float64)
+    check(lib().pp_avg_ptcl_density(mesh.p, ps.p, ec.ptr, vd.ptr))
+    return ec, vd
+
+
+def set_unsafe_procs(ps, elems_dev, safe_dev, owners_dev, rank):
+    cap = max(ps.capacity(), 1)
+    ne, npr = DevArray(cap, np.int32), DevArray(cap, np.int32)
+    check(lib().pp_set_unsafe_procs(ps.p, elems_dev.ptr, safe_dev.ptr, owners_dev.ptr, rank, ne.ptr,
+                                    npr.ptr))
+    return ne, npr
+
+
+def migrate_count(ps, new_element_dev, new_process_dev, rank, nranks):
+    counts = np.zeros(nranks, dtype=np.int32)
+    check(lib().pp_ps_migrate_count(ps.p, new_element_dev.ptr, new_process_dev.ptr, rank, nranks,
+                                    counts.ctypes.data))
+    return counts
+
+
+def migrate_pack(ps, new_element_dev, new_process_dev, rank, nranks, counts):
+    total = int(counts.sum())
+    gid = DevArray(max(total, 1), np.int64)
+    bufs = [DevArray(max(total * nc, 1), dt) for dt, nc in ps.members]
+    arr = (C.c_void_p * len(bufs))(*[b.ptr for b in bufs])
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    check(lib().pp_ps_migrate_pack(ps.p, new_element_dev.ptr, new_process_dev.ptr, rank, nranks,
+                                   counts.ctypes.data, gid.ptr, C.cast(arr, C.c_void_p)))
+    return gid, bufs

@@ -1,0 +1,154 @@
+// pp_internal.hpp -- shared host-side internals of libpumipic_hip.so (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/pumipic_hip.h"
+
+namespace pp {
+
+void set_error(const std::string& msg);
+hipStream_t stream();
+bool initialised();
+
+#define PP_HIP_CHECK(expr)                                                              \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      pp::set_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ + \
+                    ":" + std::to_string(__LINE__) + ")");                              \
+      return PP_EHIP;                                                                   \
+    }                                                                                   \
+  } while (0)
+
+#define PP_HIP_CHECK_NULL(expr)                                                         \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      pp::set_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ + \
+                    ":" + std::to_string(__LINE__) + ")");                              \
+      return nullptr;                                                                   \
+    }                                                                                   \
+  } while (0)
+
+#define PP_REQUIRE(cond, msg)        \
+  do {                               \
+    if (!(cond)) {                   \
+      pp::set_error(msg);            \
+      return PP_EINVAL;              \
+    }                                \
+  } while (0)
+
+#define PP_LAUNCH_CHECK() PP_HIP_CHECK(hipGetLastError())
+
+// Simple owning device buffer (grow-only reuse to avoid hipMalloc on the hot path).
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { release(); }
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) {
+    o.p = nullptr;
+    o.bytes = 0;
+  }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) {
+      release();
+      p = o.p;
+      bytes = o.bytes;
+      o.p = nullptr;
+      o.bytes = 0;
+    }
+    return *this;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  // ensure capacity; contents are NOT preserved when it grows
+  hipError_t reserve(size_t n) {
+    if (n <= bytes) return hipSuccess;
+    release();
+    size_t want = n + n / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) bytes = want;
+    return e;
+  }
+  template <class T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+  void swap(DevBuf& o) {
+    std::swap(p, o.p);
+    std::swap(bytes, o.bytes);
+  }
+};
+
+constexpr int kBlock = 256;
+inline unsigned grid_for(size_t n, int block = kBlock) {
+  return (unsigned)((n + (size_t)block - 1) / (size_t)block);
+}
+
+}  // namespace pp
+
+// ---------------------------------------------------------------------------------------------
+// packed per-element walk records (DESIGN.md "data layout in HBM")
+// tri : 64 B = half a 128-B line ; tet : 128 B = one line.  nbr[i] = element across local side i
+// (Omega_h template order), -1 when that side is exposed.
+struct alignas(16) pp_tri_rec {
+  double xy[3][2];  // 48
+  int nbr[3];       // 12
+  int class_id;     // 4
+};
+struct alignas(16) pp_tet_rec {
+  double xyz[4][3];  // 96
+  int nbr[4];        // 16
+  double vol;        // 8  measure_elements_real value
+  int class_id;      // 4
+  int pad;           // 4
+};
+static_assert(sizeof(pp_tri_rec) == 64, "tri record must be 64 B");
+static_assert(sizeof(pp_tet_rec) == 128, "tet record must be 128 B");
+
+struct pp_mesh {
+  int dim = 0, nverts = 0, nelems = 0, nsides = 0;
+  double tol = 0;  // compute_tolerance_from_area
+  // host copies (setup + to_host queries)
+  std::vector<double> coords, elem_measure;
+  std::vector<int> elem2verts, class_id, elem2sides, side2verts, side2elems_off, side2elems,
+      dual_off, dual_elems, vert2elems_off, vert2elems;
+  std::vector<signed char> side_exposed;
+  // device arrays
+  pp::DevBuf d_coords, d_elem2verts, d_class_id, d_elem2sides, d_side2verts, d_side2elems_off,
+      d_side2elems, d_side_exposed, d_elem_measure, d_dual_off, d_dual_elems, d_vert2elems_off,
+      d_vert2elems, d_records;
+};
+
+struct pp_ps {
+  int kind = PP_SCS;
+  int num_elems = 0, num_ptcls = 0, capacity = 0, num_rows = 0;
+  int C = 1, C_max = 1, V = 1024, sigma = 1, num_chunks = 0, num_slices = 0;
+  int pad_strat = PP_PAD_EVENLY;
+  double shuffle_padding = 0.1, extra_padding = 0.05, minimize_size = 0.8, padding_amount = 1.05;
+  int num_empty_elements = 0;
+  int nmembers = 0;
+  std::vector<int> member_bytes, member_ncomp;
+  std::vector<int> member_map;  // logical member -> storage index (pp_ps_swap_members)
+  int64_t stride = 0;           // allocated slots per component of the live buffers
+  int64_t swap_stride = 0;
+  std::vector<pp::DevBuf> data, swap;
+  bool has_gids = false;
+  pp::DevBuf d_gids;  // element -> gid (num_elems)
+  // layout (device)
+  pp::DevBuf d_offsets, d_slice_to_chunk, d_row_to_element, d_element_to_row, d_mask, d_slot_elem;
+  // scratch reused across rebuilds
+  pp::DevBuf s_ppe, s_keys, s_keys2, s_vals, s_vals2, s_hist, s_chunkw, s_misc, s_rowstart,
+      s_newidx, s_offsets2, s_s2c2, s_r2e2, s_e2r2, s_mask2, s_slot2, s_scan;
+};

@@ -1,0 +1,159 @@
+// pp_migrate.hip -- device side of particle migration.
+//   setUnsafeProcs                 src/pumipic_ptcl_ops.hpp:32-52
+//   SellCSigma::migrate send side  particle_structs/src/scs/SCS_migrate.h:29-137,189-196
+//
+// The reference packs one SoA send buffer per member type and posts T+1 host-staged MPI messages
+// per peer.  Here the particles leaving for every peer are packed rank-major into one buffer per
+// member (+ the element gid as int64, fixing the int truncation of SCS_migrate.h:77);
+// the exchange itself is a single all-to-all-v over RCCL/xGMI issued by the host layer, and the
+// received particles enter pp_ps_rebuild as "new particles" exactly like the reference
+// (SCS_migrate.h:198-213).
+#include <algorithm>
+#include "pp_internal.hpp"
+
+namespace {
+using pp::grid_for;
+using pp::kBlock;
+
+__global__ void k_unsafe(int capacity, const unsigned char* __restrict__ mask,
+                         const int* __restrict__ slot_elem, const int* __restrict__ elems,
+                         const unsigned char* __restrict__ safe, const int* __restrict__ owners,
+                         int rank, int* __restrict__ new_elems, int* __restrict__ new_procs) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity || slot_elem[pid] < 0) return;
+  int proc = rank;
+  const int nelm = elems[pid];
+  new_elems[pid] = nelm;
+  if (mask[pid] && nelm != -1 && !safe[nelm]) proc = owners[nelm];
+  new_procs[pid] = proc;
+}
+
+// a particle is sent when it is live, keeps a valid new element and is routed to another rank
+__global__ void k_send_count(int capacity, const unsigned char* __restrict__ mask,
+                             const int* __restrict__ new_element,
+                             const int* __restrict__ new_process, int rank, int nranks,
+                             int* __restrict__ counts) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity || !mask[pid] || new_element[pid] < 0) return;
+  const int p = new_process[pid];
+  if (p != rank && p >= 0 && p < nranks) atomicAdd(&counts[p], 1);
+}
+
+struct PackArgs {
+  int nmembers;
+  const void* src[8];
+  void* dst[8];
+  int bytes[8];
+  int ncomp[8];
+  long long src_stride, dst_stride;
+};
+
+__global__ void k_pack(int capacity, const unsigned char* __restrict__ mask, int* new_element,
+                       const int* __restrict__ new_process, int rank, int nranks,
+                       int* __restrict__ cursor, const long long* __restrict__ gids,
+                       long long* __restrict__ send_gid, PackArgs a) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity || !mask[pid]) return;
+  const int e = new_element[pid];
+  if (e < 0) return;
+  const int p = new_process[pid];
+  if (p == rank || p < 0 || p >= nranks) return;
+  const int idx = atomicAdd(&cursor[p], 1);
+  send_gid[idx] = gids ? gids[e] : (long long)e;
+  for (int m = 0; m < a.nmembers; ++m) {
+    const int nc = a.ncomp[m];
+    if (a.bytes[m] == 8) {
+      const unsigned long long* s = (const unsigned long long*)a.src[m];
+      unsigned long long* d = (unsigned long long*)a.dst[m];
+      for (int c = 0; c < nc; ++c) d[c * a.dst_stride + idx] = s[c * a.src_stride + pid];
+    } else if (a.bytes[m] == 4) {
+      const unsigned* s = (const unsigned*)a.src[m];
+      unsigned* d = (unsigned*)a.dst[m];
+      for (int c = 0; c < nc; ++c) d[c * a.dst_stride + idx] = s[c * a.src_stride + pid];
+    } else if (a.bytes[m] == 2) {
+      const unsigned short* s = (const unsigned short*)a.src[m];
+      unsigned short* d = (unsigned short*)a.dst[m];
+      for (int c = 0; c < nc; ++c) d[c * a.dst_stride + idx] = s[c * a.src_stride + pid];
+    } else {
+      const unsigned char* s = (const unsigned char*)a.src[m];
+      unsigned char* d = (unsigned char*)a.dst[m];
+      for (int c = 0; c < nc; ++c) d[c * a.dst_stride + idx] = s[c * a.src_stride + pid];
+    }
+  }
+  new_element[pid] = -1;  // removeSentParticles (SCS_migrate.h:189-196)
+}
+}  // namespace
+
+extern "C" {
+
+int pp_set_unsafe_procs(const pp_ps* ps, const int* elems_dev, const unsigned char* safe_dev,
+                        const int* owners_dev, int comm_rank, int* new_elems_dev,
+                        int* new_procs_dev) {
+  PP_REQUIRE(ps && elems_dev && safe_dev && owners_dev && new_elems_dev && new_procs_dev,
+             "pp_set_unsafe_procs: null argument");
+  if (ps->num_ptcls == 0 || ps->capacity == 0) return PP_OK;
+  k_unsafe<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
+      ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), elems_dev, safe_dev,
+      owners_dev, comm_rank, new_elems_dev, new_procs_dev);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+int pp_ps_migrate_count(const pp_ps* ps, const int* new_element_dev, const int* new_process_dev,
+                        int comm_rank, int nranks, int* send_counts_host) {
+  PP_REQUIRE(ps && new_element_dev && new_process_dev && send_counts_host && nranks > 0,
+             "pp_ps_migrate_count: bad argument");
+  hipStream_t st = pp::stream();
+  pp::DevBuf cnt;
+  PP_HIP_CHECK(cnt.reserve(sizeof(int) * (size_t)nranks));
+  PP_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(int) * (size_t)nranks, st));
+  if (ps->num_ptcls > 0 && ps->capacity > 0)
+    k_send_count<<<grid_for(ps->capacity), kBlock, 0, st>>>(
+        ps->capacity, ps->d_mask.as<unsigned char>(), new_element_dev, new_process_dev, comm_rank,
+        nranks, cnt.as<int>());
+  PP_LAUNCH_CHECK();
+  PP_HIP_CHECK(hipMemcpyAsync(send_counts_host, cnt.p, sizeof(int) * (size_t)nranks,
+                              hipMemcpyDeviceToHost, st));
+  PP_HIP_CHECK(hipStreamSynchronize(st));
+  return PP_OK;
+}
+
+int pp_ps_migrate_pack(const pp_ps* ps, int* new_element_dev, const int* new_process_dev,
+                       int comm_rank, int nranks, const int* send_counts_host,
+                       int64_t* send_gid_dev, void* const* send_info_dev) {
+  PP_REQUIRE(ps && new_element_dev && new_process_dev && send_counts_host && nranks > 0,
+             "pp_ps_migrate_pack: bad argument");
+  long long total = 0;
+  std::vector<int> start((size_t)nranks, 0);
+  for (int r = 0; r < nranks; ++r) {
+    start[r] = (int)total;
+    total += send_counts_host[r];
+  }
+  if (total == 0) return PP_OK;
+  PP_REQUIRE(send_gid_dev && send_info_dev, "pp_ps_migrate_pack: null send buffers");
+  hipStream_t st = pp::stream();
+  pp::DevBuf cur;
+  PP_HIP_CHECK(cur.reserve(sizeof(int) * (size_t)nranks));
+  PP_HIP_CHECK(hipMemcpyAsync(cur.p, start.data(), sizeof(int) * (size_t)nranks,
+                              hipMemcpyHostToDevice, st));
+  PackArgs a{};
+  a.nmembers = ps->nmembers;
+  for (int m = 0; m < ps->nmembers; ++m) {
+    const int s = ps->member_map[m];
+    a.src[m] = ps->data[s].p;
+    a.dst[m] = send_info_dev[m];
+    a.bytes[m] = ps->member_bytes[s];
+    a.ncomp[m] = ps->member_ncomp[s];
+  }
+  a.src_stride = ps->stride;
+  a.dst_stride = total;
+  k_pack<<<grid_for(ps->capacity), kBlock, 0, st>>>(
+      ps->capacity, ps->d_mask.as<unsigned char>(), new_element_dev, new_process_dev, comm_rank,
+      nranks, cur.as<int>(), ps->has_gids ? ps->d_gids.as<long long>() : nullptr,
+      (long long*)send_gid_dev, a);
+  PP_LAUNCH_CHECK();
+  PP_HIP_CHECK(hipStreamSynchronize(st));  // `start` and `cur` go out of scope
+  return PP_OK;
+}
+
+}  // extern "C"

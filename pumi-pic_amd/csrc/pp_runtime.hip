@@ -1,0 +1,93 @@
+// pp_runtime.hip -- device selection, stream, memory and event helpers of the C-ABI.
+#include "pp_internal.hpp"
+
+namespace pp {
+static thread_local std::string g_err;
+static hipStream_t g_stream = nullptr;
+static bool g_init = false;
+
+void set_error(const std::string& msg) { g_err = msg; }
+hipStream_t stream() { return g_stream; }
+bool initialised() { return g_init; }
+}  // namespace pp
+
+extern "C" {
+
+const char* pp_last_error(void) { return pp::g_err.c_str(); }
+const char* pp_version(void) { return "pumipic_hip 0.1 (gfx950)"; }
+
+int pp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int pp_init(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    pp::set_error("pp_init: no HIP device visible -- libpumipic_hip has no CPU fallback");
+    return PP_EHIP;
+  }
+  PP_REQUIRE(device >= 0 && device < n, "pp_init: device index out of range");
+  PP_HIP_CHECK(hipSetDevice(device));
+  if (!pp::g_stream) PP_HIP_CHECK(hipStreamCreateWithFlags(&pp::g_stream, hipStreamNonBlocking));
+  pp::g_init = true;
+  return PP_OK;
+}
+
+void* pp_stream(void) { return (void*)pp::g_stream; }
+
+int pp_sync(void) {
+  PP_HIP_CHECK(hipStreamSynchronize(pp::g_stream));
+  return PP_OK;
+}
+
+void* pp_malloc(size_t bytes) {
+  void* p = nullptr;
+  PP_HIP_CHECK_NULL(hipMalloc(&p, bytes ? bytes : 1));
+  return p;
+}
+int pp_free(void* dev) {
+  if (dev) PP_HIP_CHECK(hipFree(dev));
+  return PP_OK;
+}
+int pp_memcpy_h2d(void* dev, const void* host, size_t bytes) {
+  if (!bytes) return PP_OK;
+  PP_HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, pp::g_stream));
+  PP_HIP_CHECK(hipStreamSynchronize(pp::g_stream));
+  return PP_OK;
+}
+int pp_memcpy_d2h(void* host, const void* dev, size_t bytes) {
+  if (!bytes) return PP_OK;
+  PP_HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, pp::g_stream));
+  PP_HIP_CHECK(hipStreamSynchronize(pp::g_stream));
+  return PP_OK;
+}
+int pp_memset(void* dev, int value, size_t bytes) {
+  if (!bytes) return PP_OK;
+  PP_HIP_CHECK(hipMemsetAsync(dev, value, bytes, pp::g_stream));
+  return PP_OK;
+}
+
+void* pp_event_create(void) {
+  hipEvent_t ev = nullptr;
+  PP_HIP_CHECK_NULL(hipEventCreate(&ev));
+  return (void*)ev;
+}
+int pp_event_record(void* ev) {
+  PP_HIP_CHECK(hipEventRecord((hipEvent_t)ev, pp::g_stream));
+  return PP_OK;
+}
+float pp_event_elapsed_ms(void* start, void* stop) {
+  float ms = -1.f;
+  if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return -1.f;
+  if (hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) return -1.f;
+  return ms;
+}
+int pp_event_destroy(void* ev) {
+  if (ev) PP_HIP_CHECK(hipEventDestroy((hipEvent_t)ev));
+  return PP_OK;
+}
+
+}  // extern "C"

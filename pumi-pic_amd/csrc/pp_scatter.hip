@@ -1,0 +1,232 @@
+// pp_scatter.hip -- particle<->mesh scatter/gather.
+//   createGyroRingMappings / searchAndBuildMap   test/gyroScatter.hpp:28-166
+//   gyroScatter                                  test/gyroScatter.hpp:168-229
+//   gyroSync pack                                test/gyroScatter.hpp:245-249
+//   computeAvgPtclDensity                        test/pseudoPushAndSearch.cpp:340-374
+//
+// gyroScatter: in the reference every live particle issues 6 double atomics
+// (ring_accum[v*gnr+{ringDown,ringUp}] += 1 for the 3 vertices of its element) and the particle
+// radius is a constant (gyroScatter.hpp:184), so the first stage is a pure function of
+// the per-element live-particle counts.  Those counts come from the structure (mask summed per
+// row without atomics for SCS, offsets differences for CSR); each ELEMENT then issues one atomic
+// per (vertex, ring).  All addends are exact integers, so the sums are bit-identical to the
+// reference's particle-by-particle accumulation in any order.
+#include "pp_geom.hpp"
+#include "pp_internal.hpp"
+
+namespace {
+using pp::grid_for;
+using pp::kBlock;
+using namespace ppg;
+
+// --- ring map: one thread per ring point; BCC walk identical to search_mesh_2d (maxLoops 100)
+__global__ void k_ring_map(int num_points, int gnr, int gppr, double rmax, double theta_deg,
+                           const double* __restrict__ coords, const int* __restrict__ v2e_off,
+                           const int* __restrict__ v2e, const int* __restrict__ elem2verts,
+                           const pp_tri_rec* __restrict__ recs, int* __restrict__ fwd,
+                           int* __restrict__ bkwd) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= num_points) return;
+  const int point_id = id % gppr;
+  const int id2 = id / gppr;
+  const int ring_id = id2 % gnr;
+  const int vert_id = id2 / gnr;
+  const double torad = 3.14159265358979323846 / 180;
+  const double radius = rmax * (ring_id + 1) / gnr;
+  const double deg = theta_deg + (((double)point_id) / gppr * 360);
+  const double rad = deg * torad;
+  double sn, cs;
+  sincos_det(rad, sn, cs);
+  const V2 pt{coords[(size_t)vert_id * 2] + radius * cs, coords[(size_t)vert_id * 2 + 1] + radius * sn};
+  int elem = v2e[v2e_off[vert_id]];
+  int loops = 0;
+  bool done = false;
+  while (!done) {
+    const pp_tri_rec* r = recs + elem;
+    V2 fc[3] = {{r->xy[0][0], r->xy[0][1]}, {r->xy[1][0], r->xy[1][1]}, {r->xy[2][0], r->xy[2][1]}};
+    double bcc[3];
+    barycentric_tri(tri_area(fc), fc, pt, bcc);
+    done = all_positive3(bcc, kEpsilon);
+    if (!done) {
+      const int next = r->nbr[min3(bcc)];
+      if (next == -1) {
+        elem = -1;
+        done = true;
+      } else {
+        elem = next;
+      }
+    }
+    ++loops;
+    if (!done && loops >= 100) {
+      elem = -1;
+      break;
+    }
+  }
+  for (int i = 0; i < 3; ++i) {
+    const int v = (elem >= 0) ? elem2verts[(size_t)elem * 3 + i] : -1;
+    fwd[(size_t)id * 3 + i] = v;
+    bkwd[(size_t)id * 3 + i] = v;
+  }
+}
+
+// --- live particles per element
+// SCS: thread = (slice, row); sums the mask down its row (coalesced across rows), then one int
+// atomic per (slice,row) -- a chunk has only a few slices, so contention is negligible.
+__global__ void k_count_scs(int nslices, int C, const int* __restrict__ offsets,
+                            const int* __restrict__ s2c, const int* __restrict__ r2e,
+                            const unsigned char* __restrict__ mask, int ne,
+                            int* __restrict__ cnt) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = (int)(t / C), r = (int)(t % C);
+  if (s >= nslices) return;
+  const int start = offsets[s], rowLen = (offsets[s + 1] - start) / C;
+  int n = 0;
+  for (int p = 0; p < rowLen; ++p) n += mask[start + r + p * C];
+  if (n) {
+    const int e = r2e[s2c[s] * C + r];
+    if (e < ne) atomicAdd(&cnt[e], n);
+  }
+}
+__global__ void k_count_csr(int ne, const int* __restrict__ offsets, int* __restrict__ cnt) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < ne) cnt[e] = offsets[e + 1] - offsets[e];
+}
+__global__ void k_accumulate_rings(int ne, int nvpe, const int* __restrict__ cnt,
+                                   const int* __restrict__ elem2verts, int gnr, int ringDown,
+                                   int ringUp, double* __restrict__ ring_accum) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = t / nvpe, i = t % nvpe;
+  if (e >= ne) return;
+  const int n = cnt[e];
+  if (!n) return;
+  const int v = elem2verts[(size_t)e * nvpe + i];
+  atomicAdd(&ring_accum[(size_t)v * gnr + ringUp], (double)n);
+  atomicAdd(&ring_accum[(size_t)v * gnr + ringDown], (double)n);
+}
+__global__ void k_scatter_mapped(int nverts, int gnr, int gppr, const double* __restrict__ ring_accum,
+                                 const int* __restrict__ v2v, double* __restrict__ scatter_w) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)nverts * gnr * gppr;
+  if (t >= total) return;
+  const int v = (int)(t / ((long long)gnr * gppr));
+  const int ring = (int)((t / gppr) % gnr);
+  const double val = ring_accum[(size_t)v * gnr + ring] / gppr;
+  if (val == 0.0) return;  // adding +0.0 never changes a sum of non-negative terms
+  for (int k = 0; k < 3; ++k) {
+    const int mv = v2v[3 * t + k];
+    if (mv >= 0) atomicAdd(&scatter_w[mv], val);
+  }
+}
+__global__ void k_sync_pack(int nverts, const double* __restrict__ f, const double* __restrict__ b,
+                            double* __restrict__ out) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nverts) return;
+  out[2 * (size_t)v] = f[v];
+  out[2 * (size_t)v + 1] = b[v];
+}
+__global__ void k_slot_count(int capacity, const int* __restrict__ slot_elem, int ne,
+                             int* __restrict__ cnt) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity) return;
+  const int e = slot_elem[pid];
+  if (e >= 0 && e < ne) atomicAdd(&cnt[e], 1);
+}
+__global__ void k_vert_density(int nverts, const int* __restrict__ v2e_off,
+                               const int* __restrict__ v2e, const int* __restrict__ cnt,
+                               double* __restrict__ elem_cnt, int ne, double* __restrict__ dens) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < ne) elem_cnt[t] = (double)cnt[t];
+  if (t >= nverts) return;
+  const int first = v2e_off[t], deg = v2e_off[t + 1] - first;
+  double val = 0.00;
+  for (int j = 0; j < deg; ++j) val += (double)cnt[v2e[first + j]];
+  dens[t] = val / deg;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pp_create_gyro_ring_mappings(const pp_mesh* mesh, double rmax, int gnr, int gppr,
+                                 double theta_deg, int* forward_map_dev, int* backward_map_dev) {
+  PP_REQUIRE(mesh && forward_map_dev && backward_map_dev, "pp_create_gyro_ring_mappings: null argument");
+  PP_REQUIRE(mesh->dim == 2, "pp_create_gyro_ring_mappings: triangle meshes only (gyroScatter.hpp:72)");
+  PP_REQUIRE(gnr > 0 && gppr > 0, "pp_create_gyro_ring_mappings: gnr, gppr must be positive");
+  const long long n = (long long)mesh->nverts * gnr * gppr;
+  PP_REQUIRE(n < (1ll << 31), "pp_create_gyro_ring_mappings: too many ring points");
+  if (n == 0) return PP_OK;
+  k_ring_map<<<grid_for((size_t)n), kBlock, 0, pp::stream()>>>(
+      (int)n, gnr, gppr, rmax, theta_deg, mesh->d_coords.as<double>(),
+      mesh->d_vert2elems_off.as<int>(), mesh->d_vert2elems.as<int>(),
+      mesh->d_elem2verts.as<int>(), mesh->d_records.as<pp_tri_rec>(), forward_map_dev,
+      backward_map_dev);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, double rmax, int gnr,
+                    int gppr, double* scatter_w_dev) {
+  PP_REQUIRE(mesh && ps && v2v_dev && scatter_w_dev, "pp_gyro_scatter: null argument");
+  PP_REQUIRE(ps->num_elems == mesh->nelems, "pp_gyro_scatter: structure/mesh element mismatch");
+  PP_REQUIRE(gnr >= 2 && gppr > 0, "pp_gyro_scatter: needs gnr >= 2 (ringUp < gnr, gyroScatter.hpp:190)");
+  hipStream_t st = pp::stream();
+  const int ne = mesh->nelems, nverts = mesh->nverts, nvpe = mesh->dim + 1;
+  // constant particle radius (gyroScatter.hpp:184-187)
+  const double ringWidth = rmax / gnr;
+  const double ptclRadius = ringWidth * 1.125;
+  int ringDown = 0;
+  for (int i = 2; i <= gnr; i++) ringDown += (ptclRadius >= ringWidth * i);
+  const int ringUp = ringDown + 1;
+  static pp::DevBuf* s_cnt = new pp::DevBuf();   // library-lifetime scratch
+  static pp::DevBuf* s_ring = new pp::DevBuf();
+  PP_HIP_CHECK(s_cnt->reserve(sizeof(int) * (size_t)std::max(ne, 1)));
+  PP_HIP_CHECK(s_ring->reserve(sizeof(double) * (size_t)std::max(nverts * gnr, 1)));
+  PP_HIP_CHECK(hipMemsetAsync(s_cnt->p, 0, sizeof(int) * (size_t)std::max(ne, 1), st));
+  PP_HIP_CHECK(hipMemsetAsync(s_ring->p, 0, sizeof(double) * (size_t)std::max(nverts * gnr, 1), st));
+  PP_HIP_CHECK(hipMemsetAsync(scatter_w_dev, 0, sizeof(double) * (size_t)nverts, st));
+  if (ps->num_ptcls > 0 && ps->capacity > 0) {
+    if (ps->kind == PP_SCS)
+      k_count_scs<<<grid_for((size_t)ps->num_slices * ps->C), kBlock, 0, st>>>(
+          ps->num_slices, ps->C, ps->d_offsets.as<int>(), ps->d_slice_to_chunk.as<int>(),
+          ps->d_row_to_element.as<int>(), ps->d_mask.as<unsigned char>(), ne, s_cnt->as<int>());
+    else
+      k_count_csr<<<grid_for(ne), kBlock, 0, st>>>(ne, ps->d_offsets.as<int>(), s_cnt->as<int>());
+    k_accumulate_rings<<<grid_for((size_t)ne * nvpe), kBlock, 0, st>>>(
+        ne, nvpe, s_cnt->as<int>(), mesh->d_elem2verts.as<int>(), gnr, ringDown, ringUp,
+        s_ring->as<double>());
+    k_scatter_mapped<<<grid_for((size_t)nverts * gnr * gppr), kBlock, 0, st>>>(
+        nverts, gnr, gppr, s_ring->as<double>(), v2v_dev, scatter_w_dev);
+  }
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+int pp_gyro_sync_pack(int nverts, const double* fwd_dev, const double* bkwd_dev, double* out_dev) {
+  PP_REQUIRE(nverts >= 0 && fwd_dev && bkwd_dev && out_dev, "pp_gyro_sync_pack: bad argument");
+  if (nverts == 0) return PP_OK;
+  k_sync_pack<<<grid_for(nverts), kBlock, 0, pp::stream()>>>(nverts, fwd_dev, bkwd_dev, out_dev);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+int pp_avg_ptcl_density(const pp_mesh* mesh, const pp_ps* ps, double* elem_cnt_dev,
+                        double* vert_density_dev) {
+  PP_REQUIRE(mesh && ps && elem_cnt_dev && vert_density_dev, "pp_avg_ptcl_density: null argument");
+  PP_REQUIRE(ps->num_elems == mesh->nelems, "pp_avg_ptcl_density: structure/mesh element mismatch");
+  hipStream_t st = pp::stream();
+  const int ne = mesh->nelems, nverts = mesh->nverts;
+  static pp::DevBuf* s_cnt = new pp::DevBuf();
+  PP_HIP_CHECK(s_cnt->reserve(sizeof(int) * (size_t)std::max(ne, 1)));
+  PP_HIP_CHECK(hipMemsetAsync(s_cnt->p, 0, sizeof(int) * (size_t)std::max(ne, 1), st));
+  // the reference lambda has no mask test: every slot the parallel_for visits is counted
+  if (ps->num_ptcls > 0 && ps->capacity > 0)
+    k_slot_count<<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, ps->d_slot_elem.as<int>(),
+                                                           ne, s_cnt->as<int>());
+  k_vert_density<<<grid_for(std::max(std::max(ne, nverts), 1)), kBlock, 0, st>>>(
+      nverts, mesh->d_vert2elems_off.as<int>(), mesh->d_vert2elems.as<int>(), s_cnt->as<int>(),
+      elem_cnt_dev, ne, vert_density_dev);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+}  // extern "C"

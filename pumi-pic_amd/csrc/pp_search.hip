@@ -1,0 +1,706 @@
+// pp_search.hip -- element-to-element adjacency searches, whole walk inside one kernel.
+//
+// The reference drives the walk from the host: per iteration three ps::parallel_for kernels, a
+// min-reduction of ptcl_done and a D2H scalar read (src/pumipic_adjacency.tpp:558-608,
+// adjacency.hpp:1066-1150).  A particle's walk never depends on another particle, so here each
+// thread walks its own particle to completion; the result per particle is identical to the
+// reference's lock-step loop (a particle that needs more than `looplimit` steps is marked -1
+// exactly as ptclsNotFound does, tpp:584-606).
+//
+//   search_mesh_2d            src/pumipic_adjacency.hpp:1011-1158
+//   search_mesh (new)         src/pumipic_adjacency.tpp:72-145,231-416,460-654
+//   search_mesh (legacy 3-D)  src/pumipic_adjacency.hpp:558-768
+//
+// BCC walks read ONE packed record per visited element (tri 64 B / tet 128 B: vertex coords,
+// neighbour ids with -1 = exposed side, class id, measure) instead of the reference's chain of
+// dependent gathers elem2verts -> coords, elem2sides -> exposed -> side2elems.
+#include "pp_geom.hpp"
+#include "pp_internal.hpp"
+#include "pp_push_math.hpp"
+
+namespace {
+using pp::grid_for;
+using pp::kBlock;
+using namespace ppg;
+
+constexpr int kHardLoopCap = 1 << 22;  // guards looplimit==0 against a GPU hang
+
+struct Counters {
+  int not_found;   // particles cut off by looplimit
+  int not_in_elem; // check_initial_parents failures
+  int aborted;     // legacy search: origin not in start element at loops==0 (OMEGA_H_CHECK)
+};
+
+__device__ __forceinline__ void load_tri(const pp_tri_rec* __restrict__ recs, int e, V2 fc[3],
+                                         int nbr[3]) {
+  const pp_tri_rec* r = recs + e;
+  for (int i = 0; i < 3; ++i) {
+    fc[i] = {r->xy[i][0], r->xy[i][1]};
+    nbr[i] = r->nbr[i];
+  }
+}
+__device__ __forceinline__ void load_tet(const pp_tet_rec* __restrict__ recs, int e, V3 M[4],
+                                         int nbr[4], double& vol) {
+  const pp_tet_rec* r = recs + e;
+  for (int i = 0; i < 4; ++i) {
+    M[i] = {r->xyz[i][0], r->xyz[i][1], r->xyz[i][2]};
+    nbr[i] = r->nbr[i];
+  }
+  vol = r->vol;
+}
+
+// one BCC step in a triangle: returns done; sets next (neighbour across the arg-min edge, -1 if
+// that edge is exposed).  barycentric_tri + all_positive + min3 (hpp:1072-1081 / tpp:250-260)
+__device__ __forceinline__ bool step_tri(const pp_tri_rec* __restrict__ recs, int elem, V2 pos,
+                                         int& next) {
+  V2 fc[3];
+  int nbr[3];
+  load_tri(recs, elem, fc, nbr);
+  const double area = tri_area(fc);  // == measure_elements_real(elem), same expression
+  double bcc[3];
+  barycentric_tri(area, fc, pos, bcc);
+  const bool done = all_positive3(bcc, kEpsilon);
+  next = nbr[min3(bcc)];
+  return done;
+}
+__device__ __forceinline__ bool step_tet(const pp_tet_rec* __restrict__ recs, int elem, V3 pos,
+                                         int& next) {
+  V3 M[4];
+  int nbr[4];
+  double vol;
+  load_tet(recs, elem, M, nbr, vol);
+  double bcc[4];
+  barycentric_tet(vol, M, pos, bcc);
+  const bool done = all_positive4(bcc, kEpsilon);
+  next = nbr[min_index4(bcc)];
+  return done;
+}
+
+// BCC walk shared by search_mesh_2d, search_mesh(BCC) and the fused kernel.
+// Per iteration (reference kernel order): find exit -> exposed? -> next element -> looplimit.
+template <int DIM>
+__device__ __forceinline__ int bcc_walk(const void* __restrict__ recs, int elem, V3 pos,
+                                        int looplimit, Counters* cnt) {
+  int loops = 0;
+  bool done = false;
+  const int cap = looplimit ? looplimit : kHardLoopCap;
+  while (true) {
+    int next;
+    if (DIM == 2)
+      done = step_tri((const pp_tri_rec*)recs, elem, V2{pos.x, pos.y}, next);
+    else
+      done = step_tet((const pp_tet_rec*)recs, elem, pos, next);
+    if (!done) {
+      if (next == -1) {  // exposed side: leaves the domain
+        elem = -1;
+        done = true;
+      } else {
+        elem = next;
+      }
+    }
+    ++loops;
+    if (done) break;
+    if (loops >= cap) {
+      elem = -1;
+      atomicAdd(&cnt->not_found, 1);
+      break;
+    }
+  }
+  return elem;
+}
+
+// ------------------------------------------------------------------ search_mesh_2d
+__global__ void k_search2d(int capacity, const unsigned char* __restrict__ mask,
+                           const int* __restrict__ slot_elem, const pp_tri_rec* __restrict__ recs,
+                           int nelems, const double* __restrict__ xt, long long stride,
+                           int* __restrict__ elem_ids, int looplimit, Counters* cnt) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity) return;
+  const int e = slot_elem[pid];
+  if (e < 0) return;
+  if (!mask[pid]) {
+    elem_ids[pid] = -1;
+    return;
+  }
+  int elem = elem_ids[pid];
+  if (elem == -1) elem = e;
+  if (elem == -nelems) {  // hpp:1051-1056
+    elem_ids[pid] = -1;
+    return;
+  }
+  const V3 pos{xt[pid], xt[stride + pid], 0.0};
+  elem_ids[pid] = bcc_walk<2>(recs, elem, pos, looplimit, cnt);
+}
+
+// ------------------------------------------------------------------ search_mesh (tpp)
+struct MeshArrays {
+  const double* coords;
+  const int* elem2verts;
+  const int* elem2sides;
+  const int* side2verts;
+  const int* side2elems_off;
+  const int* side2elems;
+  const signed char* side_exposed;
+  const double* elem_measure;
+  const int* dual_off;
+  const int* dual_elems;
+};
+
+template <int DIM>
+__device__ __forceinline__ bool origin_inside(const void* __restrict__ recs, int elem, V3 orig,
+                                              double tol) {
+  if (DIM == 2) {
+    V2 fc[3];
+    int nbr[3];
+    load_tri((const pp_tri_rec*)recs, elem, fc, nbr);
+    double bcc[3];
+    barycentric_tri(tri_area(fc), fc, V2{orig.x, orig.y}, bcc);
+    return all_positive3(bcc, tol);
+  } else {
+    V3 M[4];
+    int nbr[4];
+    double vol;
+    load_tet((const pp_tet_rec*)recs, elem, M, nbr, vol);
+    double bcc[4];
+    barycentric_tet(vol, M, orig, bcc);
+    return all_positive4(bcc, tol);
+  }
+}
+
+__device__ __forceinline__ int other_elem(const MeshArrays& m, int bridge, int searchElm) {
+  const int first = m.side2elems_off[bridge];
+  const int A = m.side2elems[first], B = m.side2elems[first + 1];
+  return (A == searchElm) ? B : A;
+}
+
+// Intersection-mode exit search in one element (tpp:284-361).  Returns lastExit (side id or -1)
+template <int DIM>
+__device__ __forceinline__ int exit_by_intersection(const MeshArrays& m, int searchElm, V3 orig,
+                                                    V3 dest, double tol, int prevExit,
+                                                    double ip[3]) {
+  int lastExit = -1;
+  if (DIM == 2) {
+    int fverts[3];
+    for (int i = 0; i < 3; ++i) fverts[i] = m.elem2verts[(size_t)searchElm * 3 + i];
+    V2 xpts{0, 0};
+    for (int ei = 0; ei < 3; ++ei) {
+      const int edge_id = m.elem2sides[(size_t)searchElm * 3 + ei];
+      if (edge_id == prevExit) continue;
+      int ev2v[2];
+      V2 edge[2];
+      for (int q = 0; q < 2; ++q) {
+        ev2v[q] = m.side2verts[(size_t)edge_id * 2 + q];
+        edge[q] = {m.coords[(size_t)ev2v[q] * 2], m.coords[(size_t)ev2v[q] * 2 + 1]};
+      }
+      const int flip = is_edge_flipped(ev2v, fverts);
+      const bool success = line_edge_2d(edge, V2{orig.x, orig.y}, V2{dest.x, dest.y}, xpts, tol, flip);
+      if (success) {
+        lastExit = edge_id;
+        ip[0] = xpts.x;
+        ip[1] = xpts.y;
+      }
+    }
+  } else {
+    int tetv2v[4];
+    for (int i = 0; i < 4; ++i) tetv2v[i] = m.elem2verts[(size_t)searchElm * 4 + i];
+    V3 xpts{0, 0, 0};
+    double quality = -1;
+    int bestFace = -1;
+    for (int fi = 0; fi < 4; ++fi) {
+      const int face_id = m.elem2sides[(size_t)searchElm * 4 + fi];
+      if (face_id == prevExit) continue;
+      int fv2v[3];
+      V3 face[3];
+      for (int q = 0; q < 3; ++q) {
+        fv2v[q] = m.side2verts[(size_t)face_id * 3 + q];
+        face[q] = {m.coords[(size_t)fv2v[q] * 3], m.coords[(size_t)fv2v[q] * 3 + 1],
+                   m.coords[(size_t)fv2v[q] * 3 + 2]};
+      }
+      const int flip = is_face_flipped(fi, fv2v, tetv2v);
+      double dproj, closeness, param;
+      const bool success =
+          ray_intersects_triangle(face, orig, dest, xpts, tol, flip, dproj, closeness, param);
+      if (success) {
+        lastExit = face_id;
+        ip[0] = xpts.x;
+        ip[1] = xpts.y;
+        ip[2] = xpts.z;
+      }
+      if (dproj > -tol && (quality < 0 || closeness < quality) && lastExit == -1) {
+        quality = closeness;
+        bestFace = face_id;
+        ip[0] = xpts.x;
+        ip[1] = xpts.y;
+        ip[2] = xpts.z;
+      }
+    }
+    if (lastExit == -1) lastExit = bestFace;
+  }
+  return lastExit;
+}
+
+template <int DIM, bool MT>
+__global__ void k_search_tpp(int capacity, const unsigned char* __restrict__ mask,
+                             const int* __restrict__ slot_elem, const void* __restrict__ recs,
+                             MeshArrays m, const double* __restrict__ x,
+                             const double* __restrict__ xt, long long stride,
+                             int* __restrict__ elem_ids, int seeded, double tol,
+                             int* __restrict__ inter_faces, double* __restrict__ inter_points,
+                             int looplimit, Counters* cnt) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity) return;
+  const int e = slot_elem[pid];
+  if (e < 0) return;
+  const bool msk = mask[pid];
+  if (MT) {  // initializeIntersection visits every slot (tpp:542-547)
+    for (int i = 0; i < DIM; ++i) inter_points[(size_t)DIM * pid + i] = 0;
+    inter_faces[pid] = -1;
+  }
+  int elem;
+  bool done;
+  if (!seeded) {  // tpp:504-515
+    elem = msk ? e : -1;
+    done = !msk;
+  } else {  // tpp:516-522
+    elem = elem_ids[pid];
+    done = (msk && elem == -1) || !msk;
+  }
+  if (!msk) {
+    if (!seeded) elem_ids[pid] = -1;
+    return;
+  }
+  const V3 orig{x[pid], x[stride + pid], x[2 * stride + pid]};
+  const V3 dest{xt[pid], xt[stride + pid], xt[2 * stride + pid]};
+  if (norm(sub(dest, orig)) < tol) done = true;  // finishUnmoved tpp:525-533
+  if (!done) {                                   // check_initial_parents tpp:72-145
+    if (!origin_inside<DIM>(recs, elem, orig, tol)) {
+      atomicAdd(&cnt->not_in_elem, 1);
+      elem = -1;
+      done = true;
+    }
+  }
+  if (!done) {
+    if (!MT) {
+      elem = bcc_walk<DIM>(recs, elem, dest, looplimit, cnt);
+    } else {
+      int lastExit = -1, loops = 0, xface = -1;
+      double ip[3] = {0, 0, 0};
+      const int cap = looplimit ? looplimit : kHardLoopCap;
+      while (true) {
+        lastExit = exit_by_intersection<DIM>(m, elem, orig, dest, tol, lastExit, ip);
+        done = (lastExit == -1);
+        if (!done) {  // check_model_intersection tpp:372-385 (requireIntersection == true)
+          const bool exposed = m.side_exposed[lastExit];
+          done = exposed;
+          if (exposed) xface = lastExit;
+        }
+        if (!done) elem = other_elem(m, lastExit, elem);  // set_new_element tpp:397-414
+        ++loops;
+        if (done) break;
+        if (loops >= cap) {
+          elem = -1;
+          atomicAdd(&cnt->not_found, 1);
+          break;
+        }
+      }
+      for (int i = 0; i < DIM; ++i) inter_points[(size_t)DIM * pid + i] = ip[i];
+      inter_faces[pid] = xface;
+    }
+  }
+  elem_ids[pid] = elem;
+}
+
+// ------------------------------------------------------------------ legacy 3-D search_mesh
+__global__ void k_search_legacy3d(int capacity, const unsigned char* __restrict__ mask,
+                                  const int* __restrict__ slot_elem, MeshArrays m,
+                                  const double* __restrict__ x, const double* __restrict__ xt,
+                                  long long stride, int* __restrict__ elem_ids, int seeded,
+                                  double* __restrict__ xpoints_d, int* __restrict__ xface_d,
+                                  int looplimit, Counters* cnt) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity) return;
+  const int e = slot_elem[pid];
+  if (e < 0) {
+    if (!seeded) elem_ids[pid] = -1;
+    return;
+  }
+  if (!mask[pid]) {  // hpp:593-596
+    elem_ids[pid] = -1;
+    return;
+  }
+  const double tol = 1.0e-10;
+  int elmId = seeded ? elem_ids[pid] : e;
+  if (elmId == -1) {  // ptcl_done from the start: elem_ids_next stays -1 (hpp:580,746)
+    elem_ids[pid] = -1;
+    return;
+  }
+  const V3 orig{x[pid], x[stride + pid], x[2 * stride + pid]};
+  const V3 dest{xt[pid], xt[stride + pid], xt[2 * stride + pid]};
+  int loops = 0;
+  int result = -1;
+  bool done = false;
+  // the reference breaks when loops > looplimit (hpp:757): looplimit+1 iterations are allowed
+  const int cap = looplimit ? looplimit + 1 : kHardLoopCap;
+  while (true) {
+    int tetv2v[4];
+    V3 M[4];
+    for (int i = 0; i < 4; ++i) {
+      tetv2v[i] = m.elem2verts[(size_t)elmId * 4 + i];
+      M[i] = {m.coords[(size_t)tetv2v[i] * 3], m.coords[(size_t)tetv2v[i] * 3 + 1],
+              m.coords[(size_t)tetv2v[i] * 3 + 2]};
+    }
+    double bcc[4];
+    if (loops == 0) {
+      find_barycentric_tet(M, orig, bcc);
+      if (!all_positive4(bcc, tol)) atomicAdd(&cnt->aborted, 1);
+    }
+    int next = -1;
+    find_barycentric_tet(M, dest, bcc);
+    if (all_positive4(bcc, tol)) {
+      next = elmId;
+      done = true;
+    } else {
+      double dproj[4] = {-1, -1, -1, -1};
+      double xps[12] = {0};
+      int exposed_faces[4] = {0, 0, 0, 0};
+      int xface_ids[4] = {-1, -1, -1, -1};
+      int dual_elem_id = m.dual_off[elmId];
+      bool intersected = false;
+      int findex = 0;
+      for (int lf = 0; lf < 4; ++lf) {
+        const int face_id = m.elem2sides[(size_t)elmId * 4 + lf];
+        const bool exposed = m.side_exposed[face_id];
+        exposed_faces[findex] = exposed;
+        xface_ids[findex] = face_id;
+        int fv2v[3];
+        V3 face[3];
+        for (int q = 0; q < 3; ++q) {
+          fv2v[q] = m.side2verts[(size_t)face_id * 3 + q];
+          face[q] = {m.coords[(size_t)fv2v[q] * 3], m.coords[(size_t)fv2v[q] * 3 + 1],
+                     m.coords[(size_t)fv2v[q] * 3 + 2]};
+        }
+        const int m1 = face_map(findex * 2), m2 = face_map(findex * 2 + 1);
+        bool flip = true;
+        if (fv2v[1] == tetv2v[m1] && fv2v[2] == tetv2v[m2]) flip = false;  // hpp:660-664
+        V3 xpoint;
+        intersected = line_triangle_intx_simple(face, orig, dest, xpoint, dproj[findex], flip, tol);
+        xps[findex * 3] = xpoint.x;
+        xps[findex * 3 + 1] = xpoint.y;
+        xps[findex * 3 + 2] = xpoint.z;
+        if (intersected && exposed) {
+          done = true;
+          xpoints_d[(size_t)pid * 3] = xpoint.x;
+          xpoints_d[(size_t)pid * 3 + 1] = xpoint.y;
+          xpoints_d[(size_t)pid * 3 + 2] = xpoint.z;
+          xface_d[pid] = face_id;
+          next = -1;
+          break;
+        } else if (intersected && !exposed) {
+          next = m.dual_elems[dual_elem_id];
+          break;
+        }
+        if (!exposed) ++dual_elem_id;
+        ++findex;
+      }
+      if (!intersected) {
+        const int max_ind = max_index4(dproj);
+        if (dproj[max_ind] >= 0) {
+          const int fid = xface_ids[max_ind];
+          if (exposed_faces[max_ind]) {
+            next = -1;
+            for (int i = 0; i < 3; ++i) xpoints_d[(size_t)pid * 3 + i] = xps[max_ind * 3 + i];
+            xface_d[pid] = fid;
+            done = true;
+          } else {
+            // the reference indexes the dual value array by a face id here
+            // (hpp:726); not replicated -- neighbour across the max-dproj face.
+            next = other_elem(m, fid, elmId);
+          }
+        } else {
+          next = -1;
+          done = true;
+        }
+      }
+    }
+    result = next;  // elem_ids <- elem_ids_next after every iteration (hpp:745-748)
+    ++loops;
+    if (done) break;
+    if (loops >= cap) {
+      atomicAdd(&cnt->not_found, 1);
+      break;  // particle keeps its current element id, as in the reference
+    }
+    elmId = next;
+  }
+  elem_ids[pid] = result;
+}
+
+// ------------------------------------------------------------------ fused push + BCC walk
+// DIM 2: ellipticalPush::push + search_mesh_2d.  DIM 3: toroidal push + search_mesh (BCC) with
+// finishUnmoved and check_initial_parents.  Particle state is read once; x_tgt, phi, elem_ids
+// are written once.
+template <int DIM>
+__global__ void k_push_walk(int capacity, const unsigned char* __restrict__ mask,
+                            const int* __restrict__ slot_elem, const void* __restrict__ recs,
+                            const int* __restrict__ class_id, int nelems,
+                            const double* __restrict__ x, double* __restrict__ xt,
+                            long long stride, const float* __restrict__ pb,
+                            float* __restrict__ pphi, double h, double k, double d, double deg,
+                            double tol, int* __restrict__ elem_ids, int seeded, int looplimit,
+                            Counters* cnt) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity) return;
+  const int e = slot_elem[pid];
+  if (e < 0) return;
+  if (!mask[pid]) {
+    if (DIM == 2 || !seeded) elem_ids[pid] = -1;
+    return;
+  }
+  const int cls = class_id[e];
+  const float phi = pphi[pid], b = pb[pid];
+  double rad;
+  V3 dest;
+  int elem = seeded ? elem_ids[pid] : (DIM == 2 ? -1 : e);
+  if (DIM == 2) {
+    ppm::elliptical_advance(cls, phi, b, h, k, d, deg, dest.x, dest.y, rad);
+    dest.z = 0;
+    xt[pid] = dest.x;
+    xt[stride + pid] = dest.y;
+    pphi[pid] = (float)rad;
+    if (elem == -1) elem = e;
+    if (elem == -nelems) {
+      elem_ids[pid] = -1;
+      return;
+    }
+    elem_ids[pid] = bcc_walk<2>(recs, elem, dest, looplimit, cnt);
+  } else {
+    const V3 orig{x[pid], x[stride + pid], x[2 * stride + pid]};
+    ppm::toroidal_advance(cls, phi, b, orig.x, orig.y, h, k, d, deg, dest.x, dest.y, dest.z, rad);
+    xt[pid] = dest.x;
+    xt[stride + pid] = dest.y;
+    xt[2 * stride + pid] = dest.z;
+    pphi[pid] = (float)rad;
+    bool done = (elem == -1);
+    if (norm(sub(dest, orig)) < tol) done = true;
+    if (!done && !origin_inside<3>(recs, elem, orig, tol)) {
+      atomicAdd(&cnt->not_in_elem, 1);
+      elem = -1;
+      done = true;
+    }
+    if (!done) elem = bcc_walk<3>(recs, elem, dest, looplimit, cnt);
+    elem_ids[pid] = elem;
+  }
+}
+
+MeshArrays arrays_of(const pp_mesh* mesh) {
+  MeshArrays m;
+  m.coords = mesh->d_coords.as<double>();
+  m.elem2verts = mesh->d_elem2verts.as<int>();
+  m.elem2sides = mesh->d_elem2sides.as<int>();
+  m.side2verts = mesh->d_side2verts.as<int>();
+  m.side2elems_off = mesh->d_side2elems_off.as<int>();
+  m.side2elems = mesh->d_side2elems.as<int>();
+  m.side_exposed = mesh->d_side_exposed.as<signed char>();
+  m.elem_measure = mesh->d_elem_measure.as<double>();
+  m.dual_off = mesh->d_dual_off.as<int>();
+  m.dual_elems = mesh->d_dual_elems.as<int>();
+  return m;
+}
+
+// device-side counters; allocated once and intentionally never freed (library lifetime)
+Counters* g_cnt_dev = nullptr;
+struct CntRef {
+  Counters* get() { return g_cnt_dev; }
+} g_cnt;
+
+int reset_counters() {
+  if (!g_cnt_dev) PP_HIP_CHECK(hipMalloc((void**)&g_cnt_dev, sizeof(Counters)));
+  PP_HIP_CHECK(hipMemsetAsync(g_cnt_dev, 0, sizeof(Counters), pp::stream()));
+  return PP_OK;
+}
+int read_counters(Counters* h) {
+  PP_HIP_CHECK(hipMemcpyAsync(h, g_cnt_dev, sizeof(Counters), hipMemcpyDeviceToHost, pp::stream()));
+  PP_HIP_CHECK(hipStreamSynchronize(pp::stream()));
+  return PP_OK;
+}
+
+int member_ok(const pp_ps* ps, int m, int bytes, int ncomp, const char* what) {
+  if (m < 0 || m >= ps->nmembers) {
+    pp::set_error(std::string(what) + ": member index out of range");
+    return PP_EINVAL;
+  }
+  const int s = ps->member_map[m];
+  if (ps->member_bytes[s] != bytes || ps->member_ncomp[s] < ncomp) {
+    pp::set_error(std::string(what) + ": member has the wrong type for this operator");
+    return PP_EINVAL;
+  }
+  return PP_OK;
+}
+#define PP_MEMBER(ps, m, T) ((T*)(ps)->data[(ps)->member_map[m]].p)
+
+}  // namespace
+
+extern "C" {
+
+int pp_search_mesh_2d(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_pid,
+                      int* elem_ids_dev, int looplimit, int* found) {
+  (void)m_x;
+  (void)m_pid;
+  PP_REQUIRE(mesh && ps && elem_ids_dev, "pp_search_mesh_2d: null argument");
+  PP_REQUIRE(mesh->dim == 2, "pp_search_mesh_2d: needs a triangle mesh");
+  PP_REQUIRE(ps->num_elems == mesh->nelems, "pp_search_mesh_2d: structure/mesh element mismatch");
+  int rc;
+  if ((rc = member_ok(ps, m_xtgt, 8, 2, "pp_search_mesh_2d x_tgt"))) return rc;
+  if (found) *found = 1;
+  if (ps->num_ptcls == 0 || ps->capacity == 0) return PP_OK;
+  if ((rc = reset_counters())) return rc;
+  k_search2d<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
+      ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(),
+      mesh->d_records.as<pp_tri_rec>(), mesh->nelems, PP_MEMBER(ps, m_xtgt, double), ps->stride,
+      elem_ids_dev, looplimit, g_cnt.get());
+  PP_LAUNCH_CHECK();
+  if (found) {
+    Counters h;
+    if ((rc = read_counters(&h))) return rc;
+    *found = (h.not_found == 0);
+    if (h.not_found)
+      fprintf(stderr, "ERROR: loop limit %d exceeded. %d particles were not found. Deleting them...\n",
+              looplimit, h.not_found);
+  }
+  return PP_OK;
+}
+
+int pp_search_mesh(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_pid,
+                   int* elem_ids_dev, int elem_ids_seeded, int requireIntersection,
+                   int* inter_faces_dev, double* inter_points_dev, int looplimit, int* found,
+                   int* num_not_in_elem) {
+  (void)m_pid;
+  PP_REQUIRE(mesh && ps && elem_ids_dev, "pp_search_mesh: null argument");
+  PP_REQUIRE(ps->num_elems == mesh->nelems, "pp_search_mesh: structure/mesh element mismatch");
+  PP_REQUIRE(!requireIntersection || (inter_faces_dev && inter_points_dev),
+             "pp_search_mesh: intersection mode needs inter_faces/inter_points");
+  int rc;
+  if ((rc = member_ok(ps, m_x, 8, 3, "pp_search_mesh x"))) return rc;
+  if ((rc = member_ok(ps, m_xtgt, 8, 3, "pp_search_mesh x_tgt"))) return rc;
+  if (found) *found = 1;
+  if (num_not_in_elem) *num_not_in_elem = 0;
+  if (ps->capacity == 0) return PP_OK;
+  if (ps->num_ptcls == 0) {
+    if (!elem_ids_seeded)
+      PP_HIP_CHECK(hipMemsetAsync(elem_ids_dev, 0xff, sizeof(int) * (size_t)ps->capacity, pp::stream()));
+    return PP_OK;
+  }
+  if ((rc = reset_counters())) return rc;
+  const MeshArrays m = arrays_of(mesh);
+  const unsigned grid = grid_for(ps->capacity);
+  hipStream_t st = pp::stream();
+#define PP_TPP_ARGS                                                                              \
+  ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), mesh->d_records.p, m,  \
+      PP_MEMBER(ps, m_x, double), PP_MEMBER(ps, m_xtgt, double), ps->stride, elem_ids_dev,       \
+      elem_ids_seeded, mesh->tol, inter_faces_dev, inter_points_dev, looplimit, g_cnt.get()
+  if (mesh->dim == 2) {
+    if (requireIntersection)
+      k_search_tpp<2, true><<<grid, kBlock, 0, st>>>(PP_TPP_ARGS);
+    else
+      k_search_tpp<2, false><<<grid, kBlock, 0, st>>>(PP_TPP_ARGS);
+  } else {
+    if (requireIntersection)
+      k_search_tpp<3, true><<<grid, kBlock, 0, st>>>(PP_TPP_ARGS);
+    else
+      k_search_tpp<3, false><<<grid, kBlock, 0, st>>>(PP_TPP_ARGS);
+  }
+#undef PP_TPP_ARGS
+  PP_LAUNCH_CHECK();
+  if (found || num_not_in_elem) {
+    Counters h;
+    if ((rc = read_counters(&h))) return rc;
+    if (found) *found = (h.not_found == 0);
+    if (num_not_in_elem) *num_not_in_elem = h.not_in_elem;
+    if (h.not_in_elem)
+      fprintf(stderr,
+              "[WARNING] %d particles are not located in their starting elements. Deleting them...\n",
+              h.not_in_elem);
+    if (h.not_found)
+      fprintf(stderr, "ERROR: loop limit %d exceeded. %d particles were not found. Deleting them...\n",
+              looplimit, h.not_found);
+  }
+  return PP_OK;
+}
+
+int pp_search_mesh_legacy3d(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_pid,
+                            int* elem_ids_dev, int elem_ids_seeded, double* xpoints_dev,
+                            int* xface_dev, int looplimit, int* found) {
+  (void)m_pid;
+  PP_REQUIRE(mesh && ps && elem_ids_dev && xpoints_dev && xface_dev,
+             "pp_search_mesh_legacy3d: null argument");
+  PP_REQUIRE(mesh->dim == 3, "pp_search_mesh_legacy3d: needs a tet mesh");
+  PP_REQUIRE(ps->num_elems == mesh->nelems, "pp_search_mesh_legacy3d: structure/mesh mismatch");
+  int rc;
+  if ((rc = member_ok(ps, m_x, 8, 3, "pp_search_mesh_legacy3d x"))) return rc;
+  if ((rc = member_ok(ps, m_xtgt, 8, 3, "pp_search_mesh_legacy3d x_tgt"))) return rc;
+  if (found) *found = 1;
+  if (ps->num_ptcls == 0 || ps->capacity == 0) return PP_OK;
+  if ((rc = reset_counters())) return rc;
+  k_search_legacy3d<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
+      ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), arrays_of(mesh),
+      PP_MEMBER(ps, m_x, double), PP_MEMBER(ps, m_xtgt, double), ps->stride, elem_ids_dev,
+      elem_ids_seeded, xpoints_dev, xface_dev, looplimit, g_cnt.get());
+  PP_LAUNCH_CHECK();
+  if (found) {
+    Counters h;
+    if ((rc = read_counters(&h))) return rc;
+    *found = h.aborted ? -2 : (h.not_found == 0);
+    if (h.aborted)
+      fprintf(stderr, "Warning: %d particles not in their element at loops=0 (the reference aborts)\n",
+              h.aborted);
+    if (h.not_found) fprintf(stderr, "ERROR:loop limit %d exceeded\n", looplimit);
+  }
+  return PP_OK;
+}
+
+int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b, int m_phi,
+                   double h, double k, double d, double deg, int* elem_ids_dev,
+                   int elem_ids_seeded, int looplimit, int* found) {
+  PP_REQUIRE(mesh && ps && elem_ids_dev, "pp_push_search: null argument");
+  PP_REQUIRE(ps->num_elems == mesh->nelems, "pp_push_search: structure/mesh element mismatch");
+  int rc;
+  if ((rc = member_ok(ps, m_x, 8, 3, "pp_push_search x"))) return rc;
+  if ((rc = member_ok(ps, m_xtgt, 8, 3, "pp_push_search x_tgt"))) return rc;
+  if ((rc = member_ok(ps, m_b, 4, 1, "pp_push_search b"))) return rc;
+  if ((rc = member_ok(ps, m_phi, 4, 1, "pp_push_search phi"))) return rc;
+  if (found) *found = 1;
+  if (ps->capacity == 0) return PP_OK;
+  if (ps->num_ptcls == 0) {
+    if (!elem_ids_seeded && mesh->dim == 3)
+      PP_HIP_CHECK(hipMemsetAsync(elem_ids_dev, 0xff, sizeof(int) * (size_t)ps->capacity, pp::stream()));
+    return PP_OK;
+  }
+  if ((rc = reset_counters())) return rc;
+  const unsigned grid = grid_for(ps->capacity);
+  hipStream_t st = pp::stream();
+  // DIM 2 follows search_mesh_2d: the caller's elem_ids are always read (-1 = own element)
+  if (mesh->dim == 2) {
+    PP_REQUIRE(elem_ids_seeded, "pp_push_search (2-D): elem_ids must be initialised (-1 = own element)");
+    k_push_walk<2><<<grid, kBlock, 0, st>>>(
+        ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), mesh->d_records.p,
+        mesh->d_class_id.as<int>(), mesh->nelems, PP_MEMBER(ps, m_x, double),
+        PP_MEMBER(ps, m_xtgt, double), ps->stride, PP_MEMBER(ps, m_b, float),
+        PP_MEMBER(ps, m_phi, float), h, k, d, deg, mesh->tol, elem_ids_dev, 1, looplimit,
+        g_cnt.get());
+  } else {
+    k_push_walk<3><<<grid, kBlock, 0, st>>>(
+        ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), mesh->d_records.p,
+        mesh->d_class_id.as<int>(), mesh->nelems, PP_MEMBER(ps, m_x, double),
+        PP_MEMBER(ps, m_xtgt, double), ps->stride, PP_MEMBER(ps, m_b, float),
+        PP_MEMBER(ps, m_phi, float), h, k, d, deg, mesh->tol, elem_ids_dev, elem_ids_seeded,
+        looplimit, g_cnt.get());
+  }
+  PP_LAUNCH_CHECK();
+  if (found) {
+    Counters hc;
+    if ((rc = read_counters(&hc))) return rc;
+    *found = (hc.not_found == 0);
+  }
+  return PP_OK;
+}
+
+}  // extern "C"

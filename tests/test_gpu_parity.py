@@ -1,0 +1,565 @@
+"""GPU parity: every HIP entry point, called through the C-ABI, against the CPU oracle on the
+same seeded inputs.  Bar: bit-exact for ids / indices / integer work AND for positions that go
+through the shared deterministic sincos; float32-ulp tolerance only where the device libm is used
+(ellipticalPush::setup, a one-time initialisation)."""
+import numpy as np
+import pytest
+
+import common
+
+pytestmark = pytest.mark.gpu
+
+H, K, D = 1.72479370 - .08, .020558260, 0.6
+
+
+@pytest.fixture(scope="module")
+def capi(pp):
+    from pumipic_amd import capi as c
+    c.init(0)
+    return c
+
+
+def _live(ps_o, ps_g):
+    so, mo = ps_o.slot_info()
+    sg, mg = ps_g.slot_info()
+    return so, mo, sg, mg
+
+
+# ---------------------------------------------------------------- mesh derivation
+@pytest.mark.parametrize("which", ["plate", "box", "annulus", "torus"])
+def test_mesh_arrays_match_oracle(ppo, synth, capi, which):
+    if which == "plate":
+        dim, (c, e, cl) = 2, synth.plate_tri8_pardiag()
+    elif which == "box":
+        dim, (c, e, cl) = 3, synth.kuhn_box(3)
+    elif which == "annulus":
+        dim, (c, e, cl) = 2, synth.annulus_tri(n_b=6, n_theta=24, band_width=2)
+    else:
+        dim, (c, e, cl) = 3, synth.torus_tet(n_b=4, n_theta=12, n_planes=6)
+    mo = ppo.Mesh(dim, c, e, cl)
+    mg = capi.Mesh(dim, c, e, cl)
+    assert (mg.nsides, mg.nelems, mg.nverts) == (mo.nsides, mo.nelems, mo.nverts)
+    pairs = [(capi.MESH_ELEM2SIDES, mo.elem2sides), (capi.MESH_SIDE2VERTS, mo.side2verts),
+             (capi.MESH_SIDE2ELEMS_OFF, mo.side2elems_off), (capi.MESH_SIDE2ELEMS, mo.side2elems),
+             (capi.MESH_SIDE_EXPOSED, mo.side_exposed), (capi.MESH_ELEM_MEASURE, mo.elem_measure),
+             (capi.MESH_DUAL_OFF, mo.dual_off), (capi.MESH_DUAL_ELEMS, mo.dual_elems),
+             (capi.MESH_VERT2ELEMS_OFF, mo.vert2elems_off), (capi.MESH_VERT2ELEMS, mo.vert2elems)]
+    for wid, ref in pairs:
+        assert np.array_equal(mg.array(wid), np.asarray(ref).ravel()), wid
+    assert mg.tolerance() == mo.tolerance()
+
+
+# ---------------------------------------------------------------- structure construction
+@pytest.mark.parametrize("C,V,sigma", [(64, 1024, 2**31 - 1), (4, 2, 1), (32, 3, 7), (1, 1024, 2**31 - 1)])
+@pytest.mark.parametrize("pad", [0, 1, 2])
+def test_scs_layout_matches_oracle(ppo, synth, capi, C, V, sigma, pad):
+    pop = common.population_2d(synth, num_ptcls=1500)
+    ne = len(pop["e2v"])
+    po = ppo.PS.scs(ppo.PARTICLE_XGCM, ne, pop["ppe"], C_max=C, sigma=sigma, V=V, pad_strat=pad,
+                    particle_elements=pop["elem"], particle_info=pop["info"])
+    pg = capi.PS.scs(capi.PARTICLE_XGCM, ne, pop["ppe"], C_=C, sigma=sigma, V=V, pad_strat=pad,
+                     particle_elements=pop["elem"], particle_info=pop["info"])
+    lo, lg = po.layout(), pg.layout()
+    for k in ("C", "num_chunks", "num_slices", "capacity", "num_rows"):
+        assert lo[k] == lg[k], k
+    for k in ("offsets", "slice_to_chunk", "row_to_element", "element_to_row", "mask"):
+        assert np.array_equal(lo[k], lg[k]), k
+    so, mo = po.slot_info()
+    assert np.array_equal(so, lg["slot_elem"])
+    cap = lo["capacity"]
+    for m in range(5):
+        a, b = po.member(m)[:, :cap], pg.member(m)[:, :cap]
+        live = mo.astype(bool)
+        assert np.array_equal(a[:, live], b[:, live]), m
+    assert po.metrics() == pg.metrics()
+
+
+def test_csr_layout_matches_oracle(ppo, synth, capi):
+    pop = common.population_2d(synth, num_ptcls=1500)
+    ne = len(pop["e2v"])
+    po = ppo.PS.csr(ppo.PARTICLE_XGCM, ne, pop["ppe"], particle_elements=pop["elem"],
+                    particle_info=pop["info"])
+    pg = capi.PS.csr(capi.PARTICLE_XGCM, ne, pop["ppe"], particle_elements=pop["elem"],
+                     particle_info=pop["info"])
+    assert po.capacity() == pg.capacity() and po.nPtcls() == pg.nPtcls()
+    assert np.array_equal(po.layout()["offsets"], pg.layout()["offsets"])
+    n = po.nPtcls()
+    for m in range(5):
+        assert np.array_equal(po.member(m)[:, :n], pg.member(m)[:, :n])
+
+
+def test_empty_structure(capi, synth):
+    c, e, cl = synth.plate_tri8_pardiag()
+    mesh = capi.Mesh(2, c, e, cl)
+    ps = capi.PS.scs(capi.PARTICLE_XGCM, 8, np.zeros(8, np.int32))
+    assert ps.nPtcls() == 0 and ps.capacity() == 0
+    capi.elliptical_push(ps, mesh, H, K, D, 0.5)
+    found, _ = capi.search_mesh_2d(mesh, ps, looplimit=10)
+    assert found
+
+
+# ---------------------------------------------------------------- pushes
+@pytest.mark.parametrize("kind", ["scs", "csr"])
+def test_elliptical_push_bitwise(ppo, synth, capi, kind):
+    pop = common.population_2d(synth)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM, kind)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM, kind)
+    for _ in range(3):
+        ppo.elliptical_push(po, mo, H, K, D, 0.5, trig=1)
+        capi.elliptical_push(pg, mg, H, K, D, 0.5)
+    cap = po.capacity()
+    _, mask = po.slot_info()
+    live = mask.astype(bool)
+    assert np.array_equal(po.member(1)[:, :cap][:, live], pg.member(1)[:, :cap][:, live])
+    assert np.array_equal(po.member(4)[:, :cap][:, live], pg.member(4)[:, :cap][:, live])
+    # and the shared sincos stays within 1e-15 relative of the literal libm push
+    mo2, po2 = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM, kind)
+    for _ in range(3):
+        ppo.elliptical_push(po2, mo2, H, K, D, 0.5, trig=0)
+    a, b = po.member(1)[:2, :cap][:, live], po2.member(1)[:2, :cap][:, live]
+    assert np.abs(a - b).max() <= 1e-15 * np.abs(b).max() * 4
+
+
+def test_elliptical_setup_float_tolerance(ppo, synth, capi):
+    pop = common.population_2d(synth)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
+    ppo.elliptical_setup(po, H, K, D)
+    capi.elliptical_setup(pg, H, K, D)
+    cap = po.capacity()
+    live = po.slot_info()[1].astype(bool)
+    for m in (3, 4):
+        a, b = po.member(m)[0, :cap][live], pg.member(m)[0, :cap][live]
+        # device atan2/sin are libm-grade (not bit-identical): one float32 ulp
+        assert np.all(np.abs(a - b) <= np.spacing(np.abs(a).astype(np.float32))), m
+
+
+def test_toroidal_linear_update_bitwise(ppo, synth, capi):
+    pop = common.population_3d(synth)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
+    cap = po.capacity()
+    live = po.slot_info()[1].astype(bool)
+    ppo.toroidal_push(po, mo, H, K, D, 2.0, trig=1)
+    capi.toroidal_push(pg, mg, H, K, D, 2.0)
+    assert np.array_equal(po.member(1)[:, :cap][:, live], pg.member(1)[:, :cap][:, live])
+    assert np.array_equal(po.member(4)[:, :cap][:, live], pg.member(4)[:, :cap][:, live])
+    ppo.update_positions(po)
+    capi.update_positions(pg)
+    assert np.array_equal(po.member(0)[:, :cap], pg.member(0)[:, :cap])
+    assert np.array_equal(po.member(1)[:, :cap], pg.member(1)[:, :cap])
+    ppo.linear_push(po, 0.05, -0.5, 0.8, 0.1)
+    capi.linear_push(pg, 0.05, -0.5, 0.8, 0.1)
+    assert np.array_equal(po.member(1)[:, :cap][:, live], pg.member(1)[:, :cap][:, live])
+
+
+def test_boris_bitwise(ppo, capi):
+    rng = np.random.default_rng(3)
+    n = 1000
+    host = [rng.normal(size=n) for _ in range(15)]
+    host[12:] = [h * 1e-6 for h in host[12:]]
+    ref = [h.copy() for h in host]
+    ppo.push_boris(*ref, 1e-9)
+    dev = [capi.DevArray.from_host(h) for h in host]
+    capi.push_boris(dev, 1e-9)
+    for i in range(9):
+        assert np.array_equal(dev[i].to_host(), ref[i]), i
+
+
+def test_pseudo_push160_bitwise(ppo, synth, capi):
+    ne, np_ = 200, 5000
+    ppe, epp = synth.distribute_particles(ne, np_, 2, seed=0)
+    po = ppo.PS.scs(ppo.PERF160, ne, ppe, C_max=64, sigma=ne, V=1024)
+    pg = capi.PS.scs(capi.PERF160, ne, ppe, C_=64, sigma=ne, V=1024)
+    ped = np.sqrt(np.arange(ne, dtype=np.float64)) * np.arange(ne)
+    ppo.pseudo_push160(po, ped)
+    capi.pseudo_push160(pg, capi.DevArray.from_host(ped))
+    cap = po.capacity()
+    for m in range(3):
+        assert np.array_equal(po.member(m)[:, :cap], pg.member(m)[:, :cap], equal_nan=True), m
+
+
+# ---------------------------------------------------------------- searches
+def _pushed_2d(ppo, capi, synth, kind="scs", deg=3.0, steps=1):
+    pop = common.population_2d(synth)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM, kind)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM, kind)
+    for _ in range(steps):
+        ppo.elliptical_push(po, mo, H, K, D, deg, trig=1)
+        capi.elliptical_push(pg, mg, H, K, D, deg)
+    return pop, mo, po, mg, pg
+
+
+@pytest.mark.parametrize("kind", ["scs", "csr"])
+def test_search_mesh_2d_exact(ppo, synth, capi, kind):
+    pop, mo, po, mg, pg = _pushed_2d(ppo, capi, synth, kind, deg=8.0)
+    found_o, ids_o, loops = ppo.search_mesh_2d(mo, po, looplimit=200)
+    found_g, ids_g = capi.search_mesh_2d(mg, pg, looplimit=200)
+    assert found_o == found_g and loops > 1
+    assert np.array_equal(ids_o, ids_g.to_host()[:po.capacity()])
+    live = po.slot_info()[1].astype(bool)
+    assert (ids_o[live] != po.slot_info()[0][live]).mean() > 0.05  # particles really moved
+
+
+def test_search_mesh_2d_looplimit(ppo, synth, capi):
+    pop, mo, po, mg, pg = _pushed_2d(ppo, capi, synth, deg=40.0)
+    found_o, ids_o, _ = ppo.search_mesh_2d(mo, po, looplimit=3)
+    found_g, ids_g = capi.search_mesh_2d(mg, pg, looplimit=3)
+    assert (not found_o) and (not found_g)
+    assert np.array_equal(ids_o, ids_g.to_host()[:po.capacity()])
+
+
+@pytest.mark.parametrize("mt", [False, True])
+def test_search_mesh_tpp_2d_exact(ppo, synth, capi, mt):
+    pop, mo, po, mg, pg = _pushed_2d(ppo, capi, synth, deg=6.0)
+    # tpp search needs x_orig inside the start element: positions are the seeded ones
+    ro = ppo.search_mesh(mo, po, require_intersection=mt, looplimit=500)
+    rg = capi.search_mesh(mg, pg, require_intersection=mt, looplimit=500)
+    cap = po.capacity()
+    assert ro["found"] == rg["found"] and ro["not_in_elem"] == rg["not_in_elem"]
+    assert np.array_equal(ro["elem_ids"], rg["elem_ids"].to_host()[:cap])
+    if mt:
+        assert np.array_equal(ro["inter_faces"], rg["inter_faces"].to_host()[:cap])
+        assert np.array_equal(ro["inter_points"].ravel(), rg["inter_points"].to_host()[:cap * 2])
+        assert (ro["inter_faces"] >= 0).any()
+
+
+@pytest.mark.parametrize("mt", [False, True])
+def test_search_mesh_tpp_3d_exact(ppo, synth, capi, mt):
+    pop = common.population_3d(synth)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
+    ppo.toroidal_push(po, mo, H, K, D, 12.0, trig=1)
+    capi.toroidal_push(pg, mg, H, K, D, 12.0)
+    ro = ppo.search_mesh(mo, po, require_intersection=mt, looplimit=500)
+    rg = capi.search_mesh(mg, pg, require_intersection=mt, looplimit=500)
+    cap = po.capacity()
+    assert ro["found"] == rg["found"] and ro["not_in_elem"] == rg["not_in_elem"] == 0
+    assert np.array_equal(ro["elem_ids"], rg["elem_ids"].to_host()[:cap])
+    live = po.slot_info()[1].astype(bool)
+    assert (ro["elem_ids"][live] != po.slot_info()[0][live]).mean() > 0.05
+    if mt:
+        assert np.array_equal(ro["inter_faces"], rg["inter_faces"].to_host()[:cap])
+        assert np.array_equal(ro["inter_points"].ravel(), rg["inter_points"].to_host()[:cap * 3])
+
+
+def test_search_mesh_tpp_seeded_and_origin_check(ppo, synth, capi):
+    """elem_ids passed in (tpp:516-522) + particles whose origin is not in the seed element are
+    deleted (check_initial_parents, tpp:72-145)."""
+    pop = common.population_3d(synth)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
+    ppo.toroidal_push(po, mo, H, K, D, 5.0, trig=1)
+    capi.toroidal_push(pg, mg, H, K, D, 5.0)
+    slot_e, mask = po.slot_info()
+    seed = slot_e.copy()
+    seed[~mask.astype(bool)] = -1
+    live = np.flatnonzero(mask)
+    seed[live[::7]] = (seed[live[::7]] + 11) % mo.nelems  # wrong parents -> deleted
+    seed[live[::13]] = -1                                   # already-deleted particles stay -1
+    ro = ppo.search_mesh(mo, po, elem_ids=seed.copy(), looplimit=300)
+    rg = capi.search_mesh(mg, pg, elem_ids=capi.DevArray.from_host(seed), looplimit=300)
+    assert ro["not_in_elem"] == rg["not_in_elem"] > 0
+    assert np.array_equal(ro["elem_ids"], rg["elem_ids"].to_host()[:po.capacity()])
+
+
+def test_search_mesh_legacy3d_exact(ppo, synth, capi):
+    """pseudoPushAndSearch loop (test/pseudoPushAndSearch.cpp:513-542): push, legacy search,
+    rebuild.  After a rebuild slot order inside a row is free, so compare by particle id."""
+    pop = common.population_box(synth, n=4, num_ptcls=600)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_PUSH)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_PUSH)
+    hits = 0
+    for step in range(8):
+        ppo.linear_push(po, 1.0 / 20, -0.5, 0.8, 0.0)
+        capi.linear_push(pg, 1.0 / 20, -0.5, 0.8, 0.0)
+        ro = ppo.search_mesh_legacy3d(mo, po, looplimit=100)
+        rg = capi.search_mesh_legacy3d(mg, pg, looplimit=100)
+        assert ro["found"] == rg["found"] == 1
+        capo, capg = po.capacity(), pg.capacity()
+        ids_g = rg["elem_ids"].to_host()[:capg]
+        mko, mkg = po.slot_info()[1], pg.slot_info()[1]
+        pido, pidg = po.member(2)[0, :capo], pg.member(2)[0, :capg]
+        io, eo = common.by_id(pido, mko, ro["elem_ids"])
+        ig, eg = common.by_id(pidg, mkg, ids_g)
+        assert np.array_equal(io, ig) and np.array_equal(eo, eg), step
+        _, fo = common.by_id(pido, mko, ro["xface"])
+        _, fg = common.by_id(pidg, mkg, rg["xface"].to_host()[:capg])
+        assert np.array_equal(fo, fg)
+        _, xo = common.by_id(pido, mko, ro["xpoints"].T)
+        _, xg = common.by_id(pidg, mkg, rg["xpoints"].to_host().reshape(-1, 3)[:capg].T)
+        assert np.array_equal(xo[:, fo >= 0], xg[:, fg >= 0])
+        hits += int((fo >= 0).sum())
+        ppo.update_positions(po)
+        capi.update_positions(pg)
+        po.rebuild(ro["elem_ids"])
+        pg.rebuild(ids_g)
+        assert po.nPtcls() == pg.nPtcls()
+        if po.nPtcls() == 0:
+            break
+    assert hits > 0  # some particles reached the wall
+
+
+# ---------------------------------------------------------------- fused hot path
+@pytest.mark.parametrize("dim", [2, 3])
+def test_fused_push_search_equals_unfused(ppo, synth, capi, dim):
+    pop = common.population_2d(synth) if dim == 2 else common.population_3d(synth)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
+    cap = po.capacity()
+    ids_g = capi.DevArray.from_host(np.full(cap, -1, dtype=np.int32))
+    ids_o = None
+    for step in range(4):
+        if dim == 2:
+            ppo.elliptical_push(po, mo, H, K, D, 4.0, trig=1)
+            _, ids_o, _ = ppo.search_mesh_2d(mo, po, elem_ids=ids_o, looplimit=200)
+            capi.push_search(mg, pg, H, K, D, 4.0, ids_g, seeded=True, looplimit=200)
+        else:
+            ppo.toroidal_push(po, mo, H, K, D, 6.0, trig=1)
+            r = ppo.search_mesh(mo, po, elem_ids=ids_o, looplimit=200)
+            ids_o = r["elem_ids"]
+            capi.push_search(mg, pg, H, K, D, 6.0, ids_g, seeded=(step > 0), looplimit=200)
+        assert np.array_equal(ids_o, ids_g.to_host()[:cap]), step
+        live = po.slot_info()[1].astype(bool)
+        assert np.array_equal(po.member(1)[:, :cap][:, live], pg.member(1)[:, :cap][:, live])
+        assert np.array_equal(po.member(4)[0, :cap][live], pg.member(4)[0, :cap][live])
+        if dim == 3:  # no rebuild: ping-pong x <-> x_tgt like BASELINE config 2
+            a, b = po.member(0), po.member(1)
+            tmp = a.copy()
+            a[:] = b
+            b[:] = tmp
+            pg.swap_members(0, 1)
+
+
+# ---------------------------------------------------------------- scatter
+def test_gyro_maps_and_scatter(ppo, synth, capi):
+    pop = common.population_2d(synth, num_ptcls=4000)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
+    fo, bo = ppo.create_gyro_ring_mappings(mo, 0.038, 3, 8, 0.0, trig=1)
+    fg, bg = capi.create_gyro_ring_mappings(mg, 0.038, 3, 8, 0.0)
+    assert np.array_equal(fo, fg.to_host()) and np.array_equal(bo, bg.to_host())
+    assert (fo >= 0).mean() > 0.8
+    wo = ppo.gyro_scatter(mo, po, fo, 0.038, 3, 8)
+    wg = capi.gyro_scatter(mg, pg, fg, 0.038, 3, 8).to_host()
+    assert wo.sum() > 0
+    assert np.array_equal(wo, wg)  # multiples of 1/8: exact in any order
+    packed = capi.gyro_sync_pack(mg.nverts, capi.DevArray.from_host(wo),
+                                 capi.DevArray.from_host(2 * wo)).to_host()
+    assert np.array_equal(packed[0::2], wo) and np.array_equal(packed[1::2], 2 * wo)
+
+
+def test_gyro_scatter_reference_kat(synth, capi):
+    """test/pseudoXGCm_scatter.cpp:115-178 through the HIP path."""
+    c, e, cl = synth.plate_tri8_pardiag()
+    mesh = capi.Mesh(2, c, e, cl)
+    fwd, _ = capi.create_gyro_ring_mappings(mesh, .2, 2, 6, 15)
+    m = fwd.to_host().reshape(9, 2 * 6 * 3).copy()
+    keep = m[3].copy()
+    m[:] = 2
+    m[3] = keep
+    ppe = np.zeros(8, np.int32)
+    ppe[0] = 1
+    ps = capi.PS.scs(capi.PARTICLE_XGCM, 8, ppe, C_=64, V=32)
+    w = capi.gyro_scatter(mesh, ps, capi.DevArray.from_host(m.reshape(-1)), .2, 2, 6).to_host()
+    for i in range(9):
+        expect = {3: 2.0, 2: 12.0, 8: 0.0}.get(i, 2.0 / 3.0)
+        assert abs(w[i] - expect) <= 1e-12 * max(1.0, expect), (i, w[i])
+
+
+def test_avg_density(ppo, synth, capi):
+    pop = common.population_box(synth, n=3, num_ptcls=400)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_PUSH)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_PUSH)
+    eo, vo = ppo.avg_ptcl_density(mo, po)
+    eg, vg = capi.avg_ptcl_density(mg, pg)
+    assert np.array_equal(eo, eg.to_host()) and np.array_equal(vo, vg.to_host())
+
+
+# ---------------------------------------------------------------- rebuild
+def _check_same_population(po, pg, members):
+    """multiset equality keyed by the particle-id member (member 2)"""
+    so, mo = po.slot_info()
+    sg, mg = pg.slot_info()
+    capo, capg = po.capacity(), pg.capacity()
+    ido, idg = po.member(2)[0, :capo], pg.member(2)[0, :capg]
+    io, eo = common.by_id(ido, mo, so)
+    ig, eg = common.by_id(idg, mg, sg)
+    assert np.array_equal(io, ig)
+    assert np.array_equal(eo, eg)
+    for m in range(len(members)):
+        _, a = common.by_id(ido, mo, po.member(m)[:, :capo])
+        _, b = common.by_id(idg, mg, pg.member(m)[:, :capg])
+        assert np.array_equal(a, b), m
+
+
+@pytest.mark.parametrize("kind,C,V,sigma,pad", [("scs", 64, 1024, 2**31 - 1, 0), ("scs", 8, 4, 16, 1),
+                                                ("scs", 32, 16, 2**31 - 1, 2), ("csr", 0, 0, 0, 0)])
+def test_rebuild_matches_oracle(ppo, synth, capi, kind, C, V, sigma, pad):
+    pop = common.population_2d(synth, num_ptcls=5000)
+    ne = len(pop["e2v"])
+    if kind == "scs":
+        po = ppo.PS.scs(ppo.PARTICLE_XGCM, ne, pop["ppe"], C_max=C, sigma=sigma, V=V, pad_strat=pad,
+                        particle_elements=pop["elem"], particle_info=pop["info"])
+        pg = capi.PS.scs(capi.PARTICLE_XGCM, ne, pop["ppe"], C_=C, sigma=sigma, V=V, pad_strat=pad,
+                         particle_elements=pop["elem"], particle_info=pop["info"])
+        po.set_try_shuffling(False)  # the HIP rebuild is always the full re-layout
+    else:
+        po = ppo.PS.csr(ppo.PARTICLE_XGCM, ne, pop["ppe"], particle_elements=pop["elem"],
+                        particle_info=pop["info"])
+        pg = capi.PS.csr(capi.PARTICLE_XGCM, ne, pop["ppe"], particle_elements=pop["elem"],
+                         particle_info=pop["info"])
+    rng = np.random.default_rng(7)
+    next_id = 5000
+    for it in range(4):
+        so, mo = po.slot_info()
+        sg, mg = pg.slot_info()
+        ido = po.member(2)[0, :po.capacity()]
+        idg = pg.member(2)[0, :pg.capacity()]
+        # per-particle decision keyed by id so both structures apply the same moves
+        dec = rng.integers(0, ne, size=next_id).astype(np.int32)
+        stay = rng.random(next_id) < 0.5
+        dele = rng.random(next_id) < 0.1
+        def new_elems(slot_e, mask, ids):
+            out = np.full(len(slot_e), -1, dtype=np.int32)
+            live = mask.astype(bool)
+            i = ids[live]
+            ne_ = np.where(stay[i], slot_e[live], dec[i])
+            ne_ = np.where(dele[i], -1, ne_)
+            out[live] = ne_
+            return out
+        n_new = 37 if it % 2 == 0 else 0
+        add_e = rng.integers(0, ne, size=n_new).astype(np.int32)
+        add_info = None
+        if n_new:
+            add_info = [rng.random((3, n_new)), rng.random((3, n_new)),
+                        np.arange(next_id, next_id + n_new, dtype=np.int32),
+                        rng.random(n_new).astype(np.float32), rng.random(n_new).astype(np.float32)]
+            next_id += n_new
+        po.rebuild(new_elems(so, mo, ido), add_e if n_new else None, add_info)
+        pg.rebuild(new_elems(sg, mg, idg), add_e if n_new else None, add_info)
+        assert po.nPtcls() == pg.nPtcls()
+        _check_same_population(po, pg, ppo.PARTICLE_XGCM)
+        if kind == "scs":
+            lo, lg = po.layout(), pg.layout()
+            for k in ("C", "num_chunks", "num_slices", "capacity", "num_rows"):
+                assert lo[k] == lg[k], (k, lo[k], lg[k])
+            for k in ("offsets", "slice_to_chunk", "row_to_element", "element_to_row"):
+                assert np.array_equal(lo[k], lg[k]), k
+            # mask: same number of live slots per row (slot order inside a row is free)
+            s1, m1 = po.slot_info()
+            s2, m2 = pg.slot_info()
+            assert np.array_equal(np.bincount(s1[m1 > 0], minlength=ne),
+                                  np.bincount(s2[m2 > 0], minlength=ne))
+        else:
+            assert np.array_equal(po.layout()["offsets"], pg.layout()["offsets"])
+        # getPIDs property (ps_for.hpp:65-85)
+        off, pids = pg.get_pids()
+        se, ms = pg.slot_info()
+        assert np.all(ms[pids] == 1)
+        assert np.array_equal(np.repeat(np.arange(ne), np.diff(off)), se[pids])
+
+
+def test_rebuild_delete_all_then_refill(ppo, synth, capi):
+    pop = common.population_2d(synth, num_ptcls=800)
+    ne = len(pop["e2v"])
+    pg = capi.PS.scs(capi.PARTICLE_XGCM, ne, pop["ppe"], particle_elements=pop["elem"],
+                     particle_info=pop["info"])
+    pg.rebuild(np.full(pg.capacity(), -1, dtype=np.int32))
+    assert pg.nPtcls() == 0
+    n_new = 50
+    info = [np.ones((3, n_new)), np.zeros((3, n_new)), np.arange(n_new, dtype=np.int32),
+            np.ones(n_new, np.float32), np.ones(n_new, np.float32)]
+    pg.rebuild(np.full(max(pg.capacity(), 1), -1, dtype=np.int32), np.arange(n_new) % ne, info)
+    assert pg.nPtcls() == n_new
+    se, ms = pg.slot_info()
+    ids = pg.member(2)[0, :pg.capacity()]
+    i, e = common.by_id(ids, ms, se)
+    assert np.array_equal(i, np.arange(n_new)) and np.array_equal(e, np.arange(n_new) % ne)
+
+
+def test_rebuild_rejects_inactive_new_particles(synth, capi):
+    pop = common.population_2d(synth, num_ptcls=300)
+    ne = len(pop["e2v"])
+    pg = capi.PS.scs(capi.PARTICLE_XGCM, ne, pop["ppe"], particle_elements=pop["elem"],
+                     particle_info=pop["info"])
+    info = [np.ones((3, 1)), np.zeros((3, 1)), np.zeros(1, np.int32), np.ones(1, np.float32),
+            np.ones(1, np.float32)]
+    with pytest.raises(capi.PPError):
+        pg.rebuild(pg.slot_info()[0], np.array([-1]), info)
+
+
+# ---------------------------------------------------------------- end-to-end pseudoXGCm loop
+@pytest.mark.parametrize("kind", ["scs", "csr"])
+def test_pseudo_xgcm_steps_2d(ppo, synth, capi, kind):
+    """push -> search_mesh_2d -> updatePtclPositions -> rebuild -> gyroScatter x2, 15 steps
+    (test/pseudoXGCm.cpp:504-534); element ids by particle id and scatter sums bit-exact."""
+    pop = common.population_2d(synth, num_ptcls=4000)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM, kind)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM, kind)
+    if kind == "scs":
+        po.set_try_shuffling(False)
+    fo, bo = ppo.create_gyro_ring_mappings(mo, trig=1)
+    fg, bg = capi.create_gyro_ring_mappings(mg)
+    for step in range(15):
+        ppo.elliptical_push(po, mo, H, K, D, 2.0, trig=1)
+        _, ids_o, _ = ppo.search_mesh_2d(mo, po, looplimit=200)
+        ids_g = capi.DevArray.from_host(np.full(max(pg.capacity(), 1), -1, dtype=np.int32))
+        capi.push_search(mg, pg, H, K, D, 2.0, ids_g, seeded=True, looplimit=200)
+        so, mko = po.slot_info()
+        sg, mkg = pg.slot_info()
+        io, eo = common.by_id(po.member(2)[0, :po.capacity()], mko, ids_o)
+        ig, eg = common.by_id(pg.member(2)[0, :pg.capacity()], mkg, ids_g.to_host()[:pg.capacity()])
+        assert np.array_equal(io, ig) and np.array_equal(eo, eg), step
+        ppo.update_positions(po)
+        capi.update_positions(pg)
+        po.rebuild(ids_o)
+        pg.rebuild(ids_g)
+        assert po.nPtcls() == pg.nPtcls() > 0
+        wo = ppo.gyro_scatter(mo, po, fo)
+        wg = capi.gyro_scatter(mg, pg, fg).to_host()
+        assert np.array_equal(wo, wg), step
+    _check_same_population(po, pg, ppo.PARTICLE_XGCM)
+
+
+# ---------------------------------------------------------------- migration glue
+def test_unsafe_procs_and_pack(ppo, synth, capi):
+    pop = common.population_2d(synth, num_ptcls=3000)
+    ne = len(pop["e2v"])
+    gids = np.arange(ne, dtype=np.int64) * 3 + 5
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    pg = capi.PS.scs(capi.PARTICLE_XGCM, ne, pop["ppe"], gids=gids, particle_elements=pop["elem"],
+                     particle_info=pop["info"])
+    nranks, rank = 4, 1
+    owners = (np.arange(ne) * nranks // ne).astype(np.int32)
+    safe = (owners == rank).astype(np.uint8)
+    se, mk = pg.slot_info()
+    rng = np.random.default_rng(11)
+    elems = np.where(mk > 0, rng.integers(0, ne, size=len(se)), -1).astype(np.int32)
+    ne_o, np_o = ppo.set_unsafe_procs(po, elems, safe, owners, rank)
+    ne_g, np_g = capi.set_unsafe_procs(pg, capi.DevArray.from_host(elems),
+                                       capi.DevArray.from_host(safe),
+                                       capi.DevArray.from_host(owners), rank)
+    cap = pg.capacity()
+    assert np.array_equal(ne_o, ne_g.to_host()[:cap]) and np.array_equal(np_o, np_g.to_host()[:cap])
+    counts = capi.migrate_count(pg, ne_g, np_g, rank, nranks)
+    live = mk > 0
+    expect = np.bincount(np_o[live & (np_o != rank)], minlength=nranks)
+    assert np.array_equal(counts, expect) and counts[rank] == 0 and counts.sum() > 0
+    ids_before = pg.member(2)[0, :cap].copy()
+    x_before = pg.member(0)[:, :cap].copy()
+    gid, bufs = capi.migrate_pack(pg, ne_g, np_g, rank, nranks, counts)
+    total = int(counts.sum())
+    sent_ids = bufs[2].to_host()[:total]
+    sent_gid = gid.to_host()[:total]
+    sent_x = bufs[0].to_host()[:3 * total].reshape(3, total)
+    start = np.concatenate([[0], np.cumsum(counts)])
+    slot_of = {int(i): s for s, i in enumerate(ids_before) if live[s]}
+    for r in range(nranks):
+        seg = slice(start[r], start[r + 1])
+        for i, g, x in zip(sent_ids[seg], sent_gid[seg], sent_x[:, seg].T):
+            s = slot_of[int(i)]
+            assert np_o[s] == r and g == gids[ne_o[s]] and np.array_equal(x, x_before[:, s])
+    after = ne_g.to_host()[:cap]
+    assert np.all(after[live & (np_o != rank)] == -1)
+    assert np.array_equal(after[live & (np_o == rank)], ne_o[live & (np_o == rank)])
