@@ -42,9 +42,9 @@ BYTES = {
 }
 
 
-def build_workload(pp, capi, name, nptcl, rank, world, deg):
+def build_workload(pp, capi, name, nptcl, rank, world, deg, remainder="last"):
     synth = pp.synth
-    if name == "2d":
+    if name in ("2d", "2dc3"):
         coords, e2v, cls = synth.annulus_tri()
         dim, mdl = 2, 12
         label = "pseudoXGCm 2-D literal: 100352-tri annulus"
@@ -56,11 +56,24 @@ def build_workload(pp, capi, name, nptcl, rank, world, deg):
     # element-block ownership: rank r owns elements [r*ne/world, (r+1)*ne/world)
     lo, hi = rank * ne // world, (rank + 1) * ne // world
     cls_own = np.where((np.arange(ne) >= lo) & (np.arange(ne) < hi), cls, 1 << 20)
-    ppe = synth.xgcm_source_counts(cls_own, nptcl, mdl, seed=synth.ELEMENT_SEED + rank)
-    elem, xyz = synth.particles_in_elements(coords, e2v, ppe, seed=synth.PARTICLE_SEED + rank)
-    R = np.hypot(xyz[0], xyz[1]) if dim == 3 else xyz[0]
-    Z = xyz[2] if dim == 3 else xyz[1]
-    b, phi = synth.elliptical_state(R, Z)
+    # the synthetic population is a pure function of (mesh, n, rank, world): memoise it on disk so
+    # repeated profiler passes on one box do not regenerate 10 M particles every time
+    cache = os.path.join(os.environ.get("PP_BENCH_CACHE", "/tmp"),
+                         "pp_pop_%dd_%d_%d_%d_%s.npz" % (dim, nptcl, rank, world, remainder))
+    if os.path.exists(cache):
+        z = np.load(cache)
+        ppe, elem, xyz, b, phi = z["ppe"], z["elem"], z["xyz"], z["b"], z["phi"]
+    else:
+        ppe = synth.xgcm_source_counts(cls_own, nptcl, mdl, seed=synth.ELEMENT_SEED + rank,
+                                       remainder=remainder)
+        elem, xyz = synth.particles_in_elements(coords, e2v, ppe, seed=synth.PARTICLE_SEED + rank)
+        R = np.hypot(xyz[0], xyz[1]) if dim == 3 else xyz[0]
+        Z = xyz[2] if dim == 3 else xyz[1]
+        b, phi = synth.elliptical_state(R, Z)
+        try:
+            np.savez(cache, ppe=ppe, elem=elem, xyz=xyz, b=b, phi=phi)
+        except OSError:
+            pass
     info = [xyz, np.zeros_like(xyz), np.arange(nptcl, dtype=np.int32), b, phi]
     mesh = capi.Mesh(dim, coords, e2v, cls)
     ps = capi.PS.scs(capi.PARTICLE_XGCM, ne, ppe, C_=64, sigma=2**31 - 1, V=1024, pad_strat=0,
@@ -160,6 +173,9 @@ def main():
     ap.add_argument("--deg", type=float, default=0.5, help="degrees per push (testing.cmake:117)")
     ap.add_argument("--cpu-sample", type=int, default=300_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--remainder", default="last", choices=["last", "spread"],
+                    help="where particles left over by the Gaussian draws go: 'last' = literal "
+                         "pseudoXGCm rule (one outlier element), 'spread' = evenly")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -177,7 +193,7 @@ def main():
     from pumipic_amd import capi
     capi.init(local_rank)  # raises when the HIP library / GPU is missing: no CPU fallback
 
-    w = build_workload(pp, capi, a.workload, a.particles, rank, world, a.deg)
+    w = build_workload(pp, capi, a.workload, a.particles, rank, world, a.deg, a.remainder)
     st = Stepper(pp, capi, w, a.workload, a.deg)
 
     def barrier():
@@ -230,7 +246,7 @@ def main():
                 "parallelism": "element-block partition, %d rank(s), full-mesh replica" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
-                         "kernel": "k_push_walk<%d>" % w["dim"], "kernel_ms": kms,
+                         "kernel": "k_push_walk_rows<%d>" % w["dim"], "kernel_ms": kms,
                          "bytes_per_particle": bpp},
         }
         if not a.no_cpu_baseline and world == 1:

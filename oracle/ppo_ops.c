@@ -112,7 +112,7 @@ void ppo_elliptical_push(ppo_ps* ps, const ppo_mesh* mesh, int m_xtgt, int m_b, 
  * in the particle's local (R,Z) half-plane, plus a rigid rotation of that half-plane about the
  * Z axis by the same class-scaled angle.  The toroidal direction is taken from the CURRENT
  * position (x,y)/hypot so no atan2 is needed and every op is IEEE-exact apart from the shared
- * sincos: x_tgt = R'*(ux*c - uy*s, ux*s + uy*c), z_tgt = Z'. */
+ * sincos: x_tgt = (R'/hypot(x0,y0)) * (x0*c - y0*s, x0*s + y0*c), z_tgt = Z'. */
 void ppo_toroidal_push(ppo_ps* ps, const ppo_mesh* mesh, int m_x, int m_xtgt, int m_b, int m_phi,
                        double h, double k, double d, double deg, int trigmode) {
   slots s = get_slots(ps);
@@ -136,9 +136,9 @@ void ppo_toroidal_push(ppo_ps* ps, const ppo_mesh* mesh, int m_x, int m_xtgt, in
     const double x0 = MD(ps, m_x)[pid];
     const double y0 = MD(ps, m_x)[A + pid];
     const double r0 = sqrt(x0 * x0 + y0 * y0);
-    const double ux = x0 / r0, uy = y0 / r0;
-    MD(ps, m_xtgt)[pid] = Rn * (ux * ct - uy * st);
-    MD(ps, m_xtgt)[A + pid] = Rn * (ux * st + uy * ct);
+    const double sc = Rn / r0;
+    MD(ps, m_xtgt)[pid] = sc * (x0 * ct - y0 * st);
+    MD(ps, m_xtgt)[A + pid] = sc * (x0 * st + y0 * ct);
     MD(ps, m_xtgt)[2 * A + pid] = Zn;
     MF(ps, m_phi)[pid] = (float)rad;
   }

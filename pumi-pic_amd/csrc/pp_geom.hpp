@@ -67,13 +67,11 @@ PPD int face_map(int i) {                                      // utils.hpp:489-
 constexpr double kEpsilon = 1e-10;  // src/pumipic_constants.hpp:6
 
 // Omega_h are_close(a, 0, tol, tol) || a > 0   (utils.hpp:82)
+// are_close's relative difference for b == 0 is |a|/|a|: exactly 1.0 for every finite non-zero a
+// and NaN for +-inf / NaN, so the quotient is never formed: (|a|/|a| <= tol) == (finite && 1 <= tol)
 PPD bool gtez(double a, double tol) {
   const double am = fabs(a);
-  bool close;
-  if (am <= tol)
-    close = true;
-  else
-    close = (fabs(0.0 - a) / am) <= tol;  // rel diff == 1 unless NaN
+  const bool close = (am <= tol) || (am < __builtin_inf() && 1.0 <= tol);
   return close || a > 0;
 }
 PPD bool all_positive3(const double* a, double tol) {

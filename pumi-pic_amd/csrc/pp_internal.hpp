@@ -92,6 +92,7 @@ struct DevBuf {
 };
 
 constexpr int kBlock = 256;
+constexpr int kTileP = 8;  // particles per row handled by one thread of the row-tiled kernels
 inline unsigned grid_for(size_t n, int block = kBlock) {
   return (unsigned)((n + (size_t)block - 1) / (size_t)block);
 }
@@ -120,6 +121,7 @@ static_assert(sizeof(pp_tet_rec) == 128, "tet record must be 128 B");
 struct pp_mesh {
   int dim = 0, nverts = 0, nelems = 0, nsides = 0;
   double tol = 0;  // compute_tolerance_from_area
+  double unmoved_sq = 0;  // min{s : sqrt(s) >= tol}: norm(v) < tol  <=>  v.v < unmoved_sq
   // host copies (setup + to_host queries)
   std::vector<double> coords, elem_measure;
   std::vector<int> elem2verts, class_id, elem2sides, side2verts, side2elems_off, side2elems,
@@ -148,7 +150,12 @@ struct pp_ps {
   pp::DevBuf d_gids;  // element -> gid (num_elems)
   // layout (device)
   pp::DevBuf d_offsets, d_slice_to_chunk, d_row_to_element, d_element_to_row, d_mask, d_slot_elem;
+  // SCS row tiles for the row-major hot kernels: tile = (chunk, first p), kTileP columns wide.
+  // A chunk's slots are contiguous: slot = chunk_start[c] + row_in_chunk + p*C, p < chunk_width[c]
+  pp::DevBuf d_chunk_start, d_chunk_width, d_tiles, d_ntiles;
+  int ntiles_max = 0;
+  int tile_p = pp::kTileP;  // columns per tile (PP_TILE_P overrides, tuning knob)
   // scratch reused across rebuilds
   pp::DevBuf s_ppe, s_keys, s_keys2, s_vals, s_vals2, s_hist, s_chunkw, s_misc, s_rowstart,
-      s_newidx, s_offsets2, s_s2c2, s_r2e2, s_e2r2, s_mask2, s_slot2, s_scan;
+      s_newidx, s_offsets2, s_s2c2, s_r2e2, s_e2r2, s_mask2, s_slot2, s_scan, s_cstart2, s_cwidth2;
 };

@@ -144,6 +144,11 @@ int derive(pp_mesh& m) {
   }
   const double t = 1e-15 / min_area;  // adjacency.tpp:425
   m.tol = (t < 1e-8) ? 1e-8 : t;
+  // threshold on the SQUARED length equivalent to `sqrt(s) < tol` (sqrt is monotone, IEEE-exact)
+  double s2 = m.tol * m.tol;
+  while (std::sqrt(std::nextafter(s2, 0.0)) >= m.tol) s2 = std::nextafter(s2, 0.0);
+  while (std::sqrt(s2) < m.tol) s2 = std::nextafter(s2, std::numeric_limits<double>::infinity());
+  m.unmoved_sq = s2;
   return PP_OK;
 }
 

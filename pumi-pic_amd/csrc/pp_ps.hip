@@ -433,6 +433,22 @@ __global__ void k_init_slots(int nchunks, int C, const int* __restrict__ widths,
   }
 }
 
+__global__ void k_tile_count(int nchunks, int TP, const int* __restrict__ widths,
+                             int* __restrict__ ntl) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < nchunks) ntl[c] = (widths[c] + TP - 1) / TP;
+}
+__global__ void k_tile_fill(int nchunks, int TP, const int* __restrict__ widths,
+                            const int* __restrict__ tile_off, int* __restrict__ tiles) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nchunks) return;
+  const int n = (widths[c] + TP - 1) / TP, o = tile_off[c];
+  for (int j = 0; j < n; ++j) {
+    tiles[2 * (o + j)] = c;
+    tiles[2 * (o + j) + 1] = j * TP;
+  }
+}
+
 struct MoveArgs {
   int nmembers;
   const void* src[8];
@@ -565,7 +581,22 @@ int finish_layout_upload(pp_ps* ps, const HostLayout& L, const std::vector<int>&
       }
     }
   (void)ppe;
+  // row tiles (chunk, first p) of kTileP columns for the row-major hot kernels
+  std::vector<int> tiles;
+  if (getenv("PP_TILE_P")) ps->tile_p = std::max(1, atoi(getenv("PP_TILE_P")));
+  for (int c = 0; c < L.nchunks; ++c)
+    for (int p0 = 0; p0 < L.chunk_widths[c]; p0 += ps->tile_p) {
+      tiles.push_back(c);
+      tiles.push_back(p0);
+    }
+  const int ntiles = (int)(tiles.size() / 2);
+  ps->ntiles_max = ntiles;
+  std::vector<int> ntl(1, ntiles);
   int rc;
+  if ((rc = upload_vec(ps->d_tiles, tiles))) return rc;
+  if ((rc = upload_vec(ps->d_ntiles, ntl))) return rc;
+  if ((rc = upload_vec(ps->d_chunk_start, L.chunk_start))) return rc;
+  if ((rc = upload_vec(ps->d_chunk_width, L.chunk_widths))) return rc;
   if ((rc = upload_vec(ps->d_offsets, L.offsets))) return rc;
   if ((rc = upload_vec(ps->d_slice_to_chunk, L.slice_to_chunk))) return rc;
   if ((rc = upload_vec(ps->d_row_to_element, L.row_to_element))) return rc;
@@ -660,11 +691,15 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   }
   // ---- chunk widths, padding, offsets
   PP_HIP_CHECK(ps->s_chunkw.reserve(sizeof(int) * (size_t)nchunks * 5 + 64));
-  int* widths = ps->s_chunkw.as<int>();
-  int* nsl = widths + nchunks;
+  PP_HIP_CHECK(ps->s_cwidth2.reserve(sizeof(int) * (size_t)nchunks));
+  PP_HIP_CHECK(ps->s_cstart2.reserve(sizeof(int) * (size_t)nchunks));
+  int* widths = ps->s_cwidth2.as<int>();
+  int* nsl = ps->s_chunkw.as<int>();
   int* nslots = nsl + nchunks;
   int* slice_off = nslots + nchunks;
-  int* chunk_start = slice_off + nchunks;
+  int* tile_cnt = slice_off + nchunks;
+  int* tile_off = tile_cnt + nchunks;
+  int* chunk_start = ps->s_cstart2.as<int>();
   k_chunk_widths<<<grid_for((size_t)nchunks * 64), kBlock, 0, st>>>(nchunks, C_new, ne, keys, base,
                                                                      sorted ? 1 : 0, ppe, widths, tot);
   if (ps->shuffle_padding > 0) {
@@ -675,6 +710,9 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   k_slices_and_slots<<<grid_for(nchunks), kBlock, 0, st>>>(nchunks, C_new, ps->V, widths, nsl, nslots);
   k_scan_excl<<<1, 1024, 0, st>>>(nchunks, nsl, slice_off, &tot->nslices);
   k_scan_excl<<<1, 1024, 0, st>>>(nchunks, nslots, chunk_start, &tot->capacity);
+  k_tile_count<<<grid_for(nchunks), kBlock, 0, st>>>(nchunks, ps->tile_p, widths, tile_cnt);
+  PP_HIP_CHECK(ps->d_ntiles.reserve(sizeof(int)));
+  k_scan_excl<<<1, 1024, 0, st>>>(nchunks, tile_cnt, tile_off, ps->d_ntiles.as<int>());
   PP_LAUNCH_CHECK();
   PP_HIP_CHECK(hipMemcpyAsync(&h, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
   PP_HIP_CHECK(hipStreamSynchronize(st));  // sync #2
@@ -687,6 +725,11 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   PP_HIP_CHECK(ps->s_mask2.reserve((size_t)std::max(new_capacity, 1)));
   PP_HIP_CHECK(ps->s_slot2.reserve(sizeof(int) * (size_t)std::max(new_capacity, 1)));
   PP_HIP_CHECK(ps->s_rowstart.reserve(sizeof(int) * (size_t)nrows));
+  // sum_c ceil(w_c/TP) <= nchunks + capacity/(C*TP): no extra host sync for the tile count
+  const int ntiles_max = nchunks + new_capacity / (C_new * ps->tile_p) + 1;
+  PP_HIP_CHECK(ps->d_tiles.reserve(sizeof(int) * 2 * (size_t)ntiles_max));
+  k_tile_fill<<<grid_for(nchunks), kBlock, 0, st>>>(nchunks, ps->tile_p, widths, tile_off,
+                                                    ps->d_tiles.as<int>());
   k_fill_slices<<<grid_for(std::max(nchunks, 1)), kBlock, 0, st>>>(
       nchunks, C_new, ps->V, widths, slice_off, chunk_start, ps->s_offsets2.as<int>(),
       ps->s_s2c2.as<int>(), tot);
@@ -730,6 +773,9 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   ps->d_element_to_row.swap(ps->s_e2r2);
   ps->d_mask.swap(ps->s_mask2);
   ps->d_slot_elem.swap(ps->s_slot2);
+  ps->d_chunk_start.swap(ps->s_cstart2);
+  ps->d_chunk_width.swap(ps->s_cwidth2);
+  ps->ntiles_max = ntiles_max;
   ps->C = C_new;
   ps->num_ptcls = h.active;
   ps->num_chunks = nchunks;

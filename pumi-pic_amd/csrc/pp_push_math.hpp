@@ -25,7 +25,8 @@ PPD void elliptical_advance(int cls, float phi, float b, double h, double k, dou
 
 // 3-D tokamak restatement: the same advance in the local (R,Z) half-plane, then a
 // rigid rotation of that half-plane about the Z axis by the same class-scaled angle.  The
-// toroidal direction comes from the current position (x0,y0)/hypot -- no atan2.
+// toroidal direction comes from the current position (x0,y0) -- no atan2:
+// x_tgt = (R'/hypot(x0,y0)) * Rot(dphi) (x0,y0).
 PPD void toroidal_advance(int cls, float phi, float b, double x0, double y0, double h, double k,
                           double d, double deg, double& tx, double& ty, double& tz, double& rad) {
   const double centerFactor = cls == 1 ? 0.01 : 1.0;
@@ -40,9 +41,51 @@ PPD void toroidal_advance(int cls, float phi, float b, double x0, double y0, dou
   const double Rn = a * cs + h;
   const double Zn = b * sn + k;
   const double r0 = sqrt(x0 * x0 + y0 * y0);
-  const double ux = x0 / r0, uy = y0 / r0;
-  tx = Rn * (ux * ct - uy * st);
-  ty = Rn * (ux * st + uy * ct);
+  const double sc = Rn / r0;  // radial scale; (x0,y0) rotated by the class angle
+  tx = sc * (x0 * ct - y0 * st);
+  ty = sc * (x0 * st + y0 * ct);
+  tz = Zn;
+}
+
+// ---- row-hoisted forms used by the row-tiled kernel: everything that depends only on the parent
+// element's class is evaluated once per row; the expression trees (and therefore the bits) are
+// the same as in elliptical_advance / toroidal_advance above.
+struct ClassTerm {
+  double dphi;    // degP * pi / 180
+  double st, ct;  // sincos_det(dphi) (3-D only)
+};
+PPD ClassTerm class_term(int cls, double deg, bool need_trig) {
+  ClassTerm t;
+  const double centerFactor = cls == 1 ? 0.01 : 1.0;
+  const double distByClass = centerFactor * (double)1.0 / cls;
+  const double degP = deg * distByClass;
+  t.dphi = degP * kPi / 180.0;
+  t.st = 0;
+  t.ct = 1;
+  if (need_trig) ppg::sincos_det(t.dphi, t.st, t.ct);
+  return t;
+}
+PPD void elliptical_point(const ClassTerm& t, float phi, float b, double h, double k, double d,
+                          double& x, double& y, double& rad) {
+  const double a = b * d;
+  rad = phi + t.dphi;
+  double sn, cs;
+  ppg::sincos_det(rad, sn, cs);
+  x = a * cs + h;
+  y = b * sn + k;
+}
+PPD void toroidal_point(const ClassTerm& t, float phi, float b, double x0, double y0, double h,
+                        double k, double d, double& tx, double& ty, double& tz, double& rad) {
+  const double a = b * d;
+  rad = phi + t.dphi;
+  double sn, cs;
+  ppg::sincos_det(rad, sn, cs);
+  const double Rn = a * cs + h;
+  const double Zn = b * sn + k;
+  const double r0 = sqrt(x0 * x0 + y0 * y0);
+  const double sc = Rn / r0;
+  tx = sc * (x0 * t.ct - y0 * t.st);
+  ty = sc * (x0 * t.st + y0 * t.ct);
   tz = Zn;
 }
 

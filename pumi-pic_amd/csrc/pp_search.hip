@@ -491,6 +491,266 @@ __global__ void k_push_walk(int capacity, const unsigned char* __restrict__ mask
   }
 }
 
+// ------------------------------------------------------------------ row-tiled fused kernel (SCS)
+// Thread = (tile, row): it walks kTileP consecutive particles of ONE row.  Lanes of a wave are
+// consecutive rows, so every particle load/store is a coalesced 64-slot run (slot = start + r +
+// p*C).  What the flat kernel re-did per particle is hoisted:
+//   * per row  : the parent element's class term and the sincos of the toroidal step;
+//   * per record: particles of a row start in (or next to) the same element, so the last record
+//     read stays in registers together with everything that depends on the element only --
+//     3-D: the four face normals cross(c-a, b-a) and 1/vol (barycentric_tet, tpp:51-67);
+//     2-D: the three edge vectors (l-k) and the area (barycentric_tri, tpp:28-37).
+//   Every value is produced by the same IEEE operations in the same order as the reference
+//   (only common sub-expressions are reused), so bcc signs / arg-mins are bit-identical.
+//   * the next particle's state is loaded before the current one is processed (software
+//     prefetch) so the walk's dependent record loads overlap the streaming loads.
+// 2-D decides `all_positive` and `min3` on the NUMERATORS h_i = cross(l-k,pos-k)/2 whenever that
+// is provably the same decision as on q_i = h_i/area (division by a positive area is monotone;
+// margins of 1e-9 relative are six orders above an ulp); otherwise it falls back to the three
+// divisions.  The outcome is identical to the literal code in every case.
+template <int DIM>
+struct RecCache;
+template <>
+struct RecCache<2> {
+  int id;
+  V2 k[3];   // first vertex of edge i
+  V2 ev[3];  // l - k of edge i
+  double area, lo, hi;  // area ; kEpsilon*area*(1 -/+ 1e-9)
+  int nbr[3];
+};
+template <>
+struct RecCache<3> {
+  int id;
+  V3 a[3];   // M[0], M[1], M[2] (first vertices of faces {0,1},2,3)
+  V3 n[4];   // cross(c-a, b-a) of face f
+  double inv_vol;  // 1/vol, or NaN-free 0 with ok=false
+  bool ok;         // vol > 0
+  int nbr[4];
+};
+__device__ __forceinline__ void build(RecCache<2>& c, const V2 fc[3], int elem) {
+  for (int i = 0; i < 3; ++i) {
+    c.k[i] = fc[tri_edge_vert(i, 0)];
+    c.ev[i] = sub(fc[tri_edge_vert(i, 1)], c.k[i]);
+  }
+  c.area = tri_area(fc);
+  const double T = kEpsilon * c.area;
+  c.lo = T * (1.0 - 1e-9);
+  c.hi = T * (1.0 + 1e-9);
+  c.id = elem;
+}
+__device__ __forceinline__ void build(RecCache<3>& c, const V3 M[4], double vol, int elem) {
+  for (int f = 0; f < 4; ++f) {
+    const V3 a = M[tet_face_vert(f, 0)], b = M[tet_face_vert(f, 1)], cc = M[tet_face_vert(f, 2)];
+    c.n[f] = cross(sub(cc, a), sub(b, a));
+  }
+  c.a[0] = M[0];
+  c.a[1] = M[1];
+  c.a[2] = M[2];
+  c.ok = vol > 0;
+  c.inv_vol = c.ok ? 1.0 / vol : 0.0;
+  c.id = elem;
+}
+__device__ __forceinline__ void fetch(RecCache<2>& c, const void* __restrict__ recs, int elem) {
+  if (c.id == elem) return;
+  V2 fc[3];
+  load_tri((const pp_tri_rec*)recs, elem, fc, c.nbr);
+  build(c, fc, elem);
+}
+__device__ __forceinline__ void fetch(RecCache<3>& c, const void* __restrict__ recs, int elem) {
+  if (c.id == elem) return;
+  V3 M[4];
+  double vol;
+  load_tet((const pp_tet_rec*)recs, elem, M, c.nbr, vol);
+  build(c, M, vol, elem);
+}
+// register-resident select (a dynamic index would push the cached record to scratch)
+__device__ __forceinline__ int sel3(const int* a, int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : a[2]); }
+__device__ __forceinline__ int sel4(const int* a, int i) {
+  return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3]));
+}
+// barycentric_tet on the cached record: bcc[f] = inv_vol * ((pos - a_f) . n_f); -1 when vol <= 0
+__device__ __forceinline__ void bcc_cached(const RecCache<3>& c, V3 pos, double bcc[4]) {
+  const V3 a0 = c.a[0], a1 = c.a[1], a2 = c.a[2];
+  double vals[4];
+  vals[0] = dot(sub(pos, a0), c.n[0]);  // faces {0,2,1},{0,1,3} start at M[0]
+  vals[1] = dot(sub(pos, a0), c.n[1]);
+  vals[2] = dot(sub(pos, a1), c.n[2]);  // {1,2,3}
+  vals[3] = dot(sub(pos, a2), c.n[3]);  // {2,0,3}
+  for (int i = 0; i < 4; ++i) bcc[i] = c.ok ? c.inv_vol * vals[i] : -1.0;
+}
+__device__ __forceinline__ bool step_cached(const RecCache<3>& c, V3 pos, int& next) {
+  double bcc[4];
+  bcc_cached(c, pos, bcc);
+  next = sel4(c.nbr, min_index4(bcc));
+  return all_positive4(bcc, kEpsilon);
+}
+__device__ __forceinline__ bool inside_cached(const RecCache<3>& c, V3 orig, double tol) {
+  double bcc[4];
+  bcc_cached(c, orig, bcc);
+  return all_positive4(bcc, tol);
+}
+// 2-D step: numerators first, exact divisions only when a decision is not provable
+__device__ __forceinline__ bool step_cached(const RecCache<2>& c, V3 pos, int& next) {
+  const V2 p{pos.x, pos.y};
+  double h[3];
+  for (int i = 0; i < 3; ++i) h[i] = cross(c.ev[i], sub(p, c.k[i])) / 2.0;
+  const double A = c.area;
+  // --- provable classification of gtez(h_i / A, kEpsilon)
+  bool sure = A > 0;
+  bool allpos = true;
+  for (int i = 0; i < 3; ++i) {
+    const double m = -h[i];
+    const bool pos_ = h[i] > 0, in_ = m <= c.lo, out_ = m >= c.hi;
+    sure = sure && (pos_ || in_ || out_);
+    allpos = allpos && (pos_ || in_);
+  }
+  // --- provable strict comparisons of the quotients (min3, utils.hpp:88-92)
+  auto lt = [&](double x, double y, bool& ok) {
+    if (x >= y) return false;  // q_x >= q_y by monotonicity
+    const double mx = fmax(fabs(x), fabs(y));
+    ok = ok && ((y - x) > 1e-9 * mx) && (mx > A * 1e-250);
+    return true;
+  };
+  int idx = lt(h[0], h[1], sure) ? 0 : 1;
+  const double hidx = idx == 0 ? h[0] : h[1];
+  idx = lt(hidx, h[2], sure) ? idx : 2;
+  if (!sure) {  // literal path
+    double q[3];
+    for (int i = 0; i < 3; ++i) q[i] = h[i] / A;
+    allpos = all_positive3(q, kEpsilon);
+    idx = min3(q);
+  }
+  next = sel3(c.nbr, idx);
+  return allpos;
+}
+template <int DIM>
+__device__ __forceinline__ int bcc_walk_cached(RecCache<DIM>& c, const void* __restrict__ recs,
+                                               int elem, V3 pos, int looplimit, Counters* cnt) {
+  int loops = 0;
+  const int cap = looplimit ? looplimit : kHardLoopCap;
+  while (true) {
+    fetch(c, recs, elem);
+    int next;
+    bool done = step_cached(c, pos, next);
+    if (!done) {
+      if (next == -1) {
+        elem = -1;
+        done = true;
+      } else {
+        elem = next;
+      }
+    }
+    ++loops;
+    if (done) break;
+    if (loops >= cap) {
+      elem = -1;
+      atomicAdd(&cnt->not_found, 1);
+      break;
+    }
+  }
+  return elem;
+}
+
+struct PState {
+  unsigned char m;
+  float phi, b;
+  double x, y, z;
+  int elem;
+};
+template <int DIM>
+__device__ __forceinline__ PState load_state(int pid, const unsigned char* __restrict__ mask,
+                                             const float* __restrict__ pphi,
+                                             const float* __restrict__ pb,
+                                             const double* __restrict__ x, long long stride,
+                                             const int* __restrict__ elem_ids, bool read_ids) {
+  PState s;
+  s.m = mask[pid];
+  s.phi = pphi[pid];
+  s.b = pb[pid];
+  s.x = s.y = s.z = 0;
+  if (DIM == 3) {
+    s.x = x[pid];
+    s.y = x[stride + pid];
+    s.z = x[2 * stride + pid];
+  }
+  s.elem = read_ids ? elem_ids[pid] : -1;
+  return s;
+}
+
+template <int DIM, int OCC>
+__global__ void __launch_bounds__(256, OCC)
+    k_push_walk_rows(const int* __restrict__ ntiles_dev, int C, int TP,
+                     const int* __restrict__ tiles, const int* __restrict__ chunk_start,
+                     const int* __restrict__ chunk_width, const int* __restrict__ r2e,
+                     const unsigned char* __restrict__ mask, const void* __restrict__ recs,
+                     const int* __restrict__ class_id, int nelems, const double* __restrict__ x,
+                     double* __restrict__ xt, long long stride, const float* __restrict__ pb,
+                     float* pphi, double h, double k, double d, double deg, double tol,
+                     double unmoved_sq, int* elem_ids, int seeded, int looplimit, Counters* cnt) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int tile = (int)(g / C);
+  const int r = (int)(g - (long long)tile * C);
+  if (tile >= *ntiles_dev) return;
+  const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
+  const int start = chunk_start[c] + r;
+  const int pend = min(p0 + TP, chunk_width[c]);
+  const int e = r2e[c * C + r];
+  const ppm::ClassTerm ct = ppm::class_term(e < nelems ? class_id[e] : 1, deg, DIM == 3);
+  const bool read_ids = (DIM == 2) || seeded;
+  RecCache<DIM> cache;
+  cache.id = -1;
+  PState cur = load_state<DIM>(start + p0 * C, mask, pphi, pb, x, stride, elem_ids, read_ids);
+  for (int p = p0; p < pend; ++p) {
+    const int pid = start + p * C;
+    const PState s = cur;
+    if (p + 1 < pend)  // prefetch the next particle of this row before the dependent walk
+      cur = load_state<DIM>(pid + C, mask, pphi, pb, x, stride, elem_ids, read_ids);
+    if (!s.m) {
+      if (DIM == 2 || !seeded) elem_ids[pid] = -1;
+      continue;
+    }
+    double rad;
+    V3 dest;
+    if constexpr (DIM == 2) {
+      int elem = s.elem;
+      ppm::elliptical_point(ct, s.phi, s.b, h, k, d, dest.x, dest.y, rad);
+      dest.z = 0;
+      xt[pid] = dest.x;
+      xt[stride + pid] = dest.y;
+      pphi[pid] = (float)rad;
+      if (elem == -1) elem = e;
+      if (elem == -nelems) {
+        elem_ids[pid] = -1;
+        continue;
+      }
+      elem_ids[pid] = bcc_walk_cached<DIM>(cache, recs, elem, dest, looplimit, cnt);
+    } else {
+      int elem = seeded ? s.elem : e;
+      const V3 orig{s.x, s.y, s.z};
+      ppm::toroidal_point(ct, s.phi, s.b, orig.x, orig.y, h, k, d, dest.x, dest.y, dest.z, rad);
+      xt[pid] = dest.x;
+      xt[stride + pid] = dest.y;
+      xt[2 * stride + pid] = dest.z;
+      pphi[pid] = (float)rad;
+      bool done = (elem == -1);
+      // finishUnmoved: norm(dest-orig) < tol  <=>  |dest-orig|^2 < unmoved_sq (sqrt is monotone and
+      // correctly rounded; unmoved_sq = min{s : sqrt(s) >= tol} is found on the host)
+      const V3 dv = sub(dest, orig);
+      if (dot(dv, dv) < unmoved_sq) done = true;
+      if (!done) {
+        fetch(cache, recs, elem);
+        if (!inside_cached(cache, orig, tol)) {
+          atomicAdd(&cnt->not_in_elem, 1);
+          elem = -1;
+          done = true;
+        }
+      }
+      if (!done) elem = bcc_walk_cached<DIM>(cache, recs, elem, dest, looplimit, cnt);
+      elem_ids[pid] = elem;
+    }
+  }
+}
+
 MeshArrays arrays_of(const pp_mesh* mesh) {
   MeshArrays m;
   m.coords = mesh->d_coords.as<double>();
@@ -677,9 +937,37 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
   if ((rc = reset_counters())) return rc;
   const unsigned grid = grid_for(ps->capacity);
   hipStream_t st = pp::stream();
+  if (mesh->dim == 2)
+    PP_REQUIRE(elem_ids_seeded, "pp_push_search (2-D): elem_ids must be initialised (-1 = own element)");
+  static const bool force_flat = getenv("PP_FLAT_WALK") != nullptr;  // A/B measurement knob
+  if (ps->kind == PP_SCS && !force_flat) {
+    const unsigned rgrid = grid_for((size_t)ps->ntiles_max * ps->C);
+#define PP_ROWS_ARGS                                                                             \
+  ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(), \
+      ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(),                               \
+      ps->d_mask.as<unsigned char>(), mesh->d_records.p, mesh->d_class_id.as<int>(),             \
+      mesh->nelems, PP_MEMBER(ps, m_x, double), PP_MEMBER(ps, m_xtgt, double), ps->stride,       \
+      PP_MEMBER(ps, m_b, float), PP_MEMBER(ps, m_phi, float), h, k, d, deg, mesh->tol,           \
+      mesh->unmoved_sq, elem_ids_dev, elem_ids_seeded, looplimit, g_cnt.get()
+    // OCC = minimum waves per SIMD the register allocator must leave room for (tuning knob;
+    // measured in profiles/): 3-D defaults to 4 (104 VGPRs, no spill)
+    // OCC = waves per SIMD the register allocator must leave room for.  Measured on MI355X
+    // (profiles/r01_*): 3-D is fastest at 4 (104 VGPRs, no spill); 5 spills, 3 hides less latency.
+    static const int occ = getenv("PP_WALK_OCC") ? atoi(getenv("PP_WALK_OCC")) : 4;
+    if (rgrid > 0) {
+      if (mesh->dim == 2)
+        k_push_walk_rows<2, 4><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS);
+      else if (occ <= 3)
+        k_push_walk_rows<3, 3><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS);
+      else if (occ == 4)
+        k_push_walk_rows<3, 4><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS);
+      else
+        k_push_walk_rows<3, 5><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS);
+    }
+#undef PP_ROWS_ARGS
+  } else
   // DIM 2 follows search_mesh_2d: the caller's elem_ids are always read (-1 = own element)
   if (mesh->dim == 2) {
-    PP_REQUIRE(elem_ids_seeded, "pp_push_search (2-D): elem_ids must be initialised (-1 = own element)");
     k_push_walk<2><<<grid, kBlock, 0, st>>>(
         ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), mesh->d_records.p,
         mesh->d_class_id.as<int>(), mesh->nelems, PP_MEMBER(ps, m_x, double),

@@ -130,10 +130,11 @@ def torus_tet(n_b=14, n_theta=75, n_planes=16, h=XGC_H, k=XGC_K, d=XGC_D, b_lo=0
 
 
 # ------------------------------------------------------------------ particle populations
-def xgcm_source_counts(class_id, num_ptcls, mdl_face, seed=ELEMENT_SEED):
+def xgcm_source_counts(class_id, num_ptcls, mdl_face, seed=ELEMENT_SEED, remainder="last"):
     """Particles per element ~ round(Normal(mu, mu/4)) over elements with class_id <= mdl_face in
     element order until the total is reached; remainder into the last touched element
-    (test/pseudoXGCm.cpp:167-222)."""
+    (test/pseudoXGCm.cpp:167-222).  remainder="spread" is a non-literal option that avoids the
+    single outlier element the literal rule creates when the draws fall short of the total."""
     ne = len(class_id)
     marked = np.flatnonzero(class_id <= mdl_face)
     ppe = np.zeros(ne, dtype=np.int32)
@@ -151,7 +152,12 @@ def xgcm_source_counts(class_id, num_ptcls, mdl_face, seed=ELEMENT_SEED):
         last = over
     else:
         last = len(marked) - 1
-        draws[last] += num_ptcls - cum[-1]
+        rem = num_ptcls - cum[-1]
+        if remainder == "last":   # literal: everything into the last touched element (:210-213)
+            draws[last] += rem
+        else:                     # "spread": one extra particle per element, round-robin
+            draws += rem // len(marked)
+            draws[:rem % len(marked)] += 1
     ppe[marked] = draws
     assert ppe.sum() == num_ptcls
     return ppe
