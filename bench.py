@@ -118,8 +118,8 @@ class Stepper:
         if self.name == "c2":
             self.ps.swap_members(0, 1)  # x <-> x_tgt (O(1)); no rebuild in config 2
         elif self.name == "2dc3":
-            capi.update_positions(self.ps)
-            capi.check(capi.lib().pp_ps_rebuild(self.ps.p, self.ids.ptr, 0, None, None))
+            # the drivers' rebuild(): updatePtclPositions + migrate/rebuild (pseudoXGCm.cpp:116-140)
+            self.ps.rebuild_commit(self.ids)
             capi.gyro_scatter(self.mesh, self.ps, self.fwd, out=self.w_f)
             capi.gyro_scatter(self.mesh, self.ps, self.bkwd, out=self.w_b)
             cap = max(self.ps.capacity(), 1)

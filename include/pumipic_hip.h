@@ -145,6 +145,11 @@ int pp_ps_member_from_host(pp_ps* ps, int m, const void* in_host);
  * (the reference's in-place reshuffle fast path is not observable through id-keyed results). */
 int pp_ps_rebuild(pp_ps* ps, const int* new_element_dev, int n_new, const int* new_elems_dev,
                   const void* const* new_info_dev);
+/* updatePtclPositions (test/pseudoXGCm.cpp:102-114: x <- x_tgt, x_tgt <- 0) fused into the
+ * rebuild's single data-movement pass; result-identical to pp_update_positions + pp_ps_rebuild
+ * for every live particle.  This is what the drivers' rebuild() helper does (pseudoXGCm.cpp:116-140) */
+int pp_ps_rebuild_commit(pp_ps* ps, int m_x, int m_xtgt, const int* new_element_dev, int n_new,
+                         const int* new_elems_dev, const void* const* new_info_dev);
 /* getPIDs ps_for.hpp:65-85: offsets_dev[ne+1], pids_dev[nPtcls] */
 int pp_ps_get_pids(const pp_ps* ps, int* offsets_dev, int* pids_dev);
 /* printMetrics SellCSigma.h:465-524 */

@@ -83,6 +83,7 @@ SYMBOLS = {
     "pp_ps_member_to_host": (_I, [_V, _I, _V]),
     "pp_ps_member_from_host": (_I, [_V, _I, _V]),
     "pp_ps_rebuild": (_I, [_V, _V, _I, _V, _V]),
+    "pp_ps_rebuild_commit": (_I, [_V, _I, _I, _V, _I, _V, _V]),
     "pp_ps_get_pids": (_I, [_V, _V, _V]),
     "pp_ps_metrics": (_I, [_V, c_int_p, c_int_p, c_int_p]),
     "pp_ps_swap_members": (_I, [_V, _I, _I]),
@@ -376,6 +377,12 @@ class PS:
         check(lib().pp_ps_rebuild(self.p, ne.ptr, n_new, npe.ptr if npe else None,
                                   C.cast(arr, C.c_void_p) if arr is not None else None))
         sync()
+
+    def rebuild_commit(self, new_element, m_x=0, m_xtgt=1):
+        """updatePtclPositions + rebuild in one pass (no new particles)"""
+        ne = new_element if isinstance(new_element, DevArray) else DevArray.from_host(
+            np.ascontiguousarray(new_element, dtype=np.int32))
+        check(lib().pp_ps_rebuild_commit(self.p, m_x, m_xtgt, ne.ptr, 0, None, None))
 
     def get_pids(self):
         i = self.info()

@@ -183,20 +183,6 @@ struct Totals {  // s_misc layout
   double cw_inv;
 };
 
-__global__ void k_count_new(int capacity, const unsigned char* __restrict__ mask,
-                            const int* __restrict__ new_element, int ne, int* __restrict__ ppe,
-                            Totals* tot) {
-  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pid >= capacity) return;
-  if (!mask[pid]) return;
-  const int e = new_element[pid];
-  if (e == -1) return;
-  if (e < 0 || e >= ne) {
-    tot->invalid = 1;
-    return;
-  }
-  atomicAdd(&ppe[e], 1);
-}
 __global__ void k_count_added(int n_new, const int* __restrict__ new_elems, int ne,
                               int* __restrict__ ppe, Totals* tot) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -208,22 +194,6 @@ __global__ void k_count_added(int n_new, const int* __restrict__ new_elems, int 
   }
   atomicAdd(&ppe[e], 1);
 }
-__global__ void k_sum_ppe(int ne, const int* __restrict__ ppe, Totals* tot) {
-  int a = 0, nz = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ne; i += gridDim.x * blockDim.x) {
-    a += ppe[i];
-    nz += ppe[i] > 0;
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    a += __shfl_down(a, o);
-    nz += __shfl_down(nz, o);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&tot->active, a);
-    atomicAdd(&tot->nonempty, nz);
-  }
-}
-
 // ---- stable LSD radix sort (8-bit digits) of (key64, val32)
 constexpr int RS_TILE = 2048;  // keys per block
 __global__ void k_make_keys(int ne, const int* __restrict__ ppe, int sigma, int n_sigma,
@@ -334,30 +304,6 @@ __global__ void k_scan_excl(int n, const int* __restrict__ in, int* __restrict__
   if (t == 0 && total) *total = carry_s;
 }
 
-// ---- chunk widths: one wave per chunk (C <= 64 rows handled by lanes, larger C looped)
-__global__ void k_chunk_widths(int nchunks, int C, int ne, const unsigned long long* __restrict__ keys,
-                               unsigned long long base, int sorted, const int* __restrict__ ppe,
-                               int* __restrict__ widths, Totals* tot) {
-  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (c >= nchunks) return;
-  int w = 0;
-  for (int r = lane; r < C; r += 64) {
-    const int row = c * C + r;
-    if (row < ne) {
-      const int cnt = sorted ? (int)(keys[row] % base) : ppe[row];
-      w = max(w, cnt);
-    }
-  }
-  for (int o = 32; o > 0; o >>= 1) w = max(w, __shfl_down(w, o));
-  if (lane == 0) {
-    widths[c] = w;
-    if (w > 0) {
-      atomicAdd(&tot->cw_sum, w);
-      atomicAdd(&tot->cw_cnt, 1);
-    }
-  }
-}
 // serial sum of 1/width in chunk order (only PAD_INVERSELY needs it; order-dependent in fp)
 __global__ void k_cw_inv_serial(int nchunks, const int* __restrict__ widths, Totals* tot) {
   if (blockIdx.x || threadIdx.x) return;
@@ -419,34 +365,135 @@ __global__ void k_rows(int nrows, int ne, int sorted, const int* __restrict__ in
     e2r[i] = i;
   }
 }
-// per chunk: slot -> parent element, mask cleared, first slot of each row
-__global__ void k_init_slots(int nchunks, int C, const int* __restrict__ widths,
-                             const int* __restrict__ chunk_start, const int* __restrict__ r2e,
-                             int* __restrict__ slot_elem, unsigned char* __restrict__ mask,
-                             int* __restrict__ row_cursor) {
-  const int c = blockIdx.x;
-  const int n = widths[c] * C, start = chunk_start[c];
-  for (int r = threadIdx.x; r < C; r += blockDim.x) row_cursor[c * C + r] = start + r;
-  for (int j = threadIdx.x; j < n; j += blockDim.x) {
-    slot_elem[start + j] = r2e[c * C + (j % C)];
-    mask[start + j] = 0;
-  }
-}
-
 __global__ void k_tile_count(int nchunks, int TP, const int* __restrict__ widths,
                              int* __restrict__ ntl) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < nchunks) ntl[c] = (widths[c] + TP - 1) / TP;
 }
-__global__ void k_tile_fill(int nchunks, int TP, const int* __restrict__ widths,
-                            const int* __restrict__ tile_off, int* __restrict__ tiles) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= nchunks) return;
-  const int n = (widths[c] + TP - 1) / TP, o = tile_off[c];
-  for (int j = 0; j < n; ++j) {
-    tiles[2 * (o + j)] = c;
-    tiles[2 * (o + j) + 1] = j * TP;
+// ---- row-tiled histogram of new parents (SCS): thread = (old tile, row).  Particles that stay in
+// their element are counted in a register and leave as ONE atomic per thread; only movers issue
+// their own.  Lanes of a wave are different rows, so same-address contention inside a wave is gone.
+__global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
+                              const int* __restrict__ tiles, const int* __restrict__ chunk_start,
+                              const int* __restrict__ chunk_width, const int* __restrict__ r2e,
+                              const unsigned char* __restrict__ mask,
+                              const int* __restrict__ new_element, int ne, int* __restrict__ ppe,
+                              Totals* tot) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int tile = (int)(g / C), r = (int)(g - (long long)tile * C);
+  int live = 0;
+  if (tile < *ntiles_dev) {
+    const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
+    const int start = chunk_start[c] + r, pend = min(p0 + TP, chunk_width[c]);
+    const int e = r2e[c * C + r];
+    int stay = 0;
+    for (int p = p0; p < pend; ++p) {
+      const int pid = start + p * C;
+      if (!mask[pid]) continue;
+      const int ne_ = new_element[pid];
+      if (ne_ == -1) continue;
+      if (ne_ < 0 || ne_ >= ne) {
+        tot->invalid = 1;
+        continue;
+      }
+      ++live;
+      if (ne_ == e)
+        ++stay;
+      else
+        atomicAdd(&ppe[ne_], 1);
+    }
+    if (stay) atomicAdd(&ppe[e], stay);
   }
+  for (int o = 32; o > 0; o >>= 1) live += __shfl_down(live, o);
+  if ((threadIdx.x & 63) == 0 && live) atomicAdd(&tot->active, live);
+}
+__global__ void k_nonempty(int ne, const int* __restrict__ ppe, Totals* tot) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int nz = (i < ne && ppe[i] > 0) ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) nz += __shfl_down(nz, o);
+  if ((threadIdx.x & 63) == 0 && nz) atomicAdd(&tot->nonempty, nz);
+}
+__global__ void k_count_added_active(int n_new, Totals* tot) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&tot->active, n_new);
+}
+// single-block reduction of the chunk widths (sum, #non-zero) -- replaces one atomic per chunk
+__global__ void k_reduce_widths(int nchunks, const int* __restrict__ widths, Totals* tot) {
+  __shared__ int ssum[16], scnt[16];
+  int s = 0, c = 0;
+  for (int i = threadIdx.x; i < nchunks; i += blockDim.x) {
+    s += widths[i];
+    c += widths[i] > 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_down(s, o);
+    c += __shfl_down(c, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    ssum[threadIdx.x >> 6] = s;
+    scnt[threadIdx.x >> 6] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int S = 0, Cn = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+      S += ssum[w];
+      Cn += scnt[w];
+    }
+    tot->cw_sum = S;
+    tot->cw_cnt = Cn;
+  }
+}
+__global__ void k_chunk_widths2(int nchunks, int C, int ne, const unsigned long long* __restrict__ keys,
+                                unsigned long long base, int sorted, const int* __restrict__ ppe,
+                                int* __restrict__ widths) {
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (c >= nchunks) return;
+  int w = 0;
+  for (int r = lane; r < C; r += 64) {
+    const int row = c * C + r;
+    if (row < ne) w = max(w, sorted ? (int)(keys[row] % base) : ppe[row]);
+  }
+  for (int o = 32; o > 0; o >>= 1) w = max(w, __shfl_down(w, o));
+  if (lane == 0) widths[c] = w;
+}
+// one thread per tile: owning chunk by binary search in the tile prefix
+__global__ void k_tile_fill2(const int* __restrict__ ntiles_dev, int nchunks, int TP,
+                             const int* __restrict__ tile_off, int* __restrict__ tiles) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= *ntiles_dev) return;
+  int lo = 0, hi = nchunks - 1;  // last chunk with tile_off[c] <= t
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile_off[mid] <= t)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  tiles[2 * t] = lo;
+  tiles[2 * t + 1] = (t - tile_off[lo]) * TP;
+}
+// new layout: slot -> parent element for every slot of every tile, first slot of every row
+__global__ void k_init_slots_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
+                                   const int* __restrict__ tiles, const int* __restrict__ chunk_start,
+                                   const int* __restrict__ chunk_width, const int* __restrict__ r2e,
+                                   int* __restrict__ slot_elem, int* __restrict__ row_cursor) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int tile = (int)(g / C), r = (int)(g - (long long)tile * C);
+  if (tile >= *ntiles_dev) return;
+  const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
+  const int start = chunk_start[c] + r, pend = min(p0 + TP, chunk_width[c]);
+  const int e = r2e[c * C + r];
+  if (p0 == 0) row_cursor[c * C + r] = start;
+  for (int p = p0; p < pend; ++p) slot_elem[start + p * C] = e;
+}
+__global__ void k_rows_cursor_empty(int nchunks, int C, const int* __restrict__ chunk_width,
+                                    const int* __restrict__ chunk_start, int* __restrict__ row_cursor) {
+  // rows of zero-width chunks own no tile: give them a defined cursor
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nchunks * C) return;
+  const int c = i / C;
+  if (chunk_width[c] == 0) row_cursor[i] = chunk_start[c] + i % C;
 }
 
 struct MoveArgs {
@@ -456,14 +503,21 @@ struct MoveArgs {
   int bytes[8];
   int ncomp[8];
   long long src_stride, dst_stride;
+  // fused updatePtclPositions (test/pseudoXGCm.cpp:102-114): member commit_x takes the values of
+  // member commit_xt, member commit_xt is written as zeros.  -1 = plain copy.
+  int commit_x, commit_xt;
 };
 __device__ __forceinline__ void copy_members(const MoveArgs& a, long long from, long long to) {
   for (int m = 0; m < a.nmembers; ++m) {
     const int nc = a.ncomp[m];
     if (a.bytes[m] == 8) {
-      const unsigned long long* s = (const unsigned long long*)a.src[m];
+      const unsigned long long* s =
+          (const unsigned long long*)(m == a.commit_x ? a.src[a.commit_xt] : a.src[m]);
       unsigned long long* d = (unsigned long long*)a.dst[m];
-      for (int c = 0; c < nc; ++c) d[c * a.dst_stride + to] = s[c * a.src_stride + from];
+      if (m == a.commit_xt)
+        for (int c = 0; c < nc; ++c) d[c * a.dst_stride + to] = 0ull;
+      else
+        for (int c = 0; c < nc; ++c) d[c * a.dst_stride + to] = s[c * a.src_stride + from];
     } else if (a.bytes[m] == 4) {
       const unsigned* s = (const unsigned*)a.src[m];
       unsigned* d = (unsigned*)a.dst[m];
@@ -479,21 +533,7 @@ __device__ __forceinline__ void copy_members(const MoveArgs& a, long long from, 
     }
   }
 }
-// SCS: every live particle takes the next free slot of its new row (copySCS + CopyPSToPS fused,
-// SCS_rebuild.h:251-270 + psMemberType.h:72-112)
-__global__ void k_move_scs(int capacity, const unsigned char* __restrict__ mask,
-                           const int* __restrict__ new_element, const int* __restrict__ e2r_new,
-                           int C_new, int* __restrict__ row_cursor,
-                           unsigned char* __restrict__ new_mask, MoveArgs a) {
-  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pid >= capacity) return;
-  if (!mask[pid]) return;
-  const int e = new_element[pid];
-  if (e == -1) return;
-  const int idx = atomicAdd(&row_cursor[e2r_new[e]], C_new);
-  new_mask[idx] = 1;
-  copy_members(a, pid, idx);
-}
+// new particles (set_new_particle + CopyViewsToViews, SCS_rebuild.h:277-289)
 __global__ void k_add_scs(int n_new, const int* __restrict__ new_elems,
                           const int* __restrict__ e2r_new, int C_new, int* __restrict__ row_cursor,
                           unsigned char* __restrict__ new_mask, MoveArgs a) {
@@ -502,6 +542,162 @@ __global__ void k_add_scs(int n_new, const int* __restrict__ new_elems,
   const int idx = atomicAdd(&row_cursor[e2r_new[new_elems[i]]], C_new);
   new_mask[idx] = 1;
   copy_members(a, i, idx);
+}
+// Row-tiled move (SCS): thread = (old tile, row).  Stayers of the thread reserve their slots in the
+// new row with ONE atomic (n_stay * C) and are written in a second sweep; movers take slots one
+// by one.  Reads are coalesced 64-slot runs; every member of a particle moves in this one pass.
+__global__ void k_move_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
+                             const int* __restrict__ tiles, const int* __restrict__ chunk_start,
+                             const int* __restrict__ chunk_width, const int* __restrict__ r2e,
+                             const unsigned char* __restrict__ mask,
+                             const int* __restrict__ new_element, const int* __restrict__ e2r_new,
+                             int C_new, int* __restrict__ row_cursor,
+                             unsigned char* __restrict__ new_mask, MoveArgs a) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int tile = (int)(g / C), r = (int)(g - (long long)tile * C);
+  if (tile >= *ntiles_dev) return;
+  const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
+  const int start = chunk_start[c] + r, pend = min(p0 + TP, chunk_width[c]);
+  const int e = r2e[c * C + r];
+  unsigned stay = 0;  // TP <= 32
+  for (int p = p0; p < pend; ++p) {
+    const int pid = start + p * C;
+    if (!mask[pid]) continue;
+    const int ne_ = new_element[pid];
+    if (ne_ == -1) continue;
+    if (ne_ == e) {
+      stay |= 1u << (p - p0);
+    } else {
+      const int idx = atomicAdd(&row_cursor[e2r_new[ne_]], C_new);
+      new_mask[idx] = 1;
+      copy_members(a, pid, idx);
+    }
+  }
+  if (stay) {
+    int idx = atomicAdd(&row_cursor[e2r_new[e]], __popc(stay) * C_new);
+    for (int p = p0; p < pend; ++p)
+      if (stay & (1u << (p - p0))) {
+        new_mask[idx] = 1;
+        copy_members(a, start + p * C, idx);
+        idx += C_new;
+      }
+  }
+}
+// ---- AoS-staged move (SCS).  The row order of a Sell-C-sigma structure is a function of the
+// per-element counts, so after a rebuild adjacent old rows land in unrelated new rows: writing
+// the members straight into the new SoA scatters 4/8-byte stores over as many cache lines
+// (measured 1.6 ms for 10 M particles, ~8x write amplification).  Instead
+//   pass 1  reads the old SoA coalesced, packs each particle into ONE 16-byte-aligned record and
+//           writes it to aos[new_slot] (whole 32/64-B sectors per particle);
+//   pass 2  walks the NEW layout, reads aos[slot] contiguously and writes the new SoA coalesced.
+// Word table: record word w of slot pid lives at src[w] + pid*sscale[w] (sscale < 0: constant 0,
+// used for the fused updatePtclPositions), and goes to dst[w] + slot*dscale[w].
+constexpr int kMaxWords = 64;
+struct WordTable {
+  int nwords;  // 32-bit words per record (padded to a multiple of 4)
+  const char* src[kMaxWords];
+  char* dst[kMaxWords];
+  int sscale[kMaxWords];
+  int dscale[kMaxWords];
+};
+// pass 1a: slot assignment only (atomics), destination index per old slot (-1 = not moved)
+__global__ void k_assign_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
+                               const int* __restrict__ tiles, const int* __restrict__ chunk_start,
+                               const int* __restrict__ chunk_width, const int* __restrict__ r2e,
+                               const unsigned char* __restrict__ mask,
+                               const int* __restrict__ new_element, const int* __restrict__ e2r_new,
+                               int C_new, int* __restrict__ row_cursor,
+                               unsigned char* __restrict__ new_mask, int* __restrict__ new_idx) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int tile = (int)(g / C), r = (int)(g - (long long)tile * C);
+  if (tile >= *ntiles_dev) return;
+  const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
+  const int start = chunk_start[c] + r, pend = min(p0 + TP, chunk_width[c]);
+  const int e = r2e[c * C + r];
+  unsigned stay = 0;
+  for (int p = p0; p < pend; ++p) {
+    const int pid = start + p * C;
+    int idx = -1;
+    if (mask[pid]) {
+      const int ne_ = new_element[pid];
+      if (ne_ == e)
+        stay |= 1u << (p - p0);
+      else if (ne_ != -1) {
+        idx = atomicAdd(&row_cursor[e2r_new[ne_]], C_new);
+        new_mask[idx] = 1;
+      }
+    }
+    new_idx[pid] = idx;
+  }
+  if (stay) {
+    int idx = atomicAdd(&row_cursor[e2r_new[e]], __popc(stay) * C_new);
+    for (int p = p0; p < pend; ++p)
+      if (stay & (1u << (p - p0))) {
+        new_mask[idx] = 1;
+        new_idx[start + p * C] = idx;
+        idx += C_new;
+      }
+  }
+}
+// pass 1b: one thread per old slot packs its record; the wave transposes through LDS so that
+// NQ adjacent lanes store one whole record (full 64-B sectors leave the CU already merged:
+// 0.21 vs 0.27 ms per 10 M random records, tools/ub_scatter.hip)
+template <int NQ>
+__global__ void k_move_pack(int capacity, const int* __restrict__ new_idx,
+                            uint4* __restrict__ aos, WordTable t) {
+  __shared__ uint4 st[4][64][NQ + 1];
+  __shared__ int sd[4][64];
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int idx = (pid < capacity) ? new_idx[pid] : -1;
+  if (idx >= 0) {
+    unsigned v[NQ * 4];
+#pragma unroll
+    for (int i = 0; i < NQ * 4; ++i)
+      v[i] = (i < t.nwords && t.sscale[i] >= 0)
+                 ? *(const unsigned*)(t.src[i] + (long long)pid * t.sscale[i])
+                 : 0u;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) st[w][l][q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+  }
+  sd[w][l] = idx;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int item = j * 64 + l, rec = item / NQ, part = item % NQ;
+    const int d = sd[w][rec];
+    if (d >= 0) aos[(long long)d * NQ + part] = st[w][rec][part];
+  }
+}
+template <int NQ>
+__global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
+                              const int* __restrict__ tiles, const int* __restrict__ chunk_start,
+                              const int* __restrict__ chunk_width,
+                              const unsigned char* __restrict__ new_mask,
+                              const uint4* __restrict__ aos, WordTable t) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int tile = (int)(g / C), r = (int)(g - (long long)tile * C);
+  if (tile >= *ntiles_dev) return;
+  const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
+  const int start = chunk_start[c] + r, pend = min(p0 + TP, chunk_width[c]);
+  for (int p = p0; p < pend; ++p) {
+    const int slot = start + p * C;
+    if (!new_mask[slot]) continue;
+    const uint4* sp = aos + (long long)slot * NQ;
+    unsigned w[NQ * 4];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const uint4 v = sp[q];
+      w[4 * q] = v.x;
+      w[4 * q + 1] = v.y;
+      w[4 * q + 2] = v.z;
+      w[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < NQ * 4; ++i)
+      if (i < t.nwords) *(unsigned*)(t.dst[i] + (long long)slot * t.dscale[i]) = w[i];
+  }
 }
 // CSR counting sort (CSR_rebuild.hpp:62-108)
 __global__ void k_move_csr(int nold, const int* __restrict__ new_element, int* __restrict__ cursor,
@@ -619,47 +815,32 @@ MoveArgs make_move(const pp_ps* ps, const std::vector<pp::DevBuf>& src, int64_t 
   }
   a.src_stride = src_stride;
   a.dst_stride = dst_stride;
+  a.commit_x = a.commit_xt = -1;
   return a;
 }
 
-int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_elems,
-                const void* const* new_info) {
+// One attempt of the device re-layout for a given chunk height.  Enqueues everything up to (and
+// including) the D2H read of the totals; the caller synchronises once.
+struct LayoutPlan {
+  int C, nchunks, nrows;
+  bool sorted;
+  unsigned long long base;
+  unsigned long long* keys;
+  int* index;
+  int *widths, *nsl, *nslots, *slice_off, *tile_cnt, *tile_off, *chunk_start;
+};
+
+int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_base, LayoutPlan& L) {
   hipStream_t st = pp::stream();
   const int ne = ps->num_elems;
-  PP_HIP_CHECK(ps->s_ppe.reserve(sizeof(int) * (size_t)std::max(ne, 1)));
-  PP_HIP_CHECK(ps->s_misc.reserve(sizeof(Totals)));
-  PP_HIP_CHECK(hipMemsetAsync(ps->s_ppe.p, 0, sizeof(int) * (size_t)std::max(ne, 1), st));
-  PP_HIP_CHECK(hipMemsetAsync(ps->s_misc.p, 0, sizeof(Totals), st));
-  Totals* tot = ps->s_misc.as<Totals>();
-  int* ppe = ps->s_ppe.as<int>();
-  if (ps->capacity > 0 && ps->num_ptcls > 0)
-    k_count_new<<<grid_for(ps->capacity), kBlock, 0, st>>>(
-        ps->capacity, ps->d_mask.as<unsigned char>(), new_element, ne, ppe, tot);
-  if (n_new > 0) k_count_added<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ne, ppe, tot);
-  if (ne > 0) k_sum_ppe<<<std::min(grid_for(ne), 256u), kBlock, 0, st>>>(ne, ppe, tot);
-  PP_LAUNCH_CHECK();
-  Totals h{};
-  PP_HIP_CHECK(hipMemcpyAsync(&h, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
-  PP_HIP_CHECK(hipStreamSynchronize(st));  // sync #1
-  if (h.invalid) {
-    pp::set_error(
-        "rebuild: a particle's new element is out of range, or a new particle is marked inactive "
-        "(element id -1) -- the reference exits here (SCS_rebuild.h:147-151)");
-    return PP_EINVAL;
-  }
-  if (h.active == 0) {  // SCS_rebuild.h:168-182 (mask left untouched like the reference)
-    ps->num_ptcls = 0;
-    return PP_OK;
-  }
-  const int C_new = (h.nonempty == 0) ? 1 : std::min(h.nonempty, ps->C_max);
-  const int nchunks = ne / C_new + (ne % C_new != 0);
-  const int nrows = nchunks * C_new;
-  // ---- sort elements by (window, count)
-  const bool sorted = ps->sigma > 1 && ne > 1;
-  const unsigned long long base = (unsigned long long)h.active + 1ull;
-  unsigned long long* keys = nullptr;
-  int* index = nullptr;
-  if (sorted) {
+  L.C = C_new;
+  L.nchunks = ne / C_new + (ne % C_new != 0);
+  L.nrows = L.nchunks * C_new;
+  L.sorted = ps->sigma > 1 && ne > 1;
+  L.base = (unsigned long long)key_base;
+  L.keys = nullptr;
+  L.index = nullptr;
+  if (L.sorted) {
     const int sg = std::min(ps->sigma, std::max(ne, 1));
     const int n_sigma = ne / sg;
     PP_HIP_CHECK(ps->s_keys.reserve(sizeof(unsigned long long) * (size_t)ne));
@@ -668,10 +849,10 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     PP_HIP_CHECK(ps->s_vals2.reserve(sizeof(int) * (size_t)ne));
     const int nblk = (ne + RS_TILE - 1) / RS_TILE;
     PP_HIP_CHECK(ps->s_hist.reserve(sizeof(int) * 256 * (size_t)nblk * 2));
-    k_make_keys<<<grid_for(ne), kBlock, 0, st>>>(ne, ppe, sg, n_sigma, base,
+    k_make_keys<<<grid_for(ne), kBlock, 0, st>>>(ne, ppe, sg, n_sigma, L.base,
                                                  ps->s_keys.as<unsigned long long>(),
                                                  ps->s_vals.as<int>());
-    unsigned long long maxkey = (unsigned long long)(n_sigma > 0 ? n_sigma : 1) * base;
+    unsigned long long maxkey = (unsigned long long)(n_sigma > 0 ? n_sigma : 1) * L.base;
     int bits = 0;
     while (bits < 64 && (maxkey >> bits)) ++bits;
     unsigned long long *ka = ps->s_keys.as<unsigned long long>(),
@@ -686,36 +867,95 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       std::swap(ka, kb);
       std::swap(va, vb);
     }
-    keys = ka;
-    index = va;
+    L.keys = ka;
+    L.index = va;
   }
-  // ---- chunk widths, padding, offsets
+  const int nchunks = L.nchunks;
   PP_HIP_CHECK(ps->s_chunkw.reserve(sizeof(int) * (size_t)nchunks * 5 + 64));
   PP_HIP_CHECK(ps->s_cwidth2.reserve(sizeof(int) * (size_t)nchunks));
   PP_HIP_CHECK(ps->s_cstart2.reserve(sizeof(int) * (size_t)nchunks));
-  int* widths = ps->s_cwidth2.as<int>();
-  int* nsl = ps->s_chunkw.as<int>();
-  int* nslots = nsl + nchunks;
-  int* slice_off = nslots + nchunks;
-  int* tile_cnt = slice_off + nchunks;
-  int* tile_off = tile_cnt + nchunks;
-  int* chunk_start = ps->s_cstart2.as<int>();
-  k_chunk_widths<<<grid_for((size_t)nchunks * 64), kBlock, 0, st>>>(nchunks, C_new, ne, keys, base,
-                                                                     sorted ? 1 : 0, ppe, widths, tot);
+  L.widths = ps->s_cwidth2.as<int>();
+  L.nsl = ps->s_chunkw.as<int>();
+  L.nslots = L.nsl + nchunks;
+  L.slice_off = L.nslots + nchunks;
+  L.tile_cnt = L.slice_off + nchunks;
+  L.tile_off = L.tile_cnt + nchunks;
+  L.chunk_start = ps->s_cstart2.as<int>();
+  k_chunk_widths2<<<grid_for((size_t)nchunks * 64), kBlock, 0, st>>>(
+      nchunks, C_new, ne, L.keys, L.base, L.sorted ? 1 : 0, ppe, L.widths);
   if (ps->shuffle_padding > 0) {
-    if (ps->pad_strat == PP_PAD_INVERSELY) k_cw_inv_serial<<<1, 64, 0, st>>>(nchunks, widths, tot);
+    k_reduce_widths<<<1, 1024, 0, st>>>(nchunks, L.widths, tot);
+    if (ps->pad_strat == PP_PAD_INVERSELY) k_cw_inv_serial<<<1, 64, 0, st>>>(nchunks, L.widths, tot);
     k_apply_padding<<<grid_for(nchunks), kBlock, 0, st>>>(nchunks, ps->pad_strat,
-                                                          ps->shuffle_padding, widths, tot);
+                                                          ps->shuffle_padding, L.widths, tot);
   }
-  k_slices_and_slots<<<grid_for(nchunks), kBlock, 0, st>>>(nchunks, C_new, ps->V, widths, nsl, nslots);
-  k_scan_excl<<<1, 1024, 0, st>>>(nchunks, nsl, slice_off, &tot->nslices);
-  k_scan_excl<<<1, 1024, 0, st>>>(nchunks, nslots, chunk_start, &tot->capacity);
-  k_tile_count<<<grid_for(nchunks), kBlock, 0, st>>>(nchunks, ps->tile_p, widths, tile_cnt);
-  PP_HIP_CHECK(ps->d_ntiles.reserve(sizeof(int)));
-  k_scan_excl<<<1, 1024, 0, st>>>(nchunks, tile_cnt, tile_off, ps->d_ntiles.as<int>());
+  k_slices_and_slots<<<grid_for(nchunks), kBlock, 0, st>>>(nchunks, C_new, ps->V, L.widths, L.nsl,
+                                                           L.nslots);
+  k_scan_excl<<<1, 1024, 0, st>>>(nchunks, L.nsl, L.slice_off, &tot->nslices);
+  k_scan_excl<<<1, 1024, 0, st>>>(nchunks, L.nslots, L.chunk_start, &tot->capacity);
+  k_tile_count<<<grid_for(nchunks), kBlock, 0, st>>>(nchunks, ps->tile_p, L.widths, L.tile_cnt);
+  PP_HIP_CHECK(ps->s_scan.reserve(sizeof(int)));
+  k_scan_excl<<<1, 1024, 0, st>>>(nchunks, L.tile_cnt, L.tile_off, ps->s_scan.as<int>());
   PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_elems,
+                const void* const* new_info, int commit_x, int commit_xt) {
+  hipStream_t st = pp::stream();
+  const int ne = ps->num_elems;
+  PP_REQUIRE(n_new == 0 || new_info != nullptr, "rebuild: new particles need new_info_dev");
+  PP_HIP_CHECK(ps->s_ppe.reserve(sizeof(int) * (size_t)std::max(ne, 1)));
+  PP_HIP_CHECK(ps->s_misc.reserve(sizeof(Totals)));
+  PP_HIP_CHECK(hipMemsetAsync(ps->s_ppe.p, 0, sizeof(int) * (size_t)std::max(ne, 1), st));
+  PP_HIP_CHECK(hipMemsetAsync(ps->s_misc.p, 0, sizeof(Totals), st));
+  Totals* tot = ps->s_misc.as<Totals>();
+  int* ppe = ps->s_ppe.as<int>();
+  const bool have_old = ps->capacity > 0 && ps->num_ptcls > 0;
+  const unsigned old_grid = grid_for((size_t)ps->ntiles_max * ps->C);
+  if (have_old && old_grid > 0)
+    k_count_tiled<<<old_grid, kBlock, 0, st>>>(
+        ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(),
+        ps->d_chunk_start.as<int>(), ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(),
+        ps->d_mask.as<unsigned char>(), new_element, ne, ppe, tot);
+  if (n_new > 0) {
+    k_count_added<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ne, ppe, tot);
+    k_count_added_active<<<1, 64, 0, st>>>(n_new, tot);
+  }
+  if (ne > 0) k_nonempty<<<grid_for(ne), kBlock, 0, st>>>(ne, ppe, tot);
+  // Sort keys are (window, count) with count < key_base; an upper bound known on the host avoids
+  // a D2H read of the live count before the layout can start.
+  const long long key_base = (long long)(have_old ? ps->num_ptcls : 0) + n_new + 1;
+  LayoutPlan L;
+  int rc = enqueue_layout(ps, ps->C_max, ppe, tot, key_base, L);
+  if (rc) return rc;
+  Totals h{};
   PP_HIP_CHECK(hipMemcpyAsync(&h, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
-  PP_HIP_CHECK(hipStreamSynchronize(st));  // sync #2
+  PP_HIP_CHECK(hipStreamSynchronize(st));  // the only host sync of a regular rebuild
+  if (h.invalid) {
+    pp::set_error(
+        "rebuild: a particle's new element is out of range, or a new particle is marked inactive "
+        "(element id -1) -- the reference exits here (SCS_rebuild.h:147-151)");
+    return PP_EINVAL;
+  }
+  if (h.active == 0) {  // SCS_rebuild.h:168-182 (mask left untouched like the reference)
+    ps->num_ptcls = 0;
+    return PP_OK;
+  }
+  // chooseChunkHeight (SCS_buildFns.h:3-16): C shrinks only when fewer than C_max elements hold
+  // particles -- redo the (tiny) layout with that height
+  const int C_new = std::min(h.nonempty, ps->C_max);
+  if (C_new != ps->C_max) {
+    PP_HIP_CHECK(hipMemsetAsync(&tot->cw_sum, 0, sizeof(int) * 2, st));
+    rc = enqueue_layout(ps, C_new, ppe, tot, key_base, L);
+    if (rc) return rc;
+    const int active = h.active, nonempty = h.nonempty;
+    PP_HIP_CHECK(hipMemcpyAsync(&h, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
+    PP_HIP_CHECK(hipStreamSynchronize(st));
+    h.active = active;
+    h.nonempty = nonempty;
+  }
+  const int nchunks = L.nchunks, nrows = L.nrows;
   const int new_capacity = h.capacity, new_nslices = h.nslices;
   // ---- new layout arrays (double-buffered against the live ones)
   PP_HIP_CHECK(ps->s_offsets2.reserve(sizeof(int) * ((size_t)new_nslices + 1)));
@@ -725,40 +965,94 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   PP_HIP_CHECK(ps->s_mask2.reserve((size_t)std::max(new_capacity, 1)));
   PP_HIP_CHECK(ps->s_slot2.reserve(sizeof(int) * (size_t)std::max(new_capacity, 1)));
   PP_HIP_CHECK(ps->s_rowstart.reserve(sizeof(int) * (size_t)nrows));
-  // sum_c ceil(w_c/TP) <= nchunks + capacity/(C*TP): no extra host sync for the tile count
+  // sum_c ceil(w_c/TP) <= nchunks + capacity/(C*TP): sizes the launch without reading the count
   const int ntiles_max = nchunks + new_capacity / (C_new * ps->tile_p) + 1;
-  PP_HIP_CHECK(ps->d_tiles.reserve(sizeof(int) * 2 * (size_t)ntiles_max));
-  k_tile_fill<<<grid_for(nchunks), kBlock, 0, st>>>(nchunks, ps->tile_p, widths, tile_off,
-                                                    ps->d_tiles.as<int>());
+  PP_HIP_CHECK(ps->s_newidx.reserve(sizeof(int) * 2 * (size_t)ntiles_max));  // new tile table
+  int* new_tiles = ps->s_newidx.as<int>();
+  const int* new_ntiles = ps->s_scan.as<int>();
+  k_tile_fill2<<<grid_for(ntiles_max), kBlock, 0, st>>>(new_ntiles, nchunks, ps->tile_p, L.tile_off,
+                                                        new_tiles);
   k_fill_slices<<<grid_for(std::max(nchunks, 1)), kBlock, 0, st>>>(
-      nchunks, C_new, ps->V, widths, slice_off, chunk_start, ps->s_offsets2.as<int>(),
+      nchunks, C_new, ps->V, L.widths, L.slice_off, L.chunk_start, ps->s_offsets2.as<int>(),
       ps->s_s2c2.as<int>(), tot);
-  k_rows<<<grid_for(nrows), kBlock, 0, st>>>(nrows, ne, sorted ? 1 : 0, index,
+  k_rows<<<grid_for(nrows), kBlock, 0, st>>>(nrows, ne, L.sorted ? 1 : 0, L.index,
                                              ps->s_r2e2.as<int>(), ps->s_e2r2.as<int>());
-  k_init_slots<<<nchunks, kBlock, 0, st>>>(nchunks, C_new, widths, chunk_start,
-                                           ps->s_r2e2.as<int>(), ps->s_slot2.as<int>(),
-                                           ps->s_mask2.as<unsigned char>(),
-                                           ps->s_rowstart.as<int>());
+  PP_HIP_CHECK(hipMemsetAsync(ps->s_mask2.p, 0, (size_t)std::max(new_capacity, 1), st));
+  k_rows_cursor_empty<<<grid_for(nrows), kBlock, 0, st>>>(nchunks, C_new, L.widths, L.chunk_start,
+                                                          ps->s_rowstart.as<int>());
+  k_init_slots_tiled<<<grid_for((size_t)ntiles_max * C_new), kBlock, 0, st>>>(
+      new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_r2e2.as<int>(),
+      ps->s_slot2.as<int>(), ps->s_rowstart.as<int>());
   // ---- swap buffer sizing (SCS_rebuild.h:223-229)
   int64_t swap_stride = ps->swap_stride;
   if (swap_stride < new_capacity || swap_stride * ps->minimize_size < new_capacity) {
     swap_stride = (int64_t)(new_capacity * (1 + ps->extra_padding));
     if (swap_stride < new_capacity) swap_stride = new_capacity;
   }
-  int rc = alloc_members(ps, ps->swap, swap_stride, false);
+  rc = alloc_members(ps, ps->swap, swap_stride, false);
   if (rc) return rc;
   ps->swap_stride = swap_stride;
-  // ---- move everything in one pass
+  // ---- move every member of every live particle
   MoveArgs mv = make_move(ps, ps->data, ps->stride, ps->swap, swap_stride);
-  if (ps->capacity > 0 && ps->num_ptcls > 0)
-    k_move_scs<<<grid_for(ps->capacity), kBlock, 0, st>>>(
-        ps->capacity, ps->d_mask.as<unsigned char>(), new_element, ps->s_e2r2.as<int>(), C_new,
+  mv.commit_x = commit_x;
+  mv.commit_xt = commit_xt;
+  // record = all members as 32-bit words (fast path needs 4/8-byte scalars and <= 64 words)
+  WordTable wt{};
+  bool staged = have_old && old_grid > 0 && getenv("PP_DIRECT_MOVE") == nullptr;
+  int nw = 0;
+  for (int m = 0; m < ps->nmembers && staged; ++m) {
+    const int b = ps->member_bytes[m];
+    if (b != 4 && b != 8) staged = false;
+    for (int cc = 0; cc < ps->member_ncomp[m] && staged; ++cc)
+      for (int hw = 0; hw < b / 4; ++hw) {
+        if (nw >= kMaxWords) {
+          staged = false;
+          break;
+        }
+        const int sm = (m == commit_x) ? commit_xt : m;  // fused updatePtclPositions
+        wt.src[nw] = (const char*)ps->data[sm].p + ((size_t)cc * ps->stride) * b + hw * 4;
+        wt.sscale[nw] = (m == commit_xt) ? -1 : b;
+        wt.dst[nw] = (char*)ps->swap[m].p + ((size_t)cc * swap_stride) * b + hw * 4;
+        wt.dscale[nw] = b;
+        ++nw;
+      }
+  }
+  const int NQ = (nw + 3) / 4;
+  wt.nwords = nw;
+  if (staged && (NQ == 4 || NQ == 10 || NQ <= 3 || NQ == 6 || NQ == 8)) {
+    PP_HIP_CHECK(ps->s_aos.reserve((size_t)std::max(new_capacity, 1) * NQ * 16));
+    uint4* aos = ps->s_aos.as<uint4>();
+    const unsigned new_grid = grid_for((size_t)ntiles_max * C_new);
+#define PP_UNPACK_ARGS \
+  new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_mask2.as<unsigned char>(), aos, wt
+#define PP_STAGED(N)                                                                  \
+  case N:                                                                             \
+    k_move_pack<N><<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, new_idx, aos, wt); \
+    k_move_unpack<N><<<new_grid, kBlock, 0, st>>>(PP_UNPACK_ARGS);                    \
+    break;
+    PP_HIP_CHECK(ps->s_idx.reserve(sizeof(int) * (size_t)ps->capacity));
+    int* new_idx = ps->s_idx.as<int>();
+    k_assign_tiled<<<old_grid, kBlock, 0, st>>>(
+        ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(),
+        ps->d_chunk_start.as<int>(), ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(),
+        ps->d_mask.as<unsigned char>(), new_element, ps->s_e2r2.as<int>(), C_new,
+        ps->s_rowstart.as<int>(), ps->s_mask2.as<unsigned char>(), new_idx);
+    switch (NQ) {
+      PP_STAGED(1) PP_STAGED(2) PP_STAGED(3) PP_STAGED(4) PP_STAGED(6) PP_STAGED(8) PP_STAGED(10)
+    }
+#undef PP_STAGED
+#undef PP_UNPACK_ARGS
+  } else if (have_old && old_grid > 0)
+    k_move_tiled<<<old_grid, kBlock, 0, st>>>(
+        ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(),
+        ps->d_chunk_start.as<int>(), ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(),
+        ps->d_mask.as<unsigned char>(), new_element, ps->s_e2r2.as<int>(), C_new,
         ps->s_rowstart.as<int>(), ps->s_mask2.as<unsigned char>(), mv);
   if (n_new > 0) {
     MoveArgs add = mv;
-    for (int m = 0; m < ps->nmembers; ++m) add.src[m] = new_info ? new_info[m] : nullptr;
+    for (int m = 0; m < ps->nmembers; ++m) add.src[m] = new_info[m];
     add.src_stride = n_new;
-    PP_REQUIRE(new_info != nullptr, "rebuild: new particles need new_info_dev");
+    add.commit_x = add.commit_xt = -1;  // new particles arrive with their own positions
     k_add_scs<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ps->s_e2r2.as<int>(), C_new,
                                                   ps->s_rowstart.as<int>(),
                                                   ps->s_mask2.as<unsigned char>(), add);
@@ -775,6 +1069,10 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   ps->d_slot_elem.swap(ps->s_slot2);
   ps->d_chunk_start.swap(ps->s_cstart2);
   ps->d_chunk_width.swap(ps->s_cwidth2);
+  ps->d_tiles.swap(ps->s_newidx);
+  ps->d_ntiles.swap(ps->s_scan);
+  ps->d_elem_count.swap(ps->s_ppe);  // live particles per element == the histogram just built
+  ps->elem_count_valid = true;
   ps->ntiles_max = ntiles_max;
   ps->C = C_new;
   ps->num_ptcls = h.active;
@@ -902,6 +1200,10 @@ pp_ps* pp_ps_create_scs(int C, int sigma, int V, int num_elems, int num_ptcls,
     ok = ps->d_gids.reserve(sizeof(int64_t) * (size_t)num_elems) == hipSuccess &&
          hipMemcpy(ps->d_gids.p, gids_host, sizeof(int64_t) * (size_t)num_elems,
                    hipMemcpyHostToDevice) == hipSuccess;
+  }
+  if (ok) {
+    ok = upload_vec(ps->d_elem_count, ppe) == PP_OK && hipStreamSynchronize(pp::stream()) == hipSuccess;
+    ps->elem_count_valid = ok;
   }
   if (ok && num_ptcls > 0 && particle_elements_host && particle_info_host) {
     // initSCSData (SCS_buildFns.h:205-232) in particle order
@@ -1106,8 +1408,34 @@ int pp_ps_rebuild(pp_ps* ps, const int* new_element_dev, int n_new, const int* n
       std::iota(ps->member_map.begin(), ps->member_map.end(), 0);
       break;
     }
-  if (ps->kind == PP_SCS) return scs_rebuild(ps, new_element_dev, n_new, new_elems_dev, new_info_dev);
+  if (ps->kind == PP_SCS)
+    return scs_rebuild(ps, new_element_dev, n_new, new_elems_dev, new_info_dev, -1, -1);
+  ps->elem_count_valid = false;
   return csr_rebuild(ps, new_element_dev, n_new, new_elems_dev, new_info_dev);
+}
+
+int pp_ps_rebuild_commit(pp_ps* ps, int m_x, int m_xtgt, const int* new_element_dev, int n_new,
+                         const int* new_elems_dev, const void* const* new_info_dev) {
+  PP_REQUIRE(ps, "pp_ps_rebuild_commit: null ps");
+  PP_REQUIRE(m_x >= 0 && m_xtgt >= 0 && m_x < ps->nmembers && m_xtgt < ps->nmembers && m_x != m_xtgt,
+             "pp_ps_rebuild_commit: bad member index");
+  if (ps->kind != PP_SCS) {  // CSR: the two reference steps back to back
+    int rc = pp_update_positions(ps, m_x, m_xtgt);
+    if (rc) return rc;
+    return pp_ps_rebuild(ps, new_element_dev, n_new, new_elems_dev, new_info_dev);
+  }
+  // normalise a pending pp_ps_swap_members permutation, then fuse the commit into the move
+  if (ps->member_map[m_x] != m_x || ps->member_map[m_xtgt] != m_xtgt) {
+    std::vector<pp::DevBuf> tmp((size_t)ps->nmembers);
+    for (int q = 0; q < ps->nmembers; ++q) tmp[q].swap(ps->data[ps->member_map[q]]);
+    for (int q = 0; q < ps->nmembers; ++q) ps->data[q].swap(tmp[q]);
+    std::iota(ps->member_map.begin(), ps->member_map.end(), 0);
+  }
+  PP_REQUIRE(ps->member_bytes[m_x] == 8 && ps->member_bytes[m_xtgt] == 8 &&
+                 ps->member_ncomp[m_x] == ps->member_ncomp[m_xtgt],
+             "pp_ps_rebuild_commit: x and x_tgt must be double members of equal shape");
+  PP_REQUIRE(new_element_dev || ps->capacity == 0, "pp_ps_rebuild_commit: null new_element");
+  return scs_rebuild(ps, new_element_dev, n_new, new_elems_dev, new_info_dev, m_x, m_xtgt);
 }
 
 int pp_ps_get_pids(const pp_ps* ps, int* offsets_dev, int* pids_dev) {

@@ -460,6 +460,31 @@ def test_rebuild_matches_oracle(ppo, synth, capi, kind, C, V, sigma, pad):
         assert np.array_equal(np.repeat(np.arange(ne), np.diff(off)), se[pids])
 
 
+def test_rebuild_commit_equals_update_then_rebuild(ppo, synth, capi):
+    """pp_ps_rebuild_commit == updatePtclPositions + rebuild (pseudoXGCm.cpp:116-140), including
+    after an O(1) member swap."""
+    pop = common.population_2d(synth, num_ptcls=4000)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
+    po.set_try_shuffling(False)
+    for step in range(3):
+        ppo.elliptical_push(po, mo, H, K, D, 3.0, trig=1)
+        _, ids_o, _ = ppo.search_mesh_2d(mo, po, looplimit=200)
+        ids_g = capi.DevArray.from_host(np.full(max(pg.capacity(), 1), -1, dtype=np.int32))
+        capi.push_search(mg, pg, H, K, D, 3.0, ids_g, seeded=True, looplimit=200)
+        ppo.update_positions(po)
+        po.rebuild(ids_o)
+        if step == 1:  # exercise the permutation normalisation
+            pg.swap_members(0, 1)
+            pg.swap_members(0, 1)
+        pg.rebuild_commit(ids_g)
+        capi.sync()
+        assert po.nPtcls() == pg.nPtcls()
+        _check_same_population(po, pg, ppo.PARTICLE_XGCM)
+        assert np.array_equal(ppo.gyro_scatter(mo, po, ppo.create_gyro_ring_mappings(mo, trig=1)[0]),
+                              capi.gyro_scatter(mg, pg, capi.create_gyro_ring_mappings(mg)[0]).to_host())
+
+
 def test_rebuild_delete_all_then_refill(ppo, synth, capi):
     pop = common.population_2d(synth, num_ptcls=800)
     ne = len(pop["e2v"])
