@@ -1,0 +1,406 @@
+// particle_structs.hpp -- C++ host mirror of PUMI-PIC's particle_structs operator API over the
+// C-ABI of libpumipic_hip.so (include/pumipic_hip.h).  Header-only; compile user code with hipcc.
+//
+// Mirrors (names, argument meaning, error behaviour):
+//   MemberTypes / MemberTypeAtIndex      particle_structs/src/support/MemberTypes.h:24-73
+//   Segment<T>  seg(pid) / seg(pid,i)    particle_structs/src/support/Segment.h:29-98
+//   ParticleStructure<DataTypes>         particle_structs/src/particle_structure.hpp:63-104
+//   SellCSigma, SCS_Input                particle_structs/src/scs/SellCSigma.h:52-141, scs_input.hpp:27-36
+//   CSR, CSR_Input                       particle_structs/src/csr/CSR.hpp:37-69, CSR_input.hpp
+//   ps::parallel_for(ps, lambda, name)   particle_structs/src/ps_for.hpp:5-31
+//   createMemberViews/getMemberView/destroyViews  support/MemberTypeLibraries.h:33-41
+//   PS_LAMBDA, lid_t, gid_t              support/ppMacros.h:3-13, support/ppTypes.h:5-30
+// Kokkos::View<T*> is replaced by pumipic::View<T> (device array with shared ownership); a
+// Kokkos::TeamPolicy argument is replaced by pumipic::TeamPolicy{league, team} whose team size
+// is the chunk height C (64 = one CDNA wavefront).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <string>
+#include <type_traits>
+#include <vector>
+#include "../../include/pumipic_hip.h"
+
+#define PS_LAMBDA [=] __host__ __device__
+#define PP_INLINE __host__ __device__ inline
+#define PP_DEVICE __device__ inline
+
+namespace pumipic {
+
+typedef int lid_t;
+typedef long int gid_t;
+
+inline void pp_check(int rc, const char* what) {
+  if (rc != PP_OK) {  // the reference aborts on unrecoverable errors (ppAssert.cpp:10-13)
+    fprintf(stderr, "%s failed: %s\n", what, pp_last_error());
+    exit(EXIT_FAILURE);
+  }
+}
+
+// ---------------------------------------------------------------- device array (Kokkos::View<T*>)
+template <class T>
+class View {
+ public:
+  typedef T value_type;
+  View() : p_(nullptr), n_(0) {}
+  explicit View(size_t n) { alloc(n, true); }
+  View(const std::string&, size_t n) { alloc(n, true); }
+  View(size_t n, T init) {  // Omega_h::Write<T>(n, value)
+    alloc(n, false);
+    std::vector<T> h(n, init);
+    if (n) pp_check(pp_memcpy_h2d(p_, h.data(), n * sizeof(T)), "View fill");
+  }
+  static View wrap(T* dev, size_t n) {  // non-owning
+    View v;
+    v.p_ = dev;
+    v.n_ = n;
+    return v;
+  }
+  PP_INLINE T& operator()(size_t i) const { return p_[i]; }
+  PP_INLINE T& operator[](size_t i) const { return p_[i]; }
+  PP_INLINE size_t size() const { return n_; }
+  PP_INLINE T* data() const { return p_; }
+  std::vector<T> to_host() const {
+    std::vector<T> h(n_);
+    if (n_) pp_check(pp_memcpy_d2h(h.data(), p_, n_ * sizeof(T)), "View d2h");
+    return h;
+  }
+  void from_host(const T* h) {
+    if (n_) pp_check(pp_memcpy_h2d(p_, h, n_ * sizeof(T)), "View h2d");
+  }
+
+ private:
+  void alloc(size_t n, bool zero) {
+    n_ = n;
+    p_ = (T*)pp_malloc(n * sizeof(T));
+    if (!p_) pp_check(PP_EHIP, "View allocation");
+    own_ = std::shared_ptr<void>((void*)p_, [](void* q) { (void)pp_free(q); });
+    if (zero && n) {
+      pp_check(pp_memset(p_, 0, n * sizeof(T)), "View memset");
+      pp_check(pp_sync(), "View memset sync");
+    }
+  }
+  T* p_;
+  size_t n_;
+  std::shared_ptr<void> own_;
+};
+
+// ---------------------------------------------------------------- member type lists
+template <typename... Types>
+struct MemberTypes;
+template <>
+struct MemberTypes<> {
+  static constexpr std::size_t size = 0;
+};
+template <typename H, typename... T>
+struct MemberTypes<H, T...> {
+  static constexpr std::size_t size = 1 + MemberTypes<T...>::size;
+};
+template <std::size_t N, typename... Types>
+struct MemberTypeAtIndexImpl;
+template <typename T, typename... Types>
+struct MemberTypeAtIndexImpl<0, T, Types...> {
+  using type = T;
+};
+template <std::size_t N, typename T, typename... Types>
+struct MemberTypeAtIndexImpl<N, T, Types...> {
+  using type = typename MemberTypeAtIndexImpl<N - 1, Types...>::type;
+};
+template <std::size_t N, typename DataTypes>
+struct MemberTypeAtIndex;
+template <std::size_t N, typename... Types>
+struct MemberTypeAtIndex<N, MemberTypes<Types...>> {
+  using type = typename MemberTypeAtIndexImpl<N, Types...>::type;
+};
+template <class T>
+struct BaseType {
+  using type = T;
+  static constexpr int size = 1;
+};
+template <class T, std::size_t N>
+struct BaseType<T[N]> {
+  using type = typename BaseType<T>::type;
+  static constexpr int size = (int)N * BaseType<T>::size;
+};
+template <typename DataTypes>
+struct MemberMeta;
+template <typename... Types>
+struct MemberMeta<MemberTypes<Types...>> {
+  static std::vector<int> bytes() { return {(int)sizeof(typename BaseType<Types>::type)...}; }
+  static std::vector<int> ncomp() { return {BaseType<Types>::size...}; }
+};
+
+// ---------------------------------------------------------------- Segment (ptcls->get<N>())
+template <typename Type>
+class Segment {
+ public:
+  using Base = typename BaseType<Type>::type;
+  Segment() : p_(nullptr), stride_(0), member_(-1) {}
+  Segment(Base* p, long long stride, int member) : p_(p), stride_(stride), member_(member) {}
+  PP_INLINE Base& operator()(const int& pid) const { return p_[pid]; }
+  PP_INLINE Base& operator()(const int& pid, const int& i) const { return p_[(long long)i * stride_ + pid]; }
+  int member() const { return member_; }  // which member of the structure this accessor views
+  PP_INLINE Base* data() const { return p_; }
+  PP_INLINE long long stride() const { return stride_; }
+
+ private:
+  Base* p_;
+  long long stride_;
+  int member_;
+};
+
+// MTVs: per-member device arrays [ncomp][n] used to hand new particles to a structure
+typedef void** MemberTypeViews;
+template <typename DataTypes>
+struct MTVHeader {  // stored in front of the pointer table
+  int n;
+};
+template <typename DataTypes>
+MemberTypeViews createMemberViews(int n) {
+  const auto b = MemberMeta<DataTypes>::bytes();
+  const auto c = MemberMeta<DataTypes>::ncomp();
+  void** v = new void*[DataTypes::size + 1];
+  v[DataTypes::size] = (void*)(long)n;
+  for (std::size_t m = 0; m < DataTypes::size; ++m) {
+    v[m] = pp_malloc((size_t)std::max(n, 1) * c[m] * b[m]);
+    if (!v[m]) pp_check(PP_EHIP, "createMemberViews");
+  }
+  return v;
+}
+template <typename DataTypes, std::size_t N>
+Segment<typename MemberTypeAtIndex<N, DataTypes>::type> getMemberView(MemberTypeViews v) {
+  using T = typename MemberTypeAtIndex<N, DataTypes>::type;
+  return Segment<T>((typename BaseType<T>::type*)v[N], (long long)(long)v[DataTypes::size], (int)N);
+}
+template <typename DataTypes>
+void destroyViews(MemberTypeViews v) {
+  if (!v) return;
+  for (std::size_t m = 0; m < DataTypes::size; ++m) (void)pp_free(v[m]);
+  delete[] v;
+}
+
+// ---------------------------------------------------------------- policy / distributor stand-ins
+struct TeamPolicy {
+  int league, team;
+  TeamPolicy(int l, int t) : league(l), team(t) {}
+  int team_size() const { return team; }
+};
+inline TeamPolicy TeamPolicyAuto(int league_size, int team_size) {  // team_policy.hpp:4-11
+  return TeamPolicy(league_size, team_size < 64 ? 64 : team_size);  // wave64: C = 64
+}
+struct Distributor {  // support/psDistributor.hpp:10-40 (single-rank form)
+  int nranks = 1;
+  int num_ranks() const { return nranks; }
+};
+
+enum PaddingStrategy { PAD_EVENLY = 0, PAD_PROPORTIONALLY = 1, PAD_INVERSELY = 2 };
+
+// ---------------------------------------------------------------- ParticleStructure
+template <class DataTypes>
+class ParticleStructure {
+ public:
+  typedef DataTypes Types;
+  typedef View<lid_t> kkLidView;
+  typedef View<gid_t> kkGidView;
+  typedef MemberTypeViews MTVs;
+  template <std::size_t N>
+  using DataType = typename MemberTypeAtIndex<N, DataTypes>::type;
+  template <std::size_t N>
+  using Slice = Segment<DataType<N>>;
+
+  ParticleStructure() : h_(nullptr), name_("ptcls") {}
+  virtual ~ParticleStructure() {
+    if (h_) (void)pp_ps_destroy(h_);
+  }
+  const std::string& getName() const { return name_; }
+  lid_t nElems() const { return info().num_elems; }
+  lid_t nPtcls() const { return info().num_ptcls; }
+  lid_t capacity() const { return info().capacity; }
+  lid_t numRows() const { return info().num_rows; }
+  pp_ps* handle() const { return h_; }
+
+  // accessor invalidated by rebuild/migrate, like the reference's (drivers re-get after rebuild)
+  template <std::size_t N>
+  Slice<N> get() {
+    if (nPtcls() == 0) return Slice<N>();
+    using B = typename BaseType<DataType<N>>::type;
+    return Slice<N>((B*)pp_ps_member_ptr(h_, (int)N), pp_ps_member_stride(h_), (int)N);
+  }
+  virtual void rebuild(kkLidView new_element, kkLidView new_particle_elements = kkLidView(),
+                       MTVs new_particle_info = NULL) {
+    pp_check(pp_ps_rebuild(h_, new_element.data(), (int)new_particle_elements.size(),
+                           new_particle_elements.data(), (const void* const*)new_particle_info),
+             "ParticleStructure::rebuild");
+  }
+  virtual void migrate(kkLidView new_element, kkLidView new_process, Distributor dist = Distributor(),
+                       kkLidView new_particle_elements = kkLidView(), MTVs new_particle_info = NULL) {
+    (void)new_process;
+    if (dist.num_ranks() == 1) {  // SCS_migrate.h:20-25: serial -> rebuild
+      rebuild(new_element, new_particle_elements, new_particle_info);
+      return;
+    }
+    fprintf(stderr, "migrate across ranks is driven through pp_ps_migrate_count/pack + RCCL "
+                    "(see INTEGRATION.md); not available from this single-process header\n");
+    exit(EXIT_FAILURE);
+  }
+  virtual void printMetrics() const {
+    const pp_ps_info_t i = info();
+    if (i.kind == PP_SCS) {
+      int pc = 0, psl = 0, er = 0;
+      pp_check(pp_ps_metrics(h_, &pc, &psl, &er), "printMetrics");
+      printf("Metrics 0, C %d, V %d, sigma %d\nNelems %d, Nchunks %d, Nslices %d, Nptcls %d, "
+             "Capacity %d\nPadded Cells <Tot %%> %d %.3f\nPadded Slices <Tot %%> %d %.3f\n"
+             "Empty Rows <Tot %%> %d %.3f\n",
+             i.C, i.V, i.sigma, i.num_elems, i.num_chunks, i.num_slices, i.num_ptcls, i.capacity, pc,
+             pc * 100.0 / (i.capacity ? i.capacity : 1), psl, psl * 100.0 / (i.num_slices ? i.num_slices : 1),
+             er, er * 100.0 / (i.num_rows ? i.num_rows : 1));
+    } else {
+      printf("Metrics (Rank 0)\nNumber of Elements %d, Number of Particles %d, Capacity %d\n",
+             i.num_elems, i.num_ptcls, i.capacity);
+    }
+  }
+  pp_ps_info_t info() const {
+    pp_ps_info_t i;
+    pp_check(pp_ps_info(h_, &i), "pp_ps_info");
+    return i;
+  }
+
+ protected:
+  pp_ps* h_;
+  std::string name_;
+};
+
+template <class DataTypes>
+class SellCSigma;
+template <class DataTypes>
+class SCS_Input {
+ public:
+  typedef View<lid_t> kkLidView;
+  typedef View<gid_t> kkGidView;
+  SCS_Input(TeamPolicy& p, lid_t sigma, lid_t V_, lid_t ne_, lid_t np_, kkLidView ppe_,
+            kkGidView eg, kkLidView pes = kkLidView(), MemberTypeViews info = NULL)
+      : policy(p), sig(sigma), V(V_), ne(ne_), np(np_), ppe(ppe_), e_gids(eg), particle_elms(pes),
+        p_info(info) {
+    name = "ptcls";
+  }
+  bool always_realloc = false;
+  double minimize_size = .8;
+  double shuffle_padding = 0.1;
+  double extra_padding = 0.05;
+  PaddingStrategy padding_strat = PAD_EVENLY;
+  std::string name;
+  TeamPolicy policy;
+  lid_t sig, V, ne, np;
+  kkLidView ppe;
+  kkGidView e_gids;
+  kkLidView particle_elms;
+  MemberTypeViews p_info;
+};
+
+template <class DataTypes>
+class SellCSigma : public ParticleStructure<DataTypes> {
+ public:
+  typedef View<lid_t> kkLidView;
+  typedef View<gid_t> kkGidView;
+  typedef MemberTypeViews MTVs;
+  typedef SCS_Input<DataTypes> Input_T;
+  SellCSigma(TeamPolicy& p, lid_t sigma, lid_t vertical_chunk_size, lid_t num_elements,
+             lid_t num_particles, kkLidView particles_per_element, kkGidView element_gids,
+             kkLidView particle_elements = kkLidView(), MTVs particle_info = NULL) {
+    construct(p.team_size(), sigma, vertical_chunk_size, num_elements, num_particles,
+              particles_per_element, element_gids, particle_elements, particle_info, PAD_EVENLY, 0.1,
+              0.05);
+  }
+  SellCSigma(Input_T& in) {
+    this->name_ = in.name;
+    construct(in.policy.team_size(), in.sig, in.V, in.ne, in.np, in.ppe, in.e_gids, in.particle_elms,
+              in.p_info, in.padding_strat, in.shuffle_padding, in.extra_padding);
+  }
+  lid_t C() const { return this->info().C; }
+  lid_t V() const { return this->info().V; }
+
+ private:
+  void construct(int C, lid_t sigma, lid_t V, lid_t ne, lid_t np, kkLidView ppe, kkGidView gids,
+                 kkLidView particle_elements, MTVs particle_info, int pad, double shuffle,
+                 double extra) {
+    const auto b = MemberMeta<DataTypes>::bytes();
+    const auto c = MemberMeta<DataTypes>::ncomp();
+    std::vector<lid_t> ppe_h = ppe.to_host();
+    std::vector<gid_t> g_h = gids.to_host();
+    std::vector<int64_t> g64(g_h.begin(), g_h.end());
+    const bool with_info = particle_elements.size() > 0 && particle_info != NULL;
+    if (with_info) std::fill(ppe_h.begin(), ppe_h.end(), 0);  // particles enter through rebuild
+    this->h_ = pp_ps_create_scs(C, sigma, V, ne, with_info ? 0 : np, ppe_h.data(),
+                                g64.empty() ? nullptr : g64.data(), pad, shuffle, extra,
+                                (int)DataTypes::size, b.data(), c.data(), nullptr, nullptr);
+    if (!this->h_) pp_check(PP_EHIP, "SellCSigma construction");
+    if (with_info) {  // initSCSData (SCS_buildFns.h:205-232): device-side placement
+      kkLidView none(1);
+      pp_check(pp_ps_rebuild(this->h_, none.data(), (int)particle_elements.size(),
+                             particle_elements.data(), (const void* const*)particle_info),
+               "SellCSigma initial particles");
+    }
+  }
+};
+
+template <class DataTypes>
+class CSR : public ParticleStructure<DataTypes> {
+ public:
+  typedef View<lid_t> kkLidView;
+  typedef View<gid_t> kkGidView;
+  typedef MemberTypeViews MTVs;
+  CSR(TeamPolicy&, lid_t num_elements, lid_t num_particles, kkLidView particles_per_element,
+      kkGidView element_gids, kkLidView particle_elements = kkLidView(), MTVs particle_info = NULL) {
+    const auto b = MemberMeta<DataTypes>::bytes();
+    const auto c = MemberMeta<DataTypes>::ncomp();
+    std::vector<lid_t> ppe_h = particles_per_element.to_host();
+    std::vector<gid_t> g_h = element_gids.to_host();
+    std::vector<int64_t> g64(g_h.begin(), g_h.end());
+    const bool with_info = particle_elements.size() > 0 && particle_info != NULL;
+    if (with_info) std::fill(ppe_h.begin(), ppe_h.end(), 0);
+    this->h_ = pp_ps_create_csr(num_elements, with_info ? 0 : num_particles, ppe_h.data(),
+                                g64.empty() ? nullptr : g64.data(), 1.05, (int)DataTypes::size,
+                                b.data(), c.data(), nullptr, nullptr);
+    if (!this->h_) pp_check(PP_EHIP, "CSR construction");
+    if (with_info) {
+      kkLidView none(1);
+      pp_check(pp_ps_rebuild(this->h_, none.data(), (int)particle_elements.size(),
+                             particle_elements.data(), (const void* const*)particle_info),
+               "CSR initial particles");
+    }
+  }
+};
+
+// ---------------------------------------------------------------- parallel_for
+// One thread per slot; fn(element_id, particle_id, mask) is called for EVERY slot the reference
+// would visit, masked ones included (SellCSigma.h:545-552, CSR.hpp:198-208).
+template <class Fn>
+__global__ void ps_parallel_for_kernel(int capacity, const int* __restrict__ slot_elem,
+                                       const unsigned char* __restrict__ mask, Fn fn) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity) return;
+  const int e = slot_elem[pid];
+  if (e < 0) return;
+  fn(e, pid, (int)mask[pid]);
+}
+template <typename FunctionType, typename DataTypes>
+void parallel_for(ParticleStructure<DataTypes>* ps, FunctionType& fn, std::string = "") {
+  if (!ps || !ps->handle()) {
+    fprintf(stderr, "Structure does not support parallel for\n");
+    throw 1;  // ps_for.hpp:28-30
+  }
+  const pp_ps_info_t i = ps->info();
+  if (i.num_ptcls == 0 || i.capacity == 0) return;  // SellCSigma.h:529
+  pp_ps_layout_t L;
+  pp_check(pp_ps_layout(ps->handle(), &L), "pp_ps_layout");
+  const int block = 256, grid = (i.capacity + block - 1) / block;
+  hipLaunchKernelGGL(ps_parallel_for_kernel<FunctionType>, dim3(grid), dim3(block), 0,
+                     (hipStream_t)pp_stream(), i.capacity, L.slot_elem, L.mask, fn);
+}
+
+}  // namespace pumipic
+
+namespace particle_structs = pumipic;

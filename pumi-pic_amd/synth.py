@@ -95,7 +95,8 @@ def annulus_tri(n_b=98, n_theta=512, h=XGC_H, k=XGC_K, d=XGC_D, b_lo=0.05, b_hi=
     cls = (1 + np.repeat(I, 2) // band_width).astype(np.int32)
     # counter-clockwise check
     p = coords[e2v]
-    area = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+    a, b = p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]
+    area = a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]
     assert (area > 0).all()
     return np.ascontiguousarray(coords), e2v, cls
 

@@ -588,3 +588,29 @@ def test_unsafe_procs_and_pack(ppo, synth, capi):
     after = ne_g.to_host()[:cap]
     assert np.all(after[live & (np_o != rank)] == -1)
     assert np.array_equal(after[live & (np_o == rank)], ne_o[live & (np_o == rank)])
+
+
+# ---------------------------------------------------------------- C++ boundary (drivers/)
+def test_cpp_driver_pseudoxgcm(synth, capi, tmp_path):
+    """The pseudoXGCm driver, written against the particle_structs mirror headers with USER
+    lambdas through ps::parallel_for, runs the reference step loop end to end."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drv = os.path.join(root, "pumi-pic_amd", "drivers")
+    subprocess.check_call(["make", "-C", drv, "-s"])
+    c, e, cl = synth.annulus_tri(n_b=24, n_theta=96, band_width=3)
+    mesh_file = str(tmp_path / "annulus.bin")
+    synth.write_mesh_bin(mesh_file, 2, c, e, cl)
+    npt = 20000
+    out = subprocess.run([os.path.join(drv, "pseudoXGCm"), mesh_file, str(npt), "6", "10", "2.0", "0"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    m = re.search(r"RESULT particles (\d+) scatter_mass (\S+) touched_elements (\d+)", out.stdout)
+    assert m, out.stdout[-2000:]
+    particles, mass, touched = int(m.group(1)), float(m.group(2)), int(m.group(3))
+    assert particles == npt                      # interior bands: nobody leaves the domain
+    assert 0.9 * 18 * npt <= mass <= 18 * npt    # 2 rings x 3 verts x (8 pts x 3 mapped)/8 each
+    assert touched > 0
+    assert "Metrics 0, C 64" in out.stdout
