@@ -235,6 +235,18 @@ int pp_ps_migrate_pack(const pp_ps* ps, int* new_element_dev, const int* new_pro
                        int comm_rank, int nranks, const int* send_counts_host,
                        int64_t* send_gid_dev, void* const* send_info_dev);
 
+/* One-buffer form of the same exchange: every leaving particle is packed as ONE record
+ * [element gid int64 | all members as 32-bit words], padded to 16 B, rank-major.  A single
+ * all-to-all-v moves everything; the receiver feeds the records to pp_ps_rebuild_records, which
+ * maps gid -> lid (gid2lid_dev[ngids], or identity when NULL: full-mesh replica) and rebuilds with
+ * the received particles as new particles (SCS_migrate.h:181-213). */
+int pp_ps_migrate_record_bytes(const pp_ps* ps);
+int pp_ps_migrate_pack_records(const pp_ps* ps, int* new_element_dev, const int* new_process_dev,
+                               int comm_rank, int nranks, const int* send_counts_host,
+                               void* send_records_dev);
+int pp_ps_rebuild_records(pp_ps* ps, const int* new_element_dev, int n_recv,
+                          const void* recv_records_dev, const int* gid2lid_dev, int64_t ngids);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,6 +105,9 @@ SYMBOLS = {
     "pp_set_unsafe_procs": (_I, [_V, _V, _V, _V, _I, _V, _V]),
     "pp_ps_migrate_count": (_I, [_V, _V, _V, _I, _I, _V]),
     "pp_ps_migrate_pack": (_I, [_V, _V, _V, _I, _I, _V, _V, _V]),
+    "pp_ps_migrate_record_bytes": (_I, [_V]),
+    "pp_ps_migrate_pack_records": (_I, [_V, _V, _V, _I, _I, _V, _V]),
+    "pp_ps_rebuild_records": (_I, [_V, _V, _I, _V, _V, C.c_int64]),
 }
 
 
@@ -532,3 +535,22 @@ def migrate_pack(ps, new_element_dev, new_process_dev, rank, nranks, counts):
     check(lib().pp_ps_migrate_pack(ps.p, new_element_dev.ptr, new_process_dev.ptr, rank, nranks,
                                    counts.ctypes.data, gid.ptr, C.cast(arr, C.c_void_p)))
     return gid, bufs
+
+
+def migrate_record_bytes(ps):
+    n = lib().pp_ps_migrate_record_bytes(ps.p)
+    if n < 0:
+        check(n)
+    return n
+
+
+def migrate_pack_records(ps, new_element_dev, new_process_dev, rank, nranks, counts, out_ptr):
+    """out_ptr: raw device pointer of a buffer holding counts.sum() records"""
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    check(lib().pp_ps_migrate_pack_records(ps.p, new_element_dev.ptr, new_process_dev.ptr, rank,
+                                           nranks, counts.ctypes.data, out_ptr))
+
+
+def rebuild_records(ps, new_element_dev, n_recv, recv_ptr, gid2lid_dev=None, ngids=0):
+    check(lib().pp_ps_rebuild_records(ps.p, new_element_dev.ptr, n_recv, recv_ptr,
+                                      gid2lid_dev.ptr if gid2lid_dev is not None else None, ngids))

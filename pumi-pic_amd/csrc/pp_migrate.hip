@@ -82,9 +82,152 @@ __global__ void k_pack(int capacity, const unsigned char* __restrict__ mask, int
   }
   new_element[pid] = -1;  // removeSentParticles (SCS_migrate.h:189-196)
 }
+// ---- one-record-per-particle form: [gid (2 words) | member words ...] padded to 16 B.  One
+// buffer per step means ONE all-to-all-v over xGMI instead of one per member (the reference
+// posts T+1 messages per peer, SCS_migrate.h:143-178).
+constexpr int kRecMaxWords = 66;
+struct RecTable {
+  int nwords;       // member words (without the gid)
+  int rec_words;    // padded record length in words
+  const char* src[kRecMaxWords];
+  int scale[kRecMaxWords];
+  char* dst[kRecMaxWords];  // unpack: destination arrays [ncomp][n]
+};
+__global__ void k_pack_records(int capacity, const unsigned char* __restrict__ mask,
+                               int* new_element, const int* __restrict__ new_process, int rank,
+                               int nranks, int* __restrict__ cursor,
+                               const long long* __restrict__ gids, unsigned* __restrict__ out,
+                               RecTable t) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity || !mask[pid]) return;
+  const int e = new_element[pid];
+  if (e < 0) return;
+  const int p = new_process[pid];
+  if (p == rank || p < 0 || p >= nranks) return;
+  const int idx = atomicAdd(&cursor[p], 1);
+  unsigned* r = out + (size_t)idx * t.rec_words;
+  const long long g = gids ? gids[e] : (long long)e;
+  r[0] = (unsigned)(g & 0xffffffffll);
+  r[1] = (unsigned)((unsigned long long)g >> 32);
+  for (int w = 0; w < t.nwords; ++w) r[2 + w] = *(const unsigned*)(t.src[w] + (long long)pid * t.scale[w]);
+  new_element[pid] = -1;  // removeSentParticles (SCS_migrate.h:189-196)
+}
+__global__ void k_unpack_records(int n, const unsigned* __restrict__ rec, const int* __restrict__ gid2lid,
+                                 long long ngids, int* __restrict__ elems, int* bad, RecTable t) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned* r = rec + (size_t)i * t.rec_words;
+  const long long g = (long long)(((unsigned long long)r[1] << 32) | r[0]);
+  int lid;
+  if (gid2lid) {
+    lid = (g >= 0 && g < ngids) ? gid2lid[g] : -1;
+  } else {
+    lid = (int)g;  // full-mesh replica: global id == local id
+  }
+  if (lid < 0) *bad = 1;
+  elems[i] = lid;
+  for (int w = 0; w < t.nwords; ++w) *(unsigned*)(t.dst[w] + (long long)i * t.scale[w]) = r[2 + w];
+}
+
+int build_rec_table(const pp_ps* ps, RecTable& t) {
+  int nw = 0;
+  for (int m = 0; m < ps->nmembers; ++m) {
+    const int s = ps->member_map[m];
+    const int b = ps->member_bytes[s];
+    PP_REQUIRE(b == 4 || b == 8, "migration records need 4- or 8-byte member scalars");
+    for (int c = 0; c < ps->member_ncomp[s]; ++c)
+      for (int hw = 0; hw < b / 4; ++hw) {
+        PP_REQUIRE(nw < kRecMaxWords, "particle record too large for the migration pack");
+        t.src[nw] = (const char*)ps->data[s].p + ((size_t)c * ps->stride) * b + hw * 4;
+        t.scale[nw] = b;
+        t.dst[nw] = nullptr;
+        ++nw;
+      }
+  }
+  t.nwords = nw;
+  t.rec_words = ((2 + nw + 3) / 4) * 4;
+  return PP_OK;
+}
 }  // namespace
 
 extern "C" {
+
+int pp_ps_migrate_record_bytes(const pp_ps* ps) {
+  if (!ps) return PP_EINVAL;
+  RecTable t{};
+  const int rc = build_rec_table(ps, t);
+  return rc ? rc : t.rec_words * 4;
+}
+
+int pp_ps_migrate_pack_records(const pp_ps* ps, int* new_element_dev, const int* new_process_dev,
+                               int comm_rank, int nranks, const int* send_counts_host,
+                               void* send_records_dev) {
+  PP_REQUIRE(ps && new_element_dev && new_process_dev && send_counts_host && nranks > 0,
+             "pp_ps_migrate_pack_records: bad argument");
+  long long total = 0;
+  std::vector<int> start((size_t)nranks, 0);
+  for (int r = 0; r < nranks; ++r) {
+    start[r] = (int)total;
+    total += send_counts_host[r];
+  }
+  if (total == 0) return PP_OK;
+  PP_REQUIRE(send_records_dev, "pp_ps_migrate_pack_records: null send buffer");
+  RecTable t{};
+  int rc = build_rec_table(ps, t);
+  if (rc) return rc;
+  hipStream_t st = pp::stream();
+  pp::DevBuf cur;
+  PP_HIP_CHECK(cur.reserve(sizeof(int) * (size_t)nranks));
+  PP_HIP_CHECK(hipMemcpyAsync(cur.p, start.data(), sizeof(int) * (size_t)nranks,
+                              hipMemcpyHostToDevice, st));
+  k_pack_records<<<grid_for(ps->capacity), kBlock, 0, st>>>(
+      ps->capacity, ps->d_mask.as<unsigned char>(), new_element_dev, new_process_dev, comm_rank,
+      nranks, cur.as<int>(), ps->has_gids ? ps->d_gids.as<long long>() : nullptr,
+      (unsigned*)send_records_dev, t);
+  PP_LAUNCH_CHECK();
+  PP_HIP_CHECK(hipStreamSynchronize(st));
+  return PP_OK;
+}
+
+int pp_ps_rebuild_records(pp_ps* ps, const int* new_element_dev, int n_recv,
+                          const void* recv_records_dev, const int* gid2lid_dev, int64_t ngids) {
+  PP_REQUIRE(ps && n_recv >= 0 && (n_recv == 0 || recv_records_dev),
+             "pp_ps_rebuild_records: bad argument");
+  if (n_recv == 0) return pp_ps_rebuild(ps, new_element_dev, 0, nullptr, nullptr);
+  RecTable t{};
+  int rc = build_rec_table(ps, t);
+  if (rc) return rc;
+  hipStream_t st = pp::stream();
+  // received particles become "new particles" of the rebuild (SCS_migrate.h:198-213)
+  std::vector<pp::DevBuf> info((size_t)ps->nmembers);
+  std::vector<const void*> ptrs((size_t)ps->nmembers);
+  int w = 0;
+  for (int m = 0; m < ps->nmembers; ++m) {
+    const int s = ps->member_map[m];
+    const int b = ps->member_bytes[s], nc = ps->member_ncomp[s];
+    PP_HIP_CHECK(info[m].reserve((size_t)n_recv * nc * b));
+    ptrs[m] = info[m].p;
+    for (int c = 0; c < nc; ++c)
+      for (int hw = 0; hw < b / 4; ++hw) t.dst[w++] = (char*)info[m].p + ((size_t)c * n_recv) * b + hw * 4;
+  }
+  pp::DevBuf elems, bad;
+  PP_HIP_CHECK(elems.reserve(sizeof(int) * (size_t)n_recv));
+  PP_HIP_CHECK(bad.reserve(sizeof(int)));
+  PP_HIP_CHECK(hipMemsetAsync(bad.p, 0, sizeof(int), st));
+  k_unpack_records<<<grid_for(n_recv), kBlock, 0, st>>>(n_recv, (const unsigned*)recv_records_dev,
+                                                        gid2lid_dev, (long long)ngids,
+                                                        elems.as<int>(), bad.as<int>(), t);
+  PP_LAUNCH_CHECK();
+  int hbad = 0;
+  PP_HIP_CHECK(hipMemcpyAsync(&hbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  PP_HIP_CHECK(hipStreamSynchronize(st));
+  PP_REQUIRE(!hbad, "pp_ps_rebuild_records: received an element gid with no local id "
+                    "(assert(valid_at(index)), SCS_migrate.h:184)");
+  rc = pp_ps_rebuild(ps, new_element_dev, n_recv, elems.as<int>(), ptrs.data());
+  if (rc) return rc;
+  PP_HIP_CHECK(hipStreamSynchronize(st));  // temporaries are released on return
+  return PP_OK;
+}
 
 int pp_set_unsafe_procs(const pp_ps* ps, const int* elems_dev, const unsigned char* safe_dev,
                         const int* owners_dev, int comm_rank, int* new_elems_dev,

@@ -614,3 +614,74 @@ def test_cpp_driver_pseudoxgcm(synth, capi, tmp_path):
     assert 0.9 * 18 * npt <= mass <= 18 * npt    # 2 rings x 3 verts x (8 pts x 3 mapped)/8 each
     assert touched > 0
     assert "Metrics 0, C 64" in out.stdout
+
+
+def test_migration_records_two_virtual_ranks(ppo, synth, capi):
+    """pp_ps_migrate_pack_records + pp_ps_rebuild_records: two element-block 'ranks' living in one
+    process exchange packed records through host memory (standing in for the all-to-all-v); the
+    union of both structures must equal the single-rank oracle run, bit for bit."""
+    pop = common.population_2d(synth, n_b=12, n_theta=48, num_ptcls=3000, mdl_face=3, band_width=3)
+    ne = len(pop["e2v"])
+    world = 2
+    owners = (np.arange(ne) * world // ne).astype(np.int32)
+    mesh = capi.Mesh(2, pop["coords"], pop["e2v"], pop["cls"])
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    po.set_try_shuffling(False)
+    ranks = []
+    for r in range(world):
+        mine = owners[pop["elem"]] == r
+        elem = pop["elem"][mine]
+        info = [np.ascontiguousarray(a[..., mine]) for a in pop["info"]]
+        ps = capi.PS.scs(capi.PARTICLE_XGCM, ne, np.bincount(elem, minlength=ne).astype(np.int32),
+                         gids=np.arange(ne, dtype=np.int64), particle_elements=elem, particle_info=info)
+        ranks.append(ps)
+    recb = capi.migrate_record_bytes(ranks[0])
+    assert recb == 80
+    owners_d = capi.DevArray.from_host(owners)
+    moved = 0
+    for step in range(5):
+        ppo.elliptical_push(po, mo, H, K, D, 6.0, trig=1)
+        _, ids_o, _ = ppo.search_mesh_2d(mo, po, looplimit=200)
+        ppo.update_positions(po)
+        po.rebuild(ids_o)
+        outbox = []
+        for r, ps in enumerate(ranks):
+            ids = capi.DevArray.from_host(np.full(max(ps.capacity(), 1), -1, dtype=np.int32))
+            capi.push_search(mesh, ps, H, K, D, 6.0, ids, seeded=True, looplimit=200)
+            capi.update_positions(ps)
+            safe = capi.DevArray.from_host((owners == r).astype(np.uint8))
+            ne_d, np_d = capi.set_unsafe_procs(ps, ids, safe, owners_d, r)
+            counts = capi.migrate_count(ps, ne_d, np_d, r, world)
+            buf = capi.DevArray(max(int(counts.sum()) * recb, 1), np.uint8)
+            capi.migrate_pack_records(ps, ne_d, np_d, r, world, counts, buf.ptr)
+            outbox.append((ne_d, counts, buf.to_host()[:int(counts.sum()) * recb].reshape(-1, recb)))
+            moved += int(counts.sum())
+        for r, ps in enumerate(ranks):
+            parts = []
+            for src in range(world):
+                _, counts, data = outbox[src]
+                start = int(counts[:r].sum())
+                parts.append(data[start:start + int(counts[r])])
+            recv = np.concatenate(parts) if parts else np.zeros((0, recb), np.uint8)
+            rbuf = capi.DevArray.from_host(np.ascontiguousarray(recv).reshape(-1))
+            capi.rebuild_records(ps, outbox[r][0], len(recv), rbuf.ptr)
+            capi.sync()
+    assert moved > 0
+    ids_all, elem_all, x_all, phi_all = [], [], [], []
+    for r, ps in enumerate(ranks):
+        se, mk = ps.slot_info()
+        cap = ps.capacity()
+        live = mk.astype(bool)
+        assert np.all(owners[se[live]] == r)
+        ids_all.append(ps.member(2)[0, :cap][live])
+        elem_all.append(se[live])
+        x_all.append(ps.member(0)[:, :cap][:, live])
+        phi_all.append(ps.member(4)[0, :cap][live])
+    ids_all = np.concatenate(ids_all)
+    order = np.argsort(ids_all)
+    so, mko = po.slot_info()
+    io, eo = common.by_id(po.member(2)[0, :po.capacity()], mko, so)
+    assert np.array_equal(ids_all[order], io)
+    assert np.array_equal(np.concatenate(elem_all)[order], eo)
+    _, xo = common.by_id(po.member(2)[0, :po.capacity()], mko, po.member(0)[:, :po.capacity()])
+    assert np.array_equal(np.concatenate(x_all, axis=1)[:, order], xo)
