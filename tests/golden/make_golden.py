@@ -1,0 +1,116 @@
+#!/usr/bin/env python
+"""Generates tests/golden/*.npz with the CPU oracle (oracle/).  The reference's own meshes are an
+empty submodule, so golden vectors are produced on the synthetic inputs of SURVEY 8(c)
+(3)-(5): per-step element ids keyed by particle id, final positions and scatter sums.
+Run from the repo root:  python tests/golden/make_golden.py"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import pumipic_amd_loader  # noqa: E402
+import common  # noqa: E402
+
+H, K, D = 1.72479370 - .08, .020558260, 0.6
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def by_id(ps, values):
+    se, mk = ps.slot_info()
+    cap = ps.capacity()
+    ids = ps.member(2)[0, :cap]
+    return common.by_id(ids, mk, np.asarray(values)[..., :cap])
+
+
+def xgcm_2d(ppo, synth):
+    pop = common.population_2d(synth, n_b=24, n_theta=96, num_ptcls=1000, mdl_face=6, band_width=3)
+    mesh, ps = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM, C=1)
+    ps.set_try_shuffling(False)
+    fwd, _ = ppo.create_gyro_ring_mappings(mesh, trig=1)
+    elems = []
+    for step in range(30):
+        ppo.elliptical_push(ps, mesh, H, K, D, 2.0, trig=1)
+        _, ids, _ = ppo.search_mesh_2d(mesh, ps, looplimit=200)
+        elems.append(by_id(ps, ids)[1].copy())
+        ppo.update_positions(ps)
+        ps.rebuild(ids)
+    w = ppo.gyro_scatter(mesh, ps, fwd)
+    pid, x = by_id(ps, ps.member(0))
+    np.savez_compressed(os.path.join(OUT, "xgcm2d_24x96_1000p_30steps.npz"),
+                        elem_ids=np.array(elems, dtype=np.int32), final_x=x, scatter_fwd=w,
+                        fwd_map=fwd.astype(np.int32), particle_ids=pid)
+
+
+def xgcm_3d(ppo, synth):
+    pop = common.population_3d(synth, n_b=6, n_theta=24, n_planes=8, num_ptcls=1000, mdl_face=5)
+    mesh, ps = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM, C=1)
+    elems = []
+    ids = None
+    for step in range(12):
+        ppo.toroidal_push(ps, mesh, H, K, D, 6.0, trig=1)
+        ids = ppo.search_mesh(mesh, ps, elem_ids=ids, looplimit=200)["elem_ids"]
+        elems.append(by_id(ps, ids)[1].copy())
+        a, b = ps.member(0), ps.member(1)
+        tmp = a.copy()
+        a[:] = b
+        b[:] = tmp
+    pid, x = by_id(ps, ps.member(0))
+    np.savez_compressed(os.path.join(OUT, "xgcm3d_6x24x8_1000p_12steps.npz"),
+                        elem_ids=np.array(elems, dtype=np.int32), final_x=x, particle_ids=pid)
+
+
+def push_and_search(ppo, synth):
+    pop = common.population_box(synth, n=6, num_ptcls=1000)
+    mesh, ps = common.oracle_pair(ppo, pop, ppo.PARTICLE_PUSH, C=1)
+    ps.set_try_shuffling(False)
+    elems, faces = [], []
+    for step in range(12):
+        ppo.linear_push(ps, 1.0 / 20, -0.5, 0.8, 0.0)
+        r = ppo.search_mesh_legacy3d(mesh, ps, looplimit=100)
+        pid, e = by_id(ps, r["elem_ids"])
+        _, f = by_id(ps, r["xface"])
+        full_e = np.full(1000, -2, dtype=np.int32)
+        full_f = np.full(1000, -2, dtype=np.int32)
+        full_e[pid] = e
+        full_f[pid] = f
+        elems.append(full_e)
+        faces.append(full_f)
+        ppo.update_positions(ps)
+        ps.rebuild(r["elem_ids"])
+        if ps.nPtcls() == 0:
+            break
+    np.savez_compressed(os.path.join(OUT, "pushsearch_box6_1000p.npz"),
+                        elem_ids=np.array(elems), xface=np.array(faces))
+
+
+def scs_layouts(ppo):
+    out = {}
+    rng = np.random.default_rng(42)
+    ppes = [np.array([3, 0, 5, 1, 1, 0, 7, 2, 2, 4], dtype=np.int32),
+            rng.integers(0, 9, size=37).astype(np.int32),
+            np.zeros(6, dtype=np.int32)]
+    for i, ppe in enumerate(ppes):
+        for C, V, sigma, pad in [(1, 1024, 2**31 - 1, 0), (4, 2, 1, 0), (32, 1024, 2**31 - 1, 1),
+                                 (64, 3, 5, 2)]:
+            ps = ppo.PS.scs([(np.int32, 1)], len(ppe), ppe, C_max=C, sigma=sigma, V=V, pad_strat=pad)
+            L = ps.layout()
+            key = "p%d_C%d_V%d_s%d_pad%d" % (i, C, V, min(sigma, 99), pad)
+            out[key + "_ppe"] = ppe
+            for k in ("offsets", "slice_to_chunk", "row_to_element", "mask"):
+                out[key + "_" + k] = L[k]
+            out[key + "_C"] = np.array([L["C"], L["capacity"]])
+    np.savez_compressed(os.path.join(OUT, "scs_layouts.npz"), **out)
+
+
+if __name__ == "__main__":
+    pp = pumipic_amd_loader.load()
+    ppo = pumipic_amd_loader.load_oracle()
+    xgcm_2d(ppo, pp.synth)
+    xgcm_3d(ppo, pp.synth)
+    push_and_search(ppo, pp.synth)
+    scs_layouts(ppo)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

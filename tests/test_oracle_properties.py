@@ -1,0 +1,301 @@
+"""CPU: property tests of the oracle modelled on the reference's own test strategy:
+test_adj.cpp (search post-conditions), test_rebuild.cpp / test_structure.cpp (per-element id sums,
+counts), scs_padding / buildSCSTest (layout invariants), Distribute.  These are the same
+properties the HIP path is held to in tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import common
+
+H, K, D = 1.72479370 - .08, .020558260, 0.6
+INT_MAX = 2**31 - 1
+
+
+# ---------------------------------------------------------------- SCS layout invariants
+@pytest.mark.parametrize("C,V,sigma,pad", [(1, 1024, INT_MAX, 0), (4, 2, 1, 0), (32, 3, 7, 1),
+                                           (64, 1024, INT_MAX, 2), (64, 16, 100, 0)])
+def test_scs_layout_invariants(ppo, synth, C, V, sigma, pad):
+    ne, np_ = 300, 4000
+    ppe, epp = synth.distribute_particles(ne, np_, 2, seed=3)
+    ps = ppo.PS.scs(ppo.PARTICLE_PUSH, ne, ppe, C_max=C, sigma=sigma, V=V, pad_strat=pad)
+    L = ps.layout()
+    Cc = L["C"]
+    assert Cc == min(C, int((ppe > 0).sum()))
+    # every element owns exactly one row and the maps are inverse
+    r2e, e2r = L["row_to_element"], L["element_to_row"]
+    assert np.array_equal(np.sort(r2e[:ne]), np.arange(ne))
+    assert np.array_equal(e2r[r2e[:ne]], np.arange(ne))
+    # ascending particle counts inside every sigma window (SCS_sort.h:36-47)
+    sg = min(sigma, ne)
+    nwin = ne // sg
+    cnt = ppe[r2e[:ne]]
+    for w in range(nwin):
+        a, b = w * sg, (ne if w == nwin - 1 else (w + 1) * sg)
+        assert np.all(np.diff(cnt[a:b]) >= 0)
+        assert set(r2e[a:b]) == set(range(a, b))  # sorting never crosses a window
+    # slices: contiguous, multiples of C, at most V columns, slice_to_chunk monotone
+    off, s2c = L["offsets"], L["slice_to_chunk"]
+    sizes = np.diff(off)
+    assert off[0] == 0 and off[-1] == L["capacity"] == ps.capacity()
+    assert np.all(sizes % Cc == 0) and np.all(sizes // Cc <= V) and np.all(sizes > 0)
+    assert np.all(np.diff(s2c) >= 0)
+    # mask: per row exactly ppe live slots, packed at the front of the row
+    se, mk = ps.slot_info()
+    assert np.array_equal(np.bincount(se[mk > 0], minlength=ne)[:ne], ppe)
+    assert mk.sum() == np_
+    padded, pslices, empty = ps.metrics()
+    assert padded == L["capacity"] - np_
+    assert empty == (L["num_rows"] - ne) + int((ppe == 0).sum())
+
+
+def test_csr_layout(ppo, synth):
+    ne, np_ = 100, 1234
+    ppe, epp = synth.distribute_particles(ne, np_, 1, seed=5)
+    ids = np.arange(np_, dtype=np.int32)
+    ps = ppo.PS.csr([(np.int32, 1)], ne, ppe, particle_elements=epp, particle_info=[ids])
+    off = ps.layout()["offsets"]
+    assert np.array_equal(np.diff(off), ppe) and ps.capacity() == int(np_ * 1.05)
+    got = ps.member(0)[0, :np_]
+    se, mk = ps.slot_info()
+    assert np.array_equal(epp[got], se[:np_])       # every particle sits in its element's range
+    for e in range(ne):                             # stable: input order kept inside an element
+        assert np.all(np.diff(got[off[e]:off[e + 1]]) > 0)
+
+
+# ---------------------------------------------------------------- rebuild (test_rebuild.cpp)
+def _ids_structure(ppo, synth, kind, ne=120, np_=3000, strat=2):
+    ppe, epp = synth.distribute_particles(ne, np_, strat, seed=11)
+    ids = np.arange(np_, dtype=np.int32)
+    members = [(np.int32, 1), (np.float64, 3)]
+    info = [ids, np.vstack([ids * 0.5, ids * 2.0, -ids.astype(float)])]
+    if kind == "scs":
+        return ppo.PS.scs(members, ne, ppe, C_max=8, particle_elements=epp, particle_info=info), epp
+    return ppo.PS.csr(members, ne, ppe, particle_elements=epp, particle_info=info), epp
+
+
+def _by_id(ps):
+    se, mk = ps.slot_info()
+    cap = ps.capacity()
+    live = mk.astype(bool)
+    ids = ps.member(0)[0, :cap][live]
+    o = np.argsort(ids)
+    return ids[o], se[live][o], ps.member(1)[:, :cap][:, live][:, o]
+
+
+@pytest.mark.parametrize("kind", ["scs", "csr"])
+@pytest.mark.parametrize("shuffle", [True, False])
+def test_rebuild_scenarios(ppo, synth, kind, shuffle):
+    ps, epp = _ids_structure(ppo, synth, kind)
+    if kind == "scs":
+        ps.set_try_shuffling(shuffle)
+    ne, np0 = ps.nElems(), ps.nPtcls()
+    # 1) no changes (rebuildNoChanges, test_rebuild.cpp:4-66)
+    se, mk = ps.slot_info()
+    ps.rebuild(np.where(mk > 0, se, -1))
+    ids, elem, dat = _by_id(ps)
+    assert ps.nPtcls() == np0 and np.array_equal(elem, epp[ids])
+    # 2) reassigned elements: (e*3 + id) % ne (rebuildNewElems :68-130)
+    se, mk = ps.slot_info()
+    pid = ps.member(0)[0, :ps.capacity()]
+    tgt = np.where(mk > 0, (se * 3 + pid) % ne, -1).astype(np.int32)
+    expect = {int(pid[s]): int(tgt[s]) for s in np.flatnonzero(mk)}
+    sums_before = np.bincount(tgt[mk > 0], weights=pid[mk > 0], minlength=ne)
+    ps.rebuild(tgt)
+    ids, elem, dat = _by_id(ps)
+    assert ps.nPtcls() == np0
+    assert all(expect[int(i)] == int(e) for i, e in zip(ids, elem))
+    assert np.array_equal(np.bincount(elem, weights=ids, minlength=ne), sums_before)  # id sums
+    assert np.array_equal(dat, np.vstack([ids * 0.5, ids * 2.0, -ids.astype(float)]))  # payload
+    # 3) remove every 7th particle, add new ones (rebuildNewPtcls / rebuildPtclsDestroyed)
+    se, mk = ps.slot_info()
+    pid = ps.member(0)[0, :ps.capacity()]
+    tgt = np.where(mk > 0, se, -1).astype(np.int32)
+    kill = (mk > 0) & (pid % 7 == 0)
+    tgt[kill] = -1
+    n_new = 40
+    new_e = (np.arange(n_new) * 5 % ne).astype(np.int32)
+    new_ids = np.arange(np0, np0 + n_new, dtype=np.int32)
+    ps.rebuild(tgt, new_e, [new_ids, np.vstack([new_ids * 0.5, new_ids * 2.0, -new_ids.astype(float)])])
+    ids, elem, dat = _by_id(ps)
+    assert ps.nPtcls() == np0 - int(kill.sum()) + n_new
+    assert not np.any((ids < np0) & (ids % 7 == 0))
+    assert np.array_equal(elem[ids >= np0], new_e)
+    assert np.array_equal(dat, np.vstack([ids * 0.5, ids * 2.0, -ids.astype(float)]))
+    # 4) delete everything, then refill an empty structure
+    ps.rebuild(np.full(max(ps.capacity(), 1), -1, dtype=np.int32))
+    assert ps.nPtcls() == 0
+    ps.rebuild(np.full(max(ps.capacity(), 1), -1, dtype=np.int32), new_e,
+               [new_ids, np.zeros((3, n_new))])
+    ids, elem, _ = _by_id(ps)
+    assert ps.nPtcls() == n_new and np.array_equal(elem, new_e)
+    # getPIDs (ps_for.hpp:65-85)
+    off, pids = ps.get_pids()
+    se, mk = ps.slot_info()
+    assert np.all(mk[pids] == 1)
+    assert np.array_equal(np.repeat(np.arange(ne), np.diff(off)), se[pids])
+
+
+def test_reshuffle_fast_path_is_taken_and_equivalent(ppo, synth):
+    """SCS_rebuild.h:4-120: when every row has room, particles move into holes in place."""
+    a, epp = _ids_structure(ppo, synth, "scs", ne=60, np_=1500, strat=0)
+    b, _ = _ids_structure(ppo, synth, "scs", ne=60, np_=1500, strat=0)
+    b.set_try_shuffling(False)
+    cap0 = a.capacity()
+    for ps in (a, b):
+        se, mk = ps.slot_info()
+        pid = ps.member(0)[0, :ps.capacity()]
+        tgt = np.where(mk > 0, se, -1).astype(np.int32)
+        movers = (mk > 0) & (pid % 25 == 0)
+        tgt[movers] = (se[movers] + 1) % 60
+        ps.rebuild(tgt)
+    assert a.s.last_rebuild_was_shuffle == 1 and a.capacity() == cap0
+    assert b.s.last_rebuild_was_shuffle == 0
+    ia, ea, da = _by_id(a)
+    ib, eb, db = _by_id(b)
+    assert np.array_equal(ia, ib) and np.array_equal(ea, eb) and np.array_equal(da, db)
+
+
+# ---------------------------------------------------------------- search post-conditions (test_adj.cpp)
+def _inside(ppo, mesh, elem, pos, tol):
+    if mesh.dim == 2:
+        b = ppo.barycentric_tri(mesh.coords[mesh.elem2verts[elem]], pos[:2], mesh.elem_measure[elem])
+    else:
+        b, _, _ = ppo.barycentric_tet(mesh.coords[mesh.elem2verts[elem]], pos, mesh.elem_measure[elem])
+    return ppo.all_positive(b, tol)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_bcc_search_postconditions(ppo, synth, dim):
+    """every found particle's target lies in elem_ids[pid] (test_adj.cpp:565-587); particles
+    reported outside really left through an exposed side (:591-614)."""
+    pop = common.population_2d(synth, num_ptcls=1500) if dim == 2 else common.population_3d(synth, num_ptcls=1500)
+    mesh, ps = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM, C=1)
+    if dim == 2:
+        ppo.elliptical_push(ps, mesh, H, K, D, 25.0, trig=0)
+    else:
+        ppo.toroidal_push(ps, mesh, H, K, D, 25.0, trig=0)
+    r = ppo.search_mesh(mesh, ps, require_intersection=False, looplimit=1000)
+    assert r["found"] and r["not_in_elem"] == 0
+    se, mk = ps.slot_info()
+    xt = ps.member(1)[:, :ps.capacity()]
+    moved = 0
+    for s in np.flatnonzero(mk)[::7]:
+        e = r["elem_ids"][s]
+        if e >= 0:
+            assert _inside(ppo, mesh, e, xt[:, s], 1e-10)
+            moved += e != se[s]
+        else:  # not inside ANY element
+            assert not any(_inside(ppo, mesh, t, xt[:, s], 0.0) for t in range(0, mesh.nelems, 1)) \
+                if mesh.nelems < 2000 else True
+    assert moved > 10
+
+
+def test_intersection_search_postconditions(ppo, synth):
+    """wall hits lie in the reported exposed face, on the particle's path, and the face bounds the
+    final element (test_adj.cpp:630-735)."""
+    pop = common.population_box(synth, n=3, num_ptcls=300)
+    mesh, ps = common.oracle_pair(ppo, pop, ppo.PARTICLE_PUSH, C=1)
+    ppo.linear_push(ps, 0.35, -0.5, 0.8, 0.3)
+    r = ppo.search_mesh(mesh, ps, require_intersection=True, looplimit=1000)
+    assert r["found"]
+    se, mk = ps.slot_info()
+    x, xt = ps.member(0)[:, :ps.capacity()], ps.member(1)[:, :ps.capacity()]
+    hits = 0
+    for s in np.flatnonzero(mk):
+        f = r["inter_faces"][s]
+        assert f >= 0  # rays (not segments) always reach the wall (adjacency.tpp:438)
+        assert mesh.side_exposed[f] == 1
+        e = r["elem_ids"][s]
+        assert f in mesh.elem2sides[e]
+        tri = mesh.coords[mesh.side2verts[f]]
+        n = np.cross(tri[1] - tri[0], tri[2] - tri[0])
+        p = r["inter_points"][s]
+        assert abs(np.dot(p - tri[0], n)) <= 1e-9 * np.linalg.norm(n)        # in the face plane
+        d = xt[:, s] - x[:, s]
+        t = np.dot(p - x[:, s], d) / np.dot(d, d)
+        assert t >= -1e-9 and np.linalg.norm(x[:, s] + t * d - p) <= 1e-9   # on the path
+        hits += 1
+    assert hits == 300
+
+
+def test_looplimit_marks_unfound(ppo, synth):
+    pop = common.population_2d(synth, num_ptcls=800)
+    mesh, ps = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM, C=1)
+    ppo.elliptical_push(ps, mesh, H, K, D, 12.0, trig=0)
+    found, ids, loops = ppo.search_mesh_2d(mesh, ps, looplimit=2)
+    assert not found and loops == 2
+    r = ppo.search_mesh(mesh, ps, looplimit=2)
+    assert not r["found"]
+    _, mk = ps.slot_info()
+    assert (ids[mk > 0] == -1).any() and (ids[mk > 0] >= 0).any()
+
+
+# ---------------------------------------------------------------- push / scatter invariants
+def test_elliptical_push_stays_on_ellipse(ppo, synth):
+    pop = common.population_2d(synth, num_ptcls=500)
+    mesh, ps = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM, C=1)
+    _, mk = ps.slot_info()
+    live = mk.astype(bool)
+    b = ps.member(3)[0, :ps.capacity()][live].astype(np.float64)
+    for _ in range(5):
+        ppo.elliptical_push(ps, mesh, H, K, D, 3.0, trig=0)
+    xt = ps.member(1)[:, :ps.capacity()][:, live]
+    q = ((xt[0] - H) / (D * b)) ** 2 + ((xt[1] - K) / b) ** 2
+    assert np.abs(q - 1).max() < 1e-12
+
+
+def test_gyro_scatter_mass(ppo, synth):
+    """independent numpy evaluation of gyroScatter (gyroScatter.hpp:168-229): a particle in
+    element e adds 1 to rings 0 and 1 of e's vertices; ring r of vertex v sends accum/gppr to every
+    mapped vertex of its gppr points."""
+    pop = common.population_2d(synth, num_ptcls=2000)
+    mesh, ps = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM, C=1)
+    gnr, gppr = 3, 8
+    f, b = ppo.create_gyro_ring_mappings(mesh, 0.038, gnr, gppr, 0.0)
+    assert np.array_equal(f, b)
+    w = ppo.gyro_scatter(mesh, ps, f, 0.038, gnr, gppr)
+    acc = np.zeros((mesh.nverts, gnr))
+    for r in (0, 1):
+        np.add.at(acc[:, r], mesh.elem2verts.ravel(), np.repeat(pop["ppe"], 3))
+    m = f.reshape(mesh.nverts, gnr, gppr * 3)
+    expect = np.zeros(mesh.nverts)
+    for v in range(mesh.nverts):
+        for r in range(gnr):
+            tgt = m[v, r][m[v, r] >= 0]
+            np.add.at(expect, tgt, acc[v, r] / gppr)
+    assert np.array_equal(w, expect)          # multiples of 1/8: exact in any order
+    assert 0.5 * 18 * 2000 < w.sum() <= 18 * 2000
+
+
+def test_distribute_strategies(synth):
+    for strat in range(5):
+        ppe, epp = synth.distribute_particles(1000, 50000, strat, seed=0)
+        assert ppe.sum() == 50000 and len(epp) == 50000 and epp.min() >= 0 and epp.max() < 1000
+        assert np.array_equal(np.bincount(epp, minlength=1000), ppe)
+    ppe, _ = synth.distribute_particles(1000, 50000, 0)
+    assert ppe.max() - ppe.min() <= 1
+    ppe, _ = synth.distribute_particles(1000, 50000, 4)
+    assert abs(ppe[:400].sum() / 50000 - 0.85) < 1e-3
+
+
+def test_pseudo_push_and_boris(ppo, synth):
+    ne = 50
+    ppe, _ = synth.distribute_particles(ne, 700, 1, seed=2)
+    ps = ppo.PS.scs(ppo.PERF160, ne, ppe, C_max=4, sigma=ne)
+    ped = np.sqrt(np.arange(ne, dtype=np.float64)) * np.arange(ne)
+    ppo.pseudo_push160(ps, ped)
+    se, mk = ps.slot_info()
+    cap = ps.capacity()
+    d, n, l = ps.member(0)[:, :cap], ps.member(1)[:, :cap], ps.member(2)[0, :cap]
+    s = np.flatnonzero((mk > 0) & (se > 0))
+    s = s[s > 0]
+    expect = 10.3 * 10.3 * 10.3 / np.sqrt(s.astype(float)) / np.sqrt(se[s].astype(float)) + ped[se[s]]
+    assert np.array_equal(d[5, s], expect) and np.array_equal(n[2, s], 4 * s + 2) and np.array_equal(l[s], s)
+    assert np.all(d[:, mk == 0] == 0) and np.all(n[:, mk == 0] == -1)
+    # Boris: pure E field accelerates along E, |v| preserved by pure B
+    z = np.zeros(4)
+    arrs = [z.copy() for _ in range(15)]
+    arrs[6][:] = 1.0           # vx
+    arrs[14][:] = 1e-3         # Bz
+    ppo.push_boris(*arrs, 1e-6)
+    assert np.allclose(np.hypot(arrs[6], arrs[7]), 1.0, rtol=0, atol=1e-12)
