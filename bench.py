@@ -246,7 +246,8 @@ def main():
                 "parallelism": "element-block partition, %d rank(s), full-mesh replica" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
-                         "kernel": "k_push_walk_rows<%d>" % w["dim"], "kernel_ms": kms,
+                         "kernel": ("k_push_walk_rowsq<3> + k_walk_pending<3> (one pp_push_search call)"
+                                    if w["dim"] == 3 else "k_push_walk_rows<2>"), "kernel_ms": kms,
                          "bytes_per_particle": bpp},
         }
         if not a.no_cpu_baseline and world == 1:

@@ -29,6 +29,7 @@ struct Counters {
   int not_found;   // particles cut off by looplimit
   int not_in_elem; // check_initial_parents failures
   int aborted;     // legacy search: origin not in start element at loops==0 (OMEGA_H_CHECK)
+  int pending;     // fused kernel: entries in the deferred-walk queue
 };
 
 __device__ __forceinline__ void load_tri(const pp_tri_rec* __restrict__ recs, int e, V2 fc[3],
@@ -80,8 +81,7 @@ __device__ __forceinline__ bool step_tet(const pp_tet_rec* __restrict__ recs, in
 // Per iteration (reference kernel order): find exit -> exposed? -> next element -> looplimit.
 template <int DIM>
 __device__ __forceinline__ int bcc_walk(const void* __restrict__ recs, int elem, V3 pos,
-                                        int looplimit, Counters* cnt) {
-  int loops = 0;
+                                        int looplimit, Counters* cnt, int loops = 0) {
   bool done = false;
   const int cap = looplimit ? looplimit : kHardLoopCap;
   while (true) {
@@ -657,23 +657,36 @@ struct PState {
   double x, y, z;
   int elem;
 };
-template <int DIM>
+// NT: non-temporal (streaming) cache policy for the particle streams, so that the 4 MB L2 of an
+// XCD keeps the element records instead of particle data it will never see again
+template <bool NT, class T>
+__device__ __forceinline__ T ld(const T* p) {
+  return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT, class T>
+__device__ __forceinline__ void stg(T* p, T v) {
+  if (NT)
+    __builtin_nontemporal_store(v, p);
+  else
+    *p = v;
+}
+template <int DIM, bool NT = false>
 __device__ __forceinline__ PState load_state(int pid, const unsigned char* __restrict__ mask,
                                              const float* __restrict__ pphi,
                                              const float* __restrict__ pb,
                                              const double* __restrict__ x, long long stride,
                                              const int* __restrict__ elem_ids, bool read_ids) {
   PState s;
-  s.m = mask[pid];
-  s.phi = pphi[pid];
-  s.b = pb[pid];
+  s.m = ld<NT>(mask + pid);
+  s.phi = ld<NT>(pphi + pid);
+  s.b = ld<NT>(pb + pid);
   s.x = s.y = s.z = 0;
   if (DIM == 3) {
-    s.x = x[pid];
-    s.y = x[stride + pid];
-    s.z = x[2 * stride + pid];
+    s.x = ld<NT>(x + pid);
+    s.y = ld<NT>(x + stride + pid);
+    s.z = ld<NT>(x + 2 * stride + pid);
   }
-  s.elem = read_ids ? elem_ids[pid] : -1;
+  s.elem = read_ids ? ld<NT>(elem_ids + pid) : -1;
   return s;
 }
 
@@ -751,6 +764,355 @@ __global__ void __launch_bounds__(256, OCC)
   }
 }
 
+// ------------------------------------------------------------------ row-tiled kernel, queued walk
+// Same thread = (tile,row) mapping and register-cached seed record as k_push_walk_rows, plus:
+//
+//  * cooperative record fetch.  Measured on MI355X (tools/ub_gather.hip, profiles/r01_ub_gather):
+//    a wave instruction whose 64 lanes read 16 B of 64 DIFFERENT 128-B lines costs ~64 L1 tag
+//    cycles, so a lane-private record read (8 x dwordx4) costs 8 lookups per record and the walk
+//    was bound by the L1, not by HBM.  Here NP lanes share one record (NP = 8 for the 128-B tet
+//    record, 4 for the 64-B tri record): one global_load_lds_dwordx4 touches 64/NP lines, the
+//    16-B pieces land in a per-wave LDS staging area (XOR-swizzled through the SOURCE address so
+//    the read-back is bank-conflict free) and every lane reads its own record back with
+//    ds_read_b128.  One L1 lookup per record instead of eight.
+//  * deferred walk.  A particle takes only its FIRST walk step inside the column loop; a particle
+//    that crosses into a neighbour is written as a 32-B entry (slot, next element, destination)
+//    into the wave's own region of a queue buffer -- no atomics, the wave's entry count goes to
+//    wave_cnt[] -- and is finished by k_walk_pending, where wave w walks the entries of region w
+//    with all of them stepping together, one cooperative fetch per round.  The column loop keeps
+//    no dependent second record load and no 1-of-64-lanes walk; the second pass never gathers
+//    x_tgt (a random 8-B gather costs a whole line from HBM).
+//  * XCD-aware block order: the hardware deals blockIdx round-robin over the 8 XCDs; every XCD
+//    gets a contiguous range of logical blocks (= consecutive tiles = the same chunks' rows) so a
+//    chunk's element records are pulled into ONE XCD's 4 MB L2 instead of all eight.
+  // 64-slot groups scanned by one wave of k_walk_pending
+
+struct alignas(16) PendEntry {  // deferred-walk queue entry
+  int pid, elem;
+  double x, y, z;
+};
+static_assert(sizeof(PendEntry) == 32, "queue entry must be 32 B");
+
+// coop_issue: start the LDS-DMA of the records in `want` (one per lane, -1 = none).
+template <int DIM>
+__device__ __forceinline__ void coop_issue(const void* __restrict__ recs, int want, double2* st, int lane) {
+  constexpr int NP = DIM == 3 ? 8 : 4;  // 16-B pieces per record == lanes per record
+  constexpr int RPI = 64 / NP;          // records per wave instruction
+  const int sub = lane & (NP - 1);
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int o = RPI * j + lane / NP;  // owner lane of the record this lane helps to fetch
+    const int eo = __shfl(want, o);
+    const int piece = sub ^ (o & (NP - 1));
+    if (eo >= 0)
+      __builtin_amdgcn_global_load_lds(
+          (const void*)((const char*)recs + (size_t)eo * (NP * 16) + piece * 16),
+          (__attribute__((address_space(3))) void*)(st + j * 64), 16, 0, 0);
+  }
+}
+// coop_collect: after the DMA has landed (vmcnt(0)), lanes with take == true read their record
+// back from the staging area and rebuild the register cache for element `elem`.
+template <int DIM>
+__device__ __forceinline__ void coop_collect(RecCache<DIM>& c, bool take, int elem, const double2* st,
+                                             int lane) {
+  constexpr int NP = DIM == 3 ? 8 : 4;
+  const int sub = lane & (NP - 1);
+  if (take) {
+    const double2* mine = st + lane * NP;
+    if constexpr (DIM == 3) {
+      double v[12];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const double2 t = mine[i ^ sub];
+        v[2 * i] = t.x;
+        v[2 * i + 1] = t.y;
+      }
+      const int4 nb = *(const int4*)(mine + (6 ^ sub));
+      const double vol = mine[7 ^ sub].x;
+      V3 M[4];
+      for (int i = 0; i < 4; ++i) M[i] = {v[3 * i], v[3 * i + 1], v[3 * i + 2]};
+      c.nbr[0] = nb.x;
+      c.nbr[1] = nb.y;
+      c.nbr[2] = nb.z;
+      c.nbr[3] = nb.w;
+      build(c, M, vol, elem);
+    } else {
+      V2 fc[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double2 t = mine[i ^ sub];
+        fc[i] = {t.x, t.y};
+      }
+      const int4 nb = *(const int4*)(mine + (3 ^ sub));
+      c.nbr[0] = nb.x;
+      c.nbr[1] = nb.y;
+      c.nbr[2] = nb.z;
+      build(c, fc, elem);
+    }
+  }
+}
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+// synchronous fetch: issue, wait, collect
+template <int DIM>
+__device__ __forceinline__ void coop_fetch(RecCache<DIM>& c, const void* __restrict__ recs, int want,
+                                           double2* st, int lane) {
+  coop_issue<DIM>(recs, want, st, lane);
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the LDS-DMA pieces have landed
+  wave_lds_sync();
+  coop_collect<DIM>(c, want >= 0, want, st, lane);
+  wave_lds_sync();
+}
+
+template <int DIM, int OCC, bool NT>
+__global__ void __launch_bounds__(256, OCC)
+    k_push_walk_rowsq(const int* __restrict__ ntiles_dev, int C, int TP,
+                      const int* __restrict__ tiles, const int* __restrict__ chunk_start,
+                      const int* __restrict__ chunk_width, const int* __restrict__ r2e,
+                      const unsigned char* __restrict__ mask, const void* __restrict__ recs,
+                      const int* __restrict__ class_id, int nelems, const double* __restrict__ x,
+                      double* xt, long long stride, const float* __restrict__ pb, float* pphi,
+                      double h, double k, double d, double deg, double tol, double unmoved_sq,
+                      int* elem_ids, int seeded, int looplimit, Counters* cnt, PendEntry* gq,
+                      int* wave_cnt, int abl) {
+  constexpr int NP = DIM == 3 ? 8 : 4;
+  extern __shared__ double2 lds_dyn[];
+  double2* st = lds_dyn + (size_t)(threadIdx.x >> 6) * 64 * NP;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  int qn = 0;  // wave-uniform number of queue entries written by this wave
+
+  unsigned lb = blockIdx.x;
+  if (!(abl & 16)) {
+    const unsigned nb = gridDim.x, xq = nb >> 3, xr = nb & 7, xcd = blockIdx.x & 7;
+    lb = xcd * xq + min(xcd, xr) + (blockIdx.x >> 3);
+  }
+  const long long g = (long long)lb * blockDim.x + threadIdx.x;
+  const long long gwave = g >> 6;
+  PendEntry* wq = gq + gwave * 64 * TP;  // this wave's queue region (64*TP entries worst case)
+  const int tile = (int)(g / C);
+  const int r = (int)(g - (long long)tile * C);
+  const bool valid = tile < *ntiles_dev;
+  int start = 0, p0 = 0, pend = 0, e = 0;
+  if (valid) {
+    const int c = tiles[2 * tile];
+    p0 = tiles[2 * tile + 1];
+    start = chunk_start[c] + r;
+    pend = min(p0 + TP, chunk_width[c]);
+    e = r2e[c * C + r];
+  }
+  const ppm::ClassTerm ct = ppm::class_term((valid && e < nelems) ? class_id[e] : 1, deg, DIM == 3);
+  const bool read_ids = (DIM == 2) || seeded;
+  const int cap = looplimit ? looplimit : kHardLoopCap;
+  RecCache<DIM> cache;
+  cache.id = -1;
+  // Software pipeline over the columns.  At the top of column p everything issued during column
+  // p-1 has landed (ONE vmcnt(0) per column): the particle state of p (registers) and the seed
+  // records of p (LDS staging, DMA'd from the element id that was read one column earlier).
+  // The records are copied to the register cache, then the DMA for column p+1 and the state
+  // loads of p+1 are issued and overlap the whole of column p's arithmetic.
+  PState cur{};
+  int e1 = -1;   // raw elem_ids value of column p+1 (read two columns ahead of its use as a seed)
+  int pre = -1;  // element whose record the DMA put into this lane's staging slot for column p
+  if (p0 < pend) {
+    cur = load_state<DIM, NT>(start + p0 * C, mask, pphi, pb, x, stride, elem_ids, read_ids);
+    if (read_ids && p0 + 1 < pend) e1 = ld<NT>(elem_ids + start + (p0 + 1) * C);
+  }
+  for (int i = 0; i < TP; ++i) {  // wave-uniform trip count: every lane reaches the wave-level ops
+    const int p = p0 + i;
+    const int pid = start + p * C;
+    const bool act = p < pend;
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): state(p) and the records DMA'd for p
+    wave_lds_sync();
+    const PState s = cur;
+    const bool live = act && s.m;
+    // seed element of this column (known before the push; `done` cases just fetch in vain)
+    int elem = -1;
+    if (live) {
+      if (DIM == 2) {
+        elem = (s.elem == -1) ? e : s.elem;
+        if (elem == -nelems) elem = -1;
+      } else {
+        elem = seeded ? s.elem : e;
+      }
+    }
+    const int want = (elem >= 0 && elem != cache.id && !(abl & 1)) ? elem : -1;
+    coop_collect<DIM>(cache, want >= 0 && want == pre, want, st, lane);
+    wave_lds_sync();
+    const int miss = (want >= 0 && want != pre) ? want : -1;  // not prefetched (first column, ...)
+    if (__ballot(miss >= 0) != 0ull) coop_fetch<DIM>(cache, recs, miss, st, lane);
+    // ---- issue column p+1: record DMA from its (already known) seed, then its state loads
+    pre = -1;
+    if (act && p + 1 < pend) {
+      int seed1 = read_ids ? e1 : e;
+      if (DIM == 2 && seed1 == -1) seed1 = e;
+      if (seed1 >= 0 && seed1 < nelems && seed1 != cache.id && !(abl & 1)) pre = seed1;
+    }
+    if (__ballot(pre >= 0) != 0ull) coop_issue<DIM>(recs, pre, st, lane);
+    if (act && p + 1 < pend) {
+      cur = load_state<DIM, NT>(pid + C, mask, pphi, pb, x, stride, elem_ids, false);
+      cur.elem = e1;
+      if (read_ids && p + 2 < pend) e1 = ld<NT>(elem_ids + pid + 2 * C);
+    }
+    if (act && !s.m && (DIM == 2 || !seeded)) stg<NT>(elem_ids + pid, -1);
+    V3 dest{0, 0, 0};
+    bool done = true;
+    if (live) {
+      double rad;
+      done = false;
+      if constexpr (DIM == 2) {
+        if (abl & 2) {
+          dest.x = s.phi + 1.0;
+          dest.y = s.b;
+          rad = s.phi;
+        } else {
+          ppm::elliptical_point(ct, s.phi, s.b, h, k, d, dest.x, dest.y, rad);
+        }
+        stg<NT>(xt + pid, dest.x);
+        stg<NT>(xt + stride + pid, dest.y);
+        if (elem == -1) done = true;  // hpp:1051-1056 (seed == -nelems)
+        if (abl & 1) done = true;
+      } else {
+        if (abl & 2) {
+          dest = V3{s.x + 1e-3 * s.b, s.y, s.z};
+          rad = s.phi;
+        } else {
+          ppm::toroidal_point(ct, s.phi, s.b, s.x, s.y, h, k, d, dest.x, dest.y, dest.z, rad);
+        }
+        stg<NT>(xt + pid, dest.x);
+        stg<NT>(xt + stride + pid, dest.y);
+        stg<NT>(xt + 2 * stride + pid, dest.z);
+        done = (elem == -1);
+        // finishUnmoved: norm(dest-orig) < tol  <=>  |dest-orig|^2 < unmoved_sq (k_push_walk_rows)
+        const V3 dv = sub(dest, V3{s.x, s.y, s.z});
+        if (dot(dv, dv) < unmoved_sq) done = true;
+        if (abl & 1) done = true;
+      }
+      stg<NT>(pphi + pid, (float)rad);
+    }
+    bool need = false;
+    if (live) {
+      if constexpr (DIM == 3) {
+        if (!done && !inside_cached(cache, V3{s.x, s.y, s.z}, tol)) {
+          atomicAdd(&cnt->not_in_elem, 1);
+          elem = -1;
+          done = true;
+        }
+      }
+      if (!done) {  // first walk step on the cached record
+        int next;
+        if (step_cached(cache, dest, next)) {
+          done = true;
+        } else if (next == -1) {
+          elem = -1;
+          done = true;
+        } else {
+          elem = next;
+          if (1 >= cap) {
+            elem = -1;
+            atomicAdd(&cnt->not_found, 1);
+            done = true;
+          }
+        }
+      }
+      if (done) stg<NT>(elem_ids + pid, elem);
+      need = !done;
+    }
+    const unsigned long long bal = __ballot(need);
+    if (need) {
+      PendEntry en;
+      en.pid = pid;
+      en.elem = elem;
+      en.x = dest.x;
+      en.y = dest.y;
+      en.z = dest.z;
+      wq[qn + __popcll(bal & lt_mask)] = en;
+    }
+    qn += __popcll(bal);
+  }
+  if (lane == 0) wave_cnt[gwave] = qn;
+}
+
+// Second pass of the deferred walk.  Walk lengths are long-tailed (a crossing in a tet mesh takes
+// 1..8 steps), so a wave that simply stepped 64 entries until the last one finished would idle
+// most lanes.  Each wave therefore owns kPendRegions consecutive queue regions and REFILLS lanes
+// as they finish: a wave-uniform cursor (region, offset) hands the next unprocessed entries to
+// the free lanes, so every round's cooperative fetch + step runs with (nearly) all lanes busy.
+constexpr int kPendRegions = 4;
+template <int DIM>
+__global__ void __launch_bounds__(256, 4)
+    k_walk_pending(int nwaves, int TP, int G, const PendEntry* __restrict__ gq,
+                   const int* __restrict__ wave_cnt, const void* __restrict__ recs, int* elem_ids,
+                   int looplimit, Counters* cnt) {
+  constexpr int NP = DIM == 3 ? 8 : 4;
+  __shared__ double2 st_all[4 * 64 * NP];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double2* st = st_all + wave * 64 * NP;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const int cap = looplimit ? looplimit : kHardLoopCap;
+  const long long r0 = ((long long)blockIdx.x * 4 + wave) * G;  // first region
+  if (r0 >= nwaves) return;
+  const int nreg = (int)min((long long)G, nwaves - r0);
+  const int my_cnt = lane < nreg ? wave_cnt[r0 + lane] : 0;  // lane i holds the count of region i
+  int reg = 0, off = 0;                                      // wave-uniform cursor
+  int reg_cnt = __shfl(my_cnt, 0);
+  bool on = false;
+  PendEntry en{};
+  int welem = -1, loops = 1;
+  RecCache<DIM> cache;
+  cache.id = -1;
+  while (true) {
+    // ---- refill free lanes from the cursor
+    unsigned long long free_mask = __ballot(!on);
+    while (free_mask != 0ull && reg < nreg) {
+      const int avail = reg_cnt - off;
+      if (avail <= 0) {
+        ++reg;
+        off = 0;
+        reg_cnt = reg < nreg ? __shfl(my_cnt, reg) : 0;
+        continue;
+      }
+      const int rank = __popcll(free_mask & lt_mask);
+      const int take = min(avail, (int)__popcll(free_mask));
+      if (!on && rank < take) {
+        en = gq[(r0 + reg) * 64 * TP + off + rank];
+        welem = en.elem;
+        loops = 1;
+        on = true;
+      }
+      off += take;
+      free_mask = __ballot(!on);
+    }
+    if (__ballot(on) == 0ull) break;
+    // ---- one step for every busy lane
+    coop_fetch<DIM>(cache, recs, on ? welem : -1, st, lane);
+    if (on) {
+      int next;
+      bool fin = step_cached(cache, V3{en.x, en.y, en.z}, next);
+      if (!fin) {
+        if (next == -1) {
+          welem = -1;
+          fin = true;
+        } else {
+          welem = next;
+        }
+      }
+      ++loops;
+      if (!fin && loops >= cap) {
+        welem = -1;
+        atomicAdd(&cnt->not_found, 1);
+        fin = true;
+      }
+      if (fin) {
+        elem_ids[en.pid] = welem;
+        on = false;
+      }
+    }
+  }
+}
+
 MeshArrays arrays_of(const pp_mesh* mesh) {
   MeshArrays m;
   m.coords = mesh->d_coords.as<double>();
@@ -771,6 +1133,8 @@ Counters* g_cnt_dev = nullptr;
 struct CntRef {
   Counters* get() { return g_cnt_dev; }
 } g_cnt;
+
+pp::DevBuf g_pending_q, g_wave_cnt;  // deferred-walk queue of the fused kernel (grow-only, library lifetime)
 
 int reset_counters() {
   if (!g_cnt_dev) PP_HIP_CHECK(hipMalloc((void**)&g_cnt_dev, sizeof(Counters)));
@@ -949,12 +1313,52 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
       mesh->nelems, PP_MEMBER(ps, m_x, double), PP_MEMBER(ps, m_xtgt, double), ps->stride,       \
       PP_MEMBER(ps, m_b, float), PP_MEMBER(ps, m_phi, float), h, k, d, deg, mesh->tol,           \
       mesh->unmoved_sq, elem_ids_dev, elem_ids_seeded, looplimit, g_cnt.get()
+#define PP_ROWSQ_ARGS PP_ROWS_ARGS, g_pending_q.as<PendEntry>(), g_wave_cnt.as<int>(), abl
     // OCC = minimum waves per SIMD the register allocator must leave room for (tuning knob;
     // measured in profiles/): 3-D defaults to 4 (104 VGPRs, no spill)
     // OCC = waves per SIMD the register allocator must leave room for.  Measured on MI355X
     // (profiles/r01_*): 3-D is fastest at 4 (104 VGPRs, no spill); 5 spills, 3 hides less latency.
     static const int occ = getenv("PP_WALK_OCC") ? atoi(getenv("PP_WALK_OCC")) : 4;
-    if (rgrid > 0) {
+    // Two row-tiled variants (measured on MI355X, profiles/r01_c_*):
+    //   k_push_walk_rows   walks every particle to completion inside the column loop;
+    //   k_push_walk_rowsq  one step in the loop, cooperative LDS-DMA record fetch pipelined one
+    //                      column ahead, crossing particles finished by k_walk_pending.
+    // 3-D (128-B records, 8% of the particles cross per step, walks of 1..8 tets) is 8-30%
+    // faster with the deferred walk; 2-D (64-B records, cheap steps) is faster in one kernel.
+    // PP_WALK_QUEUE=0/1 forces one or the other (A/B knob).
+    const int wq_env = getenv("PP_WALK_QUEUE") ? atoi(getenv("PP_WALK_QUEUE")) : -1;  // per call
+    const int wq = wq_env >= 0 ? wq_env : (mesh->dim == 3 ? 1 : 0);
+    static const int abl = getenv("PP_ABL") ? atoi(getenv("PP_ABL")) : 0;  // timing ablations only
+    if (rgrid > 0 && wq > 0) {
+      const size_t lds = (size_t)(kBlock / 64) * 64 * (mesh->dim == 3 ? 8 : 4) * sizeof(double2);
+      const size_t nwaves = (size_t)rgrid * (kBlock / 64);
+      PP_HIP_CHECK(g_pending_q.reserve(nwaves * 64 * ps->tile_p * sizeof(PendEntry)));
+      PP_HIP_CHECK(g_wave_cnt.reserve(nwaves * sizeof(int)));
+      static const bool nt = getenv("PP_NT") ? atoi(getenv("PP_NT")) != 0 : true;  // A/B knob
+      if (mesh->dim == 2) {
+        if (nt)
+          k_push_walk_rowsq<2, 4, true><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
+        else
+          k_push_walk_rowsq<2, 4, false><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
+      } else if (occ <= 3) {
+        k_push_walk_rowsq<3, 3, false><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
+      } else if (nt) {
+        k_push_walk_rowsq<3, 4, true><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
+      } else {
+        k_push_walk_rowsq<3, 4, false><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
+      }
+      PP_LAUNCH_CHECK();
+      static const int G = getenv("PP_PEND_REGIONS") ? std::max(1, std::min(64, atoi(getenv("PP_PEND_REGIONS")))) : kPendRegions;
+      const unsigned pgrid = (rgrid + G - 1) / G;
+      if (mesh->dim == 2)
+        k_walk_pending<2><<<pgrid, kBlock, 0, st>>>((int)nwaves, ps->tile_p, G, g_pending_q.as<PendEntry>(),
+                                                   g_wave_cnt.as<int>(), mesh->d_records.p,
+                                                   elem_ids_dev, looplimit, g_cnt.get());
+      else
+        k_walk_pending<3><<<pgrid, kBlock, 0, st>>>((int)nwaves, ps->tile_p, G, g_pending_q.as<PendEntry>(),
+                                                   g_wave_cnt.as<int>(), mesh->d_records.p,
+                                                   elem_ids_dev, looplimit, g_cnt.get());
+    } else if (rgrid > 0) {
       if (mesh->dim == 2)
         k_push_walk_rows<2, 4><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS);
       else if (occ <= 3)
@@ -965,6 +1369,7 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
         k_push_walk_rows<3, 5><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS);
     }
 #undef PP_ROWS_ARGS
+#undef PP_ROWSQ_ARGS
   } else
   // DIM 2 follows search_mesh_2d: the caller's elem_ids are always read (-1 = own element)
   if (mesh->dim == 2) {

@@ -685,3 +685,43 @@ def test_migration_records_two_virtual_ranks(ppo, synth, capi):
     assert np.array_equal(np.concatenate(elem_all)[order], eo)
     _, xo = common.by_id(po.member(2)[0, :po.capacity()], mko, po.member(0)[:, :po.capacity()])
     assert np.array_equal(np.concatenate(x_all, axis=1)[:, order], xo)
+
+
+# ---------------------------------------------------------------- fused kernel variants
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("queue", ["0", "1"])
+@pytest.mark.parametrize("C,looplimit,deg", [(64, 200, 6.0), (64, 1, 6.0), (64, 2, 12.0), (8, 200, 6.0),
+                                             (48, 3, 25.0), (1, 200, 6.0)])
+def test_fused_variants_match_oracle(ppo, synth, capi, monkeypatch, dim, queue, C, looplimit, deg):
+    """Both row-tiled kernels (walk inside the column loop / deferred walk with the cooperative
+    record fetch) on ragged layouts, tight loop limits (particles cut off -> -1 and found == 0)
+    and pushes large enough to leave the domain."""
+    monkeypatch.setenv("PP_WALK_QUEUE", queue)
+    pop = common.population_2d(synth, num_ptcls=2500) if dim == 2 else common.population_3d(synth, num_ptcls=2500)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM, C=C)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM, C=C)
+    cap = po.capacity()
+    assert cap == pg.capacity()
+    ids_g = capi.DevArray.from_host(np.full(cap, -1, dtype=np.int32))
+    ids_o = None
+    for step in range(3):
+        if dim == 2:
+            ppo.elliptical_push(po, mo, H, K, D, deg, trig=1)
+            found_o, ids_o, _ = ppo.search_mesh_2d(mo, po, elem_ids=ids_o, looplimit=looplimit)
+            found_g = capi.push_search(mg, pg, H, K, D, deg, ids_g, seeded=True, looplimit=looplimit)
+        else:
+            ppo.toroidal_push(po, mo, H, K, D, deg, trig=1)
+            r = ppo.search_mesh(mo, po, elem_ids=ids_o, looplimit=looplimit)
+            ids_o, found_o = r["elem_ids"], r["found"]
+            found_g = capi.push_search(mg, pg, H, K, D, deg, ids_g, seeded=(step > 0), looplimit=looplimit)
+        live = po.slot_info()[1].astype(bool)
+        got = ids_g.to_host()[:cap]
+        assert np.array_equal(ids_o[:cap][live], got[live]), (step, int((ids_o[:cap][live] != got[live]).sum()))
+        assert bool(found_o) == bool(found_g), step
+        assert np.array_equal(po.member(1)[:, :cap][:, live], pg.member(1)[:, :cap][:, live])
+        if dim == 3:
+            a, b = po.member(0), po.member(1)
+            tmp = a.copy()
+            a[:] = b
+            b[:] = tmp
+            pg.swap_members(0, 1)

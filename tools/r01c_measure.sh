@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round-1 final measurements (run on the GPU box): bench lines, per-kernel rocprof stats, HBM
+# traffic counters with their calibration run, micro-benchmarks.  Output: gpurun_out/r01_c/
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r01_c
+mkdir -p $O
+cd $R
+timeout 600 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err
+timeout 300 python bench.py --remainder spread --no-cpu-baseline > $O/bench_c2_spread.json 2>/dev/null
+timeout 300 python bench.py --workload 2d --no-cpu-baseline > $O/bench_2d.json 2>/dev/null
+timeout 300 python bench.py --workload 2dc3 --no-cpu-baseline > $O/bench_2dc3.json 2>/dev/null
+timeout 120 tools/_ubg > $O/ub_gather.txt 2>&1
+timeout 120 tools/_ubs > $O/ub_stream.txt 2>&1
+cd /tmp; export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c2 -o p -- python3 $R/bench.py --no-cpu-baseline > $O/kt_c2.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_2d -o p -- python3 $R/bench.py --workload 2d --no-cpu-baseline > $O/kt_2d.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_2dc3 -o p -- python3 $R/bench.py --workload 2dc3 --no-cpu-baseline > $O/kt_2dc3.log 2>&1
+pass() { name=$1; shift
+  timeout 240 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc/$name -o p -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/pmc_$name.log 2>&1
+}
+pass fetch FETCH_SIZE TCC_EA0_RDREQ_sum
+pass write WRITE_SIZE TCC_EA0_WRREQ_sum
+pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
+pass tcc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE
+# calibration: the streaming skeleton moves exactly 37 B read + 32 B written per slot
+timeout 120 rocprofv3 --pmc FETCH_SIZE TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d $O/pmc/cal_fetch -o p -- $R/tools/_ubs > $O/pmc_cal_fetch.log 2>&1
+timeout 120 rocprofv3 --pmc WRITE_SIZE TCC_EA0_WRREQ_sum --kernel-trace --output-format csv -d $O/pmc/cal_write -o p -- $R/tools/_ubs > $O/pmc_cal_write.log 2>&1
+cd $R
+python tools/pmc_summary.py $O/pmc > $O/pmc_summary.txt 2>&1
+for k in c2 2d 2dc3; do f=$(find $O/kt_$k -name "*kernel_stats.csv" | head -1); cp "$f" $O/kernel_stats_$k.csv; done
+rm -rf $O/kt_c2 $O/kt_2d $O/kt_2dc3
+find $O/pmc -name "*.csv" ! -name "*counter_collection.csv" -delete
+cat $O/bench_c2.json; grep -B1 -A6 "rowsq\|s_rows<8, 4>\|pending" $O/pmc_summary.txt | head -80
