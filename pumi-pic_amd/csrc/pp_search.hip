@@ -690,6 +690,60 @@ __device__ __forceinline__ PState load_state(int pid, const unsigned char* __res
   return s;
 }
 
+// one particle of k_push_walk_rows: push, stores, (3-D) parent check, walk to completion
+template <int DIM>
+__device__ __forceinline__ void rows_particle(const PState& s, int pid, int e,
+                                              const ppm::ClassTerm& ct, RecCache<DIM>& cache,
+                                              const void* __restrict__ recs, int nelems,
+                                              double* __restrict__ xt, long long stride, float* pphi,
+                                              double h, double k, double d, double tol,
+                                              double unmoved_sq, int* elem_ids, int seeded,
+                                              int looplimit, Counters* cnt) {
+  if (!s.m) {
+    if (DIM == 2 || !seeded) elem_ids[pid] = -1;
+    return;
+  }
+  double rad;
+  V3 dest;
+  if constexpr (DIM == 2) {
+    int elem = s.elem;
+    ppm::elliptical_point(ct, s.phi, s.b, h, k, d, dest.x, dest.y, rad);
+    dest.z = 0;
+    xt[pid] = dest.x;
+    xt[stride + pid] = dest.y;
+    pphi[pid] = (float)rad;
+    if (elem == -1) elem = e;
+    if (elem == -nelems) {
+      elem_ids[pid] = -1;
+      return;
+    }
+    elem_ids[pid] = bcc_walk_cached<DIM>(cache, recs, elem, dest, looplimit, cnt);
+  } else {
+    int elem = seeded ? s.elem : e;
+    const V3 orig{s.x, s.y, s.z};
+    ppm::toroidal_point(ct, s.phi, s.b, orig.x, orig.y, h, k, d, dest.x, dest.y, dest.z, rad);
+    xt[pid] = dest.x;
+    xt[stride + pid] = dest.y;
+    xt[2 * stride + pid] = dest.z;
+    pphi[pid] = (float)rad;
+    bool done = (elem == -1);
+    // finishUnmoved: norm(dest-orig) < tol  <=>  |dest-orig|^2 < unmoved_sq (sqrt is monotone and
+    // correctly rounded; unmoved_sq = min{s : sqrt(s) >= tol} is found on the host)
+    const V3 dv = sub(dest, orig);
+    if (dot(dv, dv) < unmoved_sq) done = true;
+    if (!done) {
+      fetch(cache, recs, elem);
+      if (!inside_cached(cache, orig, tol)) {
+        atomicAdd(&cnt->not_in_elem, 1);
+        elem = -1;
+        done = true;
+      }
+    }
+    if (!done) elem = bcc_walk_cached<DIM>(cache, recs, elem, dest, looplimit, cnt);
+    elem_ids[pid] = elem;
+  }
+}
+
 template <int DIM, int OCC>
 __global__ void __launch_bounds__(256, OCC)
     k_push_walk_rows(const int* __restrict__ ntiles_dev, int C, int TP,
@@ -703,64 +757,59 @@ __global__ void __launch_bounds__(256, OCC)
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int tile = (int)(g / C);
   const int r = (int)(g - (long long)tile * C);
-  if (tile >= *ntiles_dev) return;
-  const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
-  const int start = chunk_start[c] + r;
-  const int pend = min(p0 + TP, chunk_width[c]);
-  const int e = r2e[c * C + r];
-  const ppm::ClassTerm ct = ppm::class_term(e < nelems ? class_id[e] : 1, deg, DIM == 3);
+  const bool valid = tile < *ntiles_dev;
+  int start = 0, p0 = 0, pend = 0, e = 0;
+  if (valid) {
+    const int c = tiles[2 * tile];
+    p0 = tiles[2 * tile + 1];
+    start = chunk_start[c] + r;
+    pend = min(p0 + TP, chunk_width[c]);
+    e = r2e[c * C + r];
+  }
+  const ppm::ClassTerm ct = ppm::class_term((valid && e < nelems) ? class_id[e] : 1, deg, DIM == 3);
   const bool read_ids = (DIM == 2) || seeded;
   RecCache<DIM> cache;
   cache.id = -1;
+  // thin tiles (at most 64/TP live rows): lane l takes (live row l/TP, column l%TP) and the tile
+  // is one iteration -- see k_push_walk_rowsq
+  {
+    const int lane = threadIdx.x & 63;
+    const bool alive0 = valid && p0 < pend && mask[start + p0 * C] != 0;
+    const unsigned long long live0 = __ballot(alive0);
+    const int nlive = __popcll(live0);
+    if (nlive * TP <= 64) {
+      if ((DIM == 2 || !seeded) && valid && !alive0)  // empty rows: the slots still read -1
+        for (int p = p0; p < pend; ++p) elem_ids[start + p * C] = -1;
+      const int krow = lane / TP, col = lane - krow * TP;
+      unsigned long long m = live0;
+      for (int j = 0; j < krow && m; ++j) m &= m - 1;
+      const bool have = krow < nlive;
+      const int src = have ? __builtin_ctzll(m) : 0;
+      const int t_start = __shfl(start, src), t_p0 = __shfl(p0, src), t_pend = __shfl(pend, src);
+      const int t_e = __shfl(e, src);
+      ppm::ClassTerm tct;
+      tct.dphi = __shfl(ct.dphi, src);
+      tct.st = __shfl(ct.st, src);
+      tct.ct = __shfl(ct.ct, src);
+      const int p = t_p0 + col;
+      if (have && p < t_pend) {
+        const int pid = t_start + p * C;
+        const PState s = load_state<DIM>(pid, mask, pphi, pb, x, stride, elem_ids, read_ids);
+        rows_particle<DIM>(s, pid, t_e, tct, cache, recs, nelems, xt, stride, pphi, h, k, d, tol,
+                           unmoved_sq, elem_ids, seeded, looplimit, cnt);
+      }
+      return;
+    }
+  }
+  if (!valid) return;
   PState cur = load_state<DIM>(start + p0 * C, mask, pphi, pb, x, stride, elem_ids, read_ids);
   for (int p = p0; p < pend; ++p) {
     const int pid = start + p * C;
     const PState s = cur;
     if (p + 1 < pend)  // prefetch the next particle of this row before the dependent walk
       cur = load_state<DIM>(pid + C, mask, pphi, pb, x, stride, elem_ids, read_ids);
-    if (!s.m) {
-      if (DIM == 2 || !seeded) elem_ids[pid] = -1;
-      continue;
-    }
-    double rad;
-    V3 dest;
-    if constexpr (DIM == 2) {
-      int elem = s.elem;
-      ppm::elliptical_point(ct, s.phi, s.b, h, k, d, dest.x, dest.y, rad);
-      dest.z = 0;
-      xt[pid] = dest.x;
-      xt[stride + pid] = dest.y;
-      pphi[pid] = (float)rad;
-      if (elem == -1) elem = e;
-      if (elem == -nelems) {
-        elem_ids[pid] = -1;
-        continue;
-      }
-      elem_ids[pid] = bcc_walk_cached<DIM>(cache, recs, elem, dest, looplimit, cnt);
-    } else {
-      int elem = seeded ? s.elem : e;
-      const V3 orig{s.x, s.y, s.z};
-      ppm::toroidal_point(ct, s.phi, s.b, orig.x, orig.y, h, k, d, dest.x, dest.y, dest.z, rad);
-      xt[pid] = dest.x;
-      xt[stride + pid] = dest.y;
-      xt[2 * stride + pid] = dest.z;
-      pphi[pid] = (float)rad;
-      bool done = (elem == -1);
-      // finishUnmoved: norm(dest-orig) < tol  <=>  |dest-orig|^2 < unmoved_sq (sqrt is monotone and
-      // correctly rounded; unmoved_sq = min{s : sqrt(s) >= tol} is found on the host)
-      const V3 dv = sub(dest, orig);
-      if (dot(dv, dv) < unmoved_sq) done = true;
-      if (!done) {
-        fetch(cache, recs, elem);
-        if (!inside_cached(cache, orig, tol)) {
-          atomicAdd(&cnt->not_in_elem, 1);
-          elem = -1;
-          done = true;
-        }
-      }
-      if (!done) elem = bcc_walk_cached<DIM>(cache, recs, elem, dest, looplimit, cnt);
-      elem_ids[pid] = elem;
-    }
+    rows_particle<DIM>(s, pid, e, ct, cache, recs, nelems, xt, stride, pphi, h, k, d, tol,
+                       unmoved_sq, elem_ids, seeded, looplimit, cnt);
   }
 }
 
@@ -782,9 +831,8 @@ __global__ void __launch_bounds__(256, OCC)
 //    with all of them stepping together, one cooperative fetch per round.  The column loop keeps
 //    no dependent second record load and no 1-of-64-lanes walk; the second pass never gathers
 //    x_tgt (a random 8-B gather costs a whole line from HBM).
-//  * XCD-aware block order: the hardware deals blockIdx round-robin over the 8 XCDs; every XCD
-//    gets a contiguous range of logical blocks (= consecutive tiles = the same chunks' rows) so a
-//    chunk's element records are pulled into ONE XCD's 4 MB L2 instead of all eight.
+//  * non-temporal particle streams, so the XCD's L2 keeps element records rather than particle
+//    data that is never re-read; thin tiles (<= 64/TP live rows) are transposed to one iteration.
   // 64-slot groups scanned by one wave of k_walk_pending
 
 struct alignas(16) PendEntry {  // deferred-walk queue entry
@@ -866,6 +914,108 @@ __device__ __forceinline__ void coop_fetch(RecCache<DIM>& c, const void* __restr
   wave_lds_sync();
 }
 
+// per-launch constants of the fused kernel's column arithmetic
+struct WalkArgs {
+  double* xt;
+  long long stride;
+  float* pphi;
+  double h, k, d, tol, unmoved_sq;
+  int* elem_ids;
+  int seeded, nelems, cap;
+  Counters* cnt;
+  int abl;
+};
+// One particle of one column, seed record already in `cache`: push, x_tgt/phi stores,
+// check_initial_parents (3-D), first walk step.  Returns true when the particle crossed into
+// `elem` and has to be finished by k_walk_pending; otherwise elem_ids[pid] is final.
+template <int DIM, bool NT>
+__device__ __forceinline__ bool column_math(const WalkArgs& A, const PState& s, bool act, bool live,
+                                            int pid, const ppm::ClassTerm& ct,
+                                            const RecCache<DIM>& cache, int& elem, V3& dest) {
+  if (act && !s.m && (DIM == 2 || !A.seeded)) stg<NT>(A.elem_ids + pid, -1);
+  if (!live) return false;
+  double rad;
+  bool done = false;
+  if constexpr (DIM == 2) {
+    if (A.abl & 2) {
+      dest.x = s.phi + 1.0;
+      dest.y = s.b;
+      rad = s.phi;
+    } else {
+      ppm::elliptical_point(ct, s.phi, s.b, A.h, A.k, A.d, dest.x, dest.y, rad);
+    }
+    stg<NT>(A.xt + pid, dest.x);
+    stg<NT>(A.xt + A.stride + pid, dest.y);
+    if (elem == -1) done = true;  // hpp:1051-1056 (seed == -nelems)
+  } else {
+    if (A.abl & 2) {
+      dest = V3{s.x + 1e-3 * s.b, s.y, s.z};
+      rad = s.phi;
+    } else {
+      ppm::toroidal_point(ct, s.phi, s.b, s.x, s.y, A.h, A.k, A.d, dest.x, dest.y, dest.z, rad);
+    }
+    stg<NT>(A.xt + pid, dest.x);
+    stg<NT>(A.xt + A.stride + pid, dest.y);
+    stg<NT>(A.xt + 2 * A.stride + pid, dest.z);
+    done = (elem == -1);
+    // finishUnmoved: norm(dest-orig) < tol  <=>  |dest-orig|^2 < unmoved_sq (k_push_walk_rows)
+    const V3 dv = sub(dest, V3{s.x, s.y, s.z});
+    if (dot(dv, dv) < A.unmoved_sq) done = true;
+  }
+  if (A.abl & 1) done = true;
+  stg<NT>(A.pphi + pid, (float)rad);
+  if constexpr (DIM == 3) {
+    if (!done && !inside_cached(cache, V3{s.x, s.y, s.z}, A.tol)) {
+      atomicAdd(&A.cnt->not_in_elem, 1);
+      elem = -1;
+      done = true;
+    }
+  }
+  if (!done) {  // first walk step on the cached record
+    int next;
+    if (step_cached(cache, dest, next)) {
+      done = true;
+    } else if (next == -1) {
+      elem = -1;
+      done = true;
+    } else {
+      elem = next;
+      if (1 >= A.cap) {
+        elem = -1;
+        atomicAdd(&A.cnt->not_found, 1);
+        done = true;
+      }
+    }
+  }
+  if (done) stg<NT>(A.elem_ids + pid, elem);
+  return !done;
+}
+// append the crossing particles of this column to the wave's queue region
+__device__ __forceinline__ void enqueue(bool need, int pid, int elem, const V3& dest, PendEntry* wq,
+                                        int& qn, unsigned long long lt_mask) {
+  const unsigned long long bal = __ballot(need);
+  if (need) {
+    PendEntry en;
+    en.pid = pid;
+    en.elem = elem;
+    en.x = dest.x;
+    en.y = dest.y;
+    en.z = dest.z;
+    wq[qn + __popcll(bal & lt_mask)] = en;
+  }
+  qn += __popcll(bal);
+}
+// seed element of a live particle (2-D: -1 = own element, -nelems = skip; 3-D: row element when
+// the caller gave no ids)
+template <int DIM>
+__device__ __forceinline__ int seed_of(const PState& s, int e, int seeded, int nelems) {
+  if (DIM == 2) {
+    const int el = (s.elem == -1) ? e : s.elem;
+    return el == -nelems ? -1 : el;
+  }
+  return seeded ? s.elem : e;
+}
+
 template <int DIM, int OCC, bool NT>
 __global__ void __launch_bounds__(256, OCC)
     k_push_walk_rowsq(const int* __restrict__ ntiles_dev, int C, int TP,
@@ -884,8 +1034,12 @@ __global__ void __launch_bounds__(256, OCC)
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   int qn = 0;  // wave-uniform number of queue entries written by this wave
 
+  // blockIdx is dealt round-robin over the 8 XCDs.  Giving every XCD a contiguous range of tiles
+  // (abl bit 16) keeps a chunk's records in one L2 but was measured at +2% on an even population
+  // and -20% on a skewed one (the over-full element's thin tiles all land on two XCDs), so the
+  // default keeps the hardware order.
   unsigned lb = blockIdx.x;
-  if (!(abl & 16)) {
+  if (abl & 16) {
     const unsigned nb = gridDim.x, xq = nb >> 3, xr = nb & 7, xcd = blockIdx.x & 7;
     lb = xcd * xq + min(xcd, xr) + (blockIdx.x >> 3);
   }
@@ -905,9 +1059,63 @@ __global__ void __launch_bounds__(256, OCC)
   }
   const ppm::ClassTerm ct = ppm::class_term((valid && e < nelems) ? class_id[e] : 1, deg, DIM == 3);
   const bool read_ids = (DIM == 2) || seeded;
-  const int cap = looplimit ? looplimit : kHardLoopCap;
+  WalkArgs A;
+  A.xt = xt;
+  A.stride = stride;
+  A.pphi = pphi;
+  A.h = h;
+  A.k = k;
+  A.d = d;
+  A.tol = tol;
+  A.unmoved_sq = unmoved_sq;
+  A.elem_ids = elem_ids;
+  A.seeded = seeded;
+  A.nelems = nelems;
+  A.cap = looplimit ? looplimit : kHardLoopCap;
+  A.cnt = cnt;
+  A.abl = abl;
   RecCache<DIM> cache;
   cache.id = -1;
+  // ---- thin tiles.  Rows fill from column 0, so the rows alive in this tile's first column bound
+  // the rows alive in all of it.  When at most 64/TP rows are alive (the tail of a chunk that holds
+  // one over-full element: BASELINE's "irregular occupancy") the column loop would run TP
+  // iterations with a handful of busy lanes; instead lane l takes (live row l/TP, column l%TP) and
+  // the whole tile is ONE iteration.  Loads are strided (one line per lane), which is cheap for
+  // the few particles concerned.
+  {
+    const bool alive0 = valid && p0 < pend && mask[start + p0 * C] != 0;
+    const unsigned long long live0 = __ballot(alive0);
+    const int nlive = __popcll(live0);
+    if (nlive * TP <= 64 && !(abl & 64)) {
+      if ((DIM == 2 || !seeded) && valid && !alive0)  // empty rows: the slots still read -1
+        for (int p = p0; p < pend; ++p) stg<NT>(elem_ids + start + p * C, -1);
+      const int krow = lane / TP, col = lane - krow * TP;
+      unsigned long long m = live0;
+      for (int j = 0; j < krow && m; ++j) m &= m - 1;  // drop the krow lowest live rows
+      const bool have = krow < nlive;
+      const int src = have ? __builtin_ctzll(m) : 0;
+      const int t_start = __shfl(start, src), t_p0 = __shfl(p0, src), t_pend = __shfl(pend, src);
+      const int t_e = __shfl(e, src);
+      ppm::ClassTerm tct;
+      tct.dphi = __shfl(ct.dphi, src);
+      tct.st = __shfl(ct.st, src);
+      tct.ct = __shfl(ct.ct, src);
+      const int p = t_p0 + col;
+      const bool act = have && p < t_pend;
+      const int pid = t_start + p * C;
+      PState s{};
+      if (act) s = load_state<DIM, NT>(pid, mask, pphi, pb, x, stride, elem_ids, read_ids);
+      const bool live = act && s.m;
+      int elem = live ? seed_of<DIM>(s, t_e, seeded, nelems) : -1;
+      const int want = (elem >= 0 && !(abl & 1)) ? elem : -1;
+      if (__ballot(want >= 0) != 0ull) coop_fetch<DIM>(cache, recs, want, st, lane);
+      V3 dest{0, 0, 0};
+      const bool need = column_math<DIM, NT>(A, s, act, live, pid, tct, cache, elem, dest);
+      enqueue(need, pid, elem, dest, wq, qn, lt_mask);
+      if (lane == 0) wave_cnt[gwave] = qn;
+      return;
+    }
+  }
   // Software pipeline over the columns.  At the top of column p everything issued during column
   // p-1 has landed (ONE vmcnt(0) per column): the particle state of p (registers) and the seed
   // records of p (LDS staging, DMA'd from the element id that was read one column earlier).
@@ -929,15 +1137,7 @@ __global__ void __launch_bounds__(256, OCC)
     const PState s = cur;
     const bool live = act && s.m;
     // seed element of this column (known before the push; `done` cases just fetch in vain)
-    int elem = -1;
-    if (live) {
-      if (DIM == 2) {
-        elem = (s.elem == -1) ? e : s.elem;
-        if (elem == -nelems) elem = -1;
-      } else {
-        elem = seeded ? s.elem : e;
-      }
-    }
+    int elem = live ? seed_of<DIM>(s, e, seeded, nelems) : -1;
     const int want = (elem >= 0 && elem != cache.id && !(abl & 1)) ? elem : -1;
     coop_collect<DIM>(cache, want >= 0 && want == pre, want, st, lane);
     wave_lds_sync();
@@ -956,81 +1156,9 @@ __global__ void __launch_bounds__(256, OCC)
       cur.elem = e1;
       if (read_ids && p + 2 < pend) e1 = ld<NT>(elem_ids + pid + 2 * C);
     }
-    if (act && !s.m && (DIM == 2 || !seeded)) stg<NT>(elem_ids + pid, -1);
     V3 dest{0, 0, 0};
-    bool done = true;
-    if (live) {
-      double rad;
-      done = false;
-      if constexpr (DIM == 2) {
-        if (abl & 2) {
-          dest.x = s.phi + 1.0;
-          dest.y = s.b;
-          rad = s.phi;
-        } else {
-          ppm::elliptical_point(ct, s.phi, s.b, h, k, d, dest.x, dest.y, rad);
-        }
-        stg<NT>(xt + pid, dest.x);
-        stg<NT>(xt + stride + pid, dest.y);
-        if (elem == -1) done = true;  // hpp:1051-1056 (seed == -nelems)
-        if (abl & 1) done = true;
-      } else {
-        if (abl & 2) {
-          dest = V3{s.x + 1e-3 * s.b, s.y, s.z};
-          rad = s.phi;
-        } else {
-          ppm::toroidal_point(ct, s.phi, s.b, s.x, s.y, h, k, d, dest.x, dest.y, dest.z, rad);
-        }
-        stg<NT>(xt + pid, dest.x);
-        stg<NT>(xt + stride + pid, dest.y);
-        stg<NT>(xt + 2 * stride + pid, dest.z);
-        done = (elem == -1);
-        // finishUnmoved: norm(dest-orig) < tol  <=>  |dest-orig|^2 < unmoved_sq (k_push_walk_rows)
-        const V3 dv = sub(dest, V3{s.x, s.y, s.z});
-        if (dot(dv, dv) < unmoved_sq) done = true;
-        if (abl & 1) done = true;
-      }
-      stg<NT>(pphi + pid, (float)rad);
-    }
-    bool need = false;
-    if (live) {
-      if constexpr (DIM == 3) {
-        if (!done && !inside_cached(cache, V3{s.x, s.y, s.z}, tol)) {
-          atomicAdd(&cnt->not_in_elem, 1);
-          elem = -1;
-          done = true;
-        }
-      }
-      if (!done) {  // first walk step on the cached record
-        int next;
-        if (step_cached(cache, dest, next)) {
-          done = true;
-        } else if (next == -1) {
-          elem = -1;
-          done = true;
-        } else {
-          elem = next;
-          if (1 >= cap) {
-            elem = -1;
-            atomicAdd(&cnt->not_found, 1);
-            done = true;
-          }
-        }
-      }
-      if (done) stg<NT>(elem_ids + pid, elem);
-      need = !done;
-    }
-    const unsigned long long bal = __ballot(need);
-    if (need) {
-      PendEntry en;
-      en.pid = pid;
-      en.elem = elem;
-      en.x = dest.x;
-      en.y = dest.y;
-      en.z = dest.z;
-      wq[qn + __popcll(bal & lt_mask)] = en;
-    }
-    qn += __popcll(bal);
+    const bool need = column_math<DIM, NT>(A, s, act, live, pid, ct, cache, elem, dest);
+    enqueue(need, pid, elem, dest, wq, qn, lt_mask);
   }
   if (lane == 0) wave_cnt[gwave] = qn;
 }

@@ -6,6 +6,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r01_c
 mkdir -p $O
 cd $R
+[ -x tools/_ubg ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ub_gather.hip -o tools/_ubg
+[ -x tools/_ubs ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ub_stream.hip -o tools/_ubs
 timeout 600 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err
 timeout 300 python bench.py --remainder spread --no-cpu-baseline > $O/bench_c2_spread.json 2>/dev/null
 timeout 300 python bench.py --workload 2d --no-cpu-baseline > $O/bench_2d.json 2>/dev/null
