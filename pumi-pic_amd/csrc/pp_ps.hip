@@ -381,40 +381,55 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
                               Totals* tot) {
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int tile = (int)(g / C), r = (int)(g - (long long)tile * C);
-  int live = 0;
-  if (tile < *ntiles_dev) {
-    const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
-    const int start = chunk_start[c] + r, pend = min(p0 + TP, chunk_width[c]);
-    const int e = r2e[c * C + r];
-    int stay = 0;
-    for (int p = p0; p < pend; ++p) {
-      const int pid = start + p * C;
-      if (!mask[pid]) continue;
-      const int ne_ = new_element[pid];
-      if (ne_ == -1) continue;
+  if (tile >= *ntiles_dev) return;
+  const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
+  const int start = chunk_start[c] + r, pend = min(p0 + TP, chunk_width[c]);
+  const int e = r2e[c * C + r];
+  int stay = 0;
+  for (int pb = p0; pb < pend; pb += 8) {  // 16 independent loads in flight, then the histogram
+    int nel[8];
+    unsigned char mk[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int pid = start + (pb + j) * C;
+      mk[j] = 0;
+      nel[j] = -1;
+      if (pb + j < pend) {
+        mk[j] = mask[pid];
+        nel[j] = new_element[pid];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ne_ = nel[j];
+      if (!mk[j] || ne_ == -1) continue;
       if (ne_ < 0 || ne_ >= ne) {
         tot->invalid = 1;
         continue;
       }
-      ++live;
       if (ne_ == e)
         ++stay;
       else
         atomicAdd(&ppe[ne_], 1);
     }
-    if (stay) atomicAdd(&ppe[e], stay);
   }
-  for (int o = 32; o > 0; o >>= 1) live += __shfl_down(live, o);
-  if ((threadIdx.x & 63) == 0 && live) atomicAdd(&tot->active, live);
+  if (stay) atomicAdd(&ppe[e], stay);
 }
+// live particles and non-empty elements of the new population, from the histogram: one atomic per
+// wave of ELEMENTS (a per-wave atomic on one counter in the particle-sized kernels serialises at
+// ~10 ns each and used to cost more than the histogram itself)
 __global__ void k_nonempty(int ne, const int* __restrict__ ppe, Totals* tot) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  int nz = (i < ne && ppe[i] > 0) ? 1 : 0;
-  for (int o = 32; o > 0; o >>= 1) nz += __shfl_down(nz, o);
-  if ((threadIdx.x & 63) == 0 && nz) atomicAdd(&tot->nonempty, nz);
-}
-__global__ void k_count_added_active(int n_new, Totals* tot) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&tot->active, n_new);
+  const int n = i < ne ? ppe[i] : 0;
+  int nz = n > 0 ? 1 : 0, sum = n;
+  for (int o = 32; o > 0; o >>= 1) {
+    nz += __shfl_down(nz, o);
+    sum += __shfl_down(sum, o);
+  }
+  if ((threadIdx.x & 63) == 0 && nz) {
+    atomicAdd(&tot->nonempty, nz);
+    atomicAdd(&tot->active, sum);
+  }
 }
 // single-block reduction of the chunk widths (sum, #non-zero) -- replaces one atomic per chunk
 __global__ void k_reduce_widths(int nchunks, const int* __restrict__ widths, Totals* tot) {
@@ -477,15 +492,24 @@ __global__ void k_tile_fill2(const int* __restrict__ ntiles_dev, int nchunks, in
 __global__ void k_init_slots_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
                                    const int* __restrict__ tiles, const int* __restrict__ chunk_start,
                                    const int* __restrict__ chunk_width, const int* __restrict__ r2e,
-                                   int* __restrict__ slot_elem, int* __restrict__ row_cursor) {
+                                   const int* __restrict__ ppe, int ne,
+                                   int* __restrict__ slot_elem, int* __restrict__ row_cursor,
+                                   unsigned char* __restrict__ new_mask) {
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int tile = (int)(g / C), r = (int)(g - (long long)tile * C);
   if (tile >= *ntiles_dev) return;
   const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
   const int start = chunk_start[c] + r, pend = min(p0 + TP, chunk_width[c]);
   const int e = r2e[c * C + r];
+  // a row's particles take its slots in column order (the row cursor starts at column 0 and
+  // advances by C), so the new mask is a function of the new per-element counts: written here as
+  // coalesced runs instead of one scattered byte store per moved particle
+  const int cnt = e < ne ? ppe[e] : 0;
   if (p0 == 0) row_cursor[c * C + r] = start;
-  for (int p = p0; p < pend; ++p) slot_elem[start + p * C] = e;
+  for (int p = p0; p < pend; ++p) {
+    slot_elem[start + p * C] = e;
+    new_mask[start + p * C] = p < cnt ? 1 : 0;
+  }
 }
 __global__ void k_rows_cursor_empty(int nchunks, int C, const int* __restrict__ chunk_width,
                                     const int* __restrict__ chunk_start, int* __restrict__ row_cursor) {
@@ -569,7 +593,6 @@ __global__ void k_move_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
       stay |= 1u << (p - p0);
     } else {
       const int idx = atomicAdd(&row_cursor[e2r_new[ne_]], C_new);
-      new_mask[idx] = 1;
       copy_members(a, pid, idx);
     }
   }
@@ -577,7 +600,6 @@ __global__ void k_move_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
     int idx = atomicAdd(&row_cursor[e2r_new[e]], __popc(stay) * C_new);
     for (int p = p0; p < pend; ++p)
       if (stay & (1u << (p - p0))) {
-        new_mask[idx] = 1;
         copy_members(a, start + p * C, idx);
         idx += C_new;
       }
@@ -615,25 +637,36 @@ __global__ void k_assign_tiled(const int* __restrict__ ntiles_dev, int C, int TP
   const int start = chunk_start[c] + r, pend = min(p0 + TP, chunk_width[c]);
   const int e = r2e[c * C + r];
   unsigned stay = 0;
-  for (int p = p0; p < pend; ++p) {
-    const int pid = start + p * C;
-    int idx = -1;
-    if (mask[pid]) {
-      const int ne_ = new_element[pid];
-      if (ne_ == e)
-        stay |= 1u << (p - p0);
-      else if (ne_ != -1) {
-        idx = atomicAdd(&row_cursor[e2r_new[ne_]], C_new);
-        new_mask[idx] = 1;
+  for (int pb = p0; pb < pend; pb += 8) {  // loads of 8 columns in flight, then the slot atomics
+    int nel[8];
+    unsigned char mk[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int pid = start + (pb + j) * C;
+      mk[j] = 0;
+      nel[j] = -1;
+      if (pb + j < pend) {
+        mk[j] = mask[pid];
+        nel[j] = new_element[pid];
       }
     }
-    new_idx[pid] = idx;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (pb + j >= pend) continue;
+      int idx = -1;
+      if (mk[j]) {
+        if (nel[j] == e)
+          stay |= 1u << (pb + j - p0);
+        else if (nel[j] != -1)
+          idx = atomicAdd(&row_cursor[e2r_new[nel[j]]], C_new);
+      }
+      new_idx[start + (pb + j) * C] = idx;
+    }
   }
   if (stay) {
     int idx = atomicAdd(&row_cursor[e2r_new[e]], __popc(stay) * C_new);
     for (int p = p0; p < pend; ++p)
       if (stay & (1u << (p - p0))) {
-        new_mask[idx] = 1;
         new_idx[start + p * C] = idx;
         idx += C_new;
       }
@@ -920,7 +953,6 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
         ps->d_mask.as<unsigned char>(), new_element, ne, ppe, tot);
   if (n_new > 0) {
     k_count_added<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ne, ppe, tot);
-    k_count_added_active<<<1, 64, 0, st>>>(n_new, tot);
   }
   if (ne > 0) k_nonempty<<<grid_for(ne), kBlock, 0, st>>>(ne, ppe, tot);
   // Sort keys are (window, count) with count < key_base; an upper bound known on the host avoids
@@ -977,12 +1009,11 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       ps->s_s2c2.as<int>(), tot);
   k_rows<<<grid_for(nrows), kBlock, 0, st>>>(nrows, ne, L.sorted ? 1 : 0, L.index,
                                              ps->s_r2e2.as<int>(), ps->s_e2r2.as<int>());
-  PP_HIP_CHECK(hipMemsetAsync(ps->s_mask2.p, 0, (size_t)std::max(new_capacity, 1), st));
   k_rows_cursor_empty<<<grid_for(nrows), kBlock, 0, st>>>(nchunks, C_new, L.widths, L.chunk_start,
                                                           ps->s_rowstart.as<int>());
   k_init_slots_tiled<<<grid_for((size_t)ntiles_max * C_new), kBlock, 0, st>>>(
       new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_r2e2.as<int>(),
-      ps->s_slot2.as<int>(), ps->s_rowstart.as<int>());
+      ppe, ne, ps->s_slot2.as<int>(), ps->s_rowstart.as<int>(), ps->s_mask2.as<unsigned char>());
   // ---- swap buffer sizing (SCS_rebuild.h:223-229)
   int64_t swap_stride = ps->swap_stride;
   if (swap_stride < new_capacity || swap_stride * ps->minimize_size < new_capacity) {
