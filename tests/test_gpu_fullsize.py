@@ -1,0 +1,162 @@
+"""BASELINE.json's configurations at FULL size on the GPU, checked through size-independent
+properties (the oracle needs minutes at these sizes): every reported element really contains its
+particle (independent numpy barycentric test on a sample), the two fused kernel variants agree on
+all 10 M ids, rebuild conserves the population (count, id sum, per-element histogram), scatter
+conserves mass, ps_combo160's pseudo-push/redistribute/rebuild loop keeps every particle."""
+import os
+
+import numpy as np
+import pytest
+
+import bench
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi(pp):
+    from pumipic_amd import capi as c
+    c.init(0)
+    return c
+
+
+def _tet_bcc(coords, e2v, elems, pts):
+    """barycentric coordinates (sum 1) of pts (n,3) in tets `elems`, plain numpy, own formula"""
+    v = coords.reshape(-1, 3)[e2v.reshape(-1, 4)[elems]]  # n,4,3
+    T = np.stack([v[:, 1] - v[:, 0], v[:, 2] - v[:, 0], v[:, 3] - v[:, 0]], axis=2)
+    lam = np.linalg.solve(T, (pts - v[:, 0])[..., None])[..., 0]
+    return np.concatenate([1 - lam.sum(1, keepdims=True), lam], axis=1)
+
+
+def test_c2_full_size_properties(pp, capi, monkeypatch):
+    """configs[1]: 100 800 tets, 10 M particles, push+search only."""
+    w = bench.build_workload(pp, capi, "c2", 10_000_000, 0, 1, 0.5)
+    s = pp.synth
+    mesh, ps = w["mesh"], w["ps"]
+    cap = ps.capacity()
+    ids = capi.DevArray.from_host(np.full(cap, -1, dtype=np.int32))
+    mask = ps.slot_info()[1].astype(bool)
+    assert int(mask.sum()) == 10_000_000
+    for step in range(3):
+        found = capi.push_search(mesh, ps, s.XGC_H, s.XGC_K, s.XGC_D, 0.5, ids, seeded=(step > 0),
+                                 looplimit=200)
+        assert found
+        ps.swap_members(0, 1)
+    got = ids.to_host()[:cap]
+    x = ps.member(0)[:, :cap]  # after the swap member 0 is the searched position
+    live = np.flatnonzero(mask)
+    assert (got[live] >= -1).all() and (got[live] < w["ne"]).all()
+    inside = live[got[live] >= 0]
+    assert len(inside) > 0.99 * len(live)
+    rng = np.random.default_rng(5)
+    samp = rng.choice(inside, size=200_000, replace=False)
+    lam = _tet_bcc(w["coords"], w["e2v"], got[samp], x[:, samp].T)
+    assert lam.min() > -1e-9, lam.min()  # each sampled particle lies in the element it was given
+    after = got
+    # the two row-tiled kernels (walk in the loop / deferred walk) agree on every id
+    res = {}
+    state = [ps.member(m).copy() for m in range(5)]
+    for q in ("0", "1"):
+        monkeypatch.setenv("PP_WALK_QUEUE", q)
+        for m in range(5):
+            ps.set_member(m, state[m])
+        idq = capi.DevArray.from_host(after.copy())
+        capi.push_search(mesh, ps, s.XGC_H, s.XGC_K, s.XGC_D, 1.5, idq, seeded=True, looplimit=200)
+        res[q] = (idq.to_host()[:cap][live], ps.member(1)[:, :cap][:, live])
+    assert np.array_equal(res["0"][0], res["1"][0])
+    assert np.array_equal(res["0"][1], res["1"][1])
+    assert (res["0"][0] != after[live]).mean() > 0.05  # the comparison covered real walks
+
+
+def test_c3_full_size_properties(pp, capi):
+    """configs[2] (2-D literal): push + search + updatePtclPositions + rebuild + gyroScatter."""
+    w = bench.build_workload(pp, capi, "2dc3", 10_000_000, 0, 1, 0.5)
+    s = pp.synth
+    mesh, ps = w["mesh"], w["ps"]
+    fwd, _ = capi.create_gyro_ring_mappings(mesh)
+    n0 = ps.nPtcls()
+    id_sum0 = int(np.arange(n0, dtype=np.int64).sum())
+    for step in range(3):
+        cap = ps.capacity()
+        ids = capi.DevArray.from_host(np.full(cap, -1, dtype=np.int32))
+        capi.push_search(mesh, ps, s.XGC_H, s.XGC_K, s.XGC_D, 0.5, ids, seeded=True, looplimit=200)
+        want = ids.to_host()[:cap]
+        mask = ps.slot_info()[1].astype(bool)
+        pid_before = ps.member(2)[0, :cap][mask]
+        elem_before = want[mask]
+        xt_before = ps.member(1)[:2, :cap][:, mask]
+        ps.rebuild_commit(ids, 0, 1)
+        se, mk = ps.slot_info()
+        mk = mk.astype(bool)
+        cap2 = ps.capacity()
+        pid_after = ps.member(2)[0, :cap2][mk]
+        kept = elem_before >= 0
+        assert ps.nPtcls() == int(kept.sum()) == int(mk.sum())
+        # every particle sits in the row of the element the search gave it
+        order_b = np.argsort(pid_before[kept])
+        order_a = np.argsort(pid_after)
+        assert np.array_equal(pid_before[kept][order_b], pid_after[order_a])
+        assert np.array_equal(elem_before[kept][order_b], se[:cap2][mk][order_a])
+        # updatePtclPositions fused into the move: x <- x_tgt, x_tgt <- 0 (pseudoXGCm.cpp:92-108)
+        assert np.array_equal(ps.member(0)[:2, :cap2][:, mk][:, order_a], xt_before[:, kept][:, order_b])
+        assert not ps.member(1)[:, :cap2][:, mk].any()
+        wsum = capi.gyro_scatter(mesh, ps, fwd).to_host()
+        assert np.isfinite(wsum).all() and wsum.min() >= 0
+    if ps.nPtcls() == n0:
+        assert int(ps.member(2)[0, :ps.capacity()][ps.slot_info()[1].astype(bool)].astype(np.int64).sum()) == id_sum0
+
+
+@pytest.mark.parametrize("kind", ["scs", "csr"])
+def test_c4_ps_combo160_full_size(pp, capi, kind):
+    """configs[3]: ps_combo160 'largeE_smallP' stress point, 1 M elements / 1 M particles, uniform
+    distribution: pseudo-push then redistribute(p=0.5) + rebuild (performance_tests/ps_combo160.cpp:
+    134-232), 3 rounds."""
+    ne = npt = 1_000_000
+    rng = np.random.default_rng(0)
+    elems = rng.integers(0, ne, size=npt).astype(np.int32)
+    ppe = np.bincount(elems, minlength=ne).astype(np.int32)
+    order = np.argsort(elems, kind="stable").astype(np.int32)
+    members = capi.PERF160
+    info = [np.zeros((17, npt)), np.zeros((4, npt), dtype=np.int32), np.arange(npt, dtype=np.int64)[None, :]]
+    if kind == "scs":
+        ps = capi.PS.scs(members, ne, ppe, C_=64, sigma=ne, V=1024, particle_elements=elems,
+                         particle_info=info)
+    else:
+        ps = capi.PS.csr(members, ne, ppe, particle_elements=elems, particle_info=info)
+    parent = capi.DevArray.from_host(np.sqrt(np.arange(ne, dtype=np.float64)) * np.arange(ne))
+    assert ps.nPtcls() == npt
+    for rnd in range(3):
+        capi.pseudo_push160(ps, parent)
+        cap = ps.capacity()
+        se, mk = ps.slot_info()
+        mk = mk.astype(bool)
+        d = ps.member(0)[:, :cap]
+        nums = ps.member(1)[:, :cap]
+        lint = ps.member(2)[0, :cap]
+        slots = np.flatnonzero(mk)
+        assert np.array_equal(lint[slots], slots)                   # lint(p) = p
+        assert np.array_equal(nums[:, slots], 4 * slots[None, :] + np.arange(4)[:, None])
+        e_of = se[:cap][slots].astype(np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            expect = 10.3 * 10.3 * 10.3 / np.sqrt(slots.astype(np.float64)) / np.sqrt(e_of) + np.sqrt(e_of) * e_of
+        ok = np.isfinite(expect)
+        assert np.allclose(d[:, slots][:, ok], expect[ok][None, :], rtol=1e-14, atol=0)
+        if kind == "scs":  # padded lanes run the functor with mask == 0; CSR has no padded lanes
+            assert (d[:, ~mk] == 0).all() and (nums[:, ~mk] == -1).all()
+        # redistribute: half of the particles draw a new element (uniform), the rest stay
+        new_elem = se[:cap].copy()
+        move = mk & (rng.random(cap) < 0.5)
+        new_elem[move] = rng.integers(0, ne, size=int(move.sum()))
+        new_elem[~mk] = -1
+        # tag every particle with its slot so the move can be followed
+        tag = np.zeros((1, ps.info().stride), dtype=np.int64)
+        tag[0, slots] = slots
+        ps.set_member(2, tag)
+        ps.rebuild(new_elem)
+        assert ps.nPtcls() == npt
+        se2, mk2 = ps.slot_info()
+        mk2 = mk2.astype(bool)
+        cap2 = ps.capacity()
+        tags = ps.member(2)[0, :cap2][mk2]
+        assert np.array_equal(np.sort(tags), slots)                  # nobody lost or duplicated
+        assert np.array_equal(se2[:cap2][mk2], new_elem[tags])       # everybody in the requested row
