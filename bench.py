@@ -223,6 +223,18 @@ def main():
 
     if rank == 0:
         kms = st.kernel_avg_ms()
+        # HBM bytes per launch from the PMC counters: collected with rocprofv3 in separate --pmc
+        # passes of THIS command (tools/r01_measure.sh) and calibrated as DESIGN.md section 4 says;
+        # a profiler cannot wrap itself, so the committed summary is reported with its provenance
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.workload)
+        if os.path.exists(tf):
+            try:
+                tj = json.load(open(tf))
+                if tj.get("particles") == a.particles and tj.get("remainder", "last") == a.remainder:
+                    traffic = tj["traffic_bytes_per_step"]
+            except (ValueError, KeyError):
+                traffic = None
         bpp = BYTES[{"2dc3": "2d"}.get(a.workload, a.workload)]
         achieved = bpp * nlive / (kms * 1e-3) / 1e9 if kms else None
         out = {
@@ -245,7 +257,9 @@ def main():
                  "2dc3": "push+search+rebuild+gyroScatter x2, deg/push=%g" % a.deg}[a.workload]),
                 "parallelism": "element-block partition, %d rank(s), full-mesh replica" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, calibrated; "
+                                         "profiles/traffic_%s.json)" % a.workload,
                          "kernel": ("k_push_walk_rowsq<3> + k_walk_pending<3> (one pp_push_search call)"
                                     if w["dim"] == 3 else "k_push_walk_rows<2>"), "kernel_ms": kms,
                          "bytes_per_particle": bpp},

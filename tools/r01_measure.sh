@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round-1 final measurements (run on the GPU box): bench lines, per-kernel rocprof stats, HBM
-# traffic counters with their calibration run, micro-benchmarks.  Output: gpurun_out/r01_c/
+# traffic counters with their calibration run, micro-benchmarks.  Output: gpurun_out/r01_d/
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r01_c
+O=$R/gpurun_out/r01_d
 mkdir -p $O
 cd $R
 [ -x tools/_ubg ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ub_gather.hip -o tools/_ubg
@@ -33,4 +33,5 @@ python tools/pmc_summary.py $O/pmc > $O/pmc_summary.txt 2>&1
 for k in c2 2d 2dc3; do f=$(find $O/kt_$k -name "*kernel_stats.csv" | head -1); cp "$f" $O/kernel_stats_$k.csv; done
 rm -rf $O/kt_c2 $O/kt_2d $O/kt_2dc3
 find $O/pmc -name "*.csv" ! -name "*counter_collection.csv" -delete
+python tools/traffic_json.py $O c2 10000000 $O/traffic_c2.json > /dev/null
 cat $O/bench_c2.json; grep -B1 -A6 "rowsq\|s_rows<8, 4>\|pending" $O/pmc_summary.txt | head -80

@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""profiles/traffic_<workload>.json from a tools/r01_measure.sh output directory: FETCH_SIZE and
+WRITE_SIZE per kernel, scaled by the calibration run of tools/ub_stream.hip (s_rows<8,4> moves
+exactly 37 B read + 32 B written per slot)."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def main(out_dir, workload, particles, dest):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(out_dir + "/pmc/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+
+    def mean(k, c):
+        for name in agg:
+            if k in name and c in agg[name]:
+                v = agg[name][c]
+                return sum(v) / len(v)
+        return None
+
+    kib = 1024.0
+    cap = 10485760 + 64 * 8 * 100  # slots of the calibration kernel (tools/ub_stream.hip)
+    rf = 37.0 * cap / (mean("s_rows<8, 4>", "FETCH_SIZE") * kib)
+    wf = 32.0 * cap / (mean("s_rows<8, 4>", "WRITE_SIZE") * kib)
+    out = {"workload": workload, "particles": particles, "remainder": "last",
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python3 bench.py --steps 10 "
+                     "--warmup 3`, tools/r01_measure.sh; scaled by the calibration run of tools/ub_stream.hip "
+                     "s_rows<8,4>: FETCH_SIZE[KiB] x 1024 x %.4f, WRITE_SIZE[KiB] x 1024 x %.4f" % (rf, wf),
+           "kernels": {}}
+    tot = 0.0
+    for k in ("k_push_walk_rowsq<3", "k_walk_pending<3"):
+        r = mean(k, "FETCH_SIZE") * kib * rf
+        w = mean(k, "WRITE_SIZE") * kib * wf
+        out["kernels"][k + ">"] = {"read_bytes": r, "write_bytes": w}
+        tot += r + w
+    out["traffic_bytes_per_step"] = tot
+    out["algorithmic_bytes_per_step"] = 69.0 * particles
+    json.dump(out, open(dest, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4])
