@@ -7,7 +7,8 @@ A "step" is one pass of the hot path over the resident particle population:
   c2 (default, BASELINE.json configs[1]): fused toroidal push + BCC adjacency walk on the
       100 800-tet tokamak mesh, 10 M particles per GPU, SCS layout (C=64), no rebuild; positions
       ping-pong x <-> x_tgt and the walk is re-seeded from the previous step's element ids.
-  c3 (configs[2]): c2 + updatePtclPositions + SCS rebuild + gyroScatter x2 every step.
+  c3 (configs[2]): c2 + updatePtclPositions + SCS rebuild + gyroScatter x2 every step (tet variant
+      of the ring map: 4 vertices per ring point); 2dc3 is the 2-D literal of it.
   2d : the literal 2-D pseudoXGCm step (elliptical push + search_mesh_2d) on 100 352 triangles.
 
 Inputs are synthetic (pumi-pic_amd/synth.py) and resident in HBM before the timed region.
@@ -93,9 +94,7 @@ class Stepper:
         self.ids = capi.DevArray.from_host(np.full(cap, -1, dtype=np.int32))
         self.first = True
         self.kernel_ms = []
-        if name == "c3":
-            raise SystemExit("workload c3 needs a 3-D gyro map: use --workload 2dc3")
-        if name == "2dc3":
+        if name in ("c3", "2dc3"):
             self.fwd, self.bkwd = capi.create_gyro_ring_mappings(self.mesh)
             self.w_f = capi.DevArray(self.mesh.nverts, np.float64)
             self.w_b = capi.DevArray(self.mesh.nverts, np.float64)
@@ -108,6 +107,10 @@ class Stepper:
         if self.name == "c2":
             capi.push_search(self.mesh, self.ps, self.h, self.k, self.d, self.deg, self.ids,
                              seeded=not self.first, looplimit=200, want_found=False)
+        elif self.name == "c3":
+            # rebuilt every step: every particle sits in its row's element, no seed ids needed
+            capi.push_search(self.mesh, self.ps, self.h, self.k, self.d, self.deg, self.ids,
+                             seeded=False, looplimit=200, want_found=False)
         else:
             capi.push_search(self.mesh, self.ps, self.h, self.k, self.d, self.deg, self.ids,
                              seeded=True, looplimit=200, want_found=False)
@@ -117,7 +120,7 @@ class Stepper:
         self.first = False
         if self.name == "c2":
             self.ps.swap_members(0, 1)  # x <-> x_tgt (O(1)); no rebuild in config 2
-        elif self.name == "2dc3":
+        elif self.name in ("c3", "2dc3"):
             # the drivers' rebuild(): updatePtclPositions + migrate/rebuild (pseudoXGCm.cpp:116-140)
             self.ps.rebuild_commit(self.ids)
             capi.gyro_scatter(self.mesh, self.ps, self.fwd, out=self.w_f)
@@ -168,7 +171,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "2d", "2dc3"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "2d", "2dc3"])
     ap.add_argument("--particles", type=int, default=10_000_000, help="particles per GPU")
     ap.add_argument("--deg", type=float, default=0.5, help="degrees per push (testing.cmake:117)")
     ap.add_argument("--cpu-sample", type=int, default=300_000)
@@ -235,7 +238,7 @@ def main():
                     traffic = tj["traffic_bytes_per_step"]
             except (ValueError, KeyError):
                 traffic = None
-        bpp = BYTES[{"2dc3": "2d"}.get(a.workload, a.workload)]
+        bpp = BYTES[{"2dc3": "2d", "c3": "c2"}.get(a.workload, a.workload)]
         achieved = bpp * nlive / (kms * 1e-3) / 1e9 if kms else None
         out = {
             "metric": "particles pushed+searched+scattered / sec / GPU; achieved HBM GB/s vs peak",
@@ -254,6 +257,7 @@ def main():
                 w["label"], a.particles,
                 {"c2": "push+search only (fused toroidal push + BCC walk), deg/push=%g" % a.deg,
                  "2d": "elliptical push + search_mesh_2d (fused), deg/push=%g" % a.deg,
+                 "c3": "push+search+rebuild+gyroScatter x2 (tet ring map), deg/push=%g" % a.deg,
                  "2dc3": "push+search+rebuild+gyroScatter x2, deg/push=%g" % a.deg}[a.workload]),
                 "parallelism": "element-block partition, %d rank(s), full-mesh replica" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

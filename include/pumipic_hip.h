@@ -206,7 +206,9 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
                    int elem_ids_seeded, int looplimit, int* found);
 
 /* ------------------------------------------------------------------ scatter / gather */
-/* createGyroRingMappings test/gyroScatter.hpp:101-166 (maps: nverts*gnr*gppr*3 ints, device) */
+/* createGyroRingMappings test/gyroScatter.hpp:101-166 (maps: nverts*gnr*gppr*(dim+1) ints, device).
+ * dim 3 is the documented tet variant: rings in the vertex's poloidal half-plane, the 4 vertices
+ * of the containing tet per ring point. */
 int pp_create_gyro_ring_mappings(const pp_mesh* mesh, double rmax, int gnr, int gppr,
                                  double theta_deg, int* forward_map_dev, int* backward_map_dev);
 /* gyroScatter test/gyroScatter.hpp:168-229: scatter_w_dev[nverts] (overwritten) */

@@ -156,9 +156,15 @@ int ppo_search_mesh_legacy3d(const ppo_mesh* mesh, ppo_ps* ps, int m_x, int m_xt
 /* src/pumipic_adjacency.hpp:1160-1252 */
 int ppo_search_mesh_2d_pt(const ppo_mesh* mesh, const double orig[2], const double dest[2],
                           int pid, int initial_elem, int* loops, int looplimit);
+/* tet variant of the single-point walk (BCC mode of search_mesh, tpp:276-285,365-416) */
+int ppo_search_mesh_3d_pt(const ppo_mesh* mesh, const double dest[3], int initial_elem,
+                          int looplimit);
 
 /* ---------------------------------------------------------------- scatter / gather */
-/* test/gyroScatter.hpp:101-166 (+ searchAndBuildMap :28-95); maps are nverts*gnr*gppr*3 ints */
+/* test/gyroScatter.hpp:101-166 (+ searchAndBuildMap :28-95); maps are nverts*gnr*gppr*(dim+1)
+ * ints.  dim 3 (documented tet variant): the ring lies in the vertex's poloidal
+ * half-plane, R' = R + r cos, Z' = Z + r sin, point = ((R'/R) x, (R'/R) y, Z'); the map holds the 4
+ * vertices of the tet that contains the point. */
 /* trig: 0 = libm cos/sin (literal reference), 1 = ppo_sincos (shared with the device) */
 void ppo_create_gyro_ring_mappings(const ppo_mesh* mesh, double rmax, int gnr, int gppr,
                                    double theta_deg, int trig, int* forward_map,

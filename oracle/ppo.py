@@ -430,7 +430,7 @@ def search_mesh_2d_pt(mesh, orig, dest, initial_elem, looplimit=0, pid=0):
 
 
 def create_gyro_ring_mappings(mesh, rmax=0.038, gnr=3, gppr=8, theta=0.0, trig=0):
-    n = mesh.nverts * gnr * gppr * 3
+    n = mesh.nverts * gnr * gppr * (mesh.dim + 1)
     f = np.empty(n, dtype=np.int32)
     b = np.empty(n, dtype=np.int32)
     lib().ppo_create_gyro_ring_mappings(mesh.p, rmax, gnr, gppr, theta, trig, _ip(f), _ip(b))

@@ -246,7 +246,7 @@ void ppo_create_gyro_ring_mappings(const ppo_mesh* mesh, double rmax, int gnr, i
   const int nverts = mesh->nverts;
   const long num_points = (long)nverts * gnr * gppr;
   const double torad = M_PI / 180;
-  const int nvpe = 3;
+  const int dim = mesh->dim, nvpe = dim + 1;
   for (long id = 0; id < num_points; ++id) {
     const int point_id = (int)(id % gppr);
     const long id2 = id / gppr;
@@ -255,21 +255,33 @@ void ppo_create_gyro_ring_mappings(const ppo_mesh* mesh, double rmax, int gnr, i
     const double radius = rmax * (ring_id + 1) / gnr;
     const double deg = theta_deg + (((double)point_id) / gppr * 360);
     const double rad = deg * torad;
-    double pt[2], sn, cs;
+    double sn, cs;
     trig(trigmode, rad, &sn, &cs);
-    pt[0] = mesh->coords[(size_t)vert_id * 2] + radius * cs;
-    pt[1] = mesh->coords[(size_t)vert_id * 2 + 1] + radius * sn;
     const int start_elem = mesh->vert2elems[mesh->vert2elems_off[vert_id]];
-    /* centroid of the start element = average(vtxCoords) = ((p0+p1)+p2)/3 (unused by the walk) */
-    double orig[2] = {0, 0};
-    for (int c = 0; c < 2; ++c) {
-      double acc = mesh->coords[(size_t)mesh->elem2verts[(size_t)start_elem * 3] * 2 + c];
-      acc = acc + mesh->coords[(size_t)mesh->elem2verts[(size_t)start_elem * 3 + 1] * 2 + c];
-      acc = acc + mesh->coords[(size_t)mesh->elem2verts[(size_t)start_elem * 3 + 2] * 2 + c];
-      orig[c] = acc / 3;
+    int parent;
+    if (dim == 2) {
+      double pt[2];
+      pt[0] = mesh->coords[(size_t)vert_id * 2] + radius * cs;
+      pt[1] = mesh->coords[(size_t)vert_id * 2 + 1] + radius * sn;
+      /* centroid of the start element = average(vtxCoords) = ((p0+p1)+p2)/3 (unused by the walk) */
+      double orig[2] = {0, 0};
+      for (int c = 0; c < 2; ++c) {
+        double acc = mesh->coords[(size_t)mesh->elem2verts[(size_t)start_elem * 3] * 2 + c];
+        acc = acc + mesh->coords[(size_t)mesh->elem2verts[(size_t)start_elem * 3 + 1] * 2 + c];
+        acc = acc + mesh->coords[(size_t)mesh->elem2verts[(size_t)start_elem * 3 + 2] * 2 + c];
+        orig[c] = acc / 3;
+      }
+      int loops = 0;
+      parent = ppo_search_mesh_2d_pt(mesh, orig, pt, (int)id, start_elem, &loops, 100);
+    } else {
+      const double xv = mesh->coords[(size_t)vert_id * 3], yv = mesh->coords[(size_t)vert_id * 3 + 1],
+                   zv = mesh->coords[(size_t)vert_id * 3 + 2];
+      const double Rv = sqrt(xv * xv + yv * yv);
+      const double Rp = Rv + radius * cs;
+      const double sc = Rp / Rv;
+      const double pt[3] = {sc * xv, sc * yv, zv + radius * sn};
+      parent = ppo_search_mesh_3d_pt(mesh, pt, start_elem, 100);
     }
-    int loops = 0;
-    const int parent = ppo_search_mesh_2d_pt(mesh, orig, pt, (int)id, start_elem, &loops, 100);
     for (int i = 0; i < nvpe; ++i) {
       const int v = (parent >= 0) ? mesh->elem2verts[(size_t)parent * nvpe + i] : -1;
       forward_map[id * nvpe + i] = v;
@@ -304,8 +316,8 @@ void ppo_gyro_scatter(const ppo_mesh* mesh, const ppo_ps* ps, const int* v2v, do
     for (int ring = 0; ring < gnr; ++ring) {
       const double accumRingVal = ring_accum[(size_t)v * gnr + ring] / gppr;
       for (int pt = 0; pt < gppr; ++pt) {
-        const long ptIdx = 3 * (vtxIdx + (long)ring * gppr + pt);
-        for (int elmVtx = 0; elmVtx < 3; ++elmVtx) {
+        const long ptIdx = nvpe * (vtxIdx + (long)ring * gppr + pt);
+        for (int elmVtx = 0; elmVtx < nvpe; ++elmVtx) {
           const int mappedVtx = v2v[ptIdx + elmVtx];
           if (mappedVtx >= 0) scatter_w[mappedVtx] += accumRingVal;
         }

@@ -177,6 +177,38 @@ int ppo_search_mesh_2d_pt(const ppo_mesh* mesh, const double orig[2], const doub
   return elem_id;
 }
 
+/* Single-point BCC walk through tets: the per-particle work of search_mesh in BCC mode
+ * (find_exit_face tpp:276-285, check_model_intersection :365-387, set_new_element :389-416)
+ * for ONE target point, used by the tet variant of the gyro ring map. */
+int ppo_search_mesh_3d_pt(const ppo_mesh* mesh, const double dest[3], int initial_elem,
+                          int looplimit) {
+  int elem_id = initial_elem, done = 0, loops = 0;
+  const ppo_v3 d = {{dest[0], dest[1], dest[2]}};
+  while (!done) {
+    int verts[4];
+    ppo_v3 M[4];
+    gather_tet(mesh, elem_id, verts, M);
+    double bcc[4];
+    ppo_barycentric_tet(mesh->elem_measure[elem_id], M, d, bcc);
+    done = ppo_all_positive(bcc, 4, PPO_EPSILON);
+    if (!done) {
+      const int side = mesh->elem2sides[(size_t)elem_id * 4 + ppo_min_index(bcc, 4)];
+      if (mesh->side_exposed[side]) {
+        elem_id = -1;
+        done = 1;
+      } else {
+        elem_id = other_elem(mesh, side, elem_id);
+      }
+    }
+    ++loops;
+    if (loops >= looplimit && !done) {
+      elem_id = -1;
+      break;
+    }
+  }
+  return elem_id;
+}
+
 /* ------------------------------------------------------------------ search_mesh (tpp) */
 int ppo_search_mesh(const ppo_mesh* mesh, ppo_ps* ps, int m_x, int m_xtgt, int m_pid,
                     int* elem_ids, int elem_ids_seeded, int requireIntersection, int* inter_faces,

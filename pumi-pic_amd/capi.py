@@ -484,7 +484,7 @@ def push_search(mesh, ps, h, k, d, deg, elem_ids, seeded=True, looplimit=0, want
 
 
 def create_gyro_ring_mappings(mesh, rmax=0.038, gnr=3, gppr=8, theta=0.0):
-    n = max(mesh.nverts * gnr * gppr * 3, 1)
+    n = max(mesh.nverts * gnr * gppr * (mesh.dim + 1), 1)
     f, b = DevArray(n, np.int32), DevArray(n, np.int32)
     check(lib().pp_create_gyro_ring_mappings(mesh.p, rmax, gnr, gppr, theta, f.ptr, b.ptr))
     return f, b

@@ -69,6 +69,64 @@ __global__ void k_ring_map(int num_points, int gnr, int gppr, double rmax, doubl
   }
 }
 
+// --- tet variant of the ring map (SURVEY 8(d) documented deviation): the ring lies in the vertex's
+// poloidal half-plane, R' = R + r cos, Z' = Z + r sin, point = ((R'/R) x, (R'/R) y, Z'); BCC walk of
+// search_mesh (tpp:276-285) from the vertex's first element, 100 loops; 4 vertices per ring point
+__global__ void k_ring_map3(int num_points, int gnr, int gppr, double rmax, double theta_deg,
+                            const double* __restrict__ coords, const int* __restrict__ v2e_off,
+                            const int* __restrict__ v2e, const int* __restrict__ elem2verts,
+                            const pp_tet_rec* __restrict__ recs, int* __restrict__ fwd,
+                            int* __restrict__ bkwd) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= num_points) return;
+  const int point_id = id % gppr;
+  const int id2 = id / gppr;
+  const int ring_id = id2 % gnr;
+  const int vert_id = id2 / gnr;
+  const double torad = 3.14159265358979323846 / 180;
+  const double radius = rmax * (ring_id + 1) / gnr;
+  const double deg = theta_deg + (((double)point_id) / gppr * 360);
+  const double rad = deg * torad;
+  double sn, cs;
+  sincos_det(rad, sn, cs);
+  const double xv = coords[(size_t)vert_id * 3], yv = coords[(size_t)vert_id * 3 + 1],
+               zv = coords[(size_t)vert_id * 3 + 2];
+  const double Rv = sqrt(xv * xv + yv * yv);
+  const double Rp = Rv + radius * cs;
+  const double sc = Rp / Rv;
+  const V3 pt{sc * xv, sc * yv, zv + radius * sn};
+  int elem = v2e[v2e_off[vert_id]];
+  int loops = 0;
+  bool done = false;
+  while (!done) {
+    const pp_tet_rec* r = recs + elem;
+    V3 M[4];
+    for (int i = 0; i < 4; ++i) M[i] = {r->xyz[i][0], r->xyz[i][1], r->xyz[i][2]};
+    double bcc[4];
+    barycentric_tet(r->vol, M, pt, bcc);
+    done = all_positive4(bcc, kEpsilon);
+    if (!done) {
+      const int next = r->nbr[min_index4(bcc)];
+      if (next == -1) {
+        elem = -1;
+        done = true;
+      } else {
+        elem = next;
+      }
+    }
+    ++loops;
+    if (!done && loops >= 100) {
+      elem = -1;
+      break;
+    }
+  }
+  for (int i = 0; i < 4; ++i) {
+    const int v = (elem >= 0) ? elem2verts[(size_t)elem * 4 + i] : -1;
+    fwd[(size_t)id * 4 + i] = v;
+    bkwd[(size_t)id * 4 + i] = v;
+  }
+}
+
 // --- live particles per element
 // SCS: thread = (slice, row); sums the mask down its row (coalesced across rows), then one int
 // atomic per (slice,row) -- a chunk has only a few slices, so contention is negligible.
@@ -103,7 +161,8 @@ __global__ void k_accumulate_rings(int ne, int nvpe, const int* __restrict__ cnt
   atomicAdd(&ring_accum[(size_t)v * gnr + ringUp], (double)n);
   atomicAdd(&ring_accum[(size_t)v * gnr + ringDown], (double)n);
 }
-__global__ void k_scatter_mapped(int nverts, int gnr, int gppr, const double* __restrict__ ring_accum,
+__global__ void k_scatter_mapped(int nverts, int gnr, int gppr, int nvpe,
+                                 const double* __restrict__ ring_accum,
                                  const int* __restrict__ v2v, double* __restrict__ scatter_w) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)nverts * gnr * gppr;
@@ -112,8 +171,8 @@ __global__ void k_scatter_mapped(int nverts, int gnr, int gppr, const double* __
   const int ring = (int)((t / gppr) % gnr);
   const double val = ring_accum[(size_t)v * gnr + ring] / gppr;
   if (val == 0.0) return;  // adding +0.0 never changes a sum of non-negative terms
-  for (int k = 0; k < 3; ++k) {
-    const int mv = v2v[3 * t + k];
+  for (int k = 0; k < nvpe; ++k) {
+    const int mv = v2v[nvpe * t + k];
     if (mv >= 0) atomicAdd(&scatter_w[mv], val);
   }
 }
@@ -150,16 +209,22 @@ extern "C" {
 int pp_create_gyro_ring_mappings(const pp_mesh* mesh, double rmax, int gnr, int gppr,
                                  double theta_deg, int* forward_map_dev, int* backward_map_dev) {
   PP_REQUIRE(mesh && forward_map_dev && backward_map_dev, "pp_create_gyro_ring_mappings: null argument");
-  PP_REQUIRE(mesh->dim == 2, "pp_create_gyro_ring_mappings: triangle meshes only (gyroScatter.hpp:72)");
   PP_REQUIRE(gnr > 0 && gppr > 0, "pp_create_gyro_ring_mappings: gnr, gppr must be positive");
   const long long n = (long long)mesh->nverts * gnr * gppr;
   PP_REQUIRE(n < (1ll << 31), "pp_create_gyro_ring_mappings: too many ring points");
   if (n == 0) return PP_OK;
-  k_ring_map<<<grid_for((size_t)n), kBlock, 0, pp::stream()>>>(
-      (int)n, gnr, gppr, rmax, theta_deg, mesh->d_coords.as<double>(),
-      mesh->d_vert2elems_off.as<int>(), mesh->d_vert2elems.as<int>(),
-      mesh->d_elem2verts.as<int>(), mesh->d_records.as<pp_tri_rec>(), forward_map_dev,
-      backward_map_dev);
+  if (mesh->dim == 2)
+    k_ring_map<<<grid_for((size_t)n), kBlock, 0, pp::stream()>>>(
+        (int)n, gnr, gppr, rmax, theta_deg, mesh->d_coords.as<double>(),
+        mesh->d_vert2elems_off.as<int>(), mesh->d_vert2elems.as<int>(),
+        mesh->d_elem2verts.as<int>(), mesh->d_records.as<pp_tri_rec>(), forward_map_dev,
+        backward_map_dev);
+  else
+    k_ring_map3<<<grid_for((size_t)n), kBlock, 0, pp::stream()>>>(
+        (int)n, gnr, gppr, rmax, theta_deg, mesh->d_coords.as<double>(),
+        mesh->d_vert2elems_off.as<int>(), mesh->d_vert2elems.as<int>(),
+        mesh->d_elem2verts.as<int>(), mesh->d_records.as<pp_tet_rec>(), forward_map_dev,
+        backward_map_dev);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -203,7 +268,7 @@ int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, do
         ne, nvpe, cnt, mesh->d_elem2verts.as<int>(), gnr, ringDown, ringUp,
         s_ring->as<double>());
     k_scatter_mapped<<<grid_for((size_t)nverts * gnr * gppr), kBlock, 0, st>>>(
-        nverts, gnr, gppr, s_ring->as<double>(), v2v_dev, scatter_w_dev);
+        nverts, gnr, gppr, nvpe, s_ring->as<double>(), v2v_dev, scatter_w_dev);
   }
   PP_LAUNCH_CHECK();
   return PP_OK;

@@ -725,3 +725,49 @@ def test_fused_variants_match_oracle(ppo, synth, capi, monkeypatch, dim, queue, 
             a[:] = b
             b[:] = tmp
             pg.swap_members(0, 1)
+
+
+def test_gyro_maps_and_scatter_3d(ppo, synth, capi):
+    """tet variant (documented deviation): ring points in the vertex's poloidal
+    half-plane, 4 vertices per ring point; map and scatter sums bit-exact vs the oracle."""
+    pop = common.population_3d(synth, n_b=5, n_theta=20, n_planes=8, num_ptcls=3000)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
+    fo, bo = ppo.create_gyro_ring_mappings(mo, rmax=0.03, trig=1)
+    fg, bg = capi.create_gyro_ring_mappings(mg, rmax=0.03)
+    assert len(fo) == mo.nverts * 3 * 8 * 4
+    assert np.array_equal(fo, fg.to_host()) and np.array_equal(bo, bg.to_host())
+    assert (fo >= 0).mean() > 0.5 and (fo < 0).any()  # rings near the wall leave the domain
+    wo = ppo.gyro_scatter(mo, po, fo, rmax=0.03)
+    wg = capi.gyro_scatter(mg, pg, fg, rmax=0.03).to_host()
+    assert np.array_equal(wo, wg) and wo.sum() > 0
+
+
+def test_pseudo_xgcm_steps_3d(ppo, synth, capi):
+    """BASELINE configs[2] on tets: toroidal push -> search_mesh (BCC) -> updatePtclPositions ->
+    rebuild -> gyroScatter (tet ring map) x2, 8 steps; element ids by particle id, positions and
+    scatter sums bit-exact vs the oracle."""
+    pop = common.population_3d(synth, n_b=5, n_theta=20, n_planes=8, num_ptcls=4000)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
+    po.set_try_shuffling(False)
+    fo, bo = ppo.create_gyro_ring_mappings(mo, trig=1)
+    fg, bg = capi.create_gyro_ring_mappings(mg)
+    for step in range(8):
+        ppo.toroidal_push(po, mo, H, K, D, 6.0, trig=1)
+        ids_o = ppo.search_mesh(mo, po, looplimit=200)["elem_ids"]
+        ids_g = capi.DevArray(max(pg.capacity(), 1), np.int32)
+        capi.push_search(mg, pg, H, K, D, 6.0, ids_g, seeded=False, looplimit=200)
+        io, eo = common.by_id(po.member(2)[0, :po.capacity()], po.slot_info()[1], ids_o[:po.capacity()])
+        ig, eg = common.by_id(pg.member(2)[0, :pg.capacity()], pg.slot_info()[1],
+                              ids_g.to_host()[:pg.capacity()])
+        assert np.array_equal(io, ig) and np.array_equal(eo, eg), step
+        ppo.update_positions(po)
+        po.rebuild(ids_o)
+        pg.rebuild_commit(ids_g, 0, 1)
+        assert po.nPtcls() == pg.nPtcls() > 0
+        for m_o, m_g in ((fo, fg), (bo, bg)):
+            wo = ppo.gyro_scatter(mo, po, m_o)
+            wg = capi.gyro_scatter(mg, pg, m_g).to_host()
+            assert np.array_equal(wo, wg), step
+    _check_same_population(po, pg, ppo.PARTICLE_XGCM)

@@ -299,3 +299,36 @@ def test_pseudo_push_and_boris(ppo, synth):
     arrs[14][:] = 1e-3         # Bz
     ppo.push_boris(*arrs, 1e-6)
     assert np.allclose(np.hypot(arrs[6], arrs[7]), 1.0, rtol=0, atol=1e-12)
+
+
+def test_gyro_ring_map_3d_points_are_inside_their_tets(ppo, synth):
+    """tet ring map: every mapped ring point really lies in the tet whose 4 vertices it lists
+    (independent numpy barycentric solve), unmapped points are outside the domain's (R,Z) range."""
+    coords, e2v, cls = synth.torus_tet(n_b=4, n_theta=16, n_planes=8)
+    mesh = ppo.Mesh(3, coords, e2v, cls)
+    rmax, gnr, gppr = 0.03, 3, 8
+    fwd, bkwd = ppo.create_gyro_ring_mappings(mesh, rmax=rmax, gnr=gnr, gppr=gppr, trig=0)
+    assert np.array_equal(fwd, bkwd)
+    fwd = fwd.reshape(mesh.nverts, gnr, gppr, 4)
+    xyz = np.asarray(coords).reshape(-1, 3)
+    tets = np.sort(np.asarray(e2v).reshape(-1, 4), axis=1)
+    known = {tuple(t) for t in tets}
+    rng = np.random.default_rng(3)
+    checked = 0
+    for v in rng.choice(mesh.nverts, size=60, replace=False):
+        R = np.hypot(xyz[v, 0], xyz[v, 1])
+        for r in range(gnr):
+            for k in range(gppr):
+                vs = fwd[v, r, k]
+                if vs[0] < 0:
+                    assert (vs < 0).all()
+                    continue
+                assert tuple(sorted(vs)) in known
+                rad = np.deg2rad(k / gppr * 360)
+                Rp, Zp = R + rmax * (r + 1) / gnr * np.cos(rad), xyz[v, 2] + rmax * (r + 1) / gnr * np.sin(rad)
+                p = np.array([Rp / R * xyz[v, 0], Rp / R * xyz[v, 1], Zp])
+                T = (xyz[vs[1:]] - xyz[vs[0]]).T
+                lam = np.linalg.solve(T, p - xyz[vs[0]])
+                assert lam.min() > -1e-7 and lam.sum() < 1 + 1e-7
+                checked += 1
+    assert checked > 500
