@@ -12,6 +12,7 @@
 namespace pp {
 
 void set_error(const std::string& msg);
+unsigned long long next_version();  // pp_runtime.hip: process-wide monotonic stamp
 hipStream_t stream();
 bool initialised();
 
@@ -157,6 +158,9 @@ struct pp_ps {
   // live particles per element, kept current by construction/rebuild (gyroScatter reads it)
   pp::DevBuf d_elem_count;
   bool elem_count_valid = false;
+  // stamp of the current particle->element assignment (unique across structures); bumped by every
+  // construction and rebuild, lets pp_gyro_scatter reuse the ring accumulation of the previous call
+  unsigned long long version = 0;
   int tile_p = pp::kTileP;  // columns per tile (PP_TILE_P overrides, tuning knob)
   // scratch reused across rebuilds
   pp::DevBuf s_ppe, s_keys, s_keys2, s_vals, s_vals2, s_hist, s_chunkw, s_misc, s_rowstart,

@@ -419,6 +419,7 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
 // wave of ELEMENTS (a per-wave atomic on one counter in the particle-sized kernels serialises at
 // ~10 ns each and used to cost more than the histogram itself)
 __global__ void k_nonempty(int ne, const int* __restrict__ ppe, Totals* tot) {
+  __shared__ int s_nz[4], s_sum[4];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = i < ne ? ppe[i] : 0;
   int nz = n > 0 ? 1 : 0, sum = n;
@@ -426,9 +427,18 @@ __global__ void k_nonempty(int ne, const int* __restrict__ ppe, Totals* tot) {
     nz += __shfl_down(nz, o);
     sum += __shfl_down(sum, o);
   }
-  if ((threadIdx.x & 63) == 0 && nz) {
-    atomicAdd(&tot->nonempty, nz);
-    atomicAdd(&tot->active, sum);
+  if ((threadIdx.x & 63) == 0) {
+    s_nz[threadIdx.x >> 6] = nz;
+    s_sum[threadIdx.x >> 6] = sum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    nz = s_nz[0] + s_nz[1] + s_nz[2] + s_nz[3];
+    sum = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    if (nz) {
+      atomicAdd(&tot->nonempty, nz);
+      atomicAdd(&tot->active, sum);
+    }
   }
 }
 // single-block reduction of the chunk widths (sum, #non-zero) -- replaces one atomic per chunk
@@ -621,6 +631,11 @@ struct WordTable {
   char* dst[kMaxWords];
   int sscale[kMaxWords];
   int dscale[kMaxWords];
+  // destinations that receive 0 (x_tgt of the fused updatePtclPositions): never staged, pass 2
+  // writes them as plain coalesced zero stores
+  int nzero;
+  char* zdst[8];
+  int zscale[8];
 };
 // pass 1a: slot assignment only (atomics), destination index per old slot (-1 = not moved)
 __global__ void k_assign_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
@@ -730,6 +745,9 @@ __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
 #pragma unroll
     for (int i = 0; i < NQ * 4; ++i)
       if (i < t.nwords) *(unsigned*)(t.dst[i] + (long long)slot * t.dscale[i]) = w[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < t.nzero) *(unsigned*)(t.zdst[i] + (long long)slot * t.zscale[i]) = 0u;
   }
 }
 // CSR counting sort (CSR_rebuild.hpp:62-108)
@@ -1030,12 +1048,19 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   // record = all members as 32-bit words (fast path needs 4/8-byte scalars and <= 64 words)
   WordTable wt{};
   bool staged = have_old && old_grid > 0 && getenv("PP_DIRECT_MOVE") == nullptr;
-  int nw = 0;
+  int nw = 0, nz = 0;
   for (int m = 0; m < ps->nmembers && staged; ++m) {
     const int b = ps->member_bytes[m];
     if (b != 4 && b != 8) staged = false;
     for (int cc = 0; cc < ps->member_ncomp[m] && staged; ++cc)
       for (int hw = 0; hw < b / 4; ++hw) {
+        char* dst = (char*)ps->swap[m].p + ((size_t)cc * swap_stride) * b + hw * 4;
+        if (m == commit_xt && nz < 8) {  // constant 0 after the fused updatePtclPositions
+          wt.zdst[nz] = dst;
+          wt.zscale[nz] = b;
+          ++nz;
+          continue;
+        }
         if (nw >= kMaxWords) {
           staged = false;
           break;
@@ -1043,12 +1068,15 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
         const int sm = (m == commit_x) ? commit_xt : m;  // fused updatePtclPositions
         wt.src[nw] = (const char*)ps->data[sm].p + ((size_t)cc * ps->stride) * b + hw * 4;
         wt.sscale[nw] = (m == commit_xt) ? -1 : b;
-        wt.dst[nw] = (char*)ps->swap[m].p + ((size_t)cc * swap_stride) * b + hw * 4;
+        wt.dst[nw] = dst;
         wt.dscale[nw] = b;
         ++nw;
       }
   }
-  const int NQ = (nw + 3) / 4;
+  wt.nzero = nz;
+  // 16-B quads per record; 3 is rounded up to 4: a 48-B record straddles 64-B sectors and the
+  // scattered stores of pass 1 become read-modify-writes (measured 0.25 -> 0.40 ms per 10 M)
+  const int NQ = (nw + 3) / 4 == 3 ? 4 : (nw + 3) / 4;
   wt.nwords = nw;
   if (staged && (NQ == 4 || NQ == 10 || NQ <= 3 || NQ == 6 || NQ == 8)) {
     PP_HIP_CHECK(ps->s_aos.reserve((size_t)std::max(new_capacity, 1) * NQ * 16));
@@ -1104,6 +1132,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   ps->d_ntiles.swap(ps->s_scan);
   ps->d_elem_count.swap(ps->s_ppe);  // live particles per element == the histogram just built
   ps->elem_count_valid = true;
+  ps->version = pp::next_version();
   ps->ntiles_max = ntiles_max;
   ps->C = C_new;
   ps->num_ptcls = h.active;
@@ -1235,6 +1264,7 @@ pp_ps* pp_ps_create_scs(int C, int sigma, int V, int num_elems, int num_ptcls,
   if (ok) {
     ok = upload_vec(ps->d_elem_count, ppe) == PP_OK && hipStreamSynchronize(pp::stream()) == hipSuccess;
     ps->elem_count_valid = ok;
+    ps->version = pp::next_version();
   }
   if (ok && num_ptcls > 0 && particle_elements_host && particle_info_host) {
     // initSCSData (SCS_buildFns.h:205-232) in particle order
@@ -1442,6 +1472,7 @@ int pp_ps_rebuild(pp_ps* ps, const int* new_element_dev, int n_new, const int* n
   if (ps->kind == PP_SCS)
     return scs_rebuild(ps, new_element_dev, n_new, new_elems_dev, new_info_dev, -1, -1);
   ps->elem_count_valid = false;
+  ps->version = pp::next_version();
   return csr_rebuild(ps, new_element_dev, n_new, new_elems_dev, new_info_dev);
 }
 

@@ -6,6 +6,10 @@ static thread_local std::string g_err;
 static hipStream_t g_stream = nullptr;
 static bool g_init = false;
 
+unsigned long long next_version() {
+  static unsigned long long v = 0;
+  return ++v;
+}
 void set_error(const std::string& msg) { g_err = msg; }
 hipStream_t stream() { return g_stream; }
 bool initialised() { return g_init; }

@@ -246,27 +246,43 @@ int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, do
   static pp::DevBuf* s_ring = new pp::DevBuf();
   PP_HIP_CHECK(s_cnt->reserve(sizeof(int) * (size_t)std::max(ne, 1)));
   PP_HIP_CHECK(s_ring->reserve(sizeof(double) * (size_t)std::max(nverts * gnr, 1)));
-  PP_HIP_CHECK(hipMemsetAsync(s_cnt->p, 0, sizeof(int) * (size_t)std::max(ne, 1), st));
-  PP_HIP_CHECK(hipMemsetAsync(s_ring->p, 0, sizeof(double) * (size_t)std::max(nverts * gnr, 1), st));
   PP_HIP_CHECK(hipMemsetAsync(scatter_w_dev, 0, sizeof(double) * (size_t)nverts, st));
   if (ps->num_ptcls > 0 && ps->capacity > 0) {
-    // live particles per element: kept current by construction / rebuild (it IS the histogram the
-    // rebuild sorts by), otherwise summed from the mask without per-particle atomics
-    const int* cnt = nullptr;
-    if (ps->elem_count_valid) {
-      cnt = ps->d_elem_count.as<int>();
-    } else {
-      if (ps->kind == PP_SCS)
-        k_count_scs<<<grid_for((size_t)ps->num_slices * ps->C), kBlock, 0, st>>>(
-            ps->num_slices, ps->C, ps->d_offsets.as<int>(), ps->d_slice_to_chunk.as<int>(),
-            ps->d_row_to_element.as<int>(), ps->d_mask.as<unsigned char>(), ne, s_cnt->as<int>());
-      else
-        k_count_csr<<<grid_for(ne), kBlock, 0, st>>>(ne, ps->d_offsets.as<int>(), s_cnt->as<int>());
-      cnt = s_cnt->as<int>();
+    // The ring accumulation depends only on (mesh, particle->element assignment, ring geometry):
+    // the forward and backward scatters of one step (gyroScatter.hpp is called twice per step,
+    // pseudoXGCm.cpp:529-530) share it.
+    static const pp_ps* c_ps = nullptr;
+    static const pp_mesh* c_mesh = nullptr;
+    static unsigned long long c_version = 0;
+    static int c_gnr = 0, c_down = -1;
+    const bool reuse = c_ps == ps && c_mesh == mesh && c_version == ps->version && ps->version != 0 &&
+                       c_gnr == gnr && c_down == ringDown;
+    if (!reuse) {
+      PP_HIP_CHECK(hipMemsetAsync(s_ring->p, 0, sizeof(double) * (size_t)std::max(nverts * gnr, 1), st));
+      // live particles per element: kept current by construction / rebuild (it IS the histogram
+      // the rebuild sorts by), otherwise summed from the mask without per-particle atomics
+      const int* cnt = nullptr;
+      if (ps->elem_count_valid) {
+        cnt = ps->d_elem_count.as<int>();
+      } else {
+        PP_HIP_CHECK(hipMemsetAsync(s_cnt->p, 0, sizeof(int) * (size_t)std::max(ne, 1), st));
+        if (ps->kind == PP_SCS)
+          k_count_scs<<<grid_for((size_t)ps->num_slices * ps->C), kBlock, 0, st>>>(
+              ps->num_slices, ps->C, ps->d_offsets.as<int>(), ps->d_slice_to_chunk.as<int>(),
+              ps->d_row_to_element.as<int>(), ps->d_mask.as<unsigned char>(), ne, s_cnt->as<int>());
+        else
+          k_count_csr<<<grid_for(ne), kBlock, 0, st>>>(ne, ps->d_offsets.as<int>(), s_cnt->as<int>());
+        cnt = s_cnt->as<int>();
+      }
+      k_accumulate_rings<<<grid_for((size_t)ne * nvpe), kBlock, 0, st>>>(
+          ne, nvpe, cnt, mesh->d_elem2verts.as<int>(), gnr, ringDown, ringUp,
+          s_ring->as<double>());
+      c_ps = ps;
+      c_mesh = mesh;
+      c_version = ps->version;
+      c_gnr = gnr;
+      c_down = ringDown;
     }
-    k_accumulate_rings<<<grid_for((size_t)ne * nvpe), kBlock, 0, st>>>(
-        ne, nvpe, cnt, mesh->d_elem2verts.as<int>(), gnr, ringDown, ringUp,
-        s_ring->as<double>());
     k_scatter_mapped<<<grid_for((size_t)nverts * gnr * gppr), kBlock, 0, st>>>(
         nverts, gnr, gppr, nvpe, s_ring->as<double>(), v2v_dev, scatter_w_dev);
   }
