@@ -771,3 +771,68 @@ def test_pseudo_xgcm_steps_3d(ppo, synth, capi):
             wg = capi.gyro_scatter(mg, pg, m_g).to_host()
             assert np.array_equal(wo, wg), step
     _check_same_population(po, pg, ppo.PARTICLE_XGCM)
+
+
+def _driver(name):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drv = os.path.join(root, "pumi-pic_amd", "drivers")
+    subprocess.check_call(["make", "-C", drv, "-s"])
+    return os.path.join(drv, name)
+
+
+@pytest.mark.parametrize("structure", [0, 1])
+@pytest.mark.parametrize("strat", [1, 2, 4])
+def test_cpp_driver_ps_combo160(capi, structure, strat):
+    """performance_tests/ps_combo160.cpp restated on the mirror headers: USER pseudo-push lambda
+    through ps::parallel_for on the 160-byte particle, then redistribute + migrate rounds; no
+    particle is lost and both timing rows are printed."""
+    import re
+    import subprocess
+    out = subprocess.run([_driver("ps_combo160"), "20000", "200000", str(strat), str(structure),
+                          "-i", "5", "-s", "64"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    m = re.search(r"RESULT structure (\S+) particles (\d+) rounds (\d+) particle_rounds (\d+)", out.stdout)
+    assert m, out.stdout[-2000:]
+    assert m.group(1) == ("Sell-64-ne" if structure == 0 else "CSR")
+    assert int(m.group(2)) == 200000 and int(m.group(4)) == 5 * 200000
+    assert "pseudo-push" in out.stderr and "migrate" in out.stderr
+
+
+def test_cpp_driver_pseudo_push_and_search(ppo, synth, capi, tmp_path):
+    """test/pseudoPushAndSearch.cpp restated on the mirror headers; the same loop run with the
+    oracle gives the same survivors, wall hits and touched elements."""
+    import re
+    import subprocess
+    coords, e2v, cls = synth.kuhn_box(6)
+    mesh_file = str(tmp_path / "box.bin")
+    synth.write_mesh_bin(mesh_file, 3, coords, e2v, cls)
+    npt = 3000
+    out = subprocess.run([_driver("pseudoPushAndSearch"), mesh_file, str(npt), "-0.5", "0.8", "0"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    m = re.search(r"RESULT particles (\d+) wall_hits (\d+) touched_elements (\d+) iterations (\d+)", out.stdout)
+    assert m, out.stdout[-2000:]
+    # the oracle's version of the loop
+    pop = common.population_box(synth, n=6, num_ptcls=npt)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_PUSH, C=64)
+    po.set_try_shuffling(False)
+    touched = np.zeros(len(e2v), dtype=bool)
+    touched[np.unique(po.slot_info()[0][po.slot_info()[1].astype(bool)])] = True
+    hits, it = 0, 1
+    while it <= 30 and po.nPtcls() > 0:
+        ppo.linear_push(po, 1.0 / 20, -0.5, 0.8, 0.0)
+        r = ppo.search_mesh_legacy3d(mo, po, looplimit=100)
+        live = po.slot_info()[1].astype(bool)
+        hits += int((r["xface"][:po.capacity()][live] >= 0).sum())
+        ppo.update_positions(po)
+        po.rebuild(r["elem_ids"])
+        if po.nPtcls() == 0:
+            break
+        se, mk = po.slot_info()
+        touched[np.unique(se[mk.astype(bool)])] = True
+        it += 1
+    assert int(m.group(1)) == po.nPtcls()
+    assert int(m.group(2)) == hits
+    assert int(m.group(3)) == int(touched.sum())
