@@ -624,18 +624,19 @@ __global__ void k_move_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
 //   pass 2  walks the NEW layout, reads aos[slot] contiguously and writes the new SoA coalesced.
 // Word table: record word w of slot pid lives at src[w] + pid*sscale[w] (sscale < 0: constant 0,
 // used for the fused updatePtclPositions), and goes to dst[w] + slot*dscale[w].
-constexpr int kMaxWords = 64;
+// Entry table: 8-byte components are moved with 64-bit accesses (record words 2i, 2i+1 counted
+// from the front), 4-byte components with 32-bit accesses (record words counted from the back,
+// so that every register index is static); destinations that receive 0 (x_tgt of the fused
+// updatePtclPositions) are never staged, pass 2 writes them as plain coalesced zero stores.
+constexpr int kMax8 = 30, kMax4 = 16;
 struct WordTable {
-  int nwords;  // 32-bit words per record (padded to a multiple of 4)
-  const char* src[kMaxWords];
-  char* dst[kMaxWords];
-  int sscale[kMaxWords];
-  int dscale[kMaxWords];
-  // destinations that receive 0 (x_tgt of the fused updatePtclPositions): never staged, pass 2
-  // writes them as plain coalesced zero stores
-  int nzero;
-  char* zdst[8];
-  int zscale[8];
+  int n8, n4, nz8, nz4;
+  const char* src8[kMax8];
+  char* dst8[kMax8];
+  const char* src4[kMax4];
+  char* dst4[kMax4];
+  char* z8[8];
+  char* z4[8];
 };
 // pass 1a: slot assignment only (atomics), destination index per old slot (-1 = not moved)
 __global__ void k_assign_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
@@ -701,10 +702,17 @@ __global__ void k_move_pack(int capacity, const int* __restrict__ new_idx,
   if (idx >= 0) {
     unsigned v[NQ * 4];
 #pragma unroll
-    for (int i = 0; i < NQ * 4; ++i)
-      v[i] = (i < t.nwords && t.sscale[i] >= 0)
-                 ? *(const unsigned*)(t.src[i] + (long long)pid * t.sscale[i])
-                 : 0u;
+    for (int i = 0; i < NQ * 4; ++i) v[i] = 0u;
+#pragma unroll
+    for (int i = 0; i < NQ * 2; ++i)
+      if (i < t.n8) {
+        const uint2 d = *(const uint2*)(t.src8[i] + (long long)pid * 8);
+        v[2 * i] = d.x;
+        v[2 * i + 1] = d.y;
+      }
+#pragma unroll
+    for (int j = 0; j < (NQ * 4 < kMax4 ? NQ * 4 : kMax4); ++j)
+      if (j < t.n4) v[NQ * 4 - 1 - j] = *(const unsigned*)(t.src4[j] + (long long)pid * 4);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) st[w][l][q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
   }
@@ -743,11 +751,16 @@ __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
       w[4 * q + 3] = v.w;
     }
 #pragma unroll
-    for (int i = 0; i < NQ * 4; ++i)
-      if (i < t.nwords) *(unsigned*)(t.dst[i] + (long long)slot * t.dscale[i]) = w[i];
+    for (int i = 0; i < NQ * 2; ++i)
+      if (i < t.n8) *(uint2*)(t.dst8[i] + (long long)slot * 8) = make_uint2(w[2 * i], w[2 * i + 1]);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (i < t.nzero) *(unsigned*)(t.zdst[i] + (long long)slot * t.zscale[i]) = 0u;
+    for (int j = 0; j < (NQ * 4 < kMax4 ? NQ * 4 : kMax4); ++j)
+      if (j < t.n4) *(unsigned*)(t.dst4[j] + (long long)slot * 4) = w[NQ * 4 - 1 - j];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (i < t.nz8) *(uint2*)(t.z8[i] + (long long)slot * 8) = make_uint2(0u, 0u);
+      if (i < t.nz4) *(unsigned*)(t.z4[i] + (long long)slot * 4) = 0u;
+    }
   }
 }
 // CSR counting sort (CSR_rebuild.hpp:62-108)
@@ -1048,36 +1061,43 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   // record = all members as 32-bit words (fast path needs 4/8-byte scalars and <= 64 words)
   WordTable wt{};
   bool staged = have_old && old_grid > 0 && getenv("PP_DIRECT_MOVE") == nullptr;
-  int nw = 0, nz = 0;
   for (int m = 0; m < ps->nmembers && staged; ++m) {
     const int b = ps->member_bytes[m];
     if (b != 4 && b != 8) staged = false;
-    for (int cc = 0; cc < ps->member_ncomp[m] && staged; ++cc)
-      for (int hw = 0; hw < b / 4; ++hw) {
-        char* dst = (char*)ps->swap[m].p + ((size_t)cc * swap_stride) * b + hw * 4;
-        if (m == commit_xt && nz < 8) {  // constant 0 after the fused updatePtclPositions
-          wt.zdst[nz] = dst;
-          wt.zscale[nz] = b;
-          ++nz;
-          continue;
-        }
-        if (nw >= kMaxWords) {
+    for (int cc = 0; cc < ps->member_ncomp[m] && staged; ++cc) {
+      char* dst = (char*)ps->swap[m].p + ((size_t)cc * swap_stride) * b;
+      if (m == commit_xt) {  // constant 0 after the fused updatePtclPositions
+        int& nz = (b == 8) ? wt.nz8 : wt.nz4;
+        if (nz >= 8) {
           staged = false;
           break;
         }
-        const int sm = (m == commit_x) ? commit_xt : m;  // fused updatePtclPositions
-        wt.src[nw] = (const char*)ps->data[sm].p + ((size_t)cc * ps->stride) * b + hw * 4;
-        wt.sscale[nw] = (m == commit_xt) ? -1 : b;
-        wt.dst[nw] = dst;
-        wt.dscale[nw] = b;
-        ++nw;
+        ((b == 8) ? wt.z8 : wt.z4)[nz++] = dst;
+        continue;
       }
+      const int sm = (m == commit_x) ? commit_xt : m;  // fused updatePtclPositions
+      const char* src = (const char*)ps->data[sm].p + ((size_t)cc * ps->stride) * b;
+      if (b == 8) {
+        if (wt.n8 >= kMax8) {
+          staged = false;
+          break;
+        }
+        wt.src8[wt.n8] = src;
+        wt.dst8[wt.n8++] = dst;
+      } else {
+        if (wt.n4 >= kMax4) {
+          staged = false;
+          break;
+        }
+        wt.src4[wt.n4] = src;
+        wt.dst4[wt.n4++] = dst;
+      }
+    }
   }
-  wt.nzero = nz;
+  const int nw = 2 * wt.n8 + wt.n4;
   // 16-B quads per record; 3 is rounded up to 4: a 48-B record straddles 64-B sectors and the
   // scattered stores of pass 1 become read-modify-writes (measured 0.25 -> 0.40 ms per 10 M)
   const int NQ = (nw + 3) / 4 == 3 ? 4 : (nw + 3) / 4;
-  wt.nwords = nw;
   if (staged && (NQ == 4 || NQ == 10 || NQ <= 3 || NQ == 6 || NQ == 8)) {
     PP_HIP_CHECK(ps->s_aos.reserve((size_t)std::max(new_capacity, 1) * NQ * 16));
     uint4* aos = ps->s_aos.as<uint4>();
