@@ -373,44 +373,57 @@ __global__ void k_tile_count(int nchunks, int TP, const int* __restrict__ widths
 // ---- row-tiled histogram of new parents (SCS): thread = (old tile, row).  Particles that stay in
 // their element are counted in a register and leave as ONE atomic per thread; only movers issue
 // their own.  Lanes of a wave are different rows, so same-address contention inside a wave is gone.
-__global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
+__global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP, int G,
                               const int* __restrict__ tiles, const int* __restrict__ chunk_start,
                               const int* __restrict__ chunk_width, const int* __restrict__ r2e,
                               const unsigned char* __restrict__ mask,
                               const int* __restrict__ new_element, int ne, int* __restrict__ ppe,
                               Totals* tot) {
+  // thread = (group of G consecutive tiles, row): consecutive tiles of one chunk are the same row
+  // of the same element, so the stayers of up to G*TP columns leave as ONE atomic (the L2 atomic
+  // rate, not the 5 B/particle read, bounds this kernel)
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int tile = (int)(g / C), r = (int)(g - (long long)tile * C);
-  if (tile >= *ntiles_dev) return;
-  const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
-  const int start = chunk_start[c] + r, pend = min(p0 + TP, chunk_width[c]);
-  const int e = r2e[c * C + r];
-  int stay = 0;
-  for (int pb = p0; pb < pend; pb += 8) {  // 16 independent loads in flight, then the histogram
-    int nel[8];
-    unsigned char mk[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int pid = start + (pb + j) * C;
-      mk[j] = 0;
-      nel[j] = -1;
-      if (pb + j < pend) {
-        mk[j] = mask[pid];
-        nel[j] = new_element[pid];
-      }
+  const int grp = (int)(g / C), r = (int)(g - (long long)grp * C);
+  const int ntiles = *ntiles_dev;
+  int cur = -1, e = -1, start = 0, stay = 0;
+  for (int k = 0; k < G; ++k) {
+    const int tile = grp * G + k;
+    if (tile >= ntiles) break;
+    const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
+    if (c != cur) {
+      if (stay) atomicAdd(&ppe[e], stay);
+      stay = 0;
+      cur = c;
+      start = chunk_start[c] + r;
+      e = r2e[c * C + r];
     }
+    const int pend = min(p0 + TP, chunk_width[c]);
+    for (int pb = p0; pb < pend; pb += 8) {  // 16 independent loads in flight, then the histogram
+      int nel[8];
+      unsigned char mk[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int ne_ = nel[j];
-      if (!mk[j] || ne_ == -1) continue;
-      if (ne_ < 0 || ne_ >= ne) {
-        tot->invalid = 1;
-        continue;
+      for (int j = 0; j < 8; ++j) {
+        const int pid = start + (pb + j) * C;
+        mk[j] = 0;
+        nel[j] = -1;
+        if (pb + j < pend) {
+          mk[j] = mask[pid];
+          nel[j] = new_element[pid];
+        }
       }
-      if (ne_ == e)
-        ++stay;
-      else
-        atomicAdd(&ppe[ne_], 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ne_ = nel[j];
+        if (!mk[j] || ne_ == -1) continue;
+        if (ne_ < 0 || ne_ >= ne) {
+          tot->invalid = 1;
+          continue;
+        }
+        if (ne_ == e)
+          ++stay;
+        else
+          atomicAdd(&ppe[ne_], 1);
+      }
     }
   }
   if (stay) atomicAdd(&ppe[e], stay);
@@ -639,54 +652,70 @@ struct WordTable {
   char* z4[8];
 };
 // pass 1a: slot assignment only (atomics), destination index per old slot (-1 = not moved)
-__global__ void k_assign_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
+__global__ void k_assign_tiled(const int* __restrict__ ntiles_dev, int C, int TP, int G,
                                const int* __restrict__ tiles, const int* __restrict__ chunk_start,
                                const int* __restrict__ chunk_width, const int* __restrict__ r2e,
                                const unsigned char* __restrict__ mask,
                                const int* __restrict__ new_element, const int* __restrict__ e2r_new,
                                int C_new, int* __restrict__ row_cursor,
                                unsigned char* __restrict__ new_mask, int* __restrict__ new_idx) {
+  // thread = (group of G consecutive tiles, row), G*TP <= 32: the stayers of a run of tiles of one
+  // chunk reserve their new slots with ONE returning atomic (see k_count_tiled)
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int tile = (int)(g / C), r = (int)(g - (long long)tile * C);
-  if (tile >= *ntiles_dev) return;
-  const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
-  const int start = chunk_start[c] + r, pend = min(p0 + TP, chunk_width[c]);
-  const int e = r2e[c * C + r];
-  unsigned stay = 0;
-  for (int pb = p0; pb < pend; pb += 8) {  // loads of 8 columns in flight, then the slot atomics
-    int nel[8];
-    unsigned char mk[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int pid = start + (pb + j) * C;
-      mk[j] = 0;
-      nel[j] = -1;
-      if (pb + j < pend) {
-        mk[j] = mask[pid];
-        nel[j] = new_element[pid];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (pb + j >= pend) continue;
-      int idx = -1;
-      if (mk[j]) {
-        if (nel[j] == e)
-          stay |= 1u << (pb + j - p0);
-        else if (nel[j] != -1)
-          idx = atomicAdd(&row_cursor[e2r_new[nel[j]]], C_new);
-      }
-      new_idx[start + (pb + j) * C] = idx;
-    }
-  }
-  if (stay) {
+  const int grp = (int)(g / C), r = (int)(g - (long long)grp * C);
+  const int ntiles = *ntiles_dev;
+  int cur = -1, e = -1, start = 0, run_p0 = 0;
+  unsigned stay = 0;  // bit b = column run_p0 + b of the current run stays in its element
+  auto flush = [&]() {
+    if (!stay) return;
     int idx = atomicAdd(&row_cursor[e2r_new[e]], __popc(stay) * C_new);
-    for (int p = p0; p < pend; ++p)
-      if (stay & (1u << (p - p0))) {
-        new_idx[start + p * C] = idx;
-        idx += C_new;
+    while (stay) {
+      const int b = __ffs(stay) - 1;
+      stay &= stay - 1;
+      new_idx[start + (run_p0 + b) * C] = idx;
+      idx += C_new;
+    }
+  };
+  for (int k = 0; k < G; ++k) {
+    const int tile = grp * G + k;
+    if (tile >= ntiles) break;
+    const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
+    if (c != cur) {
+      flush();
+      cur = c;
+      start = chunk_start[c] + r;
+      e = r2e[c * C + r];
+      run_p0 = p0;
+    }
+    const int pend = min(p0 + TP, chunk_width[c]);
+    for (int pb = p0; pb < pend; pb += 8) {  // loads of 8 columns in flight, then the slot atomics
+      int nel[8];
+      unsigned char mk[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int pid = start + (pb + j) * C;
+        mk[j] = 0;
+        nel[j] = -1;
+        if (pb + j < pend) {
+          mk[j] = mask[pid];
+          nel[j] = new_element[pid];
+        }
       }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (pb + j >= pend) continue;
+        int idx = -1;
+        if (mk[j]) {
+          if (nel[j] == e)
+            stay |= 1u << (pb + j - run_p0);
+          else if (nel[j] != -1)
+            idx = atomicAdd(&row_cursor[e2r_new[nel[j]]], C_new);
+        }
+        new_idx[start + (pb + j) * C] = idx;
+      }
+    }
   }
+  flush();
 }
 // pass 1b: one thread per old slot packs its record; the wave transposes through LDS so that
 // NQ adjacent lanes store one whole record (full 64-B sectors leave the CU already merged:
@@ -843,7 +872,7 @@ int finish_layout_upload(pp_ps* ps, const HostLayout& L, const std::vector<int>&
   (void)ppe;
   // row tiles (chunk, first p) of kTileP columns for the row-major hot kernels
   std::vector<int> tiles;
-  if (getenv("PP_TILE_P")) ps->tile_p = std::max(1, atoi(getenv("PP_TILE_P")));
+  if (getenv("PP_TILE_P")) ps->tile_p = std::min(32, std::max(1, atoi(getenv("PP_TILE_P"))));  // <= 32: stay masks
   for (int c = 0; c < L.nchunks; ++c)
     for (int p0 = 0; p0 < L.chunk_widths[c]; p0 += ps->tile_p) {
       tiles.push_back(c);
@@ -977,9 +1006,12 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   int* ppe = ps->s_ppe.as<int>();
   const bool have_old = ps->capacity > 0 && ps->num_ptcls > 0;
   const unsigned old_grid = grid_for((size_t)ps->ntiles_max * ps->C);
+  // tiles per thread of the count/assign kernels: G*TP <= 32 (stay bit mask)
+  const int G = std::max(1, 32 / ps->tile_p);
+  const unsigned grp_grid = grid_for(((size_t)ps->ntiles_max + G - 1) / G * ps->C);
   if (have_old && old_grid > 0)
-    k_count_tiled<<<old_grid, kBlock, 0, st>>>(
-        ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(),
+    k_count_tiled<<<grp_grid, kBlock, 0, st>>>(
+        ps->d_ntiles.as<int>(), ps->C, ps->tile_p, G, ps->d_tiles.as<int>(),
         ps->d_chunk_start.as<int>(), ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(),
         ps->d_mask.as<unsigned char>(), new_element, ne, ppe, tot);
   if (n_new > 0) {
@@ -1111,8 +1143,8 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     break;
     PP_HIP_CHECK(ps->s_idx.reserve(sizeof(int) * (size_t)ps->capacity));
     int* new_idx = ps->s_idx.as<int>();
-    k_assign_tiled<<<old_grid, kBlock, 0, st>>>(
-        ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(),
+    k_assign_tiled<<<grp_grid, kBlock, 0, st>>>(
+        ps->d_ntiles.as<int>(), ps->C, ps->tile_p, G, ps->d_tiles.as<int>(),
         ps->d_chunk_start.as<int>(), ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(),
         ps->d_mask.as<unsigned char>(), new_element, ps->s_e2r2.as<int>(), C_new,
         ps->s_rowstart.as<int>(), ps->s_mask2.as<unsigned char>(), new_idx);

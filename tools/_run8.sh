@@ -5,6 +5,6 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_ou
 f=$(find $R/gpurun_out/kt_c3 -name "*kernel_stats.csv" | head -1); cp $f $R/gpurun_out/kernel_stats_c3.csv
 python3 - "$f" <<'PY'
 import csv,sys
-for r in list(csv.DictReader(open(sys.argv[1])))[:8]:
+for r in list(csv.DictReader(open(sys.argv[1])))[:9]:
     print("  %-45s calls/step=%.1f us/step=%.1f" % (r["Name"][:45], int(r["Calls"])/23, float(r["TotalDurationNs"])/23e3))
 PY
