@@ -481,6 +481,123 @@ __global__ void k_reduce_widths(int nchunks, const int* __restrict__ widths, Tot
     tot->cw_cnt = Cn;
   }
 }
+// One block does the whole O(nchunks) part of the layout that used to be seven launches:
+// width reduction (cw_sum, cw_cnt), padding (EVENLY / PROPORTIONALLY / none; INVERSELY needs the
+// ordered fp sum and keeps the separate kernels), slices / slots / tiles per chunk and their three
+// exclusive scans (slice_off, chunk_start, tile_off) with totals.
+__global__ void __launch_bounds__(1024)
+    k_layout_fused(int nchunks, int C, int V, int TP, int pad_strat, double pad,
+                   int* __restrict__ widths, int* __restrict__ slice_off,
+                   int* __restrict__ chunk_start, int* __restrict__ tile_off, Totals* tot,
+                   int* __restrict__ ntiles_out) {
+  __shared__ int ssum[16], scnt[16];
+  __shared__ int w3[16][3];
+  __shared__ int carry[3];
+  __shared__ int cw_sum_s, cw_cnt_s;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  {  // ---- reduction of the unpadded widths
+    int s = 0, c = 0;
+    for (int i = t; i < nchunks; i += 1024) {
+      s += widths[i];
+      c += widths[i] > 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      s += __shfl_down(s, o);
+      c += __shfl_down(c, o);
+    }
+    if (lane == 0) {
+      ssum[wave] = s;
+      scnt[wave] = c;
+    }
+    __syncthreads();
+    if (t == 0) {
+      int S = 0, Cn = 0;
+      for (int w = 0; w < 16; ++w) {
+        S += ssum[w];
+        Cn += scnt[w];
+      }
+      cw_sum_s = S;
+      cw_cnt_s = Cn;
+      tot->cw_sum = S;
+      tot->cw_cnt = Cn;
+      carry[0] = carry[1] = carry[2] = 0;
+    }
+    __syncthreads();
+  }
+  const int cw_sum = cw_sum_s, cw_cnt = cw_cnt_s;
+  const int avg_pad = (pad > 0 && cw_sum > 0 && pad_strat == PP_PAD_EVENLY) ? (int)(cw_sum * pad / cw_cnt) : 0;
+  constexpr int ITEMS = 4;
+  for (int base = 0; base < nchunks; base += 1024 * ITEMS) {
+    int v[ITEMS][3];
+    int s0 = 0, s1 = 0, s2 = 0;
+    for (int k = 0; k < ITEMS; ++k) {
+      const int i = base + t * ITEMS + k;
+      v[k][0] = v[k][1] = v[k][2] = 0;
+      if (i < nchunks) {
+        int w = widths[i];
+        if (pad > 0 && cw_sum > 0) {
+          if (pad_strat == PP_PAD_EVENLY) {
+            if (w > 0) w += avg_pad;
+          } else {
+            w = (int)(w + w * pad);
+          }
+          widths[i] = w;
+        }
+        v[k][0] = w / V + ((w % V) != 0);
+        v[k][1] = w * C;
+        v[k][2] = (w + TP - 1) / TP;
+      }
+      s0 += v[k][0];
+      s1 += v[k][1];
+      s2 += v[k][2];
+    }
+    int i0 = s0, i1 = s1, i2 = s2;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y0 = __shfl_up(i0, o), y1 = __shfl_up(i1, o), y2 = __shfl_up(i2, o);
+      if (lane >= o) {
+        i0 += y0;
+        i1 += y1;
+        i2 += y2;
+      }
+    }
+    if (lane == 63) {
+      w3[wave][0] = i0;
+      w3[wave][1] = i1;
+      w3[wave][2] = i2;
+    }
+    __syncthreads();
+    int o0 = carry[0], o1 = carry[1], o2 = carry[2];
+    for (int w = 0; w < wave; ++w) {
+      o0 += w3[w][0];
+      o1 += w3[w][1];
+      o2 += w3[w][2];
+    }
+    int r0 = o0 + i0 - s0, r1 = o1 + i1 - s1, r2 = o2 + i2 - s2;
+    for (int k = 0; k < ITEMS; ++k) {
+      const int i = base + t * ITEMS + k;
+      if (i < nchunks) {
+        slice_off[i] = r0;
+        chunk_start[i] = r1;
+        tile_off[i] = r2;
+      }
+      r0 += v[k][0];
+      r1 += v[k][1];
+      r2 += v[k][2];
+    }
+    __syncthreads();
+    if (t == 1023) {
+      carry[0] = r0;
+      carry[1] = r1;
+      carry[2] = r2;
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    tot->nslices = carry[0];
+    tot->capacity = carry[1];
+    *ntiles_out = carry[2];
+  }
+}
 __global__ void k_chunk_widths2(int nchunks, int C, int ne, const unsigned long long* __restrict__ keys,
                                 unsigned long long base, int sorted, const int* __restrict__ ppe,
                                 int* __restrict__ widths) {
@@ -976,19 +1093,23 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
   L.chunk_start = ps->s_cstart2.as<int>();
   k_chunk_widths2<<<grid_for((size_t)nchunks * 64), kBlock, 0, st>>>(
       nchunks, C_new, ne, L.keys, L.base, L.sorted ? 1 : 0, ppe, L.widths);
-  if (ps->shuffle_padding > 0) {
+  PP_HIP_CHECK(ps->s_scan.reserve(sizeof(int)));
+  if (ps->pad_strat != PP_PAD_INVERSELY || !(ps->shuffle_padding > 0)) {
+    k_layout_fused<<<1, 1024, 0, st>>>(nchunks, C_new, ps->V, ps->tile_p, ps->pad_strat,
+                                       ps->shuffle_padding, L.widths, L.slice_off, L.chunk_start,
+                                       L.tile_off, tot, ps->s_scan.as<int>());
+  } else {
     k_reduce_widths<<<1, 1024, 0, st>>>(nchunks, L.widths, tot);
-    if (ps->pad_strat == PP_PAD_INVERSELY) k_cw_inv_serial<<<1, 64, 0, st>>>(nchunks, L.widths, tot);
+    k_cw_inv_serial<<<1, 64, 0, st>>>(nchunks, L.widths, tot);
     k_apply_padding<<<grid_for(nchunks), kBlock, 0, st>>>(nchunks, ps->pad_strat,
                                                           ps->shuffle_padding, L.widths, tot);
+    k_slices_and_slots<<<grid_for(nchunks), kBlock, 0, st>>>(nchunks, C_new, ps->V, L.widths, L.nsl,
+                                                             L.nslots);
+    k_scan_excl<<<1, 1024, 0, st>>>(nchunks, L.nsl, L.slice_off, &tot->nslices);
+    k_scan_excl<<<1, 1024, 0, st>>>(nchunks, L.nslots, L.chunk_start, &tot->capacity);
+    k_tile_count<<<grid_for(nchunks), kBlock, 0, st>>>(nchunks, ps->tile_p, L.widths, L.tile_cnt);
+    k_scan_excl<<<1, 1024, 0, st>>>(nchunks, L.tile_cnt, L.tile_off, ps->s_scan.as<int>());
   }
-  k_slices_and_slots<<<grid_for(nchunks), kBlock, 0, st>>>(nchunks, C_new, ps->V, L.widths, L.nsl,
-                                                           L.nslots);
-  k_scan_excl<<<1, 1024, 0, st>>>(nchunks, L.nsl, L.slice_off, &tot->nslices);
-  k_scan_excl<<<1, 1024, 0, st>>>(nchunks, L.nslots, L.chunk_start, &tot->capacity);
-  k_tile_count<<<grid_for(nchunks), kBlock, 0, st>>>(nchunks, ps->tile_p, L.widths, L.tile_cnt);
-  PP_HIP_CHECK(ps->s_scan.reserve(sizeof(int)));
-  k_scan_excl<<<1, 1024, 0, st>>>(nchunks, L.tile_cnt, L.tile_off, ps->s_scan.as<int>());
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
