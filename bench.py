@@ -135,7 +135,7 @@ class Stepper:
         return float(np.mean([a.elapsed_ms(b) for a, b in self.kernel_ms])) if self.kernel_ms else None
 
 
-def cpu_baseline(pp, w, name, deg, sample, steps=2):
+def cpu_baseline(pp, w, name, deg, sample, steps=20):
     """The oracle (restated reference, Kokkos::Serial semantics: C=1, unfused kernels, one pass
     per kernel per walk iteration) timed on one host core on a bounded sample of the workload."""
     ppo = pumipic_amd_loader.load_oracle()
@@ -174,7 +174,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "2d", "2dc3"])
     ap.add_argument("--particles", type=int, default=10_000_000, help="particles per GPU")
     ap.add_argument("--deg", type=float, default=0.5, help="degrees per push (testing.cmake:117)")
-    ap.add_argument("--cpu-sample", type=int, default=300_000)
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000,
+                    help="particles of the bounded CPU-baseline sample (x 20 steps, ~10 s on one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--remainder", default="last", choices=["last", "spread"],
                     help="where particles left over by the Gaussian draws go: 'last' = literal "
