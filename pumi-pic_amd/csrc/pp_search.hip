@@ -936,6 +936,7 @@ __device__ __forceinline__ bool column_math(const WalkArgs& A, const PState& s, 
   if (!live) return false;
   double rad;
   bool done = false;
+  bool origin_ok = true;
   if constexpr (DIM == 2) {
     if (A.abl & 2) {
       dest.x = s.phi + 1.0;
@@ -948,6 +949,8 @@ __device__ __forceinline__ bool column_math(const WalkArgs& A, const PState& s, 
     stg<NT>(A.xt + A.stride + pid, dest.y);
     if (elem == -1) done = true;  // hpp:1051-1056 (seed == -nelems)
   } else {
+    // parent check first (a pure function of the origin): the origin's registers die with the push
+    origin_ok = (elem == -1) || inside_cached(cache, V3{s.x, s.y, s.z}, A.tol);
     if (A.abl & 2) {
       dest = V3{s.x + 1e-3 * s.b, s.y, s.z};
       rad = s.phi;
@@ -964,12 +967,10 @@ __device__ __forceinline__ bool column_math(const WalkArgs& A, const PState& s, 
   }
   if (A.abl & 1) done = true;
   stg<NT>(A.pphi + pid, (float)rad);
-  if constexpr (DIM == 3) {
-    if (!done && !inside_cached(cache, V3{s.x, s.y, s.z}, A.tol)) {
-      atomicAdd(&A.cnt->not_in_elem, 1);
-      elem = -1;
-      done = true;
-    }
+  if (!done && !origin_ok) {  // check_initial_parents (tpp:72-145)
+    atomicAdd(&A.cnt->not_in_elem, 1);
+    elem = -1;
+    done = true;
   }
   if (!done) {  // first walk step on the cached record
     int next;
@@ -1445,7 +1446,8 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
     // OCC = minimum waves per SIMD the register allocator must leave room for (tuning knob;
     // measured in profiles/): 3-D defaults to 4 (104 VGPRs, no spill)
     // OCC = waves per SIMD the register allocator must leave room for.  Measured on MI355X
-    // (profiles/r01_*): 3-D is fastest at 4 (104 VGPRs, no spill); 5 spills, 3 hides less latency.
+    // (profiles/r01_*): 3-D is fastest at 4 (127 VGPRs, no spill); a 96-register build for 5 waves
+    // spills and runs 2x slower, 3 hides less latency.
     static const int occ = getenv("PP_WALK_OCC") ? atoi(getenv("PP_WALK_OCC")) : 4;
     // Two row-tiled variants (measured on MI355X, profiles/r01_c_*):
     //   k_push_walk_rows   walks every particle to completion inside the column loop;
