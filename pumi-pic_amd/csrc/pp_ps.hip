@@ -909,6 +909,36 @@ __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
     }
   }
 }
+// CSR staged move (same two passes as SCS): slot assignment by the element cursor, pack through
+// the LDS transpose into 64-B-multiple records, then a flat pass that writes the new SoA coalesced
+__global__ void k_assign_csr(int n, const int* __restrict__ elems, int* __restrict__ cursor,
+                             int* __restrict__ new_idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int e = elems[i];
+  new_idx[i] = e < 0 ? -1 : atomicAdd(&cursor[e], 1);  // negative ids are removed (CSR_rebuild.hpp:36-40)
+}
+template <int NQ>
+__global__ void k_unpack_flat(int n, const uint4* __restrict__ aos, WordTable t) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= n) return;
+  const uint4* sp = aos + (long long)slot * NQ;
+  unsigned w[NQ * 4];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const uint4 v = sp[q];
+    w[4 * q] = v.x;
+    w[4 * q + 1] = v.y;
+    w[4 * q + 2] = v.z;
+    w[4 * q + 3] = v.w;
+  }
+#pragma unroll
+  for (int i = 0; i < NQ * 2; ++i)
+    if (i < t.n8) *(uint2*)(t.dst8[i] + (long long)slot * 8) = make_uint2(w[2 * i], w[2 * i + 1]);
+#pragma unroll
+  for (int j = 0; j < (NQ * 4 < kMax4 ? NQ * 4 : kMax4); ++j)
+    if (j < t.n4) *(unsigned*)(t.dst4[j] + (long long)slot * 4) = w[NQ * 4 - 1 - j];
+}
 // CSR counting sort (CSR_rebuild.hpp:62-108)
 __global__ void k_move_csr(int nold, const int* __restrict__ new_element, int* __restrict__ cursor,
                            MoveArgs a) {
@@ -1114,6 +1144,43 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
   return PP_OK;
 }
 
+// Entry table of the staged move: sources are member arrays `src[m]` with component stride
+// `src_stride` (elements), destinations the swap buffers.  Returns the number of 16-B quads per
+// record, or 0 when the members do not fit the staged path (other sizes than 4/8 bytes, too many).
+int build_word_table(const pp_ps* ps, const void* const* src, int64_t src_stride, int64_t dst_stride,
+                     int commit_x, int commit_xt, WordTable& wt) {
+  wt = WordTable{};
+  for (int m = 0; m < ps->nmembers; ++m) {
+    const int b = ps->member_bytes[m];
+    if (b != 4 && b != 8) return 0;
+    for (int cc = 0; cc < ps->member_ncomp[m]; ++cc) {
+      char* dst = (char*)ps->swap[m].p + ((size_t)cc * dst_stride) * b;
+      if (m == commit_xt) {  // constant 0 after the fused updatePtclPositions
+        int& nz = (b == 8) ? wt.nz8 : wt.nz4;
+        if (nz >= 8) return 0;
+        ((b == 8) ? wt.z8 : wt.z4)[nz++] = dst;
+        continue;
+      }
+      const int sm = (m == commit_x) ? commit_xt : m;  // fused updatePtclPositions
+      const char* sp = (const char*)src[sm] + ((size_t)cc * src_stride) * b;
+      if (b == 8) {
+        if (wt.n8 >= kMax8) return 0;
+        wt.src8[wt.n8] = sp;
+        wt.dst8[wt.n8++] = dst;
+      } else {
+        if (wt.n4 >= kMax4) return 0;
+        wt.src4[wt.n4] = sp;
+        wt.dst4[wt.n4++] = dst;
+      }
+    }
+  }
+  const int nw = 2 * wt.n8 + wt.n4;
+  // 16-B quads per record; 3 is rounded up to 4: a 48-B record straddles 64-B sectors and the
+  // scattered stores of pass 1 become read-modify-writes (measured 0.25 -> 0.40 ms per 10 M)
+  const int NQ = (nw + 3) / 4 == 3 ? 4 : (nw + 3) / 4;
+  return (NQ == 4 || NQ == 10 || (NQ >= 1 && NQ <= 3) || NQ == 6 || NQ == 8) ? NQ : 0;
+}
+
 int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_elems,
                 const void* const* new_info, int commit_x, int commit_xt) {
   hipStream_t st = pp::stream();
@@ -1211,47 +1278,15 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   MoveArgs mv = make_move(ps, ps->data, ps->stride, ps->swap, swap_stride);
   mv.commit_x = commit_x;
   mv.commit_xt = commit_xt;
-  // record = all members as 32-bit words (fast path needs 4/8-byte scalars and <= 64 words)
+  // record = all members (fast path needs 4/8-byte scalars, see build_word_table)
   WordTable wt{};
-  bool staged = have_old && old_grid > 0 && getenv("PP_DIRECT_MOVE") == nullptr;
-  for (int m = 0; m < ps->nmembers && staged; ++m) {
-    const int b = ps->member_bytes[m];
-    if (b != 4 && b != 8) staged = false;
-    for (int cc = 0; cc < ps->member_ncomp[m] && staged; ++cc) {
-      char* dst = (char*)ps->swap[m].p + ((size_t)cc * swap_stride) * b;
-      if (m == commit_xt) {  // constant 0 after the fused updatePtclPositions
-        int& nz = (b == 8) ? wt.nz8 : wt.nz4;
-        if (nz >= 8) {
-          staged = false;
-          break;
-        }
-        ((b == 8) ? wt.z8 : wt.z4)[nz++] = dst;
-        continue;
-      }
-      const int sm = (m == commit_x) ? commit_xt : m;  // fused updatePtclPositions
-      const char* src = (const char*)ps->data[sm].p + ((size_t)cc * ps->stride) * b;
-      if (b == 8) {
-        if (wt.n8 >= kMax8) {
-          staged = false;
-          break;
-        }
-        wt.src8[wt.n8] = src;
-        wt.dst8[wt.n8++] = dst;
-      } else {
-        if (wt.n4 >= kMax4) {
-          staged = false;
-          break;
-        }
-        wt.src4[wt.n4] = src;
-        wt.dst4[wt.n4++] = dst;
-      }
-    }
+  int NQ = 0;
+  if (have_old && old_grid > 0 && getenv("PP_DIRECT_MOVE") == nullptr) {
+    const void* srcs[8];
+    for (int m = 0; m < ps->nmembers; ++m) srcs[m] = ps->data[m].p;
+    NQ = build_word_table(ps, srcs, ps->stride, swap_stride, commit_x, commit_xt, wt);
   }
-  const int nw = 2 * wt.n8 + wt.n4;
-  // 16-B quads per record; 3 is rounded up to 4: a 48-B record straddles 64-B sectors and the
-  // scattered stores of pass 1 become read-modify-writes (measured 0.25 -> 0.40 ms per 10 M)
-  const int NQ = (nw + 3) / 4 == 3 ? 4 : (nw + 3) / 4;
-  if (staged && (NQ == 4 || NQ == 10 || NQ <= 3 || NQ == 6 || NQ == 8)) {
+  if (NQ > 0) {
     PP_HIP_CHECK(ps->s_aos.reserve((size_t)std::max(new_capacity, 1) * NQ * 16));
     uint4* aos = ps->s_aos.as<uint4>();
     const unsigned new_grid = grid_for((size_t)ntiles_max * C_new);
@@ -1355,14 +1390,47 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   PP_HIP_CHECK(hipMemcpyAsync(ps->s_rowstart.p, ps->s_offsets2.p, sizeof(int) * ((size_t)ne + 1),
                               hipMemcpyDeviceToDevice, st));
   MoveArgs mv = make_move(ps, ps->data, ps->stride, ps->swap, swap_stride);
-  if (nold > 0)
-    k_move_csr<<<grid_for(nold), kBlock, 0, st>>>(nold, new_element, ps->s_rowstart.as<int>(), mv);
-  if (n_new > 0) {
-    PP_REQUIRE(new_info != nullptr, "rebuild: new particles need new_info_dev");
-    MoveArgs add = mv;
-    for (int m = 0; m < ps->nmembers; ++m) add.src[m] = new_info[m];
-    add.src_stride = n_new;
-    k_add_csr<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ps->s_rowstart.as<int>(), add);
+  if (n_new > 0) PP_REQUIRE(new_info != nullptr, "rebuild: new particles need new_info_dev");
+  WordTable wt{}, wt_new{};
+  int NQ = 0;
+  if (getenv("PP_DIRECT_MOVE") == nullptr) {
+    const void* srcs[8];
+    for (int m = 0; m < ps->nmembers; ++m) srcs[m] = ps->data[m].p;
+    NQ = build_word_table(ps, srcs, ps->stride, swap_stride, -1, -1, wt);
+    if (NQ > 0 && n_new > 0 && build_word_table(ps, new_info, n_new, swap_stride, -1, -1, wt_new) != NQ) NQ = 0;
+  }
+  if (NQ > 0 && on_process > 0) {
+    PP_HIP_CHECK(ps->s_aos.reserve((size_t)on_process * NQ * 16));
+    PP_HIP_CHECK(ps->s_idx.reserve(sizeof(int) * (size_t)std::max(std::max(nold, n_new), 1)));
+    uint4* aos = ps->s_aos.as<uint4>();
+    int* new_idx = ps->s_idx.as<int>();
+    int* cursor = ps->s_rowstart.as<int>();
+#define PP_CSR_STAGED(N)                                                                         \
+  case N:                                                                                        \
+    if (nold > 0) {                                                                              \
+      k_assign_csr<<<grid_for(nold), kBlock, 0, st>>>(nold, new_element, cursor, new_idx);        \
+      k_move_pack<N><<<grid_for(nold), kBlock, 0, st>>>(nold, new_idx, aos, wt);                 \
+    }                                                                                            \
+    if (n_new > 0) {                                                                             \
+      k_assign_csr<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, cursor, new_idx);       \
+      k_move_pack<N><<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_idx, aos, wt_new);           \
+    }                                                                                            \
+    k_unpack_flat<N><<<grid_for(on_process), kBlock, 0, st>>>(on_process, aos, wt);              \
+    break;
+    switch (NQ) {
+      PP_CSR_STAGED(1) PP_CSR_STAGED(2) PP_CSR_STAGED(3) PP_CSR_STAGED(4) PP_CSR_STAGED(6)
+      PP_CSR_STAGED(8) PP_CSR_STAGED(10)
+    }
+#undef PP_CSR_STAGED
+  } else {
+    if (nold > 0)
+      k_move_csr<<<grid_for(nold), kBlock, 0, st>>>(nold, new_element, ps->s_rowstart.as<int>(), mv);
+    if (n_new > 0) {
+      MoveArgs add = mv;
+      for (int m = 0; m < ps->nmembers; ++m) add.src[m] = new_info[m];
+      add.src_stride = n_new;
+      k_add_csr<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ps->s_rowstart.as<int>(), add);
+    }
   }
   ps->data.swap(ps->swap);
   std::swap(ps->stride, ps->swap_stride);
