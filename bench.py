@@ -43,12 +43,16 @@ BYTES = {
 }
 
 
-def build_workload(pp, capi, name, nptcl, rank, world, deg, remainder="last"):
+def build_workload(pp, capi, name, nptcl, rank, world, deg, remainder="last", mesh_size="100k"):
     synth = pp.synth
     if name in ("2d", "2dc3"):
         coords, e2v, cls = synth.annulus_tri()
         dim, mdl = 2, 12
         label = "pseudoXGCm 2-D literal: 100352-tri annulus"
+    elif mesh_size == "1m":  # BASELINE configs[4]: 998 400 tets (this GPU's share of the particles)
+        coords, e2v, cls = synth.torus_tet(n_b=104, n_theta=100, band_width=8)
+        dim, mdl = 3, 12
+        label = "pseudoXGCm 998400-tet tokamak mesh"
     else:
         coords, e2v, cls = synth.torus_tet()
         dim, mdl = 3, 12
@@ -60,7 +64,7 @@ def build_workload(pp, capi, name, nptcl, rank, world, deg, remainder="last"):
     # the synthetic population is a pure function of (mesh, n, rank, world): memoise it on disk so
     # repeated profiler passes on one box do not regenerate 10 M particles every time
     cache = os.path.join(os.environ.get("PP_BENCH_CACHE", "/tmp"),
-                         "pp_pop_%dd_%d_%d_%d_%s.npz" % (dim, nptcl, rank, world, remainder))
+                         "pp_pop_%dd_%d_%d_%d_%d_%s.npz" % (dim, len(e2v), nptcl, rank, world, remainder))
     if os.path.exists(cache):
         z = np.load(cache)
         ppe, elem, xyz, b, phi = z["ppe"], z["elem"], z["xyz"], z["b"], z["phi"]
@@ -177,6 +181,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4_000_000,
                     help="particles of the bounded CPU-baseline sample (x 20 steps, ~10 s on one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mesh", default="100k", choices=["100k", "1m"],
+                    help="3-D mesh: 100 800 tets (configs[1-2]) or 998 400 tets (configs[4], per-GPU share)")
     ap.add_argument("--remainder", default="last", choices=["last", "spread"],
                     help="where particles left over by the Gaussian draws go: 'last' = literal "
                          "pseudoXGCm rule (one outlier element), 'spread' = evenly")
@@ -197,7 +203,7 @@ def main():
     from pumipic_amd import capi
     capi.init(local_rank)  # raises when the HIP library / GPU is missing: no CPU fallback
 
-    w = build_workload(pp, capi, a.workload, a.particles, rank, world, a.deg, a.remainder)
+    w = build_workload(pp, capi, a.workload, a.particles, rank, world, a.deg, a.remainder, a.mesh)
     st = Stepper(pp, capi, w, a.workload, a.deg)
 
     def barrier():
