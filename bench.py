@@ -10,6 +10,10 @@ A "step" is one pass of the hot path over the resident particle population:
   c3 (configs[2]): c2 + updatePtclPositions + SCS rebuild + gyroScatter x2 every step (tet variant
       of the ring map: 4 vertices per ring point); 2dc3 is the 2-D literal of it.
   2d : the literal 2-D pseudoXGCm step (elliptical push + search_mesh_2d) on 100 352 triangles.
+  c5 (configs[4], opt-in): c3 with ownership: every rank owns a block of elements; after the search
+      the particles whose new element another rank owns are packed into records, exchanged with ONE
+      all-to-all-v (RCCL) and enter the receiver's rebuild as new particles; the two scatter fields
+      are summed over ranks (gyroSync).  Use with --mesh 1m --particles 32000000 for the config.
 
 Inputs are synthetic (pumi-pic_amd/synth.py) and resident in HBM before the timed region.
 N > 1: one process per GPU (torch.distributed / RCCL); every rank owns a contiguous block of
@@ -85,7 +89,7 @@ def build_workload(pp, capi, name, nptcl, rank, world, deg, remainder="last", me
                      shuffle_padding=0.1, extra_padding=0.0, particle_elements=elem,
                      particle_info=info)
     return dict(mesh=mesh, ps=ps, dim=dim, label=label, ne=ne, coords=coords, e2v=e2v, cls=cls,
-                ppe=ppe, elem=elem, info=info)
+                ppe=ppe, elem=elem, info=info, rank=rank, world=world)
 
 
 class Stepper:
@@ -98,7 +102,15 @@ class Stepper:
         self.ids = capi.DevArray.from_host(np.full(cap, -1, dtype=np.int32))
         self.first = True
         self.kernel_ms = []
-        if name in ("c3", "2dc3"):
+        if name == "c5":
+            from pumipic_amd import dist as ppdist
+            self.ppdist = ppdist
+            self.rank, self.world = w["rank"], w["world"]
+            owners = ppdist.element_block_owners(w["ne"], self.world)
+            self.owners = capi.DevArray.from_host(owners)
+            self.safe = capi.DevArray.from_host((owners == self.rank).astype(np.uint8))
+            self.moved = 0
+        if name in ("c3", "2dc3", "c5"):
             self.fwd, self.bkwd = capi.create_gyro_ring_mappings(self.mesh)
             self.w_f = capi.DevArray(self.mesh.nverts, np.float64)
             self.w_b = capi.DevArray(self.mesh.nverts, np.float64)
@@ -111,7 +123,7 @@ class Stepper:
         if self.name == "c2":
             capi.push_search(self.mesh, self.ps, self.h, self.k, self.d, self.deg, self.ids,
                              seeded=not self.first, looplimit=200, want_found=False)
-        elif self.name == "c3":
+        elif self.name in ("c3", "c5"):
             # rebuilt every step: every particle sits in its row's element, no seed ids needed
             capi.push_search(self.mesh, self.ps, self.h, self.k, self.d, self.deg, self.ids,
                              seeded=False, looplimit=200, want_found=False)
@@ -133,7 +145,32 @@ class Stepper:
             if cap > self.ids.n:
                 self.ids = capi.DevArray(cap, np.int32)
             self.ids.fill_bytes(0xff)
+        elif self.name == "c5":
+            capi.update_positions(self.ps)
+            ne_, npr = capi.set_unsafe_procs(self.ps, self.ids, self.safe, self.owners, self.rank)
+            sent, _ = self.ppdist.migrate(capi, self.ps, ne_, npr, self.rank, self.world)
+            self.moved += sent
+            capi.gyro_scatter(self.mesh, self.ps, self.fwd, out=self.w_f)
+            capi.gyro_scatter(self.mesh, self.ps, self.bkwd, out=self.w_b)
+            if self.world > 1:  # gyroSync: SUM over ranks of the interleaved fields
+                self._allreduce_fields()
+            cap = max(self.ps.capacity(), 1)
+            if cap > self.ids.n:
+                self.ids = capi.DevArray(cap, np.int32)
+            self.ids.fill_bytes(0xff)
         # "2d": search_mesh_2d re-seeds from the previous ids as given
+
+    def _allreduce_fields(self):
+        import ctypes
+        import torch
+        nv = self.mesh.nverts
+        if not hasattr(self, "sync_t"):
+            self.sync_t = torch.empty(2 * nv, dtype=torch.float64, device="cuda")
+        # pack both fields into one torch tensor on the device, reduce, leave the sum there
+        self.capi.check(self.capi.lib().pp_gyro_sync_pack(nv, self.w_f.ptr, self.w_b.ptr,
+                                                          ctypes.c_void_p(self.sync_t.data_ptr())))
+        self.capi.sync()
+        self.ppdist.allreduce_sum(self.sync_t)
 
     def kernel_avg_ms(self):
         return float(np.mean([a.elapsed_ms(b) for a, b in self.kernel_ms])) if self.kernel_ms else None
@@ -175,7 +212,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "2d", "2dc3"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "2d", "2dc3"])
     ap.add_argument("--particles", type=int, default=10_000_000, help="particles per GPU")
     ap.add_argument("--deg", type=float, default=0.5, help="degrees per push (testing.cmake:117)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000,
@@ -245,7 +282,7 @@ def main():
                     traffic = tj["traffic_bytes_per_step"]
             except (ValueError, KeyError):
                 traffic = None
-        bpp = BYTES[{"2dc3": "2d", "c3": "c2"}.get(a.workload, a.workload)]
+        bpp = BYTES[{"2dc3": "2d", "c3": "c2", "c5": "c2"}.get(a.workload, a.workload)]
         achieved = bpp * nlive / (kms * 1e-3) / 1e9 if kms else None
         out = {
             "metric": "particles pushed+searched+scattered / sec / GPU; achieved HBM GB/s vs peak",
@@ -265,6 +302,7 @@ def main():
                 {"c2": "push+search only (fused toroidal push + BCC walk), deg/push=%g" % a.deg,
                  "2d": "elliptical push + search_mesh_2d (fused), deg/push=%g" % a.deg,
                  "c3": "push+search+rebuild+gyroScatter x2 (tet ring map), deg/push=%g" % a.deg,
+                 "c5": "push+search+migrate(all-to-all-v)+rebuild+gyroScatter x2+gyroSync, deg/push=%g" % a.deg,
                  "2dc3": "push+search+rebuild+gyroScatter x2, deg/push=%g" % a.deg}[a.workload]),
                 "parallelism": "element-block partition, %d rank(s), full-mesh replica" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
