@@ -221,6 +221,29 @@ int pp_gyro_sync_pack(int nverts, const double* fwd_dev, const double* bkwd_dev,
 int pp_avg_ptcl_density(const pp_mesh* mesh, const pp_ps* ps, double* elem_cnt_dev,
                         double* vert_density_dev);
 
+/* ------------------------------------------------------------------ gather side (mesh/grid -> particle) */
+/* findBCCoordsInTet + interpolateTetVtx / interpolate3dFieldTet, src/pumipic_adjacency.hpp:772-809,
+ * for every live particle: bcc of the position member in its element (elem_ids_dev, or the parent
+ * element when NULL), out_dev[c*capacity + pid] = sum_f bcc[f] * field_dev[vertex_opposite(f)*dof + c].
+ * Dead slots and slots with element < 0 read 0.  *num_degenerate (may be NULL: no host sync) counts
+ * particles whose tet has vol6 <= 1e-20 (the reference aborts there, :805). */
+int pp_gather_tet_vtx(const pp_mesh* mesh, const pp_ps* ps, int m_x, const int* elem_ids_dev,
+                      const double* field_dev, int dof, double* out_dev, int* num_degenerate);
+/* interpolate2dField src/pumipic_utils.hpp:186-241 (regular (R|x, z) grid, one component) */
+int pp_interp2d_field(const pp_ps* ps, int m_x, const double* data_dev, double gridx0, double gridz0,
+                      double dx, double dz, int nx, int nz, int cyl_symm, int ncomp, int comp,
+                      double* out_dev);
+/* interp2dVector src/pumipic_utils.hpp:437-454: 3-component grid field, rotated to (x,y) when
+ * cyl_symm; out_dev[c*capacity + pid] */
+int pp_interp2d_vector(const pp_ps* ps, int m_x, const double* data3_dev, double gridx0, double gridz0,
+                       double dx, double dz, int nx, int nz, int cyl_symm, double* out_dev);
+/* interpolate3d_field src/pumipic_utils.hpp:375-418 (tri-linear, grid coordinate arrays) */
+int pp_interp3d_field(const pp_ps* ps, int m_x, int nx, int ny, int nz, const double* gridx_dev,
+                      const double* gridy_dev, const double* gridz_dev, const double* data_dev,
+                      double* out_dev);
+/* The same helpers (plus the _wgrid forms) are device-inline in pumi-pic_amd/include/pumipic_gather.hpp
+ * for use inside user lambdas. */
+
 /* ------------------------------------------------------------------ migration glue */
 /* setUnsafeProcs src/pumipic_ptcl_ops.hpp:32-52 */
 int pp_set_unsafe_procs(const pp_ps* ps, const int* elems_dev, const unsigned char* safe_dev,

@@ -186,4 +186,15 @@ void ppo_set_unsafe_procs(const ppo_ps* ps, const int* elems, const unsigned cha
 #ifdef __cplusplus
 }
 #endif
+/* gather side: src/pumipic_adjacency.hpp:772-809, src/pumipic_utils.hpp:186-241,375-454
+ * (out arrays are [component][capacity]) */
+void ppo_gather_tet_vtx(const ppo_mesh* mesh, const ppo_ps* ps, int m_x, const int* elem_ids,
+                        const double* field, int dof, double* out, int* num_degenerate);
+void ppo_interp2d_field(const ppo_ps* ps, int m_x, const double* data, double gridx0, double gridz0,
+                        double dx, double dz, int nx, int nz, int cyl, int ncomp, int comp, double* out);
+void ppo_interp2d_vector(const ppo_ps* ps, int m_x, const double* data3, double gridx0, double gridz0,
+                         double dx, double dz, int nx, int nz, int cyl, double* out);
+void ppo_interp3d_field(const ppo_ps* ps, int m_x, int nx, int ny, int nz, const double* gridx,
+                        const double* gridy, const double* gridz, const double* data, double* out);
+
 #endif

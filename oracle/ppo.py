@@ -113,6 +113,14 @@ def lib():
                                        C.c_int, C.c_int, c_double_p]
         L.ppo_avg_ptcl_density.argtypes = [C.POINTER(_MeshS), C.POINTER(_PsS), c_double_p,
                                            c_double_p]
+        L.ppo_gather_tet_vtx.argtypes = [C.POINTER(_MeshS), C.POINTER(_PsS), C.c_int, c_int_p,
+                                         c_double_p, C.c_int, c_double_p, c_int_p]
+        L.ppo_interp2d_field.argtypes = [C.POINTER(_PsS), C.c_int, c_double_p] + [C.c_double] * 4 + \
+            [C.c_int] * 5 + [c_double_p]
+        L.ppo_interp2d_vector.argtypes = [C.POINTER(_PsS), C.c_int, c_double_p] + [C.c_double] * 4 + \
+            [C.c_int] * 3 + [c_double_p]
+        L.ppo_interp3d_field.argtypes = [C.POINTER(_PsS), C.c_int, C.c_int, C.c_int, C.c_int] + \
+            [c_double_p] * 5
         L.ppo_interpolate_tet_vtx.restype = C.c_double
         L.ppo_interpolate_tet_vtx.argtypes = [C.POINTER(_MeshS), c_double_p, C.c_int, c_double_p,
                                               C.c_int, C.c_int]
@@ -442,6 +450,38 @@ def gyro_scatter(mesh, ps, v2v, rmax=0.038, gnr=3, gppr=8):
     w = np.zeros(mesh.nverts, dtype=np.float64)
     lib().ppo_gyro_scatter(mesh.p, ps.p, _ip(v2v), rmax, gnr, gppr, _dp(w))
     return w
+
+
+def gather_tet_vtx(mesh, ps, field, dof=1, elem_ids=None, m_x=0):
+    cap = max(ps.capacity(), 1)
+    field = np.ascontiguousarray(field, dtype=np.float64)
+    out = np.zeros((dof, cap), dtype=np.float64)
+    bad = C.c_int(0)
+    ids = None if elem_ids is None else _ip(np.ascontiguousarray(elem_ids, dtype=np.int32))
+    lib().ppo_gather_tet_vtx(mesh.p, ps.p, m_x, ids, _dp(field), dof, _dp(out), C.byref(bad))
+    return out, bad.value
+
+
+def interp2d_field(ps, data, gridx0, gridz0, dx, dz, nx, nz, cyl_symm=True, ncomp=1, comp=0, m_x=0):
+    data = np.ascontiguousarray(data, dtype=np.float64)
+    out = np.zeros(max(ps.capacity(), 1), dtype=np.float64)
+    lib().ppo_interp2d_field(ps.p, m_x, _dp(data), gridx0, gridz0, dx, dz, nx, nz, int(cyl_symm), ncomp,
+                             comp, _dp(out))
+    return out
+
+
+def interp2d_vector(ps, data3, gridx0, gridz0, dx, dz, nx, nz, cyl_symm=False, m_x=0):
+    data3 = np.ascontiguousarray(data3, dtype=np.float64)
+    out = np.zeros((3, max(ps.capacity(), 1)), dtype=np.float64)
+    lib().ppo_interp2d_vector(ps.p, m_x, _dp(data3), gridx0, gridz0, dx, dz, nx, nz, int(cyl_symm), _dp(out))
+    return out
+
+
+def interp3d_field(ps, gridx, gridy, gridz, data, m_x=0):
+    gx, gy, gz, d = (np.ascontiguousarray(a, dtype=np.float64) for a in (gridx, gridy, gridz, data))
+    out = np.zeros(max(ps.capacity(), 1), dtype=np.float64)
+    lib().ppo_interp3d_field(ps.p, m_x, len(gx), len(gy), len(gz), _dp(gx), _dp(gy), _dp(gz), _dp(d), _dp(out))
+    return out
 
 
 def avg_ptcl_density(mesh, ps):

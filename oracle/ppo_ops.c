@@ -359,3 +359,170 @@ double ppo_interpolate_tet_vtx(const ppo_mesh* mesh, const double* field, int el
   }
   return val;
 }
+
+/* ------------------------------------------------------------------ gather side
+ * src/pumipic_adjacency.hpp:772-809 and src/pumipic_utils.hpp:186-241,375-454, one particle at a
+ * time over the structure (the library's pp_gather_tet_vtx / pp_interp*). */
+static int find_bcc_tet(const ppo_mesh* mesh, int elem, ppo_v3 pos, double bcc[4]) {
+  ppo_v3 M[4];
+  for (int i = 0; i < 4; ++i)
+    for (int c = 0; c < 3; ++c)
+      M[i].v[c] = mesh->coords[(size_t)mesh->elem2verts[(size_t)elem * 4 + i] * 3 + c];
+  return ppo_find_barycentric_tet(M, pos, bcc);
+}
+void ppo_gather_tet_vtx(const ppo_mesh* mesh, const ppo_ps* ps, int m_x, const int* elem_ids,
+                        const double* field, int dof, double* out, int* num_degenerate) {
+  slots s = get_slots(ps);
+  const size_t A = (size_t)ps->alloc;
+  int bad = 0;
+  for (int pid = 0; pid < s.cap; ++pid) {
+    const int e = !s.mask[pid] ? -1 : (elem_ids ? elem_ids[pid] : s.elem[pid]);
+    double bcc[4];
+    int ok = e >= 0;
+    if (ok) {
+      ppo_v3 pos = {{MD(ps, m_x)[pid], MD(ps, m_x)[A + pid], MD(ps, m_x)[2 * A + pid]}};
+      ok = find_bcc_tet(mesh, e, pos, bcc);
+      if (!ok) ++bad;
+    }
+    for (int c = 0; c < dof; ++c) {
+      double val = 0;
+      if (ok)
+        for (int fi = 0; fi < 4; ++fi) {
+          const int v = mesh->elem2verts[(size_t)e * 4 + PPO_TET_OPP[fi]];
+          val = val + bcc[fi] * field[(size_t)v * dof + c];
+        }
+      out[(size_t)c * s.cap + pid] = val;
+    }
+  }
+  if (num_degenerate) *num_degenerate = bad;
+  free_slots(&s);
+}
+static double interp2d_field_pt(const double* data, double gridx0, double gridz0, double dx, double dz,
+                                int nx, int nz, const double pos[3], int cyl, int nComp, int comp) {
+  if (nx * nz == 1) return data[comp];
+  double fxz = 0, fx_z1 = 0, fx_z2 = 0;
+  double dim1 = pos[0];
+  const double z = pos[2];
+  if (cyl) dim1 = sqrt(pos[0] * pos[0] + pos[1] * pos[1]);
+  int i = (int)floor((dim1 - gridx0) / dx);
+  int j = (int)floor((z - gridz0) / dz);
+  if (i < 0) i = 0;
+  if (j < 0) j = 0;
+  const double gridXi = gridx0 + i * dx, gridXip1 = gridx0 + (i + 1) * dx;
+  const double gridZj = gridz0 + j * dz, gridZjp1 = gridz0 + (j + 1) * dz;
+  if (i >= nx - 1 && j >= nz - 1) {
+    fxz = data[(nx - 1 + (nz - 1) * nx) * nComp + comp];
+  } else if (i >= nx - 1) {
+    fx_z1 = data[(nx - 1 + j * nx) * nComp + comp];
+    fx_z2 = data[(nx - 1 + (j + 1) * nx) * nComp + comp];
+    fxz = ((gridZjp1 - z) * fx_z1 + (z - gridZj) * fx_z2) / dz;
+  } else if (j >= nz - 1) {
+    fx_z1 = data[(i + (nz - 1) * nx) * nComp + comp];
+    fx_z2 = data[(i + (nz - 1) * nx) * nComp + comp];
+    fxz = ((gridXip1 - dim1) * fx_z1 + (dim1 - gridXi) * fx_z2) / dx;
+  } else {
+    fx_z1 = ((gridXip1 - dim1) * data[(i + j * nx) * nComp + comp] +
+             (dim1 - gridXi) * data[(i + 1 + j * nx) * nComp + comp]) / dx;
+    fx_z2 = ((gridXip1 - dim1) * data[(i + (j + 1) * nx) * nComp + comp] +
+             (dim1 - gridXi) * data[(i + 1 + (j + 1) * nx) * nComp + comp]) / dx;
+    fxz = ((gridZjp1 - z) * fx_z1 + (z - gridZj) * fx_z2) / dz;
+  }
+  return fxz;
+}
+static double i2d_base(double d1, double d2, double g1, double g2, double v, double dv) {
+  return (d1 * (g2 - v) + d2 * (v - g1)) / dv;
+}
+/* interpolate2d_field -> interpolate2d (utils.hpp:258-322), cylSymm already applied to x */
+static double interp2d_field2_pt(const double* data, double gridx0, double gridz0, double dx, double dz,
+                                 int nx, int nz, const double pos[3], int cyl, int nComp, int comp) {
+  if (nx <= 1 && nz <= 1) return data[comp];
+  double x = pos[0];
+  const double z = pos[2];
+  if (cyl) x = sqrt(x * x + pos[1] * pos[1]);
+  int i = (int)floor((x - gridx0) / dx);
+  int j = (int)floor((z - gridz0) / dz);
+  if (i < 0) i = 0;
+  if (j < 0) j = 0;
+  const double gXi = gridx0 + i * dx, gXip1 = gridx0 + (i + 1) * dx;
+  const double gZj = gridz0 + j * dz, gZjp1 = gridz0 + (j + 1) * dz;
+  if (i >= nx - 1 && j >= nz - 1) return data[(nx - 1 + (nz - 1) * nx) * nComp + comp];
+  if (i >= nx - 1)
+    return i2d_base(data[(nx - 1 + j * nx) * nComp + comp], data[(nx - 1 + (j + 1) * nx) * nComp + comp],
+                    z - gZj, gZjp1 - z, z, dz);
+  if (j >= nz - 1)
+    return i2d_base(data[(i + (nz - 1) * nx) * nComp + comp], data[(i + (nz - 1) * nx) * nComp + comp],
+                    x - gXi, gXip1 - x, x, dx);
+  const double f1 = i2d_base(data[(i + j * nx) * nComp + comp], data[(i + 1 + j * nx) * nComp + comp], gXi,
+                             gXip1, x, dx);
+  const double f2 = i2d_base(data[(i + (j + 1) * nx) * nComp + comp],
+                             data[(i + 1 + (j + 1) * nx) * nComp + comp], gXi, gXip1, x, dx);
+  return i2d_base(f1, f2, gZj, gZjp1, z, dz);
+}
+void ppo_interp2d_field(const ppo_ps* ps, int m_x, const double* data, double gridx0, double gridz0,
+                        double dx, double dz, int nx, int nz, int cyl, int ncomp, int comp, double* out) {
+  slots s = get_slots(ps);
+  const size_t A = (size_t)ps->alloc;
+  for (int pid = 0; pid < s.cap; ++pid) {
+    out[pid] = 0;
+    if (!s.mask[pid]) continue;
+    const double pos[3] = {MD(ps, m_x)[pid], MD(ps, m_x)[A + pid], MD(ps, m_x)[2 * A + pid]};
+    out[pid] = interp2d_field_pt(data, gridx0, gridz0, dx, dz, nx, nz, pos, cyl, ncomp, comp);
+  }
+  free_slots(&s);
+}
+void ppo_interp2d_vector(const ppo_ps* ps, int m_x, const double* data3, double gridx0, double gridz0,
+                         double dx, double dz, int nx, int nz, int cyl, double* out) {
+  slots s = get_slots(ps);
+  const size_t A = (size_t)ps->alloc;
+  for (int pid = 0; pid < s.cap; ++pid) {
+    double f[3] = {0, 0, 0};
+    if (s.mask[pid]) {
+      const double pos[3] = {MD(ps, m_x)[pid], MD(ps, m_x)[A + pid], MD(ps, m_x)[2 * A + pid]};
+      for (int i = 0; i < 3; ++i)
+        f[i] = interp2d_field2_pt(data3, gridx0, gridz0, dx, dz, nx, nz, pos, cyl, 3, i);
+      if (cyl) {
+        const double theta = atan2(pos[1], pos[0]);
+        const double f0 = f[0], f1 = f[1];
+        f[0] = cos(theta) * f0 - sin(theta) * f1;
+        f[1] = sin(theta) * f0 + cos(theta) * f1;
+      }
+    }
+    for (int c = 0; c < 3; ++c) out[(size_t)c * s.cap + pid] = f[c];
+  }
+  free_slots(&s);
+}
+void ppo_interp3d_field(const ppo_ps* ps, int m_x, int nx, int ny, int nz, const double* gridx,
+                        const double* gridy, const double* gridz, const double* data, double* out) {
+  slots s = get_slots(ps);
+  const size_t A = (size_t)ps->alloc;
+  const double dx = gridx[1] - gridx[0];
+  const double dy = ny > 1 ? gridy[1] - gridy[0] : 1.0, dz = nz > 1 ? gridz[1] - gridz[0] : 1.0;
+  for (int pid = 0; pid < s.cap; ++pid) {
+    out[pid] = 0;
+    if (!s.mask[pid]) continue;
+    const double x = MD(ps, m_x)[pid], y = MD(ps, m_x)[A + pid], z = MD(ps, m_x)[2 * A + pid];
+    int i = (int)floor((x - gridx[0]) / dx);
+    int j = ny > 1 ? (int)floor((y - gridy[0]) / dy) : 0;
+    int k = nz > 1 ? (int)floor((z - gridz[0]) / dz) : 0;
+    i = (i < 0) ? 0 : ((i >= nx - 1) ? (nx - 2) : i);
+    j = (j < 0 || ny <= 1) ? 0 : ((j >= ny - 1) ? (ny - 2) : j);
+    k = (k < 0 || nz <= 1) ? 0 : ((k >= nz - 1) ? (nz - 2) : k);
+#define BASEG(di) i2d_base(data[(di)], data[(di) + 1], gridx[i], gridx[i + 1], x, dx)
+    const double fx_z0 = BASEG(i + j * nx + k * nx * ny);
+    double fxyz = fx_z0;
+    if (nz > 1) {
+      const double fx_z1 = BASEG(i + j * nx + (k + 1) * nx * ny);
+      const double fxz0 = i2d_base(fx_z0, fx_z1, gridz[k], gridz[k + 1], z, dz);
+      fxyz = fxz0;
+      if (ny > 1) {
+        const double fxy_z0 = BASEG(i + (j + 1) * nx + k * nx * ny);
+        const double fxy_z1 = BASEG(i + (j + 1) * nx + (k + 1) * nx * ny);
+        const double fxz1 = i2d_base(fxy_z0, fxy_z1, gridz[k], gridz[k + 1], z, dz);
+        fxyz = i2d_base(fxz0, fxz1, gridy[j], gridy[j + 1], y, dy);
+      }
+    }
+#undef BASEG
+    out[pid] = fxyz;
+  }
+  free_slots(&s);
+}

@@ -101,6 +101,10 @@ SYMBOLS = {
     "pp_create_gyro_ring_mappings": (_I, [_V, _D, _I, _I, _D, _V, _V]),
     "pp_gyro_scatter": (_I, [_V, _V, _V, _D, _I, _I, _V]),
     "pp_gyro_sync_pack": (_I, [_I, _V, _V, _V]),
+    "pp_gather_tet_vtx": (_I, [_V, _V, _I, _V, _V, _I, _V, _V]),
+    "pp_interp2d_field": (_I, [_V, _I, _V, _D, _D, _D, _D, _I, _I, _I, _I, _I, _V]),
+    "pp_interp2d_vector": (_I, [_V, _I, _V, _D, _D, _D, _D, _I, _I, _I, _V]),
+    "pp_interp3d_field": (_I, [_V, _I, _I, _I, _I, _V, _V, _V, _V, _V]),
     "pp_avg_ptcl_density": (_I, [_V, _V, _V, _V]),
     "pp_set_unsafe_procs": (_I, [_V, _V, _V, _V, _I, _V, _V]),
     "pp_ps_migrate_count": (_I, [_V, _V, _V, _I, _I, _V]),
@@ -502,6 +506,44 @@ def gyro_sync_pack(nverts, fwd, bkwd, out=None):
         out = DevArray(max(2 * nverts, 1), np.float64)
     check(lib().pp_gyro_sync_pack(nverts, fwd.ptr, bkwd.ptr, out.ptr))
     return out
+
+
+def gather_tet_vtx(mesh, ps, field, dof=1, elem_ids=None, m_x=0):
+    """host field [nverts*dof] -> host array (dof, capacity)"""
+    cap = max(ps.capacity(), 1)
+    f = DevArray.from_host(np.ascontiguousarray(field, dtype=np.float64))
+    out = DevArray(cap * dof, np.float64)
+    bad = C.c_int(0)
+    check(lib().pp_gather_tet_vtx(mesh.p, ps.p, m_x, elem_ids.ptr if elem_ids is not None else None,
+                                  f.ptr, dof, out.ptr, C.byref(bad)))
+    return out.to_host().reshape(dof, cap), bad.value
+
+
+def interp2d_field(ps, data, gridx0, gridz0, dx, dz, nx, nz, cyl_symm=True, ncomp=1, comp=0, m_x=0):
+    cap = max(ps.capacity(), 1)
+    d = DevArray.from_host(np.ascontiguousarray(data, dtype=np.float64))
+    out = DevArray(cap, np.float64)
+    check(lib().pp_interp2d_field(ps.p, m_x, d.ptr, gridx0, gridz0, dx, dz, nx, nz, int(cyl_symm), ncomp,
+                                  comp, out.ptr))
+    return out.to_host()
+
+
+def interp2d_vector(ps, data3, gridx0, gridz0, dx, dz, nx, nz, cyl_symm=False, m_x=0):
+    cap = max(ps.capacity(), 1)
+    d = DevArray.from_host(np.ascontiguousarray(data3, dtype=np.float64))
+    out = DevArray(cap * 3, np.float64)
+    check(lib().pp_interp2d_vector(ps.p, m_x, d.ptr, gridx0, gridz0, dx, dz, nx, nz, int(cyl_symm), out.ptr))
+    return out.to_host().reshape(3, cap)
+
+
+def interp3d_field(ps, gridx, gridy, gridz, data, m_x=0):
+    cap = max(ps.capacity(), 1)
+    gx, gy, gz = (DevArray.from_host(np.ascontiguousarray(g, dtype=np.float64)) for g in (gridx, gridy, gridz))
+    d = DevArray.from_host(np.ascontiguousarray(data, dtype=np.float64))
+    out = DevArray(cap, np.float64)
+    check(lib().pp_interp3d_field(ps.p, m_x, len(gridx), len(gridy), len(gridz), gx.ptr, gy.ptr, gz.ptr,
+                                  d.ptr, out.ptr))
+    return out.to_host()
 
 
 def avg_ptcl_density(mesh, ps):

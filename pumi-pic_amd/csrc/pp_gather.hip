@@ -1,0 +1,162 @@
+// pp_gather.hip -- gather side: mesh / grid field -> particle, one thread per slot.
+//   interpolateTetVtx / interpolate3dFieldTet / findBCCoordsInTet   src/pumipic_adjacency.hpp:772-809
+//   interpolate2dField / interp2dVector / interpolate3d_field       src/pumipic_utils.hpp:186-454
+// The per-particle arithmetic lives in include/pumipic_gather.hpp (shared with user lambdas).
+#include "../include/pumipic_gather.hpp"
+#include "pp_internal.hpp"
+
+namespace {
+using pp::grid_for;
+using pp::kBlock;
+
+__global__ void k_gather_tet_vtx(int capacity, const unsigned char* __restrict__ mask,
+                                 const int* __restrict__ slot_elem, const int* __restrict__ elem_ids,
+                                 const double* __restrict__ x, long long stride,
+                                 const double* __restrict__ coords, const int* __restrict__ e2v,
+                                 const double* __restrict__ field, int dof, double* __restrict__ out,
+                                 int* __restrict__ bad) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity) return;
+  const int e = !mask[pid] ? -1 : (elem_ids ? elem_ids[pid] : slot_elem[pid]);
+  double bcc[4];
+  bool ok = e >= 0;
+  if (ok) {
+    const double pos[3] = {x[pid], x[stride + pid], x[2 * stride + pid]};
+    ok = pumipic::findBCCoordsInTet(coords, e2v, pos, e, bcc);
+    if (!ok) atomicAdd(bad, 1);  // OMEGA_H_CHECK(res==1), adjacency.hpp:805
+  }
+  for (int c = 0; c < dof; ++c)
+    out[(size_t)c * capacity + pid] = ok ? pumipic::interpolateTetVtx(e2v, field, e, bcc, dof, c) : 0.0;
+}
+__global__ void k_interp2d_field(int capacity, const unsigned char* __restrict__ mask,
+                                 const double* __restrict__ x, long long stride,
+                                 const double* __restrict__ data, double gridx0, double gridz0,
+                                 double dx, double dz, int nx, int nz, int cyl, int ncomp, int comp,
+                                 double* __restrict__ out) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity) return;
+  double v = 0;
+  if (mask[pid]) {
+    const double pos[3] = {x[pid], x[stride + pid], x[2 * stride + pid]};
+    v = pumipic::interpolate2dField(data, gridx0, gridz0, dx, dz, nx, nz, pos, cyl != 0, ncomp, comp);
+  }
+  out[pid] = v;
+}
+__global__ void k_interp2d_vector(int capacity, const unsigned char* __restrict__ mask,
+                                  const double* __restrict__ x, long long stride,
+                                  const double* __restrict__ data3, double gridx0, double gridz0,
+                                  double dx, double dz, int nx, int nz, int cyl,
+                                  double* __restrict__ out) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity) return;
+  double f[3] = {0, 0, 0};
+  if (mask[pid]) {
+    const double pos[3] = {x[pid], x[stride + pid], x[2 * stride + pid]};
+    pumipic::interp2dVector(data3, gridx0, gridz0, dx, dz, nx, nz, pos, f, cyl != 0);
+  }
+  for (int c = 0; c < 3; ++c) out[(size_t)c * capacity + pid] = f[c];
+}
+__global__ void k_interp3d_field(int capacity, const unsigned char* __restrict__ mask,
+                                 const double* __restrict__ x, long long stride, int nx, int ny,
+                                 int nz, const double* __restrict__ gridx,
+                                 const double* __restrict__ gridy, const double* __restrict__ gridz,
+                                 const double* __restrict__ data, double* __restrict__ out) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity) return;
+  out[pid] = mask[pid] ? pumipic::interpolate3d_field(x[pid], x[stride + pid], x[2 * stride + pid], nx,
+                                                     ny, nz, gridx, gridy, gridz, data)
+                       : 0.0;
+}
+
+int xmember(const pp_ps* ps, int m_x, const char* what, const double** x) {
+  if (m_x < 0 || m_x >= ps->nmembers) {
+    pp::set_error(std::string(what) + ": member index out of range");
+    return PP_EINVAL;
+  }
+  const int s = ps->member_map[m_x];
+  if (ps->member_bytes[s] != 8 || ps->member_ncomp[s] < 3) {
+    pp::set_error(std::string(what) + ": the position member must be double[3]");
+    return PP_EINVAL;
+  }
+  *x = (const double*)ps->data[s].p;
+  return PP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int pp_gather_tet_vtx(const pp_mesh* mesh, const pp_ps* ps, int m_x, const int* elem_ids_dev,
+                      const double* field_dev, int dof, double* out_dev, int* num_degenerate) {
+  PP_REQUIRE(mesh && ps && field_dev && out_dev, "pp_gather_tet_vtx: null argument");
+  PP_REQUIRE(mesh->dim == 3 && dof >= 1, "pp_gather_tet_vtx: needs a tet mesh and dof >= 1");
+  PP_REQUIRE(ps->num_elems == mesh->nelems, "pp_gather_tet_vtx: structure/mesh element mismatch");
+  const double* x;
+  int rc = xmember(ps, m_x, "pp_gather_tet_vtx", &x);
+  if (rc) return rc;
+  if (num_degenerate) *num_degenerate = 0;
+  if (ps->capacity == 0) return PP_OK;
+  static pp::DevBuf* s_bad = new pp::DevBuf();
+  PP_HIP_CHECK(s_bad->reserve(sizeof(int)));
+  PP_HIP_CHECK(hipMemsetAsync(s_bad->p, 0, sizeof(int), pp::stream()));
+  k_gather_tet_vtx<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
+      ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), elem_ids_dev, x,
+      ps->stride, mesh->d_coords.as<double>(), mesh->d_elem2verts.as<int>(), field_dev, dof, out_dev,
+      s_bad->as<int>());
+  PP_LAUNCH_CHECK();
+  if (num_degenerate) {
+    PP_HIP_CHECK(hipMemcpyAsync(num_degenerate, s_bad->p, sizeof(int), hipMemcpyDeviceToHost, pp::stream()));
+    PP_HIP_CHECK(hipStreamSynchronize(pp::stream()));
+  }
+  return PP_OK;
+}
+
+int pp_interp2d_field(const pp_ps* ps, int m_x, const double* data_dev, double gridx0, double gridz0,
+                      double dx, double dz, int nx, int nz, int cyl_symm, int ncomp, int comp,
+                      double* out_dev) {
+  PP_REQUIRE(ps && data_dev && out_dev, "pp_interp2d_field: null argument");
+  PP_REQUIRE(dx > 0 && dz > 0 && nx >= 1 && nz >= 1 && ncomp >= 1 && comp >= 0 && comp < ncomp,
+             "pp_interp2d_field: bad grid (the reference checks dx > 0 && dz > 0, utils.hpp:205)");
+  const double* x;
+  int rc = xmember(ps, m_x, "pp_interp2d_field", &x);
+  if (rc) return rc;
+  if (ps->capacity == 0) return PP_OK;
+  k_interp2d_field<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
+      ps->capacity, ps->d_mask.as<unsigned char>(), x, ps->stride, data_dev, gridx0, gridz0, dx, dz, nx,
+      nz, cyl_symm, ncomp, comp, out_dev);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+int pp_interp2d_vector(const pp_ps* ps, int m_x, const double* data3_dev, double gridx0, double gridz0,
+                       double dx, double dz, int nx, int nz, int cyl_symm, double* out_dev) {
+  PP_REQUIRE(ps && data3_dev && out_dev, "pp_interp2d_vector: null argument");
+  PP_REQUIRE(dx > 0 && dz > 0 && nx >= 1 && nz >= 1, "pp_interp2d_vector: bad grid");
+  const double* x;
+  int rc = xmember(ps, m_x, "pp_interp2d_vector", &x);
+  if (rc) return rc;
+  if (ps->capacity == 0) return PP_OK;
+  k_interp2d_vector<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
+      ps->capacity, ps->d_mask.as<unsigned char>(), x, ps->stride, data3_dev, gridx0, gridz0, dx, dz, nx,
+      nz, cyl_symm, out_dev);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+int pp_interp3d_field(const pp_ps* ps, int m_x, int nx, int ny, int nz, const double* gridx_dev,
+                      const double* gridy_dev, const double* gridz_dev, const double* data_dev,
+                      double* out_dev) {
+  PP_REQUIRE(ps && gridx_dev && gridy_dev && gridz_dev && data_dev && out_dev,
+             "pp_interp3d_field: null argument");
+  PP_REQUIRE(nx >= 2 && ny >= 1 && nz >= 1, "pp_interp3d_field: needs nx >= 2");
+  const double* x;
+  int rc = xmember(ps, m_x, "pp_interp3d_field", &x);
+  if (rc) return rc;
+  if (ps->capacity == 0) return PP_OK;
+  k_interp3d_field<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
+      ps->capacity, ps->d_mask.as<unsigned char>(), x, ps->stride, nx, ny, nz, gridx_dev, gridy_dev,
+      gridz_dev, data_dev, out_dev);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+}  // extern "C"

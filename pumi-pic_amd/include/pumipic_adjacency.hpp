@@ -5,12 +5,15 @@
 //   search_mesh (legacy 3-D)     src/pumipic_adjacency.hpp:558-562
 //   migrate_ptcls / migrate_lb_ptcls   src/pumipic_ptcl_ops.hpp:53-85 (single rank: rebuild)
 //   RecordTime / SummarizeTime   support/ppTiming.hpp:34-75
+//   gather-side interpolation    src/pumipic_adjacency.hpp:772-809, src/pumipic_utils.hpp:186-454
+//                                (pumipic_gather.hpp, raw-pointer signatures)
 // Omega_h::Mesh is replaced by pumipic::Mesh (a handle that owns the derived adjacency and the
 // packed walk records on the device); Omega_h::Write<T>/Read<T> by pumipic::View<T>.
 #pragma once
 #include <chrono>
 #include <map>
 #include "particle_structs.hpp"
+#include "pumipic_gather.hpp"  // interpolateTetVtx, interpolate2dField, ... (device-inline)
 
 namespace Omega_h {
 typedef int LO;

@@ -836,3 +836,38 @@ def test_cpp_driver_pseudo_push_and_search(ppo, synth, capi, tmp_path):
     assert int(m.group(1)) == po.nPtcls()
     assert int(m.group(2)) == hits
     assert int(m.group(3)) == int(touched.sum())
+
+
+def test_gather_side_matches_oracle(ppo, synth, capi):
+    """pp_gather_tet_vtx / pp_interp2d_field / pp_interp2d_vector / pp_interp3d_field against the
+    oracle: bit-exact where only +,-,*,/,sqrt,floor are involved, 1e-12 where atan2/cos/sin are."""
+    pop = common.population_3d(synth, n_b=5, n_theta=20, n_planes=8, num_ptcls=3000)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
+    cap = po.capacity()
+    rng = np.random.default_rng(11)
+    field = rng.standard_normal(mo.nverts * 3)
+    oo, bo = ppo.gather_tet_vtx(mo, po, field, dof=3)
+    og, bg = capi.gather_tet_vtx(mg, pg, field, dof=3)
+    assert bo == bg == 0 and np.array_equal(oo[:, :cap], og[:, :cap])
+    # with explicit element ids (some -1)
+    ids = po.slot_info()[0].copy()
+    ids[::7] = -1
+    oo, _ = ppo.gather_tet_vtx(mo, po, field, dof=3, elem_ids=ids)
+    og, _ = capi.gather_tet_vtx(mg, pg, field, dof=3, elem_ids=capi.DevArray.from_host(ids))
+    assert np.array_equal(oo[:, :cap], og[:, :cap])
+    nx, nz, gx0, gz0, dx, dz = 40, 30, 0.9, -0.8, 0.04, 0.06
+    data = rng.standard_normal(nx * nz * 3)
+    for comp in range(3):
+        a = ppo.interp2d_field(po, data, gx0, gz0, dx, dz, nx, nz, True, 3, comp)
+        b = capi.interp2d_field(pg, data, gx0, gz0, dx, dz, nx, nz, True, 3, comp)
+        assert np.array_equal(a[:cap], b[:cap])
+    a = ppo.interp2d_vector(po, data, gx0, gz0, dx, dz, nx, nz, cyl_symm=False)
+    b = capi.interp2d_vector(pg, data, gx0, gz0, dx, dz, nx, nz, cyl_symm=False)
+    assert np.array_equal(a[:, :cap], b[:, :cap])
+    a = ppo.interp2d_vector(po, data, gx0, gz0, dx, dz, nx, nz, cyl_symm=True)
+    b = capi.interp2d_vector(pg, data, gx0, gz0, dx, dz, nx, nz, cyl_symm=True)
+    np.testing.assert_allclose(a[:, :cap], b[:, :cap], rtol=1e-12, atol=1e-12)
+    gx, gy, gz = np.linspace(-2.1, 2.1, 22), np.linspace(-2.1, 2.1, 18), np.linspace(-0.9, 0.9, 12)
+    d = rng.standard_normal(22 * 18 * 12)
+    assert np.array_equal(ppo.interp3d_field(po, gx, gy, gz, d)[:cap], capi.interp3d_field(pg, gx, gy, gz, d)[:cap])

@@ -332,3 +332,42 @@ def test_gyro_ring_map_3d_points_are_inside_their_tets(ppo, synth):
                 assert lam.min() > -1e-7 and lam.sum() < 1 + 1e-7
                 checked += 1
     assert checked > 500
+
+
+def test_gather_side_reproduces_linear_fields(ppo, synth):
+    """interpolateTetVtx with findBCCoordsInTet is exact for fields linear in x,y,z; the grid
+    interpolators are exact for (bi/tri-)linear data; interp2dVector rotates (R,phi) into (x,y)."""
+    pop = common.population_3d(synth, n_b=5, n_theta=20, n_planes=8, num_ptcls=3000)
+    mesh, ps = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    cap = ps.capacity()
+    live = ps.slot_info()[1].astype(bool)
+    x = ps.member(0)[:, :cap]
+    xyz = np.asarray(pop["coords"]).reshape(-1, 3)
+    coef = np.array([[0.3, -1.2, 2.0], [1.0, 0.5, -0.7], [-2.0, 0.1, 0.9]])
+    field = (xyz @ coef.T + np.array([0.5, -1.0, 2.0])).ravel()  # dof 3, vertex-major
+    out, bad = ppo.gather_tet_vtx(mesh, ps, field, dof=3)
+    assert bad == 0
+    expect = coef @ x + np.array([0.5, -1.0, 2.0])[:, None]
+    assert np.allclose(out[:, :cap][:, live], expect[:, live], rtol=1e-11, atol=1e-11)
+    assert not out[:, :cap][:, ~live].any()
+    # regular (R,z) grid, linear data f = 2R - 3z + 1
+    R = np.hypot(x[0], x[1])
+    nx, nz, gx0, gz0, dx, dz = 40, 30, 0.9, -0.8, 0.04, 0.06
+    gr, gz = gx0 + dx * np.arange(nx), gz0 + dz * np.arange(nz)
+    data = (2 * gr[None, :] - 3 * gz[:, None] + 1).ravel()  # index i + j*nx
+    got = ppo.interp2d_field(ps, data, gx0, gz0, dx, dz, nx, nz, cyl_symm=True)
+    inside = live & (R >= gr[0]) & (R < gr[-1]) & (x[2] >= gz[0]) & (x[2] < gz[-1])
+    assert inside.sum() > 1000
+    assert np.allclose(got[:cap][inside], (2 * R - 3 * x[2] + 1)[inside], rtol=1e-12, atol=1e-12)
+    # vector field with constant (R,phi,z) components -> rotated into x,y
+    d3 = np.tile(np.array([1.5, -0.5, 0.25]), nx * nz)
+    v = ppo.interp2d_vector(ps, d3, gx0, gz0, dx, dz, nx, nz, cyl_symm=True)
+    th = np.arctan2(x[1], x[0])
+    assert np.allclose(v[0, :cap][inside], (np.cos(th) * 1.5 + np.sin(th) * 0.5)[inside], atol=1e-12)
+    assert np.allclose(v[1, :cap][inside], (np.sin(th) * 1.5 - np.cos(th) * 0.5)[inside], atol=1e-12)
+    assert np.allclose(v[2, :cap][inside], 0.25, atol=1e-14)
+    # tri-linear grid, data = x + 2y - z
+    gx, gy, gzz = np.linspace(-2.1, 2.1, 22), np.linspace(-2.1, 2.1, 18), np.linspace(-0.9, 0.9, 12)
+    d = (gx[None, None, :] + 2 * gy[None, :, None] - gzz[:, None, None]).ravel()  # i + j*nx + k*nx*ny
+    got3 = ppo.interp3d_field(ps, gx, gy, gzz, d)
+    assert np.allclose(got3[:cap][live], (x[0] + 2 * x[1] - x[2])[live], rtol=1e-12, atol=1e-12)
