@@ -871,3 +871,38 @@ def test_gather_side_matches_oracle(ppo, synth, capi):
     gx, gy, gz = np.linspace(-2.1, 2.1, 22), np.linspace(-2.1, 2.1, 18), np.linspace(-0.9, 0.9, 12)
     d = rng.standard_normal(22 * 18 * 12)
     assert np.array_equal(ppo.interp3d_field(po, gx, gy, gz, d)[:cap], capi.interp3d_field(pg, gx, gy, gz, d)[:cap])
+
+
+@pytest.mark.parametrize("queue", ["0", "1"])
+def test_fused_2d_outside_sentinel_and_lost_seeds(ppo, synth, capi, monkeypatch, queue):
+    """search_mesh_2d conventions in the fused kernels: a seed of -nelems marks a particle that is
+    already outside (hpp:1051-1056: result -1, no walk), -1 means 'start from the own element'."""
+    monkeypatch.setenv("PP_WALK_QUEUE", queue)
+    pop = common.population_2d(synth, num_ptcls=3000)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
+    cap = po.capacity()
+    ne = len(pop["e2v"])
+    seeds = np.full(cap, -1, dtype=np.int32)
+    seeds[::5] = -ne
+    se = po.slot_info()[0]
+    seeds[1::5] = se[1::5]  # explicit own element
+    ppo.elliptical_push(po, mo, H, K, D, 4.0, trig=1)
+    ids_o = seeds.copy()
+    _, ids_o, _ = ppo.search_mesh_2d(mo, po, elem_ids=ids_o, looplimit=200)
+    ids_g = capi.DevArray.from_host(seeds.copy())
+    capi.push_search(mg, pg, H, K, D, 4.0, ids_g, seeded=True, looplimit=200)
+    live = po.slot_info()[1].astype(bool)
+    got = ids_g.to_host()[:cap]
+    assert np.array_equal(ids_o[:cap][live], got[live])
+    assert (got[live][seeds[:cap][live] == -ne] == -1).all()
+
+
+def test_push_search_on_an_all_deleted_structure(ppo, synth, capi):
+    """rebuild with every particle deleted, then the fused kernels on the empty structure"""
+    pop = common.population_3d(synth, num_ptcls=500)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
+    pg.rebuild(np.full(pg.capacity(), -1, dtype=np.int32))
+    assert pg.nPtcls() == 0
+    ids = capi.DevArray.from_host(np.full(max(pg.capacity(), 1), 7, dtype=np.int32))
+    assert capi.push_search(mg, pg, H, K, D, 1.0, ids, seeded=False, looplimit=50)
