@@ -1174,9 +1174,10 @@ template <int DIM>
 __global__ void __launch_bounds__(256, 4)
     k_walk_pending(int nwaves, int TP, int G, const PendEntry* __restrict__ gq,
                    const int* __restrict__ wave_cnt, const void* __restrict__ recs, int* elem_ids,
-                   int looplimit, Counters* cnt) {
+                   int looplimit, Counters* cnt, Counters* cnt_next) {
   constexpr int NP = DIM == 3 ? 8 : 4;
   __shared__ double2 st_all[4 * 64 * NP];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *cnt_next = Counters{};  // for the next pp_push_search
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double2* st = st_all + wave * 64 * NP;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -1264,6 +1265,17 @@ struct CntRef {
 } g_cnt;
 
 pp::DevBuf g_pending_q, g_wave_cnt;  // deferred-walk queue of the fused kernel (grow-only, library lifetime)
+
+// Counters of the deferred-walk kernels: two sets used alternately.  k_walk_pending zeroes the set
+// of the NEXT call, so pp_push_search needs no memset launch (8 us per step in rocprof).
+Counters* g_cnt2 = nullptr;
+int g_cnt2_cur = 0;
+int pair_counters() {
+  if (g_cnt2) return PP_OK;
+  PP_HIP_CHECK(hipMalloc((void**)&g_cnt2, 2 * sizeof(Counters)));
+  PP_HIP_CHECK(hipMemsetAsync(g_cnt2, 0, 2 * sizeof(Counters), pp::stream()));
+  return PP_OK;
+}
 
 int reset_counters() {
   if (!g_cnt_dev) PP_HIP_CHECK(hipMalloc((void**)&g_cnt_dev, sizeof(Counters)));
@@ -1427,12 +1439,12 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
       PP_HIP_CHECK(hipMemsetAsync(elem_ids_dev, 0xff, sizeof(int) * (size_t)ps->capacity, pp::stream()));
     return PP_OK;
   }
-  if ((rc = reset_counters())) return rc;
   const unsigned grid = grid_for(ps->capacity);
   hipStream_t st = pp::stream();
   if (mesh->dim == 2)
     PP_REQUIRE(elem_ids_seeded, "pp_push_search (2-D): elem_ids must be initialised (-1 = own element)");
   static const bool force_flat = getenv("PP_FLAT_WALK") != nullptr;  // A/B measurement knob
+  Counters* used = nullptr;  // the counter set this call's kernels add to
   if (ps->kind == PP_SCS && !force_flat) {
     const unsigned rgrid = grid_for((size_t)ps->ntiles_max * ps->C);
 #define PP_ROWS_ARGS                                                                             \
@@ -1442,7 +1454,14 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
       mesh->nelems, PP_MEMBER(ps, m_x, double), PP_MEMBER(ps, m_xtgt, double), ps->stride,       \
       PP_MEMBER(ps, m_b, float), PP_MEMBER(ps, m_phi, float), h, k, d, deg, mesh->tol,           \
       mesh->unmoved_sq, elem_ids_dev, elem_ids_seeded, looplimit, g_cnt.get()
-#define PP_ROWSQ_ARGS PP_ROWS_ARGS, g_pending_q.as<PendEntry>(), g_wave_cnt.as<int>(), abl
+#define PP_ROWSQ_ARGS                                                                            \
+  ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(), \
+      ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(),                               \
+      ps->d_mask.as<unsigned char>(), mesh->d_records.p, mesh->d_class_id.as<int>(),             \
+      mesh->nelems, PP_MEMBER(ps, m_x, double), PP_MEMBER(ps, m_xtgt, double), ps->stride,       \
+      PP_MEMBER(ps, m_b, float), PP_MEMBER(ps, m_phi, float), h, k, d, deg, mesh->tol,           \
+      mesh->unmoved_sq, elem_ids_dev, elem_ids_seeded, looplimit, used,                          \
+      g_pending_q.as<PendEntry>(), g_wave_cnt.as<int>(), abl
     // OCC = minimum waves per SIMD the register allocator must leave room for (tuning knob;
     // measured in profiles/): 3-D defaults to 4 (104 VGPRs, no spill)
     // OCC = waves per SIMD the register allocator must leave room for.  Measured on MI355X
@@ -1459,6 +1478,13 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
     const int wq_env = getenv("PP_WALK_QUEUE") ? atoi(getenv("PP_WALK_QUEUE")) : -1;  // per call
     const int wq = wq_env >= 0 ? wq_env : (mesh->dim == 3 ? 1 : 0);
     static const int abl = getenv("PP_ABL") ? atoi(getenv("PP_ABL")) : 0;  // timing ablations only
+    if (!(rgrid > 0 && wq > 0)) {
+      if ((rc = reset_counters())) return rc;
+      used = g_cnt.get();
+    } else {
+      if ((rc = pair_counters())) return rc;
+      used = g_cnt2 + g_cnt2_cur;
+    }
     if (rgrid > 0 && wq > 0) {
       const size_t lds = (size_t)(kBlock / 64) * 64 * (mesh->dim == 3 ? 8 : 4) * sizeof(double2);
       const size_t nwaves = (size_t)rgrid * (kBlock / 64);
@@ -1483,11 +1509,12 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
       if (mesh->dim == 2)
         k_walk_pending<2><<<pgrid, kBlock, 0, st>>>((int)nwaves, ps->tile_p, G, g_pending_q.as<PendEntry>(),
                                                    g_wave_cnt.as<int>(), mesh->d_records.p,
-                                                   elem_ids_dev, looplimit, g_cnt.get());
+                                                   elem_ids_dev, looplimit, used, g_cnt2 + (g_cnt2_cur ^ 1));
       else
         k_walk_pending<3><<<pgrid, kBlock, 0, st>>>((int)nwaves, ps->tile_p, G, g_pending_q.as<PendEntry>(),
                                                    g_wave_cnt.as<int>(), mesh->d_records.p,
-                                                   elem_ids_dev, looplimit, g_cnt.get());
+                                                   elem_ids_dev, looplimit, used, g_cnt2 + (g_cnt2_cur ^ 1));
+      g_cnt2_cur ^= 1;
     } else if (rgrid > 0) {
       if (mesh->dim == 2)
         k_push_walk_rows<2, 4><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS);
@@ -1500,9 +1527,11 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
     }
 #undef PP_ROWS_ARGS
 #undef PP_ROWSQ_ARGS
-  } else
-  // DIM 2 follows search_mesh_2d: the caller's elem_ids are always read (-1 = own element)
-  if (mesh->dim == 2) {
+  } else {
+    if ((rc = reset_counters())) return rc;
+    used = g_cnt.get();
+    // DIM 2 follows search_mesh_2d: the caller's elem_ids are always read (-1 = own element)
+    if (mesh->dim == 2) {
     k_push_walk<2><<<grid, kBlock, 0, st>>>(
         ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), mesh->d_records.p,
         mesh->d_class_id.as<int>(), mesh->nelems, PP_MEMBER(ps, m_x, double),
@@ -1516,11 +1545,13 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
         PP_MEMBER(ps, m_xtgt, double), ps->stride, PP_MEMBER(ps, m_b, float),
         PP_MEMBER(ps, m_phi, float), h, k, d, deg, mesh->tol, elem_ids_dev, elem_ids_seeded,
         looplimit, g_cnt.get());
+    }
   }
   PP_LAUNCH_CHECK();
   if (found) {
     Counters hc;
-    if ((rc = read_counters(&hc))) return rc;
+    PP_HIP_CHECK(hipMemcpyAsync(&hc, used, sizeof(Counters), hipMemcpyDeviceToHost, st));
+    PP_HIP_CHECK(hipStreamSynchronize(st));
     *found = (hc.not_found == 0);
   }
   return PP_OK;
