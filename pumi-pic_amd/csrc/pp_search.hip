@@ -1017,6 +1017,68 @@ __device__ __forceinline__ int seed_of(const PState& s, int e, int seeded, int n
   return seeded ? s.elem : e;
 }
 
+// walks the entries of `nreg` consecutive queue regions (region i holds my_cnt-of-lane-i entries)
+template <int DIM>
+__device__ __forceinline__ void walk_pending(const PendEntry* __restrict__ regions, long long region_stride,
+                                             int nreg, int my_cnt, const void* __restrict__ recs,
+                                             int* elem_ids, int cap, Counters* cnt, double2* st, int lane) {
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  int reg = 0, off = 0;  // wave-uniform cursor
+  int reg_cnt = __shfl(my_cnt, 0);
+  bool on = false;
+  PendEntry en{};
+  int welem = -1, loops = 1;
+  RecCache<DIM> cache;
+  cache.id = -1;
+  while (true) {
+    // ---- refill free lanes from the cursor
+    unsigned long long free_mask = __ballot(!on);
+    while (free_mask != 0ull && reg < nreg) {
+      const int avail = reg_cnt - off;
+      if (avail <= 0) {
+        ++reg;
+        off = 0;
+        reg_cnt = reg < nreg ? __shfl(my_cnt, reg) : 0;
+        continue;
+      }
+      const int rank = __popcll(free_mask & lt_mask);
+      const int take = min(avail, (int)__popcll(free_mask));
+      if (!on && rank < take) {
+        en = regions[reg * region_stride + off + rank];
+        welem = en.elem;
+        loops = 1;
+        on = true;
+      }
+      off += take;
+      free_mask = __ballot(!on);
+    }
+    if (__ballot(on) == 0ull) break;
+    // ---- one step for every busy lane
+    coop_fetch<DIM>(cache, recs, on ? welem : -1, st, lane);
+    if (on) {
+      int next;
+      bool fin = step_cached(cache, V3{en.x, en.y, en.z}, next);
+      if (!fin) {
+        if (next == -1) {
+          welem = -1;
+          fin = true;
+        } else {
+          welem = next;
+        }
+      }
+      ++loops;
+      if (!fin && loops >= cap) {
+        welem = -1;
+        atomicAdd(&cnt->not_found, 1);
+        fin = true;
+      }
+      if (fin) {
+        elem_ids[en.pid] = welem;
+        on = false;
+      }
+    }
+  }
+}
 template <int DIM, int OCC, bool NT>
 __global__ void __launch_bounds__(256, OCC)
     k_push_walk_rowsq(const int* __restrict__ ntiles_dev, int C, int TP,
@@ -1027,7 +1089,8 @@ __global__ void __launch_bounds__(256, OCC)
                       double* xt, long long stride, const float* __restrict__ pb, float* pphi,
                       double h, double k, double d, double deg, double tol, double unmoved_sq,
                       int* elem_ids, int seeded, int looplimit, Counters* cnt, PendEntry* gq,
-                      int* wave_cnt, int abl) {
+                      int* wave_cnt, Counters* cnt_next, int fuse, int abl) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *cnt_next = Counters{};  // for the next pp_push_search
   constexpr int NP = DIM == 3 ? 8 : 4;
   extern __shared__ double2 lds_dyn[];
   double2* st = lds_dyn + (size_t)(threadIdx.x >> 6) * 64 * NP;
@@ -1083,6 +1146,7 @@ __global__ void __launch_bounds__(256, OCC)
   // iterations with a handful of busy lanes; instead lane l takes (live row l/TP, column l%TP) and
   // the whole tile is ONE iteration.  Loads are strided (one line per lane), which is cheap for
   // the few particles concerned.
+  bool thin = false;  // wave-uniform
   {
     const bool alive0 = valid && p0 < pend && mask[start + p0 * C] != 0;
     const unsigned long long live0 = __ballot(alive0);
@@ -1113,8 +1177,7 @@ __global__ void __launch_bounds__(256, OCC)
       V3 dest{0, 0, 0};
       const bool need = column_math<DIM, NT>(A, s, act, live, pid, tct, cache, elem, dest);
       enqueue(need, pid, elem, dest, wq, qn, lt_mask);
-      if (lane == 0) wave_cnt[gwave] = qn;
-      return;
+      thin = true;
     }
   }
   // Software pipeline over the columns.  At the top of column p everything issued during column
@@ -1125,11 +1188,11 @@ __global__ void __launch_bounds__(256, OCC)
   PState cur{};
   int e1 = -1;   // raw elem_ids value of column p+1 (read two columns ahead of its use as a seed)
   int pre = -1;  // element whose record the DMA put into this lane's staging slot for column p
-  if (p0 < pend) {
+  if (!thin && p0 < pend) {
     cur = load_state<DIM, NT>(start + p0 * C, mask, pphi, pb, x, stride, elem_ids, read_ids);
     if (read_ids && p0 + 1 < pend) e1 = ld<NT>(elem_ids + start + (p0 + 1) * C);
   }
-  for (int i = 0; i < TP; ++i) {  // wave-uniform trip count: every lane reaches the wave-level ops
+  for (int i = 0; i < (thin ? 0 : TP); ++i) {  // wave-uniform trip count: every lane reaches the wave-level ops
     const int p = p0 + i;
     const int pid = start + p * C;
     const bool act = p < pend;
@@ -1162,6 +1225,20 @@ __global__ void __launch_bounds__(256, OCC)
     enqueue(need, pid, elem, dest, wq, qn, lt_mask);
   }
   if (lane == 0) wave_cnt[gwave] = qn;
+  if (!fuse) return;
+  // ---- fused second pass: the block's four waves produced four consecutive queue regions; after
+  // a barrier the first wave walks them with lane refill while the other three retire.  No second
+  // launch, and the walk overlaps the column loops of the other blocks on the CU.
+  __shared__ int s_qn[4];
+  if (lane == 0) s_qn[threadIdx.x >> 6] = qn;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // queue entries visible to the block
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if ((threadIdx.x >> 6) == 0) {
+    const int my_cnt = lane < 4 ? s_qn[lane] : 0;
+    walk_pending<DIM>(gq + (long long)lb * 4 * 64 * TP, 64ll * TP, 4, my_cnt, recs, elem_ids, A.cap, cnt,
+                      st, lane);
+  }
 }
 
 // Second pass of the deferred walk.  Walk lengths are long-tailed (a crossing in a tet mesh takes
@@ -1170,77 +1247,21 @@ __global__ void __launch_bounds__(256, OCC)
 // as they finish: a wave-uniform cursor (region, offset) hands the next unprocessed entries to
 // the free lanes, so every round's cooperative fetch + step runs with (nearly) all lanes busy.
 constexpr int kPendRegions = 4;
+// stand-alone second pass (PP_FUSE_PENDING=0): wave w owns G consecutive regions
 template <int DIM>
 __global__ void __launch_bounds__(256, 4)
     k_walk_pending(int nwaves, int TP, int G, const PendEntry* __restrict__ gq,
                    const int* __restrict__ wave_cnt, const void* __restrict__ recs, int* elem_ids,
-                   int looplimit, Counters* cnt, Counters* cnt_next) {
+                   int looplimit, Counters* cnt) {
   constexpr int NP = DIM == 3 ? 8 : 4;
   __shared__ double2 st_all[4 * 64 * NP];
-  if (blockIdx.x == 0 && threadIdx.x == 0) *cnt_next = Counters{};  // for the next pp_push_search
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double2* st = st_all + wave * 64 * NP;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  const int cap = looplimit ? looplimit : kHardLoopCap;
   const long long r0 = ((long long)blockIdx.x * 4 + wave) * G;  // first region
   if (r0 >= nwaves) return;
   const int nreg = (int)min((long long)G, nwaves - r0);
   const int my_cnt = lane < nreg ? wave_cnt[r0 + lane] : 0;  // lane i holds the count of region i
-  int reg = 0, off = 0;                                      // wave-uniform cursor
-  int reg_cnt = __shfl(my_cnt, 0);
-  bool on = false;
-  PendEntry en{};
-  int welem = -1, loops = 1;
-  RecCache<DIM> cache;
-  cache.id = -1;
-  while (true) {
-    // ---- refill free lanes from the cursor
-    unsigned long long free_mask = __ballot(!on);
-    while (free_mask != 0ull && reg < nreg) {
-      const int avail = reg_cnt - off;
-      if (avail <= 0) {
-        ++reg;
-        off = 0;
-        reg_cnt = reg < nreg ? __shfl(my_cnt, reg) : 0;
-        continue;
-      }
-      const int rank = __popcll(free_mask & lt_mask);
-      const int take = min(avail, (int)__popcll(free_mask));
-      if (!on && rank < take) {
-        en = gq[(r0 + reg) * 64 * TP + off + rank];
-        welem = en.elem;
-        loops = 1;
-        on = true;
-      }
-      off += take;
-      free_mask = __ballot(!on);
-    }
-    if (__ballot(on) == 0ull) break;
-    // ---- one step for every busy lane
-    coop_fetch<DIM>(cache, recs, on ? welem : -1, st, lane);
-    if (on) {
-      int next;
-      bool fin = step_cached(cache, V3{en.x, en.y, en.z}, next);
-      if (!fin) {
-        if (next == -1) {
-          welem = -1;
-          fin = true;
-        } else {
-          welem = next;
-        }
-      }
-      ++loops;
-      if (!fin && loops >= cap) {
-        welem = -1;
-        atomicAdd(&cnt->not_found, 1);
-        fin = true;
-      }
-      if (fin) {
-        elem_ids[en.pid] = welem;
-        on = false;
-      }
-    }
-  }
+  walk_pending<DIM>(gq + r0 * 64 * TP, 64ll * TP, nreg, my_cnt, recs, elem_ids,
+                    looplimit ? looplimit : kHardLoopCap, cnt, st_all + wave * 64 * NP, lane);
 }
 
 MeshArrays arrays_of(const pp_mesh* mesh) {
@@ -1461,7 +1482,7 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
       mesh->nelems, PP_MEMBER(ps, m_x, double), PP_MEMBER(ps, m_xtgt, double), ps->stride,       \
       PP_MEMBER(ps, m_b, float), PP_MEMBER(ps, m_phi, float), h, k, d, deg, mesh->tol,           \
       mesh->unmoved_sq, elem_ids_dev, elem_ids_seeded, looplimit, used,                          \
-      g_pending_q.as<PendEntry>(), g_wave_cnt.as<int>(), abl
+      g_pending_q.as<PendEntry>(), g_wave_cnt.as<int>(), g_cnt2 + (g_cnt2_cur ^ 1), fuse, abl
     // OCC = minimum waves per SIMD the register allocator must leave room for (tuning knob;
     // measured in profiles/): 3-D defaults to 4 (104 VGPRs, no spill)
     // OCC = waves per SIMD the register allocator must leave room for.  Measured on MI355X
@@ -1485,6 +1506,10 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
       if ((rc = pair_counters())) return rc;
       used = g_cnt2 + g_cnt2_cur;
     }
+    // PP_FUSE_PENDING=1 runs the second pass at the tail of the column-loop kernel (first wave of
+    // every block, after a barrier).  Measured slower (c2 0.293 -> 0.315 ms, c3 walk 0.218 -> 0.247):
+    // the lingering wave pins its block's LDS and wave slots, which costs more than the saved launch.
+    static const int fuse = getenv("PP_FUSE_PENDING") ? atoi(getenv("PP_FUSE_PENDING")) : 0;
     if (rgrid > 0 && wq > 0) {
       const size_t lds = (size_t)(kBlock / 64) * 64 * (mesh->dim == 3 ? 8 : 4) * sizeof(double2);
       const size_t nwaves = (size_t)rgrid * (kBlock / 64);
@@ -1504,16 +1529,18 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
         k_push_walk_rowsq<3, 4, false><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
       }
       PP_LAUNCH_CHECK();
-      static const int G = getenv("PP_PEND_REGIONS") ? std::max(1, std::min(64, atoi(getenv("PP_PEND_REGIONS")))) : kPendRegions;
-      const unsigned pgrid = (rgrid + G - 1) / G;
-      if (mesh->dim == 2)
-        k_walk_pending<2><<<pgrid, kBlock, 0, st>>>((int)nwaves, ps->tile_p, G, g_pending_q.as<PendEntry>(),
-                                                   g_wave_cnt.as<int>(), mesh->d_records.p,
-                                                   elem_ids_dev, looplimit, used, g_cnt2 + (g_cnt2_cur ^ 1));
-      else
-        k_walk_pending<3><<<pgrid, kBlock, 0, st>>>((int)nwaves, ps->tile_p, G, g_pending_q.as<PendEntry>(),
-                                                   g_wave_cnt.as<int>(), mesh->d_records.p,
-                                                   elem_ids_dev, looplimit, used, g_cnt2 + (g_cnt2_cur ^ 1));
+      if (!fuse) {
+        static const int G = getenv("PP_PEND_REGIONS") ? std::max(1, std::min(64, atoi(getenv("PP_PEND_REGIONS")))) : kPendRegions;
+        const unsigned pgrid = (rgrid + G - 1) / G;
+        if (mesh->dim == 2)
+          k_walk_pending<2><<<pgrid, kBlock, 0, st>>>((int)nwaves, ps->tile_p, G, g_pending_q.as<PendEntry>(),
+                                                     g_wave_cnt.as<int>(), mesh->d_records.p,
+                                                     elem_ids_dev, looplimit, used);
+        else
+          k_walk_pending<3><<<pgrid, kBlock, 0, st>>>((int)nwaves, ps->tile_p, G, g_pending_q.as<PendEntry>(),
+                                                     g_wave_cnt.as<int>(), mesh->d_records.p,
+                                                     elem_ids_dev, looplimit, used);
+      }
       g_cnt2_cur ^= 1;
     } else if (rgrid > 0) {
       if (mesh->dim == 2)
