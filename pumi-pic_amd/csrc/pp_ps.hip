@@ -184,15 +184,17 @@ struct Totals {  // s_misc layout
 };
 
 __global__ void k_count_added(int n_new, const int* __restrict__ new_elems, int ne,
-                              int* __restrict__ ppe, Totals* tot) {
+                              int* __restrict__ ppe, Totals* tot, int* __restrict__ rank_new) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_new) return;
   const int e = new_elems[i];
   if (e < 0 || e >= ne) {
     tot->invalid = 1;
+    if (rank_new) rank_new[i] = -1;
     return;
   }
-  atomicAdd(&ppe[e], 1);
+  const int r = atomicAdd(&ppe[e], 1);
+  if (rank_new) rank_new[i] = r;  // rank inside the new row (see k_count_tiled)
 }
 // ---- stable LSD radix sort (8-bit digits) of (key64, val32)
 constexpr int RS_TILE = 2048;  // keys per block
@@ -378,27 +380,40 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
                               const int* __restrict__ chunk_width, const int* __restrict__ r2e,
                               const unsigned char* __restrict__ mask,
                               const int* __restrict__ new_element, int ne, int* __restrict__ ppe,
-                              Totals* tot) {
-  // thread = (group of G consecutive tiles, row): consecutive tiles of one chunk are the same row
-  // of the same element, so the stayers of up to G*TP columns leave as ONE atomic (the L2 atomic
-  // rate, not the 5 B/particle read, bounds this kernel)
+                              Totals* tot, int* __restrict__ rank) {
+  // thread = (group of G consecutive tiles, row), G*TP <= 32: consecutive tiles of one chunk are
+  // the same row of the same element, so the stayers of up to 32 columns cost ONE atomic (the L2
+  // atomic rate, not the 5 B/particle read, bounds this kernel).  The atomics RETURN the old count:
+  // that is the particle's rank inside its new row, so the histogram pass is also the slot
+  // assignment (slot = row start + rank*C once the layout is known) -- one atomic per particle per
+  // rebuild instead of two.
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int grp = (int)(g / C), r = (int)(g - (long long)grp * C);
   const int ntiles = *ntiles_dev;
-  int cur = -1, e = -1, start = 0, stay = 0;
+  int cur = -1, e = -1, start = 0, run_p0 = 0;
+  unsigned stay = 0;  // bit b = column run_p0 + b of the current run stays in its element
+  auto flush = [&]() {
+    if (!stay) return;
+    int idx = atomicAdd(&ppe[e], __popc(stay));
+    while (stay) {
+      const int b = __ffs(stay) - 1;
+      stay &= stay - 1;
+      rank[start + (run_p0 + b) * C] = idx++;
+    }
+  };
   for (int k = 0; k < G; ++k) {
     const int tile = grp * G + k;
     if (tile >= ntiles) break;
     const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
     if (c != cur) {
-      if (stay) atomicAdd(&ppe[e], stay);
-      stay = 0;
+      flush();
       cur = c;
       start = chunk_start[c] + r;
       e = r2e[c * C + r];
+      run_p0 = p0;
     }
     const int pend = min(p0 + TP, chunk_width[c]);
-    for (int pb = p0; pb < pend; pb += 8) {  // 16 independent loads in flight, then the histogram
+    for (int pb = p0; pb < pend; pb += 8) {  // 16 independent loads in flight, then the atomics
       int nel[8];
       unsigned char mk[8];
 #pragma unroll
@@ -413,20 +428,22 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
+        if (pb + j >= pend) continue;
         const int ne_ = nel[j];
-        if (!mk[j] || ne_ == -1) continue;
-        if (ne_ < 0 || ne_ >= ne) {
-          tot->invalid = 1;
-          continue;
+        int rk = -1;
+        if (mk[j] && ne_ != -1) {
+          if (ne_ < 0 || ne_ >= ne)
+            tot->invalid = 1;
+          else if (ne_ == e)
+            stay |= 1u << (pb + j - run_p0);
+          else
+            rk = atomicAdd(&ppe[ne_], 1);
         }
-        if (ne_ == e)
-          ++stay;
-        else
-          atomicAdd(&ppe[ne_], 1);
+        rank[start + (pb + j) * C] = rk;
       }
     }
   }
-  if (stay) atomicAdd(&ppe[e], stay);
+  flush();
 }
 // live particles and non-empty elements of the new population, from the histogram: one atomic per
 // wave of ELEMENTS (a per-wave atomic on one counter in the particle-sized kernels serialises at
@@ -700,10 +717,14 @@ __device__ __forceinline__ void copy_members(const MoveArgs& a, long long from, 
 // new particles (set_new_particle + CopyViewsToViews, SCS_rebuild.h:277-289)
 __global__ void k_add_scs(int n_new, const int* __restrict__ new_elems,
                           const int* __restrict__ e2r_new, int C_new, int* __restrict__ row_cursor,
+                          const int* __restrict__ rank_new, const int* __restrict__ chunk_start,
                           unsigned char* __restrict__ new_mask, MoveArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_new) return;
-  const int idx = atomicAdd(&row_cursor[e2r_new[new_elems[i]]], C_new);
+  const int row = e2r_new[new_elems[i]];
+  // rank_new: slot from the rank the counting pass returned; else the row cursor (direct move)
+  const int idx = rank_new ? chunk_start[row / C_new] + row % C_new + rank_new[i] * C_new
+                           : atomicAdd(&row_cursor[row], C_new);
   new_mask[idx] = 1;
   copy_members(a, i, idx);
 }
@@ -768,83 +789,29 @@ struct WordTable {
   char* z8[8];
   char* z4[8];
 };
-// pass 1a: slot assignment only (atomics), destination index per old slot (-1 = not moved)
-__global__ void k_assign_tiled(const int* __restrict__ ntiles_dev, int C, int TP, int G,
-                               const int* __restrict__ tiles, const int* __restrict__ chunk_start,
-                               const int* __restrict__ chunk_width, const int* __restrict__ r2e,
-                               const unsigned char* __restrict__ mask,
-                               const int* __restrict__ new_element, const int* __restrict__ e2r_new,
-                               int C_new, int* __restrict__ row_cursor,
-                               unsigned char* __restrict__ new_mask, int* __restrict__ new_idx) {
-  // thread = (group of G consecutive tiles, row), G*TP <= 32: the stayers of a run of tiles of one
-  // chunk reserve their new slots with ONE returning atomic (see k_count_tiled)
-  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int grp = (int)(g / C), r = (int)(g - (long long)grp * C);
-  const int ntiles = *ntiles_dev;
-  int cur = -1, e = -1, start = 0, run_p0 = 0;
-  unsigned stay = 0;  // bit b = column run_p0 + b of the current run stays in its element
-  auto flush = [&]() {
-    if (!stay) return;
-    int idx = atomicAdd(&row_cursor[e2r_new[e]], __popc(stay) * C_new);
-    while (stay) {
-      const int b = __ffs(stay) - 1;
-      stay &= stay - 1;
-      new_idx[start + (run_p0 + b) * C] = idx;
-      idx += C_new;
-    }
-  };
-  for (int k = 0; k < G; ++k) {
-    const int tile = grp * G + k;
-    if (tile >= ntiles) break;
-    const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
-    if (c != cur) {
-      flush();
-      cur = c;
-      start = chunk_start[c] + r;
-      e = r2e[c * C + r];
-      run_p0 = p0;
-    }
-    const int pend = min(p0 + TP, chunk_width[c]);
-    for (int pb = p0; pb < pend; pb += 8) {  // loads of 8 columns in flight, then the slot atomics
-      int nel[8];
-      unsigned char mk[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int pid = start + (pb + j) * C;
-        mk[j] = 0;
-        nel[j] = -1;
-        if (pb + j < pend) {
-          mk[j] = mask[pid];
-          nel[j] = new_element[pid];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (pb + j >= pend) continue;
-        int idx = -1;
-        if (mk[j]) {
-          if (nel[j] == e)
-            stay |= 1u << (pb + j - run_p0);
-          else if (nel[j] != -1)
-            idx = atomicAdd(&row_cursor[e2r_new[nel[j]]], C_new);
-        }
-        new_idx[start + (pb + j) * C] = idx;
-      }
-    }
-  }
-  flush();
-}
 // pass 1b: one thread per old slot packs its record; the wave transposes through LDS so that
 // NQ adjacent lanes store one whole record (full 64-B sectors leave the CU already merged:
 // 0.21 vs 0.27 ms per 10 M random records, tools/ub_scatter.hip)
+// SCS passes `rs` (rank -> slot translation: slot = start of the new row + rank*C); CSR passes the
+// slot directly.
+struct RankToSlot {
+  const int* new_element;  // nullptr: new_idx already is the destination slot
+  const int* e2r_new;
+  const int* chunk_start;
+  int C_new;
+};
 template <int NQ>
-__global__ void k_move_pack(int capacity, const int* __restrict__ new_idx,
+__global__ void k_move_pack(int capacity, const int* __restrict__ new_idx, RankToSlot rs,
                             uint4* __restrict__ aos, WordTable t) {
   __shared__ uint4 st[4][64][NQ + 1];
   __shared__ int sd[4][64];
   const int pid = blockIdx.x * blockDim.x + threadIdx.x;
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int idx = (pid < capacity) ? new_idx[pid] : -1;
+  int idx = (pid < capacity) ? new_idx[pid] : -1;
+  if (idx >= 0 && rs.new_element) {
+    const int row = rs.e2r_new[rs.new_element[pid]];
+    idx = rs.chunk_start[row / rs.C_new] + row % rs.C_new + idx * rs.C_new;
+  }
   if (idx >= 0) {
     unsigned v[NQ * 4];
 #pragma unroll
@@ -1197,13 +1164,18 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   // tiles per thread of the count/assign kernels: G*TP <= 32 (stay bit mask)
   const int G = std::max(1, 32 / ps->tile_p);
   const unsigned grp_grid = grid_for(((size_t)ps->ntiles_max + G - 1) / G * ps->C);
+  // ranks inside the new rows, returned by the histogram's atomics (old particles, then new ones)
+  PP_HIP_CHECK(ps->s_idx.reserve(sizeof(int) * (size_t)std::max(ps->capacity, 1)));
+  PP_HIP_CHECK(ps->s_ranknew.reserve(sizeof(int) * (size_t)std::max(n_new, 1)));
+  int* rank = ps->s_idx.as<int>();
+  int* rank_new = ps->s_ranknew.as<int>();
   if (have_old && old_grid > 0)
     k_count_tiled<<<grp_grid, kBlock, 0, st>>>(
         ps->d_ntiles.as<int>(), ps->C, ps->tile_p, G, ps->d_tiles.as<int>(),
         ps->d_chunk_start.as<int>(), ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(),
-        ps->d_mask.as<unsigned char>(), new_element, ne, ppe, tot);
+        ps->d_mask.as<unsigned char>(), new_element, ne, ppe, tot, rank);
   if (n_new > 0) {
-    k_count_added<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ne, ppe, tot);
+    k_count_added<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ne, ppe, tot, rank_new);
   }
   if (ne > 0) k_nonempty<<<grid_for(ne), kBlock, 0, st>>>(ne, ppe, tot);
   // Sort keys are (window, count) with count < key_base; an upper bound known on the host avoids
@@ -1292,18 +1264,12 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     const unsigned new_grid = grid_for((size_t)ntiles_max * C_new);
 #define PP_UNPACK_ARGS \
   new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_mask2.as<unsigned char>(), aos, wt
-#define PP_STAGED(N)                                                                  \
-  case N:                                                                             \
-    k_move_pack<N><<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, new_idx, aos, wt); \
-    k_move_unpack<N><<<new_grid, kBlock, 0, st>>>(PP_UNPACK_ARGS);                    \
+#define PP_STAGED(N)                                                                         \
+  case N:                                                                                    \
+    k_move_pack<N><<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, rank, rs, aos, wt); \
+    k_move_unpack<N><<<new_grid, kBlock, 0, st>>>(PP_UNPACK_ARGS);                           \
     break;
-    PP_HIP_CHECK(ps->s_idx.reserve(sizeof(int) * (size_t)ps->capacity));
-    int* new_idx = ps->s_idx.as<int>();
-    k_assign_tiled<<<grp_grid, kBlock, 0, st>>>(
-        ps->d_ntiles.as<int>(), ps->C, ps->tile_p, G, ps->d_tiles.as<int>(),
-        ps->d_chunk_start.as<int>(), ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(),
-        ps->d_mask.as<unsigned char>(), new_element, ps->s_e2r2.as<int>(), C_new,
-        ps->s_rowstart.as<int>(), ps->s_mask2.as<unsigned char>(), new_idx);
+    const RankToSlot rs{new_element, ps->s_e2r2.as<int>(), L.chunk_start, C_new};
     switch (NQ) {
       PP_STAGED(1) PP_STAGED(2) PP_STAGED(3) PP_STAGED(4) PP_STAGED(6) PP_STAGED(8) PP_STAGED(10)
     }
@@ -1322,6 +1288,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     add.commit_x = add.commit_xt = -1;  // new particles arrive with their own positions
     k_add_scs<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ps->s_e2r2.as<int>(), C_new,
                                                   ps->s_rowstart.as<int>(),
+                                                  NQ > 0 ? rank_new : nullptr, L.chunk_start,
                                                   ps->s_mask2.as<unsigned char>(), add);
   }
   PP_LAUNCH_CHECK();
@@ -1365,7 +1332,7 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   // live slots are [0, offsets[ne]) == [0, num_ptcls)
   const int nold = ps->num_ptcls;
   if (nold > 0) k_count_csr<<<grid_for(nold), kBlock, 0, st>>>(nold, new_element, ne, ppe, tot);
-  if (n_new > 0) k_count_added<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ne, ppe, tot);
+  if (n_new > 0) k_count_added<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ne, ppe, tot, nullptr);
   PP_HIP_CHECK(ps->s_offsets2.reserve(sizeof(int) * ((size_t)ne + 1)));
   k_scan_excl<<<1, 1024, 0, st>>>(ne + 1, ppe, ps->s_offsets2.as<int>(), &tot->active);
   PP_LAUNCH_CHECK();
@@ -1409,11 +1376,11 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   case N:                                                                                        \
     if (nold > 0) {                                                                              \
       k_assign_csr<<<grid_for(nold), kBlock, 0, st>>>(nold, new_element, cursor, new_idx);        \
-      k_move_pack<N><<<grid_for(nold), kBlock, 0, st>>>(nold, new_idx, aos, wt);                 \
+      k_move_pack<N><<<grid_for(nold), kBlock, 0, st>>>(nold, new_idx, RankToSlot{}, aos, wt);   \
     }                                                                                            \
     if (n_new > 0) {                                                                             \
       k_assign_csr<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, cursor, new_idx);       \
-      k_move_pack<N><<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_idx, aos, wt_new);           \
+      k_move_pack<N><<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_idx, RankToSlot{}, aos, wt_new); \
     }                                                                                            \
     k_unpack_flat<N><<<grid_for(on_process), kBlock, 0, st>>>(on_process, aos, wt);              \
     break;
