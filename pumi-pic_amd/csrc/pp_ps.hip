@@ -795,9 +795,9 @@ struct WordTable {
 // SCS passes `rs` (rank -> slot translation: slot = start of the new row + rank*C); CSR passes the
 // slot directly.
 struct RankToSlot {
-  const int* new_element;  // nullptr: new_idx already is the destination slot
-  const int* e2r_new;
-  const int* chunk_start;
+  const int* new_element;  // element of every source particle
+  const int* e2r_new;      // SCS: element -> new row ; nullptr selects the CSR form
+  const int* chunk_start;  // SCS: first slot of every new chunk ; CSR: the new offsets array
   int C_new;
 };
 template <int NQ>
@@ -808,9 +808,14 @@ __global__ void k_move_pack(int capacity, const int* __restrict__ new_idx, RankT
   const int pid = blockIdx.x * blockDim.x + threadIdx.x;
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   int idx = (pid < capacity) ? new_idx[pid] : -1;
-  if (idx >= 0 && rs.new_element) {
-    const int row = rs.e2r_new[rs.new_element[pid]];
-    idx = rs.chunk_start[row / rs.C_new] + row % rs.C_new + idx * rs.C_new;
+  if (idx >= 0) {
+    const int e = rs.new_element[pid];
+    if (rs.e2r_new) {
+      const int row = rs.e2r_new[e];
+      idx = rs.chunk_start[row / rs.C_new] + row % rs.C_new + idx * rs.C_new;
+    } else {
+      idx += rs.chunk_start[e];
+    }
   }
   if (idx >= 0) {
     unsigned v[NQ * 4];
@@ -878,13 +883,6 @@ __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
 }
 // CSR staged move (same two passes as SCS): slot assignment by the element cursor, pack through
 // the LDS transpose into 64-B-multiple records, then a flat pass that writes the new SoA coalesced
-__global__ void k_assign_csr(int n, const int* __restrict__ elems, int* __restrict__ cursor,
-                             int* __restrict__ new_idx) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int e = elems[i];
-  new_idx[i] = e < 0 ? -1 : atomicAdd(&cursor[e], 1);  // negative ids are removed (CSR_rebuild.hpp:36-40)
-}
 template <int NQ>
 __global__ void k_unpack_flat(int n, const uint4* __restrict__ aos, WordTable t) {
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -924,17 +922,18 @@ __global__ void k_add_csr(int n_new, const int* __restrict__ new_elems, int* __r
   copy_members(a, i, idx);
 }
 __global__ void k_count_csr(int nold, const int* __restrict__ new_element, int ne,
-                            int* __restrict__ ppe, Totals* tot) {
+                            int* __restrict__ ppe, Totals* tot, int* __restrict__ rank) {
   const int pid = blockIdx.x * blockDim.x + threadIdx.x;
   if (pid >= nold) return;
   const int e = new_element[pid];
+  int rk = -1;  // negative ids are removed (CSR_rebuild.hpp:36-40)
   if (e > -1) {
-    if (e >= ne) {
+    if (e >= ne)
       tot->invalid = 1;
-      return;
-    }
-    atomicAdd(&ppe[e], 1);
+    else
+      rk = atomicAdd(&ppe[e], 1);  // rank inside the new element: slot = offsets[e] + rank
   }
+  rank[pid] = rk;
 }
 __global__ void k_csr_slots(int ne, const int* __restrict__ offsets, int capacity,
                             int* __restrict__ slot_elem, unsigned char* __restrict__ mask) {
@@ -1331,8 +1330,13 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   int* ppe = ps->s_ppe.as<int>();
   // live slots are [0, offsets[ne]) == [0, num_ptcls)
   const int nold = ps->num_ptcls;
-  if (nold > 0) k_count_csr<<<grid_for(nold), kBlock, 0, st>>>(nold, new_element, ne, ppe, tot);
-  if (n_new > 0) k_count_added<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ne, ppe, tot, nullptr);
+  // the counting atomics return each particle's rank inside its new element (old, then new ones)
+  PP_HIP_CHECK(ps->s_idx.reserve(sizeof(int) * (size_t)std::max(nold, 1)));
+  PP_HIP_CHECK(ps->s_ranknew.reserve(sizeof(int) * (size_t)std::max(n_new, 1)));
+  int* rank = ps->s_idx.as<int>();
+  int* rank_new = ps->s_ranknew.as<int>();
+  if (nold > 0) k_count_csr<<<grid_for(nold), kBlock, 0, st>>>(nold, new_element, ne, ppe, tot, rank);
+  if (n_new > 0) k_count_added<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ne, ppe, tot, rank_new);
   PP_HIP_CHECK(ps->s_offsets2.reserve(sizeof(int) * ((size_t)ne + 1)));
   k_scan_excl<<<1, 1024, 0, st>>>(ne + 1, ppe, ps->s_offsets2.as<int>(), &tot->active);
   PP_LAUNCH_CHECK();
@@ -1368,20 +1372,16 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   }
   if (NQ > 0 && on_process > 0) {
     PP_HIP_CHECK(ps->s_aos.reserve((size_t)on_process * NQ * 16));
-    PP_HIP_CHECK(ps->s_idx.reserve(sizeof(int) * (size_t)std::max(std::max(nold, n_new), 1)));
     uint4* aos = ps->s_aos.as<uint4>();
-    int* new_idx = ps->s_idx.as<int>();
-    int* cursor = ps->s_rowstart.as<int>();
+    const int* off2 = ps->s_offsets2.as<int>();
 #define PP_CSR_STAGED(N)                                                                         \
   case N:                                                                                        \
-    if (nold > 0) {                                                                              \
-      k_assign_csr<<<grid_for(nold), kBlock, 0, st>>>(nold, new_element, cursor, new_idx);        \
-      k_move_pack<N><<<grid_for(nold), kBlock, 0, st>>>(nold, new_idx, RankToSlot{}, aos, wt);   \
-    }                                                                                            \
-    if (n_new > 0) {                                                                             \
-      k_assign_csr<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, cursor, new_idx);       \
-      k_move_pack<N><<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_idx, RankToSlot{}, aos, wt_new); \
-    }                                                                                            \
+    if (nold > 0)                                                                                \
+      k_move_pack<N><<<grid_for(nold), kBlock, 0, st>>>(                                         \
+          nold, rank, RankToSlot{new_element, nullptr, off2, 1}, aos, wt);                       \
+    if (n_new > 0)                                                                               \
+      k_move_pack<N><<<grid_for(n_new), kBlock, 0, st>>>(                                        \
+          n_new, rank_new, RankToSlot{new_elems, nullptr, off2, 1}, aos, wt_new);                \
     k_unpack_flat<N><<<grid_for(on_process), kBlock, 0, st>>>(on_process, aos, wt);              \
     break;
     switch (NQ) {
