@@ -651,7 +651,7 @@ __global__ void k_init_slots_tiled(const int* __restrict__ ntiles_dev, int C, in
                                    const int* __restrict__ chunk_width, const int* __restrict__ r2e,
                                    const int* __restrict__ ppe, int ne,
                                    int* __restrict__ slot_elem, int* __restrict__ row_cursor,
-                                   unsigned char* __restrict__ new_mask) {
+                                   int* __restrict__ elem_slot0, unsigned char* __restrict__ new_mask) {
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int tile = (int)(g / C), r = (int)(g - (long long)tile * C);
   if (tile >= *ntiles_dev) return;
@@ -662,7 +662,10 @@ __global__ void k_init_slots_tiled(const int* __restrict__ ntiles_dev, int C, in
   // advances by C), so the new mask is a function of the new per-element counts: written here as
   // coalesced runs instead of one scattered byte store per moved particle
   const int cnt = e < ne ? ppe[e] : 0;
-  if (p0 == 0) row_cursor[c * C + r] = start;
+  if (p0 == 0) {
+    row_cursor[c * C + r] = start;
+    if (e < ne) elem_slot0[e] = start;  // first slot of the element's new row (pack: + rank*C)
+  }
   for (int p = p0; p < pend; ++p) {
     slot_elem[start + p * C] = e;
     new_mask[start + p * C] = p < cnt ? 1 : 0;
@@ -717,14 +720,13 @@ __device__ __forceinline__ void copy_members(const MoveArgs& a, long long from, 
 // new particles (set_new_particle + CopyViewsToViews, SCS_rebuild.h:277-289)
 __global__ void k_add_scs(int n_new, const int* __restrict__ new_elems,
                           const int* __restrict__ e2r_new, int C_new, int* __restrict__ row_cursor,
-                          const int* __restrict__ rank_new, const int* __restrict__ chunk_start,
+                          const int* __restrict__ rank_new, const int* __restrict__ elem_slot0,
                           unsigned char* __restrict__ new_mask, MoveArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_new) return;
-  const int row = e2r_new[new_elems[i]];
+  const int e = new_elems[i];
   // rank_new: slot from the rank the counting pass returned; else the row cursor (direct move)
-  const int idx = rank_new ? chunk_start[row / C_new] + row % C_new + rank_new[i] * C_new
-                           : atomicAdd(&row_cursor[row], C_new);
+  const int idx = rank_new ? elem_slot0[e] + rank_new[i] * C_new : atomicAdd(&row_cursor[e2r_new[e]], C_new);
   new_mask[idx] = 1;
   copy_members(a, i, idx);
 }
@@ -796,9 +798,8 @@ struct WordTable {
 // slot directly.
 struct RankToSlot {
   const int* new_element;  // element of every source particle
-  const int* e2r_new;      // SCS: element -> new row ; nullptr selects the CSR form
-  const int* chunk_start;  // SCS: first slot of every new chunk ; CSR: the new offsets array
-  int C_new;
+  const int* elem_slot0;   // first slot of the element's new row (SCS) / new offsets (CSR)
+  int step;                // slot distance between consecutive ranks: C (SCS) / 1 (CSR)
 };
 template <int NQ>
 __global__ void k_move_pack(int capacity, const int* __restrict__ new_idx, RankToSlot rs,
@@ -807,17 +808,12 @@ __global__ void k_move_pack(int capacity, const int* __restrict__ new_idx, RankT
   __shared__ int sd[4][64];
   const int pid = blockIdx.x * blockDim.x + threadIdx.x;
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  int idx = (pid < capacity) ? new_idx[pid] : -1;
-  if (idx >= 0) {
-    const int e = rs.new_element[pid];
-    if (rs.e2r_new) {
-      const int row = rs.e2r_new[e];
-      idx = rs.chunk_start[row / rs.C_new] + row % rs.C_new + idx * rs.C_new;
-    } else {
-      idx += rs.chunk_start[e];
-    }
-  }
-  if (idx >= 0) {
+  const int rk = (pid < capacity) ? new_idx[pid] : -1;
+  int idx = -1;
+  if (rk >= 0) {
+    // the member loads below depend only on rk >= 0: they are in flight while the two dependent
+    // loads of the slot translation return
+    idx = rs.elem_slot0[rs.new_element[pid]] + rk * rs.step;
     unsigned v[NQ * 4];
 #pragma unroll
     for (int i = 0; i < NQ * 4; ++i) v[i] = 0u;
@@ -1219,6 +1215,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   PP_HIP_CHECK(ps->s_mask2.reserve((size_t)std::max(new_capacity, 1)));
   PP_HIP_CHECK(ps->s_slot2.reserve(sizeof(int) * (size_t)std::max(new_capacity, 1)));
   PP_HIP_CHECK(ps->s_rowstart.reserve(sizeof(int) * (size_t)nrows));
+  PP_HIP_CHECK(ps->s_eslot0.reserve(sizeof(int) * (size_t)std::max(ne, 1)));
   // sum_c ceil(w_c/TP) <= nchunks + capacity/(C*TP): sizes the launch without reading the count
   const int ntiles_max = nchunks + new_capacity / (C_new * ps->tile_p) + 1;
   PP_HIP_CHECK(ps->s_newidx.reserve(sizeof(int) * 2 * (size_t)ntiles_max));  // new tile table
@@ -1235,7 +1232,8 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
                                                           ps->s_rowstart.as<int>());
   k_init_slots_tiled<<<grid_for((size_t)ntiles_max * C_new), kBlock, 0, st>>>(
       new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_r2e2.as<int>(),
-      ppe, ne, ps->s_slot2.as<int>(), ps->s_rowstart.as<int>(), ps->s_mask2.as<unsigned char>());
+      ppe, ne, ps->s_slot2.as<int>(), ps->s_rowstart.as<int>(), ps->s_eslot0.as<int>(),
+      ps->s_mask2.as<unsigned char>());
   // ---- swap buffer sizing (SCS_rebuild.h:223-229)
   int64_t swap_stride = ps->swap_stride;
   if (swap_stride < new_capacity || swap_stride * ps->minimize_size < new_capacity) {
@@ -1268,7 +1266,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     k_move_pack<N><<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, rank, rs, aos, wt); \
     k_move_unpack<N><<<new_grid, kBlock, 0, st>>>(PP_UNPACK_ARGS);                           \
     break;
-    const RankToSlot rs{new_element, ps->s_e2r2.as<int>(), L.chunk_start, C_new};
+    const RankToSlot rs{new_element, ps->s_eslot0.as<int>(), C_new};
     switch (NQ) {
       PP_STAGED(1) PP_STAGED(2) PP_STAGED(3) PP_STAGED(4) PP_STAGED(6) PP_STAGED(8) PP_STAGED(10)
     }
@@ -1287,7 +1285,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     add.commit_x = add.commit_xt = -1;  // new particles arrive with their own positions
     k_add_scs<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ps->s_e2r2.as<int>(), C_new,
                                                   ps->s_rowstart.as<int>(),
-                                                  NQ > 0 ? rank_new : nullptr, L.chunk_start,
+                                                  NQ > 0 ? rank_new : nullptr, ps->s_eslot0.as<int>(),
                                                   ps->s_mask2.as<unsigned char>(), add);
   }
   PP_LAUNCH_CHECK();
@@ -1378,10 +1376,10 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   case N:                                                                                        \
     if (nold > 0)                                                                                \
       k_move_pack<N><<<grid_for(nold), kBlock, 0, st>>>(                                         \
-          nold, rank, RankToSlot{new_element, nullptr, off2, 1}, aos, wt);                       \
+          nold, rank, RankToSlot{new_element, off2, 1}, aos, wt);                                \
     if (n_new > 0)                                                                               \
       k_move_pack<N><<<grid_for(n_new), kBlock, 0, st>>>(                                        \
-          n_new, rank_new, RankToSlot{new_elems, nullptr, off2, 1}, aos, wt_new);                \
+          n_new, rank_new, RankToSlot{new_elems, off2, 1}, aos, wt_new);                         \
     k_unpack_flat<N><<<grid_for(on_process), kBlock, 0, st>>>(on_process, aos, wt);              \
     break;
     switch (NQ) {
