@@ -709,9 +709,9 @@ __device__ __forceinline__ void rows_particle(const PState& s, int pid, int e,
     int elem = s.elem;
     ppm::elliptical_point(ct, s.phi, s.b, h, k, d, dest.x, dest.y, rad);
     dest.z = 0;
-    xt[pid] = dest.x;
-    xt[stride + pid] = dest.y;
-    pphi[pid] = (float)rad;
+    stg<true>(xt + pid, dest.x);
+    stg<true>(xt + stride + pid, dest.y);
+    stg<true>(pphi + pid, (float)rad);
     if (elem == -1) elem = e;
     if (elem == -nelems) {
       elem_ids[pid] = -1;
@@ -722,10 +722,10 @@ __device__ __forceinline__ void rows_particle(const PState& s, int pid, int e,
     int elem = seeded ? s.elem : e;
     const V3 orig{s.x, s.y, s.z};
     ppm::toroidal_point(ct, s.phi, s.b, orig.x, orig.y, h, k, d, dest.x, dest.y, dest.z, rad);
-    xt[pid] = dest.x;
-    xt[stride + pid] = dest.y;
-    xt[2 * stride + pid] = dest.z;
-    pphi[pid] = (float)rad;
+    stg<true>(xt + pid, dest.x);
+    stg<true>(xt + stride + pid, dest.y);
+    stg<true>(xt + 2 * stride + pid, dest.z);
+    stg<true>(pphi + pid, (float)rad);
     bool done = (elem == -1);
     // finishUnmoved: norm(dest-orig) < tol  <=>  |dest-orig|^2 < unmoved_sq (sqrt is monotone and
     // correctly rounded; unmoved_sq = min{s : sqrt(s) >= tol} is found on the host)
@@ -794,7 +794,7 @@ __global__ void __launch_bounds__(256, OCC)
       const int p = t_p0 + col;
       if (have && p < t_pend) {
         const int pid = t_start + p * C;
-        const PState s = load_state<DIM>(pid, mask, pphi, pb, x, stride, elem_ids, read_ids);
+        const PState s = load_state<DIM, true>(pid, mask, pphi, pb, x, stride, elem_ids, read_ids);
         rows_particle<DIM>(s, pid, t_e, tct, cache, recs, nelems, xt, stride, pphi, h, k, d, tol,
                            unmoved_sq, elem_ids, seeded, looplimit, cnt);
       }
@@ -802,12 +802,12 @@ __global__ void __launch_bounds__(256, OCC)
     }
   }
   if (!valid) return;
-  PState cur = load_state<DIM>(start + p0 * C, mask, pphi, pb, x, stride, elem_ids, read_ids);
+  PState cur = load_state<DIM, true>(start + p0 * C, mask, pphi, pb, x, stride, elem_ids, read_ids);
   for (int p = p0; p < pend; ++p) {
     const int pid = start + p * C;
     const PState s = cur;
     if (p + 1 < pend)  // prefetch the next particle of this row before the dependent walk
-      cur = load_state<DIM>(pid + C, mask, pphi, pb, x, stride, elem_ids, read_ids);
+      cur = load_state<DIM, true>(pid + C, mask, pphi, pb, x, stride, elem_ids, read_ids);
     rows_particle<DIM>(s, pid, e, ct, cache, recs, nelems, xt, stride, pphi, h, k, d, tol,
                        unmoved_sq, elem_ids, seeded, looplimit, cnt);
   }
