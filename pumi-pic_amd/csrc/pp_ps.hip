@@ -820,13 +820,15 @@ __global__ void k_move_pack(int capacity, const int* __restrict__ new_idx, RankT
 #pragma unroll
     for (int i = 0; i < NQ * 2; ++i)
       if (i < t.n8) {
-        const uint2 d = *(const uint2*)(t.src8[i] + (long long)pid * 8);
-        v[2 * i] = d.x;
-        v[2 * i + 1] = d.y;
+        const unsigned long long d =
+            __builtin_nontemporal_load((const unsigned long long*)(t.src8[i] + (long long)pid * 8));
+        v[2 * i] = (unsigned)d;
+        v[2 * i + 1] = (unsigned)(d >> 32);
       }
 #pragma unroll
     for (int j = 0; j < (NQ * 4 < kMax4 ? NQ * 4 : kMax4); ++j)
-      if (j < t.n4) v[NQ * 4 - 1 - j] = *(const unsigned*)(t.src4[j] + (long long)pid * 4);
+      if (j < t.n4)
+        v[NQ * 4 - 1 - j] = __builtin_nontemporal_load((const unsigned*)(t.src4[j] + (long long)pid * 4));
 #pragma unroll
     for (int q = 0; q < NQ; ++q) st[w][l][q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
   }
@@ -858,7 +860,7 @@ __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
     unsigned w[NQ * 4];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const uint4 v = sp[q];
+      const uint4 v = sp[q];  // staged records: plain loads (nt measured slower: they were just written)
       w[4 * q] = v.x;
       w[4 * q + 1] = v.y;
       w[4 * q + 2] = v.z;
@@ -866,14 +868,16 @@ __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
     }
 #pragma unroll
     for (int i = 0; i < NQ * 2; ++i)
-      if (i < t.n8) *(uint2*)(t.dst8[i] + (long long)slot * 8) = make_uint2(w[2 * i], w[2 * i + 1]);
+      if (i < t.n8)
+        __builtin_nontemporal_store(((unsigned long long)w[2 * i + 1] << 32) | w[2 * i],
+                                    (unsigned long long*)(t.dst8[i] + (long long)slot * 8));
 #pragma unroll
     for (int j = 0; j < (NQ * 4 < kMax4 ? NQ * 4 : kMax4); ++j)
-      if (j < t.n4) *(unsigned*)(t.dst4[j] + (long long)slot * 4) = w[NQ * 4 - 1 - j];
+      if (j < t.n4) __builtin_nontemporal_store(w[NQ * 4 - 1 - j], (unsigned*)(t.dst4[j] + (long long)slot * 4));
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      if (i < t.nz8) *(uint2*)(t.z8[i] + (long long)slot * 8) = make_uint2(0u, 0u);
-      if (i < t.nz4) *(unsigned*)(t.z4[i] + (long long)slot * 4) = 0u;
+      if (i < t.nz8) __builtin_nontemporal_store(0ull, (unsigned long long*)(t.z8[i] + (long long)slot * 8));
+      if (i < t.nz4) __builtin_nontemporal_store(0u, (unsigned*)(t.z4[i] + (long long)slot * 4));
     }
   }
 }
