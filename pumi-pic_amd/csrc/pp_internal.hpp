@@ -164,5 +164,5 @@ struct pp_ps {
   int tile_p = pp::kTileP;  // columns per tile (PP_TILE_P overrides, tuning knob)
   // scratch reused across rebuilds
   pp::DevBuf s_ppe, s_keys, s_keys2, s_vals, s_vals2, s_hist, s_chunkw, s_misc, s_rowstart,
-      s_newidx, s_offsets2, s_s2c2, s_r2e2, s_e2r2, s_mask2, s_slot2, s_scan, s_cstart2, s_cwidth2, s_aos, s_idx, s_ranknew, s_eslot0;
+      s_newidx, s_offsets2, s_s2c2, s_r2e2, s_e2r2, s_mask2, s_slot2, s_scan, s_cstart2, s_cwidth2, s_aos, s_idx, s_ranknew, s_eslot0, s_scan2;
 };
