@@ -197,10 +197,13 @@ int pp_search_mesh(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_pi
 int pp_search_mesh_legacy3d(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_pid,
                             int* elem_ids_dev, int elem_ids_seeded, double* xpoints_dev,
                             int* xface_dev, int looplimit, int* found);
-/* Fused hot path: elliptical (dim 2) / toroidal (dim 3) push + BCC walk in one kernel: particle
- * state is read once and x_tgt, phi, elem_ids written once.  Result-identical to
- * pp_*_push followed by pp_search_mesh_2d (dim 2) / pp_search_mesh BCC with the origin check
- * skipped (dim 3).  found may be NULL (no host sync). */
+/* Fused hot path: elliptical (dim 2) / toroidal (dim 3) push + BCC walk: particle state is read
+ * once and x_tgt, phi, elem_ids written once.  Result-identical to pp_elliptical_push +
+ * pp_search_mesh_2d (dim 2) and to pp_toroidal_push + pp_search_mesh in BCC mode (dim 3:
+ * finishUnmoved, check_initial_parents, walk, tpp:72-145,460-615).  dim 2 needs elem_ids_seeded
+ * (-1 = own element, -nelems = outside).  SCS structures use the row-tiled kernels (dim 3: column
+ * loop + deferred walk of crossing particles, two launches, library-owned queue of 32 B per tile
+ * slot); CSR structures the slot-parallel kernel.  found may be NULL (no host sync). */
 int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b, int m_phi,
                    double h, double k, double d, double deg, int* elem_ids_dev,
                    int elem_ids_seeded, int looplimit, int* found);
