@@ -8,9 +8,9 @@
 // (ring_accum[v*gnr+{ringDown,ringUp}] += 1 for the 3 vertices of its element) and the particle
 // radius is a constant (gyroScatter.hpp:184), so the first stage is a pure function of
 // the per-element live-particle counts.  Those counts come from the structure (mask summed per
-// row without atomics for SCS, offsets differences for CSR); each ELEMENT then issues one atomic
-// per (vertex, ring).  All addends are exact integers, so the sums are bit-identical to the
-// reference's particle-by-particle accumulation in any order.
+// row without atomics for SCS, offsets differences for CSR); each VERTEX then sums the counts of
+// its adjacent elements (no atomics).  All addends are exact integers, so the sums are bit-identical
+// to the reference's particle-by-particle accumulation in any order.
 #include "pp_geom.hpp"
 #include "pp_internal.hpp"
 
@@ -149,17 +149,19 @@ __global__ void k_count_csr(int ne, const int* __restrict__ offsets, int* __rest
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < ne) cnt[e] = offsets[e + 1] - offsets[e];
 }
-__global__ void k_accumulate_rings(int ne, int nvpe, const int* __restrict__ cnt,
-                                   const int* __restrict__ elem2verts, int gnr, int ringDown,
-                                   int ringUp, double* __restrict__ ring_accum) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int e = t / nvpe, i = t % nvpe;
-  if (e >= ne) return;
-  const int n = cnt[e];
-  if (!n) return;
-  const int v = elem2verts[(size_t)e * nvpe + i];
-  atomicAdd(&ring_accum[(size_t)v * gnr + ringUp], (double)n);
-  atomicAdd(&ring_accum[(size_t)v * gnr + ringDown], (double)n);
+// Gather form of the first stage: ring_accum[v][ringUp] = ring_accum[v][ringDown] = number of live
+// particles in the elements around vertex v (every particle adds 1 to both rings of each vertex of
+// its element, gyroScatter.hpp:188-197).  One thread per vertex over the vertex->element adjacency:
+// no atomics, no memset, and integer sums in double are exact in any order.
+__global__ void k_rings_from_adjacency(int nverts, int gnr, const int* __restrict__ v2e_off,
+                                       const int* __restrict__ v2e, const int* __restrict__ cnt,
+                                       int ringDown, int ringUp, double* __restrict__ ring_accum) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nverts) return;
+  long long n = 0;
+  for (int j = v2e_off[v]; j < v2e_off[v + 1]; ++j) n += cnt[v2e[j]];
+  for (int r = 0; r < gnr; ++r)
+    ring_accum[(size_t)v * gnr + r] = (r == ringUp ? (double)n : 0.0) + (r == ringDown ? (double)n : 0.0);
 }
 __global__ void k_scatter_mapped(int nverts, int gnr, int gppr, int nvpe,
                                  const double* __restrict__ ring_accum,
@@ -258,7 +260,6 @@ int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, do
     const bool reuse = c_ps == ps && c_mesh == mesh && c_version == ps->version && ps->version != 0 &&
                        c_gnr == gnr && c_down == ringDown;
     if (!reuse) {
-      PP_HIP_CHECK(hipMemsetAsync(s_ring->p, 0, sizeof(double) * (size_t)std::max(nverts * gnr, 1), st));
       // live particles per element: kept current by construction / rebuild (it IS the histogram
       // the rebuild sorts by), otherwise summed from the mask without per-particle atomics
       const int* cnt = nullptr;
@@ -274,9 +275,9 @@ int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, do
           k_count_csr<<<grid_for(ne), kBlock, 0, st>>>(ne, ps->d_offsets.as<int>(), s_cnt->as<int>());
         cnt = s_cnt->as<int>();
       }
-      k_accumulate_rings<<<grid_for((size_t)ne * nvpe), kBlock, 0, st>>>(
-          ne, nvpe, cnt, mesh->d_elem2verts.as<int>(), gnr, ringDown, ringUp,
-          s_ring->as<double>());
+      k_rings_from_adjacency<<<grid_for(nverts), kBlock, 0, st>>>(
+          nverts, gnr, mesh->d_vert2elems_off.as<int>(), mesh->d_vert2elems.as<int>(), cnt, ringDown,
+          ringUp, s_ring->as<double>());
       c_ps = ps;
       c_mesh = mesh;
       c_version = ps->version;
