@@ -99,7 +99,7 @@ class Stepper:
         self.h, self.k, self.d = s.XGC_H, s.XGC_K, s.XGC_D
         self.ps, self.mesh = w["ps"], w["mesh"]
         cap = max(self.ps.capacity(), 1)
-        self.ids = capi.DevArray.from_host(np.full(cap, -1, dtype=np.int32))
+        self.ids = capi.DevArray.from_host(np.full(cap + cap // 10, -1, dtype=np.int32))
         self.first = True
         self.kernel_ms = []
         if name == "c5":
@@ -142,8 +142,8 @@ class Stepper:
             capi.gyro_scatter(self.mesh, self.ps, self.fwd, out=self.w_f)
             capi.gyro_scatter(self.mesh, self.ps, self.bkwd, out=self.w_b)
             cap = max(self.ps.capacity(), 1)
-            if cap > self.ids.n:
-                self.ids = capi.DevArray(cap, np.int32)
+            if cap > self.ids.n:  # 10% slack: the capacity wanders by a few chunk widths per rebuild
+                self.ids = capi.DevArray(cap + cap // 10, np.int32)
             self.ids.fill_bytes(0xff)
         elif self.name == "c5":
             capi.update_positions(self.ps)
@@ -155,8 +155,8 @@ class Stepper:
             if self.world > 1:  # gyroSync: SUM over ranks of the interleaved fields
                 self._allreduce_fields()
             cap = max(self.ps.capacity(), 1)
-            if cap > self.ids.n:
-                self.ids = capi.DevArray(cap, np.int32)
+            if cap > self.ids.n:  # 10% slack: the capacity wanders by a few chunk widths per rebuild
+                self.ids = capi.DevArray(cap + cap // 10, np.int32)
             self.ids.fill_bytes(0xff)
         # "2d": search_mesh_2d re-seeds from the previous ids as given
 

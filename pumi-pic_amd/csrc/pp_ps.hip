@@ -181,6 +181,7 @@ struct Totals {  // s_misc layout
   int nslices, capacity;
   int pad0;
   double cw_inv;
+  unsigned long long max_key;  // largest sort key of this rebuild (radix passes above it are skipped)
 };
 
 __global__ void k_count_added(int n_new, const int* __restrict__ new_elems, int ne,
@@ -200,19 +201,30 @@ __global__ void k_count_added(int n_new, const int* __restrict__ new_elems, int 
 constexpr int RS_TILE = 2048;  // keys per block
 __global__ void k_make_keys(int ne, const int* __restrict__ ppe, int sigma, int n_sigma,
                             unsigned long long base, unsigned long long* __restrict__ keys,
-                            int* __restrict__ vals) {
+                            int* __restrict__ vals, Totals* tot, int no_skip) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ne) return;
-  int w = 0;
-  if (sigma > 0) {
-    w = i / sigma;
-    if (w > n_sigma - 1) w = n_sigma - 1;
+  unsigned long long key = 0;
+  if (i < ne) {
+    int w = 0;
+    if (sigma > 0) {
+      w = i / sigma;
+      if (w > n_sigma - 1) w = n_sigma - 1;
+    }
+    key = (unsigned long long)w * base + (unsigned long long)ppe[i];
+    keys[i] = key;
+    vals[i] = i;
   }
-  keys[i] = (unsigned long long)w * base + (unsigned long long)ppe[i];
-  vals[i] = i;
+  // the host sizes the number of 8-bit passes from an upper bound (total particles); the real
+  // maximum (a per-element count) usually needs one or two passes: later passes see it and copy
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long y = __shfl_down(key, o);
+    key = y > key ? y : key;
+  }
+  if ((threadIdx.x & 63) == 0 && key) atomicMax(&tot->max_key, no_skip ? ~0ull : key);
 }
 __global__ void k_rs_hist(int n, const unsigned long long* __restrict__ keys, int shift, int nblk,
-                          int* __restrict__ hist) {
+                          int* __restrict__ hist, const Totals* tot) {
+  if ((tot->max_key >> shift) == 0) return;  // every digit of this pass is 0: identity pass
   __shared__ int h[256];
   h[threadIdx.x] = 0;
   __syncthreads();
@@ -227,7 +239,18 @@ __global__ void k_rs_hist(int n, const unsigned long long* __restrict__ keys, in
 __global__ void k_rs_scatter(int n, const unsigned long long* __restrict__ keys,
                              const int* __restrict__ vals, int shift, int nblk,
                              const int* __restrict__ hist_scanned,
-                             unsigned long long* __restrict__ keys_out, int* __restrict__ vals_out) {
+                             unsigned long long* __restrict__ keys_out, int* __restrict__ vals_out,
+                             const Totals* tot) {
+  if ((tot->max_key >> shift) == 0) {  // identity pass of the stable sort: plain copy
+    for (int j = threadIdx.x; j < RS_TILE; j += 256) {
+      const int i = blockIdx.x * RS_TILE + j;
+      if (i < n) {
+        keys_out[i] = keys[i];
+        vals_out[i] = vals[i];
+      }
+    }
+    return;
+  }
   __shared__ int base_d[256];     // running count of each digit inside this tile
   __shared__ int wave_cnt[4][256];
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
@@ -269,7 +292,9 @@ __global__ void k_rs_scatter(int n, const unsigned long long* __restrict__ keys,
 }
 
 // ---- single-block exclusive scan (int); total written to *total if non-null
-__global__ void k_scan_excl(int n, const int* __restrict__ in, int* __restrict__ out, int* total) {
+__global__ void k_scan_excl(int n, const int* __restrict__ in, int* __restrict__ out, int* total,
+                            const Totals* skip_tot = nullptr, int skip_shift = 0) {
+  if (skip_tot && (skip_tot->max_key >> skip_shift) == 0) return;  // digit table of an identity pass
   __shared__ int wsum[16];
   __shared__ int carry_s;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -310,7 +335,9 @@ __global__ void k_scan_excl(int n, const int* __restrict__ in, int* __restrict__
 // elements): per-block local scan + block totals, single-block scan of the totals, offset add.
 // The single-block kernel above needs ~2.4 us per 4096 items (71 us for 125 k entries).
 __global__ void __launch_bounds__(1024) k_scan_local(int n, const int* __restrict__ in, int* __restrict__ out,
-                                                     int* __restrict__ block_tot) {
+                                                     int* __restrict__ block_tot, const Totals* skip_tot,
+                                                     int skip_shift) {
+  if (skip_tot && (skip_tot->max_key >> skip_shift) == 0) return;
   __shared__ int wsum[16];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   constexpr int ITEMS = 4;
@@ -339,22 +366,25 @@ __global__ void __launch_bounds__(1024) k_scan_local(int n, const int* __restric
   }
   if (t == 1023) block_tot[blockIdx.x] = run;
 }
-__global__ void k_scan_add(int n, int* __restrict__ out, const int* __restrict__ block_off) {
+__global__ void k_scan_add(int n, int* __restrict__ out, const int* __restrict__ block_off,
+                           const Totals* skip_tot, int skip_shift) {
+  if (skip_tot && (skip_tot->max_key >> skip_shift) == 0) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] += block_off[i / 4096];
 }
 // exclusive scan of n ints on the stream; *total (device, may be null) receives the sum
-int scan_excl(pp::DevBuf& scratch, int n, const int* in, int* out, int* total, hipStream_t st) {
+int scan_excl(pp::DevBuf& scratch, int n, const int* in, int* out, int* total, hipStream_t st,
+              const Totals* skip_tot = nullptr, int skip_shift = 0) {
   if (n <= 16384) {
-    k_scan_excl<<<1, 1024, 0, st>>>(n, in, out, total);
+    k_scan_excl<<<1, 1024, 0, st>>>(n, in, out, total, skip_tot, skip_shift);
     return PP_OK;
   }
   const int nb = (n + 4095) / 4096;
   PP_HIP_CHECK(scratch.reserve(sizeof(int) * 2 * (size_t)nb));
   int* bt = (int*)scratch.p;
-  k_scan_local<<<nb, 1024, 0, st>>>(n, in, out, bt);
-  k_scan_excl<<<1, 1024, 0, st>>>(nb, bt, bt + nb, total);
-  k_scan_add<<<grid_for(n), kBlock, 0, st>>>(n, out, bt + nb);
+  k_scan_local<<<nb, 1024, 0, st>>>(n, in, out, bt, skip_tot, skip_shift);
+  k_scan_excl<<<1, 1024, 0, st>>>(nb, bt, bt + nb, total, skip_tot, skip_shift);
+  k_scan_add<<<grid_for(n), kBlock, 0, st>>>(n, out, bt + nb, skip_tot, skip_shift);
   return PP_OK;
 }
 
@@ -1112,7 +1142,8 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
     PP_HIP_CHECK(ps->s_hist.reserve(sizeof(int) * 256 * (size_t)nblk * 2));
     k_make_keys<<<grid_for(ne), kBlock, 0, st>>>(ne, ppe, sg, n_sigma, L.base,
                                                  ps->s_keys.as<unsigned long long>(),
-                                                 ps->s_vals.as<int>());
+                                                 ps->s_vals.as<int>(), tot,
+                                                 getenv("PP_NO_RS_SKIP") != nullptr);
     unsigned long long maxkey = (unsigned long long)(n_sigma > 0 ? n_sigma : 1) * L.base;
     int bits = 0;
     while (bits < 64 && (maxkey >> bits)) ++bits;
@@ -1122,9 +1153,9 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
     int* hist = ps->s_hist.as<int>();
     int* hist_sc = hist + 256 * nblk;
     for (int shift = 0; shift < bits; shift += 8) {
-      k_rs_hist<<<nblk, 256, 0, st>>>(ne, ka, shift, nblk, hist);
-      if (scan_excl(ps->s_scan2, 256 * nblk, hist, hist_sc, nullptr, st)) return PP_EHIP;
-      k_rs_scatter<<<nblk, 256, 0, st>>>(ne, ka, va, shift, nblk, hist_sc, kb, vb);
+      k_rs_hist<<<nblk, 256, 0, st>>>(ne, ka, shift, nblk, hist, tot);
+      if (scan_excl(ps->s_scan2, 256 * nblk, hist, hist_sc, nullptr, st, tot, shift)) return PP_EHIP;
+      k_rs_scatter<<<nblk, 256, 0, st>>>(ne, ka, va, shift, nblk, hist_sc, kb, vb, tot);
       std::swap(ka, kb);
       std::swap(va, vb);
     }
