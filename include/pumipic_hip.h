@@ -197,6 +197,14 @@ int pp_search_mesh(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_pi
 int pp_search_mesh_legacy3d(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_pid,
                             int* elem_ids_dev, int elem_ids_seeded, double* xpoints_dev,
                             int* xface_dev, int looplimit, int* found);
+/* search_mesh_3d src/pumipic_adjacency.hpp:314-555 (tol 1e-20, neighbours in ask_dual order, wall
+ * hits into xpoints/xface; both are written only for particles that hit an exposed face).
+ * *found = 1 all found, 0 loop limit exceeded, -2 a particle was outside its parent element
+ * (the reference aborts there, hpp:373-379).  The fallback of hpp:510 is not replicated (it
+ * indexes the dual value array by a face id): the neighbour across that face is taken. */
+int pp_search_mesh_3d(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_pid,
+                      int* elem_ids_dev, int elem_ids_seeded, double* xpoints_dev, int* xface_dev,
+                      int looplimit, int* found);
 /* Fused hot path: elliptical (dim 2) / toroidal (dim 3) push + BCC walk: particle state is read
  * once and x_tgt, phi, elem_ids written once.  Result-identical to pp_elliptical_push +
  * pp_search_mesh_2d (dim 2) and to pp_toroidal_push + pp_search_mesh in BCC mode (dim 3:
@@ -246,6 +254,17 @@ int pp_interp3d_field(const pp_ps* ps, int m_x, int nx, int ny, int nz, const do
                       double* out_dev);
 /* The same helpers (plus the _wgrid forms) are device-inline in pumi-pic_amd/include/pumipic_gather.hpp
  * for use inside user lambdas. */
+
+/* ------------------------------------------------------------------ wall geometry */
+/* closest_point_on_triangle (wnormal == 0) / closest_point_on_triangle_wnormal
+ * src/pumipic_adjacency.hpp:824-1009 over n (triangle, point) pairs: tris_dev holds 9 doubles per
+ * triangle at stride tri_stride doubles (0 = the same triangle for every point), pts_dev / out_dev
+ * 3 doubles per point.  region_dev (may be NULL) receives the TriRegion; the plain form leaves it
+ * untouched in its EDGEAB branch, as the reference does (hpp:951-958).  Device-inline forms for
+ * user lambdas: pumi-pic_amd/include/pumipic_wall.hpp. */
+int pp_closest_point_on_triangle(int n, const double* tris_dev, int tri_stride,
+                                 const double* pts_dev, int wnormal, double* out_dev,
+                                 int* region_dev);
 
 /* ------------------------------------------------------------------ migration glue */
 /* setUnsafeProcs src/pumipic_ptcl_ops.hpp:32-52 */

@@ -20,6 +20,16 @@
 #define PPO_H
 #ifdef __cplusplus
 extern "C" {
+/* wall geometry: src/pumipic_adjacency.hpp:812-1009.  abc = 3 vertices x 3 coordinates; *reg is
+ * a TriRegion (0 VTXA,1 VTXB,2 VTXC,3 EDGEAB,4 EDGEAC,5 EDGEBC,6 TRIFACE) and is left untouched in
+ * the EDGEAB branch of the non-wnormal form, as in the reference (hpp:951-958). */
+void ppo_closest_point_on_triangle(const double abc[9], const double p[3], int wnormal, double q[3],
+                                   int* reg);
+
+#ifdef __cplusplus
+}
+#endif
+
 #endif
 
 /* ---------------------------------------------------------------- mesh */
@@ -153,6 +163,11 @@ int ppo_search_mesh(const ppo_mesh* mesh, ppo_ps* ps, int m_x, int m_xtgt, int m
 int ppo_search_mesh_legacy3d(const ppo_mesh* mesh, ppo_ps* ps, int m_x, int m_xtgt, int m_pid,
                              int* elem_ids, int elem_ids_seeded, double* xpoints, int* xface,
                              int looplimit, int* loops_out);
+/* src/pumipic_adjacency.hpp:314-555 (search_mesh_3d: tol 1e-20, dual-ordered neighbours, wall
+ * hits recorded in xpoints/xface).  Returns found, -2 when checkParent aborts. */
+int ppo_search_mesh_3d(const ppo_mesh* mesh, ppo_ps* ps, int m_x, int m_xtgt, int m_pid,
+                       int* elem_ids, int elem_ids_seeded, double* xpoints, int* xface,
+                       int looplimit, int* loops_out);
 /* src/pumipic_adjacency.hpp:1160-1252 */
 int ppo_search_mesh_2d_pt(const ppo_mesh* mesh, const double orig[2], const double dest[2],
                           int pid, int initial_elem, int* loops, int looplimit);
@@ -183,9 +198,6 @@ double ppo_interpolate_tet_vtx(const ppo_mesh* mesh, const double* field, int el
 void ppo_set_unsafe_procs(const ppo_ps* ps, const int* elems, const unsigned char* safe,
                           const int* owners, int comm_rank, int* new_elems, int* new_procs);
 
-#ifdef __cplusplus
-}
-#endif
 /* gather side: src/pumipic_adjacency.hpp:772-809, src/pumipic_utils.hpp:186-241,375-454
  * (out arrays are [component][capacity]) */
 void ppo_gather_tet_vtx(const ppo_mesh* mesh, const ppo_ps* ps, int m_x, const int* elem_ids,
@@ -196,5 +208,15 @@ void ppo_interp2d_vector(const ppo_ps* ps, int m_x, const double* data3, double 
                          double dx, double dz, int nx, int nz, int cyl, double* out);
 void ppo_interp3d_field(const ppo_ps* ps, int m_x, int nx, int ny, int nz, const double* gridx,
                         const double* gridy, const double* gridz, const double* data, double* out);
+
+/* wall geometry: src/pumipic_adjacency.hpp:812-1009.  abc = 3 vertices x 3 coordinates; *reg is
+ * a TriRegion (0 VTXA,1 VTXB,2 VTXC,3 EDGEAB,4 EDGEAC,5 EDGEBC,6 TRIFACE) and is left untouched in
+ * the EDGEAB branch of the non-wnormal form, as in the reference (hpp:951-958). */
+void ppo_closest_point_on_triangle(const double abc[9], const double p[3], int wnormal, double q[3],
+                                   int* reg);
+
+#ifdef __cplusplus
+}
+#endif
 
 #endif

@@ -104,6 +104,8 @@ def lib():
         L.ppo_search_mesh_legacy3d.argtypes = [C.POINTER(_MeshS), C.POINTER(_PsS), C.c_int, C.c_int,
                                                C.c_int, c_int_p, C.c_int, c_double_p, c_int_p,
                                                C.c_int, c_int_p]
+        L.ppo_search_mesh_3d.restype = C.c_int
+        L.ppo_search_mesh_3d.argtypes = L.ppo_search_mesh_legacy3d.argtypes
         L.ppo_search_mesh_2d_pt.restype = C.c_int
         L.ppo_search_mesh_2d_pt.argtypes = [C.POINTER(_MeshS), c_double_p, c_double_p, C.c_int,
                                             C.c_int, c_int_p, C.c_int]
@@ -121,6 +123,7 @@ def lib():
             [C.c_int] * 3 + [c_double_p]
         L.ppo_interp3d_field.argtypes = [C.POINTER(_PsS), C.c_int, C.c_int, C.c_int, C.c_int] + \
             [c_double_p] * 5
+        L.ppo_closest_point_on_triangle.argtypes = [c_double_p, c_double_p, C.c_int, c_double_p, c_int_p]
         L.ppo_interpolate_tet_vtx.restype = C.c_double
         L.ppo_interpolate_tet_vtx.argtypes = [C.POINTER(_MeshS), c_double_p, C.c_int, c_double_p,
                                               C.c_int, C.c_int]
@@ -428,6 +431,21 @@ def search_mesh_legacy3d(mesh, ps, elem_ids=None, looplimit=0, m_x=0, m_xtgt=1, 
                 loops=loops.value)
 
 
+def search_mesh_3d(mesh, ps, elem_ids=None, looplimit=0, m_x=0, m_xtgt=1, m_pid=2):
+    """search_mesh_3d (adjacency.hpp:314-555)."""
+    cap = ps.capacity()
+    seeded = elem_ids is not None
+    if elem_ids is None:
+        elem_ids = np.full(cap, -1, dtype=np.int32)
+    xface = np.full(cap, -1, dtype=np.int32)
+    xpoints = np.zeros(cap * 3, dtype=np.float64)
+    loops = C.c_int()
+    found = lib().ppo_search_mesh_3d(mesh.p, ps.p, m_x, m_xtgt, m_pid, _ip(elem_ids), int(seeded),
+                                     _dp(xpoints), _ip(xface), looplimit, C.byref(loops))
+    return dict(found=found, elem_ids=elem_ids, xface=xface, xpoints=xpoints.reshape(cap, 3),
+                loops=loops.value)
+
+
 def search_mesh_2d_pt(mesh, orig, dest, initial_elem, looplimit=0, pid=0):
     o = np.ascontiguousarray(orig, dtype=np.float64)
     d = np.ascontiguousarray(dest, dtype=np.float64)
@@ -569,3 +587,13 @@ def min_index(a):
 def max_index(a):
     a = np.ascontiguousarray(a, dtype=np.float64)
     return lib().ppo_kat_max_index(_dp(a), len(a))
+
+
+def closest_point_on_triangle(abc, p, wnormal=False, reg0=-1):
+    """closest_point_on_triangle[_wnormal] (adjacency.hpp:824-1009) -> (q[3], region)."""
+    abc = np.ascontiguousarray(abc, dtype=np.float64).reshape(9)
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    q = np.zeros(3)
+    reg = C.c_int(reg0)
+    lib().ppo_closest_point_on_triangle(_dp(abc), _dp(p), int(wnormal), _dp(q), C.byref(reg))
+    return q, reg.value

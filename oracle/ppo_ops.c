@@ -526,3 +526,119 @@ void ppo_interp3d_field(const ppo_ps* ps, int m_x, int nx, int ny, int nz, const
   }
   free_slots(&s);
 }
+
+/* ------------------------------------------------------------------ closest point on a triangle
+ * closest_point_on_triangle_wnormal src/pumipic_adjacency.hpp:824-906 (scalar intermediates are
+ * `float` in the reference and here); closest_point_on_triangle :910-1009 */
+static ppo_v3 v3_of(const double* p) {
+  ppo_v3 r = {{p[0], p[1], p[2]}};
+  return r;
+}
+static void put3(double q[3], ppo_v3 v) {
+  q[0] = v.v[0];
+  q[1] = v.v[1];
+  q[2] = v.v[2];
+}
+static void closest_wnormal(ppo_v3 a, ppo_v3 b, ppo_v3 c, ppo_v3 p, double q[3], int* reg) {
+  const ppo_v3 ab = ppo_sub3(b, a), ac = ppo_sub3(c, a), bc = ppo_sub3(c, b);
+  const float snom = (float)ppo_dot3(ppo_sub3(p, a), ab);
+  const float sdenom = (float)ppo_dot3(ppo_sub3(p, b), ppo_sub3(a, b));
+  const float tnom = (float)ppo_dot3(ppo_sub3(p, a), ac);
+  const float tdenom = (float)ppo_dot3(ppo_sub3(p, c), ppo_sub3(a, c));
+  if (snom <= 0.0 && tnom <= 0.0) {
+    if (reg) *reg = 0;
+    put3(q, a);
+    return;
+  }
+  const float unom = (float)ppo_dot3(ppo_sub3(p, b), bc);
+  const float udenom = (float)ppo_dot3(ppo_sub3(p, c), ppo_sub3(b, c));
+  if (sdenom <= 0.0 && unom <= 0.0) {
+    if (reg) *reg = 1;
+    put3(q, b);
+    return;
+  }
+  if (tdenom <= 0.0 && udenom <= 0.0) {
+    if (reg) *reg = 2;
+    put3(q, c);
+    return;
+  }
+  const ppo_v3 n = ppo_cross3(ppo_sub3(b, a), ppo_sub3(c, a));
+  const float vc = (float)ppo_dot3(n, ppo_cross3(ppo_sub3(a, p), ppo_sub3(b, p)));
+  if (vc <= 0.0 && snom >= 0.0 && sdenom >= 0.0) {
+    put3(q, ppo_add3(a, ppo_scale3(ab, (double)(snom / (snom + sdenom)))));
+    if (reg) *reg = 3;
+    return;
+  }
+  const float va = (float)ppo_dot3(n, ppo_cross3(ppo_sub3(b, p), ppo_sub3(c, p)));
+  if (va <= 0.0 && unom >= 0.0 && udenom >= 0.0) {
+    put3(q, ppo_add3(b, ppo_scale3(bc, (double)(unom / (unom + udenom)))));
+    if (reg) *reg = 5;
+    return;
+  }
+  const float vb = (float)ppo_dot3(n, ppo_cross3(ppo_sub3(c, p), ppo_sub3(a, p)));
+  if (vb <= 0.0 && tnom >= 0.0 && tdenom >= 0.0) {
+    put3(q, ppo_add3(a, ppo_scale3(ac, (double)(tnom / (tnom + tdenom)))));
+    if (reg) *reg = 4;
+    return;
+  }
+  const float u = va / (va + vb + vc);
+  const float v = vb / (va + vb + vc);
+  const float w = (float)(1.0 - u - v);
+  put3(q, ppo_add3(ppo_add3(ppo_scale3(a, (double)u), ppo_scale3(b, (double)v)), ppo_scale3(c, (double)w)));
+  if (reg) *reg = 6;
+}
+static void closest_plain(ppo_v3 pta, ppo_v3 ptb, ppo_v3 ptc, ppo_v3 ptp, double q[3], int* reg) {
+  const ppo_v3 vab = ppo_sub3(ptb, pta), vac = ppo_sub3(ptc, pta), vap = ppo_sub3(ptp, pta);
+  const double d1 = ppo_dot3(vab, vap), d2 = ppo_dot3(vac, vap);
+  if (d1 <= 0 && d2 <= 0) {
+    put3(q, pta);
+    if (reg) *reg = 0;
+    return;
+  }
+  const ppo_v3 vbp = ppo_sub3(ptp, ptb);
+  const double d3 = ppo_dot3(vab, vbp), d4 = ppo_dot3(vac, vbp);
+  if (d3 >= 0 && d4 <= d3) {
+    put3(q, ptb);
+    if (reg) *reg = 1;
+    return;
+  }
+  const double vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) {
+    const double v = d1 / (d1 - d3);
+    put3(q, ppo_add3(ppo_scale3(vab, v), pta));
+    return; /* region not reported in this branch (hpp:951-958) */
+  }
+  const ppo_v3 vcp = ppo_sub3(ptp, ptc);
+  const double d5 = ppo_dot3(vab, vcp), d6 = ppo_dot3(vac, vcp);
+  if (d6 >= 0 && d5 <= d6) {
+    put3(q, ptc);
+    if (reg) *reg = 2;
+    return;
+  }
+  const double vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) {
+    const double w = d2 / (d2 - d6);
+    put3(q, ppo_add3(ppo_scale3(vac, w), pta));
+    if (reg) *reg = 4;
+    return;
+  }
+  const double va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+    const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    put3(q, ppo_add3(ptb, ppo_scale3(ppo_sub3(ptc, ptb), w)));
+    if (reg) *reg = 5;
+    return;
+  }
+  const double inv = 1.0 / (va + vb + vc);
+  const double v = vb * inv, w = vc * inv;
+  put3(q, ppo_add3(ppo_add3(pta, ppo_scale3(vab, v)), ppo_scale3(vac, w)));
+  if (reg) *reg = 6;
+}
+void ppo_closest_point_on_triangle(const double abc[9], const double p[3], int wnormal, double q[3],
+                                   int* reg) {
+  const ppo_v3 a = v3_of(abc), b = v3_of(abc + 3), c = v3_of(abc + 6), pp = v3_of(p);
+  if (wnormal)
+    closest_wnormal(a, b, c, pp, q, reg);
+  else
+    closest_plain(a, b, c, pp, q, reg);
+}

@@ -7,6 +7,7 @@
  *   search_mesh_2d                src/pumipic_adjacency.hpp:1011-1158
  *   search_mesh_2d_pt             src/pumipic_adjacency.hpp:1160-1252
  *   search_mesh (2-D/3-D, new)    src/pumipic_adjacency.tpp:72-145,231-416,460-654
+ *   search_mesh_3d                src/pumipic_adjacency.hpp:314-555
  *   search_mesh (3-D, legacy)     src/pumipic_adjacency.hpp:558-768
  */
 #include <stdlib.h>
@@ -409,6 +410,157 @@ done:
   free(slot_mask);
   free(ptcl_done);
   free(lastExit);
+  return found;
+}
+
+/* ------------------------------------------------------------------ search_mesh_3d
+ * src/pumipic_adjacency.hpp:314-555, kernel by kernel (fill, checkParent, then per iteration
+ * checkCurrentElm, findIntersection, processUndetected, copy_elem_ids, min reduction).
+ * tol = 1e-20 for the containment and the intersection tests (hpp:330).
+ * processUndetected indexes the dual VALUE array by a face id (hpp:510); not
+ * replicated -- the neighbour across the max-projection face is taken.
+ * Returns found, or -2 when checkParent would abort (hpp:373-379). */
+static int point_within_tet(const ppo_mesh* mesh, ppo_v3 pos, int elem, double tol) {
+  int verts[4];
+  ppo_v3 M[4];
+  double bcc[4];
+  gather_tet(mesh, elem, verts, M);
+  ppo_barycentric_coords_tet(M, pos, bcc, tol); /* isPointWithinElemTet hpp:300-305 */
+  return ppo_all_positive(bcc, 4, tol);
+}
+int ppo_search_mesh_3d(const ppo_mesh* mesh, ppo_ps* ps, int m_x, int m_xtgt, int m_pid,
+                       int* elem_ids, int elem_ids_seeded, double* xpoints_d, int* xface_d,
+                       int looplimit, int* loops_out) {
+  (void)m_pid;
+  const double tol = 1.0e-20;
+  const int cap = ps->capacity;
+  int* slot_elem = (int*)xcalloc((size_t)cap, sizeof(int));
+  unsigned char* slot_mask = (unsigned char*)xcalloc((size_t)cap, 1);
+  ppo_ps_slot_info(ps, slot_elem, slot_mask);
+  int* ptcl_done = (int*)xcalloc((size_t)cap, sizeof(int));
+  int* elem_ids_next = (int*)xcalloc((size_t)cap, sizeof(int));
+  for (int i = 0; i < cap; ++i) {
+    ptcl_done[i] = 1; /* hpp:348 */
+    elem_ids_next[i] = -1;
+  }
+  int loops = 0, found = 0, aborted = 0;
+  /* fill hpp:358-369 (slots of rows outside the structure behave as masked-out slots) */
+  for (int pid = 0; pid < cap; ++pid) {
+    if (slot_elem[pid] >= 0 && slot_mask[pid]) {
+      if (!elem_ids_seeded) elem_ids[pid] = slot_elem[pid];
+      ptcl_done[pid] = (elem_ids[pid] == -1) * 2;
+    } else {
+      elem_ids[pid] = -1;
+      ptcl_done[pid] = 2;
+    }
+  }
+  /* checkParent hpp:371-382: the ROW element e, not elem_ids[pid] */
+  for (int pid = 0; pid < cap; ++pid)
+    if (slot_elem[pid] >= 0 && slot_mask[pid] && ptcl_done[pid] != 2)
+      if (!point_within_tet(mesh, vec3(ps, m_x, pid), slot_elem[pid], tol)) aborted = 1;
+  while (!found) {
+    /* checkCurrentElm hpp:397-412 */
+    for (int pid = 0; pid < cap; ++pid) {
+      if (!(slot_elem[pid] >= 0 && slot_mask[pid] && !ptcl_done[pid])) continue;
+      const int searchElm = elem_ids[pid];
+      const int inParent = point_within_tet(mesh, vec3(ps, m_xtgt, pid), searchElm, tol);
+      ptcl_done[pid] = inParent ? 2 : 0;
+      elem_ids_next[pid] = searchElm;
+    }
+    /* findIntersection hpp:414-473 */
+    for (int pid = 0; pid < cap; ++pid) {
+      if (!(slot_elem[pid] >= 0 && slot_mask[pid] && ptcl_done[pid] < 2)) continue;
+      const int searchElm = elem_ids[pid];
+      int tetv2v[4];
+      ppo_v3 M[4];
+      gather_tet(mesh, searchElm, tetv2v, M);
+      const ppo_v3 dest = vec3(ps, m_xtgt, pid), orig = vec3(ps, m_x, pid);
+      int dual_elem_id = mesh->dual_off[searchElm];
+      int adj_id = -1, ind_exp = -1;
+      double projd[4] = {0, 0, 0, 0};
+      ppo_v3 xpts = {{0, 0, 0}};
+      int face_ids[4];
+      for (int fi = 0; fi < 4; ++fi) {
+        const int face_id = mesh->elem2sides[(size_t)searchElm * 4 + fi];
+        face_ids[fi] = face_id;
+        ppo_v3 xpoint = {{0, 0, 0}};
+        int fv2v[3];
+        ppo_v3 face[3];
+        for (int q = 0; q < 3; ++q) {
+          fv2v[q] = mesh->side2verts[(size_t)face_id * 3 + q];
+          for (int c = 0; c < 3; ++c) face[q].v[c] = mesh->coords[(size_t)fv2v[q] * 3 + c];
+        }
+        const int flip = ppo_is_face_flipped(fi, fv2v, tetv2v);
+        const int det = ppo_line_triangle_intx_simple(face, orig, dest, &xpoint, &projd[fi], flip, tol);
+        const int exposed = mesh->side_exposed[face_id];
+        if (det && exposed) {
+          ind_exp = fi;
+          xpts = xpoint;
+        }
+        if (det && !exposed) adj_id = dual_elem_id;
+        if (!exposed) ++dual_elem_id;
+      }
+      if (ind_exp >= 0) { /* wall collision */
+        for (int i = 0; i < 3; ++i) xpoints_d[(size_t)pid * 3 + i] = xpts.v[i];
+        xface_d[pid] = face_ids[ind_exp];
+        elem_ids_next[pid] = -1;
+        ptcl_done[pid] = 2;
+      }
+      if (adj_id >= 0) { /* interior */
+        elem_ids_next[pid] = mesh->dual_elems[adj_id];
+        ptcl_done[pid] = 1;
+      }
+    }
+    /* processUndetected hpp:475-519 */
+    for (int pid = 0; pid < cap; ++pid) {
+      const int done = ptcl_done[pid];
+      ptcl_done[pid] = (done < 2) ? 0 : 2;
+      if (!(slot_elem[pid] >= 0 && slot_mask[pid] && done < 1)) continue;
+      const int searchElm = elem_ids[pid];
+      int tetv2v[4];
+      ppo_v3 M[4];
+      gather_tet(mesh, searchElm, tetv2v, M);
+      const ppo_v3 dest = vec3(ps, m_xtgt, pid), orig = vec3(ps, m_x, pid);
+      double projd[4] = {-1, -1, -1, -1};
+      double xpoints[12] = {0};
+      int face_ids[4];
+      for (int fi = 0; fi < 4; ++fi) {
+        const int face_id = mesh->elem2sides[(size_t)searchElm * 4 + fi];
+        face_ids[fi] = face_id;
+        ppo_v3 xpoint = {{0, 0, 0}};
+        int fv2v[3];
+        ppo_v3 face[3];
+        for (int q = 0; q < 3; ++q) {
+          fv2v[q] = mesh->side2verts[(size_t)face_id * 3 + q];
+          for (int c = 0; c < 3; ++c) face[q].v[c] = mesh->coords[(size_t)fv2v[q] * 3 + c];
+        }
+        const int flip = ppo_is_face_flipped(fi, fv2v, tetv2v);
+        ppo_line_triangle_intx_simple(face, orig, dest, &xpoint, &projd[fi], flip, tol);
+        for (int i = 0; i < 3; ++i) xpoints[fi * 3 + i] = xpoint.v[i];
+      }
+      const int max_ind = ppo_max_index(projd, 4);
+      const int face_id = face_ids[max_ind];
+      if (mesh->side_exposed[face_id]) {
+        elem_ids_next[pid] = -1;
+        for (int i = 0; i < 3; ++i) xpoints_d[(size_t)pid * 3 + i] = xpoints[max_ind * 3 + i];
+        xface_d[pid] = face_id;
+        ptcl_done[pid] = 2;
+      } else {
+        elem_ids_next[pid] = other_elem(mesh, face_id, searchElm); /* Q3: see header */
+      }
+    }
+    found = 1;
+    for (int i = 0; i < cap; ++i) elem_ids[i] = elem_ids_next[i]; /* copy_elem_ids hpp:521-524 */
+    if (min_done(ptcl_done, cap) == 0) found = 0;
+    ++loops;
+    if (looplimit && loops >= looplimit) break; /* hpp:531-552 */
+  }
+  if (loops_out) *loops_out = loops;
+  free(slot_elem);
+  free(slot_mask);
+  free(ptcl_done);
+  free(elem_ids_next);
+  if (aborted) return -2;
   return found;
 }
 

@@ -97,6 +97,8 @@ SYMBOLS = {
     "pp_search_mesh_2d": (_I, [_V, _V, _I, _I, _I, _V, _I, c_int_p]),
     "pp_search_mesh": (_I, [_V, _V, _I, _I, _I, _V, _I, _I, _V, _V, _I, c_int_p, c_int_p]),
     "pp_search_mesh_legacy3d": (_I, [_V, _V, _I, _I, _I, _V, _I, _V, _V, _I, c_int_p]),
+    "pp_closest_point_on_triangle": (_I, [_I, _V, _I, _V, _I, _V, _V]),
+    "pp_search_mesh_3d": (_I, [_V, _V, _I, _I, _I, _V, _I, _V, _V, _I, c_int_p]),
     "pp_push_search": (_I, [_V, _V, _I, _I, _I, _I, _D, _D, _D, _D, _V, _I, _I, c_int_p]),
     "pp_create_gyro_ring_mappings": (_I, [_V, _D, _I, _I, _D, _V, _V]),
     "pp_gyro_scatter": (_I, [_V, _V, _V, _D, _I, _I, _V]),
@@ -479,6 +481,20 @@ def search_mesh_legacy3d(mesh, ps, elem_ids=None, looplimit=0, m_x=0, m_xtgt=1, 
     return dict(found=found.value, elem_ids=elem_ids, xface=xface, xpoints=xpoints)
 
 
+def search_mesh_3d(mesh, ps, elem_ids=None, looplimit=0, m_x=0, m_xtgt=1, m_pid=2):
+    """search_mesh_3d (adjacency.hpp:314-555)."""
+    cap = max(ps.capacity(), 1)
+    seeded = elem_ids is not None
+    if elem_ids is None:
+        elem_ids = DevArray(cap, np.int32)
+    xface = DevArray.from_host(np.full(cap, -1, dtype=np.int32))
+    xpoints = DevArray.from_host(np.zeros(cap * 3))
+    found = C.c_int()
+    check(lib().pp_search_mesh_3d(mesh.p, ps.p, m_x, m_xtgt, m_pid, elem_ids.ptr, int(seeded),
+                                  xpoints.ptr, xface.ptr, looplimit, C.byref(found)))
+    return dict(found=found.value, elem_ids=elem_ids, xface=xface, xpoints=xpoints)
+
+
 def push_search(mesh, ps, h, k, d, deg, elem_ids, seeded=True, looplimit=0, want_found=True,
                 m_x=0, m_xtgt=1, m_b=3, m_phi=4):
     found = C.c_int(1)
@@ -596,3 +612,17 @@ def migrate_pack_records(ps, new_element_dev, new_process_dev, rank, nranks, cou
 def rebuild_records(ps, new_element_dev, n_recv, recv_ptr, gid2lid_dev=None, ngids=0):
     check(lib().pp_ps_rebuild_records(ps.p, new_element_dev.ptr, n_recv, recv_ptr,
                                       gid2lid_dev.ptr if gid2lid_dev is not None else None, ngids))
+
+
+def closest_point_on_triangle(tris, pts, wnormal=False, reg0=-1):
+    """closest_point_on_triangle[_wnormal] (adjacency.hpp:824-1009) for n points; tris is (9,) for
+    one shared triangle or (n, 9).  Returns (q[n,3], region[n])."""
+    pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+    n = len(pts)
+    tris = np.ascontiguousarray(tris, dtype=np.float64)
+    stride = 0 if tris.size == 9 else 9
+    d_t, d_p = DevArray.from_host(tris.ravel()), DevArray.from_host(pts.ravel())
+    d_q = DevArray(max(3 * n, 1), np.float64)
+    d_r = DevArray.from_host(np.full(max(n, 1), reg0, dtype=np.int32))
+    check(lib().pp_closest_point_on_triangle(n, d_t.ptr, stride, d_p.ptr, int(wnormal), d_q.ptr, d_r.ptr))
+    return d_q.to_host()[:3 * n].reshape(n, 3), d_r.to_host()[:n]

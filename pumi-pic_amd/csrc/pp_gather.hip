@@ -3,6 +3,7 @@
 //   interpolate2dField / interp2dVector / interpolate3d_field       src/pumipic_utils.hpp:186-454
 // The per-particle arithmetic lives in include/pumipic_gather.hpp (shared with user lambdas).
 #include "../include/pumipic_gather.hpp"
+#include "../include/pumipic_wall.hpp"
 #include "pp_internal.hpp"
 
 namespace {
@@ -83,6 +84,24 @@ int xmember(const pp_ps* ps, int m_x, const char* what, const double** x) {
 }
 }  // namespace
 
+// closest_point_on_triangle[_wnormal] over n (triangle, point) pairs; tri_stride 0 = one triangle
+__global__ void k_closest_point(int n, const double* __restrict__ tris, int tri_stride,
+                                const double* __restrict__ pts, int wnormal,
+                                double* __restrict__ out, int* __restrict__ region) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double abc[9], p[3], q[3];
+  for (int k = 0; k < 9; ++k) abc[k] = tris[(size_t)i * tri_stride + k];
+  for (int k = 0; k < 3; ++k) p[k] = pts[(size_t)i * 3 + k];
+  int reg = region ? region[i] : -1;  // EDGEAB of the plain form leaves the caller's value
+  if (wnormal)
+    pumipic::closest_point_on_triangle_wnormal(abc, p, q, &reg);
+  else
+    pumipic::closest_point_on_triangle(abc, p, q, &reg);
+  for (int k = 0; k < 3; ++k) out[(size_t)i * 3 + k] = q[k];
+  if (region) region[i] = reg;
+}
+
 extern "C" {
 
 int pp_gather_tet_vtx(const pp_mesh* mesh, const pp_ps* ps, int m_x, const int* elem_ids_dev,
@@ -155,6 +174,19 @@ int pp_interp3d_field(const pp_ps* ps, int m_x, int nx, int ny, int nz, const do
   k_interp3d_field<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
       ps->capacity, ps->d_mask.as<unsigned char>(), x, ps->stride, nx, ny, nz, gridx_dev, gridy_dev,
       gridz_dev, data_dev, out_dev);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+int pp_closest_point_on_triangle(int n, const double* tris_dev, int tri_stride,
+                                 const double* pts_dev, int wnormal, double* out_dev,
+                                 int* region_dev) {
+  PP_REQUIRE(n >= 0 && tris_dev && pts_dev && out_dev, "pp_closest_point_on_triangle: null argument");
+  PP_REQUIRE(tri_stride == 0 || tri_stride >= 9,
+             "pp_closest_point_on_triangle: tri_stride is 0 (one triangle) or >= 9 doubles");
+  if (n == 0) return PP_OK;
+  k_closest_point<<<grid_for(n), kBlock, 0, pp::stream()>>>(n, tris_dev, tri_stride, pts_dev, wnormal,
+                                                           out_dev, region_dev);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

@@ -5,6 +5,7 @@
 // -ffp-contract=off):
 //   barycentric_tri / barycentric_tet        src/pumipic_adjacency.tpp:23-69
 //   find_barycentric_tet                     src/pumipic_adjacency.hpp:97-133
+//   barycentric_coords_tet                   src/pumipic_adjacency.hpp:136-159
 //   ray_intersects_triangle / line_edge_2d   src/pumipic_adjacency.tpp:152-218
 //   line_triangle_intx_simple                src/pumipic_adjacency.hpp:163-183,230-273
 //   all_positive / min3 / min_index / max_index  src/pumipic_utils.hpp:78-92,125-149
@@ -154,6 +155,20 @@ PPD bool find_barycentric_tet(const V3 M[4], V3 pos, double bcc[4]) {
   else
     return false;
   for (int i = 0; i < 4; ++i) bcc[i] = inv_vol * vals[i];
+  return true;
+}
+
+// adjacency.hpp:136-159: vals scaled by 1/6 first, then 1/vol * vals (vol from the element basis)
+PPD bool barycentric_coords_tet(const V3 M[4], V3 pos, double bcc[4], double tol) {
+  double vals[4];
+  for (int f = 0; f < 4; ++f) {
+    const V3 a = M[tet_face_vert(f, 0)], b = M[tet_face_vert(f, 1)], c = M[tet_face_vert(f, 2)];
+    vals[f] = 1.0 / 6.0 * dot(sub(pos, a), cross(sub(c, a), sub(b, a)));
+    bcc[f] = 0;
+  }
+  const double vol = tet_volume(M);
+  if (vol < tol) return false;
+  for (int f = 0; f < 4; ++f) bcc[f] = 1.0 / vol * vals[f];
   return true;
 }
 

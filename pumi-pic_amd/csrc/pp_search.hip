@@ -434,6 +434,110 @@ __global__ void k_search_legacy3d(int capacity, const unsigned char* __restrict_
   elem_ids[pid] = result;
 }
 
+// ------------------------------------------------------------------ search_mesh_3d
+// src/pumipic_adjacency.hpp:314-555.  The reference runs checkCurrentElm / findIntersection /
+// processUndetected as three launches per walk iteration; a particle's walk depends on nothing
+// but its own state, so one thread carries it to the end.  tol = 1e-20 (hpp:330); neighbours in
+// ask_dual order; SURVEY Q3 (dual_elems[face_id], hpp:510) not replicated.
+__device__ __forceinline__ bool point_within_tet(const MeshArrays& m, V3 pos, int elem, double tol) {
+  V3 M[4];
+  for (int i = 0; i < 4; ++i) {
+    const int v = m.elem2verts[(size_t)elem * 4 + i];
+    M[i] = {m.coords[(size_t)v * 3], m.coords[(size_t)v * 3 + 1], m.coords[(size_t)v * 3 + 2]};
+  }
+  double bcc[4];
+  barycentric_coords_tet(M, pos, bcc, tol);  // isPointWithinElemTet hpp:300-305
+  return all_positive4(bcc, tol);
+}
+__global__ void k_search_mesh3d(int capacity, const unsigned char* __restrict__ mask,
+                                const int* __restrict__ slot_elem, MeshArrays m,
+                                const double* __restrict__ x, const double* __restrict__ xt,
+                                long long stride, int* __restrict__ elem_ids, int seeded,
+                                double* __restrict__ xpoints_d, int* __restrict__ xface_d,
+                                int looplimit, Counters* cnt) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity) return;
+  const int e = slot_elem[pid];
+  if (e < 0 || !mask[pid]) {  // fill hpp:365-368
+    elem_ids[pid] = -1;
+    return;
+  }
+  const double tol = 1.0e-20;
+  int elm = seeded ? elem_ids[pid] : e;
+  if (elm == -1) return;  // ptcl_done = 2 from the start; elem_ids_next stays -1
+  const V3 orig{x[pid], x[stride + pid], x[2 * stride + pid]};
+  const V3 dest{xt[pid], xt[stride + pid], xt[2 * stride + pid]};
+  if (!point_within_tet(m, orig, e, tol)) atomicAdd(&cnt->aborted, 1);  // checkParent hpp:371-382
+  const int cap = looplimit ? looplimit : kHardLoopCap;
+  int loops = 0;
+  while (true) {
+    int next = elm;
+    bool finished = point_within_tet(m, dest, elm, tol);  // checkCurrentElm
+    if (!finished) {                                      // findIntersection
+      int tetv2v[4];
+      for (int i = 0; i < 4; ++i) tetv2v[i] = m.elem2verts[(size_t)elm * 4 + i];
+      int dual_elem_id = m.dual_off[elm];
+      int adj_id = -1, ind_exp = -1;
+      double projd[4] = {-1, -1, -1, -1};  // processUndetected's initial values (hpp:484)
+      double xps[12];
+      int face_ids[4];
+      for (int fi = 0; fi < 4; ++fi) {
+        const int face_id = m.elem2sides[(size_t)elm * 4 + fi];
+        face_ids[fi] = face_id;
+        int fv2v[3];
+        V3 face[3];
+        for (int q = 0; q < 3; ++q) {
+          fv2v[q] = m.side2verts[(size_t)face_id * 3 + q];
+          face[q] = {m.coords[(size_t)fv2v[q] * 3], m.coords[(size_t)fv2v[q] * 3 + 1],
+                     m.coords[(size_t)fv2v[q] * 3 + 2]};
+        }
+        const bool flip = is_face_flipped(fi, fv2v, tetv2v);
+        V3 xpoint;
+        const bool det = line_triangle_intx_simple(face, orig, dest, xpoint, projd[fi], flip, tol);
+        xps[fi * 3] = xpoint.x;
+        xps[fi * 3 + 1] = xpoint.y;
+        xps[fi * 3 + 2] = xpoint.z;
+        const bool exposed = m.side_exposed[face_id];
+        if (det && exposed) ind_exp = fi;  // no break: the last detected face wins (hpp:437-445)
+        if (det && !exposed) adj_id = dual_elem_id;
+        if (!exposed) ++dual_elem_id;
+      }
+      int done = 0;
+      if (ind_exp >= 0) {  // wall collision
+        for (int i = 0; i < 3; ++i) xpoints_d[(size_t)pid * 3 + i] = xps[ind_exp * 3 + i];
+        xface_d[pid] = face_ids[ind_exp];
+        next = -1;
+        done = 2;
+      }
+      if (adj_id >= 0) {  // interior (overrides a wall hit of the same iteration, hpp:462-470)
+        next = m.dual_elems[adj_id];
+        done = 1;
+      }
+      if (done < 1) {  // processUndetected hpp:475-519
+        const int max_ind = max_index4(projd);
+        const int face_id = face_ids[max_ind];
+        if (m.side_exposed[face_id]) {
+          next = -1;
+          for (int i = 0; i < 3; ++i) xpoints_d[(size_t)pid * 3 + i] = xps[max_ind * 3 + i];
+          xface_d[pid] = face_id;
+          done = 2;
+        } else {
+          next = other_elem(m, face_id, elm);
+        }
+      }
+      finished = (done == 2);
+    }
+    elm = next;  // copy_elem_ids hpp:521-524
+    ++loops;
+    if (finished) break;
+    if (loops >= cap) {  // hpp:531-552: the particle keeps its current element id
+      atomicAdd(&cnt->not_found, 1);
+      break;
+    }
+  }
+  elem_ids[pid] = elm;
+}
+
 // ------------------------------------------------------------------ fused push + BCC walk
 // DIM 2: ellipticalPush::push + search_mesh_2d.  DIM 3: toroidal push + search_mesh (BCC) with
 // finishUnmoved and check_initial_parents.  Particle state is read once; x_tgt, phi, elem_ids
@@ -1437,6 +1541,37 @@ int pp_search_mesh_legacy3d(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt,
     *found = h.aborted ? -2 : (h.not_found == 0);
     if (h.aborted)
       fprintf(stderr, "Warning: %d particles not in their element at loops=0 (the reference aborts)\n",
+              h.aborted);
+    if (h.not_found) fprintf(stderr, "ERROR:loop limit %d exceeded\n", looplimit);
+  }
+  return PP_OK;
+}
+
+int pp_search_mesh_3d(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_pid,
+                      int* elem_ids_dev, int elem_ids_seeded, double* xpoints_dev, int* xface_dev,
+                      int looplimit, int* found) {
+  (void)m_pid;
+  PP_REQUIRE(mesh && ps && elem_ids_dev && xpoints_dev && xface_dev,
+             "pp_search_mesh_3d: null argument");
+  PP_REQUIRE(mesh->dim == 3, "pp_search_mesh_3d: needs a tet mesh");
+  PP_REQUIRE(ps->num_elems == mesh->nelems, "pp_search_mesh_3d: structure/mesh mismatch");
+  int rc;
+  if ((rc = member_ok(ps, m_x, 8, 3, "pp_search_mesh_3d x"))) return rc;
+  if ((rc = member_ok(ps, m_xtgt, 8, 3, "pp_search_mesh_3d x_tgt"))) return rc;
+  if (found) *found = 1;
+  if (ps->capacity == 0) return PP_OK;
+  if ((rc = reset_counters())) return rc;
+  k_search_mesh3d<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
+      ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), arrays_of(mesh),
+      PP_MEMBER(ps, m_x, double), PP_MEMBER(ps, m_xtgt, double), ps->stride, elem_ids_dev,
+      elem_ids_seeded, xpoints_dev, xface_dev, looplimit, g_cnt.get());
+  PP_LAUNCH_CHECK();
+  if (found) {
+    Counters h;
+    if ((rc = read_counters(&h))) return rc;
+    *found = h.aborted ? -2 : (h.not_found == 0);
+    if (h.aborted)
+      fprintf(stderr, "Search1: %d particles not in their parent element (the reference aborts)\n",
               h.aborted);
     if (h.not_found) fprintf(stderr, "ERROR:loop limit %d exceeded\n", looplimit);
   }

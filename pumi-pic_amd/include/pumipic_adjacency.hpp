@@ -13,6 +13,7 @@
 #include <chrono>
 #include <map>
 #include "particle_structs.hpp"
+#include "pumipic_wall.hpp"    // closest_point_on_triangle[_wnormal] (device-inline)
 #include "pumipic_gather.hpp"  // interpolateTetVtx, interpolate2dField, ... (device-inline)
 
 namespace Omega_h {
@@ -157,6 +158,28 @@ bool search_mesh(Mesh& mesh, ParticleStructure<ParticleType>* ptcls, Segment3d x
     fprintf(stderr, "Warning: Particle not in this element at loops=0\n");
     abort();
   }
+  return found == 1;
+}
+
+// search_mesh_3d (adjacency.hpp:314-324)
+template <class ParticleStruct, typename CurrentCoordView, typename TargetCoordView, typename SegmentInt>
+bool search_mesh_3d(Mesh& mesh, ParticleStruct* ptcls, CurrentCoordView x_ps_d,
+                    TargetCoordView xtgt_ps_d, SegmentInt pid_d, o::Write<o::LO>& elem_ids,
+                    o::Write<o::Real>& xpoints_d, o::Write<o::LO>& xface_d, int looplimit = 0,
+                    int = 0) {
+  Timer timer;
+  int seeded = 1;
+  if (elem_ids.size() == 0) {
+    elem_ids = o::Write<o::LO>((size_t)ptcls->capacity());
+    seeded = 0;
+  }
+  int found = 1;
+  pp_check(pp_search_mesh_3d(mesh.handle(), ptcls->handle(), x_ps_d.member(), xtgt_ps_d.member(),
+                             pid_d.member(), elem_ids.data(), seeded, xpoints_d.data(),
+                             xface_d.data(), looplimit, &found),
+           "search_mesh_3d");
+  if (found == -2) abort();  // OMEGA_H_CHECK(false), adjacency.hpp:373-379
+  RecordTime("Search Mesh 3d", timer.seconds());
   return found == 1;
 }
 

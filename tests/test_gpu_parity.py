@@ -263,6 +263,73 @@ def test_search_mesh_tpp_seeded_and_origin_check(ppo, synth, capi):
     assert np.array_equal(ro["elem_ids"], rg["elem_ids"].to_host()[:po.capacity()])
 
 
+@pytest.mark.parametrize("C", [1, 64])
+def test_search_mesh_3d_exact(ppo, synth, capi, C):
+    """search_mesh_3d (adjacency.hpp:314-555) in the pseudoPushAndSearch loop: ids, wall faces and
+    wall points bit-identical by particle id, step after step."""
+    pop = common.population_box(synth, n=4, num_ptcls=900)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_PUSH, C=C)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_PUSH, C=C)
+    hits = 0
+    for step in range(8):
+        ppo.linear_push(po, 0.11, -0.5, 0.8, 0.07 * step)
+        capi.linear_push(pg, 0.11, -0.5, 0.8, 0.07 * step)
+        ro = ppo.search_mesh_3d(mo, po, looplimit=100)
+        rg = capi.search_mesh_3d(mg, pg, looplimit=100)
+        assert ro["found"] == rg["found"] == 1
+        capo, capg = po.capacity(), pg.capacity()
+        ids_g = rg["elem_ids"].to_host()[:capg]
+        mko, mkg = po.slot_info()[1], pg.slot_info()[1]
+        pido, pidg = po.member(2)[0, :capo], pg.member(2)[0, :capg]
+        io, eo = common.by_id(pido, mko, ro["elem_ids"])
+        ig, eg = common.by_id(pidg, mkg, ids_g)
+        assert np.array_equal(io, ig) and np.array_equal(eo, eg), step
+        _, fo = common.by_id(pido, mko, ro["xface"])
+        _, fg = common.by_id(pidg, mkg, rg["xface"].to_host()[:capg])
+        assert np.array_equal(fo, fg)
+        _, xo = common.by_id(pido, mko, ro["xpoints"].T)
+        _, xg = common.by_id(pidg, mkg, rg["xpoints"].to_host().reshape(-1, 3)[:capg].T)
+        assert np.array_equal(xo[:, fo >= 0], xg[:, fg >= 0])
+        hits += int((fo >= 0).sum())
+        ppo.update_positions(po)
+        capi.update_positions(pg)
+        po.rebuild(ro["elem_ids"])
+        pg.rebuild(ids_g)
+        assert po.nPtcls() == pg.nPtcls()
+        if po.nPtcls() == 0:
+            break
+    assert hits > 0
+
+
+def test_search_mesh_3d_seeded_limit_and_abort(ppo, synth, capi):
+    """seed ids with -1 entries, a loop limit that leaves walks unfinished (hpp:531-552) and the
+    checkParent failure (hpp:371-382) report the same as the oracle; torus population."""
+    pop = common.population_3d(synth, num_ptcls=4000)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
+    ppo.toroidal_push(po, mo, H, K, D, 14.0, trig=1)
+    capi.toroidal_push(pg, mg, H, K, D, 14.0)
+    se, mk = po.slot_info()
+    cap = po.capacity()
+    seed = se.copy()
+    seed[~mk.astype(bool)] = -1
+    seed[np.flatnonzero(mk)[::9]] = -1
+    for limit in (0, 3):
+        ro = ppo.search_mesh_3d(mo, po, elem_ids=seed.copy(), looplimit=limit)
+        rg = capi.search_mesh_3d(mg, pg, elem_ids=capi.DevArray.from_host(seed), looplimit=limit)
+        assert ro["found"] == rg["found"] == (1 if limit == 0 else 0)
+        assert np.array_equal(ro["elem_ids"], rg["elem_ids"].to_host()[:cap])
+        assert np.array_equal(ro["xface"], rg["xface"].to_host()[:cap])
+        assert np.array_equal(ro["xpoints"].ravel(), rg["xpoints"].to_host()[:cap * 3])
+    s = np.flatnonzero(mk)[5]
+    po.member(0)[:, s] += 7.0
+    xg = pg.member(0)
+    xg[:, s] += 7.0
+    pg.set_member(0, xg)
+    assert ppo.search_mesh_3d(mo, po, looplimit=50)["found"] == -2
+    assert capi.search_mesh_3d(mg, pg, looplimit=50)["found"] == -2
+
+
 def test_search_mesh_legacy3d_exact(ppo, synth, capi):
     """pseudoPushAndSearch loop (test/pseudoPushAndSearch.cpp:513-542): push, legacy search,
     rebuild.  After a rebuild slot order inside a row is free, so compare by particle id."""
@@ -906,3 +973,21 @@ def test_push_search_on_an_all_deleted_structure(ppo, synth, capi):
     assert pg.nPtcls() == 0
     ids = capi.DevArray.from_host(np.full(max(pg.capacity(), 1), 7, dtype=np.int32))
     assert capi.push_search(mg, pg, H, K, D, 1.0, ids, seeded=False, looplimit=50)
+
+
+@pytest.mark.parametrize("wnormal", [False, True])
+def test_closest_point_on_triangle_exact(ppo, capi, wnormal):
+    """closest_point_on_triangle[_wnormal] (adjacency.hpp:824-1009): points and region codes
+    bit-identical to the oracle, per-point triangles and one shared triangle."""
+    rng = np.random.default_rng(5)
+    n = 5000
+    tris = rng.normal(size=(n, 9))
+    pts = rng.normal(size=(n, 3)) * 2
+    q, reg = capi.closest_point_on_triangle(tris, pts, wnormal=wnormal, reg0=-7)
+    exp = [ppo.closest_point_on_triangle(tris[i], pts[i], wnormal=wnormal, reg0=-7) for i in range(n)]
+    assert np.array_equal(q, np.array([e[0] for e in exp]))
+    assert np.array_equal(reg, np.array([e[1] for e in exp]))
+    assert set(reg) == ({0, 1, 2, 3, 4, 5, 6} if wnormal else {0, 1, 2, -7, 4, 5, 6})
+    q1, reg1 = capi.closest_point_on_triangle(tris[0], pts[:500], wnormal=wnormal, reg0=-7)
+    exp1 = [ppo.closest_point_on_triangle(tris[0], pts[i], wnormal=wnormal, reg0=-7) for i in range(500)]
+    assert np.array_equal(q1, np.array([e[0] for e in exp1])) and np.array_equal(reg1, [e[1] for e in exp1])

@@ -190,6 +190,67 @@ def test_bcc_search_postconditions(ppo, synth, dim):
     assert moved > 10
 
 
+def test_search_mesh_3d_agrees_with_the_other_walks(ppo, synth):
+    """search_mesh_3d (adjacency.hpp:314-555) against the two other 3-D walks on generic inputs:
+    particles that stay in the domain end in the element the BCC walk of search_mesh finds, wall
+    hits are the legacy search's (same intersection routine), and every found target is inside
+    its element (test_adj.cpp:565-587)."""
+    pop = common.population_box(synth, n=4, num_ptcls=800)
+    mesh, ps = common.oracle_pair(ppo, pop, ppo.PARTICLE_PUSH, C=1)
+    ppo.linear_push(ps, 0.6, -0.5, 0.8, 0.1)
+    r3 = ppo.search_mesh_3d(mesh, ps, looplimit=200)
+    rl = ppo.search_mesh_legacy3d(mesh, ps, looplimit=200)
+    rb = ppo.search_mesh(mesh, ps, require_intersection=False, looplimit=200)
+    assert r3["found"] == 1 and rl["found"] == 1 and rb["found"]
+    se, mk = ps.slot_info()
+    live = mk.astype(bool)
+    assert np.array_equal(r3["elem_ids"][live], rl["elem_ids"][live])
+    assert np.array_equal(r3["xface"][live], rl["xface"][live])
+    hit = live & (r3["xface"] >= 0)
+    assert hit.sum() > 20 and (live & ~hit).sum() > 100
+    assert np.array_equal(r3["xpoints"][hit], rl["xpoints"][hit])
+    assert np.all(r3["elem_ids"][hit] == -1)
+    stay = live & ~hit
+    assert np.array_equal(r3["elem_ids"][stay], rb["elem_ids"][stay])
+    assert (r3["elem_ids"][stay] != se[stay]).sum() > 50
+    xt = ps.member(1)[:, :ps.capacity()]
+    for s in np.flatnonzero(stay)[::5]:
+        assert _inside(ppo, mesh, r3["elem_ids"][s], xt[:, s], 1e-10)
+    # wall points lie on the reported exposed face and on the path
+    x0 = ps.member(0)[:, :ps.capacity()]
+    for s in np.flatnonzero(hit)[::3]:
+        f = r3["xface"][s]
+        assert mesh.side_exposed[f]
+        tri = mesh.coords[mesh.side2verts[f]]
+        n = np.cross(tri[1] - tri[0], tri[2] - tri[0])
+        assert abs(np.dot(r3["xpoints"][s] - tri[0], n)) < 1e-12
+        d, dx = xt[:, s] - x0[:, s], r3["xpoints"][s] - x0[:, s]
+        assert np.linalg.norm(np.cross(d, dx)) < 1e-12 and np.dot(d, dx) >= 0
+
+
+def test_search_mesh_3d_seeds_masks_and_loop_limit(ppo, synth):
+    """elem_ids passed in: -1 stays -1 (ptcl_done=2, hpp:361-363); a loop limit leaves the
+    unfinished particles at their current element and returns not-found (hpp:531-552); a particle
+    outside its ROW element trips checkParent (hpp:371-382)."""
+    pop = common.population_box(synth, n=4, num_ptcls=400)
+    mesh, ps = common.oracle_pair(ppo, pop, ppo.PARTICLE_PUSH, C=4)
+    ppo.linear_push(ps, 0.55, 0.3, 0.8, 0.2)
+    se, mk = ps.slot_info()
+    live = np.flatnonzero(mk)
+    seed = se.copy()
+    seed[~mk.astype(bool)] = -1
+    seed[live[::5]] = -1
+    full = ppo.search_mesh_3d(mesh, ps, elem_ids=seed.copy(), looplimit=0)
+    assert full["found"] == 1 and np.all(full["elem_ids"][live[::5]] == -1)
+    assert np.all(full["elem_ids"][~mk.astype(bool)] == -1)
+    lim = ppo.search_mesh_3d(mesh, ps, elem_ids=seed.copy(), looplimit=2)
+    assert lim["found"] == 0 and lim["loops"] == 2
+    unfinished = lim["elem_ids"] != full["elem_ids"]
+    assert unfinished.sum() > 0 and np.all(lim["elem_ids"][unfinished] >= 0)
+    ps.member(0)[:, live[3]] += 10.0  # a view of the structure's storage
+    assert ppo.search_mesh_3d(mesh, ps, looplimit=50)["found"] == -2
+
+
 def test_intersection_search_postconditions(ppo, synth):
     """wall hits lie in the reported exposed face, on the particle's path, and the face bounds the
     final element (test_adj.cpp:630-735)."""
@@ -371,3 +432,33 @@ def test_gather_side_reproduces_linear_fields(ppo, synth):
     d = (gx[None, None, :] + 2 * gy[None, :, None] - gzz[:, None, None]).ravel()  # i + j*nx + k*nx*ny
     got3 = ppo.interp3d_field(ps, gx, gy, gzz, d)
     assert np.allclose(got3[:cap][live], (x[0] + 2 * x[1] - x[2])[live], rtol=1e-12, atol=1e-12)
+
+
+def test_closest_point_on_triangle_properties(ppo):
+    """closest_point_on_triangle[_wnormal] (adjacency.hpp:824-1009): the result is on the triangle,
+    no sampled triangle point is closer, the region code names the feature the point lies on, and
+    the float-narrowed _wnormal form agrees to single precision."""
+    rng = np.random.default_rng(11)
+    uv = rng.random((400, 2))
+    uv[uv.sum(1) > 1] = 1 - uv[uv.sum(1) > 1]
+    seen = set()
+    for _ in range(60):
+        abc = rng.normal(size=(3, 3))
+        a, b, c = abc
+        samples = a + uv[:, :1] * (b - a) + uv[:, 1:] * (c - a)
+        n = np.cross(b - a, c - a)
+        for _ in range(12):
+            p = rng.normal(size=3) * 2
+            q, reg = ppo.closest_point_on_triangle(abc, p, reg0=-7)
+            qw, regw = ppo.closest_point_on_triangle(abc, p, wnormal=True)
+            seen.add(regw)
+            assert reg == (regw if regw != 3 else -7)  # EDGEAB is not reported by the plain form
+            assert np.allclose(q, qw, rtol=0, atol=2e-5 * (1 + np.abs(abc).max()))
+            assert abs(np.dot(q - a, n)) < 1e-12 * (1 + np.dot(n, n))
+            dq = np.linalg.norm(p - q)
+            assert dq <= np.linalg.norm(p - samples, axis=1).min() + 1e-12
+            if regw in (0, 1, 2):
+                assert np.array_equal(q, abc[regw])
+            elif regw == 6:  # foot of the perpendicular
+                assert np.linalg.norm(np.cross(p - q, n)) < 1e-9 * (1 + np.dot(n, n))
+    assert seen == {0, 1, 2, 3, 4, 5, 6}
