@@ -205,6 +205,33 @@ int pp_search_mesh_legacy3d(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt,
 int pp_search_mesh_3d(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_pid,
                       int* elem_ids_dev, int elem_ids_seeded, double* xpoints_dev, int* xface_dev,
                       int looplimit, int* found);
+/* trace_particle_through_mesh with a caller-supplied functor (adjacency.tpp:460-615): the walk
+ * kernel by kernel, so that any device code of the caller can run where the reference calls
+ * `func` (between find_exit_face and set_new_element, tpp:561-565).  Per-slot work arrays of
+ * `capacity` ints are the caller's: ptcl_done (tpp:486), last_exit (tpp:488).
+ *   pp_trace_begin                      setInitial, finishUnmoved, initializeIntersection,
+ *                                       check_initial_parents (tpp:503-552, 72-145)
+ *   pp_trace_find_exit_face             find_exit_face (tpp:231-363), use_bcc = !requireIntersection
+ *   pp_trace_check_model_intersection   the default functor RemoveParticleOnGeometricModelExit
+ *                                       (tpp:365-387, 617-639)
+ *   pp_trace_set_new_element            set_new_element (tpp:389-416) + the min reduction of
+ *                                       ptcl_done as *num_unfinished (0 <=> found, tpp:567-571)
+ *   pp_trace_not_found                  loop-limit clean-up (tpp:583-600)
+ * pumi-pic_amd/include/pumipic_adjacency.hpp::trace_particle_through_mesh drives them in the
+ * reference's order.  pp_search_mesh is the same walk with the default functor, fused. */
+int pp_trace_begin(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int* elem_ids_dev,
+                   int elem_ids_seeded, int requireIntersection, int* inter_faces_dev,
+                   double* inter_points_dev, int* ptcl_done_dev, int* last_exit_dev,
+                   int* num_not_in_elem);
+int pp_trace_find_exit_face(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt,
+                            const int* elem_ids_dev, int* ptcl_done_dev, int* last_exit_dev,
+                            double* inter_points_dev, int use_bcc);
+int pp_trace_check_model_intersection(const pp_mesh* mesh, pp_ps* ps, int* elem_ids_dev,
+                                      int* ptcl_done_dev, const int* last_exit_dev,
+                                      int requireIntersection, int* inter_faces_dev);
+int pp_trace_set_new_element(const pp_mesh* mesh, pp_ps* ps, int* elem_ids_dev,
+                             const int* ptcl_done_dev, const int* last_exit_dev, int* num_unfinished);
+int pp_trace_not_found(pp_ps* ps, int* elem_ids_dev, const int* ptcl_done_dev, int* num_not_found);
 /* Fused hot path: elliptical (dim 2) / toroidal (dim 3) push + BCC walk: particle state is read
  * once and x_tgt, phi, elem_ids written once.  Result-identical to pp_elliptical_push +
  * pp_search_mesh_2d (dim 2) and to pp_toroidal_push + pp_search_mesh in BCC mode (dim 3:

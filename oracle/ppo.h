@@ -159,6 +159,16 @@ int ppo_search_mesh_2d(const ppo_mesh* mesh, ppo_ps* ps, int m_x, int m_xtgt, in
 int ppo_search_mesh(const ppo_mesh* mesh, ppo_ps* ps, int m_x, int m_xtgt, int m_pid,
                     int* elem_ids, int elem_ids_seeded, int requireIntersection, int* inter_faces,
                     double* inter_points, int looplimit, int* loops_out, int* num_not_in_elem);
+/* src/pumipic_adjacency.tpp:460-615 with a caller-supplied functor (the `Func` template argument):
+ * called once per walk iteration between find_exit_face and set_new_element (tpp:561-565) */
+typedef void (*ppo_trace_functor)(void* ctx, const ppo_mesh* mesh, ppo_ps* ps, int* elem_ids,
+                                  int* inter_faces, int* lastExit, double* inter_points,
+                                  int* ptcl_done, int m_x, int m_xtgt);
+int ppo_trace_particle_through_mesh(const ppo_mesh* mesh, ppo_ps* ps, int m_x, int m_xtgt,
+                                    int m_pid, int* elem_ids, int elem_ids_seeded,
+                                    int requireIntersection, int* inter_faces,
+                                    double* inter_points, int looplimit, int* loops_out,
+                                    int* num_not_in_elem, ppo_trace_functor func, void* ctx);
 /* src/pumipic_adjacency.hpp:558-768 (legacy 3-D).  Q3 fallbacks are NOT replicated. */
 int ppo_search_mesh_legacy3d(const ppo_mesh* mesh, ppo_ps* ps, int m_x, int m_xtgt, int m_pid,
                              int* elem_ids, int elem_ids_seeded, double* xpoints, int* xface,

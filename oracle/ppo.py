@@ -416,6 +416,46 @@ def search_mesh(mesh, ps, elem_ids=None, require_intersection=False, looplimit=0
                 not_in_elem=notin.value)
 
 
+_TRACE_FUNCTOR = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, c_int_p, c_int_p, c_int_p,
+                             c_double_p, c_int_p, C.c_int, C.c_int)
+
+
+def trace_particle_through_mesh(mesh, ps, func, elem_ids=None, require_intersection=False,
+                                looplimit=0, m_x=0, m_xtgt=1, m_pid=2):
+    """trace_particle_through_mesh (adjacency.tpp:460-615) with a caller-supplied functor:
+    func(state) is called once per walk iteration where the reference calls `func` (tpp:563);
+    state = dict of numpy views (elem_ids, inter_faces, last_exit, inter_points, ptcl_done)."""
+    cap = ps.capacity()
+    dim = mesh.dim
+    seeded = elem_ids is not None
+    if elem_ids is None:
+        elem_ids = np.full(cap, -1, dtype=np.int32)
+    inter_faces = np.full(cap, -1, dtype=np.int32)
+    inter_points = np.zeros(cap * dim, dtype=np.float64)
+
+    def _cb(ctx, mesh_p, ps_p, e, f, le, ipt, done, mx, mxt):
+        st = dict(elem_ids=np.ctypeslib.as_array(e, (cap,)), inter_faces=np.ctypeslib.as_array(f, (cap,)),
+                  last_exit=np.ctypeslib.as_array(le, (cap,)),
+                  inter_points=np.ctypeslib.as_array(ipt, (cap * dim,)),
+                  ptcl_done=np.ctypeslib.as_array(done, (cap,)), mesh=mesh, ps=ps,
+                  require_intersection=bool(require_intersection))
+        func(st)
+
+    cb = _TRACE_FUNCTOR(_cb)
+    L = lib()
+    L.ppo_trace_particle_through_mesh.restype = C.c_int
+    L.ppo_trace_particle_through_mesh.argtypes = [
+        C.POINTER(_MeshS), C.POINTER(_PsS), C.c_int, C.c_int, C.c_int, c_int_p, C.c_int, C.c_int,
+        c_int_p, c_double_p, C.c_int, c_int_p, c_int_p, _TRACE_FUNCTOR, C.c_void_p]
+    loops, notin = C.c_int(), C.c_int()
+    found = L.ppo_trace_particle_through_mesh(mesh.p, ps.p, m_x, m_xtgt, m_pid, _ip(elem_ids),
+                                              int(seeded), int(require_intersection),
+                                              _ip(inter_faces), _dp(inter_points), looplimit,
+                                              C.byref(loops), C.byref(notin), cb, None)
+    return dict(found=bool(found), elem_ids=elem_ids, inter_faces=inter_faces,
+                inter_points=inter_points, loops=loops.value, not_in_elem=notin.value)
+
+
 def search_mesh_legacy3d(mesh, ps, elem_ids=None, looplimit=0, m_x=0, m_xtgt=1, m_pid=2):
     cap = ps.capacity()
     seeded = elem_ids is not None

@@ -211,9 +211,48 @@ int ppo_search_mesh_3d_pt(const ppo_mesh* mesh, const double dest[3], int initia
 }
 
 /* ------------------------------------------------------------------ search_mesh (tpp) */
+/* check_model_intersection tpp:365-387 = RemoveParticleOnGeometricModelExit tpp:617-639 */
+static void default_functor(void* ctx, const ppo_mesh* mesh, ppo_ps* ps, int* elem_ids,
+                            int* inter_faces, int* lastExit, double* inter_points, int* ptcl_done,
+                            int m_x, int m_xtgt) {
+  (void)inter_points;
+  (void)m_x;
+  (void)m_xtgt;
+  const int requireIntersection = *(const int*)ctx;
+  const int cap = ps->capacity;
+  int* slot_elem = (int*)xcalloc((size_t)cap, sizeof(int));
+  unsigned char* slot_mask = (unsigned char*)xcalloc((size_t)cap, 1);
+  ppo_ps_slot_info(ps, slot_elem, slot_mask);
+  for (int pid = 0; pid < cap; ++pid) {
+    if (slot_mask[pid] && !ptcl_done[pid]) {
+      const int bridge = lastExit[pid];
+      const int exposed = mesh->side_exposed[bridge];
+      ptcl_done[pid] = exposed;
+      if (exposed && requireIntersection)
+        inter_faces[pid] = lastExit[pid];
+      else
+        elem_ids[pid] = exposed ? -1 : elem_ids[pid]; /* leaves domain if exposed */
+    }
+  }
+  free(slot_elem);
+  free(slot_mask);
+}
 int ppo_search_mesh(const ppo_mesh* mesh, ppo_ps* ps, int m_x, int m_xtgt, int m_pid,
                     int* elem_ids, int elem_ids_seeded, int requireIntersection, int* inter_faces,
                     double* inter_points, int looplimit, int* loops_out, int* num_not_in_elem) {
+  /* search_mesh tpp:641-654: trace_particle_through_mesh with the default functor */
+  int ri = requireIntersection;
+  return ppo_trace_particle_through_mesh(mesh, ps, m_x, m_xtgt, m_pid, elem_ids, elem_ids_seeded,
+                                         requireIntersection, inter_faces, inter_points, looplimit,
+                                         loops_out, num_not_in_elem, default_functor, &ri);
+}
+/* trace_particle_through_mesh tpp:460-615; func runs between find_exit_face and set_new_element
+ * (tpp:561-565) with the arrays the reference hands its functor */
+int ppo_trace_particle_through_mesh(const ppo_mesh* mesh, ppo_ps* ps, int m_x, int m_xtgt,
+                                    int m_pid, int* elem_ids, int elem_ids_seeded,
+                                    int requireIntersection, int* inter_faces,
+                                    double* inter_points, int looplimit, int* loops_out,
+                                    int* num_not_in_elem, ppo_trace_functor func, void* ctx) {
   (void)m_pid;
   const int cap = ps->capacity;
   const int dim = mesh->dim;
@@ -378,22 +417,18 @@ int ppo_search_mesh(const ppo_mesh* mesh, ppo_ps* ps, int m_x, int m_xtgt, int m
         ptcl_done[pid] = (lastExit[pid] == -1);
       }
     }
-    /* check_model_intersection tpp:365-387 */
-    for (int pid = 0; pid < cap; ++pid) {
-      if (slot_mask[pid] && !ptcl_done[pid]) {
-        const int bridge = lastExit[pid];
-        const int exposed = mesh->side_exposed[bridge];
-        ptcl_done[pid] = exposed;
-        if (exposed && requireIntersection)
-          inter_faces[pid] = lastExit[pid];
-        else
-          elem_ids[pid] = exposed ? -1 : elem_ids[pid];
-      }
-    }
-    /* set_new_element tpp:389-416 */
+    /* the functor (tpp:563) */
+    func(ctx, mesh, ps, elem_ids, inter_faces, lastExit, inter_points, ptcl_done, m_x, m_xtgt);
+    /* set_new_element tpp:389-416.  A functor that leaves a particle unfinished on an exposed side
+     * makes the reference read past the side's single up-adjacent element; here it leaves (-1). */
     for (int pid = 0; pid < cap; ++pid)
-      if (slot_mask[pid] && !ptcl_done[pid])
-        elem_ids[pid] = other_elem(mesh, lastExit[pid], elem_ids[pid]);
+      if (slot_mask[pid] && !ptcl_done[pid]) {
+        const int b = lastExit[pid];
+        if (mesh->side2elems_off[b + 1] - mesh->side2elems_off[b] < 2)
+          elem_ids[pid] = -1;
+        else
+          elem_ids[pid] = other_elem(mesh, b, elem_ids[pid]);
+      }
     found = 1;
     if (min_done(ptcl_done, cap) == 0) found = 0;
     ++loops;

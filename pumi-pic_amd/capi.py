@@ -98,6 +98,11 @@ SYMBOLS = {
     "pp_search_mesh": (_I, [_V, _V, _I, _I, _I, _V, _I, _I, _V, _V, _I, c_int_p, c_int_p]),
     "pp_search_mesh_legacy3d": (_I, [_V, _V, _I, _I, _I, _V, _I, _V, _V, _I, c_int_p]),
     "pp_closest_point_on_triangle": (_I, [_I, _V, _I, _V, _I, _V, _V]),
+    "pp_trace_begin": (_I, [_V, _V, _I, _I, _V, _I, _I, _V, _V, _V, _V, c_int_p]),
+    "pp_trace_find_exit_face": (_I, [_V, _V, _I, _I, _V, _V, _V, _V, _I]),
+    "pp_trace_check_model_intersection": (_I, [_V, _V, _V, _V, _V, _I, _V]),
+    "pp_trace_set_new_element": (_I, [_V, _V, _V, _V, _V, c_int_p]),
+    "pp_trace_not_found": (_I, [_V, _V, _V, c_int_p]),
     "pp_search_mesh_3d": (_I, [_V, _V, _I, _I, _I, _V, _I, _V, _V, _I, c_int_p]),
     "pp_push_search": (_I, [_V, _V, _I, _I, _I, _I, _D, _D, _D, _D, _V, _I, _I, c_int_p]),
     "pp_create_gyro_ring_mappings": (_I, [_V, _D, _I, _I, _D, _V, _V]),
@@ -182,6 +187,12 @@ class DevArray:
         if self.n:
             check(lib().pp_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes))
         return out
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        assert a.size <= self.n
+        if a.size:
+            check(lib().pp_memcpy_h2d(self.ptr, a.ctypes.data, a.nbytes))
 
     def fill_bytes(self, value):
         check(lib().pp_memset(self.ptr, value, self.n * self.dtype.itemsize))
@@ -626,3 +637,46 @@ def closest_point_on_triangle(tris, pts, wnormal=False, reg0=-1):
     d_r = DevArray.from_host(np.full(max(n, 1), reg0, dtype=np.int32))
     check(lib().pp_closest_point_on_triangle(n, d_t.ptr, stride, d_p.ptr, int(wnormal), d_q.ptr, d_r.ptr))
     return d_q.to_host()[:3 * n].reshape(n, 3), d_r.to_host()[:n]
+
+
+def trace_particle_through_mesh(mesh, ps, func=None, elem_ids=None, require_intersection=False,
+                                looplimit=0, m_x=0, m_xtgt=1):
+    """trace_particle_through_mesh (adjacency.tpp:460-615) through the stepwise entry points.
+    func(state) runs where the reference calls its functor; state holds the device arrays
+    (elem_ids, inter_faces, last_exit, inter_points, ptcl_done).  None = the default functor."""
+    cap = max(ps.capacity(), 1)
+    dim = mesh.dim
+    seeded = elem_ids is not None
+    if elem_ids is None:
+        elem_ids = DevArray(cap, np.int32)
+    st = dict(elem_ids=elem_ids, inter_faces=DevArray.from_host(np.full(cap, -1, dtype=np.int32)),
+              inter_points=DevArray.from_host(np.zeros(cap * dim)), ptcl_done=DevArray(cap, np.int32),
+              last_exit=DevArray(cap, np.int32), mesh=mesh, ps=ps,
+              require_intersection=bool(require_intersection))
+    notin = C.c_int()
+    L = lib()
+    check(L.pp_trace_begin(mesh.p, ps.p, m_x, m_xtgt, elem_ids.ptr, int(seeded),
+                           int(require_intersection), st["inter_faces"].ptr, st["inter_points"].ptr,
+                           st["ptcl_done"].ptr, st["last_exit"].ptr, C.byref(notin)))
+    found, loops = False, 0
+    while not found:
+        check(L.pp_trace_find_exit_face(mesh.p, ps.p, m_x, m_xtgt, elem_ids.ptr, st["ptcl_done"].ptr,
+                                        st["last_exit"].ptr, st["inter_points"].ptr,
+                                        int(not require_intersection)))
+        if func is None:
+            check(L.pp_trace_check_model_intersection(mesh.p, ps.p, elem_ids.ptr, st["ptcl_done"].ptr,
+                                                      st["last_exit"].ptr, int(require_intersection),
+                                                      st["inter_faces"].ptr))
+        else:
+            func(st)
+        left = C.c_int()
+        check(L.pp_trace_set_new_element(mesh.p, ps.p, elem_ids.ptr, st["ptcl_done"].ptr,
+                                         st["last_exit"].ptr, C.byref(left)))
+        found = left.value == 0
+        loops += 1
+        if looplimit and loops >= looplimit:
+            nf = C.c_int()
+            check(L.pp_trace_not_found(ps.p, elem_ids.ptr, st["ptcl_done"].ptr, C.byref(nf)))
+            break
+    st.update(found=found, loops=loops, not_in_elem=notin.value)
+    return st

@@ -434,6 +434,149 @@ __global__ void k_search_legacy3d(int capacity, const unsigned char* __restrict_
   elem_ids[pid] = result;
 }
 
+// ------------------------------------------------------------------ stepwise walk
+// trace_particle_through_mesh (tpp:460-615) accepts a caller-supplied functor that runs between
+// find_exit_face and set_new_element of every walk iteration.  A functor cannot be compiled into
+// the fused kernels of this library, so the walk is also exposed kernel by kernel; the mirror
+// header drives these in the reference's order with the user's functor (any device code) between.
+template <int DIM>
+__global__ void k_trace_begin(int capacity, const unsigned char* __restrict__ mask,
+                              const int* __restrict__ slot_elem, const void* __restrict__ recs,
+                              const double* __restrict__ x, const double* __restrict__ xt,
+                              long long stride, int* __restrict__ elem_ids, int seeded, double tol,
+                              int mt, int* __restrict__ inter_faces,
+                              double* __restrict__ inter_points, int* __restrict__ ptcl_done,
+                              int* __restrict__ last_exit, Counters* cnt) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity) return;
+  last_exit[pid] = -1;
+  const int e = slot_elem[pid];
+  if (e < 0) {  // tail slots no parallel_for visits
+    ptcl_done[pid] = 1;
+    if (!seeded) elem_ids[pid] = -1;
+    return;
+  }
+  const bool msk = mask[pid];
+  if (mt) {  // initializeIntersection tpp:542-547
+    for (int i = 0; i < DIM; ++i) inter_points[(size_t)DIM * pid + i] = 0;
+    inter_faces[pid] = -1;
+  }
+  int elem;
+  bool done;
+  if (!seeded) {  // tpp:504-515
+    elem = msk ? e : -1;
+    done = !msk;
+    elem_ids[pid] = elem;
+  } else {  // tpp:516-522
+    elem = elem_ids[pid];
+    done = (msk && elem == -1) || !msk;
+  }
+  if (msk) {
+    const V3 orig{x[pid], x[stride + pid], x[2 * stride + pid]};
+    const V3 dest{xt[pid], xt[stride + pid], xt[2 * stride + pid]};
+    if (norm(sub(dest, orig)) < tol) done = true;              // finishUnmoved tpp:525-533
+    if (!done && !origin_inside<DIM>(recs, elem, orig, tol)) {  // check_initial_parents tpp:72-145
+      atomicAdd(&cnt->not_in_elem, 1);
+      elem_ids[pid] = -1;
+      done = true;
+    }
+  }
+  ptcl_done[pid] = done;
+}
+// find_exit_face tpp:231-363
+template <int DIM>
+__global__ void k_trace_find_exit(int capacity, const unsigned char* __restrict__ mask,
+                                  const void* __restrict__ recs, MeshArrays m,
+                                  const double* __restrict__ x, const double* __restrict__ xt,
+                                  long long stride, const int* __restrict__ elem_ids,
+                                  int* __restrict__ ptcl_done, int* __restrict__ last_exit,
+                                  double* __restrict__ inter_points, int use_bcc, double tol) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity || !mask[pid] || ptcl_done[pid]) return;
+  const int elem = elem_ids[pid];
+  const V3 dest{xt[pid], xt[stride + pid], xt[2 * stride + pid]};
+  if (use_bcc) {
+    int idx;
+    bool done;
+    if (DIM == 2) {
+      V2 fc[3];
+      int nbr[3];
+      load_tri((const pp_tri_rec*)recs, elem, fc, nbr);
+      double bcc[3];
+      barycentric_tri(tri_area(fc), fc, V2{dest.x, dest.y}, bcc);
+      done = all_positive3(bcc, kEpsilon);
+      idx = min3(bcc);
+    } else {
+      V3 M[4];
+      int nbr[4];
+      double vol;
+      load_tet((const pp_tet_rec*)recs, elem, M, nbr, vol);
+      double bcc[4];
+      barycentric_tet(vol, M, dest, bcc);
+      done = all_positive4(bcc, kEpsilon);
+      idx = min_index4(bcc);
+    }
+    ptcl_done[pid] = done;
+    last_exit[pid] = m.elem2sides[(size_t)elem * (DIM + 1) + idx];
+  } else {
+    const V3 orig{x[pid], x[stride + pid], x[2 * stride + pid]};
+    double ip[3];
+    for (int i = 0; i < DIM; ++i) ip[i] = inter_points[(size_t)DIM * pid + i];
+    const int ex = exit_by_intersection<DIM>(m, elem, orig, dest, tol, last_exit[pid], ip);
+    for (int i = 0; i < DIM; ++i) inter_points[(size_t)DIM * pid + i] = ip[i];
+    last_exit[pid] = ex;
+    ptcl_done[pid] = (ex == -1);
+  }
+}
+// check_model_intersection tpp:365-387 (the default functor, RemoveParticleOnGeometricModelExit)
+__global__ void k_trace_check_model(int capacity, const unsigned char* __restrict__ mask,
+                                    const signed char* __restrict__ side_exposed,
+                                    int* __restrict__ elem_ids, int* __restrict__ ptcl_done,
+                                    const int* __restrict__ last_exit, int require_intersection,
+                                    int* __restrict__ inter_faces) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity || !mask[pid] || ptcl_done[pid]) return;
+  const int bridge = last_exit[pid];
+  const bool exposed = side_exposed[bridge];
+  ptcl_done[pid] = exposed;
+  if (exposed && require_intersection)
+    inter_faces[pid] = bridge;
+  else if (exposed)
+    elem_ids[pid] = -1;
+}
+// set_new_element tpp:389-416 + the min reduction over ptcl_done (tpp:567-571) as a count of
+// unfinished slots.  A functor that leaves a particle unfinished on an exposed side would make the
+// reference read past the side's single up-adjacent element; here that particle leaves (-1).
+__global__ void k_trace_set_new_element(int capacity, const unsigned char* __restrict__ mask,
+                                        MeshArrays m, int* __restrict__ elem_ids,
+                                        const int* __restrict__ ptcl_done,
+                                        const int* __restrict__ last_exit, int* __restrict__ not_done) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool open = pid < capacity && !ptcl_done[pid];
+  if (open && mask[pid]) {
+    const int bridge = last_exit[pid];
+    const int first = m.side2elems_off[bridge];
+    if (m.side2elems_off[bridge + 1] - first < 2) {
+      elem_ids[pid] = -1;
+    } else {
+      const int A = m.side2elems[first], B = m.side2elems[first + 1];
+      elem_ids[pid] = (A == elem_ids[pid]) ? B : A;
+    }
+  }
+  const unsigned long long b = __ballot(open);
+  if (b && (threadIdx.x & 63) == 0) atomicAdd(not_done, __popcll(b));
+}
+// ptclsNotFound tpp:583-600
+__global__ void k_trace_not_found(int capacity, const unsigned char* __restrict__ mask,
+                                  int* __restrict__ elem_ids, const int* __restrict__ ptcl_done,
+                                  int* __restrict__ count) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool lost = pid < capacity && mask[pid] && !ptcl_done[pid];
+  if (lost) elem_ids[pid] = -1;
+  const unsigned long long b = __ballot(lost);
+  if (b && (threadIdx.x & 63) == 0) atomicAdd(count, __popcll(b));
+}
+
 // ------------------------------------------------------------------ search_mesh_3d
 // src/pumipic_adjacency.hpp:314-555.  The reference runs checkCurrentElm / findIntersection /
 // processUndetected as three launches per walk iteration; a particle's walk depends on nothing
@@ -1545,6 +1688,117 @@ int pp_search_mesh_legacy3d(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt,
     if (h.not_found) fprintf(stderr, "ERROR:loop limit %d exceeded\n", looplimit);
   }
   return PP_OK;
+}
+
+// ---- stepwise walk (see k_trace_begin)
+int pp_trace_begin(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int* elem_ids_dev,
+                   int elem_ids_seeded, int requireIntersection, int* inter_faces_dev,
+                   double* inter_points_dev, int* ptcl_done_dev, int* last_exit_dev,
+                   int* num_not_in_elem) {
+  PP_REQUIRE(mesh && ps && elem_ids_dev && ptcl_done_dev && last_exit_dev, "pp_trace_begin: null argument");
+  PP_REQUIRE(ps->num_elems == mesh->nelems, "pp_trace_begin: structure/mesh element mismatch");
+  PP_REQUIRE(!requireIntersection || (inter_faces_dev && inter_points_dev),
+             "pp_trace_begin: intersection mode needs inter_faces/inter_points");
+  int rc;
+  if ((rc = member_ok(ps, m_x, 8, 3, "pp_trace_begin x"))) return rc;
+  if ((rc = member_ok(ps, m_xtgt, 8, 3, "pp_trace_begin x_tgt"))) return rc;
+  if (num_not_in_elem) *num_not_in_elem = 0;
+  if (ps->capacity == 0) return PP_OK;
+  if ((rc = reset_counters())) return rc;
+  const unsigned grid = grid_for(ps->capacity);
+#define PP_TB_ARGS                                                                                \
+  ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), mesh->d_records.p,      \
+      PP_MEMBER(ps, m_x, double), PP_MEMBER(ps, m_xtgt, double), ps->stride, elem_ids_dev,        \
+      elem_ids_seeded, mesh->tol, requireIntersection, inter_faces_dev, inter_points_dev,         \
+      ptcl_done_dev, last_exit_dev, g_cnt.get()
+  if (mesh->dim == 2)
+    k_trace_begin<2><<<grid, kBlock, 0, pp::stream()>>>(PP_TB_ARGS);
+  else
+    k_trace_begin<3><<<grid, kBlock, 0, pp::stream()>>>(PP_TB_ARGS);
+#undef PP_TB_ARGS
+  PP_LAUNCH_CHECK();
+  if (num_not_in_elem) {
+    Counters h;
+    if ((rc = read_counters(&h))) return rc;
+    *num_not_in_elem = h.not_in_elem;
+    if (h.not_in_elem)
+      fprintf(stderr,
+              "[WARNING] %d particles are not located in their starting elements. Deleting them...\n",
+              h.not_in_elem);
+  }
+  return PP_OK;
+}
+
+int pp_trace_find_exit_face(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt,
+                            const int* elem_ids_dev, int* ptcl_done_dev, int* last_exit_dev,
+                            double* inter_points_dev, int use_bcc) {
+  PP_REQUIRE(mesh && ps && elem_ids_dev && ptcl_done_dev && last_exit_dev,
+             "pp_trace_find_exit_face: null argument");
+  PP_REQUIRE(use_bcc || inter_points_dev, "pp_trace_find_exit_face: intersection mode needs inter_points");
+  int rc;
+  if ((rc = member_ok(ps, m_x, 8, 3, "pp_trace_find_exit_face x"))) return rc;
+  if ((rc = member_ok(ps, m_xtgt, 8, 3, "pp_trace_find_exit_face x_tgt"))) return rc;
+  if (ps->capacity == 0) return PP_OK;
+  const unsigned grid = grid_for(ps->capacity);
+#define PP_TF_ARGS                                                                               \
+  ps->capacity, ps->d_mask.as<unsigned char>(), mesh->d_records.p, arrays_of(mesh),              \
+      PP_MEMBER(ps, m_x, double), PP_MEMBER(ps, m_xtgt, double), ps->stride, elem_ids_dev,      \
+      ptcl_done_dev, last_exit_dev, inter_points_dev, use_bcc, mesh->tol
+  if (mesh->dim == 2)
+    k_trace_find_exit<2><<<grid, kBlock, 0, pp::stream()>>>(PP_TF_ARGS);
+  else
+    k_trace_find_exit<3><<<grid, kBlock, 0, pp::stream()>>>(PP_TF_ARGS);
+#undef PP_TF_ARGS
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+int pp_trace_check_model_intersection(const pp_mesh* mesh, pp_ps* ps, int* elem_ids_dev,
+                                      int* ptcl_done_dev, const int* last_exit_dev,
+                                      int requireIntersection, int* inter_faces_dev) {
+  PP_REQUIRE(mesh && ps && elem_ids_dev && ptcl_done_dev && last_exit_dev,
+             "pp_trace_check_model_intersection: null argument");
+  PP_REQUIRE(!requireIntersection || inter_faces_dev,
+             "pp_trace_check_model_intersection: intersection mode needs inter_faces");
+  if (ps->capacity == 0) return PP_OK;
+  k_trace_check_model<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
+      ps->capacity, ps->d_mask.as<unsigned char>(), mesh->d_side_exposed.as<signed char>(),
+      elem_ids_dev, ptcl_done_dev, last_exit_dev, requireIntersection, inter_faces_dev);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+static int count_kernel_result(int* out) {
+  PP_HIP_CHECK(hipMemcpyAsync(out, &g_cnt_dev->pending, sizeof(int), hipMemcpyDeviceToHost, pp::stream()));
+  PP_HIP_CHECK(hipStreamSynchronize(pp::stream()));
+  return PP_OK;
+}
+
+int pp_trace_set_new_element(const pp_mesh* mesh, pp_ps* ps, int* elem_ids_dev,
+                             const int* ptcl_done_dev, const int* last_exit_dev, int* num_unfinished) {
+  PP_REQUIRE(mesh && ps && elem_ids_dev && ptcl_done_dev && last_exit_dev && num_unfinished,
+             "pp_trace_set_new_element: null argument");
+  *num_unfinished = 0;
+  if (ps->capacity == 0) return PP_OK;
+  int rc;
+  if ((rc = reset_counters())) return rc;
+  k_trace_set_new_element<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
+      ps->capacity, ps->d_mask.as<unsigned char>(), arrays_of(mesh), elem_ids_dev, ptcl_done_dev,
+      last_exit_dev, &g_cnt_dev->pending);
+  PP_LAUNCH_CHECK();
+  return count_kernel_result(num_unfinished);
+}
+
+int pp_trace_not_found(pp_ps* ps, int* elem_ids_dev, const int* ptcl_done_dev, int* num_not_found) {
+  PP_REQUIRE(ps && elem_ids_dev && ptcl_done_dev && num_not_found, "pp_trace_not_found: null argument");
+  *num_not_found = 0;
+  if (ps->capacity == 0) return PP_OK;
+  int rc;
+  if ((rc = reset_counters())) return rc;
+  k_trace_not_found<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
+      ps->capacity, ps->d_mask.as<unsigned char>(), elem_ids_dev, ptcl_done_dev, &g_cnt_dev->pending);
+  PP_LAUNCH_CHECK();
+  return count_kernel_result(num_not_found);
 }
 
 int pp_search_mesh_3d(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_pid,

@@ -3,6 +3,8 @@
 //   search_mesh (new, 2-D/3-D)   src/pumipic_adjacency.hpp:37-45, adjacency.tpp:641-654
 //   search_mesh_2d               src/pumipic_adjacency.hpp:1011-1020
 //   search_mesh (legacy 3-D)     src/pumipic_adjacency.hpp:558-562
+//   search_mesh_3d               src/pumipic_adjacency.hpp:314-324
+//   trace_particle_through_mesh  src/pumipic_adjacency.tpp:460-615 (functor hook), :617-639
 //   migrate_ptcls / migrate_lb_ptcls   src/pumipic_ptcl_ops.hpp:53-85 (single rank: rebuild)
 //   RecordTime / SummarizeTime   support/ppTiming.hpp:34-75
 //   gather-side interpolation    src/pumipic_adjacency.hpp:772-809, src/pumipic_utils.hpp:186-454
@@ -62,6 +64,11 @@ class Mesh {
   o::LOs verts2elems_offsets() const { return view<int>(PP_MESH_VERT2ELEMS_OFF); }
   o::LOs verts2elems() const { return view<int>(PP_MESH_VERT2ELEMS); }
   o::Reals elem_measures() const { return view<double>(PP_MESH_ELEM_MEASURE); }
+  // ask_up(dim-1, dim) {a2ab, ab2b}, mark_exposed_sides, ask_down(dim, dim-1).ab2b
+  o::LOs sides2elems_offsets() const { return view<int>(PP_MESH_SIDE2ELEMS_OFF); }
+  o::LOs sides2elems() const { return view<int>(PP_MESH_SIDE2ELEMS); }
+  View<signed char> side_is_exposed() const { return view<signed char>(PP_MESH_SIDE_EXPOSED); }
+  o::LOs elems2sides() const { return view<int>(PP_MESH_ELEM2SIDES); }
   double tolerance() const { return pp_mesh_tolerance(h_); }
 
  private:
@@ -137,6 +144,82 @@ bool search_mesh(Mesh& mesh, ParticleStructure<ParticleType>* ptcls, Segment3d x
   RecordTime("pumipic search_mesh", timer.seconds());
   return found != 0;
 }
+
+// trace_particle_through_mesh with a caller-supplied functor (adjacency.tpp:460-615).  `func` is
+// called once per walk iteration between find_exit_face and set_new_element (tpp:561-565) with
+//   (mesh, ptcls, elem_ids, inter_faces, lastExit, inter_points, ptcl_done, x_ps_orig, x_ps_tgt)
+// and may run any device code (ps::parallel_for lambdas) on those arrays.  The walk runs kernel by
+// kernel through the pp_trace_* entry points; search_mesh above is the fused form of the same walk
+// with RemoveParticleOnGeometricModelExit.
+template <class ParticleType, typename Segment3d, typename SegmentInt, typename Func>
+bool trace_particle_through_mesh(Mesh& mesh, ParticleStructure<ParticleType>* ptcls,
+                                 Segment3d x_ps_orig, Segment3d x_ps_tgt, SegmentInt pids,
+                                 o::Write<o::LO>& elem_ids, bool requireIntersection,
+                                 o::Write<o::LO>& inter_faces, o::Write<o::Real>& inter_points,
+                                 int looplimit, bool /*debug*/, Func& func) {
+  Timer timer;
+  (void)pids;
+  const size_t cap = (size_t)ptcls->capacity();
+  o::Write<o::LO> ptcl_done(cap, 0);   // tpp:486
+  o::Write<o::LO> lastExit(cap, -1);   // tpp:488
+  int seeded = 1;
+  if (elem_ids.size() == 0) {  // tpp:504-515
+    elem_ids = o::Write<o::LO>(cap, -1);
+    seeded = 0;
+  }
+  if (requireIntersection && (inter_points.size() == 0 || inter_faces.size() == 0)) {
+    inter_points = o::Write<o::Real>((size_t)mesh.dim() * cap, 0);
+    inter_faces = o::Write<o::LO>(cap, -1);
+  }
+  int notin = 0;
+  pp_check(pp_trace_begin(mesh.handle(), ptcls->handle(), x_ps_orig.member(), x_ps_tgt.member(),
+                          elem_ids.data(), seeded, requireIntersection ? 1 : 0, inter_faces.data(),
+                          inter_points.data(), ptcl_done.data(), lastExit.data(), &notin),
+           "trace_particle_through_mesh: begin");
+  bool found = false;
+  int loops = 0;
+  while (!found) {
+    pp_check(pp_trace_find_exit_face(mesh.handle(), ptcls->handle(), x_ps_orig.member(),
+                                     x_ps_tgt.member(), elem_ids.data(), ptcl_done.data(),
+                                     lastExit.data(), inter_points.data(), requireIntersection ? 0 : 1),
+             "trace_particle_through_mesh: find_exit_face");
+    func(mesh, ptcls, elem_ids, inter_faces, lastExit, inter_points, ptcl_done, x_ps_orig, x_ps_tgt);
+    int left = 0;
+    pp_check(pp_trace_set_new_element(mesh.handle(), ptcls->handle(), elem_ids.data(),
+                                      ptcl_done.data(), lastExit.data(), &left),
+             "trace_particle_through_mesh: set_new_element");
+    found = (left == 0);
+    ++loops;
+    if (looplimit && loops >= looplimit) {  // tpp:583-606
+      int nf = 0;
+      pp_check(pp_trace_not_found(ptcls->handle(), elem_ids.data(), ptcl_done.data(), &nf),
+               "trace_particle_through_mesh: not found");
+      fprintf(stderr, "ERROR: loop limit %d exceeded. %d particles were not found. Deleting them...\n",
+              looplimit, nf);
+      break;
+    }
+  }
+  RecordTime("pumipic search_mesh", timer.seconds());
+  return found;
+}
+
+// the default functor (adjacency.tpp:617-639)
+template <typename ParticleType, typename Segment3d>
+struct RemoveParticleOnGeometricModelExit {
+  RemoveParticleOnGeometricModelExit(Mesh&, bool requireIntersection)
+      : requireIntersection_(requireIntersection) {}
+  void operator()(Mesh& mesh, ParticleStructure<ParticleType>* ptcls, o::Write<o::LO>& elem_ids,
+                  o::Write<o::LO>& inter_faces, o::Write<o::LO>& lastExit, o::Write<o::Real>&,
+                  o::Write<o::LO>& ptcl_done, Segment3d, Segment3d) const {
+    pp_check(pp_trace_check_model_intersection(mesh.handle(), ptcls->handle(), elem_ids.data(),
+                                               ptcl_done.data(), lastExit.data(),
+                                               requireIntersection_ ? 1 : 0, inter_faces.data()),
+             "check_model_intersection");
+  }
+
+ private:
+  bool requireIntersection_;
+};
 
 // legacy 3-D overload: chosen when argument 7 is a Write<Real> (adjacency.hpp:558-562)
 template <class ParticleType, typename Segment3d, typename SegmentInt>

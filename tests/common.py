@@ -61,3 +61,60 @@ def gpu_pair(capi, pop, members, kind="scs", C=64, V=1024, sigma=2**31 - 1):
         ps = capi.PS.csr(members, ne, pop["ppe"], particle_elements=pop["elem"],
                          particle_info=pop["info"])
     return mesh, ps
+
+
+def class_interface_functor(topo, mask, hits):
+    """A user functor for trace_particle_through_mesh (the `Func` argument, adjacency.tpp:470-476):
+    exposed sides behave as in RemoveParticleOnGeometricModelExit; an INTERIOR side between
+    elements of different class_id stops the particle in its current element and records the side
+    in inter_faces -- what a wall model on an internal material interface does.  Operates on host
+    arrays (numpy); `topo` is the oracle mesh (side numbering is shared with the GPU library)."""
+    def func(st):
+        done, le, elem, faces = st["ptcl_done"], st["last_exit"], st["elem_ids"], st["inter_faces"]
+        idx = np.flatnonzero(mask.astype(bool) & (done[:len(mask)] == 0))
+        if idx.size == 0:
+            return
+        bridge = le[idx]
+        exposed = topo.side_exposed[bridge].astype(bool)
+        first = topo.side2elems_off[bridge]
+        a = topo.side2elems[first]
+        b = topo.side2elems[np.where(exposed, first, first + 1)]
+        iface = ~exposed & (topo.class_id[a] != topo.class_id[b])
+        done[idx] = (exposed | iface).astype(done.dtype)
+        if st["require_intersection"]:
+            faces[idx[exposed | iface]] = bridge[exposed | iface]
+            hits.append(int(iface.sum()))
+        else:
+            elem[idx[exposed]] = -1
+            faces[idx[iface]] = bridge[iface]
+            hits.append(int(iface.sum()))
+    return func
+
+
+def on_device(func):
+    """run a host functor on the device arrays of the stepwise GPU walk (download, apply, upload)"""
+    def wrapped(st):
+        keys = ("elem_ids", "inter_faces", "last_exit", "inter_points", "ptcl_done")
+        host = {k: st[k].to_host() for k in keys}
+        host.update({k: v for k, v in st.items() if k not in keys})
+        func(host)
+        for k in keys:
+            st[k].upload(host[k])
+    return wrapped
+
+
+def radial_kick(xt, dim, h, k, seed=3, lo=0.75, hi=1.3):
+    """scale the targets about the magnetic axis so that walks cross the class bands of the
+    synthetic annulus / torus (the elliptical push alone keeps a particle on its flux surface)"""
+    rng = np.random.default_rng(seed)
+    s = rng.uniform(lo, hi, xt.shape[1])
+    out = xt.copy()
+    if dim == 2:
+        out[0] = h + (xt[0] - h) * s
+        out[1] = k + (xt[1] - k) * s
+    else:
+        r = np.hypot(xt[0], xt[1])
+        rn = h + (r - h) * s
+        out[0], out[1] = xt[0] * rn / r, xt[1] * rn / r
+        out[2] = k + (xt[2] - k) * s
+    return out

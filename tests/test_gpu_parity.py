@@ -991,3 +991,109 @@ def test_closest_point_on_triangle_exact(ppo, capi, wnormal):
     q1, reg1 = capi.closest_point_on_triangle(tris[0], pts[:500], wnormal=wnormal, reg0=-7)
     exp1 = [ppo.closest_point_on_triangle(tris[0], pts[i], wnormal=wnormal, reg0=-7) for i in range(500)]
     assert np.array_equal(q1, np.array([e[0] for e in exp1])) and np.array_equal(reg1, [e[1] for e in exp1])
+
+
+@pytest.mark.parametrize("dim,mt", [(2, False), (2, True), (3, False), (3, True)])
+def test_trace_stepwise_and_functor(ppo, synth, capi, dim, mt):
+    """The kernel-by-kernel walk (pp_trace_*, adjacency.tpp:460-615): with the default functor it
+    equals the fused pp_search_mesh and the oracle; with a user functor between find_exit_face and
+    set_new_element (tpp:561-565) it equals the oracle run of the same functor."""
+    pop = common.population_2d(synth, num_ptcls=3000) if dim == 2 else common.population_3d(synth, num_ptcls=3000)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
+    (ppo.elliptical_push if dim == 2 else ppo.toroidal_push)(po, mo, H, K, D, 30.0, trig=1)
+    se, mk = po.slot_info()
+    cap = po.capacity()
+    live = mk.astype(bool)
+    xt = po.member(1)
+    xt[:, :cap][:, live] = common.radial_kick(xt[:, :cap][:, live], dim, H, K)
+    xg = pg.member(1)
+    xg[:, :cap] = xt[:, :cap]
+    pg.set_member(1, xg)
+    assert np.array_equal(pg.slot_info()[1], mk)
+    ref = ppo.search_mesh(mo, po, require_intersection=mt, looplimit=400)
+    fused = capi.search_mesh(mg, pg, require_intersection=mt, looplimit=400)
+    step = capi.trace_particle_through_mesh(mg, pg, None, require_intersection=mt, looplimit=400)
+    assert step["found"] == ref["found"] == fused["found"] and step["loops"] == ref["loops"]
+    for k, w in (("elem_ids", 1), ("inter_faces", 1), ("inter_points", dim)):
+        if k == "elem_ids" or mt:
+            a = step[k].to_host()[:cap * w]
+            assert np.array_equal(a, np.asarray(ref[k]).ravel()), k
+            assert np.array_equal(a, fused[k].to_host()[:cap * w]), k
+    hits_o, hits_g = [], []
+    wo = ppo.trace_particle_through_mesh(mo, po, common.class_interface_functor(mo, mk, hits_o),
+                                         require_intersection=mt, looplimit=400)
+    wg = capi.trace_particle_through_mesh(
+        mg, pg, common.on_device(common.class_interface_functor(mo, mk, hits_g)),
+        require_intersection=mt, looplimit=400)
+    assert hits_o == hits_g and sum(hits_o) > 50
+    assert wo["found"] == wg["found"] and wo["loops"] == wg["loops"]
+    assert np.array_equal(wo["elem_ids"], wg["elem_ids"].to_host()[:cap])
+    assert np.array_equal(wo["inter_faces"][live], wg["inter_faces"].to_host()[:cap][live])
+    if mt:
+        assert np.array_equal(wo["inter_points"], wg["inter_points"].to_host()[:cap * dim])
+
+
+def test_trace_stepwise_loop_limit_and_seed(ppo, synth, capi):
+    """seeded ids with deleted particles, origin check failures and a loop limit through the
+    stepwise entry points (tpp:516-522, 72-145, 583-600)."""
+    pop = common.population_3d(synth, num_ptcls=3000)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
+    ppo.toroidal_push(po, mo, H, K, D, 25.0, trig=1)
+    capi.toroidal_push(pg, mg, H, K, D, 25.0)
+    se, mk = po.slot_info()
+    seed = se.copy()
+    seed[~mk.astype(bool)] = -1
+    lv = np.flatnonzero(mk)
+    seed[lv[::7]] = (seed[lv[::7]] + 11) % mo.nelems
+    seed[lv[::13]] = -1
+    for limit in (0, 2):
+        ro = ppo.search_mesh(mo, po, elem_ids=seed.copy(), looplimit=limit)
+        rg = capi.trace_particle_through_mesh(mg, pg, None, elem_ids=capi.DevArray.from_host(seed),
+                                              looplimit=limit)
+        assert ro["found"] == rg["found"] and ro["loops"] == rg["loops"]
+        assert ro["not_in_elem"] == rg["not_in_elem"] > 0
+        assert np.array_equal(ro["elem_ids"], rg["elem_ids"].to_host()[:po.capacity()])
+
+
+@pytest.mark.parametrize("mt", [0, 1])
+@pytest.mark.parametrize("direction", [(-0.2, 0.9, 0.15), (0.45, 0.7, -0.3)])
+def test_cpp_driver_trace_wall_model(ppo, synth, capi, tmp_path, mt, direction):
+    """trace_particle_through_mesh with a USER functor compiled into the application
+    (drivers/traceWallModel.cpp: device lambda through ps::parallel_for at the reference's hook,
+    adjacency.tpp:470-476,563) equals the oracle's run of the same wall model; the default functor
+    through the same template equals the fused search_mesh."""
+    import re
+    import subprocess
+    coords, e2v, _ = synth.kuhn_box(6)
+    cy = coords[e2v][:, :, 1].mean(axis=1)
+    cls = (1 + np.floor(cy * 3)).astype(np.int32)  # three material slabs along y
+    mesh_file = str(tmp_path / "slabs.bin")
+    synth.write_mesh_bin(mesh_file, 3, coords, e2v, cls)
+    npt, dist = 2000, 0.62
+    out = subprocess.run([_driver("traceWallModel"), mesh_file, str(npt), str(dist)] +
+                         [repr(d) for d in direction] + [str(mt)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    m = re.search(r"RESULT found (\d+) stopped (\d+) exposed_hits (\d+) left (\d+) elem_sum (-?\d+) "
+                  r"face_sum (-?\d+) default_mismatch (\d+)", out.stdout)
+    assert m, out.stdout[-2000:]
+    found, stopped, exposed_hits, left, esum, fsum, mismatch = (int(g) for g in m.groups())
+    assert mismatch == 0
+    ppe, elem, xyz = synth.push_and_search_population(coords, e2v, npt)
+    xt = xyz + dist * np.array(direction)[:, None]
+    pop = dict(dim=3, coords=coords, e2v=e2v, cls=cls, ppe=ppe, elem=elem,
+               info=[xyz, xt, np.arange(npt, dtype=np.int32)])
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_PUSH)
+    se, mk = po.slot_info()
+    hits = []
+    w = ppo.trace_particle_through_mesh(mo, po, common.class_interface_functor(mo, mk, hits),
+                                        require_intersection=bool(mt), looplimit=200)
+    live = mk.astype(bool)
+    f, e = w["inter_faces"][live], w["elem_ids"][live]
+    exp = mo.side_exposed[np.maximum(f, 0)].astype(bool)
+    assert found == int(w["found"])
+    assert stopped == int(((f >= 0) & ~exp).sum()) == sum(hits) and stopped > 100
+    assert exposed_hits == int(((f >= 0) & exp).sum())
+    assert left == int((e < 0).sum())
+    assert esum == int(e.astype(np.int64).sum()) and fsum == int(f.astype(np.int64).sum())

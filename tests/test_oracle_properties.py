@@ -462,3 +462,57 @@ def test_closest_point_on_triangle_properties(ppo):
             elif regw == 6:  # foot of the perpendicular
                 assert np.linalg.norm(np.cross(p - q, n)) < 1e-9 * (1 + np.dot(n, n))
     assert seen == {0, 1, 2, 3, 4, 5, 6}
+
+
+@pytest.mark.parametrize("dim,mt", [(2, False), (2, True), (3, False), (3, True)])
+def test_trace_with_functor(ppo, synth, dim, mt):
+    """trace_particle_through_mesh's functor hook (adjacency.tpp:470-476,561-565): the default
+    functor passed through the hook reproduces search_mesh; a wall model on class interfaces stops
+    particles exactly on sides that separate two classes, in the element they came from."""
+    pop = common.population_2d(synth, num_ptcls=1200) if dim == 2 else common.population_3d(synth, num_ptcls=1200)
+    mesh, ps = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    (ppo.elliptical_push if dim == 2 else ppo.toroidal_push)(ps, mesh, H, K, D, 30.0, trig=1)
+    se, mk = ps.slot_info()
+    cap = ps.capacity()
+    xt = ps.member(1)
+    xt[:, :cap][:, mk.astype(bool)] = common.radial_kick(xt[:, :cap][:, mk.astype(bool)], dim, H, K)
+    ref = ppo.search_mesh(mesh, ps, require_intersection=mt, looplimit=500)
+
+    def default(st):  # check_model_intersection, tpp:372-385
+        idx = np.flatnonzero(mk.astype(bool) & (st["ptcl_done"] == 0))
+        exposed = mesh.side_exposed[st["last_exit"][idx]].astype(bool)
+        st["ptcl_done"][idx] = exposed
+        if mt:
+            st["inter_faces"][idx[exposed]] = st["last_exit"][idx[exposed]]
+        else:
+            st["elem_ids"][idx[exposed]] = -1
+    got = ppo.trace_particle_through_mesh(mesh, ps, default, require_intersection=mt, looplimit=500)
+    assert got["found"] == ref["found"] and got["loops"] == ref["loops"]
+    assert np.array_equal(got["elem_ids"], ref["elem_ids"])
+    assert np.array_equal(got["inter_faces"], ref["inter_faces"])
+    assert np.array_equal(got["inter_points"], ref["inter_points"].ravel())
+
+    hits = []
+    wall = ppo.trace_particle_through_mesh(mesh, ps, common.class_interface_functor(mesh, mk, hits),
+                                           require_intersection=mt, looplimit=500)
+    assert wall["found"] and sum(hits) > 20
+    live = np.flatnonzero(mk)
+    f = wall["inter_faces"][live]
+    stopped = live[(f >= 0) & ~mesh.side_exposed[np.maximum(f, 0)].astype(bool)]
+    assert len(stopped) == sum(hits)
+    for s in stopped:
+        side = wall["inter_faces"][s]
+        a, b = mesh.side2elems[mesh.side2elems_off[side]:mesh.side2elems_off[side] + 2]
+        assert mesh.class_id[a] != mesh.class_id[b] and wall["elem_ids"][s] in (a, b)
+        # every element on the way had the class of the start element
+        assert mesh.class_id[wall["elem_ids"][s]] == mesh.class_id[se[s]]
+    # particles that never met an interface end where the plain search puts them
+    free = np.setdiff1d(live, stopped)
+    same_class = mesh.class_id[np.maximum(ref["elem_ids"][free], 0)] == mesh.class_id[se[free]]
+    keep = free[(ref["elem_ids"][free] >= 0) & same_class]
+    if mt and dim == 3:  # the 3-D intersection walk follows the RAY to the boundary (SURVEY Q2)
+        ff = wall["inter_faces"][free]
+        assert np.all(mesh.side_exposed[ff[ff >= 0]] == 1)
+    else:
+        assert len(keep) > 100
+    assert np.array_equal(wall["elem_ids"][keep], ref["elem_ids"][keep])
