@@ -15,6 +15,12 @@ A "step" is one pass of the hot path over the resident particle population:
       all-to-all-v (RCCL) and enter the receiver's rebuild as new particles; the two scatter fields
       are summed over ranks (gyroSync).  Use with --mesh 1m --particles 32000000 for the config.
 
+  c4 (configs[3], ps_combo160): the 160-byte PerfTypes160 particle (double[17], int[4], long); a step
+      is one pseudo-push pass (ps_combo160.cpp:158-178: 160 B written per particle) + one
+      redistribute(percentMoved 0.5, uniform) + rebuild round (:186-232).  --c4-elems/--particles
+      choose the point: the stress point 1 M / 1 M (default) or the script point 50 000 / 50 M;
+      --structure scs|csr.  The roofline kernel is the pseudo-push (161 B per particle).
+
 Inputs are synthetic (pumi-pic_amd/synth.py) and resident in HBM before the timed region.
 N > 1: one process per GPU (torch.distributed / RCCL); every rank owns a contiguous block of
 elements and the particles inside it; the full mesh is replicated (reference `Input::FULL`
@@ -44,6 +50,8 @@ BYTES = {
     "c3": 69.0 + 125.0,
     # read b,phi(8) mask(1) seed(4) ; write x_tgt x,y(16) phi(4) elem(4)
     "2d": 37.0,
+    # pseudo-push: write double[17]+int[4]+long = 160, read mask 1 (parentElmData 8 B per element)
+    "c4": 161.0,
 }
 
 
@@ -90,6 +98,75 @@ def build_workload(pp, capi, name, nptcl, rank, world, deg, remainder="last", me
                      particle_info=info)
     return dict(mesh=mesh, ps=ps, dim=dim, label=label, ne=ne, coords=coords, e2v=e2v, cls=cls,
                 ppe=ppe, elem=elem, info=info, rank=rank, world=world)
+
+
+def build_c4(pp, capi, ne, nptcl, rank, structure):
+    """ps_combo160 set-up (performance_tests/ps_combo160.cpp:60-130): uniform distribution (strategy
+    1, fixed seed instead of the wall clock), Sell-64-ne (sigma = ne, V = 1024) or CSR."""
+    rng = np.random.default_rng(rank)
+    elems = np.sort(rng.integers(0, ne, size=nptcl).astype(np.int32))
+    ppe = np.bincount(elems, minlength=ne).astype(np.int32)
+    info = [np.zeros((17, nptcl)), np.zeros((4, nptcl), dtype=np.int32),
+            np.arange(nptcl, dtype=np.int64)[None, :]]
+    if structure == "scs":
+        ps = capi.PS.scs(capi.PERF160, ne, ppe, C_=64, sigma=ne, V=1024, particle_elements=elems,
+                         particle_info=info)
+    else:
+        ps = capi.PS.csr(capi.PERF160, ne, ppe, particle_elements=elems, particle_info=info)
+    parent = capi.DevArray.from_host(np.sqrt(np.arange(ne, dtype=np.float64)) * np.arange(ne))
+    return dict(ps=ps, parent=parent, ne=ne, dim=0, rank=rank, world=1,
+                label="ps_combo160 %s, %d elements" % ("Sell-64-ne" if structure == "scs" else "CSR", ne))
+
+
+class StepperC4:
+    def __init__(self, capi, w):
+        self.capi, self.ps, self.parent = capi, w["ps"], w["parent"]
+        self.new_elems = None
+        self.kernel_ms = []
+        self.round = 0
+
+    def step(self, timed=False):
+        capi = self.capi
+        if timed:
+            e0, e1 = capi.Event(), capi.Event()
+            e0.record()
+        capi.pseudo_push160(self.ps, self.parent)
+        if timed:
+            e1.record()
+            self.kernel_ms.append((e0, e1))
+        self.new_elems = capi.redistribute_particles(self.ps, 0.5, seed=self.round, out=self.new_elems)
+        self.round += 1
+        self.ps.rebuild(self.new_elems)
+        cap = max(self.ps.capacity(), 1)
+        if cap > self.new_elems.n:
+            self.new_elems = capi.DevArray(cap + cap // 10, np.int32)
+
+    def kernel_avg_ms(self):
+        self.capi.sync()
+        ms = [a.elapsed_ms(b) for a, b in self.kernel_ms]
+        return sum(ms) / len(ms) if ms else None
+
+
+def cpu_baseline_c4(pp, ne, nptcl, sample, rounds=3):
+    """the oracle's pseudo-push + redistribute + rebuild on a bounded sample, one core"""
+    from oracle import ppo
+    rng = np.random.default_rng(0)
+    ne_s = max(1, int(ne * (sample / max(nptcl, 1))))  # same particles per element as the GPU run
+    elems = np.sort(rng.integers(0, ne_s, size=sample).astype(np.int32))
+    ppe = np.bincount(elems, minlength=ne_s).astype(np.int32)
+    info = [np.zeros((17, sample)), np.zeros((4, sample), dtype=np.int32),
+            np.arange(sample, dtype=np.int64)[None, :]]
+    ps = ppo.PS.scs(ppo.PERF160, ne_s, ppe, C_max=1, sigma=ne_s, V=1024, particle_elements=elems,
+                    particle_info=info)
+    parent = np.sqrt(np.arange(ne_s, dtype=np.float64)) * np.arange(ne_s)
+    t0 = time.perf_counter()
+    for r in range(rounds):
+        ppo.pseudo_push160(ps, parent)
+        ps.rebuild(ppo.redistribute_particles(ps, 0.5, seed=r))
+    dt = time.perf_counter() - t0
+    return dict(value=sample * rounds / dt, unit="particles/s", cores=1, kind="port",
+                sample="%d particles / %d elements x %d rounds of pseudo-push + redistribute + rebuild, "
+                       "oracle (C=1 Serial semantics), 1 core" % (sample, ne_s, rounds))
 
 
 class Stepper:
@@ -212,7 +289,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "2d", "2dc3"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "2d", "2dc3"])
+    ap.add_argument("--c4-elems", type=int, default=1_000_000, help="c4: number of elements")
+    ap.add_argument("--structure", default="scs", choices=["scs", "csr"], help="c4: particle structure")
     ap.add_argument("--particles", type=int, default=10_000_000, help="particles per GPU")
     ap.add_argument("--deg", type=float, default=0.5, help="degrees per push (testing.cmake:117)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000,
@@ -240,8 +319,14 @@ def main():
     from pumipic_amd import capi
     capi.init(local_rank)  # raises when the HIP library / GPU is missing: no CPU fallback
 
-    w = build_workload(pp, capi, a.workload, a.particles, rank, world, a.deg, a.remainder, a.mesh)
-    st = Stepper(pp, capi, w, a.workload, a.deg)
+    if a.workload == "c4":
+        if "--particles" not in sys.argv:
+            a.particles = 1_000_000  # configs[3] stress point: 1 M elements / 1 M particles
+        w = build_c4(pp, capi, a.c4_elems, a.particles, rank, a.structure)
+        st = StepperC4(capi, w)
+    else:
+        w = build_workload(pp, capi, a.workload, a.particles, rank, world, a.deg, a.remainder, a.mesh)
+        st = Stepper(pp, capi, w, a.workload, a.deg)
 
     def barrier():
         capi.sync()
@@ -283,6 +368,27 @@ def main():
             except (ValueError, KeyError):
                 traffic = None
         bpp = BYTES[{"2dc3": "2d", "c3": "c2", "c5": "c2"}.get(a.workload, a.workload)]
+        if a.workload == "c4":
+            out = {
+                "metric": "particles pseudo-pushed+redistributed+rebuilt / sec / GPU; achieved HBM GB/s vs peak",
+                "value": total_particles * a.steps / dt, "unit": "particles/s", "n_gpus": world,
+                "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+                "data": "synthetic",
+                "config": {"workload": "%s, %d particles/GPU, uniform distribution, pseudo-push + "
+                                       "redistribute(0.5) + rebuild per step" % (w["label"], a.particles),
+                           "parallelism": "%d independent rank(s)" % world},
+                "roofline": {"bound": "hbm", "achieved": bpp * nlive / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": bpp * nlive / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "traffic": None, "kernel": "k_pseudo_push160", "kernel_ms": kms,
+                             "bytes_per_particle": bpp},
+            }
+            if not a.no_cpu_baseline and world == 1:
+                out["cpu_baseline"] = cpu_baseline_c4(pp, a.c4_elems, a.particles, min(a.particles, 1_000_000))
+            print(json.dumps(out))
+            if dist is not None:
+                dist.destroy_process_group()
+            return
         achieved = bpp * nlive / (kms * 1e-3) / 1e9 if kms else None
         out = {
             "metric": "particles pushed+searched+scattered / sec / GPU; achieved HBM GB/s vs peak",

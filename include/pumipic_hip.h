@@ -177,6 +177,12 @@ int pp_push_boris(int n, double* x, double* y, double* z, double* xp, double* yp
                   double dt);
 /* updatePtclPositions test/pseudoXGCm.cpp:102-114 */
 int pp_update_positions(pp_ps* ps, int m_x, int m_xtgt);
+/* redistribute_particles particle_structs/test/Distribute.h:28-89 with the uniform strategy: every
+ * live particle draws a new element with probability percent_moved, masked slots get -1.  The draws
+ * are a counter-based hash of (seed, slot) instead of the reference's Kokkos random pool (which is
+ * not reproducible), so tests can check them against the oracle. */
+int pp_redistribute_particles(const pp_ps* ps, double percent_moved, unsigned long long seed,
+                              int* new_elems_dev);
 /* pseudoPush performance_tests/ps_combo160.cpp:158-178 (members double[17], int[4], long) */
 int pp_pseudo_push160(pp_ps* ps, const double* parent_elm_data_dev);
 

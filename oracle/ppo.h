@@ -20,16 +20,6 @@
 #define PPO_H
 #ifdef __cplusplus
 extern "C" {
-/* wall geometry: src/pumipic_adjacency.hpp:812-1009.  abc = 3 vertices x 3 coordinates; *reg is
- * a TriRegion (0 VTXA,1 VTXB,2 VTXC,3 EDGEAB,4 EDGEAC,5 EDGEBC,6 TRIFACE) and is left untouched in
- * the EDGEAB branch of the non-wnormal form, as in the reference (hpp:951-958). */
-void ppo_closest_point_on_triangle(const double abc[9], const double p[3], int wnormal, double q[3],
-                                   int* reg);
-
-#ifdef __cplusplus
-}
-#endif
-
 #endif
 
 /* ---------------------------------------------------------------- mesh */
@@ -219,6 +209,9 @@ void ppo_interp2d_vector(const ppo_ps* ps, int m_x, const double* data3, double 
 void ppo_interp3d_field(const ppo_ps* ps, int m_x, int nx, int ny, int nz, const double* gridx,
                         const double* gridy, const double* gridz, const double* data, double* out);
 
+/* particle_structs/test/Distribute.h:28-89 (uniform strategy, counter-based draws) */
+void ppo_redistribute_particles(const ppo_ps* ps, double percent_moved, unsigned long long seed,
+                                int* new_elems);
 /* wall geometry: src/pumipic_adjacency.hpp:812-1009.  abc = 3 vertices x 3 coordinates; *reg is
  * a TriRegion (0 VTXA,1 VTXB,2 VTXC,3 EDGEAB,4 EDGEAC,5 EDGEBC,6 TRIFACE) and is left untouched in
  * the EDGEAB branch of the non-wnormal form, as in the reference (hpp:951-958). */

@@ -637,3 +637,13 @@ def closest_point_on_triangle(abc, p, wnormal=False, reg0=-1):
     reg = C.c_int(reg0)
     lib().ppo_closest_point_on_triangle(_dp(abc), _dp(p), int(wnormal), _dp(q), C.byref(reg))
     return q, reg.value
+
+
+def redistribute_particles(ps, percent_moved, seed=0):
+    """redistribute_particles (Distribute.h:28-89), uniform strategy -> new_elems[capacity]."""
+    out = np.empty(max(ps.capacity(), 1), dtype=np.int32)
+    L = lib()
+    L.ppo_redistribute_particles.argtypes = [C.POINTER(_PsS), C.c_double, C.c_ulonglong, c_int_p]
+    L.ppo_redistribute_particles.restype = None
+    L.ppo_redistribute_particles(ps.p, float(percent_moved), int(seed), _ip(out))
+    return out[:ps.capacity()]

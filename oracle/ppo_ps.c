@@ -735,6 +735,37 @@ void ppo_ps_get_pids(const ppo_ps* ps, int* offsets_out, int* pids_out) {
   free(cur);
 }
 
+/* redistribute_particles particle_structs/test/Distribute.h:28-89, uniform re-draws from a
+ * splitmix64 hash of (seed, slot) (the reference's Kokkos pool is not reproducible) */
+static unsigned long long splitmix64(unsigned long long z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+void ppo_redistribute_particles(const ppo_ps* ps, double percent_moved, unsigned long long seed,
+                                int* new_elems) {
+  const int cap = ps->capacity;
+  int* slot_elem = (int*)xcalloc((size_t)cap + 1, sizeof(int));
+  unsigned char* slot_mask = (unsigned char*)xcalloc((size_t)cap + 1, 1);
+  ppo_ps_slot_info(ps, slot_elem, slot_mask);
+  for (int pid = 0; pid < cap; ++pid) {
+    if (slot_elem[pid] < 0 || !slot_mask[pid]) {
+      new_elems[pid] = -1;
+      continue;
+    }
+    const unsigned long long h0 = splitmix64(seed ^ (2ull * (unsigned long long)pid));
+    const double prob = (double)(h0 >> 11) * (1.0 / 9007199254740992.0);
+    if (prob <= percent_moved)
+      new_elems[pid] = (int)(splitmix64(seed ^ (2ull * (unsigned long long)pid + 1ull)) %
+                             (unsigned long long)ps->num_elems);
+    else
+      new_elems[pid] = slot_elem[pid];
+  }
+  free(slot_elem);
+  free(slot_mask);
+}
+
 /* SellCSigma.h:465-524 */
 void ppo_scs_metrics(const ppo_ps* ps, int* padded_cells, int* padded_slices, int* empty_rows) {
   int pc = 0, psl = 0;

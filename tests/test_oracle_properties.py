@@ -516,3 +516,27 @@ def test_trace_with_functor(ppo, synth, dim, mt):
     else:
         assert len(keep) > 100
     assert np.array_equal(wall["elem_ids"][keep], ref["elem_ids"][keep])
+
+
+def test_redistribute_particles_statistics(ppo):
+    """redistribute_particles (Distribute.h:28-89), uniform strategy: masked slots get -1, about
+    percentMoved of the live particles draw a new element, uniformly over the elements, and the
+    draws depend on the seed only."""
+    ne, npt = 500, 40000
+    rng = np.random.default_rng(2)
+    elems = np.sort(rng.integers(0, ne, size=npt).astype(np.int32))
+    ppe = np.bincount(elems, minlength=ne).astype(np.int32)
+    info = [np.zeros((17, npt)), np.zeros((4, npt), dtype=np.int32), np.arange(npt, dtype=np.int64)[None, :]]
+    ps = ppo.PS.scs(ppo.PERF160, ne, ppe, C_max=32, sigma=ne, V=1024, particle_elements=elems, particle_info=info)
+    se, mk = ps.slot_info()
+    live = mk.astype(bool)
+    a = ppo.redistribute_particles(ps, 0.5, seed=7)
+    assert np.array_equal(a, ppo.redistribute_particles(ps, 0.5, seed=7))
+    assert not np.array_equal(a, ppo.redistribute_particles(ps, 0.5, seed=8))
+    assert np.all(a[~live] == -1) and np.all((a[live] >= 0) & (a[live] < ne))
+    moved = (a[live] != se[live]).mean()
+    assert 0.47 < moved < 0.53
+    cnt = np.bincount(a[live][a[live] != se[live]], minlength=ne)
+    assert cnt.min() > 0 and cnt.max() < 4 * cnt.mean()
+    assert np.array_equal(ppo.redistribute_particles(ps, 0.0, seed=1)[live], se[live])
+    assert (ppo.redistribute_particles(ps, 1.0, seed=1)[live] != se[live]).mean() > 0.99
