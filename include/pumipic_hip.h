@@ -285,6 +285,15 @@ int pp_interp2d_vector(const pp_ps* ps, int m_x, const double* data3_dev, double
 int pp_interp3d_field(const pp_ps* ps, int m_x, int nx, int ny, int nz, const double* gridx_dev,
                       const double* gridy_dev, const double* gridz_dev, const double* data_dev,
                       double* out_dev);
+/* Gather + pushBoris in one pass over the live particles: E = interpolate3dFieldTet
+ * of a 3-dof vertex field in the particle's element (elem_ids_dev, or the row element when NULL),
+ * B = interp2dVector of a 3-component (R,Z) grid, then pushBoris src/pumipic_push.hpp:17-75 on the
+ * members x (position), x_prev (previous position) and v (velocity), all double[3].  Value for value
+ * equal to pp_gather_tet_vtx(dof 3) + pp_interp2d_vector + pp_push_boris on those members. */
+int pp_boris_push_fields(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xprev, int m_v,
+                         const int* elem_ids_dev, const double* efield_vtx_dev, const double* bgrid_dev,
+                         double gridx0, double gridz0, double dx, double dz, int nx, int nz, int cyl_symm,
+                         double dt, int* num_degenerate);
 /* The same helpers (plus the _wgrid forms) are device-inline in pumi-pic_amd/include/pumipic_gather.hpp
  * for use inside user lambdas. */
 

@@ -104,6 +104,7 @@ SYMBOLS = {
     "pp_trace_set_new_element": (_I, [_V, _V, _V, _V, _V, c_int_p]),
     "pp_trace_not_found": (_I, [_V, _V, _V, c_int_p]),
     "pp_redistribute_particles": (_I, [_V, C.c_double, C.c_ulonglong, _V]),
+    "pp_boris_push_fields": (_I, [_V, _V, _I, _I, _I, _V, _V, _V] + [C.c_double] * 4 + [_I, _I, _I, C.c_double, c_int_p]),
     "pp_search_mesh_3d": (_I, [_V, _V, _I, _I, _I, _V, _I, _V, _V, _I, c_int_p]),
     "pp_push_search": (_I, [_V, _V, _I, _I, _I, _I, _D, _D, _D, _D, _V, _I, _I, c_int_p]),
     "pp_create_gyro_ring_mappings": (_I, [_V, _D, _I, _I, _D, _V, _V]),
@@ -690,3 +691,13 @@ def redistribute_particles(ps, percent_moved, seed=0, out=None):
         out = DevArray(cap, np.int32)
     check(lib().pp_redistribute_particles(ps.p, float(percent_moved), int(seed), out.ptr))
     return out
+
+
+def boris_push_fields(mesh, ps, efield_vtx, bgrid, gridx0, gridz0, dx, dz, nx, nz, dt, cyl=True,
+                      elem_ids=None, m_x=0, m_xprev=1, m_v=2):
+    """gather (vertex E, grid B) + pushBoris in one kernel; returns the number of degenerate tets"""
+    bad = C.c_int()
+    check(lib().pp_boris_push_fields(mesh.p, ps.p, m_x, m_xprev, m_v,
+                                     elem_ids.ptr if elem_ids is not None else None, efield_vtx.ptr,
+                                     bgrid.ptr, gridx0, gridz0, dx, dz, nx, nz, int(cyl), dt, C.byref(bad)))
+    return bad.value

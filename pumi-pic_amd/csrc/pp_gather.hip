@@ -4,7 +4,9 @@
 // The per-particle arithmetic lives in include/pumipic_gather.hpp (shared with user lambdas).
 #include "../include/pumipic_gather.hpp"
 #include "../include/pumipic_wall.hpp"
+#include "pp_geom.hpp"
 #include "pp_internal.hpp"
+#include "pp_push_math.hpp"
 
 namespace {
 using pp::grid_for;
@@ -83,6 +85,44 @@ int xmember(const pp_ps* ps, int m_x, const char* what, const double** x) {
   return PP_OK;
 }
 }  // namespace
+
+// Gather + Boris push in one pass: E from a 3-dof vertex field of the particle's tet
+// (interpolate3dFieldTet, adjacency.hpp:793-799), B from an (R,Z) grid (interp2dVector,
+// utils.hpp:437-454), then pushBoris (pumipic_push.hpp:17-75) on the particle's own members.
+// Equal, value for value, to pp_gather_tet_vtx + pp_interp2d_vector + pp_push_boris.
+__global__ void k_boris_fields(int capacity, const unsigned char* __restrict__ mask,
+                               const int* __restrict__ slot_elem, const int* __restrict__ elem_ids,
+                               double* __restrict__ x, double* __restrict__ xp, double* __restrict__ v,
+                               long long stride, const double* __restrict__ coords,
+                               const int* __restrict__ e2v, const double* __restrict__ efield,
+                               const double* __restrict__ bgrid, double gridx0, double gridz0, double dx,
+                               double dz, int nx, int nz, int cyl, double dt, int* __restrict__ bad) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity || !mask[pid]) return;
+  const int e = elem_ids ? elem_ids[pid] : slot_elem[pid];
+  const double pos[3] = {x[pid], x[stride + pid], x[2 * stride + pid]};
+  double E[3] = {0, 0, 0}, B[3], bcc[4];
+  if (e >= 0) {
+    if (pumipic::findBCCoordsInTet(coords, e2v, pos, e, bcc))
+      pumipic::interpolate3dFieldTet(e2v, efield, e, bcc, E);
+    else
+      atomicAdd(bad, 1);
+  }
+  pumipic::interp2dVector(bgrid, gridx0, gridz0, dx, dz, nx, nz, pos, B, cyl != 0);
+  using ppg::V3;
+  const V3 vel = ppm::boris_velocity(V3{v[pid], v[stride + pid], v[2 * stride + pid]}, V3{E[0], E[1], E[2]},
+                                     V3{B[0], B[1], B[2]}, dt);
+  const double p0 = xp[pid], p1 = xp[stride + pid], p2 = xp[2 * stride + pid];
+  xp[pid] = pos[0];
+  xp[stride + pid] = pos[1];
+  xp[2 * stride + pid] = pos[2];
+  x[pid] = p0 + vel.x * dt;
+  x[stride + pid] = p1 + vel.y * dt;
+  x[2 * stride + pid] = p2 + vel.z * dt;
+  v[pid] = vel.x;
+  v[stride + pid] = vel.y;
+  v[2 * stride + pid] = vel.z;
+}
 
 // closest_point_on_triangle[_wnormal] over n (triangle, point) pairs; tri_stride 0 = one triangle
 __global__ void k_closest_point(int n, const double* __restrict__ tris, int tri_stride,
@@ -175,6 +215,39 @@ int pp_interp3d_field(const pp_ps* ps, int m_x, int nx, int ny, int nz, const do
       ps->capacity, ps->d_mask.as<unsigned char>(), x, ps->stride, nx, ny, nz, gridx_dev, gridy_dev,
       gridz_dev, data_dev, out_dev);
   PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+int pp_boris_push_fields(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xprev, int m_v,
+                         const int* elem_ids_dev, const double* efield_vtx_dev, const double* bgrid_dev,
+                         double gridx0, double gridz0, double dx, double dz, int nx, int nz, int cyl_symm,
+                         double dt, int* num_degenerate) {
+  PP_REQUIRE(mesh && ps && efield_vtx_dev && bgrid_dev, "pp_boris_push_fields: null argument");
+  PP_REQUIRE(mesh->dim == 3, "pp_boris_push_fields: needs a tet mesh");
+  PP_REQUIRE(ps->num_elems == mesh->nelems, "pp_boris_push_fields: structure/mesh element mismatch");
+  PP_REQUIRE(dx > 0 && dz > 0 && nx >= 1 && nz >= 1 && dt > 0,
+             "pp_boris_push_fields: bad grid or dt (utils.hpp:205, pumipic_push.hpp:38)");
+  PP_REQUIRE(m_x != m_xprev && m_x != m_v && m_xprev != m_v, "pp_boris_push_fields: members must differ");
+  const double *x, *xp, *v;
+  int rc;
+  if ((rc = xmember(ps, m_x, "pp_boris_push_fields x", &x))) return rc;
+  if ((rc = xmember(ps, m_xprev, "pp_boris_push_fields x_prev", &xp))) return rc;
+  if ((rc = xmember(ps, m_v, "pp_boris_push_fields v", &v))) return rc;
+  if (num_degenerate) *num_degenerate = 0;
+  if (ps->capacity == 0) return PP_OK;
+  static pp::DevBuf* s_bad = new pp::DevBuf();
+  PP_HIP_CHECK(s_bad->reserve(sizeof(int)));
+  PP_HIP_CHECK(hipMemsetAsync(s_bad->p, 0, sizeof(int), pp::stream()));
+  k_boris_fields<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
+      ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), elem_ids_dev,
+      (double*)x, (double*)xp, (double*)v, ps->stride, mesh->d_coords.as<double>(),
+      mesh->d_elem2verts.as<int>(), efield_vtx_dev, bgrid_dev, gridx0, gridz0, dx, dz, nx, nz, cyl_symm,
+      dt, s_bad->as<int>());
+  PP_LAUNCH_CHECK();
+  if (num_degenerate) {
+    PP_HIP_CHECK(hipMemcpyAsync(num_degenerate, s_bad->p, sizeof(int), hipMemcpyDeviceToHost, pp::stream()));
+    PP_HIP_CHECK(hipStreamSynchronize(pp::stream()));
+  }
   return PP_OK;
 }
 

@@ -78,18 +78,8 @@ __global__ void k_boris(int n, double* x, double* y, double* z, double* xp, doub
   const int pid = blockIdx.x * blockDim.x + threadIdx.x;
   if (pid >= n) return;
   using namespace ppg;
-  V3 vel{vx[pid], vy[pid], vz[pid]};
-  const V3 eField{ex[pid], ey[pid], ez[pid]};
-  const V3 bField{br[pid], bt[pid], bz[pid]};
-  const double charge = 1, amu = 10;
-  const double bFieldMag = norm(bField);
-  const double qPrime = charge * 1.60217662e-19 / (amu * 1.6737236e-27) * dt * 0.5;
-  const double coeff = 2.0 * qPrime / (1.0 + (qPrime * bFieldMag) * (qPrime * bFieldMag));
-  const V3 qpE = mul(eField, qPrime);
-  const V3 vMinus = sub(vel, qpE);
-  const V3 vPrime = add(vMinus, mul(cross(vMinus, bField), qPrime));
-  vel = add(vMinus, mul(cross(vPrime, bField), coeff));
-  vel = add(vel, qpE);
+  const V3 vel = ppm::boris_velocity(V3{vx[pid], vy[pid], vz[pid]}, V3{ex[pid], ey[pid], ez[pid]},
+                                     V3{br[pid], bt[pid], bz[pid]}, dt);
   const double p0 = xp[pid], p1 = yp[pid], p2 = zp[pid];
   xp[pid] = x[pid];
   yp[pid] = y[pid];

@@ -89,4 +89,18 @@ PPD void toroidal_point(const ClassTerm& t, float phi, float b, double x0, doubl
   tz = Zn;
 }
 
+// velocity update of pushBoris (src/pumipic_push.hpp:28-58; charge = 1, amu = 10 as hard-coded there)
+PPD ppg::V3 boris_velocity(ppg::V3 vel, ppg::V3 eField, ppg::V3 bField, double dt) {
+  using namespace ppg;
+  const double charge = 1, amu = 10;
+  const double bFieldMag = norm(bField);
+  const double qPrime = charge * 1.60217662e-19 / (amu * 1.6737236e-27) * dt * 0.5;
+  const double coeff = 2.0 * qPrime / (1.0 + (qPrime * bFieldMag) * (qPrime * bFieldMag));
+  const V3 qpE = mul(eField, qPrime);
+  const V3 vMinus = sub(vel, qpE);
+  const V3 vPrime = add(vMinus, mul(cross(vMinus, bField), qPrime));
+  vel = add(vMinus, mul(cross(vPrime, bField), coeff));
+  return add(vel, qpE);
+}
+
 }  // namespace ppm

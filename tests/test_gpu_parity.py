@@ -1143,3 +1143,46 @@ def test_ps_combo160_rounds_exact(ppo, capi, kind):
             sg, mg_ = pg.slot_info()
             assert np.array_equal(np.bincount(so[mo_.astype(bool)], minlength=ne),
                                   np.bincount(sg[mg_.astype(bool)], minlength=ne))
+
+
+@pytest.mark.parametrize("cyl", [False, True])
+def test_boris_push_with_gathered_fields(ppo, synth, capi, cyl):
+    """pp_boris_push_fields (gather + pushBoris in one pass): E from a 3-dof vertex
+    field in the particle's tet, B from an (R,Z) grid, then pumipic_push.hpp:17-75.  Against the
+    oracle's composition of the three steps: bit-exact without the cylindrical rotation, 1e-12
+    relative with it (atan2/cos/sin); several steps so that x, x_prev and v all feed back."""
+    pop = common.population_3d(synth, n_b=5, n_theta=20, n_planes=8, num_ptcls=4000)
+    members = [(np.float64, 3), (np.float64, 3), (np.float64, 3), (np.int32, 1)]
+    rng = np.random.default_rng(21)
+    xyz = pop["info"][0]
+    vel = rng.standard_normal(xyz.shape) * 1e3
+    info = [xyz, xyz - vel * 1e-9, vel, np.arange(xyz.shape[1], dtype=np.int32)]
+    pop = dict(pop, info=info)
+    mo, po = common.oracle_pair(ppo, pop, members)
+    mg, pg = common.gpu_pair(capi, pop, members)
+    cap = po.capacity()
+    efield = rng.standard_normal(mo.nverts * 3) * 50.0
+    nx, nz, gx0, gz0, dx, dz = 40, 30, 0.9, -0.8, 0.04, 0.06
+    bgrid = rng.standard_normal(nx * nz * 3)
+    d_e, d_b = capi.DevArray.from_host(efield), capi.DevArray.from_host(bgrid)
+    dt = 2e-9
+    live = po.slot_info()[1].astype(bool)
+    for step in range(3):
+        E, bad = ppo.gather_tet_vtx(mo, po, efield, dof=3)
+        B = ppo.interp2d_vector(po, bgrid, gx0, gz0, dx, dz, nx, nz, cyl_symm=cyl)
+        x, xp, v = (po.member(m)[:, :cap] for m in range(3))
+        cols = [np.ascontiguousarray(a[i, live]) for a in (x, xp, v) for i in range(3)]
+        cols += [np.ascontiguousarray(E[i, :cap][live]) for i in range(3)]
+        cols += [np.ascontiguousarray(B[i, :cap][live]) for i in range(3)]
+        ppo.push_boris(*cols, dt)
+        for a, k in ((x, 0), (xp, 3), (v, 6)):
+            for i in range(3):
+                a[i, live] = cols[k + i]
+        badg = capi.boris_push_fields(mg, pg, d_e, d_b, gx0, gz0, dx, dz, nx, nz, dt, cyl=cyl)
+        assert bad == badg == 0
+        for m in range(3):
+            a, b = po.member(m)[:, :cap][:, live], pg.member(m)[:, :cap][:, live]
+            if cyl:
+                np.testing.assert_allclose(a, b, rtol=1e-12, atol=0)
+            else:
+                assert np.array_equal(a, b), (step, m)
