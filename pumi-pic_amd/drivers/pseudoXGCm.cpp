@@ -7,13 +7,15 @@
 // are USER lambdas run through ps::parallel_for exactly as in the reference; search, rebuild
 // and scatter go through the C-ABI.
 //
-//   usage: pseudoXGCm <mesh.bin> <numPtcls> <max initial model face> <maxIterations>
+//   usage: pseudoXGCm <mesh.bin | mesh.msh> <numPtcls> <max initial model face> <maxIterations>
 //                     <degrees per elliptical push> <enable prebarrier>
 // <mesh.bin> is the container written by pumi-pic_amd/synth.py:write_mesh_bin (the pumipic-data
 // .osh/.ppm meshes of the reference are not available).
 #include <cmath>
 #include <random>
+#include <iostream>
 #include "../include/pumipic_adjacency.hpp"
+#include "../include/pumipic_gmsh.hpp"
 
 #define ELEMENT_SEED 1024 * 1024
 #define PARTICLE_SEED 512 * 512
@@ -73,6 +75,23 @@ void push(PS* ptcls, p::Mesh& m, double deg) {
 
 static bool readMesh(const char* fn, int& dim, std::vector<double>& coords, std::vector<int>& e2v,
                      std::vector<int>& cls) {
+  // test/pseudoXGCm.cpp:306-324: the extension selects the reader ("msh" = Gmsh ASCII; the Omega_h
+  // binary ".osh" format belongs to a library that is not in the reference tree)
+  const std::string name(fn);
+  if (name.size() > 4 && name.substr(name.size() - 4) == ".msh") {
+    std::cout << "reading gmsh mesh " << name << "\n";
+    pumipic::gmsh::MeshData m;
+    std::string err;
+    if (!pumipic::gmsh::read(name, m, &err)) {
+      fprintf(stderr, "%s\n", err.c_str());
+      return false;
+    }
+    dim = m.dim;
+    coords.swap(m.coords);
+    e2v.swap(m.elem2verts);
+    cls.swap(m.class_id);
+    return true;
+  }
   FILE* f = fopen(fn, "rb");
   if (!f) return false;
   int hdr[4];

@@ -1186,3 +1186,29 @@ def test_boris_push_with_gathered_fields(ppo, synth, capi, cyl):
                 np.testing.assert_allclose(a, b, rtol=1e-12, atol=0)
             else:
                 assert np.array_equal(a, b), (step, m)
+
+
+def test_cpp_driver_pseudoxgcm_reads_gmsh(synth, capi, tmp_path):
+    """the pseudoXGCm driver takes a Gmsh .msh mesh like the reference's (pseudoXGCm.cpp:306-315):
+    a format-2.2 file gives the same run as the binary container of the same mesh; a 4.1 file
+    (elements regrouped by class) is read and keeps every particle."""
+    import re
+    import subprocess
+    from pumipic_amd import meshio
+    c, e, cl = synth.annulus_tri(n_b=24, n_theta=96, band_width=3)
+    files = {"bin": str(tmp_path / "a.bin"), "2.2": str(tmp_path / "a22.msh"), "4.1": str(tmp_path / "a41.msh")}
+    synth.write_mesh_bin(files["bin"], 2, c, e, cl)
+    meshio.write_gmsh(files["2.2"], 2, c, e, cl, "2.2")
+    meshio.write_gmsh(files["4.1"], 2, c, e, cl, "4.1")
+    res = {}
+    for k, f in files.items():
+        out = subprocess.run([_driver("pseudoXGCm"), f, "20000", "6", "5", "2.0", "0"],
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        m = re.search(r"RESULT particles (\d+) scatter_mass (\S+) touched_elements (\d+)", out.stdout)
+        assert m, out.stdout[-2000:]
+        res[k] = m.groups()
+        if k != "bin":
+            assert "reading gmsh mesh" in out.stdout
+    assert res["2.2"] == res["bin"]
+    assert res["4.1"][0] == "20000"
