@@ -255,7 +255,12 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
  * of the containing tet per ring point. */
 int pp_create_gyro_ring_mappings(const pp_mesh* mesh, double rmax, int gnr, int gppr,
                                  double theta_deg, int* forward_map_dev, int* backward_map_dev);
-/* gyroScatter test/gyroScatter.hpp:168-229: scatter_w_dev[nverts] (overwritten) */
+/* gyroScatter test/gyroScatter.hpp:168-229: scatter_w_dev[nverts] (overwritten).  A map written by
+ * pp_create_gyro_ring_mappings is a constant of the run; the library keeps its transpose and runs
+ * the second stage as a per-vertex gather (no FP64 atomics, additions in the reference's loop
+ * order).  The transpose is dropped when the map's memory is freed or written through this API
+ * (pp_free / pp_memcpy_h2d / pp_memset); a map edited by a user kernel in place must be passed as
+ * a copy.  Any other map pointer takes the atomic form. */
 int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, double rmax, int gnr,
                     int gppr, double* scatter_w_dev);
 /* setSyncArray of gyroSync test/gyroScatter.hpp:245-249: out[2v]=fwd[v], out[2v+1]=bkwd[v];

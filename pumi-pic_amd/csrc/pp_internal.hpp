@@ -14,6 +14,10 @@ namespace pp {
 void set_error(const std::string& msg);
 unsigned long long next_version();  // pp_runtime.hip: process-wide monotonic stamp
 hipStream_t stream();
+// pp_scatter.hip: a device range was freed / overwritten through the C-ABI -- forget the gather
+// form of any gyro ring map living there
+void gyro_map_invalidate(const void* dev, size_t bytes);
+void gyro_map_mesh_gone(const void* mesh);
 bool initialised();
 
 #define PP_HIP_CHECK(expr)                                                              \

@@ -250,6 +250,7 @@ pp_mesh* pp_mesh_create(int dim, int nverts, const double* coords_host, int nele
 }
 
 int pp_mesh_destroy(pp_mesh* m) {
+  pp::gyro_map_mesh_gone(m);
   delete m;
   return PP_OK;
 }

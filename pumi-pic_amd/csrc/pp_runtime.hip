@@ -53,11 +53,13 @@ void* pp_malloc(size_t bytes) {
   return p;
 }
 int pp_free(void* dev) {
+  if (dev) pp::gyro_map_invalidate(dev, 1);
   if (dev) PP_HIP_CHECK(hipFree(dev));
   return PP_OK;
 }
 int pp_memcpy_h2d(void* dev, const void* host, size_t bytes) {
   if (!bytes) return PP_OK;
+  pp::gyro_map_invalidate(dev, bytes);
   PP_HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, pp::g_stream));
   PP_HIP_CHECK(hipStreamSynchronize(pp::g_stream));
   return PP_OK;
@@ -70,6 +72,7 @@ int pp_memcpy_d2h(void* host, const void* dev, size_t bytes) {
 }
 int pp_memset(void* dev, int value, size_t bytes) {
   if (!bytes) return PP_OK;
+  pp::gyro_map_invalidate(dev, bytes);
   PP_HIP_CHECK(hipMemsetAsync(dev, value, bytes, pp::g_stream));
   return PP_OK;
 }

@@ -12,6 +12,7 @@
 // its adjacent elements (no atomics).  All addends are exact integers, so the sums are bit-identical
 // to the reference's particle-by-particle accumulation in any order.
 #include "pp_geom.hpp"
+#include <vector>
 #include "pp_internal.hpp"
 
 namespace {
@@ -178,6 +179,85 @@ __global__ void k_scatter_mapped(int nverts, int gnr, int gppr, int nvpe,
     if (mv >= 0) atomicAdd(&scatter_w[mv], val);
   }
 }
+// ---- gather form of the second stage.  A ring map is a constant of the run (created once,
+// gyroScatter.hpp:101-166), so pp_create_gyro_ring_mappings also builds its transpose: for every
+// target vertex the list of ring-accumulator entries that map to it, ascending.  The scatter then
+// is one thread per target summing its list -- no FP64 atomics, no memset, and the additions happen
+// in the order of the reference's sequential loop (gyroScatter.hpp:204-222).
+__global__ void k_inv_count(long long n, const int* __restrict__ v2v, int* __restrict__ cnt) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int t = v2v[i];
+  if (t >= 0) atomicAdd(&cnt[t], 1);
+}
+__global__ void k_inv_scan(int n, const int* __restrict__ cnt, int* __restrict__ off) {
+  __shared__ int part[1024];
+  const int per = (n + 1023) / 1024, b = threadIdx.x * per, e = min(b + per, n);
+  int s = 0;
+  for (int i = b; i < e; ++i) s += cnt[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int i = 0; i < 1024; ++i) {
+      const int v = part[i];
+      part[i] = run;
+      run += v;
+    }
+    off[n] = run;
+  }
+  __syncthreads();
+  s = part[threadIdx.x];
+  for (int i = b; i < e; ++i) {
+    off[i] = s;
+    s += cnt[i];
+  }
+}
+__global__ void k_inv_fill(long long n, int per_entry, const int* __restrict__ v2v,
+                           const int* __restrict__ off, int* __restrict__ cursor,
+                           int* __restrict__ src) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int t = v2v[i];
+  if (t >= 0) src[off[t] + atomicAdd(&cursor[t], 1)] = (int)(i / per_entry);
+}
+__global__ void k_inv_sort(int nverts, const int* __restrict__ off, int* __restrict__ src) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nverts) return;
+  const int b = off[t], e = off[t + 1];
+  for (int i = b + 1; i < e; ++i) {  // short lists: insertion sort
+    const int v = src[i];
+    int j = i - 1;
+    while (j >= b && src[j] > v) {
+      src[j + 1] = src[j];
+      --j;
+    }
+    src[j + 1] = v;
+  }
+}
+// 16 lanes per target vertex: the lanes fetch 16 list entries at once (the loads are what costs),
+// then every lane adds them up in list order, so the sum is the sequential one
+__global__ void k_scatter_gathered(int nverts, int gppr, const int* __restrict__ off,
+                                   const int* __restrict__ src, const double* __restrict__ ring_accum,
+                                   double* __restrict__ scatter_w) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = g >> 4, sub = g & 15, lane0 = (threadIdx.x & 63) & ~15;
+  const bool in = t < nverts;
+  const int b = in ? off[t] : 0, e = in ? off[t + 1] : 0;
+  int len = e - b;
+  for (int o = 16; o < 64; o <<= 1) len = max(len, __shfl_xor(len, o));  // wave-uniform trip count
+  double w = 0;
+  for (int base = 0; base < len; base += 16) {
+    const int j = b + base + sub;
+    const double val = j < e ? ring_accum[src[j]] / gppr : 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const double x = __shfl(val, lane0 + k);
+      if (b + base + k < e) w += x;
+    }
+  }
+  if (in && sub == 0) scatter_w[t] = w;
+}
 __global__ void k_sync_pack(int nverts, const double* __restrict__ f, const double* __restrict__ b,
                             double* __restrict__ out) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -204,7 +284,50 @@ __global__ void k_vert_density(int nverts, const int* __restrict__ v2e_off,
   dens[t] = val / deg;
 }
 
+struct InvMap {
+  const int* key[2];  // forward and backward map of one pp_create_gyro_ring_mappings call
+  size_t bytes;
+  const pp_mesh* mesh;
+  int gnr, gppr;
+  pp::DevBuf off, src;
+};
+std::vector<InvMap*> g_inv;
+const InvMap* find_inverse(const int* v2v, const pp_mesh* mesh, int gnr, int gppr) {
+  for (const InvMap* m : g_inv)
+    if ((m->key[0] == v2v || m->key[1] == v2v) && m->mesh == mesh && m->gnr == gnr && m->gppr == gppr)
+      return m;
+  return nullptr;
+}
 }  // namespace
+
+namespace pp {
+void gyro_map_invalidate(const void* dev, size_t bytes) {
+  const char* b = (const char*)dev;
+  for (size_t i = 0; i < g_inv.size();) {
+    InvMap* m = g_inv[i];
+    for (int k = 0; k < 2; ++k) {
+      const char* a = (const char*)m->key[k];
+      if (a && b < a + m->bytes && a < b + bytes) m->key[k] = nullptr;
+    }
+    if (!m->key[0] && !m->key[1]) {
+      delete m;
+      g_inv.erase(g_inv.begin() + (long)i);
+    } else {
+      ++i;
+    }
+  }
+}
+void gyro_map_mesh_gone(const void* mesh) {
+  for (size_t i = 0; i < g_inv.size();) {
+    if ((const void*)g_inv[i]->mesh == mesh) {
+      delete g_inv[i];
+      g_inv.erase(g_inv.begin() + (long)i);
+    } else {
+      ++i;
+    }
+  }
+}
+}  // namespace pp
 
 extern "C" {
 
@@ -228,6 +351,36 @@ int pp_create_gyro_ring_mappings(const pp_mesh* mesh, double rmax, int gnr, int 
         mesh->d_elem2verts.as<int>(), mesh->d_records.as<pp_tet_rec>(), forward_map_dev,
         backward_map_dev);
   PP_LAUNCH_CHECK();
+  {  // transpose of the map for the gather form of pp_gyro_scatter (both maps hold the same ids)
+    const int nvpe = mesh->dim + 1;
+    const long long entries = n * nvpe;
+    pp::gyro_map_invalidate(forward_map_dev, sizeof(int) * (size_t)entries);
+    pp::gyro_map_invalidate(backward_map_dev, sizeof(int) * (size_t)entries);
+    InvMap* m = new InvMap();
+    m->key[0] = forward_map_dev;
+    m->key[1] = backward_map_dev;
+    m->bytes = sizeof(int) * (size_t)entries;
+    m->mesh = mesh;
+    m->gnr = gnr;
+    m->gppr = gppr;
+    hipStream_t st = pp::stream();
+    const int nv = mesh->nverts;
+    pp::DevBuf cnt;
+    PP_HIP_CHECK(cnt.reserve(sizeof(int) * ((size_t)nv + 1)));
+    PP_HIP_CHECK(m->off.reserve(sizeof(int) * ((size_t)nv + 1)));
+    PP_HIP_CHECK(m->src.reserve(sizeof(int) * (size_t)std::max<long long>(entries, 1)));
+    PP_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(int) * ((size_t)nv + 1), st));
+    k_inv_count<<<grid_for((size_t)entries), kBlock, 0, st>>>(entries, forward_map_dev, cnt.as<int>());
+    k_inv_scan<<<1, 1024, 0, st>>>(nv, cnt.as<int>(), m->off.as<int>());
+    PP_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(int) * ((size_t)nv + 1), st));
+    k_inv_fill<<<grid_for((size_t)entries), kBlock, 0, st>>>(entries, nvpe * gppr, forward_map_dev,
+                                                            m->off.as<int>(), cnt.as<int>(),
+                                                            m->src.as<int>());
+    k_inv_sort<<<grid_for(nv), kBlock, 0, st>>>(nv, m->off.as<int>(), m->src.as<int>());
+    PP_LAUNCH_CHECK();
+    PP_HIP_CHECK(hipStreamSynchronize(st));  // cnt goes out of scope
+    g_inv.push_back(m);
+  }
   return PP_OK;
 }
 
@@ -248,8 +401,11 @@ int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, do
   static pp::DevBuf* s_ring = new pp::DevBuf();
   PP_HIP_CHECK(s_cnt->reserve(sizeof(int) * (size_t)std::max(ne, 1)));
   PP_HIP_CHECK(s_ring->reserve(sizeof(double) * (size_t)std::max(nverts * gnr, 1)));
-  PP_HIP_CHECK(hipMemsetAsync(scatter_w_dev, 0, sizeof(double) * (size_t)nverts, st));
-  if (ps->num_ptcls > 0 && ps->capacity > 0) {
+  static const bool no_gather = getenv("PP_SCATTER_ATOMIC") != nullptr;
+  const InvMap* inv = no_gather ? nullptr : find_inverse(v2v_dev, mesh, gnr, gppr);
+  const bool have = ps->num_ptcls > 0 && ps->capacity > 0;
+  if (!inv || !have) PP_HIP_CHECK(hipMemsetAsync(scatter_w_dev, 0, sizeof(double) * (size_t)nverts, st));
+  if (have) {
     // The ring accumulation depends only on (mesh, particle->element assignment, ring geometry):
     // the forward and backward scatters of one step (gyroScatter.hpp is called twice per step,
     // pseudoXGCm.cpp:529-530) share it.
@@ -284,8 +440,13 @@ int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, do
       c_gnr = gnr;
       c_down = ringDown;
     }
-    k_scatter_mapped<<<grid_for((size_t)nverts * gnr * gppr), kBlock, 0, st>>>(
-        nverts, gnr, gppr, nvpe, s_ring->as<double>(), v2v_dev, scatter_w_dev);
+    if (inv)
+      k_scatter_gathered<<<grid_for((size_t)nverts * 16), kBlock, 0, st>>>(nverts, gppr, inv->off.as<int>(),
+                                                             inv->src.as<int>(), s_ring->as<double>(),
+                                                             scatter_w_dev);
+    else
+      k_scatter_mapped<<<grid_for((size_t)nverts * gnr * gppr), kBlock, 0, st>>>(
+          nverts, gnr, gppr, nvpe, s_ring->as<double>(), v2v_dev, scatter_w_dev);
   }
   PP_LAUNCH_CHECK();
   return PP_OK;

@@ -1212,3 +1212,36 @@ def test_cpp_driver_pseudoxgcm_reads_gmsh(synth, capi, tmp_path):
             assert "reading gmsh mesh" in out.stdout
     assert res["2.2"] == res["bin"]
     assert res["4.1"][0] == "20000"
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_gyro_scatter_gather_and_atomic_forms(ppo, synth, capi, dim):
+    """the per-vertex gather over the transposed ring map (maps created by the library) and the
+    atomic form (any other map pointer) give the oracle's field; gppr = 6 makes the addends
+    inexact, so the gather's fixed order is checked bit for bit and the atomic form to 1e-13.
+    Overwriting a library map through the API drops its transpose."""
+    pop = common.population_2d(synth, num_ptcls=5000) if dim == 2 else common.population_3d(synth, num_ptcls=5000)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
+    for gnr, gppr in ((3, 8), (4, 6)):
+        fo, _ = ppo.create_gyro_ring_mappings(mo, 0.03, gnr, gppr, 10.0, trig=1)
+        fg, bg = capi.create_gyro_ring_mappings(mg, 0.03, gnr, gppr, 10.0)
+        assert np.array_equal(fo, fg.to_host()[:len(fo)])
+        wo = ppo.gyro_scatter(mo, po, fo, 0.03, gnr, gppr)
+        w_gather = capi.gyro_scatter(mg, pg, fg, 0.03, gnr, gppr).to_host()
+        w_bk = capi.gyro_scatter(mg, pg, bg, 0.03, gnr, gppr).to_host()
+        copy = capi.DevArray.from_host(fo)
+        w_atomic = capi.gyro_scatter(mg, pg, copy, 0.03, gnr, gppr).to_host()
+        assert wo.sum() > 0
+        assert np.array_equal(wo, w_gather) and np.array_equal(wo, w_bk)
+        np.testing.assert_allclose(w_atomic, wo, rtol=1e-13, atol=0)
+        if gppr == 8:
+            assert np.array_equal(w_atomic, wo)
+        # edit the library's map through the API: vertex 0's entries point nowhere
+        edited = fo.copy()
+        edited[edited == 0] = -1
+        fg.upload(edited)
+        we = ppo.gyro_scatter(mo, po, edited, 0.03, gnr, gppr)
+        wg = capi.gyro_scatter(mg, pg, fg, 0.03, gnr, gppr).to_host()
+        assert we[0] == 0 and wg[0] == 0
+        np.testing.assert_allclose(wg, we, rtol=1e-13, atol=0)
