@@ -111,17 +111,16 @@ __global__ void k_pseudo_push160(int capacity, const unsigned char* __restrict__
   if (p >= capacity) return;
   const int e = slot_elem[p];
   if (e < 0) return;
-  if (mask[p]) {
-    double v = 10.3;
-    v = v * v * v / sqrt((double)p) / sqrt((double)e) + ped[e];
-    for (int i = 0; i < 17; ++i) dbls[i * stride + p] = v;
-    for (int i = 0; i < 4; ++i) nums[i * stride + p] = 4 * p + i;
-    lint[p] = p;
-  } else {
-    for (int i = 0; i < 17; ++i) dbls[i * stride + p] = 0;
-    for (int i = 0; i < 4; ++i) nums[i * stride + p] = -1;
-    lint[p] = 0;
-  }
+  // write-once streams (22 of them): non-temporal stores.  Live and padded lanes store through
+  // the SAME instructions (values selected, not branched): two half-masked stores per stream would
+  // leave the CU as partial lines, and partial lines are read-modify-writes at the HBM.
+  const bool live = mask[p];
+  double v = 10.3;
+  v = v * v * v / sqrt((double)p) / sqrt((double)e) + ped[e];
+  v = live ? v : 0.0;
+  for (int i = 0; i < 17; ++i) __builtin_nontemporal_store(v, dbls + i * stride + p);
+  for (int i = 0; i < 4; ++i) __builtin_nontemporal_store(live ? 4 * p + i : -1, nums + i * stride + p);
+  __builtin_nontemporal_store(live ? (long long)p : 0ll, lint + p);
 }
 
 int check_member(const pp_ps* ps, int m, int bytes, int ncomp, const char* what) {
