@@ -52,38 +52,45 @@ bool initialised();
 
 // Simple owning device buffer (grow-only reuse to avoid hipMalloc on the hot path).
 struct DevBuf {
-  void* p = nullptr;
-  size_t bytes = 0;
+  void* p = nullptr;     // usable pointer (base + skew)
+  void* base = nullptr;  // what hipMalloc returned
+  size_t bytes = 0;      // usable bytes from p
   ~DevBuf() { release(); }
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) {
-    o.p = nullptr;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), base(o.base), bytes(o.bytes) {
+    o.p = o.base = nullptr;
     o.bytes = 0;
   }
   DevBuf& operator=(DevBuf&& o) noexcept {
     if (this != &o) {
       release();
       p = o.p;
+      base = o.base;
       bytes = o.bytes;
-      o.p = nullptr;
+      o.p = o.base = nullptr;
       o.bytes = 0;
     }
     return *this;
   }
   void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
+    if (base) (void)hipFree(base);
+    p = base = nullptr;
     bytes = 0;
   }
-  // ensure capacity; contents are NOT preserved when it grows
-  hipError_t reserve(size_t n) {
+  // ensure capacity; contents are NOT preserved when it grows.  `skew` (a multiple of 512 B) shifts
+  // the usable pointer off the allocator's alignment: arrays that are streamed side by side should
+  // not all start at the same position of the HBM channel interleave.
+  hipError_t reserve(size_t n, size_t skew = 0) {
     if (n <= bytes) return hipSuccess;
     release();
     size_t want = n + n / 8 + 256;
-    hipError_t e = hipMalloc(&p, want);
-    if (e == hipSuccess) bytes = want;
+    hipError_t e = hipMalloc(&base, want + skew);
+    if (e == hipSuccess) {
+      bytes = want;
+      p = (char*)base + skew;
+    }
     return e;
   }
   template <class T>
@@ -92,6 +99,7 @@ struct DevBuf {
   }
   void swap(DevBuf& o) {
     std::swap(p, o.p);
+    std::swap(base, o.base);
     std::swap(bytes, o.bytes);
   }
 };

@@ -146,7 +146,8 @@ int alloc_members(pp_ps* ps, std::vector<pp::DevBuf>& bufs, int64_t stride, bool
   bufs.resize((size_t)ps->nmembers);
   for (int m = 0; m < ps->nmembers; ++m) {
     const size_t bytes = (size_t)stride * ps->member_ncomp[m] * ps->member_bytes[m];
-    PP_HIP_CHECK(bufs[m].reserve(std::max<size_t>(bytes, 16)));
+    static const bool no_skew = getenv("PP_NO_MEMBER_SKEW") != nullptr;
+    PP_HIP_CHECK(bufs[m].reserve(std::max<size_t>(bytes, 16), no_skew ? 0 : (size_t)((m + 1) * 5 % 32) * 512));
     if (zero && bytes) PP_HIP_CHECK(hipMemsetAsync(bufs[m].p, 0, bytes, pp::stream()));
   }
   return PP_OK;
