@@ -1,5 +1,6 @@
 // pp_internal.hpp -- shared host-side internals of libpumipic_hip.so (not part of the C-ABI).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>

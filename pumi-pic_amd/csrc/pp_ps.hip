@@ -479,8 +479,9 @@ __global__ void k_tile_count(int nchunks, int TP, const int* __restrict__ widths
   if (c < nchunks) ntl[c] = (widths[c] + TP - 1) / TP;
 }
 // ---- row-tiled histogram of new parents (SCS): thread = (old tile, row).  Particles that stay in
-// their element are counted in a register and leave as ONE atomic per thread; only movers issue
-// their own.  Lanes of a wave are different rows, so same-address contention inside a wave is gone.
+// their element are counted in a register and leave as ONE atomic per thread, and so do the movers
+// that share one of the first three other destinations of the thread's run.  Lanes of a wave are
+// different rows, so same-address contention inside a wave is gone.
 __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP, int G,
                               const int* __restrict__ tiles, const int* __restrict__ chunk_start,
                               const int* __restrict__ chunk_width, const int* __restrict__ r2e,
@@ -497,15 +498,29 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
   const int grp = (int)(g / C), r = (int)(g - (long long)grp * C);
   const int ntiles = *ntiles_dev;
   int cur = -1, e = -1, start = 0, run_p0 = 0;
-  unsigned stay = 0;  // bit b = column run_p0 + b of the current run stays in its element
-  auto flush = [&]() {
-    if (!stay) return;
-    int idx = atomicAdd(&ppe[e], __popc(stay));
-    while (stay) {
-      const int b = __ffs(stay) - 1;
-      stay &= stay - 1;
+  // Destination table of the current run (up to 32 columns of one row): slot 0 is the row's own
+  // element (the stayers), slots 1-3 the first three other destinations met -- particles of a row
+  // leave into the few neighbours of its element, so most movers share a destination with another
+  // mover of the same thread.  bit b of a mask = column run_p0 + b goes to that key.  A particle
+  // whose destination finds no slot issues its own atomic at once.
+  int key1 = -1, key2 = -1, key3 = -1;
+  unsigned m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+  auto flush_one = [&](int key, unsigned m) {
+    if (!m) return;
+    int idx = atomicAdd(&ppe[key], __popc(m));
+    while (m) {
+      const int b = __ffs(m) - 1;
+      m &= m - 1;
       rank[start + (run_p0 + b) * C] = idx++;
     }
+  };
+  auto flush = [&]() {
+    flush_one(e, m0);
+    flush_one(key1, m1);
+    flush_one(key2, m2);
+    flush_one(key3, m3);
+    m0 = m1 = m2 = m3 = 0;
+    key1 = key2 = key3 = -1;
   };
   for (int k = 0; k < G; ++k) {
     const int tile = grp * G + k;
@@ -536,16 +551,38 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
       for (int j = 0; j < 8; ++j) {
         if (pb + j >= pend) continue;
         const int ne_ = nel[j];
+        const unsigned bit = 1u << (pb + j - run_p0);
+        bool deferred = false;
         int rk = -1;
         if (mk[j] && ne_ != -1) {
-          if (ne_ < 0 || ne_ >= ne)
+          if (ne_ < 0 || ne_ >= ne) {
             tot->invalid = 1;
-          else if (ne_ == e)
-            stay |= 1u << (pb + j - run_p0);
-          else
-            rk = atomicAdd(&ppe[ne_], 1);
+          } else {
+            deferred = true;
+            if (ne_ == e) {
+              m0 |= bit;
+            } else if (ne_ == key1) {
+              m1 |= bit;
+            } else if (ne_ == key2) {
+              m2 |= bit;
+            } else if (ne_ == key3) {
+              m3 |= bit;
+            } else if (key1 < 0) {
+              key1 = ne_;
+              m1 = bit;
+            } else if (key2 < 0) {
+              key2 = ne_;
+              m2 = bit;
+            } else if (key3 < 0) {
+              key3 = ne_;
+              m3 = bit;
+            } else {
+              deferred = false;
+              rk = atomicAdd(&ppe[ne_], 1);
+            }
+          }
         }
-        rank[start + (pb + j) * C] = rk;
+        if (!deferred) rank[start + (pb + j) * C] = rk;
       }
     }
   }
