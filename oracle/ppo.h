@@ -209,6 +209,9 @@ void ppo_interp2d_vector(const ppo_ps* ps, int m_x, const double* data3, double 
 void ppo_interp3d_field(const ppo_ps* ps, int m_x, int nx, int ny, int nz, const double* gridx,
                         const double* gridy, const double* gridz, const double* data, double* out);
 
+/* OpenMP threads of the per-particle loops (1 at load; results are thread-count independent) */
+void ppo_set_threads(int n);
+int ppo_max_threads(void);
 /* particle_structs/test/Distribute.h:28-89 (uniform strategy, counter-based draws) */
 void ppo_redistribute_particles(const ppo_ps* ps, double percent_moved, unsigned long long seed,
                                 int* new_elems);

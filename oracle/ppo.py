@@ -61,6 +61,9 @@ def lib():
     if _lib is None:
         build()
         L = C.CDLL(_LIB_PATH)
+        L.ppo_set_threads.argtypes = [C.c_int]
+        L.ppo_max_threads.restype = C.c_int
+        L.ppo_set_threads(1)  # Kokkos::Serial semantics unless a caller asks for more
         L.ppo_mesh_create.restype = C.POINTER(_MeshS)
         L.ppo_mesh_create.argtypes = [C.c_int, C.c_int, c_double_p, C.c_int, c_int_p, c_int_p]
         L.ppo_mesh_destroy.argtypes = [C.POINTER(_MeshS)]
@@ -647,3 +650,12 @@ def redistribute_particles(ps, percent_moved, seed=0):
     L.ppo_redistribute_particles.restype = None
     L.ppo_redistribute_particles(ps.p, float(percent_moved), int(seed), _ip(out))
     return out[:ps.capacity()]
+
+
+def set_threads(n):
+    """OpenMP threads of the per-particle loops (results do not depend on it)."""
+    lib().ppo_set_threads(int(n))
+
+
+def max_threads():
+    return int(lib().ppo_max_threads())

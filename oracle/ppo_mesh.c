@@ -358,3 +358,16 @@ void ppo_sincos(double x, double* s, double* c) {
     default: *s = -cs; *c = sn; break;
   }
 }
+
+/* Threads of the `#pragma omp` loops (the per-particle loops of the pushes and walks; every
+ * iteration touches its own slot only, so the results do not depend on the thread count).
+ * The library starts with ONE thread (Kokkos::Serial semantics); bench.py raises it for the
+ * all-cores baseline of SURVEY 8(d). */
+#ifdef _OPENMP
+#include <omp.h>
+void ppo_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+int ppo_max_threads(void) { return omp_get_num_procs(); }
+#else
+void ppo_set_threads(int n) { (void)n; }
+int ppo_max_threads(void) { return 1; }
+#endif

@@ -87,6 +87,7 @@ void ppo_elliptical_push(ppo_ps* ps, const ppo_mesh* mesh, int m_xtgt, int m_b, 
                          double h, double k, double d, double deg, int trigmode) {
   slots s = get_slots(ps);
   const size_t A = (size_t)ps->alloc;
+#pragma omp parallel for schedule(static)
   for (int pid = 0; pid < s.cap; ++pid) {
     if (!s.mask[pid]) continue;
     const int e = s.elem[pid];
@@ -117,6 +118,7 @@ void ppo_toroidal_push(ppo_ps* ps, const ppo_mesh* mesh, int m_x, int m_xtgt, in
                        double h, double k, double d, double deg, int trigmode) {
   slots s = get_slots(ps);
   const size_t A = (size_t)ps->alloc;
+#pragma omp parallel for schedule(static)
   for (int pid = 0; pid < s.cap; ++pid) {
     if (!s.mask[pid]) continue;
     const int e = s.elem[pid];

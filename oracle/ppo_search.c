@@ -50,6 +50,7 @@ static void gather_tet(const ppo_mesh* mesh, int elm, int verts[4], ppo_v3 M[4])
 }
 static int min_done(const int* ptcl_done, int n) {
   int mn = 1; /* callers guarantee n>0 */
+#pragma omp parallel for schedule(static) reduction(min : mn)
   for (int i = 0; i < n; ++i)
     if (ptcl_done[i] < mn) mn = ptcl_done[i];
   return mn;
@@ -84,6 +85,7 @@ int ppo_search_mesh_2d(const ppo_mesh* mesh, ppo_ps* ps, int m_x, int m_xtgt, in
     goto done;
   }
   /* hpp:1045-1062 */
+  #pragma omp parallel for schedule(static)
   for (int pid = 0; pid < cap; ++pid) {
     if (slot_elem[pid] < 0) continue;
     if (slot_mask[pid]) {
@@ -100,6 +102,7 @@ int ppo_search_mesh_2d(const ppo_mesh* mesh, ppo_ps* ps, int m_x, int m_xtgt, in
   }
   while (!found) {
     /* checkCurrentElm hpp:1067-1084 */
+    #pragma omp parallel for schedule(static)
     for (int pid = 0; pid < cap; ++pid) {
       if (slot_mask[pid] && !ptcl_done[pid]) {
         const int searchElm = elem_ids[pid];
@@ -113,6 +116,7 @@ int ppo_search_mesh_2d(const ppo_mesh* mesh, ppo_ps* ps, int m_x, int m_xtgt, in
       }
     }
     /* checkExposedEdges hpp:1086-1095 */
+    #pragma omp parallel for schedule(static)
     for (int pid = 0; pid < cap; ++pid) {
       if (slot_mask[pid] && !ptcl_done[pid]) {
         const int exposed = mesh->side_exposed[lastEdge[pid]];
@@ -121,6 +125,7 @@ int ppo_search_mesh_2d(const ppo_mesh* mesh, ppo_ps* ps, int m_x, int m_xtgt, in
       }
     }
     /* setNextElm hpp:1099-1117 */
+    #pragma omp parallel for schedule(static)
     for (int pid = 0; pid < cap; ++pid) {
       if (slot_mask[pid] && !ptcl_done[pid])
         elem_ids[pid] = other_elem(mesh, lastEdge[pid], elem_ids[pid]);
@@ -223,6 +228,7 @@ static void default_functor(void* ctx, const ppo_mesh* mesh, ppo_ps* ps, int* el
   int* slot_elem = (int*)xcalloc((size_t)cap, sizeof(int));
   unsigned char* slot_mask = (unsigned char*)xcalloc((size_t)cap, 1);
   ppo_ps_slot_info(ps, slot_elem, slot_mask);
+#pragma omp parallel for schedule(static)
   for (int pid = 0; pid < cap; ++pid) {
     if (slot_mask[pid] && !ptcl_done[pid]) {
       const int bridge = lastExit[pid];
@@ -293,6 +299,7 @@ int ppo_trace_particle_through_mesh(const ppo_mesh* mesh, ppo_ps* ps, int m_x, i
   for (int pid = 0; pid < cap; ++pid)
     if (slot_elem[pid] < 0) ptcl_done[pid] = 1;
   /* finishUnmoved tpp:525-533 */
+  #pragma omp parallel for schedule(static)
   for (int pid = 0; pid < cap; ++pid) {
     if (slot_mask[pid]) {
       const ppo_v3 d = ppo_sub3(vec3(ps, m_xtgt, pid), vec3(ps, m_x, pid));
@@ -306,6 +313,7 @@ int ppo_trace_particle_through_mesh(const ppo_mesh* mesh, ppo_ps* ps, int m_x, i
     }
   }
   /* check_initial_parents tpp:72-145 */
+  #pragma omp parallel for schedule(static) reduction(+ : notIn)
   for (int pid = 0; pid < cap; ++pid) {
     if (slot_mask[pid] && !ptcl_done[pid]) {
       const int searchElm = elem_ids[pid];
@@ -334,6 +342,7 @@ int ppo_trace_particle_through_mesh(const ppo_mesh* mesh, ppo_ps* ps, int m_x, i
   }
   while (!found) {
     /* find_exit_face tpp:231-363 */
+    #pragma omp parallel for schedule(static)
     for (int pid = 0; pid < cap; ++pid) {
       if (!(slot_mask[pid] && !ptcl_done[pid])) continue;
       const int searchElm = elem_ids[pid];
@@ -421,6 +430,7 @@ int ppo_trace_particle_through_mesh(const ppo_mesh* mesh, ppo_ps* ps, int m_x, i
     func(ctx, mesh, ps, elem_ids, inter_faces, lastExit, inter_points, ptcl_done, m_x, m_xtgt);
     /* set_new_element tpp:389-416.  A functor that leaves a particle unfinished on an exposed side
      * makes the reference read past the side's single up-adjacent element; here it leaves (-1). */
+    #pragma omp parallel for schedule(static)
     for (int pid = 0; pid < cap; ++pid)
       if (slot_mask[pid] && !ptcl_done[pid]) {
         const int b = lastExit[pid];
