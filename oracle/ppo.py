@@ -60,6 +60,7 @@ def lib():
     global _lib
     if _lib is None:
         build()
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # idle threads must not spin on shared hosts
         L = C.CDLL(_LIB_PATH)
         L.ppo_set_threads.argtypes = [C.c_int]
         L.ppo_max_threads.restype = C.c_int
@@ -658,4 +659,16 @@ def set_threads(n):
 
 
 def max_threads():
-    return int(lib().ppo_max_threads())
+    """host cores this process may really use: processors, affinity mask and cgroup CPU quota"""
+    n = int(lib().ppo_max_threads())
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
