@@ -186,6 +186,12 @@ class Stepper:
             owners = ppdist.element_block_owners(w["ne"], self.world)
             self.owners = capi.DevArray.from_host(owners)
             self.safe = capi.DevArray.from_host((owners == self.rank).astype(np.uint8))
+            if w.get("safe_layers", 0) > 0:
+                # PICpart safe zone: the core plus `safe_layers` breadth-first layers of the replicated
+                # mesh (bfsBufferLayers, pumipic_part_construct.cpp:407-437); particles migrate only
+                # when they leave it
+                self.safe, _ = capi.bfs_buffer_layers(self.mesh, self.owners, self.rank, self.world,
+                                                      w["safe_layers"], w["safe_layers"])
             self.moved = 0
         if name in ("c3", "2dc3", "c5"):
             self.fwd, self.bkwd = capi.create_gyro_ring_mappings(self.mesh)
@@ -314,6 +320,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "2d", "2dc3"])
+    ap.add_argument("--safe-layers", type=int, default=0,
+                    help="c5: breadth-first element layers around the owned block that are still safe "
+                         "(0 = BASELINE's rule: a particle migrates as soon as it leaves its owner's block)")
     ap.add_argument("--c4-elems", type=int, default=1_000_000, help="c4: number of elements")
     ap.add_argument("--structure", default="scs", choices=["scs", "csr"], help="c4: particle structure")
     ap.add_argument("--particles", type=int, default=10_000_000, help="particles per GPU")
@@ -350,6 +359,7 @@ def main():
         st = StepperC4(capi, w)
     else:
         w = build_workload(pp, capi, a.workload, a.particles, rank, world, a.deg, a.remainder, a.mesh)
+        w["safe_layers"] = a.safe_layers
         st = Stepper(pp, capi, w, a.workload, a.deg)
 
     def barrier():

@@ -318,6 +318,19 @@ int pp_closest_point_on_triangle(int n, const double* tris_dev, int tri_stride,
 int pp_set_unsafe_procs(const pp_ps* ps, const int* elems_dev, const unsigned char* safe_dev,
                         const int* owners_dev, int comm_rank, int* new_elems_dev,
                         int* new_procs_dev);
+/* PICpart safe zone and buffer by breadth-first layers, src/pumipic_part_construct.cpp:387-468.
+ * bfsBufferLayers: starting from the elements this rank owns, every layer adds the elements that
+ * share a bridge entity (bridge_dim 0 = vertex, dim-1 = side) with a visited one; is_safe_dev[e] =
+ * reached within safe_layers, has_part_host[r] = 1 when an element owned by r is reached within
+ * ghost_layers (the parts this rank buffers).  bfsSafeInward (buffer BFS + "full" safe method,
+ * :439-468): safe = own elements + buffered elements at least safe_layers away from the unbuffered
+ * region.  safe arrays are what pp_set_unsafe_procs takes. */
+int pp_bfs_buffer_layers(const pp_mesh* mesh, int bridge_dim, int comm_rank, int comm_size,
+                         int safe_layers, int ghost_layers, const int* owner_dev,
+                         unsigned char* is_safe_dev, int* has_part_host);
+int pp_bfs_safe_inward(const pp_mesh* mesh, int bridge_dim, int comm_rank, int comm_size,
+                       int safe_layers, const int* owner_dev, const int* has_part_host,
+                       unsigned char* safe_dev);
 /* SellCSigma::migrate scs/SCS_migrate.h:29-137 send side: count per destination rank
  * (send_counts_host[nranks]) ... */
 int pp_ps_migrate_count(const pp_ps* ps, const int* new_element_dev, const int* new_process_dev,

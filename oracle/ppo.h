@@ -209,6 +209,12 @@ void ppo_interp2d_vector(const ppo_ps* ps, int m_x, const double* data3, double 
 void ppo_interp3d_field(const ppo_ps* ps, int m_x, int nx, int ny, int nz, const double* gridx,
                         const double* gridy, const double* gridz, const double* data, double* out);
 
+/* src/pumipic_part_construct.cpp:387-468 (bridge_dim 0 = vertices, otherwise sides) */
+void ppo_bfs_buffer_layers(const ppo_mesh* mesh, int bridge_dim, int rank, int comm_size,
+                           int safe_layers, int ghost_layers, const int* owner,
+                           unsigned char* is_safe, int* has_part);
+void ppo_bfs_safe_inward(const ppo_mesh* mesh, int bridge_dim, int rank, int safe_layers,
+                         const int* owner, const int* has_part, unsigned char* safe);
 /* OpenMP threads of the per-particle loops (1 at load; results are thread-count independent) */
 void ppo_set_threads(int n);
 int ppo_max_threads(void);

@@ -672,3 +672,31 @@ def max_threads():
     except (OSError, ValueError):
         pass
     return max(1, n)
+
+
+def bfs_buffer_layers(mesh, owner, rank, comm_size, safe_layers, ghost_layers, bridge_dim=0):
+    """bfsBufferLayers (pumipic_part_construct.cpp:407-437) -> (is_safe[nelems] u8, has_part[comm_size])"""
+    owner = np.ascontiguousarray(owner, dtype=np.int32)
+    safe = np.zeros(max(mesh.nelems, 1), dtype=np.uint8)
+    part = np.zeros(comm_size, dtype=np.int32)
+    L = lib()
+    L.ppo_bfs_buffer_layers.restype = None
+    L.ppo_bfs_buffer_layers.argtypes = [C.POINTER(_MeshS), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        c_int_p, c_ubyte_p, c_int_p]
+    L.ppo_bfs_buffer_layers(mesh.p, bridge_dim, rank, comm_size, safe_layers, ghost_layers, _ip(owner),
+                            safe.ctypes.data_as(c_ubyte_p), _ip(part))
+    return safe[:mesh.nelems], part
+
+
+def bfs_safe_inward(mesh, owner, rank, safe_layers, has_part, bridge_dim=0):
+    """bfsSafeInward (pumipic_part_construct.cpp:439-468) -> safe[nelems] u8"""
+    owner = np.ascontiguousarray(owner, dtype=np.int32)
+    part = np.ascontiguousarray(has_part, dtype=np.int32)
+    safe = np.zeros(max(mesh.nelems, 1), dtype=np.uint8)
+    L = lib()
+    L.ppo_bfs_safe_inward.restype = None
+    L.ppo_bfs_safe_inward.argtypes = [C.POINTER(_MeshS), C.c_int, C.c_int, C.c_int, c_int_p, c_int_p,
+                                      c_ubyte_p]
+    L.ppo_bfs_safe_inward(mesh.p, bridge_dim, rank, safe_layers, _ip(owner), _ip(part),
+                          safe.ctypes.data_as(c_ubyte_p))
+    return safe[:mesh.nelems]

@@ -644,3 +644,68 @@ void ppo_closest_point_on_triangle(const double abc[9], const double p[3], int w
   else
     closest_plain(a, b, c, pp, q, reg);
 }
+
+/* ------------------------------------------------------------------ PICpart safe zone / buffer
+ * src/pumipic_part_construct.cpp:387-468 (BFS, bfsBufferLayers, bfsSafeInward), kernel by kernel */
+static int bridge_adj(const ppo_mesh* mesh, int bridge_dim, const int** off, const int** vals) {
+  if (bridge_dim == 0) {
+    *off = mesh->vert2elems_off;
+    *vals = mesh->vert2elems;
+    return mesh->nverts;
+  }
+  *off = mesh->side2elems_off;
+  *vals = mesh->side2elems;
+  return mesh->nsides;
+}
+static void bfs_sweep(int nb, const int* off, const int* vals, const int* visited, int* next) {
+  for (int b = 0; b < nb; ++b) { /* :387-405 */
+    const int deg = off[b + 1] - off[b], first = off[b];
+    int is_visited_here = 0;
+    for (int j = 0; j < deg; ++j)
+      if (visited[vals[first + j]]) is_visited_here = 1;
+    const int loops = deg * is_visited_here;
+    for (int j = 0; j < loops; ++j) next[vals[first + j]] = 1;
+  }
+}
+void ppo_bfs_buffer_layers(const ppo_mesh* mesh, int bridge_dim, int rank, int comm_size,
+                           int safe_layers, int ghost_layers, const int* owner,
+                           unsigned char* is_safe, int* has_part) {
+  const int ne = mesh->nelems;
+  int* visited = (int*)xcalloc((size_t)ne + 1, sizeof(int));
+  int* next = (int*)xcalloc((size_t)ne + 1, sizeof(int));
+  for (int e = 0; e < ne; ++e) { /* initVisit :414-418 */
+    visited[e] = (owner[e] == rank);
+    is_safe[e] = (unsigned char)visited[e];
+    next[e] = visited[e];
+  }
+  for (int r = 0; r < comm_size; ++r) has_part[r] = 0;
+  has_part[rank] = 1; /* initSelfPart */
+  const int *off, *vals;
+  const int nb = bridge_adj(mesh, bridge_dim, &off, &vals);
+  for (int i = 0; i < ghost_layers || i < safe_layers; ++i) {
+    bfs_sweep(nb, off, vals, visited, next);
+    for (int e = 0; e < ne; ++e) { /* copyVisit :427-435 */
+      visited[e] = next[e];
+      if (i == safe_layers - 1) is_safe[e] = (unsigned char)next[e];
+      if (i < ghost_layers && visited[e]) has_part[owner[e]] = 1;
+    }
+  }
+  free(visited);
+  free(next);
+}
+void ppo_bfs_safe_inward(const ppo_mesh* mesh, int bridge_dim, int rank, int safe_layers,
+                         const int* owner, const int* has_part, unsigned char* safe) {
+  const int ne = mesh->nelems;
+  int* visited = (int*)xcalloc((size_t)ne + 1, sizeof(int));
+  int* next = (int*)xcalloc((size_t)ne + 1, sizeof(int));
+  for (int e = 0; e < ne; ++e) visited[e] = next[e] = !has_part[owner[e]]; /* :444-448 */
+  const int *off, *vals;
+  const int nb = bridge_adj(mesh, bridge_dim, &off, &vals);
+  for (int i = 0; i < safe_layers; ++i) {
+    bfs_sweep(nb, off, vals, visited, next);
+    for (int e = 0; e < ne; ++e) visited[e] = next[e];
+  }
+  for (int e = 0; e < ne; ++e) safe[e] = (unsigned char)(!visited[e] || owner[e] == rank); /* :461-466 */
+  free(visited);
+  free(next);
+}

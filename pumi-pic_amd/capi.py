@@ -105,6 +105,8 @@ SYMBOLS = {
     "pp_trace_not_found": (_I, [_V, _V, _V, c_int_p]),
     "pp_redistribute_particles": (_I, [_V, C.c_double, C.c_ulonglong, _V]),
     "pp_boris_push_fields": (_I, [_V, _V, _I, _I, _I, _V, _V, _V] + [C.c_double] * 4 + [_I, _I, _I, C.c_double, c_int_p]),
+    "pp_bfs_buffer_layers": (_I, [_V, _I, _I, _I, _I, _I, _V, _V, c_int_p]),
+    "pp_bfs_safe_inward": (_I, [_V, _I, _I, _I, _I, _V, c_int_p, _V]),
     "pp_search_mesh_3d": (_I, [_V, _V, _I, _I, _I, _V, _I, _V, _V, _I, c_int_p]),
     "pp_push_search": (_I, [_V, _V, _I, _I, _I, _I, _D, _D, _D, _D, _V, _I, _I, c_int_p]),
     "pp_create_gyro_ring_mappings": (_I, [_V, _D, _I, _I, _D, _V, _V]),
@@ -701,3 +703,21 @@ def boris_push_fields(mesh, ps, efield_vtx, bgrid, gridx0, gridz0, dx, dz, nx, n
                                      elem_ids.ptr if elem_ids is not None else None, efield_vtx.ptr,
                                      bgrid.ptr, gridx0, gridz0, dx, dz, nx, nz, int(cyl), dt, C.byref(bad)))
     return bad.value
+
+
+def bfs_buffer_layers(mesh, owner_dev, rank, comm_size, safe_layers, ghost_layers, bridge_dim=0):
+    """bfsBufferLayers (pumipic_part_construct.cpp:407-437) -> (is_safe DevArray u8, has_part int32[comm_size])"""
+    safe = DevArray(max(mesh.nelems, 1), np.uint8)
+    part = np.zeros(comm_size, dtype=np.int32)
+    check(lib().pp_bfs_buffer_layers(mesh.p, bridge_dim, rank, comm_size, safe_layers, ghost_layers,
+                                     owner_dev.ptr, safe.ptr, part.ctypes.data_as(c_int_p)))
+    return safe, part
+
+
+def bfs_safe_inward(mesh, owner_dev, rank, comm_size, safe_layers, has_part, bridge_dim=0):
+    """bfsSafeInward (pumipic_part_construct.cpp:439-468) -> safe DevArray u8"""
+    part = np.ascontiguousarray(has_part, dtype=np.int32)
+    safe = DevArray(max(mesh.nelems, 1), np.uint8)
+    check(lib().pp_bfs_safe_inward(mesh.p, bridge_dim, rank, comm_size, safe_layers, owner_dev.ptr,
+                                   part.ctypes.data_as(c_int_p), safe.ptr))
+    return safe

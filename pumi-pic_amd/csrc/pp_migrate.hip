@@ -148,6 +148,65 @@ int build_rec_table(const pp_ps* ps, RecTable& t) {
   t.rec_words = ((2 + nw + 3) / 4) * 4;
   return PP_OK;
 }
+// ---- PICpart safe zone / buffer by breadth-first layers (pumipic_part_construct.cpp:387-468)
+__global__ void k_bfs_init(int ne, const int* __restrict__ owner, int rank, int* __restrict__ visited,
+                           int* __restrict__ next, unsigned char* __restrict__ safe) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  const int own = owner[e] == rank;
+  visited[e] = next[e] = own;
+  safe[e] = (unsigned char)own;
+}
+// BFS(): every bridge entity (vertex or side) with a visited adjacent element visits all of them
+__global__ void k_bfs_sweep(int nbridges, const int* __restrict__ off, const int* __restrict__ vals,
+                            const int* __restrict__ visited, int* __restrict__ next) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbridges) return;
+  const int first = off[b], last = off[b + 1];
+  bool here = false;
+  for (int j = first; j < last; ++j) here |= visited[vals[j]] != 0;
+  if (here)
+    for (int j = first; j < last; ++j) next[vals[j]] = 1;
+}
+__global__ void k_bfs_copy(int ne, int i, int safe_layers, int ghost_layers,
+                           const int* __restrict__ owner, int* __restrict__ visited,
+                           const int* __restrict__ next, unsigned char* __restrict__ safe,
+                           int* __restrict__ has_part) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  const int v = next[e];
+  visited[e] = v;
+  if (i == safe_layers - 1) safe[e] = (unsigned char)v;
+  if (i < ghost_layers && v) has_part[owner[e]] = 1;
+}
+__global__ void k_bfs_inward_init(int ne, const int* __restrict__ owner,
+                                  const int* __restrict__ has_part, int* __restrict__ visited,
+                                  int* __restrict__ next) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  visited[e] = next[e] = !has_part[owner[e]];
+}
+__global__ void k_bfs_inward_set(int ne, const int* __restrict__ owner, int rank,
+                                 const int* __restrict__ visited, unsigned char* __restrict__ safe) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  safe[e] = (unsigned char)(!visited[e] || owner[e] == rank);
+}
+int bridge_adjacency(const pp_mesh* mesh, int bridge_dim, int* n, const int** off, const int** vals) {
+  if (bridge_dim == 0) {
+    *n = mesh->nverts;
+    *off = mesh->d_vert2elems_off.as<int>();
+    *vals = mesh->d_vert2elems.as<int>();
+  } else if (bridge_dim == mesh->dim - 1) {
+    *n = mesh->nsides;
+    *off = mesh->d_side2elems_off.as<int>();
+    *vals = mesh->d_side2elems.as<int>();
+  } else {
+    pp::set_error("PICpart BFS: bridge_dim must be 0 (vertices) or dim-1 (sides)");
+    return PP_EINVAL;
+  }
+  return PP_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -296,6 +355,76 @@ int pp_ps_migrate_pack(const pp_ps* ps, int* new_element_dev, const int* new_pro
       (long long*)send_gid_dev, a);
   PP_LAUNCH_CHECK();
   PP_HIP_CHECK(hipStreamSynchronize(st));  // `start` and `cur` go out of scope
+  return PP_OK;
+}
+
+int pp_bfs_buffer_layers(const pp_mesh* mesh, int bridge_dim, int comm_rank, int comm_size,
+                         int safe_layers, int ghost_layers, const int* owner_dev,
+                         unsigned char* is_safe_dev, int* has_part_host) {
+  PP_REQUIRE(mesh && owner_dev && is_safe_dev && has_part_host, "pp_bfs_buffer_layers: null argument");
+  PP_REQUIRE(comm_size > 0 && comm_rank >= 0 && comm_rank < comm_size && safe_layers >= 0 &&
+                 ghost_layers >= 0,
+             "pp_bfs_buffer_layers: bad rank / layer counts");
+  int nb;
+  const int *off, *vals;
+  int rc = bridge_adjacency(mesh, bridge_dim, &nb, &off, &vals);
+  if (rc) return rc;
+  hipStream_t st = pp::stream();
+  const int ne = mesh->nelems;
+  pp::DevBuf visited, next, part;
+  PP_HIP_CHECK(visited.reserve(sizeof(int) * (size_t)std::max(ne, 1)));
+  PP_HIP_CHECK(next.reserve(sizeof(int) * (size_t)std::max(ne, 1)));
+  PP_HIP_CHECK(part.reserve(sizeof(int) * (size_t)comm_size));
+  PP_HIP_CHECK(hipMemsetAsync(part.p, 0, sizeof(int) * (size_t)comm_size, st));
+  const int one = 1;  // initSelfPart
+  PP_HIP_CHECK(hipMemcpyAsync(part.as<int>() + comm_rank, &one, sizeof(int), hipMemcpyHostToDevice, st));
+  if (ne > 0) {
+    k_bfs_init<<<grid_for(ne), kBlock, 0, st>>>(ne, owner_dev, comm_rank, visited.as<int>(),
+                                               next.as<int>(), is_safe_dev);
+    for (int i = 0; i < ghost_layers || i < safe_layers; ++i) {
+      if (nb > 0)
+        k_bfs_sweep<<<grid_for(nb), kBlock, 0, st>>>(nb, off, vals, visited.as<int>(), next.as<int>());
+      k_bfs_copy<<<grid_for(ne), kBlock, 0, st>>>(ne, i, safe_layers, ghost_layers, owner_dev,
+                                                 visited.as<int>(), next.as<int>(), is_safe_dev,
+                                                 part.as<int>());
+    }
+  }
+  PP_LAUNCH_CHECK();
+  PP_HIP_CHECK(hipMemcpyAsync(has_part_host, part.p, sizeof(int) * (size_t)comm_size,
+                              hipMemcpyDeviceToHost, st));
+  PP_HIP_CHECK(hipStreamSynchronize(st));
+  return PP_OK;
+}
+
+int pp_bfs_safe_inward(const pp_mesh* mesh, int bridge_dim, int comm_rank, int comm_size,
+                       int safe_layers, const int* owner_dev, const int* has_part_host,
+                       unsigned char* safe_dev) {
+  PP_REQUIRE(mesh && owner_dev && has_part_host && safe_dev, "pp_bfs_safe_inward: null argument");
+  PP_REQUIRE(comm_size > 0 && comm_rank >= 0 && comm_rank < comm_size && safe_layers >= 0,
+             "pp_bfs_safe_inward: bad rank / layer count");
+  int nb;
+  const int *off, *vals;
+  int rc = bridge_adjacency(mesh, bridge_dim, &nb, &off, &vals);
+  if (rc) return rc;
+  hipStream_t st = pp::stream();
+  const int ne = mesh->nelems;
+  if (ne == 0) return PP_OK;
+  pp::DevBuf visited, next, part;
+  PP_HIP_CHECK(visited.reserve(sizeof(int) * (size_t)ne));
+  PP_HIP_CHECK(next.reserve(sizeof(int) * (size_t)ne));
+  PP_HIP_CHECK(part.reserve(sizeof(int) * (size_t)comm_size));
+  PP_HIP_CHECK(hipMemcpyAsync(part.p, has_part_host, sizeof(int) * (size_t)comm_size,
+                              hipMemcpyHostToDevice, st));
+  k_bfs_inward_init<<<grid_for(ne), kBlock, 0, st>>>(ne, owner_dev, part.as<int>(), visited.as<int>(),
+                                                    next.as<int>());
+  for (int i = 0; i < safe_layers; ++i) {
+    if (nb > 0)
+      k_bfs_sweep<<<grid_for(nb), kBlock, 0, st>>>(nb, off, vals, visited.as<int>(), next.as<int>());
+    PP_HIP_CHECK(hipMemcpyAsync(visited.p, next.p, sizeof(int) * (size_t)ne, hipMemcpyDeviceToDevice, st));
+  }
+  k_bfs_inward_set<<<grid_for(ne), kBlock, 0, st>>>(ne, owner_dev, comm_rank, visited.as<int>(), safe_dev);
+  PP_LAUNCH_CHECK();
+  PP_HIP_CHECK(hipStreamSynchronize(st));  // the temporaries go out of scope
   return PP_OK;
 }
 

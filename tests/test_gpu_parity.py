@@ -1245,3 +1245,23 @@ def test_gyro_scatter_gather_and_atomic_forms(ppo, synth, capi, dim):
         wg = capi.gyro_scatter(mg, pg, fg, 0.03, gnr, gppr).to_host()
         assert we[0] == 0 and wg[0] == 0
         np.testing.assert_allclose(wg, we, rtol=1e-13, atol=0)
+
+
+@pytest.mark.parametrize("dim,bridge", [(2, 0), (2, 1), (3, 0), (3, 2)])
+def test_picpart_bfs_layers_exact(ppo, synth, capi, dim, bridge):
+    """pp_bfs_buffer_layers / pp_bfs_safe_inward equal the oracle's restatement of
+    pumipic_part_construct.cpp:387-468 for every rank of an 8-way element-block partition."""
+    coords, e2v, cls = synth.annulus_tri(n_b=12, n_theta=48, band_width=3) if dim == 2 else \
+        synth.torus_tet(n_b=5, n_theta=16, n_planes=8)
+    mo, mg = ppo.Mesh(dim, coords, e2v, cls), capi.Mesh(dim, coords, e2v, cls)
+    ne, nranks = mo.nelems, 8
+    owner = (np.arange(ne, dtype=np.int64) * nranks // ne).astype(np.int32)
+    d_owner = capi.DevArray.from_host(owner)
+    for rank in (0, 3, 7):
+        for safe_layers, ghost_layers in ((0, 0), (1, 3), (3, 2), (2, 6)):
+            so, po_ = ppo.bfs_buffer_layers(mo, owner, rank, nranks, safe_layers, ghost_layers, bridge)
+            sg, pg_ = capi.bfs_buffer_layers(mg, d_owner, rank, nranks, safe_layers, ghost_layers, bridge)
+            assert np.array_equal(so, sg.to_host()[:ne]) and np.array_equal(po_, pg_)
+            io = ppo.bfs_safe_inward(mo, owner, rank, safe_layers, po_, bridge)
+            ig = capi.bfs_safe_inward(mg, d_owner, rank, nranks, safe_layers, pg_, bridge)
+            assert np.array_equal(io, ig.to_host()[:ne])

@@ -540,3 +540,48 @@ def test_redistribute_particles_statistics(ppo):
     assert cnt.min() > 0 and cnt.max() < 4 * cnt.mean()
     assert np.array_equal(ppo.redistribute_particles(ps, 0.0, seed=1)[live], se[live])
     assert (ppo.redistribute_particles(ps, 1.0, seed=1)[live] != se[live]).mean() > 0.99
+
+
+@pytest.mark.parametrize("dim,bridge", [(2, 0), (2, 1), (3, 0), (3, 2)])
+def test_picpart_bfs_layers(ppo, synth, dim, bridge):
+    """bfsBufferLayers / bfsSafeInward (pumipic_part_construct.cpp:387-468) against an independent
+    breadth-first distance over the element graph: safe = within safe_layers of the core, buffered
+    parts = owners met within ghost_layers, inward safe = own + buffered elements at least
+    safe_layers+1 away from the unbuffered region."""
+    coords, e2v, cls = synth.annulus_tri(n_b=10, n_theta=40, band_width=3) if dim == 2 else \
+        synth.torus_tet(n_b=4, n_theta=12, n_planes=8)
+    mesh = ppo.Mesh(dim, coords, e2v, cls)
+    ne, nranks, rank = mesh.nelems, 5, 2
+    owner = (np.arange(ne, dtype=np.int64) * nranks // ne).astype(np.int32)
+    off, vals = (mesh.vert2elems_off, mesh.vert2elems) if bridge == 0 else (mesh.side2elems_off, mesh.side2elems)
+
+    def distance_from(seed):
+        dist = np.where(seed, 0, -1)
+        level, frontier = 0, seed.copy()
+        while frontier.any():
+            touched = np.zeros(len(off) - 1, dtype=bool)
+            rows = np.repeat(np.arange(len(off) - 1), np.diff(off))
+            np.logical_or.at(touched, rows, frontier[vals])
+            nxt = np.zeros(ne, dtype=bool)
+            nxt[vals[touched[rows]]] = True
+            nxt &= dist < 0
+            level += 1
+            dist[nxt] = level
+            frontier = nxt
+        return dist
+
+    d_core = distance_from(owner == rank)
+    for safe_layers, ghost_layers in ((0, 0), (1, 3), (2, 2), (3, 5)):
+        safe, part = ppo.bfs_buffer_layers(mesh, owner, rank, nranks, safe_layers, ghost_layers, bridge)
+        assert np.array_equal(safe.astype(bool), (d_core >= 0) & (d_core <= safe_layers))
+        exp_part = np.zeros(nranks, dtype=np.int32)
+        exp_part[np.unique(owner[(d_core >= 0) & (d_core <= ghost_layers)])] = 1
+        assert np.array_equal(part, exp_part) and part[rank] == 1
+        inward = ppo.bfs_safe_inward(mesh, owner, rank, safe_layers, part, bridge)
+        unbuffered = ~part[owner].astype(bool)
+        if unbuffered.any():
+            d_out = distance_from(unbuffered)
+            exp = (d_out > safe_layers) | (owner == rank)
+        else:
+            exp = np.ones(ne, dtype=bool)
+        assert np.array_equal(inward.astype(bool), exp)
