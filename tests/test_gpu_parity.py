@@ -2,6 +2,8 @@
 same seeded inputs.  Bar: bit-exact for ids / indices / integer work AND for positions that go
 through the shared deterministic sincos; float32-ulp tolerance only where the device libm is used
 (ellipticalPush::setup, a one-time initialisation)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1233,7 +1235,11 @@ def test_gyro_scatter_gather_and_atomic_forms(ppo, synth, capi, dim):
         copy = capi.DevArray.from_host(fo)
         w_atomic = capi.gyro_scatter(mg, pg, copy, 0.03, gnr, gppr).to_host()
         assert wo.sum() > 0
-        assert np.array_equal(wo, w_gather) and np.array_equal(wo, w_bk)
+        if os.environ.get("PP_SCATTER_ATOMIC") is None:  # the gather form: fixed summation order
+            assert np.array_equal(wo, w_gather) and np.array_equal(wo, w_bk)
+        else:
+            np.testing.assert_allclose(w_gather, wo, rtol=1e-13, atol=0)
+            np.testing.assert_allclose(w_bk, wo, rtol=1e-13, atol=0)
         np.testing.assert_allclose(w_atomic, wo, rtol=1e-13, atol=0)
         if gppr == 8:
             assert np.array_equal(w_atomic, wo)
