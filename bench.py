@@ -55,7 +55,8 @@ BYTES = {
 }
 
 
-def build_workload(pp, capi, name, nptcl, rank, world, deg, remainder="last", mesh_size="100k"):
+def build_workload(pp, capi, name, nptcl, rank, world, deg, remainder="last", mesh_size="100k",
+                   sigma=2**31 - 1):
     synth = pp.synth
     if name in ("2d", "2dc3"):
         coords, e2v, cls = synth.annulus_tri()
@@ -93,7 +94,7 @@ def build_workload(pp, capi, name, nptcl, rank, world, deg, remainder="last", me
             pass
     info = [xyz, np.zeros_like(xyz), np.arange(nptcl, dtype=np.int32), b, phi]
     mesh = capi.Mesh(dim, coords, e2v, cls)
-    ps = capi.PS.scs(capi.PARTICLE_XGCM, ne, ppe, C_=64, sigma=2**31 - 1, V=1024, pad_strat=0,
+    ps = capi.PS.scs(capi.PARTICLE_XGCM, ne, ppe, C_=64, sigma=sigma, V=1024, pad_strat=0,
                      shuffle_padding=0.1, extra_padding=0.0, particle_elements=elem,
                      particle_info=info)
     return dict(mesh=mesh, ps=ps, dim=dim, label=label, ne=ne, coords=coords, e2v=e2v, cls=cls,
@@ -320,6 +321,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "2d", "2dc3"])
+    ap.add_argument("--sigma", type=int, default=2**31 - 1,
+                    help="SCS sorting window (elements); the pseudoXGCm value is INT_MAX = full sort")
     ap.add_argument("--safe-layers", type=int, default=0,
                     help="c5: breadth-first element layers around the owned block that are still safe "
                          "(0 = BASELINE's rule: a particle migrates as soon as it leaves its owner's block)")
@@ -358,7 +361,8 @@ def main():
         w = build_c4(pp, capi, a.c4_elems, a.particles, rank, a.structure)
         st = StepperC4(capi, w)
     else:
-        w = build_workload(pp, capi, a.workload, a.particles, rank, world, a.deg, a.remainder, a.mesh)
+        w = build_workload(pp, capi, a.workload, a.particles, rank, world, a.deg, a.remainder, a.mesh,
+                           a.sigma)
         w["safe_layers"] = a.safe_layers
         st = Stepper(pp, capi, w, a.workload, a.deg)
 
@@ -437,8 +441,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "%s, %d particles/GPU, SCS C=64 sigma=inf V=1024, %s" % (
-                w["label"], a.particles,
+            "config": {"workload": "%s, %d particles/GPU, SCS C=64 sigma=%s V=1024, %s" % (
+                w["label"], a.particles, "inf" if a.sigma >= 2**31 - 1 else str(a.sigma),
                 {"c2": "push+search only (fused toroidal push + BCC walk), deg/push=%g" % a.deg,
                  "2d": "elliptical push + search_mesh_2d (fused), deg/push=%g" % a.deg,
                  "c3": "push+search+rebuild+gyroScatter x2 (tet ring map), deg/push=%g" % a.deg,
