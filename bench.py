@@ -406,6 +406,8 @@ def main():
             except (ValueError, KeyError):
                 traffic = None
         bpp = BYTES[{"2dc3": "2d", "c3": "c2", "c5": "c2"}.get(a.workload, a.workload)]
+        if a.workload == "c4" and a.structure != "scs":
+            traffic = None  # the committed PMC run is the SCS structure
         if a.workload == "c4":
             out = {
                 "metric": "particles pseudo-pushed+redistributed+rebuilt / sec / GPU; achieved HBM GB/s vs peak",
@@ -418,7 +420,10 @@ def main():
                            "parallelism": "%d independent rank(s)" % world},
                 "roofline": {"bound": "hbm", "achieved": bpp * nlive / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": bpp * nlive / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "traffic": None, "kernel": "k_pseudo_push160", "kernel_ms": kms,
+                             "traffic": traffic,
+                             "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, calibrated; "
+                                             "profiles/traffic_c4.json)",
+                             "kernel": "k_pseudo_push160", "kernel_ms": kms,
                              "bytes_per_particle": bpp},
             }
             if not a.no_cpu_baseline and world == 1:

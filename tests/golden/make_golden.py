@@ -105,6 +105,56 @@ def scs_layouts(ppo):
     np.savez_compressed(os.path.join(OUT, "scs_layouts.npz"), **out)
 
 
+def walls_and_parts(ppo, synth):
+    """search_mesh_3d, the functor walk, closest_point_on_triangle, the PICpart BFS layers and
+    redistribute_particles on fixed inputs."""
+    out = {}
+    pop = common.population_box(synth, n=5, num_ptcls=800)
+    mesh, ps = common.oracle_pair(ppo, pop, ppo.PARTICLE_PUSH, C=1)
+    ppo.linear_push(ps, 0.55, -0.5, 0.8, 0.15)
+    r = ppo.search_mesh_3d(mesh, ps, looplimit=200)
+    pid, e = by_id(ps, r["elem_ids"])
+    _, f = by_id(ps, r["xface"])
+    _, xp = by_id(ps, r["xpoints"].T)
+    out.update(s3d_pid=pid, s3d_elem=e, s3d_xface=f, s3d_xpoints=xp)
+    # functor walk on a mesh with three material slabs
+    coords, e2v, _ = synth.kuhn_box(5)
+    cls = (1 + np.floor(coords[e2v][:, :, 1].mean(axis=1) * 3)).astype(np.int32)
+    pop2 = dict(pop, cls=cls)
+    mesh2, ps2 = common.oracle_pair(ppo, pop2, ppo.PARTICLE_PUSH, C=1)
+    ppo.linear_push(ps2, 0.55, -0.5, 0.8, 0.15)
+    se, mk = ps2.slot_info()
+    for mt in (0, 1):
+        w = ppo.trace_particle_through_mesh(mesh2, ps2, common.class_interface_functor(mesh2, mk, []),
+                                            require_intersection=bool(mt), looplimit=200)
+        pid, e = by_id(ps2, w["elem_ids"])
+        _, f = by_id(ps2, w["inter_faces"])
+        out["wall%d_elem" % mt] = e
+        out["wall%d_face" % mt] = f
+    rng = np.random.default_rng(99)
+    tris, pts = rng.normal(size=(300, 9)), rng.normal(size=(300, 3)) * 2
+    for wn in (0, 1):
+        res = [ppo.closest_point_on_triangle(tris[i], pts[i], wnormal=bool(wn), reg0=-7) for i in range(300)]
+        out["cp%d_q" % wn] = np.array([q for q, _ in res])
+        out["cp%d_reg" % wn] = np.array([g for _, g in res], dtype=np.int32)
+    out.update(cp_tris=tris, cp_pts=pts)
+    c3, e3, k3 = synth.torus_tet(n_b=4, n_theta=12, n_planes=8)
+    m3 = ppo.Mesh(3, c3, e3, k3)
+    owner = (np.arange(m3.nelems, dtype=np.int64) * 6 // m3.nelems).astype(np.int32)
+    for bridge in (0, 2):
+        safe, part = ppo.bfs_buffer_layers(m3, owner, 2, 6, 2, 3, bridge)
+        out["bfs%d_safe" % bridge] = safe.copy()
+        out["bfs%d_part" % bridge] = part.copy()
+        out["bfs%d_inward" % bridge] = ppo.bfs_safe_inward(m3, owner, 2, 2, part, bridge).copy()
+    ne = 300
+    elems = np.sort(rng.integers(0, ne, size=5000).astype(np.int32))
+    ppe = np.bincount(elems, minlength=ne).astype(np.int32)
+    psr = ppo.PS.scs([(np.int32, 1)], ne, ppe, C_max=32, sigma=ne, V=1024, particle_elements=elems,
+                     particle_info=[np.arange(5000, dtype=np.int32)[None, :]])
+    out.update(redist_elems=elems, redist_new=ppo.redistribute_particles(psr, 0.4, seed=12345).copy())
+    np.savez_compressed(os.path.join(OUT, "walls_and_parts.npz"), **out)
+
+
 if __name__ == "__main__":
     pp = pumipic_amd_loader.load()
     ppo = pumipic_amd_loader.load_oracle()
@@ -112,5 +162,6 @@ if __name__ == "__main__":
     xgcm_3d(ppo, pp.synth)
     push_and_search(ppo, pp.synth)
     scs_layouts(ppo)
+    walls_and_parts(ppo, pp.synth)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

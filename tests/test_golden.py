@@ -98,6 +98,57 @@ def test_oracle_pushsearch_golden(ppo, synth):
         ps.rebuild(r["elem_ids"])
 
 
+def _walls_and_parts(api, synth, on_gpu):
+    """the checks of walls_and_parts.npz, shared by the oracle (CPU) and the HIP path (GPU)"""
+    g = _load("walls_and_parts.npz")
+    host = (lambda a: a.to_host()) if on_gpu else (lambda a: np.asarray(a))
+    pair = common.gpu_pair if on_gpu else common.oracle_pair
+    pop = common.population_box(synth, n=5, num_ptcls=800)
+    mesh, ps = pair(api, pop, api.PARTICLE_PUSH)
+    api.linear_push(ps, 0.55, -0.5, 0.8, 0.15)
+    r = api.search_mesh_3d(mesh, ps, looplimit=200)
+    cap = ps.capacity()
+    ids, mk = ps.member(2)[0, :cap], ps.slot_info()[1]
+    pid, e = common.by_id(ids, mk, host(r["elem_ids"])[:cap])
+    _, f = common.by_id(ids, mk, host(r["xface"])[:cap])
+    _, xp = common.by_id(ids, mk, host(r["xpoints"]).reshape(-1, 3)[:cap].T)
+    assert np.array_equal(pid, g["s3d_pid"]) and np.array_equal(e, g["s3d_elem"])
+    assert np.array_equal(f, g["s3d_xface"]) and np.array_equal(xp[:, f >= 0], g["s3d_xpoints"][:, f >= 0])
+    coords, e2v, _ = synth.kuhn_box(5)
+    cls = (1 + np.floor(coords[e2v][:, :, 1].mean(axis=1) * 3)).astype(np.int32)
+    return g, dict(pop, cls=cls), pair, host
+
+
+def test_oracle_walls_and_parts_golden(ppo, synth):
+    g, pop2, pair, host = _walls_and_parts(ppo, synth, False)
+    mesh2, ps2 = pair(ppo, pop2, ppo.PARTICLE_PUSH)
+    ppo.linear_push(ps2, 0.55, -0.5, 0.8, 0.15)
+    cap = ps2.capacity()
+    ids, mk = ps2.member(2)[0, :cap], ps2.slot_info()[1]
+    for mt in (0, 1):
+        w = ppo.trace_particle_through_mesh(mesh2, ps2, common.class_interface_functor(mesh2, mk, []),
+                                            require_intersection=bool(mt), looplimit=200)
+        assert np.array_equal(common.by_id(ids, mk, w["elem_ids"][:cap])[1], g["wall%d_elem" % mt])
+        assert np.array_equal(common.by_id(ids, mk, w["inter_faces"][:cap])[1], g["wall%d_face" % mt])
+    for wn in (0, 1):
+        res = [ppo.closest_point_on_triangle(g["cp_tris"][i], g["cp_pts"][i], wnormal=bool(wn), reg0=-7)
+               for i in range(len(g["cp_pts"]))]
+        assert np.array_equal(np.array([q for q, _ in res]), g["cp%d_q" % wn])
+        assert np.array_equal(np.array([r_ for _, r_ in res]), g["cp%d_reg" % wn])
+    c3, e3, k3 = synth.torus_tet(n_b=4, n_theta=12, n_planes=8)
+    m3 = ppo.Mesh(3, c3, e3, k3)
+    owner = (np.arange(m3.nelems, dtype=np.int64) * 6 // m3.nelems).astype(np.int32)
+    for bridge in (0, 2):
+        safe, part = ppo.bfs_buffer_layers(m3, owner, 2, 6, 2, 3, bridge)
+        assert np.array_equal(safe, g["bfs%d_safe" % bridge]) and np.array_equal(part, g["bfs%d_part" % bridge])
+        assert np.array_equal(ppo.bfs_safe_inward(m3, owner, 2, 2, part, bridge), g["bfs%d_inward" % bridge])
+    elems = g["redist_elems"]
+    ppe = np.bincount(elems, minlength=300).astype(np.int32)
+    psr = ppo.PS.scs([(np.int32, 1)], 300, ppe, C_max=32, sigma=300, V=1024, particle_elements=elems,
+                     particle_info=[np.arange(5000, dtype=np.int32)[None, :]])
+    assert np.array_equal(ppo.redistribute_particles(psr, 0.4, seed=12345), g["redist_new"])
+
+
 # ---------------------------------------------------------------- GPU: HIP path == golden
 @pytest.fixture(scope="module")
 def capi(pp):
@@ -172,3 +223,38 @@ def test_gpu_pushsearch_golden(synth, capi):
         assert np.array_equal(e, g["elem_ids"][step][pid]) and np.array_equal(f, g["xface"][step][pid])
         capi.update_positions(ps)
         ps.rebuild(ids)
+
+
+@pytest.mark.gpu
+def test_gpu_walls_and_parts_golden(ppo, synth, capi):
+    g, pop2, pair, host = _walls_and_parts(capi, synth, True)
+    mesh2, ps2 = pair(capi, pop2, capi.PARTICLE_PUSH)
+    capi.linear_push(ps2, 0.55, -0.5, 0.8, 0.15)
+    cap = ps2.capacity()
+    ids, mk = ps2.member(2)[0, :cap], ps2.slot_info()[1]
+    topo = ppo.Mesh(3, pop2["coords"], pop2["e2v"], pop2["cls"])  # side numbering for the host functor
+    for mt in (0, 1):
+        w = capi.trace_particle_through_mesh(
+            mesh2, ps2, common.on_device(common.class_interface_functor(topo, mk, [])),
+            require_intersection=bool(mt), looplimit=200)
+        assert np.array_equal(common.by_id(ids, mk, w["elem_ids"].to_host()[:cap])[1], g["wall%d_elem" % mt])
+        assert np.array_equal(common.by_id(ids, mk, w["inter_faces"].to_host()[:cap])[1], g["wall%d_face" % mt])
+    for wn in (0, 1):
+        q, reg = capi.closest_point_on_triangle(g["cp_tris"], g["cp_pts"], wnormal=bool(wn), reg0=-7)
+        assert np.array_equal(q, g["cp%d_q" % wn]) and np.array_equal(reg, g["cp%d_reg" % wn])
+    c3, e3, k3 = synth.torus_tet(n_b=4, n_theta=12, n_planes=8)
+    m3 = capi.Mesh(3, c3, e3, k3)
+    owner = (np.arange(m3.nelems, dtype=np.int64) * 6 // m3.nelems).astype(np.int32)
+    d_owner = capi.DevArray.from_host(owner)
+    for bridge in (0, 2):
+        safe, part = capi.bfs_buffer_layers(m3, d_owner, 2, 6, 2, 3, bridge)
+        assert np.array_equal(safe.to_host()[:m3.nelems], g["bfs%d_safe" % bridge])
+        assert np.array_equal(part, g["bfs%d_part" % bridge])
+        inward = capi.bfs_safe_inward(m3, d_owner, 2, 6, 2, part, bridge)
+        assert np.array_equal(inward.to_host()[:m3.nelems], g["bfs%d_inward" % bridge])
+    elems = g["redist_elems"]
+    ppe = np.bincount(elems, minlength=300).astype(np.int32)
+    psr = capi.PS.scs([(np.int32, 1)], 300, ppe, C_=32, sigma=300, V=1024, particle_elements=elems,
+                      particle_info=[np.arange(5000, dtype=np.int32)[None, :]])
+    assert np.array_equal(capi.redistribute_particles(psr, 0.4, seed=12345).to_host()[:psr.capacity()],
+                          g["redist_new"])

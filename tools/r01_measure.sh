@@ -35,6 +35,13 @@ pass fetch FETCH_SIZE TCC_EA0_RDREQ_sum
 pass write WRITE_SIZE TCC_EA0_WRREQ_sum
 pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 pass tcc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE
+passw() { wl=$1; name=$2; shift 2
+  timeout 240 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_$wl/$name -o p -- python3 $R/bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline > $O/pmc_${wl}_$name.log 2>&1
+}
+for wl in c3 2d c4; do
+passw $wl fetch FETCH_SIZE TCC_EA0_RDREQ_sum
+passw $wl write WRITE_SIZE TCC_EA0_WRREQ_sum
+done
 # calibration: the streaming skeleton moves exactly 37 B read + 32 B written per slot
 timeout 120 rocprofv3 --pmc FETCH_SIZE TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d $O/pmc/cal_fetch -o p -- $R/tools/_ubs > $O/pmc_cal_fetch.log 2>&1
 timeout 120 rocprofv3 --pmc WRITE_SIZE TCC_EA0_WRREQ_sum --kernel-trace --output-format csv -d $O/pmc/cal_write -o p -- $R/tools/_ubs > $O/pmc_cal_write.log 2>&1
@@ -44,4 +51,8 @@ for k in c2 2d 2dc3 c3 c4; do f=$(find $O/kt_$k -name "*kernel_stats.csv" | head
 rm -rf $O/kt_c2 $O/kt_2d $O/kt_2dc3 $O/kt_c3 $O/kt_c4
 find $O/pmc -name "*.csv" ! -name "*counter_collection.csv" -delete
 python tools/traffic_json.py $O c2 10000000 $O/traffic_c2.json > /dev/null
+python tools/traffic_json.py $O c3 10000000 $O/traffic_c3.json pmc_c3 > /dev/null
+python tools/traffic_json.py $O 2d 10000000 $O/traffic_2d.json pmc_2d > /dev/null
+python tools/traffic_json.py $O c4 1000000 $O/traffic_c4.json pmc_c4 > /dev/null
+find $O/pmc_c3 $O/pmc_2d $O/pmc_c4 -name "*.csv" -delete
 cat $O/bench_c2.json; grep -B1 -A6 "rowsq\|s_rows<8, 4>\|pending" $O/pmc_summary.txt | head -80
