@@ -8,7 +8,9 @@ A "step" is one pass of the hot path over the resident particle population:
       100 800-tet tokamak mesh, 10 M particles per GPU, SCS layout (C=64), no rebuild; positions
       ping-pong x <-> x_tgt and the walk is re-seeded from the previous step's element ids.
   c3 (configs[2]): c2 + updatePtclPositions + SCS rebuild + gyroScatter x2 every step (tet variant
-      of the ring map: 4 vertices per ring point); 2dc3 is the 2-D literal of it.
+      of the ring map: 4 vertices per ring point); 2dc3 is the 2-D literal of it.  The
+      three calls go through pp_ps_rebuild_scatter (same work, one entry point;
+      PP_BENCH_SEPARATE_SCATTER=1 issues them separately).
   2d : the literal 2-D pseudoXGCm step (elliptical push + search_mesh_2d) on 100 352 triangles.
   c5 (configs[4], opt-in): c3 with ownership: every rank owns a block of elements; after the search
       the particles whose new element another rank owns are packed into records, exchanged with ONE
@@ -222,9 +224,13 @@ class Stepper:
             self.ps.swap_members(0, 1)  # x <-> x_tgt (O(1)); no rebuild in config 2
         elif self.name in ("c3", "2dc3"):
             # the drivers' rebuild(): updatePtclPositions + migrate/rebuild (pseudoXGCm.cpp:116-140)
-            self.ps.rebuild_commit(self.ids)
-            capi.gyro_scatter(self.mesh, self.ps, self.fwd, out=self.w_f)
-            capi.gyro_scatter(self.mesh, self.ps, self.bkwd, out=self.w_b)
+            if os.environ.get("PP_BENCH_SEPARATE_SCATTER"):
+                self.ps.rebuild_commit(self.ids)
+                capi.gyro_scatter(self.mesh, self.ps, self.fwd, out=self.w_f)
+                capi.gyro_scatter(self.mesh, self.ps, self.bkwd, out=self.w_b)
+            else:  # the same three calls as one entry point (scatter enqueued before the rebuild's sync)
+                capi.rebuild_scatter(self.ps, self.mesh, self.ids, [self.fwd, self.bkwd],
+                                     [self.w_f, self.w_b])
             cap = max(self.ps.capacity(), 1)
             if cap > self.ids.n:  # 10% slack: the capacity wanders by a few chunk widths per rebuild
                 self.ids = capi.DevArray(cap + cap // 10, np.int32)

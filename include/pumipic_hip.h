@@ -150,6 +150,15 @@ int pp_ps_rebuild(pp_ps* ps, const int* new_element_dev, int n_new, const int* n
  * for every live particle.  This is what the drivers' rebuild() helper does (pseudoXGCm.cpp:116-140) */
 int pp_ps_rebuild_commit(pp_ps* ps, int m_x, int m_xtgt, const int* new_element_dev, int n_new,
                          const int* new_elems_dev, const void* const* new_info_dev);
+/* The rebuild of a pseudoXGCm step followed by its gyroScatter calls (test/pseudoXGCm.cpp:116-140,
+ * 529-530) as ONE call: result-identical to pp_ps_rebuild (m_x = m_xtgt = -1) or pp_ps_rebuild_commit
+ * followed by pp_gyro_scatter(mesh, ps, v2v_dev[k], ..., scatter_w_dev[k]) for k < nmaps.  The
+ * scatter depends on the new per-element counts only, so it is enqueued before the rebuild's one
+ * host sync and the GPU keeps working while the host waits. */
+int pp_ps_rebuild_scatter(pp_ps* ps, int m_x, int m_xtgt, const int* new_element_dev, int n_new,
+                          const int* new_elems_dev, const void* const* new_info_dev,
+                          const pp_mesh* mesh, int nmaps, const int* const* v2v_dev,
+                          double* const* scatter_w_dev, double rmax, int gnr, int gppr);
 /* getPIDs ps_for.hpp:65-85: offsets_dev[ne+1], pids_dev[nPtcls] */
 int pp_ps_get_pids(const pp_ps* ps, int* offsets_dev, int* pids_dev);
 /* printMetrics SellCSigma.h:465-524 */

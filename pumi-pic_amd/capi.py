@@ -107,6 +107,7 @@ SYMBOLS = {
     "pp_boris_push_fields": (_I, [_V, _V, _I, _I, _I, _V, _V, _V] + [C.c_double] * 4 + [_I, _I, _I, C.c_double, c_int_p]),
     "pp_bfs_buffer_layers": (_I, [_V, _I, _I, _I, _I, _I, _V, _V, c_int_p]),
     "pp_bfs_safe_inward": (_I, [_V, _I, _I, _I, _I, _V, c_int_p, _V]),
+    "pp_ps_rebuild_scatter": (_I, [_V, _I, _I, _V, _I, _V, _V, _V, _I, _V, _V, C.c_double, _I, _I]),
     "pp_search_mesh_3d": (_I, [_V, _V, _I, _I, _I, _V, _I, _V, _V, _I, c_int_p]),
     "pp_push_search": (_I, [_V, _V, _I, _I, _I, _I, _D, _D, _D, _D, _V, _I, _I, c_int_p]),
     "pp_create_gyro_ring_mappings": (_I, [_V, _D, _I, _I, _D, _V, _V]),
@@ -721,3 +722,19 @@ def bfs_safe_inward(mesh, owner_dev, rank, comm_size, safe_layers, has_part, bri
     check(lib().pp_bfs_safe_inward(mesh.p, bridge_dim, rank, comm_size, safe_layers, owner_dev.ptr,
                                    part.ctypes.data_as(c_int_p), safe.ptr))
     return safe
+
+
+def rebuild_scatter(ps, mesh, new_element, maps, outs=None, commit=True, rmax=0.038, gnr=3, gppr=8,
+                    m_x=0, m_xtgt=1):
+    """pp_ps_rebuild[_commit] + one pp_gyro_scatter per map in one call (the scatter is enqueued
+    before the rebuild's host sync).  Returns the list of output DevArrays."""
+    ne = new_element if isinstance(new_element, DevArray) else DevArray.from_host(
+        np.ascontiguousarray(new_element, dtype=np.int32))
+    if outs is None:
+        outs = [DevArray(max(mesh.nverts, 1), np.float64) for _ in maps]
+    n = len(maps)
+    v2v = (C.c_void_p * max(n, 1))(*[m.ptr for m in maps])
+    out = (C.c_void_p * max(n, 1))(*[o.ptr for o in outs])
+    check(lib().pp_ps_rebuild_scatter(ps.p, m_x if commit else -1, m_xtgt if commit else -1, ne.ptr, 0,
+                                      None, None, mesh.p, n, v2v, out, rmax, gnr, gppr))
+    return outs

@@ -19,6 +19,8 @@ hipStream_t stream();
 // form of any gyro ring map living there
 void gyro_map_invalidate(const void* dev, size_t bytes);
 void gyro_map_mesh_gone(const void* mesh);
+// pp_scatter.hip: gyroScatter for `nmaps` ring maps from an explicit per-element count array (the
+// histogram of a rebuild that is still in flight); forgets the ring accumulation kept for reuse
 bool initialised();
 
 #define PP_HIP_CHECK(expr)                                                              \
@@ -179,3 +181,10 @@ struct pp_ps {
   pp::DevBuf s_ppe, s_keys, s_keys2, s_vals, s_vals2, s_hist, s_chunkw, s_misc, s_rowstart,
       s_newidx, s_offsets2, s_s2c2, s_r2e2, s_e2r2, s_mask2, s_slot2, s_scan, s_cstart2, s_cwidth2, s_aos, s_idx, s_ranknew, s_eslot0, s_scan2;
 };
+
+namespace pp {
+// pp_scatter.hip: gyroScatter for `nmaps` ring maps from an explicit per-element count array (the
+// histogram of a rebuild that is still in flight); forgets the ring accumulation kept for reuse.
+int gyro_scatter_counts(const pp_mesh* mesh, const int* cnt_dev, int nmaps, const int* const* v2v_dev,
+                        double* const* out_dev, double rmax, int gnr, int gppr);
+}  // namespace pp

@@ -15,6 +15,7 @@
 // third-party detail and no result depends on it.
 #include <algorithm>
 #include <numeric>
+#include <functional>
 #include "pp_internal.hpp"
 
 namespace {
@@ -193,7 +194,7 @@ struct Totals {  // s_misc layout
   int invalid;   // new particle with element -1 / out of range
   int cw_sum, cw_cnt;
   int nslices, capacity;
-  int pad0;
+  int go;  // speculative tail of the rebuild may run (k_spec_check); 1 on the checked path
   double cw_inv;
   unsigned long long max_key;  // largest sort key of this rebuild (radix passes above it are skipped)
 };
@@ -449,6 +450,7 @@ __global__ void k_slices_and_slots(int nchunks, int C, int V, const int* __restr
 __global__ void k_fill_slices(int nchunks, int C, int V, const int* __restrict__ widths,
                               const int* __restrict__ slice_off, const int* __restrict__ chunk_start,
                               int* __restrict__ offsets, int* __restrict__ s2c, const Totals* tot) {
+  if (!tot->go) return;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0) offsets[tot->nslices] = tot->capacity;
   if (c >= nchunks) return;
@@ -587,6 +589,13 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
     }
   }
   flush();
+}
+// speculative rebuild tail: may it run against buffers sized for (cap_lim, nsl_lim)?
+__global__ void k_spec_check(Totals* tot, int cap_lim, int nsl_lim, int C_max) {
+  tot->go = (!tot->invalid && tot->active > 0 && tot->nonempty >= C_max && tot->capacity <= cap_lim &&
+             tot->nslices <= nsl_lim)
+                ? 1
+                : 0;
 }
 // live particles and non-empty elements of the new population, from the histogram: one atomic per
 // wave of ELEMENTS (a per-wave atomic on one counter in the particle-sized kernels serialises at
@@ -777,7 +786,9 @@ __global__ void k_chunk_widths2(int nchunks, int C, int ne, const unsigned long 
 }
 // one thread per tile: owning chunk by binary search in the tile prefix
 __global__ void k_tile_fill2(const int* __restrict__ ntiles_dev, int nchunks, int TP,
-                             const int* __restrict__ tile_off, int* __restrict__ tiles) {
+                             const int* __restrict__ tile_off, int* __restrict__ tiles,
+                             const int* __restrict__ go) {
+  if (!*go) return;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= *ntiles_dev) return;
   int lo = 0, hi = nchunks - 1;  // last chunk with tile_off[c] <= t
@@ -797,7 +808,9 @@ __global__ void k_init_slots_tiled(const int* __restrict__ ntiles_dev, int C, in
                                    const int* __restrict__ chunk_width, const int* __restrict__ r2e,
                                    const int* __restrict__ ppe, int ne,
                                    int* __restrict__ slot_elem, int* __restrict__ row_cursor,
-                                   int* __restrict__ elem_slot0, unsigned char* __restrict__ new_mask) {
+                                   int* __restrict__ elem_slot0, unsigned char* __restrict__ new_mask,
+                                   const int* __restrict__ go) {
+  if (!*go) return;
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int tile = (int)(g / C), r = (int)(g - (long long)tile * C);
   if (tile >= *ntiles_dev) return;
@@ -867,7 +880,9 @@ __device__ __forceinline__ void copy_members(const MoveArgs& a, long long from, 
 __global__ void k_add_scs(int n_new, const int* __restrict__ new_elems,
                           const int* __restrict__ e2r_new, int C_new, int* __restrict__ row_cursor,
                           const int* __restrict__ rank_new, const int* __restrict__ elem_slot0,
-                          unsigned char* __restrict__ new_mask, MoveArgs a) {
+                          unsigned char* __restrict__ new_mask, MoveArgs a,
+                          const int* __restrict__ go) {
+  if (!*go) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_new) return;
   const int e = new_elems[i];
@@ -885,7 +900,9 @@ __global__ void k_move_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
                              const unsigned char* __restrict__ mask,
                              const int* __restrict__ new_element, const int* __restrict__ e2r_new,
                              int C_new, int* __restrict__ row_cursor,
-                             unsigned char* __restrict__ new_mask, MoveArgs a) {
+                             unsigned char* __restrict__ new_mask, MoveArgs a,
+                             const int* __restrict__ go) {
+  if (!*go) return;
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int tile = (int)(g / C), r = (int)(g - (long long)tile * C);
   if (tile >= *ntiles_dev) return;
@@ -949,7 +966,8 @@ struct RankToSlot {
 };
 template <int NQ>
 __global__ void k_move_pack(int capacity, const int* __restrict__ new_idx, RankToSlot rs,
-                            uint4* __restrict__ aos, WordTable t) {
+                            uint4* __restrict__ aos, WordTable t, const int* __restrict__ go) {
+  if (go && !*go) return;
   __shared__ uint4 st[4][64][NQ + 1];
   __shared__ int sd[4][64];
   const int pid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1002,7 +1020,8 @@ __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
                               const int* __restrict__ tiles, const int* __restrict__ chunk_start,
                               const int* __restrict__ chunk_width,
                               const unsigned char* __restrict__ new_mask,
-                              const uint4* __restrict__ aos, WordTable t) {
+                              const uint4* __restrict__ aos, WordTable t, const int* __restrict__ go) {
+  if (!*go) return;
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int tile = (int)(g / C), r = (int)(g - (long long)tile * C);
   if (tile >= *ntiles_dev) return;
@@ -1366,8 +1385,11 @@ int build_word_table(const pp_ps* ps, const void* const* src, int64_t src_stride
   return (NQ == 4 || NQ == 10 || (NQ >= 1 && NQ <= 3) || NQ == 6 || NQ == 8) ? NQ : 0;
 }
 
+// `pre_sync` (may be empty): work that depends on nothing but the new per-element counts, enqueued
+// before the rebuild's host sync so that the GPU has something to run while the host wakes up
 int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_elems,
-                const void* const* new_info, int commit_x, int commit_xt) {
+                const void* const* new_info, int commit_x, int commit_xt,
+                const std::function<int(const int*)>& pre_sync = std::function<int(const int*)>()) {
   hipStream_t st = pp::stream();
   const int ne = ps->num_elems;
   PP_REQUIRE(n_new == 0 || new_info != nullptr, "rebuild: new particles need new_info_dev");
@@ -1402,9 +1424,155 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   LayoutPlan L;
   int rc = enqueue_layout(ps, ps->C_max, ppe, tot, key_base, L);
   if (rc) return rc;
-  Totals h{};
-  PP_HIP_CHECK(hipMemcpyAsync(&h, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
-  PP_HIP_CHECK(hipStreamSynchronize(st));  // the only host sync of a regular rebuild
+  int nchunks = L.nchunks, nrows = L.nrows;
+  PP_HIP_CHECK(ps->s_eslot0.reserve(sizeof(int) * (size_t)std::max(ne, 1)));
+  const int* go = &tot->go;
+  int C_new = ps->C_max;
+  int ntiles_max = 0;
+  int NQ = 0;
+  // Everything after the layout: new layout arrays, slot tables and the move of every member.
+  // `cap_sz` / `nsl_sz` size the buffers and the launches; the kernels themselves read the true
+  // counts from the device (ntiles, Totals), and all of them return at once when tot->go == 0.
+  auto enqueue_tail = [&](int cap_sz, int nsl_sz, int64_t stride_fixed) -> int {
+    PP_HIP_CHECK(ps->s_r2e2.reserve(sizeof(int) * (size_t)nrows));
+    PP_HIP_CHECK(ps->s_e2r2.reserve(sizeof(int) * (size_t)nrows));
+    PP_HIP_CHECK(ps->s_rowstart.reserve(sizeof(int) * (size_t)nrows));
+    PP_HIP_CHECK(ps->s_offsets2.reserve(sizeof(int) * ((size_t)nsl_sz + 1)));
+    PP_HIP_CHECK(ps->s_s2c2.reserve(sizeof(int) * (size_t)std::max(nsl_sz, 1)));
+    PP_HIP_CHECK(ps->s_mask2.reserve((size_t)std::max(cap_sz, 1)));
+    PP_HIP_CHECK(ps->s_slot2.reserve(sizeof(int) * (size_t)std::max(cap_sz, 1)));
+    // sum_c ceil(w_c/TP) <= nchunks + capacity/(C*TP): sizes the launch without reading the count
+    ntiles_max = nchunks + cap_sz / (C_new * ps->tile_p) + 1;
+    PP_HIP_CHECK(ps->s_newidx.reserve(sizeof(int) * 2 * (size_t)ntiles_max));  // new tile table
+    int* new_tiles = ps->s_newidx.as<int>();
+    const int* new_ntiles = ps->s_scan.as<int>();
+    k_tile_fill2<<<grid_for(ntiles_max), kBlock, 0, st>>>(new_ntiles, nchunks, ps->tile_p, L.tile_off,
+                                                          new_tiles, go);
+    k_fill_slices<<<grid_for(std::max(nchunks, 1)), kBlock, 0, st>>>(
+        nchunks, C_new, ps->V, L.widths, L.slice_off, L.chunk_start, ps->s_offsets2.as<int>(),
+        ps->s_s2c2.as<int>(), tot);
+    k_rows<<<grid_for(nrows), kBlock, 0, st>>>(nrows, ne, L.sorted ? 1 : 0, L.index,
+                                               ps->s_r2e2.as<int>(), ps->s_e2r2.as<int>());
+    k_rows_cursor_empty<<<grid_for(nrows), kBlock, 0, st>>>(nchunks, C_new, L.widths, L.chunk_start,
+                                                            ps->s_rowstart.as<int>());
+    k_init_slots_tiled<<<grid_for((size_t)ntiles_max * C_new), kBlock, 0, st>>>(
+        new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_r2e2.as<int>(),
+        ppe, ne, ps->s_slot2.as<int>(), ps->s_rowstart.as<int>(), ps->s_eslot0.as<int>(),
+        ps->s_mask2.as<unsigned char>(), go);
+    // ---- swap buffer sizing (SCS_rebuild.h:223-229)
+    int64_t swap_stride = ps->swap_stride;
+    if (stride_fixed > 0) {  // speculative tail: whatever the swap buffers hold today
+      swap_stride = stride_fixed;
+    } else if (swap_stride < cap_sz || swap_stride * ps->minimize_size < cap_sz) {
+      swap_stride = (int64_t)(cap_sz * (1 + ps->extra_padding));
+      if (swap_stride < cap_sz) swap_stride = cap_sz;
+      swap_stride = spread_stride(swap_stride);
+    }
+    int rc2 = alloc_members(ps, ps->swap, swap_stride, false);
+    if (rc2) return rc2;
+    ps->swap_stride = swap_stride;
+    // ---- move every member of every live particle
+    MoveArgs mv = make_move(ps, ps->data, ps->stride, ps->swap, swap_stride);
+    mv.commit_x = commit_x;
+    mv.commit_xt = commit_xt;
+    // record = all members (fast path needs 4/8-byte scalars, see build_word_table)
+    WordTable wt{};
+    NQ = 0;
+    if (have_old && old_grid > 0 && getenv("PP_DIRECT_MOVE") == nullptr) {
+      const void* srcs[8];
+      for (int m = 0; m < ps->nmembers; ++m) srcs[m] = ps->data[m].p;
+      NQ = build_word_table(ps, srcs, ps->stride, swap_stride, commit_x, commit_xt, wt);
+    }
+    if (NQ > 0) {
+      PP_HIP_CHECK(ps->s_aos.reserve((size_t)std::max(cap_sz, 1) * NQ * 16));
+      uint4* aos = ps->s_aos.as<uint4>();
+      const unsigned new_grid = grid_for((size_t)ntiles_max * C_new);
+#define PP_UNPACK_ARGS                                                                                  \
+  new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_mask2.as<unsigned char>(), aos, \
+      wt, go
+#define PP_STAGED(N)                                                                             \
+  case N:                                                                                        \
+    k_move_pack<N><<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, rank, rs, aos, wt, go); \
+    k_move_unpack<N><<<new_grid, kBlock, 0, st>>>(PP_UNPACK_ARGS);                               \
+    break;
+      const RankToSlot rs{new_element, ps->s_eslot0.as<int>(), C_new};
+      switch (NQ) {
+        PP_STAGED(1) PP_STAGED(2) PP_STAGED(3) PP_STAGED(4) PP_STAGED(6) PP_STAGED(8) PP_STAGED(10)
+      }
+#undef PP_STAGED
+#undef PP_UNPACK_ARGS
+    } else if (have_old && old_grid > 0)
+      k_move_tiled<<<old_grid, kBlock, 0, st>>>(
+          ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(),
+          ps->d_chunk_start.as<int>(), ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(),
+          ps->d_mask.as<unsigned char>(), new_element, ps->s_e2r2.as<int>(), C_new,
+          ps->s_rowstart.as<int>(), ps->s_mask2.as<unsigned char>(), mv, go);
+    if (n_new > 0) {
+      MoveArgs add = mv;
+      for (int m = 0; m < ps->nmembers; ++m) add.src[m] = new_info[m];
+      add.src_stride = n_new;
+      add.commit_x = add.commit_xt = -1;  // new particles arrive with their own positions
+      k_add_scs<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ps->s_e2r2.as<int>(), C_new,
+                                                    ps->s_rowstart.as<int>(),
+                                                    NQ > 0 ? rank_new : nullptr, ps->s_eslot0.as<int>(),
+                                                    ps->s_mask2.as<unsigned char>(), add, go);
+    }
+    return PP_OK;
+  };
+  // ---- speculative tail.  The host needs the new capacity and slice count to size buffers and
+  // launches, which used to cost a sync in the middle of the rebuild (the GPU drained, then waited
+  // for five launch latencies: ~80 us of a 1.1 ms step).  When every buffer already has room for
+  // what it had room for last time, the whole tail is enqueued against those LIMITS first; a
+  // one-thread kernel compares the true counts with them and clears tot->go when anything would
+  // not fit (or the chunk height changes, or the input is invalid), which turns the tail into
+  // no-ops.  The sync then happens once, after everything is queued.
+  bool speculated = false;
+  static const bool no_spec = getenv("PP_NO_SPEC_REBUILD") != nullptr;
+  if (!no_spec && have_old && old_grid > 0) {
+    long long cap_lim = std::min<long long>((long long)ps->s_mask2.bytes, (long long)(ps->s_slot2.bytes / 4));
+    // the component stride the swap buffers can hold today, on the spread_stride pattern
+    long long fit = (int)ps->swap.size() >= ps->nmembers ? (1ll << 40) : 0;
+    for (int m = 0; m < ps->nmembers && fit > 0; ++m)
+      fit = std::min<long long>(fit, (long long)(ps->swap[m].bytes /
+                                                 ((size_t)ps->member_ncomp[m] * ps->member_bytes[m])));
+    long long sq = fit / 64;
+    while (sq > 0 && sq % 32 != 17) --sq;
+    const int64_t stride_fit = sq * 64;
+    cap_lim = std::min<long long>(cap_lim, stride_fit);
+    if (cap_lim > 0 && getenv("PP_DIRECT_MOVE") == nullptr) {  // staging buffer: NQ quads per slot
+      const void* srcs[8];
+      for (int m = 0; m < ps->nmembers; ++m) srcs[m] = ps->data[m].p;
+      WordTable wt_probe{};
+      const int nq = build_word_table(ps, srcs, ps->stride, stride_fit, commit_x, commit_xt, wt_probe);
+      if (nq > 0) cap_lim = std::min<long long>(cap_lim, (long long)(ps->s_aos.bytes / ((size_t)nq * 16)));
+    }
+    const long long tiles_room = (long long)(ps->s_newidx.bytes / 8) - nchunks - 1;
+    cap_lim = std::min<long long>(cap_lim, tiles_room * (long long)(ps->C_max * ps->tile_p));
+    long long nsl_lim = std::min<long long>((long long)(ps->s_offsets2.bytes / 4) - 1, (long long)(ps->s_s2c2.bytes / 4));
+    cap_lim = std::min<long long>(cap_lim, 2147483647ll / 2);
+    if (cap_lim >= ps->capacity / 2 && cap_lim > 0 && nsl_lim > 0) {
+      k_spec_check<<<1, 1, 0, st>>>(tot, (int)cap_lim, (int)nsl_lim, ps->C_max);
+      rc = enqueue_tail((int)cap_lim, (int)nsl_lim, stride_fit);
+      if (rc) return rc;
+      speculated = true;
+    }
+  }
+  // The totals travel to pinned memory and the host waits for THAT copy only: whatever `pre_sync`
+  // enqueues behind it keeps the GPU busy while the host wakes up and issues its next calls.
+  static Totals* h_pin = nullptr;
+  static hipEvent_t ev_tot = nullptr;
+  if (!h_pin) {
+    PP_HIP_CHECK(hipHostMalloc((void**)&h_pin, sizeof(Totals)));
+    PP_HIP_CHECK(hipEventCreateWithFlags(&ev_tot, hipEventDisableTiming));
+  }
+  PP_HIP_CHECK(hipMemcpyAsync(h_pin, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
+  PP_HIP_CHECK(hipEventRecord(ev_tot, st));
+  if (pre_sync) {
+    rc = pre_sync(ppe);
+    if (rc) return rc;
+  }
+  PP_HIP_CHECK(hipEventSynchronize(ev_tot));  // the only host wait of a regular rebuild
+  Totals h = *h_pin;
   if (h.invalid) {
     pp::set_error(
         "rebuild: a particle's new element is out of range, or a new particle is marked inactive "
@@ -1415,103 +1583,32 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     ps->num_ptcls = 0;
     return PP_OK;
   }
-  // chooseChunkHeight (SCS_buildFns.h:3-16): C shrinks only when fewer than C_max elements hold
-  // particles -- redo the (tiny) layout with that height
-  const int C_new = std::min(h.nonempty, ps->C_max);
-  if (C_new != ps->C_max) {
-    PP_HIP_CHECK(hipMemsetAsync(&tot->cw_sum, 0, sizeof(int) * 2, st));
-    rc = enqueue_layout(ps, C_new, ppe, tot, key_base, L);
-    if (rc) return rc;
-    const int active = h.active, nonempty = h.nonempty;
-    PP_HIP_CHECK(hipMemcpyAsync(&h, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
-    PP_HIP_CHECK(hipStreamSynchronize(st));
-    h.active = active;
-    h.nonempty = nonempty;
-  }
-  const int nchunks = L.nchunks, nrows = L.nrows;
-  const int new_capacity = h.capacity, new_nslices = h.nslices;
-  // ---- new layout arrays (double-buffered against the live ones)
-  PP_HIP_CHECK(ps->s_offsets2.reserve(sizeof(int) * ((size_t)new_nslices + 1)));
-  PP_HIP_CHECK(ps->s_s2c2.reserve(sizeof(int) * (size_t)std::max(new_nslices, 1)));
-  PP_HIP_CHECK(ps->s_r2e2.reserve(sizeof(int) * (size_t)nrows));
-  PP_HIP_CHECK(ps->s_e2r2.reserve(sizeof(int) * (size_t)nrows));
-  PP_HIP_CHECK(ps->s_mask2.reserve((size_t)std::max(new_capacity, 1)));
-  PP_HIP_CHECK(ps->s_slot2.reserve(sizeof(int) * (size_t)std::max(new_capacity, 1)));
-  PP_HIP_CHECK(ps->s_rowstart.reserve(sizeof(int) * (size_t)nrows));
-  PP_HIP_CHECK(ps->s_eslot0.reserve(sizeof(int) * (size_t)std::max(ne, 1)));
-  // sum_c ceil(w_c/TP) <= nchunks + capacity/(C*TP): sizes the launch without reading the count
-  const int ntiles_max = nchunks + new_capacity / (C_new * ps->tile_p) + 1;
-  PP_HIP_CHECK(ps->s_newidx.reserve(sizeof(int) * 2 * (size_t)ntiles_max));  // new tile table
-  int* new_tiles = ps->s_newidx.as<int>();
-  const int* new_ntiles = ps->s_scan.as<int>();
-  k_tile_fill2<<<grid_for(ntiles_max), kBlock, 0, st>>>(new_ntiles, nchunks, ps->tile_p, L.tile_off,
-                                                        new_tiles);
-  k_fill_slices<<<grid_for(std::max(nchunks, 1)), kBlock, 0, st>>>(
-      nchunks, C_new, ps->V, L.widths, L.slice_off, L.chunk_start, ps->s_offsets2.as<int>(),
-      ps->s_s2c2.as<int>(), tot);
-  k_rows<<<grid_for(nrows), kBlock, 0, st>>>(nrows, ne, L.sorted ? 1 : 0, L.index,
-                                             ps->s_r2e2.as<int>(), ps->s_e2r2.as<int>());
-  k_rows_cursor_empty<<<grid_for(nrows), kBlock, 0, st>>>(nchunks, C_new, L.widths, L.chunk_start,
-                                                          ps->s_rowstart.as<int>());
-  k_init_slots_tiled<<<grid_for((size_t)ntiles_max * C_new), kBlock, 0, st>>>(
-      new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_r2e2.as<int>(),
-      ppe, ne, ps->s_slot2.as<int>(), ps->s_rowstart.as<int>(), ps->s_eslot0.as<int>(),
-      ps->s_mask2.as<unsigned char>());
-  // ---- swap buffer sizing (SCS_rebuild.h:223-229)
-  int64_t swap_stride = ps->swap_stride;
-  if (swap_stride < new_capacity || swap_stride * ps->minimize_size < new_capacity) {
-    swap_stride = (int64_t)(new_capacity * (1 + ps->extra_padding));
-    if (swap_stride < new_capacity) swap_stride = new_capacity;
-    swap_stride = spread_stride(swap_stride);
-  }
-  rc = alloc_members(ps, ps->swap, swap_stride, false);
-  if (rc) return rc;
-  ps->swap_stride = swap_stride;
-  // ---- move every member of every live particle
-  MoveArgs mv = make_move(ps, ps->data, ps->stride, ps->swap, swap_stride);
-  mv.commit_x = commit_x;
-  mv.commit_xt = commit_xt;
-  // record = all members (fast path needs 4/8-byte scalars, see build_word_table)
-  WordTable wt{};
-  int NQ = 0;
-  if (have_old && old_grid > 0 && getenv("PP_DIRECT_MOVE") == nullptr) {
-    const void* srcs[8];
-    for (int m = 0; m < ps->nmembers; ++m) srcs[m] = ps->data[m].p;
-    NQ = build_word_table(ps, srcs, ps->stride, swap_stride, commit_x, commit_xt, wt);
-  }
-  if (NQ > 0) {
-    PP_HIP_CHECK(ps->s_aos.reserve((size_t)std::max(new_capacity, 1) * NQ * 16));
-    uint4* aos = ps->s_aos.as<uint4>();
-    const unsigned new_grid = grid_for((size_t)ntiles_max * C_new);
-#define PP_UNPACK_ARGS \
-  new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_mask2.as<unsigned char>(), aos, wt
-#define PP_STAGED(N)                                                                         \
-  case N:                                                                                    \
-    k_move_pack<N><<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, rank, rs, aos, wt); \
-    k_move_unpack<N><<<new_grid, kBlock, 0, st>>>(PP_UNPACK_ARGS);                           \
-    break;
-    const RankToSlot rs{new_element, ps->s_eslot0.as<int>(), C_new};
-    switch (NQ) {
-      PP_STAGED(1) PP_STAGED(2) PP_STAGED(3) PP_STAGED(4) PP_STAGED(6) PP_STAGED(8) PP_STAGED(10)
+  if (getenv("PP_SPEC_DEBUG"))
+    fprintf(stderr, "rebuild: speculated %d go %d capacity %d (old %d) nslices %d active %d nonempty %d\n",
+            (int)speculated, h.go, h.capacity, ps->capacity, h.nslices, h.active, h.nonempty);
+  if (!(speculated && h.go)) {
+    // chooseChunkHeight (SCS_buildFns.h:3-16): C shrinks only when fewer than C_max elements hold
+    // particles -- redo the (tiny) layout with that height
+    C_new = std::min(h.nonempty, ps->C_max);
+    if (C_new != ps->C_max) {
+      PP_HIP_CHECK(hipMemsetAsync(&tot->cw_sum, 0, sizeof(int) * 2, st));
+      rc = enqueue_layout(ps, C_new, ppe, tot, key_base, L);
+      if (rc) return rc;
+      const int active = h.active, nonempty = h.nonempty;
+      PP_HIP_CHECK(hipMemcpyAsync(&h, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
+      PP_HIP_CHECK(hipStreamSynchronize(st));
+      h.active = active;
+      h.nonempty = nonempty;
+      nchunks = L.nchunks;
+      nrows = L.nrows;
     }
-#undef PP_STAGED
-#undef PP_UNPACK_ARGS
-  } else if (have_old && old_grid > 0)
-    k_move_tiled<<<old_grid, kBlock, 0, st>>>(
-        ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(),
-        ps->d_chunk_start.as<int>(), ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(),
-        ps->d_mask.as<unsigned char>(), new_element, ps->s_e2r2.as<int>(), C_new,
-        ps->s_rowstart.as<int>(), ps->s_mask2.as<unsigned char>(), mv);
-  if (n_new > 0) {
-    MoveArgs add = mv;
-    for (int m = 0; m < ps->nmembers; ++m) add.src[m] = new_info[m];
-    add.src_stride = n_new;
-    add.commit_x = add.commit_xt = -1;  // new particles arrive with their own positions
-    k_add_scs<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ps->s_e2r2.as<int>(), C_new,
-                                                  ps->s_rowstart.as<int>(),
-                                                  NQ > 0 ? rank_new : nullptr, ps->s_eslot0.as<int>(),
-                                                  ps->s_mask2.as<unsigned char>(), add);
+    const int one = 1;
+    PP_HIP_CHECK(hipMemcpyAsync(&tot->go, &one, sizeof(int), hipMemcpyHostToDevice, st));
+    rc = enqueue_tail(h.capacity, h.nslices, 0);
+    if (rc) return rc;
   }
+  const int new_capacity = h.capacity, new_nslices = h.nslices;
+  ntiles_max = nchunks + new_capacity / (C_new * ps->tile_p) + 1;  // launch bound of the next calls
   PP_LAUNCH_CHECK();
   // ---- swap in
   ps->data.swap(ps->swap);
@@ -1600,10 +1697,10 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   case N:                                                                                        \
     if (nold > 0)                                                                                \
       k_move_pack<N><<<grid_for(nold), kBlock, 0, st>>>(                                         \
-          nold, rank, RankToSlot{new_element, off2, 1}, aos, wt);                                \
+          nold, rank, RankToSlot{new_element, off2, 1}, aos, wt, nullptr);                                \
     if (n_new > 0)                                                                               \
       k_move_pack<N><<<grid_for(n_new), kBlock, 0, st>>>(                                        \
-          n_new, rank_new, RankToSlot{new_elems, off2, 1}, aos, wt_new);                         \
+          n_new, rank_new, RankToSlot{new_elems, off2, 1}, aos, wt_new, nullptr);                \
     k_unpack_flat<N><<<grid_for(on_process), kBlock, 0, st>>>(on_process, aos, wt);              \
     break;
     switch (NQ) {
@@ -1904,6 +2001,49 @@ int pp_ps_rebuild(pp_ps* ps, const int* new_element_dev, int n_new, const int* n
   ps->elem_count_valid = false;
   ps->version = pp::next_version();
   return csr_rebuild(ps, new_element_dev, n_new, new_elems_dev, new_info_dev);
+}
+
+int pp_ps_rebuild_scatter(pp_ps* ps, int m_x, int m_xtgt, const int* new_element_dev, int n_new,
+                          const int* new_elems_dev, const void* const* new_info_dev,
+                          const pp_mesh* mesh, int nmaps, const int* const* v2v_dev,
+                          double* const* scatter_w_dev, double rmax, int gnr, int gppr) {
+  PP_REQUIRE(ps && mesh && nmaps >= 0 && (nmaps == 0 || (v2v_dev && scatter_w_dev)),
+             "pp_ps_rebuild_scatter: null argument");
+  PP_REQUIRE(ps->num_elems == mesh->nelems, "pp_ps_rebuild_scatter: structure/mesh element mismatch");
+  PP_REQUIRE(gnr >= 2 && gppr > 0, "pp_ps_rebuild_scatter: needs gnr >= 2 (ringUp < gnr, gyroScatter.hpp:190)");
+  for (int k = 0; k < nmaps; ++k)
+    PP_REQUIRE(v2v_dev[k] && scatter_w_dev[k], "pp_ps_rebuild_scatter: null map / output");
+  const bool commit = m_x >= 0 || m_xtgt >= 0;
+  if (ps->kind != PP_SCS) {  // CSR: the reference calls back to back
+    int rc = commit ? pp_ps_rebuild_commit(ps, m_x, m_xtgt, new_element_dev, n_new, new_elems_dev, new_info_dev)
+                    : pp_ps_rebuild(ps, new_element_dev, n_new, new_elems_dev, new_info_dev);
+    for (int k = 0; k < nmaps && !rc; ++k)
+      rc = pp_gyro_scatter(mesh, ps, v2v_dev[k], rmax, gnr, gppr, scatter_w_dev[k]);
+    return rc;
+  }
+  if (commit) {
+    PP_REQUIRE(m_x >= 0 && m_xtgt >= 0 && m_x < ps->nmembers && m_xtgt < ps->nmembers && m_x != m_xtgt,
+               "pp_ps_rebuild_scatter: bad member index");
+    PP_REQUIRE(ps->member_bytes[m_x] == 8 && ps->member_bytes[m_xtgt] == 8 &&
+                   ps->member_ncomp[m_x] == ps->member_ncomp[m_xtgt],
+               "pp_ps_rebuild_scatter: x and x_tgt must be double members of equal shape");
+  }
+  PP_REQUIRE(new_element_dev || ps->capacity == 0, "pp_ps_rebuild_scatter: null new_element");
+  PP_REQUIRE(n_new >= 0 && (n_new == 0 || new_elems_dev), "pp_ps_rebuild_scatter: bad new particles");
+  for (int m = 0; m < ps->nmembers; ++m)
+    if (ps->member_map[m] != m) {  // normalise a pending pp_ps_swap_members permutation
+      std::vector<pp::DevBuf> tmp((size_t)ps->nmembers);
+      for (int q = 0; q < ps->nmembers; ++q) tmp[q].swap(ps->data[ps->member_map[q]]);
+      for (int q = 0; q < ps->nmembers; ++q) ps->data[q].swap(tmp[q]);
+      std::iota(ps->member_map.begin(), ps->member_map.end(), 0);
+      break;
+    }
+  auto scatter = [&](const int* counts) -> int {
+    return pp::gyro_scatter_counts(mesh, counts, nmaps, v2v_dev, scatter_w_dev, rmax, gnr, gppr);
+  };
+  return scs_rebuild(ps, new_element_dev, n_new, new_elems_dev, new_info_dev, commit ? m_x : -1,
+                     commit ? m_xtgt : -1, nmaps > 0 ? std::function<int(const int*)>(scatter)
+                                                     : std::function<int(const int*)>());
 }
 
 int pp_ps_rebuild_commit(pp_ps* ps, int m_x, int m_xtgt, const int* new_element_dev, int n_new,

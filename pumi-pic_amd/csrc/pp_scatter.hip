@@ -284,6 +284,12 @@ __global__ void k_vert_density(int nverts, const int* __restrict__ v2e_off,
   dens[t] = val / deg;
 }
 
+// ring accumulation kept for the next pp_gyro_scatter call on the same particle->element assignment
+const pp_ps* c_ps = nullptr;
+const pp_mesh* c_mesh = nullptr;
+unsigned long long c_version = 0;
+int c_gnr = 0, c_down = -1;
+pp::DevBuf* g_ring = nullptr;  // library-lifetime scratch: ring accumulator
 struct InvMap {
   const int* key[2];  // forward and backward map of one pp_create_gyro_ring_mappings call
   size_t bytes;
@@ -316,6 +322,37 @@ void gyro_map_invalidate(const void* dev, size_t bytes) {
       ++i;
     }
   }
+}
+int gyro_scatter_counts(const pp_mesh* mesh, const int* cnt_dev, int nmaps, const int* const* v2v_dev,
+                        double* const* out_dev, double rmax, int gnr, int gppr) {
+  hipStream_t st = pp::stream();
+  const int nverts = mesh->nverts, nvpe = mesh->dim + 1;
+  const double ringWidth = rmax / gnr;
+  const double ptclRadius = ringWidth * 1.125;  // gyroScatter.hpp:184-187
+  int ringDown = 0;
+  for (int i = 2; i <= gnr; i++) ringDown += (ptclRadius >= ringWidth * i);
+  const int ringUp = ringDown + 1;
+  if (!g_ring) g_ring = new pp::DevBuf();
+  PP_HIP_CHECK(g_ring->reserve(sizeof(double) * (size_t)std::max(nverts * gnr, 1)));
+  c_ps = nullptr;  // the accumulator no longer belongs to a (structure, version) pair
+  if (nverts == 0) return PP_OK;
+  k_rings_from_adjacency<<<grid_for(nverts), kBlock, 0, st>>>(
+      nverts, gnr, mesh->d_vert2elems_off.as<int>(), mesh->d_vert2elems.as<int>(), cnt_dev, ringDown,
+      ringUp, g_ring->as<double>());
+  static const bool no_gather = getenv("PP_SCATTER_ATOMIC") != nullptr;
+  for (int k = 0; k < nmaps; ++k) {
+    const InvMap* inv = no_gather ? nullptr : find_inverse(v2v_dev[k], mesh, gnr, gppr);
+    if (inv) {
+      k_scatter_gathered<<<grid_for((size_t)nverts * 16), kBlock, 0, st>>>(
+          nverts, gppr, inv->off.as<int>(), inv->src.as<int>(), g_ring->as<double>(), out_dev[k]);
+    } else {
+      PP_HIP_CHECK(hipMemsetAsync(out_dev[k], 0, sizeof(double) * (size_t)nverts, st));
+      k_scatter_mapped<<<grid_for((size_t)nverts * gnr * gppr), kBlock, 0, st>>>(
+          nverts, gnr, gppr, nvpe, g_ring->as<double>(), v2v_dev[k], out_dev[k]);
+    }
+  }
+  PP_LAUNCH_CHECK();
+  return PP_OK;
 }
 void gyro_map_mesh_gone(const void* mesh) {
   for (size_t i = 0; i < g_inv.size();) {
@@ -398,7 +435,8 @@ int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, do
   for (int i = 2; i <= gnr; i++) ringDown += (ptclRadius >= ringWidth * i);
   const int ringUp = ringDown + 1;
   static pp::DevBuf* s_cnt = new pp::DevBuf();   // library-lifetime scratch
-  static pp::DevBuf* s_ring = new pp::DevBuf();
+  if (!g_ring) g_ring = new pp::DevBuf();
+  pp::DevBuf* s_ring = g_ring;
   PP_HIP_CHECK(s_cnt->reserve(sizeof(int) * (size_t)std::max(ne, 1)));
   PP_HIP_CHECK(s_ring->reserve(sizeof(double) * (size_t)std::max(nverts * gnr, 1)));
   static const bool no_gather = getenv("PP_SCATTER_ATOMIC") != nullptr;
@@ -409,10 +447,6 @@ int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, do
     // The ring accumulation depends only on (mesh, particle->element assignment, ring geometry):
     // the forward and backward scatters of one step (gyroScatter.hpp is called twice per step,
     // pseudoXGCm.cpp:529-530) share it.
-    static const pp_ps* c_ps = nullptr;
-    static const pp_mesh* c_mesh = nullptr;
-    static unsigned long long c_version = 0;
-    static int c_gnr = 0, c_down = -1;
     const bool reuse = c_ps == ps && c_mesh == mesh && c_version == ps->version && ps->version != 0 &&
                        c_gnr == gnr && c_down == ringDown;
     if (!reuse) {

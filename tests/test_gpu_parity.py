@@ -1271,3 +1271,44 @@ def test_picpart_bfs_layers_exact(ppo, synth, capi, dim, bridge):
             io = ppo.bfs_safe_inward(mo, owner, rank, safe_layers, po_, bridge)
             ig = capi.bfs_safe_inward(mg, d_owner, rank, nranks, safe_layers, pg_, bridge)
             assert np.array_equal(io, ig.to_host()[:ne])
+
+
+@pytest.mark.parametrize("kind,commit", [("scs", True), ("scs", False), ("csr", True)])
+def test_rebuild_scatter_one_call(ppo, synth, capi, kind, commit):
+    """pp_ps_rebuild_scatter = pp_ps_rebuild[_commit] + pp_gyro_scatter per map: the same fields, the
+    same structure and the same particle data as the separate calls and as the oracle, over several
+    steps (the first rebuilds take the checked path, later ones the speculative one)."""
+    pop = common.population_2d(synth, num_ptcls=6000)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM, kind)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM, kind)
+    mg2, pg2 = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM, kind)
+    fo, bo = ppo.create_gyro_ring_mappings(mo, trig=1)
+    fg, bg = capi.create_gyro_ring_mappings(mg)
+    fg2, bg2 = capi.create_gyro_ring_mappings(mg2)
+    for step in range(6):
+        ppo.elliptical_push(po, mo, H, K, D, 3.0, trig=1)
+        _, ido, _ = ppo.search_mesh_2d(mo, po, looplimit=200)
+        ids1 = capi.DevArray.from_host(np.full(pg.capacity(), -1, dtype=np.int32))
+        ids2 = capi.DevArray.from_host(np.full(pg2.capacity(), -1, dtype=np.int32))
+        capi.push_search(mg, pg, H, K, D, 3.0, ids1, seeded=True, looplimit=200)
+        capi.push_search(mg2, pg2, H, K, D, 3.0, ids2, seeded=True, looplimit=200)
+        if commit:
+            ppo.update_positions(po)
+        po.rebuild(ido)
+        wf, wb = capi.rebuild_scatter(pg, mg, ids1, [fg, bg], commit=commit)
+        if commit:
+            pg2.rebuild_commit(ids2)
+        else:
+            pg2.rebuild(ids2)
+        wf2 = capi.gyro_scatter(mg2, pg2, fg2)
+        wb2 = capi.gyro_scatter(mg2, pg2, bg2)
+        assert np.array_equal(wf.to_host(), wf2.to_host()) and np.array_equal(wb.to_host(), wb2.to_host())
+        assert np.array_equal(wf.to_host()[:mo.nverts], ppo.gyro_scatter(mo, po, fo))
+        assert pg.nPtcls() == pg2.nPtcls() == po.nPtcls() and pg.capacity() == pg2.capacity()
+        assert np.array_equal(pg.slot_info()[1], pg2.slot_info()[1])
+        cap = pg.capacity()
+        io, xo = common.by_id(po.member(2)[0, :po.capacity()], po.slot_info()[1], po.member(0)[:, :po.capacity()])
+        ig, xg = common.by_id(pg.member(2)[0, :cap], pg.slot_info()[1], pg.member(0)[:, :cap])
+        assert np.array_equal(io, ig) and np.array_equal(xo, xg)
+        # a plain scatter after the fused call still sees the new population
+        assert np.array_equal(capi.gyro_scatter(mg, pg, fg).to_host(), wf.to_host())
