@@ -234,7 +234,10 @@ class Stepper:
             cap = max(self.ps.capacity(), 1)
             if cap > self.ids.n:  # 10% slack: the capacity wanders by a few chunk widths per rebuild
                 self.ids = capi.DevArray(cap + cap // 10, np.int32)
-            self.ids.fill_bytes(0xff)
+            if self.w["dim"] == 2:
+                self.ids.fill_bytes(0xff)  # search_mesh_2d reads its seeds: -1 = the row's element
+            # dim 3, unseeded (an "empty elem_ids", adjacency.tpp:504-515): the search writes every
+            # slot itself, -1 into the masked ones -- no fill
         elif self.name == "c5":
             capi.update_positions(self.ps)
             ne_, npr = capi.set_unsafe_procs(self.ps, self.ids, self.safe, self.owners, self.rank)
