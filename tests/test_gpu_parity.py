@@ -1312,3 +1312,66 @@ def test_rebuild_scatter_one_call(ppo, synth, capi, kind, commit):
         assert np.array_equal(io, ig) and np.array_equal(xo, xg)
         # a plain scatter after the fused call still sees the new population
         assert np.array_equal(capi.gyro_scatter(mg, pg, fg).to_host(), wf.to_host())
+
+
+def test_rebuild_speculative_and_checked_paths_alternate(ppo, synth, capi):
+    """The rebuild enqueues its tail speculatively when the buffers have room and falls back to the
+    checked path otherwise (DESIGN "The host sync").  Sequence: steady rebuilds (speculation holds) ->
+    a burst of new particles that outgrows every buffer (speculation fails after it was enqueued) ->
+    steady again -> almost everything deleted so that fewer than C elements hold particles (chunk
+    height changes: fails) -> an invalid id (error, the structure stays usable) -> steady.  After every
+    step the population equals the oracle's by particle id."""
+    pop = common.population_2d(synth, num_ptcls=3000)
+    ne = len(pop["e2v"])
+    po = ppo.PS.scs(ppo.PARTICLE_XGCM, ne, pop["ppe"], C_max=64, particle_elements=pop["elem"],
+                    particle_info=pop["info"])
+    pg = capi.PS.scs(capi.PARTICLE_XGCM, ne, pop["ppe"], C_=64, particle_elements=pop["elem"],
+                     particle_info=pop["info"])
+    po.set_try_shuffling(False)
+    rng = np.random.default_rng(17)
+    next_id = 3000
+
+    def step(move_frac, n_new, keep=None):
+        nonlocal next_id
+        dec = rng.integers(0, ne, size=next_id).astype(np.int32)
+        mv = rng.random(next_id) < move_frac
+        add_e = rng.integers(0, ne, size=n_new).astype(np.int32)
+        add = None
+        if n_new:
+            add = [rng.random((3, n_new)), rng.random((3, n_new)), np.arange(next_id, next_id + n_new, dtype=np.int32),
+                   rng.random(n_new).astype(np.float32), rng.random(n_new).astype(np.float32)]
+        outs = []
+        for ps_ in (po, pg):
+            se, mk = ps_.slot_info()
+            ids = ps_.member(2)[0, :ps_.capacity()]
+            new = np.full(len(se), -1, dtype=np.int32)
+            live = mk.astype(bool)
+            i = ids[live]
+            e = np.where(mv[i], dec[i], se[live])
+            if keep is not None:
+                e = np.where(np.isin(i, keep), e, -1)
+            new[live] = e
+            outs.append(new)
+        po.rebuild(outs[0], add_e if n_new else None, add)
+        pg.rebuild(outs[1], add_e if n_new else None, add)
+        next_id += n_new
+        assert po.nPtcls() == pg.nPtcls()
+        _check_same_population(po, pg, ppo.PARTICLE_XGCM)
+
+    for _ in range(3):
+        step(0.3, 0)
+    step(0.3, 90000)           # outgrows mask / slot / staging / swap buffers
+    for _ in range(2):
+        step(0.3, 0)
+    keep = np.arange(0, next_id, next_id // 30)   # ~30 particles left: fewer than 64 non-empty elements
+    step(0.0, 0, keep=keep)
+    step(0.5, 0)
+    bad = np.full(max(pg.capacity(), 1), -1, dtype=np.int32)
+    se, mk = pg.slot_info()
+    bad[:len(se)] = np.where(mk.astype(bool), se, -1)
+    bad[np.flatnonzero(mk)[0]] = ne + 5
+    with pytest.raises(capi.PPError):
+        pg.rebuild(bad)
+    step(0.5, 2000)
+    for _ in range(2):
+        step(0.2, 0)
