@@ -410,7 +410,9 @@ def main():
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
-                if tj.get("particles") == a.particles and tj.get("remainder", "last") == a.remainder:
+                if (tj.get("particles") == a.particles and tj.get("remainder", "last") == a.remainder
+                        and a.mesh == "100k" and a.sigma >= 2**31 - 1 and world == 1
+                        and (a.workload != "c4" or a.c4_elems == 1_000_000)):
                     traffic = tj["traffic_bytes_per_step"]
             except (ValueError, KeyError):
                 traffic = None
