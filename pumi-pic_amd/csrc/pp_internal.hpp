@@ -176,6 +176,7 @@ struct pp_ps {
   // stamp of the current particle->element assignment (unique across structures); bumped by every
   // construction and rebuild, lets pp_gyro_scatter reuse the ring accumulation of the previous call
   unsigned long long version = 0;
+  unsigned long long last_max_key = ~0ull;  // largest layout sort key of the previous rebuild (~0 = unknown)
   int tile_p = pp::kTileP;  // columns per tile (PP_TILE_P overrides, tuning knob)
   // scratch reused across rebuilds
   pp::DevBuf s_ppe, s_keys, s_keys2, s_vals, s_vals2, s_hist, s_chunkw, s_misc, s_rowstart,

@@ -591,9 +591,9 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
   flush();
 }
 // speculative rebuild tail: may it run against buffers sized for (cap_lim, nsl_lim)?
-__global__ void k_spec_check(Totals* tot, int cap_lim, int nsl_lim, int C_max) {
+__global__ void k_spec_check(Totals* tot, int cap_lim, int nsl_lim, int C_max, int key_bits) {
   tot->go = (!tot->invalid && tot->active > 0 && tot->nonempty >= C_max && tot->capacity <= cap_lim &&
-             tot->nslices <= nsl_lim)
+             tot->nslices <= nsl_lim && (key_bits >= 64 || (tot->max_key >> key_bits) == 0))
                 ? 1
                 : 0;
 }
@@ -1266,6 +1266,7 @@ MoveArgs make_move(const pp_ps* ps, const std::vector<pp::DevBuf>& src, int64_t 
 // including) the D2H read of the totals; the caller synchronises once.
 struct LayoutPlan {
   int C, nchunks, nrows;
+  int key_bits;  // key bits the radix passes of this attempt covered (64 = every bit)
   bool sorted;
   unsigned long long base;
   unsigned long long* keys;
@@ -1273,7 +1274,10 @@ struct LayoutPlan {
   int *widths, *nsl, *nslots, *slice_off, *tile_cnt, *tile_off, *chunk_start;
 };
 
-int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_base, LayoutPlan& L) {
+// bits_limit > 0: sort on the low `bits_limit` key bits only (the caller predicts the largest key
+// from the previous rebuild and checks the prediction against Totals::max_key afterwards)
+int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_base, LayoutPlan& L,
+                   int bits_limit = 0) {
   hipStream_t st = pp::stream();
   const int ne = ps->num_elems;
   L.C = C_new;
@@ -1281,6 +1285,7 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
   L.nrows = L.nchunks * C_new;
   L.sorted = ps->sigma > 1 && ne > 1;
   L.base = (unsigned long long)key_base;
+  L.key_bits = 64;
   L.keys = nullptr;
   L.index = nullptr;
   if (L.sorted) {
@@ -1299,6 +1304,11 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
     unsigned long long maxkey = (unsigned long long)(n_sigma > 0 ? n_sigma : 1) * L.base;
     int bits = 0;
     while (bits < 64 && (maxkey >> bits)) ++bits;
+    L.key_bits = 64;
+    if (bits_limit > 0 && bits_limit < bits) {
+      bits = bits_limit;
+      L.key_bits = (bits + 7) / 8 * 8;
+    }
     unsigned long long *ka = ps->s_keys.as<unsigned long long>(),
                        *kb = ps->s_keys2.as<unsigned long long>();
     int *va = ps->s_vals.as<int>(), *vb = ps->s_vals2.as<int>();
@@ -1422,7 +1432,16 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   // a D2H read of the live count before the layout can start.
   const long long key_base = (long long)(have_old ? ps->num_ptcls : 0) + n_new + 1;
   LayoutPlan L;
-  int rc = enqueue_layout(ps, ps->C_max, ppe, tot, key_base, L);
+  // radix passes: the largest key of the previous rebuild (+1 bit) predicts how many are needed;
+  // a pass that turns out to be unnecessary still costs five launches (45 us of a 0.44 ms step at
+  // 1 M elements / 1 M particles)
+  int bits_pred = 0;
+  static const bool no_pred = getenv("PP_NO_RS_PREDICT") != nullptr;
+  if (!no_pred && ps->last_max_key != ~0ull) {
+    while (bits_pred < 63 && (ps->last_max_key >> bits_pred)) ++bits_pred;
+    ++bits_pred;
+  }
+  int rc = enqueue_layout(ps, ps->C_max, ppe, tot, key_base, L, bits_pred);
   if (rc) return rc;
   int nchunks = L.nchunks, nrows = L.nrows;
   PP_HIP_CHECK(ps->s_eslot0.reserve(sizeof(int) * (size_t)std::max(ne, 1)));
@@ -1551,7 +1570,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     long long nsl_lim = std::min<long long>((long long)(ps->s_offsets2.bytes / 4) - 1, (long long)(ps->s_s2c2.bytes / 4));
     cap_lim = std::min<long long>(cap_lim, 2147483647ll / 2);
     if (cap_lim >= ps->capacity / 2 && cap_lim > 0 && nsl_lim > 0) {
-      k_spec_check<<<1, 1, 0, st>>>(tot, (int)cap_lim, (int)nsl_lim, ps->C_max);
+      k_spec_check<<<1, 1, 0, st>>>(tot, (int)cap_lim, (int)nsl_lim, ps->C_max, L.key_bits);
       rc = enqueue_tail((int)cap_lim, (int)nsl_lim, stride_fit);
       if (rc) return rc;
       speculated = true;
@@ -1584,21 +1603,27 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     return PP_OK;
   }
   if (getenv("PP_SPEC_DEBUG"))
-    fprintf(stderr, "rebuild: speculated %d go %d capacity %d (old %d) nslices %d active %d nonempty %d\n",
-            (int)speculated, h.go, h.capacity, ps->capacity, h.nslices, h.active, h.nonempty);
+    fprintf(stderr, "rebuild: speculated %d go %d capacity %d (old %d) nslices %d active %d nonempty %d "
+                    "key bits sorted %d max key %llu\n",
+            (int)speculated, h.go, h.capacity, ps->capacity, h.nslices, h.active, h.nonempty, L.key_bits,
+            h.max_key);
   if (!(speculated && h.go)) {
     // chooseChunkHeight (SCS_buildFns.h:3-16): C shrinks only when fewer than C_max elements hold
-    // particles -- redo the (tiny) layout with that height
+    // particles -- redo the (tiny) layout with that height; same when the predicted number of
+    // radix passes did not cover the largest key
     C_new = std::min(h.nonempty, ps->C_max);
-    if (C_new != ps->C_max) {
+    const bool sort_ok = L.key_bits >= 64 || (h.max_key >> L.key_bits) == 0;
+    if (C_new != ps->C_max || !sort_ok) {
       PP_HIP_CHECK(hipMemsetAsync(&tot->cw_sum, 0, sizeof(int) * 2, st));
       rc = enqueue_layout(ps, C_new, ppe, tot, key_base, L);
       if (rc) return rc;
       const int active = h.active, nonempty = h.nonempty;
+      const unsigned long long max_key = h.max_key;
       PP_HIP_CHECK(hipMemcpyAsync(&h, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
       PP_HIP_CHECK(hipStreamSynchronize(st));
       h.active = active;
       h.nonempty = nonempty;
+      h.max_key = std::max(h.max_key, max_key);
       nchunks = L.nchunks;
       nrows = L.nrows;
     }
@@ -1607,6 +1632,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     rc = enqueue_tail(h.capacity, h.nslices, 0);
     if (rc) return rc;
   }
+  ps->last_max_key = h.max_key;
   const int new_capacity = h.capacity, new_nslices = h.nslices;
   ntiles_max = nchunks + new_capacity / (C_new * ps->tile_p) + 1;  // launch bound of the next calls
   PP_LAUNCH_CHECK();

@@ -1318,7 +1318,8 @@ def test_rebuild_speculative_and_checked_paths_alternate(ppo, synth, capi):
     """The rebuild enqueues its tail speculatively when the buffers have room and falls back to the
     checked path otherwise (DESIGN "The host sync").  Sequence: steady rebuilds (speculation holds) ->
     a burst of new particles that outgrows every buffer (speculation fails after it was enqueued) ->
-    steady again -> almost everything deleted so that fewer than C elements hold particles (chunk
+    steady again -> every particle into one element (the layout sort needs more radix passes than
+    the previous rebuild predicted) -> almost everything deleted so that fewer than C elements hold particles (chunk
     height changes: fails) -> an invalid id (error, the structure stays usable) -> steady.  After every
     step the population equals the oracle's by particle id."""
     pop = common.population_2d(synth, num_ptcls=3000)
@@ -1331,9 +1332,11 @@ def test_rebuild_speculative_and_checked_paths_alternate(ppo, synth, capi):
     rng = np.random.default_rng(17)
     next_id = 3000
 
-    def step(move_frac, n_new, keep=None):
+    def step(move_frac, n_new, keep=None, all_to=None):
         nonlocal next_id
         dec = rng.integers(0, ne, size=next_id).astype(np.int32)
+        if all_to is not None:
+            dec[:] = all_to
         mv = rng.random(next_id) < move_frac
         add_e = rng.integers(0, ne, size=n_new).astype(np.int32)
         add = None
@@ -1363,6 +1366,9 @@ def test_rebuild_speculative_and_checked_paths_alternate(ppo, synth, capi):
     step(0.3, 90000)           # outgrows mask / slot / staging / swap buffers
     for _ in range(2):
         step(0.3, 0)
+    step(1.0, 0, all_to=7)     # one element takes everything: the sort key outgrows the predicted passes
+    step(1.0, 0)               # and spreads out again
+    step(0.3, 0)
     keep = np.arange(0, next_id, next_id // 30)   # ~30 particles left: fewer than 64 non-empty elements
     step(0.0, 0, keep=keep)
     step(0.5, 0)
