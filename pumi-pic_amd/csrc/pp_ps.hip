@@ -604,7 +604,7 @@ __global__ void k_nonempty(int ne, const int* __restrict__ ppe, Totals* tot) {
   __shared__ int s_nz[4], s_sum[4];
   int nz = 0, sum = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ne; i += gridDim.x * blockDim.x) {
-    const int n = ppe[i];  // grid-stride: at most 64 blocks touch the two counters
+    const int n = ppe[i];  // grid-stride: at most 256 blocks touch the two counters
     nz += n > 0;
     sum += n;
   }
@@ -1427,7 +1427,11 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   if (n_new > 0) {
     k_count_added<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ne, ppe, tot, rank_new);
   }
-  if (ne > 0) k_nonempty<<<std::min(grid_for(ne), 64u), kBlock, 0, st>>>(ne, ppe, tot);
+  // 64..256 blocks: each block ends with two atomics on the same two counters (~5 ns apiece), each
+  // thread strides over ne / (blocks * 256) elements
+  if (ne > 0)
+    k_nonempty<<<std::min(grid_for(ne), std::min(256u, std::max(64u, (unsigned)(ne / 4096)))), kBlock, 0, st>>>(
+        ne, ppe, tot);
   // Sort keys are (window, count) with count < key_base; an upper bound known on the host avoids
   // a D2H read of the live count before the layout can start.
   const long long key_base = (long long)(have_old ? ps->num_ptcls : 0) + n_new + 1;
