@@ -591,6 +591,9 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
   flush();
 }
 // speculative rebuild tail: may it run against buffers sized for (cap_lim, nsl_lim)?
+__global__ void k_spec_check_csr(Totals* tot, int expected) {
+  tot->go = (!tot->invalid && tot->active == expected) ? 1 : 0;
+}
 __global__ void k_spec_check(Totals* tot, int cap_lim, int nsl_lim, int C_max, int key_bits) {
   tot->go = (!tot->invalid && tot->active > 0 && tot->nonempty >= C_max && tot->capacity <= cap_lim &&
              tot->nslices <= nsl_lim && (key_bits >= 64 || (tot->max_key >> key_bits) == 0))
@@ -1060,7 +1063,9 @@ __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
 // CSR staged move (same two passes as SCS): slot assignment by the element cursor, pack through
 // the LDS transpose into 64-B-multiple records, then a flat pass that writes the new SoA coalesced
 template <int NQ>
-__global__ void k_unpack_flat(int n, const uint4* __restrict__ aos, WordTable t) {
+__global__ void k_unpack_flat(int n, const uint4* __restrict__ aos, WordTable t,
+                              const int* __restrict__ go) {
+  if (!*go) return;
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= n) return;
   const uint4* sp = aos + (long long)slot * NQ;
@@ -1082,7 +1087,8 @@ __global__ void k_unpack_flat(int n, const uint4* __restrict__ aos, WordTable t)
 }
 // CSR counting sort (CSR_rebuild.hpp:62-108)
 __global__ void k_move_csr(int nold, const int* __restrict__ new_element, int* __restrict__ cursor,
-                           MoveArgs a) {
+                           MoveArgs a, const int* __restrict__ go) {
+  if (!*go) return;
   const int pid = blockIdx.x * blockDim.x + threadIdx.x;
   if (pid >= nold) return;
   const int e = new_element[pid];
@@ -1091,7 +1097,8 @@ __global__ void k_move_csr(int nold, const int* __restrict__ new_element, int* _
   copy_members(a, pid, idx);
 }
 __global__ void k_add_csr(int n_new, const int* __restrict__ new_elems, int* __restrict__ cursor,
-                          MoveArgs a) {
+                          MoveArgs a, const int* __restrict__ go) {
+  if (!*go) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_new) return;
   const int idx = atomicAdd(&cursor[new_elems[i]], 1);
@@ -1136,7 +1143,9 @@ __global__ void k_count_csr(int nold, const int* __restrict__ new_element,
 // stores), finds the element of its first slot by bisection and then walks the offsets forward.
 // (One wave per element row, the obvious form, runs at 0.25 TB/s when rows are a few hundred slots.)
 __global__ void k_csr_slots(int ne, const int* __restrict__ offsets, int capacity,
-                            int* __restrict__ slot_elem, unsigned char* __restrict__ mask) {
+                            int* __restrict__ slot_elem, unsigned char* __restrict__ mask,
+                            const int* __restrict__ go) {
+  if (go && !*go) return;
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long first = (g >> 6) * 512 + (g & 63);
   if (first >= capacity) return;
@@ -1689,75 +1698,110 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   PP_HIP_CHECK(ps->s_offsets2.reserve(sizeof(int) * ((size_t)ne + 1)));
   if (scan_excl(ps->s_scan2, ne + 1, ppe, ps->s_offsets2.as<int>(), &tot->active, st)) return PP_EHIP;
   PP_LAUNCH_CHECK();
-  Totals h{};
-  PP_HIP_CHECK(hipMemcpyAsync(&h, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
-  PP_HIP_CHECK(hipStreamSynchronize(st));
+  if (n_new > 0) PP_REQUIRE(new_info != nullptr, "rebuild: new particles need new_info_dev");
+  const int* go = &tot->go;
+  int64_t new_stride = 0;
+  // everything after the counts: swap sizing, the two move passes, the slot tables (all kernels
+  // return at once when tot->go == 0)
+  auto enqueue_tail = [&](int on_process) -> int {
+    int64_t swap_stride = ps->swap_stride;
+    if (on_process > swap_stride)
+      swap_stride = (int64_t)(ps->padding_amount * on_process);
+    else if (on_process < ps->minimize_size * swap_stride)
+      swap_stride = (int64_t)(ps->padding_amount * on_process);
+    if (swap_stride < on_process) swap_stride = on_process;
+    int rc = alloc_members(ps, ps->swap, swap_stride, false);
+    if (rc) return rc;
+    new_stride = swap_stride;
+    PP_HIP_CHECK(ps->s_rowstart.reserve(sizeof(int) * ((size_t)ne + 1)));
+    PP_HIP_CHECK(hipMemcpyAsync(ps->s_rowstart.p, ps->s_offsets2.p, sizeof(int) * ((size_t)ne + 1),
+                                hipMemcpyDeviceToDevice, st));
+    MoveArgs mv = make_move(ps, ps->data, ps->stride, ps->swap, swap_stride);
+    WordTable wt{}, wt_new{};
+    int NQ = 0;
+    if (getenv("PP_DIRECT_MOVE") == nullptr) {
+      const void* srcs[8];
+      for (int m = 0; m < ps->nmembers; ++m) srcs[m] = ps->data[m].p;
+      NQ = build_word_table(ps, srcs, ps->stride, swap_stride, -1, -1, wt);
+      if (NQ > 0 && n_new > 0 && build_word_table(ps, new_info, n_new, swap_stride, -1, -1, wt_new) != NQ) NQ = 0;
+    }
+    if (NQ > 0 && on_process > 0) {
+      PP_HIP_CHECK(ps->s_aos.reserve((size_t)on_process * NQ * 16));
+      uint4* aos = ps->s_aos.as<uint4>();
+      const int* off2 = ps->s_offsets2.as<int>();
+#define PP_CSR_STAGED(N)                                                                         \
+  case N:                                                                                        \
+    if (nold > 0)                                                                                \
+      k_move_pack<N><<<grid_for(nold), kBlock, 0, st>>>(                                         \
+          nold, rank, RankToSlot{new_element, off2, 1}, aos, wt, go);                            \
+    if (n_new > 0)                                                                               \
+      k_move_pack<N><<<grid_for(n_new), kBlock, 0, st>>>(                                        \
+          n_new, rank_new, RankToSlot{new_elems, off2, 1}, aos, wt_new, go);                     \
+    k_unpack_flat<N><<<grid_for(on_process), kBlock, 0, st>>>(on_process, aos, wt, go);          \
+    break;
+      switch (NQ) {
+        PP_CSR_STAGED(1) PP_CSR_STAGED(2) PP_CSR_STAGED(3) PP_CSR_STAGED(4) PP_CSR_STAGED(6)
+        PP_CSR_STAGED(8) PP_CSR_STAGED(10)
+      }
+#undef PP_CSR_STAGED
+    } else {
+      if (nold > 0)
+        k_move_csr<<<grid_for(nold), kBlock, 0, st>>>(nold, new_element, ps->s_rowstart.as<int>(), mv, go);
+      if (n_new > 0) {
+        MoveArgs add = mv;
+        for (int m = 0; m < ps->nmembers; ++m) add.src[m] = new_info[m];
+        add.src_stride = n_new;
+        k_add_csr<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ps->s_rowstart.as<int>(), add, go);
+      }
+    }
+    // slot -> element and mask of the NEW structure (still addressed through the swap side)
+    const int new_cap = (int)swap_stride;
+    PP_HIP_CHECK(ps->s_slot2.reserve(sizeof(int) * (size_t)std::max(new_cap, 1)));
+    PP_HIP_CHECK(ps->s_mask2.reserve((size_t)std::max(new_cap, 1)));
+    k_csr_slots<<<grid_for(((size_t)std::max(new_cap, 1) + 7) / 8 + 64), kBlock, 0, st>>>(
+        ne, ps->s_offsets2.as<int>(), new_cap, ps->s_slot2.as<int>(), ps->s_mask2.as<unsigned char>(), go);
+    return PP_OK;
+  };
+  // Speculation (see scs_rebuild): without deletions the live count is nold + n_new; the tail is
+  // enqueued for that count and a one-thread kernel clears tot->go when the true count differs.
+  const int guess = nold + n_new;
+  bool speculated = false;
+  static const bool no_spec = getenv("PP_NO_SPEC_REBUILD") != nullptr;
+  if (!no_spec && guess > 0) {
+    k_spec_check_csr<<<1, 1, 0, st>>>(tot, guess);
+    int rc = enqueue_tail(guess);
+    if (rc) return rc;
+    speculated = true;
+  }
+  static Totals* h_pin = nullptr;
+  static hipEvent_t ev_tot = nullptr;
+  if (!h_pin) {
+    PP_HIP_CHECK(hipHostMalloc((void**)&h_pin, sizeof(Totals)));
+    PP_HIP_CHECK(hipEventCreateWithFlags(&ev_tot, hipEventDisableTiming));
+  }
+  PP_HIP_CHECK(hipMemcpyAsync(h_pin, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
+  PP_HIP_CHECK(hipEventRecord(ev_tot, st));
+  PP_HIP_CHECK(hipEventSynchronize(ev_tot));
+  const Totals h = *h_pin;
   if (h.invalid) {
     pp::set_error("rebuild: new element id out of range");
     return PP_EINVAL;
   }
   const int on_process = h.active;
-  int64_t swap_stride = ps->swap_stride;
-  if (on_process > swap_stride)
-    swap_stride = (int64_t)(ps->padding_amount * on_process);
-  else if (on_process < ps->minimize_size * swap_stride)
-    swap_stride = (int64_t)(ps->padding_amount * on_process);
-  if (swap_stride < on_process) swap_stride = on_process;
-  int rc = alloc_members(ps, ps->swap, swap_stride, false);
-  if (rc) return rc;
-  ps->swap_stride = swap_stride;
-  PP_HIP_CHECK(ps->s_rowstart.reserve(sizeof(int) * ((size_t)ne + 1)));
-  PP_HIP_CHECK(hipMemcpyAsync(ps->s_rowstart.p, ps->s_offsets2.p, sizeof(int) * ((size_t)ne + 1),
-                              hipMemcpyDeviceToDevice, st));
-  MoveArgs mv = make_move(ps, ps->data, ps->stride, ps->swap, swap_stride);
-  if (n_new > 0) PP_REQUIRE(new_info != nullptr, "rebuild: new particles need new_info_dev");
-  WordTable wt{}, wt_new{};
-  int NQ = 0;
-  if (getenv("PP_DIRECT_MOVE") == nullptr) {
-    const void* srcs[8];
-    for (int m = 0; m < ps->nmembers; ++m) srcs[m] = ps->data[m].p;
-    NQ = build_word_table(ps, srcs, ps->stride, swap_stride, -1, -1, wt);
-    if (NQ > 0 && n_new > 0 && build_word_table(ps, new_info, n_new, swap_stride, -1, -1, wt_new) != NQ) NQ = 0;
+  if (!(speculated && h.go)) {
+    const int one = 1;
+    PP_HIP_CHECK(hipMemcpyAsync(&tot->go, &one, sizeof(int), hipMemcpyHostToDevice, st));
+    int rc = enqueue_tail(on_process);
+    if (rc) return rc;
   }
-  if (NQ > 0 && on_process > 0) {
-    PP_HIP_CHECK(ps->s_aos.reserve((size_t)on_process * NQ * 16));
-    uint4* aos = ps->s_aos.as<uint4>();
-    const int* off2 = ps->s_offsets2.as<int>();
-#define PP_CSR_STAGED(N)                                                                         \
-  case N:                                                                                        \
-    if (nold > 0)                                                                                \
-      k_move_pack<N><<<grid_for(nold), kBlock, 0, st>>>(                                         \
-          nold, rank, RankToSlot{new_element, off2, 1}, aos, wt, nullptr);                                \
-    if (n_new > 0)                                                                               \
-      k_move_pack<N><<<grid_for(n_new), kBlock, 0, st>>>(                                        \
-          n_new, rank_new, RankToSlot{new_elems, off2, 1}, aos, wt_new, nullptr);                \
-    k_unpack_flat<N><<<grid_for(on_process), kBlock, 0, st>>>(on_process, aos, wt);              \
-    break;
-    switch (NQ) {
-      PP_CSR_STAGED(1) PP_CSR_STAGED(2) PP_CSR_STAGED(3) PP_CSR_STAGED(4) PP_CSR_STAGED(6)
-      PP_CSR_STAGED(8) PP_CSR_STAGED(10)
-    }
-#undef PP_CSR_STAGED
-  } else {
-    if (nold > 0)
-      k_move_csr<<<grid_for(nold), kBlock, 0, st>>>(nold, new_element, ps->s_rowstart.as<int>(), mv);
-    if (n_new > 0) {
-      MoveArgs add = mv;
-      for (int m = 0; m < ps->nmembers; ++m) add.src[m] = new_info[m];
-      add.src_stride = n_new;
-      k_add_csr<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ps->s_rowstart.as<int>(), add);
-    }
-  }
+  ps->swap_stride = new_stride;
   ps->data.swap(ps->swap);
   std::swap(ps->stride, ps->swap_stride);
   ps->d_offsets.swap(ps->s_offsets2);
+  ps->d_slot_elem.swap(ps->s_slot2);
+  ps->d_mask.swap(ps->s_mask2);
   ps->capacity = (int)ps->stride;
   ps->num_ptcls = on_process;
-  PP_HIP_CHECK(ps->d_slot_elem.reserve(sizeof(int) * (size_t)std::max(ps->capacity, 1)));
-  PP_HIP_CHECK(ps->d_mask.reserve((size_t)std::max(ps->capacity, 1)));
-  k_csr_slots<<<grid_for(((size_t)std::max(ps->capacity, 1) + 7) / 8 + 64), kBlock, 0, st>>>(
-      ne, ps->d_offsets.as<int>(), ps->capacity, ps->d_slot_elem.as<int>(),
-      ps->d_mask.as<unsigned char>());
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
