@@ -240,7 +240,9 @@ class Stepper:
             # slot itself, -1 into the masked ones -- no fill
         elif self.name == "c5":
             capi.update_positions(self.ps)
-            ne_, npr = capi.set_unsafe_procs(self.ps, self.ids, self.safe, self.owners, self.rank)
+            self.route = capi.set_unsafe_procs(self.ps, self.ids, self.safe, self.owners, self.rank,
+                                               out=getattr(self, "route", None))
+            ne_, npr = self.route
             sent, _ = self.ppdist.migrate(capi, self.ps, ne_, npr, self.rank, self.world)
             self.moved += sent
             capi.gyro_scatter(self.mesh, self.ps, self.fwd, out=self.w_f)

@@ -585,9 +585,14 @@ def avg_ptcl_density(mesh, ps):
     return ec, vd
 
 
-def set_unsafe_procs(ps, elems_dev, safe_dev, owners_dev, rank):
+def set_unsafe_procs(ps, elems_dev, safe_dev, owners_dev, rank, out=None):
+    """out = (new_elems, new_procs) DevArrays to reuse (a device allocation per step costs a
+    hipMalloc / hipFree pair, and hipFree drains the GPU)"""
     cap = max(ps.capacity(), 1)
-    ne, npr = DevArray(cap, np.int32), DevArray(cap, np.int32)
+    if out is not None and out[0].n >= cap and out[1].n >= cap:
+        ne, npr = out
+    else:
+        ne, npr = DevArray(cap + cap // 10, np.int32), DevArray(cap + cap // 10, np.int32)
     check(lib().pp_set_unsafe_procs(ps.p, elems_dev.ptr, safe_dev.ptr, owners_dev.ptr, rank, ne.ptr,
                                     npr.ptr))
     return ne, npr
