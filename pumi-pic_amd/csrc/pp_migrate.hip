@@ -9,6 +9,7 @@
 // received particles enter pp_ps_rebuild as "new particles" exactly like the reference
 // (SCS_migrate.h:198-213).
 #include <algorithm>
+#include <vector>
 #include "pp_internal.hpp"
 
 namespace {
@@ -192,6 +193,12 @@ __global__ void k_bfs_inward_set(int ne, const int* __restrict__ owner, int rank
   if (e >= ne) return;
   safe[e] = (unsigned char)(!visited[e] || owner[e] == rank);
 }
+// grow-only scratch of the per-step migration calls (library lifetime: a hipMalloc / hipFree pair
+// per call costs more than the kernels, and hipFree drains the GPU)
+pp::DevBuf& scratch(int i) {
+  static std::vector<pp::DevBuf>* v = new std::vector<pp::DevBuf>(24);
+  return (*v)[(size_t)i];
+}
 int bridge_adjacency(const pp_mesh* mesh, int bridge_dim, int* n, const int** off, const int** vals) {
   if (bridge_dim == 0) {
     *n = mesh->nverts;
@@ -235,7 +242,7 @@ int pp_ps_migrate_pack_records(const pp_ps* ps, int* new_element_dev, const int*
   int rc = build_rec_table(ps, t);
   if (rc) return rc;
   hipStream_t st = pp::stream();
-  pp::DevBuf cur;
+  pp::DevBuf& cur = scratch(0);
   PP_HIP_CHECK(cur.reserve(sizeof(int) * (size_t)nranks));
   PP_HIP_CHECK(hipMemcpyAsync(cur.p, start.data(), sizeof(int) * (size_t)nranks,
                               hipMemcpyHostToDevice, st));
@@ -258,7 +265,7 @@ int pp_ps_rebuild_records(pp_ps* ps, const int* new_element_dev, int n_recv,
   if (rc) return rc;
   hipStream_t st = pp::stream();
   // received particles become "new particles" of the rebuild (SCS_migrate.h:198-213)
-  std::vector<pp::DevBuf> info((size_t)ps->nmembers);
+  pp::DevBuf* info = &scratch(8);  // scratch(8 + m): member m of the received particles
   std::vector<const void*> ptrs((size_t)ps->nmembers);
   int w = 0;
   for (int m = 0; m < ps->nmembers; ++m) {
@@ -269,7 +276,7 @@ int pp_ps_rebuild_records(pp_ps* ps, const int* new_element_dev, int n_recv,
     for (int c = 0; c < nc; ++c)
       for (int hw = 0; hw < b / 4; ++hw) t.dst[w++] = (char*)info[m].p + ((size_t)c * n_recv) * b + hw * 4;
   }
-  pp::DevBuf elems, bad;
+  pp::DevBuf &elems = scratch(1), &bad = scratch(2);
   PP_HIP_CHECK(elems.reserve(sizeof(int) * (size_t)n_recv));
   PP_HIP_CHECK(bad.reserve(sizeof(int)));
   PP_HIP_CHECK(hipMemsetAsync(bad.p, 0, sizeof(int), st));
@@ -282,10 +289,8 @@ int pp_ps_rebuild_records(pp_ps* ps, const int* new_element_dev, int n_recv,
   PP_HIP_CHECK(hipStreamSynchronize(st));
   PP_REQUIRE(!hbad, "pp_ps_rebuild_records: received an element gid with no local id "
                     "(assert(valid_at(index)), SCS_migrate.h:184)");
-  rc = pp_ps_rebuild(ps, new_element_dev, n_recv, elems.as<int>(), ptrs.data());
-  if (rc) return rc;
-  PP_HIP_CHECK(hipStreamSynchronize(st));  // temporaries are released on return
-  return PP_OK;
+  // the scratch buffers outlive the call: the rebuild may still be reading them, in stream order
+  return pp_ps_rebuild(ps, new_element_dev, n_recv, elems.as<int>(), ptrs.data());
 }
 
 int pp_set_unsafe_procs(const pp_ps* ps, const int* elems_dev, const unsigned char* safe_dev,
@@ -306,7 +311,7 @@ int pp_ps_migrate_count(const pp_ps* ps, const int* new_element_dev, const int* 
   PP_REQUIRE(ps && new_element_dev && new_process_dev && send_counts_host && nranks > 0,
              "pp_ps_migrate_count: bad argument");
   hipStream_t st = pp::stream();
-  pp::DevBuf cnt;
+  pp::DevBuf& cnt = scratch(3);
   PP_HIP_CHECK(cnt.reserve(sizeof(int) * (size_t)nranks));
   PP_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(int) * (size_t)nranks, st));
   if (ps->num_ptcls > 0 && ps->capacity > 0)
@@ -334,7 +339,7 @@ int pp_ps_migrate_pack(const pp_ps* ps, int* new_element_dev, const int* new_pro
   if (total == 0) return PP_OK;
   PP_REQUIRE(send_gid_dev && send_info_dev, "pp_ps_migrate_pack: null send buffers");
   hipStream_t st = pp::stream();
-  pp::DevBuf cur;
+  pp::DevBuf& cur = scratch(0);
   PP_HIP_CHECK(cur.reserve(sizeof(int) * (size_t)nranks));
   PP_HIP_CHECK(hipMemcpyAsync(cur.p, start.data(), sizeof(int) * (size_t)nranks,
                               hipMemcpyHostToDevice, st));
