@@ -239,14 +239,13 @@ class Stepper:
             # dim 3, unseeded (an "empty elem_ids", adjacency.tpp:504-515): the search writes every
             # slot itself, -1 into the masked ones -- no fill
         elif self.name == "c5":
-            capi.update_positions(self.ps)
             self.route = capi.set_unsafe_procs(self.ps, self.ids, self.safe, self.owners, self.rank,
                                                out=getattr(self, "route", None))
             ne_, npr = self.route
-            sent, _ = self.ppdist.migrate(capi, self.ps, ne_, npr, self.rank, self.world)
+            # updatePtclPositions rides in the records / the rebuild, the two scatters behind it
+            sent, _ = self.ppdist.migrate(capi, self.ps, ne_, npr, self.rank, self.world, commit=True,
+                                          scatter=(self.mesh, [self.fwd, self.bkwd], [self.w_f, self.w_b]))
             self.moved += sent
-            capi.gyro_scatter(self.mesh, self.ps, self.fwd, out=self.w_f)
-            capi.gyro_scatter(self.mesh, self.ps, self.bkwd, out=self.w_b)
             if self.world > 1:  # gyroSync: SUM over ranks of the interleaved fields
                 self._allreduce_fields()
             cap = max(self.ps.capacity(), 1)

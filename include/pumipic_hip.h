@@ -362,6 +362,18 @@ int pp_ps_migrate_pack_records(const pp_ps* ps, int* new_element_dev, const int*
                                void* send_records_dev);
 int pp_ps_rebuild_records(pp_ps* ps, const int* new_element_dev, int n_recv,
                           const void* recv_records_dev, const int* gid2lid_dev, int64_t ngids);
+/* The same two calls for a step that commits positions and scatters (pseudoXGCm.cpp:116-140,
+ * 527-530) without separate passes: the records carry the particle AFTER updatePtclPositions
+ * (member m_x is read from m_xtgt, m_xtgt travels as zeros), and the receiver's rebuild commits
+ * its own particles, takes the received ones as they are and enqueues the nmaps gyroScatter
+ * calls behind it (pp_ps_rebuild_scatter).  m_x = m_xtgt = -1 / nmaps = 0 switch either part off. */
+int pp_ps_migrate_pack_records_commit(const pp_ps* ps, int m_x, int m_xtgt, int* new_element_dev,
+                                      const int* new_process_dev, int comm_rank, int nranks,
+                                      const int* send_counts_host, void* send_records_dev);
+int pp_ps_rebuild_records_scatter(pp_ps* ps, int m_x, int m_xtgt, const int* new_element_dev, int n_recv,
+                                  const void* recv_records_dev, const int* gid2lid_dev, int64_t ngids,
+                                  const pp_mesh* mesh, int nmaps, const int* const* v2v_dev,
+                                  double* const* scatter_w_dev, double rmax, int gnr, int gppr);
 
 #ifdef __cplusplus
 }

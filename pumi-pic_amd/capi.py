@@ -108,6 +108,9 @@ SYMBOLS = {
     "pp_bfs_buffer_layers": (_I, [_V, _I, _I, _I, _I, _I, _V, _V, c_int_p]),
     "pp_bfs_safe_inward": (_I, [_V, _I, _I, _I, _I, _V, c_int_p, _V]),
     "pp_ps_rebuild_scatter": (_I, [_V, _I, _I, _V, _I, _V, _V, _V, _I, _V, _V, C.c_double, _I, _I]),
+    "pp_ps_migrate_pack_records_commit": (_I, [_V, _I, _I, _V, _V, _I, _I, c_int_p, _V]),
+    "pp_ps_rebuild_records_scatter": (_I, [_V, _I, _I, _V, _I, _V, _V, C.c_int64, _V, _I, _V, _V,
+                                           C.c_double, _I, _I]),
     "pp_search_mesh_3d": (_I, [_V, _V, _I, _I, _I, _V, _I, _V, _V, _I, c_int_p]),
     "pp_push_search": (_I, [_V, _V, _I, _I, _I, _I, _D, _D, _D, _D, _V, _I, _I, c_int_p]),
     "pp_create_gyro_ring_mappings": (_I, [_V, _D, _I, _I, _D, _V, _V]),
@@ -630,6 +633,28 @@ def migrate_pack_records(ps, new_element_dev, new_process_dev, rank, nranks, cou
                                            nranks, counts.ctypes.data, out_ptr))
 
 
+def migrate_pack_records_commit(ps, new_element_dev, new_process_dev, rank, nranks, counts, out_ptr,
+                                m_x=0, m_xtgt=1):
+    """records carry the particles after updatePtclPositions (no separate pass)"""
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    check(lib().pp_ps_migrate_pack_records_commit(ps.p, m_x, m_xtgt, new_element_dev.ptr,
+                                                  new_process_dev.ptr, rank, nranks,
+                                                  counts.ctypes.data_as(c_int_p), out_ptr))
+
+
+def rebuild_records_scatter(ps, new_element_dev, n_recv, recv_ptr, mesh=None, maps=(), outs=(),
+                            commit=True, rmax=0.038, gnr=3, gppr=8, m_x=0, m_xtgt=1,
+                            gid2lid_dev=None, ngids=0):
+    """pp_ps_rebuild_records with the position commit and the step's gyroScatter calls folded in"""
+    n = len(maps)
+    v2v = (C.c_void_p * max(n, 1))(*[m.ptr for m in maps])
+    out = (C.c_void_p * max(n, 1))(*[o.ptr for o in outs])
+    check(lib().pp_ps_rebuild_records_scatter(
+        ps.p, m_x if commit else -1, m_xtgt if commit else -1, new_element_dev.ptr, n_recv, recv_ptr,
+        gid2lid_dev.ptr if gid2lid_dev is not None else None, ngids, mesh.p if mesh is not None else None,
+        n, v2v, out, rmax, gnr, gppr))
+
+
 def rebuild_records(ps, new_element_dev, n_recv, recv_ptr, gid2lid_dev=None, ngids=0):
     check(lib().pp_ps_rebuild_records(ps.p, new_element_dev.ptr, n_recv, recv_ptr,
                                       gid2lid_dev.ptr if gid2lid_dev is not None else None, ngids))
@@ -741,5 +766,6 @@ def rebuild_scatter(ps, mesh, new_element, maps, outs=None, commit=True, rmax=0.
     v2v = (C.c_void_p * max(n, 1))(*[m.ptr for m in maps])
     out = (C.c_void_p * max(n, 1))(*[o.ptr for o in outs])
     check(lib().pp_ps_rebuild_scatter(ps.p, m_x if commit else -1, m_xtgt if commit else -1, ne.ptr, 0,
-                                      None, None, mesh.p, n, v2v, out, rmax, gnr, gppr))
+                                      None, None, mesh.p if mesh is not None else None, n, v2v, out,
+                                      rmax, gnr, gppr))
     return outs

@@ -110,7 +110,8 @@ __global__ void k_pack_records(int capacity, const unsigned char* __restrict__ m
   const long long g = gids ? gids[e] : (long long)e;
   r[0] = (unsigned)(g & 0xffffffffll);
   r[1] = (unsigned)((unsigned long long)g >> 32);
-  for (int w = 0; w < t.nwords; ++w) r[2 + w] = *(const unsigned*)(t.src[w] + (long long)pid * t.scale[w]);
+  for (int w = 0; w < t.nwords; ++w)
+    r[2 + w] = t.src[w] ? *(const unsigned*)(t.src[w] + (long long)pid * t.scale[w]) : 0u;
   new_element[pid] = -1;  // removeSentParticles (SCS_migrate.h:189-196)
 }
 __global__ void k_unpack_records(int n, const unsigned* __restrict__ rec, const int* __restrict__ gid2lid,
@@ -130,16 +131,18 @@ __global__ void k_unpack_records(int n, const unsigned* __restrict__ rec, const 
   for (int w = 0; w < t.nwords; ++w) *(unsigned*)(t.dst[w] + (long long)i * t.scale[w]) = r[2 + w];
 }
 
-int build_rec_table(const pp_ps* ps, RecTable& t) {
+// commit_x / commit_xt >= 0: the record carries the particle AFTER updatePtclPositions (member
+// commit_x is read from commit_xt's arrays, member commit_xt travels as zeros)
+int build_rec_table(const pp_ps* ps, RecTable& t, int commit_x = -1, int commit_xt = -1) {
   int nw = 0;
   for (int m = 0; m < ps->nmembers; ++m) {
-    const int s = ps->member_map[m];
+    const int s = ps->member_map[m == commit_x ? commit_xt : m];
     const int b = ps->member_bytes[s];
     PP_REQUIRE(b == 4 || b == 8, "migration records need 4- or 8-byte member scalars");
     for (int c = 0; c < ps->member_ncomp[s]; ++c)
       for (int hw = 0; hw < b / 4; ++hw) {
         PP_REQUIRE(nw < kRecMaxWords, "particle record too large for the migration pack");
-        t.src[nw] = (const char*)ps->data[s].p + ((size_t)c * ps->stride) * b + hw * 4;
+        t.src[nw] = m == commit_xt ? nullptr : (const char*)ps->data[s].p + ((size_t)c * ps->stride) * b + hw * 4;
         t.scale[nw] = b;
         t.dst[nw] = nullptr;
         ++nw;
@@ -225,9 +228,29 @@ int pp_ps_migrate_record_bytes(const pp_ps* ps) {
   return rc ? rc : t.rec_words * 4;
 }
 
+static int pack_records(const pp_ps* ps, int commit_x, int commit_xt, int* new_element_dev,
+                        const int* new_process_dev, int comm_rank, int nranks,
+                        const int* send_counts_host, void* send_records_dev);
 int pp_ps_migrate_pack_records(const pp_ps* ps, int* new_element_dev, const int* new_process_dev,
                                int comm_rank, int nranks, const int* send_counts_host,
                                void* send_records_dev) {
+  return pack_records(ps, -1, -1, new_element_dev, new_process_dev, comm_rank, nranks,
+                      send_counts_host, send_records_dev);
+}
+int pp_ps_migrate_pack_records_commit(const pp_ps* ps, int m_x, int m_xtgt, int* new_element_dev,
+                                      const int* new_process_dev, int comm_rank, int nranks,
+                                      const int* send_counts_host, void* send_records_dev) {
+  PP_REQUIRE(ps && m_x >= 0 && m_xtgt >= 0 && m_x < ps->nmembers && m_xtgt < ps->nmembers && m_x != m_xtgt,
+             "pp_ps_migrate_pack_records_commit: bad member index");
+  PP_REQUIRE(ps->member_bytes[ps->member_map[m_x]] == 8 && ps->member_bytes[ps->member_map[m_xtgt]] == 8 &&
+                 ps->member_ncomp[ps->member_map[m_x]] == ps->member_ncomp[ps->member_map[m_xtgt]],
+             "pp_ps_migrate_pack_records_commit: x and x_tgt must be double members of equal shape");
+  return pack_records(ps, m_x, m_xtgt, new_element_dev, new_process_dev, comm_rank, nranks,
+                      send_counts_host, send_records_dev);
+}
+static int pack_records(const pp_ps* ps, int commit_x, int commit_xt, int* new_element_dev,
+                        const int* new_process_dev, int comm_rank, int nranks,
+                        const int* send_counts_host, void* send_records_dev) {
   PP_REQUIRE(ps && new_element_dev && new_process_dev && send_counts_host && nranks > 0,
              "pp_ps_migrate_pack_records: bad argument");
   long long total = 0;
@@ -239,7 +262,7 @@ int pp_ps_migrate_pack_records(const pp_ps* ps, int* new_element_dev, const int*
   if (total == 0) return PP_OK;
   PP_REQUIRE(send_records_dev, "pp_ps_migrate_pack_records: null send buffer");
   RecTable t{};
-  int rc = build_rec_table(ps, t);
+  int rc = build_rec_table(ps, t, commit_x, commit_xt);
   if (rc) return rc;
   hipStream_t st = pp::stream();
   pp::DevBuf& cur = scratch(0);
@@ -257,9 +280,21 @@ int pp_ps_migrate_pack_records(const pp_ps* ps, int* new_element_dev, const int*
 
 int pp_ps_rebuild_records(pp_ps* ps, const int* new_element_dev, int n_recv,
                           const void* recv_records_dev, const int* gid2lid_dev, int64_t ngids) {
+  return pp_ps_rebuild_records_scatter(ps, -1, -1, new_element_dev, n_recv, recv_records_dev, gid2lid_dev,
+                                       ngids, nullptr, 0, nullptr, nullptr, 0.0, 2, 1);
+}
+
+int pp_ps_rebuild_records_scatter(pp_ps* ps, int m_x, int m_xtgt, const int* new_element_dev, int n_recv,
+                                  const void* recv_records_dev, const int* gid2lid_dev, int64_t ngids,
+                                  const pp_mesh* mesh, int nmaps, const int* const* v2v_dev,
+                                  double* const* scatter_w_dev, double rmax, int gnr, int gppr) {
   PP_REQUIRE(ps && n_recv >= 0 && (n_recv == 0 || recv_records_dev),
              "pp_ps_rebuild_records: bad argument");
-  if (n_recv == 0) return pp_ps_rebuild(ps, new_element_dev, 0, nullptr, nullptr);
+  const bool plain = m_x < 0 && m_xtgt < 0 && nmaps == 0;
+  if (n_recv == 0)
+    return plain ? pp_ps_rebuild(ps, new_element_dev, 0, nullptr, nullptr)
+                 : pp_ps_rebuild_scatter(ps, m_x, m_xtgt, new_element_dev, 0, nullptr, nullptr, mesh, nmaps,
+                                         v2v_dev, scatter_w_dev, rmax, gnr, gppr);
   RecTable t{};
   int rc = build_rec_table(ps, t);
   if (rc) return rc;
@@ -290,7 +325,9 @@ int pp_ps_rebuild_records(pp_ps* ps, const int* new_element_dev, int n_recv,
   PP_REQUIRE(!hbad, "pp_ps_rebuild_records: received an element gid with no local id "
                     "(assert(valid_at(index)), SCS_migrate.h:184)");
   // the scratch buffers outlive the call: the rebuild may still be reading them, in stream order
-  return pp_ps_rebuild(ps, new_element_dev, n_recv, elems.as<int>(), ptrs.data());
+  if (plain) return pp_ps_rebuild(ps, new_element_dev, n_recv, elems.as<int>(), ptrs.data());
+  return pp_ps_rebuild_scatter(ps, m_x, m_xtgt, new_element_dev, n_recv, elems.as<int>(), ptrs.data(), mesh,
+                               nmaps, v2v_dev, scatter_w_dev, rmax, gnr, gppr);
 }
 
 int pp_set_unsafe_procs(const pp_ps* ps, const int* elems_dev, const unsigned char* safe_dev,

@@ -2081,9 +2081,10 @@ int pp_ps_rebuild_scatter(pp_ps* ps, int m_x, int m_xtgt, const int* new_element
                           const int* new_elems_dev, const void* const* new_info_dev,
                           const pp_mesh* mesh, int nmaps, const int* const* v2v_dev,
                           double* const* scatter_w_dev, double rmax, int gnr, int gppr) {
-  PP_REQUIRE(ps && mesh && nmaps >= 0 && (nmaps == 0 || (v2v_dev && scatter_w_dev)),
+  PP_REQUIRE(ps && nmaps >= 0 && (nmaps == 0 || (mesh && v2v_dev && scatter_w_dev)),
              "pp_ps_rebuild_scatter: null argument");
-  PP_REQUIRE(ps->num_elems == mesh->nelems, "pp_ps_rebuild_scatter: structure/mesh element mismatch");
+  PP_REQUIRE(nmaps == 0 || ps->num_elems == mesh->nelems,
+             "pp_ps_rebuild_scatter: structure/mesh element mismatch");
   PP_REQUIRE(gnr >= 2 && gppr > 0, "pp_ps_rebuild_scatter: needs gnr >= 2 (ringUp < gnr, gyroScatter.hpp:190)");
   for (int k = 0; k < nmaps; ++k)
     PP_REQUIRE(v2v_dev[k] && scatter_w_dev[k], "pp_ps_rebuild_scatter: null map / output");

@@ -47,19 +47,34 @@ def allreduce_sum(t, group=None):
     return t
 
 
-def migrate(capi, ps, new_elems, new_procs, rank, world, group=None):
+def migrate(capi, ps, new_elems, new_procs, rank, world, group=None, commit=False, scatter=None):
     """GPU path: move particles routed to other ranks and rebuild.  new_elems / new_procs are
-    capi.DevArray (capacity ints) as produced by capi.set_unsafe_procs."""
+    capi.DevArray (capacity ints) as produced by capi.set_unsafe_procs.
+    commit: fold updatePtclPositions (x <- x_tgt, x_tgt <- 0) into the records and the rebuild
+    instead of a separate pass before the call; scatter = (mesh, maps, outs): the step's gyroScatter
+    calls ride behind the rebuild (pp_ps_rebuild_scatter)."""
+    mesh, maps, outs = scatter if scatter is not None else (None, (), ())
+    fused = commit or scatter is not None
     if world == 1:  # SCS_migrate.h:20-25
-        ps.rebuild(new_elems)
+        if fused:
+            capi.rebuild_scatter(ps, mesh, new_elems, list(maps), list(outs), commit=commit)
+        else:
+            ps.rebuild(new_elems)
         return 0, 0
     counts = capi.migrate_count(ps, new_elems, new_procs, rank, world)
     recb = capi.migrate_record_bytes(ps)
     dev = torch.device("cuda", torch.cuda.current_device())
     send = torch.empty((int(counts.sum()), recb), dtype=torch.uint8, device=dev)
-    capi.migrate_pack_records(ps, new_elems, new_procs, rank, world, counts, send.data_ptr())
+    if commit:
+        capi.migrate_pack_records_commit(ps, new_elems, new_procs, rank, world, counts, send.data_ptr())
+    else:
+        capi.migrate_pack_records(ps, new_elems, new_procs, rank, world, counts, send.data_ptr())
     capi.sync()                      # library stream -> visible to the collective's stream
     recv, recv_counts = exchange_records(send, counts, group)
     torch.cuda.synchronize()
-    capi.rebuild_records(ps, new_elems, int(recv.shape[0]), recv.data_ptr())
+    if fused:
+        capi.rebuild_records_scatter(ps, new_elems, int(recv.shape[0]), recv.data_ptr(), mesh, list(maps),
+                                     list(outs), commit=commit)
+    else:
+        capi.rebuild_records(ps, new_elems, int(recv.shape[0]), recv.data_ptr())
     return int(counts.sum()), int(recv.shape[0])

@@ -685,10 +685,14 @@ def test_cpp_driver_pseudoxgcm(synth, capi, tmp_path):
     assert "Metrics 0, C 64" in out.stdout
 
 
-def test_migration_records_two_virtual_ranks(ppo, synth, capi):
+@pytest.mark.parametrize("fused", [False, True])
+def test_migration_records_two_virtual_ranks(ppo, synth, capi, fused):
     """pp_ps_migrate_pack_records + pp_ps_rebuild_records: two element-block 'ranks' living in one
     process exchange packed records through host memory (standing in for the all-to-all-v); the
-    union of both structures must equal the single-rank oracle run, bit for bit."""
+    union of both structures must equal the single-rank oracle run, bit for bit.  fused: the
+    position commit travels in the records and in the receiver's rebuild, and the two gyroScatter
+    calls ride behind it (pp_ps_migrate_pack_records_commit, pp_ps_rebuild_records_scatter); the sum
+    of the ranks' fields must equal the oracle's field."""
     pop = common.population_2d(synth, n_b=12, n_theta=48, num_ptcls=3000, mdl_face=3, band_width=3)
     ne = len(pop["e2v"])
     world = 2
@@ -708,21 +712,27 @@ def test_migration_records_two_virtual_ranks(ppo, synth, capi):
     assert recb == 80
     owners_d = capi.DevArray.from_host(owners)
     moved = 0
+    fo, bo = ppo.create_gyro_ring_mappings(mo, trig=1)
+    fg, bg = capi.create_gyro_ring_mappings(mesh)
     for step in range(5):
         ppo.elliptical_push(po, mo, H, K, D, 6.0, trig=1)
         _, ids_o, _ = ppo.search_mesh_2d(mo, po, looplimit=200)
         ppo.update_positions(po)
         po.rebuild(ids_o)
-        outbox = []
+        outbox, fields = [], []
         for r, ps in enumerate(ranks):
             ids = capi.DevArray.from_host(np.full(max(ps.capacity(), 1), -1, dtype=np.int32))
             capi.push_search(mesh, ps, H, K, D, 6.0, ids, seeded=True, looplimit=200)
-            capi.update_positions(ps)
+            if not fused:
+                capi.update_positions(ps)
             safe = capi.DevArray.from_host((owners == r).astype(np.uint8))
             ne_d, np_d = capi.set_unsafe_procs(ps, ids, safe, owners_d, r)
             counts = capi.migrate_count(ps, ne_d, np_d, r, world)
             buf = capi.DevArray(max(int(counts.sum()) * recb, 1), np.uint8)
-            capi.migrate_pack_records(ps, ne_d, np_d, r, world, counts, buf.ptr)
+            if fused:
+                capi.migrate_pack_records_commit(ps, ne_d, np_d, r, world, counts, buf.ptr)
+            else:
+                capi.migrate_pack_records(ps, ne_d, np_d, r, world, counts, buf.ptr)
             outbox.append((ne_d, counts, buf.to_host()[:int(counts.sum()) * recb].reshape(-1, recb)))
             moved += int(counts.sum())
         for r, ps in enumerate(ranks):
@@ -733,8 +743,17 @@ def test_migration_records_two_virtual_ranks(ppo, synth, capi):
                 parts.append(data[start:start + int(counts[r])])
             recv = np.concatenate(parts) if parts else np.zeros((0, recb), np.uint8)
             rbuf = capi.DevArray.from_host(np.ascontiguousarray(recv).reshape(-1))
-            capi.rebuild_records(ps, outbox[r][0], len(recv), rbuf.ptr)
+            if fused:
+                wf = capi.DevArray(mesh.nverts, np.float64)
+                wb = capi.DevArray(mesh.nverts, np.float64)
+                capi.rebuild_records_scatter(ps, outbox[r][0], len(recv), rbuf.ptr, mesh, [fg, bg], [wf, wb])
+                fields.append((wf.to_host(), wb.to_host()))
+            else:
+                capi.rebuild_records(ps, outbox[r][0], len(recv), rbuf.ptr)
             capi.sync()
+        if fused:  # gyroSync: the ranks' fields add up to the single-rank field (exact integers / 8)
+            assert np.array_equal(sum(f for f, _ in fields), ppo.gyro_scatter(mo, po, fo))
+            assert np.array_equal(sum(b for _, b in fields), ppo.gyro_scatter(mo, po, bo))
     assert moved > 0
     ids_all, elem_all, x_all, phi_all = [], [], [], []
     for r, ps in enumerate(ranks):
