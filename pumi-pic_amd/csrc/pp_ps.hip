@@ -447,34 +447,6 @@ __global__ void k_slices_and_slots(int nchunks, int C, int V, const int* __restr
   nsl[c] = w / V + ((w % V) != 0);
   nslots[c] = w * C;
 }
-__global__ void k_fill_slices(int nchunks, int C, int V, const int* __restrict__ widths,
-                              const int* __restrict__ slice_off, const int* __restrict__ chunk_start,
-                              int* __restrict__ offsets, int* __restrict__ s2c, const Totals* tot) {
-  if (!tot->go) return;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0) offsets[tot->nslices] = tot->capacity;
-  if (c >= nchunks) return;
-  const int w = widths[c];
-  const int ns = w / V + ((w % V) != 0);
-  const int so = slice_off[c], start = chunk_start[c];
-  for (int j = 0; j < ns; ++j) {
-    offsets[so + j] = start + j * V * C;
-    s2c[so + j] = c;
-  }
-}
-__global__ void k_rows(int nrows, int ne, int sorted, const int* __restrict__ index,
-                       int* __restrict__ r2e, int* __restrict__ e2r) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nrows) return;
-  if (i < ne) {
-    const int e = sorted ? index[i] : i;
-    r2e[i] = e;
-    e2r[e] = i;
-  } else {
-    r2e[i] = i;
-    e2r[i] = i;
-  }
-}
 __global__ void k_tile_count(int nchunks, int TP, const int* __restrict__ widths,
                              int* __restrict__ ntl) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -787,23 +759,60 @@ __global__ void k_chunk_widths2(int nchunks, int C, int ne, const unsigned long 
   for (int o = 32; o > 0; o >>= 1) w = max(w, __shfl_down(w, o));
   if (lane == 0) widths[c] = w;
 }
-// one thread per tile: owning chunk by binary search in the tile prefix
-__global__ void k_tile_fill2(const int* __restrict__ ntiles_dev, int nchunks, int TP,
-                             const int* __restrict__ tile_off, int* __restrict__ tiles,
-                             const int* __restrict__ go) {
-  if (!*go) return;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= *ntiles_dev) return;
-  int lo = 0, hi = nchunks - 1;  // last chunk with tile_off[c] <= t
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (tile_off[mid] <= t)
-      lo = mid;
-    else
-      hi = mid - 1;
+// The four small table fills of the new layout in ONE launch (each was a ~5 us kernel): blocks
+// [0,b1) tile table, [b1,b2) slice offsets, [b2,b3) row <-> element, [b3,b4) cursors of empty chunks.
+struct LayoutTablesArgs {
+  unsigned b1, b2, b3;
+  const int* ntiles_dev;
+  int nchunks, TP, C, V, nrows, ne, sorted;
+  const int *tile_off, *widths, *slice_off, *chunk_start, *index;
+  int *tiles, *offsets, *s2c, *r2e, *e2r, *row_cursor;
+  const Totals* tot;
+};
+__global__ void k_layout_tables(LayoutTablesArgs a) {
+  if (!a.tot->go) return;
+  const unsigned b = blockIdx.x;
+  if (b < a.b1) {  // tile -> (chunk, first column): owning chunk by bisection in the tile prefix
+    const int t = (int)(b * blockDim.x + threadIdx.x);
+    if (t >= *a.ntiles_dev) return;
+    int lo = 0, hi = a.nchunks - 1;  // last chunk with tile_off[c] <= t
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (a.tile_off[mid] <= t)
+        lo = mid;
+      else
+        hi = mid - 1;
+    }
+    a.tiles[2 * t] = lo;
+    a.tiles[2 * t + 1] = (t - a.tile_off[lo]) * a.TP;
+  } else if (b < a.b2) {  // slice offsets and slice -> chunk
+    const int c = (int)((b - a.b1) * blockDim.x + threadIdx.x);
+    if (c == 0) a.offsets[a.tot->nslices] = a.tot->capacity;
+    if (c >= a.nchunks) return;
+    const int w = a.widths[c];
+    const int ns = w / a.V + ((w % a.V) != 0);
+    const int so = a.slice_off[c], start = a.chunk_start[c];
+    for (int j = 0; j < ns; ++j) {
+      a.offsets[so + j] = start + j * a.V * a.C;
+      a.s2c[so + j] = c;
+    }
+  } else if (b < a.b3) {  // row <-> element
+    const int i = (int)((b - a.b2) * blockDim.x + threadIdx.x);
+    if (i >= a.nrows) return;
+    if (i < a.ne) {
+      const int e = a.sorted ? a.index[i] : i;
+      a.r2e[i] = e;
+      a.e2r[e] = i;
+    } else {
+      a.r2e[i] = i;
+      a.e2r[i] = i;
+    }
+  } else {  // rows of zero-width chunks own no tile: give them a defined cursor
+    const int i = (int)((b - a.b3) * blockDim.x + threadIdx.x);
+    if (i >= a.nchunks * a.C) return;
+    const int c = i / a.C;
+    if (a.widths[c] == 0) a.row_cursor[i] = a.chunk_start[c] + i % a.C;
   }
-  tiles[2 * t] = lo;
-  tiles[2 * t + 1] = (t - tile_off[lo]) * TP;
 }
 // new layout: slot -> parent element for every slot of every tile, first slot of every row
 __global__ void k_init_slots_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
@@ -832,14 +841,6 @@ __global__ void k_init_slots_tiled(const int* __restrict__ ntiles_dev, int C, in
     slot_elem[start + p * C] = e;
     new_mask[start + p * C] = p < cnt ? 1 : 0;
   }
-}
-__global__ void k_rows_cursor_empty(int nchunks, int C, const int* __restrict__ chunk_width,
-                                    const int* __restrict__ chunk_start, int* __restrict__ row_cursor) {
-  // rows of zero-width chunks own no tile: give them a defined cursor
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nchunks * C) return;
-  const int c = i / C;
-  if (chunk_width[c] == 0) row_cursor[i] = chunk_start[c] + i % C;
 }
 
 struct MoveArgs {
@@ -1478,15 +1479,33 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     PP_HIP_CHECK(ps->s_newidx.reserve(sizeof(int) * 2 * (size_t)ntiles_max));  // new tile table
     int* new_tiles = ps->s_newidx.as<int>();
     const int* new_ntiles = ps->s_scan.as<int>();
-    k_tile_fill2<<<grid_for(ntiles_max), kBlock, 0, st>>>(new_ntiles, nchunks, ps->tile_p, L.tile_off,
-                                                          new_tiles, go);
-    k_fill_slices<<<grid_for(std::max(nchunks, 1)), kBlock, 0, st>>>(
-        nchunks, C_new, ps->V, L.widths, L.slice_off, L.chunk_start, ps->s_offsets2.as<int>(),
-        ps->s_s2c2.as<int>(), tot);
-    k_rows<<<grid_for(nrows), kBlock, 0, st>>>(nrows, ne, L.sorted ? 1 : 0, L.index,
-                                               ps->s_r2e2.as<int>(), ps->s_e2r2.as<int>());
-    k_rows_cursor_empty<<<grid_for(nrows), kBlock, 0, st>>>(nchunks, C_new, L.widths, L.chunk_start,
-                                                            ps->s_rowstart.as<int>());
+    {
+      LayoutTablesArgs ta;
+      ta.b1 = grid_for(ntiles_max);
+      ta.b2 = ta.b1 + grid_for(std::max(nchunks, 1));
+      ta.b3 = ta.b2 + grid_for(nrows);
+      ta.ntiles_dev = new_ntiles;
+      ta.nchunks = nchunks;
+      ta.TP = ps->tile_p;
+      ta.C = C_new;
+      ta.V = ps->V;
+      ta.nrows = nrows;
+      ta.ne = ne;
+      ta.sorted = L.sorted ? 1 : 0;
+      ta.tile_off = L.tile_off;
+      ta.widths = L.widths;
+      ta.slice_off = L.slice_off;
+      ta.chunk_start = L.chunk_start;
+      ta.index = L.index;
+      ta.tiles = new_tiles;
+      ta.offsets = ps->s_offsets2.as<int>();
+      ta.s2c = ps->s_s2c2.as<int>();
+      ta.r2e = ps->s_r2e2.as<int>();
+      ta.e2r = ps->s_e2r2.as<int>();
+      ta.row_cursor = ps->s_rowstart.as<int>();
+      ta.tot = tot;
+      k_layout_tables<<<ta.b3 + grid_for(nrows), kBlock, 0, st>>>(ta);
+    }
     k_init_slots_tiled<<<grid_for((size_t)ntiles_max * C_new), kBlock, 0, st>>>(
         new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_r2e2.as<int>(),
         ppe, ne, ps->s_slot2.as<int>(), ps->s_rowstart.as<int>(), ps->s_eslot0.as<int>(),
