@@ -1631,6 +1631,11 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     return PP_EINVAL;
   }
   if (h.active == 0) {  // SCS_rebuild.h:168-182 (mask left untouched like the reference)
+    // the fused commit still happens: the drivers call updatePtclPositions before the rebuild
+    if (commit_x >= 0 && commit_xt >= 0 && ps->num_ptcls > 0) {
+      rc = pp_update_positions(ps, commit_x, commit_xt);
+      if (rc) return rc;
+    }
     ps->num_ptcls = 0;
     return PP_OK;
   }
