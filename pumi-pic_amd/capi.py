@@ -476,8 +476,9 @@ def search_mesh(mesh, ps, elem_ids=None, require_intersection=False, looplimit=0
     seeded = elem_ids is not None
     if elem_ids is None:
         elem_ids = DevArray(cap, np.int32)
-    inter_faces = DevArray(cap, np.int32)
-    inter_points = DevArray(cap * mesh.dim, np.float64)
+    # the reference allocates these itself when they come in empty: -1 / 0 everywhere (tpp:538-540)
+    inter_faces = DevArray.from_host(np.full(cap, -1, dtype=np.int32))
+    inter_points = DevArray.from_host(np.zeros(cap * mesh.dim))
     found, notin = C.c_int(), C.c_int()
     check(lib().pp_search_mesh(mesh.p, ps.p, m_x, m_xtgt, m_pid, elem_ids.ptr, int(seeded),
                                int(require_intersection), inter_faces.ptr, inter_points.ptr,

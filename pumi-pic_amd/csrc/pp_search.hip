@@ -250,7 +250,10 @@ __global__ void k_search_tpp(int capacity, const unsigned char* __restrict__ mas
   const int pid = blockIdx.x * blockDim.x + threadIdx.x;
   if (pid >= capacity) return;
   const int e = slot_elem[pid];
-  if (e < 0) return;
+  if (e < 0) {  // tail slots of a CSR: an elem_ids the search allocates is -1 there (tpp:506)
+    if (!seeded) elem_ids[pid] = -1;
+    return;
+  }
   const bool msk = mask[pid];
   if (MT) {  // initializeIntersection visits every slot (tpp:542-547)
     for (int i = 0; i < DIM; ++i) inter_points[(size_t)DIM * pid + i] = 0;
@@ -697,7 +700,10 @@ __global__ void k_push_walk(int capacity, const unsigned char* __restrict__ mask
   const int pid = blockIdx.x * blockDim.x + threadIdx.x;
   if (pid >= capacity) return;
   const int e = slot_elem[pid];
-  if (e < 0) return;
+  if (e < 0) {  // tail slots of a CSR (see k_search_tpp)
+    if (DIM == 3 && !seeded) elem_ids[pid] = -1;
+    return;
+  }
   if (!mask[pid]) {
     if (DIM == 2 || !seeded) elem_ids[pid] = -1;
     return;
