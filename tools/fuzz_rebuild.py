@@ -109,6 +109,21 @@ def main(seconds=60.0, seed=0):
             next_id += n_new
             a, b = population(po, members), population(pg, members)
             ok = po.nPtcls() == pg.nPtcls() and all(np.array_equal(x, y) for x, y in zip(a, b))
+            if ok and po.nPtcls() > 0:  # the layout arrays themselves (row order = stable sort by count)
+                lo, lg = po.layout(), pg.layout()
+                for k in (("C", "num_chunks", "num_slices", "capacity", "num_rows") if kind == "scs" else ("capacity",)):
+                    if lo[k] != lg[k]:
+                        print("layout field %s: oracle %s gpu %s" % (k, lo[k], lg[k]))
+                    ok &= lo[k] == lg[k]
+                keys = ("offsets", "slice_to_chunk", "row_to_element", "element_to_row", "mask") \
+                    if kind == "scs" else ("offsets",)
+                for k in keys:
+                    if ok and k in lo and k in lg:
+                        n = min(len(lo[k]), len(lg[k]))
+                        same = np.array_equal(np.asarray(lo[k])[:n], np.asarray(lg[k])[:n])
+                        if not same:
+                            print("layout array %s differs" % k)
+                        ok &= same
             if not ok:
                 print("MISMATCH round %d step %d: %s ne=%d np=%d move=%.2f del=%.2f new=%d target=%d commit=%d "
                       "oracle %d gpu %d" % (rounds, it, desc, ne, npt, move_frac, del_frac, n_new, target, commit,

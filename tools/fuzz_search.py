@@ -136,6 +136,18 @@ def main(seconds=60.0, seed=0):
                     ok &= np.array_equal(io, ig) and np.array_equal(xo, xg)
                     if po.nPtcls() == 0:
                         break
+        if ok and rng.random() < 0.3 and po.nPtcls() > 0:  # gyro ring maps + scatter, random ring geometry
+            gnr, gppr = int(rng.integers(2, 5)), int(rng.choice([4, 6, 8]))
+            rmax, theta = float(rng.uniform(0.005, 0.08)), float(rng.uniform(0, 40))
+            fo, bo = ppo.create_gyro_ring_mappings(mo, rmax, gnr, gppr, theta, trig=1)
+            fg, bg = capi.create_gyro_ring_mappings(mg, rmax, gnr, gppr, theta)
+            c = [np.array_equal(fo, fg.to_host()[:len(fo)]), np.array_equal(bo, bg.to_host()[:len(bo)])]
+            c.append(np.array_equal(ppo.gyro_scatter(mo, po, fo, rmax, gnr, gppr),
+                                    capi.gyro_scatter(mg, pg, fg, rmax, gnr, gppr).to_host()[:mo.nverts]))
+            if not all(c):
+                print("gyro maps / scatter:", c, gnr, gppr, rmax, theta)
+            ok &= all(c)
+            checks += 1
         if not ok:
             print("MISMATCH round %d: %s flow %s deg %g looplimit %d" % (rounds, desc, flow, deg, limit))
             return 1
