@@ -71,7 +71,42 @@ def main(seconds=60.0, seed=0):
                           ro["elem_ids"][d[:5]], rg["elem_ids"].to_host()[:cap][d[:5]], po.slot_info()[1][d[:5]])
                 ok &= all(c)
                 checks += 1
+            # seeded: some particles already deleted (-1), some with a wrong parent element
+            se, mk = po.slot_info()
+            seed_ids = np.where(mk.astype(bool), se, -1).astype(np.int32)
+            lv = np.flatnonzero(mk)
+            if len(lv):
+                seed_ids[lv[rng.random(len(lv)) < 0.1]] = -1
+                wrong = lv[rng.random(len(lv)) < 0.1]
+                seed_ids[wrong] = (seed_ids[wrong] + 1 + rng.integers(0, mo.nelems, size=len(wrong))) % mo.nelems
+                seed_ids[np.flatnonzero(~mk.astype(bool))] = -1
+            ro = ppo.search_mesh(mo, po, elem_ids=seed_ids.copy(), looplimit=limit)
+            rg = capi.search_mesh(mg, pg, elem_ids=capi.DevArray.from_host(seed_ids), looplimit=limit)
+            c = [ro["found"] == rg["found"], ro["not_in_elem"] == rg["not_in_elem"],
+                 np.array_equal(ro["elem_ids"], rg["elem_ids"].to_host()[:cap])]
+            if not all(c):
+                print("seeded search_mesh:", c, ro["not_in_elem"], rg["not_in_elem"])
+            ok &= all(c)
+            st = capi.trace_particle_through_mesh(mg, pg, None, elem_ids=capi.DevArray.from_host(seed_ids),
+                                                  looplimit=limit)
+            c = [ro["found"] == st["found"], ro["loops"] == st["loops"], ro["not_in_elem"] == st["not_in_elem"],
+                 np.array_equal(ro["elem_ids"], st["elem_ids"].to_host()[:cap])]
+            if not all(c):
+                print("stepwise trace:", c)
+            ok &= all(c)
+            checks += 2
             if dim == 3:
+                # a walk started from a wrong element need not terminate (checkParent looks at the ROW
+                # element, hpp:371-382): always with a loop limit
+                lim3 = limit if limit else 60
+                r3o = ppo.search_mesh_3d(mo, po, elem_ids=seed_ids.copy(), looplimit=lim3)
+                r3g = capi.search_mesh_3d(mg, pg, elem_ids=capi.DevArray.from_host(seed_ids), looplimit=lim3)
+                c = [r3o["found"] == r3g["found"], np.array_equal(r3o["elem_ids"], r3g["elem_ids"].to_host()[:cap]),
+                     np.array_equal(r3o["xface"], r3g["xface"].to_host()[:cap])]
+                if not all(c):
+                    print("seeded search_mesh_3d:", c, r3o["found"], r3g["found"])
+                ok &= all(c)
+                checks += 1
                 for fo, fg in ((ppo.search_mesh_3d, capi.search_mesh_3d), (ppo.search_mesh_legacy3d, capi.search_mesh_legacy3d)):
                     ro, rg = fo(mo, po, looplimit=limit), fg(mg, pg, looplimit=limit)
                     ok &= ro["found"] == rg["found"] and np.array_equal(ro["elem_ids"], rg["elem_ids"].to_host()[:cap])
