@@ -2,17 +2,21 @@
 """bench.py -- particles pushed+searched(+scattered+rebuilt) per second on MI355X.
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line (rank 0).
+`--gpus N` with WORLD_SIZE unset starts N rank processes itself (before anything touches the GPU)
+and fails loudly when the box has fewer than N GPUs; under torchrun (WORLD_SIZE set) every rank
+runs this file directly.  Default workload: N = 1 -> c3 (the configuration the metric names),
+N > 1 -> c5 (the migrating one, BASELINE configs[4] shares: 998 400 tets, 32 M particles per GPU).
 A "step" is one pass of the hot path over the resident particle population:
 
-  c2 (default, BASELINE.json configs[1]): fused toroidal push + BCC adjacency walk on the
+  c2 (BASELINE.json configs[1]): fused toroidal push + BCC adjacency walk on the
       100 800-tet tokamak mesh, 10 M particles per GPU, SCS layout (C=64), no rebuild; positions
       ping-pong x <-> x_tgt and the walk is re-seeded from the previous step's element ids.
-  c3 (configs[2]): c2 + updatePtclPositions + SCS rebuild + gyroScatter x2 every step (tet variant
+  c3 (configs[2], default at N = 1): c2 + updatePtclPositions + SCS rebuild + gyroScatter x2 every step (tet variant
       of the ring map: 4 vertices per ring point); 2dc3 is the 2-D literal of it.  The
       three calls go through pp_ps_rebuild_scatter (same work, one entry point;
       PP_BENCH_SEPARATE_SCATTER=1 issues them separately).
   2d : the literal 2-D pseudoXGCm step (elliptical push + search_mesh_2d) on 100 352 triangles.
-  c5 (configs[4], opt-in): c3 with ownership: every rank owns a block of elements; after the search
+  c5 (configs[4], default at N > 1): c3 with ownership: every rank owns a block of elements; after the search
       the particles whose new element another rank owns are packed into records, exchanged with ONE
       all-to-all-v (RCCL) and enter the receiver's rebuild as new particles; the two scatter fields
       are summed over ranks (gyroSync).  Use with --mesh 1m --particles 32000000 for the config.
@@ -187,6 +191,7 @@ class Stepper:
         self.ids = capi.DevArray.from_host(np.full(cap + cap // 10, -1, dtype=np.int32))
         self.first = True
         self.kernel_ms = []
+        self.steps_done = 0
         if name == "c5":
             from pumipic_amd import dist as ppdist
             self.ppdist = ppdist
@@ -201,6 +206,14 @@ class Stepper:
                 self.safe, _ = capi.bfs_buffer_layers(self.mesh, self.owners, self.rank, self.world,
                                                       w["safe_layers"], w["safe_layers"])
             self.moved = 0
+            self.comm, self.comm_kind = None, w.get("comm", "rccl")
+            if self.comm_kind == "rccl":
+                try:
+                    self.comm = self._make_comm()
+                except Exception as e:  # noqa: BLE001 -- keep the run alive on the torch glue, loudly
+                    sys.stderr.write("bench.py: RCCL communicator behind the C-ABI failed (%r); falling back to "
+                                     "--comm torch\n" % (e,))
+                    self.comm_kind = "torch"
         if name in ("c3", "2dc3", "c5"):
             self.fwd, self.bkwd = capi.create_gyro_ring_mappings(self.mesh)
             self.w_f = capi.DevArray(self.mesh.nverts, np.float64)
@@ -214,7 +227,7 @@ class Stepper:
             self.ntimed = getattr(self, "ntimed", 0) + 1
             timed = (self.ntimed - 1) % getattr(self, "sample_every", 1) == 0 and len(self.kernel_ms) < 64
         if timed:
-            e0, e1 = capi.Event(), capi.Event()
+            e0, e1, e2 = capi.Event(), capi.Event(), capi.Event()
             e0.record()
         if self.name == "c2":
             capi.push_search(self.mesh, self.ps, self.h, self.k, self.d, self.deg, self.ids,
@@ -228,8 +241,15 @@ class Stepper:
                              seeded=True, looplimit=200, want_found=False)
         if timed:
             e1.record()
-            self.kernel_ms.append((e0, e1))
         self.first = False
+        self.steps_done += 1
+        self._rest_of_step()
+        if timed:
+            e2.record()
+            self.kernel_ms.append((e0, e1, e2))
+
+    def _rest_of_step(self):
+        capi = self.capi
         if self.name == "c2":
             self.ps.swap_members(0, 1)  # x <-> x_tgt (O(1)); no rebuild in config 2
         elif self.name in ("c3", "2dc3"):
@@ -253,16 +273,39 @@ class Stepper:
                                                out=getattr(self, "route", None))
             ne_, npr = self.route
             # updatePtclPositions rides in the records / the rebuild, the two scatters behind it
-            sent, _ = self.ppdist.migrate(capi, self.ps, ne_, npr, self.rank, self.world, commit=True,
-                                          scatter=(self.mesh, [self.fwd, self.bkwd], [self.w_f, self.w_b]))
+            scat = (self.mesh, [self.fwd, self.bkwd], [self.w_f, self.w_b])
+            if self.comm is not None:  # SellCSigma::migrate + reduceCommArray behind the C-ABI (RCCL)
+                capi.migrate_begin(self.ps, ne_, npr, self.comm, commit=True, scatter=scat)
+                sent, _ = capi.migrate_end(self.ps, self.comm)
+                if self.world > 1:  # gyroSync: SUM over ranks of the interleaved fields
+                    self.sync_d = capi.gyro_sync_pack(self.mesh.nverts, self.w_f, self.w_b,
+                                                      out=getattr(self, "sync_d", None))
+                    self.comm.allreduce_sum(self.sync_d)
+            else:
+                sent, _ = self.ppdist.migrate(capi, self.ps, ne_, npr, self.rank, self.world, commit=True,
+                                              scatter=scat)
+                if self.world > 1:
+                    self._allreduce_fields()
             self.moved += sent
-            if self.world > 1:  # gyroSync: SUM over ranks of the interleaved fields
-                self._allreduce_fields()
             cap = max(self.ps.capacity(), 1)
             if cap > self.ids.n:  # 10% slack: the capacity wanders by a few chunk widths per rebuild
                 self.ids = capi.DevArray(cap + cap // 10, np.int32)
             self.ids.fill_bytes(0xff)
         # "2d": search_mesh_2d re-seeds from the previous ids as given
+
+    def _make_comm(self):
+        """pp_comm over RCCL: rank 0 draws the id, torch.distributed (already up for the timing
+        barrier) broadcasts it -- the MPI_Bcast a PUMI-PIC build would do"""
+        capi = self.capi
+        if self.world == 1:
+            return capi.Comm.env()
+        import torch
+        import torch.distributed as dist
+        t = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if self.rank == 0:
+            t.copy_(torch.tensor(list(capi.Comm.unique_id()), dtype=torch.uint8))
+        dist.broadcast(t, 0)
+        return capi.Comm.rccl(bytes(t.cpu().tolist()), self.rank, self.world)
 
     def _allreduce_fields(self):
         import ctypes
@@ -277,12 +320,19 @@ class Stepper:
         self.ppdist.allreduce_sum(self.sync_t)
 
     def kernel_avg_ms(self):
-        return float(np.mean([a.elapsed_ms(b) for a, b in self.kernel_ms])) if self.kernel_ms else None
+        """mean HIP-event time of one pp_push_search call (both kernels)"""
+        return float(np.mean([a.elapsed_ms(b) for a, b, _ in self.kernel_ms])) if self.kernel_ms else None
+
+    def step_avg_ms(self):
+        """mean HIP-event time of the whole step on the library stream (the sampled steps)"""
+        return float(np.mean([a.elapsed_ms(c) for a, _, c in self.kernel_ms])) if self.kernel_ms else None
 
 
 def cpu_baseline(pp, w, name, deg, sample, steps=20):
     """The oracle (restated reference, Kokkos::Serial semantics: C=1, unfused kernels, one pass
-    per kernel per walk iteration) timed on one host core on a bounded sample of the workload."""
+    per kernel per walk iteration, reshuffle-then-rebuild as SCS_rebuild.h:160-189) timed on one host
+    core on a bounded sample of the workload: the same step the GPU line times (c2: push + search;
+    c3 / 2dc3 / c5: + updatePtclPositions + rebuild + gyroScatter x2)."""
     ppo = pumipic_amd_loader.load_oracle()
     s = pp.synth
     idx = np.sort(np.random.default_rng(0).choice(len(w["elem"]), size=sample, replace=False))
@@ -290,49 +340,107 @@ def cpu_baseline(pp, w, name, deg, sample, steps=20):
     ppe = np.bincount(elem, minlength=w["ne"]).astype(np.int32)
     info = [np.ascontiguousarray(a[..., idx]) for a in w["info"]]
     mesh = ppo.Mesh(w["dim"], w["coords"], w["e2v"], w["cls"])
-    ps = ppo.PS.scs(ppo.PARTICLE_XGCM, w["ne"], ppe, C_max=1, particle_elements=elem,
-                    particle_info=info)
-    ids = None
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        if w["dim"] == 3:
-            ppo.toroidal_push(ps, mesh, s.XGC_H, s.XGC_K, s.XGC_D, deg, trig=0)
-            ids = ppo.search_mesh(mesh, ps, elem_ids=ids, looplimit=200)["elem_ids"]
-            a, b = ps.member(0), ps.member(1)
-            tmp = a.copy()
-            a[:] = b
-            b[:] = tmp
-        else:
-            ppo.elliptical_push(ps, mesh, s.XGC_H, s.XGC_K, s.XGC_D, deg, trig=0)
-            _, ids, _ = ppo.search_mesh_2d(mesh, ps, elem_ids=ids, looplimit=200)
-    dt = time.perf_counter() - t0
+    full = name in ("c3", "2dc3", "c5")
+    maps = ppo.create_gyro_ring_mappings(mesh) if full else None
+
+    def make_ps():
+        return ppo.PS.scs(ppo.PARTICLE_XGCM, w["ne"], ppe, C_max=1, pad_strat=0, shuffle_padding=0.1,
+                          extra_padding=0.0, particle_elements=elem, particle_info=info)
+
+    def run(ps):
+        ids = None
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            if w["dim"] == 3:
+                ppo.toroidal_push(ps, mesh, s.XGC_H, s.XGC_K, s.XGC_D, deg, trig=0)
+                ids = ppo.search_mesh(mesh, ps, elem_ids=None if full else ids, looplimit=200)["elem_ids"]
+            else:
+                ppo.elliptical_push(ps, mesh, s.XGC_H, s.XGC_K, s.XGC_D, deg, trig=0)
+                _, ids, _ = ppo.search_mesh_2d(mesh, ps, elem_ids=None if full else ids, looplimit=200)
+            if full:  # the drivers' rebuild() + the two scatters (pseudoXGCm.cpp:116-140, 529-530)
+                ppo.update_positions(ps)
+                ps.rebuild(ids)
+                ppo.gyro_scatter(mesh, ps, maps[0])
+                ppo.gyro_scatter(mesh, ps, maps[1])
+            elif w["dim"] == 3:
+                a, b = ps.member(0), ps.member(1)
+                tmp = a.copy()
+                a[:] = b
+                b[:] = tmp
+        return time.perf_counter() - t0
+
+    dt = run(make_ps())
+    what = ("push + search + updatePtclPositions + rebuild + gyroScatter x2" if full else "push + search")
     out = dict(value=sample * steps / dt, unit="particles/s", cores=1, kind="port",
-               sample="%d particles x %d steps of the same mesh/push, oracle (C=1 Serial semantics, "
-                      "libm trig), 1 core" % (sample, steps))
+               sample="%d particles x %d steps (%s) of the same mesh/push, oracle (C=1 Serial semantics, "
+                      "libm trig), 1 core" % (sample, steps, what))
     # the same loop with its per-particle loops spread over all host cores (OpenMP)
     nthr = ppo.max_threads()
     if nthr > 1:
         ppo.set_threads(nthr)
         try:
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                if w["dim"] == 3:
-                    ppo.toroidal_push(ps, mesh, s.XGC_H, s.XGC_K, s.XGC_D, deg, trig=0)
-                    ids = ppo.search_mesh(mesh, ps, elem_ids=ids, looplimit=200)["elem_ids"]
-                    a, b = ps.member(0), ps.member(1)
-                    tmp = a.copy()
-                    a[:] = b
-                    b[:] = tmp
-                else:
-                    ppo.elliptical_push(ps, mesh, s.XGC_H, s.XGC_K, s.XGC_D, deg, trig=0)
-                    _, ids, _ = ppo.search_mesh_2d(mesh, ps, elem_ids=ids, looplimit=200)
-            dt = time.perf_counter() - t0
+            dt = run(make_ps())
         finally:
             ppo.set_threads(1)
         out["all_cores"] = dict(value=sample * steps / dt, unit="particles/s", cores=nthr,
-                                note="same sample, per-particle loops under OpenMP; the position "
-                                     "swap and the slot tables stay serial")
+                                note="same sample, per-particle loops under OpenMP; the structure "
+                                     "rebuild and the slot tables stay serial")
     return out
+
+
+METRIC = {
+    "c2": "particles pushed+searched / sec / GPU; achieved HBM GB/s vs peak",
+    "2d": "particles pushed+searched / sec / GPU; achieved HBM GB/s vs peak",
+    "c3": "particles pushed+searched+scattered / sec / GPU; achieved HBM GB/s vs peak",
+    "2dc3": "particles pushed+searched+scattered / sec / GPU; achieved HBM GB/s vs peak",
+    "c5": "particles pushed+searched+migrated+scattered / sec (all GPUs); achieved HBM GB/s vs peak",
+    "c4": "particles pseudo-pushed+redistributed+rebuilt / sec / GPU; achieved HBM GB/s vs peak",
+}
+
+
+def launch_ranks(n, argv):
+    """`--gpus N` without a launcher: start N rank processes (one per GPU) from a parent that never
+    touches the GPU -- a process that has initialised HIP must not fork/exec workers -- and relay
+    their exit status.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    have = None
+    if os.environ.get("PP_BENCH_ASSUME_GPUS"):
+        have = int(os.environ["PP_BENCH_ASSUME_GPUS"])
+    else:
+        import torch  # device_count() reads the driver's topology; it does not create a HIP context
+        have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write("bench.py: --gpus %d needs %d GPUs, this box has %d -- not running a smaller job "
+                         "under that label\n" % (n, n, have))
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for pr in list(pending):
+                code = pr.poll()
+                if code is None:
+                    continue
+                pending.remove(pr)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for other in pending:  # one rank died: the others would wait in a collective for ever
+                        other.terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    sys.exit(rc)
 
 
 def main():
@@ -340,7 +448,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "2d", "2dc3"])
+    ap.add_argument("--workload", default=None, choices=["c2", "c3", "c4", "c5", "2d", "2dc3"],
+                    help="default: c3 on one GPU (the configuration the metric names), c5 on several")
     ap.add_argument("--sigma", type=int, default=2**31 - 1,
                     help="SCS sorting window (elements); the pseudoXGCm value is INT_MAX = full sort")
     ap.add_argument("--safe-layers", type=int, default=0,
@@ -348,22 +457,46 @@ def main():
                          "(0 = BASELINE's rule: a particle migrates as soon as it leaves its owner's block)")
     ap.add_argument("--c4-elems", type=int, default=1_000_000, help="c4: number of elements")
     ap.add_argument("--structure", default="scs", choices=["scs", "csr"], help="c4: particle structure")
-    ap.add_argument("--particles", type=int, default=10_000_000, help="particles per GPU")
+    ap.add_argument("--particles", type=int, default=None,
+                    help="particles per GPU (default 10 M; c5 on several GPUs 32 M; c4 1 M)")
     ap.add_argument("--deg", type=float, default=0.5, help="degrees per push (testing.cmake:117)")
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000,
-                    help="particles of the bounded CPU-baseline sample (x 20 steps, ~10 s on one core)")
+    ap.add_argument("--cpu-sample", type=int, default=None,
+                    help="particles of the bounded CPU-baseline sample (~10 s on one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mesh", default="100k", choices=["100k", "1m"],
-                    help="3-D mesh: 100 800 tets (configs[1-2]) or 998 400 tets (configs[4], per-GPU share)")
+    ap.add_argument("--mesh", default=None, choices=["100k", "1m"],
+                    help="3-D mesh: 100 800 tets (configs[1-2]) or 998 400 tets (configs[4], default of c5 "
+                         "on several GPUs)")
     ap.add_argument("--remainder", default="last", choices=["last", "spread"],
                     help="where particles left over by the Gaussian draws go: 'last' = literal "
                          "pseudoXGCm rule (one outlier element), 'spread' = evenly")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
+                    help="c5 exchange: RCCL behind the C-ABI (pp_ps_migrate / pp_allreduce_sum) or the "
+                         "torch.distributed glue of pumi-pic_amd/dist.py")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        launch_ranks(a.gpus, sys.argv[1:])  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world and rank == 0 and ("--gpus" in sys.argv or world > 1):
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus = %d\n"
+                         % (a.gpus, world, world))
+    if a.workload is None:
+        a.workload = "c3" if world == 1 else "c5"
+    if a.mesh is None:
+        a.mesh = "1m" if (a.workload == "c5" and world > 1) else "100k"
+    if a.particles is None:
+        a.particles = (1_000_000 if a.workload == "c4" else
+                       32_000_000 if (a.workload == "c5" and world > 1 and a.mesh == "1m") else 10_000_000)
+    full_step = a.workload in ("c3", "2dc3", "c5")
+    if a.cpu_sample is None:
+        a.cpu_sample = 2_000_000 if full_step else 4_000_000
     import torch
+    if world > 1 and torch.cuda.device_count() < world:
+        sys.stderr.write("bench.py: %d ranks need %d GPUs, this box has %d\n"
+                         % (world, world, torch.cuda.device_count()))
+        sys.exit(2)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -376,14 +509,13 @@ def main():
     capi.init(local_rank)  # raises when the HIP library / GPU is missing: no CPU fallback
 
     if a.workload == "c4":
-        if "--particles" not in sys.argv:
-            a.particles = 1_000_000  # configs[3] stress point: 1 M elements / 1 M particles
         w = build_c4(pp, capi, a.c4_elems, a.particles, rank, a.structure)
         st = StepperC4(capi, w)
     else:
         w = build_workload(pp, capi, a.workload, a.particles, rank, world, a.deg, a.remainder, a.mesh,
                            a.sigma)
         w["safe_layers"] = a.safe_layers
+        w["comm"] = a.comm
         st = Stepper(pp, capi, w, a.workload, a.deg)
 
     def barrier():
@@ -392,14 +524,37 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    st.sample_every = max(1, a.steps // 10)
+    def timed_run(steps):
+        st.ntimed = 0
+        st.kernel_ms = []
+        st.sample_every = max(1, steps // 10)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st.step(timed=True)
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     # Clock pre-warm.  The GPU's power management needs ~0.1 s of sustained vector-ALU load before the
-    # shader clock settles; W = 3 warm-up steps are 1 ms.  Measured on MI355X: c2 0.307 ms per step
+    # shader clock settles; W = 3 warm-up steps are a few ms.  Measured on MI355X: c2 0.307 ms per step
     # from idle clocks, 0.270 ms after 0.3 s of ANY FP64 kernel (a memset loop, which only loads the
     # memory side, gets half of that), the same as after 100+ warm-up steps.  The pre-warm runs an
     # unrelated kernel (closest point on a triangle, scratch data): the workload's state is untouched
     # and still gets exactly W warm-up and K timed steps.  PP_BENCH_PREWARM=<seconds> (0 = off).
+    # The same W + K steps from idle clocks are timed first and reported as `cold_clocks`.
     prewarm_s = float(os.environ.get("PP_BENCH_PREWARM", "0.3"))
+    cold = None
+    if prewarm_s > 0 and not os.environ.get("PP_BENCH_NO_COLD"):
+        for _ in range(a.warmup):
+            st.step()
+        cold_dt = timed_run(a.steps)
+        cold = {"ms_per_step": cold_dt / a.steps * 1e3,
+                "note": "the same W warm-up + K timed steps before the clock pre-warm (shader clock still ramping)"}
     if prewarm_s > 0:
         n = 1 << 22
         rng = np.random.default_rng(0)
@@ -414,16 +569,7 @@ def main():
         del tri, pts, scratch
     for _ in range(a.warmup):
         st.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        st.step(timed=True)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed_run(a.steps)
     nlive = w["ps"].nPtcls()
     total_particles = nlive
     if dist is not None:
@@ -434,7 +580,7 @@ def main():
     if rank == 0:
         kms = st.kernel_avg_ms()
         # HBM bytes per launch from the PMC counters: collected with rocprofv3 in separate --pmc
-        # passes of THIS command (tools/r01_measure.sh) and calibrated as DESIGN.md section 4 says;
+        # passes of THIS command (tools/r02_measure.sh) and calibrated as DESIGN.md section 4 says;
         # a profiler cannot wrap itself, so the committed summary is reported with its provenance
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.workload)
@@ -447,66 +593,86 @@ def main():
                     traffic = tj["traffic_bytes_per_step"]
             except (ValueError, KeyError):
                 traffic = None
-        bpp = BYTES[{"2dc3": "2d", "c3": "c2", "c5": "c2"}.get(a.workload, a.workload)]
         if a.workload == "c4" and a.structure != "scs":
             traffic = None  # the committed PMC run is the SCS structure
+        common = {
+            "metric": METRIC[a.workload],
+            "value": total_particles * a.steps / dt, "unit": "particles/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic", "clock_prewarm_s": prewarm_s,
+        }
+        if cold is not None:
+            common["cold_clocks"] = cold
         if a.workload == "c4":
-            out = {
-                "metric": "particles pseudo-pushed+redistributed+rebuilt / sec / GPU; achieved HBM GB/s vs peak",
-                "value": total_particles * a.steps / dt, "unit": "particles/s", "n_gpus": world,
-                "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-                "data": "synthetic", "clock_prewarm_s": prewarm_s,
-                "config": {"workload": "%s, %d particles/GPU, uniform distribution, pseudo-push + "
-                                       "redistribute(0.5) + rebuild per step" % (w["label"], a.particles),
-                           "parallelism": "%d independent rank(s)" % world},
-                "roofline": {"bound": "hbm", "achieved": bpp * nlive / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": bpp * nlive / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "traffic": traffic,
-                             "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, calibrated; "
-                                             "profiles/traffic_c4.json)",
-                             "kernel": "k_pseudo_push160", "kernel_ms": kms,
-                             "bytes_per_particle": bpp},
-            }
+            bpp = BYTES["c4"]
+            out = dict(common)
+            out["config"] = {"workload": "%s, %d particles/GPU, uniform distribution, pseudo-push + "
+                                         "redistribute(0.5) + rebuild per step" % (w["label"], a.particles),
+                             "parallelism": "%d independent rank(s)" % world}
+            out["roofline"] = {"bound": "hbm", "achieved": bpp * nlive / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": bpp * nlive / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "traffic": traffic,
+                               "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, calibrated; "
+                                               "profiles/traffic_c4.json)",
+                               "kernel": "k_pseudo_push160", "kernel_ms": kms,
+                               "bytes_per_particle": bpp}
             if not a.no_cpu_baseline and world == 1:
                 out["cpu_baseline"] = cpu_baseline_c4(pp, a.c4_elems, a.particles, min(a.particles, 1_000_000))
             print(json.dumps(out))
             if dist is not None:
                 dist.destroy_process_group()
             return
-        achieved = bpp * nlive / (kms * 1e-3) / 1e9 if kms else None
-        out = {
-            "metric": "particles pushed+searched+scattered / sec / GPU; achieved HBM GB/s vs peak",
-            "value": total_particles * a.steps / dt,
-            "unit": "particles/s",
-            "n_gpus": world,
-            "steps": a.steps,
-            "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "clock_prewarm_s": prewarm_s,
-            "config": {"workload": "%s, %d particles/GPU, SCS C=64 sigma=%s V=1024, %s" % (
-                w["label"], a.particles, "inf" if a.sigma >= 2**31 - 1 else str(a.sigma),
-                {"c2": "push+search only (fused toroidal push + BCC walk), deg/push=%g" % a.deg,
-                 "2d": "elliptical push + search_mesh_2d (fused), deg/push=%g" % a.deg,
-                 "c3": "push+search+rebuild+gyroScatter x2 (tet ring map), deg/push=%g" % a.deg,
-                 "c5": "push+search+migrate(all-to-all-v)+rebuild+gyroScatter x2+gyroSync, deg/push=%g" % a.deg,
-                 "2dc3": "push+search+rebuild+gyroScatter x2, deg/push=%g" % a.deg}[a.workload]),
-                "parallelism": "element-block partition, %d rank(s), full-mesh replica" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, calibrated; "
-                                         "profiles/traffic_%s.json)" % a.workload,
-                         "kernel": ("k_push_walk_rowsq<3> + k_walk_pending<3> (one pp_push_search call)"
-                                    if w["dim"] == 3 else "k_push_walk_rows<2>"), "kernel_ms": kms,
-                         "bytes_per_particle": bpp},
-        }
+        # Roofline.  c2 / 2d: ONE pp_push_search call is the step.  c3 / 2dc3 / c5: the WHOLE step
+        # (push+search 69 B + rebuild 125 B per particle) against the mean HIP-event time
+        # of the sampled steps; the two phases are broken out under "phases".
+        bpp_ps = BYTES["2d" if w["dim"] == 2 else "c2"]
+        sms = st.step_avg_ms()
+        ps_kernel = ("k_push_walk_rowsq<3> + k_walk_pending<3> (one pp_push_search call)"
+                     if w["dim"] == 3 else "k_push_walk_rows<2>")
+        if full_step:
+            bpp = bpp_ps + 125.0
+            achieved = bpp * nlive / (sms * 1e-3) / 1e9 if sms else None
+            rest_ms = (sms - kms) if (sms and kms) else None
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                    "traffic_unit": "bytes per step (rocprofv3 FETCH_SIZE+WRITE_SIZE of every kernel of the "
+                                    "step, calibrated; profiles/traffic_%s.json)" % a.workload,
+                    "scope": "whole step: every kernel between two steps' first launches (HIP events on the "
+                             "library stream)",
+                    "kernel": ps_kernel + " is the longest launch of the step (profiles/)",
+                    "kernel_ms": sms, "bytes_per_particle": bpp,
+                    "phases": {
+                        "push_search": {"ms": kms, "bytes_per_particle": bpp_ps,
+                                        "frac": bpp_ps * nlive / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms else None},
+                        "rebuild_scatter": {"ms": rest_ms, "bytes_per_particle": 125.0,
+                                            "frac": 125.0 * nlive / (rest_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                            if rest_ms else None,
+                                            "note": "updatePtclPositions + rebuild (+ migration) + gyroScatter x2"}}}
+        else:
+            bpp = bpp_ps
+            achieved = bpp * nlive / (kms * 1e-3) / 1e9 if kms else None
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                    "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, calibrated; "
+                                    "profiles/traffic_%s.json)" % a.workload,
+                    "kernel": ps_kernel, "kernel_ms": kms, "bytes_per_particle": bpp}
+        out = dict(common)
+        out["config"] = {"workload": "%s, %d particles/GPU, SCS C=64 sigma=%s V=1024, %s" % (
+            w["label"], a.particles, "inf" if a.sigma >= 2**31 - 1 else str(a.sigma),
+            {"c2": "push+search only (fused toroidal push + BCC walk), deg/push=%g" % a.deg,
+             "2d": "elliptical push + search_mesh_2d (fused), deg/push=%g" % a.deg,
+             "c3": "push+search+rebuild+gyroScatter x2 (tet ring map) every step, deg/push=%g" % a.deg,
+             "c5": "push+search+migrate(all-to-all-v, %s)+rebuild+gyroScatter x2+gyroSync, deg/push=%g" % (
+                 getattr(st, "comm_kind", a.comm), a.deg),
+             "2dc3": "push+search+rebuild+gyroScatter x2 every step, deg/push=%g" % a.deg}[a.workload]),
+            "parallelism": "element-block partition, %d rank(s), full-mesh replica" % world}
+        if a.workload == "c5":
+            out["rank0_sent_per_step"] = st.moved / max(1, st.steps_done)
+        out["roofline"] = roof
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(pp, w, a.workload, a.deg, min(a.cpu_sample, a.particles))
+            out["cpu_baseline"] = cpu_baseline(pp, w, a.workload, a.deg, min(a.cpu_sample, a.particles),
+                                               steps=10 if full_step else 20)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

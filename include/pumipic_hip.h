@@ -375,6 +375,99 @@ int pp_ps_rebuild_records_scatter(pp_ps* ps, int m_x, int m_xtgt, const int* new
                                   const pp_mesh* mesh, int nmaps, const int* const* v2v_dev,
                                   double* const* scatter_w_dev, double rmax, int gnr, int gppr);
 
+/* ------------------------------------------------------------------ communicators
+ * One process per GPU.  The reference passes an MPI_Comm (Distributor, support/psDistributor.hpp:10-40;
+ * Mesh::comm(), src/pumipic_comm.cpp:222-246) and stages every message through the host; here a
+ * pp_comm carries one of four transports behind the same calls:
+ *   rccl   device-resident collectives over xGMI (production): the library opens librccl at run time,
+ *          rank 0 draws a 128-byte unique id (pp_comm_unique_id) that the launcher broadcasts
+ *          (MPI_Bcast / torch.distributed / pp_bootstrap_broadcast) and every rank joins with
+ *          pp_comm_create_rccl.  All collectives are enqueued on the library stream (pp_stream()).
+ *   tcp    built-in host-staged exchange through rank 0 over sockets: the reference's host-staged MPI
+ *          pattern, for boxes where RCCL cannot form the job (several ranks on one GPU, no xGMI).
+ *   host   the caller supplies the collectives on HOST buffers (MPI in a PUMI-PIC build, gloo in the
+ *          tests); the library stages device data through pinned memory.
+ *   local  N virtual ranks inside one process (tests, debugging on one GPU): the ranks' calls are made
+ *          one after the other, so migration is split-phase there (pp_ps_migrate_begin on every
+ *          rank, then pp_ps_migrate_end on every rank).
+ * pp_comm_create_env reads the launcher's environment (RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT;
+ * PP_COMM=rccl|tcp, default rccl; PP_COMM_PORT overrides MASTER_PORT+1): WORLD_SIZE unset or 1 gives
+ * a single-rank communicator whose collectives are no-ops. */
+typedef struct pp_comm pp_comm;
+typedef struct pp_comm_host_ops {
+  /* PS_Comm_Ialltoall (SCS_migrate.h:48): one int to / from every rank */
+  int (*alltoall_int)(void* user, const int* send, int* recv);
+  /* the particle exchange (SCS_migrate.h:143-178 as one message per peer): byte counts / displacements
+   * per rank */
+  int (*alltoallv_bytes)(void* user, const void* send, const int64_t* send_bytes,
+                         const int64_t* send_displ, void* recv, const int64_t* recv_bytes,
+                         const int64_t* recv_displ);
+  /* MPI_Allreduce(SUM) of doubles (pumipic_comm.cpp:243) and of longs (pseudoXGCm.cpp:508,523) */
+  int (*allreduce_sum_f64)(void* user, double* buf, int64_t n);
+  int (*allreduce_sum_i64)(void* user, int64_t* buf, int64_t n);
+} pp_comm_host_ops;
+int pp_comm_unique_id(void* id128_out);
+pp_comm* pp_comm_create_rccl(const void* id128, int rank, int nranks);
+pp_comm* pp_comm_create_tcp(const char* root_addr, int port, int rank, int nranks);
+pp_comm* pp_comm_create_host(const pp_comm_host_ops* ops, void* user, int rank, int nranks);
+int pp_comm_create_local(int nranks, pp_comm** comms_out);
+pp_comm* pp_comm_create_env(void);
+int pp_comm_rank(const pp_comm* c);
+int pp_comm_size(const pp_comm* c);
+const char* pp_comm_kind(const pp_comm* c); /* "self", "rccl", "tcp", "host", "local" */
+int pp_comm_destroy(pp_comm* c);
+/* rank 0 sends nbytes to every other rank over TCP (root_addr:port); used to hand out the RCCL id
+ * when the launcher has no broadcast of its own */
+int pp_bootstrap_broadcast(const char* root_addr, int port, int rank, int nranks, void* buf,
+                           int nbytes);
+/* host-side pieces of SellCSigma::migrate, usable without a GPU: the count exchange
+ * (SCS_migrate.h:40-64) and the offsets both sides derive from the counts (:66-72, :129-133).
+ * Displacements are in particles, rank-major, the own rank's count is 0. */
+int pp_comm_exchange_counts(pp_comm* c, const int* send_counts_host, int* recv_counts_host);
+int pp_migrate_plan(int nranks, int rank, const int* send_counts, const int* recv_counts,
+                    int64_t* send_displ, int64_t* recv_displ, int64_t* n_send, int64_t* n_recv);
+/* Mesh::reduceCommArray(dim, SUM_OP, array) for a fully buffered (replicated) mesh,
+ * src/pumipic_comm.cpp:234-246: in-place SUM over ranks of n doubles in device memory */
+int pp_allreduce_sum(pp_comm* c, double* buf_dev, int64_t n);
+/* MPI_Allreduce(MPI_LONG, SUM) of a few host values (particle totals, test/pseudoXGCm.cpp:508,523) */
+int pp_allreduce_sum_host_i64(pp_comm* c, int64_t* vals_host, int n);
+int pp_comm_barrier(pp_comm* c);
+
+/* SellCSigma::migrate / CSR::migrate (scs/SCS_migrate.h:5-222, particle_structure.hpp:97-101):
+ * particles with new_process != rank leave (counted, packed as records, exchanged, removed), the
+ * received ones and the caller's n_new new particles enter the rebuild as new particles.  One rank:
+ * plain rebuild (SCS_migrate.h:20-25).  new_element_dev is modified (sent particles read -1
+ * afterwards, SCS_migrate.h:189-196). */
+int pp_ps_migrate(pp_ps* ps, int* new_element_dev, const int* new_process_dev, pp_comm* comm);
+/* The full form: + updatePtclPositions folded into the records and the rebuild (m_x, m_xtgt; -1 =
+ * off), + the caller's new particles, + element gid -> lid table of the receiver (NULL = identity,
+ * full-mesh replica), + the step's gyroScatter calls behind the rebuild (nmaps = 0: none).  See
+ * pp_ps_migrate_pack_records_commit / pp_ps_rebuild_records_scatter for the pieces. */
+int pp_ps_migrate_scatter(pp_ps* ps, int m_x, int m_xtgt, int* new_element_dev,
+                          const int* new_process_dev, pp_comm* comm, int n_new,
+                          const int* new_elems_dev, const void* const* new_info_dev,
+                          const int* gid2lid_dev, int64_t ngids, const pp_mesh* mesh, int nmaps,
+                          const int* const* v2v_dev, double* const* scatter_w_dev, double rmax,
+                          int gnr, int gppr);
+/* split-phase form of pp_ps_migrate_scatter: begin = count + exchange of counts + pack, end =
+ * exchange + rebuild.  Required on a `local` communicator (every virtual rank begins before any
+ * ends); on the others pp_ps_migrate_scatter is begin + end. */
+int pp_ps_migrate_begin(pp_ps* ps, int m_x, int m_xtgt, int* new_element_dev,
+                        const int* new_process_dev, pp_comm* comm, int n_new,
+                        const int* new_elems_dev, const void* const* new_info_dev,
+                        const int* gid2lid_dev, int64_t ngids, const pp_mesh* mesh, int nmaps,
+                        const int* const* v2v_dev, double* const* scatter_w_dev, double rmax,
+                        int gnr, int gppr);
+int pp_ps_migrate_end(pp_ps* ps, pp_comm* comm, int* n_sent, int* n_received);
+
+/* ------------------------------------------------------------------ tracing
+ * Kokkos::Profiling::pushRegion / popRegion of the reference (e.g. adjacency.tpp:480,613,
+ * SCS_rebuild.h:126,311) map to roctx ranges (rocprofv3 --marker-trace).  The library wraps its own
+ * entry points (search, push, rebuild, migrate, scatter) when PP_ROCTX=1; these two let a driver add
+ * its regions through the same switch. */
+int pp_range_push(const char* name);
+int pp_range_pop(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -127,6 +127,31 @@ SYMBOLS = {
     "pp_ps_migrate_record_bytes": (_I, [_V]),
     "pp_ps_migrate_pack_records": (_I, [_V, _V, _V, _I, _I, _V, _V]),
     "pp_ps_rebuild_records": (_I, [_V, _V, _I, _V, _V, C.c_int64]),
+    "pp_comm_unique_id": (_I, [_V]),
+    "pp_comm_create_rccl": (_V, [_V, _I, _I]),
+    "pp_comm_create_tcp": (_V, [C.c_char_p, _I, _I, _I]),
+    "pp_comm_create_host": (_V, [_V, _V, _I, _I]),
+    "pp_comm_create_local": (_I, [_I, c_void_pp]),
+    "pp_comm_create_env": (_V, []),
+    "pp_comm_rank": (_I, [_V]),
+    "pp_comm_size": (_I, [_V]),
+    "pp_comm_kind": (C.c_char_p, [_V]),
+    "pp_comm_destroy": (_I, [_V]),
+    "pp_bootstrap_broadcast": (_I, [C.c_char_p, _I, _I, _I, _V, _I]),
+    "pp_comm_exchange_counts": (_I, [_V, c_int_p, c_int_p]),
+    "pp_migrate_plan": (_I, [_I, _I, c_int_p, c_int_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                             C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "pp_allreduce_sum": (_I, [_V, _V, C.c_int64]),
+    "pp_allreduce_sum_host_i64": (_I, [_V, C.POINTER(C.c_int64), _I]),
+    "pp_comm_barrier": (_I, [_V]),
+    "pp_ps_migrate": (_I, [_V, _V, _V, _V]),
+    "pp_ps_migrate_scatter": (_I, [_V, _I, _I, _V, _V, _V, _I, _V, _V, _V, C.c_int64, _V, _I, _V, _V,
+                                   C.c_double, _I, _I]),
+    "pp_ps_migrate_begin": (_I, [_V, _I, _I, _V, _V, _V, _I, _V, _V, _V, C.c_int64, _V, _I, _V, _V,
+                                 C.c_double, _I, _I]),
+    "pp_ps_migrate_end": (_I, [_V, _V, c_int_p, c_int_p]),
+    "pp_range_push": (_I, [C.c_char_p]),
+    "pp_range_pop": (_I, []),
 }
 
 
@@ -770,3 +795,255 @@ def rebuild_scatter(ps, mesh, new_element, maps, outs=None, commit=True, rmax=0.
                                       None, None, mesh.p if mesh is not None else None, n, v2v, out,
                                       rmax, gnr, gppr))
     return outs
+
+
+# ------------------------------------------------------------------ communicators (pp_comm.hip)
+_ALLTOALL_INT = C.CFUNCTYPE(C.c_int, C.c_void_p, c_int_p, c_int_p)
+_ALLTOALLV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                         C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64))
+_ALLRED_F64 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
+_ALLRED_I64 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int64)
+
+
+class CommHostOps(C.Structure):
+    _fields_ = [("alltoall_int", _ALLTOALL_INT), ("alltoallv_bytes", _ALLTOALLV),
+                ("allreduce_sum_f64", _ALLRED_F64), ("allreduce_sum_i64", _ALLRED_I64)]
+
+
+class Comm:
+    """pp_comm handle.  Constructors: Comm.rccl(id, rank, n), Comm.tcp(addr, port, rank, n),
+    Comm.host(ops...), Comm.local(n) -> list, Comm.env(), Comm.torch(group) (host transport whose
+    collectives are torch.distributed calls on CPU tensors: gloo in the tests)."""
+
+    def __init__(self, p, keep=None):
+        if not p:
+            raise PPError("communicator creation failed: " + lib().pp_last_error().decode())
+        self.p = p
+        self._keep = keep
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * 128)()
+        check(lib().pp_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def rccl(cls, id128, rank, nranks):
+        buf = (C.c_ubyte * 128).from_buffer_copy(id128)
+        return cls(lib().pp_comm_create_rccl(buf, rank, nranks))
+
+    @classmethod
+    def tcp(cls, addr, port, rank, nranks):
+        return cls(lib().pp_comm_create_tcp(addr.encode(), port, rank, nranks))
+
+    @classmethod
+    def env(cls):
+        return cls(lib().pp_comm_create_env())
+
+    @classmethod
+    def local(cls, nranks):
+        arr = (C.c_void_p * nranks)()
+        check(lib().pp_comm_create_local(nranks, arr))
+        return [cls(arr[r]) for r in range(nranks)]
+
+    @classmethod
+    def host(cls, rank, nranks, alltoall_int, alltoallv_bytes, allreduce_f64, allreduce_i64):
+        """the four collectives as Python callables on numpy views of the library's host buffers"""
+        def _a2a(user, s, r):
+            try:
+                sv = np.ctypeslib.as_array(s, shape=(nranks,))
+                np.ctypeslib.as_array(r, shape=(nranks,))[:] = alltoall_int(sv.copy())
+                return 0
+            except Exception:  # noqa: BLE001 -- a Python exception must not unwind through C
+                import traceback
+                traceback.print_exc()
+                return -2
+
+        def _a2av(user, s, sb, sd, r, rb, rd):
+            try:
+                sb_ = np.ctypeslib.as_array(sb, shape=(nranks,)).copy()
+                sd_ = np.ctypeslib.as_array(sd, shape=(nranks,)).copy()
+                rb_ = np.ctypeslib.as_array(rb, shape=(nranks,)).copy()
+                rd_ = np.ctypeslib.as_array(rd, shape=(nranks,)).copy()
+                ns, nr = int((sd_ + sb_).max(initial=0)), int((rd_ + rb_).max(initial=0))
+                sbuf = np.ctypeslib.as_array(C.cast(s, C.POINTER(C.c_ubyte)), shape=(max(ns, 1),))[:ns]
+                rbuf = np.ctypeslib.as_array(C.cast(r, C.POINTER(C.c_ubyte)), shape=(max(nr, 1),))[:nr]
+                alltoallv_bytes(sbuf, sb_, sd_, rbuf, rb_, rd_)
+                return 0
+            except Exception:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return -2
+
+        def _arf(user, b, n):
+            try:
+                v = np.ctypeslib.as_array(b, shape=(int(n),))
+                v[:] = allreduce_f64(v.copy())
+                return 0
+            except Exception:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return -2
+
+        def _ari(user, b, n):
+            try:
+                v = np.ctypeslib.as_array(b, shape=(int(n),))
+                v[:] = allreduce_i64(v.copy())
+                return 0
+            except Exception:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return -2
+
+        ops = CommHostOps(_ALLTOALL_INT(_a2a), _ALLTOALLV(_a2av), _ALLRED_F64(_arf), _ALLRED_I64(_ari))
+        return cls(lib().pp_comm_create_host(C.byref(ops), None, rank, nranks), keep=ops)
+
+    @classmethod
+    def torch(cls, group=None):
+        """host transport over torch.distributed CPU collectives (gloo)"""
+        import torch
+        import torch.distributed as dist
+        rank, n = dist.get_rank(group), dist.get_world_size(group)
+
+        def a2a(send):
+            s = torch.from_numpy(np.asarray(send, dtype=np.int32).copy())
+            r = torch.empty_like(s)
+            _gloo_a2a(r, s, group)
+            return r.numpy()
+
+        def a2av(sbuf, sb, sd, rbuf, rb, rd):
+            outs = [torch.empty(int(rb[q]), dtype=torch.uint8) for q in range(n)]
+            ins = [torch.from_numpy(sbuf[int(sd[q]):int(sd[q] + sb[q])].copy()) for q in range(n)]
+            _p2p_exchange(ins, outs, rank, n, group)
+            for q in range(n):
+                if rb[q]:
+                    rbuf[int(rd[q]):int(rd[q] + rb[q])] = outs[q].numpy()
+
+        def arf(v):
+            t = torch.from_numpy(np.asarray(v, dtype=np.float64).copy())
+            dist.all_reduce(t, group=group)
+            return t.numpy()
+
+        def ari(v):
+            t = torch.from_numpy(np.asarray(v, dtype=np.int64).copy())
+            dist.all_reduce(t, group=group)
+            return t.numpy()
+
+        return cls.host(rank, n, a2a, a2av, arf, ari)
+
+    def rank(self):
+        return lib().pp_comm_rank(self.p)
+
+    def size(self):
+        return lib().pp_comm_size(self.p)
+
+    def kind(self):
+        return lib().pp_comm_kind(self.p).decode()
+
+    def exchange_counts(self, send_counts):
+        s = np.ascontiguousarray(send_counts, dtype=np.int32)
+        r = np.zeros_like(s)
+        check(lib().pp_comm_exchange_counts(self.p, s.ctypes.data_as(c_int_p), r.ctypes.data_as(c_int_p)))
+        return r
+
+    def allreduce_sum(self, dev_array, n=None):
+        check(lib().pp_allreduce_sum(self.p, dev_array.ptr if isinstance(dev_array, DevArray) else dev_array,
+                                     dev_array.n if n is None else n))
+
+    def allreduce_sum_host(self, vals):
+        v = np.ascontiguousarray(vals, dtype=np.int64).copy()
+        check(lib().pp_allreduce_sum_host_i64(self.p, v.ctypes.data_as(C.POINTER(C.c_int64)), len(v)))
+        return v
+
+    def barrier(self):
+        check(lib().pp_comm_barrier(self.p))
+
+    def destroy(self):
+        if self.p:
+            lib().pp_comm_destroy(self.p)
+            self.p = None
+
+
+def _gloo_a2a(r, s, group):
+    """gloo has no all_to_all_single on every build: gather everything, pick the column"""
+    import torch
+    import torch.distributed as dist
+    n, me = dist.get_world_size(group), dist.get_rank(group)
+    rows = [torch.empty_like(s) for _ in range(n)]
+    dist.all_gather(rows, s, group=group)
+    for q in range(n):
+        r[q] = rows[q][me]
+
+
+def _p2p_exchange(ins, outs, rank, n, group):
+    import torch.distributed as dist
+    reqs = []
+    for q in range(n):
+        if q == rank:
+            continue
+        if outs[q].numel():
+            reqs.append(dist.irecv(outs[q], src=q, group=group))
+        if ins[q].numel():
+            reqs.append(dist.isend(ins[q], dst=q, group=group))
+    for rq in reqs:
+        rq.wait()
+
+
+def migrate_plan(nranks, rank, send_counts, recv_counts):
+    s = np.ascontiguousarray(send_counts, dtype=np.int32)
+    r = np.ascontiguousarray(recv_counts, dtype=np.int32)
+    sd, rd = np.zeros(nranks, dtype=np.int64), np.zeros(nranks, dtype=np.int64)
+    ns, nr = C.c_int64(), C.c_int64()
+    i64p = C.POINTER(C.c_int64)
+    check(lib().pp_migrate_plan(nranks, rank, s.ctypes.data_as(c_int_p), r.ctypes.data_as(c_int_p),
+                                sd.ctypes.data_as(i64p), rd.ctypes.data_as(i64p), C.byref(ns), C.byref(nr)))
+    return sd, rd, ns.value, nr.value
+
+
+def _migrate_args(ps, new_elems, new_procs, comm, commit, scatter, new_particles, gid2lid, rmax, gnr, gppr,
+                  m_x, m_xtgt):
+    mesh, maps, outs = scatter if scatter is not None else (None, (), ())
+    n = len(maps)
+    v2v = (C.c_void_p * max(n, 1))(*[m.ptr for m in maps])
+    out = (C.c_void_p * max(n, 1))(*[o.ptr for o in outs])
+    n_new, npe, arr, keep = 0, None, None, [v2v, out]
+    if new_particles is not None:
+        pe, info = new_particles
+        n_new = len(pe)
+        if n_new:
+            npe = DevArray.from_host(np.ascontiguousarray(pe, dtype=np.int32))
+            arr = (C.c_void_p * len(ps.members))()
+            for i, ((dt, nc), a) in enumerate(zip(ps.members, info)):
+                d = DevArray.from_host(np.ascontiguousarray(np.asarray(a, dtype=dt).reshape(nc, n_new)))
+                keep.append(d)
+                arr[i] = d.ptr
+            keep += [npe, arr]
+    args = (ps.p, m_x if commit else -1, m_xtgt if commit else -1, new_elems.ptr, new_procs.ptr, comm.p, n_new,
+            npe.ptr if npe is not None else None, C.cast(arr, C.c_void_p) if arr is not None else None,
+            gid2lid.ptr if gid2lid is not None else None, gid2lid.n if gid2lid is not None else 0,
+            mesh.p if mesh is not None else None, n, v2v, out, rmax, gnr, gppr)
+    return args, keep
+
+
+def migrate(ps, new_elems, new_procs, comm, commit=False, scatter=None, new_particles=None, gid2lid=None,
+            rmax=0.038, gnr=3, gppr=8, m_x=0, m_xtgt=1):
+    """pp_ps_migrate_scatter: SellCSigma::migrate behind one call (any non-local communicator)"""
+    args, keep = _migrate_args(ps, new_elems, new_procs, comm, commit, scatter, new_particles, gid2lid, rmax,
+                               gnr, gppr, m_x, m_xtgt)
+    check(lib().pp_ps_migrate_scatter(*args))
+    del keep
+
+
+def migrate_begin(ps, new_elems, new_procs, comm, commit=False, scatter=None, new_particles=None,
+                  gid2lid=None, rmax=0.038, gnr=3, gppr=8, m_x=0, m_xtgt=1):
+    args, keep = _migrate_args(ps, new_elems, new_procs, comm, commit, scatter, new_particles, gid2lid, rmax,
+                               gnr, gppr, m_x, m_xtgt)
+    check(lib().pp_ps_migrate_begin(*args))
+    comm._pending_keep = keep  # buffers the end phase still reads
+
+
+def migrate_end(ps, comm):
+    ns, nr = C.c_int(), C.c_int()
+    check(lib().pp_ps_migrate_end(ps.p, comm.p, C.byref(ns), C.byref(nr)))
+    comm._pending_keep = None
+    return ns.value, nr.value

@@ -1,0 +1,714 @@
+// pp_comm.hip -- communicators of the multi-GPU path (one process per GPU).
+//
+// Reference: the MPI layer the particle structures and the mesh call into --
+//   PS_Comm_Ialltoall / Isend / Irecv / Waitall   particle_structs/src/support/ViewComm.h
+//   SellCSigma::migrate                           particle_structs/src/scs/SCS_migrate.h:29-178
+//   Distributor                                   particle_structs/src/support/psDistributor.hpp:10-138
+//   Mesh::reduceCommArray (replicated buffers)    src/pumipic_comm.cpp:234-246
+// The reference stages every message through the host (D2H, MPI, H2D).  The production transport
+// here is RCCL on the library stream: counts by one all-gather, the particles by ONE grouped
+// send/recv per peer of packed records (xGMI is point-to-point: one link per peer pair), the field
+// sum by an in-place all-reduce.  librccl is opened at run time (a process that also runs PyTorch
+// already has one loaded; linking a second copy would duplicate its state), so the library loads
+// and every single-GPU entry point works on boxes without RCCL.
+#include <arpa/inet.h>
+#include <dlfcn.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/socket.h>
+#include <unistd.h>
+#include <chrono>
+#include <thread>
+#include <rccl/rccl.h>
+#include "pp_internal.hpp"
+
+namespace pp {
+
+// ------------------------------------------------------------------ RCCL, resolved at run time
+struct RcclApi {
+  void* handle = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+static RcclApi* rccl() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return api.handle ? &api : nullptr;
+  tried = true;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names)  // a copy some other component (PyTorch) loaded already comes first
+    if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+  for (int i = 0; !h && i < 3; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+  if (!h) {
+    set_error(std::string("librccl could not be opened: ") + (dlerror() ? dlerror() : "?"));
+    return nullptr;
+  }
+#define PP_SYM(field, name)                                        \
+  api.field = (decltype(api.field))dlsym(h, name);                 \
+  if (!api.field) {                                                \
+    set_error(std::string("librccl lacks ") + name);               \
+    return nullptr;                                                \
+  }
+  PP_SYM(GetUniqueId, "ncclGetUniqueId")
+  PP_SYM(CommInitRank, "ncclCommInitRank")
+  PP_SYM(CommDestroy, "ncclCommDestroy")
+  PP_SYM(AllReduce, "ncclAllReduce")
+  PP_SYM(AllGather, "ncclAllGather")
+  PP_SYM(Send, "ncclSend")
+  PP_SYM(Recv, "ncclRecv")
+  PP_SYM(GroupStart, "ncclGroupStart")
+  PP_SYM(GroupEnd, "ncclGroupEnd")
+  PP_SYM(GetErrorString, "ncclGetErrorString")
+#undef PP_SYM
+  api.handle = h;
+  return &api;
+}
+#define PP_NCCL_CHECK(expr)                                                                      \
+  do {                                                                                           \
+    ncclResult_t _r = (expr);                                                                    \
+    if (_r != ncclSuccess) {                                                                     \
+      pp::set_error(std::string(#expr) + ": " + pp::rccl()->GetErrorString(_r) + " (" __FILE__ + \
+                    ":" + std::to_string(__LINE__) + ")");                                       \
+      return PP_EHIP;                                                                            \
+    }                                                                                            \
+  } while (0)
+
+// ------------------------------------------------------------------ TCP star through rank 0
+static bool send_all(int fd, const void* buf, size_t n) {
+  const char* p = (const char*)buf;
+  while (n) {
+    const ssize_t k = ::send(fd, p, n, MSG_NOSIGNAL);
+    if (k <= 0) return false;
+    p += k;
+    n -= (size_t)k;
+  }
+  return true;
+}
+static bool recv_all(int fd, void* buf, size_t n) {
+  char* p = (char*)buf;
+  while (n) {
+    const ssize_t k = ::recv(fd, p, n, 0);
+    if (k <= 0) return false;
+    p += k;
+    n -= (size_t)k;
+  }
+  return true;
+}
+struct TcpStar {
+  int rank = 0, nranks = 1;
+  int listen_fd = -1;
+  std::vector<int> fds;  // root: socket of every rank (own = -1); others: fds[0] = socket to root
+  ~TcpStar() {
+    for (int fd : fds)
+      if (fd >= 0) ::close(fd);
+    if (listen_fd >= 0) ::close(listen_fd);
+  }
+  int fd_of(int r) const { return rank == 0 ? fds[(size_t)r] : fds[0]; }
+  int connect_all(const char* addr, int port, double timeout_s = 120.0) {
+    if (nranks <= 1) return PP_OK;
+    sockaddr_in sa{};
+    sa.sin_family = AF_INET;
+    sa.sin_port = htons((uint16_t)port);
+    if (inet_pton(AF_INET, addr, &sa.sin_addr) != 1) {
+      addrinfo hints{}, *res = nullptr;
+      hints.ai_family = AF_INET;
+      if (getaddrinfo(addr, nullptr, &hints, &res) != 0 || !res) {
+        set_error(std::string("tcp bootstrap: cannot resolve ") + addr);
+        return PP_EINVAL;
+      }
+      sa.sin_addr = ((sockaddr_in*)res->ai_addr)->sin_addr;
+      freeaddrinfo(res);
+    }
+    const int one = 1;
+    if (rank == 0) {
+      fds.assign((size_t)nranks, -1);
+      listen_fd = ::socket(AF_INET, SOCK_STREAM, 0);
+      setsockopt(listen_fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+      sockaddr_in any = sa;
+      any.sin_addr.s_addr = htonl(INADDR_ANY);
+      if (::bind(listen_fd, (sockaddr*)&any, sizeof(any)) != 0 || ::listen(listen_fd, nranks) != 0) {
+        set_error("tcp bootstrap: rank 0 cannot listen on port " + std::to_string(port));
+        return PP_EHIP;
+      }
+      for (int k = 1; k < nranks; ++k) {
+        const int fd = ::accept(listen_fd, nullptr, nullptr);
+        int r = -1;
+        if (fd < 0 || !recv_all(fd, &r, sizeof(r)) || r <= 0 || r >= nranks || fds[(size_t)r] >= 0) {
+          set_error("tcp bootstrap: bad peer hello");
+          return PP_EHIP;
+        }
+        setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+        fds[(size_t)r] = fd;
+      }
+    } else {
+      fds.assign(1, -1);
+      const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s);
+      int fd = -1;
+      while (true) {
+        fd = ::socket(AF_INET, SOCK_STREAM, 0);
+        if (::connect(fd, (sockaddr*)&sa, sizeof(sa)) == 0) break;
+        ::close(fd);
+        fd = -1;
+        if (std::chrono::steady_clock::now() > t_end) {
+          set_error(std::string("tcp bootstrap: rank 0 not reachable at ") + addr + ":" + std::to_string(port));
+          return PP_EHIP;
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));
+      }
+      setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+      if (!send_all(fd, &rank, sizeof(rank))) {
+        set_error("tcp bootstrap: hello failed");
+        return PP_EHIP;
+      }
+      fds[0] = fd;
+    }
+    return PP_OK;
+  }
+  int bcast(void* buf, size_t n) {
+    if (nranks <= 1) return PP_OK;
+    bool ok = true;
+    if (rank == 0)
+      for (int r = 1; r < nranks; ++r) ok = ok && send_all(fds[(size_t)r], buf, n);
+    else
+      ok = recv_all(fds[0], buf, n);
+    if (!ok) set_error("tcp transport: broadcast failed (peer gone?)");
+    return ok ? PP_OK : PP_EHIP;
+  }
+};
+static int tcp_fail() {
+  set_error("tcp transport: connection lost");
+  return PP_EHIP;
+}
+static int tcp_alltoall_int(void* user, const int* send, int* recv) {
+  TcpStar* t = (TcpStar*)user;
+  const int n = t->nranks;
+  if (t->rank == 0) {
+    std::vector<int> all((size_t)n * n);
+    std::copy(send, send + n, all.begin());
+    for (int r = 1; r < n; ++r)
+      if (!recv_all(t->fds[(size_t)r], &all[(size_t)r * n], sizeof(int) * (size_t)n)) return tcp_fail();
+    std::vector<int> col((size_t)n);
+    for (int r = 0; r < n; ++r) {
+      for (int s = 0; s < n; ++s) col[(size_t)s] = all[(size_t)s * n + r];
+      if (r == 0)
+        std::copy(col.begin(), col.end(), recv);
+      else if (!send_all(t->fds[(size_t)r], col.data(), sizeof(int) * (size_t)n))
+        return tcp_fail();
+    }
+  } else {
+    if (!send_all(t->fds[0], send, sizeof(int) * (size_t)n)) return tcp_fail();
+    if (!recv_all(t->fds[0], recv, sizeof(int) * (size_t)n)) return tcp_fail();
+  }
+  return PP_OK;
+}
+static int tcp_alltoallv(void* user, const void* send, const int64_t* sb, const int64_t* sd, void* recv,
+                         const int64_t* rb, const int64_t* rd) {
+  TcpStar* t = (TcpStar*)user;
+  const int n = t->nranks;
+  if (t->rank == 0) {
+    // segments[s][r]: what rank s sends to rank r
+    std::vector<std::vector<int64_t>> bytes((size_t)n, std::vector<int64_t>((size_t)n, 0));
+    std::vector<std::vector<char>> data((size_t)n);
+    std::copy(sb, sb + n, bytes[0].begin());
+    for (int s = 1; s < n; ++s) {
+      if (!recv_all(t->fds[(size_t)s], bytes[(size_t)s].data(), sizeof(int64_t) * (size_t)n)) return tcp_fail();
+      int64_t tot = 0;
+      for (int r = 0; r < n; ++r) tot += bytes[(size_t)s][(size_t)r];
+      data[(size_t)s].resize((size_t)tot);
+      if (tot && !recv_all(t->fds[(size_t)s], data[(size_t)s].data(), (size_t)tot)) return tcp_fail();
+    }
+    for (int r = 0; r < n; ++r)
+      for (int s = 0; s < n; ++s) {
+        const int64_t b = bytes[(size_t)s][(size_t)r];
+        if (!b) continue;
+        const char* src;
+        if (s == 0) {
+          src = (const char*)send + sd[r];
+        } else {
+          int64_t off = 0;
+          for (int q = 0; q < r; ++q) off += bytes[(size_t)s][(size_t)q];
+          src = data[(size_t)s].data() + off;
+        }
+        if (r == 0) {
+          if (b != rb[s]) {
+            set_error("tcp transport: receive count mismatch");
+            return PP_ESTATE;
+          }
+          memcpy((char*)recv + rd[s], src, (size_t)b);
+        } else if (!send_all(t->fds[(size_t)r], src, (size_t)b)) {
+          return tcp_fail();
+        }
+      }
+  } else {
+    if (!send_all(t->fds[0], sb, sizeof(int64_t) * (size_t)n)) return tcp_fail();
+    for (int r = 0; r < n; ++r)  // payload in destination order
+      if (sb[r] && !send_all(t->fds[0], (const char*)send + sd[r], (size_t)sb[r])) return tcp_fail();
+    for (int s = 0; s < n; ++s)  // arrives in source order
+      if (rb[s] && !recv_all(t->fds[0], (char*)recv + rd[s], (size_t)rb[s])) return tcp_fail();
+  }
+  return PP_OK;
+}
+template <class T>
+static int tcp_allreduce(TcpStar* t, T* buf, int64_t n) {
+  if (t->nranks <= 1 || n <= 0) return PP_OK;
+  if (t->rank == 0) {
+    std::vector<T> tmp((size_t)n);
+    for (int r = 1; r < t->nranks; ++r) {  // rank order: the sum is reproducible
+      if (!recv_all(t->fds[(size_t)r], tmp.data(), sizeof(T) * (size_t)n)) return tcp_fail();
+      for (int64_t i = 0; i < n; ++i) buf[i] += tmp[(size_t)i];
+    }
+  } else if (!send_all(t->fds[0], buf, sizeof(T) * (size_t)n)) {
+    return tcp_fail();
+  }
+  return t->bcast(buf, sizeof(T) * (size_t)n);
+}
+static int tcp_allreduce_f64(void* user, double* buf, int64_t n) { return tcp_allreduce((TcpStar*)user, buf, n); }
+static int tcp_allreduce_i64(void* user, int64_t* buf, int64_t n) { return tcp_allreduce((TcpStar*)user, buf, n); }
+
+// ------------------------------------------------------------------ local world (virtual ranks)
+struct LocalWorld {
+  int nranks = 0;
+  std::vector<pp_comm*> comms;
+  // migration round: which ranks have packed, their counts and send buffers
+  std::vector<char> begun;
+  std::vector<std::vector<int>> send_counts;
+  std::vector<const void*> send_buf;
+  std::vector<int> rec_bytes;
+  int ended = 0;
+  // all-reduce round
+  std::vector<double*> red_buf;
+  int64_t red_n = 0;
+  int red_cnt = 0;
+  DevBuf red_tmp;
+};
+
+__global__ void k_local_allreduce(int nranks, double* const* bufs, long long n, double* tmp) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0;
+  for (int r = 0; r < nranks; ++r) s += bufs[r][i];  // rank order
+  tmp[i] = s;
+}
+__global__ void k_local_bcast(int nranks, double* const* bufs, long long n, const double* tmp) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double s = tmp[i];
+  for (int r = 0; r < nranks; ++r) bufs[r][i] = s;
+}
+
+int local_publish(LocalWorld* w, int rank, const std::vector<int>& send_counts, const void* d_send, int rec_bytes) {
+  PP_REQUIRE(w && !w->begun[(size_t)rank], "local communicator: this virtual rank already began a migration");
+  w->begun[(size_t)rank] = 1;
+  w->send_counts[(size_t)rank] = send_counts;
+  w->send_buf[(size_t)rank] = d_send;
+  w->rec_bytes[(size_t)rank] = rec_bytes;
+  return PP_OK;
+}
+int local_all_begun(LocalWorld* w) {
+  for (int r = 0; r < w->nranks; ++r)
+    PP_REQUIRE(w->begun[(size_t)r], "local communicator: call pp_ps_migrate_begin on every virtual rank before "
+                                    "the first pp_ps_migrate_end");
+  return PP_OK;
+}
+void local_ended(LocalWorld* w, int rank) {
+  (void)rank;
+  if (++w->ended >= w->nranks) {
+    std::fill(w->begun.begin(), w->begun.end(), 0);
+    w->ended = 0;
+  }
+}
+
+// ------------------------------------------------------------------ transport primitives
+int comm_counts(pp_comm* c, const int* d_counts, std::vector<int>& send_counts,
+                std::vector<int>& recv_counts, bool* recv_known) {
+  const int n = c->nranks;
+  hipStream_t st = stream();
+  send_counts.assign((size_t)n, 0);
+  recv_counts.assign((size_t)n, 0);
+  *recv_known = true;
+  if (c->kind == 1) {  // rccl: everyone learns the whole matrix with one collective and one sync
+    PP_HIP_CHECK(c->d_allcounts.reserve(sizeof(int) * (size_t)n * n));
+    PP_NCCL_CHECK(rccl()->AllGather(d_counts, c->d_allcounts.p, (size_t)n, ncclInt32, (ncclComm_t)c->nccl, st));
+    if (c->pin_reserve(sizeof(int) * (size_t)n * n)) return PP_EHIP;
+    PP_HIP_CHECK(hipMemcpyAsync(c->h_pin, c->d_allcounts.p, sizeof(int) * (size_t)n * n, hipMemcpyDeviceToHost, st));
+    PP_HIP_CHECK(hipStreamSynchronize(st));
+    const int* m = (const int*)c->h_pin;
+    for (int r = 0; r < n; ++r) {
+      send_counts[(size_t)r] = m[(size_t)c->rank * n + r];
+      recv_counts[(size_t)r] = m[(size_t)r * n + c->rank];
+    }
+    send_counts[(size_t)c->rank] = recv_counts[(size_t)c->rank] = 0;
+    return PP_OK;
+  }
+  if (c->pin_reserve(sizeof(int) * (size_t)n)) return PP_EHIP;
+  PP_HIP_CHECK(hipMemcpyAsync(c->h_pin, d_counts, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
+  PP_HIP_CHECK(hipStreamSynchronize(st));
+  std::copy((const int*)c->h_pin, (const int*)c->h_pin + n, send_counts.begin());
+  send_counts[(size_t)c->rank] = 0;
+  if (c->kind == 4) {  // local: the other virtual ranks may not have counted yet
+    *recv_known = false;
+    return PP_OK;
+  }
+  if (c->kind == 0) return PP_OK;
+  return pp_comm_exchange_counts(c, send_counts.data(), recv_counts.data());
+}
+
+int comm_exchange_records(pp_comm* c, const void* d_send, const std::vector<int>& send_counts,
+                          std::vector<int>& recv_counts, int rec_bytes, void** d_recv_out) {
+  const int n = c->nranks;
+  hipStream_t st = stream();
+  std::vector<int64_t> sd((size_t)n), rd((size_t)n);
+  int64_t ns = 0, nr = 0;
+  if (c->kind == 4) {  // local: read the counts the other virtual ranks published
+    LocalWorld& w = *c->world;
+    for (int r = 0; r < n; ++r) recv_counts[(size_t)r] = (r == c->rank) ? 0 : w.send_counts[(size_t)r][(size_t)c->rank];
+  }
+  int rc = pp_migrate_plan(n, c->rank, send_counts.data(), recv_counts.data(), sd.data(), rd.data(), &ns, &nr);
+  if (rc) return rc;
+  PP_HIP_CHECK(c->d_recv.reserve((size_t)std::max<int64_t>(nr, 1) * rec_bytes));
+  *d_recv_out = c->d_recv.p;
+  if (c->kind == 0 || (ns == 0 && nr == 0 && c->kind != 1)) return PP_OK;
+  if (c->kind == 1) {
+    RcclApi* R = rccl();
+    PP_NCCL_CHECK(R->GroupStart());
+    for (int p = 0; p < n; ++p) {
+      if (p == c->rank) continue;
+      if (send_counts[(size_t)p])
+        PP_NCCL_CHECK(R->Send((const char*)d_send + sd[(size_t)p] * rec_bytes, (size_t)send_counts[(size_t)p] * rec_bytes,
+                              ncclChar, p, (ncclComm_t)c->nccl, st));
+      if (recv_counts[(size_t)p])
+        PP_NCCL_CHECK(R->Recv((char*)c->d_recv.p + rd[(size_t)p] * rec_bytes, (size_t)recv_counts[(size_t)p] * rec_bytes,
+                              ncclChar, p, (ncclComm_t)c->nccl, st));
+    }
+    PP_NCCL_CHECK(R->GroupEnd());
+    return PP_OK;
+  }
+  if (c->kind == 4) {
+    LocalWorld& w = *c->world;
+    for (int s = 0; s < n; ++s) {
+      if (s == c->rank || !recv_counts[(size_t)s]) continue;
+      if (w.rec_bytes[(size_t)s] != rec_bytes) {
+        set_error("local communicator: ranks disagree on the record size");
+        return PP_ESTATE;
+      }
+      int64_t off = 0;  // rank s packed rank-major: my segment starts after its lower ranks
+      for (int q = 0; q < c->rank; ++q) off += (q == s) ? 0 : w.send_counts[(size_t)s][(size_t)q];
+      PP_HIP_CHECK(hipMemcpyAsync((char*)c->d_recv.p + rd[(size_t)s] * rec_bytes,
+                                  (const char*)w.send_buf[(size_t)s] + off * rec_bytes,
+                                  (size_t)recv_counts[(size_t)s] * rec_bytes, hipMemcpyDeviceToDevice, st));
+    }
+    return PP_OK;
+  }
+  // host-staged transports (tcp, host): D2H, the caller's / the socket exchange, H2D
+  const size_t sbytes = (size_t)ns * rec_bytes, rbytes = (size_t)nr * rec_bytes;
+  if (c->pin_reserve(sbytes + rbytes + 64)) return PP_EHIP;
+  char* hs = (char*)c->h_pin;
+  char* hr = hs + ((sbytes + 63) / 64) * 64;
+  if (sbytes) PP_HIP_CHECK(hipMemcpyAsync(hs, d_send, sbytes, hipMemcpyDeviceToHost, st));
+  PP_HIP_CHECK(hipStreamSynchronize(st));
+  std::vector<int64_t> sb((size_t)n), rb((size_t)n), sdb((size_t)n), rdb((size_t)n);
+  for (int r = 0; r < n; ++r) {
+    sb[(size_t)r] = (int64_t)send_counts[(size_t)r] * rec_bytes;
+    rb[(size_t)r] = (int64_t)recv_counts[(size_t)r] * rec_bytes;
+    sdb[(size_t)r] = sd[(size_t)r] * rec_bytes;
+    rdb[(size_t)r] = rd[(size_t)r] * rec_bytes;
+  }
+  PP_REQUIRE(c->ops.alltoallv_bytes, "host communicator: alltoallv_bytes callback missing");
+  rc = c->ops.alltoallv_bytes(c->user, hs, sb.data(), sdb.data(), hr, rb.data(), rdb.data());
+  if (rc) {
+    if (!*pp_last_error()) set_error("host communicator: alltoallv_bytes callback failed");
+    return rc < 0 ? rc : PP_EHIP;
+  }
+  if (rbytes) PP_HIP_CHECK(hipMemcpyAsync(c->d_recv.p, hr, rbytes, hipMemcpyHostToDevice, st));
+  return PP_OK;
+}
+
+}  // namespace pp
+
+int pp_comm::pin_reserve(size_t bytes) {
+  if (bytes <= h_pin_bytes) return PP_OK;
+  if (h_pin) (void)hipHostFree(h_pin);
+  h_pin = nullptr;
+  h_pin_bytes = 0;
+  const size_t want = bytes + bytes / 4 + 4096;
+  PP_HIP_CHECK(hipHostMalloc(&h_pin, want));
+  h_pin_bytes = want;
+  return PP_OK;
+}
+
+extern "C" {
+
+int pp_comm_unique_id(void* id128_out) {
+  PP_REQUIRE(id128_out, "pp_comm_unique_id: null argument");
+  static_assert(sizeof(ncclUniqueId) == 128, "the C-ABI hands the RCCL id around as 128 bytes");
+  if (!pp::rccl()) return PP_ENOTIMPL;
+  ncclUniqueId id;
+  PP_NCCL_CHECK(pp::rccl()->GetUniqueId(&id));
+  memcpy(id128_out, &id, 128);
+  return PP_OK;
+}
+
+static pp_comm* new_comm(int kind, int rank, int nranks) {
+  if (nranks < 1 || rank < 0 || rank >= nranks) {
+    pp::set_error("communicator: rank / size out of range");
+    return nullptr;
+  }
+  pp_comm* c = new pp_comm();
+  c->kind = kind;
+  c->rank = rank;
+  c->nranks = nranks;
+  return c;
+}
+
+pp_comm* pp_comm_create_rccl(const void* id128, int rank, int nranks) {
+  if (!id128) {
+    pp::set_error("pp_comm_create_rccl: null id");
+    return nullptr;
+  }
+  if (!pp::initialised()) {
+    pp::set_error("pp_comm_create_rccl: call pp_init(device) first (one process per GPU)");
+    return nullptr;
+  }
+  if (!pp::rccl()) return nullptr;
+  pp_comm* c = new_comm(1, rank, nranks);
+  if (!c) return nullptr;
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  ncclComm_t comm = nullptr;
+  const ncclResult_t r = pp::rccl()->CommInitRank(&comm, nranks, id, rank);
+  if (r != ncclSuccess) {
+    pp::set_error(std::string("ncclCommInitRank: ") + pp::rccl()->GetErrorString(r));
+    delete c;
+    return nullptr;
+  }
+  c->nccl = (void*)comm;
+  return c;
+}
+
+pp_comm* pp_comm_create_tcp(const char* root_addr, int port, int rank, int nranks) {
+  pp_comm* c = new_comm(nranks > 1 ? 2 : 0, rank, nranks);
+  if (!c || nranks == 1) return c;
+  c->tcp = new pp::TcpStar();
+  c->tcp->rank = rank;
+  c->tcp->nranks = nranks;
+  if (c->tcp->connect_all(root_addr ? root_addr : "127.0.0.1", port)) {
+    delete c->tcp;
+    delete c;
+    return nullptr;
+  }
+  c->ops.alltoall_int = pp::tcp_alltoall_int;
+  c->ops.alltoallv_bytes = pp::tcp_alltoallv;
+  c->ops.allreduce_sum_f64 = pp::tcp_allreduce_f64;
+  c->ops.allreduce_sum_i64 = pp::tcp_allreduce_i64;
+  c->user = c->tcp;
+  return c;
+}
+
+pp_comm* pp_comm_create_host(const pp_comm_host_ops* ops, void* user, int rank, int nranks) {
+  if (!ops) {
+    pp::set_error("pp_comm_create_host: null ops");
+    return nullptr;
+  }
+  pp_comm* c = new_comm(nranks > 1 ? 3 : 0, rank, nranks);
+  if (!c) return nullptr;
+  c->ops = *ops;
+  c->user = user;
+  return c;
+}
+
+int pp_comm_create_local(int nranks, pp_comm** comms_out) {
+  PP_REQUIRE(nranks >= 1 && comms_out, "pp_comm_create_local: bad argument");
+  auto w = std::make_shared<pp::LocalWorld>();
+  w->nranks = nranks;
+  w->comms.resize((size_t)nranks);
+  w->begun.assign((size_t)nranks, 0);
+  w->send_counts.assign((size_t)nranks, std::vector<int>((size_t)nranks, 0));
+  w->send_buf.assign((size_t)nranks, nullptr);
+  w->rec_bytes.assign((size_t)nranks, 0);
+  w->red_buf.assign((size_t)nranks, nullptr);
+  for (int r = 0; r < nranks; ++r) {
+    pp_comm* c = new_comm(nranks > 1 ? 4 : 0, r, nranks);
+    c->world = w;
+    w->comms[(size_t)r] = c;
+    comms_out[r] = c;
+  }
+  return PP_OK;
+}
+
+int pp_bootstrap_broadcast(const char* root_addr, int port, int rank, int nranks, void* buf, int nbytes) {
+  PP_REQUIRE(buf && nbytes >= 0 && nranks >= 1 && rank >= 0 && rank < nranks, "pp_bootstrap_broadcast: bad argument");
+  pp::TcpStar t;
+  t.rank = rank;
+  t.nranks = nranks;
+  int rc = t.connect_all(root_addr ? root_addr : "127.0.0.1", port);
+  if (rc) return rc;
+  return t.bcast(buf, (size_t)nbytes);
+}
+
+pp_comm* pp_comm_create_env(void) {
+  const char* ws = getenv("WORLD_SIZE");
+  const int world = ws ? atoi(ws) : 1;
+  const int rank = getenv("RANK") ? atoi(getenv("RANK")) : 0;
+  if (world <= 1) return new_comm(0, 0, 1);
+  const char* addr = getenv("MASTER_ADDR") ? getenv("MASTER_ADDR") : "127.0.0.1";
+  const int port = getenv("PP_COMM_PORT") ? atoi(getenv("PP_COMM_PORT"))
+                                          : (getenv("MASTER_PORT") ? atoi(getenv("MASTER_PORT")) + 1 : 29511);
+  const char* kind = getenv("PP_COMM") ? getenv("PP_COMM") : "rccl";
+  if (std::string(kind) == "tcp") return pp_comm_create_tcp(addr, port, rank, world);
+  if (std::string(kind) != "rccl") {
+    pp::set_error("pp_comm_create_env: PP_COMM must be rccl or tcp");
+    return nullptr;
+  }
+  char id[128] = {0};
+  if (rank == 0 && pp_comm_unique_id(id) != PP_OK) return nullptr;
+  if (pp_bootstrap_broadcast(addr, port, rank, world, id, 128) != PP_OK) return nullptr;
+  return pp_comm_create_rccl(id, rank, world);
+}
+
+int pp_comm_rank(const pp_comm* c) { return c ? c->rank : 0; }
+int pp_comm_size(const pp_comm* c) { return c ? c->nranks : 1; }
+const char* pp_comm_kind(const pp_comm* c) {
+  static const char* names[] = {"self", "rccl", "tcp", "host", "local"};
+  return (c && c->kind >= 0 && c->kind <= 4) ? names[c->kind] : "self";
+}
+
+int pp_comm_destroy(pp_comm* c) {
+  if (!c) return PP_OK;
+  if (c->nccl && pp::rccl()) (void)pp::rccl()->CommDestroy((ncclComm_t)c->nccl);
+  if (c->tcp) delete c->tcp;
+  if (c->h_pin) (void)hipHostFree(c->h_pin);
+  if (c->world) c->world->comms[(size_t)c->rank] = nullptr;
+  delete c;
+  return PP_OK;
+}
+
+int pp_comm_exchange_counts(pp_comm* c, const int* send_counts_host, int* recv_counts_host) {
+  PP_REQUIRE(c && send_counts_host && recv_counts_host, "pp_comm_exchange_counts: null argument");
+  const int n = c->nranks;
+  if (c->kind == 0) {
+    recv_counts_host[0] = send_counts_host[0];
+    return PP_OK;
+  }
+  if (c->kind == 2 || c->kind == 3) {
+    PP_REQUIRE(c->ops.alltoall_int, "host communicator: alltoall_int callback missing");
+    const int rc = c->ops.alltoall_int(c->user, send_counts_host, recv_counts_host);
+    if (rc && !*pp_last_error()) pp::set_error("host communicator: alltoall_int callback failed");
+    return rc ? (rc < 0 ? rc : PP_EHIP) : PP_OK;
+  }
+  if (c->kind == 1) {  // through the device: all-gather of the rows
+    hipStream_t st = pp::stream();
+    PP_HIP_CHECK(c->d_counts.reserve(sizeof(int) * (size_t)n));
+    PP_HIP_CHECK(c->d_allcounts.reserve(sizeof(int) * (size_t)n * n));
+    PP_HIP_CHECK(hipMemcpyAsync(c->d_counts.p, send_counts_host, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
+    PP_NCCL_CHECK(pp::rccl()->AllGather(c->d_counts.p, c->d_allcounts.p, (size_t)n, ncclInt32, (ncclComm_t)c->nccl, st));
+    std::vector<int> m((size_t)n * n);
+    PP_HIP_CHECK(hipMemcpyAsync(m.data(), c->d_allcounts.p, sizeof(int) * (size_t)n * n, hipMemcpyDeviceToHost, st));
+    PP_HIP_CHECK(hipStreamSynchronize(st));
+    for (int r = 0; r < n; ++r) recv_counts_host[r] = m[(size_t)r * n + c->rank];
+    return PP_OK;
+  }
+  pp::set_error("pp_comm_exchange_counts: a local communicator exchanges counts inside pp_ps_migrate_begin/_end");
+  return PP_ESTATE;
+}
+
+int pp_migrate_plan(int nranks, int rank, const int* send_counts, const int* recv_counts,
+                    int64_t* send_displ, int64_t* recv_displ, int64_t* n_send, int64_t* n_recv) {
+  PP_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks && send_counts && recv_counts && send_displ &&
+                 recv_displ && n_send && n_recv,
+             "pp_migrate_plan: bad argument");
+  int64_t s = 0, r = 0;
+  for (int p = 0; p < nranks; ++p) {
+    PP_REQUIRE(send_counts[p] >= 0 && recv_counts[p] >= 0, "pp_migrate_plan: negative count");
+    send_displ[p] = s;
+    recv_displ[p] = r;
+    if (p == rank) continue;  // a rank keeps its own particles (SCS_migrate.h:33-35)
+    s += send_counts[p];
+    r += recv_counts[p];
+  }
+  PP_REQUIRE(s <= 2147483647ll && r <= 2147483647ll, "pp_migrate_plan: more than 2^31 particles in one exchange");
+  *n_send = s;
+  *n_recv = r;
+  return PP_OK;
+}
+
+int pp_allreduce_sum(pp_comm* c, double* buf_dev, int64_t n) {
+  PP_REQUIRE(c && (buf_dev || n == 0) && n >= 0, "pp_allreduce_sum: bad argument");
+  if (c->kind == 0 || n == 0) return PP_OK;
+  pp::Range rg("pp_allreduce_sum");
+  hipStream_t st = pp::stream();
+  if (c->kind == 1) {
+    PP_NCCL_CHECK(pp::rccl()->AllReduce(buf_dev, buf_dev, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)c->nccl, st));
+    return PP_OK;
+  }
+  if (c->kind == 4) {  // deferred: the last virtual rank to call sums for all of them (stream order)
+    pp::LocalWorld& w = *c->world;
+    if (w.red_cnt == 0) w.red_n = n;
+    PP_REQUIRE(w.red_n == n && !w.red_buf[(size_t)c->rank], "local communicator: mismatched all-reduce calls");
+    w.red_buf[(size_t)c->rank] = buf_dev;
+    if (++w.red_cnt < w.nranks) return PP_OK;
+    PP_HIP_CHECK(w.red_tmp.reserve(sizeof(double) * (size_t)n + sizeof(double*) * (size_t)w.nranks));
+    double** tab = (double**)((char*)w.red_tmp.p + sizeof(double) * (size_t)n);
+    PP_HIP_CHECK(hipMemcpyAsync(tab, w.red_buf.data(), sizeof(double*) * (size_t)w.nranks, hipMemcpyHostToDevice, st));
+    pp::k_local_allreduce<<<pp::grid_for((size_t)n), pp::kBlock, 0, st>>>(w.nranks, tab, n, w.red_tmp.as<double>());
+    pp::k_local_bcast<<<pp::grid_for((size_t)n), pp::kBlock, 0, st>>>(w.nranks, tab, n, w.red_tmp.as<double>());
+    PP_LAUNCH_CHECK();
+    PP_HIP_CHECK(hipStreamSynchronize(st));  // red_buf (host) was the source of an async copy
+    std::fill(w.red_buf.begin(), w.red_buf.end(), nullptr);
+    w.red_cnt = 0;
+    return PP_OK;
+  }
+  // host-staged (MPI_Allreduce of the reference, pumipic_comm.cpp:236-245: D2H, reduce, H2D)
+  PP_REQUIRE(c->ops.allreduce_sum_f64, "host communicator: allreduce_sum_f64 callback missing");
+  if (c->pin_reserve(sizeof(double) * (size_t)n)) return PP_EHIP;
+  PP_HIP_CHECK(hipMemcpyAsync(c->h_pin, buf_dev, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+  PP_HIP_CHECK(hipStreamSynchronize(st));
+  const int rc = c->ops.allreduce_sum_f64(c->user, (double*)c->h_pin, n);
+  if (rc) {
+    if (!*pp_last_error()) pp::set_error("host communicator: allreduce_sum_f64 callback failed");
+    return rc < 0 ? rc : PP_EHIP;
+  }
+  PP_HIP_CHECK(hipMemcpyAsync(buf_dev, c->h_pin, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+  PP_HIP_CHECK(hipStreamSynchronize(st));  // the pinned buffer is reused by the next call
+  return PP_OK;
+}
+
+int pp_allreduce_sum_host_i64(pp_comm* c, int64_t* vals_host, int n) {
+  PP_REQUIRE(c && vals_host && n >= 0, "pp_allreduce_sum_host_i64: bad argument");
+  if (c->kind == 0 || n == 0) return PP_OK;
+  if (c->kind == 2 || c->kind == 3) {
+    PP_REQUIRE(c->ops.allreduce_sum_i64, "host communicator: allreduce_sum_i64 callback missing");
+    const int rc = c->ops.allreduce_sum_i64(c->user, vals_host, n);
+    return rc ? (rc < 0 ? rc : PP_EHIP) : PP_OK;
+  }
+  if (c->kind == 1) {
+    hipStream_t st = pp::stream();
+    PP_HIP_CHECK(c->d_small.reserve(sizeof(int64_t) * (size_t)n));
+    PP_HIP_CHECK(hipMemcpyAsync(c->d_small.p, vals_host, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, st));
+    PP_NCCL_CHECK(pp::rccl()->AllReduce(c->d_small.p, c->d_small.p, (size_t)n, ncclInt64, ncclSum, (ncclComm_t)c->nccl, st));
+    PP_HIP_CHECK(hipMemcpyAsync(vals_host, c->d_small.p, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+    PP_HIP_CHECK(hipStreamSynchronize(st));
+    return PP_OK;
+  }
+  pp::set_error("pp_allreduce_sum_host_i64: not available on a local communicator (sum the virtual ranks on the host)");
+  return PP_ESTATE;
+}
+
+int pp_comm_barrier(pp_comm* c) {
+  PP_REQUIRE(c, "pp_comm_barrier: null communicator");
+  if (pp::initialised()) PP_HIP_CHECK(hipStreamSynchronize(pp::stream()));
+  if (c->kind == 0 || c->kind == 4) return PP_OK;
+  int64_t one = 1;
+  return pp_allreduce_sum_host_i64(c, &one, 1);
+}
+
+}  // extern "C"

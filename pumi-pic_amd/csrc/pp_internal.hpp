@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 #include "../../include/pumipic_hip.h"
@@ -182,6 +183,69 @@ struct pp_ps {
   pp::DevBuf s_ppe, s_keys, s_keys2, s_vals, s_vals2, s_hist, s_chunkw, s_misc, s_rowstart,
       s_newidx, s_offsets2, s_s2c2, s_r2e2, s_e2r2, s_mask2, s_slot2, s_scan, s_cstart2, s_cwidth2, s_aos, s_idx, s_ranknew, s_eslot0, s_scan2;
 };
+
+// ---------------------------------------------------------------------------------------------
+// communicator (pp_comm.hip).  kind: 0 self, 1 rccl, 2 tcp, 3 host, 4 local
+namespace pp {
+struct LocalWorld;
+struct TcpStar;
+struct MigratePending {  // arguments of pp_ps_migrate_begin kept until pp_ps_migrate_end
+  bool active = false;
+  pp_ps* ps = nullptr;
+  int m_x = -1, m_xtgt = -1;
+  int* new_element = nullptr;
+  int n_new = 0;
+  const int* new_elems = nullptr;
+  const void* const* new_info = nullptr;
+  const int* gid2lid = nullptr;
+  int64_t ngids = 0;
+  const pp_mesh* mesh = nullptr;
+  int nmaps = 0;
+  std::vector<const int*> v2v;
+  std::vector<double*> outs;
+  double rmax = 0;
+  int gnr = 2, gppr = 1;
+  int rec_bytes = 0;
+  std::vector<int> send_counts, recv_counts;  // particles per rank
+  bool recv_known = false;
+  int64_t n_send = 0;
+};
+}  // namespace pp
+struct pp_comm {
+  int kind = 0, rank = 0, nranks = 1;
+  void* nccl = nullptr;  // ncclComm_t
+  pp_comm_host_ops ops{};
+  void* user = nullptr;
+  pp::TcpStar* tcp = nullptr;            // kind tcp: owns the sockets (ops/user point into it)
+  std::shared_ptr<pp::LocalWorld> world;  // kind local
+  pp::DevBuf d_counts, d_allcounts, d_send, d_recv, d_small;
+  void* h_pin = nullptr;  // pinned staging (counts matrix; host-staged transports: records)
+  size_t h_pin_bytes = 0;
+  pp::MigratePending pend;
+  int pin_reserve(size_t bytes);
+};
+namespace pp {
+// transport primitives used by the migration (pp_migrate.hip)
+// counts: d_counts holds `nranks` ints on the device (particles leaving for every rank).  Fills
+// send_counts and, when the transport can know them already, recv_counts (local: only at `end`).
+int comm_counts(pp_comm* c, const int* d_counts, std::vector<int>& send_counts,
+                std::vector<int>& recv_counts, bool* recv_known);
+// records: d_send rank-major (send_counts particles of rec_bytes each); returns the received records
+// (library-owned device buffer of the communicator) in rank order
+int comm_exchange_records(pp_comm* c, const void* d_send, const std::vector<int>& send_counts,
+                          std::vector<int>& recv_counts, int rec_bytes, void** d_recv_out);
+// local communicator bookkeeping (virtual ranks of one process)
+int local_publish(LocalWorld* w, int rank, const std::vector<int>& send_counts, const void* d_send, int rec_bytes);
+int local_all_begun(LocalWorld* w);
+void local_ended(LocalWorld* w, int rank);
+// pp_runtime.hip: roctx ranges (no-ops unless PP_ROCTX=1)
+void range_push(const char* name);
+void range_pop();
+struct Range {
+  explicit Range(const char* n) { range_push(n); }
+  ~Range() { range_pop(); }
+};
+}  // namespace pp
 
 namespace pp {
 // pp_scatter.hip: gyroScatter for `nmaps` ring maps from an explicit per-element count array (the

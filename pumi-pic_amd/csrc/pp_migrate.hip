@@ -131,6 +131,74 @@ __global__ void k_unpack_records(int n, const unsigned* __restrict__ rec, const 
   for (int w = 0; w < t.nwords; ++w) *(unsigned*)(t.dst[w] + (long long)i * t.scale[w]) = r[2 + w];
 }
 
+// ---- routing without same-address atomics.  A per-particle atomicAdd on one of `nranks` counters
+// serialises in the L2 (~10 ns each: 3 ms for 300 k leaving particles).  Instead block b owns a fixed
+// contiguous range of slots; it counts its leavers per destination in LDS (k_route_count), one thread
+// per destination turns the per-block counts into per-block start offsets (k_route_scan), and the
+// pack pass, run with the SAME block -> slot mapping, ranks its leavers with LDS atomics only.
+constexpr int kRouteBlocks = 1024;
+constexpr int kMaxRanks = 256;
+struct RankStarts {
+  int v[64];  // first record of every destination rank in the send buffer (nranks <= 64 by value)
+};
+__device__ __forceinline__ int route_dest(int pid, int capacity, const unsigned char* __restrict__ mask,
+                                          const int* __restrict__ new_element,
+                                          const int* __restrict__ new_process, int rank, int nranks) {
+  if (pid >= capacity || !mask[pid] || new_element[pid] < 0) return -1;
+  const int p = new_process[pid];
+  return (p != rank && p >= 0 && p < nranks) ? p : -1;
+}
+__global__ void k_route_count(int capacity, int per_block, const unsigned char* __restrict__ mask,
+                              const int* __restrict__ new_element, const int* __restrict__ new_process,
+                              int rank, int nranks, int* __restrict__ block_cnt) {
+  __shared__ int h[kMaxRanks];
+  for (int i = threadIdx.x; i < nranks; i += blockDim.x) h[i] = 0;
+  __syncthreads();
+  const int lo = blockIdx.x * per_block, hi = min(capacity, lo + per_block);
+  for (int pid = lo + threadIdx.x; pid < hi; pid += blockDim.x) {
+    const int p = route_dest(pid, capacity, mask, new_element, new_process, rank, nranks);
+    if (p >= 0) atomicAdd(&h[p], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nranks; i += blockDim.x) block_cnt[blockIdx.x * nranks + i] = h[i];
+}
+// thread p: exclusive scan over the blocks of destination p (in place), total to counts[p]
+__global__ void k_route_scan(int nblocks, int nranks, int* __restrict__ block_cnt, int* __restrict__ counts) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nranks) return;
+  int run = 0;
+  for (int b = 0; b < nblocks; ++b) {
+    const int c = block_cnt[b * nranks + p];
+    block_cnt[b * nranks + p] = run;
+    run += c;
+  }
+  counts[p] = run;
+}
+__global__ void k_route_pack(int capacity, int per_block, const unsigned char* __restrict__ mask,
+                             int* new_element, const int* __restrict__ new_process, int rank, int nranks,
+                             const int* __restrict__ block_start, RankStarts rs,
+                             const int* __restrict__ rank_start_dev, const long long* __restrict__ gids,
+                             unsigned* __restrict__ out, RecTable t) {
+  __shared__ int cur[kMaxRanks];
+  for (int i = threadIdx.x; i < nranks; i += blockDim.x)
+    cur[i] = block_start[blockIdx.x * nranks + i] + (rank_start_dev ? rank_start_dev[i] : rs.v[i]);
+  __syncthreads();
+  const int lo = blockIdx.x * per_block, hi = min(capacity, lo + per_block);
+  for (int pid = lo + threadIdx.x; pid < hi; pid += blockDim.x) {
+    const int p = route_dest(pid, capacity, mask, new_element, new_process, rank, nranks);
+    if (p < 0) continue;
+    const int e = new_element[pid];
+    const int idx = atomicAdd(&cur[p], 1);  // LDS
+    unsigned* r = out + (size_t)idx * t.rec_words;
+    const long long g = gids ? gids[e] : (long long)e;
+    r[0] = (unsigned)(g & 0xffffffffll);
+    r[1] = (unsigned)((unsigned long long)g >> 32);
+    for (int w = 0; w < t.nwords; ++w)
+      r[2 + w] = t.src[w] ? *(const unsigned*)(t.src[w] + (long long)pid * t.scale[w]) : 0u;
+    new_element[pid] = -1;  // removeSentParticles (SCS_migrate.h:189-196)
+  }
+}
+
 // commit_x / commit_xt >= 0: the record carries the particle AFTER updatePtclPositions (member
 // commit_x is read from commit_xt's arrays, member commit_xt travels as zeros)
 int build_rec_table(const pp_ps* ps, RecTable& t, int commit_x = -1, int commit_xt = -1) {
@@ -248,6 +316,51 @@ int pp_ps_migrate_pack_records_commit(const pp_ps* ps, int m_x, int m_xtgt, int*
   return pack_records(ps, m_x, m_xtgt, new_element_dev, new_process_dev, comm_rank, nranks,
                       send_counts_host, send_records_dev);
 }
+// per-block leaver counts of the current routing (scratch(4): [kRouteBlocks][nranks]) and their scan;
+// totals per destination to counts_dev (nranks ints)
+static int route_count(const pp_ps* ps, const int* new_element_dev, const int* new_process_dev,
+                       int comm_rank, int nranks, int* counts_dev, int* per_block_out) {
+  PP_REQUIRE(nranks <= kMaxRanks, "migration: more than 256 ranks are not supported by the routing kernels");
+  hipStream_t st = pp::stream();
+  pp::DevBuf& bc = scratch(4);
+  PP_HIP_CHECK(bc.reserve(sizeof(int) * (size_t)kRouteBlocks * nranks));
+  const int cap = std::max(ps->capacity, 1);
+  const int per_block = ((cap + kRouteBlocks - 1) / kRouteBlocks + 255) / 256 * 256;
+  *per_block_out = per_block;
+  k_route_count<<<kRouteBlocks, kBlock, 0, st>>>(ps->num_ptcls > 0 ? ps->capacity : 0, per_block,
+                                                 ps->d_mask.as<unsigned char>(), new_element_dev,
+                                                 new_process_dev, comm_rank, nranks, bc.as<int>());
+  k_route_scan<<<grid_for(nranks), kBlock, 0, st>>>(kRouteBlocks, nranks, bc.as<int>(), counts_dev);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+// pack pass of the same routing (route_count must have run on the same arrays)
+static int route_pack(const pp_ps* ps, int commit_x, int commit_xt, int* new_element_dev,
+                      const int* new_process_dev, int comm_rank, int nranks, int per_block,
+                      const int* rank_start_host, void* send_records_dev) {
+  RecTable t{};
+  int rc = build_rec_table(ps, t, commit_x, commit_xt);
+  if (rc) return rc;
+  hipStream_t st = pp::stream();
+  RankStarts rs{};
+  const int* rs_dev = nullptr;
+  if (nranks <= 64) {
+    for (int r = 0; r < nranks; ++r) rs.v[r] = rank_start_host[r];
+  } else {  // does not fit the kernel arguments: through device memory (one extra sync)
+    pp::DevBuf& cur = scratch(0);
+    PP_HIP_CHECK(cur.reserve(sizeof(int) * (size_t)nranks));
+    PP_HIP_CHECK(hipMemcpyAsync(cur.p, rank_start_host, sizeof(int) * (size_t)nranks, hipMemcpyHostToDevice, st));
+    PP_HIP_CHECK(hipStreamSynchronize(st));
+    rs_dev = cur.as<int>();
+  }
+  k_route_pack<<<kRouteBlocks, kBlock, 0, st>>>(ps->num_ptcls > 0 ? ps->capacity : 0, per_block,
+                                                ps->d_mask.as<unsigned char>(), new_element_dev,
+                                                new_process_dev, comm_rank, nranks, scratch(4).as<int>(), rs,
+                                                rs_dev, ps->has_gids ? ps->d_gids.as<long long>() : nullptr,
+                                                (unsigned*)send_records_dev, t);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
 static int pack_records(const pp_ps* ps, int commit_x, int commit_xt, int* new_element_dev,
                         const int* new_process_dev, int comm_rank, int nranks,
                         const int* send_counts_host, void* send_records_dev) {
@@ -261,20 +374,15 @@ static int pack_records(const pp_ps* ps, int commit_x, int commit_xt, int* new_e
   }
   if (total == 0) return PP_OK;
   PP_REQUIRE(send_records_dev, "pp_ps_migrate_pack_records: null send buffer");
-  RecTable t{};
-  int rc = build_rec_table(ps, t, commit_x, commit_xt);
+  pp::DevBuf& cnt = scratch(3);
+  PP_HIP_CHECK(cnt.reserve(sizeof(int) * (size_t)nranks));
+  int per_block = 0;
+  int rc = route_count(ps, new_element_dev, new_process_dev, comm_rank, nranks, cnt.as<int>(), &per_block);
   if (rc) return rc;
-  hipStream_t st = pp::stream();
-  pp::DevBuf& cur = scratch(0);
-  PP_HIP_CHECK(cur.reserve(sizeof(int) * (size_t)nranks));
-  PP_HIP_CHECK(hipMemcpyAsync(cur.p, start.data(), sizeof(int) * (size_t)nranks,
-                              hipMemcpyHostToDevice, st));
-  k_pack_records<<<grid_for(ps->capacity), kBlock, 0, st>>>(
-      ps->capacity, ps->d_mask.as<unsigned char>(), new_element_dev, new_process_dev, comm_rank,
-      nranks, cur.as<int>(), ps->has_gids ? ps->d_gids.as<long long>() : nullptr,
-      (unsigned*)send_records_dev, t);
-  PP_LAUNCH_CHECK();
-  PP_HIP_CHECK(hipStreamSynchronize(st));
+  rc = route_pack(ps, commit_x, commit_xt, new_element_dev, new_process_dev, comm_rank, nranks, per_block,
+                  start.data(), send_records_dev);
+  if (rc) return rc;
+  PP_HIP_CHECK(hipStreamSynchronize(pp::stream()));
   return PP_OK;
 }
 
@@ -284,50 +392,203 @@ int pp_ps_rebuild_records(pp_ps* ps, const int* new_element_dev, int n_recv,
                                        ngids, nullptr, 0, nullptr, nullptr, 0.0, 2, 1);
 }
 
-int pp_ps_rebuild_records_scatter(pp_ps* ps, int m_x, int m_xtgt, const int* new_element_dev, int n_recv,
-                                  const void* recv_records_dev, const int* gid2lid_dev, int64_t ngids,
-                                  const pp_mesh* mesh, int nmaps, const int* const* v2v_dev,
-                                  double* const* scatter_w_dev, double rmax, int gnr, int gppr) {
-  PP_REQUIRE(ps && n_recv >= 0 && (n_recv == 0 || recv_records_dev),
-             "pp_ps_rebuild_records: bad argument");
+// received records (+ the caller's own new particles) become the "new particles" of the rebuild
+// (SCS_migrate.h:198-213)
+static int rebuild_from_records(pp_ps* ps, int m_x, int m_xtgt, const int* new_element_dev, int n_recv,
+                                const void* recv_records_dev, const int* gid2lid_dev, int64_t ngids,
+                                int n_extra, const int* extra_elems_dev, const void* const* extra_info_dev,
+                                const pp_mesh* mesh, int nmaps, const int* const* v2v_dev,
+                                double* const* scatter_w_dev, double rmax, int gnr, int gppr) {
   const bool plain = m_x < 0 && m_xtgt < 0 && nmaps == 0;
+  const int n_tot = n_recv + n_extra;
   if (n_recv == 0)
-    return plain ? pp_ps_rebuild(ps, new_element_dev, 0, nullptr, nullptr)
-                 : pp_ps_rebuild_scatter(ps, m_x, m_xtgt, new_element_dev, 0, nullptr, nullptr, mesh, nmaps,
-                                         v2v_dev, scatter_w_dev, rmax, gnr, gppr);
+    return plain ? pp_ps_rebuild(ps, new_element_dev, n_extra, extra_elems_dev, extra_info_dev)
+                 : pp_ps_rebuild_scatter(ps, m_x, m_xtgt, new_element_dev, n_extra, extra_elems_dev,
+                                         extra_info_dev, mesh, nmaps, v2v_dev, scatter_w_dev, rmax, gnr, gppr);
   RecTable t{};
   int rc = build_rec_table(ps, t);
   if (rc) return rc;
   hipStream_t st = pp::stream();
-  // received particles become "new particles" of the rebuild (SCS_migrate.h:198-213)
-  pp::DevBuf* info = &scratch(8);  // scratch(8 + m): member m of the received particles
+  pp::DevBuf* info = &scratch(8);  // scratch(8 + m): member m of the arriving particles
   std::vector<const void*> ptrs((size_t)ps->nmembers);
   int w = 0;
   for (int m = 0; m < ps->nmembers; ++m) {
     const int s = ps->member_map[m];
     const int b = ps->member_bytes[s], nc = ps->member_ncomp[s];
-    PP_HIP_CHECK(info[m].reserve((size_t)n_recv * nc * b));
+    PP_HIP_CHECK(info[m].reserve((size_t)n_tot * nc * b));
     ptrs[m] = info[m].p;
-    for (int c = 0; c < nc; ++c)
-      for (int hw = 0; hw < b / 4; ++hw) t.dst[w++] = (char*)info[m].p + ((size_t)c * n_recv) * b + hw * 4;
+    for (int c = 0; c < nc; ++c) {
+      for (int hw = 0; hw < b / 4; ++hw) t.dst[w++] = (char*)info[m].p + ((size_t)c * n_tot) * b + hw * 4;
+      if (n_extra > 0)
+        PP_HIP_CHECK(hipMemcpyAsync((char*)info[m].p + ((size_t)c * n_tot + n_recv) * b,
+                                    (const char*)extra_info_dev[m] + ((size_t)c * n_extra) * b,
+                                    (size_t)n_extra * b, hipMemcpyDeviceToDevice, st));
+    }
   }
   pp::DevBuf &elems = scratch(1), &bad = scratch(2);
-  PP_HIP_CHECK(elems.reserve(sizeof(int) * (size_t)n_recv));
+  PP_HIP_CHECK(elems.reserve(sizeof(int) * (size_t)n_tot));
   PP_HIP_CHECK(bad.reserve(sizeof(int)));
   PP_HIP_CHECK(hipMemsetAsync(bad.p, 0, sizeof(int), st));
   k_unpack_records<<<grid_for(n_recv), kBlock, 0, st>>>(n_recv, (const unsigned*)recv_records_dev,
                                                         gid2lid_dev, (long long)ngids,
                                                         elems.as<int>(), bad.as<int>(), t);
   PP_LAUNCH_CHECK();
-  int hbad = 0;
-  PP_HIP_CHECK(hipMemcpyAsync(&hbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
-  PP_HIP_CHECK(hipStreamSynchronize(st));
-  PP_REQUIRE(!hbad, "pp_ps_rebuild_records: received an element gid with no local id "
+  if (n_extra > 0)
+    PP_HIP_CHECK(hipMemcpyAsync(elems.as<int>() + n_recv, extra_elems_dev, sizeof(int) * (size_t)n_extra,
+                                hipMemcpyDeviceToDevice, st));
+  // A gid without a local id unpacks as element -1, which the rebuild rejects like any inactive
+  // new particle BEFORE it changes the structure: no separate host sync for the check.  The
+  // scratch buffers outlive the call: the rebuild reads them in stream order.
+  rc = plain ? pp_ps_rebuild(ps, new_element_dev, n_tot, elems.as<int>(), ptrs.data())
+             : pp_ps_rebuild_scatter(ps, m_x, m_xtgt, new_element_dev, n_tot, elems.as<int>(), ptrs.data(), mesh,
+                                     nmaps, v2v_dev, scatter_w_dev, rmax, gnr, gppr);
+  if (rc == PP_EINVAL) {
+    int hbad = 0;
+    if (hipMemcpy(&hbad, bad.p, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && hbad)
+      pp::set_error("pp_ps_rebuild_records: received an element gid with no local id "
                     "(assert(valid_at(index)), SCS_migrate.h:184)");
-  // the scratch buffers outlive the call: the rebuild may still be reading them, in stream order
-  if (plain) return pp_ps_rebuild(ps, new_element_dev, n_recv, elems.as<int>(), ptrs.data());
-  return pp_ps_rebuild_scatter(ps, m_x, m_xtgt, new_element_dev, n_recv, elems.as<int>(), ptrs.data(), mesh,
-                               nmaps, v2v_dev, scatter_w_dev, rmax, gnr, gppr);
+  }
+  return rc;
+}
+
+int pp_ps_rebuild_records_scatter(pp_ps* ps, int m_x, int m_xtgt, const int* new_element_dev, int n_recv,
+                                  const void* recv_records_dev, const int* gid2lid_dev, int64_t ngids,
+                                  const pp_mesh* mesh, int nmaps, const int* const* v2v_dev,
+                                  double* const* scatter_w_dev, double rmax, int gnr, int gppr) {
+  PP_REQUIRE(ps && n_recv >= 0 && (n_recv == 0 || recv_records_dev),
+             "pp_ps_rebuild_records: bad argument");
+  return rebuild_from_records(ps, m_x, m_xtgt, new_element_dev, n_recv, recv_records_dev, gid2lid_dev, ngids,
+                              0, nullptr, nullptr, mesh, nmaps, v2v_dev, scatter_w_dev, rmax, gnr, gppr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// SellCSigma::migrate (scs/SCS_migrate.h:5-222) behind one call
+int pp_ps_migrate_begin(pp_ps* ps, int m_x, int m_xtgt, int* new_element_dev,
+                        const int* new_process_dev, pp_comm* comm, int n_new,
+                        const int* new_elems_dev, const void* const* new_info_dev,
+                        const int* gid2lid_dev, int64_t ngids, const pp_mesh* mesh, int nmaps,
+                        const int* const* v2v_dev, double* const* scatter_w_dev, double rmax,
+                        int gnr, int gppr) {
+  PP_REQUIRE(ps && comm, "pp_ps_migrate: null structure / communicator");
+  PP_REQUIRE((new_element_dev && new_process_dev) || ps->capacity == 0, "pp_ps_migrate: null routing arrays");
+  PP_REQUIRE(n_new >= 0 && (n_new == 0 || (new_elems_dev && new_info_dev)), "pp_ps_migrate: bad new particles");
+  PP_REQUIRE(nmaps >= 0 && (nmaps == 0 || (mesh && v2v_dev && scatter_w_dev)), "pp_ps_migrate: bad scatter arguments");
+  const bool commit = m_x >= 0 || m_xtgt >= 0;
+  if (commit) {
+    PP_REQUIRE(m_x >= 0 && m_xtgt >= 0 && m_x < ps->nmembers && m_xtgt < ps->nmembers && m_x != m_xtgt,
+               "pp_ps_migrate: bad member index");
+    PP_REQUIRE(ps->member_bytes[ps->member_map[m_x]] == 8 && ps->member_bytes[ps->member_map[m_xtgt]] == 8 &&
+                   ps->member_ncomp[ps->member_map[m_x]] == ps->member_ncomp[ps->member_map[m_xtgt]],
+               "pp_ps_migrate: x and x_tgt must be double members of equal shape");
+  }
+  pp::MigratePending& P = comm->pend;
+  PP_REQUIRE(!P.active, "pp_ps_migrate_begin: the previous migration on this communicator was not ended");
+  pp::Range rg("pp_ps_migrate_begin");
+  P = pp::MigratePending();
+  P.ps = ps;
+  P.m_x = commit ? m_x : -1;
+  P.m_xtgt = commit ? m_xtgt : -1;
+  P.new_element = new_element_dev;
+  P.n_new = n_new;
+  P.new_elems = new_elems_dev;
+  P.new_info = new_info_dev;
+  P.gid2lid = gid2lid_dev;
+  P.ngids = ngids;
+  P.mesh = mesh;
+  P.nmaps = nmaps;
+  for (int k = 0; k < nmaps; ++k) {
+    P.v2v.push_back(v2v_dev[k]);
+    P.outs.push_back(scatter_w_dev[k]);
+  }
+  P.rmax = rmax;
+  P.gnr = gnr;
+  P.gppr = gppr;
+  const int n = comm->nranks;
+  P.send_counts.assign((size_t)n, 0);
+  P.recv_counts.assign((size_t)n, 0);
+  P.recv_known = true;
+  if (n > 1) {
+    RecTable t{};
+    int rc = build_rec_table(ps, t, P.m_x, P.m_xtgt);
+    if (rc) return rc;
+    P.rec_bytes = t.rec_words * 4;
+    PP_HIP_CHECK(comm->d_counts.reserve(sizeof(int) * (size_t)n));
+    int per_block = 0;
+    rc = route_count(ps, new_element_dev, new_process_dev, comm->rank, n, comm->d_counts.as<int>(), &per_block);
+    if (rc) return rc;
+    rc = pp::comm_counts(comm, comm->d_counts.as<int>(), P.send_counts, P.recv_counts, &P.recv_known);
+    if (rc) return rc;
+    std::vector<int> start((size_t)n, 0);
+    int64_t tot = 0;
+    for (int r = 0; r < n; ++r) {
+      start[(size_t)r] = (int)tot;
+      if (r != comm->rank) tot += P.send_counts[(size_t)r];
+    }
+    P.n_send = tot;
+    PP_HIP_CHECK(comm->d_send.reserve((size_t)std::max<int64_t>(tot, 1) * P.rec_bytes));
+    if (tot > 0) {
+      rc = route_pack(ps, P.m_x, P.m_xtgt, new_element_dev, new_process_dev, comm->rank, n, per_block,
+                      start.data(), comm->d_send.p);
+      if (rc) return rc;
+    }
+    if (comm->kind == 4) {  // publish to the other virtual ranks
+      pp::LocalWorld* w = comm->world.get();
+      rc = pp::local_publish(w, comm->rank, P.send_counts, comm->d_send.p, P.rec_bytes);
+      if (rc) return rc;
+    }
+  }
+  P.active = true;
+  return PP_OK;
+}
+
+int pp_ps_migrate_end(pp_ps* ps, pp_comm* comm, int* n_sent, int* n_received) {
+  PP_REQUIRE(ps && comm, "pp_ps_migrate_end: null argument");
+  pp::MigratePending& P = comm->pend;
+  PP_REQUIRE(P.active && P.ps == ps, "pp_ps_migrate_end: no migration of this structure was begun on this communicator");
+  pp::Range rg("pp_ps_migrate_end");
+  P.active = false;
+  int rc;
+  int64_t nrecv = 0;
+  void* d_recv = nullptr;
+  if (comm->nranks > 1) {
+    if (comm->kind == 4) {
+      rc = pp::local_all_begun(comm->world.get());
+      if (rc) return rc;
+    }
+    rc = pp::comm_exchange_records(comm, comm->d_send.p, P.send_counts, P.recv_counts, P.rec_bytes, &d_recv);
+    if (rc) return rc;
+    for (int r = 0; r < comm->nranks; ++r)
+      if (r != comm->rank) nrecv += P.recv_counts[(size_t)r];
+  }
+  if (n_sent) *n_sent = (int)P.n_send;
+  if (n_received) *n_received = (int)nrecv;
+  rc = rebuild_from_records(ps, P.m_x, P.m_xtgt, P.new_element, (int)nrecv, d_recv, P.gid2lid, P.ngids, P.n_new,
+                            P.new_elems, P.new_info, P.mesh, P.nmaps, P.v2v.data(), P.outs.data(), P.rmax,
+                            P.gnr, P.gppr);
+  if (comm->kind == 4) pp::local_ended(comm->world.get(), comm->rank);
+  return rc;
+}
+
+int pp_ps_migrate_scatter(pp_ps* ps, int m_x, int m_xtgt, int* new_element_dev,
+                          const int* new_process_dev, pp_comm* comm, int n_new,
+                          const int* new_elems_dev, const void* const* new_info_dev,
+                          const int* gid2lid_dev, int64_t ngids, const pp_mesh* mesh, int nmaps,
+                          const int* const* v2v_dev, double* const* scatter_w_dev, double rmax,
+                          int gnr, int gppr) {
+  PP_REQUIRE(comm, "pp_ps_migrate: null communicator");
+  PP_REQUIRE(comm->kind != 4 || comm->nranks == 1,
+             "pp_ps_migrate: a local communicator needs pp_ps_migrate_begin on every virtual rank, then "
+             "pp_ps_migrate_end on every virtual rank");
+  int rc = pp_ps_migrate_begin(ps, m_x, m_xtgt, new_element_dev, new_process_dev, comm, n_new, new_elems_dev,
+                               new_info_dev, gid2lid_dev, ngids, mesh, nmaps, v2v_dev, scatter_w_dev, rmax, gnr,
+                               gppr);
+  if (rc) return rc;
+  return pp_ps_migrate_end(ps, comm, nullptr, nullptr);
+}
+
+int pp_ps_migrate(pp_ps* ps, int* new_element_dev, const int* new_process_dev, pp_comm* comm) {
+  return pp_ps_migrate_scatter(ps, -1, -1, new_element_dev, new_process_dev, comm, 0, nullptr, nullptr, nullptr,
+                               0, nullptr, 0, nullptr, nullptr, 0.0, 2, 1);
 }
 
 int pp_set_unsafe_procs(const pp_ps* ps, const int* elems_dev, const unsigned char* safe_dev,
@@ -350,12 +611,9 @@ int pp_ps_migrate_count(const pp_ps* ps, const int* new_element_dev, const int* 
   hipStream_t st = pp::stream();
   pp::DevBuf& cnt = scratch(3);
   PP_HIP_CHECK(cnt.reserve(sizeof(int) * (size_t)nranks));
-  PP_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(int) * (size_t)nranks, st));
-  if (ps->num_ptcls > 0 && ps->capacity > 0)
-    k_send_count<<<grid_for(ps->capacity), kBlock, 0, st>>>(
-        ps->capacity, ps->d_mask.as<unsigned char>(), new_element_dev, new_process_dev, comm_rank,
-        nranks, cnt.as<int>());
-  PP_LAUNCH_CHECK();
+  int per_block = 0;
+  int rc = route_count(ps, new_element_dev, new_process_dev, comm_rank, nranks, cnt.as<int>(), &per_block);
+  if (rc) return rc;
   PP_HIP_CHECK(hipMemcpyAsync(send_counts_host, cnt.p, sizeof(int) * (size_t)nranks,
                               hipMemcpyDeviceToHost, st));
   PP_HIP_CHECK(hipStreamSynchronize(st));

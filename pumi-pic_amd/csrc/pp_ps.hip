@@ -1578,6 +1578,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   // not fit (or the chunk height changes, or the input is invalid), which turns the tail into
   // no-ops.  The sync then happens once, after everything is queued.
   bool speculated = false;
+  const int64_t swap_stride_before = ps->swap_stride;  // the speculative tail re-labels the swap buffers
   static const bool no_spec = getenv("PP_NO_SPEC_REBUILD") != nullptr;
   if (!no_spec && have_old && old_grid > 0) {
     long long cap_lim = std::min<long long>((long long)ps->s_mask2.bytes, (long long)(ps->s_slot2.bytes / 4));
@@ -1625,17 +1626,23 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   PP_HIP_CHECK(hipEventSynchronize(ev_tot));  // the only host wait of a regular rebuild
   Totals h = *h_pin;
   if (h.invalid) {
+    ps->swap_stride = swap_stride_before;
     pp::set_error(
         "rebuild: a particle's new element is out of range, or a new particle is marked inactive "
         "(element id -1) -- the reference exits here (SCS_rebuild.h:147-151)");
     return PP_EINVAL;
   }
-  if (h.active == 0) {  // SCS_rebuild.h:168-182 (mask left untouched like the reference)
+  if (h.active == 0) {  // SCS_rebuild.h:168-182: no particle left -- resetMask, structure kept
+    ps->swap_stride = swap_stride_before;
     // the fused commit still happens: the drivers call updatePtclPositions before the rebuild
     if (commit_x >= 0 && commit_xt >= 0 && ps->num_ptcls > 0) {
       rc = pp_update_positions(ps, commit_x, commit_xt);
       if (rc) return rc;
     }
+    if (ps->capacity > 0) PP_HIP_CHECK(hipMemsetAsync(ps->d_mask.p, 0, (size_t)ps->capacity, st));
+    ps->d_elem_count.swap(ps->s_ppe);  // the histogram just built: all zeros
+    ps->elem_count_valid = true;
+    ps->version = pp::next_version();
     ps->num_ptcls = 0;
     return PP_OK;
   }

@@ -1,7 +1,40 @@
 // pp_runtime.hip -- device selection, stream, memory and event helpers of the C-ABI.
+#include <dlfcn.h>
 #include "pp_internal.hpp"
 
 namespace pp {
+// roctx ranges (the reference's Kokkos::Profiling::pushRegion / popRegion, e.g. adjacency.tpp:480,613).
+// Resolved at run time and only when PP_ROCTX=1: rocprofv3 --marker-trace reads the ranges of
+// librocprofiler-sdk-roctx (older tools: libroctx64).
+static int (*g_roctx_push)(const char*) = nullptr;
+static int (*g_roctx_pop)() = nullptr;
+static bool roctx_ready() {
+  static int state = -1;
+  if (state >= 0) return state == 1;
+  state = 0;
+  const char* on = getenv("PP_ROCTX");
+  if (!on || atoi(on) == 0) return false;
+  const char* names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4",
+                         "libroctx64.so"};
+  for (const char* n : names) {
+    void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) continue;
+    g_roctx_push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+    g_roctx_pop = (int (*)())dlsym(h, "roctxRangePop");
+    if (g_roctx_push && g_roctx_pop) {
+      state = 1;
+      return true;
+    }
+  }
+  return false;
+}
+void range_push(const char* name) {
+  if (roctx_ready()) (void)g_roctx_push(name);
+}
+void range_pop() {
+  if (roctx_ready()) (void)g_roctx_pop();
+}
+
 static thread_local std::string g_err;
 static hipStream_t g_stream = nullptr;
 static bool g_init = false;
@@ -94,6 +127,15 @@ float pp_event_elapsed_ms(void* start, void* stop) {
 }
 int pp_event_destroy(void* ev) {
   if (ev) PP_HIP_CHECK(hipEventDestroy((hipEvent_t)ev));
+  return PP_OK;
+}
+
+int pp_range_push(const char* name) {
+  pp::range_push(name ? name : "");
+  return PP_OK;
+}
+int pp_range_pop(void) {
+  pp::range_pop();
   return PP_OK;
 }
 

@@ -191,9 +191,34 @@ struct TeamPolicy {
 inline TeamPolicy TeamPolicyAuto(int league_size, int team_size) {  // team_policy.hpp:4-11
   return TeamPolicy(league_size, team_size < 64 ? 64 : team_size);  // wave64: C = 64
 }
-struct Distributor {  // support/psDistributor.hpp:10-40 (single-rank form)
-  int nranks = 1;
-  int num_ranks() const { return nranks; }
+// The process-wide communicator (MPI_COMM_WORLD of the reference): created on first use from the
+// launcher's environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT, PP_COMM=rccl|tcp); a
+// single-rank communicator when the program was started without a launcher.
+inline pp_comm* comm_world() {
+  static pp_comm* c = nullptr;
+  if (!c) {
+    c = pp_comm_create_env();
+    if (!c) pp_check(PP_EHIP, "pp_comm_create_env");
+  }
+  return c;
+}
+// support/psDistributor.hpp:10-138.  The reference's Distributor names an MPI communicator and,
+// optionally, the subset of ranks a structure exchanges with; the exchange here is one grouped
+// send/recv per peer with a non-zero count, so the rank subset needs no separate code path: only
+// the world form (isWorld() == true) is kept, over a pp_comm.
+class Distributor {
+ public:
+  Distributor() : comm_(nullptr) {}
+  explicit Distributor(pp_comm* c) : comm_(c) {}
+  pp_comm* comm() const { return comm_ ? comm_ : comm_world(); }
+  bool isWorld() const { return true; }
+  int num_ranks() const { return pp_comm_size(comm()); }
+  int rank_host(int i) const { return i; }
+  PP_INLINE int rank(int i) const { return i; }
+  PP_INLINE int index(int process) const { return process; }
+
+ private:
+  pp_comm* comm_;
 };
 
 enum PaddingStrategy { PAD_EVENLY = 0, PAD_PROPORTIONALLY = 1, PAD_INVERSELY = 2 };
@@ -235,16 +260,16 @@ class ParticleStructure {
                            new_particle_elements.data(), (const void* const*)new_particle_info),
              "ParticleStructure::rebuild");
   }
+  // SellCSigma::migrate / CSR::migrate (scs/SCS_migrate.h:5-222): particles whose new_process is
+  // another rank are packed, exchanged over the distributor's communicator and enter the
+  // receiver's rebuild as new particles; one rank -> plain rebuild (:20-25)
   virtual void migrate(kkLidView new_element, kkLidView new_process, Distributor dist = Distributor(),
                        kkLidView new_particle_elements = kkLidView(), MTVs new_particle_info = NULL) {
-    (void)new_process;
-    if (dist.num_ranks() == 1) {  // SCS_migrate.h:20-25: serial -> rebuild
-      rebuild(new_element, new_particle_elements, new_particle_info);
-      return;
-    }
-    fprintf(stderr, "migrate across ranks is driven through pp_ps_migrate_count/pack + RCCL "
-                    "(see INTEGRATION.md); not available from this single-process header\n");
-    exit(EXIT_FAILURE);
+    pp_check(pp_ps_migrate_scatter(h_, -1, -1, new_element.data(), new_process.data(), dist.comm(),
+                                   (int)new_particle_elements.size(), new_particle_elements.data(),
+                                   (const void* const*)new_particle_info, nullptr, 0, nullptr, 0, nullptr,
+                                   nullptr, 0.0, 2, 1),
+             "ParticleStructure::migrate");
   }
   virtual void printMetrics() const {
     const pp_ps_info_t i = info();

@@ -1,0 +1,143 @@
+"""CPU-only, world size 2-3: the host logic of pp_ps_migrate / pp_allreduce_sum that needs no GPU --
+the id broadcast (pp_bootstrap_broadcast), the count exchange (PS_Comm_Ialltoall, SCS_migrate.h:48),
+the offsets both sides derive from the counts (pp_migrate_plan, SCS_migrate.h:66-72,129-133) and the
+host collectives of the built-in TCP transport and of a caller-supplied transport (gloo through
+ctypes callbacks, the way an MPI build would plug MPI in).  The device side of the same calls is
+covered by the -m gpu tests (local communicator with virtual ranks, two processes on one GPU)."""
+import multiprocessing as mp
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _expected_counts(world):
+    """send[r][q]: particles rank r sends to rank q (diagonal ignored by the protocol)"""
+    rng = np.random.default_rng(11)
+    m = rng.integers(0, 50, size=(world, world)).astype(np.int32)
+    m[0, world - 1] = 0  # an empty pair
+    return m
+
+
+def _tcp_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        import pumipic_amd_loader
+        pumipic_amd_loader.load()
+        from pumipic_amd import capi
+        L = capi.lib()
+        # 1. the id broadcast
+        import ctypes as C
+        payload = (C.c_ubyte * 128)()
+        if rank == 0:
+            for i in range(128):
+                payload[i] = (7 * i + 3) % 251
+        capi.check(L.pp_bootstrap_broadcast(b"127.0.0.1", port, rank, world, payload, 128))
+        assert bytes(payload) == bytes((7 * i + 3) % 251 for i in range(128))
+        # 2. a TCP communicator: counts, plan, host all-reduce, barrier
+        comm = capi.Comm.tcp("127.0.0.1", port + 1, rank, world)
+        assert comm.kind() == "tcp" and comm.rank() == rank and comm.size() == world
+        m = _expected_counts(world)
+        recv = comm.exchange_counts(m[rank])
+        want = m[:, rank].copy()
+        assert np.array_equal(recv, want), (recv, want)
+        sd, rd, ns, nr = capi.migrate_plan(world, rank, m[rank], recv)
+        others = [r for r in range(world) if r != rank]
+        assert ns == int(m[rank, others].sum()) and nr == int(m[others, rank].sum())
+        run_s = run_r = 0
+        for r in range(world):
+            assert sd[r] == run_s and rd[r] == run_r
+            if r != rank:
+                run_s += m[rank, r]
+                run_r += m[r, rank]
+        tot = comm.allreduce_sum_host([rank + 1, 10 * (rank + 1)])
+        assert list(tot) == [sum(range(1, world + 1)), 10 * sum(range(1, world + 1))]
+        comm.barrier()
+        comm.destroy()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL " + repr(e) + traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tcp_transport_host_logic(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tcp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert all(r[1] == "ok" for r in res), res
+
+
+def _gloo_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch.distributed as dist
+        import pumipic_amd_loader
+        pumipic_amd_loader.load()
+        from pumipic_amd import capi
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        comm = capi.Comm.torch()
+        assert comm.kind() == "host"
+        m = _expected_counts(world)
+        recv = comm.exchange_counts(m[rank])
+        assert np.array_equal(recv, m[:, rank])
+        tot = comm.allreduce_sum_host([rank + 5])
+        assert int(tot[0]) == sum(r + 5 for r in range(world))
+        comm.barrier()
+        comm.destroy()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL " + repr(e) + traceback.format_exc()))
+
+
+def test_host_transport_over_gloo_callbacks():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert all(r[1] == "ok" for r in res), res
+
+
+def test_migrate_plan_rejects_bad_input(pp):
+    from pumipic_amd import capi
+    capi.build()
+    with pytest.raises(capi.PPError):
+        capi.migrate_plan(2, 0, [0, -1], [0, 0])
+    sd, rd, ns, nr = capi.migrate_plan(1, 0, [9], [9])
+    assert ns == 0 and nr == 0  # a rank keeps its own particles
+
+
+def test_single_rank_env_communicator(pp, monkeypatch):
+    from pumipic_amd import capi
+    capi.build()
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    c = capi.Comm.env()
+    assert c.kind() == "self" and c.size() == 1 and c.rank() == 0
+    assert list(c.exchange_counts([4])) == [4]
+    c.destroy()

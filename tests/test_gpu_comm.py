@@ -1,0 +1,317 @@
+"""-m gpu: the multi-rank path behind the C-ABI (pp_comm_*, pp_ps_migrate*, pp_allreduce_sum).
+
+A 1-GPU box cannot form a >1-rank RCCL job (RCCL refuses two ranks on one device), so the
+multi-rank behaviour is covered three ways:
+  * `local` communicator: 2-3 virtual ranks in one process through pp_ps_migrate_begin / _end,
+  * TWO PROCESSES sharing the GPU, exchanging through the built-in TCP transport and through a
+    caller-supplied transport (gloo callbacks) -- the same pp_ps_migrate_scatter entry point, the
+    same pack / unpack / rebuild kernels, only the byte mover differs from the RCCL path,
+  * RCCL itself with one rank (library resolution, communicator creation, all-gather of the
+    counts, in-place all-reduce, stream ordering).
+Every run is compared particle by particle with the single-structure CPU oracle run."""
+import multiprocessing as mp
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import common
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+H, K, D = 1.72479370 - .08, .020558260, 0.6
+NSTEPS = 5
+
+
+@pytest.fixture(scope="module")
+def capi(pp):
+    from pumipic_amd import capi as c
+    c.build()
+    c.init(0)
+    return c
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _population(synth, dim):
+    if dim == 2:
+        return common.population_2d(synth, n_b=12, n_theta=48, num_ptcls=3000, mdl_face=3, band_width=3)
+    return common.population_3d(synth, num_ptcls=3000)
+
+
+def _rank_structure(capi, pop, owners, r):
+    ne = len(pop["e2v"])
+    mine = owners[pop["elem"]] == r
+    elem = pop["elem"][mine]
+    info = [np.ascontiguousarray(a[..., mine]) for a in pop["info"]]
+    return capi.PS.scs(capi.PARTICLE_XGCM, ne, np.bincount(elem, minlength=ne).astype(np.int32),
+                       gids=np.arange(ne, dtype=np.int64), particle_elements=elem, particle_info=info)
+
+
+def _oracle_run(ppo, pop, nsteps, deg=6.0):
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    maps = ppo.create_gyro_ring_mappings(mo, trig=1)
+    fields = []
+    for _ in range(nsteps):
+        if pop["dim"] == 2:
+            ppo.elliptical_push(po, mo, H, K, D, deg, trig=1)
+            _, ids, _ = ppo.search_mesh_2d(mo, po, looplimit=200)
+        else:
+            ppo.toroidal_push(po, mo, H, K, D, deg, trig=1)
+            ids = ppo.search_mesh(mo, po, looplimit=200)["elem_ids"]
+        ppo.update_positions(po)
+        po.rebuild(ids)
+        fields.append((ppo.gyro_scatter(mo, po, maps[0]), ppo.gyro_scatter(mo, po, maps[1])))
+    so, mko = po.slot_info()
+    cap = po.capacity()
+    io, eo = common.by_id(po.member(2)[0, :cap], mko, so)
+    _, xo = common.by_id(po.member(2)[0, :cap], mko, po.member(0)[:, :cap])
+    _, pho = common.by_id(po.member(2)[0, :cap], mko, po.member(4)[0, :cap])
+    return io, eo, xo, pho, fields
+
+
+def _snapshot(ps):
+    se, mk = ps.slot_info()
+    cap = ps.capacity()
+    live = mk.astype(bool)
+    return (ps.member(2)[0, :cap][live], se[live], ps.member(0)[:, :cap][:, live],
+            ps.member(4)[0, :cap][live])
+
+
+def _check_union(snaps, owners, ref):
+    io, eo, xo, pho, _ = ref
+    ids = np.concatenate([s[0] for s in snaps])
+    order = np.argsort(ids)
+    assert np.array_equal(ids[order], io)                                   # nobody lost / duplicated
+    assert np.array_equal(np.concatenate([s[1] for s in snaps])[order], eo)  # element ids bit-exact
+    assert np.array_equal(np.concatenate([s[2] for s in snaps], axis=1)[:, order], xo)
+    assert np.array_equal(np.concatenate([s[3] for s in snaps])[order], pho)
+    for r, s in enumerate(snaps):
+        assert np.all(owners[s[1]] == r)  # every rank holds only elements it owns
+
+
+def _step(capi, mesh, ps, dim, deg, ids):
+    if dim == 2:
+        ids.fill_bytes(0xff)
+        capi.push_search(mesh, ps, H, K, D, deg, ids, seeded=True, looplimit=200)
+    else:
+        capi.push_search(mesh, ps, H, K, D, deg, ids, seeded=False, looplimit=200)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("fused", [False, True])
+def test_migrate_local_virtual_ranks(ppo, synth, capi, dim, world, fused):
+    """pp_ps_migrate_begin / _end on a `local` communicator: element-block virtual ranks of one
+    process; union of the ranks == the single-structure oracle run, and the all-reduced scatter
+    fields == the oracle's (gyroSync)."""
+    pop = _population(synth, dim)
+    ne = len(pop["e2v"])
+    owners = (np.arange(ne) * world // ne).astype(np.int32)
+    mesh = capi.Mesh(dim, pop["coords"], pop["e2v"], pop["cls"])
+    ref = _oracle_run(ppo, pop, NSTEPS)
+    comms = capi.Comm.local(world)
+    assert [c.kind() for c in comms] == ["local"] * world
+    ranks = [_rank_structure(capi, pop, owners, r) for r in range(world)]
+    owners_d = capi.DevArray.from_host(owners)
+    safes = [capi.DevArray.from_host((owners == r).astype(np.uint8)) for r in range(world)]
+    fg, bg = capi.create_gyro_ring_mappings(mesh)
+    moved = 0
+    for step in range(NSTEPS):
+        routes, fields = [], []
+        for r, ps in enumerate(ranks):
+            ids = capi.DevArray.from_host(np.full(max(ps.capacity(), 1), -1, dtype=np.int32))
+            _step(capi, mesh, ps, dim, 6.0, ids)
+            if not fused:
+                capi.update_positions(ps)
+            ne_d, np_d = capi.set_unsafe_procs(ps, ids, safes[r], owners_d, r)
+            wf, wb = capi.DevArray(mesh.nverts, np.float64), capi.DevArray(mesh.nverts, np.float64)
+            capi.migrate_begin(ps, ne_d, np_d, comms[r], commit=fused,
+                               scatter=(mesh, [fg, bg], [wf, wb]) if fused else None)
+            routes.append((ne_d, np_d))
+            fields.append((wf, wb))
+        for r, ps in enumerate(ranks):
+            ns, nr = capi.migrate_end(ps, comms[r])
+            moved += ns
+        if fused:  # gyroSync: pack both fields, SUM over the virtual ranks
+            packed = [capi.gyro_sync_pack(mesh.nverts, wf, wb) for wf, wb in fields]
+            for r in range(world):
+                comms[r].allreduce_sum(packed[r])
+            fo, bo = ref[4][step]
+            for r in range(world):
+                got = packed[r].to_host()
+                assert np.array_equal(got[0::2], fo) and np.array_equal(got[1::2], bo)
+    assert moved > 0
+    _check_union([_snapshot(ps) for ps in ranks], owners, ref)
+    with pytest.raises(capi.PPError):  # one-call form needs every virtual rank to begin first
+        capi.migrate(ranks[0], routes[0][0], routes[0][1], comms[0])
+    for c in comms:
+        c.destroy()
+
+
+def test_migrate_new_particles_ride_along(ppo, synth, capi):
+    """the caller's own new particles (new_particle_elements / new_particle_info of
+    SellCSigma::migrate, SCS_migrate.h:198-206) enter the same rebuild as the received ones"""
+    pop = _population(synth, 2)
+    ne = len(pop["e2v"])
+    world = 2
+    owners = (np.arange(ne) * world // ne).astype(np.int32)
+    comms = capi.Comm.local(world)
+    ranks = [_rank_structure(capi, pop, owners, r) for r in range(world)]
+    before = [ps.nPtcls() for ps in ranks]
+    added = []
+    for r, ps in enumerate(ranks):
+        cap = max(ps.capacity(), 1)
+        se, mk = ps.slot_info()
+        ne_h = np.where(mk.astype(bool), se, -1).astype(np.int32)
+        # route the first 7 live particles of rank r to the other rank (into an element it owns)
+        live = np.flatnonzero(mk)[:7]
+        tgt = int(np.flatnonzero(owners == 1 - r)[3])
+        ne_h[live] = tgt
+        np_h = np.full(cap, r, dtype=np.int32)
+        np_h[live] = 1 - r
+        own = int(np.flatnonzero(owners == r)[5])
+        k = 4 + r
+        info = [np.full((3, k), 0.25 + r), np.zeros((3, k)), np.arange(10**6 + 100 * r, 10**6 + 100 * r + k,
+                                                                     dtype=np.int32),
+                np.full(k, 0.5, np.float32), np.full(k, 0.125, np.float32)]
+        added.append((own, k, info[2]))
+        capi.migrate_begin(ps, capi.DevArray.from_host(ne_h), capi.DevArray.from_host(np_h), comms[r],
+                           new_particles=(np.full(k, own, np.int32), info))
+    for r, ps in enumerate(ranks):
+        ns, nr = capi.migrate_end(ps, comms[r])
+        assert ns == 7 and nr == 7
+    for r, ps in enumerate(ranks):
+        own, k, ids = added[r]
+        assert ps.nPtcls() == before[r] + k
+        pid, se, x, _ = _snapshot(ps)
+        sel = np.isin(pid, ids)
+        assert sel.sum() == k and np.all(se[sel] == own) and np.all(x[:, sel] == 0.25 + r)
+        tgt = int(np.flatnonzero(owners == r)[3])
+        assert (se == tgt).sum() >= 7
+    for c in comms:
+        c.destroy()
+
+
+def test_rccl_single_rank(ppo, synth, capi):
+    """RCCL behind the C-ABI with one rank: the library opens librccl, forms a communicator from
+    its own unique id, and the collectives run on the library stream."""
+    uid = capi.Comm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = capi.Comm.rccl(uid, 0, 1)
+    assert comm.kind() == "rccl" and comm.size() == 1
+    v = np.arange(1000, dtype=np.float64) / 8
+    d = capi.DevArray.from_host(v)
+    comm.allreduce_sum(d)
+    assert np.array_equal(d.to_host(), v)
+    assert list(comm.allreduce_sum_host([3, 4])) == [3, 4]
+    assert list(comm.exchange_counts([5])) == [5]
+    comm.barrier()
+    # migrate on one rank == rebuild (SCS_migrate.h:20-25), with commit + scatter folded in
+    pop = _population(synth, 3)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
+    fo, bo = ppo.create_gyro_ring_mappings(mo, trig=1)
+    fg, bg = capi.create_gyro_ring_mappings(mg)
+    ne = len(pop["e2v"])
+    owners = capi.DevArray.from_host(np.zeros(ne, np.int32))
+    safe = capi.DevArray.from_host(np.ones(ne, np.uint8))
+    for _ in range(3):
+        ppo.toroidal_push(po, mo, H, K, D, 6.0, trig=1)
+        ids_o = ppo.search_mesh(mo, po, looplimit=200)["elem_ids"]
+        ppo.update_positions(po)
+        po.rebuild(ids_o)
+        ids = capi.DevArray(max(pg.capacity(), 1), np.int32)
+        capi.push_search(mg, pg, H, K, D, 6.0, ids, seeded=False, looplimit=200)
+        ne_d, np_d = capi.set_unsafe_procs(pg, ids, safe, owners, 0)
+        wf, wb = capi.DevArray(mg.nverts, np.float64), capi.DevArray(mg.nverts, np.float64)
+        capi.migrate(pg, ne_d, np_d, comm, commit=True, scatter=(mg, [fg, bg], [wf, wb]))
+        assert np.array_equal(wf.to_host(), ppo.gyro_scatter(mo, po, fo))
+        assert np.array_equal(wb.to_host(), ppo.gyro_scatter(mo, po, bo))
+    so, mko = po.slot_info()
+    io, eo = common.by_id(po.member(2)[0, :po.capacity()], mko, so)
+    pid, se, x, _ = _snapshot(pg)
+    order = np.argsort(pid)
+    assert np.array_equal(pid[order], io) and np.array_equal(se[order], eo)
+    comm.destroy()
+
+
+# ---------------------------------------------------------------- two processes, one GPU
+def _proc_worker(rank, world, port, transport, dim, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import pumipic_amd_loader
+        pp = pumipic_amd_loader.load()
+        from pumipic_amd import capi
+        capi.init(0)  # both ranks on device 0
+        if transport == "gloo":
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ["MASTER_PORT"] = str(port)
+            import torch.distributed as dist
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            comm = capi.Comm.torch()
+        elif transport == "env-tcp":
+            os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                              MASTER_PORT=str(port), PP_COMM="tcp")
+            comm = capi.Comm.env()
+        else:
+            comm = capi.Comm.tcp("127.0.0.1", port, rank, world)
+        pop = _population(pp.synth, dim)
+        ne = len(pop["e2v"])
+        owners = (np.arange(ne) * world // ne).astype(np.int32)
+        mesh = capi.Mesh(dim, pop["coords"], pop["e2v"], pop["cls"])
+        ps = _rank_structure(capi, pop, owners, rank)
+        owners_d = capi.DevArray.from_host(owners)
+        safe = capi.DevArray.from_host((owners == rank).astype(np.uint8))
+        fg, bg = capi.create_gyro_ring_mappings(mesh)
+        wf, wb = capi.DevArray(mesh.nverts, np.float64), capi.DevArray(mesh.nverts, np.float64)
+        fields = []
+        for _ in range(NSTEPS):
+            ids = capi.DevArray.from_host(np.full(max(ps.capacity(), 1), -1, dtype=np.int32))
+            _step(capi, mesh, ps, dim, 6.0, ids)
+            ne_d, np_d = capi.set_unsafe_procs(ps, ids, safe, owners_d, rank)
+            capi.migrate(ps, ne_d, np_d, comm, commit=True, scatter=(mesh, [fg, bg], [wf, wb]))
+            packed = capi.gyro_sync_pack(mesh.nverts, wf, wb)
+            comm.allreduce_sum(packed)
+            fields.append(packed.to_host())
+        total = int(comm.allreduce_sum_host([ps.nPtcls()])[0])
+        comm.barrier()
+        q.put((rank, "ok", _snapshot(ps), fields, total))
+        comm.destroy()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL " + repr(e) + traceback.format_exc(), None, None, None))
+
+
+@pytest.mark.parametrize("transport,dim", [("tcp", 2), ("tcp", 3), ("gloo", 2), ("env-tcp", 3)])
+def test_two_processes_share_one_gpu(ppo, synth, capi, transport, dim):
+    """Two rank PROCESSES on one GPU run the c5 step through pp_ps_migrate_scatter +
+    pp_allreduce_sum over a host-staged transport; union == single-structure oracle run."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_proc_worker, args=(r, world, port, transport, dim, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), [r[1] for r in res]
+    pop = _population(synth, dim)
+    ne = len(pop["e2v"])
+    owners = (np.arange(ne) * world // ne).astype(np.int32)
+    ref = _oracle_run(ppo, pop, NSTEPS)
+    _check_union([r[2] for r in res], owners, ref)
+    for r in res:
+        assert r[4] == len(ref[0])
+        for step in range(NSTEPS):
+            fo, bo = ref[4][step]
+            assert np.array_equal(r[3][step][0::2], fo) and np.array_equal(r[3][step][1::2], bo)
