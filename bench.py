@@ -669,6 +669,10 @@ def main():
             "parallelism": "element-block partition, %d rank(s), full-mesh replica" % world}
         if a.workload == "c5":
             out["rank0_sent_per_step"] = st.moved / max(1, st.steps_done)
+        if full_step:
+            ip, fl, rm = w["ps"].rebuild_stats()
+            out["rebuilds"] = {"kept_layout": ip, "full_relayout": fl, "rows_traded": rm,
+                               "note": "how the structure's rebuilds ended (warm-up and cold-clock steps included)"}
         out["roofline"] = roof
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pp, w, a.workload, a.deg, min(a.cpu_sample, a.particles),

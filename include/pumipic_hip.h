@@ -141,8 +141,8 @@ int pp_ps_member_to_host(pp_ps* ps, int m, void* out_host);   /* [ncomp][stride]
 int pp_ps_member_from_host(pp_ps* ps, int m, const void* in_host);
 /* rebuild(new_element, new_particle_elements, new_particle_info) scs/SCS_rebuild.h:122-314,
  * csr/CSR_rebuild.hpp:18-118.  new_element_dev has capacity entries (-1 = delete).
- * new_info_dev[m] is a DEVICE array [ncomp][n_new].  Always a full counting-sort re-layout
- * (the reference's in-place reshuffle fast path is not observable through id-keyed results). */
+ * new_info_dev[m] is a DEVICE array [ncomp][n_new].  In place when the layout can be kept
+ * (pp_ps_set_shuffling), else the full counting-sort re-layout. */
 int pp_ps_rebuild(pp_ps* ps, const int* new_element_dev, int n_new, const int* new_elems_dev,
                   const void* const* new_info_dev);
 /* updatePtclPositions (test/pseudoXGCm.cpp:102-114: x <- x_tgt, x_tgt <- 0) fused into the
@@ -159,6 +159,26 @@ int pp_ps_rebuild_scatter(pp_ps* ps, int m_x, int m_xtgt, const int* new_element
                           const int* new_elems_dev, const void* const* new_info_dev,
                           const pp_mesh* mesh, int nmaps, const int* const* v2v_dev,
                           double* const* scatter_w_dev, double rmax, int gnr, int gppr);
+/* SellCSigma::setShuffling scs/SellCSigma.h:92 (default on, :236).  mode:
+ *   0  never in place (setShuffling(false)): every rebuild is the full counting-sort re-layout;
+ *   1  (default) the reference's decision (SCS_rebuild.h:33-42,160-189): the layout is kept iff every
+ *      row's new count fits its chunk width; then only the particles that change element move
+ *      (reshuffle, SCS_rebuild.h:4-119).  offsets / slice_to_chunk / row_to_element / element_to_row
+ *      equal the reference's after every rebuild.  The decision is evaluated on the histogram the
+ *      full re-layout needs anyway, so it costs nothing when the layout cannot be kept -- at 10^5 rows
+ *      some row overflows its padding in nearly every step (measured: 600-2500 rows per pseudoXGCm
+ *      step), so large structures practically always take the full re-layout, as the reference does;
+ *   2  elastic (experimental, this library's extension): a row that would overflow trades places with
+ *      a row of a wider chunk whose occupant fits the narrower one, or moves into a chunk appended
+ *      behind the last one (its old row becomes a padding row); the full re-layout runs only when the
+ *      allocation's headroom is used up.  Same particles per element as the other modes; row order
+ *      and capacity differ from the reference's.  Measured slower than the full re-layout on the
+ *      pseudoXGCm step: scattered 4/8-byte stores into a SoA layout cost ~35 ps each.
+ * Rows stay prefix-compact in every mode (a shrinking row back-fills its holes from its own tail). */
+int pp_ps_set_shuffling(pp_ps* ps, int mode);
+/* how the rebuilds of this structure ended so far: kept layout / full re-layout; rows that traded
+ * places (mode 2) */
+int pp_ps_rebuild_stats(const pp_ps* ps, long long* n_in_place, long long* n_full, long long* n_rows_moved);
 /* getPIDs ps_for.hpp:65-85: offsets_dev[ne+1], pids_dev[nPtcls] */
 int pp_ps_get_pids(const pp_ps* ps, int* offsets_dev, int* pids_dev);
 /* printMetrics SellCSigma.h:465-524 */

@@ -85,6 +85,8 @@ SYMBOLS = {
     "pp_ps_rebuild": (_I, [_V, _V, _I, _V, _V]),
     "pp_ps_rebuild_commit": (_I, [_V, _I, _I, _V, _I, _V, _V]),
     "pp_ps_get_pids": (_I, [_V, _V, _V]),
+    "pp_ps_set_shuffling": (_I, [_V, _I]),
+    "pp_ps_rebuild_stats": (_I, [_V, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "pp_ps_metrics": (_I, [_V, c_int_p, c_int_p, c_int_p]),
     "pp_ps_swap_members": (_I, [_V, _I, _I]),
     "pp_elliptical_setup": (_I, [_V, _I, _I, _I, _D, _D, _D]),
@@ -436,6 +438,16 @@ class PS:
         ne = new_element if isinstance(new_element, DevArray) else DevArray.from_host(
             np.ascontiguousarray(new_element, dtype=np.int32))
         check(lib().pp_ps_rebuild_commit(self.p, m_x, m_xtgt, ne.ptr, 0, None, None))
+
+    def set_try_shuffling(self, v):
+        """False / 0: never in place; True / 1: the reference's reshuffle decision; 2: elastic (default)"""
+        check(lib().pp_ps_set_shuffling(self.p, int(v)))
+
+    def rebuild_stats(self):
+        """(rebuilds that kept the layout, full re-layouts, rows that traded places)"""
+        a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()
+        check(lib().pp_ps_rebuild_stats(self.p, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def get_pids(self):
         i = self.info()
@@ -1039,7 +1051,7 @@ def migrate_begin(ps, new_elems, new_procs, comm, commit=False, scatter=None, ne
     args, keep = _migrate_args(ps, new_elems, new_procs, comm, commit, scatter, new_particles, gid2lid, rmax,
                                gnr, gppr, m_x, m_xtgt)
     check(lib().pp_ps_migrate_begin(*args))
-    comm._pending_keep = keep  # buffers the end phase still reads
+    comm._pending_keep = (keep, new_elems, new_procs)  # buffers the end phase still reads
 
 
 def migrate_end(ps, comm):

@@ -72,6 +72,7 @@ __global__ void k_interp3d_field(int capacity, const unsigned char* __restrict__
 }
 
 int xmember(const pp_ps* ps, int m_x, const char* what, const double** x) {
+  if (int rc = pp::ps_ready(ps)) return rc;
   if (m_x < 0 || m_x >= ps->nmembers) {
     pp::set_error(std::string(what) + ": member index out of range");
     return PP_EINVAL;

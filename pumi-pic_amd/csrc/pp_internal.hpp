@@ -179,6 +179,21 @@ struct pp_ps {
   unsigned long long version = 0;
   unsigned long long last_max_key = ~0ull;  // largest layout sort key of the previous rebuild (~0 = unknown)
   int tile_p = pp::kTileP;  // columns per tile (PP_TILE_P overrides, tuning knob)
+  // SellCSigma::tryShuffling (SellCSigma.h:92,213,236): a rebuild first tries to keep the layout and
+  // move only the particles that change element (SCS_rebuild.h:4-119)
+  // 0 = always the full re-layout (setShuffling(false)); 1 (default) = the reference's decision (in
+  // place iff every row fits); 2 = elastic (experimental): rows that overflow trade places with rows of
+  // wider chunks or move into chunks appended at the end, the full re-layout runs only when the
+  // allocation's headroom is used up
+  int shuffle_mode = 1;
+  int sorted_chunks = 0;  // chunks [0, sorted_chunks) are in the last full re-layout's (ascending-width) order
+  long long n_reshuffles = 0, n_full_rebuilds = 0, n_rows_moved = 0;  // how the rebuilds of this structure ended
+  pp::DevBuf d_eslot0;  // first slot of every element's row in the CURRENT layout
+  // a member whose content is logically all zero but has not been written yet (storage index, -1 =
+  // none): x_tgt after a fused updatePtclPositions of the in-place rebuild.  Cleared without a pass
+  // when the next fused push overwrites the member; any other access materialises the zeros first.
+  int zero_pending = -1;
+  pp::DevBuf s_rs, s_holes, s_rsx;  // in-place rebuild: per-element counters, per-row hole lists, elastic lists
   // scratch reused across rebuilds
   pp::DevBuf s_ppe, s_keys, s_keys2, s_vals, s_vals2, s_hist, s_chunkw, s_misc, s_rowstart,
       s_newidx, s_offsets2, s_s2c2, s_r2e2, s_e2r2, s_mask2, s_slot2, s_scan, s_cstart2, s_cwidth2, s_aos, s_idx, s_ranknew, s_eslot0, s_scan2;
@@ -248,6 +263,12 @@ struct Range {
 }  // namespace pp
 
 namespace pp {
+// pp_ps.hip: write the zeros of a member that is only logically zero (pp_ps::zero_pending); every
+// entry point that reads or exposes member data calls this first
+int ps_materialize(pp_ps* ps);
+inline int ps_ready(const pp_ps* ps) {
+  return (ps && ps->zero_pending >= 0) ? ps_materialize(const_cast<pp_ps*>(ps)) : PP_OK;
+}
 // pp_scatter.hip: gyroScatter for `nmaps` ring maps from an explicit per-element count array (the
 // histogram of a rebuild that is still in flight); forgets the ring accumulation kept for reuse.
 int gyro_scatter_counts(const pp_mesh* mesh, const int* cnt_dev, int nmaps, const int* const* v2v_dev,

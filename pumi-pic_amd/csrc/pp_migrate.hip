@@ -202,6 +202,7 @@ __global__ void k_route_pack(int capacity, int per_block, const unsigned char* _
 // commit_x / commit_xt >= 0: the record carries the particle AFTER updatePtclPositions (member
 // commit_x is read from commit_xt's arrays, member commit_xt travels as zeros)
 int build_rec_table(const pp_ps* ps, RecTable& t, int commit_x = -1, int commit_xt = -1) {
+  if (int rc = pp::ps_ready(ps)) return rc;
   int nw = 0;
   for (int m = 0; m < ps->nmembers; ++m) {
     const int s = ps->member_map[m == commit_x ? commit_xt : m];
@@ -633,6 +634,7 @@ int pp_ps_migrate_pack(const pp_ps* ps, int* new_element_dev, const int* new_pro
   }
   if (total == 0) return PP_OK;
   PP_REQUIRE(send_gid_dev && send_info_dev, "pp_ps_migrate_pack: null send buffers");
+  if (int rc = pp::ps_ready(ps)) return rc;
   hipStream_t st = pp::stream();
   pp::DevBuf& cur = scratch(0);
   PP_HIP_CHECK(cur.reserve(sizeof(int) * (size_t)nranks));

@@ -143,6 +143,12 @@ int64_t spread_stride(int64_t n) {
   while (s % 32 != 17) ++s;
   return s * 64;
 }
+// Slots allocated beyond the capacity so that the last chunk can widen in place (elastic mode of the
+// in-place rebuild): allocation only, the layout arrays do not see it.
+int64_t growth_reserve(const pp_ps* ps, int64_t cap) {
+  if (ps->shuffle_mode < 2) return 0;
+  return std::max<int64_t>(cap / 10, (int64_t)ps->C_max * 256);
+}
 int alloc_members(pp_ps* ps, std::vector<pp::DevBuf>& bufs, int64_t stride, bool zero) {
   bufs.resize((size_t)ps->nmembers);
   for (int m = 0; m < ps->nmembers; ++m) {
@@ -197,6 +203,10 @@ struct Totals {  // s_misc layout
   int go;  // speculative tail of the rebuild may run (k_spec_check); 1 on the checked path
   double cw_inv;
   unsigned long long max_key;  // largest sort key of this rebuild (radix passes above it are skipped)
+  // in-place rebuild: rows whose new count exceeds their chunk width, rows that traded places,
+  // "no home found for an overflowing row"
+  int n_over, n_moved, match_fail, pad_;
+  int dbg[8];  // the first row the elastic matching could not house (PP_SPEC_DEBUG)
 };
 
 __global__ void k_count_added(int n_new, const int* __restrict__ new_elems, int ne,
@@ -566,7 +576,11 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
 __global__ void k_spec_check_csr(Totals* tot, int expected) {
   tot->go = (!tot->invalid && tot->active == expected) ? 1 : 0;
 }
-__global__ void k_spec_check(Totals* tot, int cap_lim, int nsl_lim, int C_max, int key_bits) {
+__global__ void k_spec_check(Totals* tot, int cap_lim, int nsl_lim, int C_max, int key_bits, int keep_if_fits) {
+  if (keep_if_fits && tot->n_over == 0) {  // the reference keeps the layout here: no re-layout tail
+    tot->go = 0;
+    return;
+  }
   tot->go = (!tot->invalid && tot->active > 0 && tot->nonempty >= C_max && tot->capacity <= cap_lim &&
              tot->nslices <= nsl_lim && (key_bits >= 64 || (tot->max_key >> key_bits) == 0))
                 ? 1
@@ -600,6 +614,17 @@ __global__ void k_nonempty(int ne, const int* __restrict__ ppe, Totals* tot) {
       atomicAdd(&tot->active, sum);
     }
   }
+}
+// SellCSigma::reshuffle's test (SCS_rebuild.h:33-42) on the histogram the full re-layout needs anyway:
+// does every element's new count fit the width of the chunk its row lives in TODAY?  tot->n_over
+// counts the rows that do not (0 <=> the reference would keep the layout).
+__global__ void k_fit_check(int ne, int C, const int* __restrict__ ppe, const int* __restrict__ e2r,
+                            const int* __restrict__ chunk_width, Totals* tot) {
+  int over = 0;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x)
+    over += ppe[e] > chunk_width[e2r[e] / C];
+  for (int o = 32; o > 0; o >>= 1) over += __shfl_down(over, o);
+  if ((threadIdx.x & 63) == 0 && over) atomicAdd(&tot->n_over, over);
 }
 // single-block reduction of the chunk widths (sum, #non-zero) -- replaces one atomic per chunk
 __global__ void k_reduce_widths(int nchunks, const int* __restrict__ widths, Totals* tot) {
@@ -766,7 +791,7 @@ struct LayoutTablesArgs {
   const int* ntiles_dev;
   int nchunks, TP, C, V, nrows, ne, sorted;
   const int *tile_off, *widths, *slice_off, *chunk_start, *index;
-  int *tiles, *offsets, *s2c, *r2e, *e2r, *row_cursor;
+  int *tiles, *offsets, *s2c, *r2e, *e2r, *row_cursor, *eslot0;
   const Totals* tot;
 };
 __global__ void k_layout_tables(LayoutTablesArgs a) {
@@ -803,6 +828,7 @@ __global__ void k_layout_tables(LayoutTablesArgs a) {
       const int e = a.sorted ? a.index[i] : i;
       a.r2e[i] = e;
       a.e2r[e] = i;
+      a.eslot0[e] = a.chunk_start[i / a.C] + i % a.C;  // first slot of the element's row
     } else {
       a.r2e[i] = i;
       a.e2r[i] = i;
@@ -1215,6 +1241,608 @@ __global__ void k_pid_set(int capacity, const unsigned char* __restrict__ mask,
   }
 }
 
+
+// ------------------------------------------------------------------ in-place rebuild ("reshuffle")
+// The reference first tries to keep the layout (SCS_rebuild.h:4-119, decision :160-189): when every
+// row's arrivals fit into its holes -- new count <= chunk width -- offsets / slice_to_chunk /
+// row_to_element / element_to_row stay as they are and only the particles that change element move.
+// Same decision here; the data movement is this library's own.  Rows stay prefix-compact (the hot
+// kernels rely on it: a row's live slots are its first `count` columns), so a row that shrinks
+// back-fills the holes below its new count from its own tail:
+//   k_rs_count  thread = (run of <= 32 columns, row): arrivals per element (atomics that RETURN the
+//               arrival's rank), leavers per element, the movers' records packed to aos[slot]
+//   k_rs_fit    per element: new count = old - leavers + arrivals <= chunk width ?  totals, go flag
+//   k_rs_plan   per run: holes (columns below the new count that are empty or being left) are
+//               enumerated into the row's hole list, tail stayers (columns at or above the new count)
+//               get claim numbers behind the arrivals; new mask
+//   k_rs_move   claimant k of a row takes the row's k-th hole: movers from their staged record, tail
+//               stayers slot to slot (their source slots are nobody's target)
+// About 16 % of the particles move (8 % change element per pseudoXGCm step, as many again back-fill)
+// instead of every particle twice.
+struct RsCounters {  // one int array each, num_elems long, zeroed per rebuild (n_new lives in s_ppe)
+  int *arrive, *leave, *hole_cur, *tail_cur, *removed;
+};
+template <int NQ>
+__global__ void k_rs_count(const int* __restrict__ ntiles_dev, int C, int TP, int G,
+                           const int* __restrict__ tiles, const int* __restrict__ chunk_start,
+                           const int* __restrict__ chunk_width, const int* __restrict__ r2e,
+                           const int* __restrict__ n_old, const int* __restrict__ new_element, int ne,
+                           RsCounters cn, Totals* tot, int* __restrict__ rank, uint4* __restrict__ aos,
+                           WordTable t) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int grp = (int)(g / C), r = (int)(g - (long long)grp * C);
+  const int ntiles = *ntiles_dev;
+  int cur = -1, e = -1, start = 0, run_p0 = 0, nold = 0, nl = 0, nd = 0;
+  // movers of the run that share one of the first three destinations met leave as ONE atomic each
+  // (a row's particles cross into the few neighbours of its element, see k_count_tiled)
+  int key1 = -1, key2 = -1, key3 = -1;
+  unsigned m1 = 0, m2 = 0, m3 = 0;
+  auto flush_one = [&](int key, unsigned m) {
+    if (!m) return;
+    int idx = atomicAdd(&cn.arrive[key], __popc(m));
+    while (m) {
+      const int b = __ffs(m) - 1;
+      m &= m - 1;
+      rank[start + (run_p0 + b) * C] = idx++;
+    }
+  };
+  auto flush = [&]() {
+    flush_one(key1, m1);
+    flush_one(key2, m2);
+    flush_one(key3, m3);
+    if (nl) atomicAdd(&cn.leave[e], nl);
+    if (nd) atomicAdd(&cn.removed[e], nd);
+    m1 = m2 = m3 = 0;
+    key1 = key2 = key3 = -1;
+    nl = nd = 0;
+  };
+  for (int k = 0; k < G; ++k) {
+    const int tile = grp * G + k;
+    if (tile >= ntiles) break;
+    const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
+    if (c != cur) {
+      flush();
+      cur = c;
+      start = chunk_start[c] + r;
+      e = r2e[c * C + r];
+      nold = e < ne ? n_old[e] : 0;
+      run_p0 = p0;
+    }
+    const int pend = min(min(p0 + TP, chunk_width[c]), nold);  // live columns only
+    for (int pb = p0; pb < pend; pb += 8) {
+      int nel[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) nel[j] = (pb + j < pend) ? new_element[start + (pb + j) * C] : e;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ne_ = nel[j];
+        if (ne_ == e) continue;  // stays (or column past the live range)
+        ++nl;
+        if (ne_ == -1) {  // removed
+          ++nd;
+          continue;
+        }
+        if (ne_ < 0 || ne_ >= ne) {
+          tot->invalid = 1;
+          continue;
+        }
+        const int pid = start + (pb + j) * C;
+        {  // stage the mover: its slot may be another particle's target
+          unsigned v[NQ * 4];
+#pragma unroll
+          for (int i = 0; i < NQ * 4; ++i) v[i] = 0u;
+#pragma unroll
+          for (int i = 0; i < NQ * 2; ++i)
+            if (i < t.n8) {
+              const unsigned long long d = *(const unsigned long long*)(t.src8[i] + (long long)pid * 8);
+              v[2 * i] = (unsigned)d;
+              v[2 * i + 1] = (unsigned)(d >> 32);
+            }
+#pragma unroll
+          for (int i = 0; i < (NQ * 4 < kMax4 ? NQ * 4 : kMax4); ++i)
+            if (i < t.n4) v[NQ * 4 - 1 - i] = *(const unsigned*)(t.src4[i] + (long long)pid * 4);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            aos[(long long)pid * NQ + q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        }
+        const unsigned bit = 1u << (pb + j - run_p0);
+        if (ne_ == key1) {
+          m1 |= bit;
+        } else if (ne_ == key2) {
+          m2 |= bit;
+        } else if (ne_ == key3) {
+          m3 |= bit;
+        } else if (key1 < 0) {
+          key1 = ne_;
+          m1 = bit;
+        } else if (key2 < 0) {
+          key2 = ne_;
+          m2 = bit;
+        } else if (key3 < 0) {
+          key3 = ne_;
+          m3 = bit;
+        } else {
+          rank[pid] = atomicAdd(&cn.arrive[ne_], 1);
+        }
+      }
+    }
+  }
+  flush();
+}
+__global__ void k_rs_count_added(int n_new, const int* __restrict__ new_elems, int ne, int* __restrict__ arrive,
+                                 Totals* tot, int* __restrict__ rank_new) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_new) return;
+  const int e = new_elems[i];
+  if (e < 0 || e >= ne) {
+    tot->invalid = 1;
+    rank_new[i] = -1;
+    return;
+  }
+  rank_new[i] = atomicAdd(&arrive[e], 1);
+}
+// per element: the new count and whether it fits the row (SCS_rebuild.h:33-42: new particles of a row
+// against its holes, i.e. new count <= chunk width); totals by one atomic pair per block
+constexpr int kMaxOver = 1 << 15;  // overflowing rows the elastic mode re-homes per rebuild
+__global__ void k_rs_fit(int ne, int C, const int* __restrict__ n_old, RsCounters cn,
+                         const int* __restrict__ e2r, const int* __restrict__ chunk_width,
+                         int* __restrict__ n_new, Totals* tot, int* __restrict__ ov_list, int reference_rule) {
+  __shared__ int s_sum[4], s_nz[4];
+  int sum = 0, nz = 0;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
+    const int n = n_old[e] - cn.leave[e] + cn.arrive[e];
+    n_new[e] = n;
+    sum += n;
+    nz += n > 0;
+    // The reference counts a row's holes BEFORE its movers leave (SCS_rebuild.h:13-25: a slot is a hole
+    // when it is empty or its particle is removed; a particle that moves to another row still
+    // occupies its slot), so its test is  arrivals <= width - (old count - removed).  The in-place
+    // algorithm here needs only  new count <= width  (the elastic mode uses that).
+    const int occupied = reference_rule ? n_old[e] - cn.removed[e] + cn.arrive[e] : n;
+    if (occupied > chunk_width[e2r[e] / C]) {  // the row overflows (a few hundred of 10^5 per pseudoXGCm step)
+      const int k = atomicAdd(&tot->n_over, 1);
+      if (k < kMaxOver) ov_list[k] = e;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    sum += __shfl_down(sum, o);
+    nz += __shfl_down(nz, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_sum[threadIdx.x >> 6] = sum;
+    s_nz[threadIdx.x >> 6] = nz;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sum = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    nz = s_nz[0] + s_nz[1] + s_nz[2] + s_nz[3];
+    if (sum) atomicAdd(&tot->active, sum);
+    if (nz) atomicAdd(&tot->nonempty, nz);
+  }
+}
+// Elastic mode (this library's extension of the reshuffle): a row whose new count exceeds its chunk
+// width trades places with a row of a wider chunk whose own new count fits the narrower one; when the
+// wide row's occupant does not fit the vacated home it is re-homed in turn (a short chain down the
+// width order: chunk widths differ by about the padding).  Only row_to_element / element_to_row /
+// first-slot tables change -- offsets, slices, chunk widths and the capacity stay -- so the result is
+// the kind of layout the reference's own reshuffle leaves behind (rows no longer sorted by count).
+// One block: claims by compare-and-swap on swap_old[row] (-1 = untouched, else the element that
+// lived there before this rebuild), all-or-nothing: the tables are written only when every
+// overflowing row found a home.
+struct RsMoves {
+  int *elem, *old_row, *new_row;  // kMaxOver * kMaxDepth entries worst case is never reached: capped
+};
+constexpr int kMaxMoves = 4 * kMaxOver;
+// Rows that find no partner get a NEW row: chunks appended behind the last one (the slot space ends
+// there, so it can grow into the allocation's headroom).  Their old rows become padding rows (ids >=
+// num_elems, never live).  A previously empty element (width-0 chunk) that receives its first
+// particles is the typical customer: no swap can house it, its old home has no columns to offer.
+struct RsPool {
+  int sorted_chunks;  // chunks [0, sorted_chunks) ascend in width (the last full re-layout's order)
+  int room_slots, room_rows, room_chunks, room_tiles, room_slices;  // what the tables can still take (host)
+  int V, TP;
+  int *offsets, *s2c, *tiles, *ntiles, *chunk_start_w, *chunk_width_w, *slot_elem;
+  unsigned char* mask;
+  int* pool_list;  // scratch: overflowing elements that need a new row
+};
+__global__ void __launch_bounds__(1024)
+    k_rs_match(int ne, int C, int nchunks, const int* __restrict__ chunk_width,
+               const int* __restrict__ chunk_start, int* __restrict__ r2e, int* __restrict__ e2r,
+               int* __restrict__ eslot0, const int* __restrict__ n_new, const int* __restrict__ ov_list,
+               int* __restrict__ swap_old, RsMoves mv, Totals* tot, int probe_rows, int capacity, int nslices,
+               RsPool pl) {
+  __shared__ int s_fail, s_nmv, s_npool, s_max_small, s_max_big, s_n_small, s_n_big;
+  __shared__ int s_w_small, s_w_big, s_ch_small, s_ch_big, s_ks, s_kb, s_cap1;
+  const int nov = tot->n_over;
+  if (nov == 0 || tot->invalid) return;
+  if (nov > kMaxOver) {
+    if (threadIdx.x == 0) tot->match_fail = 1;
+    return;
+  }
+  if (threadIdx.x == 0) {
+    s_fail = s_nmv = s_npool = s_max_small = s_max_big = s_n_small = s_n_big = s_ks = s_kb = 0;
+    s_cap1 = capacity;
+  }
+  for (int i = threadIdx.x; i < nov; i += blockDim.x) swap_old[e2r[ov_list[i]]] = ov_list[i];  // homes vacated
+  __syncthreads();
+  auto record = [&](int elem, int from, int to) {
+    const int k = atomicAdd(&s_nmv, 1);
+    if (k < kMaxMoves) {
+      mv.elem[k] = elem;
+      mv.old_row[k] = from;
+      mv.new_row[k] = to;
+    } else {
+      s_fail = 1;
+    }
+  };
+  constexpr int kSmall = 64;
+  // ---- stage 1: trade places with a row of a wider chunk whose occupant fits the vacated home
+  for (int i = threadIdx.x; i < nov; i += blockDim.x) {
+    const int A = ov_list[i];
+    const int home = e2r[A], w_home = chunk_width[home / C], need = n_new[A];
+    int taken = -1, taken_occ = -1;
+    if (w_home > 0) {
+      // first sorted chunk wide enough, with the head-room a fresh layout would give the row (a home
+      // that fits exactly overflows again at the next arrival)
+      const int want = need + max(8, need / 8);
+      int lo = 0, hi = pl.sorted_chunks;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (chunk_width[mid] >= want) hi = mid; else lo = mid + 1;
+      }
+      if (lo >= pl.sorted_chunks) {  // nothing that roomy: settle for wide enough
+        lo = 0, hi = pl.sorted_chunks;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (chunk_width[mid] >= need) hi = mid; else lo = mid + 1;
+        }
+      }
+      const int row0 = lo * C, row_end = pl.sorted_chunks * C;
+      for (int k = 0; k < probe_rows && taken < 0; ++k) {
+        const int L = row0 + k;
+        if (L >= row_end) break;
+        const int wl = chunk_width[L / C];
+        if (wl < need || swap_old[L] != -1) continue;
+        const int B = r2e[L];
+        const int nB = B < ne ? n_new[B] : 0;
+        if (nB > wl || nB > w_home) continue;  // overflows itself / does not fit the vacated home
+        if (atomicCAS(&swap_old[L], -1, B) == -1) {
+          taken = L;
+          taken_occ = B;
+        }
+      }
+    }
+    if (taken >= 0) {
+      record(A, home, taken);
+      record(taken_occ, taken, home);
+    } else {
+      pl.pool_list[atomicAdd(&s_npool, 1)] = A;
+      if (need <= kSmall) {
+        atomicMax(&s_max_small, need);
+        atomicAdd(&s_n_small, 1);
+      } else {
+        atomicMax(&s_max_big, need);
+        atomicAdd(&s_n_big, 1);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- stage 2: new rows for the rest, two width classes (most newcomers hold a handful of particles)
+  const int npool = s_npool;
+  if (threadIdx.x == 0 && npool > 0) {
+    const int ws = s_n_small ? (s_max_small + 16 + pl.TP - 1) / pl.TP * pl.TP : 0;
+    const int wb = s_n_big ? (s_max_big + max(16, s_max_big / 4) + pl.TP - 1) / pl.TP * pl.TP : 0;
+    const int cs = (s_n_small + C - 1) / C, cb = (s_n_big + C - 1) / C;
+    const long long slots = (long long)C * ((long long)cs * ws + (long long)cb * wb);
+    const int tiles = cs * ((ws + pl.TP - 1) / pl.TP) + cb * ((wb + pl.TP - 1) / pl.TP);
+    const int slices = cs * ((ws + pl.V - 1) / pl.V) + cb * ((wb + pl.V - 1) / pl.V);
+    if (slots > pl.room_slots || (cs + cb) * C > pl.room_rows || cs + cb > pl.room_chunks ||
+        tiles > pl.room_tiles || slices > pl.room_slices)
+      s_fail = 1;
+    s_w_small = ws;
+    s_w_big = wb;
+    s_ch_small = cs;
+    s_ch_big = cb;
+  }
+  __syncthreads();
+  if (s_fail) {
+    if (threadIdx.x == 0) {
+      tot->match_fail = 1;
+      tot->dbg[0] = npool;
+      tot->dbg[1] = s_n_small;
+      tot->dbg[2] = s_max_small;
+      tot->dbg[3] = s_n_big;
+      tot->dbg[4] = s_max_big;
+      tot->dbg[5] = pl.room_slots;
+      tot->dbg[6] = pl.room_rows;
+      tot->dbg[7] = s_nmv;
+    }
+    return;
+  }
+  // ---- every row has a home.  The pool rows are recorded first (the move list may still overflow),
+  // then the chunks are appended and the tables written.
+  const int ws = npool ? s_w_small : 0, wb = npool ? s_w_big : 0, cs = npool ? s_ch_small : 0,
+            cb = npool ? s_ch_big : 0;
+  const int nc_new = cs + cb;
+  for (int i = threadIdx.x; i < npool; i += blockDim.x) {
+    const int A = pl.pool_list[i];
+    const bool small = n_new[A] <= kSmall;
+    const int k = atomicAdd(small ? &s_ks : &s_kb, 1);
+    const int row = (nchunks + (small ? 0 : cs)) * C + k;
+    record(A, e2r[A], row);
+    record(row, row, e2r[A]);  // the new row's padding id takes the vacated home
+  }
+  __syncthreads();
+  if (s_fail) {
+    if (threadIdx.x == 0) tot->match_fail = 1;
+    return;
+  }
+  if (nc_new) {
+    if (threadIdx.x == 0) {
+      int cap = capacity, ns = nslices, nt = *pl.ntiles;
+      for (int k = 0; k < nc_new; ++k) {
+        const int c = nchunks + k, w = k < cs ? ws : wb;
+        pl.chunk_start_w[c] = cap;
+        pl.chunk_width_w[c] = w;
+        for (int q = 0; q * pl.V < w; ++q) {
+          pl.offsets[ns] = cap + q * pl.V * C;
+          pl.s2c[ns] = c;
+          ++ns;
+        }
+        for (int p0 = 0; p0 < w; p0 += pl.TP) {
+          pl.tiles[2 * nt] = c;
+          pl.tiles[2 * nt + 1] = p0;
+          ++nt;
+        }
+        cap += w * C;
+      }
+      pl.offsets[ns] = cap;
+      *pl.ntiles = nt;
+      s_cap1 = cap;
+      tot->capacity = cap;
+      tot->nslices = ns;
+      tot->cw_sum = nt;      // tiles after the growth
+      tot->cw_cnt = nc_new;  // chunks appended (both fields are unused on this path otherwise)
+    }
+    for (int i = threadIdx.x; i < nc_new * C; i += blockDim.x) {  // new rows start as padding rows
+      const int row = nchunks * C + i;
+      r2e[row] = row;
+      e2r[row] = row;
+      swap_old[row] = row;  // "a padding row lived here": rows that get an element read as moved into
+    }
+  }
+  __syncthreads();
+  if (nc_new) {  // per-slot tables of the new chunks: small-class chunks are equally wide, then the big class
+    const int cap0 = capacity, cap1 = s_cap1, small_span = cs * ws * C;
+    for (int slot = cap0 + threadIdx.x; slot < cap1; slot += blockDim.x) {
+      const int off = slot - cap0;
+      int c, in;
+      if (off < small_span) {
+        c = off / (ws * C);
+        in = off - c * ws * C;
+      } else {
+        c = cs + (off - small_span) / (wb * C);
+        in = (off - small_span) - (c - cs) * wb * C;
+      }
+      pl.mask[slot] = 0;
+      pl.slot_elem[slot] = (nchunks + c) * C + in % C;  // the padding row's own id
+    }
+  }
+  const int nmv = s_nmv;
+  for (int k = threadIdx.x; k < nmv; k += blockDim.x) {
+    const int E = mv.elem[k], row = mv.new_row[k];
+    r2e[row] = E;
+    e2r[E] = row;
+    if (E < ne) eslot0[E] = pl.chunk_start_w[row / C] + row % C;
+  }
+  if (threadIdx.x == 0) tot->n_moved = nmv;
+}
+__global__ void k_rs_go(Totals* tot, int elastic) {
+  const bool fits = tot->n_over == 0 || (elastic && !tot->match_fail);
+  tot->go = (!tot->invalid && tot->active > 0 && fits) ? 1 : 0;
+}
+// the particles that STAY in an element whose row traded places travel too: arrival ranks behind the
+// true arrivals, records staged like the movers'.  One wave per moved element.
+template <int NQ>
+__global__ void k_rs_stage_moved(int C, const int* __restrict__ chunk_start, const int* __restrict__ n_old,
+                                 const int* __restrict__ new_element, int ne, RsMoves mv, int* __restrict__ arrive,
+                                 int* __restrict__ rank, uint4* __restrict__ aos, WordTable t,
+                                 const Totals* __restrict__ tot) {
+  if (!tot->go) return;
+  const int lane = threadIdx.x & 63;
+  const int nwaves = gridDim.x * (blockDim.x >> 6);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < tot->n_moved; k += nwaves) {
+  const int E = mv.elem[k];
+  if (E >= ne) continue;  // a padding row has no particles
+  const int row = mv.old_row[k], start = chunk_start[row / C] + row % C, nold = n_old[E];
+  for (int p0 = 0; p0 < nold; p0 += 64) {
+    const int p = p0 + lane;
+    const long long pid = start + (long long)p * C;
+    const bool stays = p < nold && new_element[pid] == E;
+    const unsigned long long bal = __ballot(stays);
+    if (!bal) continue;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&arrive[E], __popcll(bal));
+    base = __shfl(base, 0);
+    if (stays) {
+      rank[pid] = base + __popcll(bal & lt);
+      unsigned v[NQ * 4];
+#pragma unroll
+      for (int i = 0; i < NQ * 4; ++i) v[i] = 0u;
+#pragma unroll
+      for (int i = 0; i < NQ * 2; ++i)
+        if (i < t.n8) {
+          const unsigned long long d = *(const unsigned long long*)(t.src8[i] + pid * 8);
+          v[2 * i] = (unsigned)d;
+          v[2 * i + 1] = (unsigned)(d >> 32);
+        }
+#pragma unroll
+      for (int i = 0; i < (NQ * 4 < kMax4 ? NQ * 4 : kMax4); ++i)
+        if (i < t.n4) v[NQ * 4 - 1 - i] = *(const unsigned*)(t.src4[i] + pid * 4);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) aos[pid * NQ + q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    }
+  }
+  }
+}
+__global__ void k_rs_plan(const int* __restrict__ ntiles_dev, int C, int TP, int G,
+                          const int* __restrict__ tiles, const int* __restrict__ chunk_start,
+                          const int* __restrict__ chunk_width, const int* __restrict__ r2e,
+                          const int* __restrict__ n_old, const int* __restrict__ n_new,
+                          const int* __restrict__ new_element, int ne, RsCounters cn,
+                          int* __restrict__ hole_tab, int* __restrict__ rank,
+                          unsigned char* __restrict__ mask, const int* __restrict__ swap_old,
+                          int* __restrict__ slot_elem, const int* __restrict__ go) {
+  if (!*go) return;
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int grp = (int)(g / C), r = (int)(g - (long long)grp * C);
+  const int ntiles = *ntiles_dev;
+  int cur = -1, e = -1, start = 0, run_p0 = 0, nold = 0, nnew = 0, arr = 0;
+  bool moved_in = false;  // this physical row changed its element: nothing stays, every column below the new count is a hole
+  unsigned hb = 0, tb = 0;  // holes / tail stayers of the run, bit = column - run_p0
+  auto flush = [&]() {
+    if (hb) {
+      int h = atomicAdd(&cn.hole_cur[e], __popc(hb));
+      while (hb) {
+        const int b = __ffs(hb) - 1;
+        hb &= hb - 1;
+        hole_tab[start + h * C] = start + (run_p0 + b) * C;
+        ++h;
+      }
+    }
+    if (tb) {
+      int tk = arr + atomicAdd(&cn.tail_cur[e], __popc(tb));  // claims of the arrivals come first
+      while (tb) {
+        const int b = __ffs(tb) - 1;
+        tb &= tb - 1;
+        rank[start + (run_p0 + b) * C] = tk++;
+      }
+    }
+  };
+  for (int k = 0; k < G; ++k) {
+    const int tile = grp * G + k;
+    if (tile >= ntiles) break;
+    const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
+    if (c != cur) {
+      flush();
+      cur = c;
+      start = chunk_start[c] + r;
+      e = r2e[c * C + r];
+      nold = nnew = arr = 0;
+      if (e < ne) {
+        nold = n_old[e];
+        nnew = n_new[e];
+        arr = cn.arrive[e];
+      }
+      const int so = swap_old[c * C + r];
+      moved_in = so >= 0 && so != e;
+      if (moved_in) nold = so < ne ? n_old[so] : 0;  // live columns of the element that moved out
+      run_p0 = p0;
+    }
+    const int wc = chunk_width[c];
+    const int pend = min(min(p0 + TP, wc), moved_in ? wc : max(nold, nnew));
+    for (int p = p0; p < pend; ++p) {
+      const int pid = start + p * C;
+      const bool live = p < nold;
+      const bool stays = !moved_in && live && new_element[pid] == e;
+      const unsigned bit = 1u << (p - run_p0);
+      if (p < nnew) {
+        if (!stays) hb |= bit;
+      } else if (stays) {
+        tb |= bit;
+      }
+      if ((p < nnew) != live) mask[pid] = p < nnew ? 1 : 0;
+      if (moved_in) slot_elem[pid] = e;
+    }
+  }
+  flush();
+}
+template <int NQ>
+__global__ void k_rs_move(const int* __restrict__ ntiles_dev, int C, int TP, int G,
+                          const int* __restrict__ tiles, const int* __restrict__ chunk_start,
+                          const int* __restrict__ chunk_width, const int* __restrict__ r2e,
+                          const int* __restrict__ n_old, const int* __restrict__ n_new,
+                          const int* __restrict__ new_element, int ne, const int* __restrict__ eslot0,
+                          const int* __restrict__ hole_tab, const int* __restrict__ rank,
+                          const uint4* __restrict__ aos, WordTable t, const int* __restrict__ swap_old,
+                          const int* __restrict__ go) {
+  if (!*go) return;
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int grp = (int)(g / C), r = (int)(g - (long long)grp * C);
+  const int ntiles = *ntiles_dev;
+  int cur = -1, e = -1, start = 0, nold = 0, nnew = 0;
+  bool moved_out = false;  // the element that lived in this physical row traded places: all of it travels
+  for (int k = 0; k < G; ++k) {
+    const int tile = grp * G + k;
+    if (tile >= ntiles) break;
+    const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
+    if (c != cur) {
+      cur = c;
+      start = chunk_start[c] + r;
+      e = r2e[c * C + r];
+      const int so = swap_old[c * C + r];
+      moved_out = so >= 0 && so != e;
+      if (moved_out) e = so;  // the particles in these slots belong to the element that moved out
+      nold = nnew = 0;
+      if (e < ne) {
+        nold = n_old[e];
+        nnew = n_new[e];
+      }
+    }
+    const int pend = min(min(p0 + TP, chunk_width[c]), nold);
+    for (int p = p0; p < pend; ++p) {
+      const int pid = start + p * C;
+      const int ne_ = new_element[pid];
+      if (ne_ == e && !moved_out) {
+        if (p < nnew) continue;  // stays where it is
+        const long long tgt = hole_tab[start + rank[pid] * C];  // back-fill a hole of the own row
+#pragma unroll
+        for (int i = 0; i < NQ * 2; ++i)
+          if (i < t.n8)
+            *(unsigned long long*)(t.dst8[i] + tgt * 8) = *(const unsigned long long*)(t.dst8[i] + (long long)pid * 8);
+#pragma unroll
+        for (int i = 0; i < (NQ * 4 < kMax4 ? NQ * 4 : kMax4); ++i)
+          if (i < t.n4) *(unsigned*)(t.dst4[i] + tgt * 4) = *(const unsigned*)(t.dst4[i] + (long long)pid * 4);
+      } else if (ne_ >= 0) {
+        const long long tgt = hole_tab[eslot0[ne_] + rank[pid] * C];
+        const uint4* sp = aos + (long long)pid * NQ;
+        unsigned w[NQ * 4];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const uint4 v = sp[q];
+          w[4 * q] = v.x;
+          w[4 * q + 1] = v.y;
+          w[4 * q + 2] = v.z;
+          w[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < NQ * 2; ++i)
+          if (i < t.n8)
+            *(unsigned long long*)(t.dst8[i] + tgt * 8) = ((unsigned long long)w[2 * i + 1] << 32) | w[2 * i];
+#pragma unroll
+        for (int i = 0; i < (NQ * 4 < kMax4 ? NQ * 4 : kMax4); ++i)
+          if (i < t.n4) *(unsigned*)(t.dst4[i] + tgt * 4) = w[NQ * 4 - 1 - i];
+      }
+    }
+  }
+}
+// new particles take the holes their arrival ranks name
+__global__ void k_rs_add(int n_new, const int* __restrict__ new_elems, const int* __restrict__ rank_new,
+                         const int* __restrict__ eslot0, const int* __restrict__ hole_tab, int C, MoveArgs a,
+                         const int* __restrict__ go) {
+  if (!*go) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_new) return;
+  const int tgt = hole_tab[eslot0[new_elems[i]] + rank_new[i] * C];
+  copy_members(a, i, tgt);
+}
+__global__ void k_zero_gated(unsigned long long* __restrict__ p, long long n, const int* __restrict__ go) {
+  if (!*go) return;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    __builtin_nontemporal_store(0ull, p + i);
+}
+
 int finish_layout_upload(pp_ps* ps, const HostLayout& L, const std::vector<int>& ppe) {
   // slot_elem + mask image on host
   std::vector<int> slot_elem((size_t)L.capacity, -1);
@@ -1242,6 +1870,12 @@ int finish_layout_upload(pp_ps* ps, const HostLayout& L, const std::vector<int>&
   ps->ntiles_max = ntiles;
   std::vector<int> ntl(1, ntiles);
   int rc;
+  std::vector<int> eslot0((size_t)std::max(ps->num_elems, 1), 0);
+  for (int e = 0; e < ps->num_elems; ++e) {
+    const int row = L.element_to_row[e];
+    eslot0[e] = L.chunk_start[row / L.C] + row % L.C;
+  }
+  if ((rc = upload_vec(ps->d_eslot0, eslot0))) return rc;
   if ((rc = upload_vec(ps->d_tiles, tiles))) return rc;
   if ((rc = upload_vec(ps->d_ntiles, ntl))) return rc;
   if ((rc = upload_vec(ps->d_chunk_start, L.chunk_start))) return rc;
@@ -1405,14 +2039,266 @@ int build_word_table(const pp_ps* ps, const void* const* src, int64_t src_stride
   return (NQ == 4 || NQ == 10 || (NQ >= 1 && NQ <= 3) || NQ == 6 || NQ == 8) ? NQ : 0;
 }
 
+// pinned landing zone of the rebuild totals + the event the host waits on
+int totals_pin(Totals** h_pin_out, hipEvent_t* ev_out) {
+  static Totals* h_pin = nullptr;
+  static hipEvent_t ev_tot = nullptr;
+  if (!h_pin) {
+    PP_HIP_CHECK(hipHostMalloc((void**)&h_pin, sizeof(Totals)));
+    PP_HIP_CHECK(hipEventCreateWithFlags(&ev_tot, hipEventDisableTiming));
+  }
+  *h_pin_out = h_pin;
+  *ev_out = ev_tot;
+  return PP_OK;
+}
+
+// The in-place rebuild (kernels above).  Returns 1 when the rebuild is complete, 0 when the layout
+// cannot be kept (some row would overflow, nothing is left, members the staged record cannot hold:
+// the structure is untouched and the caller runs the full re-layout), < 0 on error.
+int scs_reshuffle(pp_ps* ps, const int* new_element, int n_new, const int* new_elems,
+                  const void* const* new_info, int commit_x, int commit_xt,
+                  const std::function<int(const int*)>& pre_sync) {
+  static const bool off = getenv("PP_NO_RESHUFFLE") != nullptr;
+  if (off || ps->shuffle_mode <= 0) return 0;
+  if (!(ps->capacity > 0 && ps->num_ptcls > 0) || !ps->elem_count_valid || ps->ntiles_max <= 0) return 0;
+  if (ps->d_eslot0.bytes < sizeof(int) * (size_t)std::max(ps->num_elems, 1)) return 0;
+  const bool commit = commit_x >= 0 && commit_xt >= 0;
+  const int ne = ps->num_elems;
+  // word table: every component that travels, source == destination buffer (in place).  With the
+  // fused updatePtclPositions the buffers of x and x_tgt trade places on success: x is read from /
+  // written to x_tgt's buffer, x_tgt (all zero afterwards) does not travel at all.
+  WordTable wt{};
+  for (int m = 0; m < ps->nmembers; ++m) {
+    const int b = ps->member_bytes[m];
+    if (b != 4 && b != 8) return 0;
+    if (commit && m == commit_xt) continue;
+    const pp::DevBuf& buf = (commit && m == commit_x) ? ps->data[commit_xt] : ps->data[m];
+    for (int cc = 0; cc < ps->member_ncomp[m]; ++cc) {
+      char* q = (char*)buf.p + ((size_t)cc * ps->stride) * b;
+      if (b == 8) {
+        if (wt.n8 >= kMax8) return 0;
+        wt.src8[wt.n8] = q;
+        wt.dst8[wt.n8++] = q;
+      } else {
+        if (wt.n4 >= kMax4) return 0;
+        wt.src4[wt.n4] = q;
+        wt.dst4[wt.n4++] = q;
+      }
+    }
+  }
+  const int nw = 2 * wt.n8 + wt.n4;
+  const int NQ = (nw + 3) / 4 == 3 ? 4 : (nw + 3) / 4;
+  if (!(NQ == 1 || NQ == 2 || NQ == 4 || NQ == 6 || NQ == 8 || NQ == 10)) return 0;
+  hipStream_t st = pp::stream();
+  PP_HIP_CHECK(ps->s_ppe.reserve(sizeof(int) * (size_t)std::max(ne, 1)));
+  PP_HIP_CHECK(ps->s_misc.reserve(sizeof(Totals)));
+  PP_HIP_CHECK(ps->s_rs.reserve(sizeof(int) * 5 * (size_t)std::max(ne, 1)));
+  PP_HIP_CHECK(ps->s_idx.reserve(sizeof(int) * (size_t)ps->capacity));
+  PP_HIP_CHECK(ps->s_holes.reserve(sizeof(int) * (size_t)ps->capacity));
+  PP_HIP_CHECK(ps->s_aos.reserve((size_t)ps->capacity * NQ * 16));
+  PP_HIP_CHECK(ps->s_ranknew.reserve(sizeof(int) * (size_t)std::max(n_new, 1)));
+  PP_HIP_CHECK(hipMemsetAsync(ps->s_rs.p, 0, sizeof(int) * 5 * (size_t)std::max(ne, 1), st));
+  PP_HIP_CHECK(hipMemsetAsync(ps->s_misc.p, 0, sizeof(Totals), st));
+  // elastic mode: overflow list, per-row "who lived here" marks, the list of rows that trade places
+  const bool elastic = ps->shuffle_mode >= 2;
+  const size_t rows_cap = (size_t)ps->num_rows + 64 * 1024 + 64;  // rows the structure may reach in this rebuild
+  PP_HIP_CHECK(ps->s_rsx.reserve(sizeof(int) * (2 * (size_t)kMaxOver + rows_cap + 3 * (size_t)kMaxMoves)));
+  int* ov_list = ps->s_rsx.as<int>();
+  int* pool_list = ov_list + kMaxOver;
+  int* swap_old = pool_list + kMaxOver;
+  RsMoves mvs{swap_old + rows_cap, swap_old + rows_cap + kMaxMoves, swap_old + rows_cap + 2 * (size_t)kMaxMoves};
+  PP_HIP_CHECK(hipMemsetAsync(swap_old, 0xff, sizeof(int) * (size_t)ps->num_rows, st));
+  // room for appended pool chunks: every per-slot array must cover capacity + room_slots, the per-row /
+  // per-chunk / tile / slice tables their share
+  RsPool pl{};
+  if (elastic) {
+    long long room = (long long)ps->stride - ps->capacity;
+    room = std::min<long long>(room, (long long)ps->d_mask.bytes - ps->capacity);
+    room = std::min<long long>(room, (long long)(ps->d_slot_elem.bytes / 4) - ps->capacity);
+    room = std::min<long long>(room, (long long)(ps->s_idx.bytes / 4) - ps->capacity);
+    room = std::min<long long>(room, (long long)(ps->s_holes.bytes / 4) - ps->capacity);
+    room = std::min<long long>(room, (long long)(ps->s_aos.bytes / ((size_t)NQ * 16)) - ps->capacity);
+    pl.room_slots = (int)std::max<long long>(0, std::min<long long>(room, 1 << 28));
+    long long rows = std::min<long long>((long long)(ps->d_row_to_element.bytes / 4),
+                                         (long long)(ps->d_element_to_row.bytes / 4)) - ps->num_rows;
+    rows = std::min<long long>(rows, 64 * 1024);
+    pl.room_rows = (int)std::max<long long>(0, rows);
+    pl.room_chunks = (int)std::max<long long>(
+        0, std::min<long long>((long long)(ps->d_chunk_start.bytes / 4), (long long)(ps->d_chunk_width.bytes / 4)) -
+               ps->num_chunks);
+    pl.room_tiles = (int)std::max<long long>(0, (long long)(ps->d_tiles.bytes / 8) - ps->ntiles_max - 1);
+    pl.room_slices = (int)std::max<long long>(
+        0, std::min<long long>((long long)(ps->d_offsets.bytes / 4) - ps->num_slices - 2,
+                               (long long)(ps->d_slice_to_chunk.bytes / 4) - ps->num_slices - 1));
+    pl.sorted_chunks = std::min(ps->sorted_chunks, ps->num_chunks);
+    pl.V = ps->V;
+    pl.TP = ps->tile_p;
+    pl.offsets = ps->d_offsets.as<int>();
+    pl.s2c = ps->d_slice_to_chunk.as<int>();
+    pl.tiles = ps->d_tiles.as<int>();
+    pl.ntiles = ps->d_ntiles.as<int>();
+    pl.chunk_start_w = ps->d_chunk_start.as<int>();
+    pl.chunk_width_w = ps->d_chunk_width.as<int>();
+    pl.slot_elem = ps->d_slot_elem.as<int>();
+    pl.mask = ps->d_mask.as<unsigned char>();
+    pl.pool_list = pool_list;
+  }
+  Totals* tot = ps->s_misc.as<Totals>();
+  RsCounters cn{ps->s_rs.as<int>(), ps->s_rs.as<int>() + ne, ps->s_rs.as<int>() + 2 * (size_t)ne,
+                ps->s_rs.as<int>() + 3 * (size_t)ne, ps->s_rs.as<int>() + 4 * (size_t)ne};
+  int* n_new_e = ps->s_ppe.as<int>();
+  const int* n_old = ps->d_elem_count.as<int>();
+  int* rank = ps->s_idx.as<int>();
+  int* rank_new = ps->s_ranknew.as<int>();
+  int* holes = ps->s_holes.as<int>();
+  uint4* aos = ps->s_aos.as<uint4>();
+  const int G = std::max(1, 32 / ps->tile_p);
+  const size_t tiles_bound = (size_t)ps->ntiles_max + (size_t)pl.room_tiles;
+  const unsigned grp_grid = grid_for((tiles_bound + G - 1) / G * ps->C);
+#define PP_RS_TILES                                                                                  \
+  ps->d_ntiles.as<int>(), ps->C, ps->tile_p, G, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(), \
+      ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>()
+#define PP_RS_CASE(N)                                                                                   \
+  case N:                                                                                               \
+    k_rs_count<N><<<grp_grid, kBlock, 0, st>>>(PP_RS_TILES, n_old, new_element, ne, cn, tot, rank, aos, wt); \
+    break;
+  switch (NQ) { PP_RS_CASE(1) PP_RS_CASE(2) PP_RS_CASE(4) PP_RS_CASE(6) PP_RS_CASE(8) PP_RS_CASE(10) }
+#undef PP_RS_CASE
+  if (n_new > 0) k_rs_count_added<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ne, cn.arrive, tot, rank_new);
+  k_rs_fit<<<std::min(grid_for(std::max(ne, 1)), 256u), kBlock, 0, st>>>(
+      ne, ps->C, n_old, cn, ps->d_element_to_row.as<int>(), ps->d_chunk_width.as<int>(), n_new_e, tot, ov_list,
+      elastic ? 0 : 1);
+  if (elastic) {
+    static const int probe = getenv("PP_RS_PROBE") ? atoi(getenv("PP_RS_PROBE")) : 256;
+    k_rs_match<<<1, 1024, 0, st>>>(ne, ps->C, ps->num_chunks, ps->d_chunk_width.as<int>(),
+                                   ps->d_chunk_start.as<int>(), ps->d_row_to_element.as<int>(),
+                                   ps->d_element_to_row.as<int>(), ps->d_eslot0.as<int>(), n_new_e, ov_list,
+                                   swap_old, mvs, tot, probe, ps->capacity, ps->num_slices, pl);
+  }
+  k_rs_go<<<1, 1, 0, st>>>(tot, elastic ? 1 : 0);
+  const int* go = &tot->go;
+  if (elastic) {
+#define PP_RS_CASE(N)                                                                                       \
+  case N:                                                                                                   \
+    k_rs_stage_moved<N><<<512, kBlock, 0, st>>>(ps->C, ps->d_chunk_start.as<int>(), n_old, new_element, ne, \
+                                                mvs, cn.arrive, rank, aos, wt, tot);                       \
+    break;
+    switch (NQ) { PP_RS_CASE(1) PP_RS_CASE(2) PP_RS_CASE(4) PP_RS_CASE(6) PP_RS_CASE(8) PP_RS_CASE(10) }
+#undef PP_RS_CASE
+  }
+  k_rs_plan<<<grp_grid, kBlock, 0, st>>>(PP_RS_TILES, n_old, n_new_e, new_element, ne, cn, holes, rank,
+                                        ps->d_mask.as<unsigned char>(), swap_old, ps->d_slot_elem.as<int>(), go);
+#define PP_RS_CASE(N)                                                                                     \
+  case N:                                                                                                 \
+    k_rs_move<N><<<grp_grid, kBlock, 0, st>>>(PP_RS_TILES, n_old, n_new_e, new_element, ne,              \
+                                              ps->d_eslot0.as<int>(), holes, rank, aos, wt, swap_old, go); \
+    break;
+  switch (NQ) { PP_RS_CASE(1) PP_RS_CASE(2) PP_RS_CASE(4) PP_RS_CASE(6) PP_RS_CASE(8) PP_RS_CASE(10) }
+#undef PP_RS_CASE
+#undef PP_RS_TILES
+  // x_tgt <- 0 of the fused updatePtclPositions.  Without new particles the zeros stay pending: the
+  // next fused push overwrites x_tgt of every live particle (pp_push_search), anything else that
+  // looks at the member materialises them first (pp::ps_ready).
+  static const bool no_lazy = getenv("PP_NO_LAZY_ZERO") != nullptr;
+  const bool lazy = commit && n_new == 0 && !no_lazy;
+  if (commit && !lazy) {
+    const long long nwords = (long long)ps->stride * ps->member_ncomp[commit_x];
+    k_zero_gated<<<2048, kBlock, 0, st>>>((unsigned long long*)ps->data[commit_x].p, nwords, go);
+  }
+  if (n_new > 0) {
+    MoveArgs add = make_move(ps, ps->data, ps->stride, ps->data, ps->stride);
+    for (int m = 0; m < ps->nmembers; ++m) add.src[m] = new_info[m];
+    add.src_stride = n_new;
+    if (commit) std::swap(add.dst[commit_x], add.dst[commit_xt]);  // the buffers trade places below
+    k_rs_add<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, rank_new, ps->d_eslot0.as<int>(), holes, ps->C,
+                                                 add, go);
+  }
+  PP_LAUNCH_CHECK();
+  Totals* h_pin;
+  hipEvent_t ev_tot;
+  int rc = totals_pin(&h_pin, &ev_tot);
+  if (rc) return rc;
+  PP_HIP_CHECK(hipMemcpyAsync(h_pin, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
+  PP_HIP_CHECK(hipEventRecord(ev_tot, st));
+  // the new per-element counts are final whether or not the layout can be kept: the step's
+  // scatters run behind them while the host waits
+  bool scattered = false;
+  if (pre_sync) {
+    rc = pre_sync(n_new_e);
+    if (rc) return rc;
+    scattered = true;
+  }
+  (void)scattered;
+  PP_HIP_CHECK(hipEventSynchronize(ev_tot));
+  const Totals h = *h_pin;
+  if (getenv("PP_SPEC_DEBUG"))
+    fprintf(stderr, "rebuild in place: go %d active %d nonempty %d invalid %d overflowing rows %d rows moved %d "
+                    "no home %d (need new rows %d: small %d max %d, big %d max %d; room slots %d rows %d; moves %d) "
+                    "capacity %d -> %d chunks +%d\n", h.go, h.active, h.nonempty, h.invalid, h.n_over, h.n_moved,
+            h.match_fail, h.dbg[0], h.dbg[1], h.dbg[2], h.dbg[3], h.dbg[4], h.dbg[5], h.dbg[6], h.dbg[7], ps->capacity,
+            h.capacity, h.cw_cnt);
+  if (h.invalid) {
+    pp::set_error(
+        "rebuild: a particle's new element is out of range, or a new particle is marked inactive "
+        "(element id -1) -- the reference exits here (SCS_rebuild.h:147-151)");
+    return PP_EINVAL;
+  }
+  if (!h.go) return 0;
+  ps->d_elem_count.swap(ps->s_ppe);
+  ps->version = pp::next_version();
+  ps->num_ptcls = h.active;
+  ps->num_empty_elements = (ps->num_rows - ne) + (ne - h.nonempty);
+  if (h.capacity > ps->capacity) {  // pool chunks were appended
+    ps->capacity = h.capacity;
+    ps->num_slices = h.nslices;
+    ps->ntiles_max = std::max(ps->ntiles_max, h.cw_sum);
+    ps->num_chunks += h.cw_cnt;
+    ps->num_rows = ps->num_chunks * ps->C;
+    ps->num_empty_elements = (ps->num_rows - ne) + (ne - h.nonempty);
+  }
+  if (commit) {
+    ps->data[commit_x].swap(ps->data[commit_xt]);
+    ps->zero_pending = lazy ? commit_xt : -1;
+  }
+  ++ps->n_reshuffles;
+  ps->n_rows_moved += h.n_moved;
+  return 1;
+}
+
 // `pre_sync` (may be empty): work that depends on nothing but the new per-element counts, enqueued
 // before the rebuild's host sync so that the GPU has something to run while the host wakes up
 int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_elems,
                 const void* const* new_info, int commit_x, int commit_xt,
-                const std::function<int(const int*)>& pre_sync = std::function<int(const int*)>()) {
+                const std::function<int(const int*)>& pre_sync = std::function<int(const int*)>(),
+                bool try_reshuffle = true) {
   hipStream_t st = pp::stream();
   const int ne = ps->num_elems;
   PP_REQUIRE(n_new == 0 || new_info != nullptr, "rebuild: new particles need new_info_dev");
+  {
+    int rc0 = pp::ps_ready(ps);  // zeros left pending by the previous in-place rebuild
+    if (rc0) return rc0;
+  }
+  pp::Range rg("scs_rebuild");
+  // Mode 2 (elastic, opt-in) tries the in-place path first.  Mode 1 (the reference's decision)
+  // evaluates the decision on the histogram of the full path below, which costs nothing when the
+  // layout cannot be kept -- the normal case at 10^5 rows.
+  if (try_reshuffle && ps->shuffle_mode >= 2) {
+    int rc0;
+    bool scattered = false;
+    std::function<int(const int*)> once;
+    if (pre_sync)
+      once = [&](const int* c) {
+        scattered = true;
+        return pre_sync(c);
+      };
+    rc0 = scs_reshuffle(ps, new_element, n_new, new_elems, new_info, commit_x, commit_xt, once);
+    if (rc0 < 0) return rc0;
+    if (rc0 == 1) return PP_OK;
+    // the layout cannot be kept: full re-layout (the new counts were final, so scatters that already
+    // ran behind them are not repeated)
+    return scs_rebuild(ps, new_element, n_new, new_elems, new_info, commit_x, commit_xt,
+                       scattered ? std::function<int(const int*)>() : pre_sync, false);
+  }
   PP_HIP_CHECK(ps->s_ppe.reserve(sizeof(int) * (size_t)std::max(ne, 1)));
   PP_HIP_CHECK(ps->s_misc.reserve(sizeof(Totals)));
   PP_HIP_CHECK(hipMemsetAsync(ps->s_ppe.p, 0, sizeof(int) * (size_t)std::max(ne, 1), st));
@@ -1442,6 +2328,12 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   if (ne > 0)
     k_nonempty<<<std::min(grid_for(ne), std::min(256u, std::max(64u, (unsigned)(ne / 4096)))), kBlock, 0, st>>>(
         ne, ppe, tot);
+  // the reference's reshuffle decision (mode 1), on the histogram just built
+  const bool decide_keep = try_reshuffle && ps->shuffle_mode == 1 && have_old && ne > 0 && ps->elem_count_valid &&
+                           getenv("PP_NO_RESHUFFLE") == nullptr;
+  if (decide_keep)
+    k_fit_check<<<std::min(grid_for(ne), 256u), kBlock, 0, st>>>(ne, ps->C, ppe, ps->d_element_to_row.as<int>(),
+                                                               ps->d_chunk_width.as<int>(), tot);
   // Sort keys are (window, count) with count < key_base; an upper bound known on the host avoids
   // a D2H read of the live count before the layout can start.
   const long long key_base = (long long)(have_old ? ps->num_ptcls : 0) + n_new + 1;
@@ -1503,6 +2395,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       ta.r2e = ps->s_r2e2.as<int>();
       ta.e2r = ps->s_e2r2.as<int>();
       ta.row_cursor = ps->s_rowstart.as<int>();
+      ta.eslot0 = ps->s_eslot0.as<int>();
       ta.tot = tot;
       k_layout_tables<<<ta.b3 + grid_for(nrows), kBlock, 0, st>>>(ta);
     }
@@ -1517,7 +2410,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     } else if (swap_stride < cap_sz || swap_stride * ps->minimize_size < cap_sz) {
       swap_stride = (int64_t)(cap_sz * (1 + ps->extra_padding));
       if (swap_stride < cap_sz) swap_stride = cap_sz;
-      swap_stride = spread_stride(swap_stride);
+      swap_stride = spread_stride(swap_stride + growth_reserve(ps, cap_sz));
     }
     int rc2 = alloc_members(ps, ps->swap, swap_stride, false);
     if (rc2) return rc2;
@@ -1603,7 +2496,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     long long nsl_lim = std::min<long long>((long long)(ps->s_offsets2.bytes / 4) - 1, (long long)(ps->s_s2c2.bytes / 4));
     cap_lim = std::min<long long>(cap_lim, 2147483647ll / 2);
     if (cap_lim >= ps->capacity / 2 && cap_lim > 0 && nsl_lim > 0) {
-      k_spec_check<<<1, 1, 0, st>>>(tot, (int)cap_lim, (int)nsl_lim, ps->C_max, L.key_bits);
+      k_spec_check<<<1, 1, 0, st>>>(tot, (int)cap_lim, (int)nsl_lim, ps->C_max, L.key_bits, decide_keep ? 1 : 0);
       rc = enqueue_tail((int)cap_lim, (int)nsl_lim, stride_fit);
       if (rc) return rc;
       speculated = true;
@@ -1611,12 +2504,9 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   }
   // The totals travel to pinned memory and the host waits for THAT copy only: whatever `pre_sync`
   // enqueues behind it keeps the GPU busy while the host wakes up and issues its next calls.
-  static Totals* h_pin = nullptr;
-  static hipEvent_t ev_tot = nullptr;
-  if (!h_pin) {
-    PP_HIP_CHECK(hipHostMalloc((void**)&h_pin, sizeof(Totals)));
-    PP_HIP_CHECK(hipEventCreateWithFlags(&ev_tot, hipEventDisableTiming));
-  }
+  Totals* h_pin = nullptr;
+  hipEvent_t ev_tot = nullptr;
+  if ((rc = totals_pin(&h_pin, &ev_tot))) return rc;
   PP_HIP_CHECK(hipMemcpyAsync(h_pin, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
   PP_HIP_CHECK(hipEventRecord(ev_tot, st));
   if (pre_sync) {
@@ -1631,6 +2521,22 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
         "rebuild: a particle's new element is out of range, or a new particle is marked inactive "
         "(element id -1) -- the reference exits here (SCS_rebuild.h:147-151)");
     return PP_EINVAL;
+  }
+  if (decide_keep && h.active > 0 && h.n_over == 0) {
+    // Every row's new count fits its chunk: the reference keeps the layout (SCS_rebuild.h:184-189).  The
+    // speculative re-layout tail did not run (k_spec_check); the in-place path does the work.  Rare at
+    // scale (some row of 10^5 overflows its padding nearly every step), common for small structures.
+    ps->swap_stride = swap_stride_before;
+    const int mode = ps->shuffle_mode;
+    rc = scs_reshuffle(ps, new_element, n_new, new_elems, new_info, commit_x, commit_xt,
+                       std::function<int(const int*)>());  // (the scatters ran behind the histogram above)
+    ps->shuffle_mode = mode;
+    if (rc < 0) return rc;
+    if (rc == 1) return PP_OK;
+    // cannot happen for data the in-place path supports; members it cannot stage (1/2-byte scalars) land
+    // here: full re-layout after all, without the decision
+    return scs_rebuild(ps, new_element, n_new, new_elems, new_info, commit_x, commit_xt,
+                       std::function<int(const int*)>(), false);
   }
   if (h.active == 0) {  // SCS_rebuild.h:168-182: no particle left -- resetMask, structure kept
     ps->swap_stride = swap_stride_before;
@@ -1694,8 +2600,11 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   ps->d_tiles.swap(ps->s_newidx);
   ps->d_ntiles.swap(ps->s_scan);
   ps->d_elem_count.swap(ps->s_ppe);  // live particles per element == the histogram just built
+  ps->d_eslot0.swap(ps->s_eslot0);
+  ps->sorted_chunks = nchunks;
   ps->elem_count_valid = true;
   ps->version = pp::next_version();
+  ++ps->n_full_rebuilds;
   ps->ntiles_max = ntiles_max;
   ps->C = C_new;
   ps->num_ptcls = h.active;
@@ -1839,6 +2748,17 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
 
 }  // namespace
 
+namespace pp {
+int ps_materialize(pp_ps* ps) {
+  const int s = ps->zero_pending;
+  if (s < 0) return PP_OK;
+  ps->zero_pending = -1;
+  const size_t bytes = (size_t)ps->stride * ps->member_ncomp[s] * ps->member_bytes[s];
+  if (bytes) PP_HIP_CHECK(hipMemsetAsync(ps->data[s].p, 0, bytes, pp::stream()));
+  return PP_OK;
+}
+}  // namespace pp
+
 extern "C" {
 
 pp_ps* pp_ps_create_scs(int C, int sigma, int V, int num_elems, int num_ptcls,
@@ -1876,13 +2796,14 @@ pp_ps* pp_ps_create_scs(int C, int sigma, int V, int num_elems, int num_ptcls,
   HostLayout L;
   host_layout(L, ps->C, V, sigma, num_elems, ppe_host, pad_strat, shuffle_padding);
   ps->num_chunks = L.nchunks;
+  ps->sorted_chunks = L.nchunks;
   ps->num_rows = L.nchunks * L.C;
   ps->num_slices = L.nslices;
   ps->capacity = L.capacity;
   ps->num_empty_elements = L.num_empty;
   int64_t cap = L.capacity;
   if (extra_padding > 0) cap = (int64_t)(int)(L.capacity * (1 + extra_padding));
-  ps->stride = spread_stride(std::max<int64_t>(cap, 1));
+  ps->stride = spread_stride(std::max<int64_t>(cap, 1) + growth_reserve(ps, L.capacity));
   ps->swap_stride = ps->stride;  // the reference allocates an equal-sized swap at construction
   bool ok = alloc_members(ps, ps->data, ps->stride, true) == PP_OK;
   std::vector<int> ppe(ppe_host, ppe_host + num_elems);
@@ -2017,6 +2938,7 @@ void* pp_ps_member_ptr(pp_ps* ps, int m) {
     pp::set_error("pp_ps_member_ptr: bad member index");
     return nullptr;
   }
+  if (pp::ps_ready(ps)) return nullptr;
   return ps->data[ps->member_map[m]].p;
 }
 int64_t pp_ps_member_stride(const pp_ps* ps) { return ps ? ps->stride : 0; }
@@ -2029,6 +2951,19 @@ int pp_ps_swap_members(pp_ps* ps, int a, int b) {
                  ps->member_ncomp[sa] == ps->member_ncomp[sb],
              "pp_ps_swap_members: members differ in type");
   std::swap(ps->member_map[a], ps->member_map[b]);
+  return PP_OK;
+}
+
+int pp_ps_set_shuffling(pp_ps* ps, int mode) {
+  PP_REQUIRE(ps && mode >= 0 && mode <= 2, "pp_ps_set_shuffling: mode must be 0, 1 or 2");
+  ps->shuffle_mode = mode;
+  return PP_OK;
+}
+int pp_ps_rebuild_stats(const pp_ps* ps, long long* n_in_place, long long* n_full, long long* n_rows_moved) {
+  PP_REQUIRE(ps, "pp_ps_rebuild_stats: null ps");
+  if (n_in_place) *n_in_place = ps->n_reshuffles;
+  if (n_full) *n_full = ps->n_full_rebuilds;
+  if (n_rows_moved) *n_rows_moved = ps->n_rows_moved;
   return PP_OK;
 }
 
@@ -2070,6 +3005,7 @@ int pp_ps_layout_to_host(const pp_ps* ps, int* offsets, int* slice_to_chunk, int
 
 int pp_ps_member_to_host(pp_ps* ps, int m, void* out_host) {
   PP_REQUIRE(ps && out_host && m >= 0 && m < ps->nmembers, "pp_ps_member_to_host: bad argument");
+  if (int rc = pp::ps_ready(ps)) return rc;
   const int s = ps->member_map[m];
   PP_HIP_CHECK(hipStreamSynchronize(pp::stream()));
   PP_HIP_CHECK(hipMemcpy(out_host, ps->data[s].p,
@@ -2079,6 +3015,7 @@ int pp_ps_member_to_host(pp_ps* ps, int m, void* out_host) {
 }
 int pp_ps_member_from_host(pp_ps* ps, int m, const void* in_host) {
   PP_REQUIRE(ps && in_host && m >= 0 && m < ps->nmembers, "pp_ps_member_from_host: bad argument");
+  if (int rc = pp::ps_ready(ps)) return rc;
   const int s = ps->member_map[m];
   PP_HIP_CHECK(hipStreamSynchronize(pp::stream()));
   PP_HIP_CHECK(hipMemcpy(ps->data[s].p, in_host,
@@ -2091,6 +3028,7 @@ int pp_ps_rebuild(pp_ps* ps, const int* new_element_dev, int n_new, const int* n
                   const void* const* new_info_dev) {
   PP_REQUIRE(ps && (new_element_dev || ps->capacity == 0), "pp_ps_rebuild: null argument");
   PP_REQUIRE(n_new >= 0 && (n_new == 0 || new_elems_dev), "pp_ps_rebuild: bad new particles");
+  if (int rc = pp::ps_ready(ps)) return rc;
   // storage order of members may be permuted by pp_ps_swap_members: normalise first
   for (int m = 0; m < ps->nmembers; ++m)
     if (ps->member_map[m] != m) {

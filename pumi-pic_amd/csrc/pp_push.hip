@@ -124,6 +124,7 @@ __global__ void k_pseudo_push160(int capacity, const unsigned char* __restrict__
 }
 
 int check_member(const pp_ps* ps, int m, int bytes, int ncomp, const char* what) {
+  if (int rc = pp::ps_ready(ps)) return rc;  // a member that is only logically zero gets its zeros now
   if (m < 0 || m >= ps->nmembers) {
     pp::set_error(std::string(what) + ": member index out of range");
     return PP_EINVAL;

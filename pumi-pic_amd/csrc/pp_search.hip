@@ -1563,6 +1563,7 @@ int read_counters(Counters* h) {
 }
 
 int member_ok(const pp_ps* ps, int m, int bytes, int ncomp, const char* what) {
+  if (int rc = pp::ps_ready(ps)) return rc;  // a member that is only logically zero gets its zeros now
   if (m < 0 || m >= ps->nmembers) {
     pp::set_error(std::string(what) + ": member index out of range");
     return PP_EINVAL;
@@ -1844,6 +1845,11 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
   PP_REQUIRE(mesh && ps && elem_ids_dev, "pp_push_search: null argument");
   PP_REQUIRE(ps->num_elems == mesh->nelems, "pp_push_search: structure/mesh element mismatch");
   int rc;
+  // x_tgt left "logically zero" by the in-place rebuild's fused updatePtclPositions: the 3-D push
+  // overwrites all three components of every live particle, so the zeros are never written
+  if (mesh->dim == 3 && m_xtgt >= 0 && m_xtgt < ps->nmembers && m_x != m_xtgt &&
+      ps->zero_pending == ps->member_map[m_xtgt])
+    ps->zero_pending = -1;
   if ((rc = member_ok(ps, m_x, 8, 3, "pp_push_search x"))) return rc;
   if ((rc = member_ok(ps, m_xtgt, 8, 3, "pp_push_search x_tgt"))) return rc;
   if ((rc = member_ok(ps, m_b, 4, 1, "pp_push_search b"))) return rc;

@@ -1,6 +1,20 @@
 """Shared builders for parity tests: the same synthetic mesh + particle population is loaded
 into the CPU oracle (oracle/ppo.py) and into the HIP library (pumi-pic_amd/capi.py)."""
+import os
+
 import numpy as np
+
+# PP_TEST_SHUFFLING=0 runs the suite with the reference's reshuffle fast path switched off on both
+# sides (SellCSigma::setShuffling): every rebuild is the full counting-sort re-layout.  Default: on,
+# like the reference -- the in-place rebuild is what normally runs.
+SHUFFLING = os.environ.get("PP_TEST_SHUFFLING", "1") != "0"
+
+
+def set_shuffling(*structures, on=None):
+    for ps in structures:
+        if ps is not None and hasattr(ps, "set_try_shuffling"):
+            ps.set_try_shuffling(SHUFFLING if on is None else on)
+
 
 
 def population_2d(synth, n_b=12, n_theta=48, num_ptcls=3000, mdl_face=3, band_width=3):
@@ -118,3 +132,33 @@ def radial_kick(xt, dim, h, k, seed=3, lo=0.75, hi=1.3):
         out[0], out[1] = xt[0] * rn / r, xt[1] * rn / r
         out[2] = k + (xt[2] - k) * s
     return out
+
+
+def check_scs_valid(ps, ne):
+    """structural validity of an SCS layout whatever policy produced it: rows <-> elements is a
+    bijection, every slot's parent follows its row, live slots are a prefix of every row, offsets
+    tile [0, capacity)"""
+    L = ps.layout()
+    C_, nrows, cap = L["C"], L["num_rows"], L["capacity"]
+    r2e, e2r = L["row_to_element"], L["element_to_row"]
+    assert len(r2e) == nrows and np.array_equal(np.sort(r2e), np.arange(nrows))
+    assert np.array_equal(e2r[r2e], np.arange(nrows))
+    off, s2c = L["offsets"], L["slice_to_chunk"]
+    assert off[0] == 0 and off[-1] == cap and np.all(np.diff(off) >= 0) and np.all(np.diff(off) % C_ == 0)
+    assert np.all(np.diff(s2c) >= 0)
+    se, mk = L["slot_elem"], L["mask"].astype(bool)
+    for s in range(len(s2c)):
+        c, lo, hi = s2c[s], off[s], off[s + 1]
+        if hi == lo:
+            continue
+        blk_e = se[lo:hi].reshape(-1, C_)
+        assert np.all(blk_e == r2e[c * C_:(c + 1) * C_][None, :]), "slot parent != row element"
+    # prefix compactness: per chunk, concatenate the slices' columns and check monotone masks
+    first = {}
+    for s in range(len(s2c)):
+        first.setdefault(int(s2c[s]), []).append(s)
+    for c, sl in first.items():
+        cols = np.concatenate([mk[off[s]:off[s + 1]].reshape(-1, C_) for s in sl], axis=0)
+        assert np.all(cols[1:] <= cols[:-1]), "row is not prefix-compact"
+    assert np.all(se[mk] < ne)
+    return L

@@ -462,9 +462,10 @@ def _check_same_population(po, pg, members):
         assert np.array_equal(a, b), m
 
 
+@pytest.mark.parametrize("shuffle", [False, True])
 @pytest.mark.parametrize("kind,C,V,sigma,pad", [("scs", 64, 1024, 2**31 - 1, 0), ("scs", 8, 4, 16, 1),
                                                 ("scs", 32, 16, 2**31 - 1, 2), ("csr", 0, 0, 0, 0)])
-def test_rebuild_matches_oracle(ppo, synth, capi, kind, C, V, sigma, pad):
+def test_rebuild_matches_oracle(ppo, synth, capi, kind, C, V, sigma, pad, shuffle):
     pop = common.population_2d(synth, num_ptcls=5000)
     ne = len(pop["e2v"])
     if kind == "scs":
@@ -472,8 +473,10 @@ def test_rebuild_matches_oracle(ppo, synth, capi, kind, C, V, sigma, pad):
                         particle_elements=pop["elem"], particle_info=pop["info"])
         pg = capi.PS.scs(capi.PARTICLE_XGCM, ne, pop["ppe"], C_=C, sigma=sigma, V=V, pad_strat=pad,
                          particle_elements=pop["elem"], particle_info=pop["info"])
-        po.set_try_shuffling(False)  # the HIP rebuild is always the full re-layout
+        common.set_shuffling(po, pg, on=shuffle)
     else:
+        if shuffle:
+            pytest.skip("CSR has no in-place rebuild (csr/CSR_rebuild.hpp)")
         po = ppo.PS.csr(ppo.PARTICLE_XGCM, ne, pop["ppe"], particle_elements=pop["elem"],
                         particle_info=pop["info"])
         pg = capi.PS.csr(capi.PARTICLE_XGCM, ne, pop["ppe"], particle_elements=pop["elem"],
@@ -487,8 +490,8 @@ def test_rebuild_matches_oracle(ppo, synth, capi, kind, C, V, sigma, pad):
         idg = pg.member(2)[0, :pg.capacity()]
         # per-particle decision keyed by id so both structures apply the same moves
         dec = rng.integers(0, ne, size=next_id).astype(np.int32)
-        stay = rng.random(next_id) < 0.5
-        dele = rng.random(next_id) < 0.1
+        stay = rng.random(next_id) < (0.5 if it % 2 == 0 or not shuffle else 0.97)
+        dele = rng.random(next_id) < (0.1 if it % 2 == 0 or not shuffle else 0.01)
         def new_elems(slot_e, mask, ids):
             out = np.full(len(slot_e), -1, dtype=np.int32)
             live = mask.astype(bool)
@@ -506,7 +509,10 @@ def test_rebuild_matches_oracle(ppo, synth, capi, kind, C, V, sigma, pad):
                         rng.random(n_new).astype(np.float32), rng.random(n_new).astype(np.float32)]
             next_id += n_new
         po.rebuild(new_elems(so, mo, ido), add_e if n_new else None, add_info)
+        before = pg.rebuild_stats() if kind == "scs" else (0, 0)
         pg.rebuild(new_elems(sg, mg, idg), add_e if n_new else None, add_info)
+        if kind == "scs":  # the two sides take the same reshuffle-or-rebuild decision
+            assert bool(po.s.last_rebuild_was_shuffle) == (pg.rebuild_stats()[0] > before[0])
         assert po.nPtcls() == pg.nPtcls()
         _check_same_population(po, pg, ppo.PARTICLE_XGCM)
         if kind == "scs":
@@ -535,7 +541,7 @@ def test_rebuild_commit_equals_update_then_rebuild(ppo, synth, capi):
     pop = common.population_2d(synth, num_ptcls=4000)
     mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
     mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
-    po.set_try_shuffling(False)
+    common.set_shuffling(po, pg)
     for step in range(3):
         ppo.elliptical_push(po, mo, H, K, D, 3.0, trig=1)
         _, ids_o, _ = ppo.search_mesh_2d(mo, po, looplimit=200)
@@ -561,6 +567,10 @@ def test_rebuild_delete_all_then_refill(ppo, synth, capi):
                      particle_info=pop["info"])
     pg.rebuild(np.full(pg.capacity(), -1, dtype=np.int32))
     assert pg.nPtcls() == 0
+    # the reference means to clear the mask here (SCS_rebuild.h:168-176) but its resetMask runs after
+    # num_ptcls = 0 and parallel_for returns at once; the library does clear it: no ghost particles for
+    # callers that walk slots by mask
+    assert not pg.slot_info()[1].any()
     n_new = 50
     info = [np.ones((3, n_new)), np.zeros((3, n_new)), np.arange(n_new, dtype=np.int32),
             np.ones(n_new, np.float32), np.ones(n_new, np.float32)]
@@ -592,7 +602,7 @@ def test_pseudo_xgcm_steps_2d(ppo, synth, capi, kind):
     mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM, kind)
     mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM, kind)
     if kind == "scs":
-        po.set_try_shuffling(False)
+        common.set_shuffling(po, pg)
     fo, bo = ppo.create_gyro_ring_mappings(mo, trig=1)
     fg, bg = capi.create_gyro_ring_mappings(mg)
     for step in range(15):
@@ -699,7 +709,7 @@ def test_migration_records_two_virtual_ranks(ppo, synth, capi, fused):
     owners = (np.arange(ne) * world // ne).astype(np.int32)
     mesh = capi.Mesh(2, pop["coords"], pop["e2v"], pop["cls"])
     mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
-    po.set_try_shuffling(False)
+    common.set_shuffling(po)
     ranks = []
     for r in range(world):
         mine = owners[pop["elem"]] == r
@@ -838,7 +848,7 @@ def test_pseudo_xgcm_steps_3d(ppo, synth, capi):
     pop = common.population_3d(synth, n_b=5, n_theta=20, n_planes=8, num_ptcls=4000)
     mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
     mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
-    po.set_try_shuffling(False)
+    common.set_shuffling(po, pg)
     fo, bo = ppo.create_gyro_ring_mappings(mo, trig=1)
     fg, bg = capi.create_gyro_ring_mappings(mg)
     for step in range(8):
@@ -905,7 +915,7 @@ def test_cpp_driver_pseudo_push_and_search(ppo, synth, capi, tmp_path):
     # the oracle's version of the loop
     pop = common.population_box(synth, n=6, num_ptcls=npt)
     mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_PUSH, C=64)
-    po.set_try_shuffling(False)
+    common.set_shuffling(po)
     touched = np.zeros(len(e2v), dtype=bool)
     touched[np.unique(po.slot_info()[0][po.slot_info()[1].astype(bool)])] = True
     hits, it = 0, 1
@@ -1333,7 +1343,8 @@ def test_rebuild_scatter_one_call(ppo, synth, capi, kind, commit):
         assert np.array_equal(capi.gyro_scatter(mg, pg, fg).to_host(), wf.to_host())
 
 
-def test_rebuild_speculative_and_checked_paths_alternate(ppo, synth, capi):
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_rebuild_speculative_and_checked_paths_alternate(ppo, synth, capi, shuffle):
     """The rebuild enqueues its tail speculatively when the buffers have room and falls back to the
     checked path otherwise (DESIGN "The host sync").  Sequence: steady rebuilds (speculation holds) ->
     a burst of new particles that outgrows every buffer (speculation fails after it was enqueued) ->
@@ -1347,7 +1358,7 @@ def test_rebuild_speculative_and_checked_paths_alternate(ppo, synth, capi):
                     particle_info=pop["info"])
     pg = capi.PS.scs(capi.PARTICLE_XGCM, ne, pop["ppe"], C_=64, particle_elements=pop["elem"],
                      particle_info=pop["info"])
-    po.set_try_shuffling(False)
+    common.set_shuffling(po, pg, on=shuffle)
     rng = np.random.default_rng(17)
     next_id = 3000
 
@@ -1379,7 +1390,15 @@ def test_rebuild_speculative_and_checked_paths_alternate(ppo, synth, capi):
         next_id += n_new
         assert po.nPtcls() == pg.nPtcls()
         _check_same_population(po, pg, ppo.PARTICLE_XGCM)
+        lo, lg = po.layout(), pg.layout()  # same reshuffle-or-rebuild decision => same layout arrays
+        for k in ("C", "num_chunks", "num_slices", "capacity", "num_rows"):
+            assert lo[k] == lg[k], (k, lo[k], lg[k])
+        for k in ("offsets", "slice_to_chunk", "row_to_element", "element_to_row"):
+            assert np.array_equal(lo[k], lg[k]), k
+        assert bool(po.s.last_rebuild_was_shuffle) == (pg.rebuild_stats()[0] > stats[0])
+        stats[0] = pg.rebuild_stats()[0]
 
+    stats = [0]
     for _ in range(3):
         step(0.3, 0)
     step(0.3, 90000)           # outgrows mask / slot / staging / swap buffers
@@ -1400,3 +1419,69 @@ def test_rebuild_speculative_and_checked_paths_alternate(ppo, synth, capi):
     step(0.5, 2000)
     for _ in range(2):
         step(0.2, 0)
+
+
+@pytest.mark.parametrize("C,pad_strat,shuffle_padding", [(64, 0, 0.1), (8, 0, 0.5), (32, 0, 0.3)])
+def test_elastic_rebuild_keeps_a_valid_layout(ppo, synth, capi, C, pad_strat, shuffle_padding):
+    """pp_ps_set_shuffling mode 2 (experimental): rows that overflow their padding trade places with rows
+    of wider chunks or move into appended chunks instead of forcing the full re-layout.  After every rebuild the structure is a valid
+    SCS (bijection rows <-> elements, prefix-compact rows, slot parents) and holds, element by element,
+    the same particles with the same member values as the oracle; offsets / slices / capacity are
+    untouched by a rebuild that kept the layout."""
+    pop = common.population_2d(synth, n_b=16, n_theta=64, num_ptcls=40000, mdl_face=4, band_width=4)
+    ne = len(pop["e2v"])
+    po = ppo.PS.scs(ppo.PARTICLE_XGCM, ne, pop["ppe"], C_max=C, pad_strat=pad_strat, shuffle_padding=shuffle_padding,
+                    particle_elements=pop["elem"], particle_info=pop["info"])
+    pg = capi.PS.scs(capi.PARTICLE_XGCM, ne, pop["ppe"], C_=C, pad_strat=pad_strat, shuffle_padding=shuffle_padding,
+                     particle_elements=pop["elem"], particle_info=pop["info"])
+    pg.set_try_shuffling(2)
+    rng = np.random.default_rng(5)
+    nid = 40000
+    kept = traded = 0
+    for it in range(10):
+        dec = rng.integers(0, ne, size=nid).astype(np.int32)
+        mv = rng.random(nid) < (0.08 if it != 6 else 0.6)
+        dl = rng.random(nid) < 0.01
+        outs = []
+        for ps_ in (po, pg):
+            se, mk = ps_.slot_info()
+            ids = ps_.member(2)[0, :ps_.capacity()]
+            new = np.full(len(se), -1, dtype=np.int32)
+            live = mk.astype(bool)
+            i = ids[live]
+            e = np.where(mv[i], dec[i], se[live])
+            new[live] = np.where(dl[i], -1, e)
+            outs.append(new)
+        n_new = 50 if it % 3 == 1 else 0
+        add_e = rng.integers(0, ne, size=n_new).astype(np.int32)
+        add = None
+        if n_new:
+            add = [rng.random((3, n_new)), rng.random((3, n_new)), np.arange(nid, nid + n_new, dtype=np.int32),
+                   rng.random(n_new).astype(np.float32), rng.random(n_new).astype(np.float32)]
+            nid += n_new
+        before = pg.layout()
+        st0 = pg.rebuild_stats()
+        commit = it % 2 == 0 and n_new == 0
+        if commit:
+            ppo.update_positions(po)
+        po.rebuild(outs[0], add_e if n_new else None, add)
+        if commit:
+            pg.rebuild_commit(outs[1])
+        else:
+            pg.rebuild(outs[1], add_e if n_new else None, add)
+        capi.sync()
+        st1 = pg.rebuild_stats()
+        assert po.nPtcls() == pg.nPtcls()
+        _check_same_population(po, pg, ppo.PARTICLE_XGCM)
+        after = common.check_scs_valid(pg, ne)
+        if st1[0] > st0[0]:  # kept the layout: rows traded places, chunks may have been appended
+            kept += 1
+            assert before["C"] == after["C"]
+            ns, nr = before["num_slices"], before["num_rows"]
+            assert after["num_chunks"] >= before["num_chunks"] and after["capacity"] >= before["capacity"]
+            assert np.array_equal(before["offsets"][:ns + 1], after["offsets"][:ns + 1])
+            assert np.array_equal(before["slice_to_chunk"], after["slice_to_chunk"][:ns])
+            moved = st1[2] - st0[2]
+            traded += moved
+            assert int((before["row_to_element"] != after["row_to_element"][:nr]).sum()) <= moved
+    assert kept >= 5 and traded > 0, (kept, traded)

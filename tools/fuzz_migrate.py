@@ -43,7 +43,6 @@ def main(seconds=60.0, seed=0):
         owners = (np.arange(ne, dtype=np.int64) * world // ne).astype(np.int32)
         mesh = capi.Mesh(2, pop["coords"], pop["e2v"], pop["cls"])
         mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
-        po.set_try_shuffling(False)
         fo, bo = ppo.create_gyro_ring_mappings(mo, trig=1)
         fg, bg = capi.create_gyro_ring_mappings(mesh)
         owners_d = capi.DevArray.from_host(owners)
@@ -98,7 +97,7 @@ def main(seconds=60.0, seed=0):
             ok = c_f and c_b
             ids_all, elem_all, x_all = [], [], []
             for r, ps in enumerate(ranks):
-                if ps.nPtcls() == 0:  # an emptied structure keeps its old mask (SCS_rebuild.h:168-176)
+                if ps.nPtcls() == 0:  # (the oracle keeps a stale mask behind an emptying rebuild, SCS_rebuild.h:168-176)
                     continue
                 se, mk = ps.slot_info()
                 cap = ps.capacity()

@@ -48,7 +48,6 @@ def main(seconds=60.0, seed=0):
         C = int(rng.choice([1, 8, 48, 64]))
         mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM, kind, C=C)
         mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM, kind, C=C)
-        po.set_try_shuffling(False)
         desc = "dim %d %s C=%d np=%d ne=%d" % (dim, kind, C, npt, mo.nelems)
         deg = float(rng.choice([0.0, 0.5, 3.0, 12.0, 40.0]))
         limit = int(rng.choice([0, 1, 2, 5, 200]))
@@ -168,7 +167,15 @@ def main(seconds=60.0, seed=0):
                     ids_g = capi.DevArray.from_host(np.full(max(pg.capacity(), 1), -1, dtype=np.int32))
                     io, xo = by_id(po, po.member(0))
                     ig, xg = by_id(pg, pg.member(0))
-                    ok &= np.array_equal(io, ig) and np.array_equal(xo, xg)
+                    c5 = np.array_equal(io, ig) and np.array_equal(xo, xg)
+                    if po.nPtcls() == 0 and pg.nPtcls() == 0:
+                        c5 = True  # the reference leaves a stale mask behind an emptying rebuild (SCS_rebuild.h:168-176
+                        #            runs resetMask after num_ptcls = 0, and parallel_for returns at once); the library clears it
+                    if not c5:
+                        print("after rebuild_commit step %d: ids %s x %s (oracle %d gpu %d particles, rebuild stats %s, "
+                              "oracle shuffled %d)" % (step, np.array_equal(io, ig), io.shape == ig.shape and np.array_equal(xo, xg),
+                                                        po.nPtcls(), pg.nPtcls(), pg.rebuild_stats(), po.s.last_rebuild_was_shuffle))
+                    ok &= c5
                     if po.nPtcls() == 0:
                         break
         if ok and rng.random() < 0.3 and po.nPtcls() > 0:  # gyro ring maps + scatter, random ring geometry
