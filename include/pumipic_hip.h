@@ -452,6 +452,9 @@ int pp_allreduce_sum(pp_comm* c, double* buf_dev, int64_t n);
 /* MPI_Allreduce(MPI_LONG, SUM) of a few host values (particle totals, test/pseudoXGCm.cpp:508,523) */
 int pp_allreduce_sum_host_i64(pp_comm* c, int64_t* vals_host, int n);
 int pp_comm_barrier(pp_comm* c);
+/* MPI_Allgather of nbytes host bytes per rank (timing summaries: SummarizeTimeAcrossProcesses,
+ * support/ppTiming.cpp:220-300 reduces max / min / average over ranks) */
+int pp_comm_allgather_host(pp_comm* c, const void* send_host, void* recv_host, int nbytes);
 
 /* SellCSigma::migrate / CSR::migrate (scs/SCS_migrate.h:5-222, particle_structure.hpp:97-101):
  * particles with new_process != rank leave (counted, packed as records, exchanged, removed), the

@@ -146,6 +146,7 @@ SYMBOLS = {
     "pp_allreduce_sum": (_I, [_V, _V, C.c_int64]),
     "pp_allreduce_sum_host_i64": (_I, [_V, C.POINTER(C.c_int64), _I]),
     "pp_comm_barrier": (_I, [_V]),
+    "pp_comm_allgather_host": (_I, [_V, _V, _V, _I]),
     "pp_ps_migrate": (_I, [_V, _V, _V, _V]),
     "pp_ps_migrate_scatter": (_I, [_V, _I, _I, _V, _V, _V, _I, _V, _V, _V, C.c_int64, _V, _I, _V, _V,
                                    C.c_double, _I, _I]),
@@ -969,6 +970,12 @@ class Comm:
 
     def barrier(self):
         check(lib().pp_comm_barrier(self.p))
+
+    def allgather_host(self, values):
+        v = np.ascontiguousarray(values)
+        out = np.empty((self.size(),) + v.shape, dtype=v.dtype)
+        check(lib().pp_comm_allgather_host(self.p, v.ctypes.data, out.ctypes.data, v.nbytes))
+        return out
 
     def destroy(self):
         if self.p:

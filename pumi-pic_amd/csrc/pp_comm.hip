@@ -703,6 +703,36 @@ int pp_allreduce_sum_host_i64(pp_comm* c, int64_t* vals_host, int n) {
   return PP_ESTATE;
 }
 
+int pp_comm_allgather_host(pp_comm* c, const void* send_host, void* recv_host, int nbytes) {
+  PP_REQUIRE(c && send_host && recv_host && nbytes >= 0, "pp_comm_allgather_host: bad argument");
+  const int n = c->nranks;
+  if (c->kind == 0 || nbytes == 0) {
+    memcpy(recv_host, send_host, (size_t)nbytes);
+    return PP_OK;
+  }
+  if (c->kind == 2 || c->kind == 3) {  // every rank sends the same bytes to every rank
+    PP_REQUIRE(c->ops.alltoallv_bytes, "host communicator: alltoallv_bytes callback missing");
+    std::vector<int64_t> sb((size_t)n, nbytes), sd((size_t)n, 0), rb((size_t)n, nbytes), rd((size_t)n);
+    for (int r = 0; r < n; ++r) rd[(size_t)r] = (int64_t)r * nbytes;
+    sb[(size_t)c->rank] = rb[(size_t)c->rank] = 0;
+    memcpy((char*)recv_host + (size_t)c->rank * nbytes, send_host, (size_t)nbytes);
+    const int rc = c->ops.alltoallv_bytes(c->user, send_host, sb.data(), sd.data(), recv_host, rb.data(), rd.data());
+    return rc ? (rc < 0 ? rc : PP_EHIP) : PP_OK;
+  }
+  if (c->kind == 1) {
+    hipStream_t st = pp::stream();
+    PP_HIP_CHECK(c->d_small.reserve((size_t)nbytes * ((size_t)n + 1)));
+    char* d = (char*)c->d_small.p;
+    PP_HIP_CHECK(hipMemcpyAsync(d, send_host, (size_t)nbytes, hipMemcpyHostToDevice, st));
+    PP_NCCL_CHECK(pp::rccl()->AllGather(d, d + nbytes, (size_t)nbytes, ncclChar, (ncclComm_t)c->nccl, st));
+    PP_HIP_CHECK(hipMemcpyAsync(recv_host, d + nbytes, (size_t)nbytes * n, hipMemcpyDeviceToHost, st));
+    PP_HIP_CHECK(hipStreamSynchronize(st));
+    return PP_OK;
+  }
+  pp::set_error("pp_comm_allgather_host: not available on a local communicator");
+  return PP_ESTATE;
+}
+
 int pp_comm_barrier(pp_comm* c) {
   PP_REQUIRE(c, "pp_comm_barrier: null communicator");
   if (pp::initialised()) PP_HIP_CHECK(hipStreamSynchronize(pp::stream()));

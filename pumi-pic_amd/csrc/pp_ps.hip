@@ -2355,6 +2355,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   int C_new = ps->C_max;
   int ntiles_max = 0;
   int NQ = 0;
+  bool lazy_zero = false;
   // Everything after the layout: new layout arrays, slot tables and the move of every member.
   // `cap_sz` / `nsl_sz` size the buffers and the launches; the kernels themselves read the true
   // counts from the device (ntiles, Totals), and all of them return at once when tot->go == 0.
@@ -2426,6 +2427,11 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       const void* srcs[8];
       for (int m = 0; m < ps->nmembers; ++m) srcs[m] = ps->data[m].p;
       NQ = build_word_table(ps, srcs, ps->stride, swap_stride, commit_x, commit_xt, wt);
+      // x_tgt <- 0 of the fused updatePtclPositions stays pending (pp_ps::zero_pending): the next fused
+      // push overwrites the member, anything else materialises the zeros first.  24 of the 60 bytes
+      // pass 2 would write per particle.
+      lazy_zero = NQ > 0 && commit_x >= 0 && commit_xt >= 0 && n_new == 0 && getenv("PP_NO_LAZY_ZERO") == nullptr;
+      if (lazy_zero) wt.nz8 = wt.nz4 = 0;
     }
     if (NQ > 0) {
       PP_HIP_CHECK(ps->s_aos.reserve((size_t)std::max(cap_sz, 1) * NQ * 16));
@@ -2589,6 +2595,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   // ---- swap in
   ps->data.swap(ps->swap);
   std::swap(ps->stride, ps->swap_stride);
+  ps->zero_pending = lazy_zero ? commit_xt : -1;
   ps->d_offsets.swap(ps->s_offsets2);
   ps->d_slice_to_chunk.swap(ps->s_s2c2);
   ps->d_row_to_element.swap(ps->s_r2e2);
@@ -3026,6 +3033,7 @@ int pp_ps_member_from_host(pp_ps* ps, int m, const void* in_host) {
 
 int pp_ps_rebuild(pp_ps* ps, const int* new_element_dev, int n_new, const int* new_elems_dev,
                   const void* const* new_info_dev) {
+  pp::Range rg_("ps_rebuild");
   PP_REQUIRE(ps && (new_element_dev || ps->capacity == 0), "pp_ps_rebuild: null argument");
   PP_REQUIRE(n_new >= 0 && (n_new == 0 || new_elems_dev), "pp_ps_rebuild: bad new particles");
   if (int rc = pp::ps_ready(ps)) return rc;

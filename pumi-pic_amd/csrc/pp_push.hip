@@ -157,6 +157,7 @@ int pp_elliptical_setup(pp_ps* ps, int m_x, int m_b, int m_phi, double h, double
 
 int pp_elliptical_push(pp_ps* ps, const pp_mesh* mesh, int m_xtgt, int m_b, int m_phi, double h,
                        double k, double d, double deg) {
+  pp::Range rg_("ellipticalPush");
   PP_REQUIRE(ps && mesh, "pp_elliptical_push: null argument");
   PP_REQUIRE(ps->num_elems == mesh->nelems, "pp_elliptical_push: structure/mesh element mismatch");
   int rc;

@@ -423,6 +423,7 @@ int pp_create_gyro_ring_mappings(const pp_mesh* mesh, double rmax, int gnr, int 
 
 int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, double rmax, int gnr,
                     int gppr, double* scatter_w_dev) {
+  pp::Range rg_("xgcm_gyroScatter");
   PP_REQUIRE(mesh && ps && v2v_dev && scatter_w_dev, "pp_gyro_scatter: null argument");
   PP_REQUIRE(ps->num_elems == mesh->nelems, "pp_gyro_scatter: structure/mesh element mismatch");
   PP_REQUIRE(gnr >= 2 && gppr > 0, "pp_gyro_scatter: needs gnr >= 2 (ringUp < gnr, gyroScatter.hpp:190)");

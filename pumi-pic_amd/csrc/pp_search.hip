@@ -1583,6 +1583,7 @@ extern "C" {
 
 int pp_search_mesh_2d(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_pid,
                       int* elem_ids_dev, int looplimit, int* found) {
+  pp::Range rg_("search_mesh_2d");
   (void)m_x;
   (void)m_pid;
   PP_REQUIRE(mesh && ps && elem_ids_dev, "pp_search_mesh_2d: null argument");
@@ -1613,6 +1614,7 @@ int pp_search_mesh(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_pi
                    int* elem_ids_dev, int elem_ids_seeded, int requireIntersection,
                    int* inter_faces_dev, double* inter_points_dev, int looplimit, int* found,
                    int* num_not_in_elem) {
+  pp::Range rg_("search_mesh");
   (void)m_pid;
   PP_REQUIRE(mesh && ps && elem_ids_dev, "pp_search_mesh: null argument");
   PP_REQUIRE(ps->num_elems == mesh->nelems, "pp_search_mesh: structure/mesh element mismatch");
@@ -1842,6 +1844,7 @@ int pp_search_mesh_3d(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m
 int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b, int m_phi,
                    double h, double k, double d, double deg, int* elem_ids_dev,
                    int elem_ids_seeded, int looplimit, int* found) {
+  pp::Range rg_("pp_push_search");
   PP_REQUIRE(mesh && ps && elem_ids_dev, "pp_push_search: null argument");
   PP_REQUIRE(ps->num_elems == mesh->nelems, "pp_push_search: structure/mesh element mismatch");
   int rc;

@@ -1,85 +1,161 @@
 // pseudoXGCm driver on the MI355X-native particle_structs mirror.
 //
-// Follows the reference driver's step loop (test/pseudoXGCm.cpp:422-534): build the SCS from a
-// Gaussian particles-per-element draw, place particles uniformly in their triangles, set up the
-// elliptical push state, then per iteration  push -> search_mesh_2d -> updatePtclPositions +
-// migrate/rebuild -> tagParentElements -> gyroScatter x2.  The push and the bookkeeping kernels
-// are USER lambdas run through ps::parallel_for exactly as in the reference; search, rebuild
-// and scatter go through the C-ABI.
+// The step loop, the helper functions and their signatures follow test/pseudoXGCm.cpp:102-534 of the
+// reference: setSourceElements / setInitialPtclCoords / setPtclIds / updatePtclPositions / rebuild /
+// search / tagParentElements are the reference's functions on the mirror types (user lambdas run
+// through ps::parallel_for), ellipticalPush.hpp and gyroScatter.hpp are mirrored next to this file.
+// What differs from the reference source: the includes, the mesh reader (the pumipic-data .osh / .ppm
+// files are not available: a flat binary container or Gmsh .msh, then Mesh::partition instead of a
+// .ppm partition file) and MPI, which is replaced by the launcher environment (RANK, WORLD_SIZE,
+// LOCAL_RANK, MASTER_ADDR, MASTER_PORT; PP_COMM=rccl|tcp) behind pumipic::comm_world().
 //
 //   usage: pseudoXGCm <mesh.bin | mesh.msh> <numPtcls> <max initial model face> <maxIterations>
 //                     <degrees per elliptical push> <enable prebarrier>
-// <mesh.bin> is the container written by pumi-pic_amd/synth.py:write_mesh_bin (the pumipic-data
-// .osh/.ppm meshes of the reference are not available).
 #include <cmath>
-#include <random>
 #include <iostream>
-#include "../include/pumipic_adjacency.hpp"
+#include <random>
+#include "ellipticalPush.hpp"
+#include "gyroScatter.hpp"
 #include "../include/pumipic_gmsh.hpp"
 
 #define ELEMENT_SEED 1024 * 1024
 #define PARTICLE_SEED 512 * 512
 
-using particle_structs::lid_t;
-using particle_structs::MemberTypes;
-using particle_structs::SellCSigma;
-using pumipic::fp_t;
-using pumipic::Vector3d;
+void updatePtclPositions(PS* ptcls) {
+  auto x_ps_d = ptcls->get<0>();
+  auto xtgt_ps_d = ptcls->get<1>();
+  auto updatePtclPos = PS_LAMBDA(const int&, const int& pid, const int&) {
+    x_ps_d(pid, 0) = xtgt_ps_d(pid, 0);
+    x_ps_d(pid, 1) = xtgt_ps_d(pid, 1);
+    x_ps_d(pid, 2) = xtgt_ps_d(pid, 2);
+    xtgt_ps_d(pid, 0) = 0;
+    xtgt_ps_d(pid, 1) = 0;
+    xtgt_ps_d(pid, 2) = 0;
+  };
+  ps::parallel_for(ptcls, updatePtclPos);
+}
 
-// positions now / after the push, particle id, ellipse semi-axis b, ellipse angle phi
-typedef MemberTypes<Vector3d, Vector3d, int, float, float> Particle;
-typedef ps::ParticleStructure<Particle> PS;
+void rebuild(p::Mesh& picparts, PS* ptcls, p::Distributor& dist, o::LOs elem_ids, const bool output) {
+  (void)dist;
+  (void)output;
+  updatePtclPositions(ptcls);
+  pumipic::migrate_lb_ptcls(picparts, ptcls, elem_ids, 1.05);
+}
 
-namespace ellipticalPush {
-double h, k, d;
-void setup(PS* ptcls, double h_in, double k_in, double d_in) {
-  h = h_in;
-  k = k_in;
-  d = d_in;
-  auto x_nm1 = ptcls->get<0>();
-  auto ptcl_b = ptcls->get<3>();
-  auto ptcl_phi = ptcls->get<4>();
-  const double hd = h, kd = k, dd = d;
-  auto setMajorAxis = PS_LAMBDA(const int&, const int& pid, const int& mask) {
-    if (mask) {
-      const double w = x_nm1(pid, 0), z = x_nm1(pid, 1);
-      const double phi = atan2(dd * (z - kd), w - hd);
-      ptcl_phi(pid) = (float)phi;
-      ptcl_b(pid) = (float)((z - kd) / sin(phi));
+void search(p::Mesh& picparts, PS* ptcls, p::Distributor& dist, bool output) {
+  o::Mesh* mesh = picparts.mesh();
+  Omega_h::LO maxLoops = 200;
+  const auto psCapacity = ptcls->capacity();
+  o::Write<o::LO> elem_ids((size_t)psCapacity, -1);
+  auto x = ptcls->get<0>();
+  auto xtgt = ptcls->get<1>();
+  auto pid = ptcls->get<2>();
+  bool isFound = p::search_mesh_2d(*mesh, ptcls, x, xtgt, pid, elem_ids, maxLoops);
+  if (!isFound) {  // assert(isFound) in the reference
+    fprintf(stderr, "search_mesh_2d did not find every particle\n");
+    exit(EXIT_FAILURE);
+  }
+  // rebuild the PS to set the new element-to-particle lists
+  rebuild(picparts, ptcls, dist, elem_ids, output);
+}
+
+void setPtclIds(PS* ptcls, int id_offset) {
+  auto pid_d = ptcls->get<2>();
+  auto setIDs = PS_LAMBDA(const int&, const int& pid, const int&) { pid_d(pid) = id_offset + pid; };
+  ps::parallel_for(ptcls, setIDs);
+}
+
+int setSourceElements(p::Mesh& picparts, PS::kkLidView ppe, const int mdlFace, const int numPtclsPerRank) {
+  // Deterministically generate random number of particles on each element with classification less
+  // than mdlFace (test/pseudoXGCm.cpp:167-222)
+  int comm_rank = picparts.rank();
+  const auto elm_dim = picparts.dim();
+  o::Mesh* mesh = picparts.mesh();
+  std::vector<int> face_class_ids = mesh->get_array<o::ClassId>(elm_dim, "class_id").to_host();
+  std::vector<int> face_owners = picparts.entOwners(elm_dim).to_host();
+  const int ne = mesh->nelems();
+  std::vector<int> isFaceOnClass((size_t)ne, 0);
+  int numMarked = 0;
+  for (int i = 0; i < ne; ++i)
+    if (face_class_ids[i] <= mdlFace && face_owners[i] == comm_rank) {
+      isFaceOnClass[i] = 1;
+      ++numMarked;
+    }
+  if (!numMarked) return 0;
+  int nppe = numPtclsPerRank / numMarked;
+  std::vector<int> rand_per_elem((size_t)ne, 0);
+  std::default_random_engine generator(ELEMENT_SEED);
+  std::normal_distribution<double> dist(nppe, nppe / 4);
+  int total = 0, last = -1;
+  for (int i = 0; i < ne; ++i) {
+    if (isFaceOnClass[i] && total < numPtclsPerRank) {
+      last = i;
+      rand_per_elem[i] = (int)std::round(dist(generator));
+      if (rand_per_elem[i] < 0) rand_per_elem[i] = 0;
+      total += rand_per_elem[i];
+      if (total > numPtclsPerRank) rand_per_elem[i] -= total - numPtclsPerRank;
+    }
+  }
+  if (total < numPtclsPerRank) rand_per_elem[last] += numPtclsPerRank - total;
+  int np = 0;
+  for (int v : rand_per_elem) np += v;
+  ppe.from_host(rand_per_elem.data());
+  return np;
+}
+
+void setInitialPtclCoords(p::Mesh& picparts, PS* ptcls, bool output) {
+  (void)output;
+  // a particle is placed uniformly at random inside its parent triangle (test/pseudoXGCm.cpp:224-264)
+  o::Mesh* mesh = picparts.mesh();
+  const int cap = ptcls->capacity();
+  std::vector<double> rnd(2 * (size_t)std::max(cap, 1));
+  std::default_random_engine generator(PARTICLE_SEED);
+  std::uniform_real_distribution<double> dist(0.0, 1.0);
+  for (int i = 0; i < cap; ++i) {
+    double x = dist(generator), y = dist(generator);
+    if (x + y > 1) {
+      x = 1 - x;
+      y = 1 - y;
+    }
+    rnd[2 * (size_t)i] = x;
+    rnd[2 * (size_t)i + 1] = y;
+  }
+  o::Write<double> rand_nums(rnd.size());
+  rand_nums.from_host(rnd.data());
+  auto cells2nodes = mesh->ask_elem_verts();
+  auto nodes2coords = mesh->coords();
+  auto x_ps_d = ptcls->get<0>();
+  auto lamb = PS_LAMBDA(const int& e, const int& pid, const int& mask) {
+    if (mask > 0) {
+      const int v0 = cells2nodes[3 * e], v1 = cells2nodes[3 * e + 1], v2 = cells2nodes[3 * e + 2];
+      const double r1 = rand_nums[2 * pid], r2 = rand_nums[2 * pid + 1];
+      for (int i = 0; i < 2; i++)
+        x_ps_d(pid, i) = nodes2coords[2 * v0 + i] + r1 * (nodes2coords[2 * v1 + i] - nodes2coords[2 * v0 + i]) +
+                         r2 * (nodes2coords[2 * v2 + i] - nodes2coords[2 * v0 + i]);
+      x_ps_d(pid, 2) = 0;
     }
   };
-  ps::parallel_for(ptcls, setMajorAxis);
+  ps::parallel_for(ptcls, lamb);
 }
-void push(PS* ptcls, p::Mesh& m, double deg) {
-  p::Timer timer;
-  auto class_ids = m.class_ids();
-  auto x_nm0 = ptcls->get<1>();
-  auto ptcl_b = ptcls->get<3>();
-  auto ptcl_phi = ptcls->get<4>();
-  const double hd = h, kd = k, dd = d;
-  auto setPosition = PS_LAMBDA(const int& e, const int& pid, const int& mask) {
-    if (mask) {
-      const double centerFactor = class_ids[e] == 1 ? 0.01 : 1.0;
-      const double degP = deg * (centerFactor * 1.0 / class_ids[e]);
-      const float phi = ptcl_phi(pid), b = ptcl_b(pid);
-      const double rad = phi + degP * M_PI / 180.0;
-      x_nm0(pid, 0) = (b * dd) * cos(rad) + hd;
-      x_nm0(pid, 1) = b * sin(rad) + kd;
-      ptcl_phi(pid) = (float)rad;
-    }
-  };
-  ps::parallel_for(ptcls, setPosition);
-  p::RecordTime("elliptical push", timer.seconds());
-}
-}  // namespace ellipticalPush
 
-static bool readMesh(const char* fn, int& dim, std::vector<double>& coords, std::vector<int>& e2v,
+void tagParentElements(p::Mesh& picparts, PS* ptcls, int loop) {
+  // read from the tag, mark the elements that hold particles, write it back (test/pseudoXGCm.cpp:73-91)
+  o::Mesh* mesh = picparts.mesh();
+  o::Write<o::LO> ehp_nm1 = mesh->get_array<o::LO>(picparts.dim(), "has_particles");
+  auto lamb = PS_LAMBDA(const int& e, const int&, const int& mask) {
+    if (mask > 0) ehp_nm1[e] = loop;
+  };
+  ps::parallel_for(ptcls, lamb);
+  mesh->set_tag(o::FACE, "has_particles", o::LOs(ehp_nm1));
+}
+
+static bool readMesh(const char* fn, int rank, int& dim, std::vector<double>& coords, std::vector<int>& e2v,
                      std::vector<int>& cls) {
   // test/pseudoXGCm.cpp:306-324: the extension selects the reader ("msh" = Gmsh ASCII; the Omega_h
   // binary ".osh" format belongs to a library that is not in the reference tree)
   const std::string name(fn);
   if (name.size() > 4 && name.substr(name.size() - 4) == ".msh") {
-    std::cout << "reading gmsh mesh " << name << "\n";
+    if (!rank) std::cout << "reading gmsh mesh " << name << "\n";
     pumipic::gmsh::MeshData m;
     std::string err;
     if (!pumipic::gmsh::read(name, m, &err)) {
@@ -110,130 +186,71 @@ static bool readMesh(const char* fn, int& dim, std::vector<double>& coords, std:
   return ok;
 }
 
-// Gaussian particles-per-element draw over elements with class_id <= mdlFace
-static int setSourceElements(const std::vector<int>& cls, std::vector<lid_t>& ppe, int mdlFace,
-                             int numPtcls) {
-  const int ne = (int)cls.size();
-  int numMarked = 0;
-  for (int i = 0; i < ne; ++i) numMarked += cls[i] <= mdlFace;
-  ppe.assign(ne, 0);
-  if (!numMarked) return 0;
-  const int nppe = numPtcls / numMarked;
-  std::default_random_engine generator(ELEMENT_SEED);
-  std::normal_distribution<double> dist(nppe, nppe / 4);
-  int total = 0, last = -1;
-  for (int i = 0; i < ne; ++i) {
-    if (cls[i] <= mdlFace && total < numPtcls) {
-      last = i;
-      int n = (int)std::round(dist(generator));
-      if (n < 0) n = 0;
-      total += n;
-      if (total > numPtcls) n -= total - numPtcls;
-      ppe[i] = n;
-    }
-  }
-  if (total < numPtcls) ppe[last] += numPtcls - total;
-  int np = 0;
-  for (int v : ppe) np += v;
-  return np;
-}
-
-static void setInitialPtclCoords(p::Mesh& mesh, PS* ptcls) {
-  const int cap = ptcls->capacity();
-  std::vector<double> rnd(2 * (size_t)cap);
-  std::default_random_engine generator(PARTICLE_SEED);
-  std::uniform_real_distribution<double> dist(0.0, 1.0);
-  for (int i = 0; i < cap; ++i) {
-    double x = dist(generator), y = dist(generator);
-    if (x + y > 1) {
-      x = 1 - x;
-      y = 1 - y;
-    }
-    rnd[2 * i] = x;
-    rnd[2 * i + 1] = y;
-  }
-  o::Write<double> rand_nums(rnd.size());
-  rand_nums.from_host(rnd.data());
-  auto cells2nodes = mesh.ask_elem_verts();
-  auto nodes2coords = mesh.coords();
-  auto x_ps_d = ptcls->get<0>();
-  auto pid_d = ptcls->get<2>();
-  auto lamb = PS_LAMBDA(const int& e, const int& pid, const int& mask) {
-    pid_d(pid) = pid;  // setPtclIds
-    if (mask > 0) {
-      const int v0 = cells2nodes[3 * e], v1 = cells2nodes[3 * e + 1], v2 = cells2nodes[3 * e + 2];
-      const double r1 = rand_nums[2 * pid], r2 = rand_nums[2 * pid + 1];
-      for (int i = 0; i < 2; i++)
-        x_ps_d(pid, i) = nodes2coords[2 * v0 + i] + r1 * (nodes2coords[2 * v1 + i] - nodes2coords[2 * v0 + i]) +
-                         r2 * (nodes2coords[2 * v2 + i] - nodes2coords[2 * v0 + i]);
-      x_ps_d(pid, 2) = 0;
-    }
-  };
-  ps::parallel_for(ptcls, lamb);
-}
-
-static void updatePtclPositions(PS* ptcls) {
-  auto x_ps_d = ptcls->get<0>();
-  auto xtgt_ps_d = ptcls->get<1>();
-  auto updatePtclPos = PS_LAMBDA(const int&, const int& pid, const int&) {
-    for (int i = 0; i < 3; ++i) {
-      x_ps_d(pid, i) = xtgt_ps_d(pid, i);
-      xtgt_ps_d(pid, i) = 0;
-    }
-  };
-  ps::parallel_for(ptcls, updatePtclPos);
-}
-
-static void tagParentElements(PS* ptcls, o::Write<o::LO> has_particles, int loop) {
-  auto lamb = PS_LAMBDA(const int& e, const int&, const int& mask) {
-    if (mask > 0) has_particles[e] = loop;
-  };
-  ps::parallel_for(ptcls, lamb);
-}
-
 int main(int argc, char** argv) {
-  if (argc != 7) {
-    printf("numargs %d expected 7\nUsage: %s <mesh.bin> <numPtcls> <max initial model face> "
-           "<maxIterations> <degrees per elliptical push> <enable prebarrier>\n", argc, argv[0]);
-    return 1;
+  const int numargs = 7;
+  if (argc != numargs) {
+    printf("numargs %d expected %d\n", argc, numargs);
+    auto args = "<mesh> <numPtcls> <max initial model face> <maxIterations> "
+                "<degrees per elliptical push> <enable prebarrier>";
+    std::cout << "Usage: " << argv[0] << " " << args << "\n";
+    exit(1);
   }
-  p::pp_check(pp_init(0), "pp_init");
+  // one process per GPU: the launcher's LOCAL_RANK picks the device (PP_DEVICE overrides, e.g. to run
+  // several ranks on one GPU over PP_COMM=tcp)
+  const int device = getenv("PP_DEVICE") ? atoi(getenv("PP_DEVICE")) : (getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0);
+  p::pp_check(pp_init(device), "pp_init");
+  pp_comm* world = pumipic::comm_world();
+  const int comm_rank = pp_comm_rank(world), comm_size = pp_comm_size(world);
+  if (comm_rank == 0) {
+    printf("world ranks %d (%s)\n", comm_size, pp_comm_kind(world));
+    printf("particle_structs floating point value size (bits): %zu\n", sizeof(fp_t));
+  }
+  pumipic::SetTimingVerbosity(0);
+  if (comm_rank == comm_size / 2) pumipic::EnableTiming();
+
   int dim = 0;
   std::vector<double> coords;
   std::vector<int> e2v, cls;
-  if (!readMesh(argv[1], dim, coords, e2v, cls) || dim != 2) {
+  if (!readMesh(argv[1], comm_rank, dim, coords, e2v, cls) || dim != 2) {
     fprintf(stderr, "cannot read a 2-D mesh container from %s\n", argv[1]);
     return EXIT_FAILURE;
   }
-  p::Mesh mesh(dim, coords, e2v, cls);
-  printf("Mesh loaded with <v e f> %d %d %d\n", mesh.nverts(), mesh.nsides(), mesh.nelems());
-  const int ne = mesh.nelems();
+  p::Mesh picparts(dim, coords, e2v, cls);
+  picparts.partition(world);  // element blocks, full mesh buffered, safe zone = own block
+  o::Mesh* mesh = picparts.mesh();
+  if (!comm_rank) printf("Mesh loaded with <v e f> %d %d %d\n", mesh->nverts(), mesh->nsides(), mesh->nelems());
+  p::Distributor dist(world);
 
-  // gyro-average ring maps (gyroScatter.hpp:101-166)
-  const double rmax = 0.038;
-  const int numRings = 3, ptsPerRing = 8;
-  const double theta = 0.0;
-  o::Write<o::LO> forward_map((size_t)mesh.nverts() * numRings * ptsPerRing * 3);
-  o::Write<o::LO> backward_map(forward_map.size());
-  p::pp_check(pp_create_gyro_ring_mappings(mesh.handle(), rmax, numRings, ptsPerRing, theta,
-                                           forward_map.data(), backward_map.data()),
-              "createGyroRingMappings");
+  // Build gyro avg mappings
+  const auto rmax = 0.038;
+  const auto numRings = 3;
+  const auto ptsPerRing = 8;
+  const auto theta = 0.0;
+  setGyroConfig(rmax, numRings, ptsPerRing, theta);
+  if (!comm_rank) printGyroConfig();
+  Omega_h::LOs forward_map;
+  Omega_h::LOs backward_map;
+  createGyroRingMappings(mesh, forward_map, backward_map);
 
-  const int numPtcls = atoi(argv[2]);
-  const int mdlFace = atoi(argv[3]);
-  const int maxIter = atoi(argv[4]);
-  const double degPerPush = atof(argv[5]);
-  std::vector<lid_t> ppe_h;
-  const int actualParticles = setSourceElements(cls, ppe_h, mdlFace, numPtcls);
-  fprintf(stderr, "particles created %d\nmax iterations: %d\n", actualParticles, maxIter);
+  /* Particle data */
+  const long int numPtcls = atol(argv[2]);
+  const int numPtclsPerRank = (int)(numPtcls / comm_size);
+  const bool output = numPtclsPerRank <= 30;
+  int64_t totNumReqPtcls = numPtclsPerRank;
+  p::pp_check(pp_allreduce_sum_host_i64(world, &totNumReqPtcls, 1), "MPI_Allreduce");
+  if (!comm_rank) fprintf(stderr, "particles requested %ld %ld\n", numPtcls, (long)totNumReqPtcls);
+
+  Omega_h::Int ne = mesh->nelems();
   PS::kkLidView ptcls_per_elem("ptcls_per_elem", ne);
-  ptcls_per_elem.from_host(ppe_h.data());
-  PS::kkGidView element_gids("element_gids", ne);
-  {
-    std::vector<pumipic::gid_t> g(ne);
-    for (int i = 0; i < ne; ++i) g[i] = i;
-    element_gids.from_host(g.data());
-  }
+  PS::kkGidView element_gids = picparts.globalIds(picparts.dim());
+  const int mdlFace = atoi(argv[3]);
+  int actualParticles = setSourceElements(picparts, ptcls_per_elem, mdlFace, numPtclsPerRank);
+  int64_t totNumPtcls = actualParticles;
+  p::pp_check(pp_allreduce_sum_host_i64(world, &totNumPtcls, 1), "MPI_Allreduce");
+  if (!comm_rank) fprintf(stderr, "particles created %ld\n", (long)totNumPtcls);
+  const auto maxIter = atoi(argv[4]);
+  if (!comm_rank) fprintf(stderr, "max iterations: %d\n", maxIter);
+
   const int sigma = INT_MAX;  // full sorting
   const int V = 1024;
   pumipic::TeamPolicy policy = pumipic::TeamPolicyAuto(10000, 32);
@@ -242,68 +259,79 @@ int main(int argc, char** argv) {
   scs_input.shuffle_padding = 0.1;
   scs_input.extra_padding = 0;
   scs_input.name = "ps";
-  PS* ptcls = new SellCSigma<Particle>(scs_input);
-  setInitialPtclCoords(mesh, ptcls);
+  ps::ParticleStructure<Particle>* ptcls = new SellCSigma<Particle>(scs_input);
+  setInitialPtclCoords(picparts, ptcls, output);
+  setPtclIds(ptcls, comm_rank * numPtclsPerRank);
 
-  const double h = 1.72479370 - .08, k = .020558260, d = 0.6;
+  // define parameters controlling particle motion
+  const double h = 1.72479370 - .08;
+  const auto k = .020558260;
+  const auto d = 0.6;
   ellipticalPush::setup(ptcls, h, k, d);
-  fprintf(stderr, "degrees per elliptical push %f\nellipse center %f %f ellipse ratio %.3f\n",
-          degPerPush, h, k, d);
+  const auto degPerPush = atof(argv[5]);
+  if (!comm_rank) fprintf(stderr, "degrees per elliptical push %f\n", degPerPush);
+  if (comm_rank == 0) fprintf(stderr, "ellipse center %f %f ellipse ratio %.3f\n", h, k, d);
 
-  o::Write<o::LO> has_particles((size_t)ne, -1);
-  o::Write<o::Real> fwdTag((size_t)mesh.nverts()), bkwdTag((size_t)mesh.nverts()),
-      syncTag(2 * (size_t)mesh.nverts());
-  tagParentElements(ptcls, has_particles, 0);
+  o::LOs elmTags((size_t)ne, -1);
+  mesh->add_tag(o::FACE, "has_particles", 1, elmTags);
+  const auto fwdTagName = "ptclToMeshScatterFwd";
+  mesh->add_tag(o::VERT, fwdTagName, 1, o::Reals((size_t)mesh->nverts(), 0.0));
+  const auto bkwdTagName = "ptclToMeshScatterBkwd";
+  mesh->add_tag(o::VERT, bkwdTagName, 1, o::Reals((size_t)mesh->nverts(), 0.0));
+  const auto syncTagName = "ptclToMeshSync";
+  mesh->add_tag(o::VERT, syncTagName, 2, o::Reals((size_t)mesh->nverts() * 2, 0.0));
+  tagParentElements(picparts, ptcls, 0);
 
+  const auto enable_prebarrier = atoi(argv[6]);
+  if (enable_prebarrier) {
+    if (!comm_rank) fprintf(stderr, "pre-barrier enabled\n");
+    pumipic::enable_prebarrier();
+  }
   p::Timer fullTimer;
   int iter;
+  int64_t totNp = 0;
   for (iter = 1; iter <= maxIter; iter++) {
-    if (iter == 1 || iter == maxIter) ptcls->printMetrics();
-    const long totNp = ptcls->nPtcls();
+    if ((!comm_rank || (comm_rank == comm_size / 2)) && (iter == 1 || iter == maxIter)) ptcls->printMetrics();
+    totNp = ptcls->nPtcls();
+    p::pp_check(pp_allreduce_sum_host_i64(world, &totNp, 1), "MPI_Allreduce");
     if (totNp == 0) {
       fprintf(stderr, "No particles remain... exiting push loop\n");
       break;
     }
-    fprintf(stderr, "iter %d particles %ld\n", iter, totNp);
-    ellipticalPush::push(ptcls, mesh, degPerPush);
-    // search(): search_mesh_2d from every particle's own element, then rebuild
-    o::Write<o::LO> elem_ids((size_t)ptcls->capacity(), -1);
-    auto x = ptcls->get<0>();
-    auto xtgt = ptcls->get<1>();
-    auto pid = ptcls->get<2>();
-    const bool isFound = p::search_mesh_2d(mesh, ptcls, x, xtgt, pid, elem_ids, 200);
-    if (!isFound) {
-      fprintf(stderr, "search_mesh_2d did not find every particle\n");
-      return EXIT_FAILURE;
-    }
-    updatePtclPositions(ptcls);
-    p::migrate_lb_ptcls(mesh, ptcls, elem_ids, 1.05);
-    if (ptcls->nPtcls() == 0) {
+    if (!comm_rank) fprintf(stderr, "iter %d particles %ld\n", iter, (long)totNp);
+    ellipticalPush::push(ptcls, *mesh, degPerPush, iter);
+    p::pp_check(pp_comm_barrier(world), "MPI_Barrier");
+    search(picparts, ptcls, dist, output);
+    totNp = ptcls->nPtcls();
+    p::pp_check(pp_allreduce_sum_host_i64(world, &totNp, 1), "MPI_Allreduce");
+    if (totNp == 0) {
       fprintf(stderr, "No particles remain... exiting push loop\n");
       break;
     }
-    tagParentElements(ptcls, has_particles, iter);
-    p::Timer st;
-    p::pp_check(pp_gyro_scatter(mesh.handle(), ptcls->handle(), forward_map.data(), rmax, numRings,
-                                ptsPerRing, fwdTag.data()), "gyroScatter fwd");
-    p::pp_check(pp_gyro_scatter(mesh.handle(), ptcls->handle(), backward_map.data(), rmax, numRings,
-                                ptsPerRing, bkwdTag.data()), "gyroScatter bkwd");
-    p::pp_check(pp_gyro_sync_pack(mesh.nverts(), fwdTag.data(), bkwdTag.data(), syncTag.data()),
-                "gyroSync");
-    p::RecordTime("gyro scatter", st.seconds());
+    tagParentElements(picparts, ptcls, iter);
+    gyroScatter(mesh, ptcls, forward_map, fwdTagName);
+    gyroScatter(mesh, ptcls, backward_map, bkwdTagName);
+    gyroSync(picparts, fwdTagName, bkwdTagName, syncTagName);
   }
-  const double secs = fullTimer.seconds();
-  fprintf(stderr, "%d iterations of pseudopush (seconds) %f\n", iter, secs);
-  // summary line for the harness: particle count, scatter mass, last-touched element count
-  std::vector<double> w = fwdTag.to_host();
+  if (comm_rank == 0) fprintf(stderr, "%d iterations of pseudopush (seconds) %f\n", iter, fullTimer.seconds());
+
+  // summary line for the harness: particle count over all ranks, mass of the SYNCED forward field (the
+  // sum over ranks of the ranks' scatter fields), elements this rank ever saw particles in
+  std::vector<double> w = mesh->get_array<o::Real>(0, syncTagName).to_host();
   double mass = 0;
-  for (double v : w) mass += v;
-  std::vector<int> hp = has_particles.to_host();
-  int touched = 0;
+  for (size_t v = 0; v < w.size(); v += 2) mass += w[v];
+  std::vector<int> hp = mesh->get_array<o::LO>(picparts.dim(), "has_particles").to_host();
+  int64_t touched = 0;
   for (int v : hp) touched += v >= 0;
-  printf("RESULT particles %d scatter_mass %.17g touched_elements %d\n", ptcls->nPtcls(), mass, touched);
+  int64_t np_all = ptcls->nPtcls();
+  int64_t np_rank = np_all;
+  p::pp_check(pp_allreduce_sum_host_i64(world, &np_all, 1), "MPI_Allreduce");
+  printf("RANK %d particles %ld\n", comm_rank, (long)np_rank);
+  if (comm_rank == 0)
+    printf("RESULT particles %ld scatter_mass %.17g touched_elements %ld\n", (long)np_all, mass, (long)touched);
   delete ptcls;
-  p::SummarizeTime();
-  fprintf(stderr, "done\n");
+  pumipic::SummarizeTimeAcrossProcesses();
+  if (!comm_rank) fprintf(stderr, "done\n");
+  pp_comm_destroy(world);
   return 0;
 }

@@ -12,22 +12,33 @@
 // Omega_h::Mesh is replaced by pumipic::Mesh (a handle that owns the derived adjacency and the
 // packed walk records on the device); Omega_h::Write<T>/Read<T> by pumipic::View<T>.
 #pragma once
+#include <algorithm>
 #include <chrono>
 #include <map>
 #include "particle_structs.hpp"
 #include "pumipic_wall.hpp"    // closest_point_on_triangle[_wnormal] (device-inline)
 #include "pumipic_gather.hpp"  // interpolateTetVtx, interpolate2dField, ... (device-inline)
 
+namespace pumipic {
+class Mesh;
+}
 namespace Omega_h {
 typedef int LO;
+typedef long GO;
 typedef double Real;
 typedef int ClassId;
+typedef int Int;
 template <class T>
 using Write = pumipic::View<T>;
 template <class T>
 using Read = pumipic::View<T>;
 typedef Read<LO> LOs;
+typedef Read<GO> GOs;
 typedef Read<Real> Reals;
+enum { VERT = 0, EDGE = 1, FACE = 2, REGION = 3 };
+// The drivers hold an Omega_h::Mesh* (the serial mesh inside the PICpart) next to the pumipic::Mesh
+// (the PICpart); here one handle plays both parts.
+typedef pumipic::Mesh Mesh;
 }  // namespace Omega_h
 namespace o = Omega_h;
 
@@ -71,7 +82,103 @@ class Mesh {
   o::LOs elems2sides() const { return view<int>(PP_MESH_ELEM2SIDES); }
   double tolerance() const { return pp_mesh_tolerance(h_); }
 
+  // ---- PICpart attributes (src/pumipic_mesh.hpp:40-130).  The mesh is fully buffered (every rank holds
+  // all of it, the reference's Input::FULL); elements are owned in contiguous blocks, and the safe zone
+  // is the own block plus `safe_layers` breadth-first layers (bfsBufferLayers,
+  // pumipic_part_construct.cpp:407-437; 0 = BASELINE's rule: a particle migrates as soon as it
+  // leaves its owner's block).
+  void partition(pp_comm* comm, int safe_layers = 0) {
+    comm_ = comm;
+    const int world = pp_comm_size(comm), rank = pp_comm_rank(comm);
+    std::vector<int> own((size_t)nelems_);
+    for (int e = 0; e < nelems_; ++e) own[(size_t)e] = (int)((long long)e * world / (nelems_ > 0 ? nelems_ : 1));
+    owners_ = o::Write<o::LO>((size_t)std::max(nelems_, 1));
+    owners_.from_host(own.data());
+    safe_ = View<unsigned char>((size_t)std::max(nelems_, 1));
+    if (safe_layers > 0 && world > 1) {
+      std::vector<int> has_part((size_t)world, 0);
+      pp_check(pp_bfs_buffer_layers(h_, 0, rank, world, safe_layers, safe_layers, owners_.data(), safe_.data(),
+                                    has_part.data()), "bfsBufferLayers");
+    } else {
+      std::vector<unsigned char> sf((size_t)nelems_);
+      for (int e = 0; e < nelems_; ++e) sf[(size_t)e] = own[(size_t)e] == rank;
+      safe_.from_host(sf.data());
+    }
+  }
+  pp_comm* comm() const { return comm_ ? comm_ : comm_world(); }
+  int rank() const { return pp_comm_rank(comm()); }
+  int num_ranks() const { return pp_comm_size(comm()); }
+  bool isFullMesh() const { return true; }
+  o::LOs entOwners(int dim) {
+    ensure_partition(dim);
+    return owners_;
+  }
+  View<unsigned char> safeTag() {
+    ensure_partition(dim_);
+    return safe_;
+  }
+  o::GOs globalIds(int dim) {  // full-mesh replica: global id == local id
+    (void)dim;
+    if (gids_.size() == 0) {
+      std::vector<o::GO> g((size_t)nelems_);
+      for (int e = 0; e < nelems_; ++e) g[(size_t)e] = e;
+      gids_ = o::Write<o::GO>((size_t)std::max(nelems_, 1));
+      gids_.from_host(g.data());
+    }
+    return gids_;
+  }
+  // createCommArray / reduceCommArray (src/pumipic_mesh.hpp:92-110, pumipic_comm.cpp:222-246): every
+  // entity is buffered on every rank, so the reduction is the all-reduce of the whole array
+  enum Op { SUM_OP, MAX_OP, MIN_OP };
+  template <class T>
+  o::Write<T> createCommArray(int edim, int num_entries_per_entity, T default_value) {
+    const int n = edim == 0 ? nverts_ : (edim == dim_ ? nelems_ : nsides_);
+    return o::Write<T>((size_t)n * num_entries_per_entity, default_value);
+  }
+  void reduceCommArray(int /*edim*/, Op op, o::Write<o::Real> array) {
+    if (op != SUM_OP) {
+      fprintf(stderr, "reduceCommArray: only SUM_OP is built (the hot path's gyroSync)\n");
+      exit(EXIT_FAILURE);
+    }
+    pp_check(pp_allreduce_sum(comm(), array.data(), (int64_t)array.size()), "reduceCommArray");
+  }
+  // ---- mesh tags the drivers use (Omega_h::Mesh::add_tag / set_tag / get_array)
+  template <class T>
+  void add_tag(int edim, const std::string& name, int /*ncomps*/, View<T> values) {
+    set_tag(edim, name, values);
+  }
+  void set_tag(int edim, const std::string& name, View<double> values) { real_tags_[key(edim, name)] = values; }
+  void set_tag(int edim, const std::string& name, View<int> values) { int_tags_[key(edim, name)] = values; }
+  template <class T>
+  View<T> get_array(int edim, const std::string& name) {
+    return get_array_impl(edim, name, (T*)nullptr);
+  }
+  Mesh* mesh() { return this; }             // picparts.mesh()
+  Mesh* operator->() { return this; }       // picparts->dim()
+  o::LOs ask_verts_of_elems() const { return view<int>(PP_MESH_ELEM2VERTS); }
+
  private:
+  static std::string key(int edim, const std::string& name) { return std::to_string(edim) + ":" + name; }
+  View<double> get_array_impl(int edim, const std::string& name, double*) {
+    auto it = real_tags_.find(key(edim, name));
+    if (it == real_tags_.end()) {
+      fprintf(stderr, "mesh has no real tag %s on dimension %d\n", name.c_str(), edim);
+      exit(EXIT_FAILURE);
+    }
+    return it->second;
+  }
+  View<int> get_array_impl(int edim, const std::string& name, int*) {
+    if (name == "class_id" && edim == dim_) return class_ids();
+    auto it = int_tags_.find(key(edim, name));
+    if (it == int_tags_.end()) {
+      fprintf(stderr, "mesh has no integer tag %s on dimension %d\n", name.c_str(), edim);
+      exit(EXIT_FAILURE);
+    }
+    return it->second;
+  }
+  void ensure_partition(int) {
+    if (owners_.size() == 0) partition(comm(), 0);
+  }
   template <class T>
   View<T> view(int which) const {
     size_t n = 0;
@@ -80,24 +187,122 @@ class Mesh {
   }
   pp_mesh* h_ = nullptr;
   int dim_ = 0, nverts_ = 0, nelems_ = 0, nsides_ = 0;
+  pp_comm* comm_ = nullptr;
+  o::Write<o::LO> owners_;
+  View<unsigned char> safe_;
+  o::Write<o::GO> gids_;
+  std::map<std::string, View<double>> real_tags_;
+  std::map<std::string, View<int>> int_tags_;
 };
 
-// ---------------------------------------------------------------- timing (ppTiming.hpp)
-inline std::map<std::string, std::pair<double, int>>& timing_table() {
-  static std::map<std::string, std::pair<double, int>> t;
+// ---------------------------------------------------------------- timing (support/ppTiming.hpp:34-75)
+struct TimingEntry {
+  double time = 0, prebarrier = 0;
+  int count = 0, order = 0;
+};
+inline std::map<std::string, TimingEntry>& timing_table() {
+  static std::map<std::string, TimingEntry> t;
   return t;
 }
-inline void RecordTime(const std::string& name, double seconds, double = 0) {
-  auto& e = timing_table()[name];
-  e.first += seconds;
-  e.second += 1;
+inline int& timing_verbosity() {
+  static int v = 0;
+  return v;
 }
-inline void SummarizeTime() {
-  fprintf(stderr, "%-40s %14s %8s %14s\n", "Timing", "Total(s)", "Calls", "Avg(s)");
-  for (auto& kv : timing_table())
-    fprintf(stderr, "%-40s %14.6f %8d %14.6f\n", kv.first.c_str(), kv.second.first, kv.second.second,
-            kv.second.first / kv.second.second);
+inline int& timing_enabled() {
+  static int e = -1;  // -1: default (rank 0 of the world records)
+  return e;
 }
+inline void SetTimingVerbosity(int v) { timing_verbosity() = v; }
+inline void EnableTiming() { timing_enabled() = 1; }
+inline void DisableTiming() { timing_enabled() = 0; }
+inline bool isTiming() {
+  return timing_enabled() == 1 || (timing_enabled() == -1 && pp_comm_rank(comm_world()) == 0);
+}
+inline void RecordTime(const std::string& name, double seconds, double prebarrierTime = 0.0) {
+  if (!isTiming()) return;
+  auto& t = timing_table();
+  auto it = t.find(name);
+  if (it == t.end()) {
+    it = t.emplace(name, TimingEntry()).first;
+    it->second.order = (int)t.size();
+  }
+  it->second.time += seconds;
+  it->second.prebarrier += prebarrierTime;
+  it->second.count += 1;
+  if (timing_verbosity() >= 1)
+    fprintf(stderr, "%d %s (seconds) %f pre-barrier (seconds) %f\n", pp_comm_rank(comm_world()), name.c_str(),
+            seconds, prebarrierTime);
+}
+enum TimingSortOption { SORT_ALPHA, SORT_ORDER, SORT_LONGEST, SORT_SHORTEST };
+inline std::vector<std::pair<std::string, TimingEntry>> sorted_timing(TimingSortOption sort) {
+  std::vector<std::pair<std::string, TimingEntry>> v(timing_table().begin(), timing_table().end());
+  if (sort == SORT_ORDER)
+    std::sort(v.begin(), v.end(), [](const auto& a, const auto& b) { return a.second.order < b.second.order; });
+  else if (sort == SORT_LONGEST)
+    std::sort(v.begin(), v.end(), [](const auto& a, const auto& b) { return a.second.time > b.second.time; });
+  else if (sort == SORT_SHORTEST)
+    std::sort(v.begin(), v.end(), [](const auto& a, const auto& b) { return a.second.time < b.second.time; });
+  return v;
+}
+inline void SummarizeTime(TimingSortOption sort = SORT_ALPHA) {
+  if (timing_verbosity() < 0 || !isTiming()) return;
+  fprintf(stderr, "Timing Summary %d\n%-40s %14s %8s %14s\n", pp_comm_rank(comm_world()), "Operation", "Total Time",
+          "Calls", "Average Time");
+  for (auto& kv : sorted_timing(sort))
+    fprintf(stderr, "%-40s %14.6f %8d %14.6f\n", kv.first.c_str(), kv.second.time, kv.second.count,
+            kv.second.time / kv.second.count);
+}
+// collective: max / min (with the rank that holds it) / average over the ranks that record
+inline void SummarizeTimeAcrossProcesses(TimingSortOption sort = SORT_ALPHA) {
+  pp_comm* c = comm_world();
+  const int n = pp_comm_size(c), me = pp_comm_rank(c);
+  // the operation names of rank 0 define the table (the ranks run the same program)
+  auto mine = sorted_timing(sort);
+  std::vector<double> row(2 * 64, -1.0);
+  std::vector<std::string> names;
+  for (auto& kv : mine)
+    if (names.size() < 64) names.push_back(kv.first);
+  for (size_t i = 0; i < names.size(); ++i) {
+    row[2 * i] = isTiming() ? mine[i].second.time : -1.0;
+    row[2 * i + 1] = mine[i].second.count;
+  }
+  std::vector<double> all((size_t)n * row.size());
+  pp_check(pp_comm_allgather_host(c, row.data(), all.data(), (int)(row.size() * sizeof(double))),
+           "SummarizeTimeAcrossProcesses");
+  if (me != 0 || timing_verbosity() < 0) return;
+  int nt = 0;
+  for (int r = 0; r < n; ++r) nt += all[(size_t)r * row.size()] >= 0;
+  fprintf(stderr, "Reduced Timing Summary with %d ranks\n%-40s %22s %22s %14s %10s\n", nt, "Operation",
+          "Max Time (max proc)", "Min Time (min proc)", "Average Time", "Call Count");
+  for (size_t i = 0; i < names.size(); ++i) {
+    double mx = -1, mn = 1e300, sum = 0;
+    int rmx = 0, rmn = 0, cnt = 0;
+    for (int r = 0; r < n; ++r) {
+      const double t = all[(size_t)r * row.size() + 2 * i];
+      if (t < 0) continue;
+      if (t > mx) mx = t, rmx = r;
+      if (t < mn) mn = t, rmn = r;
+      sum += t;
+      ++cnt;
+    }
+    if (cnt)
+      fprintf(stderr, "%-40s %14.6f (%5d) %14.6f (%5d) %14.6f %10d\n", names[i].c_str(), mx, rmx, mn, rmn, sum / cnt,
+              (int)all[2 * i + 1]);
+  }
+}
+// prebarrier (support/ppTiming.hpp, SCS_rebuild.h:124): optional barrier before a timed operation
+inline int& prebarrier_enabled() {
+  static int e = 0;
+  return e;
+}
+inline void enable_prebarrier() { prebarrier_enabled() = 1; }
+inline double pumipic_prebarrier(pp_comm* c = nullptr) {
+  if (!prebarrier_enabled()) return 0.0;
+  const auto t0 = std::chrono::steady_clock::now();
+  pp_check(pp_comm_barrier(c ? c : comm_world()), "prebarrier");
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+inline double prebarrier() { return pumipic_prebarrier(); }
 struct Timer {  // Kokkos::Timer stand-in; seconds() drains the stream first, like Kokkos::fence
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   void reset() { t0 = std::chrono::steady_clock::now(); }
@@ -266,18 +471,33 @@ bool search_mesh_3d(Mesh& mesh, ParticleStruct* ptcls, CurrentCoordView x_ps_d,
   return found == 1;
 }
 
-// single-rank form of migrate_lb_ptcls / migrate_ptcls (pumipic_ptcl_ops.hpp:53-85):
-// setUnsafeProcs leaves every particle on this rank, the balancer returns immediately
-// (pumipic_lb.hpp:353-358), migrate() falls through to rebuild().
+// setUnsafeProcs (src/pumipic_ptcl_ops.hpp:32-52): a particle whose new element is not safe on this
+// part goes to that element's owner
 template <class PS>
-void migrate_lb_ptcls(Mesh&, PS* ptcls, o::LOs elems, float /*tol*/, float = 0.5) {
-  Timer t;
-  ptcls->rebuild(elems);
-  RecordTime("migration", t.seconds());
+void setUnsafeProcs(Mesh& mesh, PS* ptcls, o::LOs elems, typename PS::kkLidView new_elems,
+                    typename PS::kkLidView new_procs) {
+  pp_check(pp_set_unsafe_procs(ptcls->handle(), elems.data(), mesh.safeTag().data(),
+                               mesh.entOwners(mesh.dim()).data(), mesh.rank(), new_elems.data(),
+                               new_procs.data()),
+           "setUnsafeProcs");
+}
+// migrate_ptcls / migrate_lb_ptcls (src/pumipic_ptcl_ops.hpp:53-85).  The diffusive particle balancer
+// (ParticleBalancer::repartition, pumipic_lb.hpp:352-362) is not built: particles go to the owner
+// of their element, which is what the reference does when the imbalance is within `tol`.
+template <class PS>
+void migrate_ptcls(Mesh& mesh, PS* ptcls, o::LOs elems) {
+  Timer init_timer;
+  const size_t cap = (size_t)std::max(ptcls->capacity(), 1);
+  typename PS::kkLidView new_elems("ps_element_ids", cap), new_procs("ps_process_ids", cap);
+  setUnsafeProcs(mesh, ptcls, elems, new_elems, new_procs);
+  RecordTime("migration_init", init_timer.seconds());
+  Timer migrate_timer;
+  ptcls->migrate(new_elems, new_procs, Distributor(mesh.comm()));
+  RecordTime("migration", migrate_timer.seconds());
 }
 template <class PS>
-void migrate_ptcls(Mesh& m, PS* ptcls, o::LOs elems) {
-  migrate_lb_ptcls(m, ptcls, elems, 1.0f);
+void migrate_lb_ptcls(Mesh& mesh, PS* ptcls, o::LOs elems, float /*tol*/, float = 0.5) {
+  migrate_ptcls(mesh, ptcls, elems);
 }
 
 }  // namespace pumipic

@@ -315,3 +315,37 @@ def test_two_processes_share_one_gpu(ppo, synth, capi, transport, dim):
         for step in range(NSTEPS):
             fo, bo = ref[4][step]
             assert np.array_equal(r[3][step][0::2], fo) and np.array_equal(r[3][step][1::2], bo)
+
+
+def test_cpp_driver_pseudoxgcm_two_ranks(synth, capi, tmp_path):
+    """The pseudoXGCm driver on the mirror headers (Mesh::partition, migrate_lb_ptcls -> ParticleStructure::
+    migrate -> pp_ps_migrate, gyroSync -> reduceCommArray -> pp_allreduce_sum, SummarizeTimeAcrossProcesses)
+    as TWO rank processes sharing the GPU over PP_COMM=tcp: no particle is lost or duplicated across the
+    migrations, and the synced scatter field carries every particle's contribution."""
+    import re
+    import subprocess
+    drv = os.path.join(ROOT, "pumi-pic_amd", "drivers")
+    subprocess.check_call(["make", "-C", drv, "-s"])
+    c, e, cl = synth.annulus_tri(n_b=24, n_theta=96, band_width=3)
+    mesh_file = str(tmp_path / "annulus.bin")
+    synth.write_mesh_bin(mesh_file, 2, c, e, cl)
+    npt, world = 20000, 2
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), PP_DEVICE="0",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PP_COMM="tcp")
+        procs.append(subprocess.Popen([os.path.join(drv, "pseudoXGCm"), mesh_file, str(npt), "6", "10", "2.0", "1"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    m = re.search(r"RESULT particles (\d+) scatter_mass (\S+) touched_elements (\d+)", outs[0][0])
+    assert m, outs[0][0][-2000:]
+    per_rank = [int(re.search(r"RANK %d particles (\d+)" % r, outs[r][0]).group(1)) for r in range(world)]
+    assert int(m.group(1)) == npt == sum(per_rank)          # interior bands: nobody leaves the domain
+    assert all(n > 0 for n in per_rank)
+    mass = float(m.group(2))
+    assert 0.9 * 18 * npt <= mass <= 18 * npt               # 2 rings x 3 verts x (8 pts x 3 mapped)/8 each
+    assert "world ranks 2 (tcp)" in outs[0][0]
+    assert "Reduced Timing Summary" in outs[0][1] and "gyro reduction" in outs[0][1]
