@@ -292,6 +292,21 @@ int pp_create_gyro_ring_mappings(const pp_mesh* mesh, double rmax, int gnr, int 
  * a copy.  Any other map pointer takes the atomic form. */
 int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, double rmax, int gnr,
                     int gppr, double* scatter_w_dev);
+/* gyroScatter with the particle radius the reference leaves as a TODO (test/gyroScatter.hpp:184
+ * "ptclRadius = ringWidth*1.125; //TODO compute the radius") taken PER PARTICLE, and an optional
+ * per-particle weight in place of the literal 1 (charge deposition).  Same ring selection (:186-191)
+ * and the same two additions per element vertex (:193-200) as the reference; a particle whose upper
+ * ring would be >= gnr (the reference asserts ringUp < gnr) contributes to its lower ring only and is
+ * counted in *num_clipped (may be NULL: no host sync).  radius_dev / weight_dev are slot-indexed
+ * arrays of `capacity` doubles (a double member's pointer qualifies); weight_dev == NULL means 1.
+ * The contention the reference resolves with 2*(dim+1) FP64 atomics per particle is resolved per
+ * row: ring sums of a row's run accumulate in registers and leave as one atomic per (element, ring)
+ * touched, the vertices then gather their elements' sums.  Sums are no longer exact integers, so the
+ * result depends on the summation order at the 1e-16 level (tests: <= 1e-12 relative vs the oracle).
+ * pp_gyro_scatter stays the fast path for the reference's constant radius (no particle data read). */
+int pp_gyro_scatter_radius(const pp_mesh* mesh, const pp_ps* ps, const double* radius_dev,
+                           const double* weight_dev, const int* v2v_dev, double rmax, int gnr, int gppr,
+                           double* scatter_w_dev, int* num_clipped);
 /* setSyncArray of gyroSync test/gyroScatter.hpp:245-249: out[2v]=fwd[v], out[2v+1]=bkwd[v];
  * the SUM all-reduce itself (reduceCommArray, pumipic_comm.cpp:234-246) is RCCL on this buffer */
 int pp_gyro_sync_pack(int nverts, const double* fwd_dev, const double* bkwd_dev, double* out_dev);

@@ -185,6 +185,9 @@ void ppo_create_gyro_ring_mappings(const ppo_mesh* mesh, double rmax, int gnr, i
                                    double theta_deg, int trig, int* forward_map,
                                    int* backward_map);
 /* test/gyroScatter.hpp:168-229 ; nvpe = dim+1 (3 literal; 4 = documented tet deviation) */
+void ppo_gyro_scatter_radius(const ppo_mesh* mesh, const ppo_ps* ps, const double* radius, const double* weight,
+                             const int* v2v, double rmax, int gnr, int gppr, double* scatter_w,
+                             int* num_clipped);
 void ppo_gyro_scatter(const ppo_mesh* mesh, const ppo_ps* ps, const int* v2v, double rmax, int gnr,
                       int gppr, double* scatter_w);
 /* test/pseudoPushAndSearch.cpp:340-374 */

@@ -117,6 +117,8 @@ def lib():
                                                     C.c_double, C.c_int, c_int_p, c_int_p]
         L.ppo_gyro_scatter.argtypes = [C.POINTER(_MeshS), C.POINTER(_PsS), c_int_p, C.c_double,
                                        C.c_int, C.c_int, c_double_p]
+        L.ppo_gyro_scatter_radius.argtypes = [C.POINTER(_MeshS), C.POINTER(_PsS), c_double_p, c_double_p, c_int_p,
+                                              C.c_double, C.c_int, C.c_int, c_double_p, c_int_p]
         L.ppo_avg_ptcl_density.argtypes = [C.POINTER(_MeshS), C.POINTER(_PsS), c_double_p,
                                            c_double_p]
         L.ppo_gather_tet_vtx.argtypes = [C.POINTER(_MeshS), C.POINTER(_PsS), C.c_int, c_int_p,
@@ -512,6 +514,18 @@ def gyro_scatter(mesh, ps, v2v, rmax=0.038, gnr=3, gppr=8):
     w = np.zeros(mesh.nverts, dtype=np.float64)
     lib().ppo_gyro_scatter(mesh.p, ps.p, _ip(v2v), rmax, gnr, gppr, _dp(w))
     return w
+
+
+def gyro_scatter_radius(mesh, ps, radius, v2v, weight=None, rmax=0.038, gnr=3, gppr=8):
+    """gyroScatter with a per-particle radius (slot-indexed) and optional weight -> (field, clipped)"""
+    v2v = np.ascontiguousarray(v2v, dtype=np.int32)
+    radius = np.ascontiguousarray(radius, dtype=np.float64)
+    wt = None if weight is None else np.ascontiguousarray(weight, dtype=np.float64)
+    w = np.zeros(mesh.nverts, dtype=np.float64)
+    clipped = C.c_int(0)
+    lib().ppo_gyro_scatter_radius(mesh.p, ps.p, _dp(radius), _dp(wt) if wt is not None else None, _ip(v2v), rmax,
+                                  gnr, gppr, _dp(w), C.byref(clipped))
+    return w, clipped.value
 
 
 def gather_tet_vtx(mesh, ps, field, dof=1, elem_ids=None, m_x=0):

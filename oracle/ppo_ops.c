@@ -330,6 +330,54 @@ void ppo_gyro_scatter(const ppo_mesh* mesh, const ppo_ps* ps, const int* v2v, do
   free_slots(&s);
 }
 
+/* test/gyroScatter.hpp:168-229 with the particle radius the reference leaves as a TODO (:184
+ * "const auto ptclRadius = ringWidth*1.125; //TODO compute the radius") taken per particle, and an
+ * optional per-particle weight instead of the literal 1.  Same ring selection (:186-191) and the same
+ * two additions per element vertex (:193-200); a particle whose upper ring would be >= gnr (the
+ * reference asserts ringUp < gnr, :190) contributes to its lower ring only and is counted in
+ * *num_clipped.  radius / weight are slot-indexed; weight == NULL means 1. */
+void ppo_gyro_scatter_radius(const ppo_mesh* mesh, const ppo_ps* ps, const double* radius, const double* weight,
+                             const int* v2v, double rmax, int gnr, int gppr, double* scatter_w,
+                             int* num_clipped) {
+  const int nvpe = mesh->dim + 1;
+  const double ringWidth = rmax / gnr;
+  double* ring_accum = (double*)xcalloc((size_t)gnr * mesh->nverts, sizeof(double));
+  slots s = get_slots(ps);
+  int clipped = 0;
+  for (int pid = 0; pid < s.cap; ++pid) {
+    if (!s.mask[pid]) continue;
+    const int e = s.elem[pid];
+    const double ptclRadius = radius[pid];
+    const double w = weight ? weight[pid] : 1.0;
+    int ringDown = 0;
+    for (int i = 2; i <= gnr; i++) ringDown += (ptclRadius >= ringWidth * i);
+    const int ringUp = ringDown + 1;
+    if (ringUp >= gnr) ++clipped;
+    for (int i = 0; i < nvpe; ++i) {
+      const int v = mesh->elem2verts[(size_t)e * nvpe + i];
+      if (ringUp < gnr) ring_accum[(size_t)v * gnr + ringUp] += w;
+      ring_accum[(size_t)v * gnr + ringDown] += w;
+    }
+  }
+  for (int v = 0; v < mesh->nverts; ++v) scatter_w[v] = 0;
+  for (int v = 0; v < mesh->nverts; ++v) {
+    const long vtxIdx = (long)v * gnr * gppr;
+    for (int ring = 0; ring < gnr; ++ring) {
+      const double accumRingVal = ring_accum[(size_t)v * gnr + ring] / gppr;
+      for (int pt = 0; pt < gppr; ++pt) {
+        const long ptIdx = nvpe * (vtxIdx + (long)ring * gppr + pt);
+        for (int elmVtx = 0; elmVtx < nvpe; ++elmVtx) {
+          const int mappedVtx = v2v[ptIdx + elmVtx];
+          if (mappedVtx >= 0) scatter_w[mappedVtx] += accumRingVal;
+        }
+      }
+    }
+  }
+  if (num_clipped) *num_clipped = clipped;
+  free(ring_accum);
+  free_slots(&s);
+}
+
 /* test/pseudoPushAndSearch.cpp:340-374 (counts every visited slot, masked or not) */
 void ppo_avg_ptcl_density(const ppo_mesh* mesh, const ppo_ps* ps, double* elem_cnt,
                           double* vert_density) {

@@ -118,6 +118,7 @@ SYMBOLS = {
     "pp_create_gyro_ring_mappings": (_I, [_V, _D, _I, _I, _D, _V, _V]),
     "pp_gyro_scatter": (_I, [_V, _V, _V, _D, _I, _I, _V]),
     "pp_gyro_sync_pack": (_I, [_I, _V, _V, _V]),
+    "pp_gyro_scatter_radius": (_I, [_V, _V, _V, _V, _V, _D, _I, _I, _V, c_int_p]),
     "pp_gather_tet_vtx": (_I, [_V, _V, _I, _V, _V, _I, _V, _V]),
     "pp_interp2d_field": (_I, [_V, _I, _V, _D, _D, _D, _D, _I, _I, _I, _I, _I, _V]),
     "pp_interp2d_vector": (_I, [_V, _I, _V, _D, _D, _D, _D, _I, _I, _I, _V]),
@@ -573,6 +574,19 @@ def gyro_scatter(mesh, ps, v2v_dev, rmax=0.038, gnr=3, gppr=8, out=None):
         out = DevArray(max(mesh.nverts, 1), np.float64)
     check(lib().pp_gyro_scatter(mesh.p, ps.p, v2v_dev.ptr, rmax, gnr, gppr, out.ptr))
     return out
+
+
+def gyro_scatter_radius(mesh, ps, radius_dev, v2v_dev, weight_dev=None, rmax=0.038, gnr=3, gppr=8, out=None,
+                        want_clipped=True):
+    """per-particle radius / weight form of gyroScatter -> (field DevArray, clipped count or None)"""
+    if out is None:
+        out = DevArray(max(mesh.nverts, 1), np.float64)
+    clipped = C.c_int(0)
+    check(lib().pp_gyro_scatter_radius(mesh.p, ps.p, radius_dev.ptr if isinstance(radius_dev, DevArray) else radius_dev,
+                                       weight_dev.ptr if isinstance(weight_dev, DevArray) else weight_dev,
+                                       v2v_dev.ptr, rmax, gnr, gppr, out.ptr,
+                                       C.byref(clipped) if want_clipped else None))
+    return out, (clipped.value if want_clipped else None)
 
 
 def gyro_sync_pack(nverts, fwd, bkwd, out=None):

@@ -164,6 +164,91 @@ __global__ void k_rings_from_adjacency(int nverts, int gnr, const int* __restric
   for (int r = 0; r < gnr; ++r)
     ring_accum[(size_t)v * gnr + r] = (r == ringUp ? (double)n : 0.0) + (r == ringDown ? (double)n : 0.0);
 }
+// ---- general first stage: per-particle gyro radius and weight (the reference's "TODO compute the
+// radius", gyroScatter.hpp:184).  A row's particles share their element, so the thread that walks
+// a run of a row (up to 32 columns) keeps one accumulator per ring in REGISTERS and issues one FP64
+// atomic per (element, ring) it touched -- about 4 x rings atomics per element instead of
+// 2 x (dim+1) per particle -- into elem_ring[e][ring]; the vertices then GATHER their elements' ring
+// sums over the vertex->element adjacency (no atomics, the order is the adjacency order).
+constexpr int kMaxRings = 8;
+__global__ void k_elem_rings_scs(const int* __restrict__ ntiles_dev, int C, int TP, int G,
+                                 const int* __restrict__ tiles, const int* __restrict__ chunk_start,
+                                 const int* __restrict__ chunk_width, const int* __restrict__ r2e,
+                                 const unsigned char* __restrict__ mask, const double* __restrict__ radius,
+                                 const double* __restrict__ weight, int ne, int gnr, double ringWidth,
+                                 double* __restrict__ elem_ring, int* __restrict__ clipped) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int grp = (int)(g / C), r = (int)(g - (long long)grp * C);
+  const int ntiles = *ntiles_dev;
+  double acc[kMaxRings];
+#pragma unroll
+  for (int i = 0; i < kMaxRings; ++i) acc[i] = 0.0;
+  int cur = -1, e = -1, start = 0, nclip = 0;
+  auto flush = [&]() {
+    if (e >= 0 && e < ne) {
+#pragma unroll
+      for (int i = 0; i < kMaxRings; ++i)
+        if (i < gnr && acc[i] != 0.0) atomicAdd(&elem_ring[(size_t)e * gnr + i], acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxRings; ++i) acc[i] = 0.0;
+  };
+  for (int k = 0; k < G; ++k) {
+    const int tile = grp * G + k;
+    if (tile >= ntiles) break;
+    const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
+    if (c != cur) {
+      flush();
+      cur = c;
+      start = chunk_start[c] + r;
+      e = r2e[c * C + r];
+    }
+    const int pend = min(p0 + TP, chunk_width[c]);
+    for (int p = p0; p < pend; ++p) {
+      const int pid = start + p * C;
+      if (!mask[pid]) continue;
+      const double rad = radius[pid], w = weight ? weight[pid] : 1.0;
+      int ringDown = 0;
+      for (int i = 2; i <= gnr; i++) ringDown += (rad >= ringWidth * i);  // gyroScatter.hpp:186-188
+      const int ringUp = ringDown + 1;
+#pragma unroll
+      for (int i = 0; i < kMaxRings; ++i)  // static indices keep the accumulators in registers
+        if (i == ringDown || (i == ringUp && ringUp < gnr)) acc[i] += w;
+      nclip += ringUp >= gnr;
+    }
+  }
+  flush();
+  if (nclip) atomicAdd(clipped, nclip);
+}
+// any structure: one thread per slot (CSR, or SCS without row tiles)
+__global__ void k_elem_rings_flat(int capacity, const unsigned char* __restrict__ mask,
+                                  const int* __restrict__ slot_elem, const double* __restrict__ radius,
+                                  const double* __restrict__ weight, int ne, int gnr, double ringWidth,
+                                  double* __restrict__ elem_ring, int* __restrict__ clipped) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity || !mask[pid]) return;
+  const int e = slot_elem[pid];
+  if (e < 0 || e >= ne) return;
+  const double rad = radius[pid], w = weight ? weight[pid] : 1.0;
+  int ringDown = 0;
+  for (int i = 2; i <= gnr; i++) ringDown += (rad >= ringWidth * i);
+  const int ringUp = ringDown + 1;
+  atomicAdd(&elem_ring[(size_t)e * gnr + ringDown], w);
+  if (ringUp < gnr)
+    atomicAdd(&elem_ring[(size_t)e * gnr + ringUp], w);
+  else
+    atomicAdd(clipped, 1);
+}
+__global__ void k_rings_from_elem_rings(int nverts, int gnr, const int* __restrict__ v2e_off,
+                                        const int* __restrict__ v2e, const double* __restrict__ elem_ring,
+                                        double* __restrict__ ring_accum) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)nverts * gnr) return;
+  const int v = (int)(t / gnr), ring = (int)(t % gnr);
+  double s = 0.0;
+  for (int j = v2e_off[v]; j < v2e_off[v + 1]; ++j) s += elem_ring[(size_t)v2e[j] * gnr + ring];
+  ring_accum[t] = s;
+}
 __global__ void k_scatter_mapped(int nverts, int gnr, int gppr, int nvpe,
                                  const double* __restrict__ ring_accum,
                                  const int* __restrict__ v2v, double* __restrict__ scatter_w) {
@@ -484,6 +569,59 @@ int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, do
           nverts, gnr, gppr, nvpe, s_ring->as<double>(), v2v_dev, scatter_w_dev);
   }
   PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+int pp_gyro_scatter_radius(const pp_mesh* mesh, const pp_ps* ps, const double* radius_dev,
+                           const double* weight_dev, const int* v2v_dev, double rmax, int gnr, int gppr,
+                           double* scatter_w_dev, int* num_clipped) {
+  pp::Range rg_("xgcm_gyroScatter_radius");
+  PP_REQUIRE(mesh && ps && radius_dev && v2v_dev && scatter_w_dev, "pp_gyro_scatter_radius: null argument");
+  PP_REQUIRE(ps->num_elems == mesh->nelems, "pp_gyro_scatter_radius: structure/mesh element mismatch");
+  PP_REQUIRE(gnr >= 1 && gnr <= kMaxRings && gppr > 0, "pp_gyro_scatter_radius: 1 <= gnr <= 8 rings");
+  hipStream_t st = pp::stream();
+  const int ne = mesh->nelems, nverts = mesh->nverts, nvpe = mesh->dim + 1;
+  if (num_clipped) *num_clipped = 0;
+  const bool have = ps->num_ptcls > 0 && ps->capacity > 0 && nverts > 0;
+  static pp::DevBuf* s_er = new pp::DevBuf();  // library-lifetime scratch: [ne][gnr] doubles + the clip counter
+  if (!g_ring) g_ring = new pp::DevBuf();
+  PP_HIP_CHECK(g_ring->reserve(sizeof(double) * (size_t)std::max(nverts * gnr, 1)));
+  const size_t er_bytes = sizeof(double) * (size_t)std::max(ne * gnr, 1);
+  PP_HIP_CHECK(s_er->reserve(er_bytes + 16));
+  int* clip_dev = (int*)((char*)s_er->p + er_bytes);
+  static const bool no_gather = getenv("PP_SCATTER_ATOMIC") != nullptr;
+  const InvMap* inv = no_gather ? nullptr : find_inverse(v2v_dev, mesh, gnr, gppr);
+  if (!inv || !have) PP_HIP_CHECK(hipMemsetAsync(scatter_w_dev, 0, sizeof(double) * (size_t)std::max(nverts, 1), st));
+  if (!have) return PP_OK;
+  c_ps = nullptr;  // the shared ring accumulator no longer holds the count-based rings of a structure
+  PP_HIP_CHECK(hipMemsetAsync(s_er->p, 0, er_bytes + 16, st));
+  const double ringWidth = rmax / gnr;
+  static const bool force_flat = getenv("PP_SCATTER_FLAT") != nullptr;
+  if (ps->kind == PP_SCS && ps->ntiles_max > 0 && !force_flat) {
+    const int G = std::max(1, 32 / ps->tile_p);
+    k_elem_rings_scs<<<grid_for(((size_t)ps->ntiles_max + G - 1) / G * ps->C), kBlock, 0, st>>>(
+        ps->d_ntiles.as<int>(), ps->C, ps->tile_p, G, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(),
+        ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(), ps->d_mask.as<unsigned char>(), radius_dev,
+        weight_dev, ne, gnr, ringWidth, s_er->as<double>(), clip_dev);
+  } else {
+    k_elem_rings_flat<<<grid_for(ps->capacity), kBlock, 0, st>>>(
+        ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), radius_dev, weight_dev, ne, gnr,
+        ringWidth, s_er->as<double>(), clip_dev);
+  }
+  k_rings_from_elem_rings<<<grid_for((size_t)nverts * gnr), kBlock, 0, st>>>(
+      nverts, gnr, mesh->d_vert2elems_off.as<int>(), mesh->d_vert2elems.as<int>(), s_er->as<double>(),
+      g_ring->as<double>());
+  if (inv)
+    k_scatter_gathered<<<grid_for((size_t)nverts * 16), kBlock, 0, st>>>(nverts, gppr, inv->off.as<int>(),
+                                                           inv->src.as<int>(), g_ring->as<double>(), scatter_w_dev);
+  else
+    k_scatter_mapped<<<grid_for((size_t)nverts * gnr * gppr), kBlock, 0, st>>>(
+        nverts, gnr, gppr, nvpe, g_ring->as<double>(), v2v_dev, scatter_w_dev);
+  PP_LAUNCH_CHECK();
+  if (num_clipped) {
+    PP_HIP_CHECK(hipMemcpyAsync(num_clipped, clip_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    PP_HIP_CHECK(hipStreamSynchronize(st));
+  }
   return PP_OK;
 }
 

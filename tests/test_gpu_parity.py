@@ -1485,3 +1485,43 @@ def test_elastic_rebuild_keeps_a_valid_layout(ppo, synth, capi, C, pad_strat, sh
             traded += moved
             assert int((before["row_to_element"] != after["row_to_element"][:nr]).sum()) <= moved
     assert kept >= 5 and traded > 0, (kept, traded)
+
+
+@pytest.mark.parametrize("dim,kind", [(2, "scs"), (3, "scs"), (2, "csr")])
+def test_gyro_scatter_per_particle_radius(ppo, synth, capi, dim, kind):
+    """pp_gyro_scatter_radius: the reference's TODO radius (gyroScatter.hpp:184) per particle + a weight.
+    With the reference's constant radius and weight 1 it reproduces pp_gyro_scatter bit for bit; with
+    random radii / weights it agrees with the oracle's particle-by-particle loop to 1e-12 (the sums
+    are no longer exact integers: one atomic per (element, ring) per row run, then a vertex gather)."""
+    pop = common.population_2d(synth, num_ptcls=6000) if dim == 2 else common.population_3d(synth, num_ptcls=6000)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM, kind)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM, kind)
+    rmax, gnr, gppr = 0.038, 4, 8
+    fo, _ = ppo.create_gyro_ring_mappings(mo, rmax, gnr, gppr, 0.0, trig=1)
+    fg, _ = capi.create_gyro_ring_mappings(mg, rmax, gnr, gppr, 0.0)
+    capo, capg = po.capacity(), max(pg.capacity(), 1)
+    ids_o, ids_g = po.member(2)[0, :capo], pg.member(2)[0, :capg]
+    rng = np.random.default_rng(3)
+    npt = 6000
+    # keyed by particle id so both layouts see the same per-particle values
+    rad_by_id = rng.uniform(0.5 * rmax / gnr, 1.2 * rmax, npt)       # includes radii past the last ring
+    w_by_id = rng.uniform(0.25, 4.0, npt)
+    live_o, live_g = po.slot_info()[1].astype(bool), pg.slot_info()[1].astype(bool)
+    rad_o, w_o = np.zeros(capo), np.zeros(capo)
+    rad_o[live_o], w_o[live_o] = rad_by_id[ids_o[live_o]], w_by_id[ids_o[live_o]]
+    rad_g, w_g = np.zeros(capg), np.zeros(capg)
+    lg = np.flatnonzero(live_g)
+    rad_g[lg], w_g[lg] = rad_by_id[ids_g[lg]], w_by_id[ids_g[lg]]
+    ref, clip_o = ppo.gyro_scatter_radius(mo, po, rad_o, fo, w_o, rmax, gnr, gppr)
+    got, clip_g = capi.gyro_scatter_radius(mg, pg, capi.DevArray.from_host(rad_g), fg, capi.DevArray.from_host(w_g),
+                                           rmax, gnr, gppr)
+    got = got.to_host()[:mo.nverts]
+    assert clip_o == clip_g and clip_o > 0
+    scale = np.abs(ref).max()
+    assert scale > 0 and np.abs(got - ref).max() <= 1e-12 * scale
+    # the reference's constant radius, weight 1: exact integers / eighths in any order
+    const = np.full(capg, (rmax / gnr) * 1.125)
+    a, clip = capi.gyro_scatter_radius(mg, pg, capi.DevArray.from_host(const), fg, None, rmax, gnr, gppr)
+    assert clip == 0
+    assert np.array_equal(a.to_host()[:mo.nverts], capi.gyro_scatter(mg, pg, fg, rmax, gnr, gppr).to_host()[:mo.nverts])
+    assert np.array_equal(a.to_host()[:mo.nverts], ppo.gyro_scatter(mo, po, fo, rmax, gnr, gppr))
