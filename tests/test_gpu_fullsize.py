@@ -160,3 +160,94 @@ def test_c4_ps_combo160_full_size(pp, capi, kind):
         tags = ps.member(2)[0, :cap2][mk2]
         assert np.array_equal(np.sort(tags), slots)                  # nobody lost or duplicated
         assert np.array_equal(se2[:cap2][mk2], new_elem[tags])       # everybody in the requested row
+
+
+def test_config1_restated_size_matches_oracle(pp, ppo, capi):
+    """BASELINE configs[0] at its restated size: Kuhn split of a 16^3 box = 24 576 tets,
+    100 000 particles seeded on the y = 0 model face, push (-0.5, 0.8, 0) * 1/20 per step, legacy
+    search_mesh (loop limit 100), updatePtclPositions + rebuild every step, 30 steps -- every step's
+    element ids, wall faces, wall points and surviving population equal the oracle's."""
+    import common
+    synth = pp.synth
+    pop = common.population_box(synth, n=16, num_ptcls=100_000)
+    assert len(pop["e2v"]) == 24576
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_PUSH, C=64)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_PUSH, C=64)
+    ppo.set_threads(ppo.max_threads())
+    try:
+        steps = 0
+        for it in range(30):
+            if po.nPtcls() == 0:
+                break
+            ppo.linear_push(po, 1.0 / 20, -0.5, 0.8, 0.0)
+            capi.linear_push(pg, 1.0 / 20, -0.5, 0.8, 0.0)
+            ro = ppo.search_mesh_legacy3d(mo, po, looplimit=100)
+            rg = capi.search_mesh_legacy3d(mg, pg, looplimit=100)
+            assert ro["found"] == rg["found"]
+            capo, capg = po.capacity(), pg.capacity()
+            mko, mkg = po.slot_info()[1], pg.slot_info()[1]
+            ido, idg = po.member(2)[0, :capo], pg.member(2)[0, :capg]
+            for key, width in (("elem_ids", 1), ("xface", 1), ("xpoints", 3)):
+                a = np.asarray(ro[key])
+                b = rg[key].to_host()
+                if width == 3:
+                    a, b = a[:3 * capo].reshape(capo, 3).T, b[:3 * capg].reshape(capg, 3).T
+                else:
+                    a, b = a[:capo], b[:capg]
+                io, vo = common.by_id(ido, mko, a)
+                ig, vg = common.by_id(idg, mkg, b)
+                assert np.array_equal(io, ig) and np.array_equal(vo, vg), (it, key)
+            ppo.update_positions(po)
+            po.rebuild(ro["elem_ids"])
+            pg.rebuild_commit(rg["elem_ids"], 0, 1)
+            assert po.nPtcls() == pg.nPtcls()
+            steps += 1
+        assert steps >= 10
+    finally:
+        ppo.set_threads(1)
+
+
+def test_tet_c3_full_size_properties(pp, capi):
+    """configs[2] on tets (the bench's default workload): 100 800 tets, 10 M particles, fused push + walk,
+    rebuild with the commit and both gyroScatter calls in one entry point.  Size-independent checks:
+    the population is conserved by particle id, every particle sits in the row of the element the walk
+    gave it (verified with an independent numpy barycentric test on a sample), x <- x_tgt / x_tgt <- 0,
+    and the scatter fields carry 2 rings x 4 vertices x mapped fraction of every particle."""
+    w = bench.build_workload(pp, capi, "c3", 10_000_000, 0, 1, 0.5)
+    s = pp.synth
+    mesh, ps = w["mesh"], w["ps"]
+    fwd, bkwd = capi.create_gyro_ring_mappings(mesh)
+    wf, wb = capi.DevArray(mesh.nverts, np.float64), capi.DevArray(mesh.nverts, np.float64)
+    n0 = ps.nPtcls()
+    rng = np.random.default_rng(9)
+    for step in range(3):
+        cap = ps.capacity()
+        ids = capi.DevArray(cap + cap // 10, np.int32)
+        capi.push_search(mesh, ps, s.XGC_H, s.XGC_K, s.XGC_D, 0.5, ids, seeded=False, looplimit=200)
+        want = ids.to_host()[:cap]
+        mask = ps.slot_info()[1].astype(bool)
+        pid_before = ps.member(2)[0, :cap][mask]
+        elem_before = want[mask]
+        xt_before = ps.member(1)[:, :cap][:, mask]
+        capi.rebuild_scatter(ps, mesh, ids, [fwd, bkwd], [wf, wb])
+        se, mk = ps.slot_info()
+        mk = mk.astype(bool)
+        cap2 = ps.capacity()
+        pid_after = ps.member(2)[0, :cap2][mk]
+        kept = elem_before >= 0
+        assert ps.nPtcls() == int(kept.sum()) == int(mk.sum())
+        order_b, order_a = np.argsort(pid_before[kept]), np.argsort(pid_after)
+        assert np.array_equal(pid_before[kept][order_b], pid_after[order_a])
+        assert np.array_equal(elem_before[kept][order_b], se[:cap2][mk][order_a])
+        x_after = ps.member(0)[:, :cap2][:, mk]
+        assert np.array_equal(x_after[:, order_a], xt_before[:, kept][:, order_b])
+        assert not ps.member(1)[:, :cap2][:, mk].any()          # x_tgt <- 0 (materialised on access)
+        samp = rng.choice(int(mk.sum()), size=100_000, replace=False)
+        lam = _tet_bcc(w["coords"], w["e2v"], se[:cap2][mk][samp], x_after[:, samp].T)
+        assert lam.min() > -1e-9, lam.min()
+        f, b = wf.to_host(), wb.to_host()
+        assert np.array_equal(f, b) and np.isfinite(f).all() and f.min() >= 0
+        # every particle adds 1 to two rings of its 4 vertices; each ring value is spread as value/8 over
+        # 8 points x 4 mapped vertices (points outside the domain drop out)
+        assert 0.8 * 32 * ps.nPtcls() <= f.sum() <= 32 * ps.nPtcls()
+    assert ps.nPtcls() > 0.99 * n0
