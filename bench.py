@@ -269,19 +269,21 @@ class Stepper:
             # dim 3, unseeded (an "empty elem_ids", adjacency.tpp:504-515): the search writes every
             # slot itself, -1 into the masked ones -- no fill
         elif self.name == "c5":
-            self.route = capi.set_unsafe_procs(self.ps, self.ids, self.safe, self.owners, self.rank,
-                                               out=getattr(self, "route", None))
-            ne_, npr = self.route
             # updatePtclPositions rides in the records / the rebuild, the two scatters behind it
             scat = (self.mesh, [self.fwd, self.bkwd], [self.w_f, self.w_b])
-            if self.comm is not None:  # SellCSigma::migrate + reduceCommArray behind the C-ABI (RCCL)
-                capi.migrate_begin(self.ps, ne_, npr, self.comm, commit=True, scatter=scat)
-                sent, _ = capi.migrate_end(self.ps, self.comm)
+            if self.comm is not None:
+                # migrate_lb_ptcls + gyroSync behind the C-ABI (RCCL): setUnsafeProcs is the routing rule
+                # of the pack, SellCSigma::migrate, reduceCommArray
+                sent, _ = capi.migrate_ptcls(self.ps, self.ids, self.safe, self.owners, self.comm, commit=True,
+                                             scatter=scat)
                 if self.world > 1:  # gyroSync: SUM over ranks of the interleaved fields
                     self.sync_d = capi.gyro_sync_pack(self.mesh.nverts, self.w_f, self.w_b,
                                                       out=getattr(self, "sync_d", None))
                     self.comm.allreduce_sum(self.sync_d)
             else:
+                self.route = capi.set_unsafe_procs(self.ps, self.ids, self.safe, self.owners, self.rank,
+                                                   out=getattr(self, "route", None))
+                ne_, npr = self.route
                 sent, _ = self.ppdist.migrate(capi, self.ps, ne_, npr, self.rank, self.world, commit=True,
                                               scatter=scat)
                 if self.world > 1:
@@ -290,7 +292,8 @@ class Stepper:
             cap = max(self.ps.capacity(), 1)
             if cap > self.ids.n:  # 10% slack: the capacity wanders by a few chunk widths per rebuild
                 self.ids = capi.DevArray(cap + cap // 10, np.int32)
-            self.ids.fill_bytes(0xff)
+            if self.w["dim"] == 2:
+                self.ids.fill_bytes(0xff)  # (dim 3, unseeded: the search writes every slot itself)
         # "2d": search_mesh_2d re-seeds from the previous ids as given
 
     def _make_comm(self):

@@ -497,6 +497,19 @@ int pp_ps_migrate_begin(pp_ps* ps, int m_x, int m_xtgt, int* new_element_dev,
                         const int* const* v2v_dev, double* const* scatter_w_dev, double rmax,
                         int gnr, int gppr);
 int pp_ps_migrate_end(pp_ps* ps, pp_comm* comm, int* n_sent, int* n_received);
+/* migrate_ptcls / migrate_lb_ptcls (src/pumipic_ptcl_ops.hpp:53-85) as ONE call: setUnsafeProcs
+ * (:32-52: a particle whose new element is not safe on this part goes to that element's owner) is
+ * the routing rule of the count / pack passes instead of a pass of its own that writes new_elems /
+ * new_procs, then SellCSigma::migrate as pp_ps_migrate_scatter does it.  elem_ids_dev (the search's
+ * result) is in/out: sent particles read -1 afterwards.  The particle balancer of migrate_lb_ptcls
+ * (pumipic_lb.hpp:352-362) is not built.  _begin + pp_ps_migrate_end is the split-phase form. */
+int pp_migrate_ptcls(pp_ps* ps, int m_x, int m_xtgt, int* elem_ids_dev, const unsigned char* safe_dev,
+                     const int* owners_dev, pp_comm* comm, const pp_mesh* mesh, int nmaps,
+                     const int* const* v2v_dev, double* const* scatter_w_dev, double rmax, int gnr, int gppr);
+int pp_migrate_ptcls_begin(pp_ps* ps, int m_x, int m_xtgt, int* elem_ids_dev, const unsigned char* safe_dev,
+                           const int* owners_dev, pp_comm* comm, const pp_mesh* mesh, int nmaps,
+                           const int* const* v2v_dev, double* const* scatter_w_dev, double rmax, int gnr,
+                           int gppr);
 
 /* ------------------------------------------------------------------ tracing
  * Kokkos::Profiling::pushRegion / popRegion of the reference (e.g. adjacency.tpp:480,613,

@@ -154,6 +154,8 @@ SYMBOLS = {
     "pp_ps_migrate_begin": (_I, [_V, _I, _I, _V, _V, _V, _I, _V, _V, _V, C.c_int64, _V, _I, _V, _V,
                                  C.c_double, _I, _I]),
     "pp_ps_migrate_end": (_I, [_V, _V, c_int_p, c_int_p]),
+    "pp_migrate_ptcls": (_I, [_V, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, C.c_double, _I, _I]),
+    "pp_migrate_ptcls_begin": (_I, [_V, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, C.c_double, _I, _I]),
     "pp_range_push": (_I, [C.c_char_p]),
     "pp_range_pop": (_I, []),
 }
@@ -1080,3 +1082,21 @@ def migrate_end(ps, comm):
     check(lib().pp_ps_migrate_end(ps.p, comm.p, C.byref(ns), C.byref(nr)))
     comm._pending_keep = None
     return ns.value, nr.value
+
+
+def migrate_ptcls_begin(ps, elem_ids, safe_dev, owners_dev, comm, commit=False, scatter=None, rmax=0.038, gnr=3,
+                        gppr=8, m_x=0, m_xtgt=1):
+    """pp_migrate_ptcls_begin: setUnsafeProcs + migrate without the new_elems / new_procs arrays"""
+    mesh, maps, outs = scatter if scatter is not None else (None, (), ())
+    n = len(maps)
+    v2v = (C.c_void_p * max(n, 1))(*[m.ptr for m in maps])
+    out = (C.c_void_p * max(n, 1))(*[o.ptr for o in outs])
+    check(lib().pp_migrate_ptcls_begin(ps.p, m_x if commit else -1, m_xtgt if commit else -1, elem_ids.ptr,
+                                       safe_dev.ptr, owners_dev.ptr, comm.p, mesh.p if mesh is not None else None,
+                                       n, v2v, out, rmax, gnr, gppr))
+    comm._pending_keep = (v2v, out, elem_ids, safe_dev, owners_dev)
+
+
+def migrate_ptcls(ps, elem_ids, safe_dev, owners_dev, comm, **kw):
+    migrate_ptcls_begin(ps, elem_ids, safe_dev, owners_dev, comm, **kw)
+    return migrate_end(ps, comm)

@@ -141,15 +141,24 @@ constexpr int kMaxRanks = 256;
 struct RankStarts {
   int v[64];  // first record of every destination rank in the send buffer (nranks <= 64 by value)
 };
+// where a particle goes: the caller's new_process array, or -- setUnsafeProcs folded in
+// (src/pumipic_ptcl_ops.hpp:32-52) -- the owner of its new element when that element is not safe here
+struct RouteRule {
+  const int* new_process;
+  const unsigned char* safe;
+  const int* owners;
+};
 __device__ __forceinline__ int route_dest(int pid, int capacity, const unsigned char* __restrict__ mask,
-                                          const int* __restrict__ new_element,
-                                          const int* __restrict__ new_process, int rank, int nranks) {
-  if (pid >= capacity || !mask[pid] || new_element[pid] < 0) return -1;
-  const int p = new_process[pid];
+                                          const int* __restrict__ new_element, const RouteRule rr, int rank,
+                                          int nranks) {
+  if (pid >= capacity || !mask[pid]) return -1;
+  const int e = new_element[pid];
+  if (e < 0) return -1;
+  const int p = rr.new_process ? rr.new_process[pid] : (rr.safe[e] ? rank : rr.owners[e]);
   return (p != rank && p >= 0 && p < nranks) ? p : -1;
 }
 __global__ void k_route_count(int capacity, int per_block, const unsigned char* __restrict__ mask,
-                              const int* __restrict__ new_element, const int* __restrict__ new_process,
+                              const int* __restrict__ new_element, const RouteRule new_process,
                               int rank, int nranks, int* __restrict__ block_cnt) {
   __shared__ int h[kMaxRanks];
   for (int i = threadIdx.x; i < nranks; i += blockDim.x) h[i] = 0;
@@ -175,7 +184,7 @@ __global__ void k_route_scan(int nblocks, int nranks, int* __restrict__ block_cn
   counts[p] = run;
 }
 __global__ void k_route_pack(int capacity, int per_block, const unsigned char* __restrict__ mask,
-                             int* new_element, const int* __restrict__ new_process, int rank, int nranks,
+                             int* new_element, const RouteRule new_process, int rank, int nranks,
                              const int* __restrict__ block_start, RankStarts rs,
                              const int* __restrict__ rank_start_dev, const long long* __restrict__ gids,
                              unsigned* __restrict__ out, RecTable t) {
@@ -319,7 +328,7 @@ int pp_ps_migrate_pack_records_commit(const pp_ps* ps, int m_x, int m_xtgt, int*
 }
 // per-block leaver counts of the current routing (scratch(4): [kRouteBlocks][nranks]) and their scan;
 // totals per destination to counts_dev (nranks ints)
-static int route_count(const pp_ps* ps, const int* new_element_dev, const int* new_process_dev,
+static int route_count(const pp_ps* ps, const int* new_element_dev, const RouteRule new_process_dev,
                        int comm_rank, int nranks, int* counts_dev, int* per_block_out) {
   PP_REQUIRE(nranks <= kMaxRanks, "migration: more than 256 ranks are not supported by the routing kernels");
   hipStream_t st = pp::stream();
@@ -337,7 +346,7 @@ static int route_count(const pp_ps* ps, const int* new_element_dev, const int* n
 }
 // pack pass of the same routing (route_count must have run on the same arrays)
 static int route_pack(const pp_ps* ps, int commit_x, int commit_xt, int* new_element_dev,
-                      const int* new_process_dev, int comm_rank, int nranks, int per_block,
+                      const RouteRule new_process_dev, int comm_rank, int nranks, int per_block,
                       const int* rank_start_host, void* send_records_dev) {
   RecTable t{};
   int rc = build_rec_table(ps, t, commit_x, commit_xt);
@@ -378,9 +387,10 @@ static int pack_records(const pp_ps* ps, int commit_x, int commit_xt, int* new_e
   pp::DevBuf& cnt = scratch(3);
   PP_HIP_CHECK(cnt.reserve(sizeof(int) * (size_t)nranks));
   int per_block = 0;
-  int rc = route_count(ps, new_element_dev, new_process_dev, comm_rank, nranks, cnt.as<int>(), &per_block);
+  const RouteRule rr{new_process_dev, nullptr, nullptr};
+  int rc = route_count(ps, new_element_dev, rr, comm_rank, nranks, cnt.as<int>(), &per_block);
   if (rc) return rc;
-  rc = route_pack(ps, commit_x, commit_xt, new_element_dev, new_process_dev, comm_rank, nranks, per_block,
+  rc = route_pack(ps, commit_x, commit_xt, new_element_dev, rr, comm_rank, nranks, per_block,
                   start.data(), send_records_dev);
   if (rc) return rc;
   PP_HIP_CHECK(hipStreamSynchronize(pp::stream()));
@@ -464,14 +474,53 @@ int pp_ps_rebuild_records_scatter(pp_ps* ps, int m_x, int m_xtgt, const int* new
 
 // ---------------------------------------------------------------------------------------------
 // SellCSigma::migrate (scs/SCS_migrate.h:5-222) behind one call
+static int migrate_begin_rule(pp_ps* ps, int m_x, int m_xtgt, int* new_element_dev, const RouteRule rr,
+                              pp_comm* comm, int n_new, const int* new_elems_dev,
+                              const void* const* new_info_dev, const int* gid2lid_dev, int64_t ngids,
+                              const pp_mesh* mesh, int nmaps, const int* const* v2v_dev,
+                              double* const* scatter_w_dev, double rmax, int gnr, int gppr);
 int pp_ps_migrate_begin(pp_ps* ps, int m_x, int m_xtgt, int* new_element_dev,
                         const int* new_process_dev, pp_comm* comm, int n_new,
                         const int* new_elems_dev, const void* const* new_info_dev,
                         const int* gid2lid_dev, int64_t ngids, const pp_mesh* mesh, int nmaps,
                         const int* const* v2v_dev, double* const* scatter_w_dev, double rmax,
                         int gnr, int gppr) {
+  PP_REQUIRE(ps && (new_process_dev || ps->capacity == 0), "pp_ps_migrate: null routing arrays");
+  return migrate_begin_rule(ps, m_x, m_xtgt, new_element_dev, RouteRule{new_process_dev, nullptr, nullptr}, comm,
+                            n_new, new_elems_dev, new_info_dev, gid2lid_dev, ngids, mesh, nmaps, v2v_dev,
+                            scatter_w_dev, rmax, gnr, gppr);
+}
+// migrate_lb_ptcls / migrate_ptcls (src/pumipic_ptcl_ops.hpp:53-85) as ONE call: setUnsafeProcs is the
+// routing rule of the count / pack passes (no new_elems / new_procs arrays: 16 B per slot less traffic
+// and one pass less), then SellCSigma::migrate.  elem_ids_dev is in/out: sent particles read -1
+// afterwards.
+int pp_migrate_ptcls_begin(pp_ps* ps, int m_x, int m_xtgt, int* elem_ids_dev, const unsigned char* safe_dev,
+                           const int* owners_dev, pp_comm* comm, const pp_mesh* mesh, int nmaps,
+                           const int* const* v2v_dev, double* const* scatter_w_dev, double rmax, int gnr,
+                           int gppr) {
+  PP_REQUIRE(ps && ((safe_dev && owners_dev) || ps->capacity == 0), "pp_migrate_ptcls: null safe / owner arrays");
+  return migrate_begin_rule(ps, m_x, m_xtgt, elem_ids_dev, RouteRule{nullptr, safe_dev, owners_dev}, comm, 0,
+                            nullptr, nullptr, nullptr, 0, mesh, nmaps, v2v_dev, scatter_w_dev, rmax, gnr, gppr);
+}
+int pp_migrate_ptcls(pp_ps* ps, int m_x, int m_xtgt, int* elem_ids_dev, const unsigned char* safe_dev,
+                     const int* owners_dev, pp_comm* comm, const pp_mesh* mesh, int nmaps,
+                     const int* const* v2v_dev, double* const* scatter_w_dev, double rmax, int gnr, int gppr) {
+  PP_REQUIRE(comm, "pp_migrate_ptcls: null communicator");
+  PP_REQUIRE(comm->kind != 4 || comm->nranks == 1,
+             "pp_migrate_ptcls: a local communicator needs pp_migrate_ptcls_begin on every virtual rank, then "
+             "pp_ps_migrate_end on every virtual rank");
+  int rc = pp_migrate_ptcls_begin(ps, m_x, m_xtgt, elem_ids_dev, safe_dev, owners_dev, comm, mesh, nmaps, v2v_dev,
+                                  scatter_w_dev, rmax, gnr, gppr);
+  if (rc) return rc;
+  return pp_ps_migrate_end(ps, comm, nullptr, nullptr);
+}
+static int migrate_begin_rule(pp_ps* ps, int m_x, int m_xtgt, int* new_element_dev, const RouteRule new_process_dev,
+                              pp_comm* comm, int n_new, const int* new_elems_dev,
+                              const void* const* new_info_dev, const int* gid2lid_dev, int64_t ngids,
+                              const pp_mesh* mesh, int nmaps, const int* const* v2v_dev,
+                              double* const* scatter_w_dev, double rmax, int gnr, int gppr) {
   PP_REQUIRE(ps && comm, "pp_ps_migrate: null structure / communicator");
-  PP_REQUIRE((new_element_dev && new_process_dev) || ps->capacity == 0, "pp_ps_migrate: null routing arrays");
+  PP_REQUIRE(new_element_dev || ps->capacity == 0, "pp_ps_migrate: null routing arrays");
   PP_REQUIRE(n_new >= 0 && (n_new == 0 || (new_elems_dev && new_info_dev)), "pp_ps_migrate: bad new particles");
   PP_REQUIRE(nmaps >= 0 && (nmaps == 0 || (mesh && v2v_dev && scatter_w_dev)), "pp_ps_migrate: bad scatter arguments");
   const bool commit = m_x >= 0 || m_xtgt >= 0;
@@ -613,7 +662,8 @@ int pp_ps_migrate_count(const pp_ps* ps, const int* new_element_dev, const int* 
   pp::DevBuf& cnt = scratch(3);
   PP_HIP_CHECK(cnt.reserve(sizeof(int) * (size_t)nranks));
   int per_block = 0;
-  int rc = route_count(ps, new_element_dev, new_process_dev, comm_rank, nranks, cnt.as<int>(), &per_block);
+  int rc = route_count(ps, new_element_dev, RouteRule{new_process_dev, nullptr, nullptr}, comm_rank, nranks,
+                       cnt.as<int>(), &per_block);
   if (rc) return rc;
   PP_HIP_CHECK(hipMemcpyAsync(send_counts_host, cnt.p, sizeof(int) * (size_t)nranks,
                               hipMemcpyDeviceToHost, st));

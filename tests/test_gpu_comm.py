@@ -276,8 +276,11 @@ def _proc_worker(rank, world, port, transport, dim, q):
         for _ in range(NSTEPS):
             ids = capi.DevArray.from_host(np.full(max(ps.capacity(), 1), -1, dtype=np.int32))
             _step(capi, mesh, ps, dim, 6.0, ids)
-            ne_d, np_d = capi.set_unsafe_procs(ps, ids, safe, owners_d, rank)
-            capi.migrate(ps, ne_d, np_d, comm, commit=True, scatter=(mesh, [fg, bg], [wf, wb]))
+            if transport == "tcp":  # setUnsafeProcs as its own pass, then SellCSigma::migrate
+                ne_d, np_d = capi.set_unsafe_procs(ps, ids, safe, owners_d, rank)
+                capi.migrate(ps, ne_d, np_d, comm, commit=True, scatter=(mesh, [fg, bg], [wf, wb]))
+            else:                   # migrate_lb_ptcls as one call (the routing rule rides in the pack)
+                capi.migrate_ptcls(ps, ids, safe, owners_d, comm, commit=True, scatter=(mesh, [fg, bg], [wf, wb]))
             packed = capi.gyro_sync_pack(mesh.nverts, wf, wb)
             comm.allreduce_sum(packed)
             fields.append(packed.to_host())
