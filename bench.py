@@ -241,6 +241,11 @@ class Stepper:
                              seeded=True, looplimit=200, want_found=False)
         if timed:
             e1.record()
+        if self.first and self.w.get("origin_trust", True) and self.w["dim"] == 3 and self.name != "c4":
+            # From the second step on every origin is the destination the previous walk accepted in the
+            # element the walk starts from (c3 / c5: the structure was rebuilt from the ids; c2: the ids are
+            # the seeds): pp_ps_set_origin_trust skips check_initial_parents (include/pumipic_hip.h).
+            self.ps.set_origin_trust(True)
         self.first = False
         self.steps_done += 1
         self._rest_of_step()
@@ -472,6 +477,9 @@ def main():
     ap.add_argument("--remainder", default="last", choices=["last", "spread"],
                     help="where particles left over by the Gaussian draws go: 'last' = literal "
                          "pseudoXGCm rule (one outlier element), 'spread' = evenly")
+    ap.add_argument("--no-origin-trust", action="store_true",
+                    help="run check_initial_parents every step (default: skipped from the second step on, "
+                         "pp_ps_set_origin_trust)")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
                     help="c5 exchange: RCCL behind the C-ABI (pp_ps_migrate / pp_allreduce_sum) or the "
                          "torch.distributed glue of pumi-pic_amd/dist.py")
@@ -519,6 +527,7 @@ def main():
                            a.sigma)
         w["safe_layers"] = a.safe_layers
         w["comm"] = a.comm
+        w["origin_trust"] = not a.no_origin_trust
         st = Stepper(pp, capi, w, a.workload, a.deg)
 
     def barrier():
@@ -672,6 +681,13 @@ def main():
             "parallelism": "element-block partition, %d rank(s), full-mesh replica" % world}
         if a.workload == "c5":
             out["rank0_sent_per_step"] = st.moved / max(1, st.steps_done)
+        if w["dim"] == 3:
+            nf, nie, unm = capi.push_search_counters()
+            out["origin_trust"] = {"on": bool(w.get("origin_trust", True)), "unmoved_without_test_last_step": unm,
+                                   "not_in_elem_last_step": nie,
+                                   "note": "check_initial_parents skipped from step 2 on (the origins are the "
+                                           "destinations the previous walk accepted); 0 unmoved finishes = the "
+                                           "skipped test would have passed for every particle"}
         if full_step:
             ip, fl, rm = w["ps"].rebuild_stats()
             out["rebuilds"] = {"kept_layout": ip, "full_relayout": fl, "rows_traded": rm,

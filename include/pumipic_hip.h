@@ -278,6 +278,23 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
                    double h, double k, double d, double deg, int* elem_ids_dev,
                    int elem_ids_seeded, int looplimit, int* found);
 
+/* check_initial_parents (adjacency.tpp:72-145) re-tests every step that a particle lies in the element
+ * its walk starts from.  When the starting positions ARE the destinations the previous walk accepted
+ * in exactly those elements -- the structure was rebuilt from the previous search's ids
+ * (pp_ps_rebuild_commit and friends), or the ids are re-used as seeds after pp_ps_swap_members, and
+ * nothing but removals (-1) was written to the ids in between -- the test recomputes the barycentric
+ * coordinates the walk just accepted with the tighter tolerance 1e-10 (tpp:224,255 vs the area
+ * tolerance >= 1e-8 of tpp:418-428) on bit-identical inputs, so it passes by construction.
+ * pp_ps_set_origin_trust(ps, 1) lets the caller vouch for that: the fused 3-D push skips the test
+ * (~15 % of its FP64 work).  The one path that accepts a destination without a containment test is
+ * finishUnmoved (|dest - orig| < tol, tpp:527-536); pp_push_search_counters reports how many trusted
+ * particles ended that way (0 in the pseudoXGCm flows: the slowest particle moves 1e-5 per push), so
+ * the exactness of a trusted run is checkable after the fact.  Off by default. */
+int pp_ps_set_origin_trust(pp_ps* ps, int on);
+/* counters of the last pp_push_search (one host sync): particles cut off by the loop limit, particles
+ * that failed check_initial_parents, trusted particles that finished as unmoved */
+int pp_push_search_counters(int* not_found, int* not_in_elem, int* unmoved_trusted);
+
 /* ------------------------------------------------------------------ scatter / gather */
 /* createGyroRingMappings test/gyroScatter.hpp:101-166 (maps: nverts*gnr*gppr*(dim+1) ints, device).
  * dim 3 is the documented tet variant: rings in the vertex's poloidal half-plane, the 4 vertices

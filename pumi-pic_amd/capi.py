@@ -115,6 +115,8 @@ SYMBOLS = {
                                            C.c_double, _I, _I]),
     "pp_search_mesh_3d": (_I, [_V, _V, _I, _I, _I, _V, _I, _V, _V, _I, c_int_p]),
     "pp_push_search": (_I, [_V, _V, _I, _I, _I, _I, _D, _D, _D, _D, _V, _I, _I, c_int_p]),
+    "pp_ps_set_origin_trust": (_I, [_V, _I]),
+    "pp_push_search_counters": (_I, [c_int_p, c_int_p, c_int_p]),
     "pp_create_gyro_ring_mappings": (_I, [_V, _D, _I, _I, _D, _V, _V]),
     "pp_gyro_scatter": (_I, [_V, _V, _V, _D, _I, _I, _V]),
     "pp_gyro_sync_pack": (_I, [_I, _V, _V, _V]),
@@ -452,6 +454,9 @@ class PS:
         a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()
         check(lib().pp_ps_rebuild_stats(self.p, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def set_origin_trust(self, on):
+        check(lib().pp_ps_set_origin_trust(self.p, int(bool(on))))
 
     def get_pids(self):
         i = self.info()
@@ -1100,3 +1105,10 @@ def migrate_ptcls_begin(ps, elem_ids, safe_dev, owners_dev, comm, commit=False, 
 def migrate_ptcls(ps, elem_ids, safe_dev, owners_dev, comm, **kw):
     migrate_ptcls_begin(ps, elem_ids, safe_dev, owners_dev, comm, **kw)
     return migrate_end(ps, comm)
+
+
+def push_search_counters():
+    """(not_found, not_in_elem, unmoved_trusted) of the last pp_push_search"""
+    a, b, c = C.c_int(), C.c_int(), C.c_int()
+    check(lib().pp_push_search_counters(C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value

@@ -193,6 +193,10 @@ struct pp_ps {
   // none): x_tgt after a fused updatePtclPositions of the in-place rebuild.  Cleared without a pass
   // when the next fused push overwrites the member; any other access materialises the zeros first.
   int zero_pending = -1;
+  // pp_ps_set_origin_trust: the caller vouches that every live particle's position lies in the element
+  // the fused push starts from (true when the structure was rebuilt from, or the ids are, the unmodified
+  // result of the previous search): check_initial_parents is skipped
+  bool trust_origins = false;
   pp::DevBuf s_rs, s_holes, s_rsx;  // in-place rebuild: per-element counters, per-row hole lists, elastic lists
   // scratch reused across rebuilds
   pp::DevBuf s_ppe, s_keys, s_keys2, s_vals, s_vals2, s_hist, s_chunkw, s_misc, s_rowstart,

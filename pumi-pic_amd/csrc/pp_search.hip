@@ -30,6 +30,7 @@ struct Counters {
   int not_in_elem; // check_initial_parents failures
   int aborted;     // legacy search: origin not in start element at loops==0 (OMEGA_H_CHECK)
   int pending;     // fused kernel: entries in the deferred-walk queue
+  int unmoved;     // trusted-origin mode: particles that finished as "unmoved" (no containment test ran)
 };
 
 __device__ __forceinline__ void load_tri(const pp_tri_rec* __restrict__ recs, int e, V2 fc[3],
@@ -1203,7 +1204,8 @@ __device__ __forceinline__ bool column_math(const WalkArgs& A, const PState& s, 
     if (elem == -1) done = true;  // hpp:1051-1056 (seed == -nelems)
   } else {
     // parent check first (a pure function of the origin): the origin's registers die with the push
-    origin_ok = (elem == -1) || inside_cached(cache, V3{s.x, s.y, s.z}, A.tol);
+    // abl bit 8 = the caller vouches for the origins (pp_ps_set_origin_trust): the test would pass
+    origin_ok = (elem == -1) || (A.abl & 8) || inside_cached(cache, V3{s.x, s.y, s.z}, A.tol);
     if (A.abl & 2) {
       dest = V3{s.x + 1e-3 * s.b, s.y, s.z};
       rad = s.phi;
@@ -1216,7 +1218,10 @@ __device__ __forceinline__ bool column_math(const WalkArgs& A, const PState& s, 
     done = (elem == -1);
     // finishUnmoved: norm(dest-orig) < tol  <=>  |dest-orig|^2 < unmoved_sq (k_push_walk_rows)
     const V3 dv = sub(dest, V3{s.x, s.y, s.z});
-    if (dot(dv, dv) < A.unmoved_sq) done = true;
+    if (dot(dv, dv) < A.unmoved_sq) {
+      if (!done && (A.abl & 8)) atomicAdd(&A.cnt->unmoved, 1);  // (never seen in the pseudoXGCm flows)
+      done = true;
+    }
   }
   if (A.abl & 1) done = true;
   stg<NT>(A.pphi + pid, (float)rad);
@@ -1539,6 +1544,7 @@ struct CntRef {
 } g_cnt;
 
 pp::DevBuf g_pending_q, g_wave_cnt;  // deferred-walk queue of the fused kernel (grow-only, library lifetime)
+Counters* g_last_counters = nullptr;  // the set the last pp_push_search added to (pp_push_search_counters)
 
 // Counters of the deferred-walk kernels: two sets used alternately.  k_walk_pending zeroes the set
 // of the NEXT call, so pp_push_search needs no memset launch (8 us per step in rocprof).
@@ -1902,7 +1908,8 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
     // PP_WALK_QUEUE=0/1 forces one or the other (A/B knob).
     const int wq_env = getenv("PP_WALK_QUEUE") ? atoi(getenv("PP_WALK_QUEUE")) : -1;  // per call
     const int wq = wq_env >= 0 ? wq_env : (mesh->dim == 3 ? 1 : 0);
-    static const int abl = getenv("PP_ABL") ? atoi(getenv("PP_ABL")) : 0;  // timing ablations only
+    static const int abl_env = getenv("PP_ABL") ? atoi(getenv("PP_ABL")) : 0;  // timing ablations only
+    const int abl = abl_env | (ps->trust_origins ? 8 : 0);
     if (!(rgrid > 0 && wq > 0)) {
       if ((rc = reset_counters())) return rc;
       used = g_cnt.get();
@@ -1979,12 +1986,31 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
     }
   }
   PP_LAUNCH_CHECK();
+  g_last_counters = used;
   if (found) {
     Counters hc;
     PP_HIP_CHECK(hipMemcpyAsync(&hc, used, sizeof(Counters), hipMemcpyDeviceToHost, st));
     PP_HIP_CHECK(hipStreamSynchronize(st));
     *found = (hc.not_found == 0);
   }
+  return PP_OK;
+}
+
+int pp_push_search_counters(int* not_found, int* not_in_elem, int* unmoved_trusted) {
+  Counters hc{};
+  if (g_last_counters) {
+    PP_HIP_CHECK(hipMemcpyAsync(&hc, g_last_counters, sizeof(Counters), hipMemcpyDeviceToHost, pp::stream()));
+    PP_HIP_CHECK(hipStreamSynchronize(pp::stream()));
+  }
+  if (not_found) *not_found = hc.not_found;
+  if (not_in_elem) *not_in_elem = hc.not_in_elem;
+  if (unmoved_trusted) *unmoved_trusted = hc.unmoved;
+  return PP_OK;
+}
+
+int pp_ps_set_origin_trust(pp_ps* ps, int on) {
+  PP_REQUIRE(ps, "pp_ps_set_origin_trust: null ps");
+  ps->trust_origins = on != 0;
   return PP_OK;
 }
 

@@ -841,10 +841,13 @@ def test_gyro_maps_and_scatter_3d(ppo, synth, capi):
     assert np.array_equal(wo, wg) and wo.sum() > 0
 
 
-def test_pseudo_xgcm_steps_3d(ppo, synth, capi):
+@pytest.mark.parametrize("trust", [False, True])
+def test_pseudo_xgcm_steps_3d(ppo, synth, capi, trust):
     """BASELINE configs[2] on tets: toroidal push -> search_mesh (BCC) -> updatePtclPositions ->
     rebuild -> gyroScatter (tet ring map) x2, 8 steps; element ids by particle id, positions and
-    scatter sums bit-exact vs the oracle."""
+    scatter sums bit-exact vs the oracle.  trust: from the second step on the caller vouches for the
+    origins (pp_ps_set_origin_trust: they are the destinations the previous walk accepted), the fused
+    push skips check_initial_parents -- the oracle still runs it, and nothing changes."""
     pop = common.population_3d(synth, n_b=5, n_theta=20, n_planes=8, num_ptcls=4000)
     mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
     mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
@@ -856,6 +859,9 @@ def test_pseudo_xgcm_steps_3d(ppo, synth, capi):
         ids_o = ppo.search_mesh(mo, po, looplimit=200)["elem_ids"]
         ids_g = capi.DevArray(max(pg.capacity(), 1), np.int32)
         capi.push_search(mg, pg, H, K, D, 6.0, ids_g, seeded=False, looplimit=200)
+        if trust:
+            assert capi.push_search_counters()[2] == 0  # nobody finished as "unmoved" without a test
+            pg.set_origin_trust(True)
         io, eo = common.by_id(po.member(2)[0, :po.capacity()], po.slot_info()[1], ids_o[:po.capacity()])
         ig, eg = common.by_id(pg.member(2)[0, :pg.capacity()], pg.slot_info()[1],
                               ids_g.to_host()[:pg.capacity()])

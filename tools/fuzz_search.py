@@ -122,7 +122,9 @@ def main(seconds=60.0, seed=0):
         else:
             ids_o = None
             ids_g = capi.DevArray.from_host(np.full(max(pg.capacity(), 1), -1, dtype=np.int32))
+            trust = bool(rng.random() < 0.5)  # from step 1 on the origins are the accepted destinations
             for step in range(int(rng.integers(2, 7))):
+                pg.set_origin_trust(trust and step > 0)
                 cap = po.capacity()
                 if dim == 3:
                     ppo.toroidal_push(po, mo, H, K, D, deg, trig=1)
