@@ -309,6 +309,12 @@ int pp_create_gyro_ring_mappings(const pp_mesh* mesh, double rmax, int gnr, int 
  * a copy.  Any other map pointer takes the atomic form. */
 int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, double rmax, int gnr,
                     int gppr, double* scatter_w_dev);
+/* A caller that edits a ring map in place with its own kernel / hipMemcpy (outside pp_memcpy_h2d /
+ * pp_memset / pp_free, which drop the transpose themselves) tells the library so: the map then takes
+ * the atomic form.  The two maps of one pp_create_gyro_ring_mappings call share one transpose (the
+ * reference's projection is the identity, gyroScatter.hpp:125-134); forgetting either leaves the
+ * other served. */
+int pp_gyro_map_forget(const int* map_dev);
 /* gyroScatter with the particle radius the reference leaves as a TODO (test/gyroScatter.hpp:184
  * "ptclRadius = ringWidth*1.125; //TODO compute the radius") taken PER PARTICLE, and an optional
  * per-particle weight in place of the literal 1 (charge deposition).  Same ring selection (:186-191)

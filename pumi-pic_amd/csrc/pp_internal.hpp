@@ -136,6 +136,7 @@ static_assert(sizeof(pp_tri_rec) == 64, "tri record must be 64 B");
 static_assert(sizeof(pp_tet_rec) == 128, "tet record must be 128 B");
 
 struct pp_mesh {
+  unsigned long long uid = 0;  // unique per mesh object (caches keyed on a mesh survive a new mesh at the same address)
   int dim = 0, nverts = 0, nelems = 0, nsides = 0;
   double tol = 0;  // compute_tolerance_from_area
   double unmoved_sq = 0;  // min{s : sqrt(s) >= tol}: norm(v) < tol  <=>  v.v < unmoved_sq

@@ -227,6 +227,7 @@ pp_mesh* pp_mesh_create(int dim, int nverts, const double* coords_host, int nele
   }
   if (!pp::initialised() && pp_init(0) != PP_OK) return nullptr;
   pp_mesh* m = new pp_mesh();
+  m->uid = pp::next_version();
   m->dim = dim;
   m->nverts = nverts;
   m->nelems = nelems;

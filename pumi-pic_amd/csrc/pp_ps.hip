@@ -224,10 +224,19 @@ __global__ void k_count_added(int n_new, const int* __restrict__ new_elems, int 
 }
 // ---- stable LSD radix sort (8-bit digits) of (key64, val32)
 constexpr int RS_TILE = 2048;  // keys per block
+// (also the per-element totals of the new population -- live particles, non-empty elements, rows
+// that overflow their current chunk: k_nonempty and k_fit_check in the same sweep -- when `totals`)
+struct ElemTotalsArgs {
+  int totals;  // accumulate active / nonempty
+  int fit;     // accumulate n_over against the CURRENT layout
+  int C_old;
+  const int *e2r_old, *chunk_width_old;
+};
 __global__ void k_make_keys(int ne, const int* __restrict__ ppe, int sigma, int n_sigma,
                             unsigned long long base, unsigned long long* __restrict__ keys,
-                            int* __restrict__ vals, Totals* tot, int no_skip) {
+                            int* __restrict__ vals, Totals* tot, int no_skip, ElemTotalsArgs et) {
   unsigned long long mx = 0;
+  int nz = 0, sum = 0, over = 0;
   const int base_i = blockIdx.x * RS_TILE;
   for (int j = threadIdx.x; j < RS_TILE; j += 256) {
     const int i = base_i + j;
@@ -237,10 +246,39 @@ __global__ void k_make_keys(int ne, const int* __restrict__ ppe, int sigma, int 
       w = i / sigma;
       if (w > n_sigma - 1) w = n_sigma - 1;
     }
-    const unsigned long long key = (unsigned long long)w * base + (unsigned long long)ppe[i];
+    const int n = ppe[i];
+    const unsigned long long key = (unsigned long long)w * base + (unsigned long long)n;
     keys[i] = key;
     vals[i] = i;
     mx = key > mx ? key : mx;
+    nz += n > 0;
+    sum += n;
+    if (et.fit) over += n > et.chunk_width_old[et.e2r_old[i] / et.C_old];
+  }
+  if (et.totals) {
+    __shared__ int s_t[4][3];
+    for (int o = 32; o > 0; o >>= 1) {
+      nz += __shfl_down(nz, o);
+      sum += __shfl_down(sum, o);
+      over += __shfl_down(over, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      s_t[threadIdx.x >> 6][0] = nz;
+      s_t[threadIdx.x >> 6][1] = sum;
+      s_t[threadIdx.x >> 6][2] = over;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      nz = s_t[0][0] + s_t[1][0] + s_t[2][0] + s_t[3][0];
+      sum = s_t[0][1] + s_t[1][1] + s_t[2][1] + s_t[3][1];
+      over = s_t[0][2] + s_t[1][2] + s_t[2][2] + s_t[3][2];
+      if (nz) {
+        atomicAdd(&tot->nonempty, nz);
+        atomicAdd(&tot->active, sum);
+      }
+      if (over) atomicAdd(&tot->n_over, over);
+    }
+    __syncthreads();
   }
   // the host sizes the number of 8-bit passes from an upper bound (total particles); the real
   // maximum (a per-element count) usually needs one or two passes: later passes see it and copy.
@@ -1921,7 +1959,7 @@ struct LayoutPlan {
 // bits_limit > 0: sort on the low `bits_limit` key bits only (the caller predicts the largest key
 // from the previous rebuild and checks the prediction against Totals::max_key afterwards)
 int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_base, LayoutPlan& L,
-                   int bits_limit = 0) {
+                   int bits_limit = 0, ElemTotalsArgs et = ElemTotalsArgs{0, 0, 1, nullptr, nullptr}) {
   hipStream_t st = pp::stream();
   const int ne = ps->num_elems;
   L.C = C_new;
@@ -1944,7 +1982,7 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
     k_make_keys<<<nblk, 256, 0, st>>>(ne, ppe, sg, n_sigma, L.base,
                                                  ps->s_keys.as<unsigned long long>(),
                                                  ps->s_vals.as<int>(), tot,
-                                                 getenv("PP_NO_RS_SKIP") != nullptr);
+                                                 getenv("PP_NO_RS_SKIP") != nullptr, et);
     unsigned long long maxkey = (unsigned long long)(n_sigma > 0 ? n_sigma : 1) * L.base;
     int bits = 0;
     while (bits < 64 && (maxkey >> bits)) ++bits;
@@ -2325,15 +2363,20 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   }
   // 64..256 blocks: each block ends with two atomics on the same two counters (~5 ns apiece), each
   // thread strides over ne / (blocks * 256) elements
-  if (ne > 0)
-    k_nonempty<<<std::min(grid_for(ne), std::min(256u, std::max(64u, (unsigned)(ne / 4096)))), kBlock, 0, st>>>(
-        ne, ppe, tot);
   // the reference's reshuffle decision (mode 1), on the histogram just built
   const bool decide_keep = try_reshuffle && ps->shuffle_mode == 1 && have_old && ne > 0 && ps->elem_count_valid &&
                            getenv("PP_NO_RESHUFFLE") == nullptr;
-  if (decide_keep)
-    k_fit_check<<<std::min(grid_for(ne), 256u), kBlock, 0, st>>>(ne, ps->C, ppe, ps->d_element_to_row.as<int>(),
-                                                               ps->d_chunk_width.as<int>(), tot);
+  // totals of the new population + the decision: in the sweep that makes the sort keys when the layout
+  // is sorted (one launch instead of three), else their own kernels
+  const bool totals_in_keys = ps->sigma > 1 && ne > 1;
+  if (!totals_in_keys) {
+    if (ne > 0)
+      k_nonempty<<<std::min(grid_for(ne), std::min(256u, std::max(64u, (unsigned)(ne / 4096)))), kBlock, 0, st>>>(
+          ne, ppe, tot);
+    if (decide_keep)
+      k_fit_check<<<std::min(grid_for(ne), 256u), kBlock, 0, st>>>(ne, ps->C, ppe, ps->d_element_to_row.as<int>(),
+                                                                 ps->d_chunk_width.as<int>(), tot);
+  }
   // Sort keys are (window, count) with count < key_base; an upper bound known on the host avoids
   // a D2H read of the live count before the layout can start.
   const long long key_base = (long long)(have_old ? ps->num_ptcls : 0) + n_new + 1;
@@ -2347,7 +2390,9 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     while (bits_pred < 63 && (ps->last_max_key >> bits_pred)) ++bits_pred;
     ++bits_pred;
   }
-  int rc = enqueue_layout(ps, ps->C_max, ppe, tot, key_base, L, bits_pred);
+  int rc = enqueue_layout(ps, ps->C_max, ppe, tot, key_base, L, bits_pred,
+                          ElemTotalsArgs{totals_in_keys ? 1 : 0, (totals_in_keys && decide_keep) ? 1 : 0, ps->C,
+                                         ps->d_element_to_row.as<int>(), ps->d_chunk_width.as<int>()});
   if (rc) return rc;
   int nchunks = L.nchunks, nrows = L.nrows;
   PP_HIP_CHECK(ps->s_eslot0.reserve(sizeof(int) * (size_t)std::max(ne, 1)));

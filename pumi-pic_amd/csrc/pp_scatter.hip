@@ -372,6 +372,7 @@ __global__ void k_vert_density(int nverts, const int* __restrict__ v2e_off,
 // ring accumulation kept for the next pp_gyro_scatter call on the same particle->element assignment
 const pp_ps* c_ps = nullptr;
 const pp_mesh* c_mesh = nullptr;
+unsigned long long c_mesh_uid = 0;
 unsigned long long c_version = 0;
 int c_gnr = 0, c_down = -1;
 pp::DevBuf* g_ring = nullptr;  // library-lifetime scratch: ring accumulator
@@ -379,13 +380,15 @@ struct InvMap {
   const int* key[2];  // forward and backward map of one pp_create_gyro_ring_mappings call
   size_t bytes;
   const pp_mesh* mesh;
+  unsigned long long mesh_uid;
   int gnr, gppr;
   pp::DevBuf off, src;
 };
 std::vector<InvMap*> g_inv;
 const InvMap* find_inverse(const int* v2v, const pp_mesh* mesh, int gnr, int gppr) {
   for (const InvMap* m : g_inv)
-    if ((m->key[0] == v2v || m->key[1] == v2v) && m->mesh == mesh && m->gnr == gnr && m->gppr == gppr)
+    if ((m->key[0] == v2v || m->key[1] == v2v) && m->mesh == mesh && m->mesh_uid == mesh->uid && m->gnr == gnr &&
+        m->gppr == gppr)
       return m;
   return nullptr;
 }
@@ -483,6 +486,7 @@ int pp_create_gyro_ring_mappings(const pp_mesh* mesh, double rmax, int gnr, int 
     m->key[1] = backward_map_dev;
     m->bytes = sizeof(int) * (size_t)entries;
     m->mesh = mesh;
+    m->mesh_uid = mesh->uid;
     m->gnr = gnr;
     m->gppr = gppr;
     hipStream_t st = pp::stream();
@@ -533,7 +537,8 @@ int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, do
     // The ring accumulation depends only on (mesh, particle->element assignment, ring geometry):
     // the forward and backward scatters of one step (gyroScatter.hpp is called twice per step,
     // pseudoXGCm.cpp:529-530) share it.
-    const bool reuse = c_ps == ps && c_mesh == mesh && c_version == ps->version && ps->version != 0 &&
+    const bool reuse = c_ps == ps && c_mesh == mesh && c_mesh_uid == mesh->uid && c_version == ps->version &&
+                       ps->version != 0 &&
                        c_gnr == gnr && c_down == ringDown;
     if (!reuse) {
       // live particles per element: kept current by construction / rebuild (it IS the histogram
@@ -556,6 +561,7 @@ int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, do
           ringUp, s_ring->as<double>());
       c_ps = ps;
       c_mesh = mesh;
+      c_mesh_uid = mesh->uid;
       c_version = ps->version;
       c_gnr = gnr;
       c_down = ringDown;
@@ -622,6 +628,11 @@ int pp_gyro_scatter_radius(const pp_mesh* mesh, const pp_ps* ps, const double* r
     PP_HIP_CHECK(hipMemcpyAsync(num_clipped, clip_dev, sizeof(int), hipMemcpyDeviceToHost, st));
     PP_HIP_CHECK(hipStreamSynchronize(st));
   }
+  return PP_OK;
+}
+
+int pp_gyro_map_forget(const int* map_dev) {
+  if (map_dev) pp::gyro_map_invalidate(map_dev, 1);
   return PP_OK;
 }
 

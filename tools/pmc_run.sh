@@ -12,7 +12,7 @@ BENCH_ARGS="$*"
 pass() {
   name=$1; shift
   timeout 240 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$name" -o p -- \
-    python3 "$R/bench.py" $BENCH_ARGS > "$OUT/$name.log" 2>&1
+    python3 "$R/bench.py" --no-cpu-baseline $BENCH_ARGS > "$OUT/$name.log" 2>&1
 }
 pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_VMEM SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64

@@ -43,8 +43,8 @@ def main(out_dir, workload, particles, nsteps, dest, pmc_dir, bytes_per_particle
         if sub != pmc_dir or "FETCH_SIZE" not in ctr or "WRITE_SIZE" not in ctr:
             continue
         n = min(len(ctr["FETCH_SIZE"]), len(ctr["WRITE_SIZE"]))
-        if n < nsteps or "k_closest_point" in name:
-            continue
+        if n < nsteps or "k_closest_point" in name or name.startswith("__amd_rocclr"):
+            continue  # (runtime fills / copies: < 1 MB per step; their dispatch list also holds the set-up memsets)
         r = sum(ctr["FETCH_SIZE"]) * kib * rf / nsteps
         w = sum(ctr["WRITE_SIZE"]) * kib * wf / nsteps
         short = name.replace("(anonymous namespace)::", "").split("(")[0]
