@@ -542,6 +542,17 @@ int pp_migrate_ptcls_begin(pp_ps* ps, int m_x, int m_xtgt, int* elem_ids_dev, co
 int pp_range_push(const char* name);
 int pp_range_pop(void);
 
+/* ray_intersects_triangle (segment == 0) / line_segment_intersects_triangle (segment == 1),
+ * src/pumipic_adjacency.tpp:152-201, over n (triangle, origin, destination) triples: tris_dev holds 9
+ * doubles per triangle at stride tri_stride doubles (0 = one triangle for all), orig / dest 3 doubles per
+ * ray; flip_dev (per ray) or flip_all is the orientation flag of the face (utils.hpp:501-507).  hit_dev[i]
+ * = the reference's return value; xpoint_dev (3 per ray) and dproj_closeness_param_dev (3 per ray) may
+ * be NULL.  The walk (find_exit_face, tpp:340,357) uses the ray form, as the reference does; the
+ * segment form is what a wall model calls when only hits inside the step count. */
+int pp_ray_intersects_triangle(int n, const double* tris_dev, int tri_stride, const double* orig_dev,
+                               const double* dest_dev, double tol, const int* flip_dev, int flip_all, int segment,
+                               int* hit_dev, double* xpoint_dev, double* dproj_closeness_param_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -121,6 +121,7 @@ SYMBOLS = {
     "pp_gyro_scatter": (_I, [_V, _V, _V, _D, _I, _I, _V]),
     "pp_gyro_sync_pack": (_I, [_I, _V, _V, _V]),
     "pp_gyro_map_forget": (_I, [_V]),
+    "pp_ray_intersects_triangle": (_I, [_I, _V, _I, _V, _V, _D, _V, _I, _I, _V, _V, _V]),
     "pp_gyro_scatter_radius": (_I, [_V, _V, _V, _V, _V, _D, _I, _I, _V, c_int_p]),
     "pp_gather_tet_vtx": (_I, [_V, _V, _I, _V, _V, _I, _V, _V]),
     "pp_interp2d_field": (_I, [_V, _I, _V, _D, _D, _D, _D, _I, _I, _I, _I, _I, _V]),
@@ -1113,3 +1114,19 @@ def push_search_counters():
     a, b, c = C.c_int(), C.c_int(), C.c_int()
     check(lib().pp_push_search_counters(C.byref(a), C.byref(b), C.byref(c)))
     return a.value, b.value, c.value
+
+
+def ray_intersects_triangle(tris, orig, dest, tol, flip=0, segment=False):
+    """batch ray / segment vs triangle -> (hit[n], xpoint[n,3], (dproj, closeness, param)[n,3])"""
+    orig = np.ascontiguousarray(orig, dtype=np.float64).reshape(-1, 3)
+    dest = np.ascontiguousarray(dest, dtype=np.float64).reshape(-1, 3)
+    n = len(orig)
+    tris = np.ascontiguousarray(tris, dtype=np.float64)
+    stride = 0 if tris.size == 9 else 9
+    d_t, d_o, d_d = DevArray.from_host(tris.ravel()), DevArray.from_host(orig.ravel()), DevArray.from_host(dest.ravel())
+    fl = np.asarray(flip)
+    d_f = DevArray.from_host(fl.astype(np.int32)) if fl.ndim else None
+    hit, xp, o3 = DevArray(max(n, 1), np.int32), DevArray(max(3 * n, 1), np.float64), DevArray(max(3 * n, 1), np.float64)
+    check(lib().pp_ray_intersects_triangle(n, d_t.ptr, stride, d_o.ptr, d_d.ptr, tol, d_f.ptr if d_f is not None else None,
+                                           0 if fl.ndim else int(fl), int(segment), hit.ptr, xp.ptr, o3.ptr))
+    return hit.to_host()[:n].astype(bool), xp.to_host()[:3 * n].reshape(n, 3), o3.to_host()[:3 * n].reshape(n, 3)

@@ -143,7 +143,51 @@ __global__ void k_closest_point(int n, const double* __restrict__ tris, int tri_
   if (region) region[i] = reg;
 }
 
+// ray_intersects_triangle / line_segment_intersects_triangle (adjacency.tpp:152-201) over n (triangle,
+// origin, destination) triples
+__global__ void k_ray_triangle(int n, const double* __restrict__ tris, int tri_stride,
+                               const double* __restrict__ orig, const double* __restrict__ dest, double tol,
+                               const int* __restrict__ flip, int flip_all, int segment, int* __restrict__ hit,
+                               double* __restrict__ xpoint, double* __restrict__ out3) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  ppg::V3 fv[3];
+  for (int k = 0; k < 3; ++k)
+    fv[k] = {tris[(size_t)i * tri_stride + 3 * k], tris[(size_t)i * tri_stride + 3 * k + 1],
+             tris[(size_t)i * tri_stride + 3 * k + 2]};
+  const ppg::V3 o{orig[(size_t)i * 3], orig[(size_t)i * 3 + 1], orig[(size_t)i * 3 + 2]};
+  const ppg::V3 d{dest[(size_t)i * 3], dest[(size_t)i * 3 + 1], dest[(size_t)i * 3 + 2]};
+  ppg::V3 xp;
+  double dproj, closeness, param;
+  bool h = ppg::ray_intersects_triangle(fv, o, d, xp, tol, flip ? flip[i] : flip_all, dproj, closeness, param);
+  if (segment) h = h && param <= 1 + tol;  // tpp:192-201
+  hit[i] = h ? 1 : 0;
+  if (xpoint) {
+    xpoint[(size_t)i * 3] = xp.x;
+    xpoint[(size_t)i * 3 + 1] = xp.y;
+    xpoint[(size_t)i * 3 + 2] = xp.z;
+  }
+  if (out3) {
+    out3[(size_t)i * 3] = dproj;
+    out3[(size_t)i * 3 + 1] = closeness;
+    out3[(size_t)i * 3 + 2] = param;
+  }
+}
+
 extern "C" {
+
+int pp_ray_intersects_triangle(int n, const double* tris_dev, int tri_stride, const double* orig_dev,
+                               const double* dest_dev, double tol, const int* flip_dev, int flip_all, int segment,
+                               int* hit_dev, double* xpoint_dev, double* dproj_closeness_param_dev) {
+  PP_REQUIRE(n >= 0 && tris_dev && orig_dev && dest_dev && hit_dev && (tri_stride == 0 || tri_stride >= 9),
+             "pp_ray_intersects_triangle: bad argument");
+  if (n == 0) return PP_OK;
+  k_ray_triangle<<<grid_for(n), kBlock, 0, pp::stream()>>>(n, tris_dev, tri_stride, orig_dev, dest_dev, tol, flip_dev,
+                                                          flip_all, segment, hit_dev, xpoint_dev,
+                                                          dproj_closeness_param_dev);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
 
 int pp_gather_tet_vtx(const pp_mesh* mesh, const pp_ps* ps, int m_x, const int* elem_ids_dev,
                       const double* field_dev, int dof, double* out_dev, int* num_degenerate) {

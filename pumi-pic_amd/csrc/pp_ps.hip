@@ -2368,7 +2368,8 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
                            getenv("PP_NO_RESHUFFLE") == nullptr;
   // totals of the new population + the decision: in the sweep that makes the sort keys when the layout
   // is sorted (one launch instead of three), else their own kernels
-  const bool totals_in_keys = ps->sigma > 1 && ne > 1;
+  // (up to 256 key blocks: every block ends with three atomics on the same counters, ~10 ns each)
+  const bool totals_in_keys = ps->sigma > 1 && ne > 1 && (ne + RS_TILE - 1) / RS_TILE <= 256;
   if (!totals_in_keys) {
     if (ne > 0)
       k_nonempty<<<std::min(grid_for(ne), std::min(256u, std::max(64u, (unsigned)(ne / 4096)))), kBlock, 0, st>>>(

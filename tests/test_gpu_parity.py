@@ -1531,3 +1531,30 @@ def test_gyro_scatter_per_particle_radius(ppo, synth, capi, dim, kind):
     assert clip == 0
     assert np.array_equal(a.to_host()[:mo.nverts], capi.gyro_scatter(mg, pg, fg, rmax, gnr, gppr).to_host()[:mo.nverts])
     assert np.array_equal(a.to_host()[:mo.nverts], ppo.gyro_scatter(mo, po, fo, rmax, gnr, gppr))
+
+
+@pytest.mark.parametrize("segment", [False, True])
+def test_ray_and_segment_triangle_match_oracle(ppo, capi, segment):
+    """pp_ray_intersects_triangle: ray (adjacency.tpp:152-178) and segment (tpp:192-201) forms, bit for bit
+    against the oracle on random triangles, both orientations, rays that stop short of / pass through
+    the face (test/moller_trumbore_line_tri_test.cpp:51-162 distinguishes exactly those)."""
+    rng = np.random.default_rng(12)
+    n = 4000
+    tris = rng.normal(size=(n, 9))
+    # aim at a point of the triangle (or near it), stop before or beyond it
+    bary = rng.dirichlet([1, 1, 1], size=n) + rng.normal(scale=0.2, size=(n, 3)) * (rng.random((n, 1)) < 0.3)
+    target = (tris.reshape(n, 3, 3) * bary[:, :, None]).sum(axis=1)
+    orig = target + rng.normal(size=(n, 3))
+    dest = orig + (target - orig) * rng.uniform(0.3, 1.8, size=(n, 1))
+    flip = rng.integers(0, 2, size=n)
+    hit, xp, o3 = capi.ray_intersects_triangle(tris, orig, dest, 1e-8, flip, segment)
+    nh = 0
+    for i in range(n):
+        h, x, dproj, close, par = ppo.ray_triangle(tris[i], orig[i], dest[i], 1e-8, int(flip[i]), segment)
+        assert h == hit[i], i
+        assert np.array_equal(x, xp[i]) and (dproj, close, par) == tuple(o3[i]), i
+        nh += h
+    assert 0.05 * n < nh < 0.95 * n
+    if segment:  # the segment form rejects hits beyond the destination that the ray form accepts
+        hit_ray, _, _ = capi.ray_intersects_triangle(tris, orig, dest, 1e-8, flip, False)
+        assert (hit_ray & ~hit).sum() > 0 and not (hit & ~hit_ray).any()
