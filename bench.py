@@ -94,8 +94,9 @@ def build_workload(pp, capi, name, nptcl, rank, world, deg, remainder="last", me
         R = np.hypot(xyz[0], xyz[1]) if dim == 3 else xyz[0]
         Z = xyz[2] if dim == 3 else xyz[1]
         b, phi = synth.elliptical_state(R, Z)
-        try:
-            np.savez(cache, ppe=ppe, elem=elem, xyz=xyz, b=b, phi=phi)
+        try:  # (not for the 32 M-particle populations: 1.2 GB per rank, possibly on a memory-backed /tmp)
+            if nptcl <= 16_000_000 or os.environ.get("PP_BENCH_CACHE"):
+                np.savez(cache, ppe=ppe, elem=elem, xyz=xyz, b=b, phi=phi)
         except OSError:
             pass
     info = [xyz, np.zeros_like(xyz), np.arange(nptcl, dtype=np.int32), b, phi]

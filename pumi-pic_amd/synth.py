@@ -164,28 +164,32 @@ def xgcm_source_counts(class_id, num_ptcls, mdl_face, seed=ELEMENT_SEED, remaind
     return ppe
 
 
-def particles_in_elements(coords, e2v, ppe, seed=PARTICLE_SEED):
+def particles_in_elements(coords, e2v, ppe, seed=PARTICLE_SEED, chunk=1 << 21):
     """Uniform positions inside each particle's element (pseudoXGCm.cpp:224-264 for triangles:
-    r1,r2 with the x+y>1 fold; tets: sorted-uniform barycentrics).  Returns (elem, xyz[3,np])."""
+    r1,r2 with the x+y>1 fold; tets: sorted-uniform barycentrics).  Returns (elem, xyz[3,np]).
+    Generated in chunks (the random stream is consumed in the same order, so the result does not
+    depend on the chunk size): 32 M tets' worth of vertex gathers would otherwise peak at ~7 GB per
+    rank, and 8 ranks build their populations at the same time."""
     dim = coords.shape[1]
     np_ = int(ppe.sum())
     elem = np.repeat(np.arange(len(ppe), dtype=np.int32), ppe)
     rng = np.random.Generator(np.random.PCG64(seed))
-    p = coords[e2v[elem]]  # (np, dim+1, dim)
-    if dim == 2:
-        r = rng.random((np_, 2))
-        fold = r.sum(axis=1) > 1
-        r[fold] = 1 - r[fold]
-        xy = p[:, 0] + r[:, :1] * (p[:, 1] - p[:, 0]) + r[:, 1:] * (p[:, 2] - p[:, 0])
-        xyz = np.zeros((3, np_))
-        xyz[0], xyz[1] = xy[:, 0], xy[:, 1]
-    else:
-        u = np.sort(rng.random((np_, 3)), axis=1)
-        w = np.stack([u[:, 0], u[:, 1] - u[:, 0], u[:, 2] - u[:, 1], 1 - u[:, 2]], axis=1)
-        # pull slightly towards the centroid so no particle starts on a face
-        w = 0.98 * w + 0.02 * 0.25
-        pos = np.einsum("nj,njk->nk", w, p)
-        xyz = np.ascontiguousarray(pos.T)
+    xyz = np.zeros((3, np_))
+    for lo in range(0, np_, chunk):
+        hi = min(np_, lo + chunk)
+        p = coords[e2v[elem[lo:hi]]]  # (n, dim+1, dim)
+        if dim == 2:
+            r = rng.random((hi - lo, 2))
+            fold = r.sum(axis=1) > 1
+            r[fold] = 1 - r[fold]
+            xy = p[:, 0] + r[:, :1] * (p[:, 1] - p[:, 0]) + r[:, 1:] * (p[:, 2] - p[:, 0])
+            xyz[0, lo:hi], xyz[1, lo:hi] = xy[:, 0], xy[:, 1]
+        else:
+            u = np.sort(rng.random((hi - lo, 3)), axis=1)
+            w = np.stack([u[:, 0], u[:, 1] - u[:, 0], u[:, 2] - u[:, 1], 1 - u[:, 2]], axis=1)
+            # pull slightly towards the centroid so no particle starts on a face
+            w = 0.98 * w + 0.02 * 0.25
+            xyz[:, lo:hi] = np.einsum("nj,njk->nk", w, p).T
     return elem, xyz
 
 
