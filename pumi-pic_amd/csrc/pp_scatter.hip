@@ -431,6 +431,17 @@ int gyro_scatter_counts(const pp_mesh* mesh, const int* cnt_dev, int nmaps, cons
   for (int k = 0; k < nmaps; ++k) {
     const InvMap* inv = no_gather ? nullptr : find_inverse(v2v_dev[k], mesh, gnr, gppr);
     if (inv) {
+      // the two maps of one createGyroRingMappings call hold the same ids (the reference's projection is
+      // the identity, gyroScatter.hpp:125-134) and share one transpose: the same sums in the same
+      // order -- the second field is a copy of the first
+      int same = -1;
+      for (int j = 0; j < k && same < 0; ++j)
+        if (!no_gather && find_inverse(v2v_dev[j], mesh, gnr, gppr) == inv && out_dev[j] != out_dev[k]) same = j;
+      if (same >= 0) {
+        PP_HIP_CHECK(hipMemcpyAsync(out_dev[k], out_dev[same], sizeof(double) * (size_t)nverts,
+                                    hipMemcpyDeviceToDevice, st));
+        continue;
+      }
       k_scatter_gathered<<<grid_for((size_t)nverts * 16), kBlock, 0, st>>>(
           nverts, gppr, inv->off.as<int>(), inv->src.as<int>(), g_ring->as<double>(), out_dev[k]);
     } else {
