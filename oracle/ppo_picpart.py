@@ -1,0 +1,279 @@
+"""CPU restatement (numpy) of PUMI-PIC's PICpart construction and comm-array reduction -- TEST
+INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg); the product never
+imports it.
+
+Follows, function by function,
+  src/pumipic_part_construct.cpp:75-275   Mesh::Mesh(Input&), constructPICPart
+  src/pumipic_part_construct.cpp:278-386  setOwnerByClassification, defineOwners, calculateOwnerOffset,
+                                          createGlobalNumbering, rankLidNumbering
+  src/pumipic_part_construct.cpp:470-507  setSafeEnts, sumPositives
+  src/pumipic_comm.cpp:11-191             Mesh::setupComm
+  src/pumipic_comm.cpp:249-440            Mesh::reduceCommArray (fan-in through the owners, fan-out)
+All ranks of the job are simulated inside one process (`PicParts` holds every rank's part).
+
+PARITY UNPINNED for this file: the reference's tests for these functions (test_comm_array.cpp,
+test_input_construct.cpp, test_full_mesh.cpp) need Omega_h meshes from the empty pumipic-data submodule
+and hold no golden numbers; what they assert -- minOwnership, sumEntities, fullBufferTest, the BFS safe
+zone -- is restated in tests/test_picpart_oracle.py on synthetic meshes.
+
+Two places where the reference leaves the result open, and what is fixed here (and in the HIP library):
+  * renumberBoundaryLids numbers the entities of a partially buffered part with atomics, "the order
+    doesn't need to be consistent" (pumipic_comm.cpp:66-76): here in increasing picpart entity id;
+  * the owner adds the fan-in contributions in arrival order (MPI_Waitany, :311-318): here in increasing
+    rank, the owner's own value first.
+Entity dimensions: 0 (vertices) and dim (elements); the meshes of this repo carry no edge numbering.
+"""
+import numpy as np
+
+FULL, BFS, MINIMUM, NONE = 0, 1, 2, 3          # Input::Method, src/pumipic_input.hpp:33-39
+SUM_OP, MAX_OP, MIN_OP, BCAST_OP = 0, 1, 2, 3  # Mesh::Op, src/pumipic_mesh.hpp:64-69
+
+
+def set_owner_by_classification(class_id, class_owners):
+    """setOwnerByClassification, pumipic_part_construct.cpp:278-302"""
+    return np.asarray(class_owners, dtype=np.int32)[np.asarray(class_id)]
+
+
+def define_owners(up_off, up, elem_owner, comm_size):
+    """defineOwners :305-323 -- a lower-dimension entity belongs to the smallest owner among the elements
+    around it"""
+    n = len(up_off) - 1
+    out = np.full(n, comm_size, dtype=np.int32)
+    own = np.asarray(elem_owner)[up]
+    ent = np.repeat(np.arange(n), np.diff(up_off))
+    np.minimum.at(out, ent, own)
+    return out
+
+
+def calculate_owner_offset(owner, comm_size):
+    """calculateOwnerOffset :325-334 -> exclusive scan of the entities per rank (comm_size + 1)"""
+    cnt = np.bincount(owner, minlength=comm_size)[:comm_size]
+    return np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+
+
+def create_global_numbering(owner, comm_size):
+    """createGlobalNumbering + GlobalNumberer :336-376: gid = offset of the owner + number of earlier
+    entities with the same owner"""
+    off = calculate_owner_offset(owner, comm_size)
+    gids = np.zeros(len(owner), dtype=np.int64)
+    for r in range(comm_size):
+        sel = np.flatnonzero(owner == r)
+        gids[sel] = off[r] + np.arange(len(sel))
+    return off, gids
+
+
+def rank_lid_numbering(owner, offset, gids):
+    """rankLidNumbering :378-386"""
+    return (gids - offset[owner]).astype(np.int32)
+
+
+def bfs_sweep(up_off, up, visited):
+    """BFS :388-405: every bridge entity with a visited element marks all its elements"""
+    ent = np.repeat(np.arange(len(up_off) - 1), np.diff(up_off))
+    hit = np.zeros(len(up_off) - 1, dtype=bool)
+    np.logical_or.at(hit, ent, visited[up].astype(bool))
+    nxt = visited.copy()
+    nxt[up[hit[ent]]] = 1
+    return nxt
+
+
+def bfs_buffer_layers(up_off, up, owner, rank, comm_size, safe_layers, ghost_layers):
+    """bfsBufferLayers :407-437 -> (is_safe, has_part)"""
+    visited = (owner == rank).astype(np.int32)
+    is_safe = visited.copy()
+    has_part = np.zeros(comm_size, dtype=np.int32)
+    has_part[rank] = 1
+    i = 0
+    while i < ghost_layers or i < safe_layers:
+        visited = bfs_sweep(up_off, up, visited)
+        if i == safe_layers - 1:
+            is_safe = visited.copy()
+        if i < ghost_layers:
+            has_part[np.unique(owner[visited.astype(bool)])] = 1
+        i += 1
+    return is_safe, has_part
+
+
+def bfs_safe_inward(up_off, up, owner, rank, safe_layers, has_part):
+    """bfsSafeInward :439-468"""
+    visited = (has_part[owner] == 0).astype(np.int32)
+    for _ in range(safe_layers):
+        visited = bfs_sweep(up_off, up, visited)
+    return ((visited == 0) | (owner == rank)).astype(np.int32)
+
+
+def input_safe_and_buffer(up_off, up, owner, rank, comm_size, buffer_method, safe_method, buffer_layers,
+                          safe_layers):
+    """Mesh::Mesh(Input&) :75-118 -> (is_safe, has_part, is_full_mesh)"""
+    ne = len(owner)
+    is_safe = np.full(ne, 1 if safe_method == FULL else 0, dtype=np.int32)
+    has_part = np.ones(comm_size, dtype=np.int32)
+    if (safe_method not in (NONE, FULL)) or buffer_method != FULL:
+        safe, part = bfs_buffer_layers(up_off, up, owner, rank, comm_size, safe_layers, buffer_layers)
+        if safe_method in (BFS, MINIMUM):
+            is_safe = safe
+        if buffer_method in (BFS, MINIMUM):
+            has_part = part
+    if buffer_method == BFS and safe_method == FULL:
+        is_safe = bfs_safe_inward(up_off, up, owner, rank, safe_layers, has_part)
+    return is_safe, has_part, buffer_method == FULL
+
+
+class Part:
+    """one rank's PICpart (constructPICPart :120-275 + setupComm)"""
+
+
+class PicParts:
+    def __init__(self, mesh, elem_owner, comm_size, buffer_method=FULL, safe_method=FULL, bridge_dim=0,
+                 buffer_layers=3, safe_layers=1):
+        """mesh: oracle/ppo.py Mesh (full mesh, loaded on every rank as in the reference's drivers);
+        MINIMUM is BFS with 0 layers (pumipic_input.cpp sets the layer counts that way)"""
+        self.mesh, self.comm_size = mesh, comm_size
+        dim = mesh.dim
+        owner = np.asarray(elem_owner, dtype=np.int32)
+        if buffer_method == MINIMUM:
+            buffer_layers = 0
+        if safe_method == MINIMUM:
+            safe_layers = 0
+        if bridge_dim == 0:
+            up_off, up = mesh.vert2elems_off, mesh.vert2elems
+        elif bridge_dim == dim - 1:
+            up_off, up = mesh.side2elems_off, mesh.side2elems
+        else:
+            raise ValueError("bridge_dim must be 0 or dim-1")
+        # ---- ownership and global numbering of the full mesh (constructPICPart :141-163)
+        self.owner = {0: define_owners(mesh.vert2elems_off, mesh.vert2elems, owner, comm_size), dim: owner}
+        self.offsets, self.gids, self.rank_lids = {}, {}, {}
+        for d in (0, dim):
+            self.offsets[d], self.gids[d] = create_global_numbering(self.owner[d], comm_size)
+            self.rank_lids[d] = rank_lid_numbering(self.owner[d], self.offsets[d], self.gids[d])
+        self.parts = []
+        for rank in range(comm_size):
+            p = Part()
+            p.rank = rank
+            p.is_safe_full, p.has_part, p.is_full_mesh = input_safe_and_buffer(
+                up_off, up, owner, rank, comm_size, buffer_method, safe_method, buffer_layers, safe_layers)
+            # setSafeEnts :470-494: an entity stays when an element around it belongs to a buffered part
+            keep_e = p.has_part[owner].astype(bool)
+            keep_v = np.zeros(mesh.nverts, dtype=bool)
+            keep_v[mesh.elem2verts[keep_e].ravel()] = True
+            p.ent_ids = {}  # full id -> picpart id, -1 = not in the part (:181-194)
+            p.full_ids = {}
+            for d, keep in ((0, keep_v), (dim, keep_e)):
+                ids = np.full(len(keep), -1, dtype=np.int32)
+                ids[keep] = np.arange(int(keep.sum()), dtype=np.int32)
+                p.ent_ids[d] = ids
+                p.full_ids[d] = np.flatnonzero(keep).astype(np.int32)
+            # the picpart mesh (:196-258): kept vertices / elements in full-mesh order
+            p.coords = mesh.coords[p.full_ids[0]]
+            p.elem2verts = p.ent_ids[0][mesh.elem2verts[p.full_ids[dim]]]
+            p.class_id = mesh.class_id[p.full_ids[dim]]
+            p.safe = p.is_safe_full[p.full_ids[dim]].astype(np.int32)
+            p.owners = {d: self.owner[d][p.full_ids[d]] for d in (0, dim)}
+            p.gids = {d: self.gids[d][p.full_ids[d]] for d in (0, dim)}
+            p.rank_lids = {d: self.rank_lids[d][p.full_ids[d]] for d in (0, dim)}
+            p.nents = {d: len(p.full_ids[d]) for d in (0, dim)}
+            self.parts.append(p)
+        for p in self.parts:
+            self._setup_comm(p, 0)
+            self._setup_comm(p, dim)
+        for p in self.parts:  # what the owners receive (the MPI_Ialltoall + Isend/Irecv of :113-190)
+            p.bounded_ent_ids, p.bounded_offset, p.boundary_parts, p.complete_from = {}, {}, {}, {}
+            for d in (0, dim):
+                lists, off, bparts, comp = [], [0], [], []
+                for q in self.parts:
+                    if q.rank == p.rank:
+                        off.append(off[-1])
+                        continue
+                    kind = q.is_complete[d][p.rank]
+                    if kind == 1:
+                        lists.append(q.boundary_rlids[d][p.rank])
+                        bparts.append(q.rank)
+                    if kind == 2:
+                        comp.append(q.rank)
+                    off.append(off[-1] + (len(q.boundary_rlids[d][p.rank]) if kind == 1 else 0))
+                p.bounded_ent_ids[d] = (np.concatenate(lists) if lists else np.zeros(0, np.int32)).astype(np.int32)
+                p.bounded_offset[d] = np.asarray(off, dtype=np.int32)
+                p.boundary_parts[d] = bparts  # parts that hold a boundary of this part
+                p.complete_from[d] = comp     # parts that buffer this part completely
+
+    def _setup_comm(self, p, d):
+        """Mesh::setupComm, pumipic_comm.cpp:11-111"""
+        cs = self.comm_size
+        own = p.owners[d]
+        goff = self.offsets[d]
+        poff = calculate_owner_offset(own, cs)  # picpart_ents_per_rank
+        gdiff, pdiff = np.diff(goff), np.diff(poff)
+        is_complete = (gdiff == pdiff).astype(np.int32) + (pdiff != 0).astype(np.int32)  # :54-63
+        lids = (p.gids[d] - goff[own]).astype(np.int32)                                   # :43-49
+        boundary_rlids = {}
+        for r in range(cs):
+            if is_complete[r] == 1:  # renumberBoundaryLids :66-76, in increasing entity id
+                sel = np.flatnonzero(own == r)
+                lids[sel] = np.arange(len(sel), dtype=np.int32)
+                boundary_rlids[r] = p.rank_lids[d][sel].astype(np.int32)  # gatherBoundedEnts :127-137
+        if not hasattr(p, "comm_index"):
+            p.comm_index, p.nents_offsets, p.is_complete, p.boundary_rlids, p.buffered_parts = {}, {}, {}, {}, {}
+        p.comm_index[d] = (lids + poff[own]).astype(np.int32)  # :80-86
+        p.nents_offsets[d] = poff
+        p.is_complete[d] = is_complete
+        p.boundary_rlids[d] = boundary_rlids
+        p.buffered_parts[d] = [r for r in range(cs) if pdiff[r] != 0 and r != p.rank]  # :33-40
+
+    def reduce(self, d, op, arrays):
+        """reduceCommArray :249-440 on every rank at once.  arrays[r]: (nents_r * nvals) values of rank r's
+        part, entity-major; returns the reduced arrays."""
+        cs = self.comm_size
+        arrays = [np.array(a) for a in arrays]
+        if cs == 1:
+            return arrays
+        nvals = [len(a) // max(p.nents[d], 1) for a, p in zip(arrays, self.parts)]
+        if all(p.is_full_mesh for p in self.parts) and op != BCAST_OP:  # :262-277 MPI_Allreduce
+            acc = arrays[0].copy()
+            for a in arrays[1:]:
+                acc = acc + a if op == SUM_OP else (np.maximum(acc, a) if op == MAX_OP else np.minimum(acc, a))
+            return [acc.copy() for _ in arrays]
+        # convertToComm :280-288
+        comm = []
+        for a, p, nv in zip(arrays, self.parts, nvals):
+            c = np.zeros_like(a).reshape(-1, nv)
+            c[p.comm_index[d]] = a.reshape(-1, nv)
+            comm.append(c)
+        red = [c.copy() for c in comm]
+        if op != BCAST_OP:  # fan in :300-385: the owner combines, own value first, then increasing rank
+            for p in self.parts:
+                o0, o1 = p.nents_offsets[d][p.rank], p.nents_offsets[d][p.rank + 1]
+                seg = red[p.rank][o0:o1]
+                for q in self.parts:
+                    if q.rank == p.rank:
+                        continue
+                    kind = q.is_complete[d][p.rank]
+                    if kind == 0:
+                        continue
+                    q0, q1 = q.nents_offsets[d][p.rank], q.nents_offsets[d][p.rank + 1]
+                    contrib = comm[q.rank][q0:q1]
+                    idx = np.arange(o1 - o0) if kind == 2 else p.bounded_ent_ids[d][
+                        p.bounded_offset[d][q.rank]:p.bounded_offset[d][q.rank + 1]]
+                    if op == SUM_OP:
+                        seg[idx] = seg[idx] + contrib
+                    elif op == MAX_OP:
+                        seg[idx] = np.maximum(seg[idx], contrib)
+                    else:
+                        seg[idx] = np.minimum(seg[idx], contrib)
+        out = []
+        for p in self.parts:  # fan out :386-428: every part takes the owners' segments
+            c = red[p.rank].copy()
+            for r in range(cs):
+                if r == p.rank or p.is_complete[d][r] == 0:
+                    continue
+                owner_part = self.parts[r]
+                o0 = owner_part.nents_offsets[d][r]
+                q0, q1 = p.nents_offsets[d][r], p.nents_offsets[d][r + 1]
+                if p.is_complete[d][r] == 2:
+                    c[q0:q1] = red[r][o0:o0 + (q1 - q0)]
+                else:
+                    idx = owner_part.bounded_ent_ids[d][
+                        owner_part.bounded_offset[d][p.rank]:owner_part.bounded_offset[d][p.rank + 1]]
+                    c[q0:q1] = red[r][o0 + idx]
+            out.append(c[p.comm_index[d]].reshape(-1))  # convertFromComm :432-438
+        return out

@@ -16,6 +16,14 @@ namespace pp {
 void set_error(const std::string& msg);
 unsigned long long next_version();  // pp_runtime.hip: process-wide monotonic stamp
 hipStream_t stream();
+// scope in which pp::stream() is the library's side queue (fork at `fork_ev` / now, join at scope exit)
+struct SideScope {
+  bool active = false;
+  explicit SideScope(void* fork_ev = nullptr);
+  ~SideScope();
+  SideScope(const SideScope&) = delete;
+  SideScope& operator=(const SideScope&) = delete;
+};
 // pp_scatter.hip: a device range was freed / overwritten through the C-ABI -- forget the gather
 // form of any gyro ring map living there
 void gyro_map_invalidate(const void* dev, size_t bytes);

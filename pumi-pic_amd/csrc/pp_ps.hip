@@ -207,6 +207,10 @@ struct Totals {  // s_misc layout
   // "no home found for an overflowing row"
   int n_over, n_moved, match_fail, pad_;
   int dbg[8];  // the first row the elastic matching could not house (PP_SPEC_DEBUG)
+  // one-kernel sort + layout (k_layout_coop): arrival counter of its grid barriers, and which of the two
+  // key / index buffers holds the sorted result
+  unsigned bar;
+  int sort_parity;
 };
 
 __global__ void k_count_added(int n_new, const int* __restrict__ new_elems, int ne,
@@ -231,6 +235,9 @@ struct ElemTotalsArgs {
   int fit;     // accumulate n_over against the CURRENT layout
   int C_old;
   const int *e2r_old, *chunk_width_old;
+  // per-block partial sums (3 ints a block: non-empty, live, over) for the layout kernel to add up; null =
+  // atomics on the totals (every block ends with three atomics on the same counters, ~10 ns each queued)
+  int* partial;
 };
 __global__ void k_make_keys(int ne, const int* __restrict__ ppe, int sigma, int n_sigma,
                             unsigned long long base, unsigned long long* __restrict__ keys,
@@ -272,11 +279,17 @@ __global__ void k_make_keys(int ne, const int* __restrict__ ppe, int sigma, int 
       nz = s_t[0][0] + s_t[1][0] + s_t[2][0] + s_t[3][0];
       sum = s_t[0][1] + s_t[1][1] + s_t[2][1] + s_t[3][1];
       over = s_t[0][2] + s_t[1][2] + s_t[2][2] + s_t[3][2];
-      if (nz) {
-        atomicAdd(&tot->nonempty, nz);
-        atomicAdd(&tot->active, sum);
+      if (et.partial) {
+        et.partial[3 * blockIdx.x] = nz;
+        et.partial[3 * blockIdx.x + 1] = sum;
+        et.partial[3 * blockIdx.x + 2] = over;
+      } else {
+        if (nz) {
+          atomicAdd(&tot->nonempty, nz);
+          atomicAdd(&tot->active, sum);
+        }
+        if (over) atomicAdd(&tot->n_over, over);
       }
-      if (over) atomicAdd(&tot->n_over, over);
     }
     __syncthreads();
   }
@@ -614,7 +627,11 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
 __global__ void k_spec_check_csr(Totals* tot, int expected) {
   tot->go = (!tot->invalid && tot->active == expected) ? 1 : 0;
 }
-__global__ void k_spec_check(Totals* tot, int cap_lim, int nsl_lim, int C_max, int key_bits, int keep_if_fits) {
+struct SpecArgs {
+  int on, cap_lim, nsl_lim, C_max, keep_if_fits;
+};
+__device__ __forceinline__ void spec_decide(Totals* tot, int cap_lim, int nsl_lim, int C_max, int key_bits,
+                                            int keep_if_fits) {
   if (keep_if_fits && tot->n_over == 0) {  // the reference keeps the layout here: no re-layout tail
     tot->go = 0;
     return;
@@ -623,6 +640,9 @@ __global__ void k_spec_check(Totals* tot, int cap_lim, int nsl_lim, int C_max, i
              tot->nslices <= nsl_lim && (key_bits >= 64 || (tot->max_key >> key_bits) == 0))
                 ? 1
                 : 0;
+}
+__global__ void k_spec_check(Totals* tot, int cap_lim, int nsl_lim, int C_max, int key_bits, int keep_if_fits) {
+  spec_decide(tot, cap_lim, nsl_lim, C_max, key_bits, keep_if_fits);
 }
 // live particles and non-empty elements of the new population, from the histogram: one atomic per
 // wave of ELEMENTS (a per-wave atomic on one counter in the particle-sized kernels serialises at
@@ -699,12 +719,43 @@ __global__ void __launch_bounds__(1024)
     k_layout_fused(int nchunks, int C, int V, int TP, int pad_strat, double pad,
                    int* __restrict__ widths, int* __restrict__ slice_off,
                    int* __restrict__ chunk_start, int* __restrict__ tile_off, Totals* tot,
-                   int* __restrict__ ntiles_out) {
+                   int* __restrict__ ntiles_out, SpecArgs sp, int key_bits,
+                   const int* __restrict__ partial, int npartial) {
   __shared__ int ssum[16], scnt[16];
   __shared__ int w3[16][3];
   __shared__ int carry[3];
   __shared__ int cw_sum_s, cw_cnt_s;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (partial) {  // totals of the new population: the per-block sums k_make_keys left (ElemTotalsArgs::partial)
+    int p0 = 0, p1 = 0, p2 = 0;
+    for (int i = t; i < npartial; i += 1024) {
+      p0 += partial[3 * i];
+      p1 += partial[3 * i + 1];
+      p2 += partial[3 * i + 2];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      p0 += __shfl_down(p0, o);
+      p1 += __shfl_down(p1, o);
+      p2 += __shfl_down(p2, o);
+    }
+    if (lane == 0) {
+      w3[wave][0] = p0;
+      w3[wave][1] = p1;
+      w3[wave][2] = p2;
+    }
+    __syncthreads();
+    if (t == 0) {
+      for (int w = 1; w < 16; ++w) {
+        p0 += w3[w][0];
+        p1 += w3[w][1];
+        p2 += w3[w][2];
+      }
+      tot->nonempty += p0;
+      tot->active += p1;
+      tot->n_over += p2;
+    }
+    __syncthreads();
+  }
   {  // ---- reduction of the unpadded widths
     int s = 0, c = 0;
     for (int i = t; i < nchunks; i += 1024) {
@@ -806,6 +857,8 @@ __global__ void __launch_bounds__(1024)
     tot->nslices = carry[0];
     tot->capacity = carry[1];
     *ntiles_out = carry[2];
+    // the speculative tail's gate (k_spec_check) rides here: one launch less per rebuild
+    if (sp.on) spec_decide(tot, sp.cap_lim, sp.nsl_lim, sp.C_max, key_bits, sp.keep_if_fits);
   }
 }
 __global__ void k_chunk_widths2(int nchunks, int C, int ne, const unsigned long long* __restrict__ keys,
@@ -832,9 +885,7 @@ struct LayoutTablesArgs {
   int *tiles, *offsets, *s2c, *r2e, *e2r, *row_cursor, *eslot0;
   const Totals* tot;
 };
-__global__ void k_layout_tables(LayoutTablesArgs a) {
-  if (!a.tot->go) return;
-  const unsigned b = blockIdx.x;
+__device__ __forceinline__ void layout_tables_body(const LayoutTablesArgs& a, const unsigned b) {
   if (b < a.b1) {  // tile -> (chunk, first column): owning chunk by bisection in the tile prefix
     const int t = (int)(b * blockDim.x + threadIdx.x);
     if (t >= *a.ntiles_dev) return;
@@ -877,6 +928,351 @@ __global__ void k_layout_tables(LayoutTablesArgs a) {
     const int c = i / a.C;
     if (a.widths[c] == 0) a.row_cursor[i] = a.chunk_start[c] + i % a.C;
   }
+}
+__global__ void k_layout_tables(LayoutTablesArgs a) {
+  if (!a.tot->go) return;
+  layout_tables_body(a, blockIdx.x);
+}
+// ---- The sort + layout chain of a rebuild as ONE kernel (keys, the radix passes, chunk widths, padding,
+// the three chunk scans, the speculation gate and the table fills were ~15 dependent launches of a few
+// dozen blocks each, ~5 us apiece whatever their work).  The phases are separated by grid barriers: an
+// arrival counter in device memory, release / acquire at agent scope (each XCD has its own L2).  All
+// blocks must be resident at once: the grid is ceil(ne / 2048) blocks of 256 threads, capped at 1024
+// (the chip holds 2048 such blocks); larger structures keep the launch chain.
+__device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned nblocks, unsigned& target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    target += nblocks;
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+struct CoopArgs {
+  // sort
+  int ne;
+  const int* ppe;
+  int sigma, n_sigma;
+  unsigned long long base;
+  unsigned long long *ka, *kb;
+  int *va, *vb;
+  int* hist;    // [blocks][256] digit counts of every block's tile
+  int* colpre;  // [blocks][256] the same, exclusive prefix over the blocks
+  int* dtot;    // [256] digit totals
+  int no_skip;
+  ElemTotalsArgs et;
+  // layout
+  int nchunks, C, V, TP, pad_strat;
+  double pad;
+  int *widths, *slice_off, *chunk_start, *tile_off, *ntiles_out;
+  int* blocksum;  // [blocks][3] slices / slots / tiles of every block's slab of chunks
+  SpecArgs sp;
+  int do_tables;
+  LayoutTablesArgs ta;
+  Totals* tot;
+};
+__global__ void __launch_bounds__(256) k_layout_coop(CoopArgs a) {
+  __shared__ int h[256];
+  __shared__ int base_d[256];
+  __shared__ int wave_cnt[4][256];
+  __shared__ int s_red[4][4];
+  __shared__ unsigned long long smx[4];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int b = blockIdx.x, nblk = gridDim.x;
+  unsigned target = 0;
+  Totals* tot = a.tot;
+  const int tile0 = b * RS_TILE;
+  // ---- phase 0: keys (k_make_keys), totals of the new population, digit-0 counts
+  {
+    h[t] = 0;
+    __syncthreads();
+    unsigned long long mx = 0;
+    int nz = 0, sum = 0, over = 0;
+    for (int j = t; j < RS_TILE; j += 256) {
+      const int i = tile0 + j;
+      if (i >= a.ne) break;
+      int w = 0;
+      if (a.sigma > 0) {
+        w = i / a.sigma;
+        if (w > a.n_sigma - 1) w = a.n_sigma - 1;
+      }
+      const int n = a.ppe[i];
+      const unsigned long long key = (unsigned long long)w * a.base + (unsigned long long)n;
+      a.ka[i] = key;
+      a.va[i] = i;
+      atomicAdd(&h[(int)(key & 255ull)], 1);
+      mx = key > mx ? key : mx;
+      nz += n > 0;
+      sum += n;
+      if (a.et.fit) over += n > a.et.chunk_width_old[a.et.e2r_old[i] / a.et.C_old];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      nz += __shfl_down(nz, o);
+      sum += __shfl_down(sum, o);
+      over += __shfl_down(over, o);
+      const unsigned long long y = __shfl_down(mx, o);
+      mx = y > mx ? y : mx;
+    }
+    if (lane == 0) {
+      s_red[wave][0] = nz;
+      s_red[wave][1] = sum;
+      s_red[wave][2] = over;
+      smx[wave] = mx;
+    }
+    __syncthreads();
+    if (t == 0) {
+      for (int k = 1; k < 4; ++k) {
+        nz += s_red[k][0];
+        sum += s_red[k][1];
+        over += s_red[k][2];
+        mx = smx[k] > mx ? smx[k] : mx;
+      }
+      if (a.et.totals) {
+        if (nz) {
+          atomicAdd(&tot->nonempty, nz);
+          atomicAdd(&tot->active, sum);
+        }
+        if (over) atomicAdd(&tot->n_over, over);
+      }
+      if (mx) atomicMax(&tot->max_key, a.no_skip ? ~0ull : mx);
+    }
+    a.hist[b * 256 + t] = h[t];
+  }
+  grid_barrier(&tot->bar, nblk, target);
+  // ---- stable LSD radix sort, 8 bits a pass, as many passes as the largest key needs
+  const unsigned long long max_key = __hip_atomic_load(&tot->max_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long *kin = a.ka, *kout = a.kb;
+  int *vin = a.va, *vout = a.vb;
+  int parity = 0;
+  int W = 1;  // blocks that scan the digit columns: a power of two, <= 64 (4 digits a block at least)
+  while (W * 2 <= nblk && W * 2 <= 64) W *= 2;
+  for (int shift = 0; shift < 64 && (max_key >> shift) != 0; shift += 8) {
+    if (shift > 0) {  // digit counts of this block's tile (pass 0: counted with the keys)
+      h[t] = 0;
+      __syncthreads();
+      for (int j = t; j < RS_TILE; j += 256) {
+        const int i = tile0 + j;
+        if (i < a.ne) atomicAdd(&h[(int)((kin[i] >> shift) & 255ull)], 1);
+      }
+      __syncthreads();
+      a.hist[b * 256 + t] = h[t];
+      grid_barrier(&tot->bar, nblk, target);
+    }
+    if (b < W) {  // exclusive prefix of every digit's counts over the blocks; one wave per digit
+      const int per_wave = 256 / W / 4;
+      for (int q = 0; q < per_wave; ++q) {
+        const int d = b * (256 / W) + wave * per_wave + q;
+        int carry = 0;
+        for (int j0 = 0; j0 < nblk; j0 += 64) {
+          const int j = j0 + lane;
+          const int v = j < nblk ? a.hist[j * 256 + d] : 0;
+          int incl = v;
+          for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+          }
+          if (j < nblk) a.colpre[j * 256 + d] = carry + incl - v;
+          carry += __shfl(incl, 63);
+        }
+        if (lane == 0) a.dtot[d] = carry;
+      }
+    }
+    grid_barrier(&tot->bar, nblk, target);
+    {  // first output position of every digit for this block: digits below + the same digit in lower blocks
+      const int v = a.dtot[t];
+      int incl = v;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+      }
+      if (lane == 63) s_red[wave][3] = incl;
+      __syncthreads();
+      int woff = 0;
+      for (int w = 0; w < wave; ++w) woff += s_red[w][3];
+      base_d[t] = woff + incl - v + a.colpre[b * 256 + t];
+    }
+    for (int round = 0; round < RS_TILE / 256; ++round) {  // (k_rs_scatter)
+      for (int w = 0; w < 4; ++w) wave_cnt[w][t] = 0;
+      __syncthreads();
+      const int i = tile0 + round * 256 + t;
+      const bool valid = i < a.ne;
+      unsigned long long key = 0;
+      int val = 0, digit = 0;
+      if (valid) {
+        key = kin[i];
+        val = vin[i];
+        digit = (int)((key >> shift) & 255ull);
+      }
+      unsigned long long same = __ballot(valid);
+      for (int bb = 0; bb < 8; ++bb) {
+        const unsigned long long bal = __ballot(valid && ((digit >> bb) & 1));
+        same &= ((digit >> bb) & 1) ? bal : ~bal;
+      }
+      const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      const int rank_in_wave = __popcll(same & lt);
+      if (valid && rank_in_wave == 0) wave_cnt[wave][digit] = __popcll(same);
+      __syncthreads();
+      if (valid) {
+        int off = base_d[digit];
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w][digit];
+        const int pos = off + rank_in_wave;
+        kout[pos] = key;
+        vout[pos] = val;
+      }
+      __syncthreads();
+      base_d[t] += wave_cnt[0][t] + wave_cnt[1][t] + wave_cnt[2][t] + wave_cnt[3][t];
+      __syncthreads();
+    }
+    grid_barrier(&tot->bar, nblk, target);
+    {
+      unsigned long long* ks = kin;
+      kin = kout;
+      kout = ks;
+      int* vs = vin;
+      vin = vout;
+      vout = vs;
+    }
+    parity ^= 1;
+  }
+  if (b == 0 && t == 0) tot->sort_parity = parity;
+  // ---- chunk widths of this block's slab of chunks (k_chunk_widths2) and their sum / non-zero count
+  const int S = (a.nchunks + nblk - 1) / nblk;
+  const int c0 = min(b * S, a.nchunks), c1 = min(c0 + S, a.nchunks);
+  {
+    int psum = 0, pcnt = 0;
+    for (int c = c0 + wave; c < c1; c += 4) {
+      int w = 0;
+      for (int r = lane; r < a.C; r += 64) {
+        const int row = c * a.C + r;
+        if (row < a.ne) w = max(w, (int)(kin[row] % a.base));
+      }
+      for (int o = 32; o > 0; o >>= 1) w = max(w, __shfl_down(w, o));
+      if (lane == 0) {
+        a.widths[c] = w;
+        psum += w;
+        pcnt += w > 0;
+      }
+    }
+    if (lane == 0) {
+      s_red[wave][0] = psum;
+      s_red[wave][1] = pcnt;
+    }
+    __syncthreads();
+    if (t == 0) {
+      psum = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
+      pcnt = s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1];
+      if (psum) atomicAdd(&tot->cw_sum, psum);
+      if (pcnt) atomicAdd(&tot->cw_cnt, pcnt);
+    }
+  }
+  grid_barrier(&tot->bar, nblk, target);
+  // ---- padding, slices / slots / tiles of every chunk, their exclusive scans (k_layout_fused): local
+  // scan of the slab, block totals, offsets of the lower blocks
+  const int cw_sum = __hip_atomic_load(&tot->cw_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int cw_cnt = __hip_atomic_load(&tot->cw_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int avg_pad =
+      (a.pad > 0 && cw_sum > 0 && a.pad_strat == PP_PAD_EVENLY) ? (int)(cw_sum * a.pad / cw_cnt) : 0;
+  int tot3[3] = {0, 0, 0};  // (thread 0) totals of this block's slab
+  {
+    const int IT = (S + 255) / 256;  // consecutive chunks per thread
+    const int my0 = c0 + t * IT, my1 = min(my0 + IT, c1);
+    int s0 = 0, s1 = 0, s2 = 0;
+    for (int c = my0; c < my1; ++c) {
+      int w = a.widths[c];
+      if (a.pad > 0 && cw_sum > 0) {
+        if (a.pad_strat == PP_PAD_EVENLY) {
+          if (w > 0) w += avg_pad;
+        } else {
+          w = (int)(w + w * a.pad);
+        }
+        a.widths[c] = w;
+      }
+      s0 += w / a.V + ((w % a.V) != 0);
+      s1 += w * a.C;
+      s2 += (w + a.TP - 1) / a.TP;
+    }
+    int i0 = s0, i1 = s1, i2 = s2;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y0 = __shfl_up(i0, o), y1 = __shfl_up(i1, o), y2 = __shfl_up(i2, o);
+      if (lane >= o) {
+        i0 += y0;
+        i1 += y1;
+        i2 += y2;
+      }
+    }
+    __syncthreads();  // (s_red is reused)
+    if (lane == 63) {
+      s_red[wave][0] = i0;
+      s_red[wave][1] = i1;
+      s_red[wave][2] = i2;
+    }
+    __syncthreads();
+    int r0 = i0 - s0, r1 = i1 - s1, r2 = i2 - s2;
+    for (int w = 0; w < wave; ++w) {
+      r0 += s_red[w][0];
+      r1 += s_red[w][1];
+      r2 += s_red[w][2];
+    }
+    for (int c = my0; c < my1; ++c) {  // slab-local exclusive prefixes; the block offset comes below
+      const int w = a.widths[c];
+      a.slice_off[c] = r0;
+      a.chunk_start[c] = r1;
+      a.tile_off[c] = r2;
+      r0 += w / a.V + ((w % a.V) != 0);
+      r1 += w * a.C;
+      r2 += (w + a.TP - 1) / a.TP;
+    }
+    if (t == 0) {
+      for (int k = 0; k < 3; ++k) tot3[k] = s_red[0][k] + s_red[1][k] + s_red[2][k] + s_red[3][k];
+      a.blocksum[3 * b] = tot3[0];
+      a.blocksum[3 * b + 1] = tot3[1];
+      a.blocksum[3 * b + 2] = tot3[2];
+    }
+  }
+  grid_barrier(&tot->bar, nblk, target);
+  {
+    int o0 = 0, o1 = 0, o2 = 0;
+    for (int j = t; j < b; j += 256) {
+      o0 += a.blocksum[3 * j];
+      o1 += a.blocksum[3 * j + 1];
+      o2 += a.blocksum[3 * j + 2];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      o0 += __shfl_down(o0, o);
+      o1 += __shfl_down(o1, o);
+      o2 += __shfl_down(o2, o);
+    }
+    __syncthreads();
+    if (lane == 0) {
+      s_red[wave][0] = o0;
+      s_red[wave][1] = o1;
+      s_red[wave][2] = o2;
+    }
+    __syncthreads();
+    o0 = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
+    o1 = s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1];
+    o2 = s_red[0][2] + s_red[1][2] + s_red[2][2] + s_red[3][2];
+    for (int c = c0 + t; c < c1; c += 256) {
+      a.slice_off[c] += o0;
+      a.chunk_start[c] += o1;
+      a.tile_off[c] += o2;
+    }
+    if (b == nblk - 1 && t == 0) {  // the last block knows the totals
+      tot->nslices = o0 + tot3[0];
+      tot->capacity = o1 + tot3[1];
+      *a.ntiles_out = o2 + tot3[2];
+      if (a.sp.on) spec_decide(tot, a.sp.cap_lim, a.sp.nsl_lim, a.sp.C_max, 64, a.sp.keep_if_fits);
+    }
+  }
+  if (!a.do_tables) return;
+  grid_barrier(&tot->bar, nblk, target);
+  // ---- table fills of the new layout (k_layout_tables), when the speculative tail may run
+  if (!__hip_atomic_load(&tot->go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+  LayoutTablesArgs ta = a.ta;
+  ta.index = vin;
+  const unsigned nvb = ta.b3 + (unsigned)((ta.nrows + 255) / 256);
+  for (unsigned vb = (unsigned)b; vb < nvb; vb += (unsigned)nblk) layout_tables_body(ta, vb);
 }
 // new layout: slot -> parent element for every slot of every tile, first slot of every row
 __global__ void k_init_slots_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
@@ -1944,6 +2340,20 @@ MoveArgs make_move(const pp_ps* ps, const std::vector<pp::DevBuf>& src, int64_t 
   return a;
 }
 
+int coop_block_limit() {
+  static int limit = -1;
+  if (limit < 0) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_layout_coop, 256, 0) == hipSuccess)
+      limit = std::min(1024, per_cu * prop.multiProcessorCount);
+    else
+      limit = 0;
+  }
+  return limit;
+}
+
 // One attempt of the device re-layout for a given chunk height.  Enqueues everything up to (and
 // including) the D2H read of the totals; the caller synchronises once.
 struct LayoutPlan {
@@ -1954,12 +2364,19 @@ struct LayoutPlan {
   unsigned long long* keys;
   int* index;
   int *widths, *nsl, *nslots, *slice_off, *tile_cnt, *tile_off, *chunk_start;
+  // one-kernel path (k_layout_coop): the sorted index is index_ab[Totals::sort_parity]; `tables_done` =
+  // the table fills ran in the same kernel (behind the speculation gate)
+  bool coop = false, tables_done = false;
+  int* index_ab[2] = {nullptr, nullptr};
 };
+// resident-block budget of k_layout_coop (its grid barriers need every block on the chip at once)
+int coop_block_limit();
 
 // bits_limit > 0: sort on the low `bits_limit` key bits only (the caller predicts the largest key
 // from the previous rebuild and checks the prediction against Totals::max_key afterwards)
 int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_base, LayoutPlan& L,
-                   int bits_limit = 0, ElemTotalsArgs et = ElemTotalsArgs{0, 0, 1, nullptr, nullptr}) {
+                   int bits_limit = 0, ElemTotalsArgs et = ElemTotalsArgs{0, 0, 1, nullptr, nullptr, nullptr},
+                   SpecArgs sp = SpecArgs{0, 0, 0, 0, 0}, const LayoutTablesArgs* tables = nullptr) {
   hipStream_t st = pp::stream();
   const int ne = ps->num_elems;
   L.C = C_new;
@@ -1970,6 +2387,80 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
   L.key_bits = 64;
   L.keys = nullptr;
   L.index = nullptr;
+  L.coop = L.tables_done = false;
+  // opt-in: measured SLOWER than the launch chain (tools/ub_gridbar.hip: a grid barrier costs 3.6 us at 49
+  // blocks and 29 us at 489 -- the arrivals are same-address device-scope atomics, ~57 ns each -- against
+  // 2.8 us for a kernel boundary; c3 0.871 vs 0.857 ms, ps_combo160 1 M / 1 M 0.557 vs 0.406 ms)
+  static const bool no_coop = getenv("PP_COOP_LAYOUT") == nullptr;
+  const int nblk_c = (ne + RS_TILE - 1) / RS_TILE;
+  if (!no_coop && L.sorted && !(ps->pad_strat == PP_PAD_INVERSELY && ps->shuffle_padding > 0) &&
+      nblk_c <= coop_block_limit()) {
+    const int nchunks = L.nchunks;
+    PP_HIP_CHECK(ps->s_keys.reserve(sizeof(unsigned long long) * (size_t)ne));
+    PP_HIP_CHECK(ps->s_keys2.reserve(sizeof(unsigned long long) * (size_t)ne));
+    PP_HIP_CHECK(ps->s_vals.reserve(sizeof(int) * (size_t)ne));
+    PP_HIP_CHECK(ps->s_vals2.reserve(sizeof(int) * (size_t)ne));
+    PP_HIP_CHECK(ps->s_hist.reserve(sizeof(int) * 256 * (size_t)nblk_c * 2));
+    PP_HIP_CHECK(ps->s_scan2.reserve(sizeof(int) * (256 + 3 * (size_t)nblk_c)));
+    PP_HIP_CHECK(ps->s_chunkw.reserve(sizeof(int) * (size_t)nchunks * 5 + 64));
+    PP_HIP_CHECK(ps->s_cwidth2.reserve(sizeof(int) * (size_t)nchunks));
+    PP_HIP_CHECK(ps->s_cstart2.reserve(sizeof(int) * (size_t)nchunks));
+    PP_HIP_CHECK(ps->s_scan.reserve(sizeof(int)));
+    L.widths = ps->s_cwidth2.as<int>();
+    L.nsl = ps->s_chunkw.as<int>();
+    L.nslots = L.nsl + nchunks;
+    L.slice_off = L.nslots + nchunks;
+    L.tile_cnt = L.slice_off + nchunks;
+    L.tile_off = L.tile_cnt + nchunks;
+    L.chunk_start = ps->s_cstart2.as<int>();
+    const int sg = std::min(ps->sigma, std::max(ne, 1));
+    CoopArgs a{};
+    a.ne = ne;
+    a.ppe = ppe;
+    a.sigma = sg;
+    a.n_sigma = ne / sg;
+    a.base = L.base;
+    a.ka = ps->s_keys.as<unsigned long long>();
+    a.kb = ps->s_keys2.as<unsigned long long>();
+    a.va = ps->s_vals.as<int>();
+    a.vb = ps->s_vals2.as<int>();
+    a.hist = ps->s_hist.as<int>();
+    a.colpre = a.hist + 256 * (size_t)nblk_c;
+    a.dtot = ps->s_scan2.as<int>();
+    a.blocksum = a.dtot + 256;
+    a.no_skip = getenv("PP_NO_RS_SKIP") != nullptr;
+    a.et = et;
+    a.nchunks = nchunks;
+    a.C = C_new;
+    a.V = ps->V;
+    a.TP = ps->tile_p;
+    a.pad_strat = ps->pad_strat;
+    a.pad = ps->shuffle_padding;
+    a.widths = L.widths;
+    a.slice_off = L.slice_off;
+    a.chunk_start = L.chunk_start;
+    a.tile_off = L.tile_off;
+    a.ntiles_out = ps->s_scan.as<int>();
+    a.sp = sp;
+    a.do_tables = (tables && sp.on) ? 1 : 0;
+    if (a.do_tables) {
+      a.ta = *tables;
+      a.ta.tile_off = L.tile_off;
+      a.ta.widths = L.widths;
+      a.ta.slice_off = L.slice_off;
+      a.ta.chunk_start = L.chunk_start;
+      a.ta.ntiles_dev = a.ntiles_out;
+      a.ta.tot = tot;
+    }
+    a.tot = tot;
+    k_layout_coop<<<nblk_c, 256, 0, st>>>(a);
+    L.coop = true;
+    L.tables_done = a.do_tables != 0;
+    L.index_ab[0] = a.va;
+    L.index_ab[1] = a.vb;
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+  }
   if (L.sorted) {
     const int sg = std::min(ps->sigma, std::max(ne, 1));
     const int n_sigma = ne / sg;
@@ -1978,7 +2469,11 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
     PP_HIP_CHECK(ps->s_vals.reserve(sizeof(int) * (size_t)ne));
     PP_HIP_CHECK(ps->s_vals2.reserve(sizeof(int) * (size_t)ne));
     const int nblk = (ne + RS_TILE - 1) / RS_TILE;
-    PP_HIP_CHECK(ps->s_hist.reserve(sizeof(int) * 256 * (size_t)nblk * 2));
+    PP_HIP_CHECK(ps->s_hist.reserve(sizeof(int) * (256 * (size_t)nblk * 2 + 3 * (size_t)nblk)));
+    // the layout kernel below adds up the per-block totals (the inversely-padded layout has no such kernel)
+    et.partial = (et.totals && !(ps->pad_strat == PP_PAD_INVERSELY && ps->shuffle_padding > 0))
+                     ? ps->s_hist.as<int>() + 256 * (size_t)nblk * 2
+                     : nullptr;
     k_make_keys<<<nblk, 256, 0, st>>>(ne, ppe, sg, n_sigma, L.base,
                                                  ps->s_keys.as<unsigned long long>(),
                                                  ps->s_vals.as<int>(), tot,
@@ -2023,7 +2518,8 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
   if (ps->pad_strat != PP_PAD_INVERSELY || !(ps->shuffle_padding > 0)) {
     k_layout_fused<<<1, 1024, 0, st>>>(nchunks, C_new, ps->V, ps->tile_p, ps->pad_strat,
                                        ps->shuffle_padding, L.widths, L.slice_off, L.chunk_start,
-                                       L.tile_off, tot, ps->s_scan.as<int>());
+                                       L.tile_off, tot, ps->s_scan.as<int>(), sp, L.key_bits,
+                                       L.sorted ? et.partial : nullptr, (ne + RS_TILE - 1) / RS_TILE);
   } else {
     k_reduce_widths<<<1, 1024, 0, st>>>(nchunks, L.widths, tot);
     k_cw_inv_serial<<<1, 64, 0, st>>>(nchunks, L.widths, tot);
@@ -2035,6 +2531,7 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
     k_scan_excl<<<1, 1024, 0, st>>>(nchunks, L.nslots, L.chunk_start, &tot->capacity);
     k_tile_count<<<grid_for(nchunks), kBlock, 0, st>>>(nchunks, ps->tile_p, L.widths, L.tile_cnt);
     k_scan_excl<<<1, 1024, 0, st>>>(nchunks, L.tile_cnt, L.tile_off, ps->s_scan.as<int>());
+    if (sp.on) k_spec_check<<<1, 1, 0, st>>>(tot, sp.cap_lim, sp.nsl_lim, sp.C_max, L.key_bits, sp.keep_if_fits);
   }
   PP_LAUNCH_CHECK();
   return PP_OK;
@@ -2337,11 +2834,11 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     return scs_rebuild(ps, new_element, n_new, new_elems, new_info, commit_x, commit_xt,
                        scattered ? std::function<int(const int*)>() : pre_sync, false);
   }
-  PP_HIP_CHECK(ps->s_ppe.reserve(sizeof(int) * (size_t)std::max(ne, 1)));
-  PP_HIP_CHECK(ps->s_misc.reserve(sizeof(Totals)));
-  PP_HIP_CHECK(hipMemsetAsync(ps->s_ppe.p, 0, sizeof(int) * (size_t)std::max(ne, 1), st));
-  PP_HIP_CHECK(hipMemsetAsync(ps->s_misc.p, 0, sizeof(Totals), st));
-  Totals* tot = ps->s_misc.as<Totals>();
+  // histogram and totals in one allocation: one fill clears both (a fill is a ~5 us dispatch)
+  const size_t tot_off = (sizeof(int) * (size_t)std::max(ne, 1) + 255) / 256 * 256;
+  PP_HIP_CHECK(ps->s_ppe.reserve(tot_off + sizeof(Totals)));
+  PP_HIP_CHECK(hipMemsetAsync(ps->s_ppe.p, 0, tot_off + sizeof(Totals), st));
+  Totals* tot = (Totals*)((char*)ps->s_ppe.p + tot_off);
   int* ppe = ps->s_ppe.as<int>();
   const bool have_old = ps->capacity > 0 && ps->num_ptcls > 0;
   const unsigned old_grid = grid_for((size_t)ps->ntiles_max * ps->C);
@@ -2361,6 +2858,16 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   if (n_new > 0) {
     k_count_added<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ne, ppe, tot, rank_new);
   }
+  // `pre_sync` needs nothing but the histogram: it may fork here onto the side queue and run next to the
+  // ~15 launch-bound kernels of the sort and the layout (a few dozen blocks each)
+  static hipEvent_t ev_counts = nullptr;
+  // opt-in: measured no gain (c3 0.873 vs 0.871 ms): next to the layout chain the scatter kernels run at
+  // half speed, and the two cross-queue event waits leave ~35 us bubbles in the main queue
+  static const bool side_scatter = getenv("PP_SIDE_SCATTER") != nullptr;
+  if (pre_sync && side_scatter) {
+    if (!ev_counts) PP_HIP_CHECK(hipEventCreateWithFlags(&ev_counts, hipEventDisableTiming));
+    PP_HIP_CHECK(hipEventRecord(ev_counts, st));
+  }
   // 64..256 blocks: each block ends with two atomics on the same two counters (~5 ns apiece), each
   // thread strides over ne / (blocks * 256) elements
   // the reference's reshuffle decision (mode 1), on the histogram just built
@@ -2369,7 +2876,8 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   // totals of the new population + the decision: in the sweep that makes the sort keys when the layout
   // is sorted (one launch instead of three), else their own kernels
   // (up to 256 key blocks: every block ends with three atomics on the same counters, ~10 ns each)
-  const bool totals_in_keys = ps->sigma > 1 && ne > 1 && (ne + RS_TILE - 1) / RS_TILE <= 256;
+  const bool inv_pad = ps->pad_strat == PP_PAD_INVERSELY && ps->shuffle_padding > 0;
+  const bool totals_in_keys = ps->sigma > 1 && ne > 1 && (!inv_pad || (ne + RS_TILE - 1) / RS_TILE <= 256);
   if (!totals_in_keys) {
     if (ne > 0)
       k_nonempty<<<std::min(grid_for(ne), std::min(256u, std::max(64u, (unsigned)(ne / 4096)))), kBlock, 0, st>>>(
@@ -2381,7 +2889,6 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   // Sort keys are (window, count) with count < key_base; an upper bound known on the host avoids
   // a D2H read of the live count before the layout can start.
   const long long key_base = (long long)(have_old ? ps->num_ptcls : 0) + n_new + 1;
-  LayoutPlan L;
   // radix passes: the largest key of the previous rebuild (+1 bit) predicts how many are needed;
   // a pass that turns out to be unnecessary still costs five launches (45 us of a 0.44 ms step at
   // 1 M elements / 1 M particles)
@@ -2391,21 +2898,14 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     while (bits_pred < 63 && (ps->last_max_key >> bits_pred)) ++bits_pred;
     ++bits_pred;
   }
-  int rc = enqueue_layout(ps, ps->C_max, ppe, tot, key_base, L, bits_pred,
-                          ElemTotalsArgs{totals_in_keys ? 1 : 0, (totals_in_keys && decide_keep) ? 1 : 0, ps->C,
-                                         ps->d_element_to_row.as<int>(), ps->d_chunk_width.as<int>()});
-  if (rc) return rc;
-  int nchunks = L.nchunks, nrows = L.nrows;
-  PP_HIP_CHECK(ps->s_eslot0.reserve(sizeof(int) * (size_t)std::max(ne, 1)));
-  const int* go = &tot->go;
+  LayoutPlan L;
+  int nchunks = ne / ps->C_max + (ne % ps->C_max != 0), nrows = nchunks * ps->C_max;
   int C_new = ps->C_max;
   int ntiles_max = 0;
-  int NQ = 0;
-  bool lazy_zero = false;
-  // Everything after the layout: new layout arrays, slot tables and the move of every member.
-  // `cap_sz` / `nsl_sz` size the buffers and the launches; the kernels themselves read the true
-  // counts from the device (ntiles, Totals), and all of them return at once when tot->go == 0.
-  auto enqueue_tail = [&](int cap_sz, int nsl_sz, int64_t stride_fixed) -> int {
+  int sort_parity_host = 0;  // Totals::sort_parity once the host has read the totals (one-kernel layout)
+  PP_HIP_CHECK(ps->s_eslot0.reserve(sizeof(int) * (size_t)std::max(ne, 1)));
+  // buffers and arguments of the table fills of the new layout, for buffers sized (cap_sz, nsl_sz)
+  auto make_tables = [&](int cap_sz, int nsl_sz, LayoutTablesArgs& ta) -> int {
     PP_HIP_CHECK(ps->s_r2e2.reserve(sizeof(int) * (size_t)nrows));
     PP_HIP_CHECK(ps->s_e2r2.reserve(sizeof(int) * (size_t)nrows));
     PP_HIP_CHECK(ps->s_rowstart.reserve(sizeof(int) * (size_t)nrows));
@@ -2413,39 +2913,91 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     PP_HIP_CHECK(ps->s_s2c2.reserve(sizeof(int) * (size_t)std::max(nsl_sz, 1)));
     PP_HIP_CHECK(ps->s_mask2.reserve((size_t)std::max(cap_sz, 1)));
     PP_HIP_CHECK(ps->s_slot2.reserve(sizeof(int) * (size_t)std::max(cap_sz, 1)));
+    PP_HIP_CHECK(ps->s_scan.reserve(sizeof(int)));
     // sum_c ceil(w_c/TP) <= nchunks + capacity/(C*TP): sizes the launch without reading the count
     ntiles_max = nchunks + cap_sz / (C_new * ps->tile_p) + 1;
     PP_HIP_CHECK(ps->s_newidx.reserve(sizeof(int) * 2 * (size_t)ntiles_max));  // new tile table
+    ta.b1 = grid_for(ntiles_max);
+    ta.b2 = ta.b1 + grid_for(std::max(nchunks, 1));
+    ta.b3 = ta.b2 + grid_for(nrows);
+    ta.ntiles_dev = ps->s_scan.as<int>();
+    ta.nchunks = nchunks;
+    ta.TP = ps->tile_p;
+    ta.C = C_new;
+    ta.V = ps->V;
+    ta.nrows = nrows;
+    ta.ne = ne;
+    ta.sorted = (ps->sigma > 1 && ne > 1) ? 1 : 0;
+    ta.tile_off = L.tile_off;  // (the layout's own arrays: known once it is enqueued)
+    ta.widths = L.widths;
+    ta.slice_off = L.slice_off;
+    ta.chunk_start = L.chunk_start;
+    ta.index = L.coop ? L.index_ab[sort_parity_host] : L.index;
+    ta.tiles = ps->s_newidx.as<int>();
+    ta.offsets = ps->s_offsets2.as<int>();
+    ta.s2c = ps->s_s2c2.as<int>();
+    ta.r2e = ps->s_r2e2.as<int>();
+    ta.e2r = ps->s_e2r2.as<int>();
+    ta.row_cursor = ps->s_rowstart.as<int>();
+    ta.eslot0 = ps->s_eslot0.as<int>();
+    ta.tot = tot;
+    return PP_OK;
+  };
+  // ---- limits of the speculative tail (see below): known before the layout is enqueued, so that the gate
+  // rides in the layout kernel
+  bool spec_ok = false;
+  long long cap_lim = 0, nsl_lim = 0;
+  int64_t stride_fit = 0;
+  static const bool no_spec = getenv("PP_NO_SPEC_REBUILD") != nullptr;
+  if (!no_spec && have_old && old_grid > 0) {
+    const int nchunks0 = ne / ps->C_max + (ne % ps->C_max != 0);
+    cap_lim = std::min<long long>((long long)ps->s_mask2.bytes, (long long)(ps->s_slot2.bytes / 4));
+    // the component stride the swap buffers can hold today, on the spread_stride pattern
+    long long fit = (int)ps->swap.size() >= ps->nmembers ? (1ll << 40) : 0;
+    for (int m = 0; m < ps->nmembers && fit > 0; ++m)
+      fit = std::min<long long>(fit, (long long)(ps->swap[m].bytes /
+                                                 ((size_t)ps->member_ncomp[m] * ps->member_bytes[m])));
+    long long sq = fit / 64;
+    while (sq > 0 && sq % 32 != 17) --sq;
+    stride_fit = sq * 64;
+    cap_lim = std::min<long long>(cap_lim, stride_fit);
+    if (cap_lim > 0 && getenv("PP_DIRECT_MOVE") == nullptr) {  // staging buffer: NQ quads per slot
+      const void* srcs[8];
+      for (int m = 0; m < ps->nmembers; ++m) srcs[m] = ps->data[m].p;
+      WordTable wt_probe{};
+      const int nq = build_word_table(ps, srcs, ps->stride, stride_fit, commit_x, commit_xt, wt_probe);
+      if (nq > 0) cap_lim = std::min<long long>(cap_lim, (long long)(ps->s_aos.bytes / ((size_t)nq * 16)));
+    }
+    const long long tiles_room = (long long)(ps->s_newidx.bytes / 8) - nchunks0 - 1;
+    cap_lim = std::min<long long>(cap_lim, tiles_room * (long long)(ps->C_max * ps->tile_p));
+    nsl_lim = std::min<long long>((long long)(ps->s_offsets2.bytes / 4) - 1, (long long)(ps->s_s2c2.bytes / 4));
+    cap_lim = std::min<long long>(cap_lim, 2147483647ll / 2);
+    spec_ok = cap_lim >= ps->capacity / 2 && cap_lim > 0 && nsl_lim > 0;
+  }
+  LayoutTablesArgs ta_spec{};
+  if (spec_ok)
+    if (int rct = make_tables((int)cap_lim, (int)nsl_lim, ta_spec)) return rct;
+  int rc = enqueue_layout(ps, ps->C_max, ppe, tot, key_base, L, bits_pred,
+                          ElemTotalsArgs{totals_in_keys ? 1 : 0, (totals_in_keys && decide_keep) ? 1 : 0, ps->C,
+                                         ps->d_element_to_row.as<int>(), ps->d_chunk_width.as<int>(), nullptr},
+                          SpecArgs{spec_ok ? 1 : 0, (int)cap_lim, (int)nsl_lim, ps->C_max, decide_keep ? 1 : 0},
+                          spec_ok ? &ta_spec : nullptr);
+  if (rc) return rc;
+  nchunks = L.nchunks;
+  nrows = L.nrows;
+  const int* go = &tot->go;
+  int NQ = 0;
+  bool lazy_zero = false;
+  // Everything after the layout: new layout arrays, slot tables and the move of every member.
+  // `cap_sz` / `nsl_sz` size the buffers and the launches; the kernels themselves read the true
+  // counts from the device (ntiles, Totals), and all of them return at once when tot->go == 0.
+  auto enqueue_tail = [&](int cap_sz, int nsl_sz, int64_t stride_fixed) -> int {
+    LayoutTablesArgs ta;
+    if (int rct = make_tables(cap_sz, nsl_sz, ta)) return rct;
     int* new_tiles = ps->s_newidx.as<int>();
     const int* new_ntiles = ps->s_scan.as<int>();
-    {
-      LayoutTablesArgs ta;
-      ta.b1 = grid_for(ntiles_max);
-      ta.b2 = ta.b1 + grid_for(std::max(nchunks, 1));
-      ta.b3 = ta.b2 + grid_for(nrows);
-      ta.ntiles_dev = new_ntiles;
-      ta.nchunks = nchunks;
-      ta.TP = ps->tile_p;
-      ta.C = C_new;
-      ta.V = ps->V;
-      ta.nrows = nrows;
-      ta.ne = ne;
-      ta.sorted = L.sorted ? 1 : 0;
-      ta.tile_off = L.tile_off;
-      ta.widths = L.widths;
-      ta.slice_off = L.slice_off;
-      ta.chunk_start = L.chunk_start;
-      ta.index = L.index;
-      ta.tiles = new_tiles;
-      ta.offsets = ps->s_offsets2.as<int>();
-      ta.s2c = ps->s_s2c2.as<int>();
-      ta.r2e = ps->s_r2e2.as<int>();
-      ta.e2r = ps->s_e2r2.as<int>();
-      ta.row_cursor = ps->s_rowstart.as<int>();
-      ta.eslot0 = ps->s_eslot0.as<int>();
-      ta.tot = tot;
+    if (!(L.tables_done && stride_fixed > 0))  // (speculative tail of the one-kernel layout: filled there)
       k_layout_tables<<<ta.b3 + grid_for(nrows), kBlock, 0, st>>>(ta);
-    }
     k_init_slots_tiled<<<grid_for((size_t)ntiles_max * C_new), kBlock, 0, st>>>(
         new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_r2e2.as<int>(),
         ppe, ne, ps->s_slot2.as<int>(), ps->s_rowstart.as<int>(), ps->s_eslot0.as<int>(),
@@ -2524,35 +3076,10 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   // no-ops.  The sync then happens once, after everything is queued.
   bool speculated = false;
   const int64_t swap_stride_before = ps->swap_stride;  // the speculative tail re-labels the swap buffers
-  static const bool no_spec = getenv("PP_NO_SPEC_REBUILD") != nullptr;
-  if (!no_spec && have_old && old_grid > 0) {
-    long long cap_lim = std::min<long long>((long long)ps->s_mask2.bytes, (long long)(ps->s_slot2.bytes / 4));
-    // the component stride the swap buffers can hold today, on the spread_stride pattern
-    long long fit = (int)ps->swap.size() >= ps->nmembers ? (1ll << 40) : 0;
-    for (int m = 0; m < ps->nmembers && fit > 0; ++m)
-      fit = std::min<long long>(fit, (long long)(ps->swap[m].bytes /
-                                                 ((size_t)ps->member_ncomp[m] * ps->member_bytes[m])));
-    long long sq = fit / 64;
-    while (sq > 0 && sq % 32 != 17) --sq;
-    const int64_t stride_fit = sq * 64;
-    cap_lim = std::min<long long>(cap_lim, stride_fit);
-    if (cap_lim > 0 && getenv("PP_DIRECT_MOVE") == nullptr) {  // staging buffer: NQ quads per slot
-      const void* srcs[8];
-      for (int m = 0; m < ps->nmembers; ++m) srcs[m] = ps->data[m].p;
-      WordTable wt_probe{};
-      const int nq = build_word_table(ps, srcs, ps->stride, stride_fit, commit_x, commit_xt, wt_probe);
-      if (nq > 0) cap_lim = std::min<long long>(cap_lim, (long long)(ps->s_aos.bytes / ((size_t)nq * 16)));
-    }
-    const long long tiles_room = (long long)(ps->s_newidx.bytes / 8) - nchunks - 1;
-    cap_lim = std::min<long long>(cap_lim, tiles_room * (long long)(ps->C_max * ps->tile_p));
-    long long nsl_lim = std::min<long long>((long long)(ps->s_offsets2.bytes / 4) - 1, (long long)(ps->s_s2c2.bytes / 4));
-    cap_lim = std::min<long long>(cap_lim, 2147483647ll / 2);
-    if (cap_lim >= ps->capacity / 2 && cap_lim > 0 && nsl_lim > 0) {
-      k_spec_check<<<1, 1, 0, st>>>(tot, (int)cap_lim, (int)nsl_lim, ps->C_max, L.key_bits, decide_keep ? 1 : 0);
-      rc = enqueue_tail((int)cap_lim, (int)nsl_lim, stride_fit);
-      if (rc) return rc;
-      speculated = true;
-    }
+  if (spec_ok) {  // (the gate itself ran at the end of the layout kernel)
+    rc = enqueue_tail((int)cap_lim, (int)nsl_lim, stride_fit);
+    if (rc) return rc;
+    speculated = true;
   }
   // The totals travel to pinned memory and the host waits for THAT copy only: whatever `pre_sync`
   // enqueues behind it keeps the GPU busy while the host wakes up and issues its next calls.
@@ -2562,11 +3089,17 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   PP_HIP_CHECK(hipMemcpyAsync(h_pin, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
   PP_HIP_CHECK(hipEventRecord(ev_tot, st));
   if (pre_sync) {
-    rc = pre_sync(ppe);
+    if (side_scatter) {
+      pp::SideScope fork(ev_counts);  // joins the main queue (behind the tail enqueued above) on exit
+      rc = pre_sync(ppe);
+    } else {
+      rc = pre_sync(ppe);
+    }
     if (rc) return rc;
   }
   PP_HIP_CHECK(hipEventSynchronize(ev_tot));  // the only host wait of a regular rebuild
   Totals h = *h_pin;
+  sort_parity_host = h.sort_parity & 1;
   if (h.invalid) {
     ps->swap_stride = swap_stride_before;
     pp::set_error(
@@ -2617,12 +3150,14 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     const bool sort_ok = L.key_bits >= 64 || (h.max_key >> L.key_bits) == 0;
     if (C_new != ps->C_max || !sort_ok) {
       PP_HIP_CHECK(hipMemsetAsync(&tot->cw_sum, 0, sizeof(int) * 2, st));
+      PP_HIP_CHECK(hipMemsetAsync(&tot->bar, 0, sizeof(unsigned) + sizeof(int), st));  // barrier counter, parity
       rc = enqueue_layout(ps, C_new, ppe, tot, key_base, L);
       if (rc) return rc;
       const int active = h.active, nonempty = h.nonempty;
       const unsigned long long max_key = h.max_key;
       PP_HIP_CHECK(hipMemcpyAsync(&h, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
       PP_HIP_CHECK(hipStreamSynchronize(st));
+      sort_parity_host = h.sort_parity & 1;
       h.active = active;
       h.nonempty = nonempty;
       h.max_key = std::max(h.max_key, max_key);

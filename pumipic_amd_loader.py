@@ -28,3 +28,14 @@ def load_oracle():
     sys.modules["ppo"] = mod
     spec.loader.exec_module(mod)
     return mod
+
+
+def load_oracle_picpart():
+    """ORACLE (PICpart construction / comm arrays) -- tests only."""
+    if "ppo_picpart" in sys.modules:
+        return sys.modules["ppo_picpart"]
+    spec = importlib.util.spec_from_file_location("ppo_picpart", os.path.join(ROOT, "oracle", "ppo_picpart.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["ppo_picpart"] = mod
+    spec.loader.exec_module(mod)
+    return mod
