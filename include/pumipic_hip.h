@@ -534,6 +534,68 @@ int pp_migrate_ptcls_begin(pp_ps* ps, int m_x, int m_xtgt, int* elem_ids_dev, co
                            const int* const* v2v_dev, double* const* scatter_w_dev, double rmax, int gnr,
                            int gppr);
 
+/* ------------------------------------------------------------------ PICparts and comm arrays
+ * pumipic::Mesh (src/pumipic_mesh.hpp:9-131): one rank's part of a partitioned mesh -- the elements of the
+ * core (owned) plus the whole parts reached by the buffer rule -- with the numberings and the exchange
+ * plan that Mesh::reduceCommArray needs.
+ *
+ * pp_picpart_create = Mesh::Mesh(Input&) + constructPICPart + setupComm
+ * (src/pumipic_part_construct.cpp:75-275, src/pumipic_comm.cpp:11-191).  `full` is the whole mesh, loaded
+ * on every rank as the reference's drivers do; elem_owner_host[nelems] its partition vector (ownership
+ * by classification: pp_owner_by_classification first).  buffer_method / safe_method = Input::Method
+ * (src/pumipic_input.hpp:33-39: PP_PART_FULL, _BFS, _MINIMUM, _NONE; a NONE buffer is MINIMUM),
+ * bridge_dim 0 (vertices) or dim-1 (sides), *_layers = bufferBFSLayers / safeBFSLayers (MINIMUM: 0).
+ * Entity dimensions served: 0 (vertices) and dim (elements) -- pp_mesh numbers no edges.
+ *
+ * What the reference exchanges at construction (MPI_Ialltoall of boundary sizes, Isend/Irecv of the
+ * boundary lids, :113-190) is recomputed locally instead: every rank holds the full mesh and the
+ * partition vector, so it runs the other ranks' buffer BFS itself (comm_size - 1 more sweeps on the
+ * device) and needs no message.  Two things the reference leaves open are fixed: entities of a partially
+ * buffered part are numbered in increasing part-local id (renumberBoundaryLids uses atomics, "the order
+ * doesn't need to be consistent", :66-76), and the owner combines the fan-in contributions in increasing
+ * rank (the reference: arrival order).
+ *
+ * `comm` is borrowed (must outlive the part); `full` is borrowed too when the buffer method is FULL
+ * (pp_picpart_mesh returns it, as the reference points picpart at the mesh, :199-209). */
+typedef struct pp_picpart pp_picpart;
+enum { PP_PART_FULL = 0, PP_PART_BFS = 1, PP_PART_MINIMUM = 2, PP_PART_NONE = 3 };
+enum { PP_OP_SUM = 0, PP_OP_MAX = 1, PP_OP_MIN = 2, PP_OP_BCAST = 3 }; /* Mesh::Op, pumipic_mesh.hpp:64-69 */
+enum { PP_T_I32 = 0, PP_T_F64 = 1 };                                    /* INST(LO), INST(Real), pumipic_comm.cpp:443-447 */
+/* setOwnerByClassification, src/pumipic_part_construct.cpp:278-302: owner[e] = class_owners[class_id[e]] */
+int pp_owner_by_classification(const pp_mesh* full, const int* class_owners_host, int nclass, int comm_rank,
+                               int* elem_owner_host_out);
+pp_picpart* pp_picpart_create(const pp_mesh* full, const int* elem_owner_host, int buffer_method, int safe_method,
+                              int bridge_dim, int buffer_layers, int safe_layers, pp_comm* comm);
+int pp_picpart_destroy(pp_picpart* p);
+const pp_mesh* pp_picpart_mesh(const pp_picpart* p); /* Mesh::mesh() */
+/* isFullMesh, numBuffers(dim) (core parts held, self included), nents(0), nents(dim) */
+int pp_picpart_info(const pp_picpart* p, int* is_full_mesh, int* num_buffers, int* nverts, int* nelems);
+/* arrays of the part, entity dimension edim in {0, dim}.  which:
+ *   PP_PART_GIDS (int64, globalIds)  PP_PART_OWNERS (int, entOwners)  PP_PART_RANK_LIDS (int, rankLocalIndex)
+ *   PP_PART_COMM_INDEX (int, commArrayIndex)  PP_PART_FULL_IDS (int: part entity -> full-mesh entity)
+ *   PP_PART_ENT_IDS (int, sized by the FULL mesh: full entity -> part entity, -1 = not in the part)
+ *   PP_PART_SAFE (unsigned char per element of the part, safeTag; edim ignored -- what pp_set_unsafe_procs takes) */
+enum { PP_PART_GIDS = 0, PP_PART_OWNERS = 1, PP_PART_RANK_LIDS = 2, PP_PART_COMM_INDEX = 3, PP_PART_FULL_IDS = 4,
+       PP_PART_ENT_IDS = 5, PP_PART_SAFE = 6 };
+const void* pp_picpart_array_dev(const pp_picpart* p, int which, int edim, size_t* count);
+int pp_picpart_array_to_host(const pp_picpart* p, int which, int edim, void* out_host);
+/* nentsOffsets(edim): comm_size + 1 ints; bufferedRanks(edim): up to comm_size - 1 ranks, *n of them;
+ * is_complete_part (2 complete, 1 partial, 0 absent) per rank */
+int pp_picpart_nents_offsets(const pp_picpart* p, int edim, int* offsets_host);
+int pp_picpart_buffered_ranks(const pp_picpart* p, int edim, int* ranks_host, int* n);
+int pp_picpart_complete_parts(const pp_picpart* p, int edim, int* is_complete_host);
+/* Mesh::reduceCommArray (src/pumipic_comm.cpp:249-440): array_dev holds nvals values per entity of the
+ * part (entity-major, createCommArray's layout).  Fan-in: every part sends the segments of the parts it
+ * buffers to their owners (device buffers; one grouped RCCL send/recv per peer); the owner combines its
+ * own value and the contributions in increasing rank; fan-out: the owner returns its segment (the
+ * boundary subset to parts that hold only a boundary).  PP_OP_BCAST skips the fan-in.  Full-mesh parts
+ * take the same route (it is a reduce-scatter + all-gather by ownership, the volume of a ring all-reduce).
+ * Local virtual ranks (pp_comm_create_local) call the three phases on every rank in turn. */
+int pp_picpart_reduce(pp_picpart* p, int edim, int op, int dtype, int nvals, void* array_dev);
+int pp_picpart_reduce_begin(pp_picpart* p, int edim, int op, int dtype, int nvals, void* array_dev);
+int pp_picpart_reduce_mid(pp_picpart* p);
+int pp_picpart_reduce_end(pp_picpart* p);
+
 /* ------------------------------------------------------------------ tracing
  * Kokkos::Profiling::pushRegion / popRegion of the reference (e.g. adjacency.tpp:480,613,
  * SCS_rebuild.h:126,311) map to roctx ranges (rocprofv3 --marker-trace).  The library wraps its own

@@ -228,11 +228,9 @@ class PicParts:
         if cs == 1:
             return arrays
         nvals = [len(a) // max(p.nents[d], 1) for a, p in zip(arrays, self.parts)]
-        if all(p.is_full_mesh for p in self.parts) and op != BCAST_OP:  # :262-277 MPI_Allreduce
-            acc = arrays[0].copy()
-            for a in arrays[1:]:
-                acc = acc + a if op == SUM_OP else (np.maximum(acc, a) if op == MAX_OP else np.minimum(acc, a))
-            return [acc.copy() for _ in arrays]
+        # (full-mesh parts: the reference calls MPI_Allreduce here, :262-277, whose summation order is the MPI
+        # library's; the same values come out of the fan-in / fan-out below, in THIS file's order -- own value
+        # first, then increasing rank -- which is what the HIP library does for every kind of part)
         # convertToComm :280-288
         comm = []
         for a, p, nv in zip(arrays, self.parts, nvals):

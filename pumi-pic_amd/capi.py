@@ -122,6 +122,20 @@ SYMBOLS = {
     "pp_gyro_sync_pack": (_I, [_I, _V, _V, _V]),
     "pp_gyro_map_forget": (_I, [_V]),
     "pp_ray_intersects_triangle": (_I, [_I, _V, _I, _V, _V, _D, _V, _I, _I, _V, _V, _V]),
+    "pp_owner_by_classification": (_I, [_V, c_int_p, _I, _I, c_int_p]),
+    "pp_picpart_create": (_V, [_V, c_int_p, _I, _I, _I, _I, _I, _V]),
+    "pp_picpart_destroy": (_I, [_V]),
+    "pp_picpart_mesh": (_V, [_V]),
+    "pp_picpart_info": (_I, [_V, c_int_p, c_int_p, c_int_p, c_int_p]),
+    "pp_picpart_array_dev": (_V, [_V, _I, _I, C.POINTER(C.c_size_t)]),
+    "pp_picpart_array_to_host": (_I, [_V, _I, _I, _V]),
+    "pp_picpart_nents_offsets": (_I, [_V, _I, c_int_p]),
+    "pp_picpart_buffered_ranks": (_I, [_V, _I, c_int_p, c_int_p]),
+    "pp_picpart_complete_parts": (_I, [_V, _I, c_int_p]),
+    "pp_picpart_reduce": (_I, [_V, _I, _I, _I, _I, _V]),
+    "pp_picpart_reduce_begin": (_I, [_V, _I, _I, _I, _I, _V]),
+    "pp_picpart_reduce_mid": (_I, [_V]),
+    "pp_picpart_reduce_end": (_I, [_V]),
     "pp_gyro_scatter_radius": (_I, [_V, _V, _V, _V, _V, _D, _I, _I, _V, c_int_p]),
     "pp_gather_tet_vtx": (_I, [_V, _V, _I, _V, _V, _I, _V, _V]),
     "pp_interp2d_field": (_I, [_V, _I, _V, _D, _D, _D, _D, _I, _I, _I, _I, _I, _V]),
@@ -1130,3 +1144,126 @@ def ray_intersects_triangle(tris, orig, dest, tol, flip=0, segment=False):
     check(lib().pp_ray_intersects_triangle(n, d_t.ptr, stride, d_o.ptr, d_d.ptr, tol, d_f.ptr if d_f is not None else None,
                                            0 if fl.ndim else int(fl), int(segment), hit.ptr, xp.ptr, o3.ptr))
     return hit.to_host()[:n].astype(bool), xp.to_host()[:3 * n].reshape(n, 3), o3.to_host()[:3 * n].reshape(n, 3)
+
+
+# ------------------------------------------------------------------ PICparts and comm arrays
+PART_FULL, PART_BFS, PART_MINIMUM, PART_NONE = 0, 1, 2, 3
+OP_SUM, OP_MAX, OP_MIN, OP_BCAST = 0, 1, 2, 3
+PART_GIDS, PART_OWNERS, PART_RANK_LIDS, PART_COMM_INDEX, PART_FULL_IDS, PART_ENT_IDS, PART_SAFE = range(7)
+_PART_DTYPES = {PART_GIDS: np.int64, PART_OWNERS: np.int32, PART_RANK_LIDS: np.int32, PART_COMM_INDEX: np.int32,
+                PART_FULL_IDS: np.int32, PART_ENT_IDS: np.int32, PART_SAFE: np.uint8}
+
+
+def owner_by_classification(mesh, class_owners, rank):
+    co = np.ascontiguousarray(class_owners, dtype=np.int32)
+    out = np.empty(mesh.nelems, dtype=np.int32)
+    check(lib().pp_owner_by_classification(mesh.p, co.ctypes.data_as(c_int_p), len(co), rank,
+                                           out.ctypes.data_as(c_int_p)))
+    return out
+
+
+class _PartMesh:
+    """the part's pp_mesh, owned by the PICpart (or the full mesh itself for a FULL buffer)"""
+
+    def __init__(self, p, owner):
+        self.p, self._owner = p, owner
+        d, nv, ne, ns = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(lib().pp_mesh_info(self.p, C.byref(d), C.byref(nv), C.byref(ne), C.byref(ns)))
+        self.dim, self.nverts, self.nelems, self.nsides = d.value, nv.value, ne.value, ns.value
+
+    tolerance = Mesh.tolerance
+    array = Mesh.array
+
+
+class PicPart:
+    """pumipic::Mesh (pp_picpart): PicPart(full_mesh, elem_owner, comm, buffer_method, safe_method, ...)"""
+
+    def __init__(self, mesh, elem_owner, comm=None, buffer_method=PART_FULL, safe_method=PART_FULL, bridge_dim=0,
+                 buffer_layers=3, safe_layers=1):
+        own = np.ascontiguousarray(elem_owner, dtype=np.int32)
+        assert len(own) == mesh.nelems
+        self._keep = (mesh, comm)
+        self.dim = mesh.dim
+        self.p = lib().pp_picpart_create(mesh.p, own.ctypes.data_as(c_int_p), buffer_method, safe_method, bridge_dim,
+                                         buffer_layers, safe_layers, comm.p if comm is not None else None)
+        if not self.p:
+            raise PPError("pp_picpart_create: " + lib().pp_last_error().decode())
+        f, nb, nv, ne = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(lib().pp_picpart_info(self.p, C.byref(f), C.byref(nb), C.byref(nv), C.byref(ne)))
+        self.is_full_mesh, self.num_buffers = bool(f.value), nb.value
+        self.nents = {0: nv.value, mesh.dim: ne.value}
+        self.nranks = comm.size() if comm is not None else 1
+        self.mesh = _PartMesh(lib().pp_picpart_mesh(self.p), self)
+
+    def array(self, which, edim=0):
+        cnt = C.c_size_t()
+        lib().pp_picpart_array_dev(self.p, which, edim, C.byref(cnt))
+        out = np.empty(cnt.value, dtype=_PART_DTYPES[which])
+        if cnt.value:
+            check(lib().pp_picpart_array_to_host(self.p, which, edim, out.ctypes.data))
+        return out
+
+    def array_dev(self, which, edim=0):
+        cnt = C.c_size_t()
+        ptr = lib().pp_picpart_array_dev(self.p, which, edim, C.byref(cnt))
+        return ptr, cnt.value
+
+    def nents_offsets(self, edim):
+        out = np.empty(self.nranks + 1, dtype=np.int32)
+        check(lib().pp_picpart_nents_offsets(self.p, edim, out.ctypes.data_as(c_int_p)))
+        return out
+
+    def buffered_ranks(self, edim):
+        out = np.empty(max(self.nranks, 1), dtype=np.int32)
+        n = C.c_int()
+        check(lib().pp_picpart_buffered_ranks(self.p, edim, out.ctypes.data_as(c_int_p), C.byref(n)))
+        return out[:n.value].copy()
+
+    def complete_parts(self, edim):
+        out = np.empty(self.nranks, dtype=np.int32)
+        check(lib().pp_picpart_complete_parts(self.p, edim, out.ctypes.data_as(c_int_p)))
+        return out
+
+    @staticmethod
+    def _dtype(arr):
+        if arr.dtype == np.int32:
+            return 0
+        if arr.dtype == np.float64:
+            return 1
+        raise TypeError("comm arrays are int32 or float64")
+
+    def create_comm_array(self, edim, nvals, default, dtype=np.float64):
+        """createCommArray: nvals values per entity, entity-major"""
+        return DevArray.from_host(np.full(self.nents[edim] * nvals, default, dtype=dtype))
+
+    def reduce(self, edim, op, arr):
+        nvals = arr.n // max(self.nents.get(edim, 0), 1)
+        check(lib().pp_picpart_reduce(self.p, edim, op, self._dtype(arr), nvals, arr.ptr))
+
+    def reduce_begin(self, edim, op, arr):
+        nvals = arr.n // max(self.nents.get(edim, 0), 1)
+        self._arr = arr
+        check(lib().pp_picpart_reduce_begin(self.p, edim, op, self._dtype(arr), nvals, arr.ptr))
+
+    def reduce_mid(self):
+        check(lib().pp_picpart_reduce_mid(self.p))
+
+    def reduce_end(self):
+        check(lib().pp_picpart_reduce_end(self.p))
+        self._arr = None
+
+    def __del__(self):
+        try:
+            lib().pp_picpart_destroy(self.p)
+        except Exception:
+            pass
+
+
+def picpart_reduce_all(parts, edim, op, arrays):
+    """reduceCommArray on the virtual ranks of one process (Comm.local): the three phases on every rank in turn"""
+    for p, a in zip(parts, arrays):
+        p.reduce_begin(edim, op, a)
+    for p in parts:
+        p.reduce_mid()
+    for p in parts:
+        p.reduce_end()

@@ -279,12 +279,15 @@ static int tcp_allreduce_i64(void* user, int64_t* buf, int64_t n) { return tcp_a
 struct LocalWorld {
   int nranks = 0;
   std::vector<pp_comm*> comms;
-  // migration round: which ranks have packed, their counts and send buffers
-  std::vector<char> begun;
-  std::vector<std::vector<int>> send_counts;
-  std::vector<const void*> send_buf;
-  std::vector<int> rec_bytes;
-  int ended = 0;
+  // exchange round of a channel (0 migration, 1 / 2 fan-in / fan-out of a comm-array reduction): which ranks
+  // have packed, their counts and send buffers
+  struct Chan {
+    std::vector<char> begun;
+    std::vector<std::vector<int>> send_counts;
+    std::vector<const void*> send_buf;
+    std::vector<int> rec_bytes;
+    int ended = 0;
+  } ch[3];
   // all-reduce round
   std::vector<double*> red_buf;
   int64_t red_n = 0;
@@ -306,25 +309,30 @@ __global__ void k_local_bcast(int nranks, double* const* bufs, long long n, cons
   for (int r = 0; r < nranks; ++r) bufs[r][i] = s;
 }
 
-int local_publish(LocalWorld* w, int rank, const std::vector<int>& send_counts, const void* d_send, int rec_bytes) {
-  PP_REQUIRE(w && !w->begun[(size_t)rank], "local communicator: this virtual rank already began a migration");
-  w->begun[(size_t)rank] = 1;
-  w->send_counts[(size_t)rank] = send_counts;
-  w->send_buf[(size_t)rank] = d_send;
-  w->rec_bytes[(size_t)rank] = rec_bytes;
+int local_publish(LocalWorld* w, int rank, const std::vector<int>& send_counts, const void* d_send, int rec_bytes,
+                  int chan) {
+  PP_REQUIRE(w && chan >= 0 && chan < 3 && !w->ch[chan].begun[(size_t)rank],
+             "local communicator: this virtual rank already began this exchange");
+  LocalWorld::Chan& c = w->ch[chan];
+  c.begun[(size_t)rank] = 1;
+  c.send_counts[(size_t)rank] = send_counts;
+  c.send_buf[(size_t)rank] = d_send;
+  c.rec_bytes[(size_t)rank] = rec_bytes;
   return PP_OK;
 }
-int local_all_begun(LocalWorld* w) {
+int local_all_begun(LocalWorld* w, int chan) {
   for (int r = 0; r < w->nranks; ++r)
-    PP_REQUIRE(w->begun[(size_t)r], "local communicator: call pp_ps_migrate_begin on every virtual rank before "
-                                    "the first pp_ps_migrate_end");
+    PP_REQUIRE(w->ch[chan].begun[(size_t)r],
+               "local communicator: call the `begin` half of the exchange (pp_ps_migrate_begin, "
+               "pp_picpart_reduce_begin / _mid) on every virtual rank before the first `end` half");
   return PP_OK;
 }
-void local_ended(LocalWorld* w, int rank) {
+void local_ended(LocalWorld* w, int rank, int chan) {
   (void)rank;
-  if (++w->ended >= w->nranks) {
-    std::fill(w->begun.begin(), w->begun.end(), 0);
-    w->ended = 0;
+  LocalWorld::Chan& c = w->ch[chan];
+  if (++c.ended >= w->nranks) {
+    std::fill(c.begun.begin(), c.begun.end(), 0);
+    c.ended = 0;
   }
 }
 
@@ -364,13 +372,13 @@ int comm_counts(pp_comm* c, const int* d_counts, std::vector<int>& send_counts,
 }
 
 int comm_exchange_records(pp_comm* c, const void* d_send, const std::vector<int>& send_counts,
-                          std::vector<int>& recv_counts, int rec_bytes, void** d_recv_out) {
+                          std::vector<int>& recv_counts, int rec_bytes, void** d_recv_out, int chan) {
   const int n = c->nranks;
   hipStream_t st = stream();
   std::vector<int64_t> sd((size_t)n), rd((size_t)n);
   int64_t ns = 0, nr = 0;
   if (c->kind == 4) {  // local: read the counts the other virtual ranks published
-    LocalWorld& w = *c->world;
+    LocalWorld::Chan& w = c->world->ch[chan];
     for (int r = 0; r < n; ++r) recv_counts[(size_t)r] = (r == c->rank) ? 0 : w.send_counts[(size_t)r][(size_t)c->rank];
   }
   int rc = pp_migrate_plan(n, c->rank, send_counts.data(), recv_counts.data(), sd.data(), rd.data(), &ns, &nr);
@@ -394,7 +402,7 @@ int comm_exchange_records(pp_comm* c, const void* d_send, const std::vector<int>
     return PP_OK;
   }
   if (c->kind == 4) {
-    LocalWorld& w = *c->world;
+    LocalWorld::Chan& w = c->world->ch[chan];
     for (int s = 0; s < n; ++s) {
       if (s == c->rank || !recv_counts[(size_t)s]) continue;
       if (w.rec_bytes[(size_t)s] != rec_bytes) {
@@ -531,10 +539,12 @@ int pp_comm_create_local(int nranks, pp_comm** comms_out) {
   auto w = std::make_shared<pp::LocalWorld>();
   w->nranks = nranks;
   w->comms.resize((size_t)nranks);
-  w->begun.assign((size_t)nranks, 0);
-  w->send_counts.assign((size_t)nranks, std::vector<int>((size_t)nranks, 0));
-  w->send_buf.assign((size_t)nranks, nullptr);
-  w->rec_bytes.assign((size_t)nranks, 0);
+  for (auto& ch : w->ch) {
+    ch.begun.assign((size_t)nranks, 0);
+    ch.send_counts.assign((size_t)nranks, std::vector<int>((size_t)nranks, 0));
+    ch.send_buf.assign((size_t)nranks, nullptr);
+    ch.rec_bytes.assign((size_t)nranks, 0);
+  }
   w->red_buf.assign((size_t)nranks, nullptr);
   for (int r = 0; r < nranks; ++r) {
     pp_comm* c = new_comm(nranks > 1 ? 4 : 0, r, nranks);

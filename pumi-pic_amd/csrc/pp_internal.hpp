@@ -261,11 +261,13 @@ int comm_counts(pp_comm* c, const int* d_counts, std::vector<int>& send_counts,
 // records: d_send rank-major (send_counts particles of rec_bytes each); returns the received records
 // (library-owned device buffer of the communicator) in rank order
 int comm_exchange_records(pp_comm* c, const void* d_send, const std::vector<int>& send_counts,
-                          std::vector<int>& recv_counts, int rec_bytes, void** d_recv_out);
+                          std::vector<int>& recv_counts, int rec_bytes, void** d_recv_out, int chan = 0);
 // local communicator bookkeeping (virtual ranks of one process)
-int local_publish(LocalWorld* w, int rank, const std::vector<int>& send_counts, const void* d_send, int rec_bytes);
-int local_all_begun(LocalWorld* w);
-void local_ended(LocalWorld* w, int rank);
+// (chan: 0 migration, 1 / 2 fan-in / fan-out of pp_picpart_reduce -- independent rounds of the local world)
+int local_publish(LocalWorld* w, int rank, const std::vector<int>& send_counts, const void* d_send, int rec_bytes,
+                  int chan = 0);
+int local_all_begun(LocalWorld* w, int chan = 0);
+void local_ended(LocalWorld* w, int rank, int chan = 0);
 // pp_runtime.hip: roctx ranges (no-ops unless PP_ROCTX=1)
 void range_push(const char* name);
 void range_pop();

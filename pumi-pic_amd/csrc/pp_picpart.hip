@@ -1,0 +1,614 @@
+// PICparts and comm arrays: pumipic::Mesh's construction (src/pumipic_part_construct.cpp:75-275), its
+// exchange plan (Mesh::setupComm, src/pumipic_comm.cpp:11-191) and Mesh::reduceCommArray (:249-440).
+//
+// Construction is set-up work and runs on the host over the mesh's host tables (like pp_mesh_create),
+// except for the breadth-first sweeps, which are the device kernels of pp_bfs_buffer_layers /
+// pp_bfs_safe_inward.  Nothing is exchanged at construction: every rank holds the full mesh and the
+// partition vector, so it derives what each other rank buffers by running that rank's BFS itself.
+// The reduction is device work: pack into owner-major segments, one exchange of device buffers to the
+// owners (fan-in), a gather-form combine in rank order (no atomics), one exchange back (fan-out), unpack.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#include "pp_internal.hpp"
+
+using pp::grid_for;
+using pp::kBlock;
+
+namespace {
+
+struct DimData {
+  int edim = 0, nfull = 0, nents = 0, my_count = 0;
+  std::vector<int> goff;                           // global entities per rank, exclusive scan (P + 1)
+  std::vector<int> ent_ids, full_ids;              // full -> part (-1), part -> full
+  std::vector<int> owners, rank_lids, comm_index;  // per entity of the part
+  std::vector<int64_t> gids;
+  std::vector<int> poff, is_complete, buffered;  // nentsOffsets, is_complete_part, bufferedRanks
+  std::vector<int> send_counts, recv_counts;     // fan-in: entities to every owner / from every holder
+  std::vector<int> recv_ent;                     // my entity of every received entity, rank-major
+  int nrecv = 0, nsend = 0;
+  pp::DevBuf d_gids, d_owners, d_rank_lids, d_comm_index, d_full_ids, d_ent_ids, d_recv_ent, d_contrib_off,
+      d_contrib_pos;
+};
+
+template <class T>
+int upload(pp::DevBuf& d, const std::vector<T>& h) {
+  PP_HIP_CHECK(d.reserve(std::max<size_t>(h.size(), 1) * sizeof(T)));
+  if (!h.empty()) PP_HIP_CHECK(hipMemcpy(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return PP_OK;
+}
+
+// ---- reduceCommArray kernels.  Layout of the fan-in send buffer: the segments of the other owners in
+// rank order (the comm-array order of pumipic_comm.cpp:280-288 with the own segment taken out -- it goes
+// to `mine`), so that the exchange's per-rank displacements are the prefix of the counts.
+template <class T>
+__global__ void k_part_pack(long long n, int nvals, const int* __restrict__ ci, int p0, int mycnt,
+                            const T* __restrict__ in, T* __restrict__ send, T* __restrict__ mine) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long id = i / nvals;
+  const int v = (int)(i - id * nvals);
+  const int j = ci[id];
+  if (j < p0)
+    send[(long long)j * nvals + v] = in[i];
+  else if (j < p0 + mycnt)
+    mine[(long long)(j - p0) * nvals + v] = in[i];
+  else
+    send[(long long)(j - mycnt) * nvals + v] = in[i];
+}
+// the owner's combine (:311-385), gather form: one thread per value of an owned entity walks the
+// contributions it received in increasing rank
+template <class T>
+__global__ void k_part_reduce(long long n, int nvals, int op, T* __restrict__ mine, const T* __restrict__ recv,
+                              const int* __restrict__ coff, const int* __restrict__ cpos) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long e = i / nvals;
+  const int v = (int)(i - e * nvals);
+  T x = mine[i];
+  for (int k = coff[e]; k < coff[e + 1]; ++k) {
+    const T y = recv[(long long)cpos[k] * nvals + v];
+    if (op == PP_OP_SUM)
+      x = x + y;
+    else if (op == PP_OP_MAX)
+      x = x > y ? x : y;  // maxReduce, pumipic_comm.cpp:222-227
+    else
+      x = x < y ? x : y;  // minReduce :228-233
+  }
+  mine[i] = x;
+}
+// fan-out send buffer (:386-421): every holder gets back the entities it sent, in its order
+template <class T>
+__global__ void k_part_fanout(long long n, int nvals, const int* __restrict__ recv_ent, const T* __restrict__ mine,
+                              T* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long k = i / nvals;
+  const int v = (int)(i - k * nvals);
+  out[i] = mine[(long long)recv_ent[k] * nvals + v];
+}
+template <class T>
+__global__ void k_part_unpack(long long n, int nvals, const int* __restrict__ ci, int p0, int mycnt,
+                              const T* __restrict__ mine, const T* __restrict__ recv, T* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long id = i / nvals;
+  const int v = (int)(i - id * nvals);
+  const int j = ci[id];
+  if (j < p0)
+    out[i] = recv[(long long)j * nvals + v];
+  else if (j < p0 + mycnt)
+    out[i] = mine[(long long)(j - p0) * nvals + v];
+  else
+    out[i] = recv[(long long)(j - mycnt) * nvals + v];
+}
+
+}  // namespace
+
+struct pp_picpart {
+  int rank = 0, nranks = 1, dim = 0;
+  bool is_full = false;
+  const pp_mesh* full = nullptr;
+  pp_mesh* part = nullptr;  // owned; null when the part is the full mesh
+  pp_comm* comm = nullptr;
+  std::vector<int> has_part;
+  int num_buffers = 1;
+  DimData D[2];  // 0: vertices, 1: elements
+  std::vector<unsigned char> safe;
+  pp::DevBuf d_safe;
+  // reduction scratch and the state between the phases
+  pp::DevBuf d_send, d_mine, d_out;
+  bool active = false;
+  int k = 0, op = 0, dtype = 0, nvals = 0, phase = 0;
+  void* array = nullptr;
+};
+
+namespace {
+
+DimData* dim_slot(pp_picpart* p, int edim) {
+  if (edim == 0) return &p->D[0];
+  if (edim == p->dim) return &p->D[1];
+  pp::set_error("PICpart: entity dimension must be 0 (vertices) or dim (elements) -- pp_mesh numbers no edges");
+  return nullptr;
+}
+const DimData* dim_slot(const pp_picpart* p, int edim) { return dim_slot(const_cast<pp_picpart*>(p), edim); }
+
+// Mesh::Mesh(Input&), pumipic_part_construct.cpp:75-118, for rank q: has_part (and is_safe when wanted)
+int safe_and_buffer(const pp_mesh* full, int bridge_dim, int q, int P, int buffer_method, int safe_method,
+                    int buffer_layers, int safe_layers, const int* d_owner, pp::DevBuf& d_safe_tmp,
+                    std::vector<int>& has_part, std::vector<unsigned char>* is_safe) {
+  const int ne = full->nelems;
+  has_part.assign((size_t)P, 1);
+  if (is_safe) is_safe->assign((size_t)ne, safe_method == PP_PART_FULL ? 1 : 0);
+  const bool need_bfs = (safe_method != PP_PART_NONE && safe_method != PP_PART_FULL) || buffer_method != PP_PART_FULL;
+  if (need_bfs) {
+    std::vector<int> part((size_t)P, 0);
+    int rc = pp_bfs_buffer_layers(full, bridge_dim, q, P, safe_layers, buffer_layers, d_owner,
+                                  d_safe_tmp.as<unsigned char>(), part.data());
+    if (rc) return rc;
+    if (is_safe && (safe_method == PP_PART_BFS || safe_method == PP_PART_MINIMUM) && ne > 0)
+      PP_HIP_CHECK(hipMemcpy(is_safe->data(), d_safe_tmp.p, (size_t)ne, hipMemcpyDeviceToHost));
+    if (buffer_method == PP_PART_BFS || buffer_method == PP_PART_MINIMUM) has_part = part;
+  }
+  if (is_safe && buffer_method == PP_PART_BFS && safe_method == PP_PART_FULL && ne > 0) {
+    int rc = pp_bfs_safe_inward(full, bridge_dim, q, P, safe_layers, d_owner, has_part.data(),
+                                d_safe_tmp.as<unsigned char>());
+    if (rc) return rc;
+    PP_HIP_CHECK(hipMemcpy(is_safe->data(), d_safe_tmp.p, (size_t)ne, hipMemcpyDeviceToHost));
+  }
+  return PP_OK;
+}
+
+// createGlobalNumbering + rankLidNumbering (:336-386): owner-major, in entity order inside an owner
+void global_numbering(const std::vector<int>& owner, int P, std::vector<int>& goff, std::vector<int64_t>& gid) {
+  goff.assign((size_t)P + 1, 0);
+  for (int o : owner) ++goff[(size_t)o + 1];
+  for (int r = 0; r < P; ++r) goff[(size_t)r + 1] += goff[(size_t)r];
+  std::vector<int> run(goff.begin(), goff.end() - 1);
+  gid.resize(owner.size());
+  for (size_t i = 0; i < owner.size(); ++i) gid[i] = run[(size_t)owner[i]]++;
+}
+
+// the part's side of setupComm (pumipic_comm.cpp:11-111) for one entity dimension
+void setup_holder(DimData& d, int P, int rank, const std::vector<int>& owner_full, const std::vector<int64_t>& gid_full,
+                  const std::vector<char>& keep) {
+  d.nfull = (int)owner_full.size();
+  d.ent_ids.assign((size_t)d.nfull, -1);
+  d.full_ids.clear();
+  for (int i = 0; i < d.nfull; ++i)
+    if (keep[(size_t)i]) {
+      d.ent_ids[(size_t)i] = (int)d.full_ids.size();
+      d.full_ids.push_back(i);
+    }
+  d.nents = (int)d.full_ids.size();
+  d.owners.resize((size_t)d.nents);
+  d.gids.resize((size_t)d.nents);
+  d.rank_lids.resize((size_t)d.nents);
+  d.poff.assign((size_t)P + 1, 0);
+  for (int i = 0; i < d.nents; ++i) {
+    const int f = d.full_ids[(size_t)i];
+    d.owners[(size_t)i] = owner_full[(size_t)f];
+    d.gids[(size_t)i] = gid_full[(size_t)f];
+    d.rank_lids[(size_t)i] = (int)(gid_full[(size_t)f] - d.goff[(size_t)owner_full[(size_t)f]]);
+    ++d.poff[(size_t)owner_full[(size_t)f] + 1];
+  }
+  for (int r = 0; r < P; ++r) d.poff[(size_t)r + 1] += d.poff[(size_t)r];
+  d.is_complete.assign((size_t)P, 0);
+  d.buffered.clear();
+  d.send_counts.assign((size_t)P, 0);
+  for (int r = 0; r < P; ++r) {
+    const int gdiff = d.goff[(size_t)r + 1] - d.goff[(size_t)r], pdiff = d.poff[(size_t)r + 1] - d.poff[(size_t)r];
+    d.is_complete[(size_t)r] = (gdiff == pdiff) + (pdiff != 0);  // :54-63
+    if (pdiff != 0 && r != rank) d.buffered.push_back(r);         // :33-40
+    if (r != rank) d.send_counts[(size_t)r] = pdiff;
+  }
+  d.my_count = d.poff[(size_t)rank + 1] - d.poff[(size_t)rank];
+  // comm array index (:43-86): rank lid, renumbered in entity order for a partially held part
+  std::vector<int> run((size_t)P, 0);
+  d.comm_index.resize((size_t)d.nents);
+  for (int i = 0; i < d.nents; ++i) {
+    const int o = d.owners[(size_t)i];
+    const int lid = d.is_complete[(size_t)o] == 1 ? run[(size_t)o]++ : d.rank_lids[(size_t)i];
+    d.comm_index[(size_t)i] = lid + d.poff[(size_t)o];
+  }
+  d.nsend = d.nents - d.my_count;
+}
+
+int upload_dim(DimData& d) {
+  int rc;
+  if ((rc = upload(d.d_gids, d.gids))) return rc;
+  if ((rc = upload(d.d_owners, d.owners))) return rc;
+  if ((rc = upload(d.d_rank_lids, d.rank_lids))) return rc;
+  if ((rc = upload(d.d_comm_index, d.comm_index))) return rc;
+  if ((rc = upload(d.d_full_ids, d.full_ids))) return rc;
+  if ((rc = upload(d.d_ent_ids, d.ent_ids))) return rc;
+  if ((rc = upload(d.d_recv_ent, d.recv_ent))) return rc;
+  // contributions of every owned entity, in the order they sit in the receive buffer (= rank order)
+  std::vector<int> coff((size_t)d.my_count + 1, 0), cpos((size_t)d.nrecv);
+  for (int k = 0; k < d.nrecv; ++k) ++coff[(size_t)d.recv_ent[(size_t)k] + 1];
+  for (int e = 0; e < d.my_count; ++e) coff[(size_t)e + 1] += coff[(size_t)e];
+  std::vector<int> run(coff.begin(), coff.end() - 1);
+  for (int k = 0; k < d.nrecv; ++k) cpos[(size_t)run[(size_t)d.recv_ent[(size_t)k]]++] = k;
+  if ((rc = upload(d.d_contrib_off, coff))) return rc;
+  if ((rc = upload(d.d_contrib_pos, cpos))) return rc;
+  return PP_OK;
+}
+
+template <class T>
+int reduce_phase(pp_picpart* p, int phase) {
+  DimData& d = p->D[p->k];
+  hipStream_t st = pp::stream();
+  pp_comm* c = p->comm;
+  const int nv = p->nvals, P = p->nranks;
+  const size_t es = sizeof(T);
+  T* arr = (T*)p->array;
+  const int p0 = d.poff[(size_t)p->rank];
+  void* d_recv = nullptr;
+  int rc;
+  if (phase == 0) {  // pack + (local world) publish the fan-in
+    PP_HIP_CHECK(p->d_send.reserve(std::max<size_t>((size_t)d.nsend * nv, 1) * es));
+    PP_HIP_CHECK(p->d_mine.reserve(std::max<size_t>((size_t)d.my_count * nv, 1) * es));
+    PP_HIP_CHECK(p->d_out.reserve(std::max<size_t>((size_t)d.nrecv * nv, 1) * es));
+    const long long n = (long long)d.nents * nv;
+    if (n > 0)
+      k_part_pack<T><<<grid_for((size_t)n), kBlock, 0, st>>>(n, nv, d.d_comm_index.as<int>(), p0, d.my_count, arr,
+                                                            p->d_send.as<T>(), p->d_mine.as<T>());
+    PP_LAUNCH_CHECK();
+    if (c->kind == 4 && p->op != PP_OP_BCAST)
+      return pp::local_publish(c->world.get(), c->rank, d.send_counts, p->d_send.p, (int)(nv * es), 1);
+    return PP_OK;
+  }
+  if (phase == 1) {  // fan-in exchange, combine, fan-out send buffer
+    if (p->op != PP_OP_BCAST) {
+      if (c->kind == 4 && (rc = pp::local_all_begun(c->world.get(), 1))) return rc;
+      std::vector<int> rcnt = d.recv_counts;
+      rc = pp::comm_exchange_records(c, p->d_send.p, d.send_counts, rcnt, (int)(nv * es), &d_recv, 1);
+      if (c->kind == 4) pp::local_ended(c->world.get(), c->rank, 1);
+      if (rc) return rc;
+      if (rcnt != d.recv_counts) {
+        pp::set_error("pp_picpart_reduce: the ranks disagree on the exchange plan (different partition vectors "
+                      "or buffer rules?)");
+        return PP_ESTATE;
+      }
+      const long long n = (long long)d.my_count * nv;
+      if (n > 0 && d.nrecv > 0)
+        k_part_reduce<T><<<grid_for((size_t)n), kBlock, 0, st>>>(n, nv, p->op, p->d_mine.as<T>(), (const T*)d_recv,
+                                                                d.d_contrib_off.as<int>(), d.d_contrib_pos.as<int>());
+    }
+    const long long n = (long long)d.nrecv * nv;
+    if (n > 0)
+      k_part_fanout<T><<<grid_for((size_t)n), kBlock, 0, st>>>(n, nv, d.d_recv_ent.as<int>(), p->d_mine.as<T>(),
+                                                              p->d_out.as<T>());
+    PP_LAUNCH_CHECK();
+    if (c->kind == 4) return pp::local_publish(c->world.get(), c->rank, d.recv_counts, p->d_out.p, (int)(nv * es), 2);
+    return PP_OK;
+  }
+  // phase 2: fan-out exchange (the counts of the fan-in, reversed), unpack
+  if (c->kind == 4 && (rc = pp::local_all_begun(c->world.get(), 2))) return rc;
+  std::vector<int> rcnt = d.send_counts;
+  rc = pp::comm_exchange_records(c, p->d_out.p, d.recv_counts, rcnt, (int)(nv * es), &d_recv, 2);
+  if (c->kind == 4) pp::local_ended(c->world.get(), c->rank, 2);
+  if (rc) return rc;
+  if (rcnt != d.send_counts) {
+    pp::set_error("pp_picpart_reduce: the ranks disagree on the exchange plan");
+    return PP_ESTATE;
+  }
+  const long long n = (long long)d.nents * nv;
+  if (n > 0)
+    k_part_unpack<T><<<grid_for((size_t)n), kBlock, 0, st>>>(n, nv, d.d_comm_index.as<int>(), p0, d.my_count,
+                                                            p->d_mine.as<T>(), (const T*)d_recv, arr);
+  PP_LAUNCH_CHECK();
+  (void)P;
+  return PP_OK;
+}
+
+int run_phase(pp_picpart* p, int phase) {
+  return p->dtype == PP_T_I32 ? reduce_phase<int>(p, phase) : reduce_phase<double>(p, phase);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pp_owner_by_classification(const pp_mesh* full, const int* class_owners_host, int nclass, int comm_rank,
+                               int* elem_owner_host_out) {
+  PP_REQUIRE(full && class_owners_host && elem_owner_host_out && nclass > 0, "pp_owner_by_classification: bad argument");
+  int mine = 0;
+  for (int e = 0; e < full->nelems; ++e) {
+    const int c = full->class_id[(size_t)e];
+    if (c < 0 || c >= nclass) {  // the reference prints and reads out of range (:286-290); here an error
+      pp::set_error("pp_owner_by_classification: class id of an element outside [0, nclass)");
+      return PP_EINVAL;
+    }
+    elem_owner_host_out[e] = class_owners_host[c];
+    mine += class_owners_host[c] == comm_rank;
+  }
+  if (!mine && full->nelems > 0) {  // the reference asserts (:297-301)
+    pp::set_error("pp_owner_by_classification: this rank owns no element");
+    return PP_EINVAL;
+  }
+  return PP_OK;
+}
+
+pp_picpart* pp_picpart_create(const pp_mesh* full, const int* elem_owner_host, int buffer_method, int safe_method,
+                              int bridge_dim, int buffer_layers, int safe_layers, pp_comm* comm) {
+  auto fail = [](const char* msg) -> pp_picpart* {
+    pp::set_error(msg);
+    return nullptr;
+  };
+  if (!full || !elem_owner_host) return fail("pp_picpart_create: null argument");
+  if (buffer_method < PP_PART_FULL || buffer_method > PP_PART_NONE || safe_method < PP_PART_FULL ||
+      safe_method > PP_PART_NONE)
+    return fail("pp_picpart_create: unknown buffer / safe method");
+  if (buffer_layers < 0 || safe_layers < 0) return fail("pp_picpart_create: negative layer count");
+  if (bridge_dim != 0 && bridge_dim != full->dim - 1)
+    return fail("pp_picpart_create: bridge_dim must be 0 (vertices) or dim-1 (sides)");
+  if (buffer_method == PP_PART_NONE) buffer_method = PP_PART_MINIMUM;  // pumipic_input.cpp:96-100
+  if (buffer_method == PP_PART_MINIMUM) buffer_layers = 0;             // :107-110
+  if (safe_method == PP_PART_MINIMUM) safe_layers = 0;
+  const int P = comm ? comm->nranks : 1, rank = comm ? comm->rank : 0;
+  const int ne = full->nelems, nv = full->nverts, nvpe = full->dim + 1;
+  for (int e = 0; e < ne; ++e)
+    if (elem_owner_host[e] < 0 || elem_owner_host[e] >= P)
+      return fail("pp_picpart_create: element owner outside [0, comm size)");
+  pp_picpart* p = new pp_picpart();
+  auto bail = [&](const char* msg) -> pp_picpart* {
+    if (msg) pp::set_error(msg);
+    if (p->part) pp_mesh_destroy(p->part);
+    delete p;
+    return nullptr;
+  };
+  p->rank = rank;
+  p->nranks = P;
+  p->dim = full->dim;
+  p->full = full;
+  p->comm = comm;
+  p->is_full = buffer_method == PP_PART_FULL;
+  p->D[0].edim = 0;
+  p->D[1].edim = full->dim;
+  std::vector<int> owner_e(elem_owner_host, elem_owner_host + ne);
+  pp::DevBuf d_owner, d_safe_tmp;
+  if (upload(d_owner, owner_e) != PP_OK) return bail(nullptr);
+  if (d_safe_tmp.reserve((size_t)std::max(ne, 1)) != hipSuccess) return bail("pp_picpart_create: out of device memory");
+  // ---- this rank's safe zone and buffer
+  std::vector<unsigned char> is_safe;
+  if (safe_and_buffer(full, bridge_dim, rank, P, buffer_method, safe_method, buffer_layers, safe_layers,
+                      d_owner.as<int>(), d_safe_tmp, p->has_part, &is_safe) != PP_OK)
+    return bail(nullptr);
+  p->num_buffers = 0;
+  for (int r = 0; r < P; ++r) p->num_buffers += p->has_part[(size_t)r] > 0;
+  // ---- ownership of the vertices (defineOwners :305-323) and the global numbering (:153-163)
+  std::vector<int> owner_v((size_t)nv, P);
+  for (int v = 0; v < nv; ++v)
+    for (int k = full->vert2elems_off[(size_t)v]; k < full->vert2elems_off[(size_t)v + 1]; ++k)
+      owner_v[(size_t)v] = std::min(owner_v[(size_t)v], owner_e[(size_t)full->vert2elems[(size_t)k]]);
+  for (int v = 0; v < nv; ++v)
+    if (owner_v[(size_t)v] >= P) return bail("pp_picpart_create: a vertex belongs to no element");
+  std::vector<int64_t> gid_v, gid_e;
+  global_numbering(owner_v, P, p->D[0].goff, gid_v);
+  global_numbering(owner_e, P, p->D[1].goff, gid_e);
+  // ---- entities of this part (setSafeEnts :470-494) and the holder side of setupComm
+  auto kept = [&](const std::vector<int>& has_part, std::vector<char>& keep_e, std::vector<char>& keep_v) {
+    keep_e.assign((size_t)ne, 0);
+    keep_v.assign((size_t)nv, 0);
+    for (int e = 0; e < ne; ++e)
+      if (has_part[(size_t)owner_e[(size_t)e]]) {
+        keep_e[(size_t)e] = 1;
+        for (int k = 0; k < nvpe; ++k) keep_v[(size_t)full->elem2verts[(size_t)e * nvpe + k]] = 1;
+      }
+  };
+  std::vector<char> keep_e, keep_v;
+  kept(p->has_part, keep_e, keep_v);
+  setup_holder(p->D[0], P, rank, owner_v, gid_v, keep_v);
+  setup_holder(p->D[1], P, rank, owner_e, gid_e, keep_e);
+  if (p->D[1].nents == 0 && ne > 0) return bail("pp_picpart_create: empty part on this rank (:232-235)");
+  // ---- the owner side (what the reference learns from MPI_Ialltoall + Isend/Irecv, :113-190): which of my
+  // entities every other rank holds, in that rank's order -- from that rank's own buffer rule
+  for (int k = 0; k < 2; ++k) {
+    p->D[k].recv_counts.assign((size_t)P, 0);
+    p->D[k].recv_ent.clear();
+  }
+  std::vector<int> part_q;
+  std::vector<char> ke_q, kv_q;
+  for (int q = 0; q < P; ++q) {
+    if (q == rank) continue;
+    if (buffer_method == PP_PART_FULL) {
+      part_q.assign((size_t)P, 1);
+    } else if (safe_and_buffer(full, bridge_dim, q, P, buffer_method, PP_PART_NONE, buffer_layers, 0,
+                               d_owner.as<int>(), d_safe_tmp, part_q, nullptr) != PP_OK) {
+      return bail(nullptr);
+    }
+    kept(part_q, ke_q, kv_q);
+    for (int k = 0; k < 2; ++k) {
+      DimData& d = p->D[k];
+      const std::vector<int>& owner = k == 0 ? owner_v : owner_e;
+      const std::vector<int64_t>& gid = k == 0 ? gid_v : gid_e;
+      const std::vector<char>& keep = k == 0 ? kv_q : ke_q;
+      const int g0 = d.goff[(size_t)rank];
+      const size_t before = d.recv_ent.size();
+      for (int i = 0; i < d.nfull; ++i)  // increasing full id == rank q's part order
+        if (keep[(size_t)i] && owner[(size_t)i] == rank) d.recv_ent.push_back((int)(gid[(size_t)i] - g0));
+      const int cnt = (int)(d.recv_ent.size() - before);
+      d.recv_counts[(size_t)q] = cnt;
+      // a completely held part travels in rank-lid order (its lids are not renumbered, :66-76)
+      if (cnt == d.my_count) std::iota(d.recv_ent.begin() + (long)before, d.recv_ent.end(), 0);
+    }
+  }
+  for (int k = 0; k < 2; ++k) p->D[k].nrecv = (int)p->D[k].recv_ent.size();
+  // ---- the part's mesh (:196-258): kept vertices and elements in full-mesh order
+  if (!p->is_full) {
+    const DimData &dv = p->D[0], &de = p->D[1];
+    std::vector<double> coords((size_t)dv.nents * full->dim);
+    for (int i = 0; i < dv.nents; ++i)
+      for (int c = 0; c < full->dim; ++c)
+        coords[(size_t)i * full->dim + c] = full->coords[(size_t)dv.full_ids[(size_t)i] * full->dim + c];
+    std::vector<int> e2v((size_t)de.nents * nvpe), cls((size_t)de.nents);
+    for (int i = 0; i < de.nents; ++i) {
+      const int f = de.full_ids[(size_t)i];
+      for (int k = 0; k < nvpe; ++k) e2v[(size_t)i * nvpe + k] = dv.ent_ids[(size_t)full->elem2verts[(size_t)f * nvpe + k]];
+      cls[(size_t)i] = full->class_id[(size_t)f];
+    }
+    p->part = pp_mesh_create(full->dim, dv.nents, coords.data(), de.nents, e2v.data(), cls.data());
+    if (!p->part) return bail(nullptr);
+  }
+  p->safe.resize((size_t)p->D[1].nents);
+  for (int i = 0; i < p->D[1].nents; ++i) p->safe[(size_t)i] = is_safe[(size_t)p->D[1].full_ids[(size_t)i]];
+  if (upload(p->d_safe, p->safe) != PP_OK || upload_dim(p->D[0]) != PP_OK || upload_dim(p->D[1]) != PP_OK)
+    return bail(nullptr);
+  return p;
+}
+
+int pp_picpart_destroy(pp_picpart* p) {
+  if (!p) return PP_OK;
+  if (p->part) pp_mesh_destroy(p->part);
+  delete p;
+  return PP_OK;
+}
+
+const pp_mesh* pp_picpart_mesh(const pp_picpart* p) { return p ? (p->part ? p->part : p->full) : nullptr; }
+
+int pp_picpart_info(const pp_picpart* p, int* is_full_mesh, int* num_buffers, int* nverts, int* nelems) {
+  PP_REQUIRE(p, "pp_picpart_info: null part");
+  if (is_full_mesh) *is_full_mesh = p->is_full ? 1 : 0;
+  if (num_buffers) *num_buffers = p->num_buffers;
+  if (nverts) *nverts = p->D[0].nents;
+  if (nelems) *nelems = p->D[1].nents;
+  return PP_OK;
+}
+
+const void* pp_picpart_array_dev(const pp_picpart* p, int which, int edim, size_t* count) {
+  if (!p) {
+    pp::set_error("pp_picpart_array_dev: null part");
+    return nullptr;
+  }
+  if (which == PP_PART_SAFE) {
+    if (count) *count = p->safe.size();
+    return p->d_safe.p;
+  }
+  const DimData* d = dim_slot(p, edim);
+  if (!d) return nullptr;
+  const pp::DevBuf* b = nullptr;
+  size_t n = (size_t)d->nents;
+  switch (which) {
+    case PP_PART_GIDS: b = &d->d_gids; break;
+    case PP_PART_OWNERS: b = &d->d_owners; break;
+    case PP_PART_RANK_LIDS: b = &d->d_rank_lids; break;
+    case PP_PART_COMM_INDEX: b = &d->d_comm_index; break;
+    case PP_PART_FULL_IDS: b = &d->d_full_ids; break;
+    case PP_PART_ENT_IDS: b = &d->d_ent_ids; n = (size_t)d->nfull; break;
+    default: pp::set_error("pp_picpart_array_dev: unknown array"); return nullptr;
+  }
+  if (count) *count = n;
+  return b->p;
+}
+
+int pp_picpart_array_to_host(const pp_picpart* p, int which, int edim, void* out_host) {
+  PP_REQUIRE(p && out_host, "pp_picpart_array_to_host: null argument");
+  if (which == PP_PART_SAFE) {
+    if (!p->safe.empty()) memcpy(out_host, p->safe.data(), p->safe.size());
+    return PP_OK;
+  }
+  const DimData* d = dim_slot(p, edim);
+  if (!d) return PP_EINVAL;
+  auto cp = [&](const void* src, size_t bytes) {
+    if (bytes) memcpy(out_host, src, bytes);
+    return PP_OK;
+  };
+  switch (which) {
+    case PP_PART_GIDS: return cp(d->gids.data(), d->gids.size() * sizeof(int64_t));
+    case PP_PART_OWNERS: return cp(d->owners.data(), d->owners.size() * sizeof(int));
+    case PP_PART_RANK_LIDS: return cp(d->rank_lids.data(), d->rank_lids.size() * sizeof(int));
+    case PP_PART_COMM_INDEX: return cp(d->comm_index.data(), d->comm_index.size() * sizeof(int));
+    case PP_PART_FULL_IDS: return cp(d->full_ids.data(), d->full_ids.size() * sizeof(int));
+    case PP_PART_ENT_IDS: return cp(d->ent_ids.data(), d->ent_ids.size() * sizeof(int));
+    default: break;
+  }
+  pp::set_error("pp_picpart_array_to_host: unknown array");
+  return PP_EINVAL;
+}
+
+int pp_picpart_nents_offsets(const pp_picpart* p, int edim, int* offsets_host) {
+  PP_REQUIRE(p && offsets_host, "pp_picpart_nents_offsets: null argument");
+  const DimData* d = dim_slot(p, edim);
+  if (!d) return PP_EINVAL;
+  std::copy(d->poff.begin(), d->poff.end(), offsets_host);
+  return PP_OK;
+}
+
+int pp_picpart_buffered_ranks(const pp_picpart* p, int edim, int* ranks_host, int* n) {
+  PP_REQUIRE(p && n, "pp_picpart_buffered_ranks: null argument");
+  const DimData* d = dim_slot(p, edim);
+  if (!d) return PP_EINVAL;
+  *n = (int)d->buffered.size();
+  if (ranks_host) std::copy(d->buffered.begin(), d->buffered.end(), ranks_host);
+  return PP_OK;
+}
+
+int pp_picpart_complete_parts(const pp_picpart* p, int edim, int* is_complete_host) {
+  PP_REQUIRE(p && is_complete_host, "pp_picpart_complete_parts: null argument");
+  const DimData* d = dim_slot(p, edim);
+  if (!d) return PP_EINVAL;
+  std::copy(d->is_complete.begin(), d->is_complete.end(), is_complete_host);
+  return PP_OK;
+}
+
+int pp_picpart_reduce_begin(pp_picpart* p, int edim, int op, int dtype, int nvals, void* array_dev) {
+  pp::Range rg_("picpart_reduce");
+  PP_REQUIRE(p && (array_dev || nvals == 0), "pp_picpart_reduce: null argument");
+  PP_REQUIRE(op >= PP_OP_SUM && op <= PP_OP_BCAST, "pp_picpart_reduce: unknown operation");
+  PP_REQUIRE(dtype == PP_T_I32 || dtype == PP_T_F64, "pp_picpart_reduce: dtype must be PP_T_I32 or PP_T_F64");
+  PP_REQUIRE(nvals >= 0, "pp_picpart_reduce: negative nvals");
+  PP_REQUIRE(!p->active, "pp_picpart_reduce: a reduction of this part is still between its phases");
+  DimData* d = dim_slot(p, edim);
+  if (!d) return PP_EINVAL;
+  p->k = (int)(d - p->D);
+  p->op = op;
+  p->dtype = dtype;
+  p->nvals = nvals;
+  p->array = array_dev;
+  if (p->nranks == 1 || !p->comm || nvals == 0) {  // :259-260
+    p->phase = 3;
+    p->active = true;
+    return PP_OK;
+  }
+  int rc = run_phase(p, 0);
+  if (rc) return rc;
+  p->phase = 1;
+  p->active = true;
+  return PP_OK;
+}
+int pp_picpart_reduce_mid(pp_picpart* p) {
+  PP_REQUIRE(p && p->active, "pp_picpart_reduce_mid: no reduction in flight (call pp_picpart_reduce_begin)");
+  if (p->phase == 3) return PP_OK;
+  PP_REQUIRE(p->phase == 1, "pp_picpart_reduce_mid: called twice");
+  int rc = run_phase(p, 1);
+  if (rc) {
+    p->active = false;
+    return rc;
+  }
+  p->phase = 2;
+  return PP_OK;
+}
+int pp_picpart_reduce_end(pp_picpart* p) {
+  PP_REQUIRE(p && p->active, "pp_picpart_reduce_end: no reduction in flight");
+  if (p->phase == 3) {
+    p->active = false;
+    return PP_OK;
+  }
+  PP_REQUIRE(p->phase == 2, "pp_picpart_reduce_end: call pp_picpart_reduce_mid first");
+  p->active = false;
+  return run_phase(p, 2);
+}
+int pp_picpart_reduce(pp_picpart* p, int edim, int op, int dtype, int nvals, void* array_dev) {
+  PP_REQUIRE(p, "pp_picpart_reduce: null part");
+  PP_REQUIRE(!p->comm || p->comm->kind != 4,
+             "pp_picpart_reduce: virtual ranks of one process call pp_picpart_reduce_begin / _mid / _end on every "
+             "rank in turn");
+  int rc = pp_picpart_reduce_begin(p, edim, op, dtype, nvals, array_dev);
+  if (rc) return rc;
+  if ((rc = pp_picpart_reduce_mid(p))) return rc;
+  return pp_picpart_reduce_end(p);
+}
+
+}  // extern "C"

@@ -36,6 +36,44 @@ typedef Read<LO> LOs;
 typedef Read<GO> GOs;
 typedef Read<Real> Reals;
 enum { VERT = 0, EDGE = 1, FACE = 2, REGION = 3 };
+// Omega_h::parallel_for(n, OMEGA_H_LAMBDA(LO i){...}, name) over a plain index range, on the library's
+// stream (Omega_h_for.hpp); HostWrite / HostRead: a host copy of a device array
+#define OMEGA_H_LAMBDA [=] __host__ __device__
+template <class F>
+__global__ void oh_parallel_for_kernel(int n, F f) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) f(i);
+}
+template <class F>
+void parallel_for(LO n, F f, const char* = "") {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(oh_parallel_for_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)pp_stream(), (int)n, f);
+}
+template <class T>
+class HostWrite {
+ public:
+  HostWrite() {}
+  explicit HostWrite(size_t n) : h_(n) {}
+  HostWrite(const pumipic::View<T>& v) : h_(v.size()) {
+    pumipic::pp_check(pp_sync(), "HostWrite sync");
+    h_ = v.to_host();
+  }
+  T& operator[](size_t i) { return h_[i]; }
+  const T& operator[](size_t i) const { return h_[i]; }
+  size_t size() const { return h_.size(); }
+  T* data() { return h_.data(); }
+  pumipic::View<T> write() const {  // Omega_h::Write<T>(HostWrite<T>)
+    pumipic::View<T> v(h_.size());
+    v.from_host(h_.data());
+    return v;
+  }
+
+ private:
+  std::vector<T> h_;
+};
+template <class T>
+using HostRead = HostWrite<T>;
 // The drivers hold an Omega_h::Mesh* (the serial mesh inside the PICpart) next to the pumipic::Mesh
 // (the PICpart); here one handle plays both parts.
 typedef pumipic::Mesh Mesh;
@@ -47,8 +85,59 @@ namespace pumipic {
 typedef double fp_t;
 typedef fp_t Vector3d[3];
 
+// pumipic::Input (src/pumipic_input.hpp:8-75): the full mesh, the partition vector (per element, or per
+// classification id) and the buffer / safe rules of the PICparts
+class Input {
+ public:
+  enum Method { INVALID = -1, FULL, BFS, MINIMUM, NONE };
+  enum Ownership { PARTITION, CLASSIFICATION };
+  inline Input(Mesh& mesh, Ownership rule, const std::vector<int>& partition_vector, Method bufferMethod_,
+               Method safeMethod_, pp_comm* comm_ = nullptr);
+  Ownership getRule() const { return ownership_rule; }
+  const std::vector<int>& getPartition() const { return partition; }
+  static Method getMethod(std::string s) {  // pumipic_input.cpp:139-150
+    for (auto& c : s) c = (char)toupper(c);
+    if (s == "FULL") return FULL;
+    if (s == "BFS") return BFS;
+    if (s == "MINIMUM") return MINIMUM;
+    if (s == "NONE") return NONE;
+    return INVALID;
+  }
+  int bridge_dim = 0;       // bridge dimension of the BFS (0 = vertices, dim-1 = sides)
+  int bufferBFSLayers = 3;  // layers of the buffer (Method BFS)
+  int safeBFSLayers = 1;    // layers of the safe zone (Method BFS)
+
+ private:
+  friend class Mesh;
+  Mesh& m;
+  Ownership ownership_rule;
+  std::vector<int> partition;
+  Method bufferMethod, safeMethod;
+  pp_comm* comm;
+};
+
 class Mesh {
  public:
+  // PICparts from an Input (Mesh::Mesh(Input&), src/pumipic_part_construct.cpp:75-118): this object is the
+  // part -- its own pp_mesh unless the buffer is FULL -- with the numberings and the exchange plan of
+  // reduceCommArray (pp_picpart, include/pumipic_hip.h)
+  explicit Mesh(Input& in) {
+    comm_ = in.comm ? in.comm : comm_world();
+    std::vector<int> owner;
+    if (in.ownership_rule == Input::CLASSIFICATION) {
+      owner.resize((size_t)in.m.nelems());
+      pp_check(pp_owner_by_classification(in.m.handle(), in.partition.data(), (int)in.partition.size(),
+                                          pp_comm_rank(comm_), owner.data()), "setOwnerByClassification");
+    } else {
+      owner = in.partition;
+    }
+    part_ = pp_picpart_create(in.m.handle(), owner.data(), (int)in.bufferMethod, (int)in.safeMethod, in.bridge_dim,
+                              in.bufferBFSLayers, in.safeBFSLayers, comm_);
+    if (!part_) pp_check(PP_EHIP, "pumipic::Mesh(Input&)");
+    h_ = const_cast<pp_mesh*>(pp_picpart_mesh(part_));
+    owns_mesh_ = false;
+    pp_check(pp_mesh_info(h_, &dim_, &nverts_, &nelems_, &nsides_), "pp_mesh_info");
+  }
   Mesh(int dim, const std::vector<double>& coords, const std::vector<int>& elem2verts,
        const std::vector<int>& class_id) {
     h_ = pp_mesh_create(dim, (int)(coords.size() / dim), coords.data(),
@@ -58,7 +147,8 @@ class Mesh {
     pp_check(pp_mesh_info(h_, &dim_, &nverts_, &nelems_, &nsides_), "pp_mesh_info");
   }
   ~Mesh() {
-    if (h_) (void)pp_mesh_destroy(h_);
+    if (part_) (void)pp_picpart_destroy(part_);
+    if (h_ && owns_mesh_) (void)pp_mesh_destroy(h_);
   }
   Mesh(const Mesh&) = delete;
   Mesh& operator=(const Mesh&) = delete;
@@ -108,17 +198,51 @@ class Mesh {
   pp_comm* comm() const { return comm_ ? comm_ : comm_world(); }
   int rank() const { return pp_comm_rank(comm()); }
   int num_ranks() const { return pp_comm_size(comm()); }
-  bool isFullMesh() const { return true; }
+  pp_picpart* picpart() const { return part_; }
+  bool isFullMesh() const {
+    if (!part_) return true;
+    int full = 1;
+    pp_check(pp_picpart_info(part_, &full, nullptr, nullptr, nullptr), "isFullMesh");
+    return full != 0;
+  }
+  int nents(int edim) const { return edim == 0 ? nverts_ : (edim == dim_ ? nelems_ : nsides_); }
+  int numBuffers(int /*edim*/) const {  // parts held, self included (pumipic_mesh.hpp:43)
+    int nb = num_ranks();
+    if (part_) pp_check(pp_picpart_info(part_, nullptr, &nb, nullptr, nullptr), "numBuffers");
+    return nb;
+  }
+  std::vector<int> bufferedRanks(int edim) const {
+    std::vector<int> r((size_t)num_ranks());
+    int n = 0;
+    if (part_) {
+      pp_check(pp_picpart_buffered_ranks(part_, edim, r.data(), &n), "bufferedRanks");
+    } else {
+      for (int q = 0; q < num_ranks(); ++q)
+        if (q != rank()) r[(size_t)n++] = q;
+    }
+    r.resize((size_t)n);
+    return r;
+  }
+  // rankLocalIndex / commArrayIndex / nentsOffsets (pumipic_mesh.hpp:55-59), parts built from an Input
+  o::LOs rankLocalIndex(int edim) { return part_view<o::LO>(PP_PART_RANK_LIDS, edim); }
+  o::LOs commArrayIndex(int edim) { return part_view<o::LO>(PP_PART_COMM_INDEX, edim); }
+  std::vector<int> nentsOffsets(int edim) {
+    std::vector<int> off((size_t)num_ranks() + 1, 0);
+    if (part_) pp_check(pp_picpart_nents_offsets(part_, edim, off.data()), "nentsOffsets");
+    return off;
+  }
   o::LOs entOwners(int dim) {
+    if (part_) return part_view<o::LO>(PP_PART_OWNERS, dim);
     ensure_partition(dim);
     return owners_;
   }
   View<unsigned char> safeTag() {
+    if (part_) return part_view<unsigned char>(PP_PART_SAFE, dim_);
     ensure_partition(dim_);
     return safe_;
   }
-  o::GOs globalIds(int dim) {  // full-mesh replica: global id == local id
-    (void)dim;
+  o::GOs globalIds(int dim) {  // full-mesh replica without an Input: global id == local id
+    if (part_) return part_view<o::GO>(PP_PART_GIDS, dim);
     if (gids_.size() == 0) {
       std::vector<o::GO> g((size_t)nelems_);
       for (int e = 0; e < nelems_; ++e) g[(size_t)e] = e;
@@ -129,18 +253,31 @@ class Mesh {
   }
   // createCommArray / reduceCommArray (src/pumipic_mesh.hpp:92-110, pumipic_comm.cpp:222-246): every
   // entity is buffered on every rank, so the reduction is the all-reduce of the whole array
-  enum Op { SUM_OP, MAX_OP, MIN_OP };
+  // (a part built from an Input goes through the owners: pp_picpart_reduce, fan-in / fan-out, every Op,
+  // o::LO and o::Real -- pumipic_comm.cpp:249-440)
+  enum Op { SUM_OP, MAX_OP, MIN_OP, BCAST_OP };
   template <class T>
   o::Write<T> createCommArray(int edim, int num_entries_per_entity, T default_value) {
     const int n = edim == 0 ? nverts_ : (edim == dim_ ? nelems_ : nsides_);
     return o::Write<T>((size_t)n * num_entries_per_entity, default_value);
   }
-  void reduceCommArray(int /*edim*/, Op op, o::Write<o::Real> array) {
+  void reduceCommArray(int edim, Op op, o::Write<o::Real> array) {
+    if (part_) {
+      reduce_part(edim, op, PP_T_F64, array.data(), array.size());
+      return;
+    }
     if (op != SUM_OP) {
-      fprintf(stderr, "reduceCommArray: only SUM_OP is built (the hot path's gyroSync)\n");
+      fprintf(stderr, "reduceCommArray: MAX / MIN / BCAST need a part built from a pumipic::Input\n");
       exit(EXIT_FAILURE);
     }
     pp_check(pp_allreduce_sum(comm(), array.data(), (int64_t)array.size()), "reduceCommArray");
+  }
+  void reduceCommArray(int edim, Op op, o::Write<o::LO> array) {
+    if (!part_) {
+      fprintf(stderr, "reduceCommArray<LO>: needs a part built from a pumipic::Input\n");
+      exit(EXIT_FAILURE);
+    }
+    reduce_part(edim, op, PP_T_I32, array.data(), array.size());
   }
   // ---- mesh tags the drivers use (Omega_h::Mesh::add_tag / set_tag / get_array)
   template <class T>
@@ -185,7 +322,25 @@ class Mesh {
     const void* p = pp_mesh_array_dev(h_, which, &n);
     return View<T>::wrap((T*)p, n);
   }
+  void reduce_part(int edim, Op op, int dtype, void* data, size_t n) {
+    const int ne = nents(edim);
+    if (ne <= 0) return;
+    if (n % (size_t)ne != 0) {  // pumipic_comm.cpp:253-256
+      fprintf(stderr, "Comm array size does not match the expected size for dimension %d\n", edim);
+      return;
+    }
+    pp_check(pp_picpart_reduce(part_, edim, (int)op, dtype, (int)(n / (size_t)ne), data), "reduceCommArray");
+  }
+  template <class T>
+  View<T> part_view(int which, int edim) const {
+    size_t n = 0;
+    const void* p = pp_picpart_array_dev(part_, which, edim, &n);
+    if (!p && n) pp_check(PP_EINVAL, "picpart array");
+    return View<T>::wrap((T*)p, n);
+  }
   pp_mesh* h_ = nullptr;
+  bool owns_mesh_ = true;
+  pp_picpart* part_ = nullptr;
   int dim_ = 0, nverts_ = 0, nelems_ = 0, nsides_ = 0;
   pp_comm* comm_ = nullptr;
   o::Write<o::LO> owners_;
@@ -194,6 +349,18 @@ class Mesh {
   std::map<std::string, View<double>> real_tags_;
   std::map<std::string, View<int>> int_tags_;
 };
+
+inline Input::Input(Mesh& mesh, Ownership rule, const std::vector<int>& partition_vector, Method bufferMethod_,
+                    Method safeMethod_, pp_comm* comm_)
+    : m(mesh), ownership_rule(rule), partition(partition_vector), bufferMethod(bufferMethod_),
+      safeMethod(safeMethod_), comm(comm_) {
+  if (bufferMethod == NONE) {  // pumipic_input.cpp:122-126
+    fprintf(stderr, "[WARNING] bufferMethod given as NONE, setting to MINIMUM\n");
+    bufferMethod = MINIMUM;
+  }
+  if (bufferMethod == MINIMUM) bufferBFSLayers = 0;  // :133-136
+  if (safeMethod == MINIMUM) safeBFSLayers = 0;
+}
 
 // ---------------------------------------------------------------- timing (support/ppTiming.hpp:34-75)
 struct TimingEntry {

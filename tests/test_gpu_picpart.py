@@ -1,0 +1,286 @@
+"""-m gpu: PICpart construction and comm-array reduction through the C-ABI (pp_picpart_*) against the
+oracle (oracle/ppo_picpart.py): numberings, part meshes and exchange plans bit-exact, reductions bit-exact
+for integers and for doubles (the owner adds in the same order on both sides: own value, then increasing
+rank).  Ranks: the virtual ranks of one process (Comm.local) and two rank PROCESSES sharing the GPU over
+the TCP transport; what the reference's tests assert (test/test_comm_array.cpp, test_input_construct.cpp)
+is asserted on the GPU results too."""
+import multiprocessing as mp
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import pumipic_amd_loader
+from test_picpart_oracle import slab_owners
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def capi(pp):
+    from pumipic_amd import capi as c
+    c.build()
+    c.init(0)
+    return c
+
+
+@pytest.fixture(scope="module")
+def opp():
+    return pumipic_amd_loader.load_oracle_picpart()
+
+
+def _mesh_arrays(synth, which):
+    if which == 0:
+        c, e, k = synth.kuhn_box(5)
+        return 3, c, e, k, slab_owners(c, e, 4)
+    if which == 1:
+        c, e, k = synth.annulus_tri(n_b=8, n_theta=32, band_width=3)
+        return 2, c, e, k, slab_owners(c, e, 4, axis=1)
+    c, e, k = synth.torus_tet(n_b=6, n_theta=16, n_planes=8)
+    return 3, c, e, k, slab_owners(c, e, 3, axis=2)
+
+
+CASES = [  # (mesh, buffer, safe, bridge (0 = vertices, 1 = sides), buffer layers, safe layers)
+    (0, "BFS", "BFS", 0, 1, 0), (1, "BFS", "BFS", 0, 1, 0), (0, "FULL", "FULL", 0, 3, 1), (1, "FULL", "BFS", 1, 3, 3),
+    (0, "MINIMUM", "NONE", 0, 3, 1), (2, "BFS", "FULL", 0, 2, 1), (2, "BFS", "BFS", 1, 2, 1), (1, "MINIMUM", "BFS", 0, 3, 2),
+]
+
+
+def _build(ppo, synth, capi, opp, case):
+    which, bm, sm, bridge, bl, sl = case
+    dim, c, e, k, owner = _mesh_arrays(synth, which)
+    P = int(owner.max()) + 1
+    mo = ppo.Mesh(dim, c, e, k)
+    bd = 0 if bridge == 0 else dim - 1
+    O = opp.PicParts(mo, owner, P, getattr(opp, bm), getattr(opp, sm), bridge_dim=bd, buffer_layers=bl, safe_layers=sl)
+    mg = capi.Mesh(dim, c, e, k)
+    comms = capi.Comm.local(P)
+    parts = [capi.PicPart(mg, owner, comms[r], getattr(capi, "PART_" + bm), getattr(capi, "PART_" + sm), bd, bl, sl)
+             for r in range(P)]
+    return dim, mo, mg, O, parts, comms, owner
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_construction_matches_oracle(ppo, synth, capi, opp, case):
+    dim, mo, mg, O, parts, comms, owner = _build(ppo, synth, capi, opp, case)
+    for po, pg in zip(O.parts, parts):
+        assert pg.is_full_mesh == po.is_full_mesh
+        assert pg.num_buffers == int(po.has_part.sum())
+        for d in (0, dim):
+            assert pg.nents[d] == po.nents[d]
+            assert np.array_equal(pg.array(capi.PART_GIDS, d), po.gids[d])
+            assert np.array_equal(pg.array(capi.PART_OWNERS, d), po.owners[d])
+            assert np.array_equal(pg.array(capi.PART_RANK_LIDS, d), po.rank_lids[d])
+            assert np.array_equal(pg.array(capi.PART_COMM_INDEX, d), po.comm_index[d])
+            assert np.array_equal(pg.array(capi.PART_FULL_IDS, d), po.full_ids[d])
+            assert np.array_equal(pg.array(capi.PART_ENT_IDS, d), po.ent_ids[d])
+            assert np.array_equal(pg.nents_offsets(d), po.nents_offsets[d])
+            assert np.array_equal(pg.complete_parts(d), po.is_complete[d])
+            assert pg.buffered_ranks(d).tolist() == po.buffered_parts[d]
+        assert np.array_equal(pg.array(capi.PART_SAFE).astype(np.int32), po.safe)
+        # the part's mesh: same vertices and elements as the oracle's, a working pp_mesh
+        m = pg.mesh
+        assert (m.nverts, m.nelems) == (po.nents[0], po.nents[dim])
+        if not pg.is_full_mesh:
+            assert np.array_equal(m.array(0).reshape(-1, dim), po.coords)          # PP_MESH_COORDS
+            assert np.array_equal(m.array(1).reshape(-1, dim + 1), po.elem2verts)   # PP_MESH_ELEM2VERTS
+    for c in comms:
+        c.destroy()
+
+
+def _reduce_both(capi, O, parts, d, op, host_arrays):
+    devs = [capi.DevArray.from_host(a) for a in host_arrays]
+    capi.picpart_reduce_all(parts, d, op, devs)
+    return [x.to_host() for x in devs], O.reduce(d, op, host_arrays)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_reduce_matches_oracle_and_reference_properties(ppo, synth, capi, opp, case):
+    dim, mo, mg, O, parts, comms, owner = _build(ppo, synth, capi, opp, case)
+    rng = np.random.default_rng(5)
+    P = len(parts)
+    for d in (0, dim):
+        n = [p.nents[d] for p in parts]
+        # random doubles, 3 values per entity: SUM / MAX / MIN / BCAST bit-exact
+        for op in (capi.OP_SUM, capi.OP_MAX, capi.OP_MIN, capi.OP_BCAST):
+            arrs = [rng.standard_normal(k * 3) for k in n]
+            got, want = _reduce_both(capi, O, parts, d, op, arrs)
+            for g, w in zip(got, want):
+                assert np.array_equal(g, w), (d, op)
+        arrs = [rng.integers(-1000, 1000, size=k).astype(np.int32) for k in n]
+        got, want = _reduce_both(capi, O, parts, d, capi.OP_SUM, arrs)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+        # minOwnership (test_comm_array.cpp:120-146)
+        arrs = [np.where(p.array(capi.PART_OWNERS, d) == r, r, np.iinfo(np.int32).max).astype(np.int32)
+                for r, p in enumerate(parts)]
+        got, _ = _reduce_both(capi, O, parts, d, capi.OP_MIN, arrs)
+        for p, g in zip(parts, got):
+            assert np.array_equal(g, p.array(capi.PART_OWNERS, d))
+    # sumEntities on vertices (:148-179)
+    cnt, _ = _reduce_both(capi, O, parts, 0, capi.OP_SUM, [np.ones(p.nents[0], np.int32) for p in parts])
+    got, _ = _reduce_both(capi, O, parts, 0, capi.OP_SUM, [np.repeat(1.0 / c, 3) for c in cnt])
+    for g in got:
+        assert np.all(np.abs(g - 1.0) < 1e-5)
+    # elements: 1 on the owner only (:92-117); full buffers: every entity counted comm_size times (:181-207)
+    got, _ = _reduce_both(capi, O, parts, dim, capi.OP_SUM,
+                          [np.repeat((p.array(capi.PART_OWNERS, dim) == r).astype(np.int32), 3)
+                           for r, p in enumerate(parts)])
+    for g in got:
+        assert np.all(g == 1)
+    if parts[0].is_full_mesh:
+        for d in (0, dim):
+            got, _ = _reduce_both(capi, O, parts, d, capi.OP_SUM, [np.ones(p.nents[d], np.int32) for p in parts])
+            for g in got:
+                assert np.all(g == P)
+    for c in comms:
+        c.destroy()
+
+
+def test_gyro_sync_on_bfs_parts_equals_the_full_mesh_field(ppo, synth, capi, opp):
+    """gyroSync's use (test/gyroScatter.hpp:231-258) without the full-mesh replica: every rank scatters the
+    particles of its own elements on its PART's mesh; the SUM over the parts' vertex arrays equals the
+    field of the whole population on the whole mesh, at every vertex a part holds."""
+    import common
+    pop = common.population_2d(synth, n_b=12, n_theta=48, num_ptcls=4000, mdl_face=3, band_width=3)
+    dim, P = 2, 3
+    owner = slab_owners(pop["coords"], pop["e2v"], P, axis=0)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    counts_full = np.bincount(pop["elem"], minlength=len(pop["e2v"])).astype(np.int32)
+    mg = capi.Mesh(dim, pop["coords"], pop["e2v"], pop["cls"])
+    comms = capi.Comm.local(P)
+    parts = [capi.PicPart(mg, owner, comms[r], capi.PART_BFS, capi.PART_BFS, 0, 2, 1) for r in range(P)]
+    # per-element counts as an element comm array: each rank contributes its own elements' particles
+    arrs = []
+    for r, p in enumerate(parts):
+        fid = p.array(capi.PART_FULL_IDS, dim)
+        own = p.array(capi.PART_OWNERS, dim) == r
+        arrs.append(capi.DevArray.from_host(np.where(own, counts_full[fid], 0).astype(np.int32)))
+    capi.picpart_reduce_all(parts, dim, capi.OP_SUM, arrs)
+    for p, a in zip(parts, arrs):
+        assert np.array_equal(a.to_host(), counts_full[p.array(capi.PART_FULL_IDS, dim)])
+    # vertex field: each rank's partial sums of a per-element quantity onto its vertices, reduced
+    w_full = np.zeros(mg.nverts)
+    np.add.at(w_full, pop["e2v"].ravel(), np.repeat(counts_full.astype(np.float64), dim + 1))
+    varrs = []
+    for r, p in enumerate(parts):
+        fid_e = p.array(capi.PART_FULL_IDS, dim)
+        own = p.array(capi.PART_OWNERS, dim) == r
+        e2v = p.mesh.array(1).reshape(-1, dim + 1)
+        w = np.zeros(p.nents[0])
+        np.add.at(w, e2v[own].ravel(), np.repeat(counts_full[fid_e][own].astype(np.float64), dim + 1))
+        varrs.append(capi.DevArray.from_host(w))
+    capi.picpart_reduce_all(parts, 0, capi.OP_SUM, varrs)
+    for p, a in zip(parts, varrs):
+        assert np.array_equal(a.to_host(), w_full[p.array(capi.PART_FULL_IDS, 0)])  # integers in doubles: exact
+    for c in comms:
+        c.destroy()
+
+
+def test_error_paths(synth, capi):
+    dim, c, e, k, owner = _mesh_arrays(synth, 1)
+    mg = capi.Mesh(dim, c, e, k)
+    comms = capi.Comm.local(4)
+    with pytest.raises(capi.PPError):
+        capi.PicPart(mg, np.full(len(e), 7, np.int32), comms[0])          # owner out of range
+    with pytest.raises(capi.PPError):
+        capi.PicPart(mg, owner, comms[0], capi.PART_BFS, capi.PART_BFS, bridge_dim=5)
+    p = capi.PicPart(mg, owner, comms[0], capi.PART_BFS, capi.PART_BFS, 0, 1, 0)
+    a = p.create_comm_array(0, 1, 0.0)
+    with pytest.raises(capi.PPError):
+        p.reduce(0, capi.OP_SUM, a)                                        # virtual ranks need the phases
+    with pytest.raises(capi.PPError):
+        p.reduce_mid()                                                     # nothing in flight
+    with pytest.raises(capi.PPError):
+        p.reduce_begin(1 if dim == 3 else 5, capi.OP_SUM, a)               # no edge numbering
+    assert np.array_equal(capi.owner_by_classification(mg, np.arange(int(k.max()) + 1) % 4, int(k[0]) % 4),
+                          (np.asarray(k) % 4).astype(np.int32))
+    with pytest.raises(capi.PPError):
+        capi.owner_by_classification(mg, np.zeros(int(k.max()) + 1, np.int32), 3)  # a rank that owns nothing
+    for cm in comms:
+        cm.destroy()
+
+
+# ---------------------------------------------------------------- two processes, one GPU, TCP transport
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _proc_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import pumipic_amd_loader as L
+        pp = L.load()
+        from pumipic_amd import capi
+        capi.init(0)
+        comm = capi.Comm.tcp("127.0.0.1", port, rank, world)
+        c, e, k = pp.synth.kuhn_box(5)
+        from test_picpart_oracle import slab_owners as so
+        owner = so(c, e, world)
+        mesh = capi.Mesh(3, c, e, k)
+        part = capi.PicPart(mesh, owner, comm, capi.PART_BFS, capi.PART_BFS, 0, 1, 0)
+        out = {}
+        rng = np.random.default_rng(100 + rank)
+        for d in (0, 3):
+            a = rng.standard_normal(part.nents[d] * 2)
+            dev = capi.DevArray.from_host(a)
+            part.reduce(d, capi.OP_SUM, dev)
+            out[d] = (a, dev.to_host())
+        comm.barrier()
+        q.put((rank, "ok", out))
+        comm.destroy()
+    except Exception as ex:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL " + repr(ex) + traceback.format_exc(), None))
+
+
+def test_two_processes_reduce_over_tcp(ppo, synth, capi, opp):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_proc_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), [r[1] for r in res]
+    c, e, k = synth.kuhn_box(5)
+    owner = slab_owners(c, e, world)
+    O = opp.PicParts(ppo.Mesh(3, c, e, k), owner, world, opp.BFS, opp.BFS, buffer_layers=1, safe_layers=0)
+    for d in (0, 3):
+        want = O.reduce(d, opp.SUM_OP, [res[r][2][d][0] for r in range(world)])
+        for r in range(world):
+            assert np.array_equal(res[r][2][d][1], want[r])
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_cpp_driver_comm_array(synth, capi, tmp_path, world):
+    """drivers/comm_array.cpp: the reference's test_comm_array.cpp checks on the C++ mirror (pumipic::Input,
+    Mesh(Input&), createCommArray, reduceCommArray), as rank processes sharing the GPU over PP_COMM=tcp"""
+    import subprocess
+    drv = os.path.join(ROOT, "pumi-pic_amd", "drivers")
+    subprocess.check_call(["make", "-C", drv, "-s"])
+    c, e, k = synth.kuhn_box(5)
+    mesh_file = str(tmp_path / "box.bin")
+    synth.write_mesh_bin(mesh_file, 3, c, e, k)
+    ptn = str(tmp_path / "box.ptn")
+    np.savetxt(ptn, slab_owners(c, e, world), fmt="%d")
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), PP_DEVICE="0",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PP_COMM="tcp")
+        procs.append(subprocess.Popen([os.path.join(drv, "comm_array"), mesh_file, ptn, "1", "0"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, (so[-1500:], se[-1500:])
+        assert "all checks passed" in so
