@@ -596,6 +596,45 @@ int pp_picpart_reduce_begin(pp_picpart* p, int edim, int op, int dtype, int nval
 int pp_picpart_reduce_mid(pp_picpart* p);
 int pp_picpart_reduce_end(pp_picpart* p);
 
+/* ------------------------------------------------------------------ particle load balancer
+ * pumipic::ParticleBalancer (src/pumipic_lb.hpp:33-118, src/pumipic_lb.cpp).  pp_balancer_create =
+ * ParticleBalancer(Mesh&) (pumipic_lb.cpp:23-84): the "sbar" of every element -- the set of parts on which
+ * it is safe, its owner included -- as a 64-bit mask (bit r = part r; at most 64 ranks), derived from the
+ * Input on every rank without a message; the sorted list of distinct masks is the same on every rank.
+ * pp_balancer_sbar_ids_dev = getSbarIDs (index into that list per element of the part).
+ *
+ * pp_balancer_repartition = ParticleBalancer::repartition (pumipic_lb.hpp:352-362): addWeights (device
+ * histogram of the particles staying here by the sbar of their new element, and of the particles already
+ * leaving by destination), balance, selectParticles (rewrites new_procs_dev of the particles that move;
+ * new_elems_dev are elements of the part, -1 = leaving the domain; particles pushed out of the safe zone
+ * must already carry their owner, as in the reference).  `balance` is EnGPar's weight diffusion in the
+ * reference (engpar::balanceWeights, scorec/EnGPar >= 1.1.0, not part of the reference tree); here one
+ * all-gather of the weight rows and the same integer diffusion on every rank: a part above the average
+ * sends step_factor x (its weight - the neighbour's) / (number of lighter neighbours) towards every
+ * lighter neighbour through the sbars they share, only from what it holds at the start, until
+ * max weight <= tol x average (tol 1.05 = 5 %).
+ * pp_balancer_partition = ParticleBalancer::partition (:364-377): the same from a host array of particles
+ * per element; new_procs_host (sum of the counts, element-major) receives the destinations.
+ * Virtual ranks of one process: _begin on every rank, then _end on every rank. */
+typedef struct pp_balancer pp_balancer;
+pp_balancer* pp_balancer_create(pp_picpart* part);
+int pp_balancer_destroy(pp_balancer* b);
+int pp_balancer_num_sbars(const pp_balancer* b);
+int pp_balancer_sbars(const pp_balancer* b, unsigned long long* masks_host);
+const int* pp_balancer_sbar_ids_dev(const pp_balancer* b, size_t* n);
+int pp_balancer_repartition(pp_balancer* b, const pp_ps* ps, double tol, const int* new_elems_dev, int* new_procs_dev,
+                            double step_factor);
+int pp_balancer_repartition_begin(pp_balancer* b, const pp_ps* ps, const int* new_elems_dev, int* new_procs_dev);
+int pp_balancer_repartition_end(pp_balancer* b, double tol, double step_factor);
+int pp_balancer_partition(pp_balancer* b, const int* ptcls_per_elem_host, double tol, double step_factor,
+                          int* new_procs_host);
+int pp_balancer_partition_begin(pp_balancer* b, const int* ptcls_per_elem_host);
+int pp_balancer_partition_end(pp_balancer* b, double tol, double step_factor, int* new_procs_host);
+/* the plan of the last call on this rank: *n entries (sbar index, target rank, particles), sbar-major;
+ * weights_after_host (comm size values, may be NULL): every rank's weight once the plan is carried out */
+int pp_balancer_last_plan(const pp_balancer* b, int* n, int* sbar_host, int* target_host, long long* amount_host,
+                          long long* weights_after_host);
+
 /* ------------------------------------------------------------------ tracing
  * Kokkos::Profiling::pushRegion / popRegion of the reference (e.g. adjacency.tpp:480,613,
  * SCS_rebuild.h:126,311) map to roctx ranges (rocprofv3 --marker-trace).  The library wraps its own

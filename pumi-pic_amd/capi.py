@@ -136,6 +136,18 @@ SYMBOLS = {
     "pp_picpart_reduce_begin": (_I, [_V, _I, _I, _I, _I, _V]),
     "pp_picpart_reduce_mid": (_I, [_V]),
     "pp_picpart_reduce_end": (_I, [_V]),
+    "pp_balancer_create": (_V, [_V]),
+    "pp_balancer_destroy": (_I, [_V]),
+    "pp_balancer_num_sbars": (_I, [_V]),
+    "pp_balancer_sbars": (_I, [_V, _V]),
+    "pp_balancer_sbar_ids_dev": (_V, [_V, C.POINTER(C.c_size_t)]),
+    "pp_balancer_repartition": (_I, [_V, _V, _D, _V, _V, _D]),
+    "pp_balancer_repartition_begin": (_I, [_V, _V, _V, _V]),
+    "pp_balancer_repartition_end": (_I, [_V, _D, _D]),
+    "pp_balancer_partition": (_I, [_V, c_int_p, _D, _D, c_int_p]),
+    "pp_balancer_partition_begin": (_I, [_V, c_int_p]),
+    "pp_balancer_partition_end": (_I, [_V, _D, _D, c_int_p]),
+    "pp_balancer_last_plan": (_I, [_V, c_int_p, c_int_p, c_int_p, _V, _V]),
     "pp_gyro_scatter_radius": (_I, [_V, _V, _V, _V, _V, _D, _I, _I, _V, c_int_p]),
     "pp_gather_tet_vtx": (_I, [_V, _V, _I, _V, _V, _I, _V, _V]),
     "pp_interp2d_field": (_I, [_V, _I, _V, _D, _D, _D, _D, _I, _I, _I, _I, _I, _V]),
@@ -1267,3 +1279,71 @@ def picpart_reduce_all(parts, edim, op, arrays):
         p.reduce_mid()
     for p in parts:
         p.reduce_end()
+
+
+class Balancer:
+    """pumipic::ParticleBalancer (pp_balancer) of a PicPart"""
+
+    def __init__(self, part):
+        self.part = part
+        self.p = lib().pp_balancer_create(part.p)
+        if not self.p:
+            raise PPError("pp_balancer_create: " + lib().pp_last_error().decode())
+
+    def sbars(self):
+        n = lib().pp_balancer_num_sbars(self.p)
+        out = np.zeros(n, dtype=np.uint64)
+        if n:
+            check(lib().pp_balancer_sbars(self.p, out.ctypes.data))
+        return out
+
+    def sbar_ids(self):
+        cnt = C.c_size_t()
+        ptr = lib().pp_balancer_sbar_ids_dev(self.p, C.byref(cnt))
+        out = np.empty(cnt.value, dtype=np.int32)
+        if cnt.value:
+            sync()
+            check(lib().pp_memcpy_d2h(out.ctypes.data, ptr, out.nbytes))
+        return out
+
+    def repartition(self, ps, new_elems, new_procs, tol=1.05, step_factor=0.3):
+        check(lib().pp_balancer_repartition(self.p, ps.p, tol, new_elems.ptr, new_procs.ptr, step_factor))
+
+    def repartition_begin(self, ps, new_elems, new_procs):
+        self._keep = (ps, new_elems, new_procs)
+        check(lib().pp_balancer_repartition_begin(self.p, ps.p, new_elems.ptr, new_procs.ptr))
+
+    def repartition_end(self, tol=1.05, step_factor=0.3):
+        check(lib().pp_balancer_repartition_end(self.p, tol, step_factor))
+        self._keep = None
+
+    def partition(self, ptcls_per_elem, tol=1.05, step_factor=0.3):
+        ppe = np.ascontiguousarray(ptcls_per_elem, dtype=np.int32)
+        out = np.empty(int(ppe.sum()), dtype=np.int32)
+        check(lib().pp_balancer_partition(self.p, ppe.ctypes.data_as(c_int_p), tol, step_factor,
+                                          out.ctypes.data_as(c_int_p)))
+        return out
+
+    def partition_begin(self, ptcls_per_elem):
+        self._ppe = np.ascontiguousarray(ptcls_per_elem, dtype=np.int32)
+        check(lib().pp_balancer_partition_begin(self.p, self._ppe.ctypes.data_as(c_int_p)))
+
+    def partition_end(self, tol=1.05, step_factor=0.3):
+        out = np.empty(int(self._ppe.sum()), dtype=np.int32)
+        check(lib().pp_balancer_partition_end(self.p, tol, step_factor, out.ctypes.data_as(c_int_p)))
+        return out
+
+    def last_plan(self):
+        n = C.c_int()
+        check(lib().pp_balancer_last_plan(self.p, C.byref(n), None, None, None, None))
+        sb, tg = np.empty(n.value, np.int32), np.empty(n.value, np.int32)
+        am, w = np.empty(n.value, np.int64), np.zeros(self.part.nranks, np.int64)
+        check(lib().pp_balancer_last_plan(self.p, C.byref(n), sb.ctypes.data_as(c_int_p), tg.ctypes.data_as(c_int_p),
+                                          am.ctypes.data, w.ctypes.data))
+        return [(int(a), int(b), int(c)) for a, b, c in zip(sb, tg, am)], w
+
+    def __del__(self):
+        try:
+            lib().pp_balancer_destroy(self.p)
+        except Exception:
+            pass

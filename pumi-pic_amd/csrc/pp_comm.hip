@@ -288,6 +288,10 @@ struct LocalWorld {
     std::vector<int> rec_bytes;
     int ended = 0;
   } ch[3];
+  // mailbox round (all-gather of small host rows: the balancer's weights)
+  std::vector<std::vector<char>> mail;
+  std::vector<char> mail_set;
+  int mail_reads = 0;
   // all-reduce round
   std::vector<double*> red_buf;
   int64_t red_n = 0;
@@ -334,6 +338,32 @@ void local_ended(LocalWorld* w, int rank, int chan) {
     std::fill(c.begun.begin(), c.begun.end(), 0);
     c.ended = 0;
   }
+}
+
+int local_mail_put(LocalWorld* w, int rank, const void* data, size_t bytes) {
+  PP_REQUIRE(w, "local communicator: no world");
+  if (w->mail.size() != (size_t)w->nranks) {
+    w->mail.assign((size_t)w->nranks, {});
+    w->mail_set.assign((size_t)w->nranks, 0);
+  }
+  PP_REQUIRE(!w->mail_set[(size_t)rank], "local communicator: this virtual rank already posted its row");
+  w->mail[(size_t)rank].assign((const char*)data, (const char*)data + bytes);
+  w->mail_set[(size_t)rank] = 1;
+  return PP_OK;
+}
+int local_mail_get_all(LocalWorld* w, int rank, size_t bytes, void* out) {
+  (void)rank;
+  PP_REQUIRE(w && w->mail.size() == (size_t)w->nranks, "local communicator: nothing was posted");
+  for (int r = 0; r < w->nranks; ++r) {
+    PP_REQUIRE(w->mail_set[(size_t)r] && w->mail[(size_t)r].size() == bytes,
+               "local communicator: call the `begin` half on every virtual rank before the first `end` half");
+    memcpy((char*)out + (size_t)r * bytes, w->mail[(size_t)r].data(), bytes);
+  }
+  if (++w->mail_reads >= w->nranks) {
+    std::fill(w->mail_set.begin(), w->mail_set.end(), 0);
+    w->mail_reads = 0;
+  }
+  return PP_OK;
 }
 
 // ------------------------------------------------------------------ transport primitives

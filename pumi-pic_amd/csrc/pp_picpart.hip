@@ -114,6 +114,9 @@ struct pp_picpart {
   pp_comm* comm = nullptr;
   std::vector<int> has_part;
   int num_buffers = 1;
+  // the Input the part was built from (the balancer re-derives every rank's safe zone from it)
+  std::vector<int> owner_e;
+  int buffer_method = 0, safe_method = 0, bridge_dim = 0, buffer_layers = 0, safe_layers = 0;
   DimData D[2];  // 0: vertices, 1: elements
   std::vector<unsigned char> safe;
   pp::DevBuf d_safe;
@@ -368,6 +371,12 @@ pp_picpart* pp_picpart_create(const pp_mesh* full, const int* elem_owner_host, i
   p->D[0].edim = 0;
   p->D[1].edim = full->dim;
   std::vector<int> owner_e(elem_owner_host, elem_owner_host + ne);
+  p->owner_e = owner_e;
+  p->buffer_method = buffer_method;
+  p->safe_method = safe_method;
+  p->bridge_dim = bridge_dim;
+  p->buffer_layers = buffer_layers;
+  p->safe_layers = safe_layers;
   pp::DevBuf d_owner, d_safe_tmp;
   if (upload(d_owner, owner_e) != PP_OK) return bail(nullptr);
   if (d_safe_tmp.reserve((size_t)std::max(ne, 1)) != hipSuccess) return bail("pp_picpart_create: out of device memory");
@@ -609,6 +618,431 @@ int pp_picpart_reduce(pp_picpart* p, int edim, int op, int dtype, int nvals, voi
   if (rc) return rc;
   if ((rc = pp_picpart_reduce_mid(p))) return rc;
   return pp_picpart_reduce_end(p);
+}
+
+}  // extern "C"
+
+// ================================================================================================
+// Particle load balancer: pumipic::ParticleBalancer, src/pumipic_lb.hpp / pumipic_lb.cpp.
+//
+// sbars (ParticleBalancer::ParticleBalancer, pumipic_lb.cpp:23-135): for every element the set of parts
+// on which it is safe, its owner included.  The reference collects them with three rounds of messages
+// (safe flags of the core to the owners, the owners' sbar lists to the buffers, global numbers); here
+// every rank derives all of them from the Input, as the PICpart construction does -- the set itself (a
+// 64-bit mask, bit r = part r) is the job-wide name of an sbar, and the sorted list of distinct masks is
+// the same on every rank without a message.
+// Weights (addWeights, pumipic_lb.hpp:138-237): device histogram of the particles that stay here by the
+// sbar of their new element, and of the particles already sent elsewhere by destination.
+// Balance: the reference calls EnGPar (engpar::balanceWeights, pumipic_lb.cpp:495-531; scorec/EnGPar >=
+// 1.1.0, not in the reference tree).  Here: one all-gather of the weight rows, then every rank runs the
+// same integer diffusion on the job-wide table (`diffuse` below; DESIGN.md states the scheme) -- at node
+// scale the table is a few hundred numbers, replicating the computation costs less than a second exchange.
+// Selection (selectParticles, :239-299): per sbar a list of (target, amount) consumed particle by
+// particle, particles whose new element is outside the core first; a particle that finds an exhausted
+// entry moves on to the next one (the reference lets it go and relies on further iterations), so the
+// plan's amounts are met exactly.
+namespace {
+
+__global__ void k_bal_weights(int capacity, const unsigned char* __restrict__ mask, const int* __restrict__ new_elems,
+                              const int* __restrict__ new_procs, int rank, int nranks, int ne,
+                              const int* __restrict__ sbar_me, int* __restrict__ w, int* __restrict__ forced,
+                              int* __restrict__ bad) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity || !mask[pid]) return;
+  const int pr = new_procs[pid];
+  if (pr == rank) {
+    const int e = new_elems[pid];
+    if (e == -1) return;
+    if (e < 0 || e >= ne) {
+      *bad = 1;
+      return;
+    }
+    const int s = sbar_me[e];
+    if (s >= 0) atomicAdd(&w[s], 1);
+  } else if (pr >= 0 && pr < nranks) {
+    atomicAdd(&forced[pr], 1);
+  } else {
+    *bad = 1;
+  }
+}
+// plan of this rank: entries [off[s], off[s+1]) of sbar s, each (target, remaining); cursor[s] walks them
+__global__ void k_bal_select(int capacity, const unsigned char* __restrict__ mask, const int* __restrict__ new_elems,
+                             int* __restrict__ new_procs, int rank, const int* __restrict__ owners,
+                             const int* __restrict__ sbar_me, int noncore_only, const int* __restrict__ off,
+                             int* __restrict__ cursor, const int* __restrict__ target, int* __restrict__ remaining) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity || !mask[pid]) return;
+  if (new_procs[pid] != rank) return;
+  const int e = new_elems[pid];
+  if (e < 0) return;
+  if (noncore_only && owners[e] == rank) return;
+  const int s = sbar_me[e];
+  if (s < 0) return;
+  const int end = off[s + 1];
+  for (;;) {
+    const int idx = __hip_atomic_load(&cursor[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (idx >= end) return;
+    if (atomicSub(&remaining[idx], 1) > 0) {
+      new_procs[pid] = target[idx];
+      return;
+    }
+    atomicMax(&cursor[s], idx + 1);
+  }
+}
+
+struct PlanEntry {
+  int sbar, target;
+  long long amount;
+};
+
+// The diffusion (what EnGPar's balanceWeights does in the reference): rounds until max weight <= tol x
+// average or nothing moves (at most 50).  In a round, on the weights the round started with, every part p
+// above the average visits its lighter neighbours q (parts it shares an sbar with, p still holding weight
+// there) in increasing rank and asks each for step_factor x (W_p - W_q) / (number of lighter neighbours)
+// particles, taken from the shared sbars in increasing order, never more than p held in an sbar at the
+// start of the call (a one-step migration cannot forward what is still to arrive).
+void diffuse(const std::vector<unsigned long long>& masks, const std::vector<std::vector<long long>>& weights,
+             const std::vector<long long>& forced_in, double tol, double step_factor,
+             std::vector<std::vector<PlanEntry>>& plan, std::vector<long long>& W) {
+  const int P = (int)weights.size(), M = (int)masks.size();
+  std::vector<std::vector<long long>> avail = weights;
+  W.assign((size_t)P, 0);
+  long long total = 0;
+  for (int r = 0; r < P; ++r) {
+    for (int i = 0; i < M; ++i) W[(size_t)r] += avail[(size_t)r][(size_t)i];
+    W[(size_t)r] += forced_in[(size_t)r];
+    total += W[(size_t)r];
+  }
+  std::vector<std::vector<long long>> send((size_t)P, std::vector<long long>((size_t)M * P, 0));
+  for (int it = 0; it < 50; ++it) {
+    const long long mx = *std::max_element(W.begin(), W.end());
+    if ((double)mx * P <= tol * (double)total) break;
+    const std::vector<long long> W0 = W;
+    bool moved = false;
+    for (int p = 0; p < P; ++p) {
+      if (W0[(size_t)p] * P <= total) continue;
+      std::vector<int> nbrs;
+      for (int q = 0; q < P; ++q) {
+        if (q == p || !(W0[(size_t)q] < W0[(size_t)p])) continue;
+        bool shared = false;
+        for (int i = 0; i < M && !shared; ++i)
+          shared = avail[(size_t)p][(size_t)i] > 0 && ((masks[(size_t)i] >> q) & 1ull) && ((masks[(size_t)i] >> p) & 1ull);
+        if (shared) nbrs.push_back(q);
+      }
+      for (int q : nbrs) {
+        long long want = (long long)(step_factor * (double)(W0[(size_t)p] - W0[(size_t)q]) / (double)nbrs.size());
+        for (int i = 0; i < M && want > 0; ++i) {
+          if (!(((masks[(size_t)i] >> q) & 1ull) && ((masks[(size_t)i] >> p) & 1ull))) continue;
+          const long long t = std::min(avail[(size_t)p][(size_t)i], want);
+          if (t <= 0) continue;
+          avail[(size_t)p][(size_t)i] -= t;
+          send[(size_t)p][(size_t)i * P + q] += t;
+          W[(size_t)p] -= t;
+          W[(size_t)q] += t;
+          want -= t;
+          moved = true;
+        }
+      }
+    }
+    if (!moved) break;
+  }
+  plan.assign((size_t)P, {});
+  for (int p = 0; p < P; ++p)
+    for (int i = 0; i < M; ++i)
+      for (int q = 0; q < P; ++q)
+        if (send[(size_t)p][(size_t)i * P + q] > 0) plan[(size_t)p].push_back({i, q, send[(size_t)p][(size_t)i * P + q]});
+}
+
+}  // namespace
+
+struct pp_balancer {
+  pp_picpart* part = nullptr;
+  int rank = 0, nranks = 1;
+  std::vector<unsigned long long> masks;  // sorted distinct sbars of the job
+  std::vector<int> sbar_ids;              // per element of the part: index into masks (getSbarIDs)
+  std::vector<int> sbar_me;               // the same, -1 where the sbar does not contain this rank
+  pp::DevBuf d_sbar_ids, d_sbar_me, d_w, d_forced, d_bad, d_off, d_cursor, d_target, d_remaining;
+  std::vector<PlanEntry> last_plan;
+  std::vector<long long> last_W;
+  // between _begin and _end
+  bool active = false;
+  int mode = 0;  // 1: repartition (structure), 2: partition (array)
+  const pp_ps* ps = nullptr;
+  const int* new_elems = nullptr;
+  int* new_procs = nullptr;
+  std::vector<long long> row;  // this rank's weights per sbar, then forced per destination
+  std::vector<int> ppe;
+};
+
+namespace pp {
+// local world mailbox (pp_comm.hip)
+int local_mail_put(LocalWorld* w, int rank, const void* data, size_t bytes);
+int local_mail_get_all(LocalWorld* w, int rank, size_t bytes, void* out);
+}  // namespace pp
+
+namespace {
+
+int gather_rows(pp_balancer* b, std::vector<long long>& table, bool put, bool get) {
+  pp_comm* c = b->part->comm;
+  const int P = b->nranks;
+  const size_t n = b->row.size(), bytes = n * sizeof(long long);
+  if (!c || c->kind == 0 || P == 1) {
+    table = b->row;
+    return PP_OK;
+  }
+  if (c->kind == 4) {
+    if (put) {
+      int rc = pp::local_mail_put(c->world.get(), c->rank, b->row.data(), bytes);
+      if (rc) return rc;
+    }
+    if (get) {
+      table.resize(n * (size_t)P);
+      return pp::local_mail_get_all(c->world.get(), c->rank, bytes, table.data());
+    }
+    return PP_OK;
+  }
+  if (!get) return PP_OK;  // real transports exchange in one step, at `end`
+  table.resize(n * (size_t)P);
+  return pp_comm_allgather_host(c, b->row.data(), table.data(), (int)bytes);
+}
+
+int plan_from_table(pp_balancer* b, const std::vector<long long>& table, double tol, double step_factor) {
+  const int P = b->nranks, M = (int)b->masks.size();
+  std::vector<std::vector<long long>> w((size_t)P, std::vector<long long>((size_t)M, 0));
+  std::vector<long long> forced((size_t)P, 0);
+  for (int r = 0; r < P; ++r) {
+    const long long* row = table.data() + (size_t)r * (M + P);
+    for (int i = 0; i < M; ++i) w[(size_t)r][(size_t)i] = row[i];
+    for (int q = 0; q < P; ++q) forced[(size_t)q] += row[M + q];
+  }
+  std::vector<std::vector<PlanEntry>> plan;
+  diffuse(b->masks, w, forced, tol, step_factor, plan, b->last_W);
+  b->last_plan = plan[(size_t)b->rank];
+  return PP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+pp_balancer* pp_balancer_create(pp_picpart* part) {
+  if (!part) {
+    pp::set_error("pp_balancer_create: null part");
+    return nullptr;
+  }
+  const int P = part->nranks, rank = part->rank;
+  if (P > 64) {
+    pp::set_error("pp_balancer_create: an sbar is a 64-bit set of parts -- more than 64 ranks are not supported");
+    return nullptr;
+  }
+  const pp_mesh* full = part->full;
+  const int ne = full->nelems;
+  pp_balancer* b = new pp_balancer();
+  b->part = part;
+  b->rank = rank;
+  b->nranks = P;
+  // every rank's safe zone and buffer from the Input (Mesh::Mesh(Input&) for rank q)
+  std::vector<unsigned long long> mask((size_t)ne);
+  for (int e = 0; e < ne; ++e) mask[(size_t)e] = 1ull << part->owner_e[(size_t)e];
+  pp::DevBuf d_owner, d_safe_tmp;
+  if (upload(d_owner, part->owner_e) != PP_OK || d_safe_tmp.reserve((size_t)std::max(ne, 1)) != hipSuccess) {
+    delete b;
+    return nullptr;
+  }
+  std::vector<int> has_part;
+  std::vector<unsigned char> is_safe;
+  for (int q = 0; q < P; ++q) {
+    if (safe_and_buffer(full, part->bridge_dim, q, P, part->buffer_method, part->safe_method, part->buffer_layers,
+                        part->safe_layers, d_owner.as<int>(), d_safe_tmp, has_part, &is_safe) != PP_OK) {
+      delete b;
+      return nullptr;
+    }
+    for (int e = 0; e < ne; ++e)
+      if (is_safe[(size_t)e] && has_part[(size_t)part->owner_e[(size_t)e]]) mask[(size_t)e] |= 1ull << q;
+  }
+  b->masks = mask;
+  std::sort(b->masks.begin(), b->masks.end());
+  b->masks.erase(std::unique(b->masks.begin(), b->masks.end()), b->masks.end());
+  const DimData& de = part->D[1];
+  b->sbar_ids.resize((size_t)de.nents);
+  b->sbar_me.resize((size_t)de.nents);
+  for (int i = 0; i < de.nents; ++i) {
+    const unsigned long long m = mask[(size_t)de.full_ids[(size_t)i]];
+    const int idx = (int)(std::lower_bound(b->masks.begin(), b->masks.end(), m) - b->masks.begin());
+    b->sbar_ids[(size_t)i] = idx;
+    b->sbar_me[(size_t)i] = ((m >> rank) & 1ull) ? idx : -1;
+  }
+  if (upload(b->d_sbar_ids, b->sbar_ids) != PP_OK || upload(b->d_sbar_me, b->sbar_me) != PP_OK) {
+    delete b;
+    return nullptr;
+  }
+  return b;
+}
+
+int pp_balancer_destroy(pp_balancer* b) {
+  delete b;
+  return PP_OK;
+}
+
+int pp_balancer_num_sbars(const pp_balancer* b) { return b ? (int)b->masks.size() : 0; }
+
+int pp_balancer_sbars(const pp_balancer* b, unsigned long long* masks_host) {
+  PP_REQUIRE(b && masks_host, "pp_balancer_sbars: null argument");
+  std::copy(b->masks.begin(), b->masks.end(), masks_host);
+  return PP_OK;
+}
+
+const int* pp_balancer_sbar_ids_dev(const pp_balancer* b, size_t* n) {
+  if (!b) return nullptr;
+  if (n) *n = b->sbar_ids.size();
+  return b->d_sbar_ids.as<int>();
+}
+
+int pp_balancer_repartition_begin(pp_balancer* b, const pp_ps* ps, const int* new_elems_dev, int* new_procs_dev) {
+  pp::Range rg_("balancer_weights");
+  PP_REQUIRE(b && ps && (ps->capacity == 0 || (new_elems_dev && new_procs_dev)), "pp_balancer_repartition: null argument");
+  PP_REQUIRE(!b->active, "pp_balancer_repartition: the previous call is still between its two halves");
+  PP_REQUIRE(ps->num_elems == b->part->D[1].nents, "pp_balancer_repartition: the structure is not over the part's elements");
+  hipStream_t st = pp::stream();
+  const int M = (int)b->masks.size(), P = b->nranks;
+  PP_HIP_CHECK(b->d_w.reserve(sizeof(int) * (size_t)(M + P + 1)));
+  PP_HIP_CHECK(hipMemsetAsync(b->d_w.p, 0, sizeof(int) * (size_t)(M + P + 1), st));
+  int* w = b->d_w.as<int>();
+  if (ps->capacity > 0 && ps->num_ptcls > 0)
+    k_bal_weights<<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, ps->d_mask.as<unsigned char>(), new_elems_dev,
+                                                            new_procs_dev, b->rank, P, ps->num_elems,
+                                                            b->d_sbar_me.as<int>(), w, w + M, w + M + P);
+  PP_LAUNCH_CHECK();
+  std::vector<int> h((size_t)(M + P + 1));
+  PP_HIP_CHECK(hipMemcpyAsync(h.data(), w, sizeof(int) * h.size(), hipMemcpyDeviceToHost, st));
+  PP_HIP_CHECK(hipStreamSynchronize(st));
+  PP_REQUIRE(!h[(size_t)(M + P)], "pp_balancer_repartition: a new element or new process is out of range");
+  b->row.assign(h.begin(), h.begin() + (M + P));
+  b->mode = 1;
+  b->ps = ps;
+  b->new_elems = new_elems_dev;
+  b->new_procs = new_procs_dev;
+  std::vector<long long> none;
+  int rc = gather_rows(b, none, true, false);
+  if (rc) return rc;
+  b->active = true;
+  return PP_OK;
+}
+
+int pp_balancer_repartition_end(pp_balancer* b, double tol, double step_factor) {
+  pp::Range rg_("balancer_select");
+  PP_REQUIRE(b && b->active && b->mode == 1, "pp_balancer_repartition_end: call pp_balancer_repartition_begin first");
+  b->active = false;
+  if (b->nranks == 1) return PP_OK;  // pumipic_lb.hpp:356-357
+  std::vector<long long> table;
+  int rc = gather_rows(b, table, false, true);
+  if (rc) return rc;
+  if ((rc = plan_from_table(b, table, tol, step_factor))) return rc;
+  if (b->last_plan.empty()) return PP_OK;
+  const int M = (int)b->masks.size();
+  std::vector<int> off((size_t)M + 1, 0), target, remaining;
+  for (const PlanEntry& e : b->last_plan) ++off[(size_t)e.sbar + 1];
+  for (int i = 0; i < M; ++i) off[(size_t)i + 1] += off[(size_t)i];
+  for (const PlanEntry& e : b->last_plan) {  // already sbar-major, target ascending
+    target.push_back(e.target);
+    remaining.push_back((int)e.amount);
+  }
+  std::vector<int> cursor(off.begin(), off.end() - 1);
+  if ((rc = upload(b->d_off, off)) || (rc = upload(b->d_cursor, cursor)) || (rc = upload(b->d_target, target)) ||
+      (rc = upload(b->d_remaining, remaining)))
+    return rc;
+  hipStream_t st = pp::stream();
+  const pp_ps* ps = b->ps;
+  for (int pass = 0; pass < 2; ++pass)  // selectNonCoreParticles, then selectParticles (:262-298)
+    if (ps->capacity > 0)
+      k_bal_select<<<grid_for(ps->capacity), kBlock, 0, st>>>(
+          ps->capacity, ps->d_mask.as<unsigned char>(), b->new_elems, b->new_procs, b->rank,
+          b->part->D[1].d_owners.as<int>(), b->d_sbar_me.as<int>(), pass == 0 ? 1 : 0, b->d_off.as<int>(),
+          b->d_cursor.as<int>(), b->d_target.as<int>(), b->d_remaining.as<int>());
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+int pp_balancer_repartition(pp_balancer* b, const pp_ps* ps, double tol, const int* new_elems_dev, int* new_procs_dev,
+                            double step_factor) {
+  PP_REQUIRE(b, "pp_balancer_repartition: null balancer");
+  PP_REQUIRE(!b->part->comm || b->part->comm->kind != 4,
+             "pp_balancer_repartition: virtual ranks of one process call _begin on every rank, then _end");
+  int rc = pp_balancer_repartition_begin(b, ps, new_elems_dev, new_procs_dev);
+  if (rc) return rc;
+  return pp_balancer_repartition_end(b, tol, step_factor);
+}
+
+int pp_balancer_partition_begin(pp_balancer* b, const int* ptcls_per_elem_host) {
+  PP_REQUIRE(b && ptcls_per_elem_host, "pp_balancer_partition: null argument");
+  PP_REQUIRE(!b->active, "pp_balancer_partition: the previous call is still between its two halves");
+  const int M = (int)b->masks.size(), P = b->nranks, ne = b->part->D[1].nents;
+  b->ppe.assign(ptcls_per_elem_host, ptcls_per_elem_host + ne);
+  b->row.assign((size_t)(M + P), 0);
+  for (int e = 0; e < ne; ++e) {  // addWeights(picparts, ptcls_per_elem), pumipic_lb.hpp:219-237
+    PP_REQUIRE(b->ppe[(size_t)e] >= 0, "pp_balancer_partition: negative particle count");
+    if (b->sbar_me[(size_t)e] >= 0) b->row[(size_t)b->sbar_me[(size_t)e]] += b->ppe[(size_t)e];
+  }
+  b->mode = 2;
+  std::vector<long long> none;
+  int rc = gather_rows(b, none, true, false);
+  if (rc) return rc;
+  b->active = true;
+  return PP_OK;
+}
+
+int pp_balancer_partition_end(pp_balancer* b, double tol, double step_factor, int* new_procs_host) {
+  PP_REQUIRE(b && b->active && b->mode == 2 && new_procs_host, "pp_balancer_partition_end: call pp_balancer_partition_begin first");
+  b->active = false;
+  long long np = 0;
+  for (int n : b->ppe) np += n;
+  for (long long i = 0; i < np; ++i) new_procs_host[i] = b->rank;  // setSelf :392-395
+  if (b->nranks == 1) return PP_OK;
+  std::vector<long long> table;
+  int rc = gather_rows(b, table, false, true);
+  if (rc) return rc;
+  if ((rc = plan_from_table(b, table, tol, step_factor))) return rc;
+  // selectParticles over the array (:379-...): elements in order, the plan's entries of the element's sbar in order
+  const int M = (int)b->masks.size();
+  std::vector<std::vector<std::pair<int, long long>>> per((size_t)M);
+  for (const PlanEntry& e : b->last_plan) per[(size_t)e.sbar].push_back({e.target, e.amount});
+  std::vector<size_t> cur((size_t)M, 0);
+  long long at = 0;
+  for (size_t e = 0; e < b->ppe.size(); ++e) {
+    const int s = b->sbar_me[e];
+    for (int i = 0; i < b->ppe[e]; ++i, ++at) {
+      if (s < 0) continue;
+      auto& lst = per[(size_t)s];
+      while (cur[(size_t)s] < lst.size() && lst[cur[(size_t)s]].second <= 0) ++cur[(size_t)s];
+      if (cur[(size_t)s] >= lst.size()) continue;
+      new_procs_host[at] = lst[cur[(size_t)s]].first;
+      --lst[cur[(size_t)s]].second;
+    }
+  }
+  return PP_OK;
+}
+
+int pp_balancer_partition(pp_balancer* b, const int* ptcls_per_elem_host, double tol, double step_factor,
+                          int* new_procs_host) {
+  PP_REQUIRE(b, "pp_balancer_partition: null balancer");
+  PP_REQUIRE(!b->part->comm || b->part->comm->kind != 4,
+             "pp_balancer_partition: virtual ranks of one process call _begin on every rank, then _end");
+  int rc = pp_balancer_partition_begin(b, ptcls_per_elem_host);
+  if (rc) return rc;
+  return pp_balancer_partition_end(b, tol, step_factor, new_procs_host);
+}
+
+int pp_balancer_last_plan(const pp_balancer* b, int* n, int* sbar_host, int* target_host, long long* amount_host,
+                          long long* weights_after_host) {
+  PP_REQUIRE(b && n, "pp_balancer_last_plan: null argument");
+  *n = (int)b->last_plan.size();
+  for (size_t i = 0; i < b->last_plan.size(); ++i) {
+    if (sbar_host) sbar_host[i] = b->last_plan[i].sbar;
+    if (target_host) target_host[i] = b->last_plan[i].target;
+    if (amount_host) amount_host[i] = b->last_plan[i].amount;
+  }
+  if (weights_after_host) std::copy(b->last_W.begin(), b->last_W.end(), weights_after_host);
+  return PP_OK;
 }
 
 }  // extern "C"

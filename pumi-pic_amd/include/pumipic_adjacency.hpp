@@ -362,6 +362,56 @@ inline Input::Input(Mesh& mesh, Ownership rule, const std::vector<int>& partitio
   if (safeMethod == MINIMUM) safeBFSLayers = 0;
 }
 
+// ---------------------------------------------------------------- pumipic::ParticleBalancer
+// (src/pumipic_lb.hpp:33-118) over pp_balancer: sbars, weights and the selection as in the reference, the
+// balancing step (EnGPar there) is the library's diffusion on the gathered weight table.
+class ParticleBalancer {
+ public:
+  explicit ParticleBalancer(Mesh& picparts) {
+    if (!picparts.picpart()) {
+      fprintf(stderr, "ParticleBalancer: the mesh must be built from a pumipic::Input\n");
+      exit(EXIT_FAILURE);
+    }
+    b_ = pp_balancer_create(picparts.picpart());
+    if (!b_) pp_check(PP_EHIP, "ParticleBalancer");
+  }
+  ~ParticleBalancer() {
+    if (b_) (void)pp_balancer_destroy(b_);
+  }
+  ParticleBalancer(const ParticleBalancer&) = delete;
+  ParticleBalancer& operator=(const ParticleBalancer&) = delete;
+  // new_procs of the particles that move is rewritten; particles pushed out of the safe zone must already
+  // carry their owner (pumipic_lb.hpp:41-52)
+  template <class PS>
+  void repartition(Mesh& /*picparts*/, PS* ptcls, double tol, View<int> new_elems, View<int> new_procs,
+                   double step_factor = 0.3) {
+    pp_check(pp_balancer_repartition(b_, ptcls->handle(), tol, new_elems.data(), new_procs.data(), step_factor),
+             "ParticleBalancer::repartition");
+  }
+  // array form (:54-64): particles per element of the part -> new process per particle, element-major
+  View<int> partition(Mesh& /*picparts*/, View<int> ptcls_per_elem, double tol, double step_factor = 0.3,
+                      int /*selection_iterations*/ = 5) {
+    pp_check(pp_sync(), "ParticleBalancer::partition");
+    std::vector<int> ppe = ptcls_per_elem.to_host();
+    long long np = 0;
+    for (int n : ppe) np += n;
+    std::vector<int> procs((size_t)std::max<long long>(np, 1));
+    pp_check(pp_balancer_partition(b_, ppe.data(), tol, step_factor, procs.data()), "ParticleBalancer::partition");
+    View<int> out((size_t)np);
+    out.from_host(procs.data());
+    return out;
+  }
+  o::LOs getSbarIDs(Mesh& /*picparts*/) const {
+    size_t n = 0;
+    const int* p = pp_balancer_sbar_ids_dev(b_, &n);
+    return View<int>::wrap(const_cast<int*>(p), n);
+  }
+  pp_balancer* handle() const { return b_; }
+
+ private:
+  pp_balancer* b_ = nullptr;
+};
+
 // ---------------------------------------------------------------- timing (support/ppTiming.hpp:34-75)
 struct TimingEntry {
   double time = 0, prebarrier = 0;

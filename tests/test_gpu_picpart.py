@@ -284,3 +284,115 @@ def test_cpp_driver_comm_array(synth, capi, tmp_path, world):
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, (so[-1500:], se[-1500:])
         assert "all checks passed" in so
+
+
+# ---------------------------------------------------------------- particle load balancer
+def _lb_setup(ppo, synth, capi, opp, which, P=4):
+    dim, c, e, k, owner = _mesh_arrays(synth, which)
+    owner = slab_owners(c, e, P, axis=0 if which != 1 else 1)
+    mo = ppo.Mesh(dim, c, e, k)
+    O = opp.PicParts(mo, owner, P, opp.BFS, opp.FULL, buffer_layers=3, safe_layers=1)  # test/test_lb.cpp:61-63
+    mg = capi.Mesh(dim, c, e, k)
+    comms = capi.Comm.local(P)
+    parts = [capi.PicPart(mg, owner, comms[r], capi.PART_BFS, capi.PART_FULL, 0, 3, 1) for r in range(P)]
+    return dim, O, opp.Balancer(O), parts, [capi.Balancer(p) for p in parts], comms
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_balancer_partition_matches_oracle(ppo, synth, capi, opp, which):
+    """ParticleBalancer::partition on an array of particles per element (test_lb.cpp:77-133): sbars and plan
+    equal the oracle's, the destinations carry exactly the plan's amounts, imbalance <= 1.3 afterwards"""
+    dim, O, ob, parts, bals, comms = _lb_setup(ppo, synth, capi, opp, which)
+    P = len(parts)
+    for r, (p, b) in enumerate(zip(parts, bals)):
+        assert b.sbars().tolist() == ob.masks
+        assert np.array_equal(b.sbar_ids(), ob.part_index[r])
+    ppe = [np.full(p.nents[dim], (r + 1) * 50, dtype=np.int32) for r, p in enumerate(parts)]
+    plan_o, W_o, w_o = ob.partition_counts(ppe, 1.05)
+    for b, x in zip(bals, ppe):
+        b.partition_begin(x)
+    procs = [b.partition_end(1.05) for b in bals]
+    arriving = np.zeros(P, dtype=np.int64)
+    for r, (b, pr) in enumerate(zip(bals, procs)):
+        plan, W = b.last_plan()
+        assert plan == plan_o[r] and W.tolist() == W_o
+        sent = np.bincount(pr[pr != r], minlength=P)
+        want = np.zeros(P, dtype=np.int64)
+        for _, q, t in plan:
+            want[q] += t
+        assert np.array_equal(sent, want)
+        # a particle only goes where its element is safe
+        elem_of = np.repeat(np.arange(parts[r].nents[dim]), ppe[r])
+        moved = pr != r
+        m = np.asarray(ob.masks, dtype=np.uint64)[ob.part_index[r][elem_of[moved]]]
+        assert np.all((m >> pr[moved].astype(np.uint64)) & np.uint64(1))
+        arriving += np.bincount(pr, minlength=P)
+    assert arriving.max() * P / arriving.sum() <= 1.3
+    for c in comms:
+        c.destroy()
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_balancer_repartition_then_migrate(ppo, synth, capi, opp, which):
+    """testBalancePS (test_lb.cpp:135-213): 100 particles per element on the even ranks only; two rounds of
+    repartition + migrate; imbalance <= 1.5 at the end, no particle lost, every particle in an element that
+    is safe on (or owned by) the rank that holds it; weights and plan equal the oracle's each round"""
+    dim, O, ob, parts, bals, comms = _lb_setup(ppo, synth, capi, opp, which)
+    P = len(parts)
+    members = [(np.int32, 1)]
+    structs = []
+    for r, p in enumerate(parts):
+        ne = p.nents[dim]
+        ppe = np.full(ne, 100 if r % 2 == 0 else 0, dtype=np.int32)
+        elem = np.repeat(np.arange(ne, dtype=np.int32), ppe)
+        ids = (np.arange(len(elem), dtype=np.int32) + r * 10_000_000)[None, :]
+        structs.append(capi.PS.scs(members, ne, ppe, C_=32, gids=p.array(capi.PART_GIDS, dim),
+                                   particle_elements=elem, particle_info=[ids]))
+    total = sum(s.nPtcls() for s in structs)
+    g2l = []
+    for p in parts:  # gid -> element of the part (the reference's UnorderedMap, SCS_migrate.h:181-187)
+        t = np.full(O.mesh.nelems, -1, dtype=np.int32)
+        t[p.array(capi.PART_GIDS, dim)] = np.arange(p.nents[dim], dtype=np.int32)
+        g2l.append(capi.DevArray.from_host(t))
+    for rnd in range(2):
+        ne_d, np_d, host = [], [], []
+        for r, (p, s) in enumerate(zip(parts, structs)):
+            se, mk = s.slot_info()
+            safe = p.array(capi.PART_SAFE).astype(bool)
+            own = p.array(capi.PART_OWNERS, dim)
+            live = mk.astype(bool)
+            ne_h = np.where(live, se, -1).astype(np.int32)
+            np_h = np.full(len(se), r, dtype=np.int32)
+            np_h[live] = np.where(safe[se[live]], r, own[se[live]])  # balancePtcls' setValues (:215-243)
+            ne_d.append(capi.DevArray.from_host(ne_h))
+            np_d.append(capi.DevArray.from_host(np_h))
+            host.append((ne_h[live], np_h[live]))
+        w_o, f_o = ob.weights([h[0] for h in host], [h[1] for h in host])
+        plan_o, W_o = ob.plan(w_o, f_o, 1.05)
+        for b, s, a, c in zip(bals, structs, ne_d, np_d):
+            b.repartition_begin(s, a, c)
+        for b in bals:
+            b.repartition_end(1.05)
+        for r, b in enumerate(bals):
+            plan, W = b.last_plan()
+            assert plan == plan_o[r] and W.tolist() == W_o
+            after = np_d[r].to_host()
+            live = structs[r].slot_info()[1].astype(bool)
+            sent = np.bincount(after[live][after[live] != r], minlength=P)
+            want = np.bincount(host[r][1][host[r][1] != r], minlength=P).astype(np.int64)
+            for _, q, t in plan:
+                want[q] += t
+            assert np.array_equal(sent, want)
+        for r, (s, a, c, cm) in enumerate(zip(structs, ne_d, np_d, comms)):
+            capi.migrate_begin(s, a, c, cm, gid2lid=g2l[r])
+        for s, cm in zip(structs, comms):
+            capi.migrate_end(s, cm)
+    counts = np.array([s.nPtcls() for s in structs])
+    assert counts.sum() == total
+    assert counts.max() * P / counts.sum() <= 1.5
+    for r, (p, s) in enumerate(zip(parts, structs)):
+        se, mk = s.slot_info()
+        e = se[mk.astype(bool)]
+        assert np.all(p.array(capi.PART_SAFE).astype(bool)[e] | (p.array(capi.PART_OWNERS, dim)[e] == r))
+    for c in comms:
+        c.destroy()

@@ -145,3 +145,36 @@ def test_bfs_buffers_match_c_restatement(ppo, synth, opp):
         assert np.array_equal(safe, safe_c.astype(np.int32)) and np.array_equal(part, part_c)
         inward = opp.bfs_safe_inward(mesh.vert2elems_off, mesh.vert2elems, owner, rank, 1, part)
         assert np.array_equal(inward, ppo.bfs_safe_inward(mesh, owner, rank, 1, part).astype(np.int32))
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_balancer_sbars_and_diffusion(ppo, synth, opp, which):
+    """sbars + the diffusion step (the stand-in for EnGPar's balanceWeights): the plan conserves particles,
+    sends only through sbars both parts belong to and only what the sender holds, and meets what
+    test/test_lb.cpp asks of `partition` ((rank + 1) x 50 particles per element -> imbalance <= 1.3)."""
+    mesh, owner = meshes(ppo, synth)[which]
+    P = 4
+    pic = opp.PicParts(mesh, owner, P, opp.BFS, opp.FULL, buffer_layers=3, safe_layers=1)  # test_lb.cpp:61-63
+    bal = opp.Balancer(pic)
+    dim = mesh.dim
+    for p in pic.parts:  # an element's sbar holds its owner, and a part only where the element is safe there
+        m = bal.full_mask[p.full_ids[dim]]
+        assert np.all((m >> np.uint64(p.rank)) & np.uint64(1) == (p.safe.astype(bool) | (p.owners[dim] == p.rank)))
+    ppe = [np.full(p.nents[dim], (p.rank + 1) * 50, dtype=np.int64) for p in pic.parts]
+    plan, W, w = bal.partition_counts(ppe, 1.05)
+    assert sum(W) == int(w.sum())
+    sent = np.zeros((P, len(bal.masks)), dtype=np.int64)
+    for r, pl in enumerate(plan):
+        for i, q, t in pl:
+            assert t > 0 and q != r and (bal.masks[i] >> q) & 1 and (bal.masks[i] >> r) & 1
+            sent[r, i] += t
+    assert np.all(sent <= w)
+    total = sum(int(x.sum()) for x in ppe)
+    uncounted = [int(x.sum()) - int(w[r].sum()) for r, x in enumerate(ppe)]  # particles in sbars without the rank
+    after = [W[r] + uncounted[r] for r in range(P)]
+    assert max(after) * P / total <= 1.3
+    # one rank holds everything (test_lb.cpp:160-178 has 100 per element on even ranks only)
+    ppe = [np.full(p.nents[dim], 100 if p.rank % 2 == 0 else 0, dtype=np.int64) for p in pic.parts]
+    plan, W, w = bal.partition_counts(ppe, 1.05)
+    before = [int(x.sum()) for x in ppe]
+    assert max(W) < max(before) and sum(W) == int(w.sum())
