@@ -396,3 +396,81 @@ def test_balancer_repartition_then_migrate(ppo, synth, capi, opp, which):
         assert np.all(p.array(capi.PART_SAFE).astype(bool)[e] | (p.array(capi.PART_OWNERS, dim)[e] == r))
     for c in comms:
         c.destroy()
+
+
+# ---------------------------------------------------------------- the time step on BFS parts (no full-mesh replica)
+@pytest.mark.parametrize("dim", [2, 3])
+def test_step_on_bfs_parts_matches_the_full_mesh_run(ppo, synth, capi, opp, dim):
+    """Push + search + migrate on PICparts with a 1-layer buffer and a 1- / 0-layer safe zone -- every rank holds
+    only its part's mesh; elements travel as global ids (globalIds(dim) of the part, a gid -> local table on
+    the receiver).  The union of the ranks equals the single-structure run on the full mesh, particle by
+    particle (element, position, phase bit-exact), and every particle sits in an element that is safe on its
+    rank.  Vertex counts summed through the owners (reduceCommArray) equal the full-mesh histogram."""
+    import common
+    from test_gpu_comm import _oracle_run, _population, _snapshot, _step, H, K, D, NSTEPS
+    pop = _population(synth, dim)
+    P = 5  # (a buffer is made of whole parts: with 3 slabs the middle one would hold the full mesh)
+    owner = slab_owners(pop["coords"], pop["e2v"], P, axis=0 if dim == 2 else 2)  # (the push turns in the R-z plane)
+    ne_full = len(pop["e2v"])
+    ref = _oracle_run(ppo, pop, NSTEPS)
+    mg = capi.Mesh(dim, pop["coords"], pop["e2v"], pop["cls"])
+    comms = capi.Comm.local(P)
+    # (the coarse torus: one vertex layer around a slab is most of the mesh -- its safe zone is the core)
+    parts = [capi.PicPart(mg, owner, comms[r], capi.PART_BFS, capi.PART_BFS, 0, 1, 1 if dim == 2 else 0)
+             for r in range(P)]
+    assert sum(p.nents[dim] < ne_full for p in parts) >= 4 and not any(p.is_full_mesh for p in parts)
+    structs, tables, safes, owners_d, full_ids = [], [], [], [], []
+    for r, p in enumerate(parts):
+        ent = p.array(capi.PART_ENT_IDS, dim)
+        mine = owner[pop["elem"]] == r
+        elem = ent[pop["elem"][mine]].astype(np.int32)
+        assert elem.size == 0 or elem.min() >= 0
+        info = [np.ascontiguousarray(a[..., mine]) for a in pop["info"]]
+        gids = p.array(capi.PART_GIDS, dim)
+        structs.append(capi.PS.scs(capi.PARTICLE_XGCM, p.nents[dim], np.bincount(elem, minlength=p.nents[dim]).astype(np.int32),
+                                   gids=gids, particle_elements=elem, particle_info=info))
+        t = np.full(ne_full, -1, dtype=np.int32)
+        t[gids] = np.arange(p.nents[dim], dtype=np.int32)
+        tables.append(capi.DevArray.from_host(t))
+        safes.append(capi.DevArray.from_host(p.array(capi.PART_SAFE)))
+        owners_d.append(capi.DevArray.from_host(p.array(capi.PART_OWNERS, dim)))
+        full_ids.append(p.array(capi.PART_FULL_IDS, dim))
+    moved = 0
+    for step in range(NSTEPS):
+        keep = []
+        for r, (p, ps) in enumerate(zip(parts, structs)):
+            ids = capi.DevArray.from_host(np.full(max(ps.capacity(), 1), -1, dtype=np.int32))
+            _step(capi, p.mesh, ps, dim, 6.0, ids)
+            ne_d, np_d = capi.set_unsafe_procs(ps, ids, safes[r], owners_d[r], r)
+            capi.migrate_begin(ps, ne_d, np_d, comms[r], commit=True, gid2lid=tables[r])
+            keep.append((ids, ne_d, np_d))
+        for r, ps in enumerate(structs):
+            ns, nr = capi.migrate_end(ps, comms[r])
+            moved += ns
+    assert moved > 0
+    snaps = []
+    for r, (p, ps) in enumerate(zip(parts, structs)):
+        pid, se, x, ph = _snapshot(ps)
+        assert np.all(p.array(capi.PART_SAFE).astype(bool)[se])
+        snaps.append((pid, full_ids[r][se], x, ph))
+    io, eo, xo, pho, _ = ref
+    ids = np.concatenate([s[0] for s in snaps])
+    order = np.argsort(ids)
+    assert np.array_equal(ids[order], io)
+    assert np.array_equal(np.concatenate([s[1] for s in snaps])[order], eo)
+    assert np.array_equal(np.concatenate([s[2] for s in snaps], axis=1)[:, order], xo)
+    assert np.array_equal(np.concatenate([s[3] for s in snaps])[order], pho)
+    # per-vertex particle counts: every rank adds its own particles on its part, SUM through the owners
+    cnt_full = np.zeros(mg.nverts)
+    np.add.at(cnt_full, pop["e2v"][eo].ravel(), 1.0)
+    arrs = []
+    for r, (p, ps) in enumerate(zip(parts, structs)):
+        se = _snapshot(ps)[1]
+        w = np.zeros(p.nents[0])
+        np.add.at(w, p.mesh.array(1).reshape(-1, dim + 1)[se].ravel(), 1.0)
+        arrs.append(capi.DevArray.from_host(w))
+    capi.picpart_reduce_all(parts, 0, capi.OP_SUM, arrs)
+    for p, a in zip(parts, arrs):
+        assert np.array_equal(a.to_host(), cnt_full[p.array(capi.PART_FULL_IDS, 0)])
+    for c in comms:
+        c.destroy()
