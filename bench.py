@@ -108,12 +108,17 @@ def build_workload(pp, capi, name, nptcl, rank, world, deg, remainder="last", me
                 ppe=ppe, elem=elem, info=info, rank=rank, world=world)
 
 
-def build_c4(pp, capi, ne, nptcl, rank, structure):
-    """ps_combo160 set-up (performance_tests/ps_combo160.cpp:60-130): uniform distribution (strategy
-    1, fixed seed instead of the wall clock), Sell-64-ne (sigma = ne, V = 1024) or CSR."""
-    rng = np.random.default_rng(rank)
-    elems = np.sort(rng.integers(0, ne, size=nptcl).astype(np.int32))
-    ppe = np.bincount(elems, minlength=ne).astype(np.int32)
+def build_c4(pp, capi, ne, nptcl, rank, structure, dist=1):
+    """ps_combo160 set-up (performance_tests/ps_combo160.cpp:60-130): distribution strategy `dist` (1 uniform,
+    2 gaussian, 3 exponential, 4 GITRm approximation; fixed seed instead of the wall clock), Sell-64-ne
+    (sigma = ne, V = 1024) or CSR."""
+    if dist == 1:
+        rng = np.random.default_rng(rank)
+        elems = np.sort(rng.integers(0, ne, size=nptcl).astype(np.int32))
+        ppe = np.bincount(elems, minlength=ne).astype(np.int32)
+    else:
+        ppe, elems = pp.synth.distribute_particles(ne, nptcl, dist, seed=rank)
+        elems = np.sort(elems)
     info = [np.zeros((17, nptcl)), np.zeros((4, nptcl), dtype=np.int32),
             np.arange(nptcl, dtype=np.int64)[None, :]]
     if structure == "scs":
@@ -122,13 +127,16 @@ def build_c4(pp, capi, ne, nptcl, rank, structure):
     else:
         ps = capi.PS.csr(capi.PERF160, ne, ppe, particle_elements=elems, particle_info=info)
     parent = capi.DevArray.from_host(np.sqrt(np.arange(ne, dtype=np.float64)) * np.arange(ne))
-    return dict(ps=ps, parent=parent, ne=ne, dim=0, rank=rank, world=1,
-                label="ps_combo160 %s, %d elements" % ("Sell-64-ne" if structure == "scs" else "CSR", ne))
+    names = {1: "uniform", 2: "gaussian", 3: "exponential", 4: "GITRm-like"}
+    return dict(ps=ps, parent=parent, ne=ne, dim=0, rank=rank, world=1, dist=dist,
+                label="ps_combo160 %s, %d elements, %s distribution" % (
+                    "Sell-64-ne" if structure == "scs" else "CSR", ne, names[dist]))
 
 
 class StepperC4:
     def __init__(self, capi, w):
         self.capi, self.ps, self.parent = capi, w["ps"], w["parent"]
+        self.dist = w.get("dist", 1)
         self.new_elems = None
         self.kernel_ms = []
         self.round = 0
@@ -147,7 +155,8 @@ class StepperC4:
         if timed:
             e1.record()
             self.kernel_ms.append((e0, e1))
-        self.new_elems = capi.redistribute_particles(self.ps, 0.5, seed=self.round, out=self.new_elems)
+        self.new_elems = capi.redistribute_particles(self.ps, 0.5, seed=self.round, out=self.new_elems,
+                                                     strat=self.dist)
         self.round += 1
         self.ps.rebuild(self.new_elems)
         cap = max(self.ps.capacity(), 1)
@@ -465,6 +474,9 @@ def main():
                     help="c5: breadth-first element layers around the owned block that are still safe "
                          "(0 = BASELINE's rule: a particle migrates as soon as it leaves its owner's block)")
     ap.add_argument("--c4-elems", type=int, default=1_000_000, help="c4: number of elements")
+    ap.add_argument("--c4-dist", type=int, default=1, choices=[1, 2, 3, 4],
+                    help="c4: distribution strategy of the population and of the redistribution "
+                         "(Distribute.cpp: 1 uniform, 2 gaussian, 3 exponential, 4 GITRm approximation)")
     ap.add_argument("--structure", default="scs", choices=["scs", "csr"], help="c4: particle structure")
     ap.add_argument("--particles", type=int, default=None,
                     help="particles per GPU (default 10 M; c5 on several GPUs 32 M; c4 1 M)")
@@ -521,7 +533,7 @@ def main():
     capi.init(local_rank)  # raises when the HIP library / GPU is missing: no CPU fallback
 
     if a.workload == "c4":
-        w = build_c4(pp, capi, a.c4_elems, a.particles, rank, a.structure)
+        w = build_c4(pp, capi, a.c4_elems, a.particles, rank, a.structure, a.c4_dist)
         st = StepperC4(capi, w)
     else:
         w = build_workload(pp, capi, a.workload, a.particles, rank, world, a.deg, a.remainder, a.mesh,

@@ -212,6 +212,13 @@ int pp_update_positions(pp_ps* ps, int m_x, int m_xtgt);
  * not reproducible), so tests can check them against the oracle. */
 int pp_redistribute_particles(const pp_ps* ps, double percent_moved, unsigned long long seed,
                               int* new_elems_dev);
+/* the same with the re-draw following distribution strategy `strat` of distribute_particles
+ * (particle_structs/test/Distribute.cpp:76-253, what ps_combo160 passes, :210): 1 uniform, 2 gaussian(ne/2,
+ * ne/8) truncated and clamped, 3 the uniform -> exponential conversion (lambda 1), 4 the GITRm approximation
+ * (85 % of the movers into the first 2/5 of the elements).  Strategy 0 (even) is an index rule, not a draw:
+ * not served.  Draws are hashes of (seed, slot); normal variates are Irwin-Hall sums (exact in double). */
+int pp_redistribute_particles_dist(const pp_ps* ps, int strat, double percent_moved, unsigned long long seed,
+                                   int* new_elems_dev);
 /* pseudoPush performance_tests/ps_combo160.cpp:158-178 (members double[17], int[4], long) */
 int pp_pseudo_push160(pp_ps* ps, const double* parent_elm_data_dev);
 

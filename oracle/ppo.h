@@ -222,6 +222,9 @@ void ppo_bfs_safe_inward(const ppo_mesh* mesh, int bridge_dim, int rank, int saf
 void ppo_set_threads(int n);
 int ppo_max_threads(void);
 /* particle_structs/test/Distribute.h:28-89 (uniform strategy, counter-based draws) */
+void ppo_exponential_tables(int ne, int* exp_start, int* exp_end);
+void ppo_redistribute_particles_dist(const ppo_ps* ps, int strat, double percent_moved, unsigned long long seed,
+                                     int* new_elems);
 void ppo_redistribute_particles(const ppo_ps* ps, double percent_moved, unsigned long long seed,
                                 int* new_elems);
 /* wall geometry: src/pumipic_adjacency.hpp:812-1009.  abc = 3 vertices x 3 coordinates; *reg is

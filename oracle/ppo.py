@@ -667,6 +667,16 @@ def redistribute_particles(ps, percent_moved, seed=0):
     return out[:ps.capacity()]
 
 
+def redistribute_particles_dist(ps, strat, percent_moved, seed=0):
+    """redistribute_particles with distribution strategy 1-4 (Distribute.h:28-89 + Distribute.cpp) -> new_elems"""
+    out = np.full(max(ps.capacity(), 1), -1, dtype=np.int32)
+    L = lib()
+    L.ppo_redistribute_particles_dist.argtypes = [C.POINTER(_PsS), C.c_int, C.c_double, C.c_ulonglong, c_int_p]
+    L.ppo_redistribute_particles_dist.restype = None
+    L.ppo_redistribute_particles_dist(ps.p, int(strat), float(percent_moved), int(seed), _ip(out))
+    return out[:ps.capacity()]
+
+
 def set_threads(n):
     """OpenMP threads of the per-particle loops (results do not depend on it)."""
     lib().ppo_set_threads(int(n))

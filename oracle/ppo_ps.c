@@ -15,6 +15,7 @@
 #include <string.h>
 #include <stdio.h>
 #include "ppo.h"
+#include <math.h>
 
 static void* xcalloc(size_t n, size_t s) {
   void* p = calloc(n ? n : 1, s ? s : 1);
@@ -764,6 +765,89 @@ void ppo_redistribute_particles(const ppo_ps* ps, double percent_moved, unsigned
   }
   free(slot_elem);
   free(slot_mask);
+}
+
+/* redistribute_particles with the re-draw following a distribution strategy (Distribute.h:28-89 calls
+ * distribute_particles(numElems, total, strat, ...), particle_structs/test/Distribute.cpp:60-253, device
+ * forms): 1 uniform, 2 gaussian(ne/2, ne/8) truncated to int and clamped (:106-121), 3 the uniform ->
+ * exponential conversion (:155-199, lambda = 1), 4 the GITRm approximation (85 % into the first 2/5 of the
+ * elements, :230-253).  The reference draws from a Kokkos pool; here every draw is a hash of (seed, slot):
+ *   h1 = splitmix64(seed ^ (2 slot + 1)),  g_j = splitmix64(h1 + j)
+ * and a normal variate is the Irwin-Hall sum of twelve 32-bit uniforms (sum / 2^32 - 6: exact in double), so
+ * that host and device produce the same ids.  Strategy 3's two logarithms per element are evaluated ONCE on
+ * the host into the tables exp_start / exp_end (ne ints each) -- the same tables feed the device. */
+void ppo_exponential_tables(int ne, int* exp_start, int* exp_end) {
+  const double lambda = 1.0f;
+  const double freq_max = log(1.0 / ne) * -1;
+  for (int uni = 0; uni < ne; ++uni) {
+    const double percent_elem = ((double)uni) / ne;
+    const double temp = -1 / lambda * log(1 - percent_elem) / freq_max;
+    const double temp_next = -1 / lambda * log(1 - percent_elem - 1.0 / ne) / freq_max;
+    const double a = temp * ne, b = temp_next * ne;
+    /* (the last element's end is log(0) = inf, and the reference never uses it: uni == ne-1 -> element 0) */
+    exp_start[uni] = (a >= 0 && a < 2147483647.0) ? (int)a : 2147483647;
+    exp_end[uni] = (b >= 0 && b < 2147483647.0) ? (int)b : 2147483647;
+  }
+}
+int ppo_draw_element(int strat, int ne, unsigned long long h1, const int* exp_start, const int* exp_end) {
+  if (strat == 2) {
+    double S = 0;
+    for (int j = 0; j < 12; ++j) S += (double)(splitmix64(h1 + (unsigned long long)j) >> 32);
+    const double z = S * (1.0 / 4294967296.0) - 6.0;
+    const double v = ne / 2.0 + (ne / 8.0) * z;
+    int elem = (int)v;
+    if (elem < 0) elem = 0;
+    if (elem >= ne) elem = ne - 1;
+    return elem;
+  }
+  if (strat == 3) {
+    const int uni = (int)(h1 % (unsigned long long)ne);
+    if (uni == ne - 1) return 0;
+    const int start = exp_start[uni];
+    const long long length = (long long)exp_end[uni] - start;
+    int inside = 0;
+    if (length > 1) inside = (int)(splitmix64(h1 + 1ull) % (unsigned long long)length);
+    long long e = (long long)start + inside;
+    if (e >= ne) e = (long long)(splitmix64(h1 + 2ull) % (unsigned long long)ne);
+    return (int)e;
+  }
+  if (strat == 4) {
+    const int cutoff = 2 * ne / 5;
+    const double u = (double)(splitmix64(h1 + 1ull) >> 11) * (1.0 / 9007199254740992.0);
+    const unsigned long long g = splitmix64(h1 + 2ull);
+    if (u < 0.85 && cutoff > 0) return (int)(g % (unsigned long long)cutoff);
+    return cutoff + (int)(g % (unsigned long long)(ne - cutoff));
+  }
+  return (int)(h1 % (unsigned long long)ne);
+}
+void ppo_redistribute_particles_dist(const ppo_ps* ps, int strat, double percent_moved, unsigned long long seed,
+                                     int* new_elems) {
+  const int cap = ps->capacity, ne = ps->num_elems;
+  int* slot_elem = (int*)xcalloc((size_t)cap + 1, sizeof(int));
+  unsigned char* slot_mask = (unsigned char*)xcalloc((size_t)cap + 1, 1);
+  int *es = NULL, *ee = NULL;
+  if (strat == 3) {
+    es = (int*)xcalloc((size_t)ne + 1, sizeof(int));
+    ee = (int*)xcalloc((size_t)ne + 1, sizeof(int));
+    ppo_exponential_tables(ne, es, ee);
+  }
+  ppo_ps_slot_info(ps, slot_elem, slot_mask);
+  for (int pid = 0; pid < cap; ++pid) {
+    if (slot_elem[pid] < 0 || !slot_mask[pid]) {
+      new_elems[pid] = -1;
+      continue;
+    }
+    const unsigned long long h0 = splitmix64(seed ^ (2ull * (unsigned long long)pid));
+    const double prob = (double)(h0 >> 11) * (1.0 / 9007199254740992.0);
+    if (prob <= percent_moved)
+      new_elems[pid] = ppo_draw_element(strat, ne, splitmix64(seed ^ (2ull * (unsigned long long)pid + 1ull)), es, ee);
+    else
+      new_elems[pid] = slot_elem[pid];
+  }
+  free(slot_elem);
+  free(slot_mask);
+  free(es);
+  free(ee);
 }
 
 /* SellCSigma.h:465-524 */

@@ -106,6 +106,7 @@ SYMBOLS = {
     "pp_trace_set_new_element": (_I, [_V, _V, _V, _V, _V, c_int_p]),
     "pp_trace_not_found": (_I, [_V, _V, _V, c_int_p]),
     "pp_redistribute_particles": (_I, [_V, C.c_double, C.c_ulonglong, _V]),
+    "pp_redistribute_particles_dist": (_I, [_V, _I, C.c_double, C.c_ulonglong, _V]),
     "pp_boris_push_fields": (_I, [_V, _V, _I, _I, _I, _V, _V, _V] + [C.c_double] * 4 + [_I, _I, _I, C.c_double, c_int_p]),
     "pp_bfs_buffer_layers": (_I, [_V, _I, _I, _I, _I, _I, _V, _V, c_int_p]),
     "pp_bfs_safe_inward": (_I, [_V, _I, _I, _I, _I, _V, c_int_p, _V]),
@@ -805,12 +806,13 @@ def trace_particle_through_mesh(mesh, ps, func=None, elem_ids=None, require_inte
     return st
 
 
-def redistribute_particles(ps, percent_moved, seed=0, out=None):
-    """redistribute_particles (Distribute.h:28-89), uniform strategy -> DevArray new_elems."""
+def redistribute_particles(ps, percent_moved, seed=0, out=None, strat=1):
+    """redistribute_particles (Distribute.h:28-89): strategy 1 uniform (default), 2 gaussian, 3 exponential,
+    4 GITRm approximation -> DevArray new_elems."""
     cap = max(ps.capacity(), 1)
     if out is None or out.n < cap:
         out = DevArray(cap, np.int32)
-    check(lib().pp_redistribute_particles(ps.p, float(percent_moved), int(seed), out.ptr))
+    check(lib().pp_redistribute_particles_dist(ps.p, int(strat), float(percent_moved), int(seed), out.ptr))
     return out
 
 

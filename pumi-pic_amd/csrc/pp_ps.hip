@@ -1641,9 +1641,46 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
   z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
   return z ^ (z >> 31);
 }
+// The re-draw by distribution strategy (distribute_particles' device forms, Distribute.cpp:76-253): 1 uniform,
+// 2 gaussian(ne/2, ne/8) truncated and clamped, 3 uniform -> exponential conversion (its two logarithms per
+// element come from host-made tables), 4 GITRm approximation.  Extra draws are g_j = splitmix64(h1 + j); the
+// normal variate is the Irwin-Hall sum of twelve 32-bit uniforms (exact in double: host and device agree).
+__device__ __forceinline__ int draw_element(int strat, int ne, unsigned long long h1, const int* __restrict__ exp_start,
+                                            const int* __restrict__ exp_end) {
+  if (strat == 2) {
+    double S = 0;
+    for (int j = 0; j < 12; ++j) S += (double)(splitmix64(h1 + (unsigned long long)j) >> 32);
+    const double z = S * (1.0 / 4294967296.0) - 6.0;
+    const double v = ne / 2.0 + (ne / 8.0) * z;
+    int elem = (int)v;
+    if (elem < 0) elem = 0;
+    if (elem >= ne) elem = ne - 1;
+    return elem;
+  }
+  if (strat == 3) {
+    const int uni = (int)(h1 % (unsigned long long)ne);
+    if (uni == ne - 1) return 0;
+    const int start = exp_start[uni];
+    const long long length = (long long)exp_end[uni] - start;
+    int inside = 0;
+    if (length > 1) inside = (int)(splitmix64(h1 + 1ull) % (unsigned long long)length);
+    long long e = (long long)start + inside;
+    if (e >= ne) e = (long long)(splitmix64(h1 + 2ull) % (unsigned long long)ne);
+    return (int)e;
+  }
+  if (strat == 4) {
+    const int cutoff = 2 * ne / 5;
+    const double u = (double)(splitmix64(h1 + 1ull) >> 11) * (1.0 / 9007199254740992.0);
+    const unsigned long long g = splitmix64(h1 + 2ull);
+    if (u < 0.85 && cutoff > 0) return (int)(g % (unsigned long long)cutoff);
+    return cutoff + (int)(g % (unsigned long long)(ne - cutoff));
+  }
+  return (int)(h1 % (unsigned long long)ne);
+}
 __global__ void k_redistribute(int capacity, const unsigned char* __restrict__ mask,
                                const int* __restrict__ slot_elem, int ne, double percent_moved,
-                               unsigned long long seed, int* __restrict__ new_elems) {
+                               unsigned long long seed, int* __restrict__ new_elems, int strat,
+                               const int* __restrict__ exp_start, const int* __restrict__ exp_end) {
   const int pid = blockIdx.x * blockDim.x + threadIdx.x;
   if (pid >= capacity) return;
   const int e = slot_elem[pid];
@@ -1655,7 +1692,7 @@ __global__ void k_redistribute(int capacity, const unsigned char* __restrict__ m
   const double prob = (double)(h0 >> 11) * (1.0 / 9007199254740992.0);
   if (prob <= percent_moved) {
     const unsigned long long h1 = splitmix64(seed ^ (2ull * (unsigned long long)pid + 1ull));
-    new_elems[pid] = (int)(h1 % (unsigned long long)ne);
+    new_elems[pid] = draw_element(strat, ne, h1, exp_start, exp_end);
   } else {
     new_elems[pid] = e;
   }
@@ -3725,16 +3762,47 @@ int pp_ps_get_pids(const pp_ps* ps, int* offsets_dev, int* pids_dev) {
   return PP_OK;
 }
 
-int pp_redistribute_particles(const pp_ps* ps, double percent_moved, unsigned long long seed,
-                              int* new_elems_dev) {
+int pp_redistribute_particles_dist(const pp_ps* ps, int strat, double percent_moved, unsigned long long seed,
+                                   int* new_elems_dev) {
   PP_REQUIRE(ps && new_elems_dev, "pp_redistribute_particles: null argument");
   PP_REQUIRE(percent_moved >= 0 && percent_moved <= 1, "pp_redistribute_particles: percentMoved in [0,1]");
+  PP_REQUIRE(strat >= 1 && strat <= 4,
+             "pp_redistribute_particles: strategy 1 (uniform), 2 (gaussian), 3 (exponential) or 4 (GITRm approximation)");
   if (ps->capacity == 0) return PP_OK;
+  const int ne = ps->num_elems;
+  const int *es = nullptr, *ee = nullptr;
+  if (strat == 3) {  // the conversion's logarithms, once per element count, on the host (Distribute.cpp:155-173)
+    static pp::DevBuf tab;
+    static int tab_ne = -1;
+    if (tab_ne != ne) {
+      std::vector<int> h((size_t)2 * std::max(ne, 1));
+      const double lambda = 1.0f;
+      const double freq_max = std::log(1.0 / ne) * -1;
+      for (int uni = 0; uni < ne; ++uni) {
+        const double percent_elem = ((double)uni) / ne;
+        const double temp = -1 / lambda * std::log(1 - percent_elem) / freq_max;
+        const double temp_next = -1 / lambda * std::log(1 - percent_elem - 1.0 / ne) / freq_max;
+        const double a = temp * ne, b = temp_next * ne;
+        h[(size_t)uni] = (a >= 0 && a < 2147483647.0) ? (int)a : 2147483647;
+        h[(size_t)ne + uni] = (b >= 0 && b < 2147483647.0) ? (int)b : 2147483647;
+      }
+      PP_HIP_CHECK(hipStreamSynchronize(pp::stream()));
+      PP_HIP_CHECK(tab.reserve(sizeof(int) * h.size()));
+      PP_HIP_CHECK(hipMemcpy(tab.p, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice));
+      tab_ne = ne;
+    }
+    es = tab.as<int>();
+    ee = es + ne;
+  }
   k_redistribute<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
-      ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), ps->num_elems,
-      percent_moved, seed, new_elems_dev);
+      ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), ne, percent_moved, seed,
+      new_elems_dev, strat, es, ee);
   PP_LAUNCH_CHECK();
   return PP_OK;
+}
+int pp_redistribute_particles(const pp_ps* ps, double percent_moved, unsigned long long seed,
+                              int* new_elems_dev) {
+  return pp_redistribute_particles_dist(ps, 1, percent_moved, seed, new_elems_dev);
 }
 
 int pp_ps_metrics(const pp_ps* ps, int* padded_cells, int* padded_slices, int* empty_rows) {

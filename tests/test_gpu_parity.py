@@ -1182,6 +1182,34 @@ def test_ps_combo160_rounds_exact(ppo, capi, kind):
                                   np.bincount(sg[mg_.astype(bool)], minlength=ne))
 
 
+@pytest.mark.parametrize("strat", [2, 3, 4])
+def test_redistribute_by_strategy_matches_oracle(ppo, synth, capi, strat):
+    """pp_redistribute_particles_dist: the re-draw of distribute_particles' strategies (Distribute.cpp:76-253) --
+    gaussian, exponential conversion, GITRm approximation -- slot for slot equal to the oracle, on the
+    initial layout of a population drawn with the same strategy, SCS and CSR"""
+    ne, npt = 5000, 60000
+    ppe, elems = synth.distribute_particles(ne, npt, strat, seed=1)
+    elems = np.sort(elems)
+    info = [np.zeros((17, npt)), np.zeros((4, npt), dtype=np.int32), np.arange(npt, dtype=np.int64)[None, :]]
+    po = ppo.PS.scs(ppo.PERF160, ne, ppe, C_max=64, sigma=ne, V=1024, particle_elements=elems, particle_info=info)
+    pg = capi.PS.scs(capi.PERF160, ne, ppe, C_=64, sigma=ne, V=1024, particle_elements=elems, particle_info=info)
+    for pm, seed in ((0.5, 3), (1.0, 4), (0.0, 5)):
+        a = ppo.redistribute_particles_dist(po, strat, pm, seed=seed)
+        b = capi.redistribute_particles(pg, pm, seed=seed, strat=strat).to_host()[:pg.capacity()]
+        assert np.array_equal(a, b)
+    pc = capi.PS.csr(capi.PERF160, ne, ppe, particle_elements=elems, particle_info=info)
+    oc = ppo.PS.csr(ppo.PERF160, ne, ppe, particle_elements=elems, particle_info=info)
+    assert np.array_equal(ppo.redistribute_particles_dist(oc, strat, 0.5, seed=8),
+                          capi.redistribute_particles(pc, 0.5, seed=8, strat=strat).to_host()[:pc.capacity()])
+    # rounds of redistribute + rebuild keep every particle and follow the distribution
+    for rnd in range(3):
+        ng = capi.redistribute_particles(pg, 0.5, seed=20 + rnd, strat=strat)
+        pg.rebuild(ng)
+        assert pg.nPtcls() == npt
+    with pytest.raises(capi.PPError):
+        capi.redistribute_particles(pg, 0.5, strat=0)
+
+
 @pytest.mark.parametrize("cyl", [False, True])
 def test_boris_push_with_gathered_fields(ppo, synth, capi, cyl):
     """pp_boris_push_fields (gather + pushBoris in one pass): E from a 3-dof vertex

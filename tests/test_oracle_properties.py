@@ -640,3 +640,29 @@ def test_element_ids_do_not_depend_on_the_sincos_variant(ppo, synth, dim):
         assert np.abs(xa - xb).max() <= 1e-13              # positions: 1 ulp of sincos, accumulated
         moved += 1
     assert moved == 20 and len(runs[0][-1][0]) > 0.9 * n
+
+
+def test_redistribute_particles_by_strategy(ppo):
+    """redistribute_particles with the re-draw of distribute_particles' strategies (Distribute.cpp:76-253):
+    2 gaussian(ne/2, ne/8), 3 exponential conversion, 4 GITRm approximation; strategy 1 is the uniform call"""
+    ne = 20000
+    ppe = np.full(ne, 5, dtype=np.int32)
+    elem = np.repeat(np.arange(ne, dtype=np.int32), ppe)
+    n = len(elem)
+    ps = ppo.PS.scs(ppo.PARTICLE_PUSH, ne, ppe, C_max=32, particle_elements=elem,
+                    particle_info=[np.zeros((3, n)), np.zeros((3, n)), np.arange(n, dtype=np.int32)])
+    se, mk = ps.slot_info()
+    live = mk.astype(bool)
+    assert np.array_equal(ppo.redistribute_particles_dist(ps, 1, 0.4, seed=9), ppo.redistribute_particles(ps, 0.4, seed=9))
+    for strat in (2, 3, 4):
+        a = ppo.redistribute_particles_dist(ps, strat, 1.0, seed=5)
+        assert np.all(a[~live] == -1) and a[live].min() >= 0 and a[live].max() < ne
+        assert np.array_equal(a, ppo.redistribute_particles_dist(ps, strat, 1.0, seed=5))
+        half = ppo.redistribute_particles_dist(ps, strat, 0.5, seed=5)[live]
+        assert abs((half != se[live]).mean() - 0.5) < 0.02
+    g = ppo.redistribute_particles_dist(ps, 2, 1.0, seed=5)[live]
+    assert abs(g.mean() / ne - 0.5) < 0.01 and abs(g.std() / ne - 0.125) < 0.005
+    x = ppo.redistribute_particles_dist(ps, 3, 1.0, seed=5)[live]
+    assert x.mean() / ne < 0.15 and (x < ne // 2).mean() > 0.95      # mass near element 0
+    t = ppo.redistribute_particles_dist(ps, 4, 1.0, seed=5)[live]
+    assert abs((t < 2 * ne // 5).mean() - 0.85) < 0.01
