@@ -131,6 +131,8 @@ class PicParts:
         self.mesh, self.comm_size = mesh, comm_size
         dim = mesh.dim
         owner = np.asarray(elem_owner, dtype=np.int32)
+        if buffer_method == NONE:  # pumipic_input.cpp:96-100: "bufferMethod given as NONE, setting to MINIMUM"
+            buffer_method = MINIMUM
         if buffer_method == MINIMUM:
             buffer_layers = 0
         if safe_method == MINIMUM:

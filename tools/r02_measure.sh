@@ -20,6 +20,10 @@ timeout 600 python bench.py --workload c4 > $O/bench_c4_1Me_1Mp_scs.json 2>/dev/
 timeout 600 python bench.py --workload c4 --structure csr --no-cpu-baseline > $O/bench_c4_1Me_1Mp_csr.json 2>/dev/null
 timeout 600 python bench.py --workload c4 --c4-elems 50000 --particles 50000000 --steps 10 --no-cpu-baseline > $O/bench_c4_50ke_50Mp_scs.json 2>/dev/null
 timeout 600 python bench.py --workload c4 --structure csr --c4-elems 50000 --particles 50000000 --steps 10 --no-cpu-baseline > $O/bench_c4_50ke_50Mp_csr.json 2>/dev/null
+for d in 2 3; do for st in scs csr; do
+timeout 900 python bench.py --workload c4 --structure $st --c4-dist $d --c4-elems 50000 --particles 50000000 --steps 10 --no-cpu-baseline > $O/bench_c4_50ke_50Mp_${st}_dist$d.json 2>/dev/null
+timeout 600 python bench.py --workload c4 --structure $st --c4-dist $d --no-cpu-baseline > $O/bench_c4_1Me_1Mp_${st}_dist$d.json 2>/dev/null
+done; done
 python bench.py --gpus 2 --steps 5 > $O/bench_gpus2_on_1gpu_box.txt 2>&1; echo "exit code $?" >> $O/bench_gpus2_on_1gpu_box.txt
 # ---- kernel statistics of the same commands
 cd /tmp; export TMPDIR=/tmp
@@ -34,6 +38,8 @@ kt c2 --workload c2
 kt 2dc3 --workload 2dc3
 kt c5_1m_32M --workload c5 --mesh 1m --particles 32000000 --steps 10
 kt c4 --workload c4 --c4-elems 50000 --particles 50000000 --steps 5 --warmup 2
+kt c4_1M --workload c4 --steps 30
+kt c4_1M_csr --workload c4 --structure csr --steps 30
 # ---- HBM traffic: FETCH_SIZE / WRITE_SIZE in separate passes, whole step for c3, the roofline kernels for c2
 export PP_BENCH_NO_COLD=1 PP_BENCH_PREWARM=0
 passw() { wl=$1; name=$2; shift 2
