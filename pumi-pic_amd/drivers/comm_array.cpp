@@ -1,5 +1,5 @@
 // The checks of the reference's test/test_comm_array.cpp (minOwnership, sumEntities, fullBufferTest,
-// the max reduction, the owned-element sum) written against the mirror: PICparts from a pumipic::Input,
+// the max reduction, the owned-element sum) and of test/test_lb.cpp's testBalanceArray written against the mirror: PICparts from a pumipic::Input,
 // comm arrays from createCommArray, Mesh::reduceCommArray through the owners (pp_picpart_reduce).  Runs as
 // one rank or as several rank processes (PP_COMM=tcp, RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
 //   comm_array <mesh.bin> <partition file: one owner per element> [buffer layers] [safe layers]
@@ -86,6 +86,30 @@ static bool fullBufferTest(p::Mesh& mesh, const std::vector<int>& owner, int dim
   return !anySet(fail) && picparts.isFullMesh() && picparts.nents(dim) == mesh.nents(dim);
 }
 
+// testBalanceArray of the reference's test/test_lb.cpp:77-133: (rank + 1) * 50 particles per element, one
+// ParticleBalancer::partition, the particles every rank would hold afterwards -> imbalance <= 1.3
+static bool balanceArray(p::Mesh& picparts, p::ParticleBalancer& balancer) {
+  const int rank = picparts.rank(), comm_size = picparts.num_ranks();
+  const o::LO ne = picparts.nelems();
+  const int per_elem = (rank + 1) * 50;
+  o::Write<o::LO> ptcls_per_elem((size_t)ne, per_elem);
+  auto new_procs = balancer.partition(picparts, ptcls_per_elem, 1.05);
+  o::Write<o::LO> send_ptcls((size_t)comm_size, 0);
+  o::parallel_for((o::LO)new_procs.size(), OMEGA_H_LAMBDA(o::LO ptcl) { atomicAdd(&send_ptcls[new_procs[ptcl]], 1); });
+  o::HostWrite<o::LO> send_host(send_ptcls);
+  std::vector<int64_t> per_rank((size_t)comm_size);
+  for (int i = 0; i < comm_size; ++i) per_rank[(size_t)i] = send_host[(size_t)i];
+  p::pp_check(pp_allreduce_sum_host_i64(picparts.comm(), per_rank.data(), comm_size), "allreduce");
+  int64_t total = 0, mx = 0;
+  for (int64_t v : per_rank) {
+    total += v;
+    mx = v > mx ? v : mx;
+  }
+  const double imb = mx / (total * 1.0 / comm_size);
+  if (!rank) fprintf(stderr, "Imbalance after balancing is %f\n", imb);
+  return comm_size == 1 || imb <= 1.3;
+}
+
 int main(int argc, char** argv) {
   if (argc < 3) {
     fprintf(stderr, "Usage: %s <mesh.bin> <partition filename> [buffer layers] [safe layers]\n", argv[0]);
@@ -163,6 +187,15 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < host_array.size(); ++i) success = success && host_array[i] == 1;
     if (!success) {
       fprintf(stderr, "Multielement comm operation failed on %d\n", rank);
+      ++fails;
+    }
+  }
+  {  // the balancer on parts with the reference test's Input (BFS buffer, FULL safe zone; test_lb.cpp:61-66)
+    p::Input lb_input(mesh, p::Input::PARTITION, owner, p::Input::BFS, p::Input::FULL);
+    p::Mesh lb_parts(lb_input);
+    p::ParticleBalancer balancer(lb_parts);
+    if (balancer.getSbarIDs(lb_parts).size() != (size_t)lb_parts.nelems() || !balanceArray(lb_parts, balancer)) {
+      fprintf(stderr, "balanceArray failed on %d\n", rank);
       ++fails;
     }
   }
