@@ -136,7 +136,18 @@ struct TcpStar {
       setsockopt(listen_fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
       sockaddr_in any = sa;
       any.sin_addr.s_addr = htonl(INADDR_ANY);
-      if (::bind(listen_fd, (sockaddr*)&any, sizeof(any)) != 0 || ::listen(listen_fd, nranks) != 0) {
+      // A peer that starts first may briefly hold the port itself: connecting to a port of the ephemeral range
+      // that nobody listens on yet can be given that very port as its source (a TCP self-connection); it
+      // notices and lets go (below), so the bind is retried for a few seconds before giving up.
+      const auto bind_end = std::chrono::steady_clock::now() + std::chrono::seconds(10);
+      while (::bind(listen_fd, (sockaddr*)&any, sizeof(any)) != 0) {
+        if (std::chrono::steady_clock::now() > bind_end) {
+          set_error("tcp bootstrap: rank 0 cannot listen on port " + std::to_string(port));
+          return PP_EHIP;
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));
+      }
+      if (::listen(listen_fd, nranks) != 0) {
         set_error("tcp bootstrap: rank 0 cannot listen on port " + std::to_string(port));
         return PP_EHIP;
       }
@@ -156,7 +167,13 @@ struct TcpStar {
       int fd = -1;
       while (true) {
         fd = ::socket(AF_INET, SOCK_STREAM, 0);
-        if (::connect(fd, (sockaddr*)&sa, sizeof(sa)) == 0) break;
+        if (::connect(fd, (sockaddr*)&sa, sizeof(sa)) == 0) {
+          sockaddr_in me{};
+          socklen_t len = sizeof(me);
+          const bool self = getsockname(fd, (sockaddr*)&me, &len) == 0 && me.sin_port == sa.sin_port &&
+                            me.sin_addr.s_addr == sa.sin_addr.s_addr;
+          if (!self) break;  // (connected to ourselves: rank 0 is not up yet -- release the port, try again)
+        }
         ::close(fd);
         fd = -1;
         if (std::chrono::steady_clock::now() > t_end) {

@@ -243,7 +243,7 @@ int reduce_phase(pp_picpart* p, int phase) {
   DimData& d = p->D[p->k];
   hipStream_t st = pp::stream();
   pp_comm* c = p->comm;
-  const int nv = p->nvals, P = p->nranks;
+  const int nv = p->nvals;
   const size_t es = sizeof(T);
   T* arr = (T*)p->array;
   const int p0 = d.poff[(size_t)p->rank];
@@ -302,7 +302,6 @@ int reduce_phase(pp_picpart* p, int phase) {
     k_part_unpack<T><<<grid_for((size_t)n), kBlock, 0, st>>>(n, nv, d.d_comm_index.as<int>(), p0, d.my_count,
                                                             p->d_mine.as<T>(), (const T*)d_recv, arr);
   PP_LAUNCH_CHECK();
-  (void)P;
   return PP_OK;
 }
 
