@@ -552,7 +552,10 @@ int pp_migrate_ptcls_begin(pp_ps* ps, int m_x, int m_xtgt, int* elem_ids_dev, co
  * by classification: pp_owner_by_classification first).  buffer_method / safe_method = Input::Method
  * (src/pumipic_input.hpp:33-39: PP_PART_FULL, _BFS, _MINIMUM, _NONE; a NONE buffer is MINIMUM),
  * bridge_dim 0 (vertices) or dim-1 (sides), *_layers = bufferBFSLayers / safeBFSLayers (MINIMUM: 0).
- * Entity dimensions served: 0 (vertices) and dim (elements) -- pp_mesh numbers no edges.
+ * Entity dimensions served: 0 (vertices), dim-1 (sides: edges of triangles, faces of tets) and dim (elements)
+ * -- pp_mesh numbers no edges of tets.  Vertices and elements of a part are the kept ones in full-mesh order
+ * (:181-194); its sides are numbered by the part's own pp_mesh (PP_MESH_SIDE2VERTS ...), PP_PART_FULL_IDS maps
+ * them to the full mesh.  What travels between ranks is defined on full-mesh ids.
  *
  * What the reference exchanges at construction (MPI_Ialltoall of boundary sizes, Isend/Irecv of the
  * boundary lids, :113-190) is recomputed locally instead: every rank holds the full mesh and the
@@ -577,7 +580,7 @@ int pp_picpart_destroy(pp_picpart* p);
 const pp_mesh* pp_picpart_mesh(const pp_picpart* p); /* Mesh::mesh() */
 /* isFullMesh, numBuffers(dim) (core parts held, self included), nents(0), nents(dim) */
 int pp_picpart_info(const pp_picpart* p, int* is_full_mesh, int* num_buffers, int* nverts, int* nelems);
-/* arrays of the part, entity dimension edim in {0, dim}.  which:
+/* arrays of the part, entity dimension edim in {0, dim-1, dim}.  which:
  *   PP_PART_GIDS (int64, globalIds)  PP_PART_OWNERS (int, entOwners)  PP_PART_RANK_LIDS (int, rankLocalIndex)
  *   PP_PART_COMM_INDEX (int, commArrayIndex)  PP_PART_FULL_IDS (int: part entity -> full-mesh entity)
  *   PP_PART_ENT_IDS (int, sized by the FULL mesh: full entity -> part entity, -1 = not in the part)

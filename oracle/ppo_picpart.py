@@ -21,7 +21,13 @@ Two places where the reference leaves the result open, and what is fixed here (a
     doesn't need to be consistent" (pumipic_comm.cpp:66-76): here in increasing picpart entity id;
   * the owner adds the fan-in contributions in arrival order (MPI_Waitany, :311-318): here in increasing
     rank, the owner's own value first.
-Entity dimensions: 0 (vertices) and dim (elements); the meshes of this repo carry no edge numbering.
+Entity dimensions: 0 (vertices), dim-1 (sides: edges of a triangle mesh, faces of a tet mesh) and dim
+(elements); the meshes of this repo number no edges of tets.  A part's vertices and elements are the kept
+ones in full-mesh order, as in the reference (:181-194).  Its SIDES are numbered by the part's own mesh
+(the mesh derives them from its elements -- `Mesh(part arrays)` here, pp_mesh_create in the library), not
+in full-mesh order as Omega_h's set_ents would leave them; `full_ids[dim-1]` maps them.  Everything that
+travels between ranks (global ids, the order inside a partially held part) is defined on full-mesh ids,
+so the difference stays local to the part.
 """
 import numpy as np
 
@@ -123,6 +129,17 @@ class Part:
     """one rank's PICpart (constructPICPart :120-275 + setupComm)"""
 
 
+def make_mesh(dim, coords, elem2verts, class_id):
+    """the oracle's mesh type (oracle/ppo.py), loaded lazily: derives the sides of a part's mesh"""
+    import os
+    import sys
+    if "ppo" not in sys.modules:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import pumipic_amd_loader
+        pumipic_amd_loader.load_oracle()
+    return sys.modules["ppo"].Mesh(dim, coords, elem2verts, class_id)
+
+
 class PicParts:
     def __init__(self, mesh, elem_owner, comm_size, buffer_method=FULL, safe_method=FULL, bridge_dim=0,
                  buffer_layers=3, safe_layers=1):
@@ -144,9 +161,11 @@ class PicParts:
         else:
             raise ValueError("bridge_dim must be 0 or dim-1")
         # ---- ownership and global numbering of the full mesh (constructPICPart :141-163)
-        self.owner = {0: define_owners(mesh.vert2elems_off, mesh.vert2elems, owner, comm_size), dim: owner}
+        self.owner = {0: define_owners(mesh.vert2elems_off, mesh.vert2elems, owner, comm_size), dim: owner,
+                      dim - 1: define_owners(mesh.side2elems_off, mesh.side2elems, owner, comm_size)}
+        self.dims = (0, dim - 1, dim)
         self.offsets, self.gids, self.rank_lids = {}, {}, {}
-        for d in (0, dim):
+        for d in self.dims:
             self.offsets[d], self.gids[d] = create_global_numbering(self.owner[d], comm_size)
             self.rank_lids[d] = rank_lid_numbering(self.owner[d], self.offsets[d], self.gids[d])
         self.parts = []
@@ -171,17 +190,29 @@ class PicParts:
             p.elem2verts = p.ent_ids[0][mesh.elem2verts[p.full_ids[dim]]]
             p.class_id = mesh.class_id[p.full_ids[dim]]
             p.safe = p.is_safe_full[p.full_ids[dim]].astype(np.int32)
-            p.owners = {d: self.owner[d][p.full_ids[d]] for d in (0, dim)}
-            p.gids = {d: self.gids[d][p.full_ids[d]] for d in (0, dim)}
-            p.rank_lids = {d: self.rank_lids[d][p.full_ids[d]] for d in (0, dim)}
-            p.nents = {d: len(p.full_ids[d]) for d in (0, dim)}
+            # sides: the part's own mesh numbers them; match part side <-> full side by their vertices
+            if p.is_full_mesh:
+                p.full_ids[dim - 1] = np.arange(mesh.nsides, dtype=np.int32)
+            else:
+                pm = make_mesh(dim, p.coords, p.elem2verts, p.class_id)
+                key = {tuple(sorted(v)): i for i, v in enumerate(mesh.side2verts.tolist())}
+                p.full_ids[dim - 1] = np.array(
+                    [key[tuple(sorted(p.full_ids[0][v].tolist()))] for v in np.asarray(pm.side2verts)], dtype=np.int32)
+                p.part_mesh = pm
+            ids = np.full(mesh.nsides, -1, dtype=np.int32)
+            ids[p.full_ids[dim - 1]] = np.arange(len(p.full_ids[dim - 1]), dtype=np.int32)
+            p.ent_ids[dim - 1] = ids
+            p.owners = {d: self.owner[d][p.full_ids[d]] for d in self.dims}
+            p.gids = {d: self.gids[d][p.full_ids[d]] for d in self.dims}
+            p.rank_lids = {d: self.rank_lids[d][p.full_ids[d]] for d in self.dims}
+            p.nents = {d: len(p.full_ids[d]) for d in self.dims}
             self.parts.append(p)
         for p in self.parts:
-            self._setup_comm(p, 0)
-            self._setup_comm(p, dim)
+            for d in self.dims:
+                self._setup_comm(p, d)
         for p in self.parts:  # what the owners receive (the MPI_Ialltoall + Isend/Irecv of :113-190)
             p.bounded_ent_ids, p.bounded_offset, p.boundary_parts, p.complete_from = {}, {}, {}, {}
-            for d in (0, dim):
+            for d in self.dims:
                 lists, off, bparts, comp = [], [0], [], []
                 for q in self.parts:
                     if q.rank == p.rank:
@@ -210,8 +241,9 @@ class PicParts:
         lids = (p.gids[d] - goff[own]).astype(np.int32)                                   # :43-49
         boundary_rlids = {}
         for r in range(cs):
-            if is_complete[r] == 1:  # renumberBoundaryLids :66-76, in increasing entity id
+            if is_complete[r] == 1:  # renumberBoundaryLids :66-76, in increasing full-mesh id
                 sel = np.flatnonzero(own == r)
+                sel = sel[np.argsort(p.full_ids[d][sel], kind="stable")]
                 lids[sel] = np.arange(len(sel), dtype=np.int32)
                 boundary_rlids[r] = p.rank_lids[d][sel].astype(np.int32)  # gatherBoundedEnts :127-137
         if not hasattr(p, "comm_index"):

@@ -1208,6 +1208,7 @@ class PicPart:
         self.nents = {0: nv.value, mesh.dim: ne.value}
         self.nranks = comm.size() if comm is not None else 1
         self.mesh = _PartMesh(lib().pp_picpart_mesh(self.p), self)
+        self.nents[mesh.dim - 1] = self.mesh.nsides  # sides: numbered by the part's own mesh
 
     def array(self, which, edim=0):
         cnt = C.c_size_t()

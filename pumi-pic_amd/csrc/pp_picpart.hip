@@ -8,6 +8,7 @@
 // The reduction is device work: pack into owner-major segments, one exchange of device buffers to the
 // owners (fan-in), a gather-form combine in rank order (no atomics), one exchange back (fan-out), unpack.
 #include <algorithm>
+#include <array>
 #include <cstring>
 #include <numeric>
 
@@ -117,7 +118,7 @@ struct pp_picpart {
   // the Input the part was built from (the balancer re-derives every rank's safe zone from it)
   std::vector<int> owner_e;
   int buffer_method = 0, safe_method = 0, bridge_dim = 0, buffer_layers = 0, safe_layers = 0;
-  DimData D[2];  // 0: vertices, 1: elements
+  DimData D[3];  // 0: vertices, 1: elements, 2: sides (dimension dim-1)
   std::vector<unsigned char> safe;
   pp::DevBuf d_safe;
   // reduction scratch and the state between the phases
@@ -132,7 +133,9 @@ namespace {
 DimData* dim_slot(pp_picpart* p, int edim) {
   if (edim == 0) return &p->D[0];
   if (edim == p->dim) return &p->D[1];
-  pp::set_error("PICpart: entity dimension must be 0 (vertices) or dim (elements) -- pp_mesh numbers no edges");
+  if (edim == p->dim - 1) return &p->D[2];
+  pp::set_error("PICpart: entity dimension must be 0 (vertices), dim-1 (sides) or dim (elements) -- pp_mesh "
+                "numbers no edges of tets");
   return nullptr;
 }
 const DimData* dim_slot(const pp_picpart* p, int edim) { return dim_slot(const_cast<pp_picpart*>(p), edim); }
@@ -173,18 +176,23 @@ void global_numbering(const std::vector<int>& owner, int P, std::vector<int>& go
   for (size_t i = 0; i < owner.size(); ++i) gid[i] = run[(size_t)owner[i]]++;
 }
 
-// the part's side of setupComm (pumipic_comm.cpp:11-111) for one entity dimension
-void setup_holder(DimData& d, int P, int rank, const std::vector<int>& owner_full, const std::vector<int64_t>& gid_full,
-                  const std::vector<char>& keep) {
-  d.nfull = (int)owner_full.size();
-  d.ent_ids.assign((size_t)d.nfull, -1);
-  d.full_ids.clear();
-  for (int i = 0; i < d.nfull; ++i)
-    if (keep[(size_t)i]) {
-      d.ent_ids[(size_t)i] = (int)d.full_ids.size();
-      d.full_ids.push_back(i);
-    }
+// entities of the part for one dimension: part id -> full id as given (vertices / elements: the kept ones in
+// full-mesh order, :181-194; sides: the order the part's own mesh derives)
+void set_entities(DimData& d, int nfull, std::vector<int> full_ids) {
+  d.nfull = nfull;
+  d.full_ids = std::move(full_ids);
   d.nents = (int)d.full_ids.size();
+  d.ent_ids.assign((size_t)nfull, -1);
+  for (int i = 0; i < d.nents; ++i) d.ent_ids[(size_t)d.full_ids[(size_t)i]] = i;
+}
+std::vector<int> kept_list(const std::vector<char>& keep) {
+  std::vector<int> ids;
+  for (int i = 0; i < (int)keep.size(); ++i)
+    if (keep[(size_t)i]) ids.push_back(i);
+  return ids;
+}
+// the part's side of setupComm (pumipic_comm.cpp:11-111) for one entity dimension
+void setup_holder(DimData& d, int P, int rank, const std::vector<int>& owner_full, const std::vector<int64_t>& gid_full) {
   d.owners.resize((size_t)d.nents);
   d.gids.resize((size_t)d.nents);
   d.rank_lids.resize((size_t)d.nents);
@@ -207,10 +215,15 @@ void setup_holder(DimData& d, int P, int rank, const std::vector<int>& owner_ful
     if (r != rank) d.send_counts[(size_t)r] = pdiff;
   }
   d.my_count = d.poff[(size_t)rank + 1] - d.poff[(size_t)rank];
-  // comm array index (:43-86): rank lid, renumbered in entity order for a partially held part
+  // comm array index (:43-86): rank lid, renumbered in increasing FULL-mesh id for a partially held part (what
+  // travels between ranks is defined on full-mesh ids: the owner lists the same entities in the same order)
+  std::vector<int> order((size_t)d.nents);
+  std::iota(order.begin(), order.end(), 0);
+  if (!std::is_sorted(d.full_ids.begin(), d.full_ids.end()))
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return d.full_ids[(size_t)a] < d.full_ids[(size_t)b]; });
   std::vector<int> run((size_t)P, 0);
   d.comm_index.resize((size_t)d.nents);
-  for (int i = 0; i < d.nents; ++i) {
+  for (int i : order) {
     const int o = d.owners[(size_t)i];
     const int lid = d.is_complete[(size_t)o] == 1 ? run[(size_t)o]++ : d.rank_lids[(size_t)i];
     d.comm_index[(size_t)i] = lid + d.poff[(size_t)o];
@@ -369,6 +382,7 @@ pp_picpart* pp_picpart_create(const pp_mesh* full, const int* elem_owner_host, i
   p->is_full = buffer_method == PP_PART_FULL;
   p->D[0].edim = 0;
   p->D[1].edim = full->dim;
+  p->D[2].edim = full->dim - 1;
   std::vector<int> owner_e(elem_owner_host, elem_owner_host + ne);
   p->owner_e = owner_e;
   p->buffer_method = buffer_method;
@@ -408,42 +422,9 @@ pp_picpart* pp_picpart_create(const pp_mesh* full, const int* elem_owner_host, i
   };
   std::vector<char> keep_e, keep_v;
   kept(p->has_part, keep_e, keep_v);
-  setup_holder(p->D[0], P, rank, owner_v, gid_v, keep_v);
-  setup_holder(p->D[1], P, rank, owner_e, gid_e, keep_e);
+  set_entities(p->D[0], nv, kept_list(keep_v));
+  set_entities(p->D[1], ne, kept_list(keep_e));
   if (p->D[1].nents == 0 && ne > 0) return bail("pp_picpart_create: empty part on this rank (:232-235)");
-  // ---- the owner side (what the reference learns from MPI_Ialltoall + Isend/Irecv, :113-190): which of my
-  // entities every other rank holds, in that rank's order -- from that rank's own buffer rule
-  for (int k = 0; k < 2; ++k) {
-    p->D[k].recv_counts.assign((size_t)P, 0);
-    p->D[k].recv_ent.clear();
-  }
-  std::vector<int> part_q;
-  std::vector<char> ke_q, kv_q;
-  for (int q = 0; q < P; ++q) {
-    if (q == rank) continue;
-    if (buffer_method == PP_PART_FULL) {
-      part_q.assign((size_t)P, 1);
-    } else if (safe_and_buffer(full, bridge_dim, q, P, buffer_method, PP_PART_NONE, buffer_layers, 0,
-                               d_owner.as<int>(), d_safe_tmp, part_q, nullptr) != PP_OK) {
-      return bail(nullptr);
-    }
-    kept(part_q, ke_q, kv_q);
-    for (int k = 0; k < 2; ++k) {
-      DimData& d = p->D[k];
-      const std::vector<int>& owner = k == 0 ? owner_v : owner_e;
-      const std::vector<int64_t>& gid = k == 0 ? gid_v : gid_e;
-      const std::vector<char>& keep = k == 0 ? kv_q : ke_q;
-      const int g0 = d.goff[(size_t)rank];
-      const size_t before = d.recv_ent.size();
-      for (int i = 0; i < d.nfull; ++i)  // increasing full id == rank q's part order
-        if (keep[(size_t)i] && owner[(size_t)i] == rank) d.recv_ent.push_back((int)(gid[(size_t)i] - g0));
-      const int cnt = (int)(d.recv_ent.size() - before);
-      d.recv_counts[(size_t)q] = cnt;
-      // a completely held part travels in rank-lid order (its lids are not renumbered, :66-76)
-      if (cnt == d.my_count) std::iota(d.recv_ent.begin() + (long)before, d.recv_ent.end(), 0);
-    }
-  }
-  for (int k = 0; k < 2; ++k) p->D[k].nrecv = (int)p->D[k].recv_ent.size();
   // ---- the part's mesh (:196-258): kept vertices and elements in full-mesh order
   if (!p->is_full) {
     const DimData &dv = p->D[0], &de = p->D[1];
@@ -460,9 +441,91 @@ pp_picpart* pp_picpart_create(const pp_mesh* full, const int* elem_owner_host, i
     p->part = pp_mesh_create(full->dim, dv.nents, coords.data(), de.nents, e2v.data(), cls.data());
     if (!p->part) return bail(nullptr);
   }
+  // ---- sides: the part's own mesh numbers them (pp_mesh_create derives sides from the elements); part side ->
+  // full side by their vertices.  Owner = smallest owner of the (one or two) elements around it.
+  const int ns = full->nsides, nvps = full->dim;  // vertices per side
+  std::vector<int> owner_s((size_t)ns, P);
+  for (int sd = 0; sd < ns; ++sd)
+    for (int k = full->side2elems_off[(size_t)sd]; k < full->side2elems_off[(size_t)sd + 1]; ++k)
+      owner_s[(size_t)sd] = std::min(owner_s[(size_t)sd], owner_e[(size_t)full->side2elems[(size_t)k]]);
+  {
+    std::vector<int> side_full;
+    if (p->is_full) {
+      side_full.resize((size_t)ns);
+      std::iota(side_full.begin(), side_full.end(), 0);
+    } else {
+      typedef std::array<int, 4> Key;  // sorted vertices (full ids) + side id
+      auto key_of = [&](const int* v, const std::vector<int>* to_full, int id) {
+        Key k{{0, 0, 0, id}};
+        for (int j = 0; j < nvps; ++j) k[(size_t)j] = to_full ? (*to_full)[(size_t)v[j]] : v[j];
+        std::sort(k.begin(), k.begin() + nvps);
+        return k;
+      };
+      std::vector<Key> keys((size_t)ns);
+      for (int sd = 0; sd < ns; ++sd) keys[(size_t)sd] = key_of(&full->side2verts[(size_t)sd * nvps], nullptr, sd);
+      auto less3 = [](const Key& a, const Key& b) {
+        return std::lexicographical_compare(a.begin(), a.begin() + 3, b.begin(), b.begin() + 3);
+      };
+      std::sort(keys.begin(), keys.end(), less3);
+      const pp_mesh* pm = p->part;
+      side_full.resize((size_t)pm->nsides);
+      for (int sd = 0; sd < pm->nsides; ++sd) {
+        const Key k = key_of(&pm->side2verts[(size_t)sd * nvps], &p->D[0].full_ids, -1);
+        auto it = std::lower_bound(keys.begin(), keys.end(), k, less3);
+        if (it == keys.end() || less3(k, *it)) return bail("pp_picpart_create: a side of the part is not a side of the full mesh");
+        side_full[(size_t)sd] = (*it)[3];
+      }
+    }
+    set_entities(p->D[2], ns, std::move(side_full));
+  }
+  for (int sd = 0; sd < ns; ++sd)
+    if (owner_s[(size_t)sd] >= P) return bail("pp_picpart_create: a side belongs to no element");
+  std::vector<int64_t> gid_s;
+  global_numbering(owner_s, P, p->D[2].goff, gid_s);
+  setup_holder(p->D[0], P, rank, owner_v, gid_v);
+  setup_holder(p->D[1], P, rank, owner_e, gid_e);
+  setup_holder(p->D[2], P, rank, owner_s, gid_s);
+  // ---- the owner side (what the reference learns from MPI_Ialltoall + Isend/Irecv, :113-190): which of my
+  // entities every other rank holds, in increasing full-mesh id -- from that rank's own buffer rule
+  for (int k = 0; k < 3; ++k) {
+    p->D[k].recv_counts.assign((size_t)P, 0);
+    p->D[k].recv_ent.clear();
+  }
+  std::vector<int> part_q;
+  std::vector<char> ke_q, kv_q, ks_q;
+  for (int q = 0; q < P; ++q) {
+    if (q == rank) continue;
+    if (buffer_method == PP_PART_FULL) {
+      part_q.assign((size_t)P, 1);
+    } else if (safe_and_buffer(full, bridge_dim, q, P, buffer_method, PP_PART_NONE, buffer_layers, 0,
+                               d_owner.as<int>(), d_safe_tmp, part_q, nullptr) != PP_OK) {
+      return bail(nullptr);
+    }
+    kept(part_q, ke_q, kv_q);
+    ks_q.assign((size_t)ns, 0);
+    for (int sd = 0; sd < ns; ++sd)
+      for (int k = full->side2elems_off[(size_t)sd]; k < full->side2elems_off[(size_t)sd + 1]; ++k)
+        if (ke_q[(size_t)full->side2elems[(size_t)k]]) ks_q[(size_t)sd] = 1;
+    for (int k = 0; k < 3; ++k) {
+      DimData& d = p->D[k];
+      const std::vector<int>& owner = k == 0 ? owner_v : (k == 1 ? owner_e : owner_s);
+      const std::vector<int64_t>& gid = k == 0 ? gid_v : (k == 1 ? gid_e : gid_s);
+      const std::vector<char>& keep = k == 0 ? kv_q : (k == 1 ? ke_q : ks_q);
+      const int g0 = d.goff[(size_t)rank];
+      const size_t before = d.recv_ent.size();
+      for (int i = 0; i < d.nfull; ++i)  // increasing full id: the order rank q numbers a partial part in
+        if (keep[(size_t)i] && owner[(size_t)i] == rank) d.recv_ent.push_back((int)(gid[(size_t)i] - g0));
+      const int cnt = (int)(d.recv_ent.size() - before);
+      d.recv_counts[(size_t)q] = cnt;
+      // a completely held part travels in rank-lid order (its lids are not renumbered, :66-76)
+      if (cnt == d.my_count) std::iota(d.recv_ent.begin() + (long)before, d.recv_ent.end(), 0);
+    }
+  }
+  for (int k = 0; k < 3; ++k) p->D[k].nrecv = (int)p->D[k].recv_ent.size();
   p->safe.resize((size_t)p->D[1].nents);
   for (int i = 0; i < p->D[1].nents; ++i) p->safe[(size_t)i] = is_safe[(size_t)p->D[1].full_ids[(size_t)i]];
-  if (upload(p->d_safe, p->safe) != PP_OK || upload_dim(p->D[0]) != PP_OK || upload_dim(p->D[1]) != PP_OK)
+  if (upload(p->d_safe, p->safe) != PP_OK || upload_dim(p->D[0]) != PP_OK || upload_dim(p->D[1]) != PP_OK ||
+      upload_dim(p->D[2]) != PP_OK)
     return bail(nullptr);
   return p;
 }

@@ -3,7 +3,7 @@
 // comm arrays from createCommArray, Mesh::reduceCommArray through the owners (pp_picpart_reduce).  Runs as
 // one rank or as several rank processes (PP_COMM=tcp, RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
 //   comm_array <mesh.bin> <partition file: one owner per element> [buffer layers] [safe layers]
-// Entity dimensions: vertices and elements (pp_mesh numbers no edges).
+// Entity dimensions: vertices, sides and elements (pp_mesh numbers no edges of tets).
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -142,18 +142,15 @@ int main(int argc, char** argv) {
   }
   const int buffer_layers = argc > 3 ? atoi(argv[3]) : 1, safe_layers = argc > 4 ? atoi(argv[4]) : 0;
   int fails = 0;
-  const int dims[2] = {0, dim};
-  for (int k = 0; k < 2; ++k)
+  const int dims[3] = {0, dim - 1, dim};
+  for (int k = 0; k < 3; ++k)
     if (!fullBufferTest(mesh, owner, dims[k])) {
       printf("fullBufferTest on dimension %d failed on rank %d\n", dims[k], rank);
       ++fails;
     }
   // ---- the parts: core + `buffer_layers` layers of whole parts, safe zone `safe_layers` layers
-  p::Input input(mesh, p::Input::PARTITION, owner, p::Input::BFS, p::Input::BFS);
-  input.bufferBFSLayers = buffer_layers;
-  input.safeBFSLayers = safe_layers;
-  p::Mesh picparts(input);
-  for (int k = 0; k < 2; ++k)
+  p::Mesh picparts(mesh, owner, buffer_layers, safe_layers);  // (test_comm_array.cpp:57: picparts(mesh, owner, 1, 0))
+  for (int k = 0; k < 3; ++k)
     if (!minOwnership(picparts, dims[k])) {
       printf("minOwnership on dimension %d failed on rank %d\n", dims[k], rank);
       ++fails;

@@ -131,12 +131,22 @@ class Mesh {
     } else {
       owner = in.partition;
     }
-    part_ = pp_picpart_create(in.m.handle(), owner.data(), (int)in.bufferMethod, (int)in.safeMethod, in.bridge_dim,
-                              in.bufferBFSLayers, in.safeBFSLayers, comm_);
-    if (!part_) pp_check(PP_EHIP, "pumipic::Mesh(Input&)");
-    h_ = const_cast<pp_mesh*>(pp_picpart_mesh(part_));
-    owns_mesh_ = false;
-    pp_check(pp_mesh_info(h_, &dim_, &nverts_, &nelems_, &nsides_), "pp_mesh_info");
+    init_part(in.m, owner, (int)in.bufferMethod, (int)in.safeMethod, in.bridge_dim, in.bufferBFSLayers,
+              in.safeBFSLayers, comm_);
+  }
+  // PICparts with a core and the whole mesh as buffer and safe zone (src/pumipic_part_construct.cpp:42-52)
+  Mesh(Mesh& full_mesh, const std::vector<int>& partition_vector, pp_comm* comm = nullptr) {
+    init_part(full_mesh, partition_vector, PP_PART_FULL, PP_PART_FULL, 0, 0, 0, comm);
+  }
+  // ... with all parts within buffer_layers of the core as buffer, the core plus safe_layers as safe zone
+  // (:54-73; "Ghost layers must be >= safe layers")
+  Mesh(Mesh& full_mesh, const std::vector<int>& partition_vector, int buffer_layers, int safe_layers,
+       pp_comm* comm = nullptr) {
+    if (buffer_layers < safe_layers) {
+      fprintf(stderr, "Ghost layers must be >= safe layers\n");
+      throw 1;
+    }
+    init_part(full_mesh, partition_vector, PP_PART_BFS, PP_PART_BFS, 0, buffer_layers, safe_layers, comm);
   }
   Mesh(int dim, const std::vector<double>& coords, const std::vector<int>& elem2verts,
        const std::vector<int>& class_id) {
@@ -321,6 +331,21 @@ class Mesh {
     size_t n = 0;
     const void* p = pp_mesh_array_dev(h_, which, &n);
     return View<T>::wrap((T*)p, n);
+  }
+  void init_part(Mesh& full, const std::vector<int>& owner, int buffer_method, int safe_method, int bridge_dim,
+                 int buffer_layers, int safe_layers, pp_comm* comm) {
+    comm_ = comm ? comm : comm_world();
+    if ((int)owner.size() != full.nelems()) {
+      fprintf(stderr, "pumipic::Mesh: the partition vector holds %zu owners for %d elements\n", owner.size(),
+              full.nelems());
+      exit(EXIT_FAILURE);
+    }
+    part_ = pp_picpart_create(full.handle(), owner.data(), buffer_method, safe_method, bridge_dim, buffer_layers,
+                              safe_layers, comm_);
+    if (!part_) pp_check(PP_EHIP, "pumipic::Mesh (PICparts)");
+    h_ = const_cast<pp_mesh*>(pp_picpart_mesh(part_));
+    owns_mesh_ = false;
+    pp_check(pp_mesh_info(h_, &dim_, &nverts_, &nelems_, &nsides_), "pp_mesh_info");
   }
   void reduce_part(int edim, Op op, int dtype, void* data, size_t n) {
     const int ne = nents(edim);

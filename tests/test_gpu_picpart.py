@@ -69,7 +69,7 @@ def test_construction_matches_oracle(ppo, synth, capi, opp, case):
     for po, pg in zip(O.parts, parts):
         assert pg.is_full_mesh == po.is_full_mesh
         assert pg.num_buffers == int(po.has_part.sum())
-        for d in (0, dim):
+        for d in (0, dim - 1, dim):
             assert pg.nents[d] == po.nents[d]
             assert np.array_equal(pg.array(capi.PART_GIDS, d), po.gids[d])
             assert np.array_equal(pg.array(capi.PART_OWNERS, d), po.owners[d])
@@ -102,7 +102,7 @@ def test_reduce_matches_oracle_and_reference_properties(ppo, synth, capi, opp, c
     dim, mo, mg, O, parts, comms, owner = _build(ppo, synth, capi, opp, case)
     rng = np.random.default_rng(5)
     P = len(parts)
-    for d in (0, dim):
+    for d in (0, dim - 1, dim):
         n = [p.nents[d] for p in parts]
         # random doubles, 3 values per entity: SUM / MAX / MIN / BCAST bit-exact
         for op in (capi.OP_SUM, capi.OP_MAX, capi.OP_MIN, capi.OP_BCAST):
@@ -132,7 +132,7 @@ def test_reduce_matches_oracle_and_reference_properties(ppo, synth, capi, opp, c
     for g in got:
         assert np.all(g == 1)
     if parts[0].is_full_mesh:
-        for d in (0, dim):
+        for d in (0, dim - 1, dim):
             got, _ = _reduce_both(capi, O, parts, d, capi.OP_SUM, [np.ones(p.nents[d], np.int32) for p in parts])
             for g in got:
                 assert np.all(g == P)
@@ -195,7 +195,7 @@ def test_error_paths(synth, capi):
     with pytest.raises(capi.PPError):
         p.reduce_mid()                                                     # nothing in flight
     with pytest.raises(capi.PPError):
-        p.reduce_begin(1 if dim == 3 else 5, capi.OP_SUM, a)               # no edge numbering
+        p.reduce_begin(5, capi.OP_SUM, a)                                  # no such entity dimension
     assert np.array_equal(capi.owner_by_classification(mg, np.arange(int(k.max()) + 1) % 4, int(k[0]) % 4),
                           (np.asarray(k) % 4).astype(np.int32))
     with pytest.raises(capi.PPError):

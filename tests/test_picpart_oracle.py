@@ -34,8 +34,8 @@ def test_numbering_and_ownership(ppo, synth, opp, which):
     mesh, owner = meshes(ppo, synth)[which]
     pp_ = opp.PicParts(mesh, owner, 4, opp.BFS, opp.BFS, buffer_layers=1, safe_layers=0)
     dim = mesh.dim
-    for d in (0, dim):
-        n = mesh.nverts if d == 0 else mesh.nelems
+    for d in (0, dim - 1, dim):
+        n = {0: mesh.nverts, dim - 1: mesh.nsides, dim: mesh.nelems}[d]
         assert sorted(pp_.gids[d].tolist()) == list(range(n))            # a permutation
         assert np.all(np.diff(pp_.gids[d][np.argsort(pp_.owner[d], kind="stable")]) == 1)  # owner-major, in id order
         assert np.all(pp_.rank_lids[d] == pp_.gids[d] - pp_.offsets[d][pp_.owner[d]])
@@ -48,7 +48,13 @@ def test_numbering_and_ownership(ppo, synth, opp, which):
         # the part's elements reference only kept vertices, in part numbering
         assert p.elem2verts.min() >= 0 and p.elem2verts.max() < p.nents[0]
         assert np.array_equal(p.coords[p.elem2verts], mesh.coords[mesh.elem2verts[p.full_ids[dim]]])
-        for d in (0, dim):
+        # the part's sides are the sides of its own mesh; the map to the full mesh keeps their vertices
+        pm = p.part_mesh if not p.is_full_mesh else mesh
+        assert p.nents[dim - 1] == pm.nsides
+        for sp in range(0, pm.nsides, 5):
+            assert sorted(p.full_ids[0][np.asarray(pm.side2verts)[sp]].tolist()) == \
+                sorted(mesh.side2verts[p.full_ids[dim - 1][sp]].tolist())
+        for d in (0, dim - 1, dim):
             ci = p.comm_index[d]
             assert sorted(ci.tolist()) == list(range(p.nents[d]))       # a permutation of the part's entities
             seg = np.searchsorted(p.nents_offsets[d], ci, side="right") - 1
@@ -64,7 +70,7 @@ def test_min_ownership_sum_entities_and_owned_elements(ppo, synth, opp, which):
     cs = 4
     pp_ = opp.PicParts(mesh, owner, cs, opp.BFS, opp.BFS, buffer_layers=1, safe_layers=0)
     dim = mesh.dim
-    for d in (0, dim):  # minOwnership
+    for d in (0, dim - 1, dim):  # minOwnership
         arrs = [np.where(p.owners[d] == p.rank, p.rank, np.iinfo(np.int32).max).astype(np.int32) for p in pp_.parts]
         red = pp_.reduce(d, opp.MIN_OP, arrs)
         for p, a in zip(pp_.parts, red):
@@ -100,9 +106,9 @@ def test_full_buffer(ppo, synth, opp, which):
     """fullBufferTest, test_comm_array.cpp:181-207"""
     mesh, owner = meshes(ppo, synth)[which]
     pp_ = opp.PicParts(mesh, owner, 4, opp.FULL, opp.FULL)
-    for d in (0, mesh.dim):
+    for d in (0, mesh.dim - 1, mesh.dim):
         for p in pp_.parts:
-            assert p.is_full_mesh and p.nents[d] == (mesh.nverts if d == 0 else mesh.nelems)
+            assert p.is_full_mesh and p.nents[d] == {0: mesh.nverts, mesh.dim - 1: mesh.nsides, mesh.dim: mesh.nelems}[d]
         ones = [np.ones(p.nents[d], dtype=np.int32) for p in pp_.parts]
         for a in pp_.reduce(d, opp.SUM_OP, ones):
             assert np.all(a == 4)
