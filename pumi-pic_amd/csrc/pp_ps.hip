@@ -3787,7 +3787,7 @@ int pp_redistribute_particles_dist(const pp_ps* ps, int strat, double percent_mo
   const int ne = ps->num_elems;
   const int *es = nullptr, *ee = nullptr;
   if (strat == 3) {  // the conversion's logarithms, once per element count, on the host (Distribute.cpp:155-173)
-    static pp::DevBuf tab;
+    static pp::DevBuf& tab = *new pp::DevBuf();  // (never destroyed: no hipFree after the runtime is gone)
     static int tab_ne = -1;
     if (tab_ne != ne) {
       std::vector<int> h((size_t)2 * std::max(ne, 1));
