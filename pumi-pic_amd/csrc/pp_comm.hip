@@ -139,7 +139,7 @@ struct TcpStar {
       // A peer that starts first may briefly hold the port itself: connecting to a port of the ephemeral range
       // that nobody listens on yet can be given that very port as its source (a TCP self-connection); it
       // notices and lets go (below), so the bind is retried for a few seconds before giving up.
-      const auto bind_end = std::chrono::steady_clock::now() + std::chrono::seconds(10);
+      const auto bind_end = std::chrono::steady_clock::now() + std::chrono::seconds(20);
       while (::bind(listen_fd, (sockaddr*)&any, sizeof(any)) != 0) {
         if (std::chrono::steady_clock::now() > bind_end) {
           set_error("tcp bootstrap: rank 0 cannot listen on port " + std::to_string(port));
@@ -167,6 +167,9 @@ struct TcpStar {
       int fd = -1;
       while (true) {
         fd = ::socket(AF_INET, SOCK_STREAM, 0);
+        // (SO_REUSEADDR here too: a self-connection that is closed below lingers in TIME_WAIT on the very port
+        // rank 0 wants, and the kernel lets rank 0 bind over it only if BOTH sockets carry the flag)
+        setsockopt(fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
         if (::connect(fd, (sockaddr*)&sa, sizeof(sa)) == 0) {
           sockaddr_in me{};
           socklen_t len = sizeof(me);

@@ -259,7 +259,7 @@ def _proc_worker(rank, world, port, transport, dim, q):
             comm = capi.Comm.torch()
         elif transport == "env-tcp":
             os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                              MASTER_PORT=str(port), PP_COMM="tcp")
+                              MASTER_PORT=str(port), PP_COMM="tcp", PP_COMM_PORT=str(port))
             comm = capi.Comm.env()
         else:
             comm = capi.Comm.tcp("127.0.0.1", port, rank, world)
@@ -337,7 +337,7 @@ def test_cpp_driver_pseudoxgcm_two_ranks(synth, capi, tmp_path):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), PP_DEVICE="0",
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PP_COMM="tcp")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PP_COMM="tcp", PP_COMM_PORT=str(port))
         procs.append(subprocess.Popen([os.path.join(drv, "pseudoXGCm"), mesh_file, str(npt), "6", "10", "2.0", "1"],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=300) for p in procs]

@@ -277,7 +277,7 @@ def test_cpp_driver_comm_array(synth, capi, tmp_path, world):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), PP_DEVICE="0",
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PP_COMM="tcp")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PP_COMM="tcp", PP_COMM_PORT=str(port))
         procs.append(subprocess.Popen([os.path.join(drv, "comm_array"), mesh_file, ptn, "1", "0"], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=300) for p in procs]
