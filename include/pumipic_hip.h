@@ -419,7 +419,8 @@ int pp_ps_migrate_pack(const pp_ps* ps, int* new_element_dev, const int* new_pro
 /* One-buffer form of the same exchange: every leaving particle is packed as ONE record
  * [element gid int64 | all members as 32-bit words], padded to 16 B, rank-major.  A single
  * all-to-all-v moves everything; the receiver feeds the records to pp_ps_rebuild_records, which
- * maps gid -> lid (gid2lid_dev[ngids], or identity when NULL: full-mesh replica) and rebuilds with
+ * maps gid -> lid (gid2lid_dev[ngids]; NULL: the structure's own table, built at construction from its element
+ * gids as the reference's SCS does, SCS_migrate.h:181-187 -- the identity for gids 0..ne-1) and rebuilds with
  * the received particles as new particles (SCS_migrate.h:181-213). */
 int pp_ps_migrate_record_bytes(const pp_ps* ps);
 int pp_ps_migrate_pack_records(const pp_ps* ps, int* new_element_dev, const int* new_process_dev,

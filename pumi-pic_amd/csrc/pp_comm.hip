@@ -435,7 +435,9 @@ int comm_exchange_records(pp_comm* c, const void* d_send, const std::vector<int>
   if (rc) return rc;
   PP_HIP_CHECK(c->d_recv.reserve((size_t)std::max<int64_t>(nr, 1) * rec_bytes));
   *d_recv_out = c->d_recv.p;
-  if (c->kind == 0 || (ns == 0 && nr == 0 && c->kind != 1)) return PP_OK;
+  // (nothing to send or receive: only the in-process transport may skip the exchange -- the host-staged ones are
+  // collectives through rank 0 / the caller's all-to-all-v and need every rank, even one with empty hands)
+  if (c->kind == 0 || (ns == 0 && nr == 0 && c->kind == 4)) return PP_OK;
   if (c->kind == 1) {
     RcclApi* R = rccl();
     PP_NCCL_CHECK(R->GroupStart());

@@ -174,6 +174,12 @@ struct pp_ps {
   std::vector<pp::DevBuf> data, swap;
   bool has_gids = false;
   pp::DevBuf d_gids;  // element -> gid (num_elems)
+  // gid -> element, the structure's own map (element_gid_to_lid of the reference, SCS_migrate.h:181-187), as a
+  // dense table over [0, max gid]; built at construction when the gids are not 0..ne-1 (a part of a
+  // partitioned mesh), used by the migration when the caller passes no table of its own
+  bool gids_identity = true;
+  int64_t n_gid2lid = 0;
+  pp::DevBuf d_gid2lid;
   // layout (device)
   pp::DevBuf d_offsets, d_slice_to_chunk, d_row_to_element, d_element_to_row, d_mask, d_slot_elem;
   // SCS row tiles for the row-major hot kernels: tile = (chunk, first p), kTileP columns wide.

@@ -412,6 +412,12 @@ static int rebuild_from_records(pp_ps* ps, int m_x, int m_xtgt, const int* new_e
                                 double* const* scatter_w_dev, double rmax, int gnr, int gppr) {
   const bool plain = m_x < 0 && m_xtgt < 0 && nmaps == 0;
   const int n_tot = n_recv + n_extra;
+  if (!gid2lid_dev && ps->has_gids && !ps->gids_identity) {  // the structure's own map (SCS_migrate.h:181-187)
+    PP_REQUIRE(ps->n_gid2lid > 0, "migration: the structure's element gids are too sparse for its own gid -> element "
+                                  "table -- pass gid2lid_dev");
+    gid2lid_dev = ps->d_gid2lid.as<int>();
+    ngids = ps->n_gid2lid;
+  }
   if (n_recv == 0)
     return plain ? pp_ps_rebuild(ps, new_element_dev, n_extra, extra_elems_dev, extra_info_dev)
                  : pp_ps_rebuild_scatter(ps, m_x, m_xtgt, new_element_dev, n_extra, extra_elems_dev,

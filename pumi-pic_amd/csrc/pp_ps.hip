@@ -3401,6 +3401,27 @@ int ps_materialize(pp_ps* ps) {
 
 extern "C" {
 
+// element gids of a new structure: the device copy, and the gid -> element table when they are not 0..ne-1
+static bool store_gids(pp_ps* ps, const int64_t* gids_host, int num_elems) {
+  ps->has_gids = true;
+  bool ok = ps->d_gids.reserve(sizeof(int64_t) * (size_t)num_elems) == hipSuccess &&
+            hipMemcpy(ps->d_gids.p, gids_host, sizeof(int64_t) * (size_t)num_elems, hipMemcpyHostToDevice) == hipSuccess;
+  int64_t mx = -1;
+  ps->gids_identity = true;
+  for (int e = 0; e < num_elems; ++e) {
+    if (gids_host[e] != e) ps->gids_identity = false;
+    mx = std::max<int64_t>(mx, gids_host[e]);
+  }
+  if (!ok || ps->gids_identity) return ok;
+  if (mx >= (int64_t)1 << 30) return ok;  // too sparse for a dense table: the caller passes its own map
+  std::vector<int> tab((size_t)mx + 1, -1);
+  for (int e = 0; e < num_elems; ++e)
+    if (gids_host[e] >= 0) tab[(size_t)gids_host[e]] = e;
+  ps->n_gid2lid = mx + 1;
+  return ps->d_gid2lid.reserve(sizeof(int) * tab.size()) == hipSuccess &&
+         hipMemcpy(ps->d_gid2lid.p, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice) == hipSuccess;
+}
+
 pp_ps* pp_ps_create_scs(int C, int sigma, int V, int num_elems, int num_ptcls,
                         const int* ppe_host, const int64_t* gids_host, int pad_strat,
                         double shuffle_padding, double extra_padding, int nmembers,
@@ -3448,12 +3469,7 @@ pp_ps* pp_ps_create_scs(int C, int sigma, int V, int num_elems, int num_ptcls,
   bool ok = alloc_members(ps, ps->data, ps->stride, true) == PP_OK;
   std::vector<int> ppe(ppe_host, ppe_host + num_elems);
   ok = ok && finish_layout_upload(ps, L, ppe) == PP_OK;
-  if (ok && gids_host && num_elems > 0) {
-    ps->has_gids = true;
-    ok = ps->d_gids.reserve(sizeof(int64_t) * (size_t)num_elems) == hipSuccess &&
-         hipMemcpy(ps->d_gids.p, gids_host, sizeof(int64_t) * (size_t)num_elems,
-                   hipMemcpyHostToDevice) == hipSuccess;
-  }
+  if (ok && gids_host && num_elems > 0) ok = store_gids(ps, gids_host, num_elems);
   if (ok) {
     ok = upload_vec(ps->d_elem_count, ppe) == PP_OK && hipStreamSynchronize(pp::stream()) == hipSuccess;
     ps->elem_count_valid = ok;
@@ -3524,12 +3540,7 @@ pp_ps* pp_ps_create_csr(int num_elems, int num_ptcls, const int* ppe_host,
     }
   ok = ok && upload_vec(ps->d_slot_elem, slot_elem) == PP_OK && upload_vec(ps->d_mask, mask) == PP_OK;
   if (ok) ok = hipStreamSynchronize(pp::stream()) == hipSuccess;
-  if (ok && gids_host && num_elems > 0) {
-    ps->has_gids = true;
-    ok = ps->d_gids.reserve(sizeof(int64_t) * (size_t)num_elems) == hipSuccess &&
-         hipMemcpy(ps->d_gids.p, gids_host, sizeof(int64_t) * (size_t)num_elems,
-                   hipMemcpyHostToDevice) == hipSuccess;
-  }
+  if (ok && gids_host && num_elems > 0) ok = store_gids(ps, gids_host, num_elems);
   if (ok && num_ptcls > 0 && particle_elements_host && particle_info_host) {
     std::vector<int> row(offsets.begin(), offsets.end());
     std::vector<int> slot((size_t)num_ptcls);

@@ -215,8 +215,30 @@ int main(int argc, char** argv) {
     fprintf(stderr, "cannot read a 2-D mesh container from %s\n", argv[1]);
     return EXIT_FAILURE;
   }
-  p::Mesh picparts(dim, coords, e2v, cls);
-  picparts.partition(world);  // element blocks, full mesh buffered, safe zone = own block
+  // The parts.  Default: element blocks with the full mesh buffered and the own block as safe zone (the
+  // replica BASELINE's config 5 names).  PP_PARTS=<buffer layers>:<safe layers>: PICparts from a
+  // pumipic::Input as the reference builds them (test/pseudoXGCm.cpp:379-384) -- BFS buffer and safe zone,
+  // every rank on its part's own mesh, elements travelling as global ids.
+  p::Mesh full_mesh(dim, coords, e2v, cls);
+  std::unique_ptr<p::Mesh> part_mesh;
+  if (const char* spec = getenv("PP_PARTS")) {
+    int buffer_layers = 3, safe_layers = 1;
+    if (sscanf(spec, "%d:%d", &buffer_layers, &safe_layers) < 1 || buffer_layers < safe_layers) {
+      fprintf(stderr, "PP_PARTS=<buffer layers>:<safe layers> with buffer >= safe\n");
+      return EXIT_FAILURE;
+    }
+    const int ne_full = full_mesh.nelems();
+    std::vector<int> owner((size_t)ne_full);
+    for (int e = 0; e < ne_full; ++e) owner[(size_t)e] = (int)((long long)e * comm_size / (ne_full > 0 ? ne_full : 1));
+    p::Input input(full_mesh, p::Input::PARTITION, owner, p::Input::BFS, p::Input::BFS, world);
+    input.bufferBFSLayers = buffer_layers;
+    input.safeBFSLayers = safe_layers;
+    part_mesh.reset(new p::Mesh(input));
+    if (!comm_rank) printf("PICparts from an Input: BFS buffer %d layers, safe zone %d layers\n", buffer_layers, safe_layers);
+  } else {
+    full_mesh.partition(world);  // element blocks, full mesh buffered, safe zone = own block
+  }
+  p::Mesh& picparts = part_mesh ? *part_mesh : full_mesh;
   o::Mesh* mesh = picparts.mesh();
   if (!comm_rank) printf("Mesh loaded with <v e f> %d %d %d\n", mesh->nverts(), mesh->nsides(), mesh->nelems());
   p::Distributor dist(world);
@@ -299,9 +321,16 @@ int main(int argc, char** argv) {
       break;
     }
     if (!comm_rank) fprintf(stderr, "iter %d particles %ld\n", iter, (long)totNp);
+    static const bool trace = getenv("PP_DRIVER_TRACE") != nullptr;  // per-rank progress lines on stderr
+#define PP_TRACE(what) \
+  if (trace) fprintf(stderr, "[rank %d] iter %d: %s\n", comm_rank, iter, what)
+    PP_TRACE("push");
     ellipticalPush::push(ptcls, *mesh, degPerPush, iter);
+    PP_TRACE("barrier");
     p::pp_check(pp_comm_barrier(world), "MPI_Barrier");
+    PP_TRACE("search");
     search(picparts, ptcls, dist, output);
+    PP_TRACE("searched");
     totNp = ptcls->nPtcls();
     p::pp_check(pp_allreduce_sum_host_i64(world, &totNp, 1), "MPI_Allreduce");
     if (totNp == 0) {
@@ -309,9 +338,12 @@ int main(int argc, char** argv) {
       break;
     }
     tagParentElements(picparts, ptcls, iter);
+    PP_TRACE("scatter");
     gyroScatter(mesh, ptcls, forward_map, fwdTagName);
     gyroScatter(mesh, ptcls, backward_map, bkwdTagName);
+    PP_TRACE("sync");
     gyroSync(picparts, fwdTagName, bkwdTagName, syncTagName);
+    PP_TRACE("synced");
   }
   if (comm_rank == 0) fprintf(stderr, "%d iterations of pseudopush (seconds) %f\n", iter, fullTimer.seconds());
 
@@ -319,7 +351,16 @@ int main(int argc, char** argv) {
   // sum over ranks of the ranks' scatter fields), elements this rank ever saw particles in
   std::vector<double> w = mesh->get_array<o::Real>(0, syncTagName).to_host();
   double mass = 0;
-  for (size_t v = 0; v < w.size(); v += 2) mass += w[v];
+  if (part_mesh) {  // every vertex counted once: by its owner; then summed over the ranks
+    std::vector<int> vown = picparts.entOwners(0).to_host();
+    for (size_t v = 0; v < vown.size(); ++v)
+      if (vown[v] == comm_rank) mass += w[2 * v];
+    o::Write<o::Real> m1(1, mass);
+    p::pp_check(pp_allreduce_sum(world, m1.data(), 1), "MPI_Allreduce");
+    mass = m1.to_host()[0];
+  } else {
+    for (size_t v = 0; v < w.size(); v += 2) mass += w[v];
+  }
   std::vector<int> hp = mesh->get_array<o::LO>(picparts.dim(), "has_particles").to_host();
   int64_t touched = 0;
   for (int v : hp) touched += v >= 0;

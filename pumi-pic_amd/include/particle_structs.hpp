@@ -250,7 +250,8 @@ class ParticleStructure {
   // accessor invalidated by rebuild/migrate, like the reference's (drivers re-get after rebuild)
   template <std::size_t N>
   Slice<N> get() {
-    if (nPtcls() == 0) return Slice<N>();
+    if (nPtcls() == 0) return Slice<N>(nullptr, 0, (int)N);  // (a rank may hold nothing yet: the operators still
+                                                             //  need to know WHICH member this accessor names)
     using B = typename BaseType<DataType<N>>::type;
     return Slice<N>((B*)pp_ps_member_ptr(h_, (int)N), pp_ps_member_stride(h_), (int)N);
   }

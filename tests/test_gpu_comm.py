@@ -320,6 +320,48 @@ def test_two_processes_share_one_gpu(ppo, synth, capi, transport, dim):
             assert np.array_equal(r[3][step][0::2], fo) and np.array_equal(r[3][step][1::2], bo)
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_cpp_driver_pseudoxgcm_on_picparts(synth, capi, tmp_path, world):
+    """The same driver with PP_PARTS=3:1: PICparts from a pumipic::Input (BFS buffer of 3 layers, safe zone of
+    1) as the reference's pseudoXGCm builds them -- every rank on its part's own mesh, migrate_lb_ptcls
+    routing by the part's safe tag / owners, particles travelling with element gids (the structure's own
+    gid -> element table), gyroScatter on the part, gyroSync through the owners (reduceCommArray fan-in /
+    fan-out).  No particle is lost, and the synced field, every vertex counted once by its owner, carries
+    the same mass as the run on the full-mesh replica."""
+    import re
+    import subprocess
+    drv = os.path.join(ROOT, "pumi-pic_amd", "drivers")
+    subprocess.check_call(["make", "-C", drv, "-s"])
+    c, e, cl = synth.annulus_tri(n_b=24, n_theta=96, band_width=3)
+    mesh_file = str(tmp_path / "annulus.bin")
+    synth.write_mesh_bin(mesh_file, 2, c, e, cl)
+    npt = 20000
+    results = {}
+    for mode in ("replica", "parts"):
+        port = _free_port()
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), PP_DEVICE="0",
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PP_COMM="tcp", PP_COMM_PORT=str(port))
+            if mode == "parts":
+                env["PP_PARTS"] = "3:1"
+            procs.append(subprocess.Popen([os.path.join(drv, "pseudoXGCm"), mesh_file, str(npt), "6", "10", "2.0", "1"],
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        outs = [p.communicate(timeout=300) for p in procs]
+        for p, (so, se) in zip(procs, outs):
+            assert p.returncode == 0, (mode, so[-1500:], se[-2000:])
+        m = re.search(r"RESULT particles (\d+) scatter_mass (\S+) touched_elements (\d+)", outs[0][0])
+        assert m, outs[0][0][-2000:]
+        per_rank = [int(re.search(r"RANK %d particles (\d+)" % r, outs[r][0]).group(1)) for r in range(world)]
+        created = npt if world == 2 else 3 * (npt // world)  # (4 ranks: the outer block holds no source element)
+        assert int(m.group(1)) == created == sum(per_rank), (mode, per_rank)
+        results[mode] = (float(m.group(2)), per_rank)
+        if mode == "parts":
+            assert "PICparts from an Input" in outs[0][0]
+    assert results["parts"][0] == results["replica"][0]      # integer-valued sums: exact
+    # (who holds a particle differs: the parts' safe zone is one layer wider than the replica's own-block rule)
+
+
 def test_cpp_driver_pseudoxgcm_two_ranks(synth, capi, tmp_path):
     """The pseudoXGCm driver on the mirror headers (Mesh::partition, migrate_lb_ptcls -> ParticleStructure::
     migrate -> pp_ps_migrate, gyroSync -> reduceCommArray -> pp_allreduce_sum, SummarizeTimeAcrossProcesses)

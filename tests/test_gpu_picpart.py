@@ -442,7 +442,8 @@ def test_step_on_bfs_parts_matches_the_full_mesh_run(ppo, synth, capi, opp, dim)
             ids = capi.DevArray.from_host(np.full(max(ps.capacity(), 1), -1, dtype=np.int32))
             _step(capi, p.mesh, ps, dim, 6.0, ids)
             ne_d, np_d = capi.set_unsafe_procs(ps, ids, safes[r], owners_d[r], r)
-            capi.migrate_begin(ps, ne_d, np_d, comms[r], commit=True, gid2lid=tables[r])
+            # 2-D: the caller's gid -> local table; tets: the structure's own (built from its element gids)
+            capi.migrate_begin(ps, ne_d, np_d, comms[r], commit=True, gid2lid=tables[r] if dim == 2 else None)
             keep.append((ids, ne_d, np_d))
         for r, ps in enumerate(structs):
             ns, nr = capi.migrate_end(ps, comms[r])
