@@ -293,11 +293,12 @@ def _proc_worker(rank, world, port, transport, dim, q):
         q.put((rank, "FAIL " + repr(e) + traceback.format_exc(), None, None, None))
 
 
-@pytest.mark.parametrize("transport,dim", [("tcp", 2), ("tcp", 3), ("gloo", 2), ("env-tcp", 3)])
-def test_two_processes_share_one_gpu(ppo, synth, capi, transport, dim):
-    """Two rank PROCESSES on one GPU run the c5 step through pp_ps_migrate_scatter +
-    pp_allreduce_sum over a host-staged transport; union == single-structure oracle run."""
-    world = 2
+@pytest.mark.parametrize("transport,dim,world", [("tcp", 2, 2), ("tcp", 3, 2), ("gloo", 2, 2), ("env-tcp", 3, 2),
+                                                 ("tcp", 2, 4), ("gloo", 3, 3)])
+def test_two_processes_share_one_gpu(ppo, synth, capi, transport, dim, world):
+    """Two (to four) rank PROCESSES on one GPU run the c5 step through pp_ps_migrate_scatter +
+    pp_allreduce_sum over a host-staged transport; union == single-structure oracle run.  (Three and more
+    ranks: not every rank takes part in every step's migration -- the exchange stays a collective.)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
