@@ -105,7 +105,7 @@ def _step(capi, mesh, ps, dim, deg, ids):
 
 
 @pytest.mark.parametrize("dim", [2, 3])
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 @pytest.mark.parametrize("fused", [False, True])
 def test_migrate_local_virtual_ranks(ppo, synth, capi, dim, world, fused):
     """pp_ps_migrate_begin / _end on a `local` communicator: element-block virtual ranks of one
