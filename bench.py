@@ -217,6 +217,10 @@ class Stepper:
                                                       w["safe_layers"], w["safe_layers"])
             self.moved = 0
             self.comm, self.comm_kind = None, w.get("comm", "rccl")
+            if self.comm_kind == "tcp":  # the library's host-staged transport (rehearsal on a smaller box)
+                port = int(os.environ.get("PP_COMM_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
+                self.comm = (capi.Comm.env() if self.world == 1 else
+                             capi.Comm.tcp(os.environ.get("MASTER_ADDR", "127.0.0.1"), port, self.rank, self.world))
             if self.comm_kind == "rccl":
                 try:
                     self.comm = self._make_comm()
@@ -495,9 +499,11 @@ def main():
     ap.add_argument("--no-origin-trust", action="store_true",
                     help="run check_initial_parents every step (default: skipped from the second step on, "
                          "pp_ps_set_origin_trust)")
-    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
-                    help="c5 exchange: RCCL behind the C-ABI (pp_ps_migrate / pp_allreduce_sum) or the "
-                         "torch.distributed glue of pumi-pic_amd/dist.py")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch", "tcp"],
+                    help="c5 exchange: RCCL behind the C-ABI (pp_ps_migrate / pp_allreduce_sum), the "
+                         "torch.distributed glue of pumi-pic_amd/dist.py, or the library's host-staged TCP "
+                         "transport (rehearsal of the multi-rank line on a box with fewer GPUs than ranks: "
+                         "with PP_BENCH_REHEARSAL=1 every rank uses GPU 0 and the timing barrier runs over gloo)")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -519,7 +525,16 @@ def main():
     if a.cpu_sample is None:
         a.cpu_sample = 2_000_000 if full_step else 4_000_000
     import torch
-    if world > 1 and torch.cuda.device_count() < world:
+    # Rehearsal (tests): N ranks on ONE GPU, gloo for the timing barrier, --comm tcp for the data path.  RCCL
+    # cannot put two ranks on one device, so this is how the multi-rank line's plumbing runs on a 1-GPU box;
+    # the JSON line says so and is not a measurement.
+    rehearsal = world > 1 and os.environ.get("PP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        if a.comm != "tcp":
+            sys.stderr.write("bench.py: PP_BENCH_REHEARSAL=1 needs --comm tcp\n")
+            sys.exit(2)
+        local_rank = 0
+    if world > 1 and not rehearsal and torch.cuda.device_count() < world:
         sys.stderr.write("bench.py: %d ranks need %d GPUs, this box has %d\n"
                          % (world, world, torch.cuda.device_count()))
         sys.exit(2)
@@ -528,7 +543,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     pp = pumipic_amd_loader.load()
     from pumipic_amd import capi
@@ -562,7 +580,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            t = torch.tensor([dt], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
@@ -600,7 +618,7 @@ def main():
     nlive = w["ps"].nPtcls()
     total_particles = nlive
     if dist is not None:
-        t = torch.tensor([nlive], device="cuda", dtype=torch.int64)
+        t = torch.tensor([nlive], device="cpu" if rehearsal else "cuda", dtype=torch.int64)
         dist.all_reduce(t)
         total_particles = int(t.item())
 
@@ -695,6 +713,9 @@ def main():
                  getattr(st, "comm_kind", a.comm), a.deg),
              "2dc3": "push+search+rebuild+gyroScatter x2 every step, deg/push=%g" % a.deg}[a.workload]),
             "parallelism": "element-block partition, %d rank(s), full-mesh replica" % world}
+        if rehearsal:
+            out["rehearsal"] = ("NOT a measurement: %d ranks share GPU 0, the exchange is the host-staged TCP transport "
+                                "and the timing barrier runs over gloo (PP_BENCH_REHEARSAL=1)" % world)
         if a.workload == "c5":
             out["rank0_sent_per_step"] = st.moved / max(1, st.steps_done)
         if w["dim"] == 3:

@@ -395,3 +395,31 @@ def test_cpp_driver_pseudoxgcm_two_ranks(synth, capi, tmp_path):
     assert 0.9 * 18 * npt <= mass <= 18 * npt               # 2 rings x 3 verts x (8 pts x 3 mapped)/8 each
     assert "world ranks 2 (tcp)" in outs[0][0]
     assert "Reduced Timing Summary" in outs[0][1] and "gyro reduction" in outs[0][1]
+
+
+def test_bench_multi_rank_line_rehearsal(tmp_path):
+    """bench.py's N > 1 line (the migrating c5 workload: rank start-up under torch.distributed.run, element-block
+    owners, pp_migrate_ptcls, gyroSync all-reduce, the max-over-ranks timing, ONE JSON line from rank 0) rehearsed
+    with two ranks on this box's single GPU: PP_BENCH_REHEARSAL=1 puts every rank on GPU 0, --comm tcp carries the
+    exchange and gloo the timing barrier (RCCL cannot place two ranks on one device).  Not a measurement -- the
+    line says so -- but every line of the multi-rank plumbing except the RCCL calls themselves runs."""
+    import json
+    import subprocess
+    port = _free_port()
+    env = dict(os.environ, PP_BENCH_REHEARSAL="1", PP_BENCH_PREWARM="0", PP_COMM_PORT=str(_free_port()),
+               PP_BENCH_CACHE=str(tmp_path))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "2", "--workload", "c5", "--mesh", "100k", "--particles", "300000", "--comm", "tcp",
+           "--no-cpu-baseline", "--deg", "4.0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["warmup"] == 2 and "rehearsal" in j
+    assert j["metric"].startswith("particles pushed+searched+scattered")
+    assert "migrate" in j["config"]["workload"] and "tcp" in j["config"]["workload"]
+    assert j["rank0_sent_per_step"] > 0                       # particles really crossed between the ranks
+    # whole-job particles / time (the population draws land within a fraction of a per cent of 2 x 300 000)
+    assert abs(j["value"] - 600000 * 4 / (j["ms_per_step"] * 4e-3)) / j["value"] < 1e-2
