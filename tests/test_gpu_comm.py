@@ -397,7 +397,8 @@ def test_cpp_driver_pseudoxgcm_two_ranks(synth, capi, tmp_path):
     assert "Reduced Timing Summary" in outs[0][1] and "gyro reduction" in outs[0][1]
 
 
-def test_bench_multi_rank_line_rehearsal(tmp_path):
+@pytest.mark.parametrize("launcher", ["torchrun", "self"])
+def test_bench_multi_rank_line_rehearsal(tmp_path, launcher):
     """bench.py's N > 1 line (the migrating c5 workload: rank start-up under torch.distributed.run, element-block
     owners, pp_migrate_ptcls, gyroSync all-reduce, the max-over-ranks timing, ONE JSON line from rank 0) rehearsed
     with two ranks on this box's single GPU: PP_BENCH_REHEARSAL=1 puts every rank on GPU 0, --comm tcp carries the
@@ -408,10 +409,14 @@ def test_bench_multi_rank_line_rehearsal(tmp_path):
     port = _free_port()
     env = dict(os.environ, PP_BENCH_REHEARSAL="1", PP_BENCH_PREWARM="0", PP_COMM_PORT=str(_free_port()),
                PP_BENCH_CACHE=str(tmp_path))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
-           "--warmup", "2", "--workload", "c5", "--mesh", "100k", "--particles", "300000", "--comm", "tcp",
-           "--no-cpu-baseline", "--deg", "4.0"]
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--workload", "c5",
+            "--mesh", "100k", "--particles", "300000", "--comm", "tcp", "--no-cpu-baseline", "--deg", "4.0"]
+    if launcher == "torchrun":  # the driver's way
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port)] + args
+    else:                       # `python bench.py --gpus 2`: the parent starts the ranks itself
+        cmd = [sys.executable] + args
+        env["PP_BENCH_ASSUME_GPUS"] = "2"
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
