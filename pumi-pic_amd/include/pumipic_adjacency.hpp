@@ -157,6 +157,7 @@ class Mesh {
     pp_check(pp_mesh_info(h_, &dim_, &nverts_, &nelems_, &nsides_), "pp_mesh_info");
   }
   ~Mesh() {
+    if (bal_) (void)pp_balancer_destroy(bal_);
     if (part_) (void)pp_picpart_destroy(part_);
     if (h_ && owns_mesh_) (void)pp_mesh_destroy(h_);
   }
@@ -209,6 +210,15 @@ class Mesh {
   int rank() const { return pp_comm_rank(comm()); }
   int num_ranks() const { return pp_comm_size(comm()); }
   pp_picpart* picpart() const { return part_; }
+  // the part's particle balancer (Mesh::ptclBalancer, pumipic_mesh.hpp:76; the reference builds it at the end of
+  // constructPICPart, here on first use); null for a mesh that was not built from an Input
+  pp_balancer* ptclBalancerHandle() {
+    if (!bal_ && part_) {
+      bal_ = pp_balancer_create(part_);
+      if (!bal_) pp_check(PP_EHIP, "ParticleBalancer");
+    }
+    return bal_;
+  }
   bool isFullMesh() const {
     if (!part_) return true;
     int full = 1;
@@ -366,6 +376,7 @@ class Mesh {
   pp_mesh* h_ = nullptr;
   bool owns_mesh_ = true;
   pp_picpart* part_ = nullptr;
+  pp_balancer* bal_ = nullptr;
   int dim_ = 0, nverts_ = 0, nelems_ = 0, nsides_ = 0;
   pp_comm* comm_ = nullptr;
   o::Write<o::LO> owners_;
@@ -723,9 +734,10 @@ void setUnsafeProcs(Mesh& mesh, PS* ptcls, o::LOs elems, typename PS::kkLidView 
                                new_procs.data()),
            "setUnsafeProcs");
 }
-// migrate_ptcls / migrate_lb_ptcls (src/pumipic_ptcl_ops.hpp:53-85).  The diffusive particle balancer
-// (ParticleBalancer::repartition, pumipic_lb.hpp:352-362) is not built: particles go to the owner
-// of their element, which is what the reference does when the imbalance is within `tol`.
+// migrate_ptcls / migrate_lb_ptcls (src/pumipic_ptcl_ops.hpp:53-85).  On parts built from a pumipic::Input
+// migrate_lb_ptcls runs the part's balancer between setUnsafeProcs and the migration, as the reference does
+// (ParticleBalancer::repartition, pumipic_lb.hpp:352-362); a mesh partitioned with Mesh::partition (the
+// full-mesh replica without an Input) has none: particles go to the owner of their element.
 template <class PS>
 void migrate_ptcls(Mesh& mesh, PS* ptcls, o::LOs elems) {
   Timer init_timer;
@@ -738,8 +750,24 @@ void migrate_ptcls(Mesh& mesh, PS* ptcls, o::LOs elems) {
   RecordTime("migration", migrate_timer.seconds());
 }
 template <class PS>
-void migrate_lb_ptcls(Mesh& mesh, PS* ptcls, o::LOs elems, float /*tol*/, float = 0.5) {
-  migrate_ptcls(mesh, ptcls, elems);
+void migrate_lb_ptcls(Mesh& mesh, PS* ptcls, o::LOs elems, float tol, float step_factor = 0.5) {
+  pp_balancer* balancer = mesh.ptclBalancerHandle();
+  if (!balancer) {
+    migrate_ptcls(mesh, ptcls, elems);
+    return;
+  }
+  Timer init_timer;
+  const size_t cap = (size_t)std::max(ptcls->capacity(), 1);
+  typename PS::kkLidView new_elems("ps_element_ids", cap), new_procs("ps_process_ids", cap);
+  setUnsafeProcs(mesh, ptcls, elems, new_elems, new_procs);
+  RecordTime("migration_init", init_timer.seconds());
+  Timer balance_timer;
+  pp_check(pp_balancer_repartition(balancer, ptcls->handle(), tol, new_elems.data(), new_procs.data(), step_factor),
+           "ParticleBalancer::repartition");
+  RecordTime("migration_balance", balance_timer.seconds());
+  Timer migrate_timer;
+  ptcls->migrate(new_elems, new_procs, Distributor(mesh.comm()));
+  RecordTime("migration", migrate_timer.seconds());
 }
 
 }  // namespace pumipic
