@@ -360,7 +360,13 @@ def test_cpp_driver_pseudoxgcm_on_picparts(synth, capi, tmp_path, world):
         if mode == "parts":
             assert "PICparts from an Input" in outs[0][0]
     assert results["parts"][0] == results["replica"][0]      # integer-valued sums: exact
-    # (who holds a particle differs: the parts' safe zone is one layer wider than the replica's own-block rule)
+    # who holds a particle differs: the parts' safe zone is one layer wider than the replica's own-block rule,
+    # and migrate_lb_ptcls balances on parts (the outer block of the 4-rank run creates no particle: it is fed
+    # through the elements it shares a safe zone with)
+    print("per rank: replica", results["replica"][1], "parts", results["parts"][1])
+    if world == 4:
+        assert results["parts"][1][3] > results["replica"][1][3]
+        assert max(results["parts"][1]) <= max(results["replica"][1])
 
 
 def test_cpp_driver_pseudoxgcm_two_ranks(synth, capi, tmp_path):
