@@ -155,9 +155,50 @@ def walls_and_parts(ppo, synth):
     np.savez_compressed(os.path.join(OUT, "walls_and_parts.npz"), **out)
 
 
+def picparts(ppo, synth):
+    """PICparts, comm arrays and the balancer (oracle/ppo_picpart.py): 4 ranks, slabs of a Kuhn box (tets) and
+    of an annulus (triangles), 1-layer BFS buffer / core safe zone for the comm arrays, the reference
+    test_lb.cpp's Input (BFS buffer 3, FULL safe) for the balancer"""
+    opp = pumipic_amd_loader.load_oracle_picpart()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_picpart_oracle import slab_owners
+    out = {}
+    for tag, (c, e, k), dim, axis in (("box", synth.kuhn_box(4), 3, 0),
+                                      ("ann", synth.annulus_tri(n_b=6, n_theta=24, band_width=3), 2, 1)):
+        owner = slab_owners(c, e, 4, axis=axis)
+        mesh = ppo.Mesh(dim, c, e, k)
+        P = opp.PicParts(mesh, owner, 4, opp.BFS, opp.BFS, buffer_layers=1, safe_layers=0)
+        rng = np.random.default_rng(3)
+        out[tag + "_owner"] = owner
+        for r, p in enumerate(P.parts):
+            for d in (0, dim - 1, dim):
+                out["%s_r%d_d%d_gids" % (tag, r, d)] = p.gids[d]
+                out["%s_r%d_d%d_comm_index" % (tag, r, d)] = p.comm_index[d]
+                out["%s_r%d_d%d_full_ids" % (tag, r, d)] = p.full_ids[d]
+                out["%s_r%d_d%d_complete" % (tag, r, d)] = p.is_complete[d]
+            out["%s_r%d_safe" % (tag, r)] = p.safe
+        for d in (0, dim - 1, dim):
+            arrs = [rng.standard_normal(p.nents[d] * 2) for p in P.parts]
+            red = P.reduce(d, opp.SUM_OP, arrs)
+            for r in range(4):
+                out["%s_r%d_d%d_in" % (tag, r, d)] = arrs[r]
+                out["%s_r%d_d%d_sum" % (tag, r, d)] = red[r]
+        PB = opp.PicParts(mesh, owner, 4, opp.BFS, opp.FULL, buffer_layers=3, safe_layers=1)
+        bal = opp.Balancer(PB)
+        ppe = [np.full(p.nents[dim], (p.rank + 1) * 50, dtype=np.int32) for p in PB.parts]
+        plan, W, w = bal.partition_counts(ppe, 1.05)
+        out[tag + "_sbars"] = np.asarray(bal.masks, dtype=np.uint64)
+        out[tag + "_weights_after"] = np.asarray(W, dtype=np.int64)
+        for r in range(4):
+            out["%s_r%d_sbar_ids" % (tag, r)] = bal.part_index[r]
+            out["%s_r%d_plan" % (tag, r)] = np.asarray(plan[r], dtype=np.int64).reshape(-1, 3)
+    np.savez_compressed(os.path.join(OUT, "picparts.npz"), **out)
+
+
 if __name__ == "__main__":
     pp = pumipic_amd_loader.load()
     ppo = pumipic_amd_loader.load_oracle()
+    picparts(ppo, pp.synth)
     xgcm_2d(ppo, pp.synth)
     xgcm_3d(ppo, pp.synth)
     push_and_search(ppo, pp.synth)

@@ -258,3 +258,77 @@ def test_gpu_walls_and_parts_golden(ppo, synth, capi):
                       particle_info=[np.arange(5000, dtype=np.int32)[None, :]])
     assert np.array_equal(capi.redistribute_particles(psr, 0.4, seed=12345).to_host()[:psr.capacity()],
                           g["redist_new"])
+
+
+# ---------------------------------------------------------------- PICparts, comm arrays, balancer
+def _picpart_cases(synth):
+    from test_picpart_oracle import slab_owners
+    return (("box", synth.kuhn_box(4), 3, 0), ("ann", synth.annulus_tri(n_b=6, n_theta=24, band_width=3), 2, 1)), slab_owners
+
+
+def test_oracle_picparts_golden(ppo, synth):
+    import pumipic_amd_loader
+    opp = pumipic_amd_loader.load_oracle_picpart()
+    g = _load("picparts.npz")
+    cases, slab_owners = _picpart_cases(synth)
+    for tag, (c, e, k), dim, axis in cases:
+        owner = slab_owners(c, e, 4, axis=axis)
+        assert np.array_equal(owner, g[tag + "_owner"])
+        mesh = ppo.Mesh(dim, c, e, k)
+        P = opp.PicParts(mesh, owner, 4, opp.BFS, opp.BFS, buffer_layers=1, safe_layers=0)
+        for r, p in enumerate(P.parts):
+            for d in (0, dim - 1, dim):
+                assert np.array_equal(p.gids[d], g["%s_r%d_d%d_gids" % (tag, r, d)])
+                assert np.array_equal(p.comm_index[d], g["%s_r%d_d%d_comm_index" % (tag, r, d)])
+                assert np.array_equal(p.full_ids[d], g["%s_r%d_d%d_full_ids" % (tag, r, d)])
+                assert np.array_equal(p.is_complete[d], g["%s_r%d_d%d_complete" % (tag, r, d)])
+            assert np.array_equal(p.safe, g["%s_r%d_safe" % (tag, r)])
+        for d in (0, dim - 1, dim):
+            red = P.reduce(d, opp.SUM_OP, [g["%s_r%d_d%d_in" % (tag, r, d)] for r in range(4)])
+            for r in range(4):
+                assert np.array_equal(red[r], g["%s_r%d_d%d_sum" % (tag, r, d)])
+        PB = opp.PicParts(mesh, owner, 4, opp.BFS, opp.FULL, buffer_layers=3, safe_layers=1)
+        bal = opp.Balancer(PB)
+        plan, W, _ = bal.partition_counts([np.full(p.nents[dim], (p.rank + 1) * 50, dtype=np.int32) for p in PB.parts], 1.05)
+        assert bal.masks == g[tag + "_sbars"].tolist() and W == g[tag + "_weights_after"].tolist()
+        for r in range(4):
+            assert np.array_equal(bal.part_index[r], g["%s_r%d_sbar_ids" % (tag, r)])
+            assert np.array_equal(np.asarray(plan[r], dtype=np.int64).reshape(-1, 3), g["%s_r%d_plan" % (tag, r)])
+
+
+@pytest.mark.gpu
+def test_gpu_picparts_golden(synth, capi):
+    """the HIP parts, reductions and balancer plans against the committed file (no oracle in the loop)"""
+    g = _load("picparts.npz")
+    cases, slab_owners = _picpart_cases(synth)
+    for tag, (c, e, k), dim, axis in cases:
+        owner = g[tag + "_owner"]
+        mesh = capi.Mesh(dim, c, e, k)
+        comms = capi.Comm.local(4)
+        parts = [capi.PicPart(mesh, owner, comms[r], capi.PART_BFS, capi.PART_BFS, 0, 1, 0) for r in range(4)]
+        for r, p in enumerate(parts):
+            for d in (0, dim - 1, dim):
+                assert np.array_equal(p.array(capi.PART_GIDS, d), g["%s_r%d_d%d_gids" % (tag, r, d)])
+                assert np.array_equal(p.array(capi.PART_COMM_INDEX, d), g["%s_r%d_d%d_comm_index" % (tag, r, d)])
+                assert np.array_equal(p.array(capi.PART_FULL_IDS, d), g["%s_r%d_d%d_full_ids" % (tag, r, d)])
+                assert np.array_equal(p.complete_parts(d), g["%s_r%d_d%d_complete" % (tag, r, d)])
+            assert np.array_equal(p.array(capi.PART_SAFE).astype(np.int32), g["%s_r%d_safe" % (tag, r)])
+        for d in (0, dim - 1, dim):
+            devs = [capi.DevArray.from_host(g["%s_r%d_d%d_in" % (tag, r, d)]) for r in range(4)]
+            capi.picpart_reduce_all(parts, d, capi.OP_SUM, devs)
+            for r in range(4):
+                assert np.array_equal(devs[r].to_host(), g["%s_r%d_d%d_sum" % (tag, r, d)])
+        lb_comms = capi.Comm.local(4)
+        lb_parts = [capi.PicPart(mesh, owner, lb_comms[r], capi.PART_BFS, capi.PART_FULL, 0, 3, 1) for r in range(4)]
+        bals = [capi.Balancer(p) for p in lb_parts]
+        for r, (p, b) in enumerate(zip(lb_parts, bals)):
+            assert np.array_equal(b.sbars(), g[tag + "_sbars"])
+            assert np.array_equal(b.sbar_ids(), g["%s_r%d_sbar_ids" % (tag, r)])
+            b.partition_begin(np.full(p.nents[dim], (r + 1) * 50, dtype=np.int32))
+        for r, b in enumerate(bals):
+            b.partition_end(1.05)
+            plan, W = b.last_plan()
+            assert np.array_equal(np.asarray(plan, dtype=np.int64).reshape(-1, 3), g["%s_r%d_plan" % (tag, r)])
+            assert np.array_equal(W, g[tag + "_weights_after"])
+        for cm in comms + lb_comms:
+            cm.destroy()
