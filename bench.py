@@ -487,6 +487,12 @@ def main():
     ap.add_argument("--structure", default="scs", choices=["scs", "csr"], help="c4: particle structure")
     ap.add_argument("--particles", type=int, default=None,
                     help="particles per GPU (default 10 M; c5 on several GPUs 32 M; c4 1 M)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="several GPUs: weak = --particles per GPU (default, what the driver's scaling run "
+                         "computes efficiencies from), strong = --total-particles over all GPUs "
+                         "(BASELINE configs[4]: 256 M)")
+    ap.add_argument("--total-particles", type=int, default=256_000_000,
+                    help="--scaling strong: particles of the whole job")
     ap.add_argument("--deg", type=float, default=0.5, help="degrees per push (testing.cmake:117)")
     ap.add_argument("--cpu-sample", type=int, default=None,
                     help="particles of the bounded CPU-baseline sample (~10 s on one core)")
@@ -519,6 +525,8 @@ def main():
         a.workload = "c3" if world == 1 else "c5"
     if a.mesh is None:
         a.mesh = "1m" if (a.workload == "c5" and world > 1) else "100k"
+    if a.scaling == "strong":
+        a.particles = a.total_particles // world
     if a.particles is None:
         a.particles = (1_000_000 if a.workload == "c4" else
                        32_000_000 if (a.workload == "c5" and world > 1 and a.mesh == "1m") else 10_000_000)
@@ -645,7 +653,7 @@ def main():
             "metric": METRIC[a.workload],
             "value": total_particles * a.steps / dt, "unit": "particles/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic", "clock_prewarm_s": prewarm_s,
             "value_scope": "whole job: particles of all %d rank(s) x steps / max-over-ranks time" % world,
         }

@@ -417,6 +417,9 @@ def test_bench_multi_rank_line_rehearsal(tmp_path, launcher):
                PP_BENCH_CACHE=str(tmp_path))
     args = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--workload", "c5",
             "--mesh", "100k", "--particles", "300000", "--comm", "tcp", "--no-cpu-baseline", "--deg", "4.0"]
+    if launcher == "self":      # (this variant also takes the strong-scaling split: 600 000 over the two ranks)
+        i = args.index("--particles")
+        args[i:i + 2] = ["--scaling", "strong", "--total-particles", "600000"]
     if launcher == "torchrun":  # the driver's way
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                "127.0.0.1", "--master-port", str(port)] + args
@@ -429,6 +432,7 @@ def test_bench_multi_rank_line_rehearsal(tmp_path, launcher):
     assert len(lines) == 1, r.stdout[-2000:]
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 4 and j["warmup"] == 2 and "rehearsal" in j
+    assert j["scaling"] == ("strong" if launcher == "self" else "weak")
     assert j["metric"].startswith("particles pushed+searched+scattered")
     assert "migrate" in j["config"]["workload"] and "tcp" in j["config"]["workload"]
     assert j["rank0_sent_per_step"] > 0                       # particles really crossed between the ranks
