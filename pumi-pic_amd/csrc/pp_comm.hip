@@ -13,6 +13,7 @@
 // and every single-GPU entry point works on boxes without RCCL.
 #include <arpa/inet.h>
 #include <dlfcn.h>
+#include <poll.h>
 #include <netdb.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
@@ -42,21 +43,45 @@ struct RcclApi {
 static RcclApi* rccl() {
   static RcclApi api;
   static bool tried = false;
-  if (tried) return api.handle ? &api : nullptr;
+  static std::string why;  // why the library is unusable (repeated on every later call)
+  if (tried) {
+    if (!api.handle) set_error(why);
+    return api.handle ? &api : nullptr;
+  }
   tried = true;
+  // PP_RCCL_LIB names the library to open instead of the default search list (a site build of RCCL;
+  // tests/test_comm_host_logic.py points it at a file that does not exist)
+  const char* forced = getenv("PP_RCCL_LIB");
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;
-  for (const char* n : names)  // a copy some other component (PyTorch) loaded already comes first
-    if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
-  for (int i = 0; !h && i < 3; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+  std::string last;
+  if (forced && *forced) {
+    h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+      const char* e = dlerror();  // (dlerror() clears the message: read it once)
+      last = e ? e : "?";
+    }
+  } else {
+    for (const char* n : names)  // a copy some other component (PyTorch) loaded already comes first
+      if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    for (int i = 0; !h && i < 3; ++i) {
+      h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+      if (!h) {
+        const char* e = dlerror();
+        last = e ? e : "?";
+      }
+    }
+  }
   if (!h) {
-    set_error(std::string("librccl could not be opened: ") + (dlerror() ? dlerror() : "?"));
+    why = std::string("librccl could not be opened: ") + (last.empty() ? "?" : last);
+    set_error(why);
     return nullptr;
   }
 #define PP_SYM(field, name)                                        \
   api.field = (decltype(api.field))dlsym(h, name);                 \
   if (!api.field) {                                                \
-    set_error(std::string("librccl lacks ") + name);               \
+    why = std::string("librccl lacks ") + name;                    \
+    set_error(why);                                                \
     return nullptr;                                                \
   }
   PP_SYM(GetUniqueId, "ncclGetUniqueId")
@@ -115,6 +140,8 @@ struct TcpStar {
   }
   int fd_of(int r) const { return rank == 0 ? fds[(size_t)r] : fds[0]; }
   int connect_all(const char* addr, int port, double timeout_s = 120.0) {
+    if (const char* t = getenv("PP_COMM_TIMEOUT"))  // seconds; rendezvous deadline of both sides
+      if (atof(t) > 0) timeout_s = atof(t);
     if (nranks <= 1) return PP_OK;
     sockaddr_in sa{};
     sa.sin_family = AF_INET;
@@ -151,14 +178,32 @@ struct TcpStar {
         set_error("tcp bootstrap: rank 0 cannot listen on port " + std::to_string(port));
         return PP_EHIP;
       }
+      // the same deadline the peers' connect loop has: one dead peer must not hang rank 0 for ever
+      const auto t_acc_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s);
       for (int k = 1; k < nranks; ++k) {
+        const double left =
+            std::chrono::duration<double>(t_acc_end - std::chrono::steady_clock::now()).count();
+        pollfd pfd{listen_fd, POLLIN, 0};
+        const int pr = left > 0 ? ::poll(&pfd, 1, (int)std::min(left * 1000.0 + 1.0, 2.0e9)) : 0;
+        if (pr <= 0) {
+          set_error("tcp bootstrap: rank 0 waited " + std::to_string((int)timeout_s) + " s for " +
+                    std::to_string(nranks - k) + " of " + std::to_string(nranks - 1) + " peers");
+          return PP_EHIP;
+        }
         const int fd = ::accept(listen_fd, nullptr, nullptr);
+        if (fd >= 0) {  // a peer that connects and then dies must not block the hello either
+          timeval tv{};
+          tv.tv_sec = (long)std::max(1.0, std::min(left, timeout_s));
+          setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+        }
         int r = -1;
         if (fd < 0 || !recv_all(fd, &r, sizeof(r)) || r <= 0 || r >= nranks || fds[(size_t)r] >= 0) {
           set_error("tcp bootstrap: bad peer hello");
           return PP_EHIP;
         }
         setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+        timeval none{};  // collectives block as long as the slowest rank computes
+        setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &none, sizeof(none));
         fds[(size_t)r] = fd;
       }
     } else {

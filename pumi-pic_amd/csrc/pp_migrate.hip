@@ -412,7 +412,9 @@ static int rebuild_from_records(pp_ps* ps, int m_x, int m_xtgt, const int* new_e
                                 double* const* scatter_w_dev, double rmax, int gnr, int gppr) {
   const bool plain = m_x < 0 && m_xtgt < 0 && nmaps == 0;
   const int n_tot = n_recv + n_extra;
-  if (!gid2lid_dev && ps->has_gids && !ps->gids_identity) {  // the structure's own map (SCS_migrate.h:181-187)
+  // the structure's own map (SCS_migrate.h:181-187) -- needed only to place particles that arrive
+  // (pp_ps_migrate_begin checks the same thing before anything is packed or removed)
+  if (n_recv > 0 && !gid2lid_dev && ps->has_gids && !ps->gids_identity) {
     PP_REQUIRE(ps->n_gid2lid > 0, "migration: the structure's element gids are too sparse for its own gid -> element "
                                   "table -- pass gid2lid_dev");
     gid2lid_dev = ps->d_gid2lid.as<int>();
@@ -539,6 +541,11 @@ static int migrate_begin_rule(pp_ps* ps, int m_x, int m_xtgt, int* new_element_d
   }
   pp::MigratePending& P = comm->pend;
   PP_REQUIRE(!P.active, "pp_ps_migrate_begin: the previous migration on this communicator was not ended");
+  // arrivals travel with their element's gid: with more than one rank the receiver needs a gid -> element
+  // table.  Checked here, before anything is packed or marked as sent.
+  PP_REQUIRE(comm->nranks == 1 || gid2lid_dev || !ps->has_gids || ps->gids_identity || ps->n_gid2lid > 0,
+             "migration: the structure's element gids are too sparse for its own gid -> element table -- pass "
+             "gid2lid_dev");
   pp::Range rg("pp_ps_migrate_begin");
   P = pp::MigratePending();
   P.ps = ps;
@@ -603,6 +610,14 @@ int pp_ps_migrate_end(pp_ps* ps, pp_comm* comm, int* n_sent, int* n_received) {
   PP_REQUIRE(P.active && P.ps == ps, "pp_ps_migrate_end: no migration of this structure was begun on this communicator");
   pp::Range rg("pp_ps_migrate_end");
   P.active = false;
+  // a virtual rank leaves the round on EVERY exit path: a failed exchange must not leave the
+  // channel's begun[] flags set, or every later pp_ps_migrate_begin on that world fails
+  struct LocalRoundGuard {
+    pp_comm* c;
+    ~LocalRoundGuard() {
+      if (c->kind == 4) pp::local_ended(c->world.get(), c->rank);
+    }
+  } round_guard{comm};
   int rc;
   int64_t nrecv = 0;
   void* d_recv = nullptr;
@@ -621,7 +636,6 @@ int pp_ps_migrate_end(pp_ps* ps, pp_comm* comm, int* n_sent, int* n_received) {
   rc = rebuild_from_records(ps, P.m_x, P.m_xtgt, P.new_element, (int)nrecv, d_recv, P.gid2lid, P.ngids, P.n_new,
                             P.new_elems, P.new_info, P.mesh, P.nmaps, P.v2v.data(), P.outs.data(), P.rmax,
                             P.gnr, P.gppr);
-  if (comm->kind == 4) pp::local_ended(comm->world.get(), comm->rank);
   return rc;
 }
 

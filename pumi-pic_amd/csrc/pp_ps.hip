@@ -3170,8 +3170,11 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     ps->shuffle_mode = mode;
     if (rc < 0) return rc;
     if (rc == 1) return PP_OK;
-    // cannot happen for data the in-place path supports; members it cannot stage (1/2-byte scalars) land
-    // here: full re-layout after all, without the decision
+    // The histogram's test is the loose one (new count <= chunk width); the reference's rule counts a row's
+    // holes BEFORE its movers leave (SCS_rebuild.h:13-25), which scs_reshuffle evaluates exactly.  Loose but not
+    // strict (two full rows exchanging particles: small structures) and members the in-place path cannot
+    // stage (1/2-byte scalars) land here: full re-layout after all, without the decision -- correct, at the
+    // price of a second histogram + sort + layout for that rebuild.
     return scs_rebuild(ps, new_element, n_new, new_elems, new_info, commit_x, commit_xt,
                        std::function<int(const int*)>(), false);
   }

@@ -1855,9 +1855,17 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
   PP_REQUIRE(ps->num_elems == mesh->nelems, "pp_push_search: structure/mesh element mismatch");
   int rc;
   // x_tgt left "logically zero" by the in-place rebuild's fused updatePtclPositions: the 3-D push
-  // overwrites all three components of every live particle, so the zeros are never written
-  if (mesh->dim == 3 && m_xtgt >= 0 && m_xtgt < ps->nmembers && m_x != m_xtgt &&
-      ps->zero_pending == ps->member_map[m_xtgt])
+  // overwrites all three components of every live particle, so the zeros are never written.  The
+  // flag is dropped only for a call that will run (arguments of the right shape, a 3-component
+  // target); anything else goes through member_ok -> ps_ready, which writes the zeros, and a call
+  // that fails validation leaves the structure as it was.
+  const auto shape_ok = [&](int m, int bytes, int ncomp) {
+    return m >= 0 && m < ps->nmembers && ps->member_bytes[ps->member_map[m]] == bytes &&
+           ps->member_ncomp[ps->member_map[m]] == ncomp;
+  };
+  if (mesh->dim == 3 && m_x != m_xtgt && shape_ok(m_x, 8, 3) && shape_ok(m_xtgt, 8, 3) && shape_ok(m_b, 4, 1) &&
+      shape_ok(m_phi, 4, 1) && ps->zero_pending == ps->member_map[m_xtgt] && ps->zero_pending != ps->member_map[m_x] &&
+      ps->capacity > 0 && ps->num_ptcls > 0)
     ps->zero_pending = -1;
   if ((rc = member_ok(ps, m_x, 8, 3, "pp_push_search x"))) return rc;
   if ((rc = member_ok(ps, m_xtgt, 8, 3, "pp_push_search x_tgt"))) return rc;

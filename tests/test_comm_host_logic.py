@@ -141,3 +141,55 @@ def test_single_rank_env_communicator(pp, monkeypatch):
     assert c.kind() == "self" and c.size() == 1 and c.rank() == 0
     assert list(c.exchange_counts([4])) == [4]
     c.destroy()
+
+
+def test_missing_librccl_is_an_error_not_a_crash():
+    """A box without (a usable) librccl: pp_comm_unique_id / pp_comm_create_rccl must fail with a
+    message (the library's 'works without RCCL' contract, bench.py's fallback to --comm torch relies on
+    it) -- not die inside strlen(NULL) because dlerror() was consumed twice.  Runs in a child process:
+    the loader remembers its verdict for the life of the process."""
+    import subprocess
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+os.environ["PP_RCCL_LIB"] = "/nonexistent/librccl_not_here.so"
+import pumipic_amd_loader
+pumipic_amd_loader.load()
+from pumipic_amd import capi
+for attempt in range(2):   # the second call takes the 'already tried' branch
+    try:
+        capi.Comm.unique_id()
+    except capi.PPError as e:
+        assert "librccl could not be opened" in str(e) and "librccl_not_here" in str(e), str(e)
+    else:
+        raise SystemExit("pp_comm_unique_id succeeded without a library")
+print("ok")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout, r.stderr[-2000:])
+
+
+def test_tcp_rank0_gives_up_on_a_peer_that_never_comes():
+    """rank 0 of the built-in TCP transport accepts with the same deadline its peers connect with:
+    a rank that died before the rendezvous is an error after PP_COMM_TIMEOUT seconds, not a hang."""
+    import subprocess
+    import time
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+os.environ["PP_COMM_TIMEOUT"] = "2"
+import pumipic_amd_loader
+pumipic_amd_loader.load()
+from pumipic_amd import capi
+try:
+    capi.Comm.tcp("127.0.0.1", %d, 0, 2)
+except capi.PPError as e:
+    assert "waited" in str(e) and "peers" in str(e), str(e)
+    print("ok")
+else:
+    raise SystemExit("a 2-rank communicator formed with one rank")
+""" % (ROOT, _free_port())
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout, r.stderr[-2000:])
+    assert time.time() - t0 < 60
