@@ -212,6 +212,21 @@ struct pp_ps {
   // the fused push starts from (true when the structure was rebuilt from, or the ids are, the unmodified
   // result of the previous search): check_initial_parents is skipped
   bool trust_origins = false;
+  // ---- resident records (pp_ps_set_resident_records, DESIGN "Resident records").  A structure whose
+  // particle type is the 60-byte pseudoXGCm one (double[3], double[3], 4-byte, 4-byte, 4-byte) can keep
+  // its particles as one 64-B record per slot -- x | x_tgt | m2 | m3 | m4 | aux -- between the fused
+  // entry points: pp_push_search reads and updates the records in place and counts the new parents,
+  // the rebuild is ONE pass (record read in slot order, committed record written to its new slot).
+  // While rec_resident is set the SoA arrays in `data` are stale; every other entry point goes through
+  // ps_ready(), which writes them back first.
+  int rec_mode = 0;           // 0 = never, 1 = use records where the particle type allows it
+  bool rec_resident = false;  // d_rec holds the particles
+  pp::DevBuf d_rec, s_rec;    // records of the live layout / destination of the next rebuild
+  pp::DevBuf d_runbase;       // first rank of the stayers of every (tile,row) thread of the last fused push
+  // the histogram in s_ppe (+ ranks in the records' aux words) was made by the last fused push from the
+  // ids at `fused_ids`; a rebuild that is handed the same ids skips its counting pass
+  bool fused_count_valid = false;
+  const int* fused_ids = nullptr;
   pp::DevBuf s_rs, s_holes, s_rsx;  // in-place rebuild: per-element counters, per-row hole lists, elastic lists
   // scratch reused across rebuilds
   pp::DevBuf s_ppe, s_keys, s_keys2, s_vals, s_vals2, s_hist, s_chunkw, s_misc, s_rowstart,
@@ -288,8 +303,15 @@ namespace pp {
 // entry point that reads or exposes member data calls this first
 int ps_materialize(pp_ps* ps);
 inline int ps_ready(const pp_ps* ps) {
-  return (ps && ps->zero_pending >= 0) ? ps_materialize(const_cast<pp_ps*>(ps)) : PP_OK;
+  return (ps && (ps->zero_pending >= 0 || ps->rec_resident)) ? ps_materialize(const_cast<pp_ps*>(ps)) : PP_OK;
 }
+// pp_ps.hip, resident records.  rec_usable: the structure may run the fused push on records with these
+// member roles.  rec_begin_push: makes the records current (packs the SoA arrays once), clears the
+// histogram the push is about to fill and hands out the device pointers.
+constexpr int kRecBytes = 64;
+constexpr unsigned kRecAuxLocal = 0x80000000u;  // aux = this flag | index among the stayers of the thread's run
+bool rec_usable(const pp_ps* ps, int m_x, int m_xtgt, int m_b, int m_phi);
+int rec_begin_push(pp_ps* ps, const int* ids_dev, char** rec, const int** elem_count, int** ppe, int** run_base);
 // pp_scatter.hip: gyroScatter for `nmaps` ring maps from an explicit per-element count array (the
 // histogram of a rebuild that is still in flight); forgets the ring accumulation kept for reuse.
 int gyro_scatter_counts(const pp_mesh* mesh, const int* cnt_dev, int nmaps, const int* const* v2v_dev,

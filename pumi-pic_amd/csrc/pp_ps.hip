@@ -213,6 +213,9 @@ struct Totals {  // s_misc layout
   int sort_parity;
 };
 
+// histogram and totals of a rebuild share one allocation (one fill clears both): the totals sit here
+size_t hist_tot_off(int ne) { return (sizeof(int) * (size_t)std::max(ne, 1) + 255) / 256 * 256; }
+
 __global__ void k_count_added(int n_new, const int* __restrict__ new_elems, int ne,
                               int* __restrict__ ppe, Totals* tot, int* __restrict__ rank_new) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1519,6 +1522,125 @@ __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
       if (i < t.nz8) __builtin_nontemporal_store(0ull, (unsigned long long*)(t.z8[i] + (long long)slot * 8));
       if (i < t.nz4) __builtin_nontemporal_store(0u, (unsigned*)(t.z4[i] + (long long)slot * 4));
     }
+  }
+}
+// ---- resident records (pp_internal.hpp, DESIGN "Resident records"): 64 B per slot,
+//   bytes 0-23 member 0 (double[3]) | 24-47 member 1 (double[3]) | 48 member 2 | 52 member 3 | 56 member 4 | 60 aux
+// SoA -> records in slot order (once, when the fused push first sees the structure) and back (any
+// other entry point: ps_materialize)
+struct RecSoA {
+  unsigned long long* m0;
+  unsigned long long* m1;
+  unsigned* m2;
+  unsigned* m3;
+  unsigned* m4;
+  long long stride;
+};
+__global__ void k_rec_from_soa(int capacity, const unsigned char* __restrict__ mask, RecSoA a,
+                               uint4* __restrict__ rec) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity || !mask[pid]) return;
+  unsigned long long x[3], t[3];
+  for (int c = 0; c < 3; ++c) {
+    x[c] = a.m0[c * a.stride + pid];
+    t[c] = a.m1[c * a.stride + pid];
+  }
+  uint4* r = rec + (long long)pid * 4;
+  r[0] = make_uint4((unsigned)x[0], (unsigned)(x[0] >> 32), (unsigned)x[1], (unsigned)(x[1] >> 32));
+  r[1] = make_uint4((unsigned)x[2], (unsigned)(x[2] >> 32), (unsigned)t[0], (unsigned)(t[0] >> 32));
+  r[2] = make_uint4((unsigned)t[1], (unsigned)(t[1] >> 32), (unsigned)t[2], (unsigned)(t[2] >> 32));
+  r[3] = make_uint4(a.m2[pid], a.m3[pid], a.m4[pid], 0u);
+}
+__global__ void k_rec_to_soa(int capacity, const unsigned char* __restrict__ mask, RecSoA a,
+                             const uint4* __restrict__ rec) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity || !mask[pid]) return;
+  const uint4* r = rec + (long long)pid * 4;
+  const uint4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
+  a.m0[pid] = ((unsigned long long)q0.y << 32) | q0.x;
+  a.m0[a.stride + pid] = ((unsigned long long)q0.w << 32) | q0.z;
+  a.m0[2 * a.stride + pid] = ((unsigned long long)q1.y << 32) | q1.x;
+  a.m1[pid] = ((unsigned long long)q1.w << 32) | q1.z;
+  a.m1[a.stride + pid] = ((unsigned long long)q2.y << 32) | q2.x;
+  a.m1[2 * a.stride + pid] = ((unsigned long long)q2.w << 32) | q2.z;
+  a.m2[pid] = q3.x;
+  a.m3[pid] = q3.y;
+  a.m4[pid] = q3.z;
+}
+// The rebuild's ONE data pass on records: thread = (old tile, row) reads the records of its row's
+// columns (64 consecutive records per wave instruction), finds every live particle's new slot -- first
+// slot of the new row of its element + rank * C, the rank from the fused push (pp_search.hip:
+// k_push_walk_rec) -- and the wave writes the (committed) records there through an LDS transpose, four
+// adjacent lanes one whole 64-B record.  COMMIT: updatePtclPositions rides along (x <- x_tgt, x_tgt <- 0).
+template <bool COMMIT>
+__global__ void __launch_bounds__(256)
+    k_move_rec(const int* __restrict__ ntiles_dev, int C, int TP, const int* __restrict__ tiles,
+               const int* __restrict__ chunk_start, const int* __restrict__ chunk_width,
+               const int* __restrict__ r2e, const int* __restrict__ count_old, int ne,
+               const int* __restrict__ new_element, const int* __restrict__ run_base,
+               const int* __restrict__ eslot0_new, int C_new, const uint4* __restrict__ rec_old,
+               uint4* __restrict__ rec_new, const int* __restrict__ go) {
+  if (!*go) return;
+  __shared__ uint4 st[4][64][5];
+  __shared__ int sd[4][64];
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int tile = (int)(g / C), r = (int)(g - (long long)tile * C);
+  const bool valid = tile < *ntiles_dev;
+  int start = 0, p0 = 0, plive = 0, base = 0;
+  if (valid) {
+    const int c = tiles[2 * tile];
+    p0 = tiles[2 * tile + 1];
+    start = chunk_start[c] + r;
+    const int e = r2e[c * C + r];
+    plive = min(min(p0 + TP, chunk_width[c]), e < ne ? count_old[e] : 0);  // live columns end here
+    base = run_base[g];
+  }
+  int nmax = plive - p0;  // columns this wave has to visit: the longest of its rows
+  for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+  for (int i = 0; i < nmax; ++i) {  // wave-uniform trip count
+    const int pid = start + (p0 + i) * C;
+    int dst = -1;
+    if (p0 + i < plive) {
+      const int ne_ = new_element[pid];
+      if (ne_ >= 0) {
+        const uint4* rp = rec_old + (long long)pid * 4;
+        const uint4 q1 = rp[1], q2 = rp[2], q3 = rp[3];
+        const unsigned aux = q3.w;
+        const int rank = (aux & pp::kRecAuxLocal) ? base + (int)(aux & ~pp::kRecAuxLocal) : (int)aux;
+        dst = eslot0_new[ne_] + rank * C_new;
+        if (COMMIT) {
+          st[w][l][0] = make_uint4(q1.z, q1.w, q2.x, q2.y);
+          st[w][l][1] = make_uint4(q2.z, q2.w, 0u, 0u);
+          st[w][l][2] = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+          st[w][l][0] = rp[0];
+          st[w][l][1] = q1;
+          st[w][l][2] = q2;
+        }
+        st[w][l][3] = make_uint4(q3.x, q3.y, q3.z, 0u);
+      }
+    }
+    sd[w][l] = dst;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int item = j * 64 + l, rc = item >> 2, part = item & 3;
+      const int d = sd[w][rc];
+      if (d >= 0) {
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        const uint4 x = st[w][rc][part];
+        v4u y;
+        y.x = x.x;
+        y.y = x.y;
+        y.z = x.z;
+        y.w = x.w;
+        __builtin_nontemporal_store(y, (v4u*)(rec_new + (long long)d * 4 + part));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 // CSR staged move (same two passes as SCS): slot assignment by the element cursor, pack through
@@ -2861,8 +2983,15 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   hipStream_t st = pp::stream();
   const int ne = ps->num_elems;
   PP_REQUIRE(n_new == 0 || new_info != nullptr, "rebuild: new particles need new_info_dev");
-  {
-    int rc0 = pp::ps_ready(ps);  // zeros left pending by the previous in-place rebuild
+  // Resident records: the fused push left the histogram of `new_element` in s_ppe and every particle's
+  // rank in its record -- the rebuild is the layout chain + ONE data pass (k_move_rec).  Anything else
+  // (other ids, new particles, a commit of other members) goes back to the SoA arrays first.
+  const bool rec = ps->rec_resident && ps->fused_count_valid && ps->fused_ids == new_element && n_new == 0 &&
+                   ps->shuffle_mode != 2 && ps->capacity > 0 && ps->num_ptcls > 0 &&
+                   ((commit_x == 0 && commit_xt == 1) || (commit_x < 0 && commit_xt < 0));
+  ps->fused_count_valid = false;  // consumed (or stale) either way
+  if (!rec) {
+    int rc0 = pp::ps_ready(ps);  // records -> SoA; zeros left pending by the previous in-place rebuild
     if (rc0) return rc0;
   }
   pp::Range rg("scs_rebuild");
@@ -2887,9 +3016,11 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
                        scattered ? std::function<int(const int*)>() : pre_sync, false);
   }
   // histogram and totals in one allocation: one fill clears both (a fill is a ~5 us dispatch)
-  const size_t tot_off = (sizeof(int) * (size_t)std::max(ne, 1) + 255) / 256 * 256;
-  PP_HIP_CHECK(ps->s_ppe.reserve(tot_off + sizeof(Totals)));
-  PP_HIP_CHECK(hipMemsetAsync(ps->s_ppe.p, 0, tot_off + sizeof(Totals), st));
+  const size_t tot_off = hist_tot_off(ne);
+  if (!rec) {
+    PP_HIP_CHECK(ps->s_ppe.reserve(tot_off + sizeof(Totals)));
+    PP_HIP_CHECK(hipMemsetAsync(ps->s_ppe.p, 0, tot_off + sizeof(Totals), st));
+  }
   Totals* tot = (Totals*)((char*)ps->s_ppe.p + tot_off);
   int* ppe = ps->s_ppe.as<int>();
   const bool have_old = ps->capacity > 0 && ps->num_ptcls > 0;
@@ -2902,7 +3033,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   PP_HIP_CHECK(ps->s_ranknew.reserve(sizeof(int) * (size_t)std::max(n_new, 1)));
   int* rank = ps->s_idx.as<int>();
   int* rank_new = ps->s_ranknew.as<int>();
-  if (have_old && old_grid > 0)
+  if (have_old && old_grid > 0 && !rec)
     k_count_tiled<<<grp_grid, kBlock, 0, st>>>(
         ps->d_ntiles.as<int>(), ps->C, ps->tile_p, G, ps->d_tiles.as<int>(),
         ps->d_chunk_start.as<int>(), ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(),
@@ -3012,8 +3143,12 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     long long sq = fit / 64;
     while (sq > 0 && sq % 32 != 17) --sq;
     stride_fit = sq * 64;
-    cap_lim = std::min<long long>(cap_lim, stride_fit);
-    if (cap_lim > 0 && getenv("PP_DIRECT_MOVE") == nullptr) {  // staging buffer: NQ quads per slot
+    if (rec) {  // the move writes records, not the swap arrays
+      stride_fit = ps->swap_stride;
+      cap_lim = std::min<long long>(cap_lim, (long long)(ps->s_rec.bytes / pp::kRecBytes));
+    } else
+      cap_lim = std::min<long long>(cap_lim, stride_fit);
+    if (!rec && cap_lim > 0 && getenv("PP_DIRECT_MOVE") == nullptr) {  // staging buffer: NQ quads per slot
       const void* srcs[8];
       for (int m = 0; m < ps->nmembers; ++m) srcs[m] = ps->data[m].p;
       WordTable wt_probe{};
@@ -3054,6 +3189,19 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
         new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_r2e2.as<int>(),
         ppe, ne, ps->s_slot2.as<int>(), ps->s_rowstart.as<int>(), ps->s_eslot0.as<int>(),
         ps->s_mask2.as<unsigned char>(), go);
+    if (rec) {  // ---- resident records: one pass, old records -> committed records at their new slots
+      PP_HIP_CHECK(ps->s_rec.reserve((size_t)std::max(cap_sz, 1) * pp::kRecBytes));
+#define PP_MOVE_REC_ARGS                                                                                        \
+  ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(),                \
+      ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(), ps->d_elem_count.as<int>(), ne, new_element, \
+      ps->d_runbase.as<int>(), ps->s_eslot0.as<int>(), C_new, ps->d_rec.as<uint4>(), ps->s_rec.as<uint4>(), go
+      if (commit_x >= 0)
+        k_move_rec<true><<<old_grid, kBlock, 0, st>>>(PP_MOVE_REC_ARGS);
+      else
+        k_move_rec<false><<<old_grid, kBlock, 0, st>>>(PP_MOVE_REC_ARGS);
+#undef PP_MOVE_REC_ARGS
+      return PP_OK;
+    }
     // ---- swap buffer sizing (SCS_rebuild.h:223-229)
     int64_t swap_stride = ps->swap_stride;
     if (stride_fixed > 0) {  // speculative tail: whatever the swap buffers hold today
@@ -3164,6 +3312,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     // speculative re-layout tail did not run (k_spec_check); the in-place path does the work.  Rare at
     // scale (some row of 10^5 overflows its padding nearly every step), common for small structures.
     ps->swap_stride = swap_stride_before;
+    if (rec && (rc = pp::ps_ready(ps))) return rc;  // the in-place path works on the SoA arrays
     const int mode = ps->shuffle_mode;
     rc = scs_reshuffle(ps, new_element, n_new, new_elems, new_info, commit_x, commit_xt,
                        std::function<int(const int*)>());  // (the scatters ran behind the histogram above)
@@ -3180,6 +3329,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   }
   if (h.active == 0) {  // SCS_rebuild.h:168-182: no particle left -- resetMask, structure kept
     ps->swap_stride = swap_stride_before;
+    if (rec && (rc = pp::ps_ready(ps))) return rc;
     // the fused commit still happens: the drivers call updatePtclPositions before the rebuild
     if (commit_x >= 0 && commit_xt >= 0 && ps->num_ptcls > 0) {
       rc = pp_update_positions(ps, commit_x, commit_xt);
@@ -3229,9 +3379,15 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   ntiles_max = nchunks + new_capacity / (C_new * ps->tile_p) + 1;  // launch bound of the next calls
   PP_LAUNCH_CHECK();
   // ---- swap in
-  ps->data.swap(ps->swap);
-  std::swap(ps->stride, ps->swap_stride);
-  ps->zero_pending = lazy_zero ? commit_xt : -1;
+  if (rec) {
+    ps->d_rec.swap(ps->s_rec);  // (the SoA arrays stay stale: rec_resident)
+    ps->swap_stride = swap_stride_before;
+    ps->zero_pending = -1;
+  } else {
+    ps->data.swap(ps->swap);
+    std::swap(ps->stride, ps->swap_stride);
+    ps->zero_pending = lazy_zero ? commit_xt : -1;
+  }
   ps->d_offsets.swap(ps->s_offsets2);
   ps->d_slice_to_chunk.swap(ps->s_s2c2);
   ps->d_row_to_element.swap(ps->s_r2e2);
@@ -3392,12 +3548,72 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
 }  // namespace
 
 namespace pp {
+static RecSoA rec_soa(const pp_ps* ps) {
+  RecSoA a;
+  a.m0 = ps->data[0].as<unsigned long long>();
+  a.m1 = ps->data[1].as<unsigned long long>();
+  a.m2 = ps->data[2].as<unsigned>();
+  a.m3 = ps->data[3].as<unsigned>();
+  a.m4 = ps->data[4].as<unsigned>();
+  a.stride = ps->stride;
+  return a;
+}
 int ps_materialize(pp_ps* ps) {
+  if (ps->rec_resident) {
+    // the particles live in the 64-B records: write the SoA arrays back (the capacity may have grown
+    // while nobody looked at them)
+    ps->rec_resident = false;
+    ps->fused_count_valid = false;
+    if (ps->capacity > 0) {
+      if (ps->stride < ps->capacity || (int)ps->data.size() < ps->nmembers) {
+        const int64_t stride = spread_stride((int64_t)(ps->capacity * (1 + ps->extra_padding)) + growth_reserve(ps, ps->capacity));
+        int rc = alloc_members(ps, ps->data, stride, true);
+        if (rc) return rc;
+        ps->stride = stride;
+      }
+      k_rec_to_soa<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
+          ps->capacity, ps->d_mask.as<unsigned char>(), rec_soa(ps), ps->d_rec.as<uint4>());
+      PP_LAUNCH_CHECK();
+    }
+  }
   const int s = ps->zero_pending;
   if (s < 0) return PP_OK;
   ps->zero_pending = -1;
   const size_t bytes = (size_t)ps->stride * ps->member_ncomp[s] * ps->member_bytes[s];
   if (bytes) PP_HIP_CHECK(hipMemsetAsync(ps->data[s].p, 0, bytes, pp::stream()));
+  return PP_OK;
+}
+bool rec_usable(const pp_ps* ps, int m_x, int m_xtgt, int m_b, int m_phi) {
+  if (!ps || ps->kind != PP_SCS || ps->nmembers != 5 || !ps->elem_count_valid || ps->shuffle_mode == 2) return false;
+  static const int want_b[5] = {8, 8, 4, 4, 4}, want_c[5] = {3, 3, 1, 1, 1};
+  for (int m = 0; m < 5; ++m)
+    if (ps->member_map[m] != m || ps->member_bytes[m] != want_b[m] || ps->member_ncomp[m] != want_c[m]) return false;
+  return m_x == 0 && m_xtgt == 1 && m_b == 3 && m_phi == 4;
+}
+int rec_begin_push(pp_ps* ps, const int* ids_dev, char** rec, const int** elem_count, int** ppe, int** run_base) {
+  hipStream_t st = pp::stream();
+  if (!ps->rec_resident) {
+    if (ps->zero_pending >= 0) {
+      int rc = ps_materialize(ps);  // (a 2-D push does not overwrite every component of x_tgt)
+      if (rc) return rc;
+    }
+    PP_HIP_CHECK(ps->d_rec.reserve((size_t)ps->capacity * kRecBytes));
+    k_rec_from_soa<<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, ps->d_mask.as<unsigned char>(),
+                                                             rec_soa(ps), ps->d_rec.as<uint4>());
+    PP_LAUNCH_CHECK();
+    ps->rec_resident = true;
+  }
+  // histogram + totals of the rebuild that follows (scs_rebuild): cleared here, filled by the push
+  const size_t tot_off = hist_tot_off(ps->num_elems);
+  PP_HIP_CHECK(ps->s_ppe.reserve(tot_off + sizeof(Totals)));
+  PP_HIP_CHECK(hipMemsetAsync(ps->s_ppe.p, 0, tot_off + sizeof(Totals), st));
+  PP_HIP_CHECK(ps->d_runbase.reserve(sizeof(int) * ((size_t)ps->ntiles_max * ps->C + 256)));
+  *rec = ps->d_rec.as<char>();
+  *elem_count = ps->d_elem_count.as<int>();
+  *ppe = ps->s_ppe.as<int>();
+  *run_base = ps->d_runbase.as<int>();
+  ps->fused_count_valid = true;
+  ps->fused_ids = ids_dev;
   return PP_OK;
 }
 }  // namespace pp
@@ -3608,6 +3824,20 @@ int pp_ps_swap_members(pp_ps* ps, int a, int b) {
   return PP_OK;
 }
 
+int pp_ps_set_resident_records(pp_ps* ps, int on) {
+  PP_REQUIRE(ps, "pp_ps_set_resident_records: null ps");
+  if (!on && ps->rec_resident)
+    if (int rc = pp::ps_ready(ps)) return rc;
+  ps->rec_mode = on ? 1 : 0;
+  return PP_OK;
+}
+int pp_ps_resident_records(const pp_ps* ps) { return ps ? (ps->rec_resident ? 2 : ps->rec_mode) : 0; }
+int pp_ps_ids_modified(pp_ps* ps) {
+  PP_REQUIRE(ps, "pp_ps_ids_modified: null ps");
+  ps->fused_count_valid = false;
+  return PP_OK;
+}
+
 int pp_ps_set_shuffling(pp_ps* ps, int mode) {
   PP_REQUIRE(ps && mode >= 0 && mode <= 2, "pp_ps_set_shuffling: mode must be 0, 1 or 2");
   ps->shuffle_mode = mode;
@@ -3683,7 +3913,8 @@ int pp_ps_rebuild(pp_ps* ps, const int* new_element_dev, int n_new, const int* n
   pp::Range rg_("ps_rebuild");
   PP_REQUIRE(ps && (new_element_dev || ps->capacity == 0), "pp_ps_rebuild: null argument");
   PP_REQUIRE(n_new >= 0 && (n_new == 0 || new_elems_dev), "pp_ps_rebuild: bad new particles");
-  if (int rc = pp::ps_ready(ps)) return rc;
+  if (!ps->rec_resident)  // (resident records: scs_rebuild decides whether it can stay on them)
+    if (int rc = pp::ps_ready(ps)) return rc;
   // storage order of members may be permuted by pp_ps_swap_members: normalise first
   for (int m = 0; m < ps->nmembers; ++m)
     if (ps->member_map[m] != m) {

@@ -1279,7 +1279,8 @@ __device__ __forceinline__ int seed_of(const PState& s, int e, int seeded, int n
 template <int DIM>
 __device__ __forceinline__ void walk_pending(const PendEntry* __restrict__ regions, long long region_stride,
                                              int nreg, int my_cnt, const void* __restrict__ recs,
-                                             int* elem_ids, int cap, Counters* cnt, double2* st, int lane) {
+                                             int* elem_ids, int cap, Counters* cnt, double2* st, int lane,
+                                             char* prec = nullptr, int* ppe = nullptr) {
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   int reg = 0, off = 0;  // wave-uniform cursor
   int reg_cnt = __shfl(my_cnt, 0);
@@ -1332,6 +1333,10 @@ __device__ __forceinline__ void walk_pending(const PendEntry* __restrict__ regio
       }
       if (fin) {
         elem_ids[en.pid] = welem;
+        // resident records: the particle's rank in its new row is the histogram's old count; it
+        // rides in the record's aux word to the rebuild
+        if (ppe && welem >= 0)
+          *(unsigned*)(prec + (long long)en.pid * pp::kRecBytes + 60) = (unsigned)atomicAdd(&ppe[welem], 1);
         on = false;
       }
     }
@@ -1510,7 +1515,7 @@ template <int DIM>
 __global__ void __launch_bounds__(256, 4)
     k_walk_pending(int nwaves, int TP, int G, const PendEntry* __restrict__ gq,
                    const int* __restrict__ wave_cnt, const void* __restrict__ recs, int* elem_ids,
-                   int looplimit, Counters* cnt) {
+                   int looplimit, Counters* cnt, char* prec = nullptr, int* ppe = nullptr) {
   constexpr int NP = DIM == 3 ? 8 : 4;
   __shared__ double2 st_all[4 * 64 * NP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1519,7 +1524,216 @@ __global__ void __launch_bounds__(256, 4)
   const int nreg = (int)min((long long)G, nwaves - r0);
   const int my_cnt = lane < nreg ? wave_cnt[r0 + lane] : 0;  // lane i holds the count of region i
   walk_pending<DIM>(gq + r0 * 64 * TP, 64ll * TP, nreg, my_cnt, recs, elem_ids,
-                    looplimit ? looplimit : kHardLoopCap, cnt, st_all + wave * 64 * NP, lane);
+                    looplimit ? looplimit : kHardLoopCap, cnt, st_all + wave * 64 * NP, lane, prec, ppe);
+}
+
+// ------------------------------------------------------------------ fused kernel on resident records
+// (DESIGN "Resident records").  Same thread = (tile,row) mapping, thin tiles, register-cached row record
+// and deferred walk as k_push_walk_rowsq, for the flow that rebuilds after every search (every particle
+// starts in its row's element, so the row's record is fetched once per thread).  What differs:
+//   * the particle state is ONE 64-B record per slot: x | x_tgt | m2 | b | phi | aux.  A column reads
+//     x, b, phi of 64 consecutive records and writes x_tgt, phi and aux back in place;
+//   * liveness comes from the per-element counts (rows are prefix-compact): no mask stream;
+//   * the histogram of the new parents is made here.  A particle that stays in its row's element gets
+//     aux = kRecAuxLocal | its index among the stayers of this thread's run, the run's first rank comes
+//     from ONE returning atomic per thread (run_base[thread]); a particle that crosses is counted by
+//     k_walk_pending when its walk ends (aux = rank).  The rebuild needs no counting pass.
+struct RecPushArgs {
+  char* rec;
+  const int* elem_count;  // live particles per element (current layout)
+  int* ppe;               // histogram of the new parents, zero on entry
+  int* run_base;          // [ntiles_max * C]
+};
+__device__ __forceinline__ PState load_state_rec(const char* rp) {
+  PState s;
+  const double2 q0 = *(const double2*)rp;
+  s.x = q0.x;
+  s.y = q0.y;
+  s.z = *(const double*)(rp + 16);
+  const float4 q3 = *(const float4*)(rp + 48);  // m2 | b | phi | aux
+  s.b = q3.y;
+  s.phi = q3.z;
+  s.m = 1;
+  s.elem = -1;
+  return s;
+}
+// push + parent check + first walk step of one live particle; x_tgt goes to the record.  Returns true
+// when the particle crossed into `elem` (to be finished by the second pass); `rad` = the new phase.
+template <int DIM>
+__device__ __forceinline__ bool column_math_rec(const WalkArgs& A, char* rp, const PState& s,
+                                                const ppm::ClassTerm& ct, const RecCache<DIM>& cache,
+                                                int& elem, V3& dest, float& rad_out) {
+  double rad;
+  bool done = false;
+  bool origin_ok = true;
+  if constexpr (DIM == 2) {
+    ppm::elliptical_point(ct, s.phi, s.b, A.h, A.k, A.d, dest.x, dest.y, rad);
+    dest.z = 0;
+    *(double*)(rp + 24) = dest.x;
+    *(double*)(rp + 32) = dest.y;
+  } else {
+    origin_ok = (A.abl & 8) || inside_cached(cache, V3{s.x, s.y, s.z}, A.tol);
+    ppm::toroidal_point(ct, s.phi, s.b, s.x, s.y, A.h, A.k, A.d, dest.x, dest.y, dest.z, rad);
+    *(double*)(rp + 24) = dest.x;
+    *(double2*)(rp + 32) = double2{dest.y, dest.z};
+    const V3 dv = sub(dest, V3{s.x, s.y, s.z});
+    if (dot(dv, dv) < A.unmoved_sq) {  // finishUnmoved (k_push_walk_rows)
+      if (A.abl & 8) atomicAdd(&A.cnt->unmoved, 1);
+      done = true;
+    }
+  }
+  rad_out = (float)rad;
+  if (!done && !origin_ok) {  // check_initial_parents (tpp:72-145)
+    atomicAdd(&A.cnt->not_in_elem, 1);
+    elem = -1;
+    done = true;
+  }
+  if (!done) {  // first walk step on the cached record
+    int next;
+    if (step_cached(cache, dest, next)) {
+      done = true;
+    } else if (next == -1) {
+      elem = -1;
+      done = true;
+    } else {
+      elem = next;
+      if (1 >= A.cap) {
+        elem = -1;
+        atomicAdd(&A.cnt->not_found, 1);
+        done = true;
+      }
+    }
+  }
+  return !done;
+}
+template <int DIM, int OCC>
+__global__ void __launch_bounds__(256, OCC)
+    k_push_walk_rec(const int* __restrict__ ntiles_dev, int C, int TP, const int* __restrict__ tiles,
+                    const int* __restrict__ chunk_start, const int* __restrict__ chunk_width,
+                    const int* __restrict__ r2e, const void* __restrict__ recs,
+                    const int* __restrict__ class_id, int nelems, RecPushArgs R, double h, double k, double d,
+                    double deg, double tol, double unmoved_sq, int* elem_ids, int looplimit, Counters* cnt,
+                    PendEntry* gq, int* wave_cnt, Counters* cnt_next, int abl) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *cnt_next = Counters{};  // for the next pp_push_search
+  constexpr int NP = DIM == 3 ? 8 : 4;
+  extern __shared__ double2 lds_dyn[];
+  double2* st = lds_dyn + (size_t)(threadIdx.x >> 6) * 64 * NP;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  int qn = 0;  // wave-uniform number of queue entries written by this wave
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long gwave = g >> 6;
+  PendEntry* wq = gq + gwave * 64 * TP;
+  const int tile = (int)(g / C);
+  const int r = (int)(g - (long long)tile * C);
+  const bool valid = tile < *ntiles_dev;
+  int start = 0, p0 = 0, pend = 0, e = 0, nrow = 0;  // nrow = live particles of this row
+  if (valid) {
+    const int c = tiles[2 * tile];
+    p0 = tiles[2 * tile + 1];
+    start = chunk_start[c] + r;
+    pend = min(p0 + TP, chunk_width[c]);
+    e = r2e[c * C + r];
+    nrow = e < nelems ? R.elem_count[e] : 0;
+  }
+  const ppm::ClassTerm ct = ppm::class_term((valid && e < nelems) ? class_id[e] : 1, deg, DIM == 3);
+  WalkArgs A;
+  A.xt = nullptr;
+  A.stride = 0;
+  A.pphi = nullptr;
+  A.h = h;
+  A.k = k;
+  A.d = d;
+  A.tol = tol;
+  A.unmoved_sq = unmoved_sq;
+  A.elem_ids = elem_ids;
+  A.seeded = 0;
+  A.nelems = nelems;
+  A.cap = looplimit ? looplimit : kHardLoopCap;
+  A.cnt = cnt;
+  A.abl = abl;
+  RecCache<DIM> cache;
+  cache.id = -1;
+  const bool alive0 = valid && p0 < pend && p0 < nrow;  // rows fill from column 0
+  const unsigned long long live0 = __ballot(alive0);
+  const int nlive = __popcll(live0);
+  if (nlive * TP <= 64) {
+    // ---- thin tile (k_push_walk_rowsq): lane l takes (live row l/TP, column l%TP), one iteration
+    if (valid && !alive0)
+      for (int p = p0; p < pend; ++p) elem_ids[start + p * C] = -1;
+    const int krow = lane / TP, col = lane - krow * TP;
+    unsigned long long m = live0;
+    for (int j = 0; j < krow && m; ++j) m &= m - 1;  // drop the krow lowest live rows
+    const bool have = krow < nlive;
+    const int src = have ? __builtin_ctzll(m) : 0;
+    const int t_start = __shfl(start, src), t_p0 = __shfl(p0, src), t_pend = __shfl(pend, src);
+    const int t_e = __shfl(e, src), t_nrow = __shfl(nrow, src);
+    ppm::ClassTerm tct;
+    tct.dphi = __shfl(ct.dphi, src);
+    tct.st = __shfl(ct.st, src);
+    tct.ct = __shfl(ct.ct, src);
+    const int p = t_p0 + col;
+    const bool act = have && p < t_pend;
+    const bool live = act && p < t_nrow;
+    const int pid = t_start + p * C;
+    char* rp = R.rec + (long long)pid * pp::kRecBytes;
+    PState s{};
+    if (live) s = load_state_rec(rp);
+    int elem = live ? t_e : -1;
+    if (__ballot(live) != 0ull) coop_fetch<DIM>(cache, recs, live ? t_e : -1, st, lane);
+    V3 dest{0, 0, 0};
+    float rad = 0.f;
+    const bool need = live ? column_math_rec<DIM>(A, rp, s, tct, cache, elem, dest, rad) : false;
+    if (act && !live) elem_ids[pid] = -1;
+    // the stayers of one row (TP adjacent lanes) take a contiguous rank range from ONE atomic
+    const bool stay = live && !need && elem == t_e;
+    const unsigned long long bal = __ballot(stay);
+    const int sh = (krow * TP) & 63;
+    const unsigned long long gm = (TP >= 64 ? ~0ull : ((1ull << TP) - 1ull)) << sh;
+    const int nst = have ? __popcll(bal & gm) : 0;
+    int base = 0;
+    if (have && col == 0 && nst > 0) base = atomicAdd(&R.ppe[t_e], nst);
+    base = __shfl(base, sh);
+    if (live) {
+      if (!need) elem_ids[pid] = elem;
+      const unsigned aux = stay ? (unsigned)(base + __popcll(bal & gm & lt_mask)) : 0u;
+      *(uint2*)(rp + 56) = make_uint2(__float_as_uint(rad), aux);
+    }
+    enqueue(need, pid, elem, dest, wq, qn, lt_mask);
+    if (valid) R.run_base[g] = 0;  // (ranks of a thin tile are final: no run of this thread)
+    if (lane == 0) wave_cnt[gwave] = qn;
+    return;
+  }
+  // ---- column loop: the row's record once, then TP particles of the row
+  if (__ballot(alive0) != 0ull) coop_fetch<DIM>(cache, recs, alive0 ? e : -1, st, lane);
+  int nstay = 0;
+  PState cur{};
+  if (alive0) cur = load_state_rec(R.rec + (long long)(start + p0 * C) * pp::kRecBytes);
+  for (int i = 0; i < TP; ++i) {  // wave-uniform trip count (enqueue is a wave-level operation)
+    const int p = p0 + i;
+    const int pid = start + p * C;
+    const bool act = valid && p < pend;
+    const bool live = act && p < nrow;
+    char* rp = R.rec + (long long)pid * pp::kRecBytes;
+    const PState s = cur;
+    if (act && p + 1 < pend && p + 1 < nrow) cur = load_state_rec(rp + (long long)C * pp::kRecBytes);
+    int elem = live ? e : -1;
+    V3 dest{0, 0, 0};
+    float rad = 0.f;
+    const bool need = live ? column_math_rec<DIM>(A, rp, s, ct, cache, elem, dest, rad) : false;
+    if (act && !live) elem_ids[pid] = -1;
+    if (live) {
+      unsigned aux = 0u;
+      if (!need) {
+        elem_ids[pid] = elem;
+        if (elem == e) aux = pp::kRecAuxLocal | (unsigned)(nstay++);
+      }
+      *(uint2*)(rp + 56) = make_uint2(__float_as_uint(rad), aux);
+    }
+    enqueue(need, pid, elem, dest, wq, qn, lt_mask);
+  }
+  if (valid) R.run_base[g] = nstay > 0 ? atomicAdd(&R.ppe[e], nstay) : 0;
+  if (lane == 0) wave_cnt[gwave] = qn;
 }
 
 MeshArrays arrays_of(const pp_mesh* mesh) {
@@ -1867,22 +2081,71 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
       shape_ok(m_phi, 4, 1) && ps->zero_pending == ps->member_map[m_xtgt] && ps->zero_pending != ps->member_map[m_x] &&
       ps->capacity > 0 && ps->num_ptcls > 0)
     ps->zero_pending = -1;
+  static const bool force_flat = getenv("PP_FLAT_WALK") != nullptr;  // A/B measurement knob
+  hipStream_t st = pp::stream();
+  // ---- resident records (pp_ps_set_resident_records): a search that starts every particle in its row's
+  // element (no seeds) on a structure of the 60-byte pseudoXGCm type runs on the 64-B records, and
+  // counts the new parents for the rebuild that follows
+  if (ps->rec_mode && !elem_ids_seeded && !force_flat && ps->capacity > 0 && ps->num_ptcls > 0 &&
+      ps->ntiles_max > 0 && pp::rec_usable(ps, m_x, m_xtgt, m_b, m_phi)) {
+    RecPushArgs R{};
+    if ((rc = pp::rec_begin_push(ps, elem_ids_dev, &R.rec, &R.elem_count, &R.ppe, &R.run_base))) return rc;
+    if ((rc = pair_counters())) return rc;
+    Counters* used = g_cnt2 + g_cnt2_cur;
+    static const int abl_env = getenv("PP_ABL") ? atoi(getenv("PP_ABL")) : 0;  // timing ablations only
+    const int abl = abl_env | ((ps->trust_origins && mesh->dim == 3) ? 8 : 0);
+    const unsigned rgrid = grid_for((size_t)ps->ntiles_max * ps->C);
+    const size_t lds = (size_t)(kBlock / 64) * 64 * (mesh->dim == 3 ? 8 : 4) * sizeof(double2);
+    const size_t nwaves = (size_t)rgrid * (kBlock / 64);
+    PP_HIP_CHECK(g_pending_q.reserve(nwaves * 64 * ps->tile_p * sizeof(PendEntry)));
+    PP_HIP_CHECK(g_wave_cnt.reserve(nwaves * sizeof(int)));
+#define PP_REC_ARGS                                                                                            \
+  ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(),               \
+      ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(), mesh->d_records.p, mesh->d_class_id.as<int>(), \
+      mesh->nelems, R, h, k, d, deg, mesh->tol, mesh->unmoved_sq, elem_ids_dev, looplimit, used,                \
+      g_pending_q.as<PendEntry>(), g_wave_cnt.as<int>(), g_cnt2 + (g_cnt2_cur ^ 1), abl
+    static const int G = getenv("PP_PEND_REGIONS") ? std::max(1, std::min(64, atoi(getenv("PP_PEND_REGIONS")))) : kPendRegions;
+    const unsigned pgrid = (rgrid + G - 1) / G;
+    if (mesh->dim == 2) {
+      k_push_walk_rec<2, 4><<<rgrid, kBlock, lds, st>>>(PP_REC_ARGS);
+      k_walk_pending<2><<<pgrid, kBlock, 0, st>>>((int)nwaves, ps->tile_p, G, g_pending_q.as<PendEntry>(),
+                                                 g_wave_cnt.as<int>(), mesh->d_records.p, elem_ids_dev, looplimit,
+                                                 used, R.rec, R.ppe);
+    } else {
+      k_push_walk_rec<3, 4><<<rgrid, kBlock, lds, st>>>(PP_REC_ARGS);
+      k_walk_pending<3><<<pgrid, kBlock, 0, st>>>((int)nwaves, ps->tile_p, G, g_pending_q.as<PendEntry>(),
+                                                 g_wave_cnt.as<int>(), mesh->d_records.p, elem_ids_dev, looplimit,
+                                                 used, R.rec, R.ppe);
+    }
+#undef PP_REC_ARGS
+    PP_LAUNCH_CHECK();
+    g_cnt2_cur ^= 1;
+    g_last_counters = used;
+    if (found) {
+      Counters hc;
+      PP_HIP_CHECK(hipMemcpyAsync(&hc, used, sizeof(Counters), hipMemcpyDeviceToHost, st));
+      PP_HIP_CHECK(hipStreamSynchronize(st));
+      *found = (hc.not_found == 0);
+    }
+    return PP_OK;
+  }
   if ((rc = member_ok(ps, m_x, 8, 3, "pp_push_search x"))) return rc;
   if ((rc = member_ok(ps, m_xtgt, 8, 3, "pp_push_search x_tgt"))) return rc;
   if ((rc = member_ok(ps, m_b, 4, 1, "pp_push_search b"))) return rc;
   if ((rc = member_ok(ps, m_phi, 4, 1, "pp_push_search phi"))) return rc;
   if (found) *found = 1;
   if (ps->capacity == 0) return PP_OK;
+  if (mesh->dim == 2 && !elem_ids_seeded) {
+    // search_mesh_2d reads its seeds (hpp:1051-1056); "no seeds" = every particle starts in its own element
+    PP_HIP_CHECK(hipMemsetAsync(elem_ids_dev, 0xff, sizeof(int) * (size_t)ps->capacity, st));
+    elem_ids_seeded = 1;
+  }
   if (ps->num_ptcls == 0) {
     if (!elem_ids_seeded && mesh->dim == 3)
       PP_HIP_CHECK(hipMemsetAsync(elem_ids_dev, 0xff, sizeof(int) * (size_t)ps->capacity, pp::stream()));
     return PP_OK;
   }
   const unsigned grid = grid_for(ps->capacity);
-  hipStream_t st = pp::stream();
-  if (mesh->dim == 2)
-    PP_REQUIRE(elem_ids_seeded, "pp_push_search (2-D): elem_ids must be initialised (-1 = own element)");
-  static const bool force_flat = getenv("PP_FLAT_WALK") != nullptr;  // A/B measurement knob
   Counters* used = nullptr;  // the counter set this call's kernels add to
   if (ps->kind == PP_SCS && !force_flat) {
     const unsigned rgrid = grid_for((size_t)ps->ntiles_max * ps->C);
