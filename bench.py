@@ -232,6 +232,8 @@ class Stepper:
         self.records = bool(w.get("records"))
         if self.records:
             self.ps.set_resident_records(True)
+        if w.get("rebuild") == "in-place":
+            self.ps.set_try_shuffling(2)
         if name in ("c3", "2dc3", "c5"):
             self.fwd, self.bkwd = capi.create_gyro_ring_mappings(self.mesh)
             self.w_f = capi.DevArray(self.mesh.nverts, np.float64)
@@ -514,6 +516,11 @@ def main():
     ap.add_argument("--no-origin-trust", action="store_true",
                     help="run check_initial_parents every step (default: skipped from the second step on, "
                          "pp_ps_set_origin_trust)")
+    ap.add_argument("--rebuild", default="reference", choices=["reference", "in-place"],
+                    help="c3 / 2dc3: 'reference' = SellCSigma's own decision (keep the layout iff every row fits, "
+                         "else the full count-sorted re-layout: pp_ps_set_shuffling 1); 'in-place' = rows that "
+                         "overflow trade places / move into appended chunks, only particles that change rows "
+                         "move (pp_ps_set_shuffling 2; a valid SCS whose row order is not the reference's)")
     ap.add_argument("--records", default="on", choices=["on", "off"],
                     help="c3 / 2dc3: keep the particles as 64-B records between the fused push and the "
                          "rebuild (pp_ps_set_resident_records); off = the SoA member arrays only")
@@ -582,6 +589,7 @@ def main():
         w["comm"] = a.comm
         w["origin_trust"] = not a.no_origin_trust
         w["records"] = a.records == "on" and a.workload in ("c3", "2dc3")
+        w["rebuild"] = a.rebuild if a.workload in ("c3", "2dc3") else "reference"
         st = Stepper(pp, capi, w, a.workload, a.deg)
 
     def barrier():
@@ -751,6 +759,7 @@ def main():
                                            "destinations the previous walk accepted); 0 unmoved finishes = the "
                                            "skipped test would have passed for every particle"}
         if full_step:
+            out["rebuild_mode"] = w.get("rebuild", "reference")
             out["resident_records"] = {"on": bool(getattr(st, "records", False)),
                                        "state_after_run": w["ps"].resident_records()}
             ip, fl, rm = w["ps"].rebuild_stats()

@@ -214,17 +214,22 @@ struct pp_ps {
   bool trust_origins = false;
   // ---- resident records (pp_ps_set_resident_records, DESIGN "Resident records").  A structure whose
   // particle type is the 60-byte pseudoXGCm one (double[3], double[3], 4-byte, 4-byte, 4-byte) can keep
-  // its particles as one 64-B record per slot -- x | x_tgt | m2 | m3 | m4 | aux -- between the fused
-  // entry points: pp_push_search reads and updates the records in place and counts the new parents,
-  // the rebuild is ONE pass (record read in slot order, committed record written to its new slot).
+  // its particles as one 64-B record per slot -- xa | xb | m2 | m3 | m4 | aux -- between the fused entry
+  // points: pp_push_search reads and updates the records in place, the rebuild moves whole records
+  // (every one of them in the full re-layout; only the particles that change rows in the in-place
+  // modes).  Member 0 lives in xa or xb (rec_xsel), member 1 in the other: updatePtclPositions is a flip
+  // of the selector, and member 1 is then logically zero (rec_xt_zero) until the next push writes it.
   // While rec_resident is set the SoA arrays in `data` are stale; every other entry point goes through
   // ps_ready(), which writes them back first.
   int rec_mode = 0;           // 0 = never, 1 = use records where the particle type allows it
   bool rec_resident = false;  // d_rec holds the particles
-  pp::DevBuf d_rec, s_rec;    // records of the live layout / destination of the next rebuild
-  pp::DevBuf d_runbase;       // first rank of the stayers of every (tile,row) thread of the last fused push
-  // the histogram in s_ppe (+ ranks in the records' aux words) was made by the last fused push from the
-  // ids at `fused_ids`; a rebuild that is handed the same ids skips its counting pass
+  int rec_xsel = 0;           // 0: member 0 = xa, member 1 = xb; 1: the other way round
+  bool rec_xt_zero = false;   // member 1 is logically zero
+  pp::DevBuf d_rec, s_rec;    // records of the live layout / destination of a full re-layout
+  pp::DevBuf s_stage;         // in-place rebuild: copies of the records that change rows, by old slot
+  // the in-place rebuild's counters in s_rs (+ the movers' ranks in s_idx and their records in s_stage)
+  // were filled by the last fused push from the ids at `fused_ids`; a rebuild that is handed the same
+  // ids skips its counting pass
   bool fused_count_valid = false;
   const int* fused_ids = nullptr;
   pp::DevBuf s_rs, s_holes, s_rsx;  // in-place rebuild: per-element counters, per-row hole lists, elastic lists
@@ -306,12 +311,20 @@ inline int ps_ready(const pp_ps* ps) {
   return (ps && (ps->zero_pending >= 0 || ps->rec_resident)) ? ps_materialize(const_cast<pp_ps*>(ps)) : PP_OK;
 }
 // pp_ps.hip, resident records.  rec_usable: the structure may run the fused push on records with these
-// member roles.  rec_begin_push: makes the records current (packs the SoA arrays once), clears the
-// histogram the push is about to fill and hands out the device pointers.
+// member roles.  rec_begin_push: makes the records current (packs the SoA arrays once), prepares the
+// in-place rebuild's counters when that is the structure's rebuild mode, and hands out the pointers.
 constexpr int kRecBytes = 64;
-constexpr unsigned kRecAuxLocal = 0x80000000u;  // aux = this flag | index among the stayers of the thread's run
+struct RecPushPtrs {
+  char* rec;
+  const int* elem_count;
+  int xoff, xt_zero;
+  // in-place counting at the end of the walks (null when the rebuild will count by itself)
+  int *arrive, *leave, *removed, *rank;
+  char* stage;
+  const int* slot_elem;
+};
 bool rec_usable(const pp_ps* ps, int m_x, int m_xtgt, int m_b, int m_phi);
-int rec_begin_push(pp_ps* ps, const int* ids_dev, char** rec, const int** elem_count, int** ppe, int** run_base);
+int rec_begin_push(pp_ps* ps, const int* ids_dev, RecPushPtrs* out);
 // pp_scatter.hip: gyroScatter for `nmaps` ring maps from an explicit per-element count array (the
 // histogram of a rebuild that is still in flight); forgets the ring accumulation kept for reuse.
 int gyro_scatter_counts(const pp_mesh* mesh, const int* cnt_dev, int nmaps, const int* const* v2v_dev,

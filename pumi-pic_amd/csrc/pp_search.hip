@@ -1275,12 +1275,20 @@ __device__ __forceinline__ int seed_of(const PState& s, int e, int seeded, int n
   return seeded ? s.elem : e;
 }
 
+// resident records + in-place rebuild: what the end of a deferred walk adds to (pp_ps.hip: RsCounters)
+struct RecFinish {
+  char* rec = nullptr;
+  char* stage = nullptr;           // staged copies of the movers' records, indexed like rec
+  int *arrive = nullptr, *leave = nullptr, *removed = nullptr;
+  int* rank = nullptr;             // arrival rank of every mover, by old slot
+  const int* slot_elem = nullptr;  // element of every slot
+};
 // walks the entries of `nreg` consecutive queue regions (region i holds my_cnt-of-lane-i entries)
 template <int DIM>
 __device__ __forceinline__ void walk_pending(const PendEntry* __restrict__ regions, long long region_stride,
                                              int nreg, int my_cnt, const void* __restrict__ recs,
                                              int* elem_ids, int cap, Counters* cnt, double2* st, int lane,
-                                             char* prec = nullptr, int* ppe = nullptr) {
+                                             const RecFinish* F = nullptr) {
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   int reg = 0, off = 0;  // wave-uniform cursor
   int reg_cnt = __shfl(my_cnt, 0);
@@ -1333,10 +1341,28 @@ __device__ __forceinline__ void walk_pending(const PendEntry* __restrict__ regio
       }
       if (fin) {
         elem_ids[en.pid] = welem;
-        // resident records: the particle's rank in its new row is the histogram's old count; it
-        // rides in the record's aux word to the rebuild
-        if (ppe && welem >= 0)
-          *(unsigned*)(prec + (long long)en.pid * pp::kRecBytes + 60) = (unsigned)atomicAdd(&ppe[welem], 1);
+        // resident records, in-place rebuild: the walk's end is where the rebuild's counting happens.
+        // A particle that ends outside the element of its slot leaves that row (leave / removed), takes
+        // the next arrival rank of its new element and is staged -- its slot may be another particle's
+        // target (k_rs_count does this for the SoA arrays in a pass of its own).
+        if (F) {
+          const int home = F->slot_elem[en.pid];
+          if (welem != home) {
+            atomicAdd(&F->leave[home], 1);
+            if (welem < 0) {
+              atomicAdd(&F->removed[home], 1);
+            } else {
+              F->rank[en.pid] = atomicAdd(&F->arrive[welem], 1);
+              const uint4* sp = (const uint4*)(F->rec + (long long)en.pid * pp::kRecBytes);
+              uint4* dp = (uint4*)(F->stage + (long long)en.pid * pp::kRecBytes);
+              const uint4 a = sp[0], b = sp[1], c = sp[2], d = sp[3];
+              dp[0] = a;
+              dp[1] = b;
+              dp[2] = c;
+              dp[3] = d;
+            }
+          }
+        }
         on = false;
       }
     }
@@ -1515,7 +1541,7 @@ template <int DIM>
 __global__ void __launch_bounds__(256, 4)
     k_walk_pending(int nwaves, int TP, int G, const PendEntry* __restrict__ gq,
                    const int* __restrict__ wave_cnt, const void* __restrict__ recs, int* elem_ids,
-                   int looplimit, Counters* cnt, char* prec = nullptr, int* ppe = nullptr) {
+                   int looplimit, Counters* cnt, RecFinish F = RecFinish{}) {
   constexpr int NP = DIM == 3 ? 8 : 4;
   __shared__ double2 st_all[4 * 64 * NP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1524,32 +1550,33 @@ __global__ void __launch_bounds__(256, 4)
   const int nreg = (int)min((long long)G, nwaves - r0);
   const int my_cnt = lane < nreg ? wave_cnt[r0 + lane] : 0;  // lane i holds the count of region i
   walk_pending<DIM>(gq + r0 * 64 * TP, 64ll * TP, nreg, my_cnt, recs, elem_ids,
-                    looplimit ? looplimit : kHardLoopCap, cnt, st_all + wave * 64 * NP, lane, prec, ppe);
+                    looplimit ? looplimit : kHardLoopCap, cnt, st_all + wave * 64 * NP, lane,
+                    F.arrive ? &F : nullptr);
 }
 
 // ------------------------------------------------------------------ fused kernel on resident records
 // (DESIGN "Resident records").  Same thread = (tile,row) mapping, thin tiles, register-cached row record
 // and deferred walk as k_push_walk_rowsq, for the flow that rebuilds after every search (every particle
 // starts in its row's element, so the row's record is fetched once per thread).  What differs:
-//   * the particle state is ONE 64-B record per slot: x | x_tgt | m2 | b | phi | aux.  A column reads
-//     x, b, phi of 64 consecutive records and writes x_tgt, phi and aux back in place;
+//   * the particle state is ONE 64-B record per slot: xa | xb | m2 | b | phi | aux, where x is xa or xb
+//     (xoff) and x_tgt the other -- updatePtclPositions is a flip of that selector, not a pass.  A
+//     column reads x, b, phi of 64 consecutive records and writes x_tgt and phi back in place;
 //   * liveness comes from the per-element counts (rows are prefix-compact): no mask stream;
-//   * the histogram of the new parents is made here.  A particle that stays in its row's element gets
-//     aux = kRecAuxLocal | its index among the stayers of this thread's run, the run's first rank comes
-//     from ONE returning atomic per thread (run_base[thread]); a particle that crosses is counted by
-//     k_walk_pending when its walk ends (aux = rank).  The rebuild needs no counting pass.
+//   * with the in-place rebuild's counters (RecFinish) the particles that end outside their row's element
+//     are counted, ranked and staged where their walk ends -- the rebuild needs no counting pass.
 struct RecPushArgs {
   char* rec;
   const int* elem_count;  // live particles per element (current layout)
-  int* ppe;               // histogram of the new parents, zero on entry
-  int* run_base;          // [ntiles_max * C]
+  int xoff;               // byte offset of x in the record (0 or 24); x_tgt = 24 - xoff
+  int xt_zero;            // x_tgt is logically zero: a 2-D push also writes its third component
+  int *leave, *removed;   // in-place counters of the particles the column loop itself finishes outside (null = off)
 };
-__device__ __forceinline__ PState load_state_rec(const char* rp) {
+__device__ __forceinline__ PState load_state_rec(const char* rp, int xoff) {
   PState s;
-  const double2 q0 = *(const double2*)rp;
-  s.x = q0.x;
-  s.y = q0.y;
-  s.z = *(const double*)(rp + 16);
+  const double* x = (const double*)(rp + xoff);
+  s.x = x[0];
+  s.y = x[1];
+  s.z = x[2];
   const float4 q3 = *(const float4*)(rp + 48);  // m2 | b | phi | aux
   s.b = q3.y;
   s.phi = q3.z;
@@ -1557,32 +1584,35 @@ __device__ __forceinline__ PState load_state_rec(const char* rp) {
   s.elem = -1;
   return s;
 }
-// push + parent check + first walk step of one live particle; x_tgt goes to the record.  Returns true
-// when the particle crossed into `elem` (to be finished by the second pass); `rad` = the new phase.
+// push + parent check + first walk step of one live particle; x_tgt and phi go to the record.  Returns
+// true when the particle crossed into `elem` (to be finished by the second pass).
 template <int DIM>
-__device__ __forceinline__ bool column_math_rec(const WalkArgs& A, char* rp, const PState& s,
-                                                const ppm::ClassTerm& ct, const RecCache<DIM>& cache,
-                                                int& elem, V3& dest, float& rad_out) {
+__device__ __forceinline__ bool column_math_rec(const WalkArgs& A, char* rp, int xtoff, int xt_zero,
+                                                const PState& s, const ppm::ClassTerm& ct,
+                                                const RecCache<DIM>& cache, int& elem, V3& dest) {
   double rad;
   bool done = false;
   bool origin_ok = true;
+  double* xt = (double*)(rp + xtoff);
   if constexpr (DIM == 2) {
     ppm::elliptical_point(ct, s.phi, s.b, A.h, A.k, A.d, dest.x, dest.y, rad);
     dest.z = 0;
-    *(double*)(rp + 24) = dest.x;
-    *(double*)(rp + 32) = dest.y;
+    xt[0] = dest.x;
+    xt[1] = dest.y;
+    if (xt_zero) xt[2] = 0.0;
   } else {
     origin_ok = (A.abl & 8) || inside_cached(cache, V3{s.x, s.y, s.z}, A.tol);
     ppm::toroidal_point(ct, s.phi, s.b, s.x, s.y, A.h, A.k, A.d, dest.x, dest.y, dest.z, rad);
-    *(double*)(rp + 24) = dest.x;
-    *(double2*)(rp + 32) = double2{dest.y, dest.z};
+    xt[0] = dest.x;
+    xt[1] = dest.y;
+    xt[2] = dest.z;
     const V3 dv = sub(dest, V3{s.x, s.y, s.z});
     if (dot(dv, dv) < A.unmoved_sq) {  // finishUnmoved (k_push_walk_rows)
       if (A.abl & 8) atomicAdd(&A.cnt->unmoved, 1);
       done = true;
     }
   }
-  rad_out = (float)rad;
+  *(float*)(rp + 56) = (float)rad;
   if (!done && !origin_ok) {  // check_initial_parents (tpp:72-145)
     atomicAdd(&A.cnt->not_in_elem, 1);
     elem = -1;
@@ -1637,6 +1667,7 @@ __global__ void __launch_bounds__(256, OCC)
     nrow = e < nelems ? R.elem_count[e] : 0;
   }
   const ppm::ClassTerm ct = ppm::class_term((valid && e < nelems) ? class_id[e] : 1, deg, DIM == 3);
+  const int xoff = R.xoff, xtoff = 24 - R.xoff;
   WalkArgs A;
   A.xt = nullptr;
   A.stride = 0;
@@ -1654,6 +1685,14 @@ __global__ void __launch_bounds__(256, OCC)
   A.abl = abl;
   RecCache<DIM> cache;
   cache.id = -1;
+  // a particle the column loop finishes outside every element (exit through the boundary, failed parent
+  // check): it leaves its row and is removed -- rare, one atomic pair each
+  auto lost = [&](int home) {
+    if (R.leave) {
+      atomicAdd(&R.leave[home], 1);
+      atomicAdd(&R.removed[home], 1);
+    }
+  };
   const bool alive0 = valid && p0 < pend && p0 < nrow;  // rows fill from column 0
   const unsigned long long live0 = __ballot(alive0);
   const int nlive = __popcll(live0);
@@ -1678,37 +1717,21 @@ __global__ void __launch_bounds__(256, OCC)
     const int pid = t_start + p * C;
     char* rp = R.rec + (long long)pid * pp::kRecBytes;
     PState s{};
-    if (live) s = load_state_rec(rp);
+    if (live) s = load_state_rec(rp, xoff);
     int elem = live ? t_e : -1;
     if (__ballot(live) != 0ull) coop_fetch<DIM>(cache, recs, live ? t_e : -1, st, lane);
     V3 dest{0, 0, 0};
-    float rad = 0.f;
-    const bool need = live ? column_math_rec<DIM>(A, rp, s, tct, cache, elem, dest, rad) : false;
-    if (act && !live) elem_ids[pid] = -1;
-    // the stayers of one row (TP adjacent lanes) take a contiguous rank range from ONE atomic
-    const bool stay = live && !need && elem == t_e;
-    const unsigned long long bal = __ballot(stay);
-    const int sh = (krow * TP) & 63;
-    const unsigned long long gm = (TP >= 64 ? ~0ull : ((1ull << TP) - 1ull)) << sh;
-    const int nst = have ? __popcll(bal & gm) : 0;
-    int base = 0;
-    if (have && col == 0 && nst > 0) base = atomicAdd(&R.ppe[t_e], nst);
-    base = __shfl(base, sh);
-    if (live) {
-      if (!need) elem_ids[pid] = elem;
-      const unsigned aux = stay ? (unsigned)(base + __popcll(bal & gm & lt_mask)) : 0u;
-      *(uint2*)(rp + 56) = make_uint2(__float_as_uint(rad), aux);
-    }
+    const bool need = live ? column_math_rec<DIM>(A, rp, xtoff, R.xt_zero, s, tct, cache, elem, dest) : false;
+    if (act && (!live || !need)) elem_ids[pid] = elem;
+    if (live && !need && elem < 0) lost(t_e);
     enqueue(need, pid, elem, dest, wq, qn, lt_mask);
-    if (valid) R.run_base[g] = 0;  // (ranks of a thin tile are final: no run of this thread)
     if (lane == 0) wave_cnt[gwave] = qn;
     return;
   }
   // ---- column loop: the row's record once, then TP particles of the row
   if (__ballot(alive0) != 0ull) coop_fetch<DIM>(cache, recs, alive0 ? e : -1, st, lane);
-  int nstay = 0;
   PState cur{};
-  if (alive0) cur = load_state_rec(R.rec + (long long)(start + p0 * C) * pp::kRecBytes);
+  if (alive0) cur = load_state_rec(R.rec + (long long)(start + p0 * C) * pp::kRecBytes, xoff);
   for (int i = 0; i < TP; ++i) {  // wave-uniform trip count (enqueue is a wave-level operation)
     const int p = p0 + i;
     const int pid = start + p * C;
@@ -1716,23 +1739,14 @@ __global__ void __launch_bounds__(256, OCC)
     const bool live = act && p < nrow;
     char* rp = R.rec + (long long)pid * pp::kRecBytes;
     const PState s = cur;
-    if (act && p + 1 < pend && p + 1 < nrow) cur = load_state_rec(rp + (long long)C * pp::kRecBytes);
+    if (act && p + 1 < pend && p + 1 < nrow) cur = load_state_rec(rp + (long long)C * pp::kRecBytes, xoff);
     int elem = live ? e : -1;
     V3 dest{0, 0, 0};
-    float rad = 0.f;
-    const bool need = live ? column_math_rec<DIM>(A, rp, s, ct, cache, elem, dest, rad) : false;
-    if (act && !live) elem_ids[pid] = -1;
-    if (live) {
-      unsigned aux = 0u;
-      if (!need) {
-        elem_ids[pid] = elem;
-        if (elem == e) aux = pp::kRecAuxLocal | (unsigned)(nstay++);
-      }
-      *(uint2*)(rp + 56) = make_uint2(__float_as_uint(rad), aux);
-    }
+    const bool need = live ? column_math_rec<DIM>(A, rp, xtoff, R.xt_zero, s, ct, cache, elem, dest) : false;
+    if (act && (!live || !need)) elem_ids[pid] = elem;
+    if (live && !need && elem < 0) lost(e);
     enqueue(need, pid, elem, dest, wq, qn, lt_mask);
   }
-  if (valid) R.run_base[g] = nstay > 0 ? atomicAdd(&R.ppe[e], nstay) : 0;
   if (lane == 0) wave_cnt[gwave] = qn;
 }
 
@@ -2089,7 +2103,22 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
   if (ps->rec_mode && !elem_ids_seeded && !force_flat && ps->capacity > 0 && ps->num_ptcls > 0 &&
       ps->ntiles_max > 0 && pp::rec_usable(ps, m_x, m_xtgt, m_b, m_phi)) {
     RecPushArgs R{};
-    if ((rc = pp::rec_begin_push(ps, elem_ids_dev, &R.rec, &R.elem_count, &R.ppe, &R.run_base))) return rc;
+    RecFinish F{};
+    pp::RecPushPtrs rp{};
+    if ((rc = pp::rec_begin_push(ps, elem_ids_dev, &rp))) return rc;
+    R.rec = rp.rec;
+    R.elem_count = rp.elem_count;
+    R.xoff = rp.xoff;
+    R.xt_zero = rp.xt_zero;
+    R.leave = rp.leave;
+    R.removed = rp.removed;
+    F.rec = rp.rec;
+    F.stage = rp.stage;
+    F.arrive = rp.arrive;
+    F.leave = rp.leave;
+    F.removed = rp.removed;
+    F.rank = rp.rank;
+    F.slot_elem = rp.slot_elem;
     if ((rc = pair_counters())) return rc;
     Counters* used = g_cnt2 + g_cnt2_cur;
     static const int abl_env = getenv("PP_ABL") ? atoi(getenv("PP_ABL")) : 0;  // timing ablations only
@@ -2110,12 +2139,12 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
       k_push_walk_rec<2, 4><<<rgrid, kBlock, lds, st>>>(PP_REC_ARGS);
       k_walk_pending<2><<<pgrid, kBlock, 0, st>>>((int)nwaves, ps->tile_p, G, g_pending_q.as<PendEntry>(),
                                                  g_wave_cnt.as<int>(), mesh->d_records.p, elem_ids_dev, looplimit,
-                                                 used, R.rec, R.ppe);
+                                                 used, F);
     } else {
       k_push_walk_rec<3, 4><<<rgrid, kBlock, lds, st>>>(PP_REC_ARGS);
       k_walk_pending<3><<<pgrid, kBlock, 0, st>>>((int)nwaves, ps->tile_p, G, g_pending_q.as<PendEntry>(),
                                                  g_wave_cnt.as<int>(), mesh->d_records.p, elem_ids_dev, looplimit,
-                                                 used, R.rec, R.ppe);
+                                                 used, F);
     }
 #undef PP_REC_ARGS
     PP_LAUNCH_CHECK();

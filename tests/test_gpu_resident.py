@@ -143,3 +143,49 @@ def test_resident_records_other_particle_types_stay_soa(ppo, synth, capi):
     pg.rebuild(capi.DevArray.from_host(pg.slot_info()[0].astype(np.int32)))
     assert pg.resident_records() == 1 and pg.nPtcls() == 500
     del ids
+
+
+@pytest.mark.parametrize("dim", [3, 2])
+def test_resident_records_in_place_rebuild(ppo, synth, capi, dim):
+    """shuffle mode 2 on records: the counting happens where the walks end, only the particles that change
+    rows move (whole records), rows that overflow trade places or move into appended chunks.  The layout is
+    this library's (valid SCS, rows not sorted by count), so what is compared with the oracle is what the
+    reference defines: element ids by particle id, every member of every particle, the per-element
+    populations and the gyroScatter fields."""
+    pop = (common.population_3d(synth, n_b=6, n_theta=24, n_planes=8, num_ptcls=30000) if dim == 3 else
+           common.population_2d(synth, n_b=16, n_theta=64, num_ptcls=30000, mdl_face=4, band_width=4))
+    ne = len(pop["e2v"])
+    deg = 6.0 if dim == 3 else 2.0
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
+    pg.set_try_shuffling(2)
+    pg.set_resident_records(True)
+    fo, bo = ppo.create_gyro_ring_mappings(mo, trig=1)
+    fg, bg = capi.create_gyro_ring_mappings(mg)
+    in_place = 0
+    for step in range(12):
+        ids_o = _oracle_step(ppo, dim, mo, po, deg)
+        inspect = step % 4 == 3
+        if inspect:
+            pid_g, mask_g = pg.member(2)[0, :pg.capacity()].copy(), pg.slot_info()[1].copy()
+        ids_g = capi.DevArray(max(pg.capacity(), 1), np.int32)
+        capi.push_search(mg, pg, H, K, D, deg, ids_g, seeded=False, looplimit=200)
+        assert pg.resident_records() == 2
+        if step >= 1 and dim == 3:
+            pg.set_origin_trust(True)
+        if inspect:
+            io, eo = common.by_id(po.member(2)[0, :po.capacity()], po.slot_info()[1], ids_o[:po.capacity()])
+            ig, eg = common.by_id(pid_g, mask_g, ids_g.to_host()[:pg.capacity()])
+            assert np.array_equal(io, ig) and np.array_equal(eo, eg), step
+        ppo.update_positions(po)
+        po.rebuild(ids_o)
+        st0 = pg.rebuild_stats()
+        wf, wb = capi.rebuild_scatter(pg, mg, ids_g, [fg, bg], commit=True)
+        in_place += pg.rebuild_stats()[0] > st0[0]
+        assert po.nPtcls() == pg.nPtcls() > 0
+        assert np.array_equal(ppo.gyro_scatter(mo, po, fo), wf.to_host()), step
+        assert np.array_equal(ppo.gyro_scatter(mo, po, bo), wb.to_host()), step
+        if inspect or step == 11:
+            _same_population(po, pg)
+            common.check_scs_valid(pg, ne)
+    assert in_place >= 6, in_place
