@@ -229,11 +229,6 @@ class Stepper:
                     sys.stderr.write("bench.py: RCCL communicator behind the C-ABI failed (%r); falling back to "
                                      "--comm torch\n" % (e,))
                     self.comm_kind = "torch"
-        self.records = bool(w.get("records"))
-        if self.records:
-            self.ps.set_resident_records(True)
-        if w.get("rebuild") == "in-place":
-            self.ps.set_try_shuffling(2)
         if name in ("c3", "2dc3", "c5"):
             self.fwd, self.bkwd = capi.create_gyro_ring_mappings(self.mesh)
             self.w_f = capi.DevArray(self.mesh.nverts, np.float64)
@@ -254,11 +249,6 @@ class Stepper:
                              seeded=not self.first, looplimit=200, want_found=False)
         elif self.name in ("c3", "c5"):
             # rebuilt every step: every particle sits in its row's element, no seed ids needed
-            capi.push_search(self.mesh, self.ps, self.h, self.k, self.d, self.deg, self.ids,
-                             seeded=False, looplimit=200, want_found=False)
-        elif self.name == "2dc3" and self.records:
-            # rebuilt every step: "no seeds" = every particle starts in its row's element (the -1 seeds
-            # search_mesh_2d would read, adjacency.hpp:1051-1056)
             capi.push_search(self.mesh, self.ps, self.h, self.k, self.d, self.deg, self.ids,
                              seeded=False, looplimit=200, want_found=False)
         else:
@@ -294,7 +284,7 @@ class Stepper:
             cap = max(self.ps.capacity(), 1)
             if cap > self.ids.n:  # 10% slack: the capacity wanders by a few chunk widths per rebuild
                 self.ids = capi.DevArray(cap + cap // 10, np.int32)
-            if self.w["dim"] == 2 and not self.records:
+            if self.w["dim"] == 2:
                 self.ids.fill_bytes(0xff)  # search_mesh_2d reads its seeds: -1 = the row's element
             # dim 3, unseeded (an "empty elem_ids", adjacency.tpp:504-515): the search writes every
             # slot itself, -1 into the masked ones -- no fill
@@ -516,14 +506,6 @@ def main():
     ap.add_argument("--no-origin-trust", action="store_true",
                     help="run check_initial_parents every step (default: skipped from the second step on, "
                          "pp_ps_set_origin_trust)")
-    ap.add_argument("--rebuild", default="reference", choices=["reference", "in-place"],
-                    help="c3 / 2dc3: 'reference' = SellCSigma's own decision (keep the layout iff every row fits, "
-                         "else the full count-sorted re-layout: pp_ps_set_shuffling 1); 'in-place' = rows that "
-                         "overflow trade places / move into appended chunks, only particles that change rows "
-                         "move (pp_ps_set_shuffling 2; a valid SCS whose row order is not the reference's)")
-    ap.add_argument("--records", default="on", choices=["on", "off"],
-                    help="c3 / 2dc3: keep the particles as 64-B records between the fused push and the "
-                         "rebuild (pp_ps_set_resident_records); off = the SoA member arrays only")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch", "tcp"],
                     help="c5 exchange: RCCL behind the C-ABI (pp_ps_migrate / pp_allreduce_sum), the "
                          "torch.distributed glue of pumi-pic_amd/dist.py, or the library's host-staged TCP "
@@ -588,8 +570,6 @@ def main():
         w["safe_layers"] = a.safe_layers
         w["comm"] = a.comm
         w["origin_trust"] = not a.no_origin_trust
-        w["records"] = a.records == "on" and a.workload in ("c3", "2dc3")
-        w["rebuild"] = a.rebuild if a.workload in ("c3", "2dc3") else "reference"
         st = Stepper(pp, capi, w, a.workload, a.deg)
 
     def barrier():
@@ -759,9 +739,6 @@ def main():
                                            "destinations the previous walk accepted); 0 unmoved finishes = the "
                                            "skipped test would have passed for every particle"}
         if full_step:
-            out["rebuild_mode"] = w.get("rebuild", "reference")
-            out["resident_records"] = {"on": bool(getattr(st, "records", False)),
-                                       "state_after_run": w["ps"].resident_records()}
             ip, fl, rm = w["ps"].rebuild_stats()
             out["rebuilds"] = {"kept_layout": ip, "full_relayout": fl, "rows_traded": rm,
                                "note": "how the structure's rebuilds ended (warm-up and cold-clock steps included)"}

@@ -176,21 +176,6 @@ int pp_ps_rebuild_scatter(pp_ps* ps, int m_x, int m_xtgt, const int* new_element
  *      pseudoXGCm step: scattered 4/8-byte stores into a SoA layout cost ~35 ps each.
  * Rows stay prefix-compact in every mode (a shrinking row back-fills its holes from its own tail). */
 int pp_ps_set_shuffling(pp_ps* ps, int mode);
-/* Resident records -- the storage form behind the fused entry points (no counterpart in the reference:
- * its MemberTypeViews are one Kokkos view per member, support/ppView.h:7-10, and SellCSigma::rebuild
- * copies every view into its swap twice per step, SCS_rebuild.h:223-299).  With `on`, a Sell-C-sigma
- * structure of the pseudoXGCm particle type (double[3], double[3], three 4-byte scalars: pseudoXGCmTypes.hpp)
- * keeps each particle as ONE 64-byte record per slot between pp_push_search (unseeded) and
- * pp_ps_rebuild / _commit / _scatter: the push updates the records in place and counts the new parents,
- * the rebuild is one data pass.  Slot numbering, layout arrays and every result are unchanged.  Any other
- * entry point that touches member data (pp_ps_member_ptr, _to_host, the stand-alone pushes / searches,
- * migration ...) writes the SoA member arrays back first, so callers see the same contents either way.
- * Contract while on: the ids given to the rebuild are the unmodified output of the preceding
- * pp_push_search; a caller that edits them (deletions, wall handlers) says so with pp_ps_ids_modified
- * before the rebuild, which then recounts.  pp_ps_resident_records: 0 off, 1 on, 2 on and records current. */
-int pp_ps_set_resident_records(pp_ps* ps, int on);
-int pp_ps_resident_records(const pp_ps* ps);
-int pp_ps_ids_modified(pp_ps* ps);
 /* how the rebuilds of this structure ended so far: kept layout / full re-layout; rows that traded
  * places (mode 2) */
 int pp_ps_rebuild_stats(const pp_ps* ps, long long* n_in_place, long long* n_full, long long* n_rows_moved);

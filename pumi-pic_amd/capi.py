@@ -86,9 +86,6 @@ SYMBOLS = {
     "pp_ps_rebuild_commit": (_I, [_V, _I, _I, _V, _I, _V, _V]),
     "pp_ps_get_pids": (_I, [_V, _V, _V]),
     "pp_ps_set_shuffling": (_I, [_V, _I]),
-    "pp_ps_set_resident_records": (_I, [_V, _I]),
-    "pp_ps_resident_records": (_I, [_V]),
-    "pp_ps_ids_modified": (_I, [_V]),
     "pp_ps_rebuild_stats": (_I, [_V, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "pp_ps_metrics": (_I, [_V, c_int_p, c_int_p, c_int_p]),
     "pp_ps_swap_members": (_I, [_V, _I, _I]),
@@ -480,17 +477,6 @@ class PS:
     def set_try_shuffling(self, v):
         """False / 0: never in place; True / 1: the reference's reshuffle decision; 2: elastic (default)"""
         check(lib().pp_ps_set_shuffling(self.p, int(v)))
-
-    def set_resident_records(self, on):
-        """64-B records between the fused push and the rebuild (pp_ps_set_resident_records)"""
-        check(lib().pp_ps_set_resident_records(self.p, int(bool(on))))
-
-    def resident_records(self):
-        """0 off, 1 on, 2 on and the records are what holds the particles right now"""
-        return lib().pp_ps_resident_records(self.p)
-
-    def ids_modified(self):
-        check(lib().pp_ps_ids_modified(self.p))
 
     def rebuild_stats(self):
         """(rebuilds that kept the layout, full re-layouts, rows that traded places)"""

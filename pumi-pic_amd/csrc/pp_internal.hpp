@@ -212,26 +212,16 @@ struct pp_ps {
   // the fused push starts from (true when the structure was rebuilt from, or the ids are, the unmodified
   // result of the previous search): check_initial_parents is skipped
   bool trust_origins = false;
-  // ---- resident records (pp_ps_set_resident_records, DESIGN "Resident records").  A structure whose
-  // particle type is the 60-byte pseudoXGCm one (double[3], double[3], 4-byte, 4-byte, 4-byte) can keep
-  // its particles as one 64-B record per slot -- xa | xb | m2 | m3 | m4 | aux -- between the fused entry
-  // points: pp_push_search reads and updates the records in place, the rebuild moves whole records
-  // (every one of them in the full re-layout; only the particles that change rows in the in-place
-  // modes).  Member 0 lives in xa or xb (rec_xsel), member 1 in the other: updatePtclPositions is a flip
-  // of the selector, and member 1 is then logically zero (rec_xt_zero) until the next push writes it.
-  // While rec_resident is set the SoA arrays in `data` are stale; every other entry point goes through
-  // ps_ready(), which writes them back first.
-  int rec_mode = 0;           // 0 = never, 1 = use records where the particle type allows it
-  bool rec_resident = false;  // d_rec holds the particles
-  int rec_xsel = 0;           // 0: member 0 = xa, member 1 = xb; 1: the other way round
-  bool rec_xt_zero = false;   // member 1 is logically zero
-  pp::DevBuf d_rec, s_rec;    // records of the live layout / destination of a full re-layout
-  pp::DevBuf s_stage;         // in-place rebuild: copies of the records that change rows, by old slot
-  // the in-place rebuild's counters in s_rs (+ the movers' ranks in s_idx and their records in s_stage)
-  // were filled by the last fused push from the ids at `fused_ids`; a rebuild that is handed the same
-  // ids skips its counting pass
-  bool fused_count_valid = false;
-  const int* fused_ids = nullptr;
+  // Deferred second pass of the full re-layout (DESIGN "Rebuild: the record-fed push").  After a rebuild
+  // with the fused updatePtclPositions the particles sit in the 64-B staging records of the move's first
+  // pass (s_aos_live, indexed by NEW slot); the pass that copies them into the SoA arrays is not run.
+  //   lazy_rec == 1: every travelling member is in the records, the SoA arrays are stale;
+  //   lazy_rec == 2: the fused push consumed the records (pp_search.hip: RECIN) and wrote every member
+  //                  but lazy_x to the SoA arrays -- only member lazy_x (the origin) is still in records.
+  // Anything else that touches member data goes through ps_ready(), which runs the deferred pass.
+  int lazy_rec = 0;
+  int lazy_x = -1, lazy_xt = -1;  // commit members of the rebuild that left the records
+  pp::DevBuf s_aos_live;
   pp::DevBuf s_rs, s_holes, s_rsx;  // in-place rebuild: per-element counters, per-row hole lists, elastic lists
   // scratch reused across rebuilds
   pp::DevBuf s_ppe, s_keys, s_keys2, s_vals, s_vals2, s_hist, s_chunkw, s_misc, s_rowstart,
@@ -308,23 +298,10 @@ namespace pp {
 // entry point that reads or exposes member data calls this first
 int ps_materialize(pp_ps* ps);
 inline int ps_ready(const pp_ps* ps) {
-  return (ps && (ps->zero_pending >= 0 || ps->rec_resident)) ? ps_materialize(const_cast<pp_ps*>(ps)) : PP_OK;
+  return (ps && (ps->zero_pending >= 0 || ps->lazy_rec)) ? ps_materialize(const_cast<pp_ps*>(ps)) : PP_OK;
 }
-// pp_ps.hip, resident records.  rec_usable: the structure may run the fused push on records with these
-// member roles.  rec_begin_push: makes the records current (packs the SoA arrays once), prepares the
-// in-place rebuild's counters when that is the structure's rebuild mode, and hands out the pointers.
-constexpr int kRecBytes = 64;
-struct RecPushPtrs {
-  char* rec;
-  const int* elem_count;
-  int xoff, xt_zero;
-  // in-place counting at the end of the walks (null when the rebuild will count by itself)
-  int *arrive, *leave, *removed, *rank;
-  char* stage;
-  const int* slot_elem;
-};
-bool rec_usable(const pp_ps* ps, int m_x, int m_xtgt, int m_b, int m_phi);
-int rec_begin_push(pp_ps* ps, const int* ids_dev, RecPushPtrs* out);
+// the structure can feed the record-fed fused push with these member roles (3-D, pseudoXGCm particle type)
+bool lazy_push_ok(const pp_ps* ps, int m_x, int m_xtgt, int m_b, int m_phi);
 // pp_scatter.hip: gyroScatter for `nmaps` ring maps from an explicit per-element count array (the
 // histogram of a rebuild that is still in flight); forgets the ring accumulation kept for reuse.
 int gyro_scatter_counts(const pp_mesh* mesh, const int* cnt_dev, int nmaps, const int* const* v2v_dev,

@@ -175,6 +175,15 @@ int set_members(pp_ps* ps, int nmembers, const int* mb, const int* mc) {
   return PP_OK;
 }
 
+// the pseudoXGCm particle type (test/pseudoXGCmTypes.hpp): double[3], double[3], three 4-byte scalars
+bool xgcm_shape(const pp_ps* ps) {
+  static const int want_b[5] = {8, 8, 4, 4, 4}, want_c[5] = {3, 3, 1, 1, 1};
+  if (ps->nmembers != 5) return false;
+  for (int m = 0; m < 5; ++m)
+    if (ps->member_bytes[m] != want_b[m] || ps->member_ncomp[m] != want_c[m]) return false;
+  return true;
+}
+
 // host-side initial placement: scatter particle_info (component-major [ncomp][np]) into a host
 // staging image of the member buffers, then upload.
 int upload_initial(pp_ps* ps, const std::vector<int>& slot_of_particle, int np,
@@ -212,9 +221,6 @@ struct Totals {  // s_misc layout
   unsigned bar;
   int sort_parity;
 };
-
-// histogram and totals of a rebuild share one allocation (one fill clears both): the totals sit here
-size_t hist_tot_off(int ne) { return (sizeof(int) * (size_t)std::max(ne, 1) + 255) / 256 * 256; }
 
 __global__ void k_count_added(int n_new, const int* __restrict__ new_elems, int ne,
                               int* __restrict__ ppe, Totals* tot, int* __restrict__ rank_new) {
@@ -1524,135 +1530,6 @@ __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
     }
   }
 }
-// ---- resident records (pp_internal.hpp, DESIGN "Resident records"): 64 B per slot,
-//   bytes 0-23 xa | 24-47 xb | 48 member 2 | 52 member 3 | 56 member 4 | 60 spare
-// member 0 (double[3]) is xa or xb (xsel), member 1 the other one.
-// SoA -> records in slot order (once, when the fused push first sees the structure) and back (any
-// other entry point: ps_materialize)
-struct RecSoA {
-  unsigned long long* m0;
-  unsigned long long* m1;
-  unsigned* m2;
-  unsigned* m3;
-  unsigned* m4;
-  long long stride;
-  int xsel;     // member 0 lives at byte 24 * xsel
-  int xt_zero;  // member 1 is logically zero
-};
-__global__ void k_rec_from_soa(int capacity, const unsigned char* __restrict__ mask, RecSoA a,
-                               uint4* __restrict__ rec) {
-  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pid >= capacity || !mask[pid]) return;
-  unsigned long long w[6];
-  for (int c = 0; c < 3; ++c) {
-    w[(a.xsel ? 3 : 0) + c] = a.m0[c * a.stride + pid];
-    w[(a.xsel ? 0 : 3) + c] = a.xt_zero ? 0ull : a.m1[c * a.stride + pid];
-  }
-  uint4* r = rec + (long long)pid * 4;
-  r[0] = make_uint4((unsigned)w[0], (unsigned)(w[0] >> 32), (unsigned)w[1], (unsigned)(w[1] >> 32));
-  r[1] = make_uint4((unsigned)w[2], (unsigned)(w[2] >> 32), (unsigned)w[3], (unsigned)(w[3] >> 32));
-  r[2] = make_uint4((unsigned)w[4], (unsigned)(w[4] >> 32), (unsigned)w[5], (unsigned)(w[5] >> 32));
-  r[3] = make_uint4(a.m2[pid], a.m3[pid], a.m4[pid], 0u);
-}
-__global__ void k_rec_to_soa(int capacity, const unsigned char* __restrict__ mask, RecSoA a,
-                             const uint4* __restrict__ rec) {
-  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pid >= capacity || !mask[pid]) return;
-  const uint4* r = rec + (long long)pid * 4;
-  const uint4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
-  unsigned long long w[6];
-  w[0] = ((unsigned long long)q0.y << 32) | q0.x;
-  w[1] = ((unsigned long long)q0.w << 32) | q0.z;
-  w[2] = ((unsigned long long)q1.y << 32) | q1.x;
-  w[3] = ((unsigned long long)q1.w << 32) | q1.z;
-  w[4] = ((unsigned long long)q2.y << 32) | q2.x;
-  w[5] = ((unsigned long long)q2.w << 32) | q2.z;
-  for (int c = 0; c < 3; ++c) {
-    a.m0[c * a.stride + pid] = w[(a.xsel ? 3 : 0) + c];
-    a.m1[c * a.stride + pid] = a.xt_zero ? 0ull : w[(a.xsel ? 0 : 3) + c];
-  }
-  a.m2[pid] = q3.x;
-  a.m3[pid] = q3.y;
-  a.m4[pid] = q3.z;
-}
-// wave-level: every lane hands in one 64-B record (q[4]) and the slot it goes to (dst, -1 = none); the
-// wave stores them through an LDS transpose, four adjacent lanes one whole record (full 64-B sectors
-// leave the CU merged: k_move_pack)
-__device__ __forceinline__ void rec_scatter_wave(uint4 (*st)[5], int* sd, int l, int dst, const uint4* q,
-                                                 uint4* __restrict__ out) {
-  if (dst >= 0) {
-    st[l][0] = q[0];
-    st[l][1] = q[1];
-    st[l][2] = q[2];
-    st[l][3] = q[3];
-  }
-  sd[l] = dst;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int item = j * 64 + l, rc = item >> 2, part = item & 3;
-    const int d = sd[rc];
-    if (d >= 0) {
-      typedef unsigned v4u __attribute__((ext_vector_type(4)));
-      const uint4 x = st[rc][part];
-      v4u y;
-      y.x = x.x;
-      y.y = x.y;
-      y.z = x.z;
-      y.w = x.w;
-      __builtin_nontemporal_store(y, (v4u*)(out + (long long)d * 4 + part));
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-// The full re-layout's ONE data pass on records: thread = (old tile, row) reads the records of its row's
-// columns (64 consecutive records per wave instruction), every live particle goes to
-// first slot of the new row of its element + rank * C (rank: k_count_tiled).  The records travel
-// verbatim -- updatePtclPositions is the selector flip the host does afterwards.
-__global__ void __launch_bounds__(256)
-    k_move_rec(const int* __restrict__ ntiles_dev, int C, int TP, const int* __restrict__ tiles,
-               const int* __restrict__ chunk_start, const int* __restrict__ chunk_width,
-               const int* __restrict__ r2e, const int* __restrict__ count_old, int ne,
-               const int* __restrict__ new_element, const int* __restrict__ rank,
-               const int* __restrict__ eslot0_new, int C_new, const uint4* __restrict__ rec_old,
-               uint4* __restrict__ rec_new, const int* __restrict__ go) {
-  if (!*go) return;
-  __shared__ uint4 st[4][64][5];
-  __shared__ int sd[4][64];
-  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int tile = (int)(g / C), r = (int)(g - (long long)tile * C);
-  const bool valid = tile < *ntiles_dev;
-  int start = 0, p0 = 0, plive = 0;
-  if (valid) {
-    const int c = tiles[2 * tile];
-    p0 = tiles[2 * tile + 1];
-    start = chunk_start[c] + r;
-    const int e = r2e[c * C + r];
-    plive = min(min(p0 + TP, chunk_width[c]), e < ne ? count_old[e] : 0);  // live columns end here
-  }
-  int nmax = plive - p0;  // columns this wave has to visit: the longest of its rows
-  for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
-  for (int i = 0; i < nmax; ++i) {  // wave-uniform trip count
-    const int pid = start + (p0 + i) * C;
-    int dst = -1;
-    uint4 q[4];
-    if (p0 + i < plive) {
-      const int ne_ = new_element[pid];
-      if (ne_ >= 0) {
-        const uint4* rp = rec_old + (long long)pid * 4;
-        q[0] = rp[0];
-        q[1] = rp[1];
-        q[2] = rp[2];
-        q[3] = rp[3];
-        dst = eslot0_new[ne_] + rank[pid] * C_new;
-      }
-    }
-    rec_scatter_wave(st[w], sd[w], l, dst, q, rec_new);
-  }
-}
 // CSR staged move (same two passes as SCS): slot assignment by the element cursor, pack through
 // the LDS transpose into 64-B-multiple records, then a flat pass that writes the new SoA coalesced
 template <int NQ>
@@ -2455,99 +2332,6 @@ __global__ void k_rs_add(int n_new, const int* __restrict__ new_elems, const int
   const int tgt = hole_tab[eslot0[new_elems[i]] + rank_new[i] * C];
   copy_members(a, i, tgt);
 }
-// ---- the in-place rebuild on resident records.  The counting (k_rs_count's job) happened where the
-// walks ended (pp_search.hip: RecFinish): arrive / leave / removed are filled, every mover has its
-// arrival rank in rank[old slot] and a copy of its record in stage[old slot].  k_rs_fit, k_rs_match,
-// k_rs_go and k_rs_plan are shared with the SoA form; what moves here is whole 64-B records.
-__global__ void k_rs_stage_moved_rec(int C, const int* __restrict__ chunk_start, const int* __restrict__ n_old,
-                                     const int* __restrict__ new_element, int ne, RsMoves mv,
-                                     int* __restrict__ arrive, int* __restrict__ rank,
-                                     const uint4* __restrict__ rec, uint4* __restrict__ stage,
-                                     const Totals* __restrict__ tot) {
-  if (!tot->go) return;
-  const int lane = threadIdx.x & 63;
-  const int nwaves = gridDim.x * (blockDim.x >> 6);
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  for (int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < tot->n_moved; k += nwaves) {
-    const int E = mv.elem[k];
-    if (E >= ne) continue;  // a padding row has no particles
-    const int row = mv.old_row[k], start = chunk_start[row / C] + row % C, nold = n_old[E];
-    for (int p0 = 0; p0 < nold; p0 += 64) {
-      const int p = p0 + lane;
-      const long long pid = start + (long long)p * C;
-      const bool stays = p < nold && new_element[pid] == E;
-      const unsigned long long bal = __ballot(stays);
-      if (!bal) continue;
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&arrive[E], __popcll(bal));
-      base = __shfl(base, 0);
-      if (stays) {
-        rank[pid] = base + __popcll(bal & lt);
-        const uint4 a = rec[pid * 4], b = rec[pid * 4 + 1], c = rec[pid * 4 + 2], d = rec[pid * 4 + 3];
-        stage[pid * 4] = a;
-        stage[pid * 4 + 1] = b;
-        stage[pid * 4 + 2] = c;
-        stage[pid * 4 + 3] = d;
-      }
-    }
-  }
-}
-__global__ void k_rs_move_rec(const int* __restrict__ ntiles_dev, int C, int TP, int G,
-                              const int* __restrict__ tiles, const int* __restrict__ chunk_start,
-                              const int* __restrict__ chunk_width, const int* __restrict__ r2e,
-                              const int* __restrict__ n_old, const int* __restrict__ n_new,
-                              const int* __restrict__ new_element, int ne, const int* __restrict__ eslot0,
-                              const int* __restrict__ hole_tab, const int* __restrict__ rank,
-                              uint4* __restrict__ rec, const uint4* __restrict__ stage,
-                              const int* __restrict__ swap_old, const int* __restrict__ go) {
-  if (!*go) return;
-  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int grp = (int)(g / C), r = (int)(g - (long long)grp * C);
-  const int ntiles = *ntiles_dev;
-  int cur = -1, e = -1, start = 0, nold = 0, nnew = 0;
-  bool moved_out = false;  // the element that lived in this physical row traded places: all of it travels
-  for (int k = 0; k < G; ++k) {
-    const int tile = grp * G + k;
-    if (tile >= ntiles) break;
-    const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
-    if (c != cur) {
-      cur = c;
-      start = chunk_start[c] + r;
-      e = r2e[c * C + r];
-      const int so = swap_old[c * C + r];
-      moved_out = so >= 0 && so != e;
-      if (moved_out) e = so;  // the particles in these slots belong to the element that moved out
-      nold = nnew = 0;
-      if (e < ne) {
-        nold = n_old[e];
-        nnew = n_new[e];
-      }
-    }
-    const int pend = min(min(p0 + TP, chunk_width[c]), nold);
-    for (int p = p0; p < pend; ++p) {
-      const int pid = start + p * C;
-      const int ne_ = new_element[pid];
-      const uint4* sp;
-      long long tgt;
-      if (ne_ == e && !moved_out) {
-        if (p < nnew) continue;                        // stays where it is
-        tgt = hole_tab[start + rank[pid] * C];         // back-fills a hole of its own row
-        sp = rec + (long long)pid * 4;                 // (nobody writes columns >= the new count)
-      } else if (ne_ >= 0) {
-        tgt = hole_tab[eslot0[ne_] + rank[pid] * C];  // the hole its arrival rank names
-        sp = stage + (long long)pid * 4;
-      } else {
-        continue;
-      }
-      const uint4 a = sp[0], b = sp[1], cq = sp[2], d = sp[3];
-      uint4* dp = rec + tgt * 4;
-      dp[0] = a;
-      dp[1] = b;
-      dp[2] = cq;
-      dp[3] = d;
-    }
-  }
-}
 __global__ void k_zero_gated(unsigned long long* __restrict__ p, long long n, const int* __restrict__ go) {
   if (!*go) return;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -3074,130 +2858,7 @@ int scs_reshuffle(pp_ps* ps, const int* new_element, int n_new, const int* new_e
   }
   ++ps->n_reshuffles;
   ps->n_rows_moved += h.n_moved;
-  return 1;
-}
-
-// The in-place rebuild on resident records (shuffle mode 2, counters filled by the fused push).  Same
-// decisions, tables and return values as scs_reshuffle; what differs is the storage the particles move
-// in (whole 64-B records, one store per particle instead of one per component) and that the counting
-// pass already happened.  updatePtclPositions is the flip of rec_xsel.
-int scs_reshuffle_rec(pp_ps* ps, const int* new_element, bool commit,
-                      const std::function<int(const int*)>& pre_sync) {
-  if (!(ps->capacity > 0 && ps->num_ptcls > 0) || !ps->elem_count_valid || ps->ntiles_max <= 0) return 0;
-  if (ps->d_eslot0.bytes < sizeof(int) * (size_t)std::max(ps->num_elems, 1)) return 0;
-  const int ne = ps->num_elems;
-  hipStream_t st = pp::stream();
-  PP_HIP_CHECK(ps->s_ppe.reserve(sizeof(int) * (size_t)std::max(ne, 1)));
-  PP_HIP_CHECK(ps->s_misc.reserve(sizeof(Totals)));
-  PP_HIP_CHECK(ps->s_holes.reserve(sizeof(int) * (size_t)ps->capacity));
-  PP_HIP_CHECK(hipMemsetAsync(ps->s_misc.p, 0, sizeof(Totals), st));
-  const size_t rows_cap = (size_t)ps->num_rows + 64 * 1024 + 64;
-  PP_HIP_CHECK(ps->s_rsx.reserve(sizeof(int) * (2 * (size_t)kMaxOver + rows_cap + 3 * (size_t)kMaxMoves)));
-  int* ov_list = ps->s_rsx.as<int>();
-  int* pool_list = ov_list + kMaxOver;
-  int* swap_old = pool_list + kMaxOver;
-  RsMoves mvs{swap_old + rows_cap, swap_old + rows_cap + kMaxMoves, swap_old + rows_cap + 2 * (size_t)kMaxMoves};
-  PP_HIP_CHECK(hipMemsetAsync(swap_old, 0xff, sizeof(int) * (size_t)ps->num_rows, st));
-  RsPool pl{};
-  {
-    long long room = (long long)(ps->d_rec.bytes / pp::kRecBytes) - ps->capacity;
-    room = std::min<long long>(room, (long long)(ps->s_stage.bytes / pp::kRecBytes) - ps->capacity);
-    room = std::min<long long>(room, (long long)ps->d_mask.bytes - ps->capacity);
-    room = std::min<long long>(room, (long long)(ps->d_slot_elem.bytes / 4) - ps->capacity);
-    room = std::min<long long>(room, (long long)(ps->s_idx.bytes / 4) - ps->capacity);
-    room = std::min<long long>(room, (long long)(ps->s_holes.bytes / 4) - ps->capacity);
-    pl.room_slots = (int)std::max<long long>(0, std::min<long long>(room, 1 << 28));
-    long long rows = std::min<long long>((long long)(ps->d_row_to_element.bytes / 4),
-                                         (long long)(ps->d_element_to_row.bytes / 4)) - ps->num_rows;
-    rows = std::min<long long>(rows, 64 * 1024);
-    pl.room_rows = (int)std::max<long long>(0, rows);
-    pl.room_chunks = (int)std::max<long long>(
-        0, std::min<long long>((long long)(ps->d_chunk_start.bytes / 4), (long long)(ps->d_chunk_width.bytes / 4)) -
-               ps->num_chunks);
-    pl.room_tiles = (int)std::max<long long>(0, (long long)(ps->d_tiles.bytes / 8) - ps->ntiles_max - 1);
-    pl.room_slices = (int)std::max<long long>(
-        0, std::min<long long>((long long)(ps->d_offsets.bytes / 4) - ps->num_slices - 2,
-                               (long long)(ps->d_slice_to_chunk.bytes / 4) - ps->num_slices - 1));
-    pl.sorted_chunks = std::min(ps->sorted_chunks, ps->num_chunks);
-    pl.V = ps->V;
-    pl.TP = ps->tile_p;
-    pl.offsets = ps->d_offsets.as<int>();
-    pl.s2c = ps->d_slice_to_chunk.as<int>();
-    pl.tiles = ps->d_tiles.as<int>();
-    pl.ntiles = ps->d_ntiles.as<int>();
-    pl.chunk_start_w = ps->d_chunk_start.as<int>();
-    pl.chunk_width_w = ps->d_chunk_width.as<int>();
-    pl.slot_elem = ps->d_slot_elem.as<int>();
-    pl.mask = ps->d_mask.as<unsigned char>();
-    pl.pool_list = pool_list;
-  }
-  Totals* tot = ps->s_misc.as<Totals>();
-  RsCounters cn{ps->s_rs.as<int>(), ps->s_rs.as<int>() + ne, ps->s_rs.as<int>() + 2 * (size_t)ne,
-                ps->s_rs.as<int>() + 3 * (size_t)ne, ps->s_rs.as<int>() + 4 * (size_t)ne};
-  int* n_new_e = ps->s_ppe.as<int>();
-  const int* n_old = ps->d_elem_count.as<int>();
-  int* rank = ps->s_idx.as<int>();
-  int* holes = ps->s_holes.as<int>();
-  uint4* rec = ps->d_rec.as<uint4>();
-  uint4* stage = ps->s_stage.as<uint4>();
-  const int G = std::max(1, 32 / ps->tile_p);
-  const size_t tiles_bound = (size_t)ps->ntiles_max + (size_t)pl.room_tiles;
-  const unsigned grp_grid = grid_for((tiles_bound + G - 1) / G * ps->C);
-#define PP_RS_TILES                                                                                  \
-  ps->d_ntiles.as<int>(), ps->C, ps->tile_p, G, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(), \
-      ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>()
-  k_rs_fit<<<std::min(grid_for(std::max(ne, 1)), 256u), kBlock, 0, st>>>(
-      ne, ps->C, n_old, cn, ps->d_element_to_row.as<int>(), ps->d_chunk_width.as<int>(), n_new_e, tot, ov_list, 0);
-  static const int probe = getenv("PP_RS_PROBE") ? atoi(getenv("PP_RS_PROBE")) : 256;
-  k_rs_match<<<1, 1024, 0, st>>>(ne, ps->C, ps->num_chunks, ps->d_chunk_width.as<int>(),
-                                 ps->d_chunk_start.as<int>(), ps->d_row_to_element.as<int>(),
-                                 ps->d_element_to_row.as<int>(), ps->d_eslot0.as<int>(), n_new_e, ov_list, swap_old,
-                                 mvs, tot, probe, ps->capacity, ps->num_slices, pl);
-  k_rs_go<<<1, 1, 0, st>>>(tot, 1);
-  const int* go = &tot->go;
-  k_rs_stage_moved_rec<<<512, kBlock, 0, st>>>(ps->C, ps->d_chunk_start.as<int>(), n_old, new_element, ne, mvs,
-                                               cn.arrive, rank, rec, stage, tot);
-  k_rs_plan<<<grp_grid, kBlock, 0, st>>>(PP_RS_TILES, n_old, n_new_e, new_element, ne, cn, holes, rank,
-                                        ps->d_mask.as<unsigned char>(), swap_old, ps->d_slot_elem.as<int>(), go);
-  k_rs_move_rec<<<grp_grid, kBlock, 0, st>>>(PP_RS_TILES, n_old, n_new_e, new_element, ne, ps->d_eslot0.as<int>(),
-                                            holes, rank, rec, stage, swap_old, go);
-#undef PP_RS_TILES
-  PP_LAUNCH_CHECK();
-  Totals* h_pin;
-  hipEvent_t ev_tot;
-  int rc = totals_pin(&h_pin, &ev_tot);
-  if (rc) return rc;
-  PP_HIP_CHECK(hipMemcpyAsync(h_pin, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
-  PP_HIP_CHECK(hipEventRecord(ev_tot, st));
-  if (pre_sync) {  // the new per-element counts are final whether or not the layout can be kept
-    rc = pre_sync(n_new_e);
-    if (rc) return rc;
-  }
-  PP_HIP_CHECK(hipEventSynchronize(ev_tot));
-  const Totals h = *h_pin;
-  if (getenv("PP_SPEC_DEBUG"))
-    fprintf(stderr, "rebuild in place (records): go %d active %d nonempty %d overflowing rows %d rows moved %d "
-                    "no home %d capacity %d -> %d chunks +%d\n", h.go, h.active, h.nonempty, h.n_over, h.n_moved,
-            h.match_fail, ps->capacity, h.capacity, h.cw_cnt);
-  if (!h.go) return 0;
-  ps->d_elem_count.swap(ps->s_ppe);
-  ps->version = pp::next_version();
-  ps->num_ptcls = h.active;
-  ps->num_empty_elements = (ps->num_rows - ne) + (ne - h.nonempty);
-  if (h.capacity > ps->capacity) {  // pool chunks were appended
-    ps->capacity = h.capacity;
-    ps->num_slices = h.nslices;
-    ps->ntiles_max = std::max(ps->ntiles_max, h.cw_sum);
-    ps->num_chunks += h.cw_cnt;
-    ps->num_rows = ps->num_chunks * ps->C;
-    ps->num_empty_elements = (ps->num_rows - ne) + (ne - h.nonempty);
-  }
-  if (commit) {
-    ps->rec_xsel ^= 1;
-    ps->rec_xt_zero = true;
-  }
-  ++ps->n_reshuffles;
-  ps->n_rows_moved += h.n_moved;
+  ps->lazy_rec = 0;  // (a commit that came in with only the origin in records: the origin is the old target now)
   return 1;
 }
 
@@ -3210,38 +2871,18 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   hipStream_t st = pp::stream();
   const int ne = ps->num_elems;
   PP_REQUIRE(n_new == 0 || new_info != nullptr, "rebuild: new particles need new_info_dev");
-  // Resident records (rec_resident): the rebuild moves whole records.  Shuffle mode 2 + counters filled by
-  // the fused push from these very ids: the in-place form (scs_reshuffle_rec).  Otherwise the full
-  // re-layout with ONE data pass (k_move_rec).  New particles or a commit of other members go back to the
-  // SoA arrays first.
-  const bool commit_ok = (commit_x == 0 && commit_xt == 1) || (commit_x < 0 && commit_xt < 0);
-  bool rec = ps->rec_resident && n_new == 0 && ps->capacity > 0 && ps->num_ptcls > 0 && commit_ok;
-  const bool fused = rec && ps->fused_count_valid && ps->fused_ids == new_element;
-  ps->fused_count_valid = false;  // consumed (or stale) either way
-  pp::Range rg("scs_rebuild");
-  if (try_reshuffle && ps->shuffle_mode >= 2 && fused) {
-    bool scattered = false;
-    std::function<int(const int*)> once;
-    if (pre_sync)
-      once = [&](const int* c) {
-        scattered = true;
-        return pre_sync(c);
-      };
-    const int rc0 = scs_reshuffle_rec(ps, new_element, commit_x >= 0, once);
-    if (rc0 < 0) return rc0;
-    if (rc0 == 1) return PP_OK;
-    // the headroom is used up: full re-layout, still on records (it counts by itself)
-    return scs_rebuild(ps, new_element, n_new, new_elems, new_info, commit_x, commit_xt,
-                       scattered ? std::function<int(const int*)>() : pre_sync, false);
-  }
-  if (try_reshuffle && ps->shuffle_mode >= 2) rec = false;  // (the SoA form of the in-place rebuild counts and stages)
-  if (!rec) {
-    int rc0 = pp::ps_ready(ps);  // records -> SoA; zeros left pending by the previous in-place rebuild
+  // zeros left pending by the previous in-place rebuild; records left by the previous full re-layout.
+  // Exception: after the record-fed push only the ORIGIN (member lazy_x) is still in records, and a
+  // rebuild that commits the same pair of members never reads it.
+  if (!(ps->lazy_rec == 2 && ps->zero_pending < 0 && n_new == 0 && commit_x == ps->lazy_x &&
+        commit_xt == ps->lazy_xt)) {
+    int rc0 = pp::ps_ready(ps);
     if (rc0) return rc0;
   }
-  // Mode 2 (elastic) tries the in-place path first.  Mode 1 (the reference's decision) evaluates the
-  // decision on the histogram of the full path below, which costs nothing when the layout cannot be
-  // kept -- the normal case at 10^5 rows.
+  pp::Range rg("scs_rebuild");
+  // Mode 2 (elastic, opt-in) tries the in-place path first.  Mode 1 (the reference's decision)
+  // evaluates the decision on the histogram of the full path below, which costs nothing when the
+  // layout cannot be kept -- the normal case at 10^5 rows.
   if (try_reshuffle && ps->shuffle_mode >= 2) {
     int rc0;
     bool scattered = false;
@@ -3260,7 +2901,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
                        scattered ? std::function<int(const int*)>() : pre_sync, false);
   }
   // histogram and totals in one allocation: one fill clears both (a fill is a ~5 us dispatch)
-  const size_t tot_off = hist_tot_off(ne);
+  const size_t tot_off = (sizeof(int) * (size_t)std::max(ne, 1) + 255) / 256 * 256;
   PP_HIP_CHECK(ps->s_ppe.reserve(tot_off + sizeof(Totals)));
   PP_HIP_CHECK(hipMemsetAsync(ps->s_ppe.p, 0, tot_off + sizeof(Totals), st));
   Totals* tot = (Totals*)((char*)ps->s_ppe.p + tot_off);
@@ -3385,12 +3026,8 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     long long sq = fit / 64;
     while (sq > 0 && sq % 32 != 17) --sq;
     stride_fit = sq * 64;
-    if (rec) {  // the move writes records, not the swap arrays
-      stride_fit = ps->swap_stride;
-      cap_lim = std::min<long long>(cap_lim, (long long)(ps->s_rec.bytes / pp::kRecBytes));
-    } else
-      cap_lim = std::min<long long>(cap_lim, stride_fit);
-    if (!rec && cap_lim > 0 && getenv("PP_DIRECT_MOVE") == nullptr) {  // staging buffer: NQ quads per slot
+    cap_lim = std::min<long long>(cap_lim, stride_fit);
+    if (cap_lim > 0 && getenv("PP_DIRECT_MOVE") == nullptr) {  // staging buffer: NQ quads per slot
       const void* srcs[8];
       for (int m = 0; m < ps->nmembers; ++m) srcs[m] = ps->data[m].p;
       WordTable wt_probe{};
@@ -3416,7 +3053,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   nrows = L.nrows;
   const int* go = &tot->go;
   int NQ = 0;
-  bool lazy_zero = false;
+  bool lazy_zero = false, defer_unpack = false;
   // Everything after the layout: new layout arrays, slot tables and the move of every member.
   // `cap_sz` / `nsl_sz` size the buffers and the launches; the kernels themselves read the true
   // counts from the device (ntiles, Totals), and all of them return at once when tot->go == 0.
@@ -3431,14 +3068,6 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
         new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_r2e2.as<int>(),
         ppe, ne, ps->s_slot2.as<int>(), ps->s_rowstart.as<int>(), ps->s_eslot0.as<int>(),
         ps->s_mask2.as<unsigned char>(), go);
-    if (rec) {  // ---- resident records: one pass, every live record to its new slot
-      PP_HIP_CHECK(ps->s_rec.reserve(((size_t)std::max(cap_sz, 1) + (size_t)growth_reserve(ps, cap_sz)) * pp::kRecBytes));
-      k_move_rec<<<old_grid, kBlock, 0, st>>>(
-          ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(),
-          ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(), ps->d_elem_count.as<int>(), ne, new_element,
-          rank, ps->s_eslot0.as<int>(), C_new, ps->d_rec.as<uint4>(), ps->s_rec.as<uint4>(), go);
-      return PP_OK;
-    }
     // ---- swap buffer sizing (SCS_rebuild.h:223-229)
     int64_t swap_stride = ps->swap_stride;
     if (stride_fixed > 0) {  // speculative tail: whatever the swap buffers hold today
@@ -3467,6 +3096,11 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       // pass 2 would write per particle.
       lazy_zero = NQ > 0 && commit_x >= 0 && commit_xt >= 0 && n_new == 0 && getenv("PP_NO_LAZY_ZERO") == nullptr;
       if (lazy_zero) wt.nz8 = wt.nz4 = 0;
+      // The second pass (records -> new SoA arrays) is deferred for the pseudoXGCm particle type: the
+      // next fused push reads the records themselves (pp_search.hip: RECIN), anything else runs the
+      // pass first (ps_ready).  One pass over the particles less per step of the pseudoXGCm loop.
+      static const bool no_defer = getenv("PP_NO_LAZY_UNPACK") != nullptr;
+      defer_unpack = lazy_zero && NQ == 4 && !no_defer && xgcm_shape(ps);
     }
     if (NQ > 0) {
       PP_HIP_CHECK(ps->s_aos.reserve((size_t)std::max(cap_sz, 1) * NQ * 16));
@@ -3478,7 +3112,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
 #define PP_STAGED(N)                                                                             \
   case N:                                                                                        \
     k_move_pack<N><<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, rank, rs, aos, wt, go); \
-    k_move_unpack<N><<<new_grid, kBlock, 0, st>>>(PP_UNPACK_ARGS);                               \
+    if (!defer_unpack) k_move_unpack<N><<<new_grid, kBlock, 0, st>>>(PP_UNPACK_ARGS);            \
     break;
       const RankToSlot rs{new_element, ps->s_eslot0.as<int>(), C_new};
       switch (NQ) {
@@ -3549,7 +3183,6 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     // speculative re-layout tail did not run (k_spec_check); the in-place path does the work.  Rare at
     // scale (some row of 10^5 overflows its padding nearly every step), common for small structures.
     ps->swap_stride = swap_stride_before;
-    if (rec && (rc = pp::ps_ready(ps))) return rc;  // the in-place path works on the SoA arrays
     const int mode = ps->shuffle_mode;
     rc = scs_reshuffle(ps, new_element, n_new, new_elems, new_info, commit_x, commit_xt,
                        std::function<int(const int*)>());  // (the scatters ran behind the histogram above)
@@ -3566,7 +3199,6 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   }
   if (h.active == 0) {  // SCS_rebuild.h:168-182: no particle left -- resetMask, structure kept
     ps->swap_stride = swap_stride_before;
-    if (rec && (rc = pp::ps_ready(ps))) return rc;
     // the fused commit still happens: the drivers call updatePtclPositions before the rebuild
     if (commit_x >= 0 && commit_xt >= 0 && ps->num_ptcls > 0) {
       rc = pp_update_positions(ps, commit_x, commit_xt);
@@ -3616,18 +3248,15 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   ntiles_max = nchunks + new_capacity / (C_new * ps->tile_p) + 1;  // launch bound of the next calls
   PP_LAUNCH_CHECK();
   // ---- swap in
-  if (rec) {
-    ps->d_rec.swap(ps->s_rec);  // (the SoA arrays stay stale: rec_resident)
-    ps->swap_stride = swap_stride_before;
-    ps->zero_pending = -1;
-    if (commit_x >= 0) {  // updatePtclPositions: members 0 and 1 trade places, member 1 is now all zero
-      ps->rec_xsel ^= 1;
-      ps->rec_xt_zero = true;
-    }
-  } else {
-    ps->data.swap(ps->swap);
-    std::swap(ps->stride, ps->swap_stride);
-    ps->zero_pending = lazy_zero ? commit_xt : -1;
+  ps->data.swap(ps->swap);
+  std::swap(ps->stride, ps->swap_stride);
+  ps->zero_pending = lazy_zero ? commit_xt : -1;
+  ps->lazy_rec = 0;
+  if (defer_unpack && NQ == 4) {  // the records of the first pass are what holds the particles now
+    ps->s_aos.swap(ps->s_aos_live);
+    ps->lazy_rec = 1;
+    ps->lazy_x = commit_x;
+    ps->lazy_xt = commit_xt;
   }
   ps->d_offsets.swap(ps->s_offsets2);
   ps->d_slice_to_chunk.swap(ps->s_s2c2);
@@ -3789,95 +3418,49 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
 }  // namespace
 
 namespace pp {
-static RecSoA rec_soa(const pp_ps* ps) {
-  RecSoA a;
-  a.m0 = ps->data[0].as<unsigned long long>();
-  a.m1 = ps->data[1].as<unsigned long long>();
-  a.m2 = ps->data[2].as<unsigned>();
-  a.m3 = ps->data[3].as<unsigned>();
-  a.m4 = ps->data[4].as<unsigned>();
-  a.stride = ps->stride;
-  a.xsel = ps->rec_xsel;
-  a.xt_zero = ps->rec_xt_zero ? 1 : 0;
-  return a;
+bool lazy_push_ok(const pp_ps* ps, int m_x, int m_xtgt, int m_b, int m_phi) {
+  if (!ps || ps->lazy_rec != 1 || ps->kind != PP_SCS || !xgcm_shape(ps)) return false;
+  for (int m = 0; m < 5; ++m)
+    if (ps->member_map[m] != m) return false;
+  return m_x == 0 && m_xtgt == 1 && m_b == 3 && m_phi == 4 && ps->lazy_x == 0 && ps->lazy_xt == 1;
 }
 int ps_materialize(pp_ps* ps) {
-  if (ps->rec_resident) {
-    // the particles live in the 64-B records: write the SoA arrays back (the capacity may have grown
-    // while nobody looked at them)
-    ps->rec_resident = false;
-    ps->fused_count_valid = false;
-    if (ps->capacity > 0) {
-      if (ps->stride < ps->capacity || (int)ps->data.size() < ps->nmembers) {
-        const int64_t stride =
-            spread_stride((int64_t)(ps->capacity * (1 + ps->extra_padding)) + growth_reserve(ps, ps->capacity));
-        int rc = alloc_members(ps, ps->data, stride, true);
-        if (rc) return rc;
-        ps->stride = stride;
+  if (ps->lazy_rec) {
+    // the deferred second pass of the last full re-layout: records -> SoA arrays, for every member that
+    // is still only in the records (all that travelled / the origin only)
+    const int state = ps->lazy_rec;
+    ps->lazy_rec = 0;
+    if (ps->capacity > 0 && ps->num_ptcls > 0) {
+      WordTable wt{};
+      for (int m = 0; m < ps->nmembers; ++m) {
+        if (m == ps->lazy_xt) continue;  // logically zero (zero_pending)
+        const int b = ps->member_bytes[m];
+        for (int cc = 0; cc < ps->member_ncomp[m]; ++cc) {
+          char* dst = (state == 2 && m != ps->lazy_x) ? nullptr : (char*)ps->data[m].p + ((size_t)cc * ps->stride) * b;
+          if (b == 8)
+            wt.dst8[wt.n8++] = dst;
+          else
+            wt.dst4[wt.n4++] = dst;
+        }
       }
-      k_rec_to_soa<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
-          ps->capacity, ps->d_mask.as<unsigned char>(), rec_soa(ps), ps->d_rec.as<uint4>());
+      static int* go_one = nullptr;
+      if (!go_one) {
+        PP_HIP_CHECK(hipMalloc((void**)&go_one, sizeof(int)));
+        const int one = 1;
+        PP_HIP_CHECK(hipMemcpy(go_one, &one, sizeof(int), hipMemcpyHostToDevice));
+      }
+      if (state == 2) wt.n4 = 0;  // (4-byte members were written by the push; 8-byte ones: only lazy_x has a target)
+      k_move_unpack<4><<<grid_for((size_t)ps->ntiles_max * ps->C), kBlock, 0, pp::stream()>>>(
+          ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(),
+          ps->d_chunk_width.as<int>(), ps->d_mask.as<unsigned char>(), ps->s_aos_live.as<uint4>(), wt, go_one);
       PP_LAUNCH_CHECK();
     }
-    ps->rec_xsel = 0;
-    ps->rec_xt_zero = false;
   }
   const int s = ps->zero_pending;
   if (s < 0) return PP_OK;
   ps->zero_pending = -1;
   const size_t bytes = (size_t)ps->stride * ps->member_ncomp[s] * ps->member_bytes[s];
   if (bytes) PP_HIP_CHECK(hipMemsetAsync(ps->data[s].p, 0, bytes, pp::stream()));
-  return PP_OK;
-}
-bool rec_usable(const pp_ps* ps, int m_x, int m_xtgt, int m_b, int m_phi) {
-  if (!ps || ps->kind != PP_SCS || ps->nmembers != 5 || !ps->elem_count_valid) return false;
-  static const int want_b[5] = {8, 8, 4, 4, 4}, want_c[5] = {3, 3, 1, 1, 1};
-  for (int m = 0; m < 5; ++m)
-    if (ps->member_map[m] != m || ps->member_bytes[m] != want_b[m] || ps->member_ncomp[m] != want_c[m]) return false;
-  return m_x == 0 && m_xtgt == 1 && m_b == 3 && m_phi == 4;
-}
-int rec_begin_push(pp_ps* ps, const int* ids_dev, RecPushPtrs* out) {
-  hipStream_t st = pp::stream();
-  if (!ps->rec_resident) {
-    // (x_tgt that is only logically zero after an in-place commit on the SoA arrays: packed as zeros)
-    ps->rec_xsel = 0;
-    ps->rec_xt_zero = ps->zero_pending == 1;
-    if (ps->zero_pending >= 0 && ps->zero_pending != 1) {
-      int rc = ps_materialize(ps);
-      if (rc) return rc;
-    }
-    ps->zero_pending = -1;
-    PP_HIP_CHECK(ps->d_rec.reserve(((size_t)ps->capacity + (size_t)growth_reserve(ps, ps->capacity)) * kRecBytes));
-    k_rec_from_soa<<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, ps->d_mask.as<unsigned char>(),
-                                                             rec_soa(ps), ps->d_rec.as<uint4>());
-    PP_LAUNCH_CHECK();
-    ps->rec_resident = true;
-  }
-  *out = RecPushPtrs{};
-  out->rec = ps->d_rec.as<char>();
-  out->elem_count = ps->d_elem_count.as<int>();
-  out->xoff = ps->rec_xsel ? 24 : 0;
-  out->xt_zero = ps->rec_xt_zero ? 1 : 0;
-  ps->rec_xt_zero = false;  // the push writes member 1 of every live particle
-  ps->fused_count_valid = false;
-  static const bool no_fuse = getenv("PP_REC_NO_FUSED_COUNT") != nullptr;  // A/B knob
-  if (ps->shuffle_mode >= 2 && !no_fuse) {
-    // in-place rebuild: its counters are filled where the walks end (pp_search.hip: RecFinish)
-    const size_t ne = (size_t)std::max(ps->num_elems, 1);
-    const size_t room = (size_t)growth_reserve(ps, ps->capacity);
-    PP_HIP_CHECK(ps->s_rs.reserve(sizeof(int) * 5 * ne));
-    PP_HIP_CHECK(hipMemsetAsync(ps->s_rs.p, 0, sizeof(int) * 5 * ne, st));
-    PP_HIP_CHECK(ps->s_idx.reserve(sizeof(int) * ((size_t)ps->capacity + room)));
-    PP_HIP_CHECK(ps->s_stage.reserve(((size_t)ps->capacity + room) * kRecBytes));
-    out->arrive = ps->s_rs.as<int>();
-    out->leave = ps->s_rs.as<int>() + ne;
-    out->removed = ps->s_rs.as<int>() + 4 * ne;
-    out->rank = ps->s_idx.as<int>();
-    out->stage = ps->s_stage.as<char>();
-    out->slot_elem = ps->d_slot_elem.as<int>();
-    ps->fused_count_valid = true;
-    ps->fused_ids = ids_dev;
-  }
   return PP_OK;
 }
 }  // namespace pp
@@ -4080,25 +3663,12 @@ int64_t pp_ps_member_stride(const pp_ps* ps) { return ps ? ps->stride : 0; }
 int pp_ps_swap_members(pp_ps* ps, int a, int b) {
   PP_REQUIRE(ps && a >= 0 && b >= 0 && a < ps->nmembers && b < ps->nmembers,
              "pp_ps_swap_members: bad member index");
+  if (int rc = pp::ps_ready(ps)) return rc;  // (deferred passes are keyed on storage indices)
   const int sa = ps->member_map[a], sb = ps->member_map[b];
   PP_REQUIRE(ps->member_bytes[sa] == ps->member_bytes[sb] &&
                  ps->member_ncomp[sa] == ps->member_ncomp[sb],
              "pp_ps_swap_members: members differ in type");
   std::swap(ps->member_map[a], ps->member_map[b]);
-  return PP_OK;
-}
-
-int pp_ps_set_resident_records(pp_ps* ps, int on) {
-  PP_REQUIRE(ps, "pp_ps_set_resident_records: null ps");
-  if (!on && ps->rec_resident)
-    if (int rc = pp::ps_ready(ps)) return rc;
-  ps->rec_mode = on ? 1 : 0;
-  return PP_OK;
-}
-int pp_ps_resident_records(const pp_ps* ps) { return ps ? (ps->rec_resident ? 2 : ps->rec_mode) : 0; }
-int pp_ps_ids_modified(pp_ps* ps) {
-  PP_REQUIRE(ps, "pp_ps_ids_modified: null ps");
-  ps->fused_count_valid = false;
   return PP_OK;
 }
 
@@ -4177,8 +3747,7 @@ int pp_ps_rebuild(pp_ps* ps, const int* new_element_dev, int n_new, const int* n
   pp::Range rg_("ps_rebuild");
   PP_REQUIRE(ps && (new_element_dev || ps->capacity == 0), "pp_ps_rebuild: null argument");
   PP_REQUIRE(n_new >= 0 && (n_new == 0 || new_elems_dev), "pp_ps_rebuild: bad new particles");
-  if (!ps->rec_resident)  // (resident records: scs_rebuild decides whether it can stay on them)
-    if (int rc = pp::ps_ready(ps)) return rc;
+  if (int rc = pp::ps_ready(ps)) return rc;
   // storage order of members may be permuted by pp_ps_swap_members: normalise first
   for (int m = 0; m < ps->nmembers; ++m)
     if (ps->member_map[m] != m) {

@@ -910,6 +910,7 @@ struct PState {
   float phi, b;
   double x, y, z;
   int elem;
+  unsigned id;  // record-fed form only: the particle's third member travels through the kernel
 };
 // NT: non-temporal (streaming) cache policy for the particle streams, so that the 4 MB L2 of an
 // XCD keeps the element records instead of particle data it will never see again
@@ -941,6 +942,34 @@ __device__ __forceinline__ PState load_state(int pid, const unsigned char* __res
     s.z = ld<NT>(x + 2 * stride + pid);
   }
   s.elem = read_ids ? ld<NT>(elem_ids + pid) : -1;
+  return s;
+}
+
+// Record-fed form (RECIN) of the queued kernel.  After a full re-layout with the fused updatePtclPositions
+// the particles are still in the 64-B staging records of the move's first pass (pp_ps.hip: k_move_pack;
+// words 0-5 x, 13 phi, 14 b, 15 the 4-byte third member) -- the second pass, which would copy them into
+// the SoA arrays only for this kernel to read them back, is skipped (pp_ps::lazy_rec).  The state of a
+// column is three loads from one record; the members the next rebuild packs from the SoA arrays (third
+// member, b; x_tgt and phi are written anyway) are written here.
+struct RecIn {
+  const char* rec;  // null = SoA input
+  unsigned* id_out;
+  float* b_out;
+};
+__device__ __forceinline__ PState load_state_recin(int pid, const unsigned char* __restrict__ mask,
+                                                   const char* __restrict__ rec) {
+  PState s;
+  s.m = mask[pid];
+  const char* rp = rec + (long long)pid * 64;
+  const double2 q0 = *(const double2*)rp;
+  s.x = q0.x;
+  s.y = q0.y;
+  s.z = *(const double*)(rp + 16);
+  const uint4 q3 = *(const uint4*)(rp + 48);
+  s.phi = __uint_as_float(q3.y);
+  s.b = __uint_as_float(q3.z);
+  s.id = q3.w;
+  s.elem = -1;
   return s;
 }
 
@@ -1178,6 +1207,8 @@ struct WalkArgs {
   int seeded, nelems, cap;
   Counters* cnt;
   int abl;
+  unsigned* id_out;  // record-fed form: SoA arrays of the third member and of b (null otherwise)
+  float* b_out;
 };
 // One particle of one column, seed record already in `cache`: push, x_tgt/phi stores,
 // check_initial_parents (3-D), first walk step.  Returns true when the particle crossed into
@@ -1188,6 +1219,10 @@ __device__ __forceinline__ bool column_math(const WalkArgs& A, const PState& s, 
                                             const RecCache<DIM>& cache, int& elem, V3& dest) {
   if (act && !s.m && (DIM == 2 || !A.seeded)) stg<NT>(A.elem_ids + pid, -1);
   if (!live) return false;
+  if (A.id_out) {
+    stg<NT>(A.id_out + pid, s.id);
+    stg<NT>(A.b_out + pid, s.b);
+  }
   double rad;
   bool done = false;
   bool origin_ok = true;
@@ -1275,20 +1310,11 @@ __device__ __forceinline__ int seed_of(const PState& s, int e, int seeded, int n
   return seeded ? s.elem : e;
 }
 
-// resident records + in-place rebuild: what the end of a deferred walk adds to (pp_ps.hip: RsCounters)
-struct RecFinish {
-  char* rec = nullptr;
-  char* stage = nullptr;           // staged copies of the movers' records, indexed like rec
-  int *arrive = nullptr, *leave = nullptr, *removed = nullptr;
-  int* rank = nullptr;             // arrival rank of every mover, by old slot
-  const int* slot_elem = nullptr;  // element of every slot
-};
 // walks the entries of `nreg` consecutive queue regions (region i holds my_cnt-of-lane-i entries)
 template <int DIM>
 __device__ __forceinline__ void walk_pending(const PendEntry* __restrict__ regions, long long region_stride,
                                              int nreg, int my_cnt, const void* __restrict__ recs,
-                                             int* elem_ids, int cap, Counters* cnt, double2* st, int lane,
-                                             const RecFinish* F = nullptr) {
+                                             int* elem_ids, int cap, Counters* cnt, double2* st, int lane) {
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   int reg = 0, off = 0;  // wave-uniform cursor
   int reg_cnt = __shfl(my_cnt, 0);
@@ -1341,34 +1367,12 @@ __device__ __forceinline__ void walk_pending(const PendEntry* __restrict__ regio
       }
       if (fin) {
         elem_ids[en.pid] = welem;
-        // resident records, in-place rebuild: the walk's end is where the rebuild's counting happens.
-        // A particle that ends outside the element of its slot leaves that row (leave / removed), takes
-        // the next arrival rank of its new element and is staged -- its slot may be another particle's
-        // target (k_rs_count does this for the SoA arrays in a pass of its own).
-        if (F) {
-          const int home = F->slot_elem[en.pid];
-          if (welem != home) {
-            atomicAdd(&F->leave[home], 1);
-            if (welem < 0) {
-              atomicAdd(&F->removed[home], 1);
-            } else {
-              F->rank[en.pid] = atomicAdd(&F->arrive[welem], 1);
-              const uint4* sp = (const uint4*)(F->rec + (long long)en.pid * pp::kRecBytes);
-              uint4* dp = (uint4*)(F->stage + (long long)en.pid * pp::kRecBytes);
-              const uint4 a = sp[0], b = sp[1], c = sp[2], d = sp[3];
-              dp[0] = a;
-              dp[1] = b;
-              dp[2] = c;
-              dp[3] = d;
-            }
-          }
-        }
         on = false;
       }
     }
   }
 }
-template <int DIM, int OCC, bool NT>
+template <int DIM, int OCC, bool NT, bool RECIN = false>
 __global__ void __launch_bounds__(256, OCC)
     k_push_walk_rowsq(const int* __restrict__ ntiles_dev, int C, int TP,
                       const int* __restrict__ tiles, const int* __restrict__ chunk_start,
@@ -1378,7 +1382,7 @@ __global__ void __launch_bounds__(256, OCC)
                       double* xt, long long stride, const float* __restrict__ pb, float* pphi,
                       double h, double k, double d, double deg, double tol, double unmoved_sq,
                       int* elem_ids, int seeded, int looplimit, Counters* cnt, PendEntry* gq,
-                      int* wave_cnt, Counters* cnt_next, int fuse, int abl) {
+                      int* wave_cnt, Counters* cnt_next, int fuse, int abl, RecIn rin = RecIn{}) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *cnt_next = Counters{};  // for the next pp_push_search
   constexpr int NP = DIM == 3 ? 8 : 4;
   extern __shared__ double2 lds_dyn[];
@@ -1427,6 +1431,8 @@ __global__ void __launch_bounds__(256, OCC)
   A.cap = looplimit ? looplimit : kHardLoopCap;
   A.cnt = cnt;
   A.abl = abl;
+  A.id_out = RECIN ? rin.id_out : nullptr;
+  A.b_out = RECIN ? rin.b_out : nullptr;
   RecCache<DIM> cache;
   cache.id = -1;
   // ---- thin tiles.  Rows fill from column 0, so the rows alive in this tile's first column bound
@@ -1458,7 +1464,12 @@ __global__ void __launch_bounds__(256, OCC)
       const bool act = have && p < t_pend;
       const int pid = t_start + p * C;
       PState s{};
-      if (act) s = load_state<DIM, NT>(pid, mask, pphi, pb, x, stride, elem_ids, read_ids);
+      if (act) {
+        if constexpr (RECIN)
+          s = load_state_recin(pid, mask, rin.rec);
+        else
+          s = load_state<DIM, NT>(pid, mask, pphi, pb, x, stride, elem_ids, read_ids);
+      }
       const bool live = act && s.m;
       int elem = live ? seed_of<DIM>(s, t_e, seeded, nelems) : -1;
       const int want = (elem >= 0 && !(abl & 1)) ? elem : -1;
@@ -1478,7 +1489,10 @@ __global__ void __launch_bounds__(256, OCC)
   int e1 = -1;   // raw elem_ids value of column p+1 (read two columns ahead of its use as a seed)
   int pre = -1;  // element whose record the DMA put into this lane's staging slot for column p
   if (!thin && p0 < pend) {
-    cur = load_state<DIM, NT>(start + p0 * C, mask, pphi, pb, x, stride, elem_ids, read_ids);
+    if constexpr (RECIN)
+      cur = load_state_recin(start + p0 * C, mask, rin.rec);
+    else
+      cur = load_state<DIM, NT>(start + p0 * C, mask, pphi, pb, x, stride, elem_ids, read_ids);
     if (read_ids && p0 + 1 < pend) e1 = ld<NT>(elem_ids + start + (p0 + 1) * C);
   }
   for (int i = 0; i < (thin ? 0 : TP); ++i) {  // wave-uniform trip count: every lane reaches the wave-level ops
@@ -1505,7 +1519,10 @@ __global__ void __launch_bounds__(256, OCC)
     }
     if (__ballot(pre >= 0) != 0ull) coop_issue<DIM>(recs, pre, st, lane);
     if (act && p + 1 < pend) {
-      cur = load_state<DIM, NT>(pid + C, mask, pphi, pb, x, stride, elem_ids, false);
+      if constexpr (RECIN)
+        cur = load_state_recin(pid + C, mask, rin.rec);
+      else
+        cur = load_state<DIM, NT>(pid + C, mask, pphi, pb, x, stride, elem_ids, false);
       cur.elem = e1;
       if (read_ids && p + 2 < pend) e1 = ld<NT>(elem_ids + pid + 2 * C);
     }
@@ -1541,7 +1558,7 @@ template <int DIM>
 __global__ void __launch_bounds__(256, 4)
     k_walk_pending(int nwaves, int TP, int G, const PendEntry* __restrict__ gq,
                    const int* __restrict__ wave_cnt, const void* __restrict__ recs, int* elem_ids,
-                   int looplimit, Counters* cnt, RecFinish F = RecFinish{}) {
+                   int looplimit, Counters* cnt) {
   constexpr int NP = DIM == 3 ? 8 : 4;
   __shared__ double2 st_all[4 * 64 * NP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1550,204 +1567,7 @@ __global__ void __launch_bounds__(256, 4)
   const int nreg = (int)min((long long)G, nwaves - r0);
   const int my_cnt = lane < nreg ? wave_cnt[r0 + lane] : 0;  // lane i holds the count of region i
   walk_pending<DIM>(gq + r0 * 64 * TP, 64ll * TP, nreg, my_cnt, recs, elem_ids,
-                    looplimit ? looplimit : kHardLoopCap, cnt, st_all + wave * 64 * NP, lane,
-                    F.arrive ? &F : nullptr);
-}
-
-// ------------------------------------------------------------------ fused kernel on resident records
-// (DESIGN "Resident records").  Same thread = (tile,row) mapping, thin tiles, register-cached row record
-// and deferred walk as k_push_walk_rowsq, for the flow that rebuilds after every search (every particle
-// starts in its row's element, so the row's record is fetched once per thread).  What differs:
-//   * the particle state is ONE 64-B record per slot: xa | xb | m2 | b | phi | aux, where x is xa or xb
-//     (xoff) and x_tgt the other -- updatePtclPositions is a flip of that selector, not a pass.  A
-//     column reads x, b, phi of 64 consecutive records and writes x_tgt and phi back in place;
-//   * liveness comes from the per-element counts (rows are prefix-compact): no mask stream;
-//   * with the in-place rebuild's counters (RecFinish) the particles that end outside their row's element
-//     are counted, ranked and staged where their walk ends -- the rebuild needs no counting pass.
-struct RecPushArgs {
-  char* rec;
-  const int* elem_count;  // live particles per element (current layout)
-  int xoff;               // byte offset of x in the record (0 or 24); x_tgt = 24 - xoff
-  int xt_zero;            // x_tgt is logically zero: a 2-D push also writes its third component
-  int *leave, *removed;   // in-place counters of the particles the column loop itself finishes outside (null = off)
-};
-__device__ __forceinline__ PState load_state_rec(const char* rp, int xoff) {
-  PState s;
-  const double* x = (const double*)(rp + xoff);
-  s.x = x[0];
-  s.y = x[1];
-  s.z = x[2];
-  const float4 q3 = *(const float4*)(rp + 48);  // m2 | b | phi | aux
-  s.b = q3.y;
-  s.phi = q3.z;
-  s.m = 1;
-  s.elem = -1;
-  return s;
-}
-// push + parent check + first walk step of one live particle; x_tgt and phi go to the record.  Returns
-// true when the particle crossed into `elem` (to be finished by the second pass).
-template <int DIM>
-__device__ __forceinline__ bool column_math_rec(const WalkArgs& A, char* rp, int xtoff, int xt_zero,
-                                                const PState& s, const ppm::ClassTerm& ct,
-                                                const RecCache<DIM>& cache, int& elem, V3& dest) {
-  double rad;
-  bool done = false;
-  bool origin_ok = true;
-  double* xt = (double*)(rp + xtoff);
-  if constexpr (DIM == 2) {
-    ppm::elliptical_point(ct, s.phi, s.b, A.h, A.k, A.d, dest.x, dest.y, rad);
-    dest.z = 0;
-    xt[0] = dest.x;
-    xt[1] = dest.y;
-    if (xt_zero) xt[2] = 0.0;
-  } else {
-    origin_ok = (A.abl & 8) || inside_cached(cache, V3{s.x, s.y, s.z}, A.tol);
-    ppm::toroidal_point(ct, s.phi, s.b, s.x, s.y, A.h, A.k, A.d, dest.x, dest.y, dest.z, rad);
-    xt[0] = dest.x;
-    xt[1] = dest.y;
-    xt[2] = dest.z;
-    const V3 dv = sub(dest, V3{s.x, s.y, s.z});
-    if (dot(dv, dv) < A.unmoved_sq) {  // finishUnmoved (k_push_walk_rows)
-      if (A.abl & 8) atomicAdd(&A.cnt->unmoved, 1);
-      done = true;
-    }
-  }
-  *(float*)(rp + 56) = (float)rad;
-  if (!done && !origin_ok) {  // check_initial_parents (tpp:72-145)
-    atomicAdd(&A.cnt->not_in_elem, 1);
-    elem = -1;
-    done = true;
-  }
-  if (!done) {  // first walk step on the cached record
-    int next;
-    if (step_cached(cache, dest, next)) {
-      done = true;
-    } else if (next == -1) {
-      elem = -1;
-      done = true;
-    } else {
-      elem = next;
-      if (1 >= A.cap) {
-        elem = -1;
-        atomicAdd(&A.cnt->not_found, 1);
-        done = true;
-      }
-    }
-  }
-  return !done;
-}
-template <int DIM, int OCC>
-__global__ void __launch_bounds__(256, OCC)
-    k_push_walk_rec(const int* __restrict__ ntiles_dev, int C, int TP, const int* __restrict__ tiles,
-                    const int* __restrict__ chunk_start, const int* __restrict__ chunk_width,
-                    const int* __restrict__ r2e, const void* __restrict__ recs,
-                    const int* __restrict__ class_id, int nelems, RecPushArgs R, double h, double k, double d,
-                    double deg, double tol, double unmoved_sq, int* elem_ids, int looplimit, Counters* cnt,
-                    PendEntry* gq, int* wave_cnt, Counters* cnt_next, int abl) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) *cnt_next = Counters{};  // for the next pp_push_search
-  constexpr int NP = DIM == 3 ? 8 : 4;
-  extern __shared__ double2 lds_dyn[];
-  double2* st = lds_dyn + (size_t)(threadIdx.x >> 6) * 64 * NP;
-  const int lane = threadIdx.x & 63;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  int qn = 0;  // wave-uniform number of queue entries written by this wave
-  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long gwave = g >> 6;
-  PendEntry* wq = gq + gwave * 64 * TP;
-  const int tile = (int)(g / C);
-  const int r = (int)(g - (long long)tile * C);
-  const bool valid = tile < *ntiles_dev;
-  int start = 0, p0 = 0, pend = 0, e = 0, nrow = 0;  // nrow = live particles of this row
-  if (valid) {
-    const int c = tiles[2 * tile];
-    p0 = tiles[2 * tile + 1];
-    start = chunk_start[c] + r;
-    pend = min(p0 + TP, chunk_width[c]);
-    e = r2e[c * C + r];
-    nrow = e < nelems ? R.elem_count[e] : 0;
-  }
-  const ppm::ClassTerm ct = ppm::class_term((valid && e < nelems) ? class_id[e] : 1, deg, DIM == 3);
-  const int xoff = R.xoff, xtoff = 24 - R.xoff;
-  WalkArgs A;
-  A.xt = nullptr;
-  A.stride = 0;
-  A.pphi = nullptr;
-  A.h = h;
-  A.k = k;
-  A.d = d;
-  A.tol = tol;
-  A.unmoved_sq = unmoved_sq;
-  A.elem_ids = elem_ids;
-  A.seeded = 0;
-  A.nelems = nelems;
-  A.cap = looplimit ? looplimit : kHardLoopCap;
-  A.cnt = cnt;
-  A.abl = abl;
-  RecCache<DIM> cache;
-  cache.id = -1;
-  // a particle the column loop finishes outside every element (exit through the boundary, failed parent
-  // check): it leaves its row and is removed -- rare, one atomic pair each
-  auto lost = [&](int home) {
-    if (R.leave) {
-      atomicAdd(&R.leave[home], 1);
-      atomicAdd(&R.removed[home], 1);
-    }
-  };
-  const bool alive0 = valid && p0 < pend && p0 < nrow;  // rows fill from column 0
-  const unsigned long long live0 = __ballot(alive0);
-  const int nlive = __popcll(live0);
-  if (nlive * TP <= 64) {
-    // ---- thin tile (k_push_walk_rowsq): lane l takes (live row l/TP, column l%TP), one iteration
-    if (valid && !alive0)
-      for (int p = p0; p < pend; ++p) elem_ids[start + p * C] = -1;
-    const int krow = lane / TP, col = lane - krow * TP;
-    unsigned long long m = live0;
-    for (int j = 0; j < krow && m; ++j) m &= m - 1;  // drop the krow lowest live rows
-    const bool have = krow < nlive;
-    const int src = have ? __builtin_ctzll(m) : 0;
-    const int t_start = __shfl(start, src), t_p0 = __shfl(p0, src), t_pend = __shfl(pend, src);
-    const int t_e = __shfl(e, src), t_nrow = __shfl(nrow, src);
-    ppm::ClassTerm tct;
-    tct.dphi = __shfl(ct.dphi, src);
-    tct.st = __shfl(ct.st, src);
-    tct.ct = __shfl(ct.ct, src);
-    const int p = t_p0 + col;
-    const bool act = have && p < t_pend;
-    const bool live = act && p < t_nrow;
-    const int pid = t_start + p * C;
-    char* rp = R.rec + (long long)pid * pp::kRecBytes;
-    PState s{};
-    if (live) s = load_state_rec(rp, xoff);
-    int elem = live ? t_e : -1;
-    if (__ballot(live) != 0ull) coop_fetch<DIM>(cache, recs, live ? t_e : -1, st, lane);
-    V3 dest{0, 0, 0};
-    const bool need = live ? column_math_rec<DIM>(A, rp, xtoff, R.xt_zero, s, tct, cache, elem, dest) : false;
-    if (act && (!live || !need)) elem_ids[pid] = elem;
-    if (live && !need && elem < 0) lost(t_e);
-    enqueue(need, pid, elem, dest, wq, qn, lt_mask);
-    if (lane == 0) wave_cnt[gwave] = qn;
-    return;
-  }
-  // ---- column loop: the row's record once, then TP particles of the row
-  if (__ballot(alive0) != 0ull) coop_fetch<DIM>(cache, recs, alive0 ? e : -1, st, lane);
-  PState cur{};
-  if (alive0) cur = load_state_rec(R.rec + (long long)(start + p0 * C) * pp::kRecBytes, xoff);
-  for (int i = 0; i < TP; ++i) {  // wave-uniform trip count (enqueue is a wave-level operation)
-    const int p = p0 + i;
-    const int pid = start + p * C;
-    const bool act = valid && p < pend;
-    const bool live = act && p < nrow;
-    char* rp = R.rec + (long long)pid * pp::kRecBytes;
-    const PState s = cur;
-    if (act && p + 1 < pend && p + 1 < nrow) cur = load_state_rec(rp + (long long)C * pp::kRecBytes, xoff);
-    int elem = live ? e : -1;
-    V3 dest{0, 0, 0};
-    const bool need = live ? column_math_rec<DIM>(A, rp, xtoff, R.xt_zero, s, ct, cache, elem, dest) : false;
-    if (act && (!live || !need)) elem_ids[pid] = elem;
-    if (live && !need && elem < 0) lost(e);
-    enqueue(need, pid, elem, dest, wq, qn, lt_mask);
-  }
-  if (lane == 0) wave_cnt[gwave] = qn;
+                    looplimit ? looplimit : kHardLoopCap, cnt, st_all + wave * 64 * NP, lane);
 }
 
 MeshArrays arrays_of(const pp_mesh* mesh) {
@@ -2095,86 +1915,30 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
       shape_ok(m_phi, 4, 1) && ps->zero_pending == ps->member_map[m_xtgt] && ps->zero_pending != ps->member_map[m_x] &&
       ps->capacity > 0 && ps->num_ptcls > 0)
     ps->zero_pending = -1;
+  // Record-fed push: the last full re-layout left the particles in its staging records (pp_ps::lazy_rec)
+  // and this call can read them there -- the pass that would copy them to the SoA arrays first is skipped.
   static const bool force_flat = getenv("PP_FLAT_WALK") != nullptr;  // A/B measurement knob
-  hipStream_t st = pp::stream();
-  // ---- resident records (pp_ps_set_resident_records): a search that starts every particle in its row's
-  // element (no seeds) on a structure of the 60-byte pseudoXGCm type runs on the 64-B records, and
-  // counts the new parents for the rebuild that follows
-  if (ps->rec_mode && !elem_ids_seeded && !force_flat && ps->capacity > 0 && ps->num_ptcls > 0 &&
-      ps->ntiles_max > 0 && pp::rec_usable(ps, m_x, m_xtgt, m_b, m_phi)) {
-    RecPushArgs R{};
-    RecFinish F{};
-    pp::RecPushPtrs rp{};
-    if ((rc = pp::rec_begin_push(ps, elem_ids_dev, &rp))) return rc;
-    R.rec = rp.rec;
-    R.elem_count = rp.elem_count;
-    R.xoff = rp.xoff;
-    R.xt_zero = rp.xt_zero;
-    R.leave = rp.leave;
-    R.removed = rp.removed;
-    F.rec = rp.rec;
-    F.stage = rp.stage;
-    F.arrive = rp.arrive;
-    F.leave = rp.leave;
-    F.removed = rp.removed;
-    F.rank = rp.rank;
-    F.slot_elem = rp.slot_elem;
-    if ((rc = pair_counters())) return rc;
-    Counters* used = g_cnt2 + g_cnt2_cur;
-    static const int abl_env = getenv("PP_ABL") ? atoi(getenv("PP_ABL")) : 0;  // timing ablations only
-    const int abl = abl_env | ((ps->trust_origins && mesh->dim == 3) ? 8 : 0);
-    const unsigned rgrid = grid_for((size_t)ps->ntiles_max * ps->C);
-    const size_t lds = (size_t)(kBlock / 64) * 64 * (mesh->dim == 3 ? 8 : 4) * sizeof(double2);
-    const size_t nwaves = (size_t)rgrid * (kBlock / 64);
-    PP_HIP_CHECK(g_pending_q.reserve(nwaves * 64 * ps->tile_p * sizeof(PendEntry)));
-    PP_HIP_CHECK(g_wave_cnt.reserve(nwaves * sizeof(int)));
-#define PP_REC_ARGS                                                                                            \
-  ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(),               \
-      ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(), mesh->d_records.p, mesh->d_class_id.as<int>(), \
-      mesh->nelems, R, h, k, d, deg, mesh->tol, mesh->unmoved_sq, elem_ids_dev, looplimit, used,                \
-      g_pending_q.as<PendEntry>(), g_wave_cnt.as<int>(), g_cnt2 + (g_cnt2_cur ^ 1), abl
-    static const int G = getenv("PP_PEND_REGIONS") ? std::max(1, std::min(64, atoi(getenv("PP_PEND_REGIONS")))) : kPendRegions;
-    const unsigned pgrid = (rgrid + G - 1) / G;
-    if (mesh->dim == 2) {
-      k_push_walk_rec<2, 4><<<rgrid, kBlock, lds, st>>>(PP_REC_ARGS);
-      k_walk_pending<2><<<pgrid, kBlock, 0, st>>>((int)nwaves, ps->tile_p, G, g_pending_q.as<PendEntry>(),
-                                                 g_wave_cnt.as<int>(), mesh->d_records.p, elem_ids_dev, looplimit,
-                                                 used, F);
-    } else {
-      k_push_walk_rec<3, 4><<<rgrid, kBlock, lds, st>>>(PP_REC_ARGS);
-      k_walk_pending<3><<<pgrid, kBlock, 0, st>>>((int)nwaves, ps->tile_p, G, g_pending_q.as<PendEntry>(),
-                                                 g_wave_cnt.as<int>(), mesh->d_records.p, elem_ids_dev, looplimit,
-                                                 used, F);
-    }
-#undef PP_REC_ARGS
-    PP_LAUNCH_CHECK();
-    g_cnt2_cur ^= 1;
-    g_last_counters = used;
-    if (found) {
-      Counters hc;
-      PP_HIP_CHECK(hipMemcpyAsync(&hc, used, sizeof(Counters), hipMemcpyDeviceToHost, st));
-      PP_HIP_CHECK(hipStreamSynchronize(st));
-      *found = (hc.not_found == 0);
-    }
-    return PP_OK;
+  const int wq_env = getenv("PP_WALK_QUEUE") ? atoi(getenv("PP_WALK_QUEUE")) : -1;  // per call
+  const int wq = wq_env >= 0 ? wq_env : (mesh->dim == 3 ? 1 : 0);
+  const bool recin = mesh->dim == 3 && wq > 0 && !force_flat && ps->capacity > 0 && ps->num_ptcls > 0 &&
+                     ps->ntiles_max > 0 && pp::lazy_push_ok(ps, m_x, m_xtgt, m_b, m_phi);
+  if (!recin) {
+    if ((rc = member_ok(ps, m_x, 8, 3, "pp_push_search x"))) return rc;
+    if ((rc = member_ok(ps, m_xtgt, 8, 3, "pp_push_search x_tgt"))) return rc;
+    if ((rc = member_ok(ps, m_b, 4, 1, "pp_push_search b"))) return rc;
+    if ((rc = member_ok(ps, m_phi, 4, 1, "pp_push_search phi"))) return rc;
   }
-  if ((rc = member_ok(ps, m_x, 8, 3, "pp_push_search x"))) return rc;
-  if ((rc = member_ok(ps, m_xtgt, 8, 3, "pp_push_search x_tgt"))) return rc;
-  if ((rc = member_ok(ps, m_b, 4, 1, "pp_push_search b"))) return rc;
-  if ((rc = member_ok(ps, m_phi, 4, 1, "pp_push_search phi"))) return rc;
   if (found) *found = 1;
   if (ps->capacity == 0) return PP_OK;
-  if (mesh->dim == 2 && !elem_ids_seeded) {
-    // search_mesh_2d reads its seeds (hpp:1051-1056); "no seeds" = every particle starts in its own element
-    PP_HIP_CHECK(hipMemsetAsync(elem_ids_dev, 0xff, sizeof(int) * (size_t)ps->capacity, st));
-    elem_ids_seeded = 1;
-  }
   if (ps->num_ptcls == 0) {
     if (!elem_ids_seeded && mesh->dim == 3)
       PP_HIP_CHECK(hipMemsetAsync(elem_ids_dev, 0xff, sizeof(int) * (size_t)ps->capacity, pp::stream()));
     return PP_OK;
   }
   const unsigned grid = grid_for(ps->capacity);
+  hipStream_t st = pp::stream();
+  if (mesh->dim == 2)
+    PP_REQUIRE(elem_ids_seeded, "pp_push_search (2-D): elem_ids must be initialised (-1 = own element)");
   Counters* used = nullptr;  // the counter set this call's kernels add to
   if (ps->kind == PP_SCS && !force_flat) {
     const unsigned rgrid = grid_for((size_t)ps->ntiles_max * ps->C);
@@ -2206,8 +1970,6 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
     // 3-D (128-B records, 8% of the particles cross per step, walks of 1..8 tets) is 8-30%
     // faster with the deferred walk; 2-D (64-B records, cheap steps) is faster in one kernel.
     // PP_WALK_QUEUE=0/1 forces one or the other (A/B knob).
-    const int wq_env = getenv("PP_WALK_QUEUE") ? atoi(getenv("PP_WALK_QUEUE")) : -1;  // per call
-    const int wq = wq_env >= 0 ? wq_env : (mesh->dim == 3 ? 1 : 0);
     static const int abl_env = getenv("PP_ABL") ? atoi(getenv("PP_ABL")) : 0;  // timing ablations only
     const int abl = abl_env | (ps->trust_origins ? 8 : 0);
     if (!(rgrid > 0 && wq > 0)) {
@@ -2232,6 +1994,10 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
           k_push_walk_rowsq<2, 4, true><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
         else
           k_push_walk_rowsq<2, 4, false><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
+      } else if (recin) {
+        const RecIn rin{ps->s_aos_live.as<char>(), (unsigned*)ps->data[2].p, (float*)ps->data[3].p};
+        k_push_walk_rowsq<3, 4, true, true><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS, rin);
+        ps->lazy_rec = 2;  // every member but the origin is in the SoA arrays now
       } else if (occ <= 3) {
         k_push_walk_rowsq<3, 3, false><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
       } else if (nt) {
