@@ -297,6 +297,7 @@ namespace pp {
 // pp_ps.hip: write the zeros of a member that is only logically zero (pp_ps::zero_pending); every
 // entry point that reads or exposes member data calls this first
 int ps_materialize(pp_ps* ps);
+int ps_zeros(pp_ps* ps);  // only the pending zeros of pp_ps::zero_pending
 inline int ps_ready(const pp_ps* ps) {
   return (ps && (ps->zero_pending >= 0 || ps->lazy_rec)) ? ps_materialize(const_cast<pp_ps*>(ps)) : PP_OK;
 }

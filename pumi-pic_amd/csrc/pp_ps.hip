@@ -248,12 +248,26 @@ struct ElemTotalsArgs {
   // atomics on the totals (every block ends with three atomics on the same counters, ~10 ns each queued)
   int* partial;
 };
+// fused form of the radix passes (k_rs_pass, ne <= kFusedSortBlocks tiles): pass p reads the digit table
+// H[p % 3], adds the NEXT digit's counts to H[(p+1) % 3] and clears its slice of H[(p+2) % 3];
+// k_make_keys fills H[0] and clears H[1].
+struct FusedHist {
+  int* h0;    // [256][nblk]: digit counts of the first pass per tile (null = the separate-launch sort)
+  int* hzero; // table of the second pass, cleared here
+  int nblk;
+};
 __global__ void k_make_keys(int ne, const int* __restrict__ ppe, int sigma, int n_sigma,
                             unsigned long long base, unsigned long long* __restrict__ keys,
-                            int* __restrict__ vals, Totals* tot, int no_skip, ElemTotalsArgs et) {
+                            int* __restrict__ vals, Totals* tot, int no_skip, ElemTotalsArgs et,
+                            FusedHist fh = FusedHist{nullptr, nullptr, 0}) {
   unsigned long long mx = 0;
   int nz = 0, sum = 0, over = 0;
   const int base_i = blockIdx.x * RS_TILE;
+  __shared__ int s_h0[256];
+  if (fh.h0) {
+    s_h0[threadIdx.x] = 0;
+    __syncthreads();
+  }
   for (int j = threadIdx.x; j < RS_TILE; j += 256) {
     const int i = base_i + j;
     if (i >= ne) break;
@@ -266,6 +280,7 @@ __global__ void k_make_keys(int ne, const int* __restrict__ ppe, int sigma, int 
     const unsigned long long key = (unsigned long long)w * base + (unsigned long long)n;
     keys[i] = key;
     vals[i] = i;
+    if (fh.h0) atomicAdd(&s_h0[(int)(key & 255ull)], 1);
     mx = key > mx ? key : mx;
     nz += n > 0;
     sum += n;
@@ -301,6 +316,11 @@ __global__ void k_make_keys(int ne, const int* __restrict__ ppe, int sigma, int 
       }
     }
     __syncthreads();
+  }
+  if (fh.h0) {
+    __syncthreads();
+    fh.h0[threadIdx.x * fh.nblk + blockIdx.x] = s_h0[threadIdx.x];
+    fh.hzero[threadIdx.x * fh.nblk + blockIdx.x] = 0;
   }
   // the host sizes the number of 8-bit passes from an upper bound (total particles); the real
   // maximum (a per-element count) usually needs one or two passes: later passes see it and copy.
@@ -386,6 +406,89 @@ __global__ void k_rs_scatter(int n, const unsigned long long* __restrict__ keys,
   }
 }
 
+// The scatter of a radix pass with the scan of the digit table folded in (small structures: the table
+// of <= kFusedSortBlocks tiles is read whole by every block).  The separate-launch form costs histogram +
+// table scan (single block, 9 us) + scatter per pass (23 us at 100 800 elements,
+// profiles/r03_c3_recordfed_kernel_stats.csv); here every block scans the table itself (thread d: the
+// digit's total over all tiles and over the tiles before its own; one block scan over the 256 digits).
+// (Also tried: the NEXT digit's histogram accumulated here with one atomic per key -- the high digit of
+// nearly every key is 0, so the atomics pile onto one counter per tile: 250 us per pass.)
+constexpr int kFusedSortBlocks = 64;
+__global__ void k_rs_pass(int n, const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
+                          int shift, int nblk, const int* __restrict__ hist,
+                          unsigned long long* __restrict__ keys_out, int* __restrict__ vals_out,
+                          const Totals* tot) {
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const unsigned long long max_key = tot->max_key;
+  if ((max_key >> shift) == 0) {  // identity pass of the stable sort: plain copy (so are all later ones)
+    for (int j = t; j < RS_TILE; j += 256) {
+      const int i = blockIdx.x * RS_TILE + j;
+      if (i < n) {
+        keys_out[i] = keys[i];
+        vals_out[i] = vals[i];
+      }
+    }
+    return;
+  }
+  __shared__ int gbase[256];  // first output position of this tile's keys with digit d
+  __shared__ int s_part[4];
+  {
+    int total = 0, mine = 0;
+    const int* row = hist + t * nblk;
+    for (int b = 0; b < nblk; ++b) {
+      const int h = row[b];
+      total += h;
+      if (b < (int)blockIdx.x) mine += h;
+    }
+    // exclusive scan of `total` over the 256 digits
+    int incl = total;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(incl, o);
+      if (lane >= o) incl += y;
+    }
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wave; ++w) off += s_part[w];
+    gbase[t] = off + incl - total + mine;
+  }
+  __shared__ int base_d[256];  // running count of each digit inside this tile
+  __shared__ int wave_cnt[4][256];
+  base_d[t] = 0;
+  const int tile0 = blockIdx.x * RS_TILE;
+  for (int round = 0; round < RS_TILE / 256; ++round) {
+    for (int w = 0; w < 4; ++w) wave_cnt[w][t] = 0;
+    __syncthreads();
+    const int i = tile0 + round * 256 + t;
+    const bool valid = i < n;
+    unsigned long long key = 0;
+    int val = 0, digit = 0;
+    if (valid) {
+      key = keys[i];
+      val = vals[i];
+      digit = (int)((key >> shift) & 255ull);
+    }
+    unsigned long long same = __ballot(valid);  // lanes of this wave holding the same digit
+    for (int b = 0; b < 8; ++b) {
+      const unsigned long long bal = __ballot(valid && ((digit >> b) & 1));
+      same &= ((digit >> b) & 1) ? bal : ~bal;
+    }
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int rank_in_wave = __popcll(same & lt);
+    if (valid && rank_in_wave == 0) wave_cnt[wave][digit] = __popcll(same);
+    __syncthreads();
+    if (valid) {
+      int off = base_d[digit];
+      for (int w = 0; w < wave; ++w) off += wave_cnt[w][digit];
+      const int pos = gbase[digit] + off + rank_in_wave;
+      keys_out[pos] = key;
+      vals_out[pos] = val;
+    }
+    __syncthreads();
+    base_d[t] += wave_cnt[0][t] + wave_cnt[1][t] + wave_cnt[2][t] + wave_cnt[3][t];
+    __syncthreads();
+  }
+}
 // ---- single-block exclusive scan (int); total written to *total if non-null
 __global__ void k_scan_excl(int n, const int* __restrict__ in, int* __restrict__ out, int* total,
                             const Totals* skip_tot = nullptr, int skip_shift = 0) {
@@ -2530,15 +2633,20 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
     PP_HIP_CHECK(ps->s_vals.reserve(sizeof(int) * (size_t)ne));
     PP_HIP_CHECK(ps->s_vals2.reserve(sizeof(int) * (size_t)ne));
     const int nblk = (ne + RS_TILE - 1) / RS_TILE;
-    PP_HIP_CHECK(ps->s_hist.reserve(sizeof(int) * (256 * (size_t)nblk * 2 + 3 * (size_t)nblk)));
+    PP_HIP_CHECK(ps->s_hist.reserve(sizeof(int) * (256 * (size_t)nblk * 3 + 3 * (size_t)nblk)));
     // the layout kernel below adds up the per-block totals (the inversely-padded layout has no such kernel)
     et.partial = (et.totals && !(ps->pad_strat == PP_PAD_INVERSELY && ps->shuffle_padding > 0))
-                     ? ps->s_hist.as<int>() + 256 * (size_t)nblk * 2
+                     ? ps->s_hist.as<int>() + 256 * (size_t)nblk * 3
                      : nullptr;
+    static const bool no_fused_sort = getenv("PP_NO_FUSED_SORT") != nullptr;  // A/B knob
+    const bool fused_sort = nblk <= kFusedSortBlocks && !no_fused_sort;
+    int* const H0 = ps->s_hist.as<int>();
+    int* const Hs[3] = {H0, H0 + 256 * (size_t)nblk, H0 + 256 * (size_t)nblk * 2};
     k_make_keys<<<nblk, 256, 0, st>>>(ne, ppe, sg, n_sigma, L.base,
                                                  ps->s_keys.as<unsigned long long>(),
                                                  ps->s_vals.as<int>(), tot,
-                                                 getenv("PP_NO_RS_SKIP") != nullptr, et);
+                                                 getenv("PP_NO_RS_SKIP") != nullptr, et,
+                                                 FusedHist{nullptr, nullptr, 0});
     unsigned long long maxkey = (unsigned long long)(n_sigma > 0 ? n_sigma : 1) * L.base;
     int bits = 0;
     while (bits < 64 && (maxkey >> bits)) ++bits;
@@ -2552,7 +2660,13 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
     int *va = ps->s_vals.as<int>(), *vb = ps->s_vals2.as<int>();
     int* hist = ps->s_hist.as<int>();
     int* hist_sc = hist + 256 * nblk;
-    for (int shift = 0; shift < bits; shift += 8) {
+    for (int shift = 0; fused_sort && shift < bits; shift += 8) {
+      k_rs_hist<<<nblk, 256, 0, st>>>(ne, ka, shift, nblk, Hs[0], tot);
+      k_rs_pass<<<nblk, 256, 0, st>>>(ne, ka, va, shift, nblk, Hs[0], kb, vb, tot);
+      std::swap(ka, kb);
+      std::swap(va, vb);
+    }
+    for (int shift = 0; !fused_sort && shift < bits; shift += 8) {
       k_rs_hist<<<nblk, 256, 0, st>>>(ne, ka, shift, nblk, hist, tot);
       if (scan_excl(ps->s_scan2, 256 * nblk, hist, hist_sc, nullptr, st, tot, shift)) return PP_EHIP;
       k_rs_scatter<<<nblk, 256, 0, st>>>(ne, ka, va, shift, nblk, hist_sc, kb, vb, tot);
@@ -3456,6 +3570,9 @@ int ps_materialize(pp_ps* ps) {
       PP_LAUNCH_CHECK();
     }
   }
+  return ps_zeros(ps);
+}
+int ps_zeros(pp_ps* ps) {
   const int s = ps->zero_pending;
   if (s < 0) return PP_OK;
   ps->zero_pending = -1;

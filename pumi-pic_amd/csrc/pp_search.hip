@@ -955,16 +955,21 @@ struct RecIn {
   const char* rec;  // null = SoA input
   unsigned* id_out;
   float* b_out;
+  int zero_z;  // 2-D: x_tgt is logically zero (pp_ps::zero_pending) -- the push writes its third component too
 };
+template <int DIM = 3>
 __device__ __forceinline__ PState load_state_recin(int pid, const unsigned char* __restrict__ mask,
                                                    const char* __restrict__ rec) {
   PState s;
   s.m = mask[pid];
   const char* rp = rec + (long long)pid * 64;
-  const double2 q0 = *(const double2*)rp;
-  s.x = q0.x;
-  s.y = q0.y;
-  s.z = *(const double*)(rp + 16);
+  s.x = s.y = s.z = 0;
+  if (DIM == 3) {  // (the 2-D push reads no position)
+    const double2 q0 = *(const double2*)rp;
+    s.x = q0.x;
+    s.y = q0.y;
+    s.z = *(const double*)(rp + 16);
+  }
   const uint4 q3 = *(const uint4*)(rp + 48);
   s.phi = __uint_as_float(q3.y);
   s.b = __uint_as_float(q3.z);
@@ -981,10 +986,15 @@ __device__ __forceinline__ void rows_particle(const PState& s, int pid, int e,
                                               double* __restrict__ xt, long long stride, float* pphi,
                                               double h, double k, double d, double tol,
                                               double unmoved_sq, int* elem_ids, int seeded,
-                                              int looplimit, Counters* cnt) {
+                                              int looplimit, Counters* cnt, unsigned* id_out = nullptr,
+                                              float* b_out = nullptr, int zero_z = 0) {
   if (!s.m) {
     if (DIM == 2 || !seeded) elem_ids[pid] = -1;
     return;
+  }
+  if (id_out) {  // record-fed form: the members the next rebuild packs from the SoA arrays
+    stg<true>(id_out + pid, s.id);
+    stg<true>(b_out + pid, s.b);
   }
   double rad;
   V3 dest;
@@ -994,6 +1004,7 @@ __device__ __forceinline__ void rows_particle(const PState& s, int pid, int e,
     dest.z = 0;
     stg<true>(xt + pid, dest.x);
     stg<true>(xt + stride + pid, dest.y);
+    if (zero_z) stg<true>(xt + 2 * stride + pid, 0.0);
     stg<true>(pphi + pid, (float)rad);
     if (elem == -1) elem = e;
     if (elem == -nelems) {
@@ -1027,7 +1038,7 @@ __device__ __forceinline__ void rows_particle(const PState& s, int pid, int e,
   }
 }
 
-template <int DIM, int OCC>
+template <int DIM, int OCC, bool RECIN = false>
 __global__ void __launch_bounds__(256, OCC)
     k_push_walk_rows(const int* __restrict__ ntiles_dev, int C, int TP,
                      const int* __restrict__ tiles, const int* __restrict__ chunk_start,
@@ -1036,11 +1047,24 @@ __global__ void __launch_bounds__(256, OCC)
                      const int* __restrict__ class_id, int nelems, const double* __restrict__ x,
                      double* __restrict__ xt, long long stride, const float* __restrict__ pb,
                      float* pphi, double h, double k, double d, double deg, double tol,
-                     double unmoved_sq, int* elem_ids, int seeded, int looplimit, Counters* cnt) {
+                     double unmoved_sq, int* elem_ids, int seeded, int looplimit, Counters* cnt,
+                     RecIn rin = RecIn{}) {
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int tile = (int)(g / C);
   const int r = (int)(g - (long long)tile * C);
   const bool valid = tile < *ntiles_dev;
+  unsigned* const id_out = RECIN ? rin.id_out : nullptr;
+  float* const b_out = RECIN ? rin.b_out : nullptr;
+  auto load = [&](int pid) {
+    PState s;
+    if constexpr (RECIN) {
+      s = load_state_recin<DIM>(pid, mask, rin.rec);
+      if (DIM == 2 || seeded) s.elem = elem_ids[pid];
+    } else {
+      s = load_state<DIM, true>(pid, mask, pphi, pb, x, stride, elem_ids, (DIM == 2) || seeded);
+    }
+    return s;
+  };
   int start = 0, p0 = 0, pend = 0, e = 0;
   if (valid) {
     const int c = tiles[2 * tile];
@@ -1077,22 +1101,22 @@ __global__ void __launch_bounds__(256, OCC)
       const int p = t_p0 + col;
       if (have && p < t_pend) {
         const int pid = t_start + p * C;
-        const PState s = load_state<DIM, true>(pid, mask, pphi, pb, x, stride, elem_ids, read_ids);
+        const PState s = load(pid);
         rows_particle<DIM>(s, pid, t_e, tct, cache, recs, nelems, xt, stride, pphi, h, k, d, tol,
-                           unmoved_sq, elem_ids, seeded, looplimit, cnt);
+                           unmoved_sq, elem_ids, seeded, looplimit, cnt, id_out, b_out, RECIN ? rin.zero_z : 0);
       }
       return;
     }
   }
   if (!valid) return;
-  PState cur = load_state<DIM, true>(start + p0 * C, mask, pphi, pb, x, stride, elem_ids, read_ids);
+  PState cur = load(start + p0 * C);
   for (int p = p0; p < pend; ++p) {
     const int pid = start + p * C;
     const PState s = cur;
     if (p + 1 < pend)  // prefetch the next particle of this row before the dependent walk
-      cur = load_state<DIM, true>(pid + C, mask, pphi, pb, x, stride, elem_ids, read_ids);
+      cur = load(pid + C);
     rows_particle<DIM>(s, pid, e, ct, cache, recs, nelems, xt, stride, pphi, h, k, d, tol,
-                       unmoved_sq, elem_ids, seeded, looplimit, cnt);
+                       unmoved_sq, elem_ids, seeded, looplimit, cnt, id_out, b_out, RECIN ? rin.zero_z : 0);
   }
 }
 
@@ -1465,10 +1489,12 @@ __global__ void __launch_bounds__(256, OCC)
       const int pid = t_start + p * C;
       PState s{};
       if (act) {
-        if constexpr (RECIN)
-          s = load_state_recin(pid, mask, rin.rec);
-        else
+        if constexpr (RECIN) {
+          s = load_state_recin<DIM>(pid, mask, rin.rec);
+          if (read_ids) s.elem = ld<NT>(elem_ids + pid);
+        } else {
           s = load_state<DIM, NT>(pid, mask, pphi, pb, x, stride, elem_ids, read_ids);
+        }
       }
       const bool live = act && s.m;
       int elem = live ? seed_of<DIM>(s, t_e, seeded, nelems) : -1;
@@ -1489,10 +1515,12 @@ __global__ void __launch_bounds__(256, OCC)
   int e1 = -1;   // raw elem_ids value of column p+1 (read two columns ahead of its use as a seed)
   int pre = -1;  // element whose record the DMA put into this lane's staging slot for column p
   if (!thin && p0 < pend) {
-    if constexpr (RECIN)
-      cur = load_state_recin(start + p0 * C, mask, rin.rec);
-    else
+    if constexpr (RECIN) {
+      cur = load_state_recin<DIM>(start + p0 * C, mask, rin.rec);
+      if (read_ids) cur.elem = ld<NT>(elem_ids + start + p0 * C);
+    } else {
       cur = load_state<DIM, NT>(start + p0 * C, mask, pphi, pb, x, stride, elem_ids, read_ids);
+    }
     if (read_ids && p0 + 1 < pend) e1 = ld<NT>(elem_ids + start + (p0 + 1) * C);
   }
   for (int i = 0; i < (thin ? 0 : TP); ++i) {  // wave-uniform trip count: every lane reaches the wave-level ops
@@ -1520,7 +1548,7 @@ __global__ void __launch_bounds__(256, OCC)
     if (__ballot(pre >= 0) != 0ull) coop_issue<DIM>(recs, pre, st, lane);
     if (act && p + 1 < pend) {
       if constexpr (RECIN)
-        cur = load_state_recin(pid + C, mask, rin.rec);
+        cur = load_state_recin<DIM>(pid + C, mask, rin.rec);
       else
         cur = load_state<DIM, NT>(pid + C, mask, pphi, pb, x, stride, elem_ids, false);
       cur.elem = e1;
@@ -1920,9 +1948,19 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
   static const bool force_flat = getenv("PP_FLAT_WALK") != nullptr;  // A/B measurement knob
   const int wq_env = getenv("PP_WALK_QUEUE") ? atoi(getenv("PP_WALK_QUEUE")) : -1;  // per call
   const int wq = wq_env >= 0 ? wq_env : (mesh->dim == 3 ? 1 : 0);
-  const bool recin = mesh->dim == 3 && wq > 0 && !force_flat && ps->capacity > 0 && ps->num_ptcls > 0 &&
-                     ps->ntiles_max > 0 && pp::lazy_push_ok(ps, m_x, m_xtgt, m_b, m_phi);
-  if (!recin) {
+  const bool recin = ((mesh->dim == 3 && wq > 0) || (mesh->dim == 2 && wq == 0 && elem_ids_seeded)) && !force_flat &&
+                     ps->capacity > 0 && ps->num_ptcls > 0 && ps->ntiles_max > 0 &&
+                     pp::lazy_push_ok(ps, m_x, m_xtgt, m_b, m_phi);
+  int zero_z = 0;
+  if (recin) {
+    // (a 2-D push leaves the third component of x_tgt alone: when x_tgt is only logically zero the
+    // record-fed kernel writes that component too, for every live particle -- no fill of the member)
+    if (mesh->dim == 2 && ps->zero_pending == ps->member_map[m_xtgt]) {
+      zero_z = 1;
+      ps->zero_pending = -1;
+    }
+    if ((rc = pp::ps_zeros(ps))) return rc;
+  } else {
     if ((rc = member_ok(ps, m_x, 8, 3, "pp_push_search x"))) return rc;
     if ((rc = member_ok(ps, m_xtgt, 8, 3, "pp_push_search x_tgt"))) return rc;
     if ((rc = member_ok(ps, m_b, 4, 1, "pp_push_search b"))) return rc;
@@ -1995,7 +2033,7 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
         else
           k_push_walk_rowsq<2, 4, false><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
       } else if (recin) {
-        const RecIn rin{ps->s_aos_live.as<char>(), (unsigned*)ps->data[2].p, (float*)ps->data[3].p};
+        const RecIn rin{ps->s_aos_live.as<char>(), (unsigned*)ps->data[2].p, (float*)ps->data[3].p, 0};
         k_push_walk_rowsq<3, 4, true, true><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS, rin);
         ps->lazy_rec = 2;  // every member but the origin is in the SoA arrays now
       } else if (occ <= 3) {
@@ -2020,7 +2058,11 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
       }
       g_cnt2_cur ^= 1;
     } else if (rgrid > 0) {
-      if (mesh->dim == 2)
+      if (mesh->dim == 2 && recin) {
+        const RecIn rin{ps->s_aos_live.as<char>(), (unsigned*)ps->data[2].p, (float*)ps->data[3].p, zero_z};
+        k_push_walk_rows<2, 4, true><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS, rin);
+        ps->lazy_rec = 2;
+      } else if (mesh->dim == 2)
         k_push_walk_rows<2, 4><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS);
       else if (occ <= 3)
         k_push_walk_rows<3, 3><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS);

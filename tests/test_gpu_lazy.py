@@ -125,3 +125,36 @@ def test_deferred_pass_before_other_entry_points(ppo, synth, capi):
             pg.swap_members(0, 1)
             pg.swap_members(0, 1)
     _same_population(po, pg)
+
+
+@pytest.mark.parametrize("look", ["never", "after_push", "after_rebuild"])
+def test_record_fed_push_2d(ppo, synth, capi, look):
+    """the literal pseudoXGCm loop (triangles, ellipticalPush + search_mesh_2d): the 2-D push writes two
+    components of x_tgt, the third one -- logically zero after updatePtclPositions -- is written by the
+    record-fed kernel itself"""
+    pop = common.population_2d(synth, num_ptcls=6000)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
+    common.set_shuffling(po, pg)
+    fo, bo = ppo.create_gyro_ring_mappings(mo, trig=1)
+    fg, bg = capi.create_gyro_ring_mappings(mg)
+    for step in range(12):
+        ppo.elliptical_push(po, mo, H, K, D, 2.0, trig=1)
+        ids_o = ppo.search_mesh_2d(mo, po, looplimit=200)[1]
+        ids_g = capi.DevArray.from_host(np.full(max(pg.capacity(), 1), -1, dtype=np.int32))
+        capi.push_search(mg, pg, H, K, D, 2.0, ids_g, seeded=True, looplimit=200)
+        if look == "after_push":
+            for m in range(5):
+                _, a = common.by_id(po.member(2)[0, :po.capacity()], po.slot_info()[1], po.member(m)[:, :po.capacity()])
+                _, b = common.by_id(pg.member(2)[0, :pg.capacity()], pg.slot_info()[1], pg.member(m)[:, :pg.capacity()])
+                assert np.array_equal(a, b), (step, m)
+        ppo.update_positions(po)
+        po.rebuild(ids_o)
+        wf, wb = capi.rebuild_scatter(pg, mg, ids_g, [fg, bg], commit=True)
+        assert po.nPtcls() == pg.nPtcls() > 0
+        _layouts_equal(po, pg)
+        assert np.array_equal(ppo.gyro_scatter(mo, po, fo), wf.to_host()), step
+        assert np.array_equal(ppo.gyro_scatter(mo, po, bo), wb.to_host()), step
+        if look == "after_rebuild":
+            _same_population(po, pg)
+    _same_population(po, pg)
