@@ -224,11 +224,26 @@ class Stepper:
                              capi.Comm.tcp(os.environ.get("MASTER_ADDR", "127.0.0.1"), port, self.rank, self.world))
             if self.comm_kind == "rccl":
                 try:
+                    beat("RCCL communicator")
                     self.comm = self._make_comm()
-                except Exception as e:  # noqa: BLE001 -- keep the run alive on the torch glue, loudly
-                    sys.stderr.write("bench.py: RCCL communicator behind the C-ABI failed (%r); falling back to "
-                                     "--comm torch\n" % (e,))
-                    self.comm_kind = "torch"
+                except Exception as e:  # noqa: BLE001 -- keep the run alive on the host-staged transport, loudly
+                    sys.stderr.write("bench.py: RCCL communicator behind the C-ABI failed (%r); falling back to the "
+                                     "library's host-staged TCP transport (--comm tcp): NOT an xGMI measurement\n" % (e,))
+                    self.comm_kind = "tcp"
+                    port = int(os.environ.get("PP_COMM_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
+                    self.comm = capi.Comm.tcp(os.environ.get("MASTER_ADDR", "127.0.0.1"), port, self.rank, self.world)
+            # pre-flight: the exchange and the all-reduce of a migration step with known contents, checked
+            # word by word, BEFORE anything is timed (pp_comm_selftest).  A failure here is a failure of
+            # the run: the exception leaves main() with a non-zero exit code.
+            self.preflight = None
+            if self.comm is not None and self.world > 1:
+                beat("pre-flight exchange")
+                t0 = time.perf_counter()
+                self.comm.selftest(5)
+                self.preflight = {"ok": True, "seconds": time.perf_counter() - t0, "transport": self.comm.kind(),
+                                  "what": "5-7 records of 80 B to every peer through the migration's count "
+                                          "exchange + grouped send/recv, then the gyroSync all-reduce, contents "
+                                          "checked on every rank (pp_comm_selftest)"}
         if name in ("c3", "2dc3", "c5"):
             self.fwd, self.bkwd = capi.create_gyro_ring_mappings(self.mesh)
             self.w_f = capi.DevArray(self.mesh.nverts, np.float64)
@@ -244,6 +259,9 @@ class Stepper:
         if timed:
             e0, e1, e2 = capi.Event(), capi.Event(), capi.Event()
             e0.record()
+        beat("step %d: push + search" % self.steps_done)
+        if self.steps_done == 1 and os.environ.get("PP_BENCH_STALL_RANK") == str(self.w.get("rank", 0)):
+            time.sleep(3600)  # test hook (tests/test_gpu_comm.py): this rank hangs; the watchdogs end the job
         if self.name == "c2":
             capi.push_search(self.mesh, self.ps, self.h, self.k, self.d, self.deg, self.ids,
                              seeded=not self.first, looplimit=200, want_found=False)
@@ -263,6 +281,7 @@ class Stepper:
             self.ps.set_origin_trust(True)
         self.first = False
         self.steps_done += 1
+        beat("step %d: rebuild / migration / scatter" % (self.steps_done - 1))
         self._rest_of_step()
         if timed:
             e2.record()
@@ -317,18 +336,38 @@ class Stepper:
         # "2d": search_mesh_2d re-seeds from the previous ids as given
 
     def _make_comm(self):
-        """pp_comm over RCCL: rank 0 draws the id, torch.distributed (already up for the timing
-        barrier) broadcasts it -- the MPI_Bcast a PUMI-PIC build would do"""
+        """pp_comm over RCCL: rank 0 draws the id, torch.distributed (the host-side control plane) broadcasts
+        it -- the MPI_Bcast a PUMI-PIC build would do.  Every rank reaches the same verdict: a failure on ANY
+        rank (no id, communicator not formed) raises on ALL of them, so the fallback is taken together."""
         capi = self.capi
         if self.world == 1:
             return capi.Comm.env()
         import torch
         import torch.distributed as dist
-        t = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.zeros(129, dtype=torch.uint8, device=dev)
         if self.rank == 0:
-            t.copy_(torch.tensor(list(capi.Comm.unique_id()), dtype=torch.uint8))
+            try:
+                t[1:] = torch.tensor(list(capi.Comm.unique_id()), dtype=torch.uint8)
+                t[0] = 1
+            except capi.PPError as e:
+                sys.stderr.write("bench.py: rank 0 could not draw an RCCL id: %s\n" % e)
         dist.broadcast(t, 0)
-        return capi.Comm.rccl(bytes(t.cpu().tolist()), self.rank, self.world)
+        t = t.cpu()
+        comm, err = None, None
+        if int(t[0]) == 1:
+            try:
+                comm = capi.Comm.rccl(bytes(t[1:].tolist()), self.rank, self.world)
+            except capi.PPError as e:
+                err = e
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if comm is not None:
+                comm.destroy()
+            raise RuntimeError("the RCCL communicator was not formed on every rank (this rank: %s)"
+                               % (err if err is not None else "ok" if comm is not None else "no id"))
+        return comm
 
     def _allreduce_fields(self):
         import ctypes
@@ -423,6 +462,46 @@ METRIC = {
 }
 
 
+class Watchdog:
+    """A rank that makes no progress for `limit` seconds EXITS with code 3 (a fresh failure -- never a
+    re-exec, never a retry): a hang inside a collective would otherwise hold the whole job until the
+    driver's own limit.  The main thread calls beat(label) at every phase boundary; a daemon thread checks
+    the age of the last beat (ctypes calls and torch.distributed release the GIL, so it runs while the main
+    thread is blocked)."""
+
+    def __init__(self, limit_s, rank):
+        import threading
+        self.limit, self.rank = float(limit_s), rank
+        self.last, self.label = time.monotonic(), "start"
+        self.enabled = self.limit > 0
+        if self.enabled:
+            threading.Thread(target=self._run, name="bench-watchdog", daemon=True).start()
+
+    def beat(self, label):
+        self.last, self.label = time.monotonic(), label
+
+    def stop(self):
+        self.enabled = False
+
+    def _run(self):
+        while self.enabled:
+            time.sleep(min(5.0, max(0.2, self.limit / 10)))
+            age = time.monotonic() - self.last
+            if self.enabled and age > self.limit:
+                sys.stderr.write("bench.py: rank %d made no progress for %.0f s (last phase: %s) -- giving up, "
+                                 "exit code 3\n" % (self.rank, age, self.label))
+                sys.stderr.flush()
+                os._exit(3)
+
+
+WATCHDOG = None
+
+
+def beat(label):
+    if WATCHDOG is not None:
+        WATCHDOG.beat(label)
+
+
 def launch_ranks(n, argv):
     """`--gpus N` without a launcher: start N rank processes (one per GPU) from a parent that never
     touches the GPU -- a process that has initialised HIP must not fork/exec workers -- and relay
@@ -506,6 +585,12 @@ def main():
     ap.add_argument("--no-origin-trust", action="store_true",
                     help="run check_initial_parents every step (default: skipped from the second step on, "
                          "pp_ps_set_origin_trust)")
+    ap.add_argument("--watchdog", type=float, default=None,
+                    help="seconds without progress after which a rank exits with code 3 (default: 120 on "
+                         "multi-rank runs, off on one rank; 0 = off)")
+    ap.add_argument("--no-scale-ref", action="store_true",
+                    help="N = 1: skip the extra measurement of the multi-GPU workload's one-rank share "
+                         "(c5, 998 400 tets, 32 M particles) that the line reports as `scale_ref`")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch", "tcp"],
                     help="c5 exchange: RCCL behind the C-ABI (pp_ps_migrate / pp_allreduce_sum), the "
                          "torch.distributed glue of pumi-pic_amd/dist.py, or the library's host-staged TCP "
@@ -548,11 +633,19 @@ def main():
                          % (world, world, torch.cuda.device_count()))
         sys.exit(2)
     dist = None
+    ctl_cpu = True
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        if rehearsal:
+        # The control plane (timing barrier, max-over-ranks, the broadcast of the RCCL id) is gloo on the
+        # host; the data path is the library's own RCCL communicator.  PyTorch brings its own ROCm stack
+        # (libamdhip64 / libhsa-runtime64 / librccl under torch/lib, next to the system's under /opt/rocm that
+        # libpumipic_hip.so is linked against): a second RCCL from the other stack in the same process buys
+        # nothing and doubles the channel / proxy resources.  --comm torch (the round-1 Python glue) still
+        # needs torch's nccl backend.
+        ctl_cpu = rehearsal or a.comm != "torch"
+        if ctl_cpu:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -560,6 +653,12 @@ def main():
     pp = pumipic_amd_loader.load()
     from pumipic_amd import capi
     capi.init(local_rank)  # raises when the HIP library / GPU is missing: no CPU fallback
+    global WATCHDOG
+    wd_limit = a.watchdog if a.watchdog is not None else (120.0 if world > 1 else 0.0)
+    # (building a 32 M-particle population is minutes of numpy on the host: the set-up phase gets its own,
+    # longer, allowance -- the limit proper starts with the first collective)
+    WATCHDOG = Watchdog(max(wd_limit, 900.0) if wd_limit > 0 else 0.0, rank)
+    beat("set-up")
 
     if a.workload == "c4":
         w = build_c4(pp, capi, a.c4_elems, a.particles, rank, a.structure, a.c4_dist)
@@ -570,13 +669,18 @@ def main():
         w["safe_layers"] = a.safe_layers
         w["comm"] = a.comm
         w["origin_trust"] = not a.no_origin_trust
+        beat("workload built")
+        if WATCHDOG.enabled:
+            WATCHDOG.limit = wd_limit
         st = Stepper(pp, capi, w, a.workload, a.deg)
 
     def barrier():
+        beat("barrier")
         capi.sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
+        beat("barrier passed")
 
     def timed_run(steps):
         st.ntimed = 0
@@ -589,7 +693,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([dt], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
+            t = torch.tensor([dt], device="cpu" if ctl_cpu else "cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
@@ -624,15 +728,54 @@ def main():
     for _ in range(a.warmup):
         st.step()
     dt = timed_run(a.steps)
+    kms_main, sms_main = st.kernel_avg_ms(), (st.step_avg_ms() if hasattr(st, "step_avg_ms") else None)
     nlive = w["ps"].nPtcls()
     total_particles = nlive
+    # ---- the same K steps with check_initial_parents run for every particle (no pp_ps_set_origin_trust):
+    # reported beside the headline, never as it
+    notrust_ms = None
+    if (world == 1 and a.workload in ("c2", "c3") and w["dim"] == 3 and w.get("origin_trust", True)
+            and not os.environ.get("PP_BENCH_NO_EXTRAS")):
+        w["ps"].set_origin_trust(False)
+        st.step()
+        notrust_ms = timed_run(a.steps) / a.steps * 1e3
+        w["ps"].set_origin_trust(True)
+    # ---- scale_ref: ONE rank's share of the multi-GPU workload (c5: 998 400 tets, 32 M particles, migrating
+    # step on a one-rank communicator), measured in this very run, so that the N = 1 point of a 1 -> 8 sweep
+    # and the N > 1 points (which run c5) can be compared like with like
+    scale_ref = None
+    if (world == 1 and a.workload == "c3" and not a.no_scale_ref and a.mesh == "100k" and a.particles == 10_000_000
+            and a.sigma >= 2**31 - 1 and not os.environ.get("PP_BENCH_NO_EXTRAS")):
+        t_set = time.perf_counter()
+        w5 = build_workload(pp, capi, "c5", 32_000_000, 0, 1, a.deg, a.remainder, "1m", a.sigma)
+        w5["safe_layers"], w5["comm"], w5["origin_trust"] = 0, "rccl", True
+        st5 = Stepper(pp, capi, w5, "c5", a.deg)
+        t_set = time.perf_counter() - t_set
+        for _ in range(2):
+            st5.step()
+        k5 = 8
+        capi.sync()
+        t0 = time.perf_counter()
+        for _ in range(k5):
+            st5.step()
+        capi.sync()
+        dt5 = time.perf_counter() - t0
+        n5 = w5["ps"].nPtcls()
+        scale_ref = {"workload": "c5 on one rank: %s, %d particles, push+search+migrate(no peer)+rebuild+gyroScatter x2"
+                                 % (w5["label"], 32_000_000),
+                     "ms_per_step": dt5 / k5 * 1e3, "value": n5 * k5 / dt5, "unit": "particles/s", "steps": k5,
+                     "warmup": 2, "setup_seconds": t_set,
+                     "roofline_frac": 194.0 * n5 / (dt5 / k5) / 1e9 / HBM_PEAK_GBS,
+                     "note": "the N > 1 lines of this file run exactly this workload per GPU (weak scaling); "
+                             "scaling efficiency of an N-GPU line = value / (N * scale_ref.value)"}
+        del st5, w5
     if dist is not None:
-        t = torch.tensor([nlive], device="cpu" if rehearsal else "cuda", dtype=torch.int64)
+        t = torch.tensor([nlive], device="cpu" if ctl_cpu else "cuda", dtype=torch.int64)
         dist.all_reduce(t)
         total_particles = int(t.item())
 
     if rank == 0:
-        kms = st.kernel_avg_ms()
+        kms = kms_main
         # HBM bytes per launch from the PMC counters: collected with rocprofv3 in separate --pmc
         # passes of THIS command (tools/r02_measure.sh) and calibrated as DESIGN.md section 4 says;
         # a profiler cannot wrap itself, so the committed summary is reported with its provenance
@@ -682,7 +825,7 @@ def main():
         # (push+search 69 B + rebuild 125 B per particle) against the mean HIP-event time
         # of the sampled steps; the two phases are broken out under "phases".
         bpp_ps = BYTES["2d" if w["dim"] == 2 else "c2"]
-        sms = st.step_avg_ms()
+        sms = sms_main
         ps_kernel = ("k_push_walk_rowsq<3> + k_walk_pending<3> (one pp_push_search call)"
                      if w["dim"] == 3 else "k_push_walk_rows<2>")
         if full_step:
@@ -695,7 +838,10 @@ def main():
                                     "step, calibrated; profiles/traffic_%s.json)" % a.workload,
                     "scope": "whole step: every kernel between two steps' first launches (HIP events on the "
                              "library stream)",
-                    "kernel": ps_kernel + " is the longest launch of the step (profiles/)",
+                    "kernel": "whole step; its longest launches (profiles/r03_%s_kernel_stats.csv): k_move_pack<4> "
+                              "(the re-layout's one data pass, scattered 64-B records), then the record-fed "
+                              "%s" % (a.workload, "k_push_walk_rowsq<3> (+ k_walk_pending<3>)" if w["dim"] == 3
+                                      else "k_push_walk_rows<2>"),
                     "kernel_ms": sms, "bytes_per_particle": bpp,
                     "phases": {
                         "push_search": {"ms": kms, "bytes_per_particle": bpp_ps,
@@ -726,6 +872,24 @@ def main():
                  getattr(st, "comm_kind", a.comm), a.deg),
              "2dc3": "push+search+rebuild+gyroScatter x2 every step, deg/push=%g" % a.deg}[a.workload]),
             "parallelism": "element-block partition, %d rank(s), full-mesh replica" % world}
+        if notrust_ms is not None:
+            out["ms_per_step_no_origin_trust"] = notrust_ms
+        if scale_ref is not None:
+            out["scale_ref"] = scale_ref
+        if world > 1:
+            if getattr(st, "preflight", None):
+                out["preflight"] = st.preflight
+            ref_file = os.path.join(ROOT, "profiles", "scale_ref.json")
+            if os.path.exists(ref_file) and a.workload == "c5" and a.mesh == "1m" and a.scaling == "weak":
+                try:
+                    ref = json.load(open(ref_file))
+                    out["scale_ref"] = {"value": ref["value"], "ms_per_step": ref["ms_per_step"],
+                                        "source": "profiles/scale_ref.json (this workload on one rank, from a "
+                                                  "driver-style N = 1 run of this file: key scale_ref)"}
+                    out["efficiency_vs_scale_ref"] = out["value"] / (world * ref["value"])
+                except (ValueError, KeyError):
+                    pass
+            out["watchdog_s"] = WATCHDOG.limit if WATCHDOG is not None and WATCHDOG.enabled else 0
         if rehearsal:
             out["rehearsal"] = ("NOT a measurement: %d ranks share GPU 0, the exchange is the host-staged TCP transport "
                                 "and the timing barrier runs over gloo (PP_BENCH_REHEARSAL=1)" % world)

@@ -53,6 +53,8 @@ const char* pp_version(void);
 int pp_init(int device);
 void* pp_stream(void); /* hipStream_t */
 int pp_sync(void);
+/* the HIP runtime's sticky last error of the calling thread, not cleared (0 = none; message in *msg_out) */
+int pp_peek_hip_error(const char** msg_out);
 int pp_device_count(void);
 /* plain device memory helpers so hosts without a HIP toolchain (ctypes, cgo, JNI) can drive it */
 void* pp_malloc(size_t bytes);
@@ -498,6 +500,12 @@ int pp_allreduce_sum(pp_comm* c, double* buf_dev, int64_t n);
 /* MPI_Allreduce(MPI_LONG, SUM) of a few host values (particle totals, test/pseudoXGCm.cpp:508,523) */
 int pp_allreduce_sum_host_i64(pp_comm* c, int64_t* vals_host, int n);
 int pp_comm_barrier(pp_comm* c);
+/* Checked exchange through the calls a migration step makes (count exchange, ONE grouped send / receive
+ * per peer pair, the gyroSync all-reduce) with known contents; PP_ESTATE + a message naming the rank, the
+ * peer and the word when anything arrives wrong.  bench.py runs it before the timed loop of a multi-rank
+ * job, so that a fabric / bootstrap problem is a failure in seconds (no reference counterpart: the
+ * reference trusts MPI). */
+int pp_comm_selftest(pp_comm* c, int nrec);
 /* MPI_Allgather of nbytes host bytes per rank (timing summaries: SummarizeTimeAcrossProcesses,
  * support/ppTiming.cpp:220-300 reduces max / min / average over ranks) */
 int pp_comm_allgather_host(pp_comm* c, const void* send_host, void* recv_host, int nbytes);

@@ -56,6 +56,7 @@ SYMBOLS = {
     "pp_init": (_I, [_I]),
     "pp_stream": (_V, []),
     "pp_sync": (_I, []),
+    "pp_peek_hip_error": (_I, [C.POINTER(C.c_char_p)]),
     "pp_device_count": (_I, []),
     "pp_malloc": (_V, [_S]),
     "pp_free": (_I, [_V]),
@@ -178,6 +179,7 @@ SYMBOLS = {
     "pp_allreduce_sum": (_I, [_V, _V, C.c_int64]),
     "pp_allreduce_sum_host_i64": (_I, [_V, C.POINTER(C.c_int64), _I]),
     "pp_comm_barrier": (_I, [_V]),
+    "pp_comm_selftest": (_I, [_V, _I]),
     "pp_comm_allgather_host": (_I, [_V, _V, _V, _I]),
     "pp_ps_migrate": (_I, [_V, _V, _V, _V]),
     "pp_ps_migrate_scatter": (_I, [_V, _I, _I, _V, _V, _V, _I, _V, _V, _V, C.c_int64, _V, _I, _V, _V,
@@ -230,6 +232,13 @@ def init(device=0):
 
 def sync():
     check(lib().pp_sync())
+
+
+def peek_hip_error():
+    """(code, message) of the HIP runtime's sticky last error, not cleared; (0, '') = none"""
+    msg = C.c_char_p()
+    rc = lib().pp_peek_hip_error(C.byref(msg))
+    return rc, (msg.value or b"").decode()
 
 
 # ------------------------------------------------------------------ device arrays
@@ -1021,6 +1030,10 @@ class Comm:
 
     def barrier(self):
         check(lib().pp_comm_barrier(self.p))
+
+    def selftest(self, nrec=5):
+        """checked exchange + all-reduce with known contents (pp_comm_selftest); raises PPError"""
+        check(lib().pp_comm_selftest(self.p, int(nrec)))
 
     def allgather_host(self, values):
         v = np.ascontiguousarray(values)

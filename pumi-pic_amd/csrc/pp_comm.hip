@@ -62,8 +62,25 @@ static RcclApi* rccl() {
       last = e ? e : "?";
     }
   } else {
-    for (const char* n : names)  // a copy some other component (PyTorch) loaded already comes first
-      if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    // First choice: the librccl that ships next to the HIP runtime THIS library is bound to.  A process
+    // can hold two ROCm stacks (the system's under /opt/rocm and the one bundled with PyTorch, whichever
+    // was loaded first serves our NEEDED entries); an RCCL from the other stack finds its own HSA runtime
+    // uninitialised and fails with "no ROCm-capable device is detected".
+    Dl_info hip_info{};
+    if (dladdr((void*)&hipGetDeviceCount, &hip_info) && hip_info.dli_fname) {
+      std::string dir(hip_info.dli_fname);
+      const size_t slash = dir.rfind('/');
+      if (slash != std::string::npos) {
+        dir.resize(slash + 1);
+        for (const char* n : {"librccl.so.1", "librccl.so"}) {
+          if ((h = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_LOCAL))) break;
+          const char* e = dlerror();
+          last = e ? e : "?";
+        }
+      }
+    }
+    for (const char* n : names)  // else a copy some other component loaded already
+      if (h || (h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
     for (int i = 0; !h && i < 3; ++i) {
       h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
       if (!h) {
@@ -838,6 +855,88 @@ int pp_comm_allgather_host(pp_comm* c, const void* send_host, void* recv_host, i
   }
   pp::set_error("pp_comm_allgather_host: not available on a local communicator");
   return PP_ESTATE;
+}
+
+// Checked exchange before the first real one.  Every rank sends nrec + (rank + peer) % 3 records of 80 bytes
+// (the migration's record size for the pseudoXGCm particle) to every peer through the very calls the
+// migration makes -- the count exchange (ncclAllGather / the host all-to-all) and comm_exchange_records
+// (ONE group of ncclSend / ncclRecv per step on RCCL) -- and checks what arrives word by word; then the
+// gyroSync collective (pp_allreduce_sum) on a vector whose sum is known.  A fabric or bootstrap problem
+// shows up here, in seconds and with a message, instead of inside the timed loop.
+int pp_comm_selftest(pp_comm* c, int nrec) {
+  PP_REQUIRE(c && nrec >= 0, "pp_comm_selftest: bad argument");
+  PP_REQUIRE(c->kind != 4 || c->nranks == 1, "pp_comm_selftest: not for the virtual ranks of a local communicator");
+  PP_REQUIRE(pp::initialised(), "pp_comm_selftest: call pp_init(device) first");
+  const int n = c->nranks, me = c->rank;
+  constexpr int kWords = 10;  // 80-byte records
+  hipStream_t st = pp::stream();
+  std::vector<int> want_send((size_t)n, 0);
+  int64_t ns = 0;
+  for (int q = 0; q < n; ++q)
+    if (q != me) ns += (want_send[(size_t)q] = nrec + (me + q) % 3);
+  std::vector<int64_t> h_send((size_t)std::max<int64_t>(ns, 1) * kWords);
+  {
+    int64_t k = 0;
+    for (int q = 0; q < n; ++q)
+      for (int j = 0; j < want_send[(size_t)q]; ++j, ++k)
+        for (int w = 0; w < kWords; ++w) h_send[(size_t)(k * kWords + w)] = ((int64_t)me * 1000 + q) * (w + 1) + j;
+  }
+  pp::DevBuf d_send, d_cnt, d_vec;
+  PP_HIP_CHECK(d_send.reserve(h_send.size() * sizeof(int64_t)));
+  PP_HIP_CHECK(d_cnt.reserve(sizeof(int) * (size_t)n));
+  PP_HIP_CHECK(hipMemcpyAsync(d_send.p, h_send.data(), h_send.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+  PP_HIP_CHECK(hipMemcpyAsync(d_cnt.p, want_send.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
+  std::vector<int> send_counts, recv_counts;
+  bool known = true;
+  int rc = pp::comm_counts(c, d_cnt.as<int>(), send_counts, recv_counts, &known);
+  if (rc) return rc;
+  for (int q = 0; q < n; ++q) {
+    const int expect = q == me ? 0 : nrec + (q + me) % 3;
+    if (send_counts[(size_t)q] != want_send[(size_t)q] || recv_counts[(size_t)q] != expect) {
+      pp::set_error("pp_comm_selftest: rank " + std::to_string(me) + " learned the wrong counts for peer " +
+                    std::to_string(q) + " (send " + std::to_string(send_counts[(size_t)q]) + ", recv " +
+                    std::to_string(recv_counts[(size_t)q]) + ", expected " + std::to_string(want_send[(size_t)q]) +
+                    " / " + std::to_string(expect) + ")");
+      return PP_ESTATE;
+    }
+  }
+  void* d_recv = nullptr;
+  rc = pp::comm_exchange_records(c, d_send.p, send_counts, recv_counts, kWords * 8, &d_recv);
+  if (rc) return rc;
+  int64_t nr = 0;
+  for (int q = 0; q < n; ++q) nr += recv_counts[(size_t)q];
+  std::vector<int64_t> h_recv((size_t)std::max<int64_t>(nr, 1) * kWords, -1);
+  if (nr) PP_HIP_CHECK(hipMemcpyAsync(h_recv.data(), d_recv, (size_t)nr * kWords * 8, hipMemcpyDeviceToHost, st));
+  PP_HIP_CHECK(hipStreamSynchronize(st));
+  {
+    int64_t k = 0;
+    for (int q = 0; q < n; ++q)
+      for (int j = 0; j < recv_counts[(size_t)q]; ++j, ++k)
+        for (int w = 0; w < kWords; ++w)
+          if (h_recv[(size_t)(k * kWords + w)] != ((int64_t)q * 1000 + me) * (w + 1) + j) {
+            pp::set_error("pp_comm_selftest: rank " + std::to_string(me) + " received a wrong record from rank " +
+                          std::to_string(q) + " (record " + std::to_string(j) + ", word " + std::to_string(w) + ")");
+            return PP_ESTATE;
+          }
+  }
+  // gyroSync: SUM over the ranks of v[i] = (rank + 1) * (i + 1)
+  constexpr int kVec = 256;
+  std::vector<double> v(kVec);
+  for (int i = 0; i < kVec; ++i) v[(size_t)i] = (double)(me + 1) * (i + 1);
+  PP_HIP_CHECK(d_vec.reserve(sizeof(double) * kVec));
+  PP_HIP_CHECK(hipMemcpyAsync(d_vec.p, v.data(), sizeof(double) * kVec, hipMemcpyHostToDevice, st));
+  rc = pp_allreduce_sum(c, d_vec.as<double>(), kVec);
+  if (rc) return rc;
+  PP_HIP_CHECK(hipMemcpyAsync(v.data(), d_vec.p, sizeof(double) * kVec, hipMemcpyDeviceToHost, st));
+  PP_HIP_CHECK(hipStreamSynchronize(st));
+  const double tri = 0.5 * n * (n + 1);
+  for (int i = 0; i < kVec; ++i)
+    if (v[(size_t)i] != tri * (i + 1)) {
+      pp::set_error("pp_comm_selftest: rank " + std::to_string(me) + ": all-reduce entry " + std::to_string(i) + " is " +
+                    std::to_string(v[(size_t)i]) + ", expected " + std::to_string(tri * (i + 1)));
+      return PP_ESTATE;
+    }
+  return PP_OK;
 }
 
 int pp_comm_barrier(pp_comm* c) {

@@ -101,6 +101,15 @@ int pp_init(int device) {
 
 void* pp_stream(void) { return (void*)pp::g_stream; }
 
+// the HIP runtime's sticky "last error" of this thread, without clearing it (0 = none).  A launch that
+// failed unnoticed would sit there and be picked up by the next library that checks (RCCL does after
+// its own launches); tests/conftest.py asserts after every GPU test that nothing is left behind.
+int pp_peek_hip_error(const char** msg_out) {
+  const hipError_t e = hipPeekAtLastError();
+  if (msg_out) *msg_out = e == hipSuccess ? "" : hipGetErrorString(e);
+  return (int)e;
+}
+
 int pp_sync(void) {
   PP_HIP_CHECK(hipStreamSynchronize(pp::g_stream));
   return PP_OK;

@@ -193,3 +193,26 @@ else:
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout, r.stderr[-2000:])
     assert time.time() - t0 < 60
+
+
+def test_bench_watchdog_exits_with_code_3():
+    """bench.py's Watchdog (armed on multi-rank runs): no beat for `limit` seconds -> the process exits with
+    code 3 and says which phase it was in; beats keep it alive."""
+    import subprocess
+    code = r"""
+import sys, time
+sys.path.insert(0, %r)
+import bench
+bench.WATCHDOG = bench.Watchdog(1.0, 7)
+for i in range(8):          # 2.4 s of steady progress: still alive
+    time.sleep(0.3)
+    bench.beat("step %%d" %% i)
+print("alive", flush=True)
+bench.beat("the exchange")
+time.sleep(30)              # ... then silence
+print("not reached")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stdout, r.stderr[-1500:])
+    assert "alive" in r.stdout and "not reached" not in r.stdout
+    assert "rank 7 made no progress" in r.stderr and "the exchange" in r.stderr

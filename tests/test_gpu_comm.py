@@ -155,6 +155,54 @@ def test_migrate_local_virtual_ranks(ppo, synth, capi, dim, world, fused):
         c.destroy()
 
 
+def test_config5_step_eight_owner_blocks_vs_oracle(ppo, synth, capi):
+    """BASELINE configs[4]'s time step at a size the oracle walks in seconds: a coarse torus split into
+    EIGHT contiguous element blocks (bench.py's owner rule for 8 GPUs), every virtual rank calls what
+    bench.py's c5 step calls -- pp_push_search (origins trusted from the second step on), then
+    pp_migrate_ptcls_begin / pp_ps_migrate_end with the commit and both gyroScatter maps riding along,
+    then gyroSync as pp_gyro_sync_pack + pp_allreduce_sum.  Union of the ranks and the synced fields
+    equal the single-structure oracle run (migrate_lb_ptcls src/pumipic_ptcl_ops.hpp:53-85,
+    SCS_migrate.h:29-213, gyroSync test/gyroScatter.hpp:231-258)."""
+    pop = _population(synth, 3)
+    ne, world = len(pop["e2v"]), 8
+    from pumipic_amd import dist as ppdist
+    owners = ppdist.element_block_owners(ne, world)
+    mesh = capi.Mesh(3, pop["coords"], pop["e2v"], pop["cls"])
+    ref = _oracle_run(ppo, pop, NSTEPS)
+    comms = capi.Comm.local(world)
+    ranks = [_rank_structure(capi, pop, owners, r) for r in range(world)]
+    owners_d = capi.DevArray.from_host(owners)
+    safes = [capi.DevArray.from_host((owners == r).astype(np.uint8)) for r in range(world)]
+    fg, bg = capi.create_gyro_ring_mappings(mesh)
+    moved = 0
+    for step in range(NSTEPS):
+        fields, keep = [], []
+        for r, ps in enumerate(ranks):
+            ids = capi.DevArray(max(ps.capacity(), 1), np.int32)
+            capi.push_search(mesh, ps, H, K, D, 6.0, ids, seeded=False, looplimit=200)
+            assert capi.push_search_counters()[2] == 0
+            ps.set_origin_trust(True)
+            wf, wb = capi.DevArray(mesh.nverts, np.float64), capi.DevArray(mesh.nverts, np.float64)
+            capi.migrate_ptcls_begin(ps, ids, safes[r], owners_d, comms[r], commit=True,
+                                     scatter=(mesh, [fg, bg], [wf, wb]))
+            fields.append((wf, wb))
+            keep.append(ids)
+        for r, ps in enumerate(ranks):
+            ns, nr = capi.migrate_end(ps, comms[r])
+            moved += ns
+        packed = [capi.gyro_sync_pack(mesh.nverts, wf, wb) for wf, wb in fields]
+        for r in range(world):
+            comms[r].allreduce_sum(packed[r])
+        fo, bo = ref[4][step]
+        for r in range(world):
+            got = packed[r].to_host()
+            assert np.array_equal(got[0::2], fo) and np.array_equal(got[1::2], bo)
+    assert moved > 0
+    _check_union([_snapshot(ps) for ps in ranks], owners, ref)
+    for c in comms:
+        c.destroy()
+
+
 def test_migrate_new_particles_ride_along(ppo, synth, capi):
     """the caller's own new particles (new_particle_elements / new_particle_info of
     SellCSigma::migrate, SCS_migrate.h:198-206) enter the same rebuild as the received ones"""
@@ -435,6 +483,65 @@ def test_bench_multi_rank_line_rehearsal(tmp_path, launcher):
     assert j["scaling"] == ("strong" if launcher == "self" else "weak")
     assert j["metric"].startswith("particles pushed+searched+scattered")
     assert "migrate" in j["config"]["workload"] and "tcp" in j["config"]["workload"]
+    # the pre-flight ran (checked exchange + all-reduce through the migration's own calls) and the watchdog is armed
+    assert j["preflight"]["ok"] and j["preflight"]["transport"] == "tcp" and j["watchdog_s"] == 120
     assert j["rank0_sent_per_step"] > 0                       # particles really crossed between the ranks
     # whole-job particles / time (the population draws land within a fraction of a per cent of 2 x 300 000)
     assert abs(j["value"] - 600000 * 4 / (j["ms_per_step"] * 4e-3)) / j["value"] < 1e-2
+
+
+def test_bench_watchdog_turns_a_stalled_rank_into_exit_code_3(tmp_path):
+    """a rank that stops making progress (here: rank 1 sleeps inside its second step, PP_BENCH_STALL_RANK) must
+    END the job with a non-zero exit code within the watchdog's limit -- not hold it until somebody's timeout.
+    Rank 0 then sits in the exchange with a silent peer and its own watchdog fires; bench.py's parent relays
+    code 3."""
+    import subprocess
+    import time
+    env = dict(os.environ, PP_BENCH_REHEARSAL="1", PP_BENCH_PREWARM="0", PP_COMM_PORT=str(_free_port()),
+               PP_BENCH_CACHE=str(tmp_path), PP_BENCH_ASSUME_GPUS="2", PP_BENCH_STALL_RANK="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--workload", "c5", "--mesh", "100k", "--particles", "200000", "--comm", "tcp", "--no-cpu-baseline",
+           "--deg", "4.0", "--watchdog", "8"]
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 3, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    assert "made no progress" in r.stderr and "exit code 3" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]  # no line from a job that failed
+    assert time.time() - t0 < 300
+
+
+@pytest.mark.parametrize("order", ["torch_first", "library_first"])
+def test_rccl_pairs_with_the_librarys_own_hip_runtime(order):
+    """PyTorch bundles a second ROCm stack (libamdhip64 / libhsa-runtime64 / librccl under torch/lib).  Whatever
+    the import order, the library must open the librccl that sits next to the HIP runtime it is itself bound to:
+    an RCCL from the other stack finds its HSA runtime uninitialised ("no ROCm-capable device is detected") or,
+    worse, is handed streams and pointers of a runtime it does not know.  One-rank communicator + the checked
+    exchange in a fresh process per order."""
+    import subprocess
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+order = %r
+if order == "torch_first":
+    import torch
+    torch.cuda.set_device(0)
+    torch.zeros(4, device="cuda").sum().item()     # torch's own HIP runtime is live
+import pumipic_amd_loader
+pumipic_amd_loader.load()
+from pumipic_amd import capi
+capi.init(0)
+if order == "library_first":
+    import torch                                     # torch's stack arrives after ours
+    import torch.distributed                         # (loads torch's librccl; its HIP runtime stays idle)
+import numpy as np
+comm = capi.Comm.rccl(capi.Comm.unique_id(), 0, 1)
+assert comm.kind() == "rccl"
+comm.selftest(3)
+d = capi.DevArray.from_host(np.arange(16, dtype=np.float64))
+comm.allreduce_sum(d)
+assert np.array_equal(d.to_host(), np.arange(16, dtype=np.float64))
+comm.destroy()
+print("ok")
+""" % (ROOT, order)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout.split(), (r.returncode, r.stdout[-500:], r.stderr[-3000:])

@@ -224,6 +224,10 @@ def test_tet_c3_full_size_properties(pp, capi):
         cap = ps.capacity()
         ids = capi.DevArray(cap + cap // 10, np.int32)
         capi.push_search(mesh, ps, s.XGC_H, s.XGC_K, s.XGC_D, 0.5, ids, seeded=False, looplimit=200)
+        # the mode bench.py times: from the second step on the origins are trusted (pp_ps_set_origin_trust);
+        # the counter proves that no particle finished without a containment test that would have failed
+        assert capi.push_search_counters() == (0, 0, 0)
+        ps.set_origin_trust(True)
         want = ids.to_host()[:cap]
         mask = ps.slot_info()[1].astype(bool)
         pid_before = ps.member(2)[0, :cap][mask]
@@ -251,3 +255,97 @@ def test_tet_c3_full_size_properties(pp, capi):
         # 8 points x 4 mapped vertices (points outside the domain drop out)
         assert 0.8 * 32 * ps.nPtcls() <= f.sum() <= 32 * ps.nPtcls()
     assert ps.nPtcls() > 0.99 * n0
+
+
+def test_config5_share_two_virtual_ranks_full_size(pp, capi):
+    """BASELINE configs[4] at the size one GPU carries: the 998 400-tet mesh, 32 M particles -- here as TWO
+    virtual ranks of 16 M on a `local` communicator, so the exchange really moves particles between two
+    structures.  Three steps of what bench.py's c5 step calls (pp_push_search with trusted origins from the
+    second step on, pp_migrate_ptcls_begin / pp_ps_migrate_end with commit + both gyroScatter maps,
+    gyroSync).  Size-independent checks: the population is conserved BY PARTICLE ID across the ranks (no
+    loss, no duplicate), every particle sits on the rank that owns its element and in the row of the element
+    the walk gave it, its position is the x_tgt the push wrote (x <- x_tgt, x_tgt <- 0), a sample passes an
+    independent numpy barycentric test, and the synced scatter fields carry 2 rings x 4 vertices x the mapped
+    fraction of every particle on every rank."""
+    from pumipic_amd import dist as ppdist
+    world, per_rank = 2, 16_000_000
+    s = pp.synth
+    ws = [bench.build_workload(pp, capi, "c5", per_rank, r, world, 0.5, mesh_size="1m") for r in range(world)]
+    ne = ws[0]["ne"]
+    assert ne == 998_400
+    mesh = ws[0]["mesh"]  # (the ranks of one node hold the full mesh each; here they share one copy)
+    owners = ppdist.element_block_owners(ne, world)
+    owners_d = capi.DevArray.from_host(owners)
+    safes = [capi.DevArray.from_host((owners == r).astype(np.uint8)) for r in range(world)]
+    comms = capi.Comm.local(world)
+    fwd, bkwd = capi.create_gyro_ring_mappings(mesh)
+    for r, w in enumerate(ws):  # particle ids unique across the ranks
+        tag = np.zeros((1, w["ps"].info().stride), dtype=np.int32)
+        se, mk = w["ps"].slot_info()
+        slots = np.flatnonzero(mk)
+        assert len(slots) == per_rank and np.all(owners[se[slots]] == r)
+        tag[0, slots] = np.arange(per_rank, dtype=np.int32) + r * per_rank
+        w["ps"].set_member(2, tag)
+    rng = np.random.default_rng(11)
+    total = world * per_rank
+    moved = 0
+    for step in range(3):
+        before, fields = [], []
+        for r, w in enumerate(ws):
+            ps = w["ps"]
+            cap = ps.capacity()
+            ids = capi.DevArray(cap + cap // 10, np.int32)
+            capi.push_search(mesh, ps, s.XGC_H, s.XGC_K, s.XGC_D, 0.5, ids, seeded=False, looplimit=200)
+            nf, nie, unm = capi.push_search_counters()
+            assert nf == 0 and nie == 0 and unm == 0
+            ps.set_origin_trust(True)  # from the second step on the origins are what the last walk accepted
+            if step == 2:  # what the exchange must deliver, by particle id
+                mk = ps.slot_info()[1].astype(bool)
+                before.append((ps.member(2)[0, :cap][mk], ids.to_host()[:cap][mk], ps.member(1)[:, :cap][:, mk]))
+            wf, wb = capi.DevArray(mesh.nverts, np.float64), capi.DevArray(mesh.nverts, np.float64)
+            capi.migrate_ptcls_begin(ps, ids, safes[r], owners_d, comms[r], commit=True,
+                                     scatter=(mesh, [fwd, bkwd], [wf, wb]))
+            fields.append((wf, wb, ids))
+        for r, w in enumerate(ws):
+            ns, nr = capi.migrate_end(w["ps"], comms[r])
+            moved += ns
+        packed = [capi.gyro_sync_pack(mesh.nverts, wf, wb) for wf, wb, _ in fields]
+        for r in range(world):
+            comms[r].allreduce_sum(packed[r])
+        alive = sum(w["ps"].nPtcls() for w in ws)
+        assert 0.999 * total <= alive <= total
+        for r, w in enumerate(ws):  # ownership: a rank holds only elements of its block
+            se, mk = w["ps"].slot_info()
+            assert np.all(owners[se[mk.astype(bool)]] == r)
+        g0 = packed[0].to_host()
+        assert np.array_equal(g0, packed[1].to_host())  # every rank has the same synced fields
+        f = g0[0::2]
+        assert np.array_equal(f, g0[1::2]) and np.isfinite(f).all() and f.min() >= 0
+        assert 0.8 * 32 * alive <= f.sum() <= 32 * alive
+    assert moved > 1000  # particles really crossed the block boundary
+    # ---- last step: identity of every particle
+    pid_b = np.concatenate([b[0] for b in before])
+    elem_b = np.concatenate([b[1] for b in before])
+    xt_b = np.concatenate([b[2] for b in before], axis=1)
+    kept = elem_b >= 0
+    pid_a, elem_a, x_a = [], [], []
+    for w in ws:
+        ps = w["ps"]
+        cap = ps.capacity()
+        se, mk = ps.slot_info()
+        mk = mk.astype(bool)
+        pid_a.append(ps.member(2)[0, :cap][mk])
+        elem_a.append(se[:cap][mk])
+        x_a.append(ps.member(0)[:, :cap][:, mk])
+        assert not ps.member(1)[:, :cap][:, mk].any()  # x_tgt <- 0
+    pid_a, elem_a, x_a = np.concatenate(pid_a), np.concatenate(elem_a), np.concatenate(x_a, axis=1)
+    ob, oa = np.argsort(pid_b[kept]), np.argsort(pid_a)
+    assert np.array_equal(pid_b[kept][ob], pid_a[oa])            # nobody lost, nobody duplicated
+    assert len(np.unique(pid_a)) == len(pid_a)
+    assert np.array_equal(elem_b[kept][ob], elem_a[oa])           # everybody in the row of its new element
+    assert np.array_equal(xt_b[:, kept][:, ob], x_a[:, oa])       # x <- x_tgt
+    samp = rng.choice(len(pid_a), size=200_000, replace=False)
+    lam = _tet_bcc(ws[0]["coords"], ws[0]["e2v"], elem_a[samp], x_a[:, samp].T)
+    assert lam.min() > -1e-9, lam.min()
+    for c in comms:
+        c.destroy()
