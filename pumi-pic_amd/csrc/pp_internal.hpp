@@ -301,6 +301,12 @@ int ps_zeros(pp_ps* ps);  // only the pending zeros of pp_ps::zero_pending
 inline int ps_ready(const pp_ps* ps) {
   return (ps && (ps->zero_pending >= 0 || ps->lazy_rec)) ? ps_materialize(const_cast<pp_ps*>(ps)) : PP_OK;
 }
+// pp_ps_rebuild_scatter with one more promise: member m_xtgt of every NEW particle is zero (arrivals of a
+// migration that packed with the commit) -- the rebuild may then defer its second pass as if there were none
+int ps_rebuild_scatter(pp_ps* ps, int m_x, int m_xtgt, const int* new_element_dev, int n_new,
+                       const int* new_elems_dev, const void* const* new_info_dev, const pp_mesh* mesh, int nmaps,
+                       const int* const* v2v_dev, double* const* scatter_w_dev, double rmax, int gnr, int gppr,
+                       bool new_xt_zero);
 // the structure can feed the record-fed fused push with these member roles (3-D, pseudoXGCm particle type)
 bool lazy_push_ok(const pp_ps* ps, int m_x, int m_xtgt, int m_b, int m_phi);
 // pp_scatter.hip: gyroScatter for `nmaps` ring maps from an explicit per-element count array (the

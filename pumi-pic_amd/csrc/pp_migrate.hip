@@ -210,8 +210,15 @@ __global__ void k_route_pack(int capacity, int per_block, const unsigned char* _
 
 // commit_x / commit_xt >= 0: the record carries the particle AFTER updatePtclPositions (member
 // commit_x is read from commit_xt's arrays, member commit_xt travels as zeros)
-int build_rec_table(const pp_ps* ps, RecTable& t, int commit_x = -1, int commit_xt = -1) {
-  if (int rc = pp::ps_ready(ps)) return rc;
+// shape_only: only the layout of the record is wanted (sizes, the unpack side): no member is read, so
+// nothing has to be written back to the SoA arrays first.  The same holds for a committing pack when only
+// the ORIGIN of the same commit pair is still in the re-layout's records (pp_ps::lazy_rec == 2): the
+// committed record reads member commit_xt, never commit_x.
+int build_rec_table(const pp_ps* ps, RecTable& t, int commit_x = -1, int commit_xt = -1, bool shape_only = false) {
+  const bool origin_only_missing = ps->lazy_rec == 2 && ps->zero_pending < 0 && commit_x >= 0 &&
+                                   commit_x == ps->lazy_x && commit_xt == ps->lazy_xt;
+  if (!shape_only && !origin_only_missing)
+    if (int rc = pp::ps_ready(ps)) return rc;
   int nw = 0;
   for (int m = 0; m < ps->nmembers; ++m) {
     const int s = ps->member_map[m == commit_x ? commit_xt : m];
@@ -302,7 +309,7 @@ extern "C" {
 int pp_ps_migrate_record_bytes(const pp_ps* ps) {
   if (!ps) return PP_EINVAL;
   RecTable t{};
-  const int rc = build_rec_table(ps, t);
+  const int rc = build_rec_table(ps, t, -1, -1, true);
   return rc ? rc : t.rec_words * 4;
 }
 
@@ -425,7 +432,7 @@ static int rebuild_from_records(pp_ps* ps, int m_x, int m_xtgt, const int* new_e
                  : pp_ps_rebuild_scatter(ps, m_x, m_xtgt, new_element_dev, n_extra, extra_elems_dev,
                                          extra_info_dev, mesh, nmaps, v2v_dev, scatter_w_dev, rmax, gnr, gppr);
   RecTable t{};
-  int rc = build_rec_table(ps, t);
+  int rc = build_rec_table(ps, t, -1, -1, true);
   if (rc) return rc;
   hipStream_t st = pp::stream();
   pp::DevBuf* info = &scratch(8);  // scratch(8 + m): member m of the arriving particles
@@ -458,9 +465,12 @@ static int rebuild_from_records(pp_ps* ps, int m_x, int m_xtgt, const int* new_e
   // A gid without a local id unpacks as element -1, which the rebuild rejects like any inactive
   // new particle BEFORE it changes the structure: no separate host sync for the check.  The
   // scratch buffers outlive the call: the rebuild reads them in stream order.
+  // (records packed with the commit carry member m_xtgt as zeros: build_rec_table -- with no particles of
+  // the caller's own among the new ones the rebuild may treat that member as all zero)
   rc = plain ? pp_ps_rebuild(ps, new_element_dev, n_tot, elems.as<int>(), ptrs.data())
-             : pp_ps_rebuild_scatter(ps, m_x, m_xtgt, new_element_dev, n_tot, elems.as<int>(), ptrs.data(), mesh,
-                                     nmaps, v2v_dev, scatter_w_dev, rmax, gnr, gppr);
+             : pp::ps_rebuild_scatter(ps, m_x, m_xtgt, new_element_dev, n_tot, elems.as<int>(), ptrs.data(), mesh,
+                                      nmaps, v2v_dev, scatter_w_dev, rmax, gnr, gppr,
+                                      /*new_xt_zero=*/m_x >= 0 && m_xtgt >= 0 && n_extra == 0);
   if (rc == PP_EINVAL) {
     int hbad = 0;
     if (hipMemcpy(&hbad, bad.p, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && hbad)
@@ -572,7 +582,7 @@ static int migrate_begin_rule(pp_ps* ps, int m_x, int m_xtgt, int* new_element_d
   P.recv_known = true;
   if (n > 1) {
     RecTable t{};
-    int rc = build_rec_table(ps, t, P.m_x, P.m_xtgt);
+    int rc = build_rec_table(ps, t, P.m_x, P.m_xtgt, true);
     if (rc) return rc;
     P.rec_bytes = t.rec_words * 4;
     PP_HIP_CHECK(comm->d_counts.reserve(sizeof(int) * (size_t)n));

@@ -1467,6 +1467,23 @@ __global__ void k_add_scs(int n_new, const int* __restrict__ new_elems,
   new_mask[idx] = 1;
   copy_members(a, i, idx);
 }
+// new particles of a rebuild whose second pass is deferred (pseudoXGCm particle type, committed layout of
+// k_move_pack: words 0-5 member commit_x, 13 / 14 / 15 the three 4-byte members from the back)
+__global__ void k_add_rec(int n_new, const int* __restrict__ new_elems, const int* __restrict__ rank_new,
+                          const int* __restrict__ elem_slot0, int C_new, const unsigned long long* __restrict__ x,
+                          const unsigned* __restrict__ m2, const unsigned* __restrict__ m3,
+                          const unsigned* __restrict__ m4, uint4* __restrict__ aos, const int* __restrict__ go) {
+  if (!*go) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_new) return;
+  const long long idx = elem_slot0[new_elems[i]] + (long long)rank_new[i] * C_new;
+  const unsigned long long x0 = x[i], x1 = x[(size_t)n_new + i], x2 = x[2 * (size_t)n_new + i];
+  uint4* r = aos + idx * 4;
+  r[0] = make_uint4((unsigned)x0, (unsigned)(x0 >> 32), (unsigned)x1, (unsigned)(x1 >> 32));
+  r[1] = make_uint4((unsigned)x2, (unsigned)(x2 >> 32), 0u, 0u);
+  r[2] = make_uint4(0u, 0u, 0u, 0u);
+  r[3] = make_uint4(0u, m4[i], m3[i], m2[i]);
+}
 // Row-tiled move (SCS): thread = (old tile, row).  Stayers of the thread reserve their slots in the
 // new row with ONE atomic (n_stay * C) and are written in a second sweep; movers take slots one
 // by one.  Reads are coalesced 64-slot runs; every member of a particle moves in this one pass.
@@ -2981,15 +2998,15 @@ int scs_reshuffle(pp_ps* ps, const int* new_element, int n_new, const int* new_e
 int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_elems,
                 const void* const* new_info, int commit_x, int commit_xt,
                 const std::function<int(const int*)>& pre_sync = std::function<int(const int*)>(),
-                bool try_reshuffle = true) {
+                bool try_reshuffle = true, bool new_xt_zero = false) {
   hipStream_t st = pp::stream();
   const int ne = ps->num_elems;
   PP_REQUIRE(n_new == 0 || new_info != nullptr, "rebuild: new particles need new_info_dev");
   // zeros left pending by the previous in-place rebuild; records left by the previous full re-layout.
   // Exception: after the record-fed push only the ORIGIN (member lazy_x) is still in records, and a
   // rebuild that commits the same pair of members never reads it.
-  if (!(ps->lazy_rec == 2 && ps->zero_pending < 0 && n_new == 0 && commit_x == ps->lazy_x &&
-        commit_xt == ps->lazy_xt)) {
+  if (!(ps->lazy_rec == 2 && ps->zero_pending < 0 && (n_new == 0 || new_xt_zero) && commit_x >= 0 &&
+        commit_x == ps->lazy_x && commit_xt == ps->lazy_xt)) {
     int rc0 = pp::ps_ready(ps);
     if (rc0) return rc0;
   }
@@ -3012,7 +3029,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     // the layout cannot be kept: full re-layout (the new counts were final, so scatters that already
     // ran behind them are not repeated)
     return scs_rebuild(ps, new_element, n_new, new_elems, new_info, commit_x, commit_xt,
-                       scattered ? std::function<int(const int*)>() : pre_sync, false);
+                       scattered ? std::function<int(const int*)>() : pre_sync, false, new_xt_zero);
   }
   // histogram and totals in one allocation: one fill clears both (a fill is a ~5 us dispatch)
   const size_t tot_off = (sizeof(int) * (size_t)std::max(ne, 1) + 255) / 256 * 256;
@@ -3208,7 +3225,8 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       // x_tgt <- 0 of the fused updatePtclPositions stays pending (pp_ps::zero_pending): the next fused
       // push overwrites the member, anything else materialises the zeros first.  24 of the 60 bytes
       // pass 2 would write per particle.
-      lazy_zero = NQ > 0 && commit_x >= 0 && commit_xt >= 0 && n_new == 0 && getenv("PP_NO_LAZY_ZERO") == nullptr;
+      lazy_zero = NQ > 0 && commit_x >= 0 && commit_xt >= 0 && (n_new == 0 || new_xt_zero) &&
+                  getenv("PP_NO_LAZY_ZERO") == nullptr;
       if (lazy_zero) wt.nz8 = wt.nz4 = 0;
       // The second pass (records -> new SoA arrays) is deferred for the pseudoXGCm particle type: the
       // next fused push reads the records themselves (pp_search.hip: RECIN), anything else runs the
@@ -3240,7 +3258,13 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
           ps->d_chunk_start.as<int>(), ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(),
           ps->d_mask.as<unsigned char>(), new_element, ps->s_e2r2.as<int>(), C_new,
           ps->s_rowstart.as<int>(), ps->s_mask2.as<unsigned char>(), mv, go);
-    if (n_new > 0) {
+    if (n_new > 0 && defer_unpack) {
+      // (pseudoXGCm type, member commit_xt of the arrivals known to be zero: they join the records)
+      k_add_rec<<<grid_for(n_new), kBlock, 0, st>>>(
+          n_new, new_elems, rank_new, ps->s_eslot0.as<int>(), C_new, (const unsigned long long*)new_info[commit_x],
+          (const unsigned*)new_info[2], (const unsigned*)new_info[3], (const unsigned*)new_info[4],
+          ps->s_aos.as<uint4>(), go);
+    } else if (n_new > 0) {
       MoveArgs add = mv;
       for (int m = 0; m < ps->nmembers; ++m) add.src[m] = new_info[m];
       add.src_stride = n_new;
@@ -3309,7 +3333,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     // stage (1/2-byte scalars) land here: full re-layout after all, without the decision -- correct, at the
     // price of a second histogram + sort + layout for that rebuild.
     return scs_rebuild(ps, new_element, n_new, new_elems, new_info, commit_x, commit_xt,
-                       std::function<int(const int*)>(), false);
+                       std::function<int(const int*)>(), false, new_xt_zero);
   }
   if (h.active == 0) {  // SCS_rebuild.h:168-182: no particle left -- resetMask, structure kept
     ps->swap_stride = swap_stride_before;
@@ -3886,6 +3910,14 @@ int pp_ps_rebuild_scatter(pp_ps* ps, int m_x, int m_xtgt, const int* new_element
                           const int* new_elems_dev, const void* const* new_info_dev,
                           const pp_mesh* mesh, int nmaps, const int* const* v2v_dev,
                           double* const* scatter_w_dev, double rmax, int gnr, int gppr) {
+  return pp::ps_rebuild_scatter(ps, m_x, m_xtgt, new_element_dev, n_new, new_elems_dev, new_info_dev, mesh, nmaps,
+                                v2v_dev, scatter_w_dev, rmax, gnr, gppr, false);
+}
+}  // extern "C"
+int pp::ps_rebuild_scatter(pp_ps* ps, int m_x, int m_xtgt, const int* new_element_dev, int n_new,
+                           const int* new_elems_dev, const void* const* new_info_dev, const pp_mesh* mesh, int nmaps,
+                           const int* const* v2v_dev, double* const* scatter_w_dev, double rmax, int gnr, int gppr,
+                           bool new_xt_zero) {
   PP_REQUIRE(ps && nmaps >= 0 && (nmaps == 0 || (mesh && v2v_dev && scatter_w_dev)),
              "pp_ps_rebuild_scatter: null argument");
   PP_REQUIRE(nmaps == 0 || ps->num_elems == mesh->nelems,
@@ -3923,8 +3955,10 @@ int pp_ps_rebuild_scatter(pp_ps* ps, int m_x, int m_xtgt, const int* new_element
   };
   return scs_rebuild(ps, new_element_dev, n_new, new_elems_dev, new_info_dev, commit ? m_x : -1,
                      commit ? m_xtgt : -1, nmaps > 0 ? std::function<int(const int*)>(scatter)
-                                                     : std::function<int(const int*)>());
+                                                     : std::function<int(const int*)>(),
+                     true, new_xt_zero && commit);
 }
+extern "C" {
 
 int pp_ps_rebuild_commit(pp_ps* ps, int m_x, int m_xtgt, const int* new_element_dev, int n_new,
                          const int* new_elems_dev, const void* const* new_info_dev) {
