@@ -170,16 +170,10 @@ int pp_ps_rebuild_scatter(pp_ps* ps, int m_x, int m_xtgt, const int* new_element
  *      full re-layout needs anyway, so it costs nothing when the layout cannot be kept -- at 10^5 rows
  *      some row overflows its padding in nearly every step (measured: 600-2500 rows per pseudoXGCm
  *      step), so large structures practically always take the full re-layout, as the reference does;
- *   2  elastic (experimental, this library's extension): a row that would overflow trades places with
- *      a row of a wider chunk whose occupant fits the narrower one, or moves into a chunk appended
- *      behind the last one (its old row becomes a padding row); the full re-layout runs only when the
- *      allocation's headroom is used up.  Same particles per element as the other modes; row order
- *      and capacity differ from the reference's.  Measured slower than the full re-layout on the
- *      pseudoXGCm step: scattered 4/8-byte stores into a SoA layout cost ~35 ps each.
  * Rows stay prefix-compact in every mode (a shrinking row back-fills its holes from its own tail). */
 int pp_ps_set_shuffling(pp_ps* ps, int mode);
-/* how the rebuilds of this structure ended so far: kept layout / full re-layout; rows that traded
- * places (mode 2) */
+/* how the rebuilds of this structure ended so far: kept layout / full re-layout (n_rows_moved: always 0,
+ * kept for callers of the round-2 interface) */
 int pp_ps_rebuild_stats(const pp_ps* ps, long long* n_in_place, long long* n_full, long long* n_rows_moved);
 /* getPIDs ps_for.hpp:65-85: offsets_dev[ne+1], pids_dev[nPtcls] */
 int pp_ps_get_pids(const pp_ps* ps, int* offsets_dev, int* pids_dev);

@@ -484,7 +484,7 @@ class PS:
         check(lib().pp_ps_rebuild_commit(self.p, m_x, m_xtgt, ne.ptr, 0, None, None))
 
     def set_try_shuffling(self, v):
-        """False / 0: never in place; True / 1: the reference's reshuffle decision; 2: elastic (default)"""
+        """False / 0: never in place; True / 1 (default): the reference's reshuffle decision"""
         check(lib().pp_ps_set_shuffling(self.p, int(v)))
 
     def rebuild_stats(self):

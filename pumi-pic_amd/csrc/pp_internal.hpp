@@ -16,14 +16,6 @@ namespace pp {
 void set_error(const std::string& msg);
 unsigned long long next_version();  // pp_runtime.hip: process-wide monotonic stamp
 hipStream_t stream();
-// scope in which pp::stream() is the library's side queue (fork at `fork_ev` / now, join at scope exit)
-struct SideScope {
-  bool active = false;
-  explicit SideScope(void* fork_ev = nullptr);
-  ~SideScope();
-  SideScope(const SideScope&) = delete;
-  SideScope& operator=(const SideScope&) = delete;
-};
 // pp_scatter.hip: a device range was freed / overwritten through the C-ABI -- forget the gather
 // form of any gyro ring map living there
 void gyro_map_invalidate(const void* dev, size_t bytes);
@@ -194,15 +186,11 @@ struct pp_ps {
   unsigned long long version = 0;
   unsigned long long last_max_key = ~0ull;  // largest layout sort key of the previous rebuild (~0 = unknown)
   int tile_p = pp::kTileP;  // columns per tile (PP_TILE_P overrides, tuning knob)
-  // SellCSigma::tryShuffling (SellCSigma.h:92,213,236): a rebuild first tries to keep the layout and
-  // move only the particles that change element (SCS_rebuild.h:4-119)
-  // 0 = always the full re-layout (setShuffling(false)); 1 (default) = the reference's decision (in
-  // place iff every row fits); 2 = elastic (experimental): rows that overflow trade places with rows of
-  // wider chunks or move into chunks appended at the end, the full re-layout runs only when the
-  // allocation's headroom is used up
+  // SellCSigma::tryShuffling (SellCSigma.h:92,213,236): a rebuild keeps the layout and moves only the
+  // particles that change element when every row's arrivals fit its holes (SCS_rebuild.h:4-119)
+  // 0 = always the full re-layout (setShuffling(false)); 1 (default) = the reference's decision
   int shuffle_mode = 1;
-  int sorted_chunks = 0;  // chunks [0, sorted_chunks) are in the last full re-layout's (ascending-width) order
-  long long n_reshuffles = 0, n_full_rebuilds = 0, n_rows_moved = 0;  // how the rebuilds of this structure ended
+  long long n_reshuffles = 0, n_full_rebuilds = 0;  // how the rebuilds of this structure ended
   pp::DevBuf d_eslot0;  // first slot of every element's row in the CURRENT layout
   // a member whose content is logically all zero but has not been written yet (storage index, -1 =
   // none): x_tgt after a fused updatePtclPositions of the in-place rebuild.  Cleared without a pass
@@ -222,7 +210,7 @@ struct pp_ps {
   int lazy_rec = 0;
   int lazy_x = -1, lazy_xt = -1;  // commit members of the rebuild that left the records
   pp::DevBuf s_aos_live;
-  pp::DevBuf s_rs, s_holes, s_rsx;  // in-place rebuild: per-element counters, per-row hole lists, elastic lists
+  pp::DevBuf s_rs, s_holes;  // in-place rebuild: per-element counters, per-row hole lists
   // scratch reused across rebuilds
   pp::DevBuf s_ppe, s_keys, s_keys2, s_vals, s_vals2, s_hist, s_chunkw, s_misc, s_rowstart,
       s_newidx, s_offsets2, s_s2c2, s_r2e2, s_e2r2, s_mask2, s_slot2, s_scan, s_cstart2, s_cwidth2, s_aos, s_idx, s_ranknew, s_eslot0, s_scan2;

@@ -143,12 +143,6 @@ int64_t spread_stride(int64_t n) {
   while (s % 32 != 17) ++s;
   return s * 64;
 }
-// Slots allocated beyond the capacity so that the last chunk can widen in place (elastic mode of the
-// in-place rebuild): allocation only, the layout arrays do not see it.
-int64_t growth_reserve(const pp_ps* ps, int64_t cap) {
-  if (ps->shuffle_mode < 2) return 0;
-  return std::max<int64_t>(cap / 10, (int64_t)ps->C_max * 256);
-}
 int alloc_members(pp_ps* ps, std::vector<pp::DevBuf>& bufs, int64_t stride, bool zero) {
   bufs.resize((size_t)ps->nmembers);
   for (int m = 0; m < ps->nmembers; ++m) {
@@ -214,12 +208,7 @@ struct Totals {  // s_misc layout
   unsigned long long max_key;  // largest sort key of this rebuild (radix passes above it are skipped)
   // in-place rebuild: rows whose new count exceeds their chunk width, rows that traded places,
   // "no home found for an overflowing row"
-  int n_over, n_moved, match_fail, pad_;
-  int dbg[8];  // the first row the elastic matching could not house (PP_SPEC_DEBUG)
-  // one-kernel sort + layout (k_layout_coop): arrival counter of its grid barriers, and which of the two
-  // key / index buffers holds the sorted result
-  unsigned bar;
-  int sort_parity;
+  int n_over, pad_[3];  // rows whose new count exceeds their chunk width (the reference then re-lays out)
 };
 
 __global__ void k_count_added(int n_new, const int* __restrict__ new_elems, int ne,
@@ -1045,347 +1034,6 @@ __global__ void k_layout_tables(LayoutTablesArgs a) {
   if (!a.tot->go) return;
   layout_tables_body(a, blockIdx.x);
 }
-// ---- The sort + layout chain of a rebuild as ONE kernel (keys, the radix passes, chunk widths, padding,
-// the three chunk scans, the speculation gate and the table fills were ~15 dependent launches of a few
-// dozen blocks each, ~5 us apiece whatever their work).  The phases are separated by grid barriers: an
-// arrival counter in device memory, release / acquire at agent scope (each XCD has its own L2).  All
-// blocks must be resident at once: the grid is ceil(ne / 2048) blocks of 256 threads, capped at 1024
-// (the chip holds 2048 such blocks); larger structures keep the launch chain.
-__device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned nblocks, unsigned& target) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    target += nblocks;
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-}
-struct CoopArgs {
-  // sort
-  int ne;
-  const int* ppe;
-  int sigma, n_sigma;
-  unsigned long long base;
-  unsigned long long *ka, *kb;
-  int *va, *vb;
-  int* hist;    // [blocks][256] digit counts of every block's tile
-  int* colpre;  // [blocks][256] the same, exclusive prefix over the blocks
-  int* dtot;    // [256] digit totals
-  int no_skip;
-  ElemTotalsArgs et;
-  // layout
-  int nchunks, C, V, TP, pad_strat;
-  double pad;
-  int *widths, *slice_off, *chunk_start, *tile_off, *ntiles_out;
-  int* blocksum;  // [blocks][3] slices / slots / tiles of every block's slab of chunks
-  SpecArgs sp;
-  int do_tables;
-  LayoutTablesArgs ta;
-  Totals* tot;
-};
-__global__ void __launch_bounds__(256) k_layout_coop(CoopArgs a) {
-  __shared__ int h[256];
-  __shared__ int base_d[256];
-  __shared__ int wave_cnt[4][256];
-  __shared__ int s_red[4][4];
-  __shared__ unsigned long long smx[4];
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  const int b = blockIdx.x, nblk = gridDim.x;
-  unsigned target = 0;
-  Totals* tot = a.tot;
-  const int tile0 = b * RS_TILE;
-  // ---- phase 0: keys (k_make_keys), totals of the new population, digit-0 counts
-  {
-    h[t] = 0;
-    __syncthreads();
-    unsigned long long mx = 0;
-    int nz = 0, sum = 0, over = 0;
-    for (int j = t; j < RS_TILE; j += 256) {
-      const int i = tile0 + j;
-      if (i >= a.ne) break;
-      int w = 0;
-      if (a.sigma > 0) {
-        w = i / a.sigma;
-        if (w > a.n_sigma - 1) w = a.n_sigma - 1;
-      }
-      const int n = a.ppe[i];
-      const unsigned long long key = (unsigned long long)w * a.base + (unsigned long long)n;
-      a.ka[i] = key;
-      a.va[i] = i;
-      atomicAdd(&h[(int)(key & 255ull)], 1);
-      mx = key > mx ? key : mx;
-      nz += n > 0;
-      sum += n;
-      if (a.et.fit) over += n > a.et.chunk_width_old[a.et.e2r_old[i] / a.et.C_old];
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-      nz += __shfl_down(nz, o);
-      sum += __shfl_down(sum, o);
-      over += __shfl_down(over, o);
-      const unsigned long long y = __shfl_down(mx, o);
-      mx = y > mx ? y : mx;
-    }
-    if (lane == 0) {
-      s_red[wave][0] = nz;
-      s_red[wave][1] = sum;
-      s_red[wave][2] = over;
-      smx[wave] = mx;
-    }
-    __syncthreads();
-    if (t == 0) {
-      for (int k = 1; k < 4; ++k) {
-        nz += s_red[k][0];
-        sum += s_red[k][1];
-        over += s_red[k][2];
-        mx = smx[k] > mx ? smx[k] : mx;
-      }
-      if (a.et.totals) {
-        if (nz) {
-          atomicAdd(&tot->nonempty, nz);
-          atomicAdd(&tot->active, sum);
-        }
-        if (over) atomicAdd(&tot->n_over, over);
-      }
-      if (mx) atomicMax(&tot->max_key, a.no_skip ? ~0ull : mx);
-    }
-    a.hist[b * 256 + t] = h[t];
-  }
-  grid_barrier(&tot->bar, nblk, target);
-  // ---- stable LSD radix sort, 8 bits a pass, as many passes as the largest key needs
-  const unsigned long long max_key = __hip_atomic_load(&tot->max_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  unsigned long long *kin = a.ka, *kout = a.kb;
-  int *vin = a.va, *vout = a.vb;
-  int parity = 0;
-  int W = 1;  // blocks that scan the digit columns: a power of two, <= 64 (4 digits a block at least)
-  while (W * 2 <= nblk && W * 2 <= 64) W *= 2;
-  for (int shift = 0; shift < 64 && (max_key >> shift) != 0; shift += 8) {
-    if (shift > 0) {  // digit counts of this block's tile (pass 0: counted with the keys)
-      h[t] = 0;
-      __syncthreads();
-      for (int j = t; j < RS_TILE; j += 256) {
-        const int i = tile0 + j;
-        if (i < a.ne) atomicAdd(&h[(int)((kin[i] >> shift) & 255ull)], 1);
-      }
-      __syncthreads();
-      a.hist[b * 256 + t] = h[t];
-      grid_barrier(&tot->bar, nblk, target);
-    }
-    if (b < W) {  // exclusive prefix of every digit's counts over the blocks; one wave per digit
-      const int per_wave = 256 / W / 4;
-      for (int q = 0; q < per_wave; ++q) {
-        const int d = b * (256 / W) + wave * per_wave + q;
-        int carry = 0;
-        for (int j0 = 0; j0 < nblk; j0 += 64) {
-          const int j = j0 + lane;
-          const int v = j < nblk ? a.hist[j * 256 + d] : 0;
-          int incl = v;
-          for (int o = 1; o < 64; o <<= 1) {
-            const int y = __shfl_up(incl, o);
-            if (lane >= o) incl += y;
-          }
-          if (j < nblk) a.colpre[j * 256 + d] = carry + incl - v;
-          carry += __shfl(incl, 63);
-        }
-        if (lane == 0) a.dtot[d] = carry;
-      }
-    }
-    grid_barrier(&tot->bar, nblk, target);
-    {  // first output position of every digit for this block: digits below + the same digit in lower blocks
-      const int v = a.dtot[t];
-      int incl = v;
-      for (int o = 1; o < 64; o <<= 1) {
-        const int y = __shfl_up(incl, o);
-        if (lane >= o) incl += y;
-      }
-      if (lane == 63) s_red[wave][3] = incl;
-      __syncthreads();
-      int woff = 0;
-      for (int w = 0; w < wave; ++w) woff += s_red[w][3];
-      base_d[t] = woff + incl - v + a.colpre[b * 256 + t];
-    }
-    for (int round = 0; round < RS_TILE / 256; ++round) {  // (k_rs_scatter)
-      for (int w = 0; w < 4; ++w) wave_cnt[w][t] = 0;
-      __syncthreads();
-      const int i = tile0 + round * 256 + t;
-      const bool valid = i < a.ne;
-      unsigned long long key = 0;
-      int val = 0, digit = 0;
-      if (valid) {
-        key = kin[i];
-        val = vin[i];
-        digit = (int)((key >> shift) & 255ull);
-      }
-      unsigned long long same = __ballot(valid);
-      for (int bb = 0; bb < 8; ++bb) {
-        const unsigned long long bal = __ballot(valid && ((digit >> bb) & 1));
-        same &= ((digit >> bb) & 1) ? bal : ~bal;
-      }
-      const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-      const int rank_in_wave = __popcll(same & lt);
-      if (valid && rank_in_wave == 0) wave_cnt[wave][digit] = __popcll(same);
-      __syncthreads();
-      if (valid) {
-        int off = base_d[digit];
-        for (int w = 0; w < wave; ++w) off += wave_cnt[w][digit];
-        const int pos = off + rank_in_wave;
-        kout[pos] = key;
-        vout[pos] = val;
-      }
-      __syncthreads();
-      base_d[t] += wave_cnt[0][t] + wave_cnt[1][t] + wave_cnt[2][t] + wave_cnt[3][t];
-      __syncthreads();
-    }
-    grid_barrier(&tot->bar, nblk, target);
-    {
-      unsigned long long* ks = kin;
-      kin = kout;
-      kout = ks;
-      int* vs = vin;
-      vin = vout;
-      vout = vs;
-    }
-    parity ^= 1;
-  }
-  if (b == 0 && t == 0) tot->sort_parity = parity;
-  // ---- chunk widths of this block's slab of chunks (k_chunk_widths2) and their sum / non-zero count
-  const int S = (a.nchunks + nblk - 1) / nblk;
-  const int c0 = min(b * S, a.nchunks), c1 = min(c0 + S, a.nchunks);
-  {
-    int psum = 0, pcnt = 0;
-    for (int c = c0 + wave; c < c1; c += 4) {
-      int w = 0;
-      for (int r = lane; r < a.C; r += 64) {
-        const int row = c * a.C + r;
-        if (row < a.ne) w = max(w, (int)(kin[row] % a.base));
-      }
-      for (int o = 32; o > 0; o >>= 1) w = max(w, __shfl_down(w, o));
-      if (lane == 0) {
-        a.widths[c] = w;
-        psum += w;
-        pcnt += w > 0;
-      }
-    }
-    if (lane == 0) {
-      s_red[wave][0] = psum;
-      s_red[wave][1] = pcnt;
-    }
-    __syncthreads();
-    if (t == 0) {
-      psum = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
-      pcnt = s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1];
-      if (psum) atomicAdd(&tot->cw_sum, psum);
-      if (pcnt) atomicAdd(&tot->cw_cnt, pcnt);
-    }
-  }
-  grid_barrier(&tot->bar, nblk, target);
-  // ---- padding, slices / slots / tiles of every chunk, their exclusive scans (k_layout_fused): local
-  // scan of the slab, block totals, offsets of the lower blocks
-  const int cw_sum = __hip_atomic_load(&tot->cw_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int cw_cnt = __hip_atomic_load(&tot->cw_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int avg_pad =
-      (a.pad > 0 && cw_sum > 0 && a.pad_strat == PP_PAD_EVENLY) ? (int)(cw_sum * a.pad / cw_cnt) : 0;
-  int tot3[3] = {0, 0, 0};  // (thread 0) totals of this block's slab
-  {
-    const int IT = (S + 255) / 256;  // consecutive chunks per thread
-    const int my0 = c0 + t * IT, my1 = min(my0 + IT, c1);
-    int s0 = 0, s1 = 0, s2 = 0;
-    for (int c = my0; c < my1; ++c) {
-      int w = a.widths[c];
-      if (a.pad > 0 && cw_sum > 0) {
-        if (a.pad_strat == PP_PAD_EVENLY) {
-          if (w > 0) w += avg_pad;
-        } else {
-          w = (int)(w + w * a.pad);
-        }
-        a.widths[c] = w;
-      }
-      s0 += w / a.V + ((w % a.V) != 0);
-      s1 += w * a.C;
-      s2 += (w + a.TP - 1) / a.TP;
-    }
-    int i0 = s0, i1 = s1, i2 = s2;
-    for (int o = 1; o < 64; o <<= 1) {
-      const int y0 = __shfl_up(i0, o), y1 = __shfl_up(i1, o), y2 = __shfl_up(i2, o);
-      if (lane >= o) {
-        i0 += y0;
-        i1 += y1;
-        i2 += y2;
-      }
-    }
-    __syncthreads();  // (s_red is reused)
-    if (lane == 63) {
-      s_red[wave][0] = i0;
-      s_red[wave][1] = i1;
-      s_red[wave][2] = i2;
-    }
-    __syncthreads();
-    int r0 = i0 - s0, r1 = i1 - s1, r2 = i2 - s2;
-    for (int w = 0; w < wave; ++w) {
-      r0 += s_red[w][0];
-      r1 += s_red[w][1];
-      r2 += s_red[w][2];
-    }
-    for (int c = my0; c < my1; ++c) {  // slab-local exclusive prefixes; the block offset comes below
-      const int w = a.widths[c];
-      a.slice_off[c] = r0;
-      a.chunk_start[c] = r1;
-      a.tile_off[c] = r2;
-      r0 += w / a.V + ((w % a.V) != 0);
-      r1 += w * a.C;
-      r2 += (w + a.TP - 1) / a.TP;
-    }
-    if (t == 0) {
-      for (int k = 0; k < 3; ++k) tot3[k] = s_red[0][k] + s_red[1][k] + s_red[2][k] + s_red[3][k];
-      a.blocksum[3 * b] = tot3[0];
-      a.blocksum[3 * b + 1] = tot3[1];
-      a.blocksum[3 * b + 2] = tot3[2];
-    }
-  }
-  grid_barrier(&tot->bar, nblk, target);
-  {
-    int o0 = 0, o1 = 0, o2 = 0;
-    for (int j = t; j < b; j += 256) {
-      o0 += a.blocksum[3 * j];
-      o1 += a.blocksum[3 * j + 1];
-      o2 += a.blocksum[3 * j + 2];
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-      o0 += __shfl_down(o0, o);
-      o1 += __shfl_down(o1, o);
-      o2 += __shfl_down(o2, o);
-    }
-    __syncthreads();
-    if (lane == 0) {
-      s_red[wave][0] = o0;
-      s_red[wave][1] = o1;
-      s_red[wave][2] = o2;
-    }
-    __syncthreads();
-    o0 = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
-    o1 = s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1];
-    o2 = s_red[0][2] + s_red[1][2] + s_red[2][2] + s_red[3][2];
-    for (int c = c0 + t; c < c1; c += 256) {
-      a.slice_off[c] += o0;
-      a.chunk_start[c] += o1;
-      a.tile_off[c] += o2;
-    }
-    if (b == nblk - 1 && t == 0) {  // the last block knows the totals
-      tot->nslices = o0 + tot3[0];
-      tot->capacity = o1 + tot3[1];
-      *a.ntiles_out = o2 + tot3[2];
-      if (a.sp.on) spec_decide(tot, a.sp.cap_lim, a.sp.nsl_lim, a.sp.C_max, 64, a.sp.keep_if_fits);
-    }
-  }
-  if (!a.do_tables) return;
-  grid_barrier(&tot->bar, nblk, target);
-  // ---- table fills of the new layout (k_layout_tables), when the speculative tail may run
-  if (!__hip_atomic_load(&tot->go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-  LayoutTablesArgs ta = a.ta;
-  ta.index = vin;
-  const unsigned nvb = ta.b3 + (unsigned)((ta.nrows + 255) / 256);
-  for (unsigned vb = (unsigned)b; vb < nvb; vb += (unsigned)nblk) layout_tables_body(ta, vb);
-}
 // new layout: slot -> parent element for every slot of every tile, first slot of every row
 __global__ void k_init_slots_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
                                    const int* __restrict__ tiles, const int* __restrict__ chunk_start,
@@ -1998,10 +1646,9 @@ __global__ void k_rs_count_added(int n_new, const int* __restrict__ new_elems, i
 }
 // per element: the new count and whether it fits the row (SCS_rebuild.h:33-42: new particles of a row
 // against its holes, i.e. new count <= chunk width); totals by one atomic pair per block
-constexpr int kMaxOver = 1 << 15;  // overflowing rows the elastic mode re-homes per rebuild
 __global__ void k_rs_fit(int ne, int C, const int* __restrict__ n_old, RsCounters cn,
                          const int* __restrict__ e2r, const int* __restrict__ chunk_width,
-                         int* __restrict__ n_new, Totals* tot, int* __restrict__ ov_list, int reference_rule) {
+                         int* __restrict__ n_new, Totals* tot) {
   __shared__ int s_sum[4], s_nz[4];
   int sum = 0, nz = 0;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
@@ -2011,13 +1658,9 @@ __global__ void k_rs_fit(int ne, int C, const int* __restrict__ n_old, RsCounter
     nz += n > 0;
     // The reference counts a row's holes BEFORE its movers leave (SCS_rebuild.h:13-25: a slot is a hole
     // when it is empty or its particle is removed; a particle that moves to another row still
-    // occupies its slot), so its test is  arrivals <= width - (old count - removed).  The in-place
-    // algorithm here needs only  new count <= width  (the elastic mode uses that).
-    const int occupied = reference_rule ? n_old[e] - cn.removed[e] + cn.arrive[e] : n;
-    if (occupied > chunk_width[e2r[e] / C]) {  // the row overflows (a few hundred of 10^5 per pseudoXGCm step)
-      const int k = atomicAdd(&tot->n_over, 1);
-      if (k < kMaxOver) ov_list[k] = e;
-    }
+    // occupies its slot), so its test is  arrivals <= width - (old count - removed).
+    const int occupied = n_old[e] - cn.removed[e] + cn.arrive[e];
+    if (occupied > chunk_width[e2r[e] / C]) atomicAdd(&tot->n_over, 1);  // the row overflows: no in-place rebuild
   }
   for (int o = 32; o > 0; o >>= 1) {
     sum += __shfl_down(sum, o);
@@ -2035,271 +1678,8 @@ __global__ void k_rs_fit(int ne, int C, const int* __restrict__ n_old, RsCounter
     if (nz) atomicAdd(&tot->nonempty, nz);
   }
 }
-// Elastic mode (this library's extension of the reshuffle): a row whose new count exceeds its chunk
-// width trades places with a row of a wider chunk whose own new count fits the narrower one; when the
-// wide row's occupant does not fit the vacated home it is re-homed in turn (a short chain down the
-// width order: chunk widths differ by about the padding).  Only row_to_element / element_to_row /
-// first-slot tables change -- offsets, slices, chunk widths and the capacity stay -- so the result is
-// the kind of layout the reference's own reshuffle leaves behind (rows no longer sorted by count).
-// One block: claims by compare-and-swap on swap_old[row] (-1 = untouched, else the element that
-// lived there before this rebuild), all-or-nothing: the tables are written only when every
-// overflowing row found a home.
-struct RsMoves {
-  int *elem, *old_row, *new_row;  // kMaxOver * kMaxDepth entries worst case is never reached: capped
-};
-constexpr int kMaxMoves = 4 * kMaxOver;
-// Rows that find no partner get a NEW row: chunks appended behind the last one (the slot space ends
-// there, so it can grow into the allocation's headroom).  Their old rows become padding rows (ids >=
-// num_elems, never live).  A previously empty element (width-0 chunk) that receives its first
-// particles is the typical customer: no swap can house it, its old home has no columns to offer.
-struct RsPool {
-  int sorted_chunks;  // chunks [0, sorted_chunks) ascend in width (the last full re-layout's order)
-  int room_slots, room_rows, room_chunks, room_tiles, room_slices;  // what the tables can still take (host)
-  int V, TP;
-  int *offsets, *s2c, *tiles, *ntiles, *chunk_start_w, *chunk_width_w, *slot_elem;
-  unsigned char* mask;
-  int* pool_list;  // scratch: overflowing elements that need a new row
-};
-__global__ void __launch_bounds__(1024)
-    k_rs_match(int ne, int C, int nchunks, const int* __restrict__ chunk_width,
-               const int* __restrict__ chunk_start, int* __restrict__ r2e, int* __restrict__ e2r,
-               int* __restrict__ eslot0, const int* __restrict__ n_new, const int* __restrict__ ov_list,
-               int* __restrict__ swap_old, RsMoves mv, Totals* tot, int probe_rows, int capacity, int nslices,
-               RsPool pl) {
-  __shared__ int s_fail, s_nmv, s_npool, s_max_small, s_max_big, s_n_small, s_n_big;
-  __shared__ int s_w_small, s_w_big, s_ch_small, s_ch_big, s_ks, s_kb, s_cap1;
-  const int nov = tot->n_over;
-  if (nov == 0 || tot->invalid) return;
-  if (nov > kMaxOver) {
-    if (threadIdx.x == 0) tot->match_fail = 1;
-    return;
-  }
-  if (threadIdx.x == 0) {
-    s_fail = s_nmv = s_npool = s_max_small = s_max_big = s_n_small = s_n_big = s_ks = s_kb = 0;
-    s_cap1 = capacity;
-  }
-  for (int i = threadIdx.x; i < nov; i += blockDim.x) swap_old[e2r[ov_list[i]]] = ov_list[i];  // homes vacated
-  __syncthreads();
-  auto record = [&](int elem, int from, int to) {
-    const int k = atomicAdd(&s_nmv, 1);
-    if (k < kMaxMoves) {
-      mv.elem[k] = elem;
-      mv.old_row[k] = from;
-      mv.new_row[k] = to;
-    } else {
-      s_fail = 1;
-    }
-  };
-  constexpr int kSmall = 64;
-  // ---- stage 1: trade places with a row of a wider chunk whose occupant fits the vacated home
-  for (int i = threadIdx.x; i < nov; i += blockDim.x) {
-    const int A = ov_list[i];
-    const int home = e2r[A], w_home = chunk_width[home / C], need = n_new[A];
-    int taken = -1, taken_occ = -1;
-    if (w_home > 0) {
-      // first sorted chunk wide enough, with the head-room a fresh layout would give the row (a home
-      // that fits exactly overflows again at the next arrival)
-      const int want = need + max(8, need / 8);
-      int lo = 0, hi = pl.sorted_chunks;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (chunk_width[mid] >= want) hi = mid; else lo = mid + 1;
-      }
-      if (lo >= pl.sorted_chunks) {  // nothing that roomy: settle for wide enough
-        lo = 0, hi = pl.sorted_chunks;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (chunk_width[mid] >= need) hi = mid; else lo = mid + 1;
-        }
-      }
-      const int row0 = lo * C, row_end = pl.sorted_chunks * C;
-      for (int k = 0; k < probe_rows && taken < 0; ++k) {
-        const int L = row0 + k;
-        if (L >= row_end) break;
-        const int wl = chunk_width[L / C];
-        if (wl < need || swap_old[L] != -1) continue;
-        const int B = r2e[L];
-        const int nB = B < ne ? n_new[B] : 0;
-        if (nB > wl || nB > w_home) continue;  // overflows itself / does not fit the vacated home
-        if (atomicCAS(&swap_old[L], -1, B) == -1) {
-          taken = L;
-          taken_occ = B;
-        }
-      }
-    }
-    if (taken >= 0) {
-      record(A, home, taken);
-      record(taken_occ, taken, home);
-    } else {
-      pl.pool_list[atomicAdd(&s_npool, 1)] = A;
-      if (need <= kSmall) {
-        atomicMax(&s_max_small, need);
-        atomicAdd(&s_n_small, 1);
-      } else {
-        atomicMax(&s_max_big, need);
-        atomicAdd(&s_n_big, 1);
-      }
-    }
-  }
-  __syncthreads();
-  // ---- stage 2: new rows for the rest, two width classes (most newcomers hold a handful of particles)
-  const int npool = s_npool;
-  if (threadIdx.x == 0 && npool > 0) {
-    const int ws = s_n_small ? (s_max_small + 16 + pl.TP - 1) / pl.TP * pl.TP : 0;
-    const int wb = s_n_big ? (s_max_big + max(16, s_max_big / 4) + pl.TP - 1) / pl.TP * pl.TP : 0;
-    const int cs = (s_n_small + C - 1) / C, cb = (s_n_big + C - 1) / C;
-    const long long slots = (long long)C * ((long long)cs * ws + (long long)cb * wb);
-    const int tiles = cs * ((ws + pl.TP - 1) / pl.TP) + cb * ((wb + pl.TP - 1) / pl.TP);
-    const int slices = cs * ((ws + pl.V - 1) / pl.V) + cb * ((wb + pl.V - 1) / pl.V);
-    if (slots > pl.room_slots || (cs + cb) * C > pl.room_rows || cs + cb > pl.room_chunks ||
-        tiles > pl.room_tiles || slices > pl.room_slices)
-      s_fail = 1;
-    s_w_small = ws;
-    s_w_big = wb;
-    s_ch_small = cs;
-    s_ch_big = cb;
-  }
-  __syncthreads();
-  if (s_fail) {
-    if (threadIdx.x == 0) {
-      tot->match_fail = 1;
-      tot->dbg[0] = npool;
-      tot->dbg[1] = s_n_small;
-      tot->dbg[2] = s_max_small;
-      tot->dbg[3] = s_n_big;
-      tot->dbg[4] = s_max_big;
-      tot->dbg[5] = pl.room_slots;
-      tot->dbg[6] = pl.room_rows;
-      tot->dbg[7] = s_nmv;
-    }
-    return;
-  }
-  // ---- every row has a home.  The pool rows are recorded first (the move list may still overflow),
-  // then the chunks are appended and the tables written.
-  const int ws = npool ? s_w_small : 0, wb = npool ? s_w_big : 0, cs = npool ? s_ch_small : 0,
-            cb = npool ? s_ch_big : 0;
-  const int nc_new = cs + cb;
-  for (int i = threadIdx.x; i < npool; i += blockDim.x) {
-    const int A = pl.pool_list[i];
-    const bool small = n_new[A] <= kSmall;
-    const int k = atomicAdd(small ? &s_ks : &s_kb, 1);
-    const int row = (nchunks + (small ? 0 : cs)) * C + k;
-    record(A, e2r[A], row);
-    record(row, row, e2r[A]);  // the new row's padding id takes the vacated home
-  }
-  __syncthreads();
-  if (s_fail) {
-    if (threadIdx.x == 0) tot->match_fail = 1;
-    return;
-  }
-  if (nc_new) {
-    if (threadIdx.x == 0) {
-      int cap = capacity, ns = nslices, nt = *pl.ntiles;
-      for (int k = 0; k < nc_new; ++k) {
-        const int c = nchunks + k, w = k < cs ? ws : wb;
-        pl.chunk_start_w[c] = cap;
-        pl.chunk_width_w[c] = w;
-        for (int q = 0; q * pl.V < w; ++q) {
-          pl.offsets[ns] = cap + q * pl.V * C;
-          pl.s2c[ns] = c;
-          ++ns;
-        }
-        for (int p0 = 0; p0 < w; p0 += pl.TP) {
-          pl.tiles[2 * nt] = c;
-          pl.tiles[2 * nt + 1] = p0;
-          ++nt;
-        }
-        cap += w * C;
-      }
-      pl.offsets[ns] = cap;
-      *pl.ntiles = nt;
-      s_cap1 = cap;
-      tot->capacity = cap;
-      tot->nslices = ns;
-      tot->cw_sum = nt;      // tiles after the growth
-      tot->cw_cnt = nc_new;  // chunks appended (both fields are unused on this path otherwise)
-    }
-    for (int i = threadIdx.x; i < nc_new * C; i += blockDim.x) {  // new rows start as padding rows
-      const int row = nchunks * C + i;
-      r2e[row] = row;
-      e2r[row] = row;
-      swap_old[row] = row;  // "a padding row lived here": rows that get an element read as moved into
-    }
-  }
-  __syncthreads();
-  if (nc_new) {  // per-slot tables of the new chunks: small-class chunks are equally wide, then the big class
-    const int cap0 = capacity, cap1 = s_cap1, small_span = cs * ws * C;
-    for (int slot = cap0 + threadIdx.x; slot < cap1; slot += blockDim.x) {
-      const int off = slot - cap0;
-      int c, in;
-      if (off < small_span) {
-        c = off / (ws * C);
-        in = off - c * ws * C;
-      } else {
-        c = cs + (off - small_span) / (wb * C);
-        in = (off - small_span) - (c - cs) * wb * C;
-      }
-      pl.mask[slot] = 0;
-      pl.slot_elem[slot] = (nchunks + c) * C + in % C;  // the padding row's own id
-    }
-  }
-  const int nmv = s_nmv;
-  for (int k = threadIdx.x; k < nmv; k += blockDim.x) {
-    const int E = mv.elem[k], row = mv.new_row[k];
-    r2e[row] = E;
-    e2r[E] = row;
-    if (E < ne) eslot0[E] = pl.chunk_start_w[row / C] + row % C;
-  }
-  if (threadIdx.x == 0) tot->n_moved = nmv;
-}
-__global__ void k_rs_go(Totals* tot, int elastic) {
-  const bool fits = tot->n_over == 0 || (elastic && !tot->match_fail);
-  tot->go = (!tot->invalid && tot->active > 0 && fits) ? 1 : 0;
-}
-// the particles that STAY in an element whose row traded places travel too: arrival ranks behind the
-// true arrivals, records staged like the movers'.  One wave per moved element.
-template <int NQ>
-__global__ void k_rs_stage_moved(int C, const int* __restrict__ chunk_start, const int* __restrict__ n_old,
-                                 const int* __restrict__ new_element, int ne, RsMoves mv, int* __restrict__ arrive,
-                                 int* __restrict__ rank, uint4* __restrict__ aos, WordTable t,
-                                 const Totals* __restrict__ tot) {
-  if (!tot->go) return;
-  const int lane = threadIdx.x & 63;
-  const int nwaves = gridDim.x * (blockDim.x >> 6);
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  for (int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < tot->n_moved; k += nwaves) {
-  const int E = mv.elem[k];
-  if (E >= ne) continue;  // a padding row has no particles
-  const int row = mv.old_row[k], start = chunk_start[row / C] + row % C, nold = n_old[E];
-  for (int p0 = 0; p0 < nold; p0 += 64) {
-    const int p = p0 + lane;
-    const long long pid = start + (long long)p * C;
-    const bool stays = p < nold && new_element[pid] == E;
-    const unsigned long long bal = __ballot(stays);
-    if (!bal) continue;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&arrive[E], __popcll(bal));
-    base = __shfl(base, 0);
-    if (stays) {
-      rank[pid] = base + __popcll(bal & lt);
-      unsigned v[NQ * 4];
-#pragma unroll
-      for (int i = 0; i < NQ * 4; ++i) v[i] = 0u;
-#pragma unroll
-      for (int i = 0; i < NQ * 2; ++i)
-        if (i < t.n8) {
-          const unsigned long long d = *(const unsigned long long*)(t.src8[i] + pid * 8);
-          v[2 * i] = (unsigned)d;
-          v[2 * i + 1] = (unsigned)(d >> 32);
-        }
-#pragma unroll
-      for (int i = 0; i < (NQ * 4 < kMax4 ? NQ * 4 : kMax4); ++i)
-        if (i < t.n4) v[NQ * 4 - 1 - i] = *(const unsigned*)(t.src4[i] + pid * 4);
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) aos[pid * NQ + q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-    }
-  }
-  }
+__global__ void k_rs_go(Totals* tot) {
+  tot->go = (!tot->invalid && tot->active > 0 && tot->n_over == 0) ? 1 : 0;
 }
 __global__ void k_rs_plan(const int* __restrict__ ntiles_dev, int C, int TP, int G,
                           const int* __restrict__ tiles, const int* __restrict__ chunk_start,
@@ -2307,14 +1687,12 @@ __global__ void k_rs_plan(const int* __restrict__ ntiles_dev, int C, int TP, int
                           const int* __restrict__ n_old, const int* __restrict__ n_new,
                           const int* __restrict__ new_element, int ne, RsCounters cn,
                           int* __restrict__ hole_tab, int* __restrict__ rank,
-                          unsigned char* __restrict__ mask, const int* __restrict__ swap_old,
-                          int* __restrict__ slot_elem, const int* __restrict__ go) {
+                          unsigned char* __restrict__ mask, const int* __restrict__ go) {
   if (!*go) return;
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int grp = (int)(g / C), r = (int)(g - (long long)grp * C);
   const int ntiles = *ntiles_dev;
   int cur = -1, e = -1, start = 0, run_p0 = 0, nold = 0, nnew = 0, arr = 0;
-  bool moved_in = false;  // this physical row changed its element: nothing stays, every column below the new count is a hole
   unsigned hb = 0, tb = 0;  // holes / tail stayers of the run, bit = column - run_p0
   auto flush = [&]() {
     if (hb) {
@@ -2350,17 +1728,13 @@ __global__ void k_rs_plan(const int* __restrict__ ntiles_dev, int C, int TP, int
         nnew = n_new[e];
         arr = cn.arrive[e];
       }
-      const int so = swap_old[c * C + r];
-      moved_in = so >= 0 && so != e;
-      if (moved_in) nold = so < ne ? n_old[so] : 0;  // live columns of the element that moved out
       run_p0 = p0;
     }
-    const int wc = chunk_width[c];
-    const int pend = min(min(p0 + TP, wc), moved_in ? wc : max(nold, nnew));
+    const int pend = min(min(p0 + TP, chunk_width[c]), max(nold, nnew));
     for (int p = p0; p < pend; ++p) {
       const int pid = start + p * C;
       const bool live = p < nold;
-      const bool stays = !moved_in && live && new_element[pid] == e;
+      const bool stays = live && new_element[pid] == e;
       const unsigned bit = 1u << (p - run_p0);
       if (p < nnew) {
         if (!stays) hb |= bit;
@@ -2368,7 +1742,6 @@ __global__ void k_rs_plan(const int* __restrict__ ntiles_dev, int C, int TP, int
         tb |= bit;
       }
       if ((p < nnew) != live) mask[pid] = p < nnew ? 1 : 0;
-      if (moved_in) slot_elem[pid] = e;
     }
   }
   flush();
@@ -2380,14 +1753,12 @@ __global__ void k_rs_move(const int* __restrict__ ntiles_dev, int C, int TP, int
                           const int* __restrict__ n_old, const int* __restrict__ n_new,
                           const int* __restrict__ new_element, int ne, const int* __restrict__ eslot0,
                           const int* __restrict__ hole_tab, const int* __restrict__ rank,
-                          const uint4* __restrict__ aos, WordTable t, const int* __restrict__ swap_old,
-                          const int* __restrict__ go) {
+                          const uint4* __restrict__ aos, WordTable t, const int* __restrict__ go) {
   if (!*go) return;
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int grp = (int)(g / C), r = (int)(g - (long long)grp * C);
   const int ntiles = *ntiles_dev;
   int cur = -1, e = -1, start = 0, nold = 0, nnew = 0;
-  bool moved_out = false;  // the element that lived in this physical row traded places: all of it travels
   for (int k = 0; k < G; ++k) {
     const int tile = grp * G + k;
     if (tile >= ntiles) break;
@@ -2396,9 +1767,6 @@ __global__ void k_rs_move(const int* __restrict__ ntiles_dev, int C, int TP, int
       cur = c;
       start = chunk_start[c] + r;
       e = r2e[c * C + r];
-      const int so = swap_old[c * C + r];
-      moved_out = so >= 0 && so != e;
-      if (moved_out) e = so;  // the particles in these slots belong to the element that moved out
       nold = nnew = 0;
       if (e < ne) {
         nold = n_old[e];
@@ -2409,7 +1777,7 @@ __global__ void k_rs_move(const int* __restrict__ ntiles_dev, int C, int TP, int
     for (int p = p0; p < pend; ++p) {
       const int pid = start + p * C;
       const int ne_ = new_element[pid];
-      if (ne_ == e && !moved_out) {
+      if (ne_ == e) {
         if (p < nnew) continue;  // stays where it is
         const long long tgt = hole_tab[start + rank[pid] * C];  // back-fill a hole of the own row
 #pragma unroll
@@ -2521,20 +1889,6 @@ MoveArgs make_move(const pp_ps* ps, const std::vector<pp::DevBuf>& src, int64_t 
   return a;
 }
 
-int coop_block_limit() {
-  static int limit = -1;
-  if (limit < 0) {
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_layout_coop, 256, 0) == hipSuccess)
-      limit = std::min(1024, per_cu * prop.multiProcessorCount);
-    else
-      limit = 0;
-  }
-  return limit;
-}
-
 // One attempt of the device re-layout for a given chunk height.  Enqueues everything up to (and
 // including) the D2H read of the totals; the caller synchronises once.
 struct LayoutPlan {
@@ -2545,13 +1899,7 @@ struct LayoutPlan {
   unsigned long long* keys;
   int* index;
   int *widths, *nsl, *nslots, *slice_off, *tile_cnt, *tile_off, *chunk_start;
-  // one-kernel path (k_layout_coop): the sorted index is index_ab[Totals::sort_parity]; `tables_done` =
-  // the table fills ran in the same kernel (behind the speculation gate)
-  bool coop = false, tables_done = false;
-  int* index_ab[2] = {nullptr, nullptr};
 };
-// resident-block budget of k_layout_coop (its grid barriers need every block on the chip at once)
-int coop_block_limit();
 
 // bits_limit > 0: sort on the low `bits_limit` key bits only (the caller predicts the largest key
 // from the previous rebuild and checks the prediction against Totals::max_key afterwards)
@@ -2568,80 +1916,6 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
   L.key_bits = 64;
   L.keys = nullptr;
   L.index = nullptr;
-  L.coop = L.tables_done = false;
-  // opt-in: measured SLOWER than the launch chain (tools/ub_gridbar.hip: a grid barrier costs 3.6 us at 49
-  // blocks and 29 us at 489 -- the arrivals are same-address device-scope atomics, ~57 ns each -- against
-  // 2.8 us for a kernel boundary; c3 0.871 vs 0.857 ms, ps_combo160 1 M / 1 M 0.557 vs 0.406 ms)
-  static const bool no_coop = getenv("PP_COOP_LAYOUT") == nullptr;
-  const int nblk_c = (ne + RS_TILE - 1) / RS_TILE;
-  if (!no_coop && L.sorted && !(ps->pad_strat == PP_PAD_INVERSELY && ps->shuffle_padding > 0) &&
-      nblk_c <= coop_block_limit()) {
-    const int nchunks = L.nchunks;
-    PP_HIP_CHECK(ps->s_keys.reserve(sizeof(unsigned long long) * (size_t)ne));
-    PP_HIP_CHECK(ps->s_keys2.reserve(sizeof(unsigned long long) * (size_t)ne));
-    PP_HIP_CHECK(ps->s_vals.reserve(sizeof(int) * (size_t)ne));
-    PP_HIP_CHECK(ps->s_vals2.reserve(sizeof(int) * (size_t)ne));
-    PP_HIP_CHECK(ps->s_hist.reserve(sizeof(int) * 256 * (size_t)nblk_c * 2));
-    PP_HIP_CHECK(ps->s_scan2.reserve(sizeof(int) * (256 + 3 * (size_t)nblk_c)));
-    PP_HIP_CHECK(ps->s_chunkw.reserve(sizeof(int) * (size_t)nchunks * 5 + 64));
-    PP_HIP_CHECK(ps->s_cwidth2.reserve(sizeof(int) * (size_t)nchunks));
-    PP_HIP_CHECK(ps->s_cstart2.reserve(sizeof(int) * (size_t)nchunks));
-    PP_HIP_CHECK(ps->s_scan.reserve(sizeof(int)));
-    L.widths = ps->s_cwidth2.as<int>();
-    L.nsl = ps->s_chunkw.as<int>();
-    L.nslots = L.nsl + nchunks;
-    L.slice_off = L.nslots + nchunks;
-    L.tile_cnt = L.slice_off + nchunks;
-    L.tile_off = L.tile_cnt + nchunks;
-    L.chunk_start = ps->s_cstart2.as<int>();
-    const int sg = std::min(ps->sigma, std::max(ne, 1));
-    CoopArgs a{};
-    a.ne = ne;
-    a.ppe = ppe;
-    a.sigma = sg;
-    a.n_sigma = ne / sg;
-    a.base = L.base;
-    a.ka = ps->s_keys.as<unsigned long long>();
-    a.kb = ps->s_keys2.as<unsigned long long>();
-    a.va = ps->s_vals.as<int>();
-    a.vb = ps->s_vals2.as<int>();
-    a.hist = ps->s_hist.as<int>();
-    a.colpre = a.hist + 256 * (size_t)nblk_c;
-    a.dtot = ps->s_scan2.as<int>();
-    a.blocksum = a.dtot + 256;
-    a.no_skip = getenv("PP_NO_RS_SKIP") != nullptr;
-    a.et = et;
-    a.nchunks = nchunks;
-    a.C = C_new;
-    a.V = ps->V;
-    a.TP = ps->tile_p;
-    a.pad_strat = ps->pad_strat;
-    a.pad = ps->shuffle_padding;
-    a.widths = L.widths;
-    a.slice_off = L.slice_off;
-    a.chunk_start = L.chunk_start;
-    a.tile_off = L.tile_off;
-    a.ntiles_out = ps->s_scan.as<int>();
-    a.sp = sp;
-    a.do_tables = (tables && sp.on) ? 1 : 0;
-    if (a.do_tables) {
-      a.ta = *tables;
-      a.ta.tile_off = L.tile_off;
-      a.ta.widths = L.widths;
-      a.ta.slice_off = L.slice_off;
-      a.ta.chunk_start = L.chunk_start;
-      a.ta.ntiles_dev = a.ntiles_out;
-      a.ta.tot = tot;
-    }
-    a.tot = tot;
-    k_layout_coop<<<nblk_c, 256, 0, st>>>(a);
-    L.coop = true;
-    L.tables_done = a.do_tables != 0;
-    L.index_ab[0] = a.va;
-    L.index_ab[1] = a.vb;
-    PP_LAUNCH_CHECK();
-    return PP_OK;
-  }
   if (L.sorted) {
     const int sg = std::min(ps->sigma, std::max(ne, 1));
     const int n_sigma = ne / sg;
@@ -2826,50 +2100,6 @@ int scs_reshuffle(pp_ps* ps, const int* new_element, int n_new, const int* new_e
   PP_HIP_CHECK(ps->s_ranknew.reserve(sizeof(int) * (size_t)std::max(n_new, 1)));
   PP_HIP_CHECK(hipMemsetAsync(ps->s_rs.p, 0, sizeof(int) * 5 * (size_t)std::max(ne, 1), st));
   PP_HIP_CHECK(hipMemsetAsync(ps->s_misc.p, 0, sizeof(Totals), st));
-  // elastic mode: overflow list, per-row "who lived here" marks, the list of rows that trade places
-  const bool elastic = ps->shuffle_mode >= 2;
-  const size_t rows_cap = (size_t)ps->num_rows + 64 * 1024 + 64;  // rows the structure may reach in this rebuild
-  PP_HIP_CHECK(ps->s_rsx.reserve(sizeof(int) * (2 * (size_t)kMaxOver + rows_cap + 3 * (size_t)kMaxMoves)));
-  int* ov_list = ps->s_rsx.as<int>();
-  int* pool_list = ov_list + kMaxOver;
-  int* swap_old = pool_list + kMaxOver;
-  RsMoves mvs{swap_old + rows_cap, swap_old + rows_cap + kMaxMoves, swap_old + rows_cap + 2 * (size_t)kMaxMoves};
-  PP_HIP_CHECK(hipMemsetAsync(swap_old, 0xff, sizeof(int) * (size_t)ps->num_rows, st));
-  // room for appended pool chunks: every per-slot array must cover capacity + room_slots, the per-row /
-  // per-chunk / tile / slice tables their share
-  RsPool pl{};
-  if (elastic) {
-    long long room = (long long)ps->stride - ps->capacity;
-    room = std::min<long long>(room, (long long)ps->d_mask.bytes - ps->capacity);
-    room = std::min<long long>(room, (long long)(ps->d_slot_elem.bytes / 4) - ps->capacity);
-    room = std::min<long long>(room, (long long)(ps->s_idx.bytes / 4) - ps->capacity);
-    room = std::min<long long>(room, (long long)(ps->s_holes.bytes / 4) - ps->capacity);
-    room = std::min<long long>(room, (long long)(ps->s_aos.bytes / ((size_t)NQ * 16)) - ps->capacity);
-    pl.room_slots = (int)std::max<long long>(0, std::min<long long>(room, 1 << 28));
-    long long rows = std::min<long long>((long long)(ps->d_row_to_element.bytes / 4),
-                                         (long long)(ps->d_element_to_row.bytes / 4)) - ps->num_rows;
-    rows = std::min<long long>(rows, 64 * 1024);
-    pl.room_rows = (int)std::max<long long>(0, rows);
-    pl.room_chunks = (int)std::max<long long>(
-        0, std::min<long long>((long long)(ps->d_chunk_start.bytes / 4), (long long)(ps->d_chunk_width.bytes / 4)) -
-               ps->num_chunks);
-    pl.room_tiles = (int)std::max<long long>(0, (long long)(ps->d_tiles.bytes / 8) - ps->ntiles_max - 1);
-    pl.room_slices = (int)std::max<long long>(
-        0, std::min<long long>((long long)(ps->d_offsets.bytes / 4) - ps->num_slices - 2,
-                               (long long)(ps->d_slice_to_chunk.bytes / 4) - ps->num_slices - 1));
-    pl.sorted_chunks = std::min(ps->sorted_chunks, ps->num_chunks);
-    pl.V = ps->V;
-    pl.TP = ps->tile_p;
-    pl.offsets = ps->d_offsets.as<int>();
-    pl.s2c = ps->d_slice_to_chunk.as<int>();
-    pl.tiles = ps->d_tiles.as<int>();
-    pl.ntiles = ps->d_ntiles.as<int>();
-    pl.chunk_start_w = ps->d_chunk_start.as<int>();
-    pl.chunk_width_w = ps->d_chunk_width.as<int>();
-    pl.slot_elem = ps->d_slot_elem.as<int>();
-    pl.mask = ps->d_mask.as<unsigned char>();
-    pl.pool_list = pool_list;
-  }
   Totals* tot = ps->s_misc.as<Totals>();
   RsCounters cn{ps->s_rs.as<int>(), ps->s_rs.as<int>() + ne, ps->s_rs.as<int>() + 2 * (size_t)ne,
                 ps->s_rs.as<int>() + 3 * (size_t)ne, ps->s_rs.as<int>() + 4 * (size_t)ne};
@@ -2880,8 +2110,7 @@ int scs_reshuffle(pp_ps* ps, const int* new_element, int n_new, const int* new_e
   int* holes = ps->s_holes.as<int>();
   uint4* aos = ps->s_aos.as<uint4>();
   const int G = std::max(1, 32 / ps->tile_p);
-  const size_t tiles_bound = (size_t)ps->ntiles_max + (size_t)pl.room_tiles;
-  const unsigned grp_grid = grid_for((tiles_bound + G - 1) / G * ps->C);
+  const unsigned grp_grid = grid_for(((size_t)ps->ntiles_max + G - 1) / G * ps->C);
 #define PP_RS_TILES                                                                                  \
   ps->d_ntiles.as<int>(), ps->C, ps->tile_p, G, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(), \
       ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>()
@@ -2893,32 +2122,15 @@ int scs_reshuffle(pp_ps* ps, const int* new_element, int n_new, const int* new_e
 #undef PP_RS_CASE
   if (n_new > 0) k_rs_count_added<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ne, cn.arrive, tot, rank_new);
   k_rs_fit<<<std::min(grid_for(std::max(ne, 1)), 256u), kBlock, 0, st>>>(
-      ne, ps->C, n_old, cn, ps->d_element_to_row.as<int>(), ps->d_chunk_width.as<int>(), n_new_e, tot, ov_list,
-      elastic ? 0 : 1);
-  if (elastic) {
-    static const int probe = getenv("PP_RS_PROBE") ? atoi(getenv("PP_RS_PROBE")) : 256;
-    k_rs_match<<<1, 1024, 0, st>>>(ne, ps->C, ps->num_chunks, ps->d_chunk_width.as<int>(),
-                                   ps->d_chunk_start.as<int>(), ps->d_row_to_element.as<int>(),
-                                   ps->d_element_to_row.as<int>(), ps->d_eslot0.as<int>(), n_new_e, ov_list,
-                                   swap_old, mvs, tot, probe, ps->capacity, ps->num_slices, pl);
-  }
-  k_rs_go<<<1, 1, 0, st>>>(tot, elastic ? 1 : 0);
+      ne, ps->C, n_old, cn, ps->d_element_to_row.as<int>(), ps->d_chunk_width.as<int>(), n_new_e, tot);
+  k_rs_go<<<1, 1, 0, st>>>(tot);
   const int* go = &tot->go;
-  if (elastic) {
-#define PP_RS_CASE(N)                                                                                       \
-  case N:                                                                                                   \
-    k_rs_stage_moved<N><<<512, kBlock, 0, st>>>(ps->C, ps->d_chunk_start.as<int>(), n_old, new_element, ne, \
-                                                mvs, cn.arrive, rank, aos, wt, tot);                       \
-    break;
-    switch (NQ) { PP_RS_CASE(1) PP_RS_CASE(2) PP_RS_CASE(4) PP_RS_CASE(6) PP_RS_CASE(8) PP_RS_CASE(10) }
-#undef PP_RS_CASE
-  }
   k_rs_plan<<<grp_grid, kBlock, 0, st>>>(PP_RS_TILES, n_old, n_new_e, new_element, ne, cn, holes, rank,
-                                        ps->d_mask.as<unsigned char>(), swap_old, ps->d_slot_elem.as<int>(), go);
+                                        ps->d_mask.as<unsigned char>(), go);
 #define PP_RS_CASE(N)                                                                                     \
   case N:                                                                                                 \
     k_rs_move<N><<<grp_grid, kBlock, 0, st>>>(PP_RS_TILES, n_old, n_new_e, new_element, ne,              \
-                                              ps->d_eslot0.as<int>(), holes, rank, aos, wt, swap_old, go); \
+                                              ps->d_eslot0.as<int>(), holes, rank, aos, wt, go);          \
     break;
   switch (NQ) { PP_RS_CASE(1) PP_RS_CASE(2) PP_RS_CASE(4) PP_RS_CASE(6) PP_RS_CASE(8) PP_RS_CASE(10) }
 #undef PP_RS_CASE
@@ -2959,11 +2171,8 @@ int scs_reshuffle(pp_ps* ps, const int* new_element, int n_new, const int* new_e
   PP_HIP_CHECK(hipEventSynchronize(ev_tot));
   const Totals h = *h_pin;
   if (getenv("PP_SPEC_DEBUG"))
-    fprintf(stderr, "rebuild in place: go %d active %d nonempty %d invalid %d overflowing rows %d rows moved %d "
-                    "no home %d (need new rows %d: small %d max %d, big %d max %d; room slots %d rows %d; moves %d) "
-                    "capacity %d -> %d chunks +%d\n", h.go, h.active, h.nonempty, h.invalid, h.n_over, h.n_moved,
-            h.match_fail, h.dbg[0], h.dbg[1], h.dbg[2], h.dbg[3], h.dbg[4], h.dbg[5], h.dbg[6], h.dbg[7], ps->capacity,
-            h.capacity, h.cw_cnt);
+    fprintf(stderr, "rebuild in place: go %d active %d nonempty %d invalid %d overflowing rows %d\n", h.go, h.active,
+            h.nonempty, h.invalid, h.n_over);
   if (h.invalid) {
     pp::set_error(
         "rebuild: a particle's new element is out of range, or a new particle is marked inactive "
@@ -2975,20 +2184,11 @@ int scs_reshuffle(pp_ps* ps, const int* new_element, int n_new, const int* new_e
   ps->version = pp::next_version();
   ps->num_ptcls = h.active;
   ps->num_empty_elements = (ps->num_rows - ne) + (ne - h.nonempty);
-  if (h.capacity > ps->capacity) {  // pool chunks were appended
-    ps->capacity = h.capacity;
-    ps->num_slices = h.nslices;
-    ps->ntiles_max = std::max(ps->ntiles_max, h.cw_sum);
-    ps->num_chunks += h.cw_cnt;
-    ps->num_rows = ps->num_chunks * ps->C;
-    ps->num_empty_elements = (ps->num_rows - ne) + (ne - h.nonempty);
-  }
   if (commit) {
     ps->data[commit_x].swap(ps->data[commit_xt]);
     ps->zero_pending = lazy ? commit_xt : -1;
   }
   ++ps->n_reshuffles;
-  ps->n_rows_moved += h.n_moved;
   ps->lazy_rec = 0;  // (a commit that came in with only the origin in records: the origin is the old target now)
   return 1;
 }
@@ -3011,26 +2211,8 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     if (rc0) return rc0;
   }
   pp::Range rg("scs_rebuild");
-  // Mode 2 (elastic, opt-in) tries the in-place path first.  Mode 1 (the reference's decision)
-  // evaluates the decision on the histogram of the full path below, which costs nothing when the
-  // layout cannot be kept -- the normal case at 10^5 rows.
-  if (try_reshuffle && ps->shuffle_mode >= 2) {
-    int rc0;
-    bool scattered = false;
-    std::function<int(const int*)> once;
-    if (pre_sync)
-      once = [&](const int* c) {
-        scattered = true;
-        return pre_sync(c);
-      };
-    rc0 = scs_reshuffle(ps, new_element, n_new, new_elems, new_info, commit_x, commit_xt, once);
-    if (rc0 < 0) return rc0;
-    if (rc0 == 1) return PP_OK;
-    // the layout cannot be kept: full re-layout (the new counts were final, so scatters that already
-    // ran behind them are not repeated)
-    return scs_rebuild(ps, new_element, n_new, new_elems, new_info, commit_x, commit_xt,
-                       scattered ? std::function<int(const int*)>() : pre_sync, false, new_xt_zero);
-  }
+  // The reference's reshuffle decision (SellCSigma::setShuffling) is evaluated on the histogram of the full
+  // path below, which costs nothing when the layout cannot be kept -- the normal case at 10^5 rows.
   // histogram and totals in one allocation: one fill clears both (a fill is a ~5 us dispatch)
   const size_t tot_off = (sizeof(int) * (size_t)std::max(ne, 1) + 255) / 256 * 256;
   PP_HIP_CHECK(ps->s_ppe.reserve(tot_off + sizeof(Totals)));
@@ -3055,20 +2237,10 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   if (n_new > 0) {
     k_count_added<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ne, ppe, tot, rank_new);
   }
-  // `pre_sync` needs nothing but the histogram: it may fork here onto the side queue and run next to the
-  // ~15 launch-bound kernels of the sort and the layout (a few dozen blocks each)
-  static hipEvent_t ev_counts = nullptr;
-  // opt-in: measured no gain (c3 0.873 vs 0.871 ms): next to the layout chain the scatter kernels run at
-  // half speed, and the two cross-queue event waits leave ~35 us bubbles in the main queue
-  static const bool side_scatter = getenv("PP_SIDE_SCATTER") != nullptr;
-  if (pre_sync && side_scatter) {
-    if (!ev_counts) PP_HIP_CHECK(hipEventCreateWithFlags(&ev_counts, hipEventDisableTiming));
-    PP_HIP_CHECK(hipEventRecord(ev_counts, st));
-  }
   // 64..256 blocks: each block ends with two atomics on the same two counters (~5 ns apiece), each
   // thread strides over ne / (blocks * 256) elements
   // the reference's reshuffle decision (mode 1), on the histogram just built
-  const bool decide_keep = try_reshuffle && ps->shuffle_mode == 1 && have_old && ne > 0 && ps->elem_count_valid &&
+  const bool decide_keep = try_reshuffle && ps->shuffle_mode >= 1 && have_old && ne > 0 && ps->elem_count_valid &&
                            getenv("PP_NO_RESHUFFLE") == nullptr;
   // totals of the new population + the decision: in the sweep that makes the sort keys when the layout
   // is sorted (one launch instead of three), else their own kernels
@@ -3099,7 +2271,6 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   int nchunks = ne / ps->C_max + (ne % ps->C_max != 0), nrows = nchunks * ps->C_max;
   int C_new = ps->C_max;
   int ntiles_max = 0;
-  int sort_parity_host = 0;  // Totals::sort_parity once the host has read the totals (one-kernel layout)
   PP_HIP_CHECK(ps->s_eslot0.reserve(sizeof(int) * (size_t)std::max(ne, 1)));
   // buffers and arguments of the table fills of the new layout, for buffers sized (cap_sz, nsl_sz)
   auto make_tables = [&](int cap_sz, int nsl_sz, LayoutTablesArgs& ta) -> int {
@@ -3129,7 +2300,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     ta.widths = L.widths;
     ta.slice_off = L.slice_off;
     ta.chunk_start = L.chunk_start;
-    ta.index = L.coop ? L.index_ab[sort_parity_host] : L.index;
+    ta.index = L.index;
     ta.tiles = ps->s_newidx.as<int>();
     ta.offsets = ps->s_offsets2.as<int>();
     ta.s2c = ps->s_s2c2.as<int>();
@@ -3158,7 +2329,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     while (sq > 0 && sq % 32 != 17) --sq;
     stride_fit = sq * 64;
     cap_lim = std::min<long long>(cap_lim, stride_fit);
-    if (cap_lim > 0 && getenv("PP_DIRECT_MOVE") == nullptr) {  // staging buffer: NQ quads per slot
+    if (cap_lim > 0) {  // staging buffer: NQ quads per slot
       const void* srcs[8];
       for (int m = 0; m < ps->nmembers; ++m) srcs[m] = ps->data[m].p;
       WordTable wt_probe{};
@@ -3193,8 +2364,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     if (int rct = make_tables(cap_sz, nsl_sz, ta)) return rct;
     int* new_tiles = ps->s_newidx.as<int>();
     const int* new_ntiles = ps->s_scan.as<int>();
-    if (!(L.tables_done && stride_fixed > 0))  // (speculative tail of the one-kernel layout: filled there)
-      k_layout_tables<<<ta.b3 + grid_for(nrows), kBlock, 0, st>>>(ta);
+    k_layout_tables<<<ta.b3 + grid_for(nrows), kBlock, 0, st>>>(ta);
     k_init_slots_tiled<<<grid_for((size_t)ntiles_max * C_new), kBlock, 0, st>>>(
         new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_r2e2.as<int>(),
         ppe, ne, ps->s_slot2.as<int>(), ps->s_rowstart.as<int>(), ps->s_eslot0.as<int>(),
@@ -3206,7 +2376,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     } else if (swap_stride < cap_sz || swap_stride * ps->minimize_size < cap_sz) {
       swap_stride = (int64_t)(cap_sz * (1 + ps->extra_padding));
       if (swap_stride < cap_sz) swap_stride = cap_sz;
-      swap_stride = spread_stride(swap_stride + growth_reserve(ps, cap_sz));
+      swap_stride = spread_stride(swap_stride);
     }
     int rc2 = alloc_members(ps, ps->swap, swap_stride, false);
     if (rc2) return rc2;
@@ -3218,7 +2388,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     // record = all members (fast path needs 4/8-byte scalars, see build_word_table)
     WordTable wt{};
     NQ = 0;
-    if (have_old && old_grid > 0 && getenv("PP_DIRECT_MOVE") == nullptr) {
+    if (have_old && old_grid > 0) {
       const void* srcs[8];
       for (int m = 0; m < ps->nmembers; ++m) srcs[m] = ps->data[m].p;
       NQ = build_word_table(ps, srcs, ps->stride, swap_stride, commit_x, commit_xt, wt);
@@ -3298,17 +2468,11 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   PP_HIP_CHECK(hipMemcpyAsync(h_pin, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
   PP_HIP_CHECK(hipEventRecord(ev_tot, st));
   if (pre_sync) {
-    if (side_scatter) {
-      pp::SideScope fork(ev_counts);  // joins the main queue (behind the tail enqueued above) on exit
-      rc = pre_sync(ppe);
-    } else {
-      rc = pre_sync(ppe);
-    }
+    rc = pre_sync(ppe);
     if (rc) return rc;
   }
   PP_HIP_CHECK(hipEventSynchronize(ev_tot));  // the only host wait of a regular rebuild
   Totals h = *h_pin;
-  sort_parity_host = h.sort_parity & 1;
   if (h.invalid) {
     ps->swap_stride = swap_stride_before;
     pp::set_error(
@@ -3362,15 +2526,13 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     const bool sort_ok = L.key_bits >= 64 || (h.max_key >> L.key_bits) == 0;
     if (C_new != ps->C_max || !sort_ok) {
       PP_HIP_CHECK(hipMemsetAsync(&tot->cw_sum, 0, sizeof(int) * 2, st));
-      PP_HIP_CHECK(hipMemsetAsync(&tot->bar, 0, sizeof(unsigned) + sizeof(int), st));  // barrier counter, parity
       rc = enqueue_layout(ps, C_new, ppe, tot, key_base, L);
       if (rc) return rc;
       const int active = h.active, nonempty = h.nonempty;
       const unsigned long long max_key = h.max_key;
       PP_HIP_CHECK(hipMemcpyAsync(&h, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
       PP_HIP_CHECK(hipStreamSynchronize(st));
-      sort_parity_host = h.sort_parity & 1;
-      h.active = active;
+          h.active = active;
       h.nonempty = nonempty;
       h.max_key = std::max(h.max_key, max_key);
       nchunks = L.nchunks;
@@ -3408,7 +2570,6 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   ps->d_ntiles.swap(ps->s_scan);
   ps->d_elem_count.swap(ps->s_ppe);  // live particles per element == the histogram just built
   ps->d_eslot0.swap(ps->s_eslot0);
-  ps->sorted_chunks = nchunks;
   ps->elem_count_valid = true;
   ps->version = pp::next_version();
   ++ps->n_full_rebuilds;
@@ -3466,7 +2627,7 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     MoveArgs mv = make_move(ps, ps->data, ps->stride, ps->swap, swap_stride);
     WordTable wt{}, wt_new{};
     int NQ = 0;
-    if (getenv("PP_DIRECT_MOVE") == nullptr) {
+    {
       const void* srcs[8];
       for (int m = 0; m < ps->nmembers; ++m) srcs[m] = ps->data[m].p;
       NQ = build_word_table(ps, srcs, ps->stride, swap_stride, -1, -1, wt);
@@ -3664,14 +2825,13 @@ pp_ps* pp_ps_create_scs(int C, int sigma, int V, int num_elems, int num_ptcls,
   HostLayout L;
   host_layout(L, ps->C, V, sigma, num_elems, ppe_host, pad_strat, shuffle_padding);
   ps->num_chunks = L.nchunks;
-  ps->sorted_chunks = L.nchunks;
   ps->num_rows = L.nchunks * L.C;
   ps->num_slices = L.nslices;
   ps->capacity = L.capacity;
   ps->num_empty_elements = L.num_empty;
   int64_t cap = L.capacity;
   if (extra_padding > 0) cap = (int64_t)(int)(L.capacity * (1 + extra_padding));
-  ps->stride = spread_stride(std::max<int64_t>(cap, 1) + growth_reserve(ps, L.capacity));
+  ps->stride = spread_stride(std::max<int64_t>(cap, 1));
   ps->swap_stride = ps->stride;  // the reference allocates an equal-sized swap at construction
   bool ok = alloc_members(ps, ps->data, ps->stride, true) == PP_OK;
   std::vector<int> ppe(ppe_host, ppe_host + num_elems);
@@ -3814,7 +2974,7 @@ int pp_ps_swap_members(pp_ps* ps, int a, int b) {
 }
 
 int pp_ps_set_shuffling(pp_ps* ps, int mode) {
-  PP_REQUIRE(ps && mode >= 0 && mode <= 2, "pp_ps_set_shuffling: mode must be 0, 1 or 2");
+  PP_REQUIRE(ps && (mode == 0 || mode == 1), "pp_ps_set_shuffling: mode must be 0 or 1");
   ps->shuffle_mode = mode;
   return PP_OK;
 }
@@ -3822,7 +2982,7 @@ int pp_ps_rebuild_stats(const pp_ps* ps, long long* n_in_place, long long* n_ful
   PP_REQUIRE(ps, "pp_ps_rebuild_stats: null ps");
   if (n_in_place) *n_in_place = ps->n_reshuffles;
   if (n_full) *n_full = ps->n_full_rebuilds;
-  if (n_rows_moved) *n_rows_moved = ps->n_rows_moved;
+  if (n_rows_moved) *n_rows_moved = 0;  // (rows never trade places: the experimental elastic mode of round 2 is gone)
   return PP_OK;
 }
 

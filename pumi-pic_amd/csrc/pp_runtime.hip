@@ -37,9 +37,6 @@ void range_pop() {
 
 static thread_local std::string g_err;
 static hipStream_t g_stream = nullptr;
-static hipStream_t g_side = nullptr;      // second queue: work that overlaps a launch-bound stretch of the main one
-static hipStream_t g_override = nullptr;  // SideScope: stream() answers with the side queue
-static hipEvent_t g_side_ev[2] = {nullptr, nullptr};
 static bool g_init = false;
 
 unsigned long long next_version() {
@@ -47,26 +44,7 @@ unsigned long long next_version() {
   return ++v;
 }
 void set_error(const std::string& msg) { g_err = msg; }
-hipStream_t stream() { return g_override ? g_override : g_stream; }
-// Fork: everything enqueued through pp::stream() while the scope lives goes to the side queue, ordered
-// behind what the main queue holds at `fork_ev` (recorded by the caller on the main stream, or null =
-// now).  The destructor joins: the main queue waits for the side work at the point it has reached.
-SideScope::SideScope(void* fork_ev) {
-  if (!g_side || g_override) return;  // (nested scopes stay on the outer one)
-  hipEvent_t ev = (hipEvent_t)fork_ev;
-  if (!ev) {
-    ev = g_side_ev[0];
-    if (hipEventRecord(ev, g_stream) != hipSuccess) return;
-  }
-  if (hipStreamWaitEvent(g_side, ev, 0) != hipSuccess) return;
-  g_override = g_side;
-  active = true;
-}
-SideScope::~SideScope() {
-  if (!active) return;
-  g_override = nullptr;
-  if (hipEventRecord(g_side_ev[1], g_side) == hipSuccess) (void)hipStreamWaitEvent(g_stream, g_side_ev[1], 0);
-}
+hipStream_t stream() { return g_stream; }
 bool initialised() { return g_init; }
 }  // namespace pp
 
@@ -91,10 +69,6 @@ int pp_init(int device) {
   PP_REQUIRE(device >= 0 && device < n, "pp_init: device index out of range");
   PP_HIP_CHECK(hipSetDevice(device));
   if (!pp::g_stream) PP_HIP_CHECK(hipStreamCreateWithFlags(&pp::g_stream, hipStreamNonBlocking));
-  if (!pp::g_side) {
-    PP_HIP_CHECK(hipStreamCreateWithFlags(&pp::g_side, hipStreamNonBlocking));
-    for (int k = 0; k < 2; ++k) PP_HIP_CHECK(hipEventCreateWithFlags(&pp::g_side_ev[k], hipEventDisableTiming));
-  }
   pp::g_init = true;
   return PP_OK;
 }

@@ -1074,7 +1074,6 @@ __global__ void __launch_bounds__(256, OCC)
     e = r2e[c * C + r];
   }
   const ppm::ClassTerm ct = ppm::class_term((valid && e < nelems) ? class_id[e] : 1, deg, DIM == 3);
-  const bool read_ids = (DIM == 2) || seeded;
   RecCache<DIM> cache;
   cache.id = -1;
   // thin tiles (at most 64/TP live rows): lane l takes (live row l/TP, column l%TP) and the tile
@@ -1230,7 +1229,7 @@ struct WalkArgs {
   int* elem_ids;
   int seeded, nelems, cap;
   Counters* cnt;
-  int abl;
+  int trust;  // pp_ps_set_origin_trust: check_initial_parents is skipped
   unsigned* id_out;  // record-fed form: SoA arrays of the third member and of b (null otherwise)
   float* b_out;
 };
@@ -1251,26 +1250,15 @@ __device__ __forceinline__ bool column_math(const WalkArgs& A, const PState& s, 
   bool done = false;
   bool origin_ok = true;
   if constexpr (DIM == 2) {
-    if (A.abl & 2) {
-      dest.x = s.phi + 1.0;
-      dest.y = s.b;
-      rad = s.phi;
-    } else {
-      ppm::elliptical_point(ct, s.phi, s.b, A.h, A.k, A.d, dest.x, dest.y, rad);
-    }
+    ppm::elliptical_point(ct, s.phi, s.b, A.h, A.k, A.d, dest.x, dest.y, rad);
     stg<NT>(A.xt + pid, dest.x);
     stg<NT>(A.xt + A.stride + pid, dest.y);
     if (elem == -1) done = true;  // hpp:1051-1056 (seed == -nelems)
   } else {
     // parent check first (a pure function of the origin): the origin's registers die with the push
-    // abl bit 8 = the caller vouches for the origins (pp_ps_set_origin_trust): the test would pass
-    origin_ok = (elem == -1) || (A.abl & 8) || inside_cached(cache, V3{s.x, s.y, s.z}, A.tol);
-    if (A.abl & 2) {
-      dest = V3{s.x + 1e-3 * s.b, s.y, s.z};
-      rad = s.phi;
-    } else {
-      ppm::toroidal_point(ct, s.phi, s.b, s.x, s.y, A.h, A.k, A.d, dest.x, dest.y, dest.z, rad);
-    }
+    // trust: the caller vouches for the origins (pp_ps_set_origin_trust) -- the test would pass
+    origin_ok = (elem == -1) || A.trust || inside_cached(cache, V3{s.x, s.y, s.z}, A.tol);
+    ppm::toroidal_point(ct, s.phi, s.b, s.x, s.y, A.h, A.k, A.d, dest.x, dest.y, dest.z, rad);
     stg<NT>(A.xt + pid, dest.x);
     stg<NT>(A.xt + A.stride + pid, dest.y);
     stg<NT>(A.xt + 2 * A.stride + pid, dest.z);
@@ -1278,11 +1266,10 @@ __device__ __forceinline__ bool column_math(const WalkArgs& A, const PState& s, 
     // finishUnmoved: norm(dest-orig) < tol  <=>  |dest-orig|^2 < unmoved_sq (k_push_walk_rows)
     const V3 dv = sub(dest, V3{s.x, s.y, s.z});
     if (dot(dv, dv) < A.unmoved_sq) {
-      if (!done && (A.abl & 8)) atomicAdd(&A.cnt->unmoved, 1);  // (never seen in the pseudoXGCm flows)
+      if (!done && A.trust) atomicAdd(&A.cnt->unmoved, 1);  // (never seen in the pseudoXGCm flows)
       done = true;
     }
   }
-  if (A.abl & 1) done = true;
   stg<NT>(A.pphi + pid, (float)rad);
   if (!done && !origin_ok) {  // check_initial_parents (tpp:72-145)
     atomicAdd(&A.cnt->not_in_elem, 1);
@@ -1406,7 +1393,7 @@ __global__ void __launch_bounds__(256, OCC)
                       double* xt, long long stride, const float* __restrict__ pb, float* pphi,
                       double h, double k, double d, double deg, double tol, double unmoved_sq,
                       int* elem_ids, int seeded, int looplimit, Counters* cnt, PendEntry* gq,
-                      int* wave_cnt, Counters* cnt_next, int fuse, int abl, RecIn rin = RecIn{}) {
+                      int* wave_cnt, Counters* cnt_next, int trust, RecIn rin = RecIn{}) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *cnt_next = Counters{};  // for the next pp_push_search
   constexpr int NP = DIM == 3 ? 8 : 4;
   extern __shared__ double2 lds_dyn[];
@@ -1415,16 +1402,10 @@ __global__ void __launch_bounds__(256, OCC)
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   int qn = 0;  // wave-uniform number of queue entries written by this wave
 
-  // blockIdx is dealt round-robin over the 8 XCDs.  Giving every XCD a contiguous range of tiles
-  // (abl bit 16) keeps a chunk's records in one L2 but was measured at +2% on an even population
-  // and -20% on a skewed one (the over-full element's thin tiles all land on two XCDs), so the
-  // default keeps the hardware order.
-  unsigned lb = blockIdx.x;
-  if (abl & 16) {
-    const unsigned nb = gridDim.x, xq = nb >> 3, xr = nb & 7, xcd = blockIdx.x & 7;
-    lb = xcd * xq + min(xcd, xr) + (blockIdx.x >> 3);
-  }
-  const long long g = (long long)lb * blockDim.x + threadIdx.x;
+  // (blockIdx is dealt round-robin over the 8 XCDs.  Giving every XCD a contiguous range of tiles keeps a
+  // chunk's records in one L2 but was measured at +2 % on an even population and -20 % on a skewed one --
+  // the over-full element's thin tiles all land on two XCDs -- so the hardware order stays.)
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long gwave = g >> 6;
   PendEntry* wq = gq + gwave * 64 * TP;  // this wave's queue region (64*TP entries worst case)
   const int tile = (int)(g / C);
@@ -1454,7 +1435,7 @@ __global__ void __launch_bounds__(256, OCC)
   A.nelems = nelems;
   A.cap = looplimit ? looplimit : kHardLoopCap;
   A.cnt = cnt;
-  A.abl = abl;
+  A.trust = trust;
   A.id_out = RECIN ? rin.id_out : nullptr;
   A.b_out = RECIN ? rin.b_out : nullptr;
   RecCache<DIM> cache;
@@ -1470,7 +1451,7 @@ __global__ void __launch_bounds__(256, OCC)
     const bool alive0 = valid && p0 < pend && mask[start + p0 * C] != 0;
     const unsigned long long live0 = __ballot(alive0);
     const int nlive = __popcll(live0);
-    if (nlive * TP <= 64 && !(abl & 64)) {
+    if (nlive * TP <= 64) {
       if ((DIM == 2 || !seeded) && valid && !alive0)  // empty rows: the slots still read -1
         for (int p = p0; p < pend; ++p) stg<NT>(elem_ids + start + p * C, -1);
       const int krow = lane / TP, col = lane - krow * TP;
@@ -1498,7 +1479,7 @@ __global__ void __launch_bounds__(256, OCC)
       }
       const bool live = act && s.m;
       int elem = live ? seed_of<DIM>(s, t_e, seeded, nelems) : -1;
-      const int want = (elem >= 0 && !(abl & 1)) ? elem : -1;
+      const int want = elem >= 0 ? elem : -1;
       if (__ballot(want >= 0) != 0ull) coop_fetch<DIM>(cache, recs, want, st, lane);
       V3 dest{0, 0, 0};
       const bool need = column_math<DIM, NT>(A, s, act, live, pid, tct, cache, elem, dest);
@@ -1533,7 +1514,7 @@ __global__ void __launch_bounds__(256, OCC)
     const bool live = act && s.m;
     // seed element of this column (known before the push; `done` cases just fetch in vain)
     int elem = live ? seed_of<DIM>(s, e, seeded, nelems) : -1;
-    const int want = (elem >= 0 && elem != cache.id && !(abl & 1)) ? elem : -1;
+    const int want = (elem >= 0 && elem != cache.id) ? elem : -1;
     coop_collect<DIM>(cache, want >= 0 && want == pre, want, st, lane);
     wave_lds_sync();
     const int miss = (want >= 0 && want != pre) ? want : -1;  // not prefetched (first column, ...)
@@ -1543,7 +1524,7 @@ __global__ void __launch_bounds__(256, OCC)
     if (act && p + 1 < pend) {
       int seed1 = read_ids ? e1 : e;
       if (DIM == 2 && seed1 == -1) seed1 = e;
-      if (seed1 >= 0 && seed1 < nelems && seed1 != cache.id && !(abl & 1)) pre = seed1;
+      if (seed1 >= 0 && seed1 < nelems && seed1 != cache.id) pre = seed1;
     }
     if (__ballot(pre >= 0) != 0ull) coop_issue<DIM>(recs, pre, st, lane);
     if (act && p + 1 < pend) {
@@ -1559,20 +1540,6 @@ __global__ void __launch_bounds__(256, OCC)
     enqueue(need, pid, elem, dest, wq, qn, lt_mask);
   }
   if (lane == 0) wave_cnt[gwave] = qn;
-  if (!fuse) return;
-  // ---- fused second pass: the block's four waves produced four consecutive queue regions; after
-  // a barrier the first wave walks them with lane refill while the other three retire.  No second
-  // launch, and the walk overlaps the column loops of the other blocks on the CU.
-  __shared__ int s_qn[4];
-  if (lane == 0) s_qn[threadIdx.x >> 6] = qn;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // queue entries visible to the block
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  if ((threadIdx.x >> 6) == 0) {
-    const int my_cnt = lane < 4 ? s_qn[lane] : 0;
-    walk_pending<DIM>(gq + (long long)lb * 4 * 64 * TP, 64ll * TP, 4, my_cnt, recs, elem_ids, A.cap, cnt,
-                      st, lane);
-  }
 }
 
 // Second pass of the deferred walk.  Walk lengths are long-tailed (a crossing in a tet mesh takes
@@ -1581,7 +1548,7 @@ __global__ void __launch_bounds__(256, OCC)
 // as they finish: a wave-uniform cursor (region, offset) hands the next unprocessed entries to
 // the free lanes, so every round's cooperative fetch + step runs with (nearly) all lanes busy.
 constexpr int kPendRegions = 4;
-// stand-alone second pass (PP_FUSE_PENDING=0): wave w owns G consecutive regions
+// second pass: wave w owns G consecutive regions
 template <int DIM>
 __global__ void __launch_bounds__(256, 4)
     k_walk_pending(int nwaves, int TP, int G, const PendEntry* __restrict__ gq,
@@ -1945,10 +1912,9 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
     ps->zero_pending = -1;
   // Record-fed push: the last full re-layout left the particles in its staging records (pp_ps::lazy_rec)
   // and this call can read them there -- the pass that would copy them to the SoA arrays first is skipped.
-  static const bool force_flat = getenv("PP_FLAT_WALK") != nullptr;  // A/B measurement knob
   const int wq_env = getenv("PP_WALK_QUEUE") ? atoi(getenv("PP_WALK_QUEUE")) : -1;  // per call
   const int wq = wq_env >= 0 ? wq_env : (mesh->dim == 3 ? 1 : 0);
-  const bool recin = ((mesh->dim == 3 && wq > 0) || (mesh->dim == 2 && wq == 0 && elem_ids_seeded)) && !force_flat &&
+  const bool recin = ((mesh->dim == 3 && wq > 0) || (mesh->dim == 2 && wq == 0 && elem_ids_seeded)) &&
                      ps->capacity > 0 && ps->num_ptcls > 0 && ps->ntiles_max > 0 &&
                      pp::lazy_push_ok(ps, m_x, m_xtgt, m_b, m_phi);
   int zero_z = 0;
@@ -1978,7 +1944,7 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
   if (mesh->dim == 2)
     PP_REQUIRE(elem_ids_seeded, "pp_push_search (2-D): elem_ids must be initialised (-1 = own element)");
   Counters* used = nullptr;  // the counter set this call's kernels add to
-  if (ps->kind == PP_SCS && !force_flat) {
+  if (ps->kind == PP_SCS) {
     const unsigned rgrid = grid_for((size_t)ps->ntiles_max * ps->C);
 #define PP_ROWS_ARGS                                                                             \
   ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(), \
@@ -1994,13 +1960,9 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
       mesh->nelems, PP_MEMBER(ps, m_x, double), PP_MEMBER(ps, m_xtgt, double), ps->stride,       \
       PP_MEMBER(ps, m_b, float), PP_MEMBER(ps, m_phi, float), h, k, d, deg, mesh->tol,           \
       mesh->unmoved_sq, elem_ids_dev, elem_ids_seeded, looplimit, used,                          \
-      g_pending_q.as<PendEntry>(), g_wave_cnt.as<int>(), g_cnt2 + (g_cnt2_cur ^ 1), fuse, abl
-    // OCC = minimum waves per SIMD the register allocator must leave room for (tuning knob;
-    // measured in profiles/): 3-D defaults to 4 (104 VGPRs, no spill)
-    // OCC = waves per SIMD the register allocator must leave room for.  Measured on MI355X
-    // (profiles/r01_*): 3-D is fastest at 4 (127 VGPRs, no spill); a 96-register build for 5 waves
-    // spills and runs 2x slower, 3 hides less latency.
-    static const int occ = getenv("PP_WALK_OCC") ? atoi(getenv("PP_WALK_OCC")) : 4;
+      g_pending_q.as<PendEntry>(), g_wave_cnt.as<int>(), g_cnt2 + (g_cnt2_cur ^ 1), trust
+    // (kernels are built for 4 waves per SIMD: measured fastest on MI355X -- 3-D needs 126 VGPRs, a
+    // 96-register build for 5 waves spills and runs 2x slower, 3 waves hide less latency)
     // Two row-tiled variants (measured on MI355X, profiles/r01_c_*):
     //   k_push_walk_rows   walks every particle to completion inside the column loop;
     //   k_push_walk_rowsq  one step in the loop, cooperative LDS-DMA record fetch pipelined one
@@ -2008,8 +1970,7 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
     // 3-D (128-B records, 8% of the particles cross per step, walks of 1..8 tets) is 8-30%
     // faster with the deferred walk; 2-D (64-B records, cheap steps) is faster in one kernel.
     // PP_WALK_QUEUE=0/1 forces one or the other (A/B knob).
-    static const int abl_env = getenv("PP_ABL") ? atoi(getenv("PP_ABL")) : 0;  // timing ablations only
-    const int abl = abl_env | (ps->trust_origins ? 8 : 0);
+    const int trust = ps->trust_origins ? 1 : 0;
     if (!(rgrid > 0 && wq > 0)) {
       if ((rc = reset_counters())) return rc;
       used = g_cnt.get();
@@ -2017,35 +1978,23 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
       if ((rc = pair_counters())) return rc;
       used = g_cnt2 + g_cnt2_cur;
     }
-    // PP_FUSE_PENDING=1 runs the second pass at the tail of the column-loop kernel (first wave of
-    // every block, after a barrier).  Measured slower (c2 0.293 -> 0.315 ms, c3 walk 0.218 -> 0.247):
-    // the lingering wave pins its block's LDS and wave slots, which costs more than the saved launch.
-    static const int fuse = getenv("PP_FUSE_PENDING") ? atoi(getenv("PP_FUSE_PENDING")) : 0;
     if (rgrid > 0 && wq > 0) {
       const size_t lds = (size_t)(kBlock / 64) * 64 * (mesh->dim == 3 ? 8 : 4) * sizeof(double2);
       const size_t nwaves = (size_t)rgrid * (kBlock / 64);
       PP_HIP_CHECK(g_pending_q.reserve(nwaves * 64 * ps->tile_p * sizeof(PendEntry)));
       PP_HIP_CHECK(g_wave_cnt.reserve(nwaves * sizeof(int)));
-      static const bool nt = getenv("PP_NT") ? atoi(getenv("PP_NT")) != 0 : true;  // A/B knob
       if (mesh->dim == 2) {
-        if (nt)
-          k_push_walk_rowsq<2, 4, true><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
-        else
-          k_push_walk_rowsq<2, 4, false><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
+        k_push_walk_rowsq<2, 4, true><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
       } else if (recin) {
         const RecIn rin{ps->s_aos_live.as<char>(), (unsigned*)ps->data[2].p, (float*)ps->data[3].p, 0};
         k_push_walk_rowsq<3, 4, true, true><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS, rin);
         ps->lazy_rec = 2;  // every member but the origin is in the SoA arrays now
-      } else if (occ <= 3) {
-        k_push_walk_rowsq<3, 3, false><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
-      } else if (nt) {
-        k_push_walk_rowsq<3, 4, true><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
       } else {
-        k_push_walk_rowsq<3, 4, false><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
+        k_push_walk_rowsq<3, 4, true><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
       }
       PP_LAUNCH_CHECK();
-      if (!fuse) {
-        static const int G = getenv("PP_PEND_REGIONS") ? std::max(1, std::min(64, atoi(getenv("PP_PEND_REGIONS")))) : kPendRegions;
+      {  // second pass: a wave owns kPendRegions consecutive queue regions and refills its lanes
+        constexpr int G = kPendRegions;
         const unsigned pgrid = (rgrid + G - 1) / G;
         if (mesh->dim == 2)
           k_walk_pending<2><<<pgrid, kBlock, 0, st>>>((int)nwaves, ps->tile_p, G, g_pending_q.as<PendEntry>(),
@@ -2064,12 +2013,8 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
         ps->lazy_rec = 2;
       } else if (mesh->dim == 2)
         k_push_walk_rows<2, 4><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS);
-      else if (occ <= 3)
-        k_push_walk_rows<3, 3><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS);
-      else if (occ == 4)
-        k_push_walk_rows<3, 4><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS);
       else
-        k_push_walk_rows<3, 5><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS);
+        k_push_walk_rows<3, 4><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS);
     }
 #undef PP_ROWS_ARGS
 #undef PP_ROWSQ_ARGS

@@ -1455,72 +1455,6 @@ def test_rebuild_speculative_and_checked_paths_alternate(ppo, synth, capi, shuff
         step(0.2, 0)
 
 
-@pytest.mark.parametrize("C,pad_strat,shuffle_padding", [(64, 0, 0.1), (8, 0, 0.5), (32, 0, 0.3)])
-def test_elastic_rebuild_keeps_a_valid_layout(ppo, synth, capi, C, pad_strat, shuffle_padding):
-    """pp_ps_set_shuffling mode 2 (experimental): rows that overflow their padding trade places with rows
-    of wider chunks or move into appended chunks instead of forcing the full re-layout.  After every rebuild the structure is a valid
-    SCS (bijection rows <-> elements, prefix-compact rows, slot parents) and holds, element by element,
-    the same particles with the same member values as the oracle; offsets / slices / capacity are
-    untouched by a rebuild that kept the layout."""
-    pop = common.population_2d(synth, n_b=16, n_theta=64, num_ptcls=40000, mdl_face=4, band_width=4)
-    ne = len(pop["e2v"])
-    po = ppo.PS.scs(ppo.PARTICLE_XGCM, ne, pop["ppe"], C_max=C, pad_strat=pad_strat, shuffle_padding=shuffle_padding,
-                    particle_elements=pop["elem"], particle_info=pop["info"])
-    pg = capi.PS.scs(capi.PARTICLE_XGCM, ne, pop["ppe"], C_=C, pad_strat=pad_strat, shuffle_padding=shuffle_padding,
-                     particle_elements=pop["elem"], particle_info=pop["info"])
-    pg.set_try_shuffling(2)
-    rng = np.random.default_rng(5)
-    nid = 40000
-    kept = traded = 0
-    for it in range(10):
-        dec = rng.integers(0, ne, size=nid).astype(np.int32)
-        mv = rng.random(nid) < (0.08 if it != 6 else 0.6)
-        dl = rng.random(nid) < 0.01
-        outs = []
-        for ps_ in (po, pg):
-            se, mk = ps_.slot_info()
-            ids = ps_.member(2)[0, :ps_.capacity()]
-            new = np.full(len(se), -1, dtype=np.int32)
-            live = mk.astype(bool)
-            i = ids[live]
-            e = np.where(mv[i], dec[i], se[live])
-            new[live] = np.where(dl[i], -1, e)
-            outs.append(new)
-        n_new = 50 if it % 3 == 1 else 0
-        add_e = rng.integers(0, ne, size=n_new).astype(np.int32)
-        add = None
-        if n_new:
-            add = [rng.random((3, n_new)), rng.random((3, n_new)), np.arange(nid, nid + n_new, dtype=np.int32),
-                   rng.random(n_new).astype(np.float32), rng.random(n_new).astype(np.float32)]
-            nid += n_new
-        before = pg.layout()
-        st0 = pg.rebuild_stats()
-        commit = it % 2 == 0 and n_new == 0
-        if commit:
-            ppo.update_positions(po)
-        po.rebuild(outs[0], add_e if n_new else None, add)
-        if commit:
-            pg.rebuild_commit(outs[1])
-        else:
-            pg.rebuild(outs[1], add_e if n_new else None, add)
-        capi.sync()
-        st1 = pg.rebuild_stats()
-        assert po.nPtcls() == pg.nPtcls()
-        _check_same_population(po, pg, ppo.PARTICLE_XGCM)
-        after = common.check_scs_valid(pg, ne)
-        if st1[0] > st0[0]:  # kept the layout: rows traded places, chunks may have been appended
-            kept += 1
-            assert before["C"] == after["C"]
-            ns, nr = before["num_slices"], before["num_rows"]
-            assert after["num_chunks"] >= before["num_chunks"] and after["capacity"] >= before["capacity"]
-            assert np.array_equal(before["offsets"][:ns + 1], after["offsets"][:ns + 1])
-            assert np.array_equal(before["slice_to_chunk"], after["slice_to_chunk"][:ns])
-            moved = st1[2] - st0[2]
-            traded += moved
-            assert int((before["row_to_element"] != after["row_to_element"][:nr]).sum()) <= moved
-    assert kept >= 5 and traded > 0, (kept, traded)
-
-
 @pytest.mark.parametrize("dim,kind", [(2, "scs"), (3, "scs"), (2, "csr")])
 def test_gyro_scatter_per_particle_radius(ppo, synth, capi, dim, kind):
     """pp_gyro_scatter_radius: the reference's TODO radius (gyroScatter.hpp:184) per particle + a weight.

@@ -60,10 +60,9 @@ def main(seconds=60.0, seed=0):
             pg = capi.PS.scs(capi.PARTICLE_XGCM, ne, ppe, C_=C, sigma=sigma, V=V, pad_strat=pad,
                              particle_elements=elems, particle_info=info)
             shuffle = bool(rng.random() < 0.6)  # SellCSigma::setShuffling on both sides
-            elastic = shuffle and rng.random() < 0.3  # mode 2 on the GPU side: populations only
             po.set_try_shuffling(shuffle)
-            pg.set_try_shuffling(2 if elastic else shuffle)
-            desc = "scs C=%d V=%d sigma=%d pad=%d shuffle=%d elastic=%d" % (C, V, sigma, pad, shuffle, elastic)
+            pg.set_try_shuffling(shuffle)
+            desc = "scs C=%d V=%d sigma=%d pad=%d shuffle=%d" % (C, V, sigma, pad, shuffle)
         else:
             po = ppo.PS.csr(members, ne, ppe, particle_elements=elems, particle_info=info)
             pg = capi.PS.csr(capi.PARTICLE_XGCM, ne, ppe, particle_elements=elems, particle_info=info)
@@ -122,17 +121,6 @@ def main(seconds=60.0, seed=0):
             if po.nPtcls() == 0 and pg.nPtcls() == 0:
                 ok = True  # the reference leaves a stale mask behind an emptying rebuild; the library clears it
             in_place = False
-            if kind == "scs" and elastic:
-                inplace_total += pg.rebuild_stats()[0] > before[0]
-                try:
-                    common.check_scs_valid(pg, ne)
-                except AssertionError as e_:
-                    print("elastic layout invalid:", e_)
-                    ok = False
-                if not ok:
-                    print("MISMATCH (elastic) round %d step %d: %s ne=%d np=%d" % (rounds, it, desc, ne, npt))
-                    return 1
-                continue
             if kind == "scs":  # same reshuffle-or-rebuild decision on both sides
                 in_place = pg.rebuild_stats()[0] > before[0]
                 inplace_total += in_place
