@@ -78,6 +78,8 @@ pp_mesh* pp_mesh_create(int dim, int nverts, const double* coords_host, int nele
                         const int* elem2verts_host, const int* class_id_host);
 int pp_mesh_destroy(pp_mesh* m);
 int pp_mesh_info(const pp_mesh* m, int* dim, int* nverts, int* nelems, int* nsides);
+/* number of edges (Omega_h Mesh::nedges()): the sides of a triangle mesh, the derived edges of a tet mesh */
+int pp_mesh_num_edges(const pp_mesh* m);
 /* compute_tolerance_from_area, adjacency.tpp:418-428 */
 double pp_mesh_tolerance(const pp_mesh* m);
 enum {
@@ -94,7 +96,13 @@ enum {
   PP_MESH_DUAL_ELEMS = 10, /* int */
   PP_MESH_VERT2ELEMS_OFF = 11, /* int nverts+1 */
   PP_MESH_VERT2ELEMS = 12, /* int */
-  PP_MESH_ELEM_RECORDS = 13 /* packed per-element walk records (DESIGN.md "data layout") */
+  PP_MESH_ELEM_RECORDS = 13, /* packed per-element walk records (DESIGN.md "data layout") */
+  /* edges of a TET mesh (entity dimension 1; Omega_h ask_down(3,1) / ask_up(1,3)), derived on first use,
+   * local order (0,1),(1,2),(2,0),(0,3),(1,3),(2,3), numbered as first seen like the sides */
+  PP_MESH_ELEM2EDGES = 14,     /* int nelems*6 */
+  PP_MESH_EDGE2VERTS = 15,     /* int nedges*2 */
+  PP_MESH_EDGE2ELEMS_OFF = 16, /* int nedges+1 */
+  PP_MESH_EDGE2ELEMS = 17      /* int */
 };
 /* device pointer + item count of a mesh array (for user kernels written against the C++ mirror) */
 const void* pp_mesh_array_dev(const pp_mesh* m, int which, size_t* count);

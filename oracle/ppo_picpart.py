@@ -21,9 +21,9 @@ Two places where the reference leaves the result open, and what is fixed here (a
     doesn't need to be consistent" (pumipic_comm.cpp:66-76): here in increasing picpart entity id;
   * the owner adds the fan-in contributions in arrival order (MPI_Waitany, :311-318): here in increasing
     rank, the owner's own value first.
-Entity dimensions: 0 (vertices), dim-1 (sides: edges of a triangle mesh, faces of a tet mesh) and dim
-(elements); the meshes of this repo number no edges of tets.  A part's vertices and elements are the kept
-ones in full-mesh order, as in the reference (:181-194).  Its SIDES are numbered by the part's own mesh
+Entity dimensions: every one from 0 (vertices) to dim (elements) -- sides (dim-1) and, for tets, edges (1) --
+as the reference loops them.  A part's vertices and elements are the kept
+ones in full-mesh order, as in the reference (:181-194).  Its SIDES and EDGES are numbered by the part's own mesh
 (the mesh derives them from its elements -- `Mesh(part arrays)` here, pp_mesh_create in the library), not
 in full-mesh order as Omega_h's set_ents would leave them; `full_ids[dim-1]` maps them.  Everything that
 travels between ranks (global ids, the order inside a partially held part) is defined on full-mesh ids,
@@ -125,6 +125,30 @@ def input_safe_and_buffer(up_off, up, owner, rank, comm_size, buffer_method, saf
     return is_safe, has_part, buffer_method == FULL
 
 
+TET_EDGE_VERTS = np.array([[0, 1], [1, 2], [2, 0], [0, 3], [1, 3], [2, 3]])  # Omega_h simplex_down_template(3, 1)
+
+
+def tet_edges(elem2verts):
+    """edges of a tet mesh -- what the reference asks Omega_h for (ask_down(3, 1), ask_up(1, 3)): numbered in
+    first-seen order over (element, local edge), the vertex pair kept in the orientation first seen.
+    Returns (edge2verts [n,2], elem2edges [ne,6], up_off [n+1], up)."""
+    e2v = np.asarray(elem2verts, dtype=np.int64).reshape(-1, 4)
+    ne = len(e2v)
+    pairs = e2v[:, TET_EDGE_VERTS].reshape(-1, 2)
+    key = np.minimum(pairs[:, 0], pairs[:, 1]) * (int(e2v.max()) + 1 if ne else 1) + np.maximum(pairs[:, 0], pairs[:, 1])
+    uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind="stable")          # unique keys in the order they are first met
+    new_id = np.empty(len(uniq), dtype=np.int64)
+    new_id[order] = np.arange(len(uniq))
+    elem2edges = new_id[inv].reshape(ne, 6).astype(np.int32)
+    edge2verts = pairs[first[order]].astype(np.int32)
+    flat = elem2edges.ravel()
+    cnt = np.bincount(flat, minlength=len(uniq))
+    up_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    up = (np.argsort(flat, kind="stable") // 6).astype(np.int32)  # elements around every edge, ascending
+    return edge2verts, elem2edges, up_off, up
+
+
 class Part:
     """one rank's PICpart (constructPICPart :120-275 + setupComm)"""
 
@@ -161,9 +185,17 @@ class PicParts:
         else:
             raise ValueError("bridge_dim must be 0 or dim-1")
         # ---- ownership and global numbering of the full mesh (constructPICPart :141-163)
-        self.owner = {0: define_owners(mesh.vert2elems_off, mesh.vert2elems, owner, comm_size), dim: owner,
-                      dim - 1: define_owners(mesh.side2elems_off, mesh.side2elems, owner, comm_size)}
-        self.dims = (0, dim - 1, dim)
+        # entities between the vertices and the elements: the sides, and for tets the edges as well (the
+        # reference numbers every dimension 0..dim, pumipic_part_construct.cpp:141-163)
+        mid = {dim - 1: (np.asarray(mesh.side2verts).reshape(-1, dim), mesh.side2elems_off, mesh.side2elems)}
+        if dim == 3:
+            ev, self.elem2edges, eoff, eup = tet_edges(mesh.elem2verts)
+            mid[1] = (ev, eoff, eup)
+        self.mid = mid
+        self.owner = {0: define_owners(mesh.vert2elems_off, mesh.vert2elems, owner, comm_size), dim: owner}
+        for d, (_, ent_off, ent_up) in mid.items():
+            self.owner[d] = define_owners(ent_off, ent_up, owner, comm_size)
+        self.dims = tuple(sorted(self.owner))
         self.offsets, self.gids, self.rank_lids = {}, {}, {}
         for d in self.dims:
             self.offsets[d], self.gids[d] = create_global_numbering(self.owner[d], comm_size)
@@ -190,18 +222,22 @@ class PicParts:
             p.elem2verts = p.ent_ids[0][mesh.elem2verts[p.full_ids[dim]]]
             p.class_id = mesh.class_id[p.full_ids[dim]]
             p.safe = p.is_safe_full[p.full_ids[dim]].astype(np.int32)
-            # sides: the part's own mesh numbers them; match part side <-> full side by their vertices
-            if p.is_full_mesh:
-                p.full_ids[dim - 1] = np.arange(mesh.nsides, dtype=np.int32)
-            else:
-                pm = make_mesh(dim, p.coords, p.elem2verts, p.class_id)
-                key = {tuple(sorted(v)): i for i, v in enumerate(mesh.side2verts.tolist())}
-                p.full_ids[dim - 1] = np.array(
-                    [key[tuple(sorted(p.full_ids[0][v].tolist()))] for v in np.asarray(pm.side2verts)], dtype=np.int32)
-                p.part_mesh = pm
-            ids = np.full(mesh.nsides, -1, dtype=np.int32)
-            ids[p.full_ids[dim - 1]] = np.arange(len(p.full_ids[dim - 1]), dtype=np.int32)
-            p.ent_ids[dim - 1] = ids
+            # sides / edges: the part's own mesh numbers them; match part entity <-> full entity by their vertices
+            if not p.is_full_mesh:
+                p.part_mesh = make_mesh(dim, p.coords, p.elem2verts, p.class_id)
+            for d, (verts_full, _, _) in mid.items():
+                nfull = len(verts_full)
+                if p.is_full_mesh:
+                    p.full_ids[d] = np.arange(nfull, dtype=np.int32)
+                else:
+                    part_verts = (np.asarray(p.part_mesh.side2verts).reshape(-1, dim) if d == dim - 1
+                                  else tet_edges(p.elem2verts)[0])
+                    key = {tuple(sorted(v)): i for i, v in enumerate(np.asarray(verts_full).tolist())}
+                    p.full_ids[d] = np.array([key[tuple(sorted(p.full_ids[0][v].tolist()))] for v in part_verts],
+                                             dtype=np.int32)
+                ids = np.full(nfull, -1, dtype=np.int32)
+                ids[p.full_ids[d]] = np.arange(len(p.full_ids[d]), dtype=np.int32)
+                p.ent_ids[d] = ids
             p.owners = {d: self.owner[d][p.full_ids[d]] for d in self.dims}
             p.gids = {d: self.gids[d][p.full_ids[d]] for d in self.dims}
             p.rank_lids = {d: self.rank_lids[d][p.full_ids[d]] for d in self.dims}

@@ -22,13 +22,15 @@ SCS, CSR = 0, 1
 
 (MESH_COORDS, MESH_ELEM2VERTS, MESH_CLASS_ID, MESH_ELEM2SIDES, MESH_SIDE2VERTS,
  MESH_SIDE2ELEMS_OFF, MESH_SIDE2ELEMS, MESH_SIDE_EXPOSED, MESH_ELEM_MEASURE, MESH_DUAL_OFF,
- MESH_DUAL_ELEMS, MESH_VERT2ELEMS_OFF, MESH_VERT2ELEMS, MESH_ELEM_RECORDS) = range(14)
+ MESH_DUAL_ELEMS, MESH_VERT2ELEMS_OFF, MESH_VERT2ELEMS, MESH_ELEM_RECORDS, MESH_ELEM2EDGES, MESH_EDGE2VERTS,
+ MESH_EDGE2ELEMS_OFF, MESH_EDGE2ELEMS) = range(18)
 _MESH_DTYPES = {MESH_COORDS: np.float64, MESH_ELEM2VERTS: np.int32, MESH_CLASS_ID: np.int32,
                 MESH_ELEM2SIDES: np.int32, MESH_SIDE2VERTS: np.int32,
                 MESH_SIDE2ELEMS_OFF: np.int32, MESH_SIDE2ELEMS: np.int32,
                 MESH_SIDE_EXPOSED: np.int8, MESH_ELEM_MEASURE: np.float64, MESH_DUAL_OFF: np.int32,
                 MESH_DUAL_ELEMS: np.int32, MESH_VERT2ELEMS_OFF: np.int32,
-                MESH_VERT2ELEMS: np.int32}
+                MESH_VERT2ELEMS: np.int32, MESH_ELEM2EDGES: np.int32, MESH_EDGE2VERTS: np.int32,
+                MESH_EDGE2ELEMS_OFF: np.int32, MESH_EDGE2ELEMS: np.int32}
 
 
 class PPError(RuntimeError):
@@ -70,6 +72,7 @@ SYMBOLS = {
     "pp_mesh_create": (_V, [_I, _I, _V, _I, _V, _V]),
     "pp_mesh_destroy": (_I, [_V]),
     "pp_mesh_info": (_I, [_V, c_int_p, c_int_p, c_int_p, c_int_p]),
+    "pp_mesh_num_edges": (_I, [_V]),
     "pp_mesh_tolerance": (_D, [_V]),
     "pp_mesh_array_dev": (_V, [_V, _I, C.POINTER(_S)]),
     "pp_mesh_array_to_host": (_I, [_V, _I, _V]),
@@ -317,6 +320,13 @@ class Mesh:
 
     def tolerance(self):
         return lib().pp_mesh_tolerance(self.p)
+
+    def num_edges(self):
+        """Omega_h Mesh::nedges(): sides of a triangle mesh, derived edges of a tet mesh"""
+        n = lib().pp_mesh_num_edges(self.p)
+        if n < 0:
+            check(n)
+        return n
 
     def array(self, which):
         cnt = C.c_size_t()
@@ -1222,6 +1232,8 @@ class PicPart:
         self.nranks = comm.size() if comm is not None else 1
         self.mesh = _PartMesh(lib().pp_picpart_mesh(self.p), self)
         self.nents[mesh.dim - 1] = self.mesh.nsides  # sides: numbered by the part's own mesh
+        if mesh.dim == 3:                             # edges of tets likewise
+            self.nents[1] = lib().pp_mesh_num_edges(self.mesh.p)
 
     def array(self, which, edim=0):
         cnt = C.c_size_t()

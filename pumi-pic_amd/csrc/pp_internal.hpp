@@ -23,6 +23,7 @@ void gyro_map_mesh_gone(const void* mesh);
 // pp_scatter.hip: gyroScatter for `nmaps` ring maps from an explicit per-element count array (the
 // histogram of a rebuild that is still in flight); forgets the ring accumulation kept for reuse
 bool initialised();
+// pp_mesh.hip: derive (once) and return the edges of a tet mesh; PP_EINVAL for a 2-D mesh
 
 #define PP_HIP_CHECK(expr)                                                              \
   do {                                                                                  \
@@ -145,12 +146,22 @@ struct pp_mesh {
   std::vector<int> elem2verts, class_id, elem2sides, side2verts, side2elems_off, side2elems,
       dual_off, dual_elems, vert2elems_off, vert2elems;
   std::vector<signed char> side_exposed;
+  // edges of a tet mesh (entity dimension 1 of a 3-D mesh; in 2-D the edges are the sides), derived on first
+  // use (pp_mesh_edges): Omega_h's template order (0,1),(1,2),(2,0),(0,3),(1,3),(2,3), numbered in
+  // first-seen order over (element, local edge), edge2verts in the orientation first seen
+  bool edges_ready = false;
+  int nedges = 0;
+  std::vector<int> elem2edges, edge2verts, edge2elems_off, edge2elems;
+  pp::DevBuf d_elem2edges, d_edge2verts, d_edge2elems_off, d_edge2elems;
   // device arrays
   pp::DevBuf d_coords, d_elem2verts, d_class_id, d_elem2sides, d_side2verts, d_side2elems_off,
       d_side2elems, d_side_exposed, d_elem_measure, d_dual_off, d_dual_elems, d_vert2elems_off,
       d_vert2elems, d_records;
 };
 
+namespace pp {
+int mesh_edges(const pp_mesh* mesh);
+}
 struct pp_ps {
   int kind = PP_SCS;
   int num_elems = 0, num_ptcls = 0, capacity = 0, num_rows = 0;

@@ -217,6 +217,59 @@ int pack_and_upload(pp_mesh& m) {
 
 }  // namespace
 
+namespace pp {
+// Edges of a tet mesh (the reference gets them from Omega_h: ask_down(3, 1) / ask_up(1, 3)).  Same rule as
+// the sides in derive(): first-seen numbering over (element, local edge), the stored vertex pair in the
+// orientation of the first element that has the edge.
+int mesh_edges(const pp_mesh* mesh) {
+  pp_mesh& m = *const_cast<pp_mesh*>(mesh);
+  PP_REQUIRE(m.dim == 3, "edges are a separate entity dimension only for tet meshes (2-D: the sides)");
+  if (m.edges_ready) return PP_OK;
+  static const int TE3[6][2] = {{0, 1}, {1, 2}, {2, 0}, {0, 3}, {1, 3}, {2, 3}};
+  const int ne = m.nelems;
+  m.elem2edges.assign((size_t)ne * 6, -1);
+  m.edge2verts.clear();
+  std::unordered_map<Key3, int, Key3Hash> table;
+  table.reserve((size_t)ne * 2);
+  std::vector<int> cnt;
+  for (int e = 0; e < ne; ++e)
+    for (int le = 0; le < 6; ++le) {
+      const int a = m.elem2verts[(size_t)e * 4 + TE3[le][0]], b = m.elem2verts[(size_t)e * 4 + TE3[le][1]];
+      const Key3 k{std::min(a, b), std::max(a, b), -1};
+      auto it = table.find(k);
+      int id;
+      if (it == table.end()) {
+        id = (int)cnt.size();
+        table.emplace(k, id);
+        cnt.push_back(0);
+        m.edge2verts.push_back(a);
+        m.edge2verts.push_back(b);
+      } else {
+        id = it->second;
+      }
+      ++cnt[(size_t)id];
+      m.elem2edges[(size_t)e * 6 + le] = id;
+    }
+  m.nedges = (int)cnt.size();
+  m.edge2elems_off.assign((size_t)m.nedges + 1, 0);
+  for (int i = 0; i < m.nedges; ++i) m.edge2elems_off[(size_t)i + 1] = m.edge2elems_off[(size_t)i] + cnt[(size_t)i];
+  m.edge2elems.assign((size_t)m.edge2elems_off[(size_t)m.nedges], -1);
+  std::vector<int> fill((size_t)m.nedges, 0);
+  for (int e = 0; e < ne; ++e)
+    for (int le = 0; le < 6; ++le) {
+      const int id = m.elem2edges[(size_t)e * 6 + le];
+      m.edge2elems[(size_t)m.edge2elems_off[(size_t)id] + fill[(size_t)id]++] = e;
+    }
+  int rc;
+  if ((rc = upload(m.d_elem2edges, m.elem2edges))) return rc;
+  if ((rc = upload(m.d_edge2verts, m.edge2verts))) return rc;
+  if ((rc = upload(m.d_edge2elems_off, m.edge2elems_off))) return rc;
+  if ((rc = upload(m.d_edge2elems, m.edge2elems))) return rc;
+  m.edges_ready = true;
+  return PP_OK;
+}
+}  // namespace pp
+
 extern "C" {
 
 pp_mesh* pp_mesh_create(int dim, int nverts, const double* coords_host, int nelems,
@@ -256,6 +309,13 @@ int pp_mesh_destroy(pp_mesh* m) {
   return PP_OK;
 }
 
+int pp_mesh_num_edges(const pp_mesh* m) {
+  if (!m) return PP_EINVAL;
+  if (m->dim == 2) return m->nsides;
+  const int rc = pp::mesh_edges(m);
+  return rc ? rc : m->nedges;
+}
+
 int pp_mesh_info(const pp_mesh* m, int* dim, int* nverts, int* nelems, int* nsides) {
   PP_REQUIRE(m, "pp_mesh_info: null mesh");
   if (dim) *dim = m->dim;
@@ -270,6 +330,7 @@ double pp_mesh_tolerance(const pp_mesh* m) { return m ? m->tol : 0.0; }
 static const void* mesh_array(const pp_mesh* m, int which, size_t* count, size_t* item,
                               const void** host) {
   const void* d = nullptr;
+  if (which >= PP_MESH_ELEM2EDGES && which <= PP_MESH_EDGE2ELEMS && m->dim == 3) (void)pp::mesh_edges(m);
 #define PP_CASE(W, VEC, DEV, T) \
   case W:                       \
     *count = m->VEC.size();     \
@@ -291,6 +352,10 @@ static const void* mesh_array(const pp_mesh* m, int which, size_t* count, size_t
     PP_CASE(PP_MESH_DUAL_ELEMS, dual_elems, d_dual_elems, int)
     PP_CASE(PP_MESH_VERT2ELEMS_OFF, vert2elems_off, d_vert2elems_off, int)
     PP_CASE(PP_MESH_VERT2ELEMS, vert2elems, d_vert2elems, int)
+    PP_CASE(PP_MESH_ELEM2EDGES, elem2edges, d_elem2edges, int)
+    PP_CASE(PP_MESH_EDGE2VERTS, edge2verts, d_edge2verts, int)
+    PP_CASE(PP_MESH_EDGE2ELEMS_OFF, edge2elems_off, d_edge2elems_off, int)
+    PP_CASE(PP_MESH_EDGE2ELEMS, edge2elems, d_edge2elems, int)
     case PP_MESH_ELEM_RECORDS:
       *count = (size_t)m->nelems;
       *item = (m->dim == 2) ? sizeof(pp_tri_rec) : sizeof(pp_tet_rec);

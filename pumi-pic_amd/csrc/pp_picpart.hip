@@ -118,7 +118,8 @@ struct pp_picpart {
   // the Input the part was built from (the balancer re-derives every rank's safe zone from it)
   std::vector<int> owner_e;
   int buffer_method = 0, safe_method = 0, bridge_dim = 0, buffer_layers = 0, safe_layers = 0;
-  DimData D[3];  // 0: vertices, 1: elements, 2: sides (dimension dim-1)
+  DimData D[4];  // 0: vertices, 1: elements, 2: sides (dimension dim-1), 3: edges of a tet mesh (dimension 1)
+  int nslots = 3;  // 4 for tet meshes
   std::vector<unsigned char> safe;
   pp::DevBuf d_safe;
   // reduction scratch and the state between the phases
@@ -134,8 +135,8 @@ DimData* dim_slot(pp_picpart* p, int edim) {
   if (edim == 0) return &p->D[0];
   if (edim == p->dim) return &p->D[1];
   if (edim == p->dim - 1) return &p->D[2];
-  pp::set_error("PICpart: entity dimension must be 0 (vertices), dim-1 (sides) or dim (elements) -- pp_mesh "
-                "numbers no edges of tets");
+  if (edim == 1 && p->dim == 3) return &p->D[3];
+  pp::set_error("PICpart: entity dimension must be between 0 (vertices) and the mesh dimension (elements)");
   return nullptr;
 }
 const DimData* dim_slot(const pp_picpart* p, int edim) { return dim_slot(const_cast<pp_picpart*>(p), edim); }
@@ -441,20 +442,43 @@ pp_picpart* pp_picpart_create(const pp_mesh* full, const int* elem_owner_host, i
     p->part = pp_mesh_create(full->dim, dv.nents, coords.data(), de.nents, e2v.data(), cls.data());
     if (!p->part) return bail(nullptr);
   }
-  // ---- sides: the part's own mesh numbers them (pp_mesh_create derives sides from the elements); part side ->
-  // full side by their vertices.  Owner = smallest owner of the (one or two) elements around it.
-  const int ns = full->nsides, nvps = full->dim;  // vertices per side
-  std::vector<int> owner_s((size_t)ns, P);
-  for (int sd = 0; sd < ns; ++sd)
-    for (int k = full->side2elems_off[(size_t)sd]; k < full->side2elems_off[(size_t)sd + 1]; ++k)
-      owner_s[(size_t)sd] = std::min(owner_s[(size_t)sd], owner_e[(size_t)full->side2elems[(size_t)k]]);
-  {
+  // ---- sides (and, for tets, edges): the part's own mesh numbers them (pp_mesh derives them from its
+  // elements); part entity -> full entity by their vertices.  Owner = smallest owner of the elements around
+  // it (defineOwners :305-323 over ask_up(d, dim)).  The reference loops every dimension 0..dim
+  // (pumipic_part_construct.cpp:141-163, test/test_comm_array.cpp:48-66).
+  p->nslots = full->dim == 3 ? 4 : 3;
+  if (full->dim == 3) {
+    if (pp::mesh_edges(full) != PP_OK) return bail(nullptr);
+    if (p->part && pp::mesh_edges(p->part) != PP_OK) return bail(nullptr);
+    p->D[3].edim = 1;
+  }
+  struct MidDim {
+    int slot, nvpe, nfull;
+    const std::vector<int>*ent2verts, *up_off, *up, *part_ent2verts;
+    int npart;
+  };
+  std::vector<MidDim> mids;
+  mids.push_back(MidDim{2, full->dim, full->nsides, &full->side2verts, &full->side2elems_off, &full->side2elems,
+                        p->part ? &p->part->side2verts : nullptr, p->part ? p->part->nsides : 0});
+  if (full->dim == 3)
+    mids.push_back(MidDim{3, 2, full->nedges, &full->edge2verts, &full->edge2elems_off, &full->edge2elems,
+                          p->part ? &p->part->edge2verts : nullptr, p->part ? p->part->nedges : 0});
+  std::vector<int> owner_mid[2];
+  std::vector<int64_t> gid_mid[2];
+  for (size_t mi = 0; mi < mids.size(); ++mi) {
+    const MidDim& M = mids[mi];
+    const int ns = M.nfull, nvps = M.nvpe;
+    std::vector<int>& owner_s = owner_mid[mi];
+    owner_s.assign((size_t)ns, P);
+    for (int sd = 0; sd < ns; ++sd)
+      for (int k = (*M.up_off)[(size_t)sd]; k < (*M.up_off)[(size_t)sd + 1]; ++k)
+        owner_s[(size_t)sd] = std::min(owner_s[(size_t)sd], owner_e[(size_t)(*M.up)[(size_t)k]]);
     std::vector<int> side_full;
     if (p->is_full) {
       side_full.resize((size_t)ns);
       std::iota(side_full.begin(), side_full.end(), 0);
     } else {
-      typedef std::array<int, 4> Key;  // sorted vertices (full ids) + side id
+      typedef std::array<int, 4> Key;  // sorted vertices (full ids) + entity id
       auto key_of = [&](const int* v, const std::vector<int>* to_full, int id) {
         Key k{{0, 0, 0, id}};
         for (int j = 0; j < nvps; ++j) k[(size_t)j] = to_full ? (*to_full)[(size_t)v[j]] : v[j];
@@ -462,37 +486,40 @@ pp_picpart* pp_picpart_create(const pp_mesh* full, const int* elem_owner_host, i
         return k;
       };
       std::vector<Key> keys((size_t)ns);
-      for (int sd = 0; sd < ns; ++sd) keys[(size_t)sd] = key_of(&full->side2verts[(size_t)sd * nvps], nullptr, sd);
+      for (int sd = 0; sd < ns; ++sd) keys[(size_t)sd] = key_of(&(*M.ent2verts)[(size_t)sd * nvps], nullptr, sd);
       auto less3 = [](const Key& a, const Key& b) {
         return std::lexicographical_compare(a.begin(), a.begin() + 3, b.begin(), b.begin() + 3);
       };
       std::sort(keys.begin(), keys.end(), less3);
-      const pp_mesh* pm = p->part;
-      side_full.resize((size_t)pm->nsides);
-      for (int sd = 0; sd < pm->nsides; ++sd) {
-        const Key k = key_of(&pm->side2verts[(size_t)sd * nvps], &p->D[0].full_ids, -1);
+      side_full.resize((size_t)M.npart);
+      for (int sd = 0; sd < M.npart; ++sd) {
+        const Key k = key_of(&(*M.part_ent2verts)[(size_t)sd * nvps], &p->D[0].full_ids, -1);
         auto it = std::lower_bound(keys.begin(), keys.end(), k, less3);
-        if (it == keys.end() || less3(k, *it)) return bail("pp_picpart_create: a side of the part is not a side of the full mesh");
+        if (it == keys.end() || less3(k, *it))
+          return bail("pp_picpart_create: a side / edge of the part is not one of the full mesh");
         side_full[(size_t)sd] = (*it)[3];
       }
     }
-    set_entities(p->D[2], ns, std::move(side_full));
+    set_entities(p->D[M.slot], ns, std::move(side_full));
+    for (int sd = 0; sd < ns; ++sd)
+      if (owner_s[(size_t)sd] >= P) return bail("pp_picpart_create: a side / edge belongs to no element");
+    global_numbering(owner_s, P, p->D[M.slot].goff, gid_mid[mi]);
   }
-  for (int sd = 0; sd < ns; ++sd)
-    if (owner_s[(size_t)sd] >= P) return bail("pp_picpart_create: a side belongs to no element");
-  std::vector<int64_t> gid_s;
-  global_numbering(owner_s, P, p->D[2].goff, gid_s);
+  const std::vector<int>& owner_s = owner_mid[0];
+  const std::vector<int64_t>& gid_s = gid_mid[0];
+  const int ns = full->nsides;
   setup_holder(p->D[0], P, rank, owner_v, gid_v);
   setup_holder(p->D[1], P, rank, owner_e, gid_e);
   setup_holder(p->D[2], P, rank, owner_s, gid_s);
+  if (p->nslots == 4) setup_holder(p->D[3], P, rank, owner_mid[1], gid_mid[1]);
   // ---- the owner side (what the reference learns from MPI_Ialltoall + Isend/Irecv, :113-190): which of my
   // entities every other rank holds, in increasing full-mesh id -- from that rank's own buffer rule
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < p->nslots; ++k) {
     p->D[k].recv_counts.assign((size_t)P, 0);
     p->D[k].recv_ent.clear();
   }
   std::vector<int> part_q;
-  std::vector<char> ke_q, kv_q, ks_q;
+  std::vector<char> ke_q, kv_q, ks_q, kd_q;
   for (int q = 0; q < P; ++q) {
     if (q == rank) continue;
     if (buffer_method == PP_PART_FULL) {
@@ -506,11 +533,17 @@ pp_picpart* pp_picpart_create(const pp_mesh* full, const int* elem_owner_host, i
     for (int sd = 0; sd < ns; ++sd)
       for (int k = full->side2elems_off[(size_t)sd]; k < full->side2elems_off[(size_t)sd + 1]; ++k)
         if (ke_q[(size_t)full->side2elems[(size_t)k]]) ks_q[(size_t)sd] = 1;
-    for (int k = 0; k < 3; ++k) {
+    if (p->nslots == 4) {  // an edge is held when an element around it is
+      kd_q.assign((size_t)full->nedges, 0);
+      for (int ed = 0; ed < full->nedges; ++ed)
+        for (int k = full->edge2elems_off[(size_t)ed]; k < full->edge2elems_off[(size_t)ed + 1]; ++k)
+          if (ke_q[(size_t)full->edge2elems[(size_t)k]]) kd_q[(size_t)ed] = 1;
+    }
+    for (int k = 0; k < p->nslots; ++k) {
       DimData& d = p->D[k];
-      const std::vector<int>& owner = k == 0 ? owner_v : (k == 1 ? owner_e : owner_s);
-      const std::vector<int64_t>& gid = k == 0 ? gid_v : (k == 1 ? gid_e : gid_s);
-      const std::vector<char>& keep = k == 0 ? kv_q : (k == 1 ? ke_q : ks_q);
+      const std::vector<int>& owner = k == 0 ? owner_v : (k == 1 ? owner_e : (k == 2 ? owner_s : owner_mid[1]));
+      const std::vector<int64_t>& gid = k == 0 ? gid_v : (k == 1 ? gid_e : (k == 2 ? gid_s : gid_mid[1]));
+      const std::vector<char>& keep = k == 0 ? kv_q : (k == 1 ? ke_q : (k == 2 ? ks_q : kd_q));
       const int g0 = d.goff[(size_t)rank];
       const size_t before = d.recv_ent.size();
       for (int i = 0; i < d.nfull; ++i)  // increasing full id: the order rank q numbers a partial part in
@@ -521,11 +554,11 @@ pp_picpart* pp_picpart_create(const pp_mesh* full, const int* elem_owner_host, i
       if (cnt == d.my_count) std::iota(d.recv_ent.begin() + (long)before, d.recv_ent.end(), 0);
     }
   }
-  for (int k = 0; k < 3; ++k) p->D[k].nrecv = (int)p->D[k].recv_ent.size();
+  for (int k = 0; k < p->nslots; ++k) p->D[k].nrecv = (int)p->D[k].recv_ent.size();
   p->safe.resize((size_t)p->D[1].nents);
   for (int i = 0; i < p->D[1].nents; ++i) p->safe[(size_t)i] = is_safe[(size_t)p->D[1].full_ids[(size_t)i]];
   if (upload(p->d_safe, p->safe) != PP_OK || upload_dim(p->D[0]) != PP_OK || upload_dim(p->D[1]) != PP_OK ||
-      upload_dim(p->D[2]) != PP_OK)
+      upload_dim(p->D[2]) != PP_OK || (p->nslots == 4 && upload_dim(p->D[3]) != PP_OK))
     return bail(nullptr);
   return p;
 }

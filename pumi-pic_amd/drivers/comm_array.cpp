@@ -142,17 +142,17 @@ int main(int argc, char** argv) {
   }
   const int buffer_layers = argc > 3 ? atoi(argv[3]) : 1, safe_layers = argc > 4 ? atoi(argv[4]) : 0;
   int fails = 0;
-  const int dims[3] = {0, dim - 1, dim};
-  for (int k = 0; k < 3; ++k)
-    if (!fullBufferTest(mesh, owner, dims[k])) {
-      printf("fullBufferTest on dimension %d failed on rank %d\n", dims[k], rank);
+  // every entity dimension 0..dim, as the reference loops them (test/test_comm_array.cpp:48-66)
+  for (int d = 0; d <= dim; ++d)
+    if (!fullBufferTest(mesh, owner, d)) {
+      printf("fullBufferTest on dimension %d failed on rank %d\n", d, rank);
       ++fails;
     }
   // ---- the parts: core + `buffer_layers` layers of whole parts, safe zone `safe_layers` layers
   p::Mesh picparts(mesh, owner, buffer_layers, safe_layers);  // (test_comm_array.cpp:57: picparts(mesh, owner, 1, 0))
-  for (int k = 0; k < 3; ++k)
-    if (!minOwnership(picparts, dims[k])) {
-      printf("minOwnership on dimension %d failed on rank %d\n", dims[k], rank);
+  for (int d = 0; d <= dim; ++d)
+    if (!minOwnership(picparts, d)) {
+      printf("minOwnership on dimension %d failed on rank %d\n", d, rank);
       ++fails;
     }
   if (!sumEntities(picparts, 0)) {

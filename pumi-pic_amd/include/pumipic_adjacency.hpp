@@ -225,7 +225,16 @@ class Mesh {
     pp_check(pp_picpart_info(part_, &full, nullptr, nullptr, nullptr), "isFullMesh");
     return full != 0;
   }
-  int nents(int edim) const { return edim == 0 ? nverts_ : (edim == dim_ ? nelems_ : nsides_); }
+  // Omega_h Mesh::nents(dim): vertices, edges (the sides of a triangle mesh; derived on first use for tets),
+  // faces / sides, elements
+  int nents(int edim) const {
+    if (edim == 0) return nverts_;
+    if (edim == dim_) return nelems_;
+    if (edim == dim_ - 1) return nsides_;
+    const int n = pp_mesh_num_edges(part_ ? pp_picpart_mesh(part_) : h_);
+    pp_check(n < 0 ? n : 0, "nents(1)");
+    return n;
+  }
   int numBuffers(int /*edim*/) const {  // parts held, self included (pumipic_mesh.hpp:43)
     int nb = num_ranks();
     if (part_) pp_check(pp_picpart_info(part_, nullptr, &nb, nullptr, nullptr), "numBuffers");
@@ -278,8 +287,7 @@ class Mesh {
   enum Op { SUM_OP, MAX_OP, MIN_OP, BCAST_OP };
   template <class T>
   o::Write<T> createCommArray(int edim, int num_entries_per_entity, T default_value) {
-    const int n = edim == 0 ? nverts_ : (edim == dim_ ? nelems_ : nsides_);
-    return o::Write<T>((size_t)n * num_entries_per_entity, default_value);
+    return o::Write<T>((size_t)nents(edim) * num_entries_per_entity, default_value);
   }
   void reduceCommArray(int edim, Op op, o::Write<o::Real> array) {
     if (part_) {

@@ -183,6 +183,19 @@ def picparts(ppo, synth):
             for r in range(4):
                 out["%s_r%d_d%d_in" % (tag, r, d)] = arrs[r]
                 out["%s_r%d_d%d_sum" % (tag, r, d)] = red[r]
+        if dim == 3:  # round 3: entity dimension 1 of the tet mesh (edges), with draws of its own so that the
+            rng1 = np.random.default_rng(31)  # vectors of rounds 1-2 stay what they were
+            for r, p in enumerate(P.parts):
+                out["%s_r%d_d1_gids" % (tag, r)] = p.gids[1]
+                out["%s_r%d_d1_comm_index" % (tag, r)] = p.comm_index[1]
+                out["%s_r%d_d1_full_ids" % (tag, r)] = p.full_ids[1]
+                out["%s_r%d_d1_complete" % (tag, r)] = p.is_complete[1]
+            arrs = [rng1.standard_normal(p.nents[1] * 2) for p in P.parts]
+            red = P.reduce(1, opp.SUM_OP, arrs)
+            for r in range(4):
+                out["%s_r%d_d1_in" % (tag, r)] = arrs[r]
+                out["%s_r%d_d1_sum" % (tag, r)] = red[r]
+            out[tag + "_edge2verts"] = P.mid[1][0]
         PB = opp.PicParts(mesh, owner, 4, opp.BFS, opp.FULL, buffer_layers=3, safe_layers=1)
         bal = opp.Balancer(PB)
         ppe = [np.full(p.nents[dim], (p.rank + 1) * 50, dtype=np.int32) for p in PB.parts]

@@ -277,13 +277,13 @@ def test_oracle_picparts_golden(ppo, synth):
         mesh = ppo.Mesh(dim, c, e, k)
         P = opp.PicParts(mesh, owner, 4, opp.BFS, opp.BFS, buffer_layers=1, safe_layers=0)
         for r, p in enumerate(P.parts):
-            for d in (0, dim - 1, dim):
+            for d in range(dim + 1):
                 assert np.array_equal(p.gids[d], g["%s_r%d_d%d_gids" % (tag, r, d)])
                 assert np.array_equal(p.comm_index[d], g["%s_r%d_d%d_comm_index" % (tag, r, d)])
                 assert np.array_equal(p.full_ids[d], g["%s_r%d_d%d_full_ids" % (tag, r, d)])
                 assert np.array_equal(p.is_complete[d], g["%s_r%d_d%d_complete" % (tag, r, d)])
             assert np.array_equal(p.safe, g["%s_r%d_safe" % (tag, r)])
-        for d in (0, dim - 1, dim):
+        for d in range(dim + 1):
             red = P.reduce(d, opp.SUM_OP, [g["%s_r%d_d%d_in" % (tag, r, d)] for r in range(4)])
             for r in range(4):
                 assert np.array_equal(red[r], g["%s_r%d_d%d_sum" % (tag, r, d)])
@@ -307,13 +307,13 @@ def test_gpu_picparts_golden(synth, capi):
         comms = capi.Comm.local(4)
         parts = [capi.PicPart(mesh, owner, comms[r], capi.PART_BFS, capi.PART_BFS, 0, 1, 0) for r in range(4)]
         for r, p in enumerate(parts):
-            for d in (0, dim - 1, dim):
+            for d in range(dim + 1):
                 assert np.array_equal(p.array(capi.PART_GIDS, d), g["%s_r%d_d%d_gids" % (tag, r, d)])
                 assert np.array_equal(p.array(capi.PART_COMM_INDEX, d), g["%s_r%d_d%d_comm_index" % (tag, r, d)])
                 assert np.array_equal(p.array(capi.PART_FULL_IDS, d), g["%s_r%d_d%d_full_ids" % (tag, r, d)])
                 assert np.array_equal(p.complete_parts(d), g["%s_r%d_d%d_complete" % (tag, r, d)])
             assert np.array_equal(p.array(capi.PART_SAFE).astype(np.int32), g["%s_r%d_safe" % (tag, r)])
-        for d in (0, dim - 1, dim):
+        for d in range(dim + 1):
             devs = [capi.DevArray.from_host(g["%s_r%d_d%d_in" % (tag, r, d)]) for r in range(4)]
             capi.picpart_reduce_all(parts, d, capi.OP_SUM, devs)
             for r in range(4):

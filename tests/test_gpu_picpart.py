@@ -69,7 +69,7 @@ def test_construction_matches_oracle(ppo, synth, capi, opp, case):
     for po, pg in zip(O.parts, parts):
         assert pg.is_full_mesh == po.is_full_mesh
         assert pg.num_buffers == int(po.has_part.sum())
-        for d in (0, dim - 1, dim):
+        for d in range(dim + 1):  # every entity dimension (test/test_comm_array.cpp:48-66), tet edges included
             assert pg.nents[d] == po.nents[d]
             assert np.array_equal(pg.array(capi.PART_GIDS, d), po.gids[d])
             assert np.array_equal(pg.array(capi.PART_OWNERS, d), po.owners[d])
@@ -91,6 +91,23 @@ def test_construction_matches_oracle(ppo, synth, capi, opp, case):
         c.destroy()
 
 
+def test_tet_edges_match_oracle(ppo, synth, capi, opp):
+    """entity dimension 1 of a tet mesh (Omega_h ask_down(3,1) / ask_up(1,3)): PP_MESH_ELEM2EDGES /
+    EDGE2VERTS / EDGE2ELEMS equal the oracle's first-seen derivation; every edge is an edge of its tets"""
+    c, e, k = synth.torus_tet(n_b=4, n_theta=12, n_planes=6)
+    mg = capi.Mesh(3, c, e, k)
+    ev, e2e, off, up = opp.tet_edges(e)
+    assert mg.num_edges() == len(ev)
+    assert np.array_equal(mg.array(15).reshape(-1, 2), ev)       # PP_MESH_EDGE2VERTS
+    assert np.array_equal(mg.array(14).reshape(-1, 6), e2e)      # PP_MESH_ELEM2EDGES
+    assert np.array_equal(mg.array(16), off)                     # PP_MESH_EDGE2ELEMS_OFF
+    got_up, got_off = mg.array(17), mg.array(16)
+    for ed in range(0, len(ev), 11):
+        assert sorted(got_up[got_off[ed]:got_off[ed + 1]].tolist()) == sorted(up[off[ed]:off[ed + 1]].tolist())
+        for el in got_up[got_off[ed]:got_off[ed + 1]]:
+            assert set(ev[ed].tolist()) <= set(np.asarray(e).reshape(-1, 4)[el].tolist())
+
+
 def _reduce_both(capi, O, parts, d, op, host_arrays):
     devs = [capi.DevArray.from_host(a) for a in host_arrays]
     capi.picpart_reduce_all(parts, d, op, devs)
@@ -102,7 +119,7 @@ def test_reduce_matches_oracle_and_reference_properties(ppo, synth, capi, opp, c
     dim, mo, mg, O, parts, comms, owner = _build(ppo, synth, capi, opp, case)
     rng = np.random.default_rng(5)
     P = len(parts)
-    for d in (0, dim - 1, dim):
+    for d in range(dim + 1):
         n = [p.nents[d] for p in parts]
         # random doubles, 3 values per entity: SUM / MAX / MIN / BCAST bit-exact
         for op in (capi.OP_SUM, capi.OP_MAX, capi.OP_MIN, capi.OP_BCAST):
@@ -132,7 +149,7 @@ def test_reduce_matches_oracle_and_reference_properties(ppo, synth, capi, opp, c
     for g in got:
         assert np.all(g == 1)
     if parts[0].is_full_mesh:
-        for d in (0, dim - 1, dim):
+        for d in range(dim + 1):
             got, _ = _reduce_both(capi, O, parts, d, capi.OP_SUM, [np.ones(p.nents[d], np.int32) for p in parts])
             for g in got:
                 assert np.all(g == P)

@@ -34,8 +34,14 @@ def test_numbering_and_ownership(ppo, synth, opp, which):
     mesh, owner = meshes(ppo, synth)[which]
     pp_ = opp.PicParts(mesh, owner, 4, opp.BFS, opp.BFS, buffer_layers=1, safe_layers=0)
     dim = mesh.dim
-    for d in (0, dim - 1, dim):
-        n = {0: mesh.nverts, dim - 1: mesh.nsides, dim: mesh.nelems}[d]
+    assert pp_.dims == tuple(range(dim + 1))  # every entity dimension, as test_comm_array.cpp:48-66 loops them
+    nfull = {0: mesh.nverts, dim - 1: mesh.nsides, dim: mesh.nelems}
+    if dim == 3:
+        nfull[1] = len(pp_.mid[1][0])
+        # Euler's formula for a ball-like tet mesh: V - E + F - T = 1
+        assert mesh.nverts - nfull[1] + mesh.nsides - mesh.nelems == 1
+    for d in pp_.dims:
+        n = nfull[d]
         assert sorted(pp_.gids[d].tolist()) == list(range(n))            # a permutation
         assert np.all(np.diff(pp_.gids[d][np.argsort(pp_.owner[d], kind="stable")]) == 1)  # owner-major, in id order
         assert np.all(pp_.rank_lids[d] == pp_.gids[d] - pp_.offsets[d][pp_.owner[d]])
@@ -54,7 +60,12 @@ def test_numbering_and_ownership(ppo, synth, opp, which):
         for sp in range(0, pm.nsides, 5):
             assert sorted(p.full_ids[0][np.asarray(pm.side2verts)[sp]].tolist()) == \
                 sorted(mesh.side2verts[p.full_ids[dim - 1][sp]].tolist())
-        for d in (0, dim - 1, dim):
+        if dim == 3:  # the part's edges are the edges of its own elements; the map keeps their vertices
+            pe = opp.tet_edges(p.elem2verts)[0]
+            assert p.nents[1] == len(pe)
+            for ep in range(0, len(pe), 7):
+                assert sorted(p.full_ids[0][pe[ep]].tolist()) == sorted(pp_.mid[1][0][p.full_ids[1][ep]].tolist())
+        for d in pp_.dims:
             ci = p.comm_index[d]
             assert sorted(ci.tolist()) == list(range(p.nents[d]))       # a permutation of the part's entities
             seg = np.searchsorted(p.nents_offsets[d], ci, side="right") - 1
@@ -70,7 +81,7 @@ def test_min_ownership_sum_entities_and_owned_elements(ppo, synth, opp, which):
     cs = 4
     pp_ = opp.PicParts(mesh, owner, cs, opp.BFS, opp.BFS, buffer_layers=1, safe_layers=0)
     dim = mesh.dim
-    for d in (0, dim - 1, dim):  # minOwnership
+    for d in range(dim + 1):  # minOwnership, every dimension (test_comm_array.cpp:48-66)
         arrs = [np.where(p.owners[d] == p.rank, p.rank, np.iinfo(np.int32).max).astype(np.int32) for p in pp_.parts]
         red = pp_.reduce(d, opp.MIN_OP, arrs)
         for p, a in zip(pp_.parts, red):
@@ -106,9 +117,12 @@ def test_full_buffer(ppo, synth, opp, which):
     """fullBufferTest, test_comm_array.cpp:181-207"""
     mesh, owner = meshes(ppo, synth)[which]
     pp_ = opp.PicParts(mesh, owner, 4, opp.FULL, opp.FULL)
-    for d in (0, mesh.dim - 1, mesh.dim):
+    nfull = {0: mesh.nverts, mesh.dim - 1: mesh.nsides, mesh.dim: mesh.nelems}
+    if mesh.dim == 3:
+        nfull[1] = len(pp_.mid[1][0])
+    for d in range(mesh.dim + 1):
         for p in pp_.parts:
-            assert p.is_full_mesh and p.nents[d] == {0: mesh.nverts, mesh.dim - 1: mesh.nsides, mesh.dim: mesh.nelems}[d]
+            assert p.is_full_mesh and p.nents[d] == nfull[d]
         ones = [np.ones(p.nents[d], dtype=np.int32) for p in pp_.parts]
         for a in pp_.reduce(d, opp.SUM_OP, ones):
             assert np.all(a == 4)

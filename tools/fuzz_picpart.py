@@ -80,7 +80,7 @@ def main(seconds=60.0, seed=0):
         parts = [capi.PicPart(mg, owner, comms[r], getattr(capi, "PART_" + bm), getattr(capi, "PART_" + sm), bridge,
                               bl, sl) for r in range(P)]
         for po, pg in zip(O.parts, parts):
-            for d in (0, dim - 1, dim):
+            for d in range(dim + 1):
                 for which_arr, want in ((capi.PART_GIDS, po.gids[d]), (capi.PART_OWNERS, po.owners[d]),
                                         (capi.PART_RANK_LIDS, po.rank_lids[d]), (capi.PART_COMM_INDEX, po.comm_index[d]),
                                         (capi.PART_FULL_IDS, po.full_ids[d]), (capi.PART_ENT_IDS, po.ent_ids[d])):
@@ -89,7 +89,7 @@ def main(seconds=60.0, seed=0):
                 assert np.array_equal(pg.complete_parts(d), po.is_complete[d]), cfg
             assert np.array_equal(pg.array(capi.PART_SAFE).astype(np.int32), po.safe), cfg
         for _ in range(3):
-            d = (0, dim - 1, dim)[int(rng.integers(0, 3))]
+            d = int(rng.integers(0, dim + 1))
             op = int(rng.integers(0, 4))
             nv = int(rng.integers(1, 4))
             if rng.integers(0, 2):
