@@ -605,6 +605,13 @@ int pp_picpart_array_to_host(const pp_picpart* p, int which, int edim, void* out
 int pp_picpart_nents_offsets(const pp_picpart* p, int edim, int* offsets_host);
 int pp_picpart_buffered_ranks(const pp_picpart* p, int edim, int* ranks_host, int* n);
 int pp_picpart_complete_parts(const pp_picpart* p, int edim, int* is_complete_host);
+/* the owner's side of partially held parts: Mesh::boundary_parts / offset_bounded_per_dim / bounded_ent_ids
+ * (src/pumipic_mesh.hpp:131-136, gathered in pumipic_comm.cpp:113-190) -- ranks that hold a boundary of this
+ * rank's entities (ascending), prefix of their counts, and the rank-local ids they hold in sending order.
+ * Null outputs are skipped (first call: sizes).  pp_picpart_num_global: Mesh::num_entites[edim]. */
+int pp_picpart_bounded(const pp_picpart* p, int edim, int* n_boundaries, int* boundary_parts_host, int* offsets_host,
+                       int* n_ids, int* ent_ids_host);
+long long pp_picpart_num_global(const pp_picpart* p, int edim);
 /* Mesh::reduceCommArray (src/pumipic_comm.cpp:249-440): array_dev holds nvals values per entity of the
  * part (entity-major, createCommArray's layout).  Fan-in: every part sends the segments of the parts it
  * buffers to their owners (device buffers; one grouped RCCL send/recv per peer); the owner combines its

@@ -3,3 +3,4 @@ rebuild/migrate) behind a C-ABI (include/pumipic_hip.h).  Python here is plumbin
 bench.py only; the product is pumi-pic_amd/csrc (HIP) + pumi-pic_amd/include (C++ host API)."""
 from . import synth  # noqa: F401
 from . import ptlio  # noqa: F401
+from . import ppmio  # noqa: F401

@@ -136,6 +136,8 @@ SYMBOLS = {
     "pp_picpart_array_to_host": (_I, [_V, _I, _I, _V]),
     "pp_picpart_nents_offsets": (_I, [_V, _I, c_int_p]),
     "pp_picpart_buffered_ranks": (_I, [_V, _I, c_int_p, c_int_p]),
+    "pp_picpart_bounded": (_I, [_V, _I, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
+    "pp_picpart_num_global": (C.c_longlong, [_V, _I]),
     "pp_picpart_complete_parts": (_I, [_V, _I, c_int_p]),
     "pp_picpart_reduce": (_I, [_V, _I, _I, _I, _I, _V]),
     "pp_picpart_reduce_begin": (_I, [_V, _I, _I, _I, _I, _V]),
@@ -1258,6 +1260,20 @@ class PicPart:
         n = C.c_int()
         check(lib().pp_picpart_buffered_ranks(self.p, edim, out.ctypes.data_as(c_int_p), C.byref(n)))
         return out[:n.value].copy()
+
+    def bounded(self, edim):
+        """(boundary_parts, offset_bounded, bounded_ent_ids) of src/pumipic_mesh.hpp:131-136"""
+        nb, nid = C.c_int(), C.c_int()
+        check(lib().pp_picpart_bounded(self.p, edim, C.byref(nb), None, None, C.byref(nid), None))
+        parts = np.empty(max(nb.value, 1), dtype=np.int32)
+        off = np.empty(nb.value + 1, dtype=np.int32)
+        ids = np.empty(max(nid.value, 1), dtype=np.int32)
+        check(lib().pp_picpart_bounded(self.p, edim, C.byref(nb), parts.ctypes.data_as(c_int_p),
+                                       off.ctypes.data_as(c_int_p), C.byref(nid), ids.ctypes.data_as(c_int_p)))
+        return parts[:nb.value].copy(), off, ids[:nid.value].copy()
+
+    def num_global(self, edim):
+        return int(lib().pp_picpart_num_global(self.p, edim))
 
     def complete_parts(self, edim):
         out = np.empty(self.nranks, dtype=np.int32)

@@ -563,6 +563,40 @@ pp_picpart* pp_picpart_create(const pp_mesh* full, const int* elem_owner_host, i
   return p;
 }
 
+// the owner's side of a partially held part, as the reference keeps (and writes to its .ppm files,
+// src/pumipic_file.cpp:80-115): boundary_parts (ranks that hold only a boundary of my entities, ascending),
+// offset_bounded_per_dim (prefix over them) and bounded_ent_ids (my rank-local ids they hold, in the order
+// they send them).  Null outputs are skipped: call once for the sizes.
+int pp_picpart_bounded(const pp_picpart* p, int edim, int* n_boundaries, int* boundary_parts_host, int* offsets_host,
+                       int* n_ids, int* ent_ids_host) {
+  PP_REQUIRE(p, "pp_picpart_bounded: null part");
+  const DimData* d = dim_slot(p, edim);
+  if (!d) return PP_EINVAL;
+  int nb = 0, nid = 0, pos = 0;
+  if (offsets_host) offsets_host[0] = 0;
+  for (int q = 0; q < p->nranks; ++q) {
+    const int cnt = q == p->rank || d->recv_counts.empty() ? 0 : d->recv_counts[(size_t)q];
+    if (cnt > 0 && cnt != d->my_count) {  // (all of mine = a completely buffered part: no list travels)
+      if (boundary_parts_host) boundary_parts_host[nb] = q;
+      if (ent_ids_host)
+        for (int k = 0; k < cnt; ++k) ent_ids_host[nid + k] = d->recv_ent[(size_t)pos + k];
+      nid += cnt;
+      ++nb;
+      if (offsets_host) offsets_host[nb] = nid;
+    }
+    pos += cnt;
+  }
+  if (n_boundaries) *n_boundaries = nb;
+  if (n_ids) *n_ids = nid;
+  return PP_OK;
+}
+// global number of entities of a dimension (Mesh::num_entites, pumipic_mesh.hpp:106)
+long long pp_picpart_num_global(const pp_picpart* p, int edim) {
+  if (!p) return PP_EINVAL;
+  const DimData* d = dim_slot(p, edim);
+  return d && !d->goff.empty() ? (long long)d->goff.back() : -1;
+}
+
 int pp_picpart_destroy(pp_picpart* p) {
   if (!p) return PP_OK;
   if (p->part) pp_mesh_destroy(p->part);
