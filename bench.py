@@ -269,6 +269,11 @@ class Stepper:
             # rebuilt every step: every particle sits in its row's element, no seed ids needed
             capi.push_search(self.mesh, self.ps, self.h, self.k, self.d, self.deg, self.ids,
                              seeded=False, looplimit=200, want_found=False)
+        elif self.name == "2dc3":
+            # rebuilt every step: no seeds = every particle starts in its row's element (the -1 seeds
+            # search_mesh_2d would read, adjacency.hpp:1051-1056) -- no fill of the ids per step
+            capi.push_search(self.mesh, self.ps, self.h, self.k, self.d, self.deg, self.ids,
+                             seeded=False, looplimit=200, want_found=False)
         else:
             capi.push_search(self.mesh, self.ps, self.h, self.k, self.d, self.deg, self.ids,
                              seeded=True, looplimit=200, want_found=False)
@@ -303,9 +308,7 @@ class Stepper:
             cap = max(self.ps.capacity(), 1)
             if cap > self.ids.n:  # 10% slack: the capacity wanders by a few chunk widths per rebuild
                 self.ids = capi.DevArray(cap + cap // 10, np.int32)
-            if self.w["dim"] == 2:
-                self.ids.fill_bytes(0xff)  # search_mesh_2d reads its seeds: -1 = the row's element
-            # dim 3, unseeded (an "empty elem_ids", adjacency.tpp:504-515): the search writes every
+            # unseeded (an "empty elem_ids", adjacency.tpp:504-515; 2-D: every seed -1) (an "empty elem_ids", adjacency.tpp:504-515): the search writes every
             # slot itself, -1 into the masked ones -- no fill
         elif self.name == "c5":
             # updatePtclPositions rides in the records / the rebuild, the two scatters behind it
@@ -751,7 +754,7 @@ def main():
         w5["safe_layers"], w5["comm"], w5["origin_trust"] = 0, "rccl", True
         st5 = Stepper(pp, capi, w5, "c5", a.deg)
         t_set = time.perf_counter() - t_set
-        for _ in range(2):
+        for _ in range(12):  # (the clocks fell back while the host built the population: ~35 ms of steps)
             st5.step()
         k5 = 8
         capi.sync()
@@ -764,7 +767,7 @@ def main():
         scale_ref = {"workload": "c5 on one rank: %s, %d particles, push+search+migrate(no peer)+rebuild+gyroScatter x2"
                                  % (w5["label"], 32_000_000),
                      "ms_per_step": dt5 / k5 * 1e3, "value": n5 * k5 / dt5, "unit": "particles/s", "steps": k5,
-                     "warmup": 2, "setup_seconds": t_set,
+                     "warmup": 12, "setup_seconds": t_set,
                      "roofline_frac": 194.0 * n5 / (dt5 / k5) / 1e9 / HBM_PEAK_GBS,
                      "note": "the N > 1 lines of this file run exactly this workload per GPU (weak scaling); "
                              "scaling efficiency of an N-GPU line = value / (N * scale_ref.value)"}
@@ -777,7 +780,7 @@ def main():
     if rank == 0:
         kms = kms_main
         # HBM bytes per launch from the PMC counters: collected with rocprofv3 in separate --pmc
-        # passes of THIS command (tools/r02_measure.sh) and calibrated as DESIGN.md section 4 says;
+        # passes of THIS command (tools/r03_measure.sh) and calibrated as DESIGN.md section 4 says;
         # a profiler cannot wrap itself, so the committed summary is reported with its provenance
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.workload)

@@ -281,10 +281,16 @@ int pp_trace_not_found(pp_ps* ps, int* elem_ids_dev, const int* ptcl_done_dev, i
 /* Fused hot path: elliptical (dim 2) / toroidal (dim 3) push + BCC walk: particle state is read
  * once and x_tgt, phi, elem_ids written once.  Result-identical to pp_elliptical_push +
  * pp_search_mesh_2d (dim 2) and to pp_toroidal_push + pp_search_mesh in BCC mode (dim 3:
- * finishUnmoved, check_initial_parents, walk, tpp:72-145,460-615).  dim 2 needs elem_ids_seeded
- * (-1 = own element, -nelems = outside).  SCS structures use the row-tiled kernels (dim 3: column
- * loop + deferred walk of crossing particles, two launches, library-owned queue of 32 B per tile
- * slot); CSR structures the slot-parallel kernel.  found may be NULL (no host sync). */
+ * finishUnmoved, check_initial_parents, walk, tpp:72-145,460-615).  dim 2: the seeds search_mesh_2d
+ * reads (-1 = own element, -nelems = outside); elem_ids_seeded == 0 = "every seed is -1" without the
+ * caller filling the array (the loop that rebuilds after every search).  SCS structures use the
+ * row-tiled kernels (dim 3: column loop + deferred walk of crossing particles, two launches,
+ * library-owned queue of 32 B per tile slot); CSR structures the slot-parallel kernel.  found may be
+ * NULL (no host sync).
+ * After pp_ps_rebuild_commit / _scatter / a committing migration of a structure of the pseudoXGCm
+ * particle type this call reads the re-layout's staging records directly (the pass that would copy them
+ * into the member arrays is deferred: DESIGN.md "The record-fed push"); any other entry point that touches
+ * member data runs that pass first, so callers see the same member contents either way. */
 int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b, int m_phi,
                    double h, double k, double d, double deg, int* elem_ids_dev,
                    int elem_ids_seeded, int looplimit, int* found);

@@ -2264,8 +2264,10 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   int bits_pred = 0;
   static const bool no_pred = getenv("PP_NO_RS_PREDICT") != nullptr;
   if (!no_pred && ps->last_max_key != ~0ull) {
-    while (bits_pred < 63 && (ps->last_max_key >> bits_pred)) ++bits_pred;
-    ++bits_pred;
+    // (margin: 1/16 of the last maximum.  A whole extra bit -- round 2 -- launched a third, idle, 8-bit pass
+    // for the literal pseudoXGCm population, whose largest row holds 60 000 particles: 16 bits exactly)
+    const unsigned long long guess = ps->last_max_key + ps->last_max_key / 16 + 16;
+    while (bits_pred < 63 && (guess >> bits_pred)) ++bits_pred;
   }
   LayoutPlan L;
   int nchunks = ne / ps->C_max + (ne % ps->C_max != 0), nrows = nchunks * ps->C_max;

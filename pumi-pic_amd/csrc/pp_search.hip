@@ -1059,9 +1059,9 @@ __global__ void __launch_bounds__(256, OCC)
     PState s;
     if constexpr (RECIN) {
       s = load_state_recin<DIM>(pid, mask, rin.rec);
-      if (DIM == 2 || seeded) s.elem = elem_ids[pid];
+      if (seeded) s.elem = elem_ids[pid];
     } else {
-      s = load_state<DIM, true>(pid, mask, pphi, pb, x, stride, elem_ids, (DIM == 2) || seeded);
+      s = load_state<DIM, true>(pid, mask, pphi, pb, x, stride, elem_ids, seeded != 0);
     }
     return s;
   };
@@ -1420,7 +1420,7 @@ __global__ void __launch_bounds__(256, OCC)
     e = r2e[c * C + r];
   }
   const ppm::ClassTerm ct = ppm::class_term((valid && e < nelems) ? class_id[e] : 1, deg, DIM == 3);
-  const bool read_ids = (DIM == 2) || seeded;
+  const bool read_ids = seeded != 0;  // (2-D without seeds: every seed is -1, the row's element)
   WalkArgs A;
   A.xt = xt;
   A.stride = stride;
@@ -1914,7 +1914,7 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
   // and this call can read them there -- the pass that would copy them to the SoA arrays first is skipped.
   const int wq_env = getenv("PP_WALK_QUEUE") ? atoi(getenv("PP_WALK_QUEUE")) : -1;  // per call
   const int wq = wq_env >= 0 ? wq_env : (mesh->dim == 3 ? 1 : 0);
-  const bool recin = ((mesh->dim == 3 && wq > 0) || (mesh->dim == 2 && wq == 0 && elem_ids_seeded)) &&
+  const bool recin = ((mesh->dim == 3 && wq > 0) || (mesh->dim == 2 && wq == 0)) &&
                      ps->capacity > 0 && ps->num_ptcls > 0 && ps->ntiles_max > 0 &&
                      pp::lazy_push_ok(ps, m_x, m_xtgt, m_b, m_phi);
   int zero_z = 0;
@@ -1941,8 +1941,6 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
   }
   const unsigned grid = grid_for(ps->capacity);
   hipStream_t st = pp::stream();
-  if (mesh->dim == 2)
-    PP_REQUIRE(elem_ids_seeded, "pp_push_search (2-D): elem_ids must be initialised (-1 = own element)");
   Counters* used = nullptr;  // the counter set this call's kernels add to
   if (ps->kind == PP_SCS) {
     const unsigned rgrid = grid_for((size_t)ps->ntiles_max * ps->C);
@@ -2027,7 +2025,7 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
         ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), mesh->d_records.p,
         mesh->d_class_id.as<int>(), mesh->nelems, PP_MEMBER(ps, m_x, double),
         PP_MEMBER(ps, m_xtgt, double), ps->stride, PP_MEMBER(ps, m_b, float),
-        PP_MEMBER(ps, m_phi, float), h, k, d, deg, mesh->tol, elem_ids_dev, 1, looplimit,
+        PP_MEMBER(ps, m_phi, float), h, k, d, deg, mesh->tol, elem_ids_dev, elem_ids_seeded, looplimit,
         g_cnt.get());
   } else {
     k_push_walk<3><<<grid, kBlock, 0, st>>>(

@@ -127,8 +127,9 @@ def test_deferred_pass_before_other_entry_points(ppo, synth, capi):
     _same_population(po, pg)
 
 
+@pytest.mark.parametrize("seeded", [True, False])
 @pytest.mark.parametrize("look", ["never", "after_push", "after_rebuild"])
-def test_record_fed_push_2d(ppo, synth, capi, look):
+def test_record_fed_push_2d(ppo, synth, capi, look, seeded):
     """the literal pseudoXGCm loop (triangles, ellipticalPush + search_mesh_2d): the 2-D push writes two
     components of x_tgt, the third one -- logically zero after updatePtclPositions -- is written by the
     record-fed kernel itself"""
@@ -141,8 +142,11 @@ def test_record_fed_push_2d(ppo, synth, capi, look):
     for step in range(12):
         ppo.elliptical_push(po, mo, H, K, D, 2.0, trig=1)
         ids_o = ppo.search_mesh_2d(mo, po, looplimit=200)[1]
-        ids_g = capi.DevArray.from_host(np.full(max(pg.capacity(), 1), -1, dtype=np.int32))
-        capi.push_search(mg, pg, H, K, D, 2.0, ids_g, seeded=True, looplimit=200)
+        if seeded:
+            ids_g = capi.DevArray.from_host(np.full(max(pg.capacity(), 1), -1, dtype=np.int32))
+        else:  # "no seeds" = every seed -1, the array is not even initialised
+            ids_g = capi.DevArray.from_host(np.full(max(pg.capacity(), 1), 123456789, dtype=np.int32))
+        capi.push_search(mg, pg, H, K, D, 2.0, ids_g, seeded=seeded, looplimit=200)
         if look == "after_push":
             for m in range(5):
                 _, a = common.by_id(po.member(2)[0, :po.capacity()], po.slot_info()[1], po.member(m)[:, :po.capacity()])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """profiles/traffic_<workload>.json for a WHOLE step (c3 / c5): FETCH_SIZE and WRITE_SIZE of every kernel
-a step launches, summed, per step -- from the two --pmc passes of tools/r02_measure.sh (`bench.py
+a step launches, summed, per step -- from the two --pmc passes of tools/r03_measure.sh (`bench.py
 --workload W --steps K --warmup W0` with PP_BENCH_NO_COLD=1 PP_BENCH_PREWARM=0, so every per-step
 kernel runs exactly K + W0 times) and scaled by the calibration run of tools/ub_stream.hip (s_rows<8,4>
 moves exactly 37 B read + 32 B written per slot; MI355X_MICROARCH.md: FETCH_SIZE tallies 128-B requests
@@ -34,7 +34,7 @@ def main(out_dir, workload, particles, nsteps, dest, pmc_dir, bytes_per_particle
     out = {"workload": workload, "particles": particles, "remainder": "last", "steps_profiled": nsteps,
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python3 bench.py --workload %s "
                      "--steps 10 --warmup 3 --no-cpu-baseline` (PP_BENCH_NO_COLD=1 PP_BENCH_PREWARM=0), "
-                     "tools/r02_measure.sh; every kernel that runs once per step or more, summed per step; scaled by "
+                     "tools/r03_measure.sh; every kernel that runs once per step or more, summed per step; scaled by "
                      "the calibration run of tools/ub_stream.hip s_rows<8,4>: FETCH_SIZE[KiB] x 1024 x %.4f, "
                      "WRITE_SIZE[KiB] x 1024 x %.4f" % (workload, rf, wf),
            "kernels": {}}
@@ -43,10 +43,13 @@ def main(out_dir, workload, particles, nsteps, dest, pmc_dir, bytes_per_particle
         if sub != pmc_dir or "FETCH_SIZE" not in ctr or "WRITE_SIZE" not in ctr:
             continue
         n = min(len(ctr["FETCH_SIZE"]), len(ctr["WRITE_SIZE"]))
-        if n < nsteps or "k_closest_point" in name or name.startswith("__amd_rocclr"):
+        if n < nsteps - 1 or "k_closest_point" in name or name.startswith("__amd_rocclr"):
             continue  # (runtime fills / copies: < 1 MB per step; their dispatch list also holds the set-up memsets)
-        r = sum(ctr["FETCH_SIZE"]) * kib * rf / nsteps
-        w = sum(ctr["WRITE_SIZE"]) * kib * wf / nsteps
+        # per launch x launches per step: the record-fed push runs in every step but the first (whose push
+        # reads the SoA arrays the structure was built into), so it has nsteps - 1 launches
+        lps = max(1, round(n / nsteps))
+        r = sum(ctr["FETCH_SIZE"][:n]) / n * lps * kib * rf
+        w = sum(ctr["WRITE_SIZE"][:n]) / n * lps * kib * wf
         short = name.replace("(anonymous namespace)::", "").split("(")[0]
         out["kernels"][short] = {"launches_per_step": round(n / nsteps, 2), "read_bytes_per_step": r,
                                  "write_bytes_per_step": w}
