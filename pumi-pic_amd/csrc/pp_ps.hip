@@ -237,9 +237,8 @@ struct ElemTotalsArgs {
   // atomics on the totals (every block ends with three atomics on the same counters, ~10 ns each queued)
   int* partial;
 };
-// fused form of the radix passes (k_rs_pass, ne <= kFusedSortBlocks tiles): pass p reads the digit table
-// H[p % 3], adds the NEXT digit's counts to H[(p+1) % 3] and clears its slice of H[(p+2) % 3];
-// k_make_keys fills H[0] and clears H[1].
+// fused form of the radix passes (k_rs_pass, ne <= kFusedSortBlocks tiles): the sweep that makes the keys
+// also counts the first pass's digits per tile (h0); hzero is scratch it clears.
 struct FusedHist {
   int* h0;    // [256][nblk]: digit counts of the first pass per tile (null = the separate-launch sort)
   int* hzero; // table of the second pass, cleared here
@@ -1937,7 +1936,7 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
                                                  ps->s_keys.as<unsigned long long>(),
                                                  ps->s_vals.as<int>(), tot,
                                                  getenv("PP_NO_RS_SKIP") != nullptr, et,
-                                                 FusedHist{nullptr, nullptr, 0});
+                                                 fused_sort ? FusedHist{Hs[0], Hs[1], nblk} : FusedHist{nullptr, nullptr, 0});
     unsigned long long maxkey = (unsigned long long)(n_sigma > 0 ? n_sigma : 1) * L.base;
     int bits = 0;
     while (bits < 64 && (maxkey >> bits)) ++bits;
@@ -1952,7 +1951,7 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
     int* hist = ps->s_hist.as<int>();
     int* hist_sc = hist + 256 * nblk;
     for (int shift = 0; fused_sort && shift < bits; shift += 8) {
-      k_rs_hist<<<nblk, 256, 0, st>>>(ne, ka, shift, nblk, Hs[0], tot);
+      if (shift > 0) k_rs_hist<<<nblk, 256, 0, st>>>(ne, ka, shift, nblk, Hs[0], tot);  // (pass 0: k_make_keys)
       k_rs_pass<<<nblk, 256, 0, st>>>(ne, ka, va, shift, nblk, Hs[0], kb, vb, tot);
       std::swap(ka, kb);
       std::swap(va, vb);

@@ -324,7 +324,7 @@ __global__ void k_inv_sort(int nverts, const int* __restrict__ off, int* __restr
 // then every lane adds them up in list order, so the sum is the sequential one
 __global__ void k_scatter_gathered(int nverts, int gppr, const int* __restrict__ off,
                                    const int* __restrict__ src, const double* __restrict__ ring_accum,
-                                   double* __restrict__ scatter_w) {
+                                   double* __restrict__ scatter_w, double* __restrict__ scatter_w2 = nullptr) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = g >> 4, sub = g & 15, lane0 = (threadIdx.x & 63) & ~15;
   const bool in = t < nverts;
@@ -341,7 +341,10 @@ __global__ void k_scatter_gathered(int nverts, int gppr, const int* __restrict__
       if (b + base + k < e) w += x;
     }
   }
-  if (in && sub == 0) scatter_w[t] = w;
+  if (in && sub == 0) {
+    scatter_w[t] = w;
+    if (scatter_w2) scatter_w2[t] = w;  // a second map with the same transpose: the same sums in the same order
+  }
 }
 __global__ void k_sync_pack(int nverts, const double* __restrict__ f, const double* __restrict__ b,
                             double* __restrict__ out) {
@@ -438,12 +441,21 @@ int gyro_scatter_counts(const pp_mesh* mesh, const int* cnt_dev, int nmaps, cons
       for (int j = 0; j < k && same < 0; ++j)
         if (!no_gather && find_inverse(v2v_dev[j], mesh, gnr, gppr) == inv && out_dev[j] != out_dev[k]) same = j;
       if (same >= 0) {
+        if (same == k - 1) continue;  // (written by the launch of map k-1, below)
         PP_HIP_CHECK(hipMemcpyAsync(out_dev[k], out_dev[same], sizeof(double) * (size_t)nverts,
                                     hipMemcpyDeviceToDevice, st));
         continue;
       }
+      // the next map shares this one's transpose (forward / backward of one call): one launch writes both fields
+      double* twin = nullptr;
+      if (k + 1 < nmaps && out_dev[k + 1] != out_dev[k] && find_inverse(v2v_dev[k + 1], mesh, gnr, gppr) == inv) {
+        bool first_same = true;  // (map k+1 must resolve to `same == k`, i.e. no earlier map shares it)
+        for (int j = 0; j < k; ++j)
+          if (find_inverse(v2v_dev[j], mesh, gnr, gppr) == inv && out_dev[j] != out_dev[k + 1]) first_same = false;
+        if (first_same) twin = out_dev[k + 1];
+      }
       k_scatter_gathered<<<grid_for((size_t)nverts * 16), kBlock, 0, st>>>(
-          nverts, gppr, inv->off.as<int>(), inv->src.as<int>(), g_ring->as<double>(), out_dev[k]);
+          nverts, gppr, inv->off.as<int>(), inv->src.as<int>(), g_ring->as<double>(), out_dev[k], twin);
     } else {
       PP_HIP_CHECK(hipMemsetAsync(out_dev[k], 0, sizeof(double) * (size_t)nverts, st));
       k_scatter_mapped<<<grid_for((size_t)nverts * gnr * gppr), kBlock, 0, st>>>(
