@@ -656,6 +656,10 @@ def main():
     pp = pumipic_amd_loader.load()
     from pumipic_amd import capi
     capi.init(local_rank)  # raises when the HIP library / GPU is missing: no CPU fallback
+    # PyTorch creates its HIP context lazily at the first torch.cuda call -- 50-60 ms on a fresh box, which used
+    # to land inside the first timed region (the barrier's torch.cuda.synchronize()): seen as sporadic
+    # 3 ms/step `cold_clocks` values in round 3's runs.  Pay it here, before anything is timed.
+    torch.cuda.synchronize()
     global WATCHDOG
     wd_limit = a.watchdog if a.watchdog is not None else (120.0 if world > 1 else 0.0)
     # (building a 32 M-particle population is minutes of numpy on the host: the set-up phase gets its own,
