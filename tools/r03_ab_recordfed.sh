@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3: record-fed push (deferred second pass of the re-layout): new tests, the fused-flow tests, c3 A/B
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r03_try3
+O=$R/gpurun_out/r03_ab_recordfed
 mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests/test_gpu_lazy.py -x -q > $O/pytest_lazy.txt 2>&1
