@@ -223,6 +223,9 @@ struct pp_ps {
   pp::DevBuf s_aos_live;
   pp::DevBuf s_rs, s_holes;  // in-place rebuild: per-element counters, per-row hole lists
   // scratch reused across rebuilds
+  void* ppe_zeroed = nullptr;  // == s_ppe.p: that buffer was cleared by the previous re-layout's tail
+  size_t ppe_zeroed_bytes = 0;
+  int wide_skip = 0;  // full re-layouts left before the one-pass layout sort is tried again (it overflowed)
   pp::DevBuf s_ppe, s_keys, s_keys2, s_vals, s_vals2, s_hist, s_chunkw, s_misc, s_rowstart,
       s_newidx, s_offsets2, s_s2c2, s_r2e2, s_e2r2, s_mask2, s_slot2, s_scan, s_cstart2, s_cwidth2, s_aos, s_idx, s_ranknew, s_eslot0, s_scan2;
 };

@@ -208,7 +208,9 @@ struct Totals {  // s_misc layout
   unsigned long long max_key;  // largest sort key of this rebuild (radix passes above it are skipped)
   // in-place rebuild: rows whose new count exceeds their chunk width, rows that traded places,
   // "no home found for an overflowing row"
-  int n_over, pad_[3];  // rows whose new count exceeds their chunk width (the reference then re-lays out)
+  int n_over;    // rows whose new count exceeds their chunk width (the reference then re-lays out)
+  int sort_bad;  // one-pass layout sort: more keys in the overflow digit than its fix-up holds (re-sort with every pass)
+  int pad_[2];
 };
 
 __global__ void k_count_added(int n_new, const int* __restrict__ new_elems, int ne,
@@ -237,42 +239,65 @@ struct ElemTotalsArgs {
   // atomics on the totals (every block ends with three atomics on the same counters, ~10 ns each queued)
   int* partial;
 };
-// fused form of the radix passes (k_rs_pass, ne <= kFusedSortBlocks tiles): the sweep that makes the keys
-// also counts the first pass's digits per tile (h0); hzero is scratch it clears.
+// fused form of the radix passes (k_rs_pass / k_rs_pass_wide, ne <= kFusedSortBlocks tiles): the sweep that
+// makes the keys also counts the first pass's digits per tile.
+constexpr int kWideBits = 11, kWideDigits = 1 << kWideBits;
 struct FusedHist {
-  int* h0;    // [256][nblk]: digit counts of the first pass per tile (null = the separate-launch sort)
-  int* hzero; // table of the second pass, cleared here
+  int* h0;   // digit counts of the first pass per tile: [256][nblk], wide: [nblk][kWideDigits] (null = separate launches)
   int nblk;
+  int wide;  // the ONE pass over an 11-bit digit; keys of 2047 and more share the last digit (k_rs_pass_wide)
 };
+__device__ __forceinline__ int wide_digit(unsigned long long key) {
+  return key < (unsigned long long)(kWideDigits - 1) ? (int)key : kWideDigits - 1;
+}
 __global__ void k_make_keys(int ne, const int* __restrict__ ppe, int sigma, int n_sigma,
                             unsigned long long base, unsigned long long* __restrict__ keys,
                             int* __restrict__ vals, Totals* tot, int no_skip, ElemTotalsArgs et,
-                            FusedHist fh = FusedHist{nullptr, nullptr, 0}) {
+                            FusedHist fh = FusedHist{nullptr, 0, 0}) {
   unsigned long long mx = 0;
   int nz = 0, sum = 0, over = 0;
   const int base_i = blockIdx.x * RS_TILE;
-  __shared__ int s_h0[256];
+  __shared__ int s_h0[kWideDigits];
+  const int dmask = fh.wide ? kWideDigits - 1 : 255;  // (digits of the first pass)
   if (fh.h0) {
-    s_h0[threadIdx.x] = 0;
+    for (int d = threadIdx.x; d <= dmask; d += 256) s_h0[d] = 0;
     __syncthreads();
   }
-  for (int j = threadIdx.x; j < RS_TILE; j += 256) {
-    const int i = base_i + j;
+  // (loads of the whole tile first -- counts, then the old row and chunk width of the fit test: three dependent
+  // global loads per element would otherwise be paid eight times in a row)
+  constexpr int R = RS_TILE / 256;
+  int nn[R], cw_old[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = base_i + r * 256 + threadIdx.x;
+    nn[r] = i < ne ? ppe[i] : 0;
+    cw_old[r] = (et.fit && i < ne) ? et.e2r_old[i] : 0;
+  }
+  if (et.fit) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = base_i + r * 256 + threadIdx.x;
+      cw_old[r] = i < ne ? et.chunk_width_old[cw_old[r] / et.C_old] : 0;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = base_i + r * 256 + threadIdx.x;
     if (i >= ne) break;
     int w = 0;
     if (sigma > 0) {
       w = i / sigma;
       if (w > n_sigma - 1) w = n_sigma - 1;
     }
-    const int n = ppe[i];
+    const int n = nn[r];
     const unsigned long long key = (unsigned long long)w * base + (unsigned long long)n;
     keys[i] = key;
     vals[i] = i;
-    if (fh.h0) atomicAdd(&s_h0[(int)(key & 255ull)], 1);
+    if (fh.h0) atomicAdd(&s_h0[fh.wide ? wide_digit(key) : (int)(key & 255ull)], 1);
     mx = key > mx ? key : mx;
     nz += n > 0;
     sum += n;
-    if (et.fit) over += n > et.chunk_width_old[et.e2r_old[i] / et.C_old];
+    if (et.fit) over += n > cw_old[r];
   }
   if (et.totals) {
     __shared__ int s_t[4][3];
@@ -307,8 +332,10 @@ __global__ void k_make_keys(int ne, const int* __restrict__ ppe, int sigma, int 
   }
   if (fh.h0) {
     __syncthreads();
-    fh.h0[threadIdx.x * fh.nblk + blockIdx.x] = s_h0[threadIdx.x];
-    fh.hzero[threadIdx.x * fh.nblk + blockIdx.x] = 0;
+    if (fh.wide)
+      for (int d = threadIdx.x; d < kWideDigits; d += 256) fh.h0[(size_t)blockIdx.x * kWideDigits + d] = s_h0[d];
+    else
+      fh.h0[threadIdx.x * fh.nblk + blockIdx.x] = s_h0[threadIdx.x];
   }
   // the host sizes the number of 8-bit passes from an upper bound (total particles); the real
   // maximum (a per-element count) usually needs one or two passes: later passes see it and copy.
@@ -423,10 +450,11 @@ __global__ void k_rs_pass(int n, const unsigned long long* __restrict__ keys, co
   {
     int total = 0, mine = 0;
     const int* row = hist + t * nblk;
-    for (int b = 0; b < nblk; ++b) {
+#pragma unroll 8
+    for (int b = 0; b < nblk; ++b) {  // (independent loads in flight: the loop is latency-bound)
       const int h = row[b];
       total += h;
-      if (b < (int)blockIdx.x) mine += h;
+      mine += b < (int)blockIdx.x ? h : 0;
     }
     // exclusive scan of `total` over the 256 digits
     int incl = total;
@@ -475,6 +503,105 @@ __global__ void k_rs_pass(int n, const unsigned long long* __restrict__ keys, co
     __syncthreads();
     base_d[t] += wave_cnt[0][t] + wave_cnt[1][t] + wave_cnt[2][t] + wave_cnt[3][t];
     __syncthreads();
+  }
+}
+// The whole sort as ONE counting pass, for structures with one sort window (the keys are the per-element
+// counts): digit = min(key, 2047).  Counts of ~100 per element resolve exactly; the few rows above 2046 (the
+// literal pseudoXGCm population piles its remainder into one element) land in the last digit in element order
+// and are ordered by k_layout_fused's prologue (wide_fix_tail: up to 1024 of them, else Totals::sort_bad and
+// the caller re-sorts with every 8-bit pass).  Two 8-bit passes + the second histogram cost 34 us at 100 800
+// elements.  hist is [nblk][kWideDigits] (k_make_keys).  Ranks inside the tile
+// as in k_rs_pass, with 16 waves per tile (two rounds); the per-wave counts live in a [16][2048] byte table
+// whose used entries are put back to zero by their writers.
+constexpr int kWideThreads = 1024;
+__global__ void __launch_bounds__(kWideThreads)
+    k_rs_pass_wide(int n, const unsigned long long* __restrict__ keys, const int* __restrict__ vals, int nblk,
+                   const int* __restrict__ hist, unsigned long long* __restrict__ keys_out,
+                   int* __restrict__ vals_out) {
+  constexpr int NW = kWideThreads / 64, R = RS_TILE / kWideThreads, K = kWideDigits / kWideThreads;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  __shared__ int base_d[kWideDigits];                   // next output position of this tile's keys with digit d
+  __shared__ unsigned char wave_cnt[NW][kWideDigits];   // (a wave holds at most 64 keys of one digit)
+  __shared__ int s_part[NW];
+  // this tile's keys first: their loads fly while the digit table is summed
+  const int tile0 = blockIdx.x * RS_TILE;
+  unsigned long long key[R];
+  int val[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = tile0 + r * kWideThreads + t;
+    key[r] = i < n ? keys[i] : 0ull;
+    val[r] = i < n ? vals[i] : 0;
+  }
+  for (int q = t; q < NW * kWideDigits / 16; q += kWideThreads) ((uint4*)&wave_cnt[0][0])[q] = make_uint4(0, 0, 0, 0);
+  {
+    int total[K], mine[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) total[k] = mine[k] = 0;
+    // (thread t owns digits k*1024 + t.  The table was written by the previous kernel's blocks on other XCDs:
+    // every batch of loads costs a trip past the L2, so 16 rows = 32 loads are in flight at a time)
+    for (int b0 = 0; b0 < nblk; b0 += 16) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int b = b0 + j;
+        const int* row = hist + (size_t)min(b, nblk - 1) * kWideDigits + t;
+        const bool before = b < (int)blockIdx.x;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int h = b < nblk ? row[k * kWideThreads] : 0;
+          total[k] += h;
+          mine[k] += before ? h : 0;
+        }
+      }
+    }
+    int carry = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {  // exclusive scan over the digits in order d = k*1024 + t
+      int incl = total[k];
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+      }
+      if (lane == 63) s_part[wave] = incl;
+      __syncthreads();
+      int off = 0, all = 0;
+      for (int w = 0; w < NW; ++w) {
+        const int p = s_part[w];
+        off += w < wave ? p : 0;
+        all += p;
+      }
+      base_d[k * kWideThreads + t] = carry + off + incl - total[k] + mine[k];
+      carry += all;
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool valid = tile0 + r * kWideThreads + t < n;
+    const int digit = wide_digit(key[r]);
+    unsigned long long same = __ballot(valid);  // lanes of this wave holding the same digit
+    for (int b = 0; b < kWideBits; ++b) {
+      const unsigned long long bal = __ballot(valid && ((digit >> b) & 1));
+      same &= ((digit >> b) & 1) ? bal : ~bal;
+    }
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int rank_in_wave = __popcll(same & lt);
+    const bool leader = valid && rank_in_wave == 0;
+    const int cnt = __popcll(same);
+    if (leader) wave_cnt[wave][digit] = (unsigned char)cnt;  // own row: zeroed by this wave's leaders last round
+    __syncthreads();
+    if (valid) {
+      int off = base_d[digit];
+      for (int w = 0; w < wave; ++w) off += wave_cnt[w][digit];
+      const int pos = off + rank_in_wave;
+      keys_out[pos] = key[r];
+      vals_out[pos] = val[r];
+    }
+    __syncthreads();
+    if (leader) {
+      atomicAdd(&base_d[digit], cnt);
+      wave_cnt[wave][digit] = 0;
+    }
   }
 }
 // ---- single-block exclusive scan (int); total written to *total if non-null
@@ -736,7 +863,7 @@ __device__ __forceinline__ void spec_decide(Totals* tot, int cap_lim, int nsl_li
     tot->go = 0;
     return;
   }
-  tot->go = (!tot->invalid && tot->active > 0 && tot->nonempty >= C_max && tot->capacity <= cap_lim &&
+  tot->go = (!tot->invalid && !tot->sort_bad && tot->active > 0 && tot->nonempty >= C_max && tot->capacity <= cap_lim &&
              tot->nslices <= nsl_lim && (key_bits >= 64 || (tot->max_key >> key_bits) == 0))
                 ? 1
                 : 0;
@@ -811,6 +938,42 @@ __global__ void k_reduce_widths(int nchunks, const int* __restrict__ widths, Tot
     tot->cw_cnt = Cn;
   }
 }
+// Prologue of the layout kernel after k_rs_pass_wide (one block of 1024 threads): the keys of the overflow
+// digit sit at the end of the sorted arrays in element order; order them by key, ties by position (= the
+// stable order the 8-bit passes produce).
+__device__ void wide_fix_tail(int ne, int nblk, const int* __restrict__ hist, unsigned long long* keys,
+                              int* vals, Totals* tot) {
+  __shared__ unsigned long long fk[1024];
+  __shared__ int fv[1024];
+  __shared__ int s_n[16];
+  const int t = threadIdx.x;
+  int n = 0;
+  for (int b = t; b < nblk; b += 1024) n += hist[(size_t)b * kWideDigits + kWideDigits - 1];
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
+  if ((t & 63) == 0) s_n[t >> 6] = n;
+  __syncthreads();
+  n = 0;
+  for (int w = 0; w < 16; ++w) n += s_n[w];
+  if (n <= 1) return;  // (block-uniform)
+  if (n > 1024) {
+    if (t == 0) tot->sort_bad = 1;
+    return;
+  }
+  const int start = ne - n;
+  if (t < n) {
+    fk[t] = keys[start + t];
+    fv[t] = vals[start + t];
+  }
+  __syncthreads();
+  if (t < n) {
+    const unsigned long long k = fk[t];
+    int r = 0;
+    for (int j = 0; j < n; ++j) r += (fk[j] < k) || (fk[j] == k && j < t);
+    keys[start + r] = k;
+    vals[start + r] = fv[t];
+  }
+  __syncthreads();
+}
 // One block does the whole O(nchunks) part of the layout that used to be seven launches:
 // width reduction (cw_sum, cw_cnt), padding (EVENLY / PROPORTIONALLY / none; INVERSELY needs the
 // ordered fp sum and keeps the separate kernels), slices / slots / tiles per chunk and their three
@@ -820,7 +983,11 @@ __global__ void __launch_bounds__(1024)
                    int* __restrict__ widths, int* __restrict__ slice_off,
                    int* __restrict__ chunk_start, int* __restrict__ tile_off, Totals* tot,
                    int* __restrict__ ntiles_out, SpecArgs sp, int key_bits,
-                   const int* __restrict__ partial, int npartial) {
+                   const int* __restrict__ partial, int npartial,
+                   const unsigned long long* keys_sorted = nullptr, int ne = 0,
+                   unsigned long long* fix_keys = nullptr, int* fix_vals = nullptr,
+                   const int* __restrict__ wide_hist = nullptr) {
+  if (fix_keys) wide_fix_tail(ne, npartial, wide_hist, fix_keys, fix_vals, tot);
   __shared__ int ssum[16], scnt[16];
   __shared__ int w3[16][3];
   __shared__ int carry[3];
@@ -859,8 +1026,12 @@ __global__ void __launch_bounds__(1024)
   {  // ---- reduction of the unpadded widths
     int s = 0, c = 0;
     for (int i = t; i < nchunks; i += 1024) {
-      s += widths[i];
-      c += widths[i] > 0;
+      // keys_sorted: one sort window, keys = counts in ascending order -- a chunk's widest row is its last
+      // (k_chunk_widths2 folded in: one launch less)
+      const int w = keys_sorted ? (int)keys_sorted[min(i * C + C - 1, ne - 1)] : widths[i];
+      if (keys_sorted) widths[i] = w;
+      s += w;
+      c += w > 0;
     }
     for (int o = 32; o > 0; o >>= 1) {
       s += __shfl_down(s, o);
@@ -1040,9 +1211,13 @@ __global__ void k_init_slots_tiled(const int* __restrict__ ntiles_dev, int C, in
                                    const int* __restrict__ ppe, int ne,
                                    int* __restrict__ slot_elem, int* __restrict__ row_cursor,
                                    int* __restrict__ elem_slot0, unsigned char* __restrict__ new_mask,
-                                   const int* __restrict__ go) {
+                                   const int* __restrict__ go, int* __restrict__ zero_next = nullptr,
+                                   int zero_words = 0) {
   if (!*go) return;
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // the histogram + totals block of the NEXT rebuild (today's d_elem_count, free once this tail runs) is
+  // cleared here instead of by a fill at the start of that rebuild (a fill is a ~6 us dispatch)
+  for (long long i = g; i < zero_words; i += (long long)gridDim.x * blockDim.x) zero_next[i] = 0;
   const int tile = (int)(g / C), r = (int)(g - (long long)tile * C);
   if (tile >= *ntiles_dev) return;
   const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
@@ -1894,6 +2069,7 @@ struct LayoutPlan {
   int C, nchunks, nrows;
   int key_bits;  // key bits the radix passes of this attempt covered (64 = every bit)
   bool sorted;
+  bool wide;  // sorted by k_rs_pass_wide: the layout kernel orders the overflow digit
   unsigned long long base;
   unsigned long long* keys;
   int* index;
@@ -1904,9 +2080,11 @@ struct LayoutPlan {
 // from the previous rebuild and checks the prediction against Totals::max_key afterwards)
 int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_base, LayoutPlan& L,
                    int bits_limit = 0, ElemTotalsArgs et = ElemTotalsArgs{0, 0, 1, nullptr, nullptr, nullptr},
-                   SpecArgs sp = SpecArgs{0, 0, 0, 0, 0}, const LayoutTablesArgs* tables = nullptr) {
+                   SpecArgs sp = SpecArgs{0, 0, 0, 0, 0}, const LayoutTablesArgs* tables = nullptr,
+                   bool allow_wide = false) {
   hipStream_t st = pp::stream();
   const int ne = ps->num_elems;
+  L.wide = false;
   L.C = C_new;
   L.nchunks = ne / C_new + (ne % C_new != 0);
   L.nrows = L.nchunks * C_new;
@@ -1923,20 +2101,14 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
     PP_HIP_CHECK(ps->s_vals.reserve(sizeof(int) * (size_t)ne));
     PP_HIP_CHECK(ps->s_vals2.reserve(sizeof(int) * (size_t)ne));
     const int nblk = (ne + RS_TILE - 1) / RS_TILE;
-    PP_HIP_CHECK(ps->s_hist.reserve(sizeof(int) * (256 * (size_t)nblk * 3 + 3 * (size_t)nblk)));
+    PP_HIP_CHECK(ps->s_hist.reserve(sizeof(int) * (std::max(256 * (size_t)nblk * 3, (size_t)nblk * kWideDigits) +
+                                                   3 * (size_t)nblk)));
     // the layout kernel below adds up the per-block totals (the inversely-padded layout has no such kernel)
-    et.partial = (et.totals && !(ps->pad_strat == PP_PAD_INVERSELY && ps->shuffle_padding > 0))
-                     ? ps->s_hist.as<int>() + 256 * (size_t)nblk * 3
-                     : nullptr;
-    static const bool no_fused_sort = getenv("PP_NO_FUSED_SORT") != nullptr;  // A/B knob
+    int* const partial_at = ps->s_hist.as<int>() + std::max(256 * (size_t)nblk * 3, (size_t)nblk * kWideDigits);
+    et.partial = (et.totals && !(ps->pad_strat == PP_PAD_INVERSELY && ps->shuffle_padding > 0)) ? partial_at : nullptr;
+    static const bool no_fused_sort = getenv("PP_NO_FUSED_SORT") != nullptr;  // A/B knobs
+    static const bool no_wide_sort = getenv("PP_NO_WIDE_SORT") != nullptr;
     const bool fused_sort = nblk <= kFusedSortBlocks && !no_fused_sort;
-    int* const H0 = ps->s_hist.as<int>();
-    int* const Hs[3] = {H0, H0 + 256 * (size_t)nblk, H0 + 256 * (size_t)nblk * 2};
-    k_make_keys<<<nblk, 256, 0, st>>>(ne, ppe, sg, n_sigma, L.base,
-                                                 ps->s_keys.as<unsigned long long>(),
-                                                 ps->s_vals.as<int>(), tot,
-                                                 getenv("PP_NO_RS_SKIP") != nullptr, et,
-                                                 fused_sort ? FusedHist{Hs[0], Hs[1], nblk} : FusedHist{nullptr, nullptr, 0});
     unsigned long long maxkey = (unsigned long long)(n_sigma > 0 ? n_sigma : 1) * L.base;
     int bits = 0;
     while (bits < 64 && (maxkey >> bits)) ++bits;
@@ -1945,14 +2117,30 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
       bits = bits_limit;
       L.key_bits = (bits + 7) / 8 * 8;
     }
+    // one sort window (the keys are the counts): ONE counting pass, see k_rs_pass_wide
+    const bool wide_sort = fused_sort && !no_wide_sort && allow_wide && n_sigma <= 1 && ps->wide_skip == 0 &&
+                           (ps->pad_strat != PP_PAD_INVERSELY || !(ps->shuffle_padding > 0));  // (needs k_layout_fused)
+    L.wide = wide_sort;
+    if (wide_sort) L.key_bits = 64;  // (its own check: Totals::sort_bad)
+    int* const H0 = ps->s_hist.as<int>();
+    k_make_keys<<<nblk, 256, 0, st>>>(ne, ppe, sg, n_sigma, L.base,
+                                                 ps->s_keys.as<unsigned long long>(),
+                                                 ps->s_vals.as<int>(), tot,
+                                                 getenv("PP_NO_RS_SKIP") != nullptr, et,
+                                                 fused_sort ? FusedHist{H0, nblk, wide_sort ? 1 : 0} : FusedHist{nullptr, 0, 0});
     unsigned long long *ka = ps->s_keys.as<unsigned long long>(),
                        *kb = ps->s_keys2.as<unsigned long long>();
     int *va = ps->s_vals.as<int>(), *vb = ps->s_vals2.as<int>();
     int* hist = ps->s_hist.as<int>();
     int* hist_sc = hist + 256 * nblk;
-    for (int shift = 0; fused_sort && shift < bits; shift += 8) {
-      if (shift > 0) k_rs_hist<<<nblk, 256, 0, st>>>(ne, ka, shift, nblk, Hs[0], tot);  // (pass 0: k_make_keys)
-      k_rs_pass<<<nblk, 256, 0, st>>>(ne, ka, va, shift, nblk, Hs[0], kb, vb, tot);
+    if (wide_sort) {
+      k_rs_pass_wide<<<nblk, kWideThreads, 0, st>>>(ne, ka, va, nblk, H0, kb, vb);
+      std::swap(ka, kb);
+      std::swap(va, vb);
+    }
+    for (int shift = 0; fused_sort && !wide_sort && shift < bits; shift += 8) {
+      if (shift > 0) k_rs_hist<<<nblk, 256, 0, st>>>(ne, ka, shift, nblk, H0, tot);  // (pass 0: k_make_keys)
+      k_rs_pass<<<nblk, 256, 0, st>>>(ne, ka, va, shift, nblk, H0, kb, vb, tot);
       std::swap(ka, kb);
       std::swap(va, vb);
     }
@@ -1977,14 +2165,22 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
   L.tile_cnt = L.slice_off + nchunks;
   L.tile_off = L.tile_cnt + nchunks;
   L.chunk_start = ps->s_cstart2.as<int>();
-  k_chunk_widths2<<<grid_for((size_t)nchunks * 64), kBlock, 0, st>>>(
-      nchunks, C_new, ne, L.keys, L.base, L.sorted ? 1 : 0, ppe, L.widths);
+  const bool fused_layout = ps->pad_strat != PP_PAD_INVERSELY || !(ps->shuffle_padding > 0);
+  // one sort window: the keys are the counts, ascending -- the layout kernel reads a chunk's width off its last row
+  // (after the one-pass sort it has to: the overflow digit is ordered by that kernel's prologue)
+  const bool widths_in_layout = fused_layout && L.sorted && ne > 0 && ne / std::min(ps->sigma, std::max(ne, 1)) <= 1 &&
+                                (L.wide || getenv("PP_NO_FUSED_WIDTHS") == nullptr);
+  if (!widths_in_layout)
+    k_chunk_widths2<<<grid_for((size_t)nchunks * 64), kBlock, 0, st>>>(
+        nchunks, C_new, ne, L.keys, L.base, L.sorted ? 1 : 0, ppe, L.widths);
   PP_HIP_CHECK(ps->s_scan.reserve(sizeof(int)));
-  if (ps->pad_strat != PP_PAD_INVERSELY || !(ps->shuffle_padding > 0)) {
+  if (fused_layout) {
     k_layout_fused<<<1, 1024, 0, st>>>(nchunks, C_new, ps->V, ps->tile_p, ps->pad_strat,
                                        ps->shuffle_padding, L.widths, L.slice_off, L.chunk_start,
                                        L.tile_off, tot, ps->s_scan.as<int>(), sp, L.key_bits,
-                                       L.sorted ? et.partial : nullptr, (ne + RS_TILE - 1) / RS_TILE);
+                                       L.sorted ? et.partial : nullptr, (ne + RS_TILE - 1) / RS_TILE,
+                                       widths_in_layout ? L.keys : nullptr, ne, L.wide ? L.keys : nullptr,
+                                       L.wide ? L.index : nullptr, L.wide ? ps->s_hist.as<int>() : nullptr);
   } else {
     k_reduce_widths<<<1, 1024, 0, st>>>(nchunks, L.widths, tot);
     k_cw_inv_serial<<<1, 64, 0, st>>>(nchunks, L.widths, tot);
@@ -2215,7 +2411,10 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   // histogram and totals in one allocation: one fill clears both (a fill is a ~5 us dispatch)
   const size_t tot_off = (sizeof(int) * (size_t)std::max(ne, 1) + 255) / 256 * 256;
   PP_HIP_CHECK(ps->s_ppe.reserve(tot_off + sizeof(Totals)));
-  PP_HIP_CHECK(hipMemsetAsync(ps->s_ppe.p, 0, tot_off + sizeof(Totals), st));
+  // (cleared by the tail of the previous full re-layout when that is what this buffer last saw: pp_ps::ppe_zeroed)
+  if (!(ps->ppe_zeroed == ps->s_ppe.p && ps->ppe_zeroed_bytes >= tot_off + sizeof(Totals)))
+    PP_HIP_CHECK(hipMemsetAsync(ps->s_ppe.p, 0, tot_off + sizeof(Totals), st));
+  ps->ppe_zeroed = nullptr;
   Totals* tot = (Totals*)((char*)ps->s_ppe.p + tot_off);
   int* ppe = ps->s_ppe.as<int>();
   const bool have_old = ps->capacity > 0 && ps->num_ptcls > 0;
@@ -2350,13 +2549,17 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
                           ElemTotalsArgs{totals_in_keys ? 1 : 0, (totals_in_keys && decide_keep) ? 1 : 0, ps->C,
                                          ps->d_element_to_row.as<int>(), ps->d_chunk_width.as<int>(), nullptr},
                           SpecArgs{spec_ok ? 1 : 0, (int)cap_lim, (int)nsl_lim, ps->C_max, decide_keep ? 1 : 0},
-                          spec_ok ? &ta_spec : nullptr);
+                          spec_ok ? &ta_spec : nullptr, /*allow_wide=*/true);
   if (rc) return rc;
   nchunks = L.nchunks;
   nrows = L.nrows;
   const int* go = &tot->go;
   int NQ = 0;
   bool lazy_zero = false, defer_unpack = false;
+  // today's per-element counts are not read by a re-layout that commits: its tail clears them for the next one
+  static const bool no_prezero = getenv("PP_NO_PREZERO") != nullptr;
+  const bool prezero = !no_prezero && ps->d_elem_count.p && ps->d_elem_count.p != ps->s_ppe.p &&
+                       ps->d_elem_count.bytes >= tot_off + sizeof(Totals);
   // Everything after the layout: new layout arrays, slot tables and the move of every member.
   // `cap_sz` / `nsl_sz` size the buffers and the launches; the kernels themselves read the true
   // counts from the device (ntiles, Totals), and all of them return at once when tot->go == 0.
@@ -2369,7 +2572,8 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     k_init_slots_tiled<<<grid_for((size_t)ntiles_max * C_new), kBlock, 0, st>>>(
         new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_r2e2.as<int>(),
         ppe, ne, ps->s_slot2.as<int>(), ps->s_rowstart.as<int>(), ps->s_eslot0.as<int>(),
-        ps->s_mask2.as<unsigned char>(), go);
+        ps->s_mask2.as<unsigned char>(), go, prezero ? ps->d_elem_count.as<int>() : nullptr,
+        prezero ? (int)((tot_off + sizeof(Totals)) / sizeof(int)) : 0);
     // ---- swap buffer sizing (SCS_rebuild.h:223-229)
     int64_t swap_stride = ps->swap_stride;
     if (stride_fixed > 0) {  // speculative tail: whatever the swap buffers hold today
@@ -2524,7 +2728,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     // particles -- redo the (tiny) layout with that height; same when the predicted number of
     // radix passes did not cover the largest key
     C_new = std::min(h.nonempty, ps->C_max);
-    const bool sort_ok = L.key_bits >= 64 || (h.max_key >> L.key_bits) == 0;
+    const bool sort_ok = (L.key_bits >= 64 || (h.max_key >> L.key_bits) == 0) && !h.sort_bad;
     if (C_new != ps->C_max || !sort_ok) {
       PP_HIP_CHECK(hipMemsetAsync(&tot->cw_sum, 0, sizeof(int) * 2, st));
       rc = enqueue_layout(ps, C_new, ppe, tot, key_base, L);
@@ -2544,6 +2748,9 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     rc = enqueue_tail(h.capacity, h.nslices, 0);
     if (rc) return rc;
   }
+  // (a population whose rows mostly exceed the one-pass sort's digit range: the 8-bit passes for a while)
+  if (h.sort_bad) ps->wide_skip = 64;
+  else if (ps->wide_skip > 0) --ps->wide_skip;
   ps->last_max_key = h.max_key;
   const int new_capacity = h.capacity, new_nslices = h.nslices;
   ntiles_max = nchunks + new_capacity / (C_new * ps->tile_p) + 1;  // launch bound of the next calls
@@ -2570,6 +2777,10 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   ps->d_tiles.swap(ps->s_newidx);
   ps->d_ntiles.swap(ps->s_scan);
   ps->d_elem_count.swap(ps->s_ppe);  // live particles per element == the histogram just built
+  if (prezero) {
+    ps->ppe_zeroed = ps->s_ppe.p;
+    ps->ppe_zeroed_bytes = tot_off + sizeof(Totals);
+  }
   ps->d_eslot0.swap(ps->s_eslot0);
   ps->elem_count_valid = true;
   ps->version = pp::next_version();

@@ -1048,7 +1048,8 @@ __global__ void __launch_bounds__(256, OCC)
                      double* __restrict__ xt, long long stride, const float* __restrict__ pb,
                      float* pphi, double h, double k, double d, double deg, double tol,
                      double unmoved_sq, int* elem_ids, int seeded, int looplimit, Counters* cnt,
-                     RecIn rin = RecIn{}) {
+                     Counters* cnt_next, RecIn rin = RecIn{}) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *cnt_next = Counters{};  // for the next pp_push_search
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int tile = (int)(g / C);
   const int r = (int)(g - (long long)tile * C);
@@ -1950,7 +1951,7 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
       ps->d_mask.as<unsigned char>(), mesh->d_records.p, mesh->d_class_id.as<int>(),             \
       mesh->nelems, PP_MEMBER(ps, m_x, double), PP_MEMBER(ps, m_xtgt, double), ps->stride,       \
       PP_MEMBER(ps, m_b, float), PP_MEMBER(ps, m_phi, float), h, k, d, deg, mesh->tol,           \
-      mesh->unmoved_sq, elem_ids_dev, elem_ids_seeded, looplimit, g_cnt.get()
+      mesh->unmoved_sq, elem_ids_dev, elem_ids_seeded, looplimit, used, g_cnt2 + (g_cnt2_cur ^ 1)
 #define PP_ROWSQ_ARGS                                                                            \
   ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(), \
       ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(),                               \
@@ -1969,13 +1970,9 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
     // faster with the deferred walk; 2-D (64-B records, cheap steps) is faster in one kernel.
     // PP_WALK_QUEUE=0/1 forces one or the other (A/B knob).
     const int trust = ps->trust_origins ? 1 : 0;
-    if (!(rgrid > 0 && wq > 0)) {
-      if ((rc = reset_counters())) return rc;
-      used = g_cnt.get();
-    } else {
-      if ((rc = pair_counters())) return rc;
-      used = g_cnt2 + g_cnt2_cur;
-    }
+    // (two counter sets used alternately: the kernels of a call clear the set of the next one -- no fill launch)
+    if ((rc = pair_counters())) return rc;
+    used = g_cnt2 + g_cnt2_cur;
     if (rgrid > 0 && wq > 0) {
       const size_t lds = (size_t)(kBlock / 64) * 64 * (mesh->dim == 3 ? 8 : 4) * sizeof(double2);
       const size_t nwaves = (size_t)rgrid * (kBlock / 64);
@@ -2013,6 +2010,7 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
         k_push_walk_rows<2, 4><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS);
       else
         k_push_walk_rows<3, 4><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS);
+      g_cnt2_cur ^= 1;
     }
 #undef PP_ROWS_ARGS
 #undef PP_ROWSQ_ARGS

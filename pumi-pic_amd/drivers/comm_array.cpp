@@ -3,7 +3,7 @@
 // comm arrays from createCommArray, Mesh::reduceCommArray through the owners (pp_picpart_reduce).  Runs as
 // one rank or as several rank processes (PP_COMM=tcp, RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
 //   comm_array <mesh.bin> <partition file: one owner per element> [buffer layers] [safe layers]
-// Entity dimensions: vertices, sides and elements (pp_mesh numbers no edges of tets).
+// Entity dimensions: 0..dim as the reference loops them (edges of tets included, pp_mesh_num_edges).
 #include <climits>
 #include <cmath>
 #include <cstdio>

@@ -535,6 +535,52 @@ def test_rebuild_matches_oracle(ppo, synth, capi, kind, C, V, sigma, pad, shuffl
         assert np.array_equal(np.repeat(np.arange(ne), np.diff(off)), se[pids])
 
 
+@pytest.mark.parametrize("heavy", [6, 1100])
+def test_rebuild_layout_sort_with_heavy_rows(ppo, capi, heavy):
+    """The one-pass layout sort (k_rs_pass_wide) keeps rows of 2047 and more particles in one digit and orders
+    them in the layout kernel (up to 1024 rows; more than that: the 8-bit passes run instead).  Heavy rows with
+    ties, light rows around them, rows that become heavy / light from one rebuild to the next: layout arrays
+    and population equal the oracle's (stable ascending order, SCS_sort.h)."""
+    ne = 3000
+    rng = np.random.default_rng(heavy)
+    n = heavy * 2060 + 80000 + 20 * ne
+
+    def counts(step):
+        idx = rng.permutation(ne)
+        c = np.zeros(ne, dtype=np.int64)
+        c[idx[:heavy]] = rng.integers(2040, 2060, size=heavy)  # around the digit boundary, many ties
+        c[idx[:3]] = [5000, 5000, 2047] if step % 2 == 0 else [2046, 70000 // (step + 1), 2048]
+        light = idx[heavy:]
+        c[light] = rng.multinomial(n - int(c.sum()), np.full(len(light), 1.0 / len(light)))
+        return c
+
+    c0 = counts(0)
+    elem = np.repeat(np.arange(ne, dtype=np.int32), c0)
+    xyz = rng.random((3, n))
+    info = [xyz, np.zeros_like(xyz), np.arange(n, dtype=np.int32), rng.random(n).astype(np.float32),
+            rng.random(n).astype(np.float32)]
+    kw = dict(sigma=2**31 - 1, V=1024, pad_strat=0, particle_elements=elem, particle_info=info)
+    po = ppo.PS.scs(ppo.PARTICLE_XGCM, ne, c0.astype(np.int32), C_max=64, **kw)
+    pg = capi.PS.scs(capi.PARTICLE_XGCM, ne, c0.astype(np.int32), C_=64, **kw)
+    common.set_shuffling(po, pg, on=False)
+    for step in range(1, 4):
+        dest = np.repeat(np.arange(ne, dtype=np.int32), counts(step))[rng.permutation(n)]  # by particle id
+        for ps in (po, pg):
+            se, mk = ps.slot_info()
+            ids = ps.member(2)[0, :ps.capacity()]
+            ne_ = np.full(len(se), -1, dtype=np.int32)
+            live = mk.astype(bool)
+            ne_[live] = dest[ids[live]]
+            ps.rebuild(ne_, None, None)
+        assert po.nPtcls() == pg.nPtcls() == n
+        lo, lg = po.layout(), pg.layout()
+        for k in ("C", "num_chunks", "num_slices", "capacity", "num_rows"):
+            assert lo[k] == lg[k], (k, lo[k], lg[k])
+        for k in ("offsets", "slice_to_chunk", "row_to_element", "element_to_row"):
+            assert np.array_equal(lo[k], lg[k]), (step, k)
+        _check_same_population(po, pg, ppo.PARTICLE_XGCM)
+
+
 def test_rebuild_commit_equals_update_then_rebuild(ppo, synth, capi):
     """pp_ps_rebuild_commit == updatePtclPositions + rebuild (pseudoXGCm.cpp:116-140), including
     after an O(1) member swap."""
