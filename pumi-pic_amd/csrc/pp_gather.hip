@@ -203,7 +203,7 @@ int pp_gather_tet_vtx(const pp_mesh* mesh, const pp_ps* ps, int m_x, const int* 
   PP_HIP_CHECK(s_bad->reserve(sizeof(int)));
   PP_HIP_CHECK(hipMemsetAsync(s_bad->p, 0, sizeof(int), pp::stream()));
   k_gather_tet_vtx<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
-      ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), elem_ids_dev, x,
+      ps->capacity, ps->d_mask.as<unsigned char>(), pp::slot_elem(ps), elem_ids_dev, x,
       ps->stride, mesh->d_coords.as<double>(), mesh->d_elem2verts.as<int>(), field_dev, dof, out_dev,
       s_bad->as<int>());
   PP_LAUNCH_CHECK();
@@ -284,7 +284,7 @@ int pp_boris_push_fields(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xprev, i
   PP_HIP_CHECK(s_bad->reserve(sizeof(int)));
   PP_HIP_CHECK(hipMemsetAsync(s_bad->p, 0, sizeof(int), pp::stream()));
   k_boris_fields<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
-      ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), elem_ids_dev,
+      ps->capacity, ps->d_mask.as<unsigned char>(), pp::slot_elem(ps), elem_ids_dev,
       (double*)x, (double*)xp, (double*)v, ps->stride, mesh->d_coords.as<double>(),
       mesh->d_elem2verts.as<int>(), efield_vtx_dev, bgrid_dev, gridx0, gridz0, dx, dz, nx, nz, cyl_symm,
       dt, s_bad->as<int>());

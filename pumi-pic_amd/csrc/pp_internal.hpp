@@ -185,6 +185,9 @@ struct pp_ps {
   pp::DevBuf d_gid2lid;
   // layout (device)
   pp::DevBuf d_offsets, d_slice_to_chunk, d_row_to_element, d_element_to_row, d_mask, d_slot_elem;
+  // slot -> parent element: the row-tiled kernels of the time step never read it, so the SCS re-layout leaves it
+  // unwritten (40 MB per 10 M slots) and pp::slot_elem() fills it when something asks
+  mutable bool slot_elem_valid = true;
   // SCS row tiles for the row-major hot kernels: tile = (chunk, first p), kTileP columns wide.
   // A chunk's slots are contiguous: slot = chunk_start[c] + row_in_chunk + p*C, p < chunk_width[c]
   pp::DevBuf d_chunk_start, d_chunk_width, d_tiles, d_ntiles;
@@ -300,6 +303,7 @@ namespace pp {
 // entry point that reads or exposes member data calls this first
 int ps_materialize(pp_ps* ps);
 int ps_zeros(pp_ps* ps);  // only the pending zeros of pp_ps::zero_pending
+const int* slot_elem(const pp_ps* ps);  // d_slot_elem, filled first when the last re-layout left it out (pp_ps.hip)
 inline int ps_ready(const pp_ps* ps) {
   return (ps && (ps->zero_pending >= 0 || ps->lazy_rec)) ? ps_materialize(const_cast<pp_ps*>(ps)) : PP_OK;
 }

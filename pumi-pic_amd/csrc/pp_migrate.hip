@@ -678,7 +678,7 @@ int pp_set_unsafe_procs(const pp_ps* ps, const int* elems_dev, const unsigned ch
              "pp_set_unsafe_procs: null argument");
   if (ps->num_ptcls == 0 || ps->capacity == 0) return PP_OK;
   k_unsafe<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
-      ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), elems_dev, safe_dev,
+      ps->capacity, ps->d_mask.as<unsigned char>(), pp::slot_elem(ps), elems_dev, safe_dev,
       owners_dev, comm_rank, new_elems_dev, new_procs_dev);
   PP_LAUNCH_CHECK();
   return PP_OK;

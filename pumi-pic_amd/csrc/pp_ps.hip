@@ -740,6 +740,40 @@ __global__ void k_tile_count(int nchunks, int TP, const int* __restrict__ widths
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < nchunks) ntl[c] = (widths[c] + TP - 1) / TP;
 }
+// The same for chunk heights that are a multiple of 4: a thread covers four adjacent rows of a tile, so the
+// mask leaves as 4-byte words (k_init_slots_tiled stores single bytes: 10.7 us per 10 M slots against the
+// ~3 us its 10 MB cost) and the optional slot -> element table as 16-byte quads.
+__global__ void k_init_slots_tiled4(const int* __restrict__ ntiles_dev, int C, int TP,
+                                    const int* __restrict__ tiles, const int* __restrict__ chunk_start,
+                                    const int* __restrict__ chunk_width, const int* __restrict__ r2e,
+                                    const int* __restrict__ ppe, int ne, int* __restrict__ slot_elem,
+                                    int* __restrict__ row_cursor, int* __restrict__ elem_slot0,
+                                    unsigned char* __restrict__ new_mask, const int* __restrict__ go,
+                                    int* __restrict__ zero_next, int zero_words) {
+  if (!*go) return;
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (long long i = g; i < zero_words; i += (long long)gridDim.x * blockDim.x) zero_next[i] = 0;
+  const int Q = C >> 2;
+  const int tile = (int)(g / Q), r = 4 * (int)(g - (long long)tile * Q);
+  if (tile >= *ntiles_dev) return;
+  const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
+  const int start = chunk_start[c] + r, pend = min(p0 + TP, chunk_width[c]);
+  const int4 e = *(const int4*)(r2e + c * C + r);
+  const int c0 = e.x < ne ? ppe[e.x] : 0, c1 = e.y < ne ? ppe[e.y] : 0, c2 = e.z < ne ? ppe[e.z] : 0,
+            c3 = e.w < ne ? ppe[e.w] : 0;
+  if (p0 == 0) {
+    *(int4*)(row_cursor + c * C + r) = make_int4(start, start + 1, start + 2, start + 3);
+    if (e.x < ne) elem_slot0[e.x] = start;
+    if (e.y < ne) elem_slot0[e.y] = start + 1;
+    if (e.z < ne) elem_slot0[e.z] = start + 2;
+    if (e.w < ne) elem_slot0[e.w] = start + 3;
+  }
+  for (int p = p0; p < pend; ++p) {
+    if (slot_elem) *(int4*)(slot_elem + start + p * C) = e;
+    *(unsigned*)(new_mask + start + p * C) =
+        (p < c0 ? 1u : 0u) | (p < c1 ? 0x100u : 0u) | (p < c2 ? 0x10000u : 0u) | (p < c3 ? 0x1000000u : 0u);
+  }
+}
 // ---- row-tiled histogram of new parents (SCS): thread = (old tile, row).  Particles that stay in
 // their element are counted in a register and leave as ONE atomic per thread, and so do the movers
 // that share one of the first three other destinations of the thread's run.  Lanes of a wave are
@@ -1204,6 +1238,18 @@ __global__ void k_layout_tables(LayoutTablesArgs a) {
   if (!a.tot->go) return;
   layout_tables_body(a, blockIdx.x);
 }
+// slot -> parent element of every slot of every tile (what k_init_slots_tiled leaves out, see pp::slot_elem)
+__global__ void k_fill_slot_elem(const int* __restrict__ ntiles_dev, int C, int TP, const int* __restrict__ tiles,
+                                 const int* __restrict__ chunk_start, const int* __restrict__ chunk_width,
+                                 const int* __restrict__ r2e, int* __restrict__ slot_elem) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int tile = (int)(g / C), r = (int)(g - (long long)tile * C);
+  if (tile >= *ntiles_dev) return;
+  const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
+  const int start = chunk_start[c] + r, pend = min(p0 + TP, chunk_width[c]);
+  const int e = r2e[c * C + r];
+  for (int p = p0; p < pend; ++p) slot_elem[start + p * C] = e;
+}
 // new layout: slot -> parent element for every slot of every tile, first slot of every row
 __global__ void k_init_slots_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
                                    const int* __restrict__ tiles, const int* __restrict__ chunk_start,
@@ -1232,7 +1278,7 @@ __global__ void k_init_slots_tiled(const int* __restrict__ ntiles_dev, int C, in
     if (e < ne) elem_slot0[e] = start;  // first slot of the element's new row (pack: + rank*C)
   }
   for (int p = p0; p < pend; ++p) {
-    slot_elem[start + p * C] = e;
+    if (slot_elem) slot_elem[start + p * C] = e;
     new_mask[start + p * C] = p < cnt ? 1 : 0;
   }
 }
@@ -2043,6 +2089,7 @@ int finish_layout_upload(pp_ps* ps, const HostLayout& L, const std::vector<int>&
   if ((rc = upload_vec(ps->d_element_to_row, L.element_to_row))) return rc;
   if ((rc = upload_vec(ps->d_mask, mask))) return rc;
   if ((rc = upload_vec(ps->d_slot_elem, slot_elem))) return rc;
+  ps->slot_elem_valid = true;
   PP_HIP_CHECK(hipStreamSynchronize(pp::stream()));
   return PP_OK;
 }
@@ -2557,6 +2604,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   int NQ = 0;
   bool lazy_zero = false, defer_unpack = false;
   // today's per-element counts are not read by a re-layout that commits: its tail clears them for the next one
+  static const bool lazy_slot_elem = getenv("PP_EAGER_SLOT_ELEM") == nullptr;  // (pp::slot_elem)
   static const bool no_prezero = getenv("PP_NO_PREZERO") != nullptr;
   const bool prezero = !no_prezero && ps->d_elem_count.p && ps->d_elem_count.p != ps->s_ppe.p &&
                        ps->d_elem_count.bytes >= tot_off + sizeof(Totals);
@@ -2569,11 +2617,16 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     int* new_tiles = ps->s_newidx.as<int>();
     const int* new_ntiles = ps->s_scan.as<int>();
     k_layout_tables<<<ta.b3 + grid_for(nrows), kBlock, 0, st>>>(ta);
-    k_init_slots_tiled<<<grid_for((size_t)ntiles_max * C_new), kBlock, 0, st>>>(
-        new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_r2e2.as<int>(),
-        ppe, ne, ps->s_slot2.as<int>(), ps->s_rowstart.as<int>(), ps->s_eslot0.as<int>(),
-        ps->s_mask2.as<unsigned char>(), go, prezero ? ps->d_elem_count.as<int>() : nullptr,
-        prezero ? (int)((tot_off + sizeof(Totals)) / sizeof(int)) : 0);
+#define PP_INIT_SLOTS_ARGS                                                                                        \
+  new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_r2e2.as<int>(), ppe, ne,               \
+      lazy_slot_elem ? nullptr : ps->s_slot2.as<int>(), ps->s_rowstart.as<int>(), ps->s_eslot0.as<int>(),        \
+      ps->s_mask2.as<unsigned char>(), go, prezero ? ps->d_elem_count.as<int>() : nullptr,                         \
+      prezero ? (int)((tot_off + sizeof(Totals)) / sizeof(int)) : 0
+    if (C_new % 4 == 0)
+      k_init_slots_tiled4<<<grid_for((size_t)ntiles_max * (C_new / 4)), kBlock, 0, st>>>(PP_INIT_SLOTS_ARGS);
+    else
+      k_init_slots_tiled<<<grid_for((size_t)ntiles_max * C_new), kBlock, 0, st>>>(PP_INIT_SLOTS_ARGS);
+#undef PP_INIT_SLOTS_ARGS
     // ---- swap buffer sizing (SCS_rebuild.h:223-229)
     int64_t swap_stride = ps->swap_stride;
     if (stride_fixed > 0) {  // speculative tail: whatever the swap buffers hold today
@@ -2772,6 +2825,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   ps->d_element_to_row.swap(ps->s_e2r2);
   ps->d_mask.swap(ps->s_mask2);
   ps->d_slot_elem.swap(ps->s_slot2);
+  ps->slot_elem_valid = !lazy_slot_elem;
   ps->d_chunk_start.swap(ps->s_cstart2);
   ps->d_chunk_width.swap(ps->s_cwidth2);
   ps->d_tiles.swap(ps->s_newidx);
@@ -2813,7 +2867,7 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   PP_HIP_CHECK(ps->s_ranknew.reserve(sizeof(int) * (size_t)std::max(n_new, 1)));
   int* rank = ps->s_idx.as<int>();
   int* rank_new = ps->s_ranknew.as<int>();
-  if (nold > 0) k_count_csr<<<grid_for(nold), kBlock, 0, st>>>(nold, new_element, ps->d_slot_elem.as<int>(), ne, ppe, tot, rank);
+  if (nold > 0) k_count_csr<<<grid_for(nold), kBlock, 0, st>>>(nold, new_element, pp::slot_elem(ps), ne, ppe, tot, rank);
   if (n_new > 0) k_count_added<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ne, ppe, tot, rank_new);
   PP_HIP_CHECK(ps->s_offsets2.reserve(sizeof(int) * ((size_t)ne + 1)));
   if (scan_excl(ps->s_scan2, ne + 1, ppe, ps->s_offsets2.as<int>(), &tot->active, st)) return PP_EHIP;
@@ -2929,6 +2983,16 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
 }  // namespace
 
 namespace pp {
+const int* slot_elem(const pp_ps* ps) {
+  if (!ps->slot_elem_valid) {
+    if (ps->kind == PP_SCS && ps->capacity > 0 && ps->ntiles_max > 0)
+      k_fill_slot_elem<<<grid_for((size_t)ps->ntiles_max * ps->C), kBlock, 0, pp::stream()>>>(
+          ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(),
+          ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(), ps->d_slot_elem.as<int>());
+    ps->slot_elem_valid = true;
+  }
+  return ps->d_slot_elem.as<int>();
+}
 bool lazy_push_ok(const pp_ps* ps, int m_x, int m_xtgt, int m_b, int m_phi) {
   if (!ps || ps->lazy_rec != 1 || ps->kind != PP_SCS || !xgcm_shape(ps)) return false;
   for (int m = 0; m < 5; ++m)
@@ -3118,6 +3182,7 @@ pp_ps* pp_ps_create_csr(int num_elems, int num_ptcls, const int* ppe_host,
       mask[j] = 1;
     }
   ok = ok && upload_vec(ps->d_slot_elem, slot_elem) == PP_OK && upload_vec(ps->d_mask, mask) == PP_OK;
+  ps->slot_elem_valid = true;
   if (ok) ok = hipStreamSynchronize(pp::stream()) == hipSuccess;
   if (ok && gids_host && num_elems > 0) ok = store_gids(ps, gids_host, num_elems);
   if (ok && num_ptcls > 0 && particle_elements_host && particle_info_host) {
@@ -3205,13 +3270,14 @@ int pp_ps_layout(const pp_ps* ps, pp_ps_layout_t* out) {
   out->row_to_element = ps->d_row_to_element.as<int>();
   out->element_to_row = ps->d_element_to_row.as<int>();
   out->mask = ps->d_mask.as<unsigned char>();
-  out->slot_elem = ps->d_slot_elem.as<int>();
+  out->slot_elem = pp::slot_elem(ps);
   return PP_OK;
 }
 
 int pp_ps_layout_to_host(const pp_ps* ps, int* offsets, int* slice_to_chunk, int* row_to_element,
                          int* element_to_row, unsigned char* mask, int* slot_elem) {
   PP_REQUIRE(ps, "pp_ps_layout_to_host: null ps");
+  if (slot_elem) (void)pp::slot_elem(ps);
   PP_HIP_CHECK(hipStreamSynchronize(pp::stream()));
   const size_t noff = (ps->kind == PP_SCS) ? (size_t)ps->num_slices + 1 : (size_t)ps->num_elems + 1;
   if (offsets) PP_HIP_CHECK(hipMemcpy(offsets, ps->d_offsets.p, noff * sizeof(int), hipMemcpyDeviceToHost));
@@ -3229,7 +3295,7 @@ int pp_ps_layout_to_host(const pp_ps* ps, int* offsets, int* slice_to_chunk, int
   if (mask && ps->capacity)
     PP_HIP_CHECK(hipMemcpy(mask, ps->d_mask.p, (size_t)ps->capacity, hipMemcpyDeviceToHost));
   if (slot_elem && ps->capacity)
-    PP_HIP_CHECK(hipMemcpy(slot_elem, ps->d_slot_elem.p, (size_t)ps->capacity * sizeof(int),
+    PP_HIP_CHECK(hipMemcpy(slot_elem, pp::slot_elem(ps), (size_t)ps->capacity * sizeof(int),
                            hipMemcpyDeviceToHost));
   return PP_OK;
 }
@@ -3367,11 +3433,11 @@ int pp_ps_get_pids(const pp_ps* ps, int* offsets_dev, int* pids_dev) {
   PP_HIP_CHECK(hipMemsetAsync(cur.p, 0, sizeof(int) * ((size_t)ne + 1), st));
   if (ps->capacity > 0 && ps->num_ptcls > 0)
     k_pid_count<<<grid_for(ps->capacity), kBlock, 0, st>>>(
-        ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), ppe.as<int>());
+        ps->capacity, ps->d_mask.as<unsigned char>(), pp::slot_elem(ps), ppe.as<int>());
   k_scan_excl<<<1, 1024, 0, st>>>(ne + 1, ppe.as<int>(), offsets_dev, nullptr);
   if (ps->capacity > 0 && ps->num_ptcls > 0)
     k_pid_set<<<grid_for(ps->capacity), kBlock, 0, st>>>(
-        ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), offsets_dev,
+        ps->capacity, ps->d_mask.as<unsigned char>(), pp::slot_elem(ps), offsets_dev,
         cur.as<int>(), pids_dev);
   PP_LAUNCH_CHECK();
   PP_HIP_CHECK(hipStreamSynchronize(st));
@@ -3411,7 +3477,7 @@ int pp_redistribute_particles_dist(const pp_ps* ps, int strat, double percent_mo
     ee = es + ne;
   }
   k_redistribute<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
-      ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), ne, percent_moved, seed,
+      ps->capacity, ps->d_mask.as<unsigned char>(), pp::slot_elem(ps), ne, percent_moved, seed,
       new_elems_dev, strat, es, ee);
   PP_LAUNCH_CHECK();
   return PP_OK;

@@ -166,7 +166,7 @@ int pp_elliptical_push(pp_ps* ps, const pp_mesh* mesh, int m_xtgt, int m_b, int 
   if ((rc = check_member(ps, m_phi, 4, 1, "pp_elliptical_push phi"))) return rc;
   if (ps->num_ptcls == 0 || ps->capacity == 0) return PP_OK;
   k_elliptical_push<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
-      ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(),
+      ps->capacity, ps->d_mask.as<unsigned char>(), pp::slot_elem(ps),
       mesh->d_class_id.as<int>(), PP_MEMBER(ps, m_xtgt, double), ps->stride,
       PP_MEMBER(ps, m_b, float), PP_MEMBER(ps, m_phi, float), h, k, d, deg);
   PP_LAUNCH_CHECK();
@@ -184,7 +184,7 @@ int pp_toroidal_push(pp_ps* ps, const pp_mesh* mesh, int m_x, int m_xtgt, int m_
   if ((rc = check_member(ps, m_phi, 4, 1, "pp_toroidal_push phi"))) return rc;
   if (ps->num_ptcls == 0 || ps->capacity == 0) return PP_OK;
   k_toroidal_push<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
-      ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(),
+      ps->capacity, ps->d_mask.as<unsigned char>(), pp::slot_elem(ps),
       mesh->d_class_id.as<int>(), PP_MEMBER(ps, m_x, double), PP_MEMBER(ps, m_xtgt, double),
       ps->stride, PP_MEMBER(ps, m_b, float), PP_MEMBER(ps, m_phi, float), h, k, d, deg);
   PP_LAUNCH_CHECK();
@@ -224,7 +224,7 @@ int pp_update_positions(pp_ps* ps, int m_x, int m_xtgt) {
   if ((rc = check_member(ps, m_xtgt, 8, 3, "pp_update_positions x_tgt"))) return rc;
   if (ps->num_ptcls == 0 || ps->capacity == 0) return PP_OK;
   k_update_positions<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
-      ps->capacity, ps->d_slot_elem.as<int>(), PP_MEMBER(ps, m_x, double),
+      ps->capacity, pp::slot_elem(ps), PP_MEMBER(ps, m_x, double),
       PP_MEMBER(ps, m_xtgt, double), ps->stride);
   PP_LAUNCH_CHECK();
   return PP_OK;
@@ -238,7 +238,7 @@ int pp_pseudo_push160(pp_ps* ps, const double* parent_elm_data_dev) {
   if ((rc = check_member(ps, 2, 8, 1, "pp_pseudo_push160 lint"))) return rc;
   if (ps->num_ptcls == 0 || ps->capacity == 0) return PP_OK;
   k_pseudo_push160<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
-      ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(),
+      ps->capacity, ps->d_mask.as<unsigned char>(), pp::slot_elem(ps),
       PP_MEMBER(ps, 0, double), PP_MEMBER(ps, 1, int), PP_MEMBER(ps, 2, long long), ps->stride,
       parent_elm_data_dev);
   PP_LAUNCH_CHECK();

@@ -634,7 +634,7 @@ int pp_gyro_scatter_radius(const pp_mesh* mesh, const pp_ps* ps, const double* r
         weight_dev, ne, gnr, ringWidth, s_er->as<double>(), clip_dev);
   } else {
     k_elem_rings_flat<<<grid_for(ps->capacity), kBlock, 0, st>>>(
-        ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), radius_dev, weight_dev, ne, gnr,
+        ps->capacity, ps->d_mask.as<unsigned char>(), pp::slot_elem(ps), radius_dev, weight_dev, ne, gnr,
         ringWidth, s_er->as<double>(), clip_dev);
   }
   k_rings_from_elem_rings<<<grid_for((size_t)nverts * gnr), kBlock, 0, st>>>(
@@ -678,7 +678,7 @@ int pp_avg_ptcl_density(const pp_mesh* mesh, const pp_ps* ps, double* elem_cnt_d
   PP_HIP_CHECK(hipMemsetAsync(s_cnt->p, 0, sizeof(int) * (size_t)std::max(ne, 1), st));
   // the reference lambda has no mask test: every slot the parallel_for visits is counted
   if (ps->num_ptcls > 0 && ps->capacity > 0)
-    k_slot_count<<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, ps->d_slot_elem.as<int>(),
+    k_slot_count<<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, pp::slot_elem(ps),
                                                            ne, s_cnt->as<int>());
   k_vert_density<<<grid_for(std::max(std::max(ne, nverts), 1)), kBlock, 0, st>>>(
       nverts, mesh->d_vert2elems_off.as<int>(), mesh->d_vert2elems.as<int>(), s_cnt->as<int>(),

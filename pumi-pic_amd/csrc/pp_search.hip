@@ -1645,7 +1645,7 @@ int pp_search_mesh_2d(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m
   if (ps->num_ptcls == 0 || ps->capacity == 0) return PP_OK;
   if ((rc = reset_counters())) return rc;
   k_search2d<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
-      ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(),
+      ps->capacity, ps->d_mask.as<unsigned char>(), pp::slot_elem(ps),
       mesh->d_records.as<pp_tri_rec>(), mesh->nelems, PP_MEMBER(ps, m_xtgt, double), ps->stride,
       elem_ids_dev, looplimit, g_cnt.get());
   PP_LAUNCH_CHECK();
@@ -1686,7 +1686,7 @@ int pp_search_mesh(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_pi
   const unsigned grid = grid_for(ps->capacity);
   hipStream_t st = pp::stream();
 #define PP_TPP_ARGS                                                                              \
-  ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), mesh->d_records.p, m,  \
+  ps->capacity, ps->d_mask.as<unsigned char>(), pp::slot_elem(ps), mesh->d_records.p, m,  \
       PP_MEMBER(ps, m_x, double), PP_MEMBER(ps, m_xtgt, double), ps->stride, elem_ids_dev,       \
       elem_ids_seeded, mesh->tol, inter_faces_dev, inter_points_dev, looplimit, g_cnt.get()
   if (mesh->dim == 2) {
@@ -1733,7 +1733,7 @@ int pp_search_mesh_legacy3d(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt,
   if (ps->num_ptcls == 0 || ps->capacity == 0) return PP_OK;
   if ((rc = reset_counters())) return rc;
   k_search_legacy3d<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
-      ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), arrays_of(mesh),
+      ps->capacity, ps->d_mask.as<unsigned char>(), pp::slot_elem(ps), arrays_of(mesh),
       PP_MEMBER(ps, m_x, double), PP_MEMBER(ps, m_xtgt, double), ps->stride, elem_ids_dev,
       elem_ids_seeded, xpoints_dev, xface_dev, looplimit, g_cnt.get());
   PP_LAUNCH_CHECK();
@@ -1766,7 +1766,7 @@ int pp_trace_begin(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int* ele
   if ((rc = reset_counters())) return rc;
   const unsigned grid = grid_for(ps->capacity);
 #define PP_TB_ARGS                                                                                \
-  ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), mesh->d_records.p,      \
+  ps->capacity, ps->d_mask.as<unsigned char>(), pp::slot_elem(ps), mesh->d_records.p,      \
       PP_MEMBER(ps, m_x, double), PP_MEMBER(ps, m_xtgt, double), ps->stride, elem_ids_dev,        \
       elem_ids_seeded, mesh->tol, requireIntersection, inter_faces_dev, inter_points_dev,         \
       ptcl_done_dev, last_exit_dev, g_cnt.get()
@@ -1875,7 +1875,7 @@ int pp_search_mesh_3d(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m
   if (ps->capacity == 0) return PP_OK;
   if ((rc = reset_counters())) return rc;
   k_search_mesh3d<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
-      ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), arrays_of(mesh),
+      ps->capacity, ps->d_mask.as<unsigned char>(), pp::slot_elem(ps), arrays_of(mesh),
       PP_MEMBER(ps, m_x, double), PP_MEMBER(ps, m_xtgt, double), ps->stride, elem_ids_dev,
       elem_ids_seeded, xpoints_dev, xface_dev, looplimit, g_cnt.get());
   PP_LAUNCH_CHECK();
@@ -2020,14 +2020,14 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
     // DIM 2 follows search_mesh_2d: the caller's elem_ids are always read (-1 = own element)
     if (mesh->dim == 2) {
     k_push_walk<2><<<grid, kBlock, 0, st>>>(
-        ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), mesh->d_records.p,
+        ps->capacity, ps->d_mask.as<unsigned char>(), pp::slot_elem(ps), mesh->d_records.p,
         mesh->d_class_id.as<int>(), mesh->nelems, PP_MEMBER(ps, m_x, double),
         PP_MEMBER(ps, m_xtgt, double), ps->stride, PP_MEMBER(ps, m_b, float),
         PP_MEMBER(ps, m_phi, float), h, k, d, deg, mesh->tol, elem_ids_dev, elem_ids_seeded, looplimit,
         g_cnt.get());
   } else {
     k_push_walk<3><<<grid, kBlock, 0, st>>>(
-        ps->capacity, ps->d_mask.as<unsigned char>(), ps->d_slot_elem.as<int>(), mesh->d_records.p,
+        ps->capacity, ps->d_mask.as<unsigned char>(), pp::slot_elem(ps), mesh->d_records.p,
         mesh->d_class_id.as<int>(), mesh->nelems, PP_MEMBER(ps, m_x, double),
         PP_MEMBER(ps, m_xtgt, double), ps->stride, PP_MEMBER(ps, m_b, float),
         PP_MEMBER(ps, m_phi, float), h, k, d, deg, mesh->tol, elem_ids_dev, elem_ids_seeded,
