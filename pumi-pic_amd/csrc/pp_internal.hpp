@@ -162,6 +162,9 @@ struct pp_mesh {
 namespace pp {
 int mesh_edges(const pp_mesh* mesh);
 }
+namespace pp {
+struct GyroRide;
+}
 struct pp_ps {
   int kind = PP_SCS;
   int num_elems = 0, num_ptcls = 0, capacity = 0, num_rows = 0;
@@ -228,6 +231,8 @@ struct pp_ps {
   // scratch reused across rebuilds
   void* ppe_zeroed = nullptr;  // == s_ppe.p: that buffer was cleared by the previous re-layout's tail
   size_t ppe_zeroed_bytes = 0;
+  const pp::GyroRide* ride = nullptr;  // set for the duration of a pp_ps_rebuild_scatter call (consumed by enqueue_layout)
+  bool ride_done = false;
   int wide_skip = 0;  // full re-layouts left before the one-pass layout sort is tried again (it overflowed)
   pp::DevBuf s_ppe, s_keys, s_keys2, s_vals, s_vals2, s_hist, s_chunkw, s_misc, s_rowstart,
       s_newidx, s_offsets2, s_s2c2, s_r2e2, s_e2r2, s_mask2, s_slot2, s_scan, s_cstart2, s_cwidth2, s_aos, s_idx, s_ranknew, s_eslot0, s_scan2;
@@ -319,4 +324,57 @@ bool lazy_push_ok(const pp_ps* ps, int m_x, int m_xtgt, int m_b, int m_phi);
 // histogram of a rebuild that is still in flight); forgets the ring accumulation kept for reuse.
 int gyro_scatter_counts(const pp_mesh* mesh, const int* cnt_dev, int nmaps, const int* const* v2v_dev,
                         double* const* out_dev, double rmax, int gnr, int gppr);
+// The same scatter RIDING in the launches of the rebuild that makes the counts (pp_ps_rebuild_scatter): its two
+// kernels are a few hundred blocks of latency-bound gathers, and so are the rebuild's key sweep (49 blocks at
+// 10^5 elements) and layout kernel (one block) -- side by side they cost what the longer one costs.  The first
+// stage runs as extra blocks of k_make_keys (both need only the finished histogram), the second as extra
+// blocks of k_layout_fused (a kernel boundary later).  gyro_scatter_ride() fills the arguments when the calls
+// reduce to the ring accumulation + ONE transposed-map gather (one map, or the two maps of one
+// pp_create_gyro_ring_mappings call), else leaves on = 0 and the caller uses gyro_scatter_counts().
+struct GyroRide {
+  int on = 0;
+  int nverts = 0, gnr = 0, ringDown = 0, ringUp = 0, gppr = 1;
+  const int *v2e_off = nullptr, *v2e = nullptr;   // vertex -> elements
+  double* ring = nullptr;                         // [nverts][gnr]
+  const int *off = nullptr, *src = nullptr;       // transposed ring map
+  double *out = nullptr, *out2 = nullptr;
+};
+int gyro_scatter_ride(const pp_mesh* mesh, int nmaps, const int* const* v2v_dev, double* const* out_dev,
+                      double rmax, int gnr, int gppr, GyroRide* ride);
+// first stage, thread = vertex: ring_accum[v][ringUp] = ring_accum[v][ringDown] = live particles in the elements
+// around v (gyroScatter.hpp:188-197 as a gather; integer sums in double are exact in any order)
+__device__ __forceinline__ void gyro_rings_body(int v, int nverts, int gnr, const int* __restrict__ v2e_off,
+                                                const int* __restrict__ v2e, const int* __restrict__ cnt,
+                                                int ringDown, int ringUp, double* __restrict__ ring_accum) {
+  if (v >= nverts) return;
+  long long n = 0;
+  for (int j = v2e_off[v]; j < v2e_off[v + 1]; ++j) n += cnt[v2e[j]];
+  for (int r = 0; r < gnr; ++r)
+    ring_accum[(size_t)v * gnr + r] = (r == ringUp ? (double)n : 0.0) + (r == ringDown ? (double)n : 0.0);
+}
+// second stage, 16 lanes per target vertex (g = 16 * vertex + lane; groups of 16 do not straddle waves): the
+// lanes fetch 16 list entries at once, then every lane adds them up in list order = the sequential sum
+__device__ __forceinline__ void gyro_gather_body(int g, int nverts, int gppr, const int* __restrict__ off,
+                                                 const int* __restrict__ src, const double* __restrict__ ring_accum,
+                                                 double* __restrict__ scatter_w, double* __restrict__ scatter_w2) {
+  const int t = g >> 4, sub = g & 15, lane0 = (threadIdx.x & 63) & ~15;
+  const bool in = t < nverts;
+  const int b = in ? off[t] : 0, e = in ? off[t + 1] : 0;
+  int len = e - b;
+  for (int o = 16; o < 64; o <<= 1) len = max(len, __shfl_xor(len, o));  // wave-uniform trip count
+  double w = 0;
+  for (int base = 0; base < len; base += 16) {
+    const int j = b + base + sub;
+    const double val = j < e ? ring_accum[src[j]] / gppr : 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const double x = __shfl(val, lane0 + k);
+      if (b + base + k < e) w += x;
+    }
+  }
+  if (in && sub == 0) {
+    scatter_w[t] = w;
+    if (scatter_w2) scatter_w2[t] = w;  // a second map with the same transpose: the same sums in the same order
+  }
+}
 }  // namespace pp

@@ -14,9 +14,12 @@
 // ordered by ascending element id (stable sort); Kokkos' bitonic sort_by_key_thread order is a
 // third-party detail and no result depends on it.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <numeric>
 #include <functional>
 #include "pp_internal.hpp"
+#include "pp_ps_sort.hpp"  // Totals, the layout sort, scans
 
 namespace {
 
@@ -197,22 +200,6 @@ int upload_initial(pp_ps* ps, const std::vector<int>& slot_of_particle, int np,
 }
 
 // ------------------------------------------------------------------ device kernels
-struct Totals {  // s_misc layout
-  int active;    // live particles after the rebuild
-  int nonempty;  // elements with >= 1 particle
-  int invalid;   // new particle with element -1 / out of range
-  int cw_sum, cw_cnt;
-  int nslices, capacity;
-  int go;  // speculative tail of the rebuild may run (k_spec_check); 1 on the checked path
-  double cw_inv;
-  unsigned long long max_key;  // largest sort key of this rebuild (radix passes above it are skipped)
-  // in-place rebuild: rows whose new count exceeds their chunk width, rows that traded places,
-  // "no home found for an overflowing row"
-  int n_over;    // rows whose new count exceeds their chunk width (the reference then re-lays out)
-  int sort_bad;  // one-pass layout sort: more keys in the overflow digit than its fix-up holds (re-sort with every pass)
-  int pad_[2];
-};
-
 __global__ void k_count_added(int n_new, const int* __restrict__ new_elems, int ne,
                               int* __restrict__ ppe, Totals* tot, int* __restrict__ rank_new) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -225,520 +212,6 @@ __global__ void k_count_added(int n_new, const int* __restrict__ new_elems, int 
   }
   const int r = atomicAdd(&ppe[e], 1);
   if (rank_new) rank_new[i] = r;  // rank inside the new row (see k_count_tiled)
-}
-// ---- stable LSD radix sort (8-bit digits) of (key64, val32)
-constexpr int RS_TILE = 2048;  // keys per block
-// (also the per-element totals of the new population -- live particles, non-empty elements, rows
-// that overflow their current chunk: k_nonempty and k_fit_check in the same sweep -- when `totals`)
-struct ElemTotalsArgs {
-  int totals;  // accumulate active / nonempty
-  int fit;     // accumulate n_over against the CURRENT layout
-  int C_old;
-  const int *e2r_old, *chunk_width_old;
-  // per-block partial sums (3 ints a block: non-empty, live, over) for the layout kernel to add up; null =
-  // atomics on the totals (every block ends with three atomics on the same counters, ~10 ns each queued)
-  int* partial;
-};
-// fused form of the radix passes (k_rs_pass / k_rs_pass_wide, ne <= kFusedSortBlocks tiles): the sweep that
-// makes the keys also counts the first pass's digits per tile.
-constexpr int kWideBits = 11, kWideDigits = 1 << kWideBits;
-struct FusedHist {
-  int* h0;   // digit counts of the first pass per tile: [256][nblk], wide: [nblk][kWideDigits] (null = separate launches)
-  int nblk;
-  int wide;  // the ONE pass over an 11-bit digit; keys of 2047 and more share the last digit (k_rs_pass_wide)
-};
-__device__ __forceinline__ int wide_digit(unsigned long long key) {
-  return key < (unsigned long long)(kWideDigits - 1) ? (int)key : kWideDigits - 1;
-}
-__global__ void k_make_keys(int ne, const int* __restrict__ ppe, int sigma, int n_sigma,
-                            unsigned long long base, unsigned long long* __restrict__ keys,
-                            int* __restrict__ vals, Totals* tot, int no_skip, ElemTotalsArgs et,
-                            FusedHist fh = FusedHist{nullptr, 0, 0}) {
-  unsigned long long mx = 0;
-  int nz = 0, sum = 0, over = 0;
-  const int base_i = blockIdx.x * RS_TILE;
-  __shared__ int s_h0[kWideDigits];
-  const int dmask = fh.wide ? kWideDigits - 1 : 255;  // (digits of the first pass)
-  if (fh.h0) {
-    for (int d = threadIdx.x; d <= dmask; d += 256) s_h0[d] = 0;
-    __syncthreads();
-  }
-  // (loads of the whole tile first -- counts, then the old row and chunk width of the fit test: three dependent
-  // global loads per element would otherwise be paid eight times in a row)
-  constexpr int R = RS_TILE / 256;
-  int nn[R], cw_old[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int i = base_i + r * 256 + threadIdx.x;
-    nn[r] = i < ne ? ppe[i] : 0;
-    cw_old[r] = (et.fit && i < ne) ? et.e2r_old[i] : 0;
-  }
-  if (et.fit) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i = base_i + r * 256 + threadIdx.x;
-      cw_old[r] = i < ne ? et.chunk_width_old[cw_old[r] / et.C_old] : 0;
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int i = base_i + r * 256 + threadIdx.x;
-    if (i >= ne) break;
-    int w = 0;
-    if (sigma > 0) {
-      w = i / sigma;
-      if (w > n_sigma - 1) w = n_sigma - 1;
-    }
-    const int n = nn[r];
-    const unsigned long long key = (unsigned long long)w * base + (unsigned long long)n;
-    keys[i] = key;
-    vals[i] = i;
-    if (fh.h0) atomicAdd(&s_h0[fh.wide ? wide_digit(key) : (int)(key & 255ull)], 1);
-    mx = key > mx ? key : mx;
-    nz += n > 0;
-    sum += n;
-    if (et.fit) over += n > cw_old[r];
-  }
-  if (et.totals) {
-    __shared__ int s_t[4][3];
-    for (int o = 32; o > 0; o >>= 1) {
-      nz += __shfl_down(nz, o);
-      sum += __shfl_down(sum, o);
-      over += __shfl_down(over, o);
-    }
-    if ((threadIdx.x & 63) == 0) {
-      s_t[threadIdx.x >> 6][0] = nz;
-      s_t[threadIdx.x >> 6][1] = sum;
-      s_t[threadIdx.x >> 6][2] = over;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      nz = s_t[0][0] + s_t[1][0] + s_t[2][0] + s_t[3][0];
-      sum = s_t[0][1] + s_t[1][1] + s_t[2][1] + s_t[3][1];
-      over = s_t[0][2] + s_t[1][2] + s_t[2][2] + s_t[3][2];
-      if (et.partial) {
-        et.partial[3 * blockIdx.x] = nz;
-        et.partial[3 * blockIdx.x + 1] = sum;
-        et.partial[3 * blockIdx.x + 2] = over;
-      } else {
-        if (nz) {
-          atomicAdd(&tot->nonempty, nz);
-          atomicAdd(&tot->active, sum);
-        }
-        if (over) atomicAdd(&tot->n_over, over);
-      }
-    }
-    __syncthreads();
-  }
-  if (fh.h0) {
-    __syncthreads();
-    if (fh.wide)
-      for (int d = threadIdx.x; d < kWideDigits; d += 256) fh.h0[(size_t)blockIdx.x * kWideDigits + d] = s_h0[d];
-    else
-      fh.h0[threadIdx.x * fh.nblk + blockIdx.x] = s_h0[threadIdx.x];
-  }
-  // the host sizes the number of 8-bit passes from an upper bound (total particles); the real
-  // maximum (a per-element count) usually needs one or two passes: later passes see it and copy.
-  // One atomic per 2048 keys: same-address atomics serialise at ~10 ns each.
-  __shared__ unsigned long long smx[4];
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned long long y = __shfl_down(mx, o);
-    mx = y > mx ? y : mx;
-  }
-  if ((threadIdx.x & 63) == 0) smx[threadIdx.x >> 6] = mx;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int k = 1; k < 4; ++k) mx = smx[k] > mx ? smx[k] : mx;
-    if (mx) atomicMax(&tot->max_key, no_skip ? ~0ull : mx);
-  }
-}
-__global__ void k_rs_hist(int n, const unsigned long long* __restrict__ keys, int shift, int nblk,
-                          int* __restrict__ hist, const Totals* tot) {
-  if ((tot->max_key >> shift) == 0) return;  // every digit of this pass is 0: identity pass
-  __shared__ int h[256];
-  h[threadIdx.x] = 0;
-  __syncthreads();
-  const int base = blockIdx.x * RS_TILE;
-  for (int j = threadIdx.x; j < RS_TILE; j += 256) {
-    const int i = base + j;
-    if (i < n) atomicAdd(&h[(int)((keys[i] >> shift) & 255ull)], 1);
-  }
-  __syncthreads();
-  hist[threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
-}
-__global__ void k_rs_scatter(int n, const unsigned long long* __restrict__ keys,
-                             const int* __restrict__ vals, int shift, int nblk,
-                             const int* __restrict__ hist_scanned,
-                             unsigned long long* __restrict__ keys_out, int* __restrict__ vals_out,
-                             const Totals* tot) {
-  if ((tot->max_key >> shift) == 0) {  // identity pass of the stable sort: plain copy
-    for (int j = threadIdx.x; j < RS_TILE; j += 256) {
-      const int i = blockIdx.x * RS_TILE + j;
-      if (i < n) {
-        keys_out[i] = keys[i];
-        vals_out[i] = vals[i];
-      }
-    }
-    return;
-  }
-  __shared__ int base_d[256];     // running count of each digit inside this tile
-  __shared__ int wave_cnt[4][256];
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  base_d[t] = 0;
-  const int tile0 = blockIdx.x * RS_TILE;
-  for (int round = 0; round < RS_TILE / 256; ++round) {
-    for (int w = 0; w < 4; ++w) wave_cnt[w][t] = 0;
-    __syncthreads();
-    const int i = tile0 + round * 256 + t;
-    const bool valid = i < n;
-    unsigned long long key = 0;
-    int val = 0, digit = 0;
-    if (valid) {
-      key = keys[i];
-      val = vals[i];
-      digit = (int)((key >> shift) & 255ull);
-    }
-    // lanes of this wave holding the same digit
-    unsigned long long same = __ballot(valid);
-    for (int b = 0; b < 8; ++b) {
-      const unsigned long long bal = __ballot(valid && ((digit >> b) & 1));
-      same &= ((digit >> b) & 1) ? bal : ~bal;
-    }
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int rank_in_wave = __popcll(same & lt);
-    if (valid && rank_in_wave == 0) wave_cnt[wave][digit] = __popcll(same);
-    __syncthreads();
-    if (valid) {
-      int off = base_d[digit];
-      for (int w = 0; w < wave; ++w) off += wave_cnt[w][digit];
-      const int pos = hist_scanned[digit * nblk + blockIdx.x] + off + rank_in_wave;
-      keys_out[pos] = key;
-      vals_out[pos] = val;
-    }
-    __syncthreads();
-    base_d[t] += wave_cnt[0][t] + wave_cnt[1][t] + wave_cnt[2][t] + wave_cnt[3][t];
-    __syncthreads();
-  }
-}
-
-// The scatter of a radix pass with the scan of the digit table folded in (small structures: the table
-// of <= kFusedSortBlocks tiles is read whole by every block).  The separate-launch form costs histogram +
-// table scan (single block, 9 us) + scatter per pass (23 us at 100 800 elements,
-// profiles/r03_c3_recordfed_kernel_stats.csv); here every block scans the table itself (thread d: the
-// digit's total over all tiles and over the tiles before its own; one block scan over the 256 digits).
-// (Also tried: the NEXT digit's histogram accumulated here with one atomic per key -- the high digit of
-// nearly every key is 0, so the atomics pile onto one counter per tile: 250 us per pass.)
-constexpr int kFusedSortBlocks = 64;
-__global__ void k_rs_pass(int n, const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
-                          int shift, int nblk, const int* __restrict__ hist,
-                          unsigned long long* __restrict__ keys_out, int* __restrict__ vals_out,
-                          const Totals* tot) {
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  const unsigned long long max_key = tot->max_key;
-  if ((max_key >> shift) == 0) {  // identity pass of the stable sort: plain copy (so are all later ones)
-    for (int j = t; j < RS_TILE; j += 256) {
-      const int i = blockIdx.x * RS_TILE + j;
-      if (i < n) {
-        keys_out[i] = keys[i];
-        vals_out[i] = vals[i];
-      }
-    }
-    return;
-  }
-  __shared__ int gbase[256];  // first output position of this tile's keys with digit d
-  __shared__ int s_part[4];
-  {
-    int total = 0, mine = 0;
-    const int* row = hist + t * nblk;
-#pragma unroll 8
-    for (int b = 0; b < nblk; ++b) {  // (independent loads in flight: the loop is latency-bound)
-      const int h = row[b];
-      total += h;
-      mine += b < (int)blockIdx.x ? h : 0;
-    }
-    // exclusive scan of `total` over the 256 digits
-    int incl = total;
-    for (int o = 1; o < 64; o <<= 1) {
-      const int y = __shfl_up(incl, o);
-      if (lane >= o) incl += y;
-    }
-    if (lane == 63) s_part[wave] = incl;
-    __syncthreads();
-    int off = 0;
-    for (int w = 0; w < wave; ++w) off += s_part[w];
-    gbase[t] = off + incl - total + mine;
-  }
-  __shared__ int base_d[256];  // running count of each digit inside this tile
-  __shared__ int wave_cnt[4][256];
-  base_d[t] = 0;
-  const int tile0 = blockIdx.x * RS_TILE;
-  for (int round = 0; round < RS_TILE / 256; ++round) {
-    for (int w = 0; w < 4; ++w) wave_cnt[w][t] = 0;
-    __syncthreads();
-    const int i = tile0 + round * 256 + t;
-    const bool valid = i < n;
-    unsigned long long key = 0;
-    int val = 0, digit = 0;
-    if (valid) {
-      key = keys[i];
-      val = vals[i];
-      digit = (int)((key >> shift) & 255ull);
-    }
-    unsigned long long same = __ballot(valid);  // lanes of this wave holding the same digit
-    for (int b = 0; b < 8; ++b) {
-      const unsigned long long bal = __ballot(valid && ((digit >> b) & 1));
-      same &= ((digit >> b) & 1) ? bal : ~bal;
-    }
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int rank_in_wave = __popcll(same & lt);
-    if (valid && rank_in_wave == 0) wave_cnt[wave][digit] = __popcll(same);
-    __syncthreads();
-    if (valid) {
-      int off = base_d[digit];
-      for (int w = 0; w < wave; ++w) off += wave_cnt[w][digit];
-      const int pos = gbase[digit] + off + rank_in_wave;
-      keys_out[pos] = key;
-      vals_out[pos] = val;
-    }
-    __syncthreads();
-    base_d[t] += wave_cnt[0][t] + wave_cnt[1][t] + wave_cnt[2][t] + wave_cnt[3][t];
-    __syncthreads();
-  }
-}
-// The whole sort as ONE counting pass, for structures with one sort window (the keys are the per-element
-// counts): digit = min(key, 2047).  Counts of ~100 per element resolve exactly; the few rows above 2046 (the
-// literal pseudoXGCm population piles its remainder into one element) land in the last digit in element order
-// and are ordered by k_layout_fused's prologue (wide_fix_tail: up to 1024 of them, else Totals::sort_bad and
-// the caller re-sorts with every 8-bit pass).  Two 8-bit passes + the second histogram cost 34 us at 100 800
-// elements.  hist is [nblk][kWideDigits] (k_make_keys).  Ranks inside the tile
-// as in k_rs_pass, with 16 waves per tile (two rounds); the per-wave counts live in a [16][2048] byte table
-// whose used entries are put back to zero by their writers.
-constexpr int kWideThreads = 1024;
-__global__ void __launch_bounds__(kWideThreads)
-    k_rs_pass_wide(int n, const unsigned long long* __restrict__ keys, const int* __restrict__ vals, int nblk,
-                   const int* __restrict__ hist, unsigned long long* __restrict__ keys_out,
-                   int* __restrict__ vals_out) {
-  constexpr int NW = kWideThreads / 64, R = RS_TILE / kWideThreads, K = kWideDigits / kWideThreads;
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  __shared__ int base_d[kWideDigits];                   // next output position of this tile's keys with digit d
-  __shared__ unsigned char wave_cnt[NW][kWideDigits];   // (a wave holds at most 64 keys of one digit)
-  __shared__ int s_part[NW];
-  // this tile's keys first: their loads fly while the digit table is summed
-  const int tile0 = blockIdx.x * RS_TILE;
-  unsigned long long key[R];
-  int val[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int i = tile0 + r * kWideThreads + t;
-    key[r] = i < n ? keys[i] : 0ull;
-    val[r] = i < n ? vals[i] : 0;
-  }
-  for (int q = t; q < NW * kWideDigits / 16; q += kWideThreads) ((uint4*)&wave_cnt[0][0])[q] = make_uint4(0, 0, 0, 0);
-  {
-    int total[K], mine[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) total[k] = mine[k] = 0;
-    // (thread t owns digits k*1024 + t.  The table was written by the previous kernel's blocks on other XCDs:
-    // every batch of loads costs a trip past the L2, so 16 rows = 32 loads are in flight at a time)
-    for (int b0 = 0; b0 < nblk; b0 += 16) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int b = b0 + j;
-        const int* row = hist + (size_t)min(b, nblk - 1) * kWideDigits + t;
-        const bool before = b < (int)blockIdx.x;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const int h = b < nblk ? row[k * kWideThreads] : 0;
-          total[k] += h;
-          mine[k] += before ? h : 0;
-        }
-      }
-    }
-    int carry = 0;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {  // exclusive scan over the digits in order d = k*1024 + t
-      int incl = total[k];
-      for (int o = 1; o < 64; o <<= 1) {
-        const int y = __shfl_up(incl, o);
-        if (lane >= o) incl += y;
-      }
-      if (lane == 63) s_part[wave] = incl;
-      __syncthreads();
-      int off = 0, all = 0;
-      for (int w = 0; w < NW; ++w) {
-        const int p = s_part[w];
-        off += w < wave ? p : 0;
-        all += p;
-      }
-      base_d[k * kWideThreads + t] = carry + off + incl - total[k] + mine[k];
-      carry += all;
-      __syncthreads();
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const bool valid = tile0 + r * kWideThreads + t < n;
-    const int digit = wide_digit(key[r]);
-    unsigned long long same = __ballot(valid);  // lanes of this wave holding the same digit
-    for (int b = 0; b < kWideBits; ++b) {
-      const unsigned long long bal = __ballot(valid && ((digit >> b) & 1));
-      same &= ((digit >> b) & 1) ? bal : ~bal;
-    }
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int rank_in_wave = __popcll(same & lt);
-    const bool leader = valid && rank_in_wave == 0;
-    const int cnt = __popcll(same);
-    if (leader) wave_cnt[wave][digit] = (unsigned char)cnt;  // own row: zeroed by this wave's leaders last round
-    __syncthreads();
-    if (valid) {
-      int off = base_d[digit];
-      for (int w = 0; w < wave; ++w) off += wave_cnt[w][digit];
-      const int pos = off + rank_in_wave;
-      keys_out[pos] = key[r];
-      vals_out[pos] = val[r];
-    }
-    __syncthreads();
-    if (leader) {
-      atomicAdd(&base_d[digit], cnt);
-      wave_cnt[wave][digit] = 0;
-    }
-  }
-}
-// ---- single-block exclusive scan (int); total written to *total if non-null
-__global__ void k_scan_excl(int n, const int* __restrict__ in, int* __restrict__ out, int* total,
-                            const Totals* skip_tot = nullptr, int skip_shift = 0) {
-  if (skip_tot && (skip_tot->max_key >> skip_shift) == 0) return;  // digit table of an identity pass
-  __shared__ int wsum[16];
-  __shared__ int carry_s;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  if (t == 0) carry_s = 0;
-  __syncthreads();
-  constexpr int ITEMS = 4;
-  for (int base = 0; base < n; base += 1024 * ITEMS) {
-    int v[ITEMS];
-    int s = 0;
-    for (int k = 0; k < ITEMS; ++k) {
-      const int i = base + t * ITEMS + k;
-      v[k] = (i < n) ? in[i] : 0;
-      s += v[k];
-    }
-    int incl = s;
-    for (int o = 1; o < 64; o <<= 1) {
-      const int y = __shfl_up(incl, o);
-      if (lane >= o) incl += y;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wsum[w];
-    int run = carry_s + woff + incl - s;
-    for (int k = 0; k < ITEMS; ++k) {
-      const int i = base + t * ITEMS + k;
-      if (i < n) out[i] = run;
-      run += v[k];
-    }
-    __syncthreads();
-    if (t == 1023) carry_s = run;
-    __syncthreads();
-  }
-  if (t == 0 && total) *total = carry_s;
-}
-
-// ---- three-launch scan for long arrays (radix digit tables of ~10^5 entries, CSR offsets of 10^6
-// elements): per-block local scan + block totals, single-block scan of the totals, offset add.
-// The single-block kernel above needs ~2.4 us per 4096 items (71 us for 125 k entries).
-__global__ void __launch_bounds__(1024) k_scan_local(int n, const int* __restrict__ in, int* __restrict__ out,
-                                                     int* __restrict__ block_tot, const Totals* skip_tot,
-                                                     int skip_shift) {
-  if (skip_tot && (skip_tot->max_key >> skip_shift) == 0) return;
-  __shared__ int wsum[16];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  constexpr int ITEMS = 4;
-  const int base = blockIdx.x * 1024 * ITEMS;
-  int v[ITEMS];
-  int s = 0;
-  for (int k = 0; k < ITEMS; ++k) {
-    const int i = base + t * ITEMS + k;
-    v[k] = (i < n) ? in[i] : 0;
-    s += v[k];
-  }
-  int incl = s;
-  for (int o = 1; o < 64; o <<= 1) {
-    const int y = __shfl_up(incl, o);
-    if (lane >= o) incl += y;
-  }
-  if (lane == 63) wsum[wave] = incl;
-  __syncthreads();
-  int woff = 0;
-  for (int w = 0; w < wave; ++w) woff += wsum[w];
-  int run = woff + incl - s;
-  for (int k = 0; k < ITEMS; ++k) {
-    const int i = base + t * ITEMS + k;
-    if (i < n) out[i] = run;
-    run += v[k];
-  }
-  if (t == 1023) block_tot[blockIdx.x] = run;
-}
-__global__ void k_scan_add(int n, int* __restrict__ out, const int* __restrict__ block_off,
-                           const Totals* skip_tot, int skip_shift) {
-  if (skip_tot && (skip_tot->max_key >> skip_shift) == 0) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] += block_off[i / 4096];
-}
-// exclusive scan of n ints on the stream; *total (device, may be null) receives the sum
-int scan_excl(pp::DevBuf& scratch, int n, const int* in, int* out, int* total, hipStream_t st,
-              const Totals* skip_tot = nullptr, int skip_shift = 0) {
-  if (n <= 16384) {
-    k_scan_excl<<<1, 1024, 0, st>>>(n, in, out, total, skip_tot, skip_shift);
-    return PP_OK;
-  }
-  const int nb = (n + 4095) / 4096;
-  PP_HIP_CHECK(scratch.reserve(sizeof(int) * 2 * (size_t)nb));
-  int* bt = (int*)scratch.p;
-  k_scan_local<<<nb, 1024, 0, st>>>(n, in, out, bt, skip_tot, skip_shift);
-  k_scan_excl<<<1, 1024, 0, st>>>(nb, bt, bt + nb, total, skip_tot, skip_shift);
-  k_scan_add<<<grid_for(n), kBlock, 0, st>>>(n, out, bt + nb, skip_tot, skip_shift);
-  return PP_OK;
-}
-
-// serial sum of 1/width in chunk order (only PAD_INVERSELY needs it; order-dependent in fp)
-__global__ void k_cw_inv_serial(int nchunks, const int* __restrict__ widths, Totals* tot) {
-  if (blockIdx.x || threadIdx.x) return;
-  double s = 0;
-  for (int c = 0; c < nchunks; ++c)
-    if (widths[c] > 0) s += 1.0 / widths[c];
-  tot->cw_inv = s;
-}
-__global__ void k_apply_padding(int nchunks, int pad_strat, double pad, int* __restrict__ widths,
-                                const Totals* tot) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= nchunks) return;
-  const int cw_sum = tot->cw_sum;
-  if (cw_sum <= 0) return;
-  int w = widths[c];
-  if (pad_strat == PP_PAD_EVENLY) {
-    const int avg_pad = (int)(cw_sum * pad / tot->cw_cnt);
-    if (w > 0) w += avg_pad;
-  } else if (pad_strat == PP_PAD_PROPORTIONALLY) {
-    w = (int)(w + w * pad);
-  } else {
-    const double cw_sum2 = cw_sum / tot->cw_inv * pad;
-    if (w != 0) w = (int)(w + cw_sum2 / w);
-  }
-  widths[c] = w;
-}
-__global__ void k_slices_and_slots(int nchunks, int C, int V, const int* __restrict__ widths,
-                                   int* __restrict__ nsl, int* __restrict__ nslots) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= nchunks) return;
-  const int w = widths[c];
-  nsl[c] = w / V + ((w % V) != 0);
-  nslots[c] = w * C;
-}
-__global__ void k_tile_count(int nchunks, int TP, const int* __restrict__ widths,
-                             int* __restrict__ ntl) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < nchunks) ntl[c] = (widths[c] + TP - 1) / TP;
 }
 // The same for chunk heights that are a multiple of 4: a thread covers four adjacent rows of a tile, so the
 // mask leaves as 4-byte words (k_init_slots_tiled stores single bytes: 10.7 us per 10 M slots against the
@@ -972,42 +445,6 @@ __global__ void k_reduce_widths(int nchunks, const int* __restrict__ widths, Tot
     tot->cw_cnt = Cn;
   }
 }
-// Prologue of the layout kernel after k_rs_pass_wide (one block of 1024 threads): the keys of the overflow
-// digit sit at the end of the sorted arrays in element order; order them by key, ties by position (= the
-// stable order the 8-bit passes produce).
-__device__ void wide_fix_tail(int ne, int nblk, const int* __restrict__ hist, unsigned long long* keys,
-                              int* vals, Totals* tot) {
-  __shared__ unsigned long long fk[1024];
-  __shared__ int fv[1024];
-  __shared__ int s_n[16];
-  const int t = threadIdx.x;
-  int n = 0;
-  for (int b = t; b < nblk; b += 1024) n += hist[(size_t)b * kWideDigits + kWideDigits - 1];
-  for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
-  if ((t & 63) == 0) s_n[t >> 6] = n;
-  __syncthreads();
-  n = 0;
-  for (int w = 0; w < 16; ++w) n += s_n[w];
-  if (n <= 1) return;  // (block-uniform)
-  if (n > 1024) {
-    if (t == 0) tot->sort_bad = 1;
-    return;
-  }
-  const int start = ne - n;
-  if (t < n) {
-    fk[t] = keys[start + t];
-    fv[t] = vals[start + t];
-  }
-  __syncthreads();
-  if (t < n) {
-    const unsigned long long k = fk[t];
-    int r = 0;
-    for (int j = 0; j < n; ++j) r += (fk[j] < k) || (fk[j] == k && j < t);
-    keys[start + r] = k;
-    vals[start + r] = fv[t];
-  }
-  __syncthreads();
-}
 // One block does the whole O(nchunks) part of the layout that used to be seven launches:
 // width reduction (cw_sum, cw_cnt), padding (EVENLY / PROPORTIONALLY / none; INVERSELY needs the
 // ordered fp sum and keeps the separate kernels), slices / slots / tiles per chunk and their three
@@ -1020,7 +457,13 @@ __global__ void __launch_bounds__(1024)
                    const int* __restrict__ partial, int npartial,
                    const unsigned long long* keys_sorted = nullptr, int ne = 0,
                    unsigned long long* fix_keys = nullptr, int* fix_vals = nullptr,
-                   const int* __restrict__ wide_hist = nullptr) {
+                   const int* __restrict__ wide_hist = nullptr, pp::GyroRide ride = pp::GyroRide{},
+                   Totals* host_out = nullptr, int host_stamp = 0) {
+  if (blockIdx.x > 0) {  // gyroScatter's second stage riding along (pp::GyroRide; its first stage rode k_make_keys)
+    pp::gyro_gather_body((blockIdx.x - 1) * 1024 + threadIdx.x, ride.nverts, ride.gppr, ride.off, ride.src, ride.ring,
+                         ride.out, ride.out2);
+    return;
+  }
   if (fix_keys) wide_fix_tail(ne, npartial, wide_hist, fix_keys, fix_vals, tot);
   __shared__ int ssum[16], scnt[16];
   __shared__ int w3[16][3];
@@ -1164,6 +607,19 @@ __global__ void __launch_bounds__(1024)
     *ntiles_out = carry[2];
     // the speculative tail's gate (k_spec_check) rides here: one launch less per rebuild
     if (sp.on) spec_decide(tot, sp.cap_lim, sp.nsl_lim, sp.C_max, key_bits, sp.keep_if_fits);
+    // the totals, final now, straight into the host's pinned landing zone: no copy dispatch (4 us + a 6 us gap
+    // before the next kernel) between this kernel and the tail
+    // (host_stamp != 0: the host polls pad_[0] for it instead of waiting for an event behind this kernel -- an
+    // event record is a barrier packet, 6 us before the next kernel starts)
+    if (host_out) {
+      Totals v = *tot;
+      v.pad_[0] = 0;
+      *host_out = v;
+      if (host_stamp) {
+        __threadfence_system();
+        __hip_atomic_store(&host_out->pad_[0], host_stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
 }
 __global__ void k_chunk_widths2(int nchunks, int C, int ne, const unsigned long long* __restrict__ keys,
@@ -2117,6 +1573,7 @@ struct LayoutPlan {
   int key_bits;  // key bits the radix passes of this attempt covered (64 = every bit)
   bool sorted;
   bool wide;  // sorted by k_rs_pass_wide: the layout kernel orders the overflow digit
+  bool totals_on_host;  // the layout kernel wrote the totals to the pinned landing zone itself
   unsigned long long base;
   unsigned long long* keys;
   int* index;
@@ -2128,10 +1585,12 @@ struct LayoutPlan {
 int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_base, LayoutPlan& L,
                    int bits_limit = 0, ElemTotalsArgs et = ElemTotalsArgs{0, 0, 1, nullptr, nullptr, nullptr},
                    SpecArgs sp = SpecArgs{0, 0, 0, 0, 0}, const LayoutTablesArgs* tables = nullptr,
-                   bool allow_wide = false) {
+                   bool allow_wide = false, Totals* host_out = nullptr, int host_stamp = 0) {
   hipStream_t st = pp::stream();
   const int ne = ps->num_elems;
+  pp::GyroRide ride{};
   L.wide = false;
+  L.totals_on_host = false;
   L.C = C_new;
   L.nchunks = ne / C_new + (ne % C_new != 0);
   L.nrows = L.nchunks * C_new;
@@ -2170,11 +1629,16 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
     L.wide = wide_sort;
     if (wide_sort) L.key_bits = 64;  // (its own check: Totals::sort_bad)
     int* const H0 = ps->s_hist.as<int>();
-    k_make_keys<<<nblk, 256, 0, st>>>(ne, ppe, sg, n_sigma, L.base,
+    // gyroScatter of a pp_ps_rebuild_scatter call rides in this launch and in the layout kernel's (pp::GyroRide)
+    const bool ride_ok = ps->ride && ps->ride->on && !ps->ride_done &&
+                         (ps->pad_strat != PP_PAD_INVERSELY || !(ps->shuffle_padding > 0));
+    if (ride_ok) ride = *ps->ride;
+    k_make_keys<<<nblk + (ride.on ? grid_for(ride.nverts) : 0), 256, 0, st>>>(ne, ppe, sg, n_sigma, L.base,
                                                  ps->s_keys.as<unsigned long long>(),
                                                  ps->s_vals.as<int>(), tot,
                                                  getenv("PP_NO_RS_SKIP") != nullptr, et,
-                                                 fused_sort ? FusedHist{H0, nblk, wide_sort ? 1 : 0} : FusedHist{nullptr, 0, 0});
+                                                 fused_sort ? FusedHist{H0, nblk, wide_sort ? 1 : 0} : FusedHist{nullptr, 0, 0},
+                                                 nblk, ride);
     unsigned long long *ka = ps->s_keys.as<unsigned long long>(),
                        *kb = ps->s_keys2.as<unsigned long long>();
     int *va = ps->s_vals.as<int>(), *vb = ps->s_vals2.as<int>();
@@ -2222,12 +1686,16 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
         nchunks, C_new, ne, L.keys, L.base, L.sorted ? 1 : 0, ppe, L.widths);
   PP_HIP_CHECK(ps->s_scan.reserve(sizeof(int)));
   if (fused_layout) {
-    k_layout_fused<<<1, 1024, 0, st>>>(nchunks, C_new, ps->V, ps->tile_p, ps->pad_strat,
+    k_layout_fused<<<1 + (ride.on ? (unsigned)(((size_t)ride.nverts * 16 + 1023) / 1024) : 0), 1024, 0, st>>>(
+                                       nchunks, C_new, ps->V, ps->tile_p, ps->pad_strat,
                                        ps->shuffle_padding, L.widths, L.slice_off, L.chunk_start,
                                        L.tile_off, tot, ps->s_scan.as<int>(), sp, L.key_bits,
                                        L.sorted ? et.partial : nullptr, (ne + RS_TILE - 1) / RS_TILE,
                                        widths_in_layout ? L.keys : nullptr, ne, L.wide ? L.keys : nullptr,
-                                       L.wide ? L.index : nullptr, L.wide ? ps->s_hist.as<int>() : nullptr);
+                                       L.wide ? L.index : nullptr, L.wide ? ps->s_hist.as<int>() : nullptr, ride,
+                                       host_out, host_stamp);
+    if (ride.on) ps->ride_done = true;
+    L.totals_on_host = host_out != nullptr;
   } else {
     k_reduce_widths<<<1, 1024, 0, st>>>(nchunks, L.widths, tot);
     k_cw_inv_serial<<<1, 64, 0, st>>>(nchunks, L.widths, tot);
@@ -2287,7 +1755,8 @@ int totals_pin(Totals** h_pin_out, hipEvent_t* ev_out) {
   static Totals* h_pin = nullptr;
   static hipEvent_t ev_tot = nullptr;
   if (!h_pin) {
-    PP_HIP_CHECK(hipHostMalloc((void**)&h_pin, sizeof(Totals)));
+    PP_HIP_CHECK(hipHostMalloc((void**)&h_pin, sizeof(Totals), hipHostMallocCoherent | hipHostMallocMapped));
+    memset(h_pin, 0, sizeof(Totals));
     PP_HIP_CHECK(hipEventCreateWithFlags(&ev_tot, hipEventDisableTiming));
   }
   *h_pin_out = h_pin;
@@ -2592,11 +2061,21 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   LayoutTablesArgs ta_spec{};
   if (spec_ok)
     if (int rct = make_tables((int)cap_lim, (int)nsl_lim, ta_spec)) return rct;
+  Totals* h_pin = nullptr;
+  hipEvent_t ev_tot = nullptr;
+  if (int rcp = totals_pin(&h_pin, &ev_tot)) return rcp;
+  static const bool no_direct_totals = getenv("PP_NO_DIRECT_TOTALS") != nullptr;
+  // the host polls the landing zone for this rebuild's stamp (no event in the stream); one poll that runs into
+  // its time limit (the memory turned out not to be visible mid-stream) switches back to the event for good
+  static bool poll_totals = getenv("PP_NO_POLL_TOTALS") == nullptr;
+  static int stamp_seq = 0;
+  const int stamp = (poll_totals && !no_direct_totals) ? (stamp_seq = stamp_seq % 1000000 + 1) : 0;
   int rc = enqueue_layout(ps, ps->C_max, ppe, tot, key_base, L, bits_pred,
                           ElemTotalsArgs{totals_in_keys ? 1 : 0, (totals_in_keys && decide_keep) ? 1 : 0, ps->C,
                                          ps->d_element_to_row.as<int>(), ps->d_chunk_width.as<int>(), nullptr},
                           SpecArgs{spec_ok ? 1 : 0, (int)cap_lim, (int)nsl_lim, ps->C_max, decide_keep ? 1 : 0},
-                          spec_ok ? &ta_spec : nullptr, /*allow_wide=*/true);
+                          spec_ok ? &ta_spec : nullptr, /*allow_wide=*/true, no_direct_totals ? nullptr : h_pin, stamp);
+  const bool polling = stamp != 0 && L.totals_on_host;
   if (rc) return rc;
   nchunks = L.nchunks;
   nrows = L.nrows;
@@ -2713,23 +2192,42 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   // no-ops.  The sync then happens once, after everything is queued.
   bool speculated = false;
   const int64_t swap_stride_before = ps->swap_stride;  // the speculative tail re-labels the swap buffers
+  // The totals are final when the layout kernel ends.  They travel to pinned memory right behind it and the
+  // host waits for THAT copy only: the tail (tables, slot init, the move) is enqueued behind the copy and is
+  // still running when the host has finished its bookkeeping and the caller issues the next push -- the
+  // host's wake-up is off the GPU's critical path (before: copy behind the tail, 27 us idle per step once the
+  // scatter kernels that used to cover it rode in the rebuild's own launches).
+  // (the layout kernel writes them there itself; the separate-kernel layout of PAD_INVERSELY copies them)
+  if (!L.totals_on_host) PP_HIP_CHECK(hipMemcpyAsync(h_pin, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
+  if (!polling) PP_HIP_CHECK(hipEventRecord(ev_tot, st));
   if (spec_ok) {  // (the gate itself ran at the end of the layout kernel)
     rc = enqueue_tail((int)cap_lim, (int)nsl_lim, stride_fit);
     if (rc) return rc;
     speculated = true;
   }
-  // The totals travel to pinned memory and the host waits for THAT copy only: whatever `pre_sync`
-  // enqueues behind it keeps the GPU busy while the host wakes up and issues its next calls.
-  Totals* h_pin = nullptr;
-  hipEvent_t ev_tot = nullptr;
-  if ((rc = totals_pin(&h_pin, &ev_tot))) return rc;
-  PP_HIP_CHECK(hipMemcpyAsync(h_pin, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
-  PP_HIP_CHECK(hipEventRecord(ev_tot, st));
-  if (pre_sync) {
+  if (pre_sync && !ps->ride_done) {  // (ride_done: the scatter rode in the key sweep and the layout kernel)
     rc = pre_sync(ppe);
     if (rc) return rc;
   }
-  PP_HIP_CHECK(hipEventSynchronize(ev_tot));  // the only host wait of a regular rebuild
+  if (polling) {  // the only host wait of a regular rebuild
+    const auto t0 = std::chrono::steady_clock::now();
+    volatile int* flag = &h_pin->pad_[0];
+    long spins = 0;
+    while (*flag != stamp) {
+      if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+        PP_HIP_CHECK(hipStreamSynchronize(st));  // everything queued has run: either the stamp is there now ...
+        if (*flag != stamp) {                    // ... or kernel stores do not reach this memory mid-stream
+          poll_totals = false;
+          PP_HIP_CHECK(hipMemcpyAsync(h_pin, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
+          PP_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        break;
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  } else {
+    PP_HIP_CHECK(hipEventSynchronize(ev_tot));
+  }
   Totals h = *h_pin;
   if (h.invalid) {
     ps->swap_stride = swap_stride_before;
@@ -3391,10 +2889,18 @@ int pp::ps_rebuild_scatter(pp_ps* ps, int m_x, int m_xtgt, const int* new_elemen
   auto scatter = [&](const int* counts) -> int {
     return pp::gyro_scatter_counts(mesh, counts, nmaps, v2v_dev, scatter_w_dev, rmax, gnr, gppr);
   };
-  return scs_rebuild(ps, new_element_dev, n_new, new_elems_dev, new_info_dev, commit ? m_x : -1,
-                     commit ? m_xtgt : -1, nmaps > 0 ? std::function<int(const int*)>(scatter)
-                                                     : std::function<int(const int*)>(),
-                     true, new_xt_zero && commit);
+  pp::GyroRide ride{};
+  if (nmaps > 0)
+    if (int rc = pp::gyro_scatter_ride(mesh, nmaps, v2v_dev, scatter_w_dev, rmax, gnr, gppr, &ride)) return rc;
+  ps->ride = &ride;
+  ps->ride_done = false;
+  const int rc = scs_rebuild(ps, new_element_dev, n_new, new_elems_dev, new_info_dev, commit ? m_x : -1,
+                             commit ? m_xtgt : -1, nmaps > 0 ? std::function<int(const int*)>(scatter)
+                                                             : std::function<int(const int*)>(),
+                             true, new_xt_zero && commit);
+  ps->ride = nullptr;
+  ps->ride_done = false;
+  return rc;
 }
 extern "C" {
 

@@ -157,12 +157,8 @@ __global__ void k_count_csr(int ne, const int* __restrict__ offsets, int* __rest
 __global__ void k_rings_from_adjacency(int nverts, int gnr, const int* __restrict__ v2e_off,
                                        const int* __restrict__ v2e, const int* __restrict__ cnt,
                                        int ringDown, int ringUp, double* __restrict__ ring_accum) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= nverts) return;
-  long long n = 0;
-  for (int j = v2e_off[v]; j < v2e_off[v + 1]; ++j) n += cnt[v2e[j]];
-  for (int r = 0; r < gnr; ++r)
-    ring_accum[(size_t)v * gnr + r] = (r == ringUp ? (double)n : 0.0) + (r == ringDown ? (double)n : 0.0);
+  pp::gyro_rings_body(blockIdx.x * blockDim.x + threadIdx.x, nverts, gnr, v2e_off, v2e, cnt, ringDown, ringUp,
+                      ring_accum);  // (pp_internal.hpp: shared with the rebuild's key sweep, pp::GyroRide)
 }
 // ---- general first stage: per-particle gyro radius and weight (the reference's "TODO compute the
 // radius", gyroScatter.hpp:184).  A row's particles share their element, so the thread that walks
@@ -325,26 +321,8 @@ __global__ void k_inv_sort(int nverts, const int* __restrict__ off, int* __restr
 __global__ void k_scatter_gathered(int nverts, int gppr, const int* __restrict__ off,
                                    const int* __restrict__ src, const double* __restrict__ ring_accum,
                                    double* __restrict__ scatter_w, double* __restrict__ scatter_w2 = nullptr) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  const int t = g >> 4, sub = g & 15, lane0 = (threadIdx.x & 63) & ~15;
-  const bool in = t < nverts;
-  const int b = in ? off[t] : 0, e = in ? off[t + 1] : 0;
-  int len = e - b;
-  for (int o = 16; o < 64; o <<= 1) len = max(len, __shfl_xor(len, o));  // wave-uniform trip count
-  double w = 0;
-  for (int base = 0; base < len; base += 16) {
-    const int j = b + base + sub;
-    const double val = j < e ? ring_accum[src[j]] / gppr : 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const double x = __shfl(val, lane0 + k);
-      if (b + base + k < e) w += x;
-    }
-  }
-  if (in && sub == 0) {
-    scatter_w[t] = w;
-    if (scatter_w2) scatter_w2[t] = w;  // a second map with the same transpose: the same sums in the same order
-  }
+  pp::gyro_gather_body(blockIdx.x * blockDim.x + threadIdx.x, nverts, gppr, off, src, ring_accum, scatter_w,
+                       scatter_w2);  // (pp_internal.hpp: shared with the rebuild's layout kernel, pp::GyroRide)
 }
 __global__ void k_sync_pack(int nverts, const double* __restrict__ f, const double* __restrict__ b,
                             double* __restrict__ out) {
@@ -413,6 +391,36 @@ void gyro_map_invalidate(const void* dev, size_t bytes) {
       ++i;
     }
   }
+}
+int gyro_scatter_ride(const pp_mesh* mesh, int nmaps, const int* const* v2v_dev, double* const* out_dev,
+                      double rmax, int gnr, int gppr, GyroRide* ride) {
+  *ride = GyroRide{};
+  static const bool off = getenv("PP_SCATTER_ATOMIC") != nullptr || getenv("PP_NO_SCATTER_RIDE") != nullptr;
+  if (off || mesh->nverts <= 0 || nmaps < 1 || nmaps > 2) return PP_OK;
+  const InvMap* inv = find_inverse(v2v_dev[0], mesh, gnr, gppr);
+  if (!inv) return PP_OK;
+  if (nmaps == 2 && !(find_inverse(v2v_dev[1], mesh, gnr, gppr) == inv && out_dev[1] != out_dev[0])) return PP_OK;
+  const double ringWidth = rmax / gnr;
+  const double ptclRadius = ringWidth * 1.125;  // gyroScatter.hpp:184-187
+  int ringDown = 0;
+  for (int i = 2; i <= gnr; i++) ringDown += (ptclRadius >= ringWidth * i);
+  if (!g_ring) g_ring = new pp::DevBuf();
+  PP_HIP_CHECK(g_ring->reserve(sizeof(double) * (size_t)std::max(mesh->nverts * gnr, 1)));
+  c_ps = nullptr;  // the accumulator no longer belongs to a (structure, version) pair
+  ride->on = 1;
+  ride->nverts = mesh->nverts;
+  ride->gnr = gnr;
+  ride->ringDown = ringDown;
+  ride->ringUp = ringDown + 1;
+  ride->gppr = gppr;
+  ride->v2e_off = mesh->d_vert2elems_off.as<int>();
+  ride->v2e = mesh->d_vert2elems.as<int>();
+  ride->ring = g_ring->as<double>();
+  ride->off = inv->off.as<int>();
+  ride->src = inv->src.as<int>();
+  ride->out = out_dev[0];
+  ride->out2 = nmaps == 2 ? out_dev[1] : nullptr;
+  return PP_OK;
 }
 int gyro_scatter_counts(const pp_mesh* mesh, const int* cnt_dev, int nmaps, const int* const* v2v_dev,
                         double* const* out_dev, double rmax, int gnr, int gppr) {

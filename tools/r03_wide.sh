@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r03_wide; mkdir -p $O; cd $R
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.txt 2>&1; tail -3 $O/pytest.txt
 for i in 1 2; do
-for cfg in "X=1" "PP_EAGER_SLOT_ELEM=1"; do
+for cfg in "X=1" "PP_NO_POLL_TOTALS=1"; do
   for wl in c3 2dc3; do
     echo "== $cfg $wl" >> $O/ab.txt
     env $cfg PP_BENCH_NO_EXTRAS=1 timeout 300 python bench.py --workload $wl --no-cpu-baseline --no-scale-ref 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['ms_per_step'], j['roofline']['frac'])" >> $O/ab.txt
