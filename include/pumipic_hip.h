@@ -569,10 +569,11 @@ int pp_migrate_ptcls_begin(pp_ps* ps, int m_x, int m_xtgt, int* elem_ids_dev, co
  * by classification: pp_owner_by_classification first).  buffer_method / safe_method = Input::Method
  * (src/pumipic_input.hpp:33-39: PP_PART_FULL, _BFS, _MINIMUM, _NONE; a NONE buffer is MINIMUM),
  * bridge_dim 0 (vertices) or dim-1 (sides), *_layers = bufferBFSLayers / safeBFSLayers (MINIMUM: 0).
- * Entity dimensions served: 0 (vertices), dim-1 (sides: edges of triangles, faces of tets) and dim (elements)
- * -- pp_mesh numbers no edges of tets.  Vertices and elements of a part are the kept ones in full-mesh order
- * (:181-194); its sides are numbered by the part's own pp_mesh (PP_MESH_SIDE2VERTS ...), PP_PART_FULL_IDS maps
- * them to the full mesh.  What travels between ranks is defined on full-mesh ids.
+ * Entity dimensions served: every dimension 0..dim, as the reference loops them (vertices, edges, faces of
+ * tets, elements; the edges of a tet mesh are numbered by pp_mesh_num_edges / PP_MESH_EDGE2VERTS).  Vertices
+ * and elements of a part are the kept ones in full-mesh order (:181-194); its sides and edges are numbered by
+ * the part's own pp_mesh (PP_MESH_SIDE2VERTS, PP_MESH_EDGE2VERTS ...), PP_PART_FULL_IDS maps them to the full
+ * mesh.  What travels between ranks is defined on full-mesh ids.
  *
  * What the reference exchanges at construction (MPI_Ialltoall of boundary sizes, Isend/Irecv of the
  * boundary lids, :113-190) is recomputed locally instead: every rank holds the full mesh and the

@@ -36,10 +36,11 @@ void updatePtclPositions(PS* ptcls) {
 }
 
 void rebuild(p::Mesh& picparts, PS* ptcls, p::Distributor& dist, o::LOs elem_ids, const bool output) {
-  (void)dist;
   (void)output;
   updatePtclPositions(ptcls);
-  pumipic::migrate_lb_ptcls(picparts, ptcls, elem_ids, 1.05);
+  // (the reference's driver builds `dist` and its migrate_lb_ptcls then uses the world form; here the subset is
+  // handed on, so that the migration is checked against it)
+  pumipic::migrate_lb_ptcls(picparts, ptcls, elem_ids, 1.05, 0.5, &dist);
 }
 
 void search(p::Mesh& picparts, PS* ptcls, p::Distributor& dist, bool output) {
@@ -241,7 +242,12 @@ int main(int argc, char** argv) {
   p::Mesh& picparts = part_mesh ? *part_mesh : full_mesh;
   o::Mesh* mesh = picparts.mesh();
   if (!comm_rank) printf("Mesh loaded with <v e f> %d %d %d\n", mesh->nverts(), mesh->nsides(), mesh->nelems());
-  p::Distributor dist(world);
+  // the ranks this part exchanges particles with: itself + the buffered ranks (test/pseudoXGCm.cpp:390-396);
+  // PP_DIST_SELF_ONLY=1 lists nobody else (a migration to another rank must then be refused: tests)
+  std::vector<int> dist_ranks(1, comm_rank);
+  if (!getenv("PP_DIST_SELF_ONLY"))
+    for (int r : picparts.bufferedRanks(picparts.dim())) dist_ranks.push_back(r);
+  p::Distributor dist((int)dist_ranks.size(), dist_ranks.data(), world);
 
   // Build gyro avg mappings
   const auto rmax = 0.038;

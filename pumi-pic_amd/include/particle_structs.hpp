@@ -21,6 +21,8 @@
 #include <memory>
 #include <string>
 #include <type_traits>
+#include <utility>
+#include <map>
 #include <vector>
 #include "../../include/pumipic_hip.h"
 
@@ -202,23 +204,53 @@ inline pp_comm* comm_world() {
   }
   return c;
 }
-// support/psDistributor.hpp:10-138.  The reference's Distributor names an MPI communicator and,
-// optionally, the subset of ranks a structure exchanges with; the exchange here is one grouped
-// send/recv per peer with a non-zero count, so the rank subset needs no separate code path: only
-// the world form (isWorld() == true) is kept, over a pp_comm.
+// support/psDistributor.hpp:10-138.  A Distributor names the communicator a structure migrates over and,
+// optionally, the subset of ranks it exchanges with (`Distributor(nr, rnks)`: self + the buffered ranks of a
+// PICpart in test/pseudoXGCm.cpp:390-396, the two neighbours in particle_structs/test/test_migrate.cpp:60-64).
+// The exchange here is one grouped send/recv per peer with a non-zero count whatever the subset, so the subset
+// changes no message; what it keeps is the reference's contract -- index(process) is defined for the listed
+// ranks only -- which ParticleStructure::migrate checks before anything moves (a particle bound for a rank
+// outside the subset is an error here, undefined behaviour there).
 class Distributor {
  public:
   Distributor() : comm_(nullptr) {}
   explicit Distributor(pp_comm* c) : comm_(c) {}
+  Distributor(int nr, const int* rnks, pp_comm* c = nullptr) : comm_(c) { setRanks(nr, rnks); }
+  template <class ViewT, class = decltype(std::declval<const ViewT&>().size())>
+  explicit Distributor(const ViewT& rnks, pp_comm* c = nullptr) : comm_(c) {
+    setRanks(rnks);
+  }
+  void setRanks(int nr, const int* rnks) {
+    ranks_.assign(rnks, rnks + nr);
+    buildMap();
+  }
+  template <class ViewT>
+  void setRanks(const ViewT& rnks) {
+    ranks_.resize(rnks.size());
+    for (size_t i = 0; i < ranks_.size(); ++i) ranks_[i] = rnks[i];
+    buildMap();
+  }
+  void buildMap() {
+    index_.clear();
+    for (size_t i = 0; i < ranks_.size(); ++i) index_[ranks_[i]] = (int)i;
+  }
   pp_comm* comm() const { return comm_ ? comm_ : comm_world(); }
-  bool isWorld() const { return true; }
-  int num_ranks() const { return pp_comm_size(comm()); }
-  int rank_host(int i) const { return i; }
-  PP_INLINE int rank(int i) const { return i; }
-  PP_INLINE int index(int process) const { return process; }
+  pp_comm* mpi_comm() const { return comm(); }
+  bool isWorld() const { return ranks_.empty(); }
+  int num_ranks() const { return isWorld() ? pp_comm_size(comm()) : (int)ranks_.size(); }
+  int rank_host(int i) const { return isWorld() ? i : ranks_[(size_t)i]; }
+  int rank(int i) const { return rank_host(i); }
+  // position of `process` in the subset; -1 when it is not listed (the reference: undefined)
+  int index(int process) const {
+    if (isWorld()) return process;
+    const auto it = index_.find(process);
+    return it == index_.end() ? -1 : it->second;
+  }
 
  private:
   pp_comm* comm_;
+  std::vector<int> ranks_;
+  std::map<int, int> index_;
 };
 
 enum PaddingStrategy { PAD_EVENLY = 0, PAD_PROPORTIONALLY = 1, PAD_INVERSELY = 2 };
@@ -266,6 +298,18 @@ class ParticleStructure {
   // receiver's rebuild as new particles; one rank -> plain rebuild (:20-25)
   virtual void migrate(kkLidView new_element, kkLidView new_process, Distributor dist = Distributor(),
                        kkLidView new_particle_elements = kkLidView(), MTVs new_particle_info = NULL) {
+    if (!dist.isWorld() && capacity() > 0) {  // every leaving particle goes to a rank of the subset
+      const int world = pp_comm_size(dist.comm()), self = pp_comm_rank(dist.comm());
+      std::vector<int> sends((size_t)world, 0);
+      pp_check(pp_ps_migrate_count(h_, new_element.data(), new_process.data(), self, world, sends.data()),
+               "ParticleStructure::migrate (send counts)");
+      for (int r = 0; r < world; ++r)
+        if (r != self && sends[(size_t)r] > 0 && dist.index(r) < 0) {
+          fprintf(stderr, "[ERROR] ParticleStructure::migrate: %d particle(s) bound for rank %d, which the "
+                          "Distributor does not list\n", sends[(size_t)r], r);
+          pp_check(PP_EINVAL, "ParticleStructure::migrate (Distributor rank subset)");
+        }
+    }
     pp_check(pp_ps_migrate_scatter(h_, -1, -1, new_element.data(), new_process.data(), dist.comm(),
                                    (int)new_particle_elements.size(), new_particle_elements.data(),
                                    (const void* const*)new_particle_info, nullptr, 0, nullptr, 0, nullptr,

@@ -746,22 +746,26 @@ void setUnsafeProcs(Mesh& mesh, PS* ptcls, o::LOs elems, typename PS::kkLidView 
 // migrate_lb_ptcls runs the part's balancer between setUnsafeProcs and the migration, as the reference does
 // (ParticleBalancer::repartition, pumipic_lb.hpp:352-362); a mesh partitioned with Mesh::partition (the
 // full-mesh replica without an Input) has none: particles go to the owner of their element.
+// (`dist`: the reference's two functions migrate over the world Distributor; a caller that holds the subset
+// form -- self + the buffered ranks of its part, test/pseudoXGCm.cpp:390-396 -- may pass it: the migration is
+// then checked against it, ParticleStructure::migrate)
 template <class PS>
-void migrate_ptcls(Mesh& mesh, PS* ptcls, o::LOs elems) {
+void migrate_ptcls(Mesh& mesh, PS* ptcls, o::LOs elems, const Distributor* dist = nullptr) {
   Timer init_timer;
   const size_t cap = (size_t)std::max(ptcls->capacity(), 1);
   typename PS::kkLidView new_elems("ps_element_ids", cap), new_procs("ps_process_ids", cap);
   setUnsafeProcs(mesh, ptcls, elems, new_elems, new_procs);
   RecordTime("migration_init", init_timer.seconds());
   Timer migrate_timer;
-  ptcls->migrate(new_elems, new_procs, Distributor(mesh.comm()));
+  ptcls->migrate(new_elems, new_procs, dist ? *dist : Distributor(mesh.comm()));
   RecordTime("migration", migrate_timer.seconds());
 }
 template <class PS>
-void migrate_lb_ptcls(Mesh& mesh, PS* ptcls, o::LOs elems, float tol, float step_factor = 0.5) {
+void migrate_lb_ptcls(Mesh& mesh, PS* ptcls, o::LOs elems, float tol, float step_factor = 0.5,
+                      const Distributor* dist = nullptr) {
   pp_balancer* balancer = mesh.ptclBalancerHandle();
   if (!balancer) {
-    migrate_ptcls(mesh, ptcls, elems);
+    migrate_ptcls(mesh, ptcls, elems, dist);
     return;
   }
   Timer init_timer;
@@ -774,7 +778,7 @@ void migrate_lb_ptcls(Mesh& mesh, PS* ptcls, o::LOs elems, float tol, float step
            "ParticleBalancer::repartition");
   RecordTime("migration_balance", balance_timer.seconds());
   Timer migrate_timer;
-  ptcls->migrate(new_elems, new_procs, Distributor(mesh.comm()));
+  ptcls->migrate(new_elems, new_procs, dist ? *dist : Distributor(mesh.comm()));
   RecordTime("migration", migrate_timer.seconds());
 }
 

@@ -451,6 +451,36 @@ def test_cpp_driver_pseudoxgcm_two_ranks(synth, capi, tmp_path):
     assert "Reduced Timing Summary" in outs[0][1] and "gyro reduction" in outs[0][1]
 
 
+def test_cpp_driver_distributor_rank_subset_is_enforced(synth, capi, tmp_path):
+    """support/psDistributor.hpp:10-138, the rank-subset form: the driver lists itself + the buffered ranks of
+    its part (the two-rank test above runs with that list); with PP_DIST_SELF_ONLY=1 it lists nobody else, and
+    the first migration that has a particle for the other rank is refused by ParticleStructure::migrate (the
+    reference's Distributor::index() is undefined for a rank that is not listed)."""
+    import subprocess
+    drv = os.path.join(ROOT, "pumi-pic_amd", "drivers")
+    subprocess.check_call(["make", "-C", drv, "-s"])
+    c, e, cl = synth.annulus_tri(n_b=24, n_theta=96, band_width=3)
+    mesh_file = str(tmp_path / "annulus.bin")
+    synth.write_mesh_bin(mesh_file, 2, c, e, cl)
+    world, port = 2, _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), PP_DEVICE="0",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PP_COMM="tcp", PP_COMM_PORT=str(port),
+                   PP_COMM_TIMEOUT="20", PP_DIST_SELF_ONLY="1")
+        procs.append(subprocess.Popen([os.path.join(drv, "pseudoXGCm"), mesh_file, "20000", "6", "10", "2.0", "1"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=120))
+        except subprocess.TimeoutExpired:   # the peer of a rank that stopped waits for it: end it
+            p.kill()
+            outs.append(p.communicate())
+    assert any(p.returncode not in (0, None) and "which the Distributor does not list" in se
+               for p, (so, se) in zip(procs, outs)), [se[-500:] for _, se in outs]
+
+
 @pytest.mark.parametrize("launcher", ["torchrun", "self"])
 def test_bench_multi_rank_line_rehearsal(tmp_path, launcher):
     """bench.py's N > 1 line (the migrating c5 workload: rank start-up under torch.distributed.run, element-block
