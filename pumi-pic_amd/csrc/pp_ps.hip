@@ -251,7 +251,6 @@ __global__ void k_init_slots_tiled4(const int* __restrict__ ntiles_dev, int C, i
 // their element are counted in a register and leave as ONE atomic per thread, and so do the movers
 // that share one of the first three other destinations of the thread's run.  Lanes of a wave are
 // different rows, so same-address contention inside a wave is gone.
-template <bool BATCH>
 __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP, int G,
                               const int* __restrict__ tiles, const int* __restrict__ chunk_start,
                               const int* __restrict__ chunk_width, const int* __restrict__ r2e,
@@ -275,7 +274,9 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
   // whose destination finds no slot issues its own atomic at once.
   int key1 = -1, key2 = -1, key3 = -1;
   unsigned m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-  auto store_ranks = [&](unsigned m, int idx) {
+  auto flush_one = [&](int key, unsigned m) {
+    if (!m) return;
+    int idx = atomicAdd(&ppe[key], __popc(m));
     while (m) {
       const int b = __ffs(m) - 1;
       m &= m - 1;
@@ -283,24 +284,10 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
     }
   };
   auto flush = [&]() {
-    if constexpr (BATCH) {
-      // the (up to four) returning atomics of a run issued back to back and only then consumed: one round trip
-      // to the atomic units per run instead of four.  Pays where a third of the particles move (998 400 tets /
-      // 32 M particles: 412 -> 359 us) and costs where few do (100 800 tets / 10 M: 66 -> 76 us)
-      const int i0 = m0 ? atomicAdd(&ppe[e], __popc(m0)) : 0;
-      const int i1 = m1 ? atomicAdd(&ppe[key1], __popc(m1)) : 0;
-      const int i2 = m2 ? atomicAdd(&ppe[key2], __popc(m2)) : 0;
-      const int i3 = m3 ? atomicAdd(&ppe[key3], __popc(m3)) : 0;
-      store_ranks(m0, i0);
-      store_ranks(m1, i1);
-      store_ranks(m2, i2);
-      store_ranks(m3, i3);
-    } else {
-      if (m0) store_ranks(m0, atomicAdd(&ppe[e], __popc(m0)));
-      if (m1) store_ranks(m1, atomicAdd(&ppe[key1], __popc(m1)));
-      if (m2) store_ranks(m2, atomicAdd(&ppe[key2], __popc(m2)));
-      if (m3) store_ranks(m3, atomicAdd(&ppe[key3], __popc(m3)));
-    }
+    flush_one(e, m0);
+    flush_one(key1, m1);
+    flush_one(key2, m2);
+    flush_one(key3, m3);
     m0 = m1 = m2 = m3 = 0;
     key1 = key2 = key3 = -1;
   };
@@ -1956,21 +1943,11 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   PP_HIP_CHECK(ps->s_ranknew.reserve(sizeof(int) * (size_t)std::max(n_new, 1)));
   int* rank = ps->s_idx.as<int>();
   int* rank_new = ps->s_ranknew.as<int>();
-  if (have_old && old_grid > 0) {
-    // short rows = small elements = many movers per run: the batched form of the run's atomics (k_count_tiled)
-    static const int count_batch_env = getenv("PP_COUNT_BATCH") ? atoi(getenv("PP_COUNT_BATCH")) : -1;  // A/B
-    const long long rows_live = std::max(1, ne - ps->num_empty_elements + (ps->num_rows - ne));
-    const bool batch = count_batch_env >= 0 ? count_batch_env != 0 : ps->num_ptcls / rows_live <= 48;
-#define PP_COUNT_ARGS                                                                                             \
-  ps->d_ntiles.as<int>(), ps->C, ps->tile_p, G, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(),              \
-      ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(), ps->d_mask.as<unsigned char>(), new_element, ne, \
-      ppe, tot, rank
-    if (batch)
-      k_count_tiled<true><<<grp_grid, kBlock, 0, st>>>(PP_COUNT_ARGS);
-    else
-      k_count_tiled<false><<<grp_grid, kBlock, 0, st>>>(PP_COUNT_ARGS);
-#undef PP_COUNT_ARGS
-  }
+  if (have_old && old_grid > 0)
+    k_count_tiled<<<grp_grid, kBlock, 0, st>>>(
+        ps->d_ntiles.as<int>(), ps->C, ps->tile_p, G, ps->d_tiles.as<int>(),
+        ps->d_chunk_start.as<int>(), ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(),
+        ps->d_mask.as<unsigned char>(), new_element, ne, ppe, tot, rank);
   if (n_new > 0) {
     k_count_added<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ne, ppe, tot, rank_new);
   }

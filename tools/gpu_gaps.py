@@ -5,7 +5,7 @@ import csv
 import sys
 
 
-def main(path, marker="k_push_walk_rowsq", last_steps=15):
+def main(path, marker="k_push_walk_rows", last_steps=15):
     rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
     starts = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
     if len(starts) < last_steps + 2:
