@@ -216,3 +216,22 @@ print("not reached")
     assert r.returncode == 3, (r.returncode, r.stdout, r.stderr[-1500:])
     assert "alive" in r.stdout and "not reached" not in r.stdout
     assert "rank 7 made no progress" in r.stderr and "the exchange" in r.stderr
+
+
+def test_mirror_distributor_rank_subset_host_logic(pp, tmp_path):
+    """support/psDistributor.hpp:10-138 in the mirror headers (pumi-pic_amd/include/particle_structs.hpp): the
+    world form and the rank-subset form, host side -- tests/cpp/distributor_host.cpp, compiled with hipcc and
+    run without a GPU (no HIP call is made).  What a subset means for a migration is a GPU test
+    (tests/test_gpu_comm.py::test_cpp_driver_distributor_rank_subset_is_enforced)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    libdir = os.path.join(ROOT, "pumi-pic_amd")
+    exe = str(tmp_path / "distributor_host")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17",
+                           os.path.join(ROOT, "tests", "cpp", "distributor_host.cpp"), "-o", exe,
+                           "-L" + libdir, "-lpumipic_hip", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
+    assert out.returncode == 0 and "all checks passed" in out.stdout, out.stdout
