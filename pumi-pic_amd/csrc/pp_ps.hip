@@ -458,13 +458,14 @@ __global__ void __launch_bounds__(1024)
                    const unsigned long long* keys_sorted = nullptr, int ne = 0,
                    unsigned long long* fix_keys = nullptr, int* fix_vals = nullptr,
                    const int* __restrict__ wide_hist = nullptr, pp::GyroRide ride = pp::GyroRide{},
-                   Totals* host_out = nullptr, int host_stamp = 0) {
+                   Totals* host_out = nullptr, int host_stamp = 0,
+                   const int* __restrict__ wide_tail_start = nullptr) {
   if (blockIdx.x > 0) {  // gyroScatter's second stage riding along (pp::GyroRide; its first stage rode k_make_keys)
     pp::gyro_gather_body((blockIdx.x - 1) * 1024 + threadIdx.x, ride.nverts, ride.gppr, ride.off, ride.src, ride.ring,
                          ride.out, ride.out2);
     return;
   }
-  if (fix_keys) wide_fix_tail(ne, npartial, wide_hist, fix_keys, fix_vals, tot);
+  if (fix_keys) wide_fix_tail(ne, npartial, wide_hist, fix_keys, fix_vals, tot, wide_tail_start);
   __shared__ int ssum[16], scnt[16];
   __shared__ int w3[16][3];
   __shared__ int carry[3];
@@ -1574,6 +1575,7 @@ struct LayoutPlan {
   bool sorted;
   bool wide;  // sorted by k_rs_pass_wide: the layout kernel orders the overflow digit
   bool totals_on_host;  // the layout kernel wrote the totals to the pinned landing zone itself
+  const int* wide_tail_start;  // one-pass sort over many tiles: first output position of the overflow digit
   unsigned long long base;
   unsigned long long* keys;
   int* index;
@@ -1590,6 +1592,7 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
   const int ne = ps->num_elems;
   pp::GyroRide ride{};
   L.wide = false;
+  L.wide_tail_start = nullptr;
   L.totals_on_host = false;
   L.C = C_new;
   L.nchunks = ne / C_new + (ne % C_new != 0);
@@ -1607,10 +1610,11 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
     PP_HIP_CHECK(ps->s_vals.reserve(sizeof(int) * (size_t)ne));
     PP_HIP_CHECK(ps->s_vals2.reserve(sizeof(int) * (size_t)ne));
     const int nblk = (ne + RS_TILE - 1) / RS_TILE;
-    PP_HIP_CHECK(ps->s_hist.reserve(sizeof(int) * (std::max(256 * (size_t)nblk * 3, (size_t)nblk * kWideDigits) +
-                                                   3 * (size_t)nblk)));
+    const int nseg = (nblk + kWideSeg - 1) / kWideSeg;
+    const size_t hist_words = std::max(256 * (size_t)nblk * 3, ((size_t)nblk + nseg + 1) * kWideDigits);
+    PP_HIP_CHECK(ps->s_hist.reserve(sizeof(int) * (hist_words + 3 * (size_t)nblk)));
     // the layout kernel below adds up the per-block totals (the inversely-padded layout has no such kernel)
-    int* const partial_at = ps->s_hist.as<int>() + std::max(256 * (size_t)nblk * 3, (size_t)nblk * kWideDigits);
+    int* const partial_at = ps->s_hist.as<int>() + hist_words;
     et.partial = (et.totals && !(ps->pad_strat == PP_PAD_INVERSELY && ps->shuffle_padding > 0)) ? partial_at : nullptr;
     static const bool no_fused_sort = getenv("PP_NO_FUSED_SORT") != nullptr;  // A/B knobs
     static const bool no_wide_sort = getenv("PP_NO_WIDE_SORT") != nullptr;
@@ -1624,9 +1628,14 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
       L.key_bits = (bits + 7) / 8 * 8;
     }
     // one sort window (the keys are the counts): ONE counting pass, see k_rs_pass_wide
-    const bool wide_sort = fused_sort && !no_wide_sort && allow_wide && n_sigma <= 1 && ps->wide_skip == 0 &&
+    // (up to 64 tiles every block sweeps the digit table itself; beyond that k_wide_seg / k_wide_base prefix it)
+    static const bool no_wide_big = getenv("PP_NO_WIDE_SORT_BIG") != nullptr;
+    const bool wide_sort = (fused_sort || (!no_fused_sort && !no_wide_big)) && !no_wide_sort && allow_wide &&
+                           n_sigma <= 1 && ps->wide_skip == 0 &&
                            (ps->pad_strat != PP_PAD_INVERSELY || !(ps->shuffle_padding > 0));  // (needs k_layout_fused)
+    const bool wide_big = wide_sort && !fused_sort;
     L.wide = wide_sort;
+    L.wide_tail_start = nullptr;
     if (wide_sort) L.key_bits = 64;  // (its own check: Totals::sort_bad)
     int* const H0 = ps->s_hist.as<int>();
     // gyroScatter of a pp_ps_rebuild_scatter call rides in this launch and in the layout kernel's (pp::GyroRide)
@@ -1637,7 +1646,8 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
                                                  ps->s_keys.as<unsigned long long>(),
                                                  ps->s_vals.as<int>(), tot,
                                                  getenv("PP_NO_RS_SKIP") != nullptr, et,
-                                                 fused_sort ? FusedHist{H0, nblk, wide_sort ? 1 : 0} : FusedHist{nullptr, 0, 0},
+                                                 (fused_sort || wide_big) ? FusedHist{H0, nblk, wide_sort ? 1 : 0}
+                                                                          : FusedHist{nullptr, 0, 0},
                                                  nblk, ride);
     unsigned long long *ka = ps->s_keys.as<unsigned long long>(),
                        *kb = ps->s_keys2.as<unsigned long long>();
@@ -1645,7 +1655,15 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
     int* hist = ps->s_hist.as<int>();
     int* hist_sc = hist + 256 * nblk;
     if (wide_sort) {
-      k_rs_pass_wide<<<nblk, kWideThreads, 0, st>>>(ne, ka, va, nblk, H0, kb, vb);
+      int *seg_base = nullptr, *digit_base = nullptr;
+      if (wide_big) {
+        seg_base = H0 + (size_t)nblk * kWideDigits;
+        k_wide_seg<<<dim3(kWideDigits / 256, nseg), 256, 0, st>>>(nblk, H0, seg_base);
+        digit_base = seg_base + (size_t)nseg * kWideDigits;
+        k_wide_base<<<1, 1024, 0, st>>>(nseg, seg_base, digit_base);
+        L.wide_tail_start = digit_base + kWideDigits - 1;  // first output position of the overflow digit
+      }
+      k_rs_pass_wide<<<nblk, kWideThreads, 0, st>>>(ne, ka, va, nblk, H0, kb, vb, seg_base, digit_base);
       std::swap(ka, kb);
       std::swap(va, vb);
     }
@@ -1655,7 +1673,7 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
       std::swap(ka, kb);
       std::swap(va, vb);
     }
-    for (int shift = 0; !fused_sort && shift < bits; shift += 8) {
+    for (int shift = 0; !fused_sort && !wide_sort && shift < bits; shift += 8) {
       k_rs_hist<<<nblk, 256, 0, st>>>(ne, ka, shift, nblk, hist, tot);
       if (scan_excl(ps->s_scan2, 256 * nblk, hist, hist_sc, nullptr, st, tot, shift)) return PP_EHIP;
       k_rs_scatter<<<nblk, 256, 0, st>>>(ne, ka, va, shift, nblk, hist_sc, kb, vb, tot);
@@ -1693,7 +1711,7 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
                                        L.sorted ? et.partial : nullptr, (ne + RS_TILE - 1) / RS_TILE,
                                        widths_in_layout ? L.keys : nullptr, ne, L.wide ? L.keys : nullptr,
                                        L.wide ? L.index : nullptr, L.wide ? ps->s_hist.as<int>() : nullptr, ride,
-                                       host_out, host_stamp);
+                                       host_out, host_stamp, L.wide ? L.wide_tail_start : nullptr);
     if (ride.on) ps->ride_done = true;
     L.totals_on_host = host_out != nullptr;
   } else {

@@ -315,6 +315,67 @@ __global__ void k_rs_pass(int n, const unsigned long long* __restrict__ keys, co
     __syncthreads();
   }
 }
+// Digit table of the one-pass sort for MANY tiles (> kFusedSortBlocks: every block sweeping the whole table
+// stops paying): the tiles are cut into segments of kWideSeg; k_wide_seg turns hist[b][d] into the count of
+// digit d in the earlier tiles of b's segment and leaves the segment totals, k_wide_base turns those into the
+// count of digit d in the earlier segments and writes the first output position of every digit (digit-major
+// order: all of digit 0, then digit 1 ...).  A tile's base for digit d is then base[d] + seg_tot[segment][d] +
+// hist[b][d]: three loads per digit in k_rs_pass_wide.
+constexpr int kWideSeg = 16;
+__global__ void k_wide_seg(int nblk, int* __restrict__ hist, int* __restrict__ seg_tot) {
+  const int d = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
+  const int b0 = s * kWideSeg;
+  int h[kWideSeg];
+#pragma unroll
+  for (int j = 0; j < kWideSeg; ++j) h[j] = b0 + j < nblk ? hist[(size_t)(b0 + j) * kWideDigits + d] : 0;
+  int run = 0;
+#pragma unroll
+  for (int j = 0; j < kWideSeg; ++j) {
+    if (b0 + j < nblk) hist[(size_t)(b0 + j) * kWideDigits + d] = run;
+    run += h[j];
+  }
+  seg_tot[(size_t)s * kWideDigits + d] = run;
+}
+__global__ void __launch_bounds__(1024) k_wide_base(int nseg, int* __restrict__ seg_tot, int* __restrict__ base) {
+  constexpr int K = kWideDigits / 1024;
+  __shared__ int s_part[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  int total[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {  // thread t owns digits k*1024 + t: prefix over the segments, in place
+    int run = 0;
+    for (int s0 = 0; s0 < nseg; s0 += 16) {  // (16 loads in flight)
+      int v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = s0 + j < nseg ? seg_tot[(size_t)(s0 + j) * kWideDigits + k * 1024 + t] : 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (s0 + j < nseg) seg_tot[(size_t)(s0 + j) * kWideDigits + k * 1024 + t] = run;
+        run += v[j];
+      }
+    }
+    total[k] = run;
+  }
+  int carry = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {  // exclusive scan of the digit totals in digit order
+    int incl = total[k];
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(incl, o);
+      if (lane >= o) incl += y;
+    }
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    int off = 0, all = 0;
+    for (int w = 0; w < 16; ++w) {
+      off += w < wave ? s_part[w] : 0;
+      all += s_part[w];
+    }
+    base[k * 1024 + t] = carry + off + incl - total[k];
+    carry += all;
+    __syncthreads();
+  }
+}
 // The whole sort as ONE counting pass, for structures with one sort window (the keys are the per-element
 // counts): digit = min(key, 2047).  Counts of ~100 per element resolve exactly; the few rows above 2046 (the
 // literal pseudoXGCm population piles its remainder into one element) land in the last digit in element order
@@ -327,7 +388,8 @@ constexpr int kWideThreads = 1024;
 __global__ void __launch_bounds__(kWideThreads)
     k_rs_pass_wide(int n, const unsigned long long* __restrict__ keys, const int* __restrict__ vals, int nblk,
                    const int* __restrict__ hist, unsigned long long* __restrict__ keys_out,
-                   int* __restrict__ vals_out) {
+                   int* __restrict__ vals_out, const int* __restrict__ seg_base = nullptr,
+                   const int* __restrict__ digit_base = nullptr) {
   constexpr int NW = kWideThreads / 64, R = RS_TILE / kWideThreads, K = kWideDigits / kWideThreads;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   __shared__ int base_d[kWideDigits];                   // next output position of this tile's keys with digit d
@@ -344,7 +406,14 @@ __global__ void __launch_bounds__(kWideThreads)
     val[r] = i < n ? vals[i] : 0;
   }
   for (int q = t; q < NW * kWideDigits / 16; q += kWideThreads) ((uint4*)&wave_cnt[0][0])[q] = make_uint4(0, 0, 0, 0);
-  {
+  if (seg_base) {  // many tiles: the table was prefixed by k_wide_seg / k_wide_base
+    const int* sb = seg_base + (size_t)(blockIdx.x / kWideSeg) * kWideDigits;
+    const int* hb = hist + (size_t)blockIdx.x * kWideDigits;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      base_d[k * kWideThreads + t] = digit_base[k * kWideThreads + t] + sb[k * kWideThreads + t] + hb[k * kWideThreads + t];
+    __syncthreads();
+  } else {
     int total[K], mine[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) total[k] = mine[k] = 0;
@@ -554,18 +623,22 @@ __global__ void k_tile_count(int nchunks, int TP, const int* __restrict__ widths
 // digit sit at the end of the sorted arrays in element order; order them by key, ties by position (= the
 // stable order the 8-bit passes produce).
 __device__ void wide_fix_tail(int ne, int nblk, const int* __restrict__ hist, unsigned long long* keys,
-                              int* vals, Totals* tot) {
+                              int* vals, Totals* tot, const int* __restrict__ tail_start = nullptr) {
   __shared__ unsigned long long fk[1024];
   __shared__ int fv[1024];
   __shared__ int s_n[16];
   const int t = threadIdx.x;
   int n = 0;
-  for (int b = t; b < nblk; b += 1024) n += hist[(size_t)b * kWideDigits + kWideDigits - 1];
-  for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
-  if ((t & 63) == 0) s_n[t >> 6] = n;
-  __syncthreads();
-  n = 0;
-  for (int w = 0; w < 16; ++w) n += s_n[w];
+  if (tail_start) {  // (many tiles: the first output position of the overflow digit is in the prefixed table)
+    n = ne - *tail_start;
+  } else {
+    for (int b = t; b < nblk; b += 1024) n += hist[(size_t)b * kWideDigits + kWideDigits - 1];
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
+    if ((t & 63) == 0) s_n[t >> 6] = n;
+    __syncthreads();
+    n = 0;
+    for (int w = 0; w < 16; ++w) n += s_n[w];
+  }
   if (n <= 1) return;  // (block-uniform)
   if (n > 1024) {
     if (t == 0) tot->sort_bad = 1;

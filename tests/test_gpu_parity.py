@@ -535,13 +535,13 @@ def test_rebuild_matches_oracle(ppo, synth, capi, kind, C, V, sigma, pad, shuffl
         assert np.array_equal(np.repeat(np.arange(ne), np.diff(off)), se[pids])
 
 
-@pytest.mark.parametrize("heavy", [6, 1100])
-def test_rebuild_layout_sort_with_heavy_rows(ppo, capi, heavy):
+@pytest.mark.parametrize("heavy,ne", [(6, 3000), (1100, 3000), (6, 140000)])
+def test_rebuild_layout_sort_with_heavy_rows(ppo, capi, heavy, ne):
     """The one-pass layout sort (k_rs_pass_wide) keeps rows of 2047 and more particles in one digit and orders
     them in the layout kernel (up to 1024 rows; more than that: the 8-bit passes run instead).  Heavy rows with
     ties, light rows around them, rows that become heavy / light from one rebuild to the next: layout arrays
-    and population equal the oracle's (stable ascending order, SCS_sort.h)."""
-    ne = 3000
+    and population equal the oracle's (stable ascending order, SCS_sort.h).  140 000 elements = 69 sort tiles:
+    the digit table is prefixed by its own two kernels instead of being swept by every block."""
     rng = np.random.default_rng(heavy)
     n = heavy * 2060 + 80000 + 20 * ne
 
