@@ -535,7 +535,7 @@ def test_rebuild_matches_oracle(ppo, synth, capi, kind, C, V, sigma, pad, shuffl
         assert np.array_equal(np.repeat(np.arange(ne), np.diff(off)), se[pids])
 
 
-@pytest.mark.parametrize("heavy,ne", [(6, 3000), (1100, 3000), (6, 140000)])
+@pytest.mark.parametrize("heavy,ne", [(6, 3000), (1100, 3000), (6, 140000), (1100, 140000)])
 def test_rebuild_layout_sort_with_heavy_rows(ppo, capi, heavy, ne):
     """The one-pass layout sort (k_rs_pass_wide) keeps rows of 2047 and more particles in one digit and orders
     them in the layout kernel (up to 1024 rows; more than that: the 8-bit passes run instead).  Heavy rows with
