@@ -15,6 +15,11 @@ A "step" is one pass of the hot path over the resident particle population:
       of the ring map: 4 vertices per ring point); 2dc3 is the 2-D literal of it.  The
       three calls go through pp_ps_rebuild_scatter (same work, one entry point;
       PP_BENCH_SEPARATE_SCATTER=1 issues them separately).
+  c2mt: configs[1] in the reference's INTERSECTION mode (search_mesh with requireIntersection, adjacency.tpp:284-361:
+      Moeller-Trumbore per face): toroidal push, then every particle's ray is followed element by element to
+      the domain boundary (~tens of tets per particle; exit face + intersection point written).  The same rays
+      every step (positions are not committed).  Walk-bound, not stream-bound: the line also reports elements
+      visited per particle and the time per visited element.
   2d : the literal 2-D pseudoXGCm step (elliptical push + search_mesh_2d) on 100 352 triangles.
   c5 (configs[4], default at N > 1): c3 with ownership: every rank owns a block of elements; after the search
       the particles whose new element another rank owns are packed into records, exchanged with ONE
@@ -59,6 +64,8 @@ BYTES = {
     "2d": 37.0,
     # pseudo-push: write double[17]+int[4]+long = 160, read mask 1 (parentElmData 8 B per element)
     "c4": 161.0,
+    # read x(24) b,phi(8) mask(1) ; write x_tgt(24) phi(4) elem(4) inter_face(4) inter_point(24)
+    "c2mt": 93.0,
 }
 
 
@@ -244,6 +251,9 @@ class Stepper:
                                   "what": "5-7 records of 80 B to every peer through the migration's count "
                                           "exchange + grouped send/recv, then the gyroSync all-reduce, contents "
                                           "checked on every rank (pp_comm_selftest)"}
+        if name == "c2mt":
+            self.xface = capi.DevArray(cap + cap // 10, np.int32)
+            self.xpts = capi.DevArray(3 * (cap + cap // 10), np.float64)
         if name in ("c3", "2dc3", "c5"):
             self.fwd, self.bkwd = capi.create_gyro_ring_mappings(self.mesh)
             self.w_f = capi.DevArray(self.mesh.nverts, np.float64)
@@ -262,7 +272,11 @@ class Stepper:
         beat("step %d: push + search" % self.steps_done)
         if self.steps_done == 1 and os.environ.get("PP_BENCH_STALL_RANK") == str(self.w.get("rank", 0)):
             time.sleep(3600)  # test hook (tests/test_gpu_comm.py): this rank hangs; the watchdogs end the job
-        if self.name == "c2":
+        if self.name == "c2mt":
+            capi.toroidal_push(self.ps, self.mesh, self.h, self.k, self.d, self.deg)
+            capi.check(capi.lib().pp_search_mesh(self.mesh.p, self.ps.p, 0, 1, 2, self.ids.ptr, 0, 1,
+                                                 self.xface.ptr, self.xpts.ptr, 2000, None, None))
+        elif self.name == "c2":
             capi.push_search(self.mesh, self.ps, self.h, self.k, self.d, self.deg, self.ids,
                              seeded=not self.first, looplimit=200, want_found=False)
         elif self.name in ("c3", "c5"):
@@ -279,7 +293,7 @@ class Stepper:
                              seeded=True, looplimit=200, want_found=False)
         if timed:
             e1.record()
-        if self.first and self.w.get("origin_trust", True) and self.w["dim"] == 3 and self.name != "c4":
+        if self.first and self.w.get("origin_trust", True) and self.w["dim"] == 3 and self.name not in ("c4", "c2mt"):
             # From the second step on every origin is the destination the previous walk accepted in the
             # element the walk starts from (c3 / c5: the structure was rebuilt from the ids; c2: the ids are
             # the seeds): pp_ps_set_origin_trust skips check_initial_parents (include/pumipic_hip.h).
@@ -294,7 +308,9 @@ class Stepper:
 
     def _rest_of_step(self):
         capi = self.capi
-        if self.name == "c2":
+        if self.name == "c2mt":
+            pass  # the rays end at the wall: nothing is committed, every step follows the same rays
+        elif self.name == "c2":
             self.ps.swap_members(0, 1)  # x <-> x_tgt (O(1)); no rebuild in config 2
         elif self.name in ("c3", "2dc3"):
             # the drivers' rebuild(): updatePtclPositions + migrate/rebuild (pseudoXGCm.cpp:116-140)
@@ -416,6 +432,10 @@ def cpu_baseline(pp, w, name, deg, sample, steps=20):
         ids = None
         t0 = time.perf_counter()
         for _ in range(steps):
+            if name == "c2mt":
+                ppo.toroidal_push(ps, mesh, s.XGC_H, s.XGC_K, s.XGC_D, deg, trig=0)
+                ppo.search_mesh(mesh, ps, require_intersection=True, looplimit=2000)
+                continue
             if w["dim"] == 3:
                 ppo.toroidal_push(ps, mesh, s.XGC_H, s.XGC_K, s.XGC_D, deg, trig=0)
                 ids = ppo.search_mesh(mesh, ps, elem_ids=None if full else ids, looplimit=200)["elem_ids"]
@@ -435,7 +455,8 @@ def cpu_baseline(pp, w, name, deg, sample, steps=20):
         return time.perf_counter() - t0
 
     dt = run(make_ps())
-    what = ("push + search + updatePtclPositions + rebuild + gyroScatter x2" if full else "push + search")
+    what = ("push + search + updatePtclPositions + rebuild + gyroScatter x2" if full else
+            "push + search_mesh in intersection mode (rays to the wall)" if name == "c2mt" else "push + search")
     out = dict(value=sample * steps / dt, unit="particles/s", cores=1, kind="port",
                sample="%d particles x %d steps (%s) of the same mesh/push, oracle (C=1 Serial semantics, "
                       "libm trig), 1 core" % (sample, steps, what))
@@ -456,6 +477,7 @@ def cpu_baseline(pp, w, name, deg, sample, steps=20):
 METRIC = {
     "c2": "particles pushed+searched / sec / GPU; achieved HBM GB/s vs peak",
     "2d": "particles pushed+searched / sec / GPU; achieved HBM GB/s vs peak",
+    "c2mt": "particles pushed+searched / sec / GPU; achieved HBM GB/s vs peak",
     "c3": "particles pushed+searched+scattered / sec / GPU; achieved HBM GB/s vs peak",
     "2dc3": "particles pushed+searched+scattered / sec / GPU; achieved HBM GB/s vs peak",
     # BASELINE.json's metric string; the migration is part of the step (config.workload says so) and `value`
@@ -555,7 +577,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=None, choices=["c2", "c3", "c4", "c5", "2d", "2dc3"],
+    ap.add_argument("--workload", default=None, choices=["c2", "c2mt", "c3", "c4", "c5", "2d", "2dc3"],
                     help="default: c3 on one GPU (the configuration the metric names), c5 on several")
     ap.add_argument("--sigma", type=int, default=2**31 - 1,
                     help="SCS sorting window (elements); the pseudoXGCm value is INT_MAX = full sort")
@@ -620,7 +642,7 @@ def main():
                        32_000_000 if (a.workload == "c5" and world > 1 and a.mesh == "1m") else 10_000_000)
     full_step = a.workload in ("c3", "2dc3", "c5")
     if a.cpu_sample is None:
-        a.cpu_sample = 2_000_000 if full_step else 4_000_000
+        a.cpu_sample = 2_000_000 if full_step else 100_000 if a.workload == "c2mt" else 4_000_000
     import torch
     # Rehearsal (tests): N ranks on ONE GPU, gloo for the timing barrier, --comm tcp for the data path.  RCCL
     # cannot put two ranks on one device, so this is how the multi-rank line's plumbing runs on a 1-GPU box;
@@ -831,9 +853,10 @@ def main():
         # Roofline.  c2 / 2d: ONE pp_push_search call is the step.  c3 / 2dc3 / c5: the WHOLE step
         # (push+search 69 B + rebuild 125 B per particle) against the mean HIP-event time
         # of the sampled steps; the two phases are broken out under "phases".
-        bpp_ps = BYTES["2d" if w["dim"] == 2 else "c2"]
+        bpp_ps = BYTES["2d" if w["dim"] == 2 else "c2mt" if a.workload == "c2mt" else "c2"]
         sms = sms_main
-        ps_kernel = ("k_push_walk_rowsq<3> + k_walk_pending<3> (one pp_push_search call)"
+        ps_kernel = ("k_search_mt3 (pp_search_mesh, intersection mode; + k_toroidal_push)" if a.workload == "c2mt" else
+                     "k_push_walk_rowsq<3> + k_walk_pending<3> (one pp_push_search call)"
                      if w["dim"] == 3 else "k_push_walk_rows<2>")
         if full_step:
             bpp = bpp_ps + 125.0
@@ -873,6 +896,8 @@ def main():
         out["config"] = {"workload": "%s, %d particles/GPU, SCS C=64 sigma=%s V=1024, %s" % (
             w["label"], a.particles, "inf" if a.sigma >= 2**31 - 1 else str(a.sigma),
             {"c2": "push+search only (fused toroidal push + BCC walk), deg/push=%g" % a.deg,
+             "c2mt": "toroidal push + search_mesh in intersection mode (Moeller-Trumbore, every ray followed to the "
+                     "domain boundary), deg/push=%g" % a.deg,
              "2d": "elliptical push + search_mesh_2d (fused), deg/push=%g" % a.deg,
              "c3": "push+search+rebuild+gyroScatter x2 (tet ring map) every step, deg/push=%g" % a.deg,
              "c5": "push+search+migrate(all-to-all-v, %s)+rebuild+gyroScatter x2+gyroSync, deg/push=%g" % (
@@ -902,7 +927,15 @@ def main():
                                 "and the timing barrier runs over gloo (PP_BENCH_REHEARSAL=1)" % world)
         if a.workload == "c5":
             out["rank0_sent_per_step"] = st.moved / max(1, st.steps_done)
-        if w["dim"] == 3:
+        if a.workload == "c2mt":
+            nsteps = capi.search_walk_steps()
+            out["walk"] = {"elements_visited_per_particle": nsteps / max(nlive, 1),
+                           "ns_per_visited_element": (kms * 1e6 / nsteps) if (kms and nsteps) else None,
+                           "visited_elements_per_s": nsteps / (kms * 1e-3) if kms else None,
+                           "note": "intersection mode follows the RAY to the boundary (adjacency.tpp:488, "
+                                   "'trajectories are considered as rays'): cost scales with elements visited; "
+                                   "one visit = one 128-B record + up to 4 ray/triangle tests"}
+        elif w["dim"] == 3:
             nf, nie, unm = capi.push_search_counters()
             out["origin_trust"] = {"on": bool(w.get("origin_trust", True)), "unmoved_without_test_last_step": unm,
                                    "not_in_elem_last_step": nie,

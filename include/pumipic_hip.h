@@ -308,6 +308,10 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
  * particles ended that way (0 in the pseudoXGCm flows: the slowest particle moves 1e-5 per push), so
  * the exactness of a trusted run is checkable after the fact.  Off by default. */
 int pp_ps_set_origin_trust(pp_ps* ps, int on);
+/* Elements visited, summed over all particles, by the last pp_search_mesh call that ran in intersection
+ * mode on a tet mesh (the ray of adjacency.tpp:284-361 is followed to the domain boundary: the walk
+ * length, not the particle count, is what that search costs).  One host sync; 0 when no such call ran. */
+int pp_search_walk_steps(unsigned long long* steps);
 /* counters of the last pp_push_search (one host sync): particles cut off by the loop limit, particles
  * that failed check_initial_parents, trusted particles that finished as unmoved */
 int pp_push_search_counters(int* not_found, int* not_in_elem, int* unmoved_trusted);

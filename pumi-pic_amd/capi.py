@@ -121,6 +121,7 @@ SYMBOLS = {
     "pp_search_mesh_3d": (_I, [_V, _V, _I, _I, _I, _V, _I, _V, _V, _I, c_int_p]),
     "pp_push_search": (_I, [_V, _V, _I, _I, _I, _I, _D, _D, _D, _D, _V, _I, _I, c_int_p]),
     "pp_ps_set_origin_trust": (_I, [_V, _I]),
+    "pp_search_walk_steps": (_I, [_V]),
     "pp_push_search_counters": (_I, [c_int_p, c_int_p, c_int_p]),
     "pp_create_gyro_ring_mappings": (_I, [_V, _D, _I, _I, _D, _V, _V]),
     "pp_gyro_scatter": (_I, [_V, _V, _V, _D, _I, _I, _V]),
@@ -1167,6 +1168,13 @@ def push_search_counters():
     a, b, c = C.c_int(), C.c_int(), C.c_int()
     check(lib().pp_push_search_counters(C.byref(a), C.byref(b), C.byref(c)))
     return a.value, b.value, c.value
+
+
+def search_walk_steps():
+    """elements visited by the last intersection-mode pp_search_mesh on tets (all particles)"""
+    n = C.c_ulonglong()
+    check(lib().pp_search_walk_steps(C.byref(n)))
+    return int(n.value)
 
 
 def ray_intersects_triangle(tris, orig, dest, tol, flip=0, segment=False):

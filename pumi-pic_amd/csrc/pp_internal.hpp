@@ -89,6 +89,8 @@ struct DevBuf {
   // not all start at the same position of the HBM channel interleave.
   hipError_t reserve(size_t n, size_t skew = 0) {
     if (n <= bytes) return hipSuccess;
+    static const bool dbg = getenv("PP_ALLOC_DEBUG") != nullptr;  // (tools/r04_coldsteps.py: who re-allocates when)
+    if (dbg) fprintf(stderr, "pp alloc: %zu -> %zu bytes\n", bytes, n + n / 8 + 256);
     release();
     size_t want = n + n / 8 + 256;
     hipError_t e = hipMalloc(&base, want + skew);
@@ -131,7 +133,7 @@ struct alignas(16) pp_tet_rec {
   int nbr[4];        // 16
   double vol;        // 8  measure_elements_real value
   int class_id;      // 4
-  int pad;           // 4
+  unsigned mt_code;  // 4  Moeller-Trumbore face codes: per face the stored side's vertices as tet-local indices (pp_mesh.hip)
 };
 static_assert(sizeof(pp_tri_rec) == 64, "tri record must be 64 B");
 static_assert(sizeof(pp_tet_rec) == 128, "tet record must be 128 B");
@@ -149,6 +151,7 @@ struct pp_mesh {
   // edges of a tet mesh (entity dimension 1 of a 3-D mesh; in 2-D the edges are the sides), derived on first
   // use (pp_mesh_edges): Omega_h's template order (0,1),(1,2),(2,0),(0,3),(1,3),(2,3), numbered in
   // first-seen order over (element, local edge), edge2verts in the orientation first seen
+  bool mt_packed_ok = true;  // no element has the same neighbour behind two faces (k_search_mt3)
   bool edges_ready = false;
   int nedges = 0;
   std::vector<int> elem2edges, edge2verts, edge2elems_off, edge2elems;

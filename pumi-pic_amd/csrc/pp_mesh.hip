@@ -192,7 +192,31 @@ int pack_and_upload(pp_mesh& m) {
       }
       r.vol = m.elem_measure[e];
       r.class_id = m.class_id[e];
-      r.pad = 0;
+      // Moeller-Trumbore face codes (pp_search.hip: k_search_mt3).  ray_intersects_triangle works on the STORED
+      // side: faceVerts = coords of bridgeVerts[face_id] in the side's own vertex order, flip = isFaceFlipped
+      // (adjacency.tpp:322-331,152-157).  Byte fi of `mt_code`: the tet-local indices (2 bits each) of
+      // faceVerts[0], faceVerts[2 - flip], faceVerts[flip + 1] -- the vertex the two edges start from and
+      // the far ends of edge1 and edge2.
+      unsigned code = 0;
+      const int* tv = &m.elem2verts[(size_t)e * 4];
+      for (int fi = 0; fi < 4; ++fi) {
+        const int sid = m.elem2sides[(size_t)e * 4 + fi];
+        const int* fv = &m.side2verts[(size_t)sid * 3];
+        const int flip = ppg::is_face_flipped(fi, fv, tv) ? 1 : 0;
+        auto local = [&](int v) {
+          for (int i = 0; i < 4; ++i)
+            if (tv[i] == v) return i;
+          return 0;
+        };
+        const unsigned c = (unsigned)local(fv[0]) | ((unsigned)local(fv[2 - flip]) << 2) | ((unsigned)local(fv[flip + 1]) << 4);
+        code |= c << (8 * fi);
+      }
+      r.mt_code = code;
+      // the packed walk names the face a particle came through by the neighbour behind it: needs the
+      // neighbours of an element to be distinct (true for any simplicial complex; checked, not assumed)
+      for (int i = 0; i < 4; ++i)
+        for (int j = i + 1; j < 4; ++j)
+          if (r.nbr[i] >= 0 && r.nbr[i] == r.nbr[j]) m.mt_packed_ok = false;
     }
     PP_HIP_CHECK(m.d_records.reserve(std::max<size_t>(rec.size() * sizeof(pp_tet_rec), 128)));
     if (ne) PP_HIP_CHECK(hipMemcpy(m.d_records.p, rec.data(), rec.size() * sizeof(pp_tet_rec),

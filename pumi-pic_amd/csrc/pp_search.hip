@@ -1566,6 +1566,227 @@ __global__ void __launch_bounds__(256, 4)
                     looplimit ? looplimit : kHardLoopCap, cnt, st_all + wave * 64 * NP, lane);
 }
 
+// ------------------------------------------------------------------ Moeller-Trumbore walk on packed records
+// search_mesh with requireIntersection (adjacency.tpp:284-361 + the native handler :617-639) follows every
+// moving particle's RAY element by element until it meets an exposed face: tens of tets per particle, and per
+// tet and face the reference gathers elem2sides -> side2verts -> 3 x coords.  Here a walk step is ONE 128-B
+// record (cooperative LDS-DMA fetch, see coop_issue): the four vertices, the neighbours, the volume and
+// `mt_code` -- per face the stored side's three vertices as tet-local indices with isFaceFlipped already
+// applied (pp_mesh.hip) -- so ray_intersects_triangle sees exactly the operands of the reference, in its
+// order; the lane reads the vertices a face names straight out of the staged record (dynamic LDS addresses:
+// no register-array indexing).  Ray direction and length are per-particle constants (the reference recomputes
+// them per face: same operations, same values).
+//  * Persistent waves: a wave draws chunks of 64 * per_lane consecutive slots from ONE device counter and hands
+//    them to its lanes AS THEY FALL FREE (wave-uniform cursor): walk lengths differ by the distance to the
+//    wall -- a wave that waited for its longest walk would idle most lanes, and waves with fixed shares would
+//    finish at different times.
+//  * A walking particle tests the THREE faces it did not come in through (the reference skips face_id ==
+//    prevExit); only a particle's first element has four candidates, and check_initial_parents on top.  The
+//    first steps are therefore batched: fresh lanes wait until `start_batch` of them (or nobody walking) are
+//    there, then the wave runs one START round for them; all other rounds are 3-face WALK rounds.  Per round
+//    one cooperative fetch and one pass over the faces with (nearly) all participating lanes busy.
+__device__ __forceinline__ double lds_rec_double(const double2* mine, int sw, int d) {
+  return ((const double*)(mine + ((d >> 1) ^ sw)))[d & 1];
+}
+__device__ __forceinline__ V3 lds_rec_vertex(const double2* mine, int sw, int v) {
+  const int d = 3 * v;
+  return V3{lds_rec_double(mine, sw, d), lds_rec_double(mine, sw, d + 1), lds_rec_double(mine, sw, d + 2)};
+}
+struct MtFace {  // running state of search_findExitFace_intersect_3d over the faces of one element
+  int lastExit, bestFace;
+  double quality;
+};
+// one face of the element staged at `mine`: ray_intersects_triangle (tpp:152-178) on the stored side named by
+// code byte `c`, then the reference's bookkeeping (tpp:333-348): last success wins; without a success so far
+// the face with dproj > -tol that is closest in (u, v) -- candidates overwrite the intersection point
+__device__ __forceinline__ void mt_face(const double2* mine, int sw, unsigned c, int fi, V3 orig, V3 dir, double tol,
+                                        MtFace& F, V3& ip) {
+  const V3 f0 = lds_rec_vertex(mine, sw, c & 3), fa = lds_rec_vertex(mine, sw, (c >> 2) & 3),
+           fb = lds_rec_vertex(mine, sw, (c >> 4) & 3);
+  const V3 edge1 = sub(fa, f0), edge2 = sub(fb, f0);
+  const V3 faceNorm = cross(edge2, edge1);
+  const V3 pvec = cross(dir, edge2);
+  const double dproj = dot(dir, faceNorm);
+  const double invdet = 1.0 / dproj;
+  const V3 tvec = sub(orig, f0);
+  const double u = invdet * dot(tvec, pvec);
+  const V3 qvec = cross(tvec, edge1);
+  const double v = invdet * dot(dir, qvec);
+  const double t = invdet * dot(edge2, qvec);
+  const V3 xp = add(orig, mul(dir, t));
+  const double m1 = PPG_KMIN(fabs(u), fabs(1 - u));
+  const double m2 = PPG_KMIN(fabs(v), fabs(1 - v));
+  const double m3 = PPG_KMIN(fabs(u + v), fabs(1 - u - v));
+  const double mm = PPG_KMAX(m1, m2);
+  const double closeness = PPG_KMAX(mm, m3);
+  const bool success = (dproj >= tol) && (t >= -tol) && (u >= -tol) && (v >= -tol) && (u + v <= 1.0 + 2 * tol);
+  if (success) {
+    F.lastExit = fi;
+    ip = xp;
+  }
+  if (dproj > -tol && (F.quality < 0 || closeness < F.quality) && F.lastExit == -1) {
+    F.quality = closeness;
+    F.bestFace = fi;
+    ip = xp;
+  }
+}
+__global__ void __launch_bounds__(256, 2)
+    k_search_mt3(int capacity, int per_lane, int start_batch, const unsigned char* __restrict__ mask,
+                 const int* __restrict__ slot_elem, const void* __restrict__ recs,
+                 const int* __restrict__ elem2sides, const double* __restrict__ x,
+                 const double* __restrict__ xt, long long stride, int* __restrict__ elem_ids, int seeded,
+                 double tol, int* __restrict__ inter_faces, double* __restrict__ inter_points, int looplimit,
+                 Counters* cnt, unsigned long long* __restrict__ steps_out) {
+  // steps_out[0]: elements visited; steps_out[1]: the chunk counter (both zeroed by the host)
+  __shared__ double2 st_all[4 * 64 * 8];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sw = lane & 7;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  double2* st = st_all + wave * 64 * 8;
+  const double2* mine = st + lane * 8;
+  const long long chunk = 64ll * per_lane;
+  long long next = 0, wend = 0;  // wave-uniform cursor into the current chunk
+  bool more = true;              // the counter has not run past the capacity yet
+  const int cap = looplimit ? looplimit : kHardLoopCap;
+  bool on = false, chk = false;
+  int pid = 0, elem = -1, prev = -1, loops = 0;
+  unsigned nsteps = 0;  // elements this lane's particles visited (pp_search_walk_steps)
+  V3 orig{0, 0, 0}, dir{0, 0, 0}, ip{0, 0, 0};
+  while (true) {
+    // ---- refill: free lanes take the next slots until every lane walks or the wave's slots are used up
+    unsigned long long free_mask = __ballot(!on);
+    while (free_mask != 0ull && (next < wend || more)) {
+      if (next >= wend) {  // draw the next chunk
+        unsigned long long c0 = 0;
+        if (lane == 0) c0 = atomicAdd(steps_out + 1, (unsigned long long)chunk);
+        next = (long long)__shfl(c0, 0);
+        wend = min((long long)capacity, next + chunk);
+        if (next >= capacity) {
+          more = false;
+          next = wend = 0;
+          break;
+        }
+      }
+      const int nfree = __popcll(free_mask);
+      const int take = (int)min((long long)nfree, wend - next);
+      const int rank = __popcll(free_mask & lt_mask);
+      if (!on && rank < take) {
+        pid = (int)(next + rank);
+        const int e = slot_elem[pid];
+        if (e < 0) {  // tail slots of a CSR: an elem_ids the search allocates is -1 there (tpp:506)
+          if (!seeded) elem_ids[pid] = -1;
+        } else {
+          int el = -1;
+          bool walk = false;
+          V3 o{0, 0, 0}, d{0, 0, 0};
+          if (mask[pid]) {
+            el = seeded ? elem_ids[pid] : e;  // tpp:504-522
+            if (el != -1) {
+              o = V3{x[pid], x[stride + pid], x[2 * stride + pid]};
+              d = V3{xt[pid], xt[stride + pid], xt[2 * stride + pid]};
+              walk = !(norm(sub(d, o)) < tol);  // finishUnmoved tpp:525-533
+            }
+          }
+          if (!walk) {  // initializeIntersection values (tpp:542-547); the parent stays as it is
+            inter_points[(size_t)3 * pid] = 0;
+            inter_points[(size_t)3 * pid + 1] = 0;
+            inter_points[(size_t)3 * pid + 2] = 0;
+            inter_faces[pid] = -1;
+            if (!seeded || el != -1) elem_ids[pid] = el;
+          } else {
+            on = true;
+            chk = true;
+            elem = el;
+            prev = -1;
+            loops = 0;
+            orig = o;
+            ip = V3{0, 0, 0};
+            const V3 displacement = sub(d, o);
+            dir = divs(displacement, norm(displacement));
+          }
+        }
+      }
+      next += take;
+      free_mask = __ballot(!on);
+    }
+    const unsigned long long on_mask = __ballot(on);
+    if (on_mask == 0ull) break;
+    // ---- which kind of round: START (first element: parent check + four faces) or WALK (three faces)
+    const unsigned long long start_mask = __ballot(on && chk);
+    const bool start_round = start_mask != 0ull && (__popcll(start_mask) >= start_batch || start_mask == on_mask ||
+                                                    (next >= wend && !more));
+    const bool act = on && (chk == start_round);
+    coop_issue<3>(recs, act ? elem : -1, st, lane);
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the LDS-DMA pieces have landed
+    wave_lds_sync();
+    if (act) {
+      ++nsteps;
+      const int4 nb = *(const int4*)(mine + (6 ^ sw));
+      const double2 tail = mine[7 ^ sw];  // vol | class_id, mt_code
+      const unsigned code = (unsigned)(__double_as_longlong(tail.y) >> 32);
+      bool fin = false;
+      int xf = -1;  // local index of the exposed face the ray leaves through
+      MtFace F{-1, -1, -1.0};
+      if (start_round) {  // (wave-uniform)
+        chk = false;
+        V3 M[4];
+        for (int v = 0; v < 4; ++v) M[v] = lds_rec_vertex(mine, sw, v);
+        double bcc[4];
+        barycentric_tet(tail.x, M, orig, bcc);
+        if (!all_positive4(bcc, tol)) {  // check_initial_parents (tpp:72-145)
+          atomicAdd(&cnt->not_in_elem, 1);
+          elem = -1;
+          fin = true;
+        } else {
+#pragma unroll
+          for (int fi = 0; fi < 4; ++fi) mt_face(mine, sw, code >> (8 * fi), fi, orig, dir, tol, F, ip);
+        }
+      } else {
+        // the face the ray came in through (face_id == prevExit, tpp:320) is the one with `prev` behind it
+        const int entry = nb.x == prev ? 0 : nb.y == prev ? 1 : nb.z == prev ? 2 : 3;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int fi = j + (j >= entry ? 1 : 0);
+          mt_face(mine, sw, code >> (8 * fi), fi, orig, dir, tol, F, ip);
+        }
+      }
+      if (!fin) {
+        const int lastExit = F.lastExit == -1 ? F.bestFace : F.lastExit;
+        fin = lastExit == -1;
+        if (!fin) {
+          const int nx = lastExit == 0 ? nb.x : lastExit == 1 ? nb.y : lastExit == 2 ? nb.z : nb.w;
+          if (nx == -1) {  // check_model_intersection (tpp:372-385): exposed -> done, the parent stays
+            fin = true;
+            xf = lastExit;
+          } else {  // set_new_element (tpp:397-414)
+            prev = elem;
+            elem = nx;
+          }
+        }
+        ++loops;
+        if (!fin && loops >= cap) {
+          elem = -1;
+          atomicAdd(&cnt->not_found, 1);
+          fin = true;
+        }
+      }
+      if (fin) {
+        inter_points[(size_t)3 * pid] = ip.x;
+        inter_points[(size_t)3 * pid + 1] = ip.y;
+        inter_points[(size_t)3 * pid + 2] = ip.z;
+        inter_faces[pid] = xf >= 0 ? elem2sides[(size_t)elem * 4 + xf] : -1;
+        elem_ids[pid] = elem;
+        on = false;
+      }
+    }
+    wave_lds_sync();  // the staging area is free for the next round's DMA
+  }
+  {
+    unsigned long long n = nsteps;
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    if (lane == 0) atomicAdd(steps_out, n);
+  }
+}
+
 MeshArrays arrays_of(const pp_mesh* mesh) {
   MeshArrays m;
   m.coords = mesh->d_coords.as<double>();
@@ -1587,6 +1808,7 @@ struct CntRef {
   Counters* get() { return g_cnt_dev; }
 } g_cnt;
 
+unsigned long long* g_mt_steps = nullptr;  // elements visited by the last packed Moeller-Trumbore search
 pp::DevBuf g_pending_q, g_wave_cnt;  // deferred-walk queue of the fused kernel (grow-only, library lifetime)
 Counters* g_last_counters = nullptr;  // the set the last pp_push_search added to (pp_push_search_counters)
 
@@ -1695,7 +1917,33 @@ int pp_search_mesh(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_pi
     else
       k_search_tpp<2, false><<<grid, kBlock, 0, st>>>(PP_TPP_ARGS);
   } else {
-    if (requireIntersection)
+    // intersection mode on tets: the walk on packed records with lane refill (k_search_mt3);
+    // PP_MT_PACKED=0 keeps the one-thread-per-slot form on the Omega_h-style arrays (A/B knob)
+    static const bool mt_packed_off = getenv("PP_MT_PACKED") != nullptr && atoi(getenv("PP_MT_PACKED")) == 0;
+    if (requireIntersection && mesh->mt_packed_ok && !mt_packed_off) {
+      static const int per_lane_env = getenv("PP_MT_PER_LANE") ? atoi(getenv("PP_MT_PER_LANE")) : 0;
+      static const int start_batch_env = getenv("PP_MT_START_BATCH") ? atoi(getenv("PP_MT_START_BATCH")) : 0;
+      const int per_lane = per_lane_env > 0 ? per_lane_env : 2;  // (chunks of 128 slots; 1 / 2 / 4 / 8: 24.0 / 15.8 / 16.1 / 17.1 ms for c2mt)
+      const int start_batch = start_batch_env > 0 ? start_batch_env : 12;
+      // persistent blocks: as many as are resident at once (4 per CU: 112 VGPRs, 32 KB of LDS each), fewer when the
+      // structure is small; the chunks of slots are drawn from a device counter
+      static int resident_blocks = 0;
+      if (!resident_blocks) {
+        int dev = 0, cus = 0;
+        PP_HIP_CHECK(hipGetDevice(&dev));
+        PP_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        resident_blocks = std::max(cus, 1) * 4;
+      }
+      const size_t chunks = ((size_t)ps->capacity + 64 * (size_t)per_lane - 1) / (64 * (size_t)per_lane);
+      const unsigned mt_grid = (unsigned)std::min<size_t>((chunks + 3) / 4, (size_t)resident_blocks);
+      if (!g_mt_steps) PP_HIP_CHECK(hipMalloc((void**)&g_mt_steps, 2 * sizeof(unsigned long long)));
+      PP_HIP_CHECK(hipMemsetAsync(g_mt_steps, 0, 2 * sizeof(unsigned long long), st));
+      k_search_mt3<<<mt_grid, kBlock, 0, st>>>(
+          ps->capacity, per_lane, start_batch, ps->d_mask.as<unsigned char>(), pp::slot_elem(ps), mesh->d_records.p,
+          mesh->d_elem2sides.as<int>(), PP_MEMBER(ps, m_x, double), PP_MEMBER(ps, m_xtgt, double), ps->stride,
+          elem_ids_dev, elem_ids_seeded, mesh->tol, inter_faces_dev, inter_points_dev, looplimit, g_cnt.get(),
+          g_mt_steps);
+    } else if (requireIntersection)
       k_search_tpp<3, true><<<grid, kBlock, 0, st>>>(PP_TPP_ARGS);
     else
       k_search_tpp<3, false><<<grid, kBlock, 0, st>>>(PP_TPP_ARGS);
@@ -2054,6 +2302,16 @@ int pp_push_search_counters(int* not_found, int* not_in_elem, int* unmoved_trust
   if (not_found) *not_found = hc.not_found;
   if (not_in_elem) *not_in_elem = hc.not_in_elem;
   if (unmoved_trusted) *unmoved_trusted = hc.unmoved;
+  return PP_OK;
+}
+
+int pp_search_walk_steps(unsigned long long* steps) {
+  PP_REQUIRE(steps, "pp_search_walk_steps: null argument");
+  *steps = 0;
+  if (g_mt_steps) {
+    PP_HIP_CHECK(hipMemcpyAsync(steps, g_mt_steps, sizeof(unsigned long long), hipMemcpyDeviceToHost, pp::stream()));
+    PP_HIP_CHECK(hipStreamSynchronize(pp::stream()));
+  }
   return PP_OK;
 }
 

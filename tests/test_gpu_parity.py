@@ -245,6 +245,67 @@ def test_search_mesh_tpp_3d_exact(ppo, synth, capi, mt):
         assert np.array_equal(ro["inter_points"].ravel(), rg["inter_points"].to_host()[:cap * 3])
 
 
+@pytest.mark.parametrize("kind", ["scs", "csr"])
+@pytest.mark.parametrize("looplimit,deg", [(2000, 12.0), (3, 12.0), (2000, 0.0), (40, 30.0)])
+def test_search_mesh_intersection_mode_packed_walk(ppo, synth, capi, kind, looplimit, deg):
+    """search_mesh with requireIntersection on tets (adjacency.tpp:284-361: Moeller-Trumbore per face, the ray
+    followed to the domain boundary) through the packed-record walk with lane refill (k_search_mt3): parents,
+    exit faces and intersection points bit-equal to the oracle -- unseeded and seeded (with wrong parents and
+    deleted particles, tpp:516-522, 72-145), loop limits that cut rays off (tpp:584-606), a push of zero
+    degrees (every particle 'unmoved', tpp:525-533), SCS and CSR (tail slots).  (tools/gpu_test_matrix.sh
+    runs the suite with PP_MT_PACKED=0 too: the one-thread-per-slot form on the Omega_h-style arrays.)"""
+    pop = common.population_3d(synth, n_b=6, n_theta=24, n_planes=10, num_ptcls=4000)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM, kind=kind)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM, kind=kind)
+    ppo.toroidal_push(po, mo, H, K, D, deg, trig=1)
+    capi.toroidal_push(pg, mg, H, K, D, deg)
+    cap = po.capacity()
+    slot_e, mask = po.slot_info()
+    live = np.flatnonzero(mask)
+    seed = slot_e.copy().astype(np.int32)
+    seed[~mask.astype(bool)] = -1
+    seed[live[::9]] = (seed[live[::9]] + 17) % mo.nelems  # wrong parents -> deleted by check_initial_parents
+    seed[live[::11]] = -1                                   # already deleted: stay -1, untouched outputs
+    for seeded in (False, True):
+        ro = ppo.search_mesh(mo, po, elem_ids=seed.copy() if seeded else None, require_intersection=True,
+                             looplimit=looplimit)
+        ncap = max(pg.capacity(), 1)
+        rg = capi.search_mesh(mg, pg, elem_ids=capi.DevArray.from_host(np.resize(seed, ncap)) if seeded else None,
+                              require_intersection=True, looplimit=looplimit)
+        assert ro["found"] == rg["found"], (seeded, ro["found"])
+        assert ro["not_in_elem"] == rg["not_in_elem"]
+        assert np.array_equal(ro["elem_ids"][:cap], rg["elem_ids"].to_host()[:cap])
+        assert np.array_equal(ro["inter_faces"][:cap], rg["inter_faces"].to_host()[:cap])
+        assert np.array_equal(ro["inter_points"].ravel()[:cap * 3], rg["inter_points"].to_host()[:cap * 3])
+        if deg > 0 and looplimit >= 2000:
+            assert (ro["inter_faces"][:cap][mask.astype(bool)] >= 0).mean() > 0.5  # the rays do reach the wall
+            if not os.environ.get("PP_MT_PACKED") == "0":
+                assert capi.search_walk_steps() > 3 * len(live)  # ... through several elements each
+
+
+def test_mt_face_codes_cover_every_stored_side_order(ppo, synth, capi):
+    """The packed walk reads per (tet, face) which tet-local vertex is faceVerts[0], faceVerts[2 - flip],
+    faceVerts[flip + 1] of the STORED side (bridgeVerts order + isFaceFlipped, adjacency.tpp:322-331): on a
+    mesh whose sides are seen first from either of their two elements both flip values and all three choices
+    of the first vertex must occur, or the test above would not exercise them."""
+    pop = common.population_3d(synth, n_b=6, n_theta=24, n_planes=10, num_ptcls=10)
+    mg, _ = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
+    e2v = np.asarray(pop["e2v"])
+    e2s = mg.array(capi.MESH_ELEM2SIDES).reshape(-1, 4)
+    s2v = mg.array(capi.MESH_SIDE2VERTS).reshape(-1, 3)
+    tmpl = [(0, 2, 1), (0, 1, 3), (1, 2, 3), (2, 0, 3)]
+    firsts, flips = set(), set()
+    for e in range(0, len(e2v), 7):
+        for fi in range(4):
+            fv = s2v[e2s[e, fi]]
+            loc = [int(np.flatnonzero(e2v[e] == v)[0]) for v in fv]
+            assert sorted(loc) == sorted(tmpl[fi])
+            firsts.add(tmpl[fi].index(loc[0]))
+            k = tmpl[fi].index(loc[0])
+            flips.add(loc[1] != tmpl[fi][(k + 1) % 3])
+    assert firsts == {0, 1, 2} and flips == {False, True}
+
+
 def test_search_mesh_tpp_seeded_and_origin_check(ppo, synth, capi):
     """elem_ids passed in (tpp:516-522) + particles whose origin is not in the seed element are
     deleted (check_initial_parents, tpp:72-145)."""

@@ -12,6 +12,6 @@ for cfg in "PP_TILE_P=4" "PP_TILE_P=16" "PP_TILE_P=32" "PP_WALK_QUEUE=1" "PP_WAL
            "PP_NO_PREZERO=1" "PP_EAGER_SLOT_ELEM=1" "PP_NO_SCATTER_RIDE=1" "PP_NO_DIRECT_TOTALS=1" \
            "PP_NO_POLL_TOTALS=1" "PP_NO_SPEC_REBUILD=1" "PP_NO_LAZY_ZERO=1" \
            "PP_SCATTER_ATOMIC=1" "PP_SCATTER_FLAT=1" "PP_NO_STRIDE_SPREAD=1" "PP_NO_MEMBER_SKEW=1" \
-           "PP_TEST_SHUFFLING=0"; do
+           "PP_TEST_SHUFFLING=0" "PP_MT_PACKED=0" "PP_MT_PER_LANE=3"; do
   echo "== $cfg"; env $cfg timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -2
 done
