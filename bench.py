@@ -293,7 +293,7 @@ class Stepper:
                              seeded=True, looplimit=200, want_found=False)
         if timed:
             e1.record()
-        if self.first and self.w.get("origin_trust", True) and self.w["dim"] == 3 and self.name not in ("c4", "c2mt"):
+        if self.first and self.w.get("origin_trust", False) and self.w["dim"] == 3 and self.name not in ("c4", "c2mt"):
             # From the second step on every origin is the destination the previous walk accepted in the
             # element the walk starts from (c3 / c5: the structure was rebuilt from the ids; c2: the ids are
             # the seeds): pp_ps_set_origin_trust skips check_initial_parents (include/pumipic_hip.h).
@@ -474,6 +474,154 @@ def cpu_baseline(pp, w, name, deg, sample, steps=20):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------
+# `also`: the other single-GPU configurations of BASELINE.json and the pieces the headline's step does not
+# exercise, measured in the same run (N = 1, default c3 line only).  Each returns a small dict; bench.py's
+# main() guards every call.
+def clock_prewarm(capi, seconds):
+    """~0.1 s of FP64 vector load settles the shader clock; an unrelated kernel on scratch data"""
+    if seconds <= 0:
+        return
+    n = 1 << 22
+    rng = np.random.default_rng(0)
+    tri = capi.DevArray.from_host(rng.normal(size=9))
+    pts = capi.DevArray.from_host(rng.normal(size=3 * n))
+    scratch = capi.DevArray(3 * n, np.float64)
+    t_end = time.perf_counter() + seconds
+    while time.perf_counter() < t_end:
+        for _ in range(20):
+            capi.check(capi.lib().pp_closest_point_on_triangle(n, tri.ptr, 0, pts.ptr, 0, scratch.ptr, None))
+        capi.sync()
+
+
+def _time_steps(capi, st, warm, k):
+    clock_prewarm(capi, float(os.environ.get("PP_BENCH_PREWARM", "0.3")))  # (the host just built a population)
+    for _ in range(warm):
+        st.step()
+    capi.sync()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        st.step()
+    capi.sync()
+    return (time.perf_counter() - t0) / k
+
+
+def also_c2(pp, capi, a, w_main, st_main):
+    """BASELINE configs[1]: push + search only (fused toroidal push + BCC walk), same mesh and population"""
+    w = build_workload(pp, capi, "c2", a.particles, 0, 1, a.deg, a.remainder, "100k", a.sigma)
+    w["origin_trust"] = w_main.get("origin_trust", False)
+    st = Stepper(pp, capi, w, "c2", a.deg)
+    dt = _time_steps(capi, st, 12, 20)
+    n = w["ps"].nPtcls()
+    return {"workload": "configs[1]: %s, %d particles, push+search only, ids re-used as seeds" % (w["label"], n),
+            "ms_per_step": dt * 1e3, "value": n / dt, "unit": "particles/s", "steps": 20, "warmup": 12,
+            "bytes_per_particle": BYTES["c2"], "roofline_frac": BYTES["c2"] * n / dt / 1e9 / HBM_PEAK_GBS}
+
+
+def also_c2mt(pp, capi, a, w_main, st_main):
+    """configs[1] in the reference's intersection mode (Moeller-Trumbore, rays followed to the wall)"""
+    w = build_workload(pp, capi, "c2mt", a.particles, 0, 1, a.deg, a.remainder, "100k", a.sigma)
+    st = Stepper(pp, capi, w, "c2mt", a.deg)
+    dt = _time_steps(capi, st, 2, 4)
+    n = w["ps"].nPtcls()
+    nsteps = capi.search_walk_steps()
+    return {"workload": "configs[1], search_mesh with requireIntersection: %s, %d particles, toroidal push + "
+                        "Moeller-Trumbore walk of every ray to the domain boundary" % (w["label"], n),
+            "ms_per_step": dt * 1e3, "value": n / dt, "unit": "particles/s", "steps": 4, "warmup": 2,
+            "elements_visited_per_particle": nsteps / max(n, 1),
+            "visited_elements_per_s": nsteps / dt,
+            "bytes_per_particle": BYTES["c2mt"], "roofline_frac": BYTES["c2mt"] * n / dt / 1e9 / HBM_PEAK_GBS,
+            "note": "walk-bound: one visit = one 128-B record (L2 / Infinity Cache) + 3-4 ray/triangle tests in "
+                    "FP64; the HBM fraction is reported for completeness, it is not what bounds this search"}
+
+
+def also_c4(pp, capi, a, w_main, st_main):
+    """BASELINE configs[3]: ps_combo160 largeE_smallP, 1 M elements / 1 M particles, Sell-64-ne"""
+    w = build_c4(pp, capi, 1_000_000, 1_000_000, 0, "scs", 1)
+    st = StepperC4(capi, w)
+    dt = _time_steps(capi, st, 8, 30)
+    n = w["ps"].nPtcls()
+    st.kernel_ms, st.ntimed, st.sample_every = [], 0, 1
+    for _ in range(8):
+        st.step(timed=True)
+    kms = st.kernel_avg_ms()
+    return {"workload": "configs[3]: %s, %d particles, pseudo-push + redistribute(0.5) + rebuild per step"
+                        % (w["label"], n),
+            "ms_per_step": dt * 1e3, "value": n / dt, "unit": "particles/s", "steps": 30, "warmup": 8,
+            "pseudo_push_ms": kms,
+            "pseudo_push_roofline_frac": BYTES["c4"] * n / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms else None,
+            "step_roofline_frac": (BYTES["c4"] + 328.0) * n / dt / 1e9 / HBM_PEAK_GBS,
+            "note": "step fraction on 161 (pseudo-push) + 328 (rebuild: 160 read + 160 written + new element + "
+                    "mask) algorithmic B/particle; at one particle per element the step is a chain of kernels "
+                    "that sweep 10^6 rows, not a stream"}
+
+
+def also_general_scatter(pp, capi, a, w_main, st_main):
+    """pp_gyro_scatter_radius on the headline's structure: per-particle radius (and weight 1), the kernel the
+    reference's gyroScatter would be without its constant radius (test/gyroScatter.hpp:182-204: 2*(dim+1) FP64
+    atomics per particle there; here one per (element, ring) touched by a row's run)"""
+    ps, mesh = w_main["ps"], w_main["mesh"]
+    cap = max(ps.capacity(), 1)
+    rng = np.random.default_rng(1)
+    radius = capi.DevArray.from_host(rng.uniform(0.0, 0.038 * 0.6, size=cap))
+    out = capi.DevArray(mesh.nverts, np.float64)
+    clock_prewarm(capi, float(os.environ.get("PP_BENCH_PREWARM", "0.3")))
+    for _ in range(3):
+        capi.gyro_scatter_radius(mesh, ps, radius, st_main.fwd, out=out, want_clipped=False)
+    capi.sync()
+    k = 10
+    t0 = time.perf_counter()
+    for _ in range(k):
+        capi.gyro_scatter_radius(mesh, ps, radius, st_main.fwd, out=out, want_clipped=False)
+    capi.sync()
+    dt = (time.perf_counter() - t0) / k
+    n = ps.nPtcls()
+    bpp = 8.0 + 1.0  # radius + mask per particle; the element's ring sums and the vertex field are O(mesh)
+    return {"workload": "gyroScatter with a per-particle radius (pp_gyro_scatter_radius) on the headline's "
+                        "structure: %d particles, one field" % n,
+            "ms_per_call": dt * 1e3, "value": n / dt, "unit": "particles/s", "calls": k,
+            "bytes_per_particle": bpp, "roofline_frac": bpp * n / dt / 1e9 / HBM_PEAK_GBS,
+            "reference_atomics_per_particle": 8, "note": "the timed step's gyroScatter is the constant-radius form "
+            "(a function of per-element counts, O(vertices)); this is the per-particle form beside it"}
+
+
+def also_parallel_for(pp, capi, a, w_main, st_main):
+    """the operator API itself: the reference driver's USER lambda through ps::parallel_for (C++ mirror header,
+    drivers/ps_combo160.cpp) against the library's restatement of the same pass, 1 M / 1 M and 50 k / 50 M"""
+    import subprocess
+    drv = os.path.join(ROOT, "pumi-pic_amd", "drivers", "ps_combo160")
+    if not os.path.exists(drv):
+        subprocess.check_call(["make", "-C", os.path.dirname(drv), "-s"])
+    out = {}
+    for label, ne, npt in (("1Me_1Mp", 1_000_000, 1_000_000), ("50ke_50Mp", 50_000, 50_000_000)):
+        env = dict(os.environ, PS_COMBO_CMP="10")
+        r = subprocess.run([drv, str(ne), str(npt), "1", "0", "-i", "1"], env=env, capture_output=True, text=True,
+                           timeout=120)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("PUSHCMP")]
+        if r.returncode != 0 or not line:
+            out[label] = {"error": "driver exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
+            continue
+        tok = line[0].split()
+        val = lambda key: float(tok[tok.index(key) + 1])  # noqa: E731
+        lam, libk, once = val("parallel_for_lambda_ms"), val("library_kernel_ms"), val("parallel_for_single_store_lambda_ms")
+        n = int(tok[tok.index("particles") + 1])
+        out[label] = {"particles": n, "elements": ne, "parallel_for_lambda_ms": lam, "library_kernel_ms": libk,
+                      "parallel_for_single_store_lambda_ms": once,
+                      "lambda_over_library": lam / libk if libk else None,
+                      "single_store_lambda_over_library": once / libk if libk else None,
+                      "lambda_roofline_frac": BYTES["c4"] * n / (lam * 1e-3) / 1e9 / HBM_PEAK_GBS if lam else None}
+    out["note"] = ("pseudo-push of performance_tests/ps_combo160.cpp:158-183 as a user lambda through the mirror's "
+                   "ps::parallel_for vs pp_pseudo_push160, HIP events around 10 back-to-back passes, Sell-64-ne; "
+                   "the reference's lambda stores every double twice (10.3, then the value: the compiler must keep "
+                   "the first store, parentElmData(e) is read in between) -- `single_store` is the same lambda "
+                   "writing each value once, i.e. what ps::parallel_for itself costs")
+    return out
+
+
+ALSO = {"c2": also_c2, "c2mt": also_c2mt, "c4_1Me_1Mp": also_c4, "c3_general_scatter": also_general_scatter,
+        "ps_parallel_for": also_parallel_for}
+
+
 METRIC = {
     "c2": "particles pushed+searched / sec / GPU; achieved HBM GB/s vs peak",
     "2d": "particles pushed+searched / sec / GPU; achieved HBM GB/s vs peak",
@@ -607,9 +755,15 @@ def main():
     ap.add_argument("--remainder", default="last", choices=["last", "spread"],
                     help="where particles left over by the Gaussian draws go: 'last' = literal "
                          "pseudoXGCm rule (one outlier element), 'spread' = evenly")
-    ap.add_argument("--no-origin-trust", action="store_true",
-                    help="run check_initial_parents every step (default: skipped from the second step on, "
-                         "pp_ps_set_origin_trust)")
+    ap.add_argument("--origin-trust", action="store_true",
+                    help="skip check_initial_parents from the second step on (pp_ps_set_origin_trust: exact, "
+                         "the origins are the destinations the previous walk accepted; buys nothing on the "
+                         "record-fed kernels, so off by default since round 4)")
+    ap.add_argument("--no-origin-trust", action="store_true", help=argparse.SUPPRESS)  # (round 2-3 default was on)
+    ap.add_argument("--no-also", action="store_true",
+                    help="N = 1, c3: skip the extra measurements the line reports under `also` (configs[1] c2, "
+                         "configs[3] c4, the intersection-mode search c2mt, the general scatter, the "
+                         "ps::parallel_for lambda)")
     ap.add_argument("--watchdog", type=float, default=None,
                     help="seconds without progress after which a rank exits with code 3 (default: 120 on "
                          "multi-rank runs, off on one rank; 0 = off)")
@@ -662,6 +816,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # a first-run RCCL failure must be diagnosable from the run's stderr tail: WARN prints nothing on success
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
         torch.cuda.set_device(local_rank)
         # The control plane (timing barrier, max-over-ranks, the broadcast of the RCCL id) is gloo on the
         # host; the data path is the library's own RCCL communicator.  PyTorch brings its own ROCm stack
@@ -697,7 +853,7 @@ def main():
                            a.sigma)
         w["safe_layers"] = a.safe_layers
         w["comm"] = a.comm
-        w["origin_trust"] = not a.no_origin_trust
+        w["origin_trust"] = bool(a.origin_trust) and not a.no_origin_trust
         beat("workload built")
         if WATCHDOG.enabled:
             WATCHDOG.limit = wd_limit
@@ -711,15 +867,22 @@ def main():
             dist.barrier()
         beat("barrier passed")
 
-    def timed_run(steps):
+    def timed_run(steps, trace=None):
         st.ntimed = 0
         st.kernel_ms = []
         st.sample_every = max(1, steps // 10)
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
+            t1 = time.perf_counter()
             st.step(timed=True)
+            if trace is not None:  # host time of the call (it returns when the rebuild's totals are on the host)
+                trace.append(round((time.perf_counter() - t1) * 1e3, 3))
+        if trace is not None:
+            t1 = time.perf_counter()
         barrier()
+        if trace is not None:
+            trace.append(round((time.perf_counter() - t1) * 1e3, 3))
         dt = time.perf_counter() - t0
         if dist is not None:
             t = torch.tensor([dt], device="cpu" if ctl_cpu else "cuda", dtype=torch.float64)
@@ -739,48 +902,49 @@ def main():
     if prewarm_s > 0 and not os.environ.get("PP_BENCH_NO_COLD"):
         for _ in range(a.warmup):
             st.step()
-        cold_dt = timed_run(a.steps)
+        cold_trace = []
+        cold_dt = timed_run(a.steps, trace=cold_trace)
         cold = {"ms_per_step": cold_dt / a.steps * 1e3,
+                "host_ms_of_each_step_then_closing_barrier": cold_trace,
                 "note": "the same W warm-up + K timed steps before the clock pre-warm (shader clock still ramping)"}
-    if prewarm_s > 0:
-        n = 1 << 22
-        rng = np.random.default_rng(0)
-        tri = capi.DevArray.from_host(rng.normal(size=9))
-        pts = capi.DevArray.from_host(rng.normal(size=3 * n))
-        scratch = capi.DevArray(3 * n, np.float64)
-        t_end = time.perf_counter() + prewarm_s
-        while time.perf_counter() < t_end:
-            for _ in range(20):
-                capi.check(capi.lib().pp_closest_point_on_triangle(n, tri.ptr, 0, pts.ptr, 0, scratch.ptr, None))
-            capi.sync()
-        del tri, pts, scratch
+    clock_prewarm(capi, prewarm_s)
     for _ in range(a.warmup):
         st.step()
     dt = timed_run(a.steps)
     kms_main, sms_main = st.kernel_avg_ms(), (st.step_avg_ms() if hasattr(st, "step_avg_ms") else None)
     nlive = w["ps"].nPtcls()
     total_particles = nlive
-    # ---- the same K steps with check_initial_parents run for every particle (no pp_ps_set_origin_trust):
-    # reported beside the headline, never as it
+    # ---- everything below is EXTRA: measured after the headline, each piece guarded -- an exception, an
+    # out-of-memory or a time budget that runs out in an extra must never cost the line its headline
+    # (round-3 advisor finding); a failed piece reports {"error": ...} in its place.
+    extras_on = world == 1 and not os.environ.get("PP_BENCH_NO_EXTRAS")
+    t_extras = time.perf_counter()
+    EXTRA_BUDGET_S = float(os.environ.get("PP_BENCH_EXTRA_BUDGET", "150"))
+
+    def guarded(fn, *args):
+        if time.perf_counter() - t_extras > EXTRA_BUDGET_S:
+            return {"error": "skipped: the extras' time budget (%g s) was used up" % EXTRA_BUDGET_S}
+        try:
+            return fn(*args)
+        except Exception as e:  # noqa: BLE001
+            return {"error": "%s: %s" % (type(e).__name__, e)}
+
     notrust_ms = None
-    if (world == 1 and a.workload in ("c2", "c3") and w["dim"] == 3 and w.get("origin_trust", True)
-            and not os.environ.get("PP_BENCH_NO_EXTRAS")):
-        w["ps"].set_origin_trust(False)
-        st.step()
-        notrust_ms = timed_run(a.steps) / a.steps * 1e3
-        w["ps"].set_origin_trust(True)
     # ---- scale_ref: ONE rank's share of the multi-GPU workload (c5: 998 400 tets, 32 M particles, migrating
     # step on a one-rank communicator), measured in this very run, so that the N = 1 point of a 1 -> 8 sweep
     # and the N > 1 points (which run c5) can be compared like with like
     scale_ref = None
-    if (world == 1 and a.workload == "c3" and not a.no_scale_ref and a.mesh == "100k" and a.particles == 10_000_000
-            and a.sigma >= 2**31 - 1 and not os.environ.get("PP_BENCH_NO_EXTRAS")):
+    also = None
+    default_c3 = (a.workload == "c3" and a.mesh == "100k" and a.particles == 10_000_000 and a.sigma >= 2**31 - 1)
+
+    def measure_scale_ref():
         t_set = time.perf_counter()
         w5 = build_workload(pp, capi, "c5", 32_000_000, 0, 1, a.deg, a.remainder, "1m", a.sigma)
-        w5["safe_layers"], w5["comm"], w5["origin_trust"] = 0, "rccl", True
+        w5["safe_layers"], w5["comm"], w5["origin_trust"] = 0, "rccl", w.get("origin_trust", False)
         st5 = Stepper(pp, capi, w5, "c5", a.deg)
         t_set = time.perf_counter() - t_set
-        for _ in range(12):  # (the clocks fell back while the host built the population: ~35 ms of steps)
+        clock_prewarm(capi, prewarm_s)  # (the clocks fell back while the host built the population)
+        for _ in range(12):
             st5.step()
         k5 = 8
         capi.sync()
@@ -790,14 +954,18 @@ def main():
         capi.sync()
         dt5 = time.perf_counter() - t0
         n5 = w5["ps"].nPtcls()
-        scale_ref = {"workload": "c5 on one rank: %s, %d particles, push+search+migrate(no peer)+rebuild+gyroScatter x2"
-                                 % (w5["label"], 32_000_000),
-                     "ms_per_step": dt5 / k5 * 1e3, "value": n5 * k5 / dt5, "unit": "particles/s", "steps": k5,
-                     "warmup": 12, "setup_seconds": t_set,
-                     "roofline_frac": 194.0 * n5 / (dt5 / k5) / 1e9 / HBM_PEAK_GBS,
-                     "note": "the N > 1 lines of this file run exactly this workload per GPU (weak scaling); "
-                             "scaling efficiency of an N-GPU line = value / (N * scale_ref.value)"}
-        del st5, w5
+        return {"workload": "c5 on one rank: %s, %d particles, push+search+migrate(no peer)+rebuild+gyroScatter x2"
+                            % (w5["label"], 32_000_000),
+                "ms_per_step": dt5 / k5 * 1e3, "value": n5 * k5 / dt5, "unit": "particles/s", "steps": k5,
+                "warmup": 12, "setup_seconds": t_set,
+                "roofline_frac": 194.0 * n5 / (dt5 / k5) / 1e9 / HBM_PEAK_GBS,
+                "note": "the N > 1 lines of this file run exactly this workload per GPU (weak scaling); "
+                        "scaling efficiency of an N-GPU line = value / (N * scale_ref.value)"}
+
+    if extras_on and default_c3 and not a.no_scale_ref:
+        scale_ref = guarded(measure_scale_ref)
+    if extras_on and default_c3 and not a.no_also:
+        also = {k: guarded(f, pp, capi, a, w, st) for k, f in ALSO.items()}
     if dist is not None:
         t = torch.tensor([nlive], device="cpu" if ctl_cpu else "cuda", dtype=torch.int64)
         dist.all_reduce(t)
@@ -899,15 +1067,19 @@ def main():
              "c2mt": "toroidal push + search_mesh in intersection mode (Moeller-Trumbore, every ray followed to the "
                      "domain boundary), deg/push=%g" % a.deg,
              "2d": "elliptical push + search_mesh_2d (fused), deg/push=%g" % a.deg,
-             "c3": "push+search+rebuild+gyroScatter x2 (tet ring map) every step, deg/push=%g" % a.deg,
+             "c3": "push+search+rebuild+gyroScatter x2 (tet ring map) every step, deg/push=%g; the second scatter "
+                   "field is a device copy of the first (the two ring maps of one createGyroRingMappings call hold "
+                   "the same ids); check_initial_parents %s" % (
+                       a.deg, "skipped from step 2 on (--origin-trust)" if w.get("origin_trust") else
+                       "runs every step"),
              "c5": "push+search+migrate(all-to-all-v, %s)+rebuild+gyroScatter x2+gyroSync, deg/push=%g" % (
                  getattr(st, "comm_kind", a.comm), a.deg),
              "2dc3": "push+search+rebuild+gyroScatter x2 every step, deg/push=%g" % a.deg}[a.workload]),
             "parallelism": "element-block partition, %d rank(s), full-mesh replica" % world}
-        if notrust_ms is not None:
-            out["ms_per_step_no_origin_trust"] = notrust_ms
         if scale_ref is not None:
             out["scale_ref"] = scale_ref
+        if also is not None:
+            out["also"] = also
         if world > 1:
             if getattr(st, "preflight", None):
                 out["preflight"] = st.preflight
@@ -937,11 +1109,12 @@ def main():
                                    "one visit = one 128-B record + up to 4 ray/triangle tests"}
         elif w["dim"] == 3:
             nf, nie, unm = capi.push_search_counters()
-            out["origin_trust"] = {"on": bool(w.get("origin_trust", True)), "unmoved_without_test_last_step": unm,
+            out["origin_trust"] = {"on": bool(w.get("origin_trust", False)), "unmoved_without_test_last_step": unm,
                                    "not_in_elem_last_step": nie,
-                                   "note": "check_initial_parents skipped from step 2 on (the origins are the "
-                                           "destinations the previous walk accepted); 0 unmoved finishes = the "
-                                           "skipped test would have passed for every particle"}
+                                   "note": "on: check_initial_parents skipped from step 2 on (the origins are the "
+                                           "destinations the previous walk accepted; 0 unmoved finishes = the "
+                                           "skipped test would have passed for every particle); off (default): "
+                                           "the test runs for every particle every step"}
         if full_step:
             ip, fl, rm = w["ps"].rebuild_stats()
             out["rebuilds"] = {"kept_layout": ip, "full_relayout": fl, "rows_traded": rm,

@@ -144,6 +144,71 @@ int main(int argc, char** argv) {
     p::RecordTime(name + " pseudo-push", t.seconds());
   }
 
+  // ---- PS_COMBO_CMP=<passes>: the user lambda through ps::parallel_for (what the reference's driver times,
+  // ps_combo160.cpp:158-183) next to the library's own restatement of that pass (pp_pseudo_push160, what
+  // bench.py --workload c4 times), HIP events on the library stream around `passes` back-to-back launches
+  if (const char* cmp = getenv("PS_COMBO_CMP")) {
+    const int passes = std::max(1, atoi(cmp));
+    auto dbls = ptcls->get<0>();
+    auto nums = ptcls->get<1>();
+    auto lint = ptcls->get<2>();
+    auto pseudoPush = PS_LAMBDA(const int& e, const int& p, const int& mask) {
+      if (mask) {
+        for (int i = 0; i < 17; i++) {
+          dbls(p, i) = 10.3;
+          dbls(p, i) = dbls(p, i) * dbls(p, i) * dbls(p, i) / sqrt((double)p) / sqrt((double)e) +
+                       parentElmData(e);
+        }
+        for (int i = 0; i < 4; i++) nums(p, i) = 4 * p + i;
+        lint(p) = p;
+      } else {
+        for (int i = 0; i < 17; i++) dbls(p, i) = 0;
+        for (int i = 0; i < 4; i++) nums(p, i) = -1;
+        lint(p) = 0;
+      }
+    };
+    // the same values with ONE store per component: the reference's lambda stores 10.3 first and the compiler may
+    // not drop that store (parentElmData(e), read in between, could alias it) -- 296 instead of 160 bytes written
+    auto pseudoPushOnce = PS_LAMBDA(const int& e, const int& p, const int& mask) {
+      if (mask) {
+        const double pe = parentElmData(e);
+        for (int i = 0; i < 17; i++) {
+          const double d = 10.3;
+          dbls(p, i) = d * d * d / sqrt((double)p) / sqrt((double)e) + pe;
+        }
+        for (int i = 0; i < 4; i++) nums(p, i) = 4 * p + i;
+        lint(p) = p;
+      } else {
+        for (int i = 0; i < 17; i++) dbls(p, i) = 0;
+        for (int i = 0; i < 4; i++) nums(p, i) = -1;
+        lint(p) = 0;
+      }
+    };
+    void *e0 = pp_event_create(), *e1 = pp_event_create(), *e2 = pp_event_create(), *e3 = pp_event_create();
+    for (int w = 0; w < 3; ++w) {  // warm-up of the kernels
+      ps::parallel_for(ptcls, pseudoPush, "pseudo push");
+      ps::parallel_for(ptcls, pseudoPushOnce, "pseudo push");
+      p::pp_check(pp_pseudo_push160(ptcls->handle(), parentElmData.data()), "pp_pseudo_push160");
+    }
+    p::pp_check(pp_event_record(e0), "event");
+    for (int k = 0; k < passes; ++k) ps::parallel_for(ptcls, pseudoPush, "pseudo push");
+    p::pp_check(pp_event_record(e1), "event");
+    for (int k = 0; k < passes; ++k)
+      p::pp_check(pp_pseudo_push160(ptcls->handle(), parentElmData.data()), "pp_pseudo_push160");
+    p::pp_check(pp_event_record(e2), "event");
+    for (int k = 0; k < passes; ++k) ps::parallel_for(ptcls, pseudoPushOnce, "pseudo push");
+    p::pp_check(pp_event_record(e3), "event");
+    p::pp_check(pp_sync(), "sync");
+    printf("PUSHCMP structure %s particles %d passes %d parallel_for_lambda_ms %.6f library_kernel_ms %.6f "
+           "parallel_for_single_store_lambda_ms %.6f\n",
+           name.c_str(), ptcls->nPtcls(), passes, pp_event_elapsed_ms(e0, e1) / passes,
+           pp_event_elapsed_ms(e1, e2) / passes, pp_event_elapsed_ms(e2, e3) / passes);
+    pp_event_destroy(e0);
+    pp_event_destroy(e1);
+    pp_event_destroy(e2);
+    pp_event_destroy(e3);
+  }
+
   // ---- redistribute + migrate (ps_combo160.cpp:186-232; one rank: migrate == rebuild)
   printf("Performing %d iterations of migrate/rebuild on each structure\nBeginning migrate on structure %s\n",
          iters, name.c_str());
