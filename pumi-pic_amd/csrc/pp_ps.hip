@@ -1592,8 +1592,12 @@ int build_word_table(const pp_ps* ps, const void* const* src, int64_t src_stride
   const int nw = 2 * wt.n8 + wt.n4;
   // 16-B quads per record; 3 is rounded up to 4: a 48-B record straddles 64-B sectors and the
   // scattered stores of pass 1 become read-modify-writes (measured 0.25 -> 0.40 ms per 10 M)
-  const int NQ = (nw + 3) / 4 == 3 ? 4 : (nw + 3) / 4;
-  return (NQ == 4 || NQ == 10 || (NQ >= 1 && NQ <= 3) || NQ == 6 || NQ == 8) ? NQ : 0;
+  int NQ = (nw + 3) / 4 == 3 ? 4 : (nw + 3) / 4;
+  // the same for the 160-B ps_combo160 particle: every other 160-B record starts in the middle of a 64-B sector;
+  // padded to 192 B (whole sectors) the scattered stores of pass 1 are plain writes (PP_NO_REC_PAD=1: A/B knob)
+  static const bool no_pad = getenv("PP_NO_REC_PAD") != nullptr;
+  if (NQ == 10 && !no_pad) NQ = 12;
+  return (NQ == 4 || NQ == 10 || NQ == 12 || (NQ >= 1 && NQ <= 3) || NQ == 6 || NQ == 8) ? NQ : 0;
 }
 
 // pinned landing zone of the rebuild totals + the event the host waits on
@@ -2001,7 +2005,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     break;
       const RankToSlot rs{new_element, ps->s_eslot0.as<int>(), C_new};
       switch (NQ) {
-        PP_STAGED(1) PP_STAGED(2) PP_STAGED(3) PP_STAGED(4) PP_STAGED(6) PP_STAGED(8) PP_STAGED(10)
+        PP_STAGED(1) PP_STAGED(2) PP_STAGED(3) PP_STAGED(4) PP_STAGED(6) PP_STAGED(8) PP_STAGED(10) PP_STAGED(12)
       }
 #undef PP_STAGED
 #undef PP_UNPACK_ARGS
@@ -2259,7 +2263,7 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     break;
       switch (NQ) {
         PP_CSR_STAGED(1) PP_CSR_STAGED(2) PP_CSR_STAGED(3) PP_CSR_STAGED(4) PP_CSR_STAGED(6)
-        PP_CSR_STAGED(8) PP_CSR_STAGED(10)
+        PP_CSR_STAGED(8) PP_CSR_STAGED(10) PP_CSR_STAGED(12)
       }
 #undef PP_CSR_STAGED
     } else {

@@ -1595,12 +1595,14 @@ __device__ __forceinline__ V3 lds_rec_vertex(const double2* mine, int sw, int v)
 struct MtFace {  // running state of search_findExitFace_intersect_3d over the faces of one element
   int lastExit, bestFace;
   double quality;
+  double t_ip;  // ray parameter of the intersection point the reference would hold now (xpoint = orig + dir * t)
+  bool upd;     // ... if any face of this element wrote it
 };
 // one face of the element staged at `mine`: ray_intersects_triangle (tpp:152-178) on the stored side named by
 // code byte `c`, then the reference's bookkeeping (tpp:333-348): last success wins; without a success so far
 // the face with dproj > -tol that is closest in (u, v) -- candidates overwrite the intersection point
 __device__ __forceinline__ void mt_face(const double2* mine, int sw, unsigned c, int fi, V3 orig, V3 dir, double tol,
-                                        MtFace& F, V3& ip) {
+                                        MtFace& F) {
   const V3 f0 = lds_rec_vertex(mine, sw, c & 3), fa = lds_rec_vertex(mine, sw, (c >> 2) & 3),
            fb = lds_rec_vertex(mine, sw, (c >> 4) & 3);
   const V3 edge1 = sub(fa, f0), edge2 = sub(fb, f0);
@@ -1613,21 +1615,24 @@ __device__ __forceinline__ void mt_face(const double2* mine, int sw, unsigned c,
   const V3 qvec = cross(tvec, edge1);
   const double v = invdet * dot(dir, qvec);
   const double t = invdet * dot(edge2, qvec);
-  const V3 xp = add(orig, mul(dir, t));
   const double m1 = PPG_KMIN(fabs(u), fabs(1 - u));
   const double m2 = PPG_KMIN(fabs(v), fabs(1 - v));
   const double m3 = PPG_KMIN(fabs(u + v), fabs(1 - u - v));
   const double mm = PPG_KMAX(m1, m2);
   const double closeness = PPG_KMAX(mm, m3);
   const bool success = (dproj >= tol) && (t >= -tol) && (u >= -tol) && (v >= -tol) && (u + v <= 1.0 + 2 * tol);
+  // (the reference stores xpoint = orig + dir * t at both places; the point is a function of t alone, so t is
+  // kept and the point formed once per element, from the last t written -- the same value)
   if (success) {
     F.lastExit = fi;
-    ip = xp;
+    F.t_ip = t;
+    F.upd = true;
   }
   if (dproj > -tol && (F.quality < 0 || closeness < F.quality) && F.lastExit == -1) {
     F.quality = closeness;
     F.bestFace = fi;
-    ip = xp;
+    F.t_ip = t;
+    F.upd = true;
   }
 }
 __global__ void __launch_bounds__(256, 2)
@@ -1725,7 +1730,7 @@ __global__ void __launch_bounds__(256, 2)
       const unsigned code = (unsigned)(__double_as_longlong(tail.y) >> 32);
       bool fin = false;
       int xf = -1;  // local index of the exposed face the ray leaves through
-      MtFace F{-1, -1, -1.0};
+      MtFace F{-1, -1, -1.0, 0.0, false};
       if (start_round) {  // (wave-uniform)
         chk = false;
         V3 M[4];
@@ -1738,7 +1743,7 @@ __global__ void __launch_bounds__(256, 2)
           fin = true;
         } else {
 #pragma unroll
-          for (int fi = 0; fi < 4; ++fi) mt_face(mine, sw, code >> (8 * fi), fi, orig, dir, tol, F, ip);
+          for (int fi = 0; fi < 4; ++fi) mt_face(mine, sw, code >> (8 * fi), fi, orig, dir, tol, F);
         }
       } else {
         // the face the ray came in through (face_id == prevExit, tpp:320) is the one with `prev` behind it
@@ -1746,10 +1751,11 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           const int fi = j + (j >= entry ? 1 : 0);
-          mt_face(mine, sw, code >> (8 * fi), fi, orig, dir, tol, F, ip);
+          mt_face(mine, sw, code >> (8 * fi), fi, orig, dir, tol, F);
         }
       }
       if (!fin) {
+        if (F.upd) ip = add(orig, mul(dir, F.t_ip));
         const int lastExit = F.lastExit == -1 ? F.bestFace : F.lastExit;
         fin = lastExit == -1;
         if (!fin) {

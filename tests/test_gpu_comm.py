@@ -155,6 +155,71 @@ def test_migrate_local_virtual_ranks(ppo, synth, capi, dim, world, fused):
         c.destroy()
 
 
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_migrate_send_right_then_back_reference_properties(synth, capi, world):
+    """particle_structs/test/test_migrate.cpp, migrateSendRight (:4-101), on virtual ranks of one process.
+    Every rank sends the particles of its LAST element to rank + 1 (`new_process(p) = (local_rank + 1) %
+    local_csize` for `e == num_elems - 1`, :21-24) after stamping them with its own rank (`rnks(p) =
+    local_rank`, :26).  The reference then asserts, per live particle (:40-51): in the last element no particle
+    still carries the local rank ("Failed to send particle"), in any other element none carries a foreign one
+    ("Incorrectly received particle").  Second half (:55-99): everything is sent back to the rank it is stamped
+    with (`new_process(p) = rnks(p)`, :70) and `rank != local_rank` must hold for no particle (:82-86).  The
+    particle counts those assertions imply (a ring: what leaves the last element arrives at the right
+    neighbour's last element; the way back restores the original populations BY PARTICLE ID) are checked on
+    top.  Stamp = member b (float, exact for small integers), id = member 2."""
+    pop = _population(synth, 3)
+    ne = len(pop["e2v"])
+    n = len(pop["elem"])
+    ranks, ids0 = [], []
+    for r in range(world):  # every rank: the same elements (the reference runs one mesh per rank), own particle ids
+        info = [a.copy() for a in pop["info"]]
+        info[2] = (np.arange(n) + r * n).astype(np.int32)
+        info[3] = np.full(n, float(r), dtype=np.float32)  # rnks(p) = local_rank
+        ranks.append(capi.PS.scs(capi.PARTICLE_XGCM, ne, pop["ppe"], C_=64, gids=np.arange(ne, dtype=np.int64),
+                                 particle_elements=pop["elem"], particle_info=info))
+        ids0.append(np.sort(info[2]))
+    comms = capi.Comm.local(world)
+    last = int(np.flatnonzero(pop["ppe"])[-1])  # the reference's fixture has particles in element num_elems - 1;
+    n_last = int(pop["ppe"][last])              # here: the last element that holds any
+
+    def live(ps):
+        se, mk = ps.slot_info()
+        cap = ps.capacity()
+        m = mk.astype(bool)
+        return se[m], ps.member(2)[0, :cap][m], ps.member(3)[0, :cap][m].astype(np.int32)
+
+    def migrate_all(dest_of):
+        keep = []
+        for r, ps in enumerate(ranks):
+            se, mk = ps.slot_info()
+            cap = max(ps.capacity(), 1)
+            stamp = ps.member(3)[0, :cap].astype(np.int32)
+            ne_h = np.where(mk > 0, se, -1).astype(np.int32)  # new_element(p) = e
+            np_h = np.full(cap, r, dtype=np.int32)
+            np_h[mk > 0] = dest_of(r, se[mk > 0], stamp[mk > 0])
+            ne_d, np_d = capi.DevArray.from_host(ne_h), capi.DevArray.from_host(np_h)
+            capi.migrate_begin(ps, ne_d, np_d, comms[r])
+            keep.append((ne_d, np_d))
+        return sum(capi.migrate_end(ps, comms[r])[0] for r, ps in enumerate(ranks))
+
+    sent = migrate_all(lambda r, e, stamp: np.where(e == last, (r + 1) % world, r))
+    assert sent == world * n_last
+    for r, ps in enumerate(ranks):
+        e, pid, stamp = live(ps)
+        assert len(e) == n                                     # n_last left, n_last arrived
+        assert not np.any((e == last) & (stamp == r))          # :42-46 "Failed to send particle"
+        assert not np.any((e != last) & (stamp != r))          # :47-50 "Incorrectly received particle"
+        assert np.all(stamp[e == last] == (r - 1) % world)     # they came from the left neighbour
+    back = migrate_all(lambda r, e, stamp: stamp)              # new_process(p) = rnks(p), :70
+    assert back == world * n_last
+    for r, ps in enumerate(ranks):
+        e, pid, stamp = live(ps)
+        assert np.all(stamp == r)                              # :82-86 "Incorrectly received / failed to send"
+        assert np.array_equal(np.sort(pid), ids0[r])           # everybody is home, nobody twice
+    for c in comms:
+        c.destroy()
+
+
 def test_config5_step_eight_owner_blocks_vs_oracle(ppo, synth, capi):
     """BASELINE configs[4]'s time step at a size the oracle walks in seconds: a coarse torus split into
     EIGHT contiguous element blocks (bench.py's owner rule for 8 GPUs), every virtual rank calls what
