@@ -152,7 +152,15 @@ int pp_ps_member_from_host(pp_ps* ps, int m, const void* in_host);
 /* rebuild(new_element, new_particle_elements, new_particle_info) scs/SCS_rebuild.h:122-314,
  * csr/CSR_rebuild.hpp:18-118.  new_element_dev has capacity entries (-1 = delete).
  * new_info_dev[m] is a DEVICE array [ncomp][n_new].  In place when the layout can be kept
- * (pp_ps_set_shuffling), else the full counting-sort re-layout. */
+ * (pp_ps_set_shuffling), else the full counting-sort re-layout.
+ * LIFETIME OF THE INPUTS: the call returns when the new totals are on the host (the one host wait
+ * of a rebuild); the kernels that move the particles are still running then and read
+ * new_element_dev, new_elems_dev and the new_info_dev arrays.  They are ordered on the library
+ * stream (pp_stream), so any later library call and pp_free / hipFree are safe; a caller that
+ * overwrites or frees those buffers from ANOTHER stream must first wait for the library stream
+ * (pp_sync, or an event recorded on pp_stream).  The same holds for the migration entry points.
+ * THREADS: structures are independent (each owns its scratch, its pinned landing zone and its
+ * stamps); calls on ONE structure must not overlap, and all calls share one stream. */
 int pp_ps_rebuild(pp_ps* ps, const int* new_element_dev, int n_new, const int* new_elems_dev,
                   const void* const* new_info_dev);
 /* updatePtclPositions (test/pseudoXGCm.cpp:102-114: x <- x_tgt, x_tgt <- 0) fused into the

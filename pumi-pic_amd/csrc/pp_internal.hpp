@@ -231,6 +231,14 @@ struct pp_ps {
   int lazy_x = -1, lazy_xt = -1;  // commit members of the rebuild that left the records
   pp::DevBuf s_aos_live;
   pp::DevBuf s_rs, s_holes;  // in-place rebuild: per-element counters, per-row hole lists
+  // pinned landing zone of the rebuild's totals (host-mapped) + its event, and the stamp the host polls for
+  void* h_totals = nullptr;
+  void* ev_totals = nullptr;
+  int totals_stamp = 0;
+  ~pp_ps() {
+    if (h_totals) (void)hipHostFree(h_totals);
+    if (ev_totals) (void)hipEventDestroy((hipEvent_t)ev_totals);
+  }
   // scratch reused across rebuilds
   void* ppe_zeroed = nullptr;  // == s_ppe.p: that buffer was cleared by the previous re-layout's tail
   size_t ppe_zeroed_bytes = 0;

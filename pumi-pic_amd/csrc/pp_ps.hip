@@ -1445,6 +1445,7 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
     int* const partial_at = ps->s_hist.as<int>() + hist_words;
     et.partial = (et.totals && !(ps->pad_strat == PP_PAD_INVERSELY && ps->shuffle_padding > 0)) ? partial_at : nullptr;
     static const bool no_fused_sort = getenv("PP_NO_FUSED_SORT") != nullptr;  // A/B knobs
+    static const bool no_rs_skip = getenv("PP_NO_RS_SKIP") != nullptr;
     static const bool no_wide_sort = getenv("PP_NO_WIDE_SORT") != nullptr;
     const bool fused_sort = nblk <= kFusedSortBlocks && !no_fused_sort;
     unsigned long long maxkey = (unsigned long long)(n_sigma > 0 ? n_sigma : 1) * L.base;
@@ -1473,7 +1474,7 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
     k_make_keys<<<nblk + (ride.on ? grid_for(ride.nverts) : 0), 256, 0, st>>>(ne, ppe, sg, n_sigma, L.base,
                                                  ps->s_keys.as<unsigned long long>(),
                                                  ps->s_vals.as<int>(), tot,
-                                                 getenv("PP_NO_RS_SKIP") != nullptr, et,
+                                                 no_rs_skip, et,
                                                  (fused_sort || wide_big) ? FusedHist{H0, nblk, wide_sort ? 1 : 0}
                                                                           : FusedHist{nullptr, 0, 0},
                                                  nblk, ride);
@@ -1523,10 +1524,11 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
   L.tile_off = L.tile_cnt + nchunks;
   L.chunk_start = ps->s_cstart2.as<int>();
   const bool fused_layout = ps->pad_strat != PP_PAD_INVERSELY || !(ps->shuffle_padding > 0);
+  static const bool no_fused_widths = getenv("PP_NO_FUSED_WIDTHS") != nullptr;
   // one sort window: the keys are the counts, ascending -- the layout kernel reads a chunk's width off its last row
   // (after the one-pass sort it has to: the overflow digit is ordered by that kernel's prologue)
   const bool widths_in_layout = fused_layout && L.sorted && ne > 0 && ne / std::min(ps->sigma, std::max(ne, 1)) <= 1 &&
-                                (L.wide || getenv("PP_NO_FUSED_WIDTHS") == nullptr);
+                                (L.wide || !no_fused_widths);
   if (!widths_in_layout)
     k_chunk_widths2<<<grid_for((size_t)nchunks * 64), kBlock, 0, st>>>(
         nchunks, C_new, ne, L.keys, L.base, L.sorted ? 1 : 0, ppe, L.widths);
@@ -1600,17 +1602,16 @@ int build_word_table(const pp_ps* ps, const void* const* src, int64_t src_stride
   return (NQ == 4 || NQ == 10 || NQ == 12 || (NQ >= 1 && NQ <= 3) || NQ == 6 || NQ == 8) ? NQ : 0;
 }
 
-// pinned landing zone of the rebuild totals + the event the host waits on
-int totals_pin(Totals** h_pin_out, hipEvent_t* ev_out) {
-  static Totals* h_pin = nullptr;
-  static hipEvent_t ev_tot = nullptr;
-  if (!h_pin) {
-    PP_HIP_CHECK(hipHostMalloc((void**)&h_pin, sizeof(Totals), hipHostMallocCoherent | hipHostMallocMapped));
-    memset(h_pin, 0, sizeof(Totals));
-    PP_HIP_CHECK(hipEventCreateWithFlags(&ev_tot, hipEventDisableTiming));
+// pinned landing zone of the rebuild totals + the event the host waits on: one per STRUCTURE (two host threads
+// that rebuild different structures share nothing; round-3 advisor finding)
+int totals_pin(pp_ps* ps, Totals** h_pin_out, hipEvent_t* ev_out) {
+  if (!ps->h_totals) {
+    PP_HIP_CHECK(hipHostMalloc(&ps->h_totals, sizeof(Totals), hipHostMallocCoherent | hipHostMallocMapped));
+    memset(ps->h_totals, 0, sizeof(Totals));
+    PP_HIP_CHECK(hipEventCreateWithFlags((hipEvent_t*)&ps->ev_totals, hipEventDisableTiming));
   }
-  *h_pin_out = h_pin;
-  *ev_out = ev_tot;
+  *h_pin_out = (Totals*)ps->h_totals;
+  *ev_out = (hipEvent_t)ps->ev_totals;
   return PP_OK;
 }
 
@@ -1716,7 +1717,7 @@ int scs_reshuffle(pp_ps* ps, const int* new_element, int n_new, const int* new_e
   PP_LAUNCH_CHECK();
   Totals* h_pin;
   hipEvent_t ev_tot;
-  int rc = totals_pin(&h_pin, &ev_tot);
+  int rc = totals_pin(ps, &h_pin, &ev_tot);
   if (rc) return rc;
   PP_HIP_CHECK(hipMemcpyAsync(h_pin, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
   PP_HIP_CHECK(hipEventRecord(ev_tot, st));
@@ -1731,7 +1732,8 @@ int scs_reshuffle(pp_ps* ps, const int* new_element, int n_new, const int* new_e
   (void)scattered;
   PP_HIP_CHECK(hipEventSynchronize(ev_tot));
   const Totals h = *h_pin;
-  if (getenv("PP_SPEC_DEBUG"))
+  static const bool spec_debug_rs = getenv("PP_SPEC_DEBUG") != nullptr;
+  if (spec_debug_rs)
     fprintf(stderr, "rebuild in place: go %d active %d nonempty %d invalid %d overflowing rows %d\n", h.go, h.active,
             h.nonempty, h.invalid, h.n_over);
   if (h.invalid) {
@@ -1804,8 +1806,9 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   // 64..256 blocks: each block ends with two atomics on the same two counters (~5 ns apiece), each
   // thread strides over ne / (blocks * 256) elements
   // the reference's reshuffle decision (mode 1), on the histogram just built
+  static const bool no_reshuffle = getenv("PP_NO_RESHUFFLE") != nullptr;
   const bool decide_keep = try_reshuffle && ps->shuffle_mode >= 1 && have_old && ne > 0 && ps->elem_count_valid &&
-                           getenv("PP_NO_RESHUFFLE") == nullptr;
+                           !no_reshuffle;
   // totals of the new population + the decision: in the sweep that makes the sort keys when the layout
   // is sorted (one launch instead of three), else their own kernels
   // (up to 256 key blocks: every block ends with three atomics on the same counters, ~10 ns each)
@@ -1913,13 +1916,12 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     if (int rct = make_tables((int)cap_lim, (int)nsl_lim, ta_spec)) return rct;
   Totals* h_pin = nullptr;
   hipEvent_t ev_tot = nullptr;
-  if (int rcp = totals_pin(&h_pin, &ev_tot)) return rcp;
+  if (int rcp = totals_pin(ps, &h_pin, &ev_tot)) return rcp;
   static const bool no_direct_totals = getenv("PP_NO_DIRECT_TOTALS") != nullptr;
   // the host polls the landing zone for this rebuild's stamp (no event in the stream); one poll that runs into
   // its time limit (the memory turned out not to be visible mid-stream) switches back to the event for good
   static bool poll_totals = getenv("PP_NO_POLL_TOTALS") == nullptr;
-  static int stamp_seq = 0;
-  const int stamp = (poll_totals && !no_direct_totals) ? (stamp_seq = stamp_seq % 1000000 + 1) : 0;
+  const int stamp = (poll_totals && !no_direct_totals) ? (ps->totals_stamp = ps->totals_stamp % 1000000 + 1) : 0;
   int rc = enqueue_layout(ps, ps->C_max, ppe, tot, key_base, L, bits_pred,
                           ElemTotalsArgs{totals_in_keys ? 1 : 0, (totals_in_keys && decide_keep) ? 1 : 0, ps->C,
                                          ps->d_element_to_row.as<int>(), ps->d_chunk_width.as<int>(), nullptr},
@@ -1982,8 +1984,8 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       // x_tgt <- 0 of the fused updatePtclPositions stays pending (pp_ps::zero_pending): the next fused
       // push overwrites the member, anything else materialises the zeros first.  24 of the 60 bytes
       // pass 2 would write per particle.
-      lazy_zero = NQ > 0 && commit_x >= 0 && commit_xt >= 0 && (n_new == 0 || new_xt_zero) &&
-                  getenv("PP_NO_LAZY_ZERO") == nullptr;
+      static const bool no_lazy_zero = getenv("PP_NO_LAZY_ZERO") != nullptr;
+      lazy_zero = NQ > 0 && commit_x >= 0 && commit_xt >= 0 && (n_new == 0 || new_xt_zero) && !no_lazy_zero;
       if (lazy_zero) wt.nz8 = wt.nz4 = 0;
       // The second pass (records -> new SoA arrays) is deferred for the pseudoXGCm particle type: the
       // next fused push reads the records themselves (pp_search.hip: RECIN), anything else runs the
@@ -2119,7 +2121,8 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     ps->num_ptcls = 0;
     return PP_OK;
   }
-  if (getenv("PP_SPEC_DEBUG"))
+  static const bool spec_debug = getenv("PP_SPEC_DEBUG") != nullptr;
+  if (spec_debug)
     fprintf(stderr, "rebuild: speculated %d go %d capacity %d (old %d) nslices %d active %d nonempty %d "
                     "key bits sorted %d max key %llu\n",
             (int)speculated, h.go, h.capacity, ps->capacity, h.nslices, h.active, h.nonempty, L.key_bits,
@@ -2295,12 +2298,9 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     if (rc) return rc;
     speculated = true;
   }
-  static Totals* h_pin = nullptr;
-  static hipEvent_t ev_tot = nullptr;
-  if (!h_pin) {
-    PP_HIP_CHECK(hipHostMalloc((void**)&h_pin, sizeof(Totals)));
-    PP_HIP_CHECK(hipEventCreateWithFlags(&ev_tot, hipEventDisableTiming));
-  }
+  Totals* h_pin = nullptr;
+  hipEvent_t ev_tot = nullptr;
+  if (int rcp = totals_pin(ps, &h_pin, &ev_tot)) return rcp;
   PP_HIP_CHECK(hipMemcpyAsync(h_pin, tot, sizeof(Totals), hipMemcpyDeviceToHost, st));
   PP_HIP_CHECK(hipEventRecord(ev_tot, st));
   PP_HIP_CHECK(hipEventSynchronize(ev_tot));
@@ -2366,12 +2366,15 @@ int ps_materialize(pp_ps* ps) {
             wt.dst4[wt.n4++] = dst;
         }
       }
-      static int* go_one = nullptr;
-      if (!go_one) {
-        PP_HIP_CHECK(hipMalloc((void**)&go_one, sizeof(int)));
+      static int* const go_one = [] {  // a device 1 (initialised once, thread-safe: function-local static)
+        int* p1 = nullptr;
         const int one = 1;
-        PP_HIP_CHECK(hipMemcpy(go_one, &one, sizeof(int), hipMemcpyHostToDevice));
-      }
+        if (hipMalloc((void**)&p1, sizeof(int)) != hipSuccess ||
+            hipMemcpy(p1, &one, sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+          return (int*)nullptr;
+        return p1;
+      }();
+      PP_REQUIRE(go_one != nullptr, "ps_materialize: device allocation failed");
       if (state == 2) wt.n4 = 0;  // (4-byte members were written by the push; 8-byte ones: only lazy_x has a target)
       k_move_unpack<4><<<grid_for((size_t)ps->ntiles_max * ps->C), kBlock, 0, pp::stream()>>>(
           ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(),

@@ -1657,68 +1657,72 @@ __global__ void __launch_bounds__(256, 2)
   unsigned nsteps = 0;  // elements this lane's particles visited (pp_search_walk_steps)
   V3 orig{0, 0, 0}, dir{0, 0, 0}, ip{0, 0, 0};
   while (true) {
-    // ---- refill: free lanes take the next slots until every lane walks or the wave's slots are used up
+    // ---- refill + START round, batched: the refill (loads, norm, the ray direction's divisions, ~25 registers
+    // of per-particle state) and the first element's round (parent check + four faces) cost more than a walk
+    // round and would run for one or two lanes nearly every round -- lanes that fall free wait until
+    // `start_batch` of them (or nobody walking) are there, then take the next slots together
     unsigned long long free_mask = __ballot(!on);
-    while (free_mask != 0ull && (next < wend || more)) {
-      if (next >= wend) {  // draw the next chunk
-        unsigned long long c0 = 0;
-        if (lane == 0) c0 = atomicAdd(steps_out + 1, (unsigned long long)chunk);
-        next = (long long)__shfl(c0, 0);
-        wend = min((long long)capacity, next + chunk);
-        if (next >= capacity) {
-          more = false;
-          next = wend = 0;
-          break;
+    if (__popcll(free_mask) >= start_batch || free_mask == ~0ull) {
+      while (free_mask != 0ull && (next < wend || more)) {
+        if (next >= wend) {  // draw the next chunk
+          unsigned long long c0 = 0;
+          if (lane == 0) c0 = atomicAdd(steps_out + 1, (unsigned long long)chunk);
+          next = (long long)__shfl(c0, 0);
+          wend = min((long long)capacity, next + chunk);
+          if (next >= capacity) {
+            more = false;
+            next = wend = 0;
+            break;
+          }
         }
-      }
-      const int nfree = __popcll(free_mask);
-      const int take = (int)min((long long)nfree, wend - next);
-      const int rank = __popcll(free_mask & lt_mask);
-      if (!on && rank < take) {
-        pid = (int)(next + rank);
-        const int e = slot_elem[pid];
-        if (e < 0) {  // tail slots of a CSR: an elem_ids the search allocates is -1 there (tpp:506)
-          if (!seeded) elem_ids[pid] = -1;
-        } else {
-          int el = -1;
-          bool walk = false;
-          V3 o{0, 0, 0}, d{0, 0, 0};
-          if (mask[pid]) {
-            el = seeded ? elem_ids[pid] : e;  // tpp:504-522
-            if (el != -1) {
-              o = V3{x[pid], x[stride + pid], x[2 * stride + pid]};
-              d = V3{xt[pid], xt[stride + pid], xt[2 * stride + pid]};
-              walk = !(norm(sub(d, o)) < tol);  // finishUnmoved tpp:525-533
+        const int nfree = __popcll(free_mask);
+        const int take = (int)min((long long)nfree, wend - next);
+        const int rank = __popcll(free_mask & lt_mask);
+        if (!on && rank < take) {
+          pid = (int)(next + rank);
+          const int e = slot_elem[pid];
+          if (e < 0) {  // tail slots of a CSR: an elem_ids the search allocates is -1 there (tpp:506)
+            if (!seeded) elem_ids[pid] = -1;
+          } else {
+            int el = -1;
+            bool walk = false;
+            V3 o{0, 0, 0}, d{0, 0, 0};
+            if (mask[pid]) {
+              el = seeded ? elem_ids[pid] : e;  // tpp:504-522
+              if (el != -1) {
+                o = V3{x[pid], x[stride + pid], x[2 * stride + pid]};
+                d = V3{xt[pid], xt[stride + pid], xt[2 * stride + pid]};
+                walk = !(norm(sub(d, o)) < tol);  // finishUnmoved tpp:525-533
+              }
+            }
+            if (!walk) {  // initializeIntersection values (tpp:542-547); the parent stays as it is
+              inter_points[(size_t)3 * pid] = 0;
+              inter_points[(size_t)3 * pid + 1] = 0;
+              inter_points[(size_t)3 * pid + 2] = 0;
+              inter_faces[pid] = -1;
+              if (!seeded || el != -1) elem_ids[pid] = el;
+            } else {
+              on = true;
+              chk = true;
+              elem = el;
+              prev = -1;
+              loops = 0;
+              orig = o;
+              ip = V3{0, 0, 0};
+              const V3 displacement = sub(d, o);
+              dir = divs(displacement, norm(displacement));
             }
           }
-          if (!walk) {  // initializeIntersection values (tpp:542-547); the parent stays as it is
-            inter_points[(size_t)3 * pid] = 0;
-            inter_points[(size_t)3 * pid + 1] = 0;
-            inter_points[(size_t)3 * pid + 2] = 0;
-            inter_faces[pid] = -1;
-            if (!seeded || el != -1) elem_ids[pid] = el;
-          } else {
-            on = true;
-            chk = true;
-            elem = el;
-            prev = -1;
-            loops = 0;
-            orig = o;
-            ip = V3{0, 0, 0};
-            const V3 displacement = sub(d, o);
-            dir = divs(displacement, norm(displacement));
-          }
         }
+        next += take;
+        free_mask = __ballot(!on);
       }
-      next += take;
-      free_mask = __ballot(!on);
     }
     const unsigned long long on_mask = __ballot(on);
     if (on_mask == 0ull) break;
-    // ---- which kind of round: START (first element: parent check + four faces) or WALK (three faces)
-    const unsigned long long start_mask = __ballot(on && chk);
-    const bool start_round = start_mask != 0ull && (__popcll(start_mask) >= start_batch || start_mask == on_mask ||
-                                                    (next >= wend && !more));
+    // ---- which kind of round: START (first element: parent check + four faces) for the lanes just filled,
+    // else WALK (three faces)
+    const bool start_round = __ballot(on && chk) != 0ull;
     const bool act = on && (chk == start_round);
     coop_issue<3>(recs, act ? elem : -1, st, lane);
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the LDS-DMA pieces have landed

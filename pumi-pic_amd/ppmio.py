@@ -13,8 +13,9 @@ Scalars and arrays are framed by Omega_h's binary::write_value / write_array (Om
 SCOREC/omega_h scorec-v10.8.x -- NOT in the reference tree, restated from its published source): a value is
 its raw little-endian bytes; an array is an I32 element count followed, in a zlib build (OMEGA_H_USE_ZLIB, the
 compile-time switch file.cpp:76-80 reads), by an I64 compressed byte count and one zlib stream
-(compress2, Z_BEST_SPEED), else by the raw elements.  The file itself does not say which; the reader takes
-`compress=None` = "try the zlib framing, fall back to raw".
+(compress2, Z_BEST_SPEED), else by the raw elements.  The file itself does not say which; with `compress=None` the
+reader decides on the file's first array (a positive check: the compressed size fits, the stream inflates to
+4 x count bytes) and then requires the whole file to parse in that framing.
 
 PARITY UNPINNED: the reference's data submodule (pumipic-data) is empty here, so no `.ppm` written by the
 reference was available; what is checked is the round trip and that the fields written for a part equal the
@@ -92,12 +93,34 @@ class _Reader:
         return np.frombuffer(raw, dtype="<i4").astype(np.int32)
 
 
+class _NotZlibFramed(ValueError):
+    pass
+
+
+def _first_array_is_zlib(buf):
+    """Positive check of the framing on the FIRST array of the file (offset 2 + 8 + 4: version, is_full_mesh,
+    num_entites, num_cores; version 1 has no num_entites): zlib framing = I32 count, I64 compressed size that fits
+    the file, a stream that inflates to exactly 4 * count bytes.  The whole file then has to parse in the framing
+    detected here -- a file that starts in one framing and continues in the other is an error, not a guess."""
+    ver = struct.unpack_from("<b", buf, 0)[0]
+    p = 2 + (8 if ver >= 2 else 0) + 4
+    if p + 4 > len(buf):
+        raise ValueError("truncated .ppm file")
+    n = struct.unpack_from("<i", buf, p)[0]
+    if n < 0 or p + 12 > len(buf):
+        return False
+    nz = struct.unpack_from("<q", buf, p + 4)[0]
+    if nz < 0 or p + 12 + nz > len(buf):
+        return False
+    try:
+        return len(zlib.decompress(buf[p + 12:p + 12 + nz])) == 4 * n
+    except zlib.error:
+        return False
+
+
 def loads(buf, compress=None):
-    if compress is None:
-        try:
-            return loads(buf, True)
-        except (ValueError, zlib.error, struct.error):
-            return loads(buf, False)
+    if compress is None:  # the file does not say which framing it uses: decide on its first array, then insist
+        compress = _first_array_is_zlib(buf)
     r = _Reader(buf, compress)
     part = {"version": r.value("<b"), "is_full_mesh": bool(r.value("<b")), "dims": []}
     if part["version"] not in (1, 2):

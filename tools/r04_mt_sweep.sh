@@ -6,5 +6,5 @@ run() { env "$@" python bench.py --workload c2mt --steps 5 --warmup 1 --no-cpu-b
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-44s ms/step %8.3f  visits/particle %.1f  ns/visit %s' % ('$*', j['ms_per_step'], j['walk']['elements_visited_per_particle'], j['walk']['ns_per_visited_element']))"; }
 for pl in 1 2 4 8 16; do run PP_MT_PER_LANE=$pl; done
-for sb in 4 8 16 24; do run PP_MT_START_BATCH=$sb PP_MT_PER_LANE=2; done
+for sb in 4 8 12 16 24 32; do run PP_MT_START_BATCH=$sb; done
 run PP_MT_PACKED=0

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """profiles/traffic_<workload>.json for a WHOLE step (c3 / c5): FETCH_SIZE and WRITE_SIZE of every kernel
-a step launches, summed, per step -- from the two --pmc passes of tools/r03_measure.sh (`bench.py
+a step launches, summed, per step -- from the two --pmc passes of tools/r04_measure.sh (round 3: r03_measure.sh) (`bench.py
 --workload W --steps K --warmup W0` with PP_BENCH_NO_COLD=1 PP_BENCH_PREWARM=0, so every per-step
 kernel runs exactly K + W0 times) and scaled by the calibration run of tools/ub_stream.hip (s_rows<8,4>
 moves exactly 37 B read + 32 B written per slot; MI355X_MICROARCH.md: FETCH_SIZE tallies 128-B requests
@@ -34,7 +34,7 @@ def main(out_dir, workload, particles, nsteps, dest, pmc_dir, bytes_per_particle
     out = {"workload": workload, "particles": particles, "remainder": "last", "steps_profiled": nsteps,
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python3 bench.py --workload %s "
                      "--steps 10 --warmup 3 --no-cpu-baseline` (PP_BENCH_NO_COLD=1 PP_BENCH_PREWARM=0), "
-                     "tools/r03_measure.sh; every kernel that runs once per step or more, summed per step; scaled by "
+                     "tools/r04_measure.sh (round 3: r03_measure.sh); every kernel that runs once per step or more, summed per step; scaled by "
                      "the calibration run of tools/ub_stream.hip s_rows<8,4>: FETCH_SIZE[KiB] x 1024 x %.4f, "
                      "WRITE_SIZE[KiB] x 1024 x %.4f" % (workload, rf, wf),
            "kernels": {}}
