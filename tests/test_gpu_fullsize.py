@@ -207,6 +207,75 @@ def test_config1_restated_size_matches_oracle(pp, ppo, capi):
         ppo.set_threads(1)
 
 
+def test_c2_intersection_mode_full_size(pp, ppo, capi):
+    """configs[1] in the reference's intersection mode (search_mesh with requireIntersection,
+    adjacency.tpp:284-361, through the packed-record walk k_search_mt3): 100 800 tets, 10 M particles.
+    Size-independent properties with an independent numpy evaluation: every moved particle's ray ends on an
+    EXPOSED face of the element it reports (the rays are followed to the boundary), the intersection point lies
+    in that face's plane, inside the face, on the ray beyond the origin, and in the reported element; then a
+    50 000-particle sample is searched by the oracle from the same positions and must agree bit for bit
+    (parents, exit faces, intersection points)."""
+    w = bench.build_workload(pp, capi, "c2mt", 10_000_000, 0, 1, 0.5)
+    s = pp.synth
+    mesh, ps = w["mesh"], w["ps"]
+    cap = ps.capacity()
+    capi.toroidal_push(ps, mesh, s.XGC_H, s.XGC_K, s.XGC_D, 0.5)
+    r = capi.search_mesh(mesh, ps, require_intersection=True, looplimit=2000)
+    assert r["found"] and r["not_in_elem"] == 0
+    se, mk = ps.slot_info()
+    live = np.flatnonzero(mk)
+    assert len(live) == 10_000_000
+    ids, faces = r["elem_ids"].to_host()[:cap], r["inter_faces"].to_host()[:cap]
+    pts = r["inter_points"].to_host()[:3 * cap].reshape(cap, 3)
+    steps = capi.search_walk_steps()
+    assert steps > 20 * len(live)  # tens of elements per ray
+    assert (faces[~mk.astype(bool)] == -1).all() and not pts[~mk.astype(bool)].any()
+    assert (ids[live] >= 0).all() and (faces[live] >= 0).all()  # every ray of this push reaches the wall
+    exposed = mesh.array(capi.MESH_SIDE_EXPOSED)
+    assert exposed[faces[live]].all()
+    e2s = mesh.array(capi.MESH_ELEM2SIDES).reshape(-1, 4)
+    rng = np.random.default_rng(11)
+    samp = rng.choice(live, size=200_000, replace=False)
+    assert (e2s[ids[samp]] == faces[samp][:, None]).any(axis=1).all()  # the face belongs to the reported element
+    s2v = mesh.array(capi.MESH_SIDE2VERTS).reshape(-1, 3)
+    coords = np.asarray(w["coords"]).reshape(-1, 3)
+    tri = coords[s2v[faces[samp]]]  # n,3,3
+    x0 = ps.member(0)[:, :cap][:, samp].T
+    x1 = ps.member(1)[:, :cap][:, samp].T
+    n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    scale = np.abs(coords).max()
+    assert np.abs(np.einsum("ij,ij->i", pts[samp] - tri[:, 0], n)).max() < 1e-9 * scale        # in the plane
+    d = x1 - x0
+    t = np.einsum("ij,ij->i", pts[samp] - x0, d) / np.einsum("ij,ij->i", d, d)
+    assert t.min() > 0                                                                           # ahead of the origin
+    assert np.abs(pts[samp] - (x0 + t[:, None] * d)).max() < 1e-9 * scale                        # on the ray
+    A = np.stack([tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]], axis=2)                         # n,3,2
+    uv = np.stack([np.linalg.lstsq(A[i], pts[samp][i] - tri[i, 0], rcond=None)[0] for i in range(0, len(samp), 40)])
+    assert uv.min() > -1e-6 and (uv.sum(1) < 1 + 1e-6).all()                                     # inside the face
+    lam = _tet_bcc(w["coords"], w["e2v"], ids[samp], pts[samp])
+    assert lam.min() > -1e-6                                                                     # in the element
+    # ---- oracle on a sample of the same particles (same origins, same pushed targets)
+    sub = np.sort(rng.choice(live, size=50_000, replace=False))
+    elem = se[sub].astype(np.int32)
+    order = np.argsort(elem, kind="stable")
+    sub, elem = sub[order], elem[order]
+    info = [ps.member(m)[:, :cap][:, sub] for m in range(5)]
+    mo = ppo.Mesh(3, w["coords"], w["e2v"], w["cls"])
+    po = ppo.PS.scs(ppo.PARTICLE_XGCM, w["ne"], np.bincount(elem, minlength=w["ne"]).astype(np.int32), C_max=64,
+                    particle_elements=elem, particle_info=info)
+    ro = ppo.search_mesh(mo, po, require_intersection=True, looplimit=2000)
+    so, mko = po.slot_info()
+    lo = np.flatnonzero(mko)
+    pid_o = po.member(2)[0, :po.capacity()][lo]
+    pid_g = ps.member(2)[0, :cap]
+    slot_of = {int(p): int(sl) for p, sl in zip(pid_g[sub], sub)}
+    gs = np.array([slot_of[int(p)] for p in pid_o])
+    assert np.array_equal(ro["elem_ids"][lo], ids[gs])
+    assert np.array_equal(ro["inter_faces"][lo], faces[gs])
+    assert np.array_equal(ro["inter_points"].reshape(-1, 3)[lo], pts[gs])
+
+
 def test_tet_c3_full_size_properties(pp, capi):
     """configs[2] on tets (the bench's default workload): 100 800 tets, 10 M particles, fused push + walk,
     rebuild with the commit and both gyroScatter calls in one entry point.  Size-independent checks:
