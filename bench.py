@@ -495,6 +495,8 @@ def clock_prewarm(capi, seconds):
 
 
 def _time_steps(capi, st, warm, k):
+    import gc
+    gc.collect()  # (finalisers of set-up temporaries -- hipFree -- now, not inside the timed steps)
     clock_prewarm(capi, float(os.environ.get("PP_BENCH_PREWARM", "0.3")))  # (the host just built a population)
     for _ in range(warm):
         st.step()
@@ -859,6 +861,15 @@ def main():
             WATCHDOG.limit = wd_limit
         st = Stepper(pp, capi, w, a.workload, a.deg)
 
+    # The host must not stall inside a timed region: Python's cyclic collector, when it happens to run there, also
+    # runs the finalisers of every device array the set-up left behind (pp_free -> hipFree: a device
+    # synchronisation and an unmap each) -- a one-off 35-55 ms pause among the first steps after a population was
+    # built (seen as `cold_clocks` 3.49 ms per step in BENCH_r03, as 17 against 12 ms in c2mt runs; cold step traces
+    # in DESIGN.md "Round 4").  Collect now, keep the collector off while steps are timed.
+    import gc
+    gc.collect()
+    gc.disable()
+
     def barrier():
         beat("barrier")
         capi.sync()
@@ -914,6 +925,7 @@ def main():
     kms_main, sms_main = st.kernel_avg_ms(), (st.step_avg_ms() if hasattr(st, "step_avg_ms") else None)
     nlive = w["ps"].nPtcls()
     total_particles = nlive
+    gc.enable()
     # ---- everything below is EXTRA: measured after the headline, each piece guarded -- an exception, an
     # out-of-memory or a time budget that runs out in an extra must never cost the line its headline
     # (round-3 advisor finding); a failed piece reports {"error": ...} in its place.

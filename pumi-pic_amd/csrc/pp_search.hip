@@ -1585,12 +1585,15 @@ __global__ void __launch_bounds__(256, 4)
 //    first steps are therefore batched: fresh lanes wait until `start_batch` of them (or nobody walking) are
 //    there, then the wave runs one START round for them; all other rounds are 3-face WALK rounds.  Per round
 //    one cooperative fetch and one pass over the faces with (nearly) all participating lanes busy.
-__device__ __forceinline__ double lds_rec_double(const double2* mine, int sw, int d) {
-  return ((const double*)(mine + ((d >> 1) ^ sw)))[d & 1];
-}
+// The staged record of a lane is its 128 bytes with the 16-B pieces XOR-swizzled (piece q at slot q ^ (lane & 7),
+// see coop_issue): byte b of the record lives at b ^ ((lane & 7) << 4) -- the swizzle touches bits 4-6 only, the
+// half-piece bit 3 stays.  A vertex is three doubles at bytes 24 v, 24 v + 8, 24 v + 16: one multiply, two adds,
+// three xor-adds per vertex (the generic piece / half arithmetic cost ~7 integer instructions per double).
 __device__ __forceinline__ V3 lds_rec_vertex(const double2* mine, int sw, int v) {
-  const int d = 3 * v;
-  return V3{lds_rec_double(mine, sw, d), lds_rec_double(mine, sw, d + 1), lds_rec_double(mine, sw, d + 2)};
+  const char* m = (const char*)mine;
+  const unsigned swz = (unsigned)sw << 4, b = (unsigned)v * 24u;
+  return V3{*(const double*)(m + (b ^ swz)), *(const double*)(m + ((b + 8u) ^ swz)),
+            *(const double*)(m + ((b + 16u) ^ swz))};
 }
 struct MtFace {  // running state of search_findExitFace_intersect_3d over the faces of one element
   int lastExit, bestFace;
