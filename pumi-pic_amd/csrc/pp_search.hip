@@ -1618,25 +1618,25 @@ __device__ __forceinline__ void mt_face(const double2* mine, int sw, unsigned c,
   const V3 qvec = cross(tvec, edge1);
   const double v = invdet * dot(dir, qvec);
   const double t = invdet * dot(edge2, qvec);
-  const double m1 = PPG_KMIN(fabs(u), fabs(1 - u));
-  const double m2 = PPG_KMIN(fabs(v), fabs(1 - v));
-  const double m3 = PPG_KMIN(fabs(u + v), fabs(1 - u - v));
+  // Kokkos::min(a, b) = (b < a) ? b : a.  In each of the three pairs below the operands are NaN together or not
+  // at all (|x| and |1 - x|; |u + v| and |1 - u - v|: inf - inf on one side is inf - inf on the other), and for
+  // non-NaN operands the selection equals fmin's -- one v_min_f64 instead of compare + two selects.  The two
+  // Kokkos::max stay literal: their operands can be NaN one at a time (u NaN with v finite when dproj == 0).
+  const double m1 = __builtin_fmin(fabs(u), fabs(1 - u));
+  const double m2 = __builtin_fmin(fabs(v), fabs(1 - v));
+  const double m3 = __builtin_fmin(fabs(u + v), fabs(1 - u - v));
   const double mm = PPG_KMAX(m1, m2);
   const double closeness = PPG_KMAX(mm, m3);
   const bool success = (dproj >= tol) && (t >= -tol) && (u >= -tol) && (v >= -tol) && (u + v <= 1.0 + 2 * tol);
   // (the reference stores xpoint = orig + dir * t at both places; the point is a function of t alone, so t is
   // kept and the point formed once per element, from the last t written -- the same value)
-  if (success) {
-    F.lastExit = fi;
-    F.t_ip = t;
-    F.upd = true;
-  }
-  if (dproj > -tol && (F.quality < 0 || closeness < F.quality) && F.lastExit == -1) {
-    F.quality = closeness;
-    F.bestFace = fi;
-    F.t_ip = t;
-    F.upd = true;
-  }
+  F.lastExit = success ? fi : F.lastExit;
+  F.t_ip = success ? t : F.t_ip;
+  const bool cand = dproj > -tol && (F.quality < 0 || closeness < F.quality) && F.lastExit == -1;
+  F.quality = cand ? closeness : F.quality;
+  F.bestFace = cand ? fi : F.bestFace;
+  F.t_ip = cand ? t : F.t_ip;
+  F.upd = F.upd || success || cand;
 }
 __global__ void __launch_bounds__(256, 2)
     k_search_mt3(int capacity, int per_lane, int start_batch, const unsigned char* __restrict__ mask,

@@ -298,17 +298,34 @@ class ParticleStructure {
   // receiver's rebuild as new particles; one rank -> plain rebuild (:20-25)
   virtual void migrate(kkLidView new_element, kkLidView new_process, Distributor dist = Distributor(),
                        kkLidView new_particle_elements = kkLidView(), MTVs new_particle_info = NULL) {
-    if (!dist.isWorld() && capacity() > 0) {  // every leaving particle goes to a rank of the subset
+    if (!dist.isWorld()) {  // every leaving particle goes to a rank of the subset
+      // The check is COLLECTIVE: a rank that found a violation and left alone would leave its peers waiting
+      // in the exchange (round-3 advisor) -- every rank contributes its verdict to one host all-gather and
+      // all of them stop together, each naming the ranks at fault.
       const int world = pp_comm_size(dist.comm()), self = pp_comm_rank(dist.comm());
-      std::vector<int> sends((size_t)world, 0);
-      pp_check(pp_ps_migrate_count(h_, new_element.data(), new_process.data(), self, world, sends.data()),
-               "ParticleStructure::migrate (send counts)");
+      int bad = 0;
+      if (capacity() > 0) {
+        std::vector<int> sends((size_t)world, 0);
+        pp_check(pp_ps_migrate_count(h_, new_element.data(), new_process.data(), self, world, sends.data()),
+                 "ParticleStructure::migrate (send counts)");
+        for (int r = 0; r < world; ++r)
+          if (r != self && sends[(size_t)r] > 0 && dist.index(r) < 0) {
+            fprintf(stderr, "[ERROR] ParticleStructure::migrate: %d particle(s) bound for rank %d, which the "
+                            "Distributor does not list\n", sends[(size_t)r], r);
+            bad = 1;
+          }
+      }
+      std::vector<int> verdicts((size_t)world, 0);
+      pp_check(pp_comm_allgather_host(dist.comm(), &bad, verdicts.data(), (int)sizeof(int)),
+               "ParticleStructure::migrate (Distributor verdicts)");
       for (int r = 0; r < world; ++r)
-        if (r != self && sends[(size_t)r] > 0 && dist.index(r) < 0) {
-          fprintf(stderr, "[ERROR] ParticleStructure::migrate: %d particle(s) bound for rank %d, which the "
-                          "Distributor does not list\n", sends[(size_t)r], r);
-          pp_check(PP_EINVAL, "ParticleStructure::migrate (Distributor rank subset)");
+        if (verdicts[(size_t)r]) {
+          if (r != self)
+            fprintf(stderr, "[ERROR] ParticleStructure::migrate: rank %d has particles for a rank its Distributor "
+                            "does not list; stopping with it\n", r);
+          bad = 1;
         }
+      if (bad) pp_check(PP_EINVAL, "ParticleStructure::migrate (Distributor rank subset)");
     }
     pp_check(pp_ps_migrate_scatter(h_, -1, -1, new_element.data(), new_process.data(), dist.comm(),
                                    (int)new_particle_elements.size(), new_particle_elements.data(),

@@ -520,7 +520,8 @@ def test_cpp_driver_distributor_rank_subset_is_enforced(synth, capi, tmp_path):
     """support/psDistributor.hpp:10-138, the rank-subset form: the driver lists itself + the buffered ranks of
     its part (the two-rank test above runs with that list); with PP_DIST_SELF_ONLY=1 it lists nobody else, and
     the first migration that has a particle for the other rank is refused by ParticleStructure::migrate (the
-    reference's Distributor::index() is undefined for a rank that is not listed)."""
+    reference's Distributor::index() is undefined for a rank that is not listed) -- on EVERY rank: the ranks
+    exchange their verdicts before anyone leaves, so no peer is left waiting in the exchange."""
     import subprocess
     drv = os.path.join(ROOT, "pumi-pic_amd", "drivers")
     subprocess.check_call(["make", "-C", drv, "-s"])
@@ -535,15 +536,11 @@ def test_cpp_driver_distributor_rank_subset_is_enforced(synth, capi, tmp_path):
                    PP_COMM_TIMEOUT="20", PP_DIST_SELF_ONLY="1")
         procs.append(subprocess.Popen([os.path.join(drv, "pseudoXGCm"), mesh_file, "20000", "6", "10", "2.0", "1"],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = []
-    for p in procs:
-        try:
-            outs.append(p.communicate(timeout=120))
-        except subprocess.TimeoutExpired:   # the peer of a rank that stopped waits for it: end it
-            p.kill()
-            outs.append(p.communicate())
-    assert any(p.returncode not in (0, None) and "which the Distributor does not list" in se
-               for p, (so, se) in zip(procs, outs)), [se[-500:] for _, se in outs]
+    outs = [p.communicate(timeout=120) for p in procs]  # (no rank is left waiting: the verdict is collective)
+    assert any("which the Distributor does not list" in se for _, se in outs), [se[-500:] for _, se in outs]
+    for p, (so, se) in zip(procs, outs):  # EVERY rank stops, with a non-zero exit code, on its own
+        assert p.returncode not in (0, None), se[-500:]
+        assert "Distributor rank subset" in se, se[-500:]
 
 
 @pytest.mark.parametrize("launcher", ["torchrun", "self"])
