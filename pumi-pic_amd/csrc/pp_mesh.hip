@@ -171,6 +171,9 @@ int pack_and_upload(pp_mesh& m) {
         }
       }
       r.class_id = m.class_id[e];
+      for (int i = 0; i < 3; ++i)  // (the packed intersection walk names the entry edge by the neighbour behind it)
+        for (int j = i + 1; j < 3; ++j)
+          if (r.nbr[i] >= 0 && r.nbr[i] == r.nbr[j]) m.mt_packed_ok = false;
     }
     PP_HIP_CHECK(m.d_records.reserve(std::max<size_t>(rec.size() * sizeof(pp_tri_rec), 64)));
     if (ne) PP_HIP_CHECK(hipMemcpy(m.d_records.p, rec.data(), rec.size() * sizeof(pp_tri_rec),

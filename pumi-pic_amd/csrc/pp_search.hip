@@ -240,6 +240,30 @@ __device__ __forceinline__ int exit_by_intersection(const MeshArrays& m, int sea
   return lastExit;
 }
 
+// search_findExitFace_intersect_2d (tpp:287-311) on the packed 64-B triangle record.  Edge ei of a triangle is
+// {v_ei, v_ei+1}; the reference hands line_edge_2d the STORED edge and isFaceFlipped (utils.hpp:495-499), which
+// together always select (v_ei, v_ei+1) -- flip is true exactly when the side is stored the other way round
+// and then swaps it back (line_edge_2d: vtx1 = flip, vtx2 = !flip) -- so the record's own vertices in template
+// order with flip = 0 are the reference's operands.  The edge the path came in through (edge_id == prevExit) is
+// the one with the previous element behind it (pp_mesh::mt_packed_ok).  Returns the local edge index or -1.
+__device__ __forceinline__ int exit_by_intersection_packed2(const pp_tri_rec* __restrict__ recs, int elem, int prev,
+                                                            V3 orig, V3 dest, double tol, double ip[3], int nbr[3]) {
+  V2 fc[3];
+  load_tri(recs, elem, fc, nbr);
+  int lastExit = -1;
+  V2 xpts{0, 0};
+  for (int ei = 0; ei < 3; ++ei) {
+    if (prev >= 0 && nbr[ei] == prev) continue;
+    const V2 edge[2] = {fc[ei], fc[(ei + 1) % 3]};
+    if (line_edge_2d(edge, V2{orig.x, orig.y}, V2{dest.x, dest.y}, xpts, tol, 0)) {
+      lastExit = ei;
+      ip[0] = xpts.x;
+      ip[1] = xpts.y;
+    }
+  }
+  return lastExit;
+}
+
 template <int DIM, bool MT>
 __global__ void k_search_tpp(int capacity, const unsigned char* __restrict__ mask,
                              const int* __restrict__ slot_elem, const void* __restrict__ recs,
@@ -247,7 +271,7 @@ __global__ void k_search_tpp(int capacity, const unsigned char* __restrict__ mas
                              const double* __restrict__ xt, long long stride,
                              int* __restrict__ elem_ids, int seeded, double tol,
                              int* __restrict__ inter_faces, double* __restrict__ inter_points,
-                             int looplimit, Counters* cnt) {
+                             int looplimit, Counters* cnt, int packed2 = 0) {
   const int pid = blockIdx.x * blockDim.x + threadIdx.x;
   if (pid >= capacity) return;
   const int e = slot_elem[pid];
@@ -290,7 +314,30 @@ __global__ void k_search_tpp(int capacity, const unsigned char* __restrict__ mas
       int lastExit = -1, loops = 0, xface = -1;
       double ip[3] = {0, 0, 0};
       const int cap = looplimit ? looplimit : kHardLoopCap;
-      while (true) {
+      int prev = -1;
+      while (DIM == 2 && packed2) {  // triangles: the walk on the packed records (one 64-B record per element)
+        int nbr[3];
+        const int le = exit_by_intersection_packed2((const pp_tri_rec*)recs, elem, prev, orig, dest, tol, ip, nbr);
+        done = (le == -1);
+        if (!done) {  // check_model_intersection tpp:372-385 (requireIntersection == true)
+          const int nx = le == 0 ? nbr[0] : le == 1 ? nbr[1] : nbr[2];
+          done = nx == -1;
+          if (done) {
+            xface = m.elem2sides[(size_t)elem * 3 + le];
+          } else {  // set_new_element tpp:397-414
+            prev = elem;
+            elem = nx;
+          }
+        }
+        ++loops;
+        if (done) break;
+        if (loops >= cap) {
+          elem = -1;
+          atomicAdd(&cnt->not_found, 1);
+          break;
+        }
+      }
+      while (!(DIM == 2 && packed2)) {
         lastExit = exit_by_intersection<DIM>(m, elem, orig, dest, tol, lastExit, ip);
         done = (lastExit == -1);
         if (!done) {  // check_model_intersection tpp:372-385 (requireIntersection == true)
@@ -1924,15 +1971,15 @@ int pp_search_mesh(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_pi
   ps->capacity, ps->d_mask.as<unsigned char>(), pp::slot_elem(ps), mesh->d_records.p, m,  \
       PP_MEMBER(ps, m_x, double), PP_MEMBER(ps, m_xtgt, double), ps->stride, elem_ids_dev,       \
       elem_ids_seeded, mesh->tol, inter_faces_dev, inter_points_dev, looplimit, g_cnt.get()
+  // intersection mode: the walk on packed records (tets: k_search_mt3 with lane refill; triangles: the packed
+  // branch of k_search_tpp); PP_MT_PACKED=0 keeps the form on the Omega_h-style arrays (A/B knob)
+  static const bool mt_packed_off = getenv("PP_MT_PACKED") != nullptr && atoi(getenv("PP_MT_PACKED")) == 0;
   if (mesh->dim == 2) {
     if (requireIntersection)
-      k_search_tpp<2, true><<<grid, kBlock, 0, st>>>(PP_TPP_ARGS);
+      k_search_tpp<2, true><<<grid, kBlock, 0, st>>>(PP_TPP_ARGS, (mesh->mt_packed_ok && !mt_packed_off) ? 1 : 0);
     else
       k_search_tpp<2, false><<<grid, kBlock, 0, st>>>(PP_TPP_ARGS);
   } else {
-    // intersection mode on tets: the walk on packed records with lane refill (k_search_mt3);
-    // PP_MT_PACKED=0 keeps the one-thread-per-slot form on the Omega_h-style arrays (A/B knob)
-    static const bool mt_packed_off = getenv("PP_MT_PACKED") != nullptr && atoi(getenv("PP_MT_PACKED")) == 0;
     if (requireIntersection && mesh->mt_packed_ok && !mt_packed_off) {
       static const int per_lane_env = getenv("PP_MT_PER_LANE") ? atoi(getenv("PP_MT_PER_LANE")) : 0;
       static const int start_batch_env = getenv("PP_MT_START_BATCH") ? atoi(getenv("PP_MT_START_BATCH")) : 0;
