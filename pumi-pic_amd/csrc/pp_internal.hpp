@@ -230,6 +230,13 @@ struct pp_ps {
   int lazy_rec = 0;
   int lazy_x = -1, lazy_xt = -1;  // commit members of the rebuild that left the records
   pp::DevBuf s_aos_live;
+  // Position of a slot's record in s_aos_live.  rec_rm: ROW-MAJOR inside a chunk -- the record of (row r, column p)
+  // of chunk c is number chunk_start[c] + r * chunk_width[c] + p, so the particles of a row (consecutive ranks of
+  // one element) are consecutive 64-B records and the re-layout's scattered stores leave as runs instead of
+  // single records (round 4); else the record index is the slot.  d_erec0 / s_erec0: first record of every
+  // element's row in the current / the new layout.
+  bool rec_rm = false;
+  pp::DevBuf d_erec0, s_erec0;
   pp::DevBuf s_rs, s_holes;  // in-place rebuild: per-element counters, per-row hole lists
   // pinned landing zone of the rebuild's totals (host-mapped) + its event, and the stamp the host polls for
   void* h_totals = nullptr;

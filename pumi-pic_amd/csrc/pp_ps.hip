@@ -50,7 +50,7 @@ __global__ void k_init_slots_tiled4(const int* __restrict__ ntiles_dev, int C, i
                                     const int* __restrict__ ppe, int ne, int* __restrict__ slot_elem,
                                     int* __restrict__ row_cursor, int* __restrict__ elem_slot0,
                                     unsigned char* __restrict__ new_mask, const int* __restrict__ go,
-                                    int* __restrict__ zero_next, int zero_words) {
+                                    int* __restrict__ zero_next, int zero_words, int* __restrict__ elem_rec0) {
   if (!*go) return;
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   for (long long i = g; i < zero_words; i += (long long)gridDim.x * blockDim.x) zero_next[i] = 0;
@@ -68,6 +68,13 @@ __global__ void k_init_slots_tiled4(const int* __restrict__ ntiles_dev, int C, i
     if (e.y < ne) elem_slot0[e.y] = start + 1;
     if (e.z < ne) elem_slot0[e.z] = start + 2;
     if (e.w < ne) elem_slot0[e.w] = start + 3;
+    if (elem_rec0) {  // first record of the row when the staging records are row-major inside the chunk (pp_ps::rec_rm)
+      const int w = chunk_width[c], q0 = chunk_start[c] + r * w;
+      if (e.x < ne) elem_rec0[e.x] = q0;
+      if (e.y < ne) elem_rec0[e.y] = q0 + w;
+      if (e.z < ne) elem_rec0[e.z] = q0 + 2 * w;
+      if (e.w < ne) elem_rec0[e.w] = q0 + 3 * w;
+    }
   }
   for (int p = p0; p < pend; ++p) {
     if (slot_elem) *(int4*)(slot_elem + start + p * C) = e;
@@ -556,7 +563,7 @@ __global__ void k_init_slots_tiled(const int* __restrict__ ntiles_dev, int C, in
                                    int* __restrict__ slot_elem, int* __restrict__ row_cursor,
                                    int* __restrict__ elem_slot0, unsigned char* __restrict__ new_mask,
                                    const int* __restrict__ go, int* __restrict__ zero_next = nullptr,
-                                   int zero_words = 0) {
+                                   int zero_words = 0, int* __restrict__ elem_rec0 = nullptr) {
   if (!*go) return;
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   // the histogram + totals block of the NEXT rebuild (today's d_elem_count, free once this tail runs) is
@@ -574,6 +581,7 @@ __global__ void k_init_slots_tiled(const int* __restrict__ ntiles_dev, int C, in
   if (p0 == 0) {
     row_cursor[c * C + r] = start;
     if (e < ne) elem_slot0[e] = start;  // first slot of the element's new row (pack: + rank*C)
+    if (e < ne && elem_rec0) elem_rec0[e] = chunk_start[c] + r * chunk_width[c];
   }
   for (int p = p0; p < pend; ++p) {
     if (slot_elem) slot_elem[start + p * C] = e;
@@ -642,6 +650,8 @@ __global__ void k_add_rec(int n_new, const int* __restrict__ new_elems, const in
   if (!*go) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_new) return;
+  // (elem_slot0 / C_new: first slot of the row and the slot distance of consecutive ranks -- or, with row-major
+  // records, the row's first record and 1)
   const long long idx = elem_slot0[new_elems[i]] + (long long)rank_new[i] * C_new;
   const unsigned long long x0 = x[i], x1 = x[(size_t)n_new + i], x2 = x[2 * (size_t)n_new + i];
   uint4* r = aos + idx * 4;
@@ -774,22 +784,78 @@ __global__ void k_move_pack(int capacity, const int* __restrict__ new_idx, RankT
     }
   }
 }
+// The same pass for records that stay the particle data (pp_ps::rec_rm): destination = first RECORD of the new
+// row + rank, i.e. the particles of a row are consecutive records.  A block holds 4 columns x 64 rows; the
+// stayers of a row in those columns carry consecutive ranks (k_count_tiled hands a run its ranks in column
+// order), so the transpose goes through LDS at BLOCK level and the block's records leave row by row: up to
+// 256 contiguous bytes per row instead of four 64-byte stores 4 KB apart (c3: 294 -> 224 us for the pass).
+template <int NQ>
+__global__ void k_move_pack_rm(int capacity, const int* __restrict__ new_idx, RankToSlot rs,
+                               uint4* __restrict__ aos, WordTable t, const int* __restrict__ go) {
+  if (go && !*go) return;
+  __shared__ uint4 st[4][64][NQ + 1];
+  __shared__ int sd[4][64];
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int rk = (pid < capacity) ? new_idx[pid] : -1;
+  int idx = -1;
+  if (rk >= 0) {
+    idx = rs.elem_slot0[rs.new_element[pid]] + rk * rs.step;
+    unsigned v[NQ * 4];
+#pragma unroll
+    for (int i = 0; i < NQ * 4; ++i) v[i] = 0u;
+#pragma unroll
+    for (int i = 0; i < NQ * 2; ++i)
+      if (i < t.n8) {
+        const unsigned long long d =
+            __builtin_nontemporal_load((const unsigned long long*)(t.src8[i] + (long long)pid * 8));
+        v[2 * i] = (unsigned)d;
+        v[2 * i + 1] = (unsigned)(d >> 32);
+      }
+#pragma unroll
+    for (int j = 0; j < (NQ * 4 < kMax4 ? NQ * 4 : kMax4); ++j)
+      if (j < t.n4)
+        v[NQ * 4 - 1 - j] = __builtin_nontemporal_load((const unsigned*)(t.src4[j] + (long long)pid * 4));
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) st[w][l][q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+  }
+  sd[w][l] = idx;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int item = j * 256 + threadIdx.x, rec = item / NQ, part = item % NQ;
+    const int row = rec >> 2, col = rec & 3;  // the (up to) four records of one row are adjacent items
+    const int d = sd[col][row];
+    if (d >= 0) {
+      typedef unsigned v4u __attribute__((ext_vector_type(4)));
+      const uint4 x = st[col][row][part];
+      v4u y;
+      y.x = x.x;
+      y.y = x.y;
+      y.z = x.z;
+      y.w = x.w;
+      __builtin_nontemporal_store(y, (v4u*)(aos + (long long)d * NQ + part));
+    }
+  }
+}
 template <int NQ>
 __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
                               const int* __restrict__ tiles, const int* __restrict__ chunk_start,
                               const int* __restrict__ chunk_width,
                               const unsigned char* __restrict__ new_mask,
-                              const uint4* __restrict__ aos, WordTable t, const int* __restrict__ go) {
+                              const uint4* __restrict__ aos, WordTable t, const int* __restrict__ go,
+                              int rec_rm = 0) {
   if (!*go) return;
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int tile = (int)(g / C), r = (int)(g - (long long)tile * C);
   if (tile >= *ntiles_dev) return;
   const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
   const int start = chunk_start[c] + r, pend = min(p0 + TP, chunk_width[c]);
+  const long long rbase = (long long)chunk_start[c] + (long long)r * chunk_width[c];  // row-major records (pp_ps::rec_rm)
   for (int p = p0; p < pend; ++p) {
     const int slot = start + p * C;
     if (!new_mask[slot]) continue;
-    const uint4* sp = aos + (long long)slot * NQ;
+    const uint4* sp = aos + (rec_rm ? rbase + p : (long long)slot) * NQ;
     unsigned w[NQ * 4];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -1946,9 +2012,13 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   nrows = L.nrows;
   const int* go = &tot->go;
   int NQ = 0;
-  bool lazy_zero = false, defer_unpack = false;
+  bool lazy_zero = false, defer_unpack = false, use_rm = false;
   // today's per-element counts are not read by a re-layout that commits: its tail clears them for the next one
   static const bool lazy_slot_elem = getenv("PP_EAGER_SLOT_ELEM") == nullptr;  // (pp::slot_elem)
+  // staging records row-major inside a chunk (pp_ps::rec_rm; PP_NO_RM_RECORDS=1: slot order, the A/B knob)
+  static const bool no_rm = getenv("PP_NO_RM_RECORDS") != nullptr;
+  const bool want_rm = !no_rm && have_old && old_grid > 0;
+  if (want_rm) PP_HIP_CHECK(ps->s_erec0.reserve(sizeof(int) * (size_t)std::max(ne, 1)));
   static const bool no_prezero = getenv("PP_NO_PREZERO") != nullptr;
   const bool prezero = !no_prezero && ps->d_elem_count.p && ps->d_elem_count.p != ps->s_ppe.p &&
                        ps->d_elem_count.bytes >= tot_off + sizeof(Totals);
@@ -1965,7 +2035,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_r2e2.as<int>(), ppe, ne,               \
       lazy_slot_elem ? nullptr : ps->s_slot2.as<int>(), ps->s_rowstart.as<int>(), ps->s_eslot0.as<int>(),        \
       ps->s_mask2.as<unsigned char>(), go, prezero ? ps->d_elem_count.as<int>() : nullptr,                         \
-      prezero ? (int)((tot_off + sizeof(Totals)) / sizeof(int)) : 0
+      prezero ? (int)((tot_off + sizeof(Totals)) / sizeof(int)) : 0, want_rm ? ps->s_erec0.as<int>() : nullptr
     if (C_new % 4 == 0)
       k_init_slots_tiled4<<<grid_for((size_t)ntiles_max * (C_new / 4)), kBlock, 0, st>>>(PP_INIT_SLOTS_ARGS);
     else
@@ -2012,13 +2082,23 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       const unsigned new_grid = grid_for((size_t)ntiles_max * C_new);
 #define PP_UNPACK_ARGS                                                                                  \
   new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_mask2.as<unsigned char>(), aos, \
-      wt, go
+      wt, go, use_rm ? 1 : 0
 #define PP_STAGED(N)                                                                             \
   case N:                                                                                        \
-    k_move_pack<N><<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, rank, rs, aos, wt, go); \
+    if (use_rm)                                                                                  \
+      k_move_pack_rm<N><<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, rank, rs_rm, aos, wt, go); \
+    else                                                                                         \
+      k_move_pack<N><<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, rank, rs, aos, wt, go); \
     if (!defer_unpack) k_move_unpack<N><<<new_grid, kBlock, 0, st>>>(PP_UNPACK_ARGS);            \
     break;
       const RankToSlot rs{new_element, ps->s_eslot0.as<int>(), C_new};
+      // the staging records row-major inside a chunk: the particles of a row, which carry consecutive ranks,
+      // are consecutive records, and the pack's block-level transpose stores them as runs
+      const RankToSlot rs_rm{new_element, ps->s_erec0.as<int>(), 1};
+      // (only where the records stay the particle data -- the pseudoXGCm flows, where nine particles in ten keep
+      // their row: c3 -3.3 %, 2dc3 -3.6 %, c5 share -3.2 %.  ps_combo160 redistributes half of its particles to
+      // random elements: nothing to merge, and its second pass reads row-major records 2.5 % slower)
+      use_rm = want_rm && defer_unpack;
       switch (NQ) {
         PP_STAGED(1) PP_STAGED(2) PP_STAGED(3) PP_STAGED(4) PP_STAGED(6) PP_STAGED(8) PP_STAGED(10) PP_STAGED(12)
       }
@@ -2033,7 +2113,8 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     if (n_new > 0 && defer_unpack) {
       // (pseudoXGCm type, member commit_xt of the arrivals known to be zero: they join the records)
       k_add_rec<<<grid_for(n_new), kBlock, 0, st>>>(
-          n_new, new_elems, rank_new, ps->s_eslot0.as<int>(), C_new, (const unsigned long long*)new_info[commit_x],
+          n_new, new_elems, rank_new, use_rm ? ps->s_erec0.as<int>() : ps->s_eslot0.as<int>(), use_rm ? 1 : C_new,
+          (const unsigned long long*)new_info[commit_x],
           (const unsigned*)new_info[2], (const unsigned*)new_info[3], (const unsigned*)new_info[4],
           ps->s_aos.as<uint4>(), go);
     } else if (n_new > 0) {
@@ -2182,6 +2263,8 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     ps->lazy_rec = 1;
     ps->lazy_x = commit_x;
     ps->lazy_xt = commit_xt;
+    ps->rec_rm = use_rm;
+    if (use_rm) ps->d_erec0.swap(ps->s_erec0);
   }
   ps->d_offsets.swap(ps->s_offsets2);
   ps->d_slice_to_chunk.swap(ps->s_s2c2);
@@ -2391,7 +2474,8 @@ int ps_materialize(pp_ps* ps) {
       if (state == 2) wt.n4 = 0;  // (4-byte members were written by the push; 8-byte ones: only lazy_x has a target)
       k_move_unpack<4><<<grid_for((size_t)ps->ntiles_max * ps->C), kBlock, 0, pp::stream()>>>(
           ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(),
-          ps->d_chunk_width.as<int>(), ps->d_mask.as<unsigned char>(), ps->s_aos_live.as<uint4>(), wt, go_one);
+          ps->d_chunk_width.as<int>(), ps->d_mask.as<unsigned char>(), ps->s_aos_live.as<uint4>(), wt, go_one,
+          ps->rec_rm ? 1 : 0);
       PP_LAUNCH_CHECK();
     }
   }

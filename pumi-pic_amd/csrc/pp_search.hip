@@ -1003,13 +1003,15 @@ struct RecIn {
   unsigned* id_out;
   float* b_out;
   int zero_z;  // 2-D: x_tgt is logically zero (pp_ps::zero_pending) -- the push writes its third component too
+  int rm;      // records row-major inside a chunk (pp_ps::rec_rm): (row r, column p) of chunk c is record
+               // chunk_start[c] + r * chunk_width[c] + p; else the record index is the slot
 };
 template <int DIM = 3>
 __device__ __forceinline__ PState load_state_recin(int pid, const unsigned char* __restrict__ mask,
-                                                   const char* __restrict__ rec) {
+                                                   const char* __restrict__ rec, long long ri) {
   PState s;
   s.m = mask[pid];
-  const char* rp = rec + (long long)pid * 64;
+  const char* rp = rec + ri * 64;
   s.x = s.y = s.z = 0;
   if (DIM == 3) {  // (the 2-D push reads no position)
     const double2 q0 = *(const double2*)rp;
@@ -1103,10 +1105,10 @@ __global__ void __launch_bounds__(256, OCC)
   const bool valid = tile < *ntiles_dev;
   unsigned* const id_out = RECIN ? rin.id_out : nullptr;
   float* const b_out = RECIN ? rin.b_out : nullptr;
-  auto load = [&](int pid) {
+  auto load = [&](int pid, long long ri) {
     PState s;
     if constexpr (RECIN) {
-      s = load_state_recin<DIM>(pid, mask, rin.rec);
+      s = load_state_recin<DIM>(pid, mask, rin.rec, ri);
       if (seeded) s.elem = elem_ids[pid];
     } else {
       s = load_state<DIM, true>(pid, mask, pphi, pb, x, stride, elem_ids, seeded != 0);
@@ -1114,12 +1116,18 @@ __global__ void __launch_bounds__(256, OCC)
     return s;
   };
   int start = 0, p0 = 0, pend = 0, e = 0;
+  long long rb = 0, rs = 1;  // record of column p: rb + p * rs (row-major records: the row's first record, 1)
   if (valid) {
     const int c = tiles[2 * tile];
     p0 = tiles[2 * tile + 1];
     start = chunk_start[c] + r;
-    pend = min(p0 + TP, chunk_width[c]);
+    const int cw = chunk_width[c];
+    pend = min(p0 + TP, cw);
     e = r2e[c * C + r];
+    if (RECIN && rin.rm)
+      rb = (long long)chunk_start[c] + (long long)r * cw;
+    else
+      rb = start, rs = C;
   }
   const ppm::ClassTerm ct = ppm::class_term((valid && e < nelems) ? class_id[e] : 1, deg, DIM == 3);
   RecCache<DIM> cache;
@@ -1141,6 +1149,7 @@ __global__ void __launch_bounds__(256, OCC)
       const int src = have ? __builtin_ctzll(m) : 0;
       const int t_start = __shfl(start, src), t_p0 = __shfl(p0, src), t_pend = __shfl(pend, src);
       const int t_e = __shfl(e, src);
+      const long long t_rb = __shfl(rb, src), t_rs = __shfl(rs, src);
       ppm::ClassTerm tct;
       tct.dphi = __shfl(ct.dphi, src);
       tct.st = __shfl(ct.st, src);
@@ -1148,7 +1157,7 @@ __global__ void __launch_bounds__(256, OCC)
       const int p = t_p0 + col;
       if (have && p < t_pend) {
         const int pid = t_start + p * C;
-        const PState s = load(pid);
+        const PState s = load(pid, t_rb + p * t_rs);
         rows_particle<DIM>(s, pid, t_e, tct, cache, recs, nelems, xt, stride, pphi, h, k, d, tol,
                            unmoved_sq, elem_ids, seeded, looplimit, cnt, id_out, b_out, RECIN ? rin.zero_z : 0);
       }
@@ -1156,12 +1165,12 @@ __global__ void __launch_bounds__(256, OCC)
     }
   }
   if (!valid) return;
-  PState cur = load(start + p0 * C);
+  PState cur = load(start + p0 * C, rb + p0 * rs);
   for (int p = p0; p < pend; ++p) {
     const int pid = start + p * C;
     const PState s = cur;
     if (p + 1 < pend)  // prefetch the next particle of this row before the dependent walk
-      cur = load(pid + C);
+      cur = load(pid + C, rb + (p + 1) * rs);
     rows_particle<DIM>(s, pid, e, ct, cache, recs, nelems, xt, stride, pphi, h, k, d, tol,
                        unmoved_sq, elem_ids, seeded, looplimit, cnt, id_out, b_out, RECIN ? rin.zero_z : 0);
   }
@@ -1460,12 +1469,16 @@ __global__ void __launch_bounds__(256, OCC)
   const int r = (int)(g - (long long)tile * C);
   const bool valid = tile < *ntiles_dev;
   int start = 0, p0 = 0, pend = 0, e = 0;
+  int rbase = 0;  // RECIN: record of column p = rbase + p * rstride (row-major records: first record of the row, 1)
+  const int rstride = (RECIN && rin.rm) ? 1 : C;
   if (valid) {
     const int c = tiles[2 * tile];
     p0 = tiles[2 * tile + 1];
     start = chunk_start[c] + r;
-    pend = min(p0 + TP, chunk_width[c]);
+    const int cw = chunk_width[c];
+    pend = min(p0 + TP, cw);
     e = r2e[c * C + r];
+    rbase = (RECIN && rin.rm) ? chunk_start[c] + r * cw : start;
   }
   const ppm::ClassTerm ct = ppm::class_term((valid && e < nelems) ? class_id[e] : 1, deg, DIM == 3);
   const bool read_ids = seeded != 0;  // (2-D without seeds: every seed is -1, the row's element)
@@ -1509,6 +1522,7 @@ __global__ void __launch_bounds__(256, OCC)
       const int src = have ? __builtin_ctzll(m) : 0;
       const int t_start = __shfl(start, src), t_p0 = __shfl(p0, src), t_pend = __shfl(pend, src);
       const int t_e = __shfl(e, src);
+      const int t_rbase = RECIN ? __shfl(rbase, src) : 0;
       ppm::ClassTerm tct;
       tct.dphi = __shfl(ct.dphi, src);
       tct.st = __shfl(ct.st, src);
@@ -1519,7 +1533,7 @@ __global__ void __launch_bounds__(256, OCC)
       PState s{};
       if (act) {
         if constexpr (RECIN) {
-          s = load_state_recin<DIM>(pid, mask, rin.rec);
+          s = load_state_recin<DIM>(pid, mask, rin.rec, (long long)t_rbase + (long long)p * rstride);
           if (read_ids) s.elem = ld<NT>(elem_ids + pid);
         } else {
           s = load_state<DIM, NT>(pid, mask, pphi, pb, x, stride, elem_ids, read_ids);
@@ -1545,7 +1559,7 @@ __global__ void __launch_bounds__(256, OCC)
   int pre = -1;  // element whose record the DMA put into this lane's staging slot for column p
   if (!thin && p0 < pend) {
     if constexpr (RECIN) {
-      cur = load_state_recin<DIM>(start + p0 * C, mask, rin.rec);
+      cur = load_state_recin<DIM>(start + p0 * C, mask, rin.rec, (long long)rbase + (long long)p0 * rstride);
       if (read_ids) cur.elem = ld<NT>(elem_ids + start + p0 * C);
     } else {
       cur = load_state<DIM, NT>(start + p0 * C, mask, pphi, pb, x, stride, elem_ids, read_ids);
@@ -1577,7 +1591,7 @@ __global__ void __launch_bounds__(256, OCC)
     if (__ballot(pre >= 0) != 0ull) coop_issue<DIM>(recs, pre, st, lane);
     if (act && p + 1 < pend) {
       if constexpr (RECIN)
-        cur = load_state_recin<DIM>(pid + C, mask, rin.rec);
+        cur = load_state_recin<DIM>(pid + C, mask, rin.rec, (long long)rbase + (long long)(p + 1) * rstride);
       else
         cur = load_state<DIM, NT>(pid + C, mask, pphi, pb, x, stride, elem_ids, false);
       cur.elem = e1;
@@ -2289,7 +2303,7 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
       if (mesh->dim == 2) {
         k_push_walk_rowsq<2, 4, true><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
       } else if (recin) {
-        const RecIn rin{ps->s_aos_live.as<char>(), (unsigned*)ps->data[2].p, (float*)ps->data[3].p, 0};
+        const RecIn rin{ps->s_aos_live.as<char>(), (unsigned*)ps->data[2].p, (float*)ps->data[3].p, 0, ps->rec_rm ? 1 : 0};
         k_push_walk_rowsq<3, 4, true, true><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS, rin);
         ps->lazy_rec = 2;  // every member but the origin is in the SoA arrays now
       } else {
@@ -2311,7 +2325,8 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
       g_cnt2_cur ^= 1;
     } else if (rgrid > 0) {
       if (mesh->dim == 2 && recin) {
-        const RecIn rin{ps->s_aos_live.as<char>(), (unsigned*)ps->data[2].p, (float*)ps->data[3].p, zero_z};
+        const RecIn rin{ps->s_aos_live.as<char>(), (unsigned*)ps->data[2].p, (float*)ps->data[3].p, zero_z,
+                        ps->rec_rm ? 1 : 0};
         k_push_walk_rows<2, 4, true><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS, rin);
         ps->lazy_rec = 2;
       } else if (mesh->dim == 2)
