@@ -1277,6 +1277,73 @@ __device__ __forceinline__ void coop_fetch(RecCache<DIM>& c, const void* __restr
   wave_lds_sync();
 }
 
+// ---- record-fed form: the wave's PARTICLE records through the LDS too.  A column's 64 records (64 B each) are
+// fetched cooperatively like the element records -- 4 lanes per record, 16 records per global_load_lds
+// instruction: 16 cache lines per instruction when the records are row-major (each record half a line of its
+// own row), against 64 lines for each of the three 16-B loads a lane-private read needs -- and land in a 4 KB
+// staging area next to a HALVED element-record area (32 records; a wave whose 64 lanes all need a new element
+// record fetches in two rounds: in the rebuilt-every-step flows this form serves that is the first column of a
+// tile).  No VGPRs hold data in flight: the state of column p + 1 is DMA'd while column p computes, into the
+// buffer column p was just read out of.
+__device__ __forceinline__ void prec_issue(const char* __restrict__ rec, int my_ri, double2* pst, int lane) {
+  const int sub = lane & 3;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int o = 16 * j + (lane >> 2);  // owner lane of the record this lane helps to fetch
+    const int ri = __shfl(my_ri, o);
+    const int piece = sub ^ (o & 3);
+    if (ri >= 0)
+      __builtin_amdgcn_global_load_lds((const void*)(rec + (long long)ri * 64 + piece * 16),
+                                       (__attribute__((address_space(3))) void*)(pst + j * 64), 16, 0, 0);
+  }
+}
+template <int DIM>
+__device__ __forceinline__ PState prec_collect(const double2* pst, int lane) {
+  const double2* mine = pst + lane * 4;
+  const int sub = lane & 3;
+  PState s;
+  s.m = 0;
+  s.x = s.y = s.z = 0;
+  if (DIM == 3) {
+    const double2 q0 = mine[0 ^ sub];
+    s.x = q0.x;
+    s.y = q0.y;
+    s.z = mine[1 ^ sub].x;
+  }
+  const uint4 q3 = *(const uint4*)(mine + (3 ^ sub));
+  s.phi = __uint_as_float(q3.y);
+  s.b = __uint_as_float(q3.z);
+  s.id = q3.w;
+  s.elem = -1;
+  return s;
+}
+// element records through HALF a staging area (32 records): lanes 0-31, then lanes 32-63
+template <int DIM>
+__device__ __forceinline__ void coop_fetch_half(RecCache<DIM>& c, const void* __restrict__ recs, int want,
+                                                double2* st, int lane) {
+  constexpr int NP = DIM == 3 ? 8 : 4;
+  constexpr int RPI = 64 / NP;
+  const int sub = lane & (NP - 1);
+  for (int h = 0; h < 2; ++h) {
+    const bool mine_now = want >= 0 && (lane >> 5) == h;
+    if (__ballot(mine_now) == 0ull) continue;  // (wave-uniform)
+#pragma unroll
+    for (int j = 0; j < NP / 2; ++j) {
+      const int o = 32 * h + RPI * j + lane / NP;
+      const int eo = __shfl(want, o);
+      const int piece = sub ^ (o & (NP - 1));
+      if (eo >= 0)
+        __builtin_amdgcn_global_load_lds(
+            (const void*)((const char*)recs + (size_t)eo * (NP * 16) + piece * 16),
+            (__attribute__((address_space(3))) void*)(st + j * 64), 16, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+    wave_lds_sync();
+    coop_collect<DIM>(c, mine_now, want, st - h * 32 * NP, lane);  // (lane - 32 h) * NP from the area's start
+    wave_lds_sync();
+  }
+}
+
 // per-launch constants of the fused kernel's column arithmetic
 struct WalkArgs {
   double* xt;
@@ -1554,6 +1621,49 @@ __global__ void __launch_bounds__(256, OCC)
   // records of p (LDS staging, DMA'd from the element id that was read one column earlier).
   // The records are copied to the register cache, then the DMA for column p+1 and the state
   // loads of p+1 are issued and overlap the whole of column p's arithmetic.
+  if constexpr (RECIN) {
+    static_assert(DIM == 3, "the record-fed queued kernel is the tet form (2-D: k_push_walk_rows)");
+    // ---- record-fed form: particle records through the LDS (prec_issue / prec_collect), element records through
+    // the other half of the wave's staging area.  At the top of column p the DMA of column p has landed; the
+    // state is read out, the DMA of column p + 1 goes into the same buffer and overlaps the arithmetic of p.
+    double2* const pst = st + 32 * NP;  // (DIM 3: 4 KB of element records + 4 KB of particle records)
+    unsigned char m_cur = 0, m_nxt = 0;
+    int e_cur = -1, e_nxt = -1;
+    {
+      const bool first = !thin && p0 < pend;
+      prec_issue(rin.rec, first ? rbase + p0 * rstride : -1, pst, lane);
+      if (first) {
+        m_cur = mask[start + p0 * C];
+        if (read_ids) e_cur = ld<NT>(elem_ids + start + p0 * C);
+      }
+    }
+    for (int i = 0; i < (thin ? 0 : TP); ++i) {  // wave-uniform trip count
+      const int p = p0 + i;
+      const int pid = start + p * C;
+      const bool act = p < pend;
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the records of column p (and its mask / seed loads)
+      wave_lds_sync();
+      PState s = prec_collect<DIM>(pst, lane);
+      s.m = act ? m_cur : 0;
+      if (read_ids) s.elem = e_cur;
+      wave_lds_sync();  // the buffer is free again
+      const bool nxt = act && p + 1 < pend;
+      prec_issue(rin.rec, nxt ? rbase + (p + 1) * rstride : -1, pst, lane);
+      if (nxt) {
+        m_nxt = mask[pid + C];
+        if (read_ids) e_nxt = ld<NT>(elem_ids + pid + C);
+      }
+      const bool live = act && s.m;
+      int elem = live ? seed_of<DIM>(s, e, seeded, nelems) : -1;
+      const int want = (elem >= 0 && elem != cache.id) ? elem : -1;
+      if (__ballot(want >= 0) != 0ull) coop_fetch_half<DIM>(cache, recs, want, st, lane);
+      V3 dest{0, 0, 0};
+      const bool need = column_math<DIM, NT>(A, s, act, live, pid, ct, cache, elem, dest);
+      enqueue(need, pid, elem, dest, wq, qn, lt_mask);
+      m_cur = m_nxt;
+      e_cur = e_nxt;
+    }
+  } else {
   PState cur{};
   int e1 = -1;   // raw elem_ids value of column p+1 (read two columns ahead of its use as a seed)
   int pre = -1;  // element whose record the DMA put into this lane's staging slot for column p
@@ -1600,6 +1710,7 @@ __global__ void __launch_bounds__(256, OCC)
     V3 dest{0, 0, 0};
     const bool need = column_math<DIM, NT>(A, s, act, live, pid, ct, cache, elem, dest);
     enqueue(need, pid, elem, dest, wq, qn, lt_mask);
+  }
   }
   if (lane == 0) wave_cnt[gwave] = qn;
 }
