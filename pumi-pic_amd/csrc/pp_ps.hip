@@ -791,12 +791,23 @@ __global__ void k_move_pack(int capacity, const int* __restrict__ new_idx, RankT
 // 256 contiguous bytes per row instead of four 64-byte stores 4 KB apart (c3: 294 -> 224 us for the pass).
 template <int NQ>
 __global__ void k_move_pack_rm(int capacity, const int* __restrict__ new_idx, RankToSlot rs,
-                               uint4* __restrict__ aos, WordTable t, const int* __restrict__ go) {
+                               uint4* __restrict__ aos, WordTable t, const int* __restrict__ go, int wide) {
   if (go && !*go) return;
-  __shared__ uint4 st[4][64][NQ + 1];
-  __shared__ int sd[4][64];
-  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __shared__ uint4 st[256][NQ + 1];
+  __shared__ int sd[256];
+  // which old slot: 4 columns x 64 rows of the block's 256 consecutive slots, or (wide: chunk height 64) 8 columns x
+  // 32 rows -- block pairs share 8 columns, so a row's run is up to 8 records = 512 contiguous bytes
+  const int tid = threadIdx.x;
+  int pid, li;  // li = LDS index: records of one row adjacent
+  if (wide) {  // wide = log2(columns per block), chunk height 64: 2^wide columns x (256 >> wide) rows
+    const int nrow = 256 >> wide, col = tid / nrow, row = tid - col * nrow;
+    const int sub = blockIdx.x & ((64 / nrow) - 1);  // which group of rows of the column block
+    pid = (blockIdx.x / (64 / nrow)) * (64 << wide) + col * 64 + sub * nrow + row;
+    li = (row << wide) + col;
+  } else {
+    pid = blockIdx.x * 256 + tid;
+    li = (tid & 63) * 4 + (tid >> 6);
+  }
   const int rk = (pid < capacity) ? new_idx[pid] : -1;
   int idx = -1;
   if (rk >= 0) {
@@ -817,18 +828,17 @@ __global__ void k_move_pack_rm(int capacity, const int* __restrict__ new_idx, Ra
       if (j < t.n4)
         v[NQ * 4 - 1 - j] = __builtin_nontemporal_load((const unsigned*)(t.src4[j] + (long long)pid * 4));
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) st[w][l][q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    for (int q = 0; q < NQ; ++q) st[li][q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
   }
-  sd[w][l] = idx;
+  sd[li] = idx;
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < NQ; ++j) {
-    const int item = j * 256 + threadIdx.x, rec = item / NQ, part = item % NQ;
-    const int row = rec >> 2, col = rec & 3;  // the (up to) four records of one row are adjacent items
-    const int d = sd[col][row];
+    const int item = j * 256 + tid, rec = item / NQ, part = item % NQ;  // the records of one row are adjacent items
+    const int d = sd[rec];
     if (d >= 0) {
       typedef unsigned v4u __attribute__((ext_vector_type(4)));
-      const uint4 x = st[col][row][part];
+      const uint4 x = st[rec][part];
       v4u y;
       y.x = x.x;
       y.y = x.y;
@@ -2086,7 +2096,8 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
 #define PP_STAGED(N)                                                                             \
   case N:                                                                                        \
     if (use_rm)                                                                                  \
-      k_move_pack_rm<N><<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, rank, rs_rm, aos, wt, go); \
+      k_move_pack_rm<N><<<(grid_for(ps->capacity) + 15) / 16 * 16, kBlock, 0, st>>>(ps->capacity, rank, rs_rm, aos, wt, go, \
+                                                                                  ps->C == 64 ? rm_wide : 0); \
     else                                                                                         \
       k_move_pack<N><<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, rank, rs, aos, wt, go); \
     if (!defer_unpack) k_move_unpack<N><<<new_grid, kBlock, 0, st>>>(PP_UNPACK_ARGS);            \
@@ -2095,6 +2106,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       // the staging records row-major inside a chunk: the particles of a row, which carry consecutive ranks,
       // are consecutive records, and the pack's block-level transpose stores them as runs
       const RankToSlot rs_rm{new_element, ps->s_erec0.as<int>(), 1};
+      static const int rm_wide = getenv("PP_RM_WIDE") ? atoi(getenv("PP_RM_WIDE")) : 3;  // log2(columns per block)
       // (only where the records stay the particle data -- the pseudoXGCm flows, where nine particles in ten keep
       // their row: c3 -3.3 %, 2dc3 -3.6 %, c5 share -3.2 %.  ps_combo160 redistributes half of its particles to
       // random elements: nothing to merge, and its second pass reads row-major records 2.5 % slower)
