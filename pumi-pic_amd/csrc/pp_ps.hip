@@ -44,43 +44,79 @@ __global__ void k_count_added(int n_new, const int* __restrict__ new_elems, int 
 // The same for chunk heights that are a multiple of 4: a thread covers four adjacent rows of a tile, so the
 // mask leaves as 4-byte words (k_init_slots_tiled stores single bytes: 10.7 us per 10 M slots against the
 // ~3 us its 10 MB cost) and the optional slot -> element table as 16-byte quads.
-__global__ void k_init_slots_tiled4(const int* __restrict__ ntiles_dev, int C, int TP,
-                                    const int* __restrict__ tiles, const int* __restrict__ chunk_start,
-                                    const int* __restrict__ chunk_width, const int* __restrict__ r2e,
-                                    const int* __restrict__ ppe, int ne, int* __restrict__ slot_elem,
-                                    int* __restrict__ row_cursor, int* __restrict__ elem_slot0,
-                                    unsigned char* __restrict__ new_mask, const int* __restrict__ go,
-                                    int* __restrict__ zero_next, int zero_words, int* __restrict__ elem_rec0) {
-  if (!*go) return;
-  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  for (long long i = g; i < zero_words; i += (long long)gridDim.x * blockDim.x) zero_next[i] = 0;
+struct InitSlotsArgs {
+  const int* ntiles_dev;
+  int C, TP;
+  const int *tiles, *chunk_start, *chunk_width, *r2e, *ppe;
+  int ne;
+  int *slot_elem, *row_cursor, *elem_slot0;
+  unsigned char* new_mask;
+  const int* go;
+  int* zero_next;
+  int zero_words;
+  int* elem_rec0;
+  // non-null: the tile table and row -> element are NOT read (k_layout_tables writes them in the same launch):
+  // the tile's chunk by bisection in tile_off, the row's element from the sorted index
+  const int* tile_off;
+  const int* index;
+  int nchunks, sorted;
+};
+// (g: global thread index; nthreads: threads of the launch or of the block range that runs this body)
+__device__ __forceinline__ void init_slots_tiled4_body(const InitSlotsArgs& a, long long g, long long nthreads) {
+  const int C = a.C, TP = a.TP, ne = a.ne;
+  for (long long i = g; i < a.zero_words; i += nthreads) a.zero_next[i] = 0;
   const int Q = C >> 2;
   const int tile = (int)(g / Q), r = 4 * (int)(g - (long long)tile * Q);
-  if (tile >= *ntiles_dev) return;
-  const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
-  const int start = chunk_start[c] + r, pend = min(p0 + TP, chunk_width[c]);
-  const int4 e = *(const int4*)(r2e + c * C + r);
-  const int c0 = e.x < ne ? ppe[e.x] : 0, c1 = e.y < ne ? ppe[e.y] : 0, c2 = e.z < ne ? ppe[e.z] : 0,
-            c3 = e.w < ne ? ppe[e.w] : 0;
+  if (tile >= *a.ntiles_dev) return;
+  int c, p0;
+  int4 e;
+  if (a.tile_off) {
+    int lo = 0, hi = a.nchunks - 1;  // last chunk with tile_off[c] <= tile (as k_layout_tables)
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (a.tile_off[mid] <= tile)
+        lo = mid;
+      else
+        hi = mid - 1;
+    }
+    c = lo;
+    p0 = (tile - a.tile_off[lo]) * TP;
+    const int row = c * C + r;
+    e.x = (row < ne && a.sorted) ? a.index[row] : row;
+    e.y = (row + 1 < ne && a.sorted) ? a.index[row + 1] : row + 1;
+    e.z = (row + 2 < ne && a.sorted) ? a.index[row + 2] : row + 2;
+    e.w = (row + 3 < ne && a.sorted) ? a.index[row + 3] : row + 3;
+  } else {
+    c = a.tiles[2 * tile];
+    p0 = a.tiles[2 * tile + 1];
+    e = *(const int4*)(a.r2e + c * C + r);
+  }
+  const int start = a.chunk_start[c] + r, pend = min(p0 + TP, a.chunk_width[c]);
+  const int c0 = e.x < ne ? a.ppe[e.x] : 0, c1 = e.y < ne ? a.ppe[e.y] : 0, c2 = e.z < ne ? a.ppe[e.z] : 0,
+            c3 = e.w < ne ? a.ppe[e.w] : 0;
   if (p0 == 0) {
-    *(int4*)(row_cursor + c * C + r) = make_int4(start, start + 1, start + 2, start + 3);
-    if (e.x < ne) elem_slot0[e.x] = start;
-    if (e.y < ne) elem_slot0[e.y] = start + 1;
-    if (e.z < ne) elem_slot0[e.z] = start + 2;
-    if (e.w < ne) elem_slot0[e.w] = start + 3;
-    if (elem_rec0) {  // first record of the row when the staging records are row-major inside the chunk (pp_ps::rec_rm)
-      const int w = chunk_width[c], q0 = chunk_start[c] + r * w;
-      if (e.x < ne) elem_rec0[e.x] = q0;
-      if (e.y < ne) elem_rec0[e.y] = q0 + w;
-      if (e.z < ne) elem_rec0[e.z] = q0 + 2 * w;
-      if (e.w < ne) elem_rec0[e.w] = q0 + 3 * w;
+    *(int4*)(a.row_cursor + c * C + r) = make_int4(start, start + 1, start + 2, start + 3);
+    if (e.x < ne) a.elem_slot0[e.x] = start;
+    if (e.y < ne) a.elem_slot0[e.y] = start + 1;
+    if (e.z < ne) a.elem_slot0[e.z] = start + 2;
+    if (e.w < ne) a.elem_slot0[e.w] = start + 3;
+    if (a.elem_rec0) {  // first record of the row when the staging records are row-major inside the chunk (pp_ps::rec_rm)
+      const int w = a.chunk_width[c], q0 = a.chunk_start[c] + r * w;
+      if (e.x < ne) a.elem_rec0[e.x] = q0;
+      if (e.y < ne) a.elem_rec0[e.y] = q0 + w;
+      if (e.z < ne) a.elem_rec0[e.z] = q0 + 2 * w;
+      if (e.w < ne) a.elem_rec0[e.w] = q0 + 3 * w;
     }
   }
   for (int p = p0; p < pend; ++p) {
-    if (slot_elem) *(int4*)(slot_elem + start + p * C) = e;
-    *(unsigned*)(new_mask + start + p * C) =
+    if (a.slot_elem) *(int4*)(a.slot_elem + start + p * C) = e;
+    *(unsigned*)(a.new_mask + start + p * C) =
         (p < c0 ? 1u : 0u) | (p < c1 ? 0x100u : 0u) | (p < c2 ? 0x10000u : 0u) | (p < c3 ? 0x1000000u : 0u);
   }
+}
+__global__ void k_init_slots_tiled4(InitSlotsArgs a) {
+  if (!*a.go) return;
+  init_slots_tiled4_body(a, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
 }
 // ---- row-tiled histogram of new parents (SCS): thread = (old tile, row).  Particles that stay in
 // their element are counted in a register and leave as ONE atomic per thread, and so do the movers
@@ -542,6 +578,16 @@ __device__ __forceinline__ void layout_tables_body(const LayoutTablesArgs& a, co
 __global__ void k_layout_tables(LayoutTablesArgs a) {
   if (!a.tot->go) return;
   layout_tables_body(a, blockIdx.x);
+}
+// the table fills AND the slot initialisation in one launch: the slot blocks do not read the tables (InitSlotsArgs::
+// tile_off / index), so nothing orders the two ranges -- one launch and ~6 us of its latency less per re-layout
+__global__ void k_layout_tables_slots(LayoutTablesArgs a, InitSlotsArgs ia, unsigned table_blocks) {
+  if (!a.tot->go) return;
+  if (blockIdx.x < table_blocks)
+    layout_tables_body(a, blockIdx.x);
+  else
+    init_slots_tiled4_body(ia, (long long)(blockIdx.x - table_blocks) * blockDim.x + threadIdx.x,
+                           (long long)(gridDim.x - table_blocks) * blockDim.x);
 }
 // slot -> parent element of every slot of every tile (what k_init_slots_tiled leaves out, see pp::slot_elem)
 __global__ void k_fill_slot_elem(const int* __restrict__ ntiles_dev, int C, int TP, const int* __restrict__ tiles,
@@ -2040,17 +2086,29 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     if (int rct = make_tables(cap_sz, nsl_sz, ta)) return rct;
     int* new_tiles = ps->s_newidx.as<int>();
     const int* new_ntiles = ps->s_scan.as<int>();
-    k_layout_tables<<<ta.b3 + grid_for(nrows), kBlock, 0, st>>>(ta);
-#define PP_INIT_SLOTS_ARGS                                                                                        \
-  new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_r2e2.as<int>(), ppe, ne,               \
-      lazy_slot_elem ? nullptr : ps->s_slot2.as<int>(), ps->s_rowstart.as<int>(), ps->s_eslot0.as<int>(),        \
-      ps->s_mask2.as<unsigned char>(), go, prezero ? ps->d_elem_count.as<int>() : nullptr,                         \
-      prezero ? (int)((tot_off + sizeof(Totals)) / sizeof(int)) : 0, want_rm ? ps->s_erec0.as<int>() : nullptr
-    if (C_new % 4 == 0)
-      k_init_slots_tiled4<<<grid_for((size_t)ntiles_max * (C_new / 4)), kBlock, 0, st>>>(PP_INIT_SLOTS_ARGS);
-    else
-      k_init_slots_tiled<<<grid_for((size_t)ntiles_max * C_new), kBlock, 0, st>>>(PP_INIT_SLOTS_ARGS);
-#undef PP_INIT_SLOTS_ARGS
+    InitSlotsArgs isa{new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_r2e2.as<int>(), ppe, ne,
+                      lazy_slot_elem ? nullptr : ps->s_slot2.as<int>(), ps->s_rowstart.as<int>(),
+                      ps->s_eslot0.as<int>(), ps->s_mask2.as<unsigned char>(), go,
+                      prezero ? ps->d_elem_count.as<int>() : nullptr,
+                      prezero ? (int)((tot_off + sizeof(Totals)) / sizeof(int)) : 0,
+                      want_rm ? ps->s_erec0.as<int>() : nullptr, nullptr, nullptr, nchunks, ta.sorted};
+    static const bool no_merge = getenv("PP_NO_TABLES_SLOTS_MERGE") != nullptr;
+    const unsigned table_blocks = ta.b3 + grid_for(nrows);
+    if (C_new % 4 == 0 && !no_merge) {  // one launch: table blocks + slot blocks (which find tile and element themselves)
+      isa.tile_off = L.tile_off;
+      isa.index = L.index;
+      k_layout_tables_slots<<<table_blocks + grid_for((size_t)ntiles_max * (C_new / 4)), kBlock, 0, st>>>(ta, isa,
+                                                                                                      table_blocks);
+    } else {
+      k_layout_tables<<<table_blocks, kBlock, 0, st>>>(ta);
+      if (C_new % 4 == 0)
+        k_init_slots_tiled4<<<grid_for((size_t)ntiles_max * (C_new / 4)), kBlock, 0, st>>>(isa);
+      else
+        k_init_slots_tiled<<<grid_for((size_t)ntiles_max * C_new), kBlock, 0, st>>>(
+            isa.ntiles_dev, isa.C, isa.TP, isa.tiles, isa.chunk_start, isa.chunk_width, isa.r2e, isa.ppe, isa.ne,
+            isa.slot_elem, isa.row_cursor, isa.elem_slot0, isa.new_mask, isa.go, isa.zero_next, isa.zero_words,
+            isa.elem_rec0);
+    }
     // ---- swap buffer sizing (SCS_rebuild.h:223-229)
     int64_t swap_stride = ps->swap_stride;
     if (stride_fixed > 0) {  // speculative tail: whatever the swap buffers hold today
