@@ -127,7 +127,7 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
                               const int* __restrict__ chunk_width, const int* __restrict__ r2e,
                               const unsigned char* __restrict__ mask,
                               const int* __restrict__ new_element, int ne, int* __restrict__ ppe,
-                              Totals* tot, int* __restrict__ rank) {
+                              Totals* tot, int* __restrict__ rank, int merge) {
   // thread = (group of G consecutive tiles, row), G*TP <= 32: consecutive tiles of one chunk are
   // the same row of the same element, so the stayers of up to 32 columns cost ONE atomic (the L2
   // atomic rate, not the 5 B/particle read, bounds this kernel).  The atomics RETURN the old count:
@@ -225,6 +225,42 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
         if (!deferred) rank[start + (pb + j) * C] = rk;
       }
     }
+  }
+  // The stayers of the thread's LAST run, merged over the block: the four waves of a block are consecutive tile
+  // groups -- mostly of one chunk, i.e. the same 64 rows = the same 64 counters.  Waves whose last run lies in the
+  // same chunk add their stayer counts up in LDS (the LDS atomic hands each its place inside the block's range) and
+  // the first of them issues ONE returning atomic per row for all: up to four times fewer of the atomics whose rate
+  // bounds this kernel.  (Runs that end inside the loop -- a group that spans chunks -- flush as before.)
+  __shared__ int s_last[4];
+  __shared__ int s_sum[4][64];
+  const int wv = threadIdx.x >> 6;
+  const bool blockwise = merge && C == 64 && blockDim.x == 256;  // (lane == row)
+  if (blockwise) {
+    if ((threadIdx.x & 63) == 0) s_last[wv] = cur;  // -1: the wave had no tile
+    s_sum[wv][threadIdx.x & 63] = 0;
+    __syncthreads();
+    int lead = wv;
+    for (int w = wv - 1; w >= 0; --w)
+      if (s_last[w] == cur) lead = w;
+    const int n0 = __popc(m0);
+    int loc = 0;
+    if (cur >= 0 && n0) loc = atomicAdd(&s_sum[lead][r], n0);
+    __syncthreads();
+    if (cur >= 0 && lead == wv) {  // (wave-uniform) this wave's `e` is the element of row r of that chunk
+      const int t = s_sum[wv][r];
+      s_sum[wv][r] = t ? atomicAdd(&ppe[e], t) : 0;
+    }
+    __syncthreads();
+    if (n0) {
+      int idx = s_sum[lead][r] + loc;
+      unsigned m = m0;
+      while (m) {
+        const int b = __ffs(m) - 1;
+        m &= m - 1;
+        rank[start + (run_p0 + b) * C] = idx++;
+      }
+    }
+    m0 = 0;
   }
   flush();
 }
@@ -1930,11 +1966,12 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   PP_HIP_CHECK(ps->s_ranknew.reserve(sizeof(int) * (size_t)std::max(n_new, 1)));
   int* rank = ps->s_idx.as<int>();
   int* rank_new = ps->s_ranknew.as<int>();
+  static const bool no_count_merge = getenv("PP_NO_COUNT_MERGE") != nullptr;
   if (have_old && old_grid > 0)
     k_count_tiled<<<grp_grid, kBlock, 0, st>>>(
         ps->d_ntiles.as<int>(), ps->C, ps->tile_p, G, ps->d_tiles.as<int>(),
         ps->d_chunk_start.as<int>(), ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(),
-        ps->d_mask.as<unsigned char>(), new_element, ne, ppe, tot, rank);
+        ps->d_mask.as<unsigned char>(), new_element, ne, ppe, tot, rank, no_count_merge ? 0 : 1);
   if (n_new > 0) {
     k_count_added<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ne, ppe, tot, rank_new);
   }
