@@ -266,7 +266,12 @@ class Stepper:
         if timed:
             self.ntimed = getattr(self, "ntimed", 0) + 1
             timed = (self.ntimed - 1) % getattr(self, "sample_every", 1) == 0 and len(self.kernel_ms) < 64
+        whole = True
         if timed:
+            # a sampled step is bracketed EITHER as a whole (e0 .. e2) OR around its pp_push_search call (e0 .. e1),
+            # alternately: an event record is a barrier packet (~6 us), and one in the middle of a span would be
+            # measured by it
+            whole = len(self.kernel_ms) % 2 == 0 or self.name in ("c2", "2d", "c2mt")
             e0, e1, e2 = capi.Event(), capi.Event(), capi.Event()
             e0.record()
         beat("step %d: push + search" % self.steps_done)
@@ -291,8 +296,10 @@ class Stepper:
         else:
             capi.push_search(self.mesh, self.ps, self.h, self.k, self.d, self.deg, self.ids,
                              seeded=True, looplimit=200, want_found=False)
-        if timed:
+        if timed and (not whole or self.name in ("c2", "2d", "c2mt")):
             e1.record()
+        else:
+            e1 = None
         if self.first and self.w.get("origin_trust", False) and self.w["dim"] == 3 and self.name not in ("c4", "c2mt"):
             # From the second step on every origin is the destination the previous walk accepted in the
             # element the walk starts from (c3 / c5: the structure was rebuilt from the ids; c2: the ids are
@@ -303,7 +310,10 @@ class Stepper:
         beat("step %d: rebuild / migration / scatter" % (self.steps_done - 1))
         self._rest_of_step()
         if timed:
-            e2.record()
+            if whole:
+                e2.record()
+            else:
+                e2 = None
             self.kernel_ms.append((e0, e1, e2))
 
     def _rest_of_step(self):
@@ -401,12 +411,14 @@ class Stepper:
         self.ppdist.allreduce_sum(self.sync_t)
 
     def kernel_avg_ms(self):
-        """mean HIP-event time of one pp_push_search call (both kernels)"""
-        return float(np.mean([a.elapsed_ms(b) for a, b, _ in self.kernel_ms])) if self.kernel_ms else None
+        """median HIP-event time of one pp_push_search call (both kernels) over the sampled steps"""
+        ms = [a.elapsed_ms(b) for a, b, _ in self.kernel_ms if b is not None]
+        return float(np.median(ms)) if ms else None
 
     def step_avg_ms(self):
-        """mean HIP-event time of the whole step on the library stream (the sampled steps)"""
-        return float(np.mean([a.elapsed_ms(c) for a, _, c in self.kernel_ms])) if self.kernel_ms else None
+        """median HIP-event time of the whole step on the library stream (the sampled steps)"""
+        ms = [a.elapsed_ms(c) for a, _, c in self.kernel_ms if c is not None]
+        return float(np.median(ms)) if ms else None
 
 
 def cpu_baseline(pp, w, name, deg, sample, steps=20):
@@ -881,7 +893,10 @@ def main():
     def timed_run(steps, trace=None):
         st.ntimed = 0
         st.kernel_ms = []
-        st.sample_every = max(1, steps // 10)
+        # HIP events bracket about seven of the K timed steps (whole step and pp_push_search call alternately, the
+        # median of each is reported): an event record is a barrier packet (~6 us) on a 0.6 ms step -- three records
+        # on every second step (round 3) cost the line ~1.5 %
+        st.sample_every = max(1, steps // 6)
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -1031,7 +1046,7 @@ def main():
                 dist.destroy_process_group()
             return
         # Roofline.  c2 / 2d: ONE pp_push_search call is the step.  c3 / 2dc3 / c5: the WHOLE step
-        # (push+search 69 B + rebuild 125 B per particle) against the mean HIP-event time
+        # (push+search 69 B + rebuild 125 B per particle) against the median HIP-event time
         # of the sampled steps; the two phases are broken out under "phases".
         bpp_ps = BYTES["2d" if w["dim"] == 2 else "c2mt" if a.workload == "c2mt" else "c2"]
         sms = sms_main
