@@ -168,6 +168,14 @@ int mesh_edges(const pp_mesh* mesh);
 namespace pp {
 struct GyroRide;
 }
+// First record of row r of chunk c when the staging records are row-major inside a chunk (pp_ps::rec_rm).  The row
+// pitch is the chunk width rounded up to EVEN and every chunk gets one spare column (C records), so that every row
+// starts on a 128-byte line and the records of columns (2j, 2j+1) of a row are one line: the record-fed push
+// fetches them together.  The record buffer holds capacity + C * nchunks records.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int pp_rec_row0(int chunk_start, int c, int r, int w, int C) { return chunk_start + C * c + r * (w + (w & 1)); }
 struct pp_ps {
   int kind = PP_SCS;
   int num_elems = 0, num_ptcls = 0, capacity = 0, num_rows = 0;
@@ -231,10 +239,10 @@ struct pp_ps {
   int lazy_x = -1, lazy_xt = -1;  // commit members of the rebuild that left the records
   pp::DevBuf s_aos_live;
   // Position of a slot's record in s_aos_live.  rec_rm: ROW-MAJOR inside a chunk -- the record of (row r, column p)
-  // of chunk c is number chunk_start[c] + r * chunk_width[c] + p, so the particles of a row (consecutive ranks of
-  // one element) are consecutive 64-B records and the re-layout's scattered stores leave as runs instead of
-  // single records (round 4); else the record index is the slot.  d_erec0 / s_erec0: first record of every
-  // element's row in the current / the new layout.
+  // of chunk c is number pp_rec_row0(chunk_start[c], c, r, chunk_width[c], C) + p, so the particles of a row
+  // (consecutive ranks of one element) are consecutive 64-B records and the re-layout's scattered stores leave as
+  // runs instead of single records (round 4); else the record index is the slot.  d_erec0 / s_erec0: first record
+  // of every element's row in the current / the new layout.
   bool rec_rm = false;
   pp::DevBuf d_erec0, s_erec0;
   pp::DevBuf s_rs, s_holes;  // in-place rebuild: per-element counters, per-row hole lists

@@ -101,11 +101,11 @@ __device__ __forceinline__ void init_slots_tiled4_body(const InitSlotsArgs& a, l
     if (e.z < ne) a.elem_slot0[e.z] = start + 2;
     if (e.w < ne) a.elem_slot0[e.w] = start + 3;
     if (a.elem_rec0) {  // first record of the row when the staging records are row-major inside the chunk (pp_ps::rec_rm)
-      const int w = a.chunk_width[c], q0 = a.chunk_start[c] + r * w;
+      const int w = a.chunk_width[c], q0 = pp_rec_row0(a.chunk_start[c], c, r, w, C), pt = w + (w & 1);
       if (e.x < ne) a.elem_rec0[e.x] = q0;
-      if (e.y < ne) a.elem_rec0[e.y] = q0 + w;
-      if (e.z < ne) a.elem_rec0[e.z] = q0 + 2 * w;
-      if (e.w < ne) a.elem_rec0[e.w] = q0 + 3 * w;
+      if (e.y < ne) a.elem_rec0[e.y] = q0 + pt;
+      if (e.z < ne) a.elem_rec0[e.z] = q0 + 2 * pt;
+      if (e.w < ne) a.elem_rec0[e.w] = q0 + 3 * pt;
     }
   }
   for (int p = p0; p < pend; ++p) {
@@ -663,7 +663,7 @@ __global__ void k_init_slots_tiled(const int* __restrict__ ntiles_dev, int C, in
   if (p0 == 0) {
     row_cursor[c * C + r] = start;
     if (e < ne) elem_slot0[e] = start;  // first slot of the element's new row (pack: + rank*C)
-    if (e < ne && elem_rec0) elem_rec0[e] = chunk_start[c] + r * chunk_width[c];
+    if (e < ne && elem_rec0) elem_rec0[e] = pp_rec_row0(chunk_start[c], c, r, chunk_width[c], C);
   }
   for (int p = p0; p < pend; ++p) {
     if (slot_elem) slot_elem[start + p * C] = e;
@@ -943,7 +943,7 @@ __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
   if (tile >= *ntiles_dev) return;
   const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
   const int start = chunk_start[c] + r, pend = min(p0 + TP, chunk_width[c]);
-  const long long rbase = (long long)chunk_start[c] + (long long)r * chunk_width[c];  // row-major records (pp_ps::rec_rm)
+  const long long rbase = pp_rec_row0(chunk_start[c], c, r, chunk_width[c], C);  // row-major records (pp_ps::rec_rm)
   for (int p = p0; p < pend; ++p) {
     const int slot = start + p * C;
     if (!new_mask[slot]) continue;
@@ -2075,7 +2075,9 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       for (int m = 0; m < ps->nmembers; ++m) srcs[m] = ps->data[m].p;
       WordTable wt_probe{};
       const int nq = build_word_table(ps, srcs, ps->stride, stride_fit, commit_x, commit_xt, wt_probe);
-      if (nq > 0) cap_lim = std::min<long long>(cap_lim, (long long)(ps->s_aos.bytes / ((size_t)nq * 16)));
+      if (nq > 0)
+        cap_lim = std::min<long long>(cap_lim, (long long)(ps->s_aos.bytes / ((size_t)nq * 16)) -
+                                                   (long long)ps->C_max * nchunks0);
     }
     const long long tiles_room = (long long)(ps->s_newidx.bytes / 8) - nchunks0 - 1;
     cap_lim = std::min<long long>(cap_lim, tiles_room * (long long)(ps->C_max * ps->tile_p));
@@ -2182,7 +2184,8 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       defer_unpack = lazy_zero && NQ == 4 && !no_defer && xgcm_shape(ps);
     }
     if (NQ > 0) {
-      PP_HIP_CHECK(ps->s_aos.reserve((size_t)std::max(cap_sz, 1) * NQ * 16));
+      // (+ one spare column per chunk: the row-major record geometry, pp_rec_row0)
+      PP_HIP_CHECK(ps->s_aos.reserve(((size_t)std::max(cap_sz, 1) + (size_t)C_new * nchunks) * NQ * 16));
       uint4* aos = ps->s_aos.as<uint4>();
       const unsigned new_grid = grid_for((size_t)ntiles_max * C_new);
 #define PP_UNPACK_ARGS                                                                                  \

@@ -1004,7 +1004,8 @@ struct RecIn {
   float* b_out;
   int zero_z;  // 2-D: x_tgt is logically zero (pp_ps::zero_pending) -- the push writes its third component too
   int rm;      // records row-major inside a chunk (pp_ps::rec_rm): (row r, column p) of chunk c is record
-               // chunk_start[c] + r * chunk_width[c] + p; else the record index is the slot
+               // pp_rec_row0(chunk_start[c], c, r, chunk_width[c], C) + p; else the record index is the slot
+  int no_pairs;  // PP_NO_PAIR_FETCH=1 (A/B knob): one column per fetch also on row-major records
 };
 template <int DIM = 3>
 __device__ __forceinline__ PState load_state_recin(int pid, const unsigned char* __restrict__ mask,
@@ -1125,7 +1126,7 @@ __global__ void __launch_bounds__(256, OCC)
     pend = min(p0 + TP, cw);
     e = r2e[c * C + r];
     if (RECIN && rin.rm)
-      rb = (long long)chunk_start[c] + (long long)r * cw;
+      rb = pp_rec_row0(chunk_start[c], c, r, cw, C);
     else
       rb = start, rs = C;
   }
@@ -1311,6 +1312,40 @@ __device__ __forceinline__ PState prec_collect(const double2* pst, int lane) {
     s.z = mine[1 ^ sub].x;
   }
   const uint4 q3 = *(const uint4*)(mine + (3 ^ sub));
+  s.phi = __uint_as_float(q3.y);
+  s.b = __uint_as_float(q3.z);
+  s.id = q3.w;
+  s.elem = -1;
+  return s;
+}
+// Two columns at once: with row-major records of even pitch (pp_rec_row0) the records of columns (2j, 2j + 1) of a row
+// are ONE 128-byte line; 8 lanes fetch it (as for an element record), the pair lands in the wave's whole 8 KB area.
+__device__ __forceinline__ void prec_issue_pair(const char* __restrict__ rec, int my_ri, double2* st, int lane) {
+  const int sub = lane & 7;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int o = 8 * j + (lane >> 3);
+    const int ri = __shfl(my_ri, o);
+    const int piece = sub ^ (o & 7);
+    if (ri >= 0)
+      __builtin_amdgcn_global_load_lds((const void*)(rec + (long long)ri * 64 + piece * 16),
+                                       (__attribute__((address_space(3))) void*)(st + j * 64), 16, 0, 0);
+  }
+}
+template <int DIM>
+__device__ __forceinline__ PState prec_collect_pair(const double2* st, int lane, int which) {
+  const double2* mine = st + lane * 8;
+  const int sub = lane & 7, b = 4 * which;
+  PState s;
+  s.m = 0;
+  s.x = s.y = s.z = 0;
+  if (DIM == 3) {
+    const double2 q0 = mine[(b + 0) ^ sub];
+    s.x = q0.x;
+    s.y = q0.y;
+    s.z = mine[(b + 1) ^ sub].x;
+  }
+  const uint4 q3 = *(const uint4*)(mine + ((b + 3) ^ sub));
   s.phi = __uint_as_float(q3.y);
   s.b = __uint_as_float(q3.z);
   s.id = q3.w;
@@ -1507,7 +1542,9 @@ __device__ __forceinline__ void walk_pending(const PendEntry* __restrict__ regio
     }
   }
 }
-template <int DIM, int OCC, bool NT, bool RECIN = false>
+// RECIN: 0 SoA input; 1 record-fed, one column per fetch; 2 record-fed, unseeded search on row-major records: the
+// element record once per tile, two columns (one cache line per row) per fetch
+template <int DIM, int OCC, bool NT, int RECIN = 0>
 __global__ void __launch_bounds__(256, OCC)
     k_push_walk_rowsq(const int* __restrict__ ntiles_dev, int C, int TP,
                       const int* __restrict__ tiles, const int* __restrict__ chunk_start,
@@ -1545,7 +1582,7 @@ __global__ void __launch_bounds__(256, OCC)
     const int cw = chunk_width[c];
     pend = min(p0 + TP, cw);
     e = r2e[c * C + r];
-    rbase = (RECIN && rin.rm) ? chunk_start[c] + r * cw : start;
+    rbase = (RECIN && rin.rm) ? pp_rec_row0(chunk_start[c], c, r, cw, C) : start;
   }
   const ppm::ClassTerm ct = ppm::class_term((valid && e < nelems) ? class_id[e] : 1, deg, DIM == 3);
   const bool read_ids = seeded != 0;  // (2-D without seeds: every seed is -1, the row's element)
@@ -1626,6 +1663,53 @@ __global__ void __launch_bounds__(256, OCC)
     // ---- record-fed form: particle records through the LDS (prec_issue / prec_collect), element records through
     // the other half of the wave's staging area.  At the top of column p the DMA of column p has landed; the
     // state is read out, the DMA of column p + 1 goes into the same buffer and overlaps the arithmetic of p.
+    // -- unseeded search on row-major records (the rebuilt-every-step flows): every live particle starts in its
+    // row's element, so the element record is fetched ONCE per tile, up front, and from then on the wave's whole
+    // staging area belongs to the particle records: two columns = one cache line per row per fetch
+    // (prec_issue_pair).  The pair of columns (p + 2, p + 3) is DMA'd while column p + 1 computes.
+    if constexpr (RECIN == 2) {  // (the host checks: row-major records, no seeds, an even tile width)
+      if (!thin) {
+        const int want0 = (valid && e < nelems && p0 < pend && mask[start + p0 * C] != 0) ? e : -1;
+        if (__ballot(want0 >= 0) != 0ull) coop_fetch<DIM>(cache, recs, want0, st, lane);
+      }
+      unsigned char ma = 0, mb = 0, ma_n = 0, mb_n = 0;
+      {
+        const bool first = !thin && p0 < pend;
+        prec_issue_pair(rin.rec, first ? rbase + p0 : -1, st, lane);
+        if (first) ma = mask[start + p0 * C];
+        if (first && p0 + 1 < pend) mb = mask[start + (p0 + 1) * C];
+      }
+      for (int i = 0; i < (thin ? 0 : TP); ++i) {  // wave-uniform trip count; ONE column per iteration, one fetch per two
+        const int p = p0 + i, pid = start + p * C, which = i & 1;
+        const bool act = p < pend;
+        if (which == 0) {
+          __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the pair's records (and its mask bytes)
+          wave_lds_sync();
+        }
+        PState s = prec_collect_pair<DIM>(st, lane, which);
+        s.m = act ? (which ? mb : ma) : 0;
+        if (which == 1) {
+          wave_lds_sync();  // both columns are out: the area is free for the next pair
+          const bool nxt = act && p + 1 < pend && i + 1 < TP;
+          prec_issue_pair(rin.rec, nxt ? rbase + p + 1 : -1, st, lane);
+          if (nxt) {
+            ma_n = mask[pid + C];
+            mb_n = p + 2 < pend ? mask[pid + 2 * C] : 0;
+          }
+        }
+        const bool live = act && s.m;
+        int elem = live ? e : -1;
+        V3 dest{0, 0, 0};
+        const bool need = column_math<DIM, NT>(A, s, act, live, pid, ct, cache, elem, dest);
+        enqueue(need, pid, elem, dest, wq, qn, lt_mask);
+        if (which == 1) {
+          ma = ma_n;
+          mb = mb_n;
+        }
+      }
+      if (lane == 0) wave_cnt[gwave] = qn;
+      return;
+    }
     double2* const pst = st + 32 * NP;  // (DIM 3: 4 KB of element records + 4 KB of particle records)
     unsigned char m_cur = 0, m_nxt = 0;
     int e_cur = -1, e_nxt = -1;
@@ -2414,8 +2498,13 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
       if (mesh->dim == 2) {
         k_push_walk_rowsq<2, 4, true><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
       } else if (recin) {
-        const RecIn rin{ps->s_aos_live.as<char>(), (unsigned*)ps->data[2].p, (float*)ps->data[3].p, 0, ps->rec_rm ? 1 : 0};
-        k_push_walk_rowsq<3, 4, true, true><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS, rin);
+        static const int no_pairs = getenv("PP_NO_PAIR_FETCH") != nullptr ? 1 : 0;
+        const RecIn rin{ps->s_aos_live.as<char>(), (unsigned*)ps->data[2].p, (float*)ps->data[3].p, 0, ps->rec_rm ? 1 : 0,
+                        no_pairs};
+        if (ps->rec_rm && !elem_ids_seeded && (ps->tile_p & 1) == 0 && (ps->C & 1) == 0 && !no_pairs)
+          k_push_walk_rowsq<3, 4, true, 2><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS, rin);
+        else
+          k_push_walk_rowsq<3, 4, true, 1><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS, rin);
         ps->lazy_rec = 2;  // every member but the origin is in the SoA arrays now
       } else {
         k_push_walk_rowsq<3, 4, true><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
@@ -2437,7 +2526,7 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
     } else if (rgrid > 0) {
       if (mesh->dim == 2 && recin) {
         const RecIn rin{ps->s_aos_live.as<char>(), (unsigned*)ps->data[2].p, (float*)ps->data[3].p, zero_z,
-                        ps->rec_rm ? 1 : 0};
+                        ps->rec_rm ? 1 : 0, 0};
         k_push_walk_rows<2, 4, true><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS, rin);
         ps->lazy_rec = 2;
       } else if (mesh->dim == 2)
