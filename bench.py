@@ -246,7 +246,19 @@ class Stepper:
             if self.comm is not None and self.world > 1:
                 beat("pre-flight exchange")
                 t0 = time.perf_counter()
-                self.comm.selftest(5)
+                everywhere = self._selftest_everywhere()
+                if not everywhere and self.comm_kind != "rccl":
+                    raise RuntimeError("the pre-flight exchange failed on some rank (transport %s)" % self.comm_kind)
+                if not everywhere:
+                    # the RCCL data path returned an error or wrong contents on some rank (and did not hang -- a hang
+                    # is the watchdog's): every rank moves to the host-staged transport together, loudly
+                    sys.stderr.write("bench.py: the pre-flight exchange over RCCL failed on some rank; falling back to "
+                                     "the library's host-staged TCP transport: NOT an xGMI measurement\n")
+                    self.comm.destroy()
+                    self.comm_kind = "tcp"
+                    port = int(os.environ.get("PP_COMM_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
+                    self.comm = capi.Comm.tcp(os.environ.get("MASTER_ADDR", "127.0.0.1"), port, self.rank, self.world)
+                    self.comm.selftest(5)
                 self.preflight = {"ok": True, "seconds": time.perf_counter() - t0, "transport": self.comm.kind(),
                                   "what": "5-7 records of 80 B to every peer through the migration's count "
                                           "exchange + grouped send/recv, then the gyroSync all-reduce, contents "
@@ -363,6 +375,25 @@ class Stepper:
             if self.w["dim"] == 2:
                 self.ids.fill_bytes(0xff)  # (dim 3, unseeded: the search writes every slot itself)
         # "2d": search_mesh_2d re-seeds from the previous ids as given
+
+    def _selftest_everywhere(self):
+        """pp_comm_selftest on this rank, then the verdict of ALL ranks over the host-side control plane"""
+        import torch
+        import torch.distributed as dist
+        ok = 1
+        try:
+            self.comm.selftest(5)
+        except self.capi.PPError as e:
+            sys.stderr.write("bench.py: rank %d: pre-flight exchange failed: %s\n" % (self.rank, e))
+            ok = 0
+        if not (dist.is_available() and dist.is_initialized()):
+            if not ok:
+                raise RuntimeError("pre-flight exchange failed and there is no control plane to agree on a fallback")
+            return True
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item()) == 1
 
     def _make_comm(self):
         """pp_comm over RCCL: rank 0 draws the id, torch.distributed (the host-side control plane) broadcasts
@@ -527,9 +558,27 @@ def also_c2(pp, capi, a, w_main, st_main):
     st = Stepper(pp, capi, w, "c2", a.deg)
     dt = _time_steps(capi, st, 12, 20)
     n = w["ps"].nPtcls()
-    return {"workload": "configs[1]: %s, %d particles, push+search only, ids re-used as seeds" % (w["label"], n),
-            "ms_per_step": dt * 1e3, "value": n / dt, "unit": "particles/s", "steps": 20, "warmup": 12,
-            "bytes_per_particle": BYTES["c2"], "roofline_frac": BYTES["c2"] * n / dt / 1e9 / HBM_PEAK_GBS}
+    out = {"workload": "configs[1]: %s, %d particles, push+search only, ids re-used as seeds" % (w["label"], n),
+           "ms_per_step": dt * 1e3, "value": n / dt, "unit": "particles/s", "steps": 20, "warmup": 12,
+           "bytes_per_particle": BYTES["c2"], "roofline_frac": BYTES["c2"] * n / dt / 1e9 / HBM_PEAK_GBS}
+    # Config 2 never rebuilds: with every step more particles have left the element of their row, the walk starts
+    # from per-particle seed records instead of the row's one, and the SAME call gets slower.  HIP events around
+    # every step of a fresh structure show the whole curve (step 1: every particle in its row's element, no seeds).
+    del st, w
+    w = build_workload(pp, capi, "c2", a.particles, 0, 1, a.deg, a.remainder, "100k", a.sigma)
+    st = Stepper(pp, capi, w, "c2", a.deg)
+    st.sample_every = 1
+    clock_prewarm(capi, float(os.environ.get("PP_BENCH_PREWARM", "0.3")))
+    for _ in range(32):
+        st.step(timed=True)
+    capi.sync()
+    ms = [e0.elapsed_ms(e1) for e0, e1, _ in st.kernel_ms]
+    out["ms_of_step_on_a_fresh_structure"] = {str(i): ms[i - 1] for i in (1, 2, 3, 4, 8, 16, 24, 32)}
+    out["roofline_frac_fastest_step"] = BYTES["c2"] * n / min(ms) / 1e6 / HBM_PEAK_GBS
+    out["note"] = ("no rebuild in config 2: the structure loses its element locality step by step (the curve above: "
+                   "a HIP event pair around every step, which adds ~10 us to each); ms_per_step is wall clock over "
+                   "steps 13-32 of the first structure")
+    return out
 
 
 def also_c2mt(pp, capi, a, w_main, st_main):

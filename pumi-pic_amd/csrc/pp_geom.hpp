@@ -72,17 +72,19 @@ constexpr double kEpsilon = 1e-10;  // src/pumipic_constants.hpp:6
 // and NaN for +-inf / NaN, so the quotient is never formed: (|a|/|a| <= tol) == (finite && 1 <= tol)
 PPD bool gtez(double a, double tol) {
   const double am = fabs(a);
-  const bool close = (am <= tol) || (am < __builtin_inf() && 1.0 <= tol);
-  return close || a > 0;
+  // (non-short-circuit & and |: the operands have no side effects, and on the device a short-circuit chain is a chain
+  // of exec-mask branches around three instructions each)
+  const bool close = (am <= tol) | ((am < __builtin_inf()) & (1.0 <= tol));
+  return close | (a > 0);
 }
 PPD bool all_positive3(const double* a, double tol) {
   bool p = true;
-  for (int i = 0; i < 3; ++i) p = p && gtez(a[i], tol);
+  for (int i = 0; i < 3; ++i) p = p & gtez(a[i], tol);
   return p;
 }
 PPD bool all_positive4(const double* a, double tol) {
   bool p = true;
-  for (int i = 0; i < 4; ++i) p = p && gtez(a[i], tol);
+  for (int i = 0; i < 4; ++i) p = p & gtez(a[i], tol);
   return p;
 }
 PPD int min3(const double* a) {
@@ -332,12 +334,12 @@ PPD void sincos_det(double x, double& s, double& c) {
     n = (int)((long long)fn & 3);
   }
   const double sn = ksin(y0, y1), cs = kcos(y0, y1);
-  switch (n & 3) {
-    case 0: s = sn; c = cs; break;
-    case 1: s = cs; c = -sn; break;
-    case 2: s = -sn; c = -cs; break;
-    default: s = -cs; c = sn; break;
-  }
+  // quadrant n: (s, c) = (sn, cs), (cs, -sn), (-sn, -cs), (-cs, sn) -- as selects (a four-way switch is four
+  // exec-mask branches per call on the device)
+  const bool odd = (n & 1) != 0;
+  const double ss = odd ? cs : sn, cc = odd ? sn : cs;
+  s = (n & 2) ? -ss : ss;
+  c = ((n + 1) & 2) ? -cc : cc;
 }
 
 }  // namespace ppg

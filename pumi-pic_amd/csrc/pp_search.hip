@@ -1321,15 +1321,21 @@ __device__ __forceinline__ PState prec_collect(const double2* pst, int lane) {
 // Two columns at once: with row-major records of even pitch (pp_rec_row0) the records of columns (2j, 2j + 1) of a row
 // are ONE 128-byte line; 8 lanes fetch it (as for an element record), the pair lands in the wave's whole 8 KB area.
 __device__ __forceinline__ void prec_issue_pair(const char* __restrict__ rec, int my_ri, double2* st, int lane) {
+  // One wave-uniform test instead of one exec-mask branch per instruction: the rows of a tile have their pair or
+  // none has (a wave of C = 64 rows is one tile); where a wave holds rows of two tiles (C < 64, the grid's last
+  // wave) the rows without a pair re-fetch the line of a row that has one -- into staging nobody reads.
+  const unsigned long long have = __ballot(my_ri >= 0);
+  if (have == 0ull) return;
+  const int any_ri = __shfl(my_ri, (int)__builtin_ctzll(have));
   const int sub = lane & 7;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int o = 8 * j + (lane >> 3);
-    const int ri = __shfl(my_ri, o);
+    int ri = __shfl(my_ri, o);
+    ri = ri >= 0 ? ri : any_ri;
     const int piece = sub ^ (o & 7);
-    if (ri >= 0)
-      __builtin_amdgcn_global_load_lds((const void*)(rec + (long long)ri * 64 + piece * 16),
-                                       (__attribute__((address_space(3))) void*)(st + j * 64), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const void*)(rec + (long long)ri * 64 + piece * 16),
+                                     (__attribute__((address_space(3))) void*)(st + j * 64), 16, 0, 0);
   }
 }
 template <int DIM>
