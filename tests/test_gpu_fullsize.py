@@ -282,14 +282,28 @@ def test_tet_c3_full_size_properties(pp, capi):
     the population is conserved by particle id, every particle sits in the row of the element the walk
     gave it (verified with an independent numpy barycentric test on a sample), x <- x_tgt / x_tgt <- 0,
     and the scatter fields carry 2 rings x 4 vertices x mapped fraction of every particle."""
-    w = bench.build_workload(pp, capi, "c3", 10_000_000, 0, 1, 0.5)
+    _tet_c3_properties(pp, capi, 10_000_000, "100k", 3)
+
+
+@pytest.mark.skipif(not os.environ.get("PP_TEST_BIG"), reason="opt-in (PP_TEST_BIG=<particles>): minutes of host work")
+def test_tet_c3_byte_offsets_beyond_int32(pp, capi):
+    """The same properties with a population whose member arrays are longer than 2^31 BYTES (one GPU, 288 GB of HBM:
+    PP_TEST_BIG=300000000 on the 998 400-tet mesh -- 8-byte members end at byte 2.4e9 of their array, the 64-byte
+    records at 1.9e10): every slot -> address product in the kernels has to be 64-bit."""
+    n = int(os.environ["PP_TEST_BIG"])
+    assert n * 8 > 2**31
+    _tet_c3_properties(pp, capi, n, "1m", 2)
+
+
+def _tet_c3_properties(pp, capi, nparticles, mesh_name, steps):
+    w = bench.build_workload(pp, capi, "c3", nparticles, 0, 1, 0.5, "last", mesh_name)
     s = pp.synth
     mesh, ps = w["mesh"], w["ps"]
     fwd, bkwd = capi.create_gyro_ring_mappings(mesh)
     wf, wb = capi.DevArray(mesh.nverts, np.float64), capi.DevArray(mesh.nverts, np.float64)
     n0 = ps.nPtcls()
     rng = np.random.default_rng(9)
-    for step in range(3):
+    for step in range(steps):
         cap = ps.capacity()
         ids = capi.DevArray(cap + cap // 10, np.int32)
         capi.push_search(mesh, ps, s.XGC_H, s.XGC_K, s.XGC_D, 0.5, ids, seeded=False, looplimit=200)
