@@ -176,6 +176,18 @@ struct GyroRide;
 __host__ __device__
 #endif
 inline int pp_rec_row0(int chunk_start, int c, int r, int w, int C) { return chunk_start + C * c + r * (w + (w & 1)); }
+namespace pp {
+// (see pp_ps::hot) columns [c1p, w) of row `row` of chunk `chunk`, whose first slot is `start`, hold particles of
+// that row only
+struct HotRow {
+  int on = 0;
+  int chunk = 0, row = 0;
+  int c1p = 0;    // multiple of 32: a tile group of the histogram, four 8-column blocks of the pack
+  int w = 0;      // the row's particle count
+  int start = 0;  // chunk_start[chunk]
+};
+}  // namespace pp
+
 struct pp_ps {
   int kind = PP_SCS;
   int num_elems = 0, num_ptcls = 0, capacity = 0, num_rows = 0;
@@ -245,6 +257,13 @@ struct pp_ps {
   // of every element's row in the current / the new layout.
   bool rec_rm = false;
   pp::DevBuf d_erec0, s_erec0;
+  // One over-full row at the end of the CURRENT layout (pseudoXGCm's remainder rule puts 60 000 particles into
+  // one element, pseudoXGCm.cpp:167-222): with a full sort the rows are in ascending order of their counts, so it
+  // is the last row of the last chunk, and beyond the second-largest count the chunk's other 63 rows are padding
+  // -- 3.8 M slots that the histogram and the first pass of the next re-layout would visit to find 60 000
+  // particles.  Set by a full re-layout (chunk height 64, one sort window, row-major records), cleared by anything
+  // that changes rows in place.
+  pp::HotRow hot;
   pp::DevBuf s_rs, s_holes;  // in-place rebuild: per-element counters, per-row hole lists
   // pinned landing zone of the rebuild's totals (host-mapped) + its event, and the stamp the host polls for
   void* h_totals = nullptr;

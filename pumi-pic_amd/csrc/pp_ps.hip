@@ -118,6 +118,96 @@ __global__ void k_init_slots_tiled4(InitSlotsArgs a) {
   if (!*a.go) return;
   init_slots_tiled4_body(a, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
 }
+// (pp_ps::hot) Histogram and ranks of the columns [c1p, w) of the over-full row: thread = four consecutive columns,
+// block = 1024 of them.  The particles that stay get consecutive ranks in column order behind ONE atomic per block
+// (the next re-layout stores them as one run); the ones that leave go to a handful of neighbours: an LDS table of
+// up to 16 destinations, one atomic per destination and block.
+constexpr int kHotCols = 4;
+__device__ __forceinline__ void count_hot_row(const pp::HotRow& hot, unsigned blk, int C, const int* __restrict__ r2e,
+                                              const unsigned char* __restrict__ mask,
+                                              const int* __restrict__ new_element, int ne, int* __restrict__ ppe,
+                                              Totals* tot, int* __restrict__ rank) {
+  __shared__ int h_key[16], h_cnt[16], h_base[16];
+  __shared__ int w_stay[4], s_stay_base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 16) {
+    h_key[tid] = -1;
+    h_cnt[tid] = 0;
+  }
+  __syncthreads();
+  const int e = r2e[hot.chunk * C + hot.row];
+  const int col0 = hot.c1p + (int)(blk * 256 + tid) * kHotCols;
+  const long long slot0 = (long long)hot.start + hot.row;
+  int nel[kHotCols], slot[kHotCols], loc[kHotCols];  // slot: -1 none, -2 stays, -3 own atomic (rank in loc), >= 0 table entry
+  int nstay = 0;
+#pragma unroll
+  for (int j = 0; j < kHotCols; ++j) {
+    const int p = col0 + j;
+    nel[j] = -1;
+    if (p < hot.w) {
+      const long long pid = slot0 + (long long)p * C;
+      if (mask[pid]) nel[j] = new_element[pid];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kHotCols; ++j) {
+    slot[j] = -1;
+    loc[j] = -1;
+    const int ne_ = nel[j];
+    if (ne_ == -1) continue;
+    if (ne_ < 0 || ne_ >= ne) {
+      tot->invalid = 1;
+      continue;
+    }
+    if (ne_ == e) {
+      slot[j] = -2;
+      loc[j] = nstay++;
+      continue;
+    }
+    int k = 0;
+    for (; k < 16; ++k) {
+      int cur = h_key[k];
+      if (cur == -1) cur = atomicCAS(&h_key[k], -1, ne_);
+      if (cur == -1 || cur == ne_) break;
+    }
+    if (k < 16) {
+      slot[j] = k;
+      loc[j] = atomicAdd(&h_cnt[k], 1);
+    } else {
+      slot[j] = -3;
+      loc[j] = atomicAdd(&ppe[ne_], 1);
+    }
+  }
+  // exclusive scan of the stay counts over the block (column order)
+  int inc = nstay;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(inc, o);
+    if (lane >= o) inc += y;
+  }
+  if (lane == 63) w_stay[wave] = inc;
+  __syncthreads();
+  int before = inc - nstay;
+  for (int w = 0; w < wave; ++w) before += w_stay[w];
+  if (tid == 0) {
+    const int total = w_stay[0] + w_stay[1] + w_stay[2] + w_stay[3];
+    s_stay_base = total ? atomicAdd(&ppe[e], total) : 0;
+  }
+  if (tid < 16 && h_key[tid] != -1) h_base[tid] = atomicAdd(&ppe[h_key[tid]], h_cnt[tid]);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kHotCols; ++j) {
+    const int p = col0 + j;
+    if (p >= hot.w) continue;
+    int rk = -1;
+    if (slot[j] == -2)
+      rk = s_stay_base + before + loc[j];
+    else if (slot[j] == -3)
+      rk = loc[j];
+    else if (slot[j] >= 0)
+      rk = h_base[slot[j]] + loc[j];
+    rank[slot0 + (long long)p * C] = rk;
+  }
+}
 // ---- row-tiled histogram of new parents (SCS): thread = (old tile, row).  Particles that stay in
 // their element are counted in a register and leave as ONE atomic per thread, and so do the movers
 // that share one of the first three other destinations of the thread's run.  Lanes of a wave are
@@ -127,7 +217,12 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
                               const int* __restrict__ chunk_width, const int* __restrict__ r2e,
                               const unsigned char* __restrict__ mask,
                               const int* __restrict__ new_element, int ne, int* __restrict__ ppe,
-                              Totals* tot, int* __restrict__ rank, int merge) {
+                              Totals* tot, int* __restrict__ rank, int merge, pp::HotRow hot = pp::HotRow{},
+                              unsigned main_blocks = ~0u) {
+  if (blockIdx.x >= main_blocks) {  // (pp_ps::hot) the columns only the over-full row has particles in
+    count_hot_row(hot, blockIdx.x - main_blocks, C, r2e, mask, new_element, ne, ppe, tot, rank);
+    return;
+  }
   // thread = (group of G consecutive tiles, row), G*TP <= 32: consecutive tiles of one chunk are
   // the same row of the same element, so the stayers of up to 32 columns cost ONE atomic (the L2
   // atomic rate, not the 5 B/particle read, bounds this kernel).  The atomics RETURN the old count:
@@ -166,6 +261,7 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
     const int tile = grp * G + k;
     if (tile >= ntiles) break;
     const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
+    if (hot.on && c == hot.chunk && p0 >= hot.c1p) continue;  // (the hot blocks' columns: the other rows are padding there)
     if (c != cur) {
       flush();
       cur = c;
@@ -526,6 +622,9 @@ __global__ void __launch_bounds__(1024)
     tot->nslices = carry[0];
     tot->capacity = carry[1];
     *ntiles_out = carry[2];
+    // (pp_ps::hot: with one sort window the keys are the counts in ascending order)
+    tot->second_key1 = (keys_sorted && ne >= 2 && nchunks >= 1 && keys_sorted[ne - 2] < (1ull << 30)) ? (int)keys_sorted[ne - 2] + 1 : 0;
+    tot->last_chunk_start = nchunks >= 1 ? chunk_start[nchunks - 1] : 0;
     // the speculative tail's gate (k_spec_check) rides here: one launch less per rebuild
     if (sp.on) spec_decide(tot, sp.cap_lim, sp.nsl_lim, sp.C_max, key_bits, sp.keep_if_fits);
     // the totals, final now, straight into the host's pinned landing zone: no copy dispatch (4 us + a 6 us gap
@@ -873,7 +972,8 @@ __global__ void k_move_pack(int capacity, const int* __restrict__ new_idx, RankT
 // 256 contiguous bytes per row instead of four 64-byte stores 4 KB apart (c3: 294 -> 224 us for the pass).
 template <int NQ>
 __global__ void k_move_pack_rm(int capacity, const int* __restrict__ new_idx, RankToSlot rs,
-                               uint4* __restrict__ aos, WordTable t, const int* __restrict__ go, int wide) {
+                               uint4* __restrict__ aos, WordTable t, const int* __restrict__ go, int wide,
+                               pp::HotRow hot = pp::HotRow{}, unsigned main_blocks = ~0u) {
   if (go && !*go) return;
   __shared__ uint4 st[256][NQ + 1];
   __shared__ int sd[256];
@@ -881,7 +981,14 @@ __global__ void k_move_pack_rm(int capacity, const int* __restrict__ new_idx, Ra
   // 32 rows -- block pairs share 8 columns, so a row's run is up to 8 records = 512 contiguous bytes
   const int tid = threadIdx.x;
   int pid, li;  // li = LDS index: records of one row adjacent
-  if (wide) {  // wide = log2(columns per block), chunk height 64: 2^wide columns x (256 >> wide) rows
+  if (blockIdx.x >= main_blocks) {
+    // (pp_ps::hot; `capacity` ends the main blocks' slots where these columns begin) 256 columns of the over-full
+    // row: one run of up to 16 KB
+    const int p = hot.c1p + (int)(blockIdx.x - main_blocks) * 256 + tid;
+    pid = p < hot.w ? hot.start + p * 64 + hot.row : 0x7fffffff;
+    li = tid;
+    capacity = 0x7fffffff;
+  } else if (wide) {  // wide = log2(columns per block), chunk height 64: 2^wide columns x (256 >> wide) rows
     const int nrow = 256 >> wide, col = tid / nrow, row = tid - col * nrow;
     const int sub = blockIdx.x & ((64 / nrow) - 1);  // which group of rows of the column block
     pid = (blockIdx.x / (64 / nrow)) * (64 << wide) + col * 64 + sub * nrow + row;
@@ -1924,6 +2031,7 @@ int scs_reshuffle(pp_ps* ps, const int* new_element, int n_new, const int* new_e
   }
   ++ps->n_reshuffles;
   ps->lazy_rec = 0;  // (a commit that came in with only the origin in records: the origin is the old target now)
+  ps->hot = pp::HotRow{};  // (rows changed in place)
   return 1;
 }
 
@@ -1967,11 +2075,20 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   int* rank = ps->s_idx.as<int>();
   int* rank_new = ps->s_ranknew.as<int>();
   static const bool no_count_merge = getenv("PP_NO_COUNT_MERGE") != nullptr;
-  if (have_old && old_grid > 0)
-    k_count_tiled<<<grp_grid, kBlock, 0, st>>>(
+  // (pp_ps::hot) the over-full row's own columns go through their own blocks -- in the steady state of the
+  // record-fed loop, where this rebuild takes the row-major staged path again (the test at the top of this function)
+  static const bool no_hot = getenv("PP_NO_HOT_ROW") != nullptr;
+  const bool steady = ps->lazy_rec == 2 && ps->zero_pending < 0 && (n_new == 0 || new_xt_zero) && commit_x >= 0 &&
+                      commit_x == ps->lazy_x && commit_xt == ps->lazy_xt;
+  const pp::HotRow hot_now =
+      (steady && ps->rec_rm && ps->hot.on && have_old && old_grid > 0 && ps->C == 64 && !no_hot) ? ps->hot : pp::HotRow{};
+  if (have_old && old_grid > 0) {
+    const unsigned hot_blocks = hot_now.on ? (unsigned)((hot_now.w - hot_now.c1p + 256 * kHotCols - 1) / (256 * kHotCols)) : 0u;
+    k_count_tiled<<<grp_grid + hot_blocks, kBlock, 0, st>>>(
         ps->d_ntiles.as<int>(), ps->C, ps->tile_p, G, ps->d_tiles.as<int>(),
         ps->d_chunk_start.as<int>(), ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(),
-        ps->d_mask.as<unsigned char>(), new_element, ne, ppe, tot, rank, no_count_merge ? 0 : 1);
+        ps->d_mask.as<unsigned char>(), new_element, ne, ppe, tot, rank, no_count_merge ? 0 : 1, hot_now, grp_grid);
+  }
   if (n_new > 0) {
     k_count_added<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ne, ppe, tot, rank_new);
   }
@@ -2194,8 +2311,8 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
 #define PP_STAGED(N)                                                                             \
   case N:                                                                                        \
     if (use_rm)                                                                                  \
-      k_move_pack_rm<N><<<(grid_for(ps->capacity) + 15) / 16 * 16, kBlock, 0, st>>>(ps->capacity, rank, rs_rm, aos, wt, go, \
-                                                                                  ps->C == 64 ? rm_wide : 0); \
+      k_move_pack_rm<N><<<pack_main + pack_hot, kBlock, 0, st>>>(pack_end, rank, rs_rm, aos, wt, go, \
+                                                                 ps->C == 64 ? rm_wide : 0, hot_now, pack_main); \
     else                                                                                         \
       k_move_pack<N><<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, rank, rs, aos, wt, go); \
     if (!defer_unpack) k_move_unpack<N><<<new_grid, kBlock, 0, st>>>(PP_UNPACK_ARGS);            \
@@ -2209,6 +2326,11 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       // their row: c3 -3.3 %, 2dc3 -3.6 %, c5 share -3.2 %.  ps_combo160 redistributes half of its particles to
       // random elements: nothing to merge, and its second pass reads row-major records 2.5 % slower)
       use_rm = want_rm && defer_unpack;
+      PP_REQUIRE(!hot_now.on || use_rm, "rebuild (internal): the over-full row's blocks need the row-major staged path");
+      // (pp_ps::hot) the main blocks end where the columns of the over-full row begin, its own blocks follow
+      const int pack_end = hot_now.on ? hot_now.start + 64 * hot_now.c1p : ps->capacity;
+      const unsigned pack_main = (grid_for(pack_end) + 15) / 16 * 16;
+      const unsigned pack_hot = hot_now.on ? (unsigned)((hot_now.w - hot_now.c1p + 255) / 256) : 0u;
       switch (NQ) {
         PP_STAGED(1) PP_STAGED(2) PP_STAGED(3) PP_STAGED(4) PP_STAGED(6) PP_STAGED(8) PP_STAGED(10) PP_STAGED(12)
       }
@@ -2319,6 +2441,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       if (rc) return rc;
     }
     if (ps->capacity > 0) PP_HIP_CHECK(hipMemsetAsync(ps->d_mask.p, 0, (size_t)ps->capacity, st));
+    ps->hot = pp::HotRow{};
     ps->d_elem_count.swap(ps->s_ppe);  // the histogram just built: all zeros
     ps->elem_count_valid = true;
     ps->version = pp::next_version();
@@ -2328,9 +2451,9 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   static const bool spec_debug = getenv("PP_SPEC_DEBUG") != nullptr;
   if (spec_debug)
     fprintf(stderr, "rebuild: speculated %d go %d capacity %d (old %d) nslices %d active %d nonempty %d "
-                    "key bits sorted %d max key %llu\n",
+                    "key bits sorted %d max key %llu; over-full row's blocks %d (columns %d..%d)\n",
             (int)speculated, h.go, h.capacity, ps->capacity, h.nslices, h.active, h.nonempty, L.key_bits,
-            h.max_key);
+            h.max_key, hot_now.on, hot_now.c1p, hot_now.w);
   if (!(speculated && h.go)) {
     // chooseChunkHeight (SCS_buildFns.h:3-16): C shrinks only when fewer than C_max elements hold
     // particles -- redo the (tiny) layout with that height; same when the predicted number of
@@ -2368,6 +2491,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   std::swap(ps->stride, ps->swap_stride);
   ps->zero_pending = lazy_zero ? commit_xt : -1;
   ps->lazy_rec = 0;
+  ps->hot = pp::HotRow{};
   if (defer_unpack && NQ == 4) {  // the records of the first pass are what holds the particles now
     ps->s_aos.swap(ps->s_aos_live);
     ps->lazy_rec = 1;
@@ -2375,6 +2499,18 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     ps->lazy_xt = commit_xt;
     ps->rec_rm = use_rm;
     if (use_rm) ps->d_erec0.swap(ps->s_erec0);
+    // (pp_ps::hot) one sort window: the rows are in ascending order of their counts, the last row holds the largest
+    if (use_rm && C_new == 64 && h.second_key1 > 0 && h.max_key < (1ull << 30) && !no_hot) {
+      const int c1p = (h.second_key1 - 1 + 31) / 32 * 32, w = (int)h.max_key;
+      if (w - c1p >= 2048) {
+        ps->hot.on = 1;
+        ps->hot.chunk = nchunks - 1;
+        ps->hot.row = (ne - 1) % 64;
+        ps->hot.c1p = c1p;
+        ps->hot.w = w;
+        ps->hot.start = h.last_chunk_start;
+      }
+    }
   }
   ps->d_offsets.swap(ps->s_offsets2);
   ps->d_slice_to_chunk.swap(ps->s_s2c2);

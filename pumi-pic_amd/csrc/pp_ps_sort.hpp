@@ -27,7 +27,9 @@ struct Totals {  // s_misc layout
   // "no home found for an overflowing row"
   int n_over;    // rows whose new count exceeds their chunk width (the reference then re-lays out)
   int sort_bad;  // one-pass layout sort: more keys in the overflow digit than its fix-up holds (re-sort with every pass)
-  int pad_[2];
+  int pad_[2];   // ([0]: the stamp the host polls for)
+  int second_key1;       // 1 + the second-largest count of a one-window sort (0: not known) and the first slot of
+  int last_chunk_start;  // the last chunk: what pp_ps::hot is made of
 };
 
 // ---- stable LSD radix sort (8-bit digits) of (key64, val32)

@@ -984,6 +984,74 @@ def test_pseudo_xgcm_steps_3d(ppo, synth, capi, trust):
     _check_same_population(po, pg, ppo.PARTICLE_XGCM)
 
 
+@pytest.mark.parametrize("gap,slow", [(3000, True), (9000, True), (9000, False)])
+def test_pseudo_xgcm_steps_3d_over_full_row(ppo, synth, capi, gap, slow):
+    """The same loop on a population with ONE over-full element (pseudoXGCm's remainder rule, pseudoXGCm.cpp:167-222):
+    with a full sort it is the last row of the last chunk, and in the steady state of the record-fed loop the
+    histogram and the first pass of the re-layout visit its own columns through their own blocks (pp_ps::hot;
+    PP_NO_HOT_ROW=1 is the A/B knob).  Layout arrays, element ids by particle id, every member and the scatter
+    sums equal the oracle's after every step; particles leave the element and arrive in it on the way."""
+    coords, e2v, cls = synth.torus_tet(n_b=5, n_theta=20, n_planes=8)
+    # (a few hundred populated elements: with fewer than 64 the chunk height shrinks, SCS_buildFns.h:3-16)
+    rng = np.random.default_rng(7)
+    marked = np.flatnonzero(cls <= 5)
+    ppe = np.zeros(len(e2v), dtype=np.int32)
+    some = rng.choice(marked, size=min(400, len(marked)), replace=False)
+    ppe[some] = rng.integers(5, 40, size=len(some))
+    # slow: an element of class 1 (0.01 x the angle per push: its particles trickle out); else of the fastest class
+    # (the cloud crosses into the next elements within a few steps: thousands of arrivals in one row)
+    have = np.flatnonzero(ppe > 0)
+    pick = have[cls[have] == (cls[have].min() if slow else cls[have].max())]
+    big = int(pick[len(pick) // 2])
+    ppe[big] += gap
+    n = int(ppe.sum())
+    elem, xyz = synth.particles_in_elements(coords, e2v, ppe)
+    b, phi = synth.elliptical_state(np.hypot(xyz[0], xyz[1]), xyz[2])
+    pop = dict(dim=3, coords=coords, e2v=e2v, cls=cls, ppe=ppe, elem=elem,
+               info=[xyz, np.zeros_like(xyz), np.arange(n, dtype=np.int32), b, phi])
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
+    common.set_shuffling(po, pg)
+    fo, _ = ppo.create_gyro_ring_mappings(mo, trig=1)
+    fg, _ = capi.create_gyro_ring_mappings(mg)
+    deg = 0.5 if slow else 6.0
+    hot_steps = 0
+    for step in range(6):
+        ppo.toroidal_push(po, mo, H, K, D, deg, trig=1)
+        ids_o = ppo.search_mesh(mo, po, looplimit=200)["elem_ids"]
+        ids_g = capi.DevArray(max(pg.capacity(), 1), np.int32)
+        capi.push_search(mg, pg, H, K, D, deg, ids_g, seeded=False, looplimit=200)
+        io, eo = common.by_id(po.member(2)[0, :po.capacity()], po.slot_info()[1], ids_o[:po.capacity()])
+        ig, eg = common.by_id(pg.member(2)[0, :pg.capacity()], pg.slot_info()[1],
+                              ids_g.to_host()[:pg.capacity()]) if step == 0 else (None, None)
+        if step == 0:  # (reading members materialises the records: only before the steady state begins)
+            assert np.array_equal(io, ig) and np.array_equal(eo, eg)
+        if step == 3:  # a few of the over-full element's particles are removed on the way
+            kill = np.flatnonzero(ids_o[:po.capacity()] == big)[:50]
+            kill_ids = po.member(2)[0, kill]
+            ids_o = ids_o.copy()
+            ids_o[kill] = -1
+            hg = ids_g.to_host()
+            live_g = pg.slot_info()[1].astype(bool)
+            pid_g = pg.member(2)[0, :pg.capacity()]
+            hg[:pg.capacity()][np.isin(pid_g, kill_ids) & live_g] = -1
+            ids_g = capi.DevArray.from_host(hg)
+        ppo.update_positions(po)
+        po.rebuild(ids_o)
+        pg.rebuild_commit(ids_g, 0, 1)
+        assert po.nPtcls() == pg.nPtcls() > 0
+        lo, lg = po.layout(), pg.layout()
+        for k in ("offsets", "slice_to_chunk", "row_to_element"):
+            assert np.array_equal(lo[k], lg[k]), (step, k)
+        assert np.array_equal(ppo.gyro_scatter(mo, po, fo), capi.gyro_scatter(mg, pg, fg).to_host()), step
+        cnt = np.sort(np.bincount(lg["slot_elem"][lg["mask"].astype(bool)], minlength=len(e2v)))
+        hot_steps += int(cnt[-1] - cnt[-2] >= 2048 + 32)  # (the next rebuild goes through the over-full row's blocks)
+    assert po.slot_info()[1].sum() == pg.slot_info()[1].sum()
+    if slow:  # the over-full row was there to the end
+        assert hot_steps == 6
+    _check_same_population(po, pg, ppo.PARTICLE_XGCM)
+
+
 def _driver(name):
     import os
     import subprocess

@@ -13,6 +13,6 @@ for cfg in "PP_TILE_P=4" "PP_TILE_P=16" "PP_TILE_P=32" "PP_WALK_QUEUE=1" "PP_WAL
            "PP_NO_POLL_TOTALS=1" "PP_NO_SPEC_REBUILD=1" "PP_NO_LAZY_ZERO=1" \
            "PP_SCATTER_ATOMIC=1" "PP_SCATTER_FLAT=1" "PP_NO_STRIDE_SPREAD=1" "PP_NO_MEMBER_SKEW=1" \
            "PP_TEST_SHUFFLING=0" "PP_MT_PACKED=0" "PP_MT_PER_LANE=3" "PP_MT_START_BATCH=1" \
-           "PP_NO_REC_PAD=1" "PP_NO_RM_RECORDS=1" "PP_NO_PAIR_FETCH=1" "PP_RM_WIDE=0" "PP_NO_TABLES_SLOTS_MERGE=1" "PP_NO_COUNT_MERGE=1"; do
+           "PP_NO_REC_PAD=1" "PP_NO_RM_RECORDS=1" "PP_NO_PAIR_FETCH=1" "PP_RM_WIDE=0" "PP_NO_TABLES_SLOTS_MERGE=1" "PP_NO_COUNT_MERGE=1" "PP_NO_HOT_ROW=1"; do
   echo "== $cfg"; env $cfg timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -2
 done
