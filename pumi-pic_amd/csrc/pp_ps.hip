@@ -218,9 +218,11 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
                               const unsigned char* __restrict__ mask,
                               const int* __restrict__ new_element, int ne, int* __restrict__ ppe,
                               Totals* tot, int* __restrict__ rank, int merge, pp::HotRow hot = pp::HotRow{},
-                              unsigned main_blocks = ~0u) {
-  if (blockIdx.x >= main_blocks) {  // (pp_ps::hot) the columns only the over-full row has particles in
-    count_hot_row(hot, blockIdx.x - main_blocks, C, r2e, mask, new_element, ne, ppe, tot, rank);
+                              unsigned hot_blocks = 0u) {
+  // (pp_ps::hot) the columns only the over-full row has particles in: the FIRST blocks of the grid (each is a chain
+  // of round trips: at the end of the grid they would be the kernel's tail)
+  if (blockIdx.x < hot_blocks) {
+    count_hot_row(hot, blockIdx.x, C, r2e, mask, new_element, ne, ppe, tot, rank);
     return;
   }
   // thread = (group of G consecutive tiles, row), G*TP <= 32: consecutive tiles of one chunk are
@@ -229,7 +231,7 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
   // that is the particle's rank inside its new row, so the histogram pass is also the slot
   // assignment (slot = row start + rank*C once the layout is known) -- one atomic per particle per
   // rebuild instead of two.
-  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long g = (long long)(blockIdx.x - hot_blocks) * blockDim.x + threadIdx.x;
   const int grp = (int)(g / C), r = (int)(g - (long long)grp * C);
   const int ntiles = *ntiles_dev;
   int cur = -1, e = -1, start = 0, run_p0 = 0;
@@ -973,7 +975,7 @@ __global__ void k_move_pack(int capacity, const int* __restrict__ new_idx, RankT
 template <int NQ>
 __global__ void k_move_pack_rm(int capacity, const int* __restrict__ new_idx, RankToSlot rs,
                                uint4* __restrict__ aos, WordTable t, const int* __restrict__ go, int wide,
-                               pp::HotRow hot = pp::HotRow{}, unsigned main_blocks = ~0u) {
+                               pp::HotRow hot = pp::HotRow{}, unsigned hot_blocks = 0u) {
   if (go && !*go) return;
   __shared__ uint4 st[256][NQ + 1];
   __shared__ int sd[256];
@@ -981,20 +983,21 @@ __global__ void k_move_pack_rm(int capacity, const int* __restrict__ new_idx, Ra
   // 32 rows -- block pairs share 8 columns, so a row's run is up to 8 records = 512 contiguous bytes
   const int tid = threadIdx.x;
   int pid, li;  // li = LDS index: records of one row adjacent
-  if (blockIdx.x >= main_blocks) {
+  const unsigned bid = blockIdx.x - hot_blocks;  // (of the main blocks)
+  if (blockIdx.x < hot_blocks) {
     // (pp_ps::hot; `capacity` ends the main blocks' slots where these columns begin) 256 columns of the over-full
-    // row: one run of up to 16 KB
-    const int p = hot.c1p + (int)(blockIdx.x - main_blocks) * 256 + tid;
+    // row: one run of up to 16 KB.  The first blocks of the grid, as in the histogram.
+    const int p = hot.c1p + (int)blockIdx.x * 256 + tid;
     pid = p < hot.w ? hot.start + p * 64 + hot.row : 0x7fffffff;
     li = tid;
     capacity = 0x7fffffff;
   } else if (wide) {  // wide = log2(columns per block), chunk height 64: 2^wide columns x (256 >> wide) rows
     const int nrow = 256 >> wide, col = tid / nrow, row = tid - col * nrow;
-    const int sub = blockIdx.x & ((64 / nrow) - 1);  // which group of rows of the column block
-    pid = (blockIdx.x / (64 / nrow)) * (64 << wide) + col * 64 + sub * nrow + row;
+    const int sub = bid & ((64 / nrow) - 1);  // which group of rows of the column block
+    pid = (bid / (64 / nrow)) * (64 << wide) + col * 64 + sub * nrow + row;
     li = (row << wide) + col;
   } else {
-    pid = blockIdx.x * 256 + tid;
+    pid = bid * 256 + tid;
     li = (tid & 63) * 4 + (tid >> 6);
   }
   const int rk = (pid < capacity) ? new_idx[pid] : -1;
@@ -2087,7 +2090,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     k_count_tiled<<<grp_grid + hot_blocks, kBlock, 0, st>>>(
         ps->d_ntiles.as<int>(), ps->C, ps->tile_p, G, ps->d_tiles.as<int>(),
         ps->d_chunk_start.as<int>(), ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(),
-        ps->d_mask.as<unsigned char>(), new_element, ne, ppe, tot, rank, no_count_merge ? 0 : 1, hot_now, grp_grid);
+        ps->d_mask.as<unsigned char>(), new_element, ne, ppe, tot, rank, no_count_merge ? 0 : 1, hot_now, hot_blocks);
   }
   if (n_new > 0) {
     k_count_added<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ne, ppe, tot, rank_new);
@@ -2312,7 +2315,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   case N:                                                                                        \
     if (use_rm)                                                                                  \
       k_move_pack_rm<N><<<pack_main + pack_hot, kBlock, 0, st>>>(pack_end, rank, rs_rm, aos, wt, go, \
-                                                                 ps->C == 64 ? rm_wide : 0, hot_now, pack_main); \
+                                                                 ps->C == 64 ? rm_wide : 0, hot_now, pack_hot); \
     else                                                                                         \
       k_move_pack<N><<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, rank, rs, aos, wt, go); \
     if (!defer_unpack) k_move_unpack<N><<<new_grid, kBlock, 0, st>>>(PP_UNPACK_ARGS);            \
