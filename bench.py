@@ -981,7 +981,11 @@ def main():
         cold_dt = timed_run(a.steps, trace=cold_trace)
         cold = {"ms_per_step": cold_dt / a.steps * 1e3,
                 "host_ms_of_each_step_then_closing_barrier": cold_trace,
-                "note": "the same W warm-up + K timed steps before the clock pre-warm (shader clock still ramping)"}
+                "note": "the same W warm-up + K timed steps before the clock pre-warm, on the population as built: "
+                        "the shader clock is still ramping AND the step gets faster as the population ages (per-element "
+                        "counts even out, the layout needs less padding: 0.639 ms in the first ten steps of a fresh c3 "
+                        "structure, 0.605 after seventy, tools/r04_age_exp.py) -- ms_per_step is measured on steps "
+                        "2W+K+1 .. 2W+2K of the structure's life"}
     clock_prewarm(capi, prewarm_s)
     for _ in range(a.warmup):
         st.step()
