@@ -91,6 +91,35 @@ def test_construction_matches_oracle(ppo, synth, capi, opp, case):
         c.destroy()
 
 
+@pytest.mark.parametrize("which", [0, 2])
+def test_full_mesh_parts_reference_checks(ppo, synth, capi, opp, which):
+    """test/test_full_mesh.cpp:32-59 on `Input(mesh, owners, FULL, FULL)`: every rank's picpart has the entity counts
+    of the serial mesh in EVERY dimension (:36-42) and its elements carry the serial mesh's global ids in the serial
+    order -- the `global_serial` tag of `:45-57`: the part's full-mesh ids are the identity -- and every element is
+    safe.  The 8-GPU configuration starts from exactly these parts."""
+    dim, c, e, k, owner = _mesh_arrays(synth, which)
+    P = int(owner.max()) + 1
+    mg = capi.Mesh(dim, c, e, k)
+    comms = capi.Comm.local(P)
+    parts = [capi.PicPart(mg, owner, comms[r], capi.PART_FULL, capi.PART_FULL, 0, 3, 1) for r in range(P)]
+    mo = ppo.Mesh(dim, c, e, k)
+    O = opp.PicParts(mo, owner, P, opp.FULL, opp.FULL, bridge_dim=0, buffer_layers=3, safe_layers=1)
+    serial = [len(c) if d == 0 else len(e) if d == dim else O.parts[0].nents[d] for d in range(dim + 1)]
+    for r, pg in enumerate(parts):
+        assert pg.is_full_mesh
+        for d in range(dim + 1):
+            assert pg.nents[d] == serial[d], (r, d)                                    # :36-42
+            assert np.array_equal(pg.array(capi.PART_FULL_IDS, d), np.arange(serial[d]))   # :45-57, every dimension
+            # (the PICpart's own global numbering goes owner by owner: a permutation, the same on every rank)
+            assert np.array_equal(np.sort(pg.array(capi.PART_GIDS, d)), np.arange(serial[d]))
+            assert np.array_equal(pg.array(capi.PART_GIDS, d), parts[0].array(capi.PART_GIDS, d))
+        assert pg.array(capi.PART_SAFE).all()
+        assert np.array_equal(pg.array(capi.PART_OWNERS, dim), owner)
+        assert (pg.mesh.nverts, pg.mesh.nelems) == (len(c), len(e))
+    for cm in comms:
+        cm.destroy()
+
+
 def test_tet_edges_match_oracle(ppo, synth, capi, opp):
     """entity dimension 1 of a tet mesh (Omega_h ask_down(3,1) / ask_up(1,3)): PP_MESH_ELEM2EDGES /
     EDGE2VERTS / EDGE2ELEMS equal the oracle's first-seen derivation; every edge is an edge of its tets"""
