@@ -212,6 +212,7 @@ __device__ __forceinline__ void count_hot_row(const pp::HotRow& hot, unsigned bl
 // their element are counted in a register and leave as ONE atomic per thread, and so do the movers
 // that share one of the first three other destinations of the thread's run.  Lanes of a wave are
 // different rows, so same-address contention inside a wave is gone.
+template <int NK, bool UNI>
 __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP, int G,
                               const int* __restrict__ tiles, const int* __restrict__ chunk_start,
                               const int* __restrict__ chunk_width, const int* __restrict__ r2e,
@@ -240,11 +241,18 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
   // leave into the few neighbours of its element, so most movers share a destination with another
   // mover of the same thread.  bit b of a mask = column run_p0 + b goes to that key.  A particle
   // whose destination finds no slot issues its own atomic at once.
-  int key1 = -1, key2 = -1, key3 = -1;
-  unsigned m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-  auto flush_one = [&](int key, unsigned m) {
+  // (NK keys; every index below is a constant after unrolling: the table stays in registers)
+  int key[NK];
+  unsigned mk_[NK];
+  unsigned m0 = 0;
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    key[k] = -1;
+    mk_[k] = 0;
+  }
+  auto flush_one = [&](int dest, unsigned m) {
     if (!m) return;
-    int idx = atomicAdd(&ppe[key], __popc(m));
+    int idx = atomicAdd(&ppe[dest], __popc(m));
     while (m) {
       const int b = __ffs(m) - 1;
       m &= m - 1;
@@ -253,16 +261,25 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
   };
   auto flush = [&]() {
     flush_one(e, m0);
-    flush_one(key1, m1);
-    flush_one(key2, m2);
-    flush_one(key3, m3);
-    m0 = m1 = m2 = m3 = 0;
-    key1 = key2 = key3 = -1;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      flush_one(key[k], mk_[k]);
+      key[k] = -1;
+      mk_[k] = 0;
+    }
+    m0 = 0;
   };
   for (int k = 0; k < G; ++k) {
     const int tile = grp * G + k;
     if (tile >= ntiles) break;
-    const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
+    int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
+    if constexpr (UNI) {
+      // (chunk height 64) a wave is the 64 rows of ONE tile group: chunk, first column and width are the same in every lane -- said
+      // out loud, the compiler keeps them (and the bounds tests and half of the address arithmetic below) on the
+      // scalar unit
+      c = __builtin_amdgcn_readfirstlane(c);
+      p0 = __builtin_amdgcn_readfirstlane(p0);
+    }
     if (hot.on && c == hot.chunk && p0 >= hot.c1p) continue;  // (the hot blocks' columns: the other rows are padding there)
     if (c != cur) {
       flush();
@@ -299,24 +316,23 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
             deferred = true;
             if (ne_ == e) {
               m0 |= bit;
-            } else if (ne_ == key1) {
-              m1 |= bit;
-            } else if (ne_ == key2) {
-              m2 |= bit;
-            } else if (ne_ == key3) {
-              m3 |= bit;
-            } else if (key1 < 0) {
-              key1 = ne_;
-              m1 = bit;
-            } else if (key2 < 0) {
-              key2 = ne_;
-              m2 = bit;
-            } else if (key3 < 0) {
-              key3 = ne_;
-              m3 = bit;
             } else {
-              deferred = false;
-              rk = atomicAdd(&ppe[ne_], 1);
+              // The keys fill in order: the first free one ends the search.  As selects over the unrolled table: the
+              // if / else-if cascade this was compiled to one exec-mask branch per test and cost the kernel 10 %
+              // (66.4 -> 60.0 us; predicating the outer tests as well: 61.8).
+              bool placed = false;
+#pragma unroll
+              for (int k = 0; k < NK; ++k) {
+                if (!placed && (key[k] == ne_ || key[k] < 0)) {
+                  key[k] = ne_;
+                  mk_[k] |= bit;
+                  placed = true;
+                }
+              }
+              if (!placed) {
+                deferred = false;
+                rk = atomicAdd(&ppe[ne_], 1);
+              }
             }
           }
         }
@@ -2087,10 +2103,16 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       (steady && ps->rec_rm && ps->hot.on && have_old && old_grid > 0 && ps->C == 64 && !no_hot) ? ps->hot : pp::HotRow{};
   if (have_old && old_grid > 0) {
     const unsigned hot_blocks = hot_now.on ? (unsigned)((hot_now.w - hot_now.c1p + 256 * kHotCols - 1) / (256 * kHotCols)) : 0u;
-    k_count_tiled<<<grp_grid + hot_blocks, kBlock, 0, st>>>(
-        ps->d_ntiles.as<int>(), ps->C, ps->tile_p, G, ps->d_tiles.as<int>(),
-        ps->d_chunk_start.as<int>(), ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(),
-        ps->d_mask.as<unsigned char>(), new_element, ne, ppe, tot, rank, no_count_merge ? 0 : 1, hot_now, hot_blocks);
+    // (three keys beside the row's own element; six: 64.3 against 60.3 us at c3, 366 against 358 at the c5 share)
+#define PP_COUNT_ARGS                                                                                      \
+  ps->d_ntiles.as<int>(), ps->C, ps->tile_p, G, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(),        \
+      ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(), ps->d_mask.as<unsigned char>(), new_element, \
+      ne, ppe, tot, rank, no_count_merge ? 0 : 1, hot_now, hot_blocks
+    if (ps->C == 64)
+      k_count_tiled<3, true><<<grp_grid + hot_blocks, kBlock, 0, st>>>(PP_COUNT_ARGS);
+    else
+      k_count_tiled<3, false><<<grp_grid + hot_blocks, kBlock, 0, st>>>(PP_COUNT_ARGS);
+#undef PP_COUNT_ARGS
   }
   if (n_new > 0) {
     k_count_added<<<grid_for(n_new), kBlock, 0, st>>>(n_new, new_elems, ne, ppe, tot, rank_new);
