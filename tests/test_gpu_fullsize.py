@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import bench
+import common
 
 pytestmark = pytest.mark.gpu
 
@@ -338,6 +339,65 @@ def _tet_c3_properties(pp, capi, nparticles, mesh_name, steps):
         # 8 points x 4 mapped vertices (points outside the domain drop out)
         assert 0.8 * 32 * ps.nPtcls() <= f.sum() <= 32 * ps.nPtcls()
     assert ps.nPtcls() > 0.99 * n0
+
+
+@pytest.mark.parametrize("name", ["c3", "2dc3"])
+def test_c3_full_size_equals_oracle(pp, ppo, capi, name):
+    """configs[2] at BASELINE's size AGAINST THE ORACLE, particle by particle (tets: the north-star variant; 2dc3:
+    the 2-D literal of pseudoXGCm, 100 352 triangles, elliptical push + search_mesh_2d): 100 800 tets, 10 M particles (the
+    literal population: one element holds 60 000), three steps of what bench.py times -- pp_push_search without
+    seeds, pp_ps_rebuild_scatter with the commit and both ring maps -- in the steady state of the record-fed
+    loop (nothing reads a member between the steps: row-major records, two columns per fetch, the over-full row's
+    own blocks all run).  After every step the per-element particle counts, the layout arrays and both scatter
+    fields equal the oracle's; after the last, every member of every particle equals the oracle's by particle id,
+    bit for bit.  The oracle runs its per-particle loops on all host cores (results do not depend on the thread
+    count); its structure has the same C, sigma, V and padding."""
+    w = bench.build_workload(pp, capi, name, 10_000_000, 0, 1, 0.5)
+    s = pp.synth
+    mg, pg = w["mesh"], w["ps"]
+    dim = w["dim"]
+    mo = ppo.Mesh(dim, w["coords"], w["e2v"], w["cls"])
+    po = ppo.PS.scs(ppo.PARTICLE_XGCM, w["ne"], w["ppe"], C_max=64, sigma=2**31 - 1, V=1024, pad_strat=0,
+                    shuffle_padding=0.1, extra_padding=0.0, particle_elements=w["elem"], particle_info=w["info"])
+    fo, bo = ppo.create_gyro_ring_mappings(mo, trig=1)
+    fg, bg = capi.create_gyro_ring_mappings(mg)
+    wf, wb = capi.DevArray(mg.nverts, np.float64), capi.DevArray(mg.nverts, np.float64)
+    ppo.set_threads(ppo.max_threads())
+    try:
+        for step in range(3):
+            if dim == 3:
+                ppo.toroidal_push(po, mo, s.XGC_H, s.XGC_K, s.XGC_D, 0.5, trig=1)
+                ids_o = ppo.search_mesh(mo, po, looplimit=200)["elem_ids"]
+            else:
+                ppo.elliptical_push(po, mo, s.XGC_H, s.XGC_K, s.XGC_D, 0.5, trig=1)
+                _, ids_o, _ = ppo.search_mesh_2d(mo, po, looplimit=200)
+            cap = pg.capacity()
+            ids_g = capi.DevArray(cap + cap // 10, np.int32)
+            capi.push_search(mg, pg, s.XGC_H, s.XGC_K, s.XGC_D, 0.5, ids_g, seeded=False, looplimit=200)
+            if dim == 3:
+                assert capi.push_search_counters() == (0, 0, 0)
+            ppo.update_positions(po)
+            po.rebuild(ids_o)
+            capi.rebuild_scatter(pg, mg, ids_g, [fg, bg], [wf, wb])
+            assert po.nPtcls() == pg.nPtcls()
+            lo, lg = po.layout(), pg.layout()
+            for k in ("offsets", "slice_to_chunk", "row_to_element", "mask"):
+                assert np.array_equal(lo[k], lg[k]), (step, k)
+            assert np.array_equal(ppo.gyro_scatter(mo, po, fo), wf.to_host()), step
+            assert np.array_equal(ppo.gyro_scatter(mo, po, bo), wb.to_host()), step
+    finally:
+        ppo.set_threads(1)
+    so, mko = po.slot_info()
+    sg, mkg = pg.slot_info()
+    capo, capg = po.capacity(), pg.capacity()
+    ido, idg = po.member(2)[0, :capo], pg.member(2)[0, :capg]
+    io, eo = common.by_id(ido, mko, so)
+    ig, eg = common.by_id(idg, mkg, sg)
+    assert np.array_equal(io, ig) and np.array_equal(eo, eg)
+    for m in range(len(ppo.PARTICLE_XGCM)):
+        _, a = common.by_id(ido, mko, po.member(m)[:, :capo])
+        _, b = common.by_id(idg, mkg, pg.member(m)[:, :capg])
+        assert np.array_equal(a, b), m
 
 
 def test_config5_share_two_virtual_ranks_full_size(pp, capi):
