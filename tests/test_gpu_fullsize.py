@@ -400,7 +400,7 @@ def test_c3_full_size_equals_oracle(pp, ppo, capi, name):
         assert np.array_equal(a, b), m
 
 
-def test_config5_share_two_virtual_ranks_full_size(pp, capi):
+def test_config5_share_two_virtual_ranks_full_size(pp, ppo, capi):
     """BASELINE configs[4] at the size one GPU carries: the 998 400-tet mesh, 32 M particles -- here as TWO
     virtual ranks of 16 M on a `local` communicator, so the exchange really moves particles between two
     structures.  Three steps of what bench.py's c5 step calls (pp_push_search with trusted origins from the
@@ -427,7 +427,8 @@ def test_config5_share_two_virtual_ranks_full_size(pp, capi):
         se, mk = w["ps"].slot_info()
         slots = np.flatnonzero(mk)
         assert len(slots) == per_rank and np.all(owners[se[slots]] == r)
-        tag[0, slots] = np.arange(per_rank, dtype=np.int32) + r * per_rank
+        # (rank r's k-th particle becomes k + r * per_rank: the numbering of the oracle run at the end of the test)
+        tag[0, slots] = w["ps"].member(2)[0, slots] + r * per_rank
         w["ps"].set_member(2, tag)
     rng = np.random.default_rng(11)
     total = world * per_rank
@@ -490,5 +491,35 @@ def test_config5_share_two_virtual_ranks_full_size(pp, capi):
     samp = rng.choice(len(pid_a), size=200_000, replace=False)
     lam = _tet_bcc(ws[0]["coords"], ws[0]["e2v"], elem_a[samp], x_a[:, samp].T)
     assert lam.min() > -1e-9, lam.min()
+    # ---- and against the ORACLE: ONE structure holding both ranks' particles, the same three steps without any
+    # exchange (per-particle loops on all host cores).  The union of the two ranks equals it particle by particle
+    # -- element, position, b, phi, bit for bit -- and the synced scatter field is the single structure's.
+    b_a = np.concatenate([w["ps"].member(3)[0, :w["ps"].capacity()][w["ps"].slot_info()[1].astype(bool)] for w in ws])
+    phi_a = np.concatenate([w["ps"].member(4)[0, :w["ps"].capacity()][w["ps"].slot_info()[1].astype(bool)] for w in ws])
+    mo = ppo.Mesh(3, ws[0]["coords"], ws[0]["e2v"], ws[0]["cls"])
+    info = [np.concatenate([w["info"][m] for w in ws], axis=-1) for m in range(5)]
+    info[2] = np.concatenate([np.arange(per_rank, dtype=np.int32) + r * per_rank for r in range(world)])
+    po = ppo.PS.scs(ppo.PARTICLE_XGCM, ne, ws[0]["ppe"] + ws[1]["ppe"], C_max=64, sigma=2**31 - 1, V=1024, pad_strat=0,
+                    shuffle_padding=0.1, extra_padding=0.0, particle_elements=np.concatenate([w["elem"] for w in ws]),
+                    particle_info=info)
+    fo, _ = ppo.create_gyro_ring_mappings(mo, trig=1)
+    ppo.set_threads(ppo.max_threads())
+    try:
+        for step in range(3):
+            ppo.toroidal_push(po, mo, s.XGC_H, s.XGC_K, s.XGC_D, 0.5, trig=1)
+            ids_o = ppo.search_mesh(mo, po, looplimit=200)["elem_ids"]
+            ppo.update_positions(po)
+            po.rebuild(ids_o)
+    finally:
+        ppo.set_threads(1)
+    so, mko = po.slot_info()
+    capo = po.capacity()
+    ido = po.member(2)[0, :capo]
+    io, eo = common.by_id(ido, mko, so)
+    assert np.array_equal(io, pid_a[oa]) and np.array_equal(eo, elem_a[oa])
+    assert np.array_equal(common.by_id(ido, mko, po.member(0)[:, :capo])[1], x_a[:, oa])
+    assert np.array_equal(common.by_id(ido, mko, po.member(3)[:, :capo])[1][0], b_a[oa])
+    assert np.array_equal(common.by_id(ido, mko, po.member(4)[:, :capo])[1][0], phi_a[oa])
+    assert np.array_equal(ppo.gyro_scatter(mo, po, fo), f)        # SUM over the ranks == the one structure's field
     for c in comms:
         c.destroy()
