@@ -69,6 +69,46 @@ def test_c2_full_size_properties(pp, capi, monkeypatch):
     assert (res["0"][0] != after[live]).mean() > 0.05  # the comparison covered real walks
 
 
+def test_c2_full_size_equals_oracle(pp, ppo, capi):
+    """configs[1] at BASELINE's size against the oracle, particle by particle: 100 800 tets, 10 M particles, six steps of
+    push + search with the ids re-used as seeds and x <-> x_tgt swapped in between (no rebuild: by the last step
+    a third of the particles has left the element of its row and walks from its own seed record).  After every
+    step the element id of every particle equals the oracle's; after the last, so do x, x_tgt and phi."""
+    w = bench.build_workload(pp, capi, "c2", 10_000_000, 0, 1, 0.5)
+    s = pp.synth
+    mg, pg = w["mesh"], w["ps"]
+    mo = ppo.Mesh(3, w["coords"], w["e2v"], w["cls"])
+    po = ppo.PS.scs(ppo.PARTICLE_XGCM, w["ne"], w["ppe"], C_max=64, sigma=2**31 - 1, V=1024, pad_strat=0,
+                    shuffle_padding=0.1, extra_padding=0.0, particle_elements=w["elem"], particle_info=w["info"])
+    capg, capo = pg.capacity(), po.capacity()
+    ids_g = capi.DevArray.from_host(np.full(capg, -1, dtype=np.int32))
+    idg, mkg = pg.member(2)[0, :capg].copy(), pg.slot_info()[1]
+    ido, mko = po.member(2)[0, :capo].copy(), po.slot_info()[1]
+    ids_o = None
+    ppo.set_threads(ppo.max_threads())
+    try:
+        for step in range(6):
+            capi.push_search(mg, pg, s.XGC_H, s.XGC_K, s.XGC_D, 0.5, ids_g, seeded=(step > 0), looplimit=200)
+            ppo.toroidal_push(po, mo, s.XGC_H, s.XGC_K, s.XGC_D, 0.5, trig=1)
+            ids_o = ppo.search_mesh(mo, po, elem_ids=ids_o, looplimit=200)["elem_ids"]
+            _, eg = common.by_id(idg, mkg, ids_g.to_host()[:capg])
+            _, eo = common.by_id(ido, mko, ids_o[:capo])
+            assert np.array_equal(eg, eo), step
+            if step < 5:
+                pg.swap_members(0, 1)
+                a, b = po.member(0), po.member(1)
+                tmp = a.copy()
+                a[:] = b
+                b[:] = tmp
+    finally:
+        ppo.set_threads(1)
+    assert (eo != common.by_id(ido, mko, po.slot_info()[0])[1]).mean() > 0.25  # (a third has left its row's element)
+    for m in (0, 1, 4):
+        _, a = common.by_id(ido, mko, po.member(m)[:, :capo])
+        _, b = common.by_id(idg, mkg, pg.member(m)[:, :capg])
+        assert np.array_equal(a, b), m
+
+
 def test_c3_full_size_properties(pp, capi):
     """configs[2] (2-D literal): push + search + updatePtclPositions + rebuild + gyroScatter."""
     w = bench.build_workload(pp, capi, "2dc3", 10_000_000, 0, 1, 0.5)
