@@ -254,8 +254,8 @@ def test_c2_intersection_mode_full_size(pp, ppo, capi):
     Size-independent properties with an independent numpy evaluation: every moved particle's ray ends on an
     EXPOSED face of the element it reports (the rays are followed to the boundary), the intersection point lies
     in that face's plane, inside the face, on the ray beyond the origin, and in the reported element; then a
-    50 000-particle sample is searched by the oracle from the same positions and must agree bit for bit
-    (parents, exit faces, intersection points)."""
+    ALL 10 M particles (PP_TEST_MT_SAMPLE for fewer) are searched by the oracle from the same positions, on all host
+    cores, and must agree bit for bit (parents, exit faces, intersection points)."""
     w = bench.build_workload(pp, capi, "c2mt", 10_000_000, 0, 1, 0.5)
     s = pp.synth
     mesh, ps = w["mesh"], w["ps"]
@@ -297,7 +297,8 @@ def test_c2_intersection_mode_full_size(pp, ppo, capi):
     lam = _tet_bcc(w["coords"], w["e2v"], ids[samp], pts[samp])
     assert lam.min() > -1e-6                                                                     # in the element
     # ---- oracle on a sample of the same particles (same origins, same pushed targets)
-    sub = np.sort(rng.choice(live, size=50_000, replace=False))
+    nsub = min(int(os.environ.get("PP_TEST_MT_SAMPLE", "10000000")), len(live))
+    sub = np.sort(rng.choice(live, size=nsub, replace=False))
     elem = se[sub].astype(np.int32)
     order = np.argsort(elem, kind="stable")
     sub, elem = sub[order], elem[order]
@@ -305,13 +306,19 @@ def test_c2_intersection_mode_full_size(pp, ppo, capi):
     mo = ppo.Mesh(3, w["coords"], w["e2v"], w["cls"])
     po = ppo.PS.scs(ppo.PARTICLE_XGCM, w["ne"], np.bincount(elem, minlength=w["ne"]).astype(np.int32), C_max=64,
                     particle_elements=elem, particle_info=info)
-    ro = ppo.search_mesh(mo, po, require_intersection=True, looplimit=2000)
+    ppo.set_threads(ppo.max_threads())  # (the rays of different particles are independent)
+    try:
+        ro = ppo.search_mesh(mo, po, require_intersection=True, looplimit=2000)
+    finally:
+        ppo.set_threads(1)
     so, mko = po.slot_info()
     lo = np.flatnonzero(mko)
     pid_o = po.member(2)[0, :po.capacity()][lo]
     pid_g = ps.member(2)[0, :cap]
-    slot_of = {int(p): int(sl) for p, sl in zip(pid_g[sub], sub)}
-    gs = np.array([slot_of[int(p)] for p in pid_o])
+    slot_of = np.full(int(pid_g[live].max()) + 1, -1, dtype=np.int64)
+    slot_of[pid_g[sub]] = sub
+    gs = slot_of[pid_o]
+    assert (gs >= 0).all()
     assert np.array_equal(ro["elem_ids"][lo], ids[gs])
     assert np.array_equal(ro["inter_faces"][lo], faces[gs])
     assert np.array_equal(ro["inter_points"].reshape(-1, 3)[lo], pts[gs])
