@@ -447,7 +447,8 @@ def test_c3_full_size_equals_oracle(pp, ppo, capi, name):
         assert np.array_equal(a, b), m
 
 
-def test_config5_share_two_virtual_ranks_full_size(pp, ppo, capi):
+@pytest.mark.parametrize("world,per_rank", [(2, 16_000_000), (8, 2_000_000)])
+def test_config5_share_two_virtual_ranks_full_size(pp, ppo, capi, world, per_rank):
     """BASELINE configs[4] at the size one GPU carries: the 998 400-tet mesh, 32 M particles -- here as TWO
     virtual ranks of 16 M on a `local` communicator, so the exchange really moves particles between two
     structures.  Three steps of what bench.py's c5 step calls (pp_push_search with trusted origins from the
@@ -458,7 +459,7 @@ def test_config5_share_two_virtual_ranks_full_size(pp, ppo, capi):
     independent numpy barycentric test, and the synced scatter fields carry 2 rings x 4 vertices x the mapped
     fraction of every particle on every rank."""
     from pumipic_amd import dist as ppdist
-    world, per_rank = 2, 16_000_000
+    # (world 2: the 32 M particles one GPU of configs[4] carries; world 8: the eight owner blocks of the node, 16 M)
     s = pp.synth
     ws = [bench.build_workload(pp, capi, "c5", per_rank, r, world, 0.5, mesh_size="1m") for r in range(world)]
     ne = ws[0]["ne"]
@@ -509,7 +510,8 @@ def test_config5_share_two_virtual_ranks_full_size(pp, ppo, capi):
             se, mk = w["ps"].slot_info()
             assert np.all(owners[se[mk.astype(bool)]] == r)
         g0 = packed[0].to_host()
-        assert np.array_equal(g0, packed[1].to_host())  # every rank has the same synced fields
+        for r in range(1, world):
+            assert np.array_equal(g0, packed[r].to_host())  # every rank has the same synced fields
         f = g0[0::2]
         assert np.array_equal(f, g0[1::2]) and np.isfinite(f).all() and f.min() >= 0
         assert 0.8 * 32 * alive <= f.sum() <= 32 * alive
@@ -546,7 +548,7 @@ def test_config5_share_two_virtual_ranks_full_size(pp, ppo, capi):
     mo = ppo.Mesh(3, ws[0]["coords"], ws[0]["e2v"], ws[0]["cls"])
     info = [np.concatenate([w["info"][m] for w in ws], axis=-1) for m in range(5)]
     info[2] = np.concatenate([np.arange(per_rank, dtype=np.int32) + r * per_rank for r in range(world)])
-    po = ppo.PS.scs(ppo.PARTICLE_XGCM, ne, ws[0]["ppe"] + ws[1]["ppe"], C_max=64, sigma=2**31 - 1, V=1024, pad_strat=0,
+    po = ppo.PS.scs(ppo.PARTICLE_XGCM, ne, sum(w["ppe"] for w in ws), C_max=64, sigma=2**31 - 1, V=1024, pad_strat=0,
                     shuffle_padding=0.1, extra_padding=0.0, particle_elements=np.concatenate([w["elem"] for w in ws]),
                     particle_info=info)
     fo, _ = ppo.create_gyro_ring_mappings(mo, trig=1)
