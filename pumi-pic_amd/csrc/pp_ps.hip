@@ -302,41 +302,43 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
           nel[j] = new_element[pid];
         }
       }
+      // Two passes over the batch (the kernel is bound by instruction issue, the scalar unit above all -- ~70 scalar
+      // instructions and 14 branches per particle when every particle went through the table code).  First the
+      // eight particles without a branch: who stays (a bit of m0), who leaves (a bit of `mv`), who is dead (-1).
+      // Then ONLY the leavers, one per iteration of a loop whose trip count is the largest number of leavers any
+      // lane of the wave has among its eight (one particle in five leaves: four or five iterations, not eight).
+      unsigned mv = 0;
+      bool anybad = false;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        if (pb + j >= pend) continue;
         const int ne_ = nel[j];
-        const unsigned bit = 1u << (pb + j - run_p0);
-        bool deferred = false;
-        int rk = -1;
-        if (mk[j] && ne_ != -1) {
-          if (ne_ < 0 || ne_ >= ne) {
-            tot->invalid = 1;
-          } else {
-            deferred = true;
-            if (ne_ == e) {
-              m0 |= bit;
-            } else {
-              // The keys fill in order: the first free one ends the search.  As selects over the unrolled table: the
-              // if / else-if cascade this was compiled to one exec-mask branch per test and cost the kernel 10 %
-              // (66.4 -> 60.0 us; predicating the outer tests as well: 61.8).
-              bool placed = false;
+        const bool in = pb + j < pend;
+        const bool live = in && mk[j] && ne_ != -1;
+        const bool bad = live && (ne_ < 0 || ne_ >= ne);
+        const bool good = live && !bad;
+        const bool stays = good && ne_ == e;
+        m0 |= stays ? (1u << (pb + j - run_p0)) : 0u;
+        mv |= (good && !stays) ? (1u << j) : 0u;
+        anybad = anybad || bad;
+        if (in && !good) rank[start + (pb + j) * C] = -1;
+      }
+      if (anybad) tot->invalid = 1;
+      while (mv) {
+        const int j = __ffs(mv) - 1;
+        mv &= mv - 1;
+        int ne_ = nel[0];  // nel[j] by selects (a dynamic index would put the batch into scratch)
 #pragma unroll
-              for (int k = 0; k < NK; ++k) {
-                if (!placed && (key[k] == ne_ || key[k] < 0)) {
-                  key[k] = ne_;
-                  mk_[k] |= bit;
-                  placed = true;
-                }
-              }
-              if (!placed) {
-                deferred = false;
-                rk = atomicAdd(&ppe[ne_], 1);
-              }
-            }
-          }
+        for (int q = 1; q < 8; ++q) ne_ = j == q ? nel[q] : ne_;
+        const unsigned bit = 1u << (pb + j - run_p0);
+        bool placed = false;  // (the keys fill in order: the first matching or free one ends the search)
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          const bool here = !placed && (key[k] == ne_ || key[k] < 0);
+          key[k] = here ? ne_ : key[k];
+          mk_[k] |= here ? bit : 0u;
+          placed = placed || here;
         }
-        if (!deferred) rank[start + (pb + j) * C] = rk;
+        if (!placed) rank[start + (pb + j) * C] = atomicAdd(&ppe[ne_], 1);  // no room in the table: its own atomic
       }
     }
   }
