@@ -57,8 +57,18 @@ int pp_sync(void);
 int pp_peek_hip_error(const char** msg_out);
 int pp_device_count(void);
 /* plain device memory helpers so hosts without a HIP toolchain (ctypes, cgo, JNI) can drive it */
+/* pp_malloc / pp_free are POOLED: a freed block is kept (up to an eighth of the device memory) and handed to the
+ * next request it fits, without hipFree's device synchronisation -- the per-step arrays of the reference's drivers
+ * (Omega_h::Write<LO> elem_ids(capacity, -1) per search, test/pseudoXGCm.cpp:142-146; new_elems / new_procs per
+ * migration, src/pumipic_ptcl_ops.hpp:56-60) cost a free-list lookup.  Reuse is ordered by the library stream:
+ * code that reads such a block from ANOTHER stream must finish before the block is freed. */
 void* pp_malloc(size_t bytes);
 int pp_free(void* dev);
+int pp_pool_trim(void); /* hand every cached block back to the runtime */
+int pp_pool_stats(size_t* live_bytes, size_t* cached_bytes, long long* hits, long long* misses);
+/* Kokkos::View<T*>(name, n) filled with a value / Omega_h::Write<T>(n, value): `count` items of pattern_bytes
+ * (1, 2, 4, 8) each, on the library stream */
+int pp_fill(void* dev, const void* pattern_host, int pattern_bytes, size_t count);
 int pp_memcpy_h2d(void* dev, const void* host, size_t bytes);
 int pp_memcpy_d2h(void* host, const void* dev, size_t bytes);
 int pp_memset(void* dev, int value, size_t bytes);
@@ -145,6 +155,20 @@ typedef struct pp_ps_layout_t {
 } pp_ps_layout_t;
 /* device pointers used by the header-only ps::parallel_for (SellCSigma.h:526-558, CSR.hpp:186-213) */
 int pp_ps_layout(const pp_ps* ps, pp_ps_layout_t* out);
+/* What the header-only ps::parallel_for needs to visit every slot (thread = slot): the mask and the slot's
+ * parent element.  Sell-C-sigma with chunk height 64: 64 consecutive slots are the 64 rows of one column of ONE
+ * chunk, so the element is row_to_element[64 * group_chunk[pid / 64] + pid % 64] -- one wave-uniform load from a
+ * capacity/64 table plus a coalesced load from the 0.4 MB row table, instead of 4 B per slot from a capacity-long
+ * slot -> element table (which a full re-layout leaves unwritten until somebody asks: pp_ps_layout).  Else
+ * (CSR, other chunk heights): group_chunk is NULL and slot_elem is filled. */
+typedef struct pp_ps_iter_t {
+  int capacity;
+  const unsigned char* mask;
+  const int* group_chunk;    /* capacity/64 entries, or NULL */
+  const int* row_to_element; /* with group_chunk */
+  const int* slot_elem;      /* without group_chunk */
+} pp_ps_iter_t;
+int pp_ps_iteration(const pp_ps* ps, pp_ps_iter_t* out);
 int pp_ps_layout_to_host(const pp_ps* ps, int* offsets, int* slice_to_chunk, int* row_to_element,
                          int* element_to_row, unsigned char* mask, int* slot_elem);
 int pp_ps_member_to_host(pp_ps* ps, int m, void* out_host);   /* [ncomp][stride] */

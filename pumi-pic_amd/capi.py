@@ -65,6 +65,9 @@ SYMBOLS = {
     "pp_memcpy_h2d": (_I, [_V, _V, _S]),
     "pp_memcpy_d2h": (_I, [_V, _V, _S]),
     "pp_memset": (_I, [_V, _I, _S]),
+    "pp_pool_trim": (_I, []),
+    "pp_pool_stats": (_I, [C.POINTER(_S), C.POINTER(_S), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "pp_fill": (_I, [_V, _V, _I, _S]),
     "pp_event_create": (_V, []),
     "pp_event_record": (_I, [_V]),
     "pp_event_elapsed_ms": (C.c_float, [_V, _V]),
@@ -83,6 +86,7 @@ SYMBOLS = {
     "pp_ps_member_ptr": (_V, [_V, _I]),
     "pp_ps_member_stride": (C.c_int64, [_V]),
     "pp_ps_layout": (_I, [_V, C.POINTER(PsLayout)]),
+    "pp_ps_iteration": (_I, [_V, _V]),
     "pp_ps_layout_to_host": (_I, [_V, _V, _V, _V, _V, _V, _V]),
     "pp_ps_member_to_host": (_I, [_V, _I, _V]),
     "pp_ps_member_from_host": (_I, [_V, _I, _V]),

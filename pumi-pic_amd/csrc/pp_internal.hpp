@@ -23,6 +23,11 @@ void gyro_map_mesh_gone(const void* mesh);
 // pp_scatter.hip: gyroScatter for `nmaps` ring maps from an explicit per-element count array (the
 // histogram of a rebuild that is still in flight); forgets the ring accumulation kept for reuse
 bool initialised();
+// pp_runtime.hip: the device memory pool behind pp_malloc / pp_free
+void* pool_alloc(size_t bytes);
+int pool_free(void* dev);
+int pool_trim();
+void pool_stats(size_t* live_bytes, size_t* cached_bytes, long long* hits, long long* misses);
 // pp_mesh.hip: derive (once) and return the edges of a tet mesh; PP_EINVAL for a 2-D mesh
 
 #define PP_HIP_CHECK(expr)                                                              \
@@ -94,6 +99,11 @@ struct DevBuf {
     release();
     size_t want = n + n / 8 + 256;
     hipError_t e = hipMalloc(&base, want + skew);
+    if (e != hipSuccess) {  // blocks cached by the pp_malloc pool may be what is in the way
+      (void)hipGetLastError();
+      (void)pool_trim();
+      e = hipMalloc(&base, want + skew);
+    }
     if (e == hipSuccess) {
       bytes = want;
       p = (char*)base + skew;
@@ -214,6 +224,9 @@ struct pp_ps {
   // slot -> parent element: the row-tiled kernels of the time step never read it, so the SCS re-layout leaves it
   // unwritten (40 MB per 10 M slots) and pp::slot_elem() fills it when something asks
   mutable bool slot_elem_valid = true;
+  // 64-slot group -> chunk (chunk height 64; pp_ps_iteration): filled on first use after a re-layout
+  mutable pp::DevBuf d_group_chunk;
+  mutable bool group_chunk_valid = false;
   // SCS row tiles for the row-major hot kernels: tile = (chunk, first p), kTileP columns wide.
   // A chunk's slots are contiguous: slot = chunk_start[c] + row_in_chunk + p*C, p < chunk_width[c]
   pp::DevBuf d_chunk_start, d_chunk_width, d_tiles, d_ntiles;
@@ -354,6 +367,7 @@ namespace pp {
 int ps_materialize(pp_ps* ps);
 int ps_zeros(pp_ps* ps);  // only the pending zeros of pp_ps::zero_pending
 const int* slot_elem(const pp_ps* ps);  // d_slot_elem, filled first when the last re-layout left it out (pp_ps.hip)
+const int* group_chunk(const pp_ps* ps);  // d_group_chunk (SCS, chunk height 64), else nullptr
 inline int ps_ready(const pp_ps* ps) {
   return (ps && (ps->zero_pending >= 0 || ps->lazy_rec)) ? ps_materialize(const_cast<pp_ps*>(ps)) : PP_OK;
 }

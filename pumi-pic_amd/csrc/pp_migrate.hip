@@ -16,17 +16,18 @@ namespace {
 using pp::grid_for;
 using pp::kBlock;
 
-__global__ void k_unsafe(int capacity, const unsigned char* __restrict__ mask,
-                         const int* __restrict__ slot_elem, const int* __restrict__ elems,
+// (every slot of the capacity, like the reference's parallel_for: the slots of padding rows are masked off and
+// keep this rank; no slot -> element table is read)
+__global__ void k_unsafe(int capacity, const unsigned char* __restrict__ mask, const int* __restrict__ elems,
                          const unsigned char* __restrict__ safe, const int* __restrict__ owners,
                          int rank, int* __restrict__ new_elems, int* __restrict__ new_procs) {
   const int pid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pid >= capacity || slot_elem[pid] < 0) return;
+  if (pid >= capacity) return;
   int proc = rank;
-  const int nelm = elems[pid];
-  new_elems[pid] = nelm;
+  const int nelm = __builtin_nontemporal_load(elems + pid);
+  __builtin_nontemporal_store(nelm, new_elems + pid);
   if (mask[pid] && nelm != -1 && !safe[nelm]) proc = owners[nelm];
-  new_procs[pid] = proc;
+  __builtin_nontemporal_store(proc, new_procs + pid);
 }
 
 // a particle is sent when it is live, keeps a valid new element and is routed to another rank
@@ -678,8 +679,8 @@ int pp_set_unsafe_procs(const pp_ps* ps, const int* elems_dev, const unsigned ch
              "pp_set_unsafe_procs: null argument");
   if (ps->num_ptcls == 0 || ps->capacity == 0) return PP_OK;
   k_unsafe<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
-      ps->capacity, ps->d_mask.as<unsigned char>(), pp::slot_elem(ps), elems_dev, safe_dev,
-      owners_dev, comm_rank, new_elems_dev, new_procs_dev);
+      ps->capacity, ps->d_mask.as<unsigned char>(), elems_dev, safe_dev, owners_dev, comm_rank, new_elems_dev,
+      new_procs_dev);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

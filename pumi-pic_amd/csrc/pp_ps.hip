@@ -756,6 +756,16 @@ __global__ void k_fill_slot_elem(const int* __restrict__ ntiles_dev, int C, int 
   const int e = r2e[c * C + r];
   for (int p = p0; p < pend; ++p) slot_elem[start + p * C] = e;
 }
+// 64-slot group -> chunk, chunk height 64 (pp_ps_iteration): thread = tile
+__global__ void k_fill_group_chunk(const int* __restrict__ ntiles_dev, int TP, const int* __restrict__ tiles,
+                                   const int* __restrict__ chunk_start, const int* __restrict__ chunk_width,
+                                   int* __restrict__ group_chunk) {
+  const int tile = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tile >= *ntiles_dev) return;
+  const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
+  const int g0 = chunk_start[c] >> 6, pend = min(p0 + TP, chunk_width[c]);
+  for (int p = p0; p < pend; ++p) group_chunk[g0 + p] = c;
+}
 // new layout: slot -> parent element for every slot of every tile, first slot of every row
 __global__ void k_init_slots_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
                                    const int* __restrict__ tiles, const int* __restrict__ chunk_start,
@@ -1674,6 +1684,7 @@ int finish_layout_upload(pp_ps* ps, const HostLayout& L, const std::vector<int>&
   if ((rc = upload_vec(ps->d_mask, mask))) return rc;
   if ((rc = upload_vec(ps->d_slot_elem, slot_elem))) return rc;
   ps->slot_elem_valid = true;
+  ps->group_chunk_valid = false;
   PP_HIP_CHECK(hipStreamSynchronize(pp::stream()));
   return PP_OK;
 }
@@ -2352,7 +2363,11 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       // (only where the records stay the particle data -- the pseudoXGCm flows, where nine particles in ten keep
       // their row: c3 -3.3 %, 2dc3 -3.6 %, c5 share -3.2 %.  ps_combo160 redistributes half of its particles to
       // random elements: nothing to merge, and its second pass reads row-major records 2.5 % slower)
-      use_rm = want_rm && defer_unpack;
+      // ... and for every type whose record is one 64-B half line or less, deferred or not (the drop-in loop of
+      // test/pseudoXGCm.cpp rebuilds without the fused commit and reads the SoA arrays right away: pass 1 358 ->
+      // row-major, pass 2 reads the same records back): two records share a 128-B line, so runs are what keeps
+      // the scattered stores whole lines
+      use_rm = want_rm && (defer_unpack || NQ <= 4);
       PP_REQUIRE(!hot_now.on || use_rm, "rebuild (internal): the over-full row's blocks need the row-major staged path");
       // (pp_ps::hot) the main blocks end where the columns of the over-full row begin, its own blocks follow
       const int pack_end = hot_now.on ? hot_now.start + 64 * hot_now.c1p : ps->capacity;
@@ -2546,6 +2561,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   ps->d_mask.swap(ps->s_mask2);
   ps->d_slot_elem.swap(ps->s_slot2);
   ps->slot_elem_valid = !lazy_slot_elem;
+  ps->group_chunk_valid = false;
   ps->d_chunk_start.swap(ps->s_cstart2);
   ps->d_chunk_width.swap(ps->s_cwidth2);
   ps->d_tiles.swap(ps->s_newidx);
@@ -2709,6 +2725,17 @@ const int* slot_elem(const pp_ps* ps) {
     ps->slot_elem_valid = true;
   }
   return ps->d_slot_elem.as<int>();
+}
+const int* group_chunk(const pp_ps* ps) {
+  if (ps->kind != PP_SCS || ps->C != 64 || ps->capacity <= 0 || ps->ntiles_max <= 0) return nullptr;
+  if (!ps->group_chunk_valid) {
+    if (ps->d_group_chunk.reserve(sizeof(int) * ((size_t)ps->capacity / 64 + 1)) != hipSuccess) return nullptr;
+    k_fill_group_chunk<<<grid_for((size_t)ps->ntiles_max), kBlock, 0, pp::stream()>>>(
+        ps->d_ntiles.as<int>(), ps->tile_p, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(),
+        ps->d_chunk_width.as<int>(), ps->d_group_chunk.as<int>());
+    ps->group_chunk_valid = true;
+  }
+  return ps->d_group_chunk.as<int>();
 }
 bool lazy_push_ok(const pp_ps* ps, int m_x, int m_xtgt, int m_b, int m_phi) {
   if (!ps || ps->lazy_rec != 1 || ps->kind != PP_SCS || !xgcm_shape(ps)) return false;
@@ -2904,6 +2931,7 @@ pp_ps* pp_ps_create_csr(int num_elems, int num_ptcls, const int* ppe_host,
     }
   ok = ok && upload_vec(ps->d_slot_elem, slot_elem) == PP_OK && upload_vec(ps->d_mask, mask) == PP_OK;
   ps->slot_elem_valid = true;
+  ps->group_chunk_valid = false;
   if (ok) ok = hipStreamSynchronize(pp::stream()) == hipSuccess;
   if (ok && gids_host && num_elems > 0) ok = store_gids(ps, gids_host, num_elems);
   if (ok && num_ptcls > 0 && particle_elements_host && particle_info_host) {
@@ -2992,6 +3020,16 @@ int pp_ps_layout(const pp_ps* ps, pp_ps_layout_t* out) {
   out->element_to_row = ps->d_element_to_row.as<int>();
   out->mask = ps->d_mask.as<unsigned char>();
   out->slot_elem = pp::slot_elem(ps);
+  return PP_OK;
+}
+
+int pp_ps_iteration(const pp_ps* ps, pp_ps_iter_t* out) {
+  PP_REQUIRE(ps && out, "pp_ps_iteration: null argument");
+  out->capacity = ps->capacity;
+  out->mask = ps->d_mask.as<unsigned char>();
+  out->group_chunk = pp::group_chunk(ps);
+  out->row_to_element = ps->d_row_to_element.as<int>();
+  out->slot_elem = out->group_chunk ? nullptr : pp::slot_elem(ps);
   return PP_OK;
 }
 

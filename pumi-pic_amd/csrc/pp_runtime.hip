@@ -1,5 +1,8 @@
 // pp_runtime.hip -- device selection, stream, memory and event helpers of the C-ABI.
 #include <dlfcn.h>
+#include <map>
+#include <mutex>
+#include <unordered_map>
 #include "pp_internal.hpp"
 
 namespace pp {
@@ -46,6 +49,115 @@ unsigned long long next_version() {
 void set_error(const std::string& msg) { g_err = msg; }
 hipStream_t stream() { return g_stream; }
 bool initialised() { return g_init; }
+
+// ---- the pool (see pp_malloc below)
+__global__ void k_fill64(unsigned long long* __restrict__ p, unsigned long long v, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+namespace {
+struct Pool {
+  std::mutex mu;
+  std::unordered_map<void*, size_t> live;     // handed out: pointer -> block size
+  std::multimap<size_t, void*> idle;          // cached: block size -> pointer
+  size_t live_bytes = 0, idle_bytes = 0, limit = 0;
+  long long hits = 0, misses = 0;
+};
+Pool& pool() {
+  static Pool* p = new Pool();  // (never destroyed: frees may arrive from static destructors of the caller)
+  return *p;
+}
+size_t round_block(size_t n) {
+  if (n <= 4096) return 4096;
+  if (n <= ((size_t)1 << 20)) {  // next power of two
+    size_t r = 4096;
+    while (r < n) r <<= 1;
+    return r;
+  }
+  return (n + ((size_t)2 << 20) - 1) / ((size_t)2 << 20) * ((size_t)2 << 20);  // 2 MiB granules
+}
+void trim_locked(Pool& P, size_t keep) {
+  while (P.idle_bytes > keep && !P.idle.empty()) {
+    auto it = std::prev(P.idle.end());  // largest first
+    (void)hipFree(it->second);
+    P.idle_bytes -= it->first;
+    P.idle.erase(it);
+  }
+}
+}  // namespace
+void* pool_alloc(size_t bytes) {
+  Pool& P = pool();
+  const size_t want = round_block(bytes);
+  std::lock_guard<std::mutex> lk(P.mu);
+  auto it = P.idle.lower_bound(want);
+  if (it != P.idle.end() && it->first <= want + want / 8) {
+    void* p = it->second;
+    const size_t sz = it->first;
+    P.idle.erase(it);
+    P.idle_bytes -= sz;
+    P.live[p] = sz;
+    P.live_bytes += sz;
+    ++P.hits;
+    return p;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess && !P.idle.empty()) {  // out of memory with blocks cached: give them back, try again
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(g_stream);
+    trim_locked(P, 0);
+    e = hipMalloc(&p, want);
+  }
+  if (e != hipSuccess) {
+    set_error(std::string("pp_malloc: hipMalloc of ") + std::to_string(want) + " bytes: " + hipGetErrorString(e));
+    return nullptr;
+  }
+  ++P.misses;
+  P.live[p] = want;
+  P.live_bytes += want;
+  return p;
+}
+int pool_free(void* dev) {
+  Pool& P = pool();
+  std::lock_guard<std::mutex> lk(P.mu);
+  auto it = P.live.find(dev);
+  if (it == P.live.end()) {  // not from pp_malloc (a pointer the caller got from hipMalloc): the runtime's free
+    PP_HIP_CHECK(hipFree(dev));
+    return PP_OK;
+  }
+  const size_t sz = it->second;
+  P.live.erase(it);
+  P.live_bytes -= sz;
+  if (!P.limit) {
+    size_t fr = 0, tot = 0;
+    P.limit = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot / 8 > ((size_t)1 << 30)) ? tot / 8 : ((size_t)1 << 30);
+  }
+  if (sz > P.limit) {
+    PP_HIP_CHECK(hipFree(dev));
+    return PP_OK;
+  }
+  P.idle.emplace(sz, dev);
+  P.idle_bytes += sz;
+  if (P.idle_bytes > P.limit) {  // (blocks in the cache may still be read by queued kernels: drain first)
+    (void)hipStreamSynchronize(g_stream);
+    trim_locked(P, P.limit / 2);
+  }
+  return PP_OK;
+}
+int pool_trim() {
+  Pool& P = pool();
+  std::lock_guard<std::mutex> lk(P.mu);
+  if (!P.idle.empty()) PP_HIP_CHECK(hipStreamSynchronize(g_stream));
+  trim_locked(P, 0);
+  return PP_OK;
+}
+void pool_stats(size_t* live_bytes, size_t* cached_bytes, long long* hits, long long* misses) {
+  Pool& P = pool();
+  std::lock_guard<std::mutex> lk(P.mu);
+  if (live_bytes) *live_bytes = P.live_bytes;
+  if (cached_bytes) *cached_bytes = P.idle_bytes;
+  if (hits) *hits = P.hits;
+  if (misses) *misses = P.misses;
+}
 }  // namespace pp
 
 extern "C" {
@@ -89,14 +201,51 @@ int pp_sync(void) {
   return PP_OK;
 }
 
+// ---- device memory pool behind pp_malloc / pp_free.
+// The reference's drivers allocate per step (a fresh elem_ids array per search, new_elems / new_procs per
+// migration: test/pseudoXGCm.cpp:142-146, src/pumipic_ptcl_ops.hpp:56-60) and Kokkos serves those from its own
+// pools; hipMalloc / hipFree cost 0.1-1 ms apiece at these sizes and hipFree drains the device.  A freed block
+// goes to a size-keyed free list and is handed out again to the next request it fits (within 1/8 of its size).
+// Safe without events because everything the library and the mirror headers enqueue runs on ONE stream
+// (pp_stream()): whatever still reads a freed block was enqueued before whatever the next owner enqueues.
+// Cached bytes are bounded (an eighth of the device memory, at least 1 GiB); an allocation failure empties the
+// cache and retries.
 void* pp_malloc(size_t bytes) {
-  void* p = nullptr;
-  PP_HIP_CHECK_NULL(hipMalloc(&p, bytes ? bytes : 1));
-  return p;
+  return pp::pool_alloc(bytes ? bytes : 1);
 }
 int pp_free(void* dev) {
-  if (dev) pp::gyro_map_invalidate(dev, 1);
-  if (dev) PP_HIP_CHECK(hipFree(dev));
+  if (!dev) return PP_OK;
+  pp::gyro_map_invalidate(dev, 1);
+  return pp::pool_free(dev);
+}
+int pp_pool_trim(void) { return pp::pool_trim(); }
+int pp_pool_stats(size_t* live_bytes, size_t* cached_bytes, long long* hits, long long* misses) {
+  pp::pool_stats(live_bytes, cached_bytes, hits, misses);
+  return PP_OK;
+}
+// fill `count` items of `pattern_bytes` (1, 2, 4 or 8) bytes each with the pattern at pattern_host, on the
+// library stream: Kokkos::View / Omega_h::Write<T>(n, value) without a host array and a copy
+int pp_fill(void* dev, const void* pattern_host, int pattern_bytes, size_t count) {
+  PP_REQUIRE(pattern_host && (pattern_bytes == 1 || pattern_bytes == 2 || pattern_bytes == 4 || pattern_bytes == 8),
+             "pp_fill: pattern of 1, 2, 4 or 8 bytes");
+  if (!count) return PP_OK;
+  PP_REQUIRE(dev, "pp_fill: null device pointer");
+  pp::gyro_map_invalidate(dev, count * (size_t)pattern_bytes);
+  unsigned long long v = 0;
+  memcpy(&v, pattern_host, (size_t)pattern_bytes);
+  bool same = true;  // every byte equal (0, -1, ...): the runtime's byte fill
+  for (int i = 1; i < pattern_bytes; ++i) same = same && ((v >> (8 * i)) & 0xff) == (v & 0xff);
+  if (same) {
+    PP_HIP_CHECK(hipMemsetAsync(dev, (int)(v & 0xff), count * (size_t)pattern_bytes, pp::g_stream));
+  } else if (pattern_bytes == 2) {
+    PP_HIP_CHECK(hipMemsetD16Async((hipDeviceptr_t)dev, (unsigned short)v, count, pp::g_stream));
+  } else if (pattern_bytes == 4) {
+    PP_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)dev, (int)(unsigned)v, count, pp::g_stream));
+  } else {
+    pp::k_fill64<<<(unsigned)std::min<size_t>((count + 255) / 256, 4096), 256, 0, pp::g_stream>>>(
+        (unsigned long long*)dev, v, count);
+    PP_LAUNCH_CHECK();
+  }
   return PP_OK;
 }
 int pp_memcpy_h2d(void* dev, const void* host, size_t bytes) {

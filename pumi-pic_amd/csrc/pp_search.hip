@@ -15,6 +15,8 @@
 // neighbour ids with -1 = exposed side, class id, measure) instead of the reference's chain of
 // dependent gathers elem2verts -> coords, elem2sides -> exposed -> side2elems.
 #include "pp_geom.hpp"
+#include <atomic>
+#include <chrono>
 #include "pp_internal.hpp"
 #include "pp_push_math.hpp"
 
@@ -31,6 +33,13 @@ struct Counters {
   int aborted;     // legacy search: origin not in start element at loops==0 (OMEGA_H_CHECK)
   int pending;     // fused kernel: entries in the deferred-walk queue
   int unmoved;     // trusted-origin mode: particles that finished as "unmoved" (no containment test ran)
+};
+// landing zone of search_mesh_2d's result in host-mapped memory: a one-thread kernel behind the search writes the
+// count and then the stamp, the host polls the stamp -- the `bool found` every search returns (adjacency.hpp:1011-1020)
+// without a stream synchronisation (~25 us of idle GPU per step of the drop-in loop)
+struct FoundPin {
+  int stamp;
+  int not_found;
 };
 
 __device__ __forceinline__ void load_tri(const pp_tri_rec* __restrict__ recs, int e, V2 fc[3],
@@ -926,8 +935,7 @@ __device__ __forceinline__ bool step_cached(const RecCache<2>& c, V3 pos, int& n
 }
 template <int DIM>
 __device__ __forceinline__ int bcc_walk_cached(RecCache<DIM>& c, const void* __restrict__ recs,
-                                               int elem, V3 pos, int looplimit, Counters* cnt) {
-  int loops = 0;
+                                               int elem, V3 pos, int looplimit, Counters* cnt, int loops = 0) {
   const int cap = looplimit ? looplimit : kHardLoopCap;
   while (true) {
     fetch(c, recs, elem);
@@ -1175,6 +1183,137 @@ __global__ void __launch_bounds__(256, OCC)
     rows_particle<DIM>(s, pid, e, ct, cache, recs, nelems, xt, stride, pphi, h, k, d, tol,
                        unmoved_sq, elem_ids, seeded, looplimit, cnt, id_out, b_out, RECIN ? rin.zero_z : 0);
   }
+}
+
+// ------------------------------------------------------------------ search_mesh_2d, row-tiled (SCS)
+// The stand-alone search_mesh_2d of the drop-in loop (test/pseudoXGCm.cpp:142-156: push by a user lambda, then
+// this) with the thread = (tile, row) mapping of k_push_walk_rows: the row's element record is fetched ONCE and
+// serves the tile's columns from registers (nine particles in ten end where they started), and a wave's loads
+// of a column are 64 consecutive slots.  The flat form (k_search2d, thread = slot) fetches a 64-B record per
+// slot -- 64 different lines per wave instruction -- and reads the 4-B slot -> element table on top.
+// The inputs of the tile's columns are loaded as one batch.  A particle that does not end in its row's element
+// after the first step (or is seeded elsewhere) is a MOVER: its walk needs records nobody has fetched yet, a chain
+// of dependent loads that would stall the wave once per column (some lane of 64 moves in every column).  Movers go
+// to a per-wave list in LDS and are walked afterwards, one per lane: the chains of a tile's ~50 movers run side by
+// side instead of one column after the other (144 -> see DESIGN.md, round 5).
+struct Mover2 {
+  int pid, elem, loops, pad;
+  double x, y;
+};
+constexpr int kMoverQ = 192;  // list entries per wave; drained when fewer than 64 are free
+template <int TPMAX>
+__global__ void __launch_bounds__(256, 4)
+    k_search2d_rows(const int* __restrict__ ntiles_dev, int C, int TP, const int* __restrict__ tiles,
+                    const int* __restrict__ chunk_start, const int* __restrict__ chunk_width,
+                    const int* __restrict__ r2e, const unsigned char* __restrict__ mask,
+                    const pp_tri_rec* __restrict__ recs, int nelems, const double* __restrict__ xt,
+                    long long stride, int* __restrict__ elem_ids, int looplimit, Counters* cnt) {
+  __shared__ Mover2 q[4][kMoverQ];
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int tile = (int)(g / C);
+  const int r = (int)(g - (long long)tile * C);
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool valid = tile < *ntiles_dev;
+  int start = 0, p0 = 0, pend = 0, e = nelems;
+  if (valid) {
+    const int c = tiles[2 * tile];
+    p0 = tiles[2 * tile + 1];
+    start = chunk_start[c] + r;
+    pend = min(p0 + TP, chunk_width[c]);
+    e = r2e[c * C + r];
+  }
+  const int cap = looplimit ? looplimit : kHardLoopCap;
+  RecCache<2> cache;
+  cache.id = -1;
+  int nq = 0;  // wave-uniform
+  auto drain = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int base = 0; base < nq; base += 64) {  // (the row's cached record is given up: re-fetched below)
+      const int i = base + lane;
+      if (i < nq) {
+        const Mover2 m = q[wv][i];
+        stg<true>(elem_ids + m.pid, bcc_walk_cached<2>(cache, recs, m.elem, V3{m.x, m.y, 0.0}, looplimit, cnt, m.loops));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    nq = 0;
+  };
+  // (wave-uniform trip count: the tile's columns are the same in every lane of a wave when C == 64; other chunk
+  // heights may mix tiles in a wave, so the bound is the wave's widest)
+  int ncol = valid ? pend - p0 : 0;
+  for (int o = 32; o > 0; o >>= 1) ncol = max(ncol, __shfl_xor(ncol, o));
+  for (int pb = 0; pb < ncol; pb += TPMAX) {
+    unsigned char m[TPMAX];
+    int seed[TPMAX];
+    double x[TPMAX], y[TPMAX];
+#pragma unroll
+    for (int j = 0; j < TPMAX; ++j) {
+      const int pid = start + (p0 + pb + j) * C;
+      m[j] = 0;
+      seed[j] = -1;
+      x[j] = y[j] = 0;
+      if (p0 + pb + j < pend) {
+        m[j] = ld<true>(mask + pid);
+        seed[j] = ld<true>(elem_ids + pid);
+        x[j] = ld<true>(xt + pid);
+        y[j] = ld<true>(xt + stride + pid);
+      }
+    }
+    // (behind the batch's loads: the record is the end of a chain of four dependent loads)
+    if (valid && e < nelems) fetch(cache, recs, e);
+#pragma unroll
+    for (int j = 0; j < TPMAX; ++j) {
+      const bool in = p0 + pb + j < pend;
+      const int pid = start + (p0 + pb + j) * C;
+      int out = -1, melem = -1, mloops = 0;
+      bool mover = false;
+      if (in && m[j]) {
+        const int elem = seed[j] == -1 ? e : seed[j];  // hpp:1047-1056
+        if (elem != -nelems && elem >= 0 && elem < nelems) {
+          if (elem == cache.id) {  // the first step of bcc_walk, on the row's record
+            int next;
+            const bool done = step_cached(cache, V3{x[j], y[j], 0.0}, next);
+            if (done) {
+              out = elem;
+            } else if (next == -1) {
+              out = -1;  // exposed side: leaves the domain
+            } else if (1 >= cap) {
+              atomicAdd(&cnt->not_found, 1);
+            } else {
+              mover = true;
+              melem = next;
+              mloops = 1;
+            }
+          } else {
+            mover = true;
+            melem = elem;
+          }
+        }
+      }
+      if (in && !mover) stg<true>(elem_ids + pid, out);
+      const unsigned long long mv = __ballot(mover);
+      if (mover) {
+        const int at = nq + __popcll(mv & ((1ull << lane) - 1ull));
+        q[wv][at] = Mover2{pid, melem, mloops, 0, x[j], y[j]};
+      }
+      nq += __popcll(mv);
+      if (nq > kMoverQ - 64) {  // (rare: more than 128 movers in the tile so far)
+        drain();
+        if (valid && e < nelems) fetch(cache, recs, e);  // (the drain walked with the row's cache)
+      }
+    }
+  }
+  if (nq) drain();
+}
+// one thread behind the search kernel (stream order): the count, then the stamp, into host-mapped memory.  (A ticket
+// counter inside the search kernel -- the last of 48 000 blocks reports -- serialised that many atomics on one
+// address: 125 -> 390 us.)
+__global__ void k_report_found(const Counters* __restrict__ cnt, FoundPin* pin, int stamp) {
+  pin->not_found = cnt->not_found;
+  __threadfence_system();
+  __hip_atomic_store(&pin->stamp, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ------------------------------------------------------------------ row-tiled kernel, queued walk
@@ -2109,6 +2248,10 @@ int read_counters(Counters* h) {
   return PP_OK;
 }
 
+FoundPin* g_found_pin = nullptr;
+int g_found_stamp = 0;
+bool g_found_poll = true;  // (one poll that times out switches back to the stream synchronisation for good)
+
 int member_ok(const pp_ps* ps, int m, int bytes, int ncomp, const char* what) {
   if (int rc = pp::ps_ready(ps)) return rc;  // a member that is only logically zero gets its zeros now
   if (m < 0 || m >= ps->nmembers) {
@@ -2141,10 +2284,54 @@ int pp_search_mesh_2d(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m
   if (found) *found = 1;
   if (ps->num_ptcls == 0 || ps->capacity == 0) return PP_OK;
   if ((rc = reset_counters())) return rc;
-  k_search2d<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
-      ps->capacity, ps->d_mask.as<unsigned char>(), pp::slot_elem(ps),
-      mesh->d_records.as<pp_tri_rec>(), mesh->nelems, PP_MEMBER(ps, m_xtgt, double), ps->stride,
-      elem_ids_dev, looplimit, g_cnt.get());
+  if (ps->kind == PP_SCS && ps->ntiles_max > 0 && ps->tile_p <= 8) {
+    if (found && g_found_poll && !g_found_pin) {
+      if (hipHostMalloc((void**)&g_found_pin, sizeof(FoundPin), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        g_found_pin = nullptr;
+        g_found_poll = false;
+      } else {
+        memset(g_found_pin, 0, sizeof(FoundPin));
+      }
+    }
+    const bool poll = found && g_found_poll && g_found_pin;
+    const int stamp = poll ? (g_found_stamp = g_found_stamp % 1000000 + 1) : 0;
+    k_search2d_rows<8><<<grid_for((size_t)ps->ntiles_max * ps->C), kBlock, 0, pp::stream()>>>(
+        ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(),
+        ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(), ps->d_mask.as<unsigned char>(),
+        mesh->d_records.as<pp_tri_rec>(), mesh->nelems, PP_MEMBER(ps, m_xtgt, double), ps->stride, elem_ids_dev,
+        looplimit, g_cnt.get());
+    if (poll) k_report_found<<<1, 1, 0, pp::stream()>>>(g_cnt.get(), g_found_pin, stamp);
+    PP_LAUNCH_CHECK();
+    if (poll) {
+      const auto t0 = std::chrono::steady_clock::now();
+      volatile int* flag = &g_found_pin->stamp;
+      long spins = 0;
+      bool seen = true;
+      while (*flag != stamp) {
+        if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(500)) {
+          PP_HIP_CHECK(hipStreamSynchronize(pp::stream()));
+          if (*flag != stamp) {  // kernel stores do not reach this memory mid-stream here: the stream's way from now on
+            g_found_poll = false;
+            seen = false;
+          }
+          break;
+        }
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      if (seen) {
+        const int nf = g_found_pin->not_found;
+        *found = (nf == 0);
+        if (nf)
+          fprintf(stderr, "ERROR: loop limit %d exceeded. %d particles were not found. Deleting them...\n", looplimit, nf);
+        return PP_OK;
+      }
+    }
+  } else  // CSR: thread = slot
+    k_search2d<<<grid_for(ps->capacity), kBlock, 0, pp::stream()>>>(
+        ps->capacity, ps->d_mask.as<unsigned char>(), pp::slot_elem(ps),
+        mesh->d_records.as<pp_tri_rec>(), mesh->nelems, PP_MEMBER(ps, m_xtgt, double), ps->stride,
+        elem_ids_dev, looplimit, g_cnt.get());
   PP_LAUNCH_CHECK();
   if (found) {
     Counters h;

@@ -139,8 +139,10 @@ int main(int argc, char** argv) {
         lint(p) = 0;
       }
     };
+    p::fence();  // Kokkos::fence() on both sides of the timed pass (ps_combo160.cpp:180-184)
     p::Timer t;
     ps::parallel_for(ptcls, pseudoPush, "pseudo push");
+    p::fence();
     p::RecordTime(name + " pseudo-push", t.seconds());
   }
 
@@ -234,8 +236,10 @@ int main(int argc, char** argv) {
     }
     p::RecordTime("redistribute", t.seconds());
     kkLidView new_process("new_process", (size_t)cap);
+    p::fence();
     p::Timer tm;
     ptcls->migrate(new_elms, new_process);
+    p::fence();
     p::RecordTime(name + " migrate", tm.seconds());
     checksum += ptcls->nPtcls();
   }

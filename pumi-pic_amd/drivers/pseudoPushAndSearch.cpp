@@ -204,6 +204,7 @@ int main(int argc, char** argv) {
     }
     tagParentElements(ptcls, has_particles, iter);
   }
+  p::fence();
   fprintf(stderr, "%d iterations of pseudopush (seconds) %f\n", iter, fullTimer.seconds());
   std::vector<int> hp = has_particles.to_host();
   int touched = 0;

@@ -150,6 +150,40 @@ void tagParentElements(p::Mesh& picparts, PS* ptcls, int loop) {
   mesh->set_tag(o::FACE, "has_particles", o::LOs(ehp_nm1));
 }
 
+// PP_DRIVER_DUMP=<prefix>: the structure as raw arrays (capacity entries each, slot order; x: three components
+// `stride` apart) for the harness that replays the run on the CPU oracle (tests/test_gpu_driver.py)
+template <class T>
+static void dumpArray(const std::string& path, const T* dev, size_t n) {
+  std::vector<T> h(n);
+  if (n) p::pp_check(pp_memcpy_d2h(h.data(), dev, n * sizeof(T)), "dump");
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f || fwrite(h.data(), sizeof(T), n, f) != n) {
+    fprintf(stderr, "cannot write %s\n", path.c_str());
+    exit(EXIT_FAILURE);
+  }
+  fclose(f);
+}
+static void dumpState(const std::string& prefix, const char* tag, PS* ptcls, int rank) {
+  const std::string base = prefix + "_r" + std::to_string(rank) + "_" + tag;
+  const size_t cap = (size_t)ptcls->capacity();
+  pp_ps_layout_t L;
+  p::pp_check(pp_ps_layout(ptcls->handle(), &L), "pp_ps_layout");
+  const pp_ps_info_t info = ptcls->info();
+  auto x = ptcls->get<0>();
+  auto id = ptcls->get<2>();
+  auto b = ptcls->get<3>();
+  auto phi = ptcls->get<4>();
+  dumpArray(base + "_mask.u8", L.mask, cap);
+  dumpArray(base + "_elem.i32", L.slot_elem, cap);
+  dumpArray(base + "_x.f64", x.data(), (size_t)(2 * info.stride) + cap);
+  dumpArray(base + "_id.i32", id.data(), cap);
+  dumpArray(base + "_b.f32", b.data(), cap);
+  dumpArray(base + "_phi.f32", phi.data(), cap);
+  FILE* f = fopen((base + "_meta.txt").c_str(), "w");
+  fprintf(f, "%zu %lld %d\n", cap, (long long)info.stride, ptcls->nPtcls());
+  fclose(f);
+}
+
 static bool readMesh(const char* fn, int rank, int& dim, std::vector<double>& coords, std::vector<int>& e2v,
                      std::vector<int>& cls) {
   // test/pseudoXGCm.cpp:306-324: the extension selects the reader ("msh" = Gmsh ASCII; the Omega_h
@@ -296,6 +330,8 @@ int main(int argc, char** argv) {
   const auto k = .020558260;
   const auto d = 0.6;
   ellipticalPush::setup(ptcls, h, k, d);
+  const char* dump = getenv("PP_DRIVER_DUMP");
+  if (dump) dumpState(dump, "initial", ptcls, comm_rank);
   const auto degPerPush = atof(argv[5]);
   if (!comm_rank) fprintf(stderr, "degrees per elliptical push %f\n", degPerPush);
   if (comm_rank == 0) fprintf(stderr, "ellipse center %f %f ellipse ratio %.3f\n", h, k, d);
@@ -351,6 +387,7 @@ int main(int argc, char** argv) {
     gyroSync(picparts, fwdTagName, bkwdTagName, syncTagName);
     PP_TRACE("synced");
   }
+  p::fence();  // (the reference's loop ends in gyroSync's MPI_Allreduce, which waits for the device)
   if (comm_rank == 0) fprintf(stderr, "%d iterations of pseudopush (seconds) %f\n", iter, fullTimer.seconds());
 
   // summary line for the harness: particle count over all ranks, mass of the SYNCED forward field (the
@@ -366,6 +403,12 @@ int main(int argc, char** argv) {
     mass = m1.to_host()[0];
   } else {
     for (size_t v = 0; v < w.size(); v += 2) mass += w[v];
+  }
+  if (dump) {
+    dumpState(dump, "final", ptcls, comm_rank);
+    const std::string base = std::string(dump) + "_r" + std::to_string(comm_rank) + "_final";
+    dumpArray(base + "_fwd.f64", mesh->get_array<o::Real>(0, fwdTagName).data(), (size_t)mesh->nverts());
+    dumpArray(base + "_bkwd.f64", mesh->get_array<o::Real>(0, bkwdTagName).data(), (size_t)mesh->nverts());
   }
   std::vector<int> hp = mesh->get_array<o::LO>(picparts.dim(), "has_particles").to_host();
   int64_t touched = 0;

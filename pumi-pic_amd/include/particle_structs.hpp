@@ -50,10 +50,16 @@ class View {
   View() : p_(nullptr), n_(0) {}
   explicit View(size_t n) { alloc(n, true); }
   View(const std::string&, size_t n) { alloc(n, true); }
-  View(size_t n, T init) {  // Omega_h::Write<T>(n, value)
+  View(size_t n, T init) {  // Omega_h::Write<T>(n, value): filled on the device, on the library stream
     alloc(n, false);
-    std::vector<T> h(n, init);
-    if (n) pp_check(pp_memcpy_h2d(p_, h.data(), n * sizeof(T)), "View fill");
+    if (n) pp_check(fill_(init), "View fill");
+  }
+  // Kokkos::View<T*>(Kokkos::ViewAllocateWithoutInitializing(name), n): for arrays whose every entry is written
+  // before it is read (a 50 MB fill per 10 M slots otherwise)
+  static View uninitialized(size_t n) {
+    View v;
+    v.alloc(n, false);
+    return v;
   }
   static View wrap(T* dev, size_t n) {  // non-owning
     View v;
@@ -77,12 +83,18 @@ class View {
  private:
   void alloc(size_t n, bool zero) {
     n_ = n;
-    p_ = (T*)pp_malloc(n * sizeof(T));
+    p_ = (T*)pp_malloc(n * sizeof(T));  // (pooled: include/pumipic_hip.h)
     if (!p_) pp_check(PP_EHIP, "View allocation");
     own_ = std::shared_ptr<void>((void*)p_, [](void* q) { (void)pp_free(q); });
-    if (zero && n) {
-      pp_check(pp_memset(p_, 0, n * sizeof(T)), "View memset");
-      pp_check(pp_sync(), "View memset sync");
+    // Kokkos::View zero-initialises; stream-ordered like everything else that touches the array
+    if (zero && n) pp_check(pp_memset(p_, 0, n * sizeof(T)), "View memset");
+  }
+  int fill_(const T& v) {
+    if constexpr (sizeof(T) == 1 || sizeof(T) == 2 || sizeof(T) == 4 || sizeof(T) == 8) {
+      return pp_fill(p_, &v, (int)sizeof(T), n_);
+    } else {
+      std::vector<T> h(n_, v);
+      return pp_memcpy_h2d(p_, h.data(), n_ * sizeof(T));
     }
   }
   T* p_;
@@ -298,7 +310,7 @@ class ParticleStructure {
   // receiver's rebuild as new particles; one rank -> plain rebuild (:20-25)
   virtual void migrate(kkLidView new_element, kkLidView new_process, Distributor dist = Distributor(),
                        kkLidView new_particle_elements = kkLidView(), MTVs new_particle_info = NULL) {
-    if (!dist.isWorld()) {  // every leaving particle goes to a rank of the subset
+    if (!dist.isWorld() && pp_comm_size(dist.comm()) > 1) {  // every leaving particle goes to a rank of the subset
       // The check is COLLECTIVE: a rank that found a violation and left alone would leave its peers waiting
       // in the exchange (round-3 advisor) -- every rank contributes its verdict to one host all-gather and
       // all of them stop together, each naming the ranks at fault.
@@ -463,7 +475,9 @@ class CSR : public ParticleStructure<DataTypes> {
 
 // ---------------------------------------------------------------- parallel_for
 // One thread per slot; fn(element_id, particle_id, mask) is called for EVERY slot the reference
-// would visit, masked ones included (SellCSigma.h:545-552, CSR.hpp:198-208).
+// would visit, masked ones included (SellCSigma.h:545-552, CSR.hpp:198-208).  Sell-C-sigma with chunk
+// height 64 (the wave): the 64 slots of a wave are the 64 rows of one column of one chunk -- the chunk comes from
+// a wave-uniform load, the element from the row table (pp_ps_iteration); else from the slot -> element table.
 template <class Fn>
 __global__ void ps_parallel_for_kernel(int capacity, const int* __restrict__ slot_elem,
                                        const unsigned char* __restrict__ mask, Fn fn) {
@@ -473,19 +487,32 @@ __global__ void ps_parallel_for_kernel(int capacity, const int* __restrict__ slo
   if (e < 0) return;
   fn(e, pid, (int)mask[pid]);
 }
+template <class Fn>
+__global__ void ps_parallel_for_kernel_c64(int capacity, const int* __restrict__ group_chunk,
+                                           const int* __restrict__ row_to_element,
+                                           const unsigned char* __restrict__ mask, Fn fn) {
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= capacity) return;
+  const int c = __builtin_amdgcn_readfirstlane(group_chunk[pid >> 6]);
+  const int e = row_to_element[(c << 6) + (pid & 63)];
+  fn(e, pid, (int)mask[pid]);
+}
 template <typename FunctionType, typename DataTypes>
 void parallel_for(ParticleStructure<DataTypes>* ps, FunctionType& fn, std::string = "") {
   if (!ps || !ps->handle()) {
     fprintf(stderr, "Structure does not support parallel for\n");
     throw 1;  // ps_for.hpp:28-30
   }
-  const pp_ps_info_t i = ps->info();
-  if (i.num_ptcls == 0 || i.capacity == 0) return;  // SellCSigma.h:529
-  pp_ps_layout_t L;
-  pp_check(pp_ps_layout(ps->handle(), &L), "pp_ps_layout");
-  const int block = 256, grid = (i.capacity + block - 1) / block;
-  hipLaunchKernelGGL(ps_parallel_for_kernel<FunctionType>, dim3(grid), dim3(block), 0,
-                     (hipStream_t)pp_stream(), i.capacity, L.slot_elem, L.mask, fn);
+  pp_ps_iter_t it;
+  pp_check(pp_ps_iteration(ps->handle(), &it), "pp_ps_iteration");
+  if (ps->nPtcls() == 0 || it.capacity == 0) return;  // SellCSigma.h:529
+  const int block = 256, grid = (it.capacity + block - 1) / block;
+  if (it.group_chunk)
+    hipLaunchKernelGGL(ps_parallel_for_kernel_c64<FunctionType>, dim3(grid), dim3(block), 0,
+                       (hipStream_t)pp_stream(), it.capacity, it.group_chunk, it.row_to_element, it.mask, fn);
+  else
+    hipLaunchKernelGGL(ps_parallel_for_kernel<FunctionType>, dim3(grid), dim3(block), 0,
+                       (hipStream_t)pp_stream(), it.capacity, it.slot_elem, it.mask, fn);
 }
 
 }  // namespace pumipic

@@ -564,11 +564,22 @@ inline double pumipic_prebarrier(pp_comm* c = nullptr) {
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 inline double prebarrier() { return pumipic_prebarrier(); }
-struct Timer {  // Kokkos::Timer stand-in; seconds() drains the stream first, like Kokkos::fence
+// Kokkos::fence(): the host waits for everything enqueued on the library stream
+inline void fence() { pp_check(pp_sync(), "fence"); }
+// Kokkos::Timer: a host clock.  Like the reference's, seconds() does NOT wait for the device (test/ellipticalPush.hpp:39,68
+// records the launch of an asynchronous kernel); callers that want device time fence first, as the reference does
+// (performance_tests/ps_combo160.cpp:180-184).  PP_TIMER_FENCE=1 in the environment (or SetTimerFence(true)) makes every
+// seconds() fence: per-operation tables that hold device time, at the price of one host wait per recorded operation.
+inline int& timer_fence_flag() {
+  static int f = (getenv("PP_TIMER_FENCE") && atoi(getenv("PP_TIMER_FENCE"))) ? 1 : 0;
+  return f;
+}
+inline void SetTimerFence(bool on) { timer_fence_flag() = on ? 1 : 0; }
+struct Timer {
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   void reset() { t0 = std::chrono::steady_clock::now(); }
   double seconds() const {
-    (void)pp_sync();
+    if (timer_fence_flag()) (void)pp_sync();
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
 };
@@ -753,7 +764,8 @@ template <class PS>
 void migrate_ptcls(Mesh& mesh, PS* ptcls, o::LOs elems, const Distributor* dist = nullptr) {
   Timer init_timer;
   const size_t cap = (size_t)std::max(ptcls->capacity(), 1);
-  typename PS::kkLidView new_elems("ps_element_ids", cap), new_procs("ps_process_ids", cap);
+  // (setUnsafeProcs writes every slot of both arrays)
+  auto new_elems = PS::kkLidView::uninitialized(cap), new_procs = PS::kkLidView::uninitialized(cap);
   setUnsafeProcs(mesh, ptcls, elems, new_elems, new_procs);
   RecordTime("migration_init", init_timer.seconds());
   Timer migrate_timer;
@@ -770,7 +782,8 @@ void migrate_lb_ptcls(Mesh& mesh, PS* ptcls, o::LOs elems, float tol, float step
   }
   Timer init_timer;
   const size_t cap = (size_t)std::max(ptcls->capacity(), 1);
-  typename PS::kkLidView new_elems("ps_element_ids", cap), new_procs("ps_process_ids", cap);
+  // (setUnsafeProcs writes every slot of both arrays)
+  auto new_elems = PS::kkLidView::uninitialized(cap), new_procs = PS::kkLidView::uninitialized(cap);
   setUnsafeProcs(mesh, ptcls, elems, new_elems, new_procs);
   RecordTime("migration_init", init_timer.seconds());
   Timer balance_timer;
