@@ -171,6 +171,9 @@ typedef struct pp_ps_iter_t {
 int pp_ps_iteration(const pp_ps* ps, pp_ps_iter_t* out);
 int pp_ps_layout_to_host(const pp_ps* ps, int* offsets, int* slice_to_chunk, int* row_to_element,
                          int* element_to_row, unsigned char* mask, int* slot_elem);
+/* element_to_gid (the kkGidView the structure was built with, SellCSigma.h:209): copies num_elems gids to
+ * out_host and returns num_elems; 0 when the structure has none; negative on error */
+int pp_ps_gids_to_host(const pp_ps* ps, int64_t* out_host);
 int pp_ps_member_to_host(pp_ps* ps, int m, void* out_host);   /* [ncomp][stride] */
 int pp_ps_member_from_host(pp_ps* ps, int m, const void* in_host);
 /* rebuild(new_element, new_particle_elements, new_particle_info) scs/SCS_rebuild.h:122-314,

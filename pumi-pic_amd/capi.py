@@ -88,6 +88,7 @@ SYMBOLS = {
     "pp_ps_layout": (_I, [_V, C.POINTER(PsLayout)]),
     "pp_ps_iteration": (_I, [_V, _V]),
     "pp_ps_layout_to_host": (_I, [_V, _V, _V, _V, _V, _V, _V]),
+    "pp_ps_gids_to_host": (_I, [_V, _V]),
     "pp_ps_member_to_host": (_I, [_V, _I, _V]),
     "pp_ps_member_from_host": (_I, [_V, _I, _V]),
     "pp_ps_rebuild": (_I, [_V, _V, _I, _V, _V]),

@@ -3059,6 +3059,14 @@ int pp_ps_layout_to_host(const pp_ps* ps, int* offsets, int* slice_to_chunk, int
   return PP_OK;
 }
 
+int pp_ps_gids_to_host(const pp_ps* ps, int64_t* out_host) {
+  PP_REQUIRE(ps && out_host, "pp_ps_gids_to_host: null argument");
+  if (!ps->has_gids || ps->num_elems == 0) return 0;
+  PP_HIP_CHECK(hipStreamSynchronize(pp::stream()));
+  PP_HIP_CHECK(hipMemcpy(out_host, ps->d_gids.p, sizeof(int64_t) * (size_t)ps->num_elems, hipMemcpyDeviceToHost));
+  return ps->num_elems;
+}
+
 int pp_ps_member_to_host(pp_ps* ps, int m, void* out_host) {
   PP_REQUIRE(ps && out_host && m >= 0 && m < ps->nmembers, "pp_ps_member_to_host: bad argument");
   if (int rc = pp::ps_ready(ps)) return rc;

@@ -8,6 +8,9 @@
 //   SellCSigma, SCS_Input                particle_structs/src/scs/SellCSigma.h:52-141, scs_input.hpp:27-36
 //   CSR, CSR_Input                       particle_structs/src/csr/CSR.hpp:37-69, CSR_input.hpp
 //   ps::parallel_for(ps, lambda, name)   particle_structs/src/ps_for.hpp:5-31
+//   ps::copy<MSpace>(ps)                 particle_structs/src/ps_for.hpp:33-55 (device -> host snapshot)
+//   ParticleStructure::getPIDs           particle_structs/src/ps_for.hpp:57-85
+//   printFormat                          scs/SellCSigma.h:403-463, csr/CSR.hpp:232-266
 //   createMemberViews/getMemberView/destroyViews  support/MemberTypeLibraries.h:33-41
 //   PS_LAMBDA, lid_t, gid_t              support/ppMacros.h:3-13, support/ppTypes.h:5-30
 // Kokkos::View<T*> is replaced by pumipic::View<T> (device array with shared ownership); a
@@ -18,7 +21,9 @@
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
+#include <iostream>
 #include <memory>
+#include <sstream>
 #include <string>
 #include <type_traits>
 #include <utility>
@@ -361,6 +366,70 @@ class ParticleStructure {
              i.num_elems, i.num_ptcls, i.capacity);
     }
   }
+  // printFormat (scs/SellCSigma.h:403-463, csr/CSR.hpp:232-266): the structure's layout as text on stdout --
+  // chunks with their elements(gids), slices with the particle mask of every slot; CSR: one `1` per particle
+  virtual void printFormat(const char* prefix = "") const {
+    const pp_ps_info_t i = info();
+    std::vector<int64_t> gids((size_t)std::max(i.num_elems, 1));
+    const int ngids = pp_ps_gids_to_host(h_, gids.data());
+    std::stringstream ss;
+    char buffer[1000];
+    if (i.kind == PP_SCS) {
+      std::vector<int> off((size_t)i.num_slices + 1), s2c((size_t)std::max(i.num_slices, 1)), r2e((size_t)std::max(i.num_rows, 1));
+      std::vector<unsigned char> mask((size_t)std::max(i.capacity, 1));
+      pp_check(pp_ps_layout_to_host(h_, off.data(), s2c.data(), r2e.data(), nullptr, mask.data(), nullptr), "printFormat");
+      snprintf(buffer, sizeof(buffer), "%s\nParticle Structures Sell-C-Sigma C: %d sigma: %d V: %d.\nNumber of Elements: %d.\n"
+               "Number of Particles: %d.\nNumber of Chunks: %d.\nNumber of Slices: %d.\n", prefix, i.C, i.sigma, i.V,
+               i.num_elems, i.num_ptcls, i.num_chunks, i.num_slices);
+      ss << buffer;
+      int last_chunk = -1;
+      for (int sl = 0; sl < i.num_slices; ++sl) {
+        const int chunk = s2c[(size_t)sl];
+        if (chunk != last_chunk) {
+          last_chunk = chunk;
+          ss << "  Chunk " << chunk << ". Elements" << (ngids > 0 ? "(GID)" : "") << ":";
+          for (int row = chunk * i.C; row < (chunk + 1) * i.C; ++row) {
+            const int elem = r2e[(size_t)row];
+            ss << " " << elem;
+            if (ngids > 0) ss << "(" << (elem < ngids ? (long)gids[(size_t)elem] : -1L) << ")";  // (padding rows: no gid)
+          }
+          ss << "\n";
+        }
+        ss << "    Slice " << sl;
+        for (int j = off[(size_t)sl]; j < off[(size_t)sl + 1]; ++j) {
+          if ((j - off[(size_t)sl]) % i.C == 0) ss << " |";
+          ss << " " << (int)mask[(size_t)j];
+        }
+        ss << "\n";
+      }
+    } else {
+      std::vector<int> off((size_t)i.num_elems + 1);
+      pp_check(pp_ps_layout_to_host(h_, off.data(), nullptr, nullptr, nullptr, nullptr, nullptr), "printFormat");
+      snprintf(buffer, sizeof(buffer), "%s\nParticle Structures CSR\nNumber of Elements: %d.\nNumber of Particles: %d.",
+               prefix, i.num_elems, i.num_ptcls);
+      ss << buffer;
+      for (int e = 1; e <= i.num_elems; ++e) {
+        if (off[(size_t)e] == off[(size_t)e - 1]) continue;
+        if (ngids > 0)
+          snprintf(buffer, sizeof(buffer), "\n  Element %2d(%2ld) |", e - 1, (long)gids[(size_t)e - 1]);
+        else
+          snprintf(buffer, sizeof(buffer), "\n  Element %2d |", e - 1);
+        ss << buffer;
+        for (int j = off[(size_t)e - 1]; j < off[(size_t)e]; ++j) ss << " 1";
+      }
+      ss << "\n";
+    }
+    std::cout << ss.str();
+  }
+  // getPIDs (ps_for.hpp:57-85): offsets[e] .. offsets[e+1] index the slots of element e's live particles in pids
+  // (the reference fills each element's range in the order of its atomics; here in slot order)
+  template <typename ViewT>
+  void getPIDs(ViewT& pids, ViewT& offsets) {
+    offsets = ViewT("offsets", (size_t)nElems() + 1);
+    pids = ViewT("pids", (size_t)std::max(nPtcls(), 1));
+    pp_check(pp_ps_get_pids(h_, offsets.data(), pids.data()), "getPIDs");
+    if (nPtcls() == 0) pids = ViewT();
+  }
   pp_ps_info_t info() const {
     pp_ps_info_t i;
     pp_check(pp_ps_info(h_, &i), "pp_ps_info");
@@ -445,14 +514,51 @@ class SellCSigma : public ParticleStructure<DataTypes> {
   }
 };
 
+// csr/CSR_input.hpp:10-42
+template <class DataTypes>
+class CSR_Input {
+ public:
+  typedef View<lid_t> kkLidView;
+  typedef View<gid_t> kkGidView;
+  typedef MemberTypeViews MTVs;
+  typedef TeamPolicy PolicyType;
+  CSR_Input(PolicyType& p, lid_t num_elements, lid_t num_particles, kkLidView particles_per_element,
+            kkGidView element_gids, kkLidView particle_elements = kkLidView(), MTVs particle_info = NULL)
+      : policy(p), ne(num_elements), np(num_particles), ppe(particles_per_element), e_gids(element_gids),
+        particle_elems(particle_elements), p_info(particle_info) {
+    name = "ptcls";
+  }
+  bool always_realloc = false;   // (the library's swap buffers grow on demand and are kept: nothing to choose)
+  double minimize_size = 0.8;
+  double padding_amount = 1.05;  // capacity = padding_amount * num_ptcls
+  std::string name;
+  PolicyType policy;
+  lid_t ne, np;
+  kkLidView ppe;
+  kkGidView e_gids;
+  kkLidView particle_elems;
+  MTVs p_info;
+};
+
 template <class DataTypes>
 class CSR : public ParticleStructure<DataTypes> {
  public:
   typedef View<lid_t> kkLidView;
   typedef View<gid_t> kkGidView;
   typedef MemberTypeViews MTVs;
+  typedef CSR_Input<DataTypes> Input_T;
+  CSR(Input_T& in) {  // csr/CSR.hpp:146-156
+    this->name_ = in.name;
+    construct(in.ne, in.np, in.ppe, in.e_gids, in.particle_elems, in.p_info, in.padding_amount);
+  }
   CSR(TeamPolicy&, lid_t num_elements, lid_t num_particles, kkLidView particles_per_element,
       kkGidView element_gids, kkLidView particle_elements = kkLidView(), MTVs particle_info = NULL) {
+    construct(num_elements, num_particles, particles_per_element, element_gids, particle_elements, particle_info, 1.05);
+  }
+
+ private:
+  void construct(lid_t num_elements, lid_t num_particles, kkLidView particles_per_element, kkGidView element_gids,
+                 kkLidView particle_elements, MTVs particle_info, double padding_amount) {
     const auto b = MemberMeta<DataTypes>::bytes();
     const auto c = MemberMeta<DataTypes>::ncomp();
     std::vector<lid_t> ppe_h = particles_per_element.to_host();
@@ -461,7 +567,7 @@ class CSR : public ParticleStructure<DataTypes> {
     const bool with_info = particle_elements.size() > 0 && particle_info != NULL;
     if (with_info) std::fill(ppe_h.begin(), ppe_h.end(), 0);
     this->h_ = pp_ps_create_csr(num_elements, with_info ? 0 : num_particles, ppe_h.data(),
-                                g64.empty() ? nullptr : g64.data(), 1.05, (int)DataTypes::size,
+                                g64.empty() ? nullptr : g64.data(), padding_amount, (int)DataTypes::size,
                                 b.data(), c.data(), nullptr, nullptr);
     if (!this->h_) pp_check(PP_EHIP, "CSR construction");
     if (with_info) {
@@ -513,6 +619,89 @@ void parallel_for(ParticleStructure<DataTypes>* ps, FunctionType& fn, std::strin
   else
     hipLaunchKernelGGL(ps_parallel_for_kernel<FunctionType>, dim3(grid), dim3(block), 0,
                        (hipStream_t)pp_stream(), it.capacity, it.slot_elem, it.mask, fn);
+}
+
+// ---------------------------------------------------------------- ps::copy<MSpace> (ps_for.hpp:33-55)
+// The reference copies a structure into another memory space (SellCSigma::copy<MSpace>, scs/SellCSigma.h:336-391:
+// a deep copy of every layout array and member view) -- its tests read a device structure back with it and run
+// the same PS_LAMBDA on the host copy (particle_structs/test/test_structure.cpp).  Here: a HOST SNAPSHOT with the
+// same read interface (nElems / nPtcls / capacity / numRows, get<N>() -> Segment over host memory, the layout arrays,
+// ps::parallel_for on the host); rebuild / migrate stay with the device structure.
+struct HostSpace {};
+struct DeviceSpace {};
+template <class DataTypes>
+class HostParticleStructure {
+ public:
+  typedef DataTypes Types;
+  template <std::size_t N>
+  using DataType = typename MemberTypeAtIndex<N, DataTypes>::type;
+  template <std::size_t N>
+  using Slice = Segment<DataType<N>>;
+  explicit HostParticleStructure(ParticleStructure<DataTypes>* old) : name_(old->getName()), i_(old->info()) {
+    const auto b = MemberMeta<DataTypes>::bytes();
+    const auto c = MemberMeta<DataTypes>::ncomp();
+    data_.resize(DataTypes::size);
+    for (std::size_t m = 0; m < DataTypes::size; ++m) {
+      data_[m].resize((size_t)std::max<int64_t>(i_.stride, 1) * c[m] * b[m]);
+      if (i_.capacity > 0) pp_check(pp_ps_member_to_host(old->handle(), (int)m, data_[m].data()), "ps::copy (members)");
+    }
+    const bool scs = i_.kind == PP_SCS;
+    offsets.resize(scs ? (size_t)i_.num_slices + 1 : (size_t)i_.num_elems + 1);
+    slice_to_chunk.resize(scs ? (size_t)std::max(i_.num_slices, 1) : 1);
+    row_to_element.resize(scs ? (size_t)std::max(i_.num_rows, 1) : 1);
+    element_to_row.resize(scs ? (size_t)std::max(i_.num_rows, 1) : 1);
+    particle_mask.resize((size_t)std::max(i_.capacity, 1));
+    slot_element.resize((size_t)std::max(i_.capacity, 1));
+    pp_check(pp_ps_layout_to_host(old->handle(), offsets.data(), scs ? slice_to_chunk.data() : nullptr,
+                                  scs ? row_to_element.data() : nullptr, scs ? element_to_row.data() : nullptr,
+                                  particle_mask.data(), slot_element.data()), "ps::copy (layout)");
+  }
+  const std::string& getName() const { return name_; }
+  lid_t nElems() const { return i_.num_elems; }
+  lid_t nPtcls() const { return i_.num_ptcls; }
+  lid_t capacity() const { return i_.capacity; }
+  lid_t numRows() const { return i_.num_rows; }
+  const pp_ps_info_t& info() const { return i_; }
+  template <std::size_t N>
+  Slice<N> get() {
+    if (nPtcls() == 0) return Slice<N>(nullptr, 0, (int)N);
+    using B = typename BaseType<DataType<N>>::type;
+    return Slice<N>((B*)data_[N].data(), i_.stride, (int)N);
+  }
+  // layout arrays of the snapshot (SellCSigma.h:186-215 / CSR.hpp:92-93), host memory
+  std::vector<lid_t> offsets, slice_to_chunk, row_to_element, element_to_row, slot_element;
+  std::vector<unsigned char> particle_mask;
+
+ private:
+  std::string name_;
+  pp_ps_info_t i_;
+  std::vector<std::vector<char>> data_;
+};
+template <typename MSpace, typename DataTypes>
+HostParticleStructure<DataTypes>* copy(ParticleStructure<DataTypes>* old) {
+  if (!old || !old->handle()) {
+    fprintf(stderr, "Structure does not support copy\n");
+    throw 1;  // ps_for.hpp:52-54
+  }
+  if (!std::is_same<MSpace, HostSpace>::value) {  // scs/SellCSigma.h:339-342
+    fprintf(stderr, "Copy to same memory space not supported\n");
+    exit(EXIT_FAILURE);
+  }
+  return new HostParticleStructure<DataTypes>(old);
+}
+// the same PS_LAMBDA on the host copy: every slot in slot order
+template <typename FunctionType, typename DataTypes>
+void parallel_for(HostParticleStructure<DataTypes>* ps, FunctionType& fn, std::string = "") {
+  if (!ps) {
+    fprintf(stderr, "Structure does not support parallel for\n");
+    throw 1;
+  }
+  if (ps->nPtcls() == 0) return;
+  for (lid_t pid = 0; pid < ps->capacity(); ++pid) {
+    const lid_t e = ps->slot_element[(size_t)pid];
+    if (e < 0) continue;
+    fn(e, pid, (int)ps->particle_mask[(size_t)pid]);
+  }
 }
 
 }  // namespace pumipic

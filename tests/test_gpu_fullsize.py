@@ -85,21 +85,33 @@ def test_c2_full_size_equals_oracle(pp, ppo, capi):
     idg, mkg = pg.member(2)[0, :capg].copy(), pg.slot_info()[1]
     ido, mko = po.member(2)[0, :capo].copy(), po.slot_info()[1]
     ids_o = None
+    # The libm link of the parity chain, at this size (round 5): a SECOND oracle structure takes the same six steps
+    # with trig=0 -- glibc sin/cos, what the reference's Kokkos::Serial build calls -- and is compared with the HIP
+    # path after every step: element ids of all 10 M particles, then x, x_tgt, phi within 1e-12 relative.
+    pl = ppo.PS.scs(ppo.PARTICLE_XGCM, w["ne"], w["ppe"], C_max=64, sigma=2**31 - 1, V=1024, pad_strat=0,
+                    shuffle_padding=0.1, extra_padding=0.0, particle_elements=w["elem"], particle_info=w["info"])
+    ids_l = None
+    libm_diff = []
     ppo.set_threads(ppo.max_threads())
     try:
         for step in range(6):
             capi.push_search(mg, pg, s.XGC_H, s.XGC_K, s.XGC_D, 0.5, ids_g, seeded=(step > 0), looplimit=200)
             ppo.toroidal_push(po, mo, s.XGC_H, s.XGC_K, s.XGC_D, 0.5, trig=1)
             ids_o = ppo.search_mesh(mo, po, elem_ids=ids_o, looplimit=200)["elem_ids"]
+            ppo.toroidal_push(pl, mo, s.XGC_H, s.XGC_K, s.XGC_D, 0.5, trig=0)
+            ids_l = ppo.search_mesh(mo, pl, elem_ids=ids_l, looplimit=200)["elem_ids"]
             _, eg = common.by_id(idg, mkg, ids_g.to_host()[:capg])
             _, eo = common.by_id(ido, mko, ids_o[:capo])
+            _, el = common.by_id(ido, mko, ids_l[:capo])
             assert np.array_equal(eg, eo), step
+            libm_diff.append(int((eg != el).sum()))
             if step < 5:
                 pg.swap_members(0, 1)
-                a, b = po.member(0), po.member(1)
-                tmp = a.copy()
-                a[:] = b
-                b[:] = tmp
+                for q in (po, pl):
+                    a, b = q.member(0), q.member(1)
+                    tmp = a.copy()
+                    a[:] = b
+                    b[:] = tmp
     finally:
         ppo.set_threads(1)
     assert (eo != common.by_id(ido, mko, po.slot_info()[0])[1]).mean() > 0.25  # (a third has left its row's element)
@@ -107,6 +119,12 @@ def test_c2_full_size_equals_oracle(pp, ppo, capi):
         _, a = common.by_id(ido, mko, po.member(m)[:, :capo])
         _, b = common.by_id(idg, mkg, pg.member(m)[:, :capg])
         assert np.array_equal(a, b), m
+        _, c = common.by_id(ido, mko, pl.member(m)[:, :capo])
+        c = c.astype(np.float64)  # (relative to the particle's own scale: the largest component of the member)
+        rel = np.abs(c - b) / np.maximum(np.abs(c).max(axis=0, keepdims=True), 1e-300)
+        assert rel.max() <= 1e-12, (m, rel.max())
+    print("HIP path vs oracle(libm), 10 M particles: particles in another element after steps 1-6: %s" % libm_diff)
+    assert max(libm_diff) == 0, libm_diff
 
 
 def test_c3_full_size_properties(pp, capi):
@@ -409,15 +427,28 @@ def test_c3_full_size_equals_oracle(pp, ppo, capi, name):
     fo, bo = ppo.create_gyro_ring_mappings(mo, trig=1)
     fg, bg = capi.create_gyro_ring_mappings(mg)
     wf, wb = capi.DevArray(mg.nverts, np.float64), capi.DevArray(mg.nverts, np.float64)
+    # The libm link of the parity chain, at this size (round 5): a SECOND oracle structure takes the same steps with
+    # trig=0 (glibc sin/cos: the reference's Kokkos::Serial build).  After every step its per-particle elements (by
+    # particle id) and its scatter field are compared with the shared-sincos oracle, which the HIP path equals bit
+    # for bit (the assertions below); at the end positions and phi within 1e-12 relative (north_star's tolerance).
+    pl = ppo.PS.scs(ppo.PARTICLE_XGCM, w["ne"], w["ppe"], C_max=64, sigma=2**31 - 1, V=1024, pad_strat=0,
+                    shuffle_padding=0.1, extra_padding=0.0, particle_elements=w["elem"], particle_info=w["info"])
+    libm_diff = []
     ppo.set_threads(ppo.max_threads())
     try:
         for step in range(3):
             if dim == 3:
                 ppo.toroidal_push(po, mo, s.XGC_H, s.XGC_K, s.XGC_D, 0.5, trig=1)
                 ids_o = ppo.search_mesh(mo, po, looplimit=200)["elem_ids"]
+                ppo.toroidal_push(pl, mo, s.XGC_H, s.XGC_K, s.XGC_D, 0.5, trig=0)
+                ids_l = ppo.search_mesh(mo, pl, looplimit=200)["elem_ids"]
             else:
                 ppo.elliptical_push(po, mo, s.XGC_H, s.XGC_K, s.XGC_D, 0.5, trig=1)
                 _, ids_o, _ = ppo.search_mesh_2d(mo, po, looplimit=200)
+                ppo.elliptical_push(pl, mo, s.XGC_H, s.XGC_K, s.XGC_D, 0.5, trig=0)
+                _, ids_l, _ = ppo.search_mesh_2d(mo, pl, looplimit=200)
+            ppo.update_positions(pl)
+            pl.rebuild(ids_l)
             cap = pg.capacity()
             ids_g = capi.DevArray(cap + cap // 10, np.int32)
             capi.push_search(mg, pg, s.XGC_H, s.XGC_K, s.XGC_D, 0.5, ids_g, seeded=False, looplimit=200)
@@ -432,6 +463,15 @@ def test_c3_full_size_equals_oracle(pp, ppo, capi, name):
                 assert np.array_equal(lo[k], lg[k]), (step, k)
             assert np.array_equal(ppo.gyro_scatter(mo, po, fo), wf.to_host()), step
             assert np.array_equal(ppo.gyro_scatter(mo, po, bo), wb.to_host()), step
+            # libm oracle against the shared-sincos oracle (== the HIP path): same particles in the same elements
+            sl, mkl = pl.slot_info()
+            so_, mko_ = po.slot_info()
+            il, el = common.by_id(pl.member(2)[0, :pl.capacity()], mkl, sl)
+            io_, eo_ = common.by_id(po.member(2)[0, :po.capacity()], mko_, so_)
+            assert np.array_equal(il, io_), step
+            libm_diff.append(int((el != eo_).sum()))
+            if libm_diff[-1] == 0:
+                assert np.array_equal(ppo.gyro_scatter(mo, pl, fo), wf.to_host()), step
     finally:
         ppo.set_threads(1)
     so, mko = po.slot_info()
@@ -441,10 +481,19 @@ def test_c3_full_size_equals_oracle(pp, ppo, capi, name):
     io, eo = common.by_id(ido, mko, so)
     ig, eg = common.by_id(idg, mkg, sg)
     assert np.array_equal(io, ig) and np.array_equal(eo, eg)
+    sl, mkl = pl.slot_info()
+    idl = pl.member(2)[0, :pl.capacity()]
     for m in range(len(ppo.PARTICLE_XGCM)):
         _, a = common.by_id(ido, mko, po.member(m)[:, :capo])
         _, b = common.by_id(idg, mkg, pg.member(m)[:, :capg])
         assert np.array_equal(a, b), m
+        _, c = common.by_id(idl, mkl, pl.member(m)[:, :pl.capacity()])
+        c = c.astype(np.float64)  # (relative to the particle's own scale: the largest component of the member)
+        rel = np.abs(c - b) / np.maximum(np.abs(c).max(axis=0, keepdims=True), 1e-300)
+        assert rel.max() <= 1e-12, (m, rel.max())  # HIP path vs oracle(libm): north_star's 1e-12 relative
+    print("%s: HIP path vs oracle(libm), 10 M particles: particles in another element after steps 1-3: %s"
+          % (name, libm_diff))
+    assert max(libm_diff) == 0, libm_diff
 
 
 @pytest.mark.parametrize("world,per_rank", [(2, 16_000_000), (8, 2_000_000)])
