@@ -343,6 +343,10 @@ class Stepper:
             else:  # the same three calls as one entry point (scatter enqueued before the rebuild's sync)
                 capi.rebuild_scatter(self.ps, self.mesh, self.ids, [self.fwd, self.bkwd],
                                      [self.w_f, self.w_b])
+            # the search's `found` (every search of the reference returns it, the driver asserts it:
+            # test/pseudoXGCm.cpp:153-154): it came to the host with the rebuild's totals -- no wait of its own
+            if not capi.last_search_found(self.ps):
+                raise RuntimeError("search: particles were cut off by the loop limit")
             cap = max(self.ps.capacity(), 1)
             if cap > self.ids.n:  # 10% slack: the capacity wanders by a few chunk widths per rebuild
                 self.ids = capi.DevArray(cap + cap // 10, np.int32)
@@ -369,6 +373,8 @@ class Stepper:
                 if self.world > 1:
                     self._allreduce_fields()
             self.moved += sent
+            if not capi.last_search_found(self.ps):  # (as above: delivered with the migration's rebuild totals)
+                raise RuntimeError("search: particles were cut off by the loop limit")
             cap = max(self.ps.capacity(), 1)
             if cap > self.ids.n:  # 10% slack: the capacity wanders by a few chunk widths per rebuild
                 self.ids = capi.DevArray(cap + cap // 10, np.int32)
@@ -1210,7 +1216,8 @@ def main():
                    "field is a device copy of the first (the two ring maps of one createGyroRingMappings call hold "
                    "the same ids); check_initial_parents %s" % (
                        a.deg, "skipped from step 2 on (--origin-trust)" if w.get("origin_trust") else
-                       "runs every step"),
+                       "runs every step") + "; the search's found flag is read every step (it reaches the host with "
+                   "the rebuild's totals)",
              "c5": "push+search+migrate(all-to-all-v, %s)+rebuild+gyroScatter x2+gyroSync, deg/push=%g" % (
                  getattr(st, "comm_kind", a.comm), a.deg),
              "2dc3": "push+search+rebuild+gyroScatter x2 every step, deg/push=%g" % a.deg}[a.workload]),

@@ -350,6 +350,13 @@ int pp_search_walk_steps(unsigned long long* steps);
 /* counters of the last pp_push_search (one host sync): particles cut off by the loop limit, particles
  * that failed check_initial_parents, trusted particles that finished as unmoved */
 int pp_push_search_counters(int* not_found, int* not_in_elem, int* unmoved_trusted);
+/* The `bool found` of the most recent pp_push_search (the value every search of the reference returns and its
+ * drivers assert, test/pseudoXGCm.cpp:153-154) for callers that passed found = NULL to keep the step free of a
+ * host wait: the full re-layout of pp_ps_rebuild* / the migration that follows the search carries the search's
+ * not-found count to the host WITH ITS OWN TOTALS (the one host wait a rebuild has anyway), and this call returns
+ * it without touching the device.  When the last rebuild of `ps` did not carry it (in-place rebuild, CSR) the
+ * counters are read with one host sync, as pp_push_search_counters does. */
+int pp_ps_last_search_found(const pp_ps* ps, int* found);
 
 /* ------------------------------------------------------------------ scatter / gather */
 /* createGyroRingMappings test/gyroScatter.hpp:101-166 (maps: nverts*gnr*gppr*(dim+1) ints, device).

@@ -89,6 +89,7 @@ SYMBOLS = {
     "pp_ps_iteration": (_I, [_V, _V]),
     "pp_ps_layout_to_host": (_I, [_V, _V, _V, _V, _V, _V, _V]),
     "pp_ps_gids_to_host": (_I, [_V, _V]),
+    "pp_ps_last_search_found": (_I, [_V, c_int_p]),
     "pp_ps_member_to_host": (_I, [_V, _I, _V]),
     "pp_ps_member_from_host": (_I, [_V, _I, _V]),
     "pp_ps_rebuild": (_I, [_V, _V, _I, _V, _V]),
@@ -1173,6 +1174,14 @@ def push_search_counters():
     a, b, c = C.c_int(), C.c_int(), C.c_int()
     check(lib().pp_push_search_counters(C.byref(a), C.byref(b), C.byref(c)))
     return a.value, b.value, c.value
+
+
+def last_search_found(ps):
+    """the `found` of the most recent pp_push_search, delivered with the totals of the structure's last rebuild
+    (no host sync of its own when a full re-layout carried it)"""
+    f = C.c_int()
+    check(lib().pp_ps_last_search_found(ps.p, C.byref(f)))
+    return bool(f.value)
 
 
 def search_walk_steps():

@@ -282,6 +282,9 @@ struct pp_ps {
   void* h_totals = nullptr;
   void* ev_totals = nullptr;
   int totals_stamp = 0;
+  // not_found counter of the most recent pp_push_search as the last full re-layout's totals carried it to the host
+  // (-1: not carried): pp_ps_last_search_found
+  int search_nf = -1;
   ~pp_ps() {
     if (h_totals) (void)hipHostFree(h_totals);
     if (ev_totals) (void)hipEventDestroy((hipEvent_t)ev_totals);
@@ -368,6 +371,7 @@ int ps_materialize(pp_ps* ps);
 int ps_zeros(pp_ps* ps);  // only the pending zeros of pp_ps::zero_pending
 const int* slot_elem(const pp_ps* ps);  // d_slot_elem, filled first when the last re-layout left it out (pp_ps.hip)
 const int* group_chunk(const pp_ps* ps);  // d_group_chunk (SCS, chunk height 64), else nullptr
+const int* search_not_found_dev();  // pp_search.hip: device address of the last pp_push_search's not_found counter
 inline int ps_ready(const pp_ps* ps) {
   return (ps && (ps->zero_pending >= 0 || ps->lazy_rec)) ? ps_materialize(const_cast<pp_ps*>(ps)) : PP_OK;
 }

@@ -386,6 +386,7 @@ __global__ void k_spec_check_csr(Totals* tot, int expected) {
 }
 struct SpecArgs {
   int on, cap_lim, nsl_lim, C_max, keep_if_fits;
+  const int* search_nf = nullptr;  // not_found counter of the last pp_push_search: travels to the host with the totals
 };
 __device__ __forceinline__ void spec_decide(Totals* tot, int cap_lim, int nsl_lim, int C_max, int key_bits,
                                             int keep_if_fits) {
@@ -651,6 +652,7 @@ __global__ void __launch_bounds__(1024)
     // before the next kernel) between this kernel and the tail
     // (host_stamp != 0: the host polls pad_[0] for it instead of waiting for an event behind this kernel -- an
     // event record is a barrier packet, 6 us before the next kernel starts)
+    tot->pad_[1] = sp.search_nf ? *sp.search_nf : -1;  // (pp_ps_last_search_found)
     if (host_out) {
       Totals v = *tot;
       v.pad_[0] = 0;
@@ -2076,6 +2078,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   hipStream_t st = pp::stream();
   const int ne = ps->num_elems;
   PP_REQUIRE(n_new == 0 || new_info != nullptr, "rebuild: new particles need new_info_dev");
+  ps->search_nf = -1;
   // zeros left pending by the previous in-place rebuild; records left by the previous full re-layout.
   // Exception: after the record-fed push only the ORIGIN (member lazy_x) is still in records, and a
   // rebuild that commits the same pair of members never reads it.
@@ -2254,7 +2257,8 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   int rc = enqueue_layout(ps, ps->C_max, ppe, tot, key_base, L, bits_pred,
                           ElemTotalsArgs{totals_in_keys ? 1 : 0, (totals_in_keys && decide_keep) ? 1 : 0, ps->C,
                                          ps->d_element_to_row.as<int>(), ps->d_chunk_width.as<int>(), nullptr},
-                          SpecArgs{spec_ok ? 1 : 0, (int)cap_lim, (int)nsl_lim, ps->C_max, decide_keep ? 1 : 0},
+                          SpecArgs{spec_ok ? 1 : 0, (int)cap_lim, (int)nsl_lim, ps->C_max, decide_keep ? 1 : 0,
+                                   pp::search_not_found_dev()},
                           spec_ok ? &ta_spec : nullptr, /*allow_wide=*/true, no_direct_totals ? nullptr : h_pin, stamp);
   const bool polling = stamp != 0 && L.totals_on_host;
   if (rc) return rc;
@@ -2449,6 +2453,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     PP_HIP_CHECK(hipEventSynchronize(ev_tot));
   }
   Totals h = *h_pin;
+  ps->search_nf = L.totals_on_host ? h.pad_[1] : -1;
   if (h.invalid) {
     ps->swap_stride = swap_stride_before;
     pp::set_error(
@@ -3056,6 +3061,18 @@ int pp_ps_layout_to_host(const pp_ps* ps, int* offsets, int* slice_to_chunk, int
   if (slot_elem && ps->capacity)
     PP_HIP_CHECK(hipMemcpy(slot_elem, pp::slot_elem(ps), (size_t)ps->capacity * sizeof(int),
                            hipMemcpyDeviceToHost));
+  return PP_OK;
+}
+
+int pp_ps_last_search_found(const pp_ps* ps, int* found) {
+  PP_REQUIRE(ps && found, "pp_ps_last_search_found: null argument");
+  if (ps->search_nf >= 0) {
+    *found = ps->search_nf == 0;
+    return PP_OK;
+  }
+  int nf = 0;  // (the rebuild did not carry it: in place, CSR, separate-kernel layout) one host sync
+  if (int rc = pp_push_search_counters(&nf, nullptr, nullptr)) return rc;
+  *found = nf == 0;
   return PP_OK;
 }
 

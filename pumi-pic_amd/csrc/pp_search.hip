@@ -2269,6 +2269,10 @@ int member_ok(const pp_ps* ps, int m, int bytes, int ncomp, const char* what) {
 
 }  // namespace
 
+namespace pp {
+const int* search_not_found_dev() { return g_last_counters ? &g_last_counters->not_found : nullptr; }
+}  // namespace pp
+
 extern "C" {
 
 int pp_search_mesh_2d(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_pid,

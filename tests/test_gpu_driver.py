@@ -204,3 +204,41 @@ def test_cpp_boundary_api(capi, tmp_path):
     assert sum(body.count("1") for _, _, body in rows) == npt
     assert all(int(g) == 3 * int(e) + 5 for e, g, _ in rows)
     assert "Element  3(" not in csr  # element 3 holds no particle: no line (CSR.hpp:249)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("looplimit,deg", [(200, 2.0), (1, 25.0)])
+def test_found_rides_with_the_rebuild_totals(pp, ppo, capi, dim, looplimit, deg):
+    """pp_ps_last_search_found: the `found` of a pp_push_search that was called WITHOUT a found pointer (no host
+    wait in the step) comes to the host with the totals of the rebuild that follows, and equals what the same
+    search returns when it is asked directly -- both when every particle is found and when the loop limit cuts
+    particles off (found == false, the reference then deletes them)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import common
+    s = pp.synth
+    pop = (common.population_2d(s, n_b=16, n_theta=64, num_ptcls=40000, mdl_face=4) if dim == 2 else
+           common.population_3d(s, n_b=8, n_theta=24, n_planes=8, num_ptcls=40000, mdl_face=6))
+    answers = []
+    for direct in (True, False):
+        mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)
+        cap = pg.capacity()
+        ids = capi.DevArray.from_host(np.full(cap + cap // 10, -1, dtype=np.int32))
+        fwd, bkwd = capi.create_gyro_ring_mappings(mg)
+        for step in range(3):  # (the second and third step run the record-fed kernels)
+            f = capi.push_search(mg, pg, s.XGC_H, s.XGC_K, s.XGC_D, deg, ids, seeded=False, looplimit=looplimit,
+                                 want_found=direct)
+            capi.rebuild_scatter(pg, mg, ids, [fwd, bkwd])
+            if not direct:
+                f = capi.last_search_found(pg)
+            answers.append((direct, step, f, pg.nPtcls()))
+            cap = pg.capacity()
+            if cap > ids.n:
+                ids = capi.DevArray.from_host(np.full(cap + cap // 10, -1, dtype=np.int32))
+    a = [x[2:] for x in answers if x[0]]
+    b = [x[2:] for x in answers if not x[0]]
+    assert a == b, answers
+    if looplimit == 1:
+        assert not a[0][0] and a[0][1] < 40000  # particles were cut off and deleted
+    else:
+        assert all(f for f, _ in a)
