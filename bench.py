@@ -699,7 +699,7 @@ def also_driver_pseudoxgcm(pp, capi, a, w_main, st_main):
     drv = os.path.join(ROOT, "pumi-pic_amd", "drivers", "pseudoXGCm")
     if not os.path.exists(drv):
         subprocess.check_call(["make", "-C", os.path.dirname(drv), "-s"])
-    nptcl, iters = a.particles, 20
+    nptcl, iters = a.particles, 100  # (the first iterations grow the library's buffers and the pool: amortised)
     coords, e2v, cls = pp.synth.annulus_tri()
     out = {}
     with tempfile.TemporaryDirectory() as tmp:

@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpumipic_hip.so")
+# (PUMIPIC_HIP_LIB: another build of the same library, e.g. the laboratory build `make -C csrc lab`)
+LIB_PATH = os.environ.get("PUMIPIC_HIP_LIB") or os.path.join(_HERE, "libpumipic_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 c_int_p = C.POINTER(C.c_int)

@@ -11,6 +11,18 @@
 #include <vector>
 #include "../../include/pumipic_hip.h"
 
+// Laboratory switches.  The A/B knobs the kernels were tuned with are gone from the library: the variants that lost
+// are deleted (profiles/r0x_rejected_* keep their patches and numbers).  What is left under this macro forces a
+// FALLBACK path that is still live code -- the checked rebuild a structure takes when a buffer must grow, the
+// atomic scatter of a ring map without a transpose, the unpacked Moeller-Trumbore walk of a mesh whose records
+// cannot be packed -- so that tests can drive it at scale.  It reads the environment only in a build with
+// -DPP_LAB (make lab); the shipped library compiles every one of them to a constant.
+#ifdef PP_LAB
+#define PP_LAB_ENV(name) getenv(name)
+#else
+#define PP_LAB_ENV(name) ((const char*)nullptr)
+#endif
+
 namespace pp {
 
 void set_error(const std::string& msg);
@@ -94,7 +106,7 @@ struct DevBuf {
   // not all start at the same position of the HBM channel interleave.
   hipError_t reserve(size_t n, size_t skew = 0) {
     if (n <= bytes) return hipSuccess;
-    static const bool dbg = getenv("PP_ALLOC_DEBUG") != nullptr;  // (tools/r04_coldsteps.py: who re-allocates when)
+    static const bool dbg = PP_LAB_ENV("PP_ALLOC_DEBUG") != nullptr;  // (tools/r04_coldsteps.py: who re-allocates when)
     if (dbg) fprintf(stderr, "pp alloc: %zu -> %zu bytes\n", bytes, n + n / 8 + 256);
     release();
     size_t want = n + n / 8 + 256;

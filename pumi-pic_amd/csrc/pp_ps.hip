@@ -21,6 +21,9 @@
 #include "pp_internal.hpp"
 #include "pp_ps_sort.hpp"   // Totals, the layout sort, scans
 #include "pp_ps_build.hpp"  // host-side construction (HostLayout, member allocation, uploads)
+#include "pp_ps_move.hpp"        // the two passes that move every member of every particle (+ new particles)
+#include "pp_ps_inplace.hpp"     // kernels of the in-place rebuild (the reference's reshuffle)
+#include "pp_ps_distribute.hpp"  // redistribute_particles, getPIDs kernels
 
 namespace {
 
@@ -802,343 +805,6 @@ __global__ void k_init_slots_tiled(const int* __restrict__ ntiles_dev, int C, in
   }
 }
 
-struct MoveArgs {
-  int nmembers;
-  const void* src[8];
-  void* dst[8];
-  int bytes[8];
-  int ncomp[8];
-  long long src_stride, dst_stride;
-  // fused updatePtclPositions (test/pseudoXGCm.cpp:102-114): member commit_x takes the values of
-  // member commit_xt, member commit_xt is written as zeros.  -1 = plain copy.
-  int commit_x, commit_xt;
-};
-__device__ __forceinline__ void copy_members(const MoveArgs& a, long long from, long long to) {
-  for (int m = 0; m < a.nmembers; ++m) {
-    const int nc = a.ncomp[m];
-    if (a.bytes[m] == 8) {
-      const unsigned long long* s =
-          (const unsigned long long*)(m == a.commit_x ? a.src[a.commit_xt] : a.src[m]);
-      unsigned long long* d = (unsigned long long*)a.dst[m];
-      if (m == a.commit_xt)
-        for (int c = 0; c < nc; ++c) d[c * a.dst_stride + to] = 0ull;
-      else
-        for (int c = 0; c < nc; ++c) d[c * a.dst_stride + to] = s[c * a.src_stride + from];
-    } else if (a.bytes[m] == 4) {
-      const unsigned* s = (const unsigned*)a.src[m];
-      unsigned* d = (unsigned*)a.dst[m];
-      for (int c = 0; c < nc; ++c) d[c * a.dst_stride + to] = s[c * a.src_stride + from];
-    } else if (a.bytes[m] == 2) {
-      const unsigned short* s = (const unsigned short*)a.src[m];
-      unsigned short* d = (unsigned short*)a.dst[m];
-      for (int c = 0; c < nc; ++c) d[c * a.dst_stride + to] = s[c * a.src_stride + from];
-    } else {
-      const unsigned char* s = (const unsigned char*)a.src[m];
-      unsigned char* d = (unsigned char*)a.dst[m];
-      for (int c = 0; c < nc; ++c) d[c * a.dst_stride + to] = s[c * a.src_stride + from];
-    }
-  }
-}
-// new particles (set_new_particle + CopyViewsToViews, SCS_rebuild.h:277-289)
-__global__ void k_add_scs(int n_new, const int* __restrict__ new_elems,
-                          const int* __restrict__ e2r_new, int C_new, int* __restrict__ row_cursor,
-                          const int* __restrict__ rank_new, const int* __restrict__ elem_slot0,
-                          unsigned char* __restrict__ new_mask, MoveArgs a,
-                          const int* __restrict__ go) {
-  if (!*go) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_new) return;
-  const int e = new_elems[i];
-  // rank_new: slot from the rank the counting pass returned; else the row cursor (direct move)
-  const int idx = rank_new ? elem_slot0[e] + rank_new[i] * C_new : atomicAdd(&row_cursor[e2r_new[e]], C_new);
-  new_mask[idx] = 1;
-  copy_members(a, i, idx);
-}
-// new particles of a rebuild whose second pass is deferred (pseudoXGCm particle type, committed layout of
-// k_move_pack: words 0-5 member commit_x, 13 / 14 / 15 the three 4-byte members from the back)
-__global__ void k_add_rec(int n_new, const int* __restrict__ new_elems, const int* __restrict__ rank_new,
-                          const int* __restrict__ elem_slot0, int C_new, const unsigned long long* __restrict__ x,
-                          const unsigned* __restrict__ m2, const unsigned* __restrict__ m3,
-                          const unsigned* __restrict__ m4, uint4* __restrict__ aos, const int* __restrict__ go) {
-  if (!*go) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_new) return;
-  // (elem_slot0 / C_new: first slot of the row and the slot distance of consecutive ranks -- or, with row-major
-  // records, the row's first record and 1)
-  const long long idx = elem_slot0[new_elems[i]] + (long long)rank_new[i] * C_new;
-  const unsigned long long x0 = x[i], x1 = x[(size_t)n_new + i], x2 = x[2 * (size_t)n_new + i];
-  uint4* r = aos + idx * 4;
-  r[0] = make_uint4((unsigned)x0, (unsigned)(x0 >> 32), (unsigned)x1, (unsigned)(x1 >> 32));
-  r[1] = make_uint4((unsigned)x2, (unsigned)(x2 >> 32), 0u, 0u);
-  r[2] = make_uint4(0u, 0u, 0u, 0u);
-  r[3] = make_uint4(0u, m4[i], m3[i], m2[i]);
-}
-// Row-tiled move (SCS): thread = (old tile, row).  Stayers of the thread reserve their slots in the
-// new row with ONE atomic (n_stay * C) and are written in a second sweep; movers take slots one
-// by one.  Reads are coalesced 64-slot runs; every member of a particle moves in this one pass.
-__global__ void k_move_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
-                             const int* __restrict__ tiles, const int* __restrict__ chunk_start,
-                             const int* __restrict__ chunk_width, const int* __restrict__ r2e,
-                             const unsigned char* __restrict__ mask,
-                             const int* __restrict__ new_element, const int* __restrict__ e2r_new,
-                             int C_new, int* __restrict__ row_cursor,
-                             unsigned char* __restrict__ new_mask, MoveArgs a,
-                             const int* __restrict__ go) {
-  if (!*go) return;
-  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int tile = (int)(g / C), r = (int)(g - (long long)tile * C);
-  if (tile >= *ntiles_dev) return;
-  const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
-  const int start = chunk_start[c] + r, pend = min(p0 + TP, chunk_width[c]);
-  const int e = r2e[c * C + r];
-  unsigned stay = 0;  // TP <= 32
-  for (int p = p0; p < pend; ++p) {
-    const int pid = start + p * C;
-    if (!mask[pid]) continue;
-    const int ne_ = new_element[pid];
-    if (ne_ == -1) continue;
-    if (ne_ == e) {
-      stay |= 1u << (p - p0);
-    } else {
-      const int idx = atomicAdd(&row_cursor[e2r_new[ne_]], C_new);
-      copy_members(a, pid, idx);
-    }
-  }
-  if (stay) {
-    int idx = atomicAdd(&row_cursor[e2r_new[e]], __popc(stay) * C_new);
-    for (int p = p0; p < pend; ++p)
-      if (stay & (1u << (p - p0))) {
-        copy_members(a, start + p * C, idx);
-        idx += C_new;
-      }
-  }
-}
-// ---- AoS-staged move (SCS).  The row order of a Sell-C-sigma structure is a function of the
-// per-element counts, so after a rebuild adjacent old rows land in unrelated new rows: writing
-// the members straight into the new SoA scatters 4/8-byte stores over as many cache lines
-// (measured 1.6 ms for 10 M particles, ~8x write amplification).  Instead
-//   pass 1  reads the old SoA coalesced, packs each particle into ONE 16-byte-aligned record and
-//           writes it to aos[new_slot] (whole 32/64-B sectors per particle);
-//   pass 2  walks the NEW layout, reads aos[slot] contiguously and writes the new SoA coalesced.
-// Word table: record word w of slot pid lives at src[w] + pid*sscale[w] (sscale < 0: constant 0,
-// used for the fused updatePtclPositions), and goes to dst[w] + slot*dscale[w].
-// Entry table: 8-byte components are moved with 64-bit accesses (record words 2i, 2i+1 counted
-// from the front), 4-byte components with 32-bit accesses (record words counted from the back,
-// so that every register index is static); destinations that receive 0 (x_tgt of the fused
-// updatePtclPositions) are never staged, pass 2 writes them as plain coalesced zero stores.
-constexpr int kMax8 = 30, kMax4 = 16;
-struct WordTable {
-  int n8, n4, nz8, nz4;
-  const char* src8[kMax8];
-  char* dst8[kMax8];
-  const char* src4[kMax4];
-  char* dst4[kMax4];
-  char* z8[8];
-  char* z4[8];
-};
-// pass 1b: one thread per old slot packs its record; the wave transposes through LDS so that
-// NQ adjacent lanes store one whole record (full 64-B sectors leave the CU already merged:
-// 0.21 vs 0.27 ms per 10 M random records, tools/ub_scatter.hip)
-// SCS passes `rs` (rank -> slot translation: slot = start of the new row + rank*C); CSR passes the
-// slot directly.
-struct RankToSlot {
-  const int* new_element;  // element of every source particle
-  const int* elem_slot0;   // first slot of the element's new row (SCS) / new offsets (CSR)
-  int step;                // slot distance between consecutive ranks: C (SCS) / 1 (CSR)
-};
-template <int NQ>
-__global__ void k_move_pack(int capacity, const int* __restrict__ new_idx, RankToSlot rs,
-                            uint4* __restrict__ aos, WordTable t, const int* __restrict__ go) {
-  if (go && !*go) return;
-  __shared__ uint4 st[4][64][NQ + 1];
-  __shared__ int sd[4][64];
-  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int rk = (pid < capacity) ? new_idx[pid] : -1;
-  int idx = -1;
-  if (rk >= 0) {
-    // the member loads below depend only on rk >= 0: they are in flight while the two dependent
-    // loads of the slot translation return
-    idx = rs.elem_slot0[rs.new_element[pid]] + rk * rs.step;
-    unsigned v[NQ * 4];
-#pragma unroll
-    for (int i = 0; i < NQ * 4; ++i) v[i] = 0u;
-#pragma unroll
-    for (int i = 0; i < NQ * 2; ++i)
-      if (i < t.n8) {
-        const unsigned long long d =
-            __builtin_nontemporal_load((const unsigned long long*)(t.src8[i] + (long long)pid * 8));
-        v[2 * i] = (unsigned)d;
-        v[2 * i + 1] = (unsigned)(d >> 32);
-      }
-#pragma unroll
-    for (int j = 0; j < (NQ * 4 < kMax4 ? NQ * 4 : kMax4); ++j)
-      if (j < t.n4)
-        v[NQ * 4 - 1 - j] = __builtin_nontemporal_load((const unsigned*)(t.src4[j] + (long long)pid * 4));
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) st[w][l][q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-  }
-  sd[w][l] = idx;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int j = 0; j < NQ; ++j) {
-    const int item = j * 64 + l, rec = item / NQ, part = item % NQ;
-    const int d = sd[w][rec];
-    if (d >= 0) {  // non-temporal: the record is read once, by pass 2 (c3 -1.4 %, 160-B particles -4 %)
-      typedef unsigned v4u __attribute__((ext_vector_type(4)));
-      const uint4 x = st[w][rec][part];
-      v4u y;
-      y.x = x.x;
-      y.y = x.y;
-      y.z = x.z;
-      y.w = x.w;
-      __builtin_nontemporal_store(y, (v4u*)(aos + (long long)d * NQ + part));
-    }
-  }
-}
-// The same pass for records that stay the particle data (pp_ps::rec_rm): destination = first RECORD of the new
-// row + rank, i.e. the particles of a row are consecutive records.  A block holds 4 columns x 64 rows; the
-// stayers of a row in those columns carry consecutive ranks (k_count_tiled hands a run its ranks in column
-// order), so the transpose goes through LDS at BLOCK level and the block's records leave row by row: up to
-// 256 contiguous bytes per row instead of four 64-byte stores 4 KB apart (c3: 294 -> 224 us for the pass).
-template <int NQ>
-__global__ void k_move_pack_rm(int capacity, const int* __restrict__ new_idx, RankToSlot rs,
-                               uint4* __restrict__ aos, WordTable t, const int* __restrict__ go, int wide,
-                               pp::HotRow hot = pp::HotRow{}, unsigned hot_blocks = 0u) {
-  if (go && !*go) return;
-  __shared__ uint4 st[256][NQ + 1];
-  __shared__ int sd[256];
-  // which old slot: 4 columns x 64 rows of the block's 256 consecutive slots, or (wide: chunk height 64) 8 columns x
-  // 32 rows -- block pairs share 8 columns, so a row's run is up to 8 records = 512 contiguous bytes
-  const int tid = threadIdx.x;
-  int pid, li;  // li = LDS index: records of one row adjacent
-  const unsigned bid = blockIdx.x - hot_blocks;  // (of the main blocks)
-  if (blockIdx.x < hot_blocks) {
-    // (pp_ps::hot; `capacity` ends the main blocks' slots where these columns begin) 256 columns of the over-full
-    // row: one run of up to 16 KB.  The first blocks of the grid, as in the histogram.
-    const int p = hot.c1p + (int)blockIdx.x * 256 + tid;
-    pid = p < hot.w ? hot.start + p * 64 + hot.row : 0x7fffffff;
-    li = tid;
-    capacity = 0x7fffffff;
-  } else if (wide) {  // wide = log2(columns per block), chunk height 64: 2^wide columns x (256 >> wide) rows
-    const int nrow = 256 >> wide, col = tid / nrow, row = tid - col * nrow;
-    const int sub = bid & ((64 / nrow) - 1);  // which group of rows of the column block
-    pid = (bid / (64 / nrow)) * (64 << wide) + col * 64 + sub * nrow + row;
-    li = (row << wide) + col;
-  } else {
-    pid = bid * 256 + tid;
-    li = (tid & 63) * 4 + (tid >> 6);
-  }
-  const int rk = (pid < capacity) ? new_idx[pid] : -1;
-  int idx = -1;
-  if (rk >= 0) {
-    idx = rs.elem_slot0[rs.new_element[pid]] + rk * rs.step;
-    unsigned v[NQ * 4];
-#pragma unroll
-    for (int i = 0; i < NQ * 4; ++i) v[i] = 0u;
-#pragma unroll
-    for (int i = 0; i < NQ * 2; ++i)
-      if (i < t.n8) {
-        const unsigned long long d =
-            __builtin_nontemporal_load((const unsigned long long*)(t.src8[i] + (long long)pid * 8));
-        v[2 * i] = (unsigned)d;
-        v[2 * i + 1] = (unsigned)(d >> 32);
-      }
-#pragma unroll
-    for (int j = 0; j < (NQ * 4 < kMax4 ? NQ * 4 : kMax4); ++j)
-      if (j < t.n4)
-        v[NQ * 4 - 1 - j] = __builtin_nontemporal_load((const unsigned*)(t.src4[j] + (long long)pid * 4));
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) st[li][q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-  }
-  sd[li] = idx;
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < NQ; ++j) {
-    const int item = j * 256 + tid, rec = item / NQ, part = item % NQ;  // the records of one row are adjacent items
-    const int d = sd[rec];
-    if (d >= 0) {
-      typedef unsigned v4u __attribute__((ext_vector_type(4)));
-      const uint4 x = st[rec][part];
-      v4u y;
-      y.x = x.x;
-      y.y = x.y;
-      y.z = x.z;
-      y.w = x.w;
-      __builtin_nontemporal_store(y, (v4u*)(aos + (long long)d * NQ + part));
-    }
-  }
-}
-template <int NQ>
-__global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
-                              const int* __restrict__ tiles, const int* __restrict__ chunk_start,
-                              const int* __restrict__ chunk_width,
-                              const unsigned char* __restrict__ new_mask,
-                              const uint4* __restrict__ aos, WordTable t, const int* __restrict__ go,
-                              int rec_rm = 0) {
-  if (!*go) return;
-  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int tile = (int)(g / C), r = (int)(g - (long long)tile * C);
-  if (tile >= *ntiles_dev) return;
-  const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
-  const int start = chunk_start[c] + r, pend = min(p0 + TP, chunk_width[c]);
-  const long long rbase = pp_rec_row0(chunk_start[c], c, r, chunk_width[c], C);  // row-major records (pp_ps::rec_rm)
-  for (int p = p0; p < pend; ++p) {
-    const int slot = start + p * C;
-    if (!new_mask[slot]) continue;
-    const uint4* sp = aos + (rec_rm ? rbase + p : (long long)slot) * NQ;
-    unsigned w[NQ * 4];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      // plain loads: the lanes of a wave read 64-B-strided records, every line serves several
-      // instructions; a non-temporal hint throws that reuse away (c3 +5 %, 160-B particles +20 %)
-      const uint4 v = sp[q];
-      w[4 * q] = v.x;
-      w[4 * q + 1] = v.y;
-      w[4 * q + 2] = v.z;
-      w[4 * q + 3] = v.w;
-    }
-#pragma unroll
-    for (int i = 0; i < NQ * 2; ++i)
-      if (i < t.n8)
-        __builtin_nontemporal_store(((unsigned long long)w[2 * i + 1] << 32) | w[2 * i],
-                                    (unsigned long long*)(t.dst8[i] + (long long)slot * 8));
-#pragma unroll
-    for (int j = 0; j < (NQ * 4 < kMax4 ? NQ * 4 : kMax4); ++j)
-      if (j < t.n4) __builtin_nontemporal_store(w[NQ * 4 - 1 - j], (unsigned*)(t.dst4[j] + (long long)slot * 4));
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (i < t.nz8) __builtin_nontemporal_store(0ull, (unsigned long long*)(t.z8[i] + (long long)slot * 8));
-      if (i < t.nz4) __builtin_nontemporal_store(0u, (unsigned*)(t.z4[i] + (long long)slot * 4));
-    }
-  }
-}
-// CSR staged move (same two passes as SCS): slot assignment by the element cursor, pack through
-// the LDS transpose into 64-B-multiple records, then a flat pass that writes the new SoA coalesced
-template <int NQ>
-__global__ void k_unpack_flat(int n, const uint4* __restrict__ aos, WordTable t,
-                              const int* __restrict__ go) {
-  if (!*go) return;
-  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= n) return;
-  const uint4* sp = aos + (long long)slot * NQ;
-  unsigned w[NQ * 4];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const uint4 v = sp[q];
-    w[4 * q] = v.x;
-    w[4 * q + 1] = v.y;
-    w[4 * q + 2] = v.z;
-    w[4 * q + 3] = v.w;
-  }
-#pragma unroll
-  for (int i = 0; i < NQ * 2; ++i)
-    if (i < t.n8) *(uint2*)(t.dst8[i] + (long long)slot * 8) = make_uint2(w[2 * i], w[2 * i + 1]);
-#pragma unroll
-  for (int j = 0; j < (NQ * 4 < kMax4 ? NQ * 4 : kMax4); ++j)
-    if (j < t.n4) *(unsigned*)(t.dst4[j] + (long long)slot * 4) = w[NQ * 4 - 1 - j];
-}
 // CSR counting sort (CSR_rebuild.hpp:62-108)
 __global__ void k_move_csr(int nold, const int* __restrict__ new_element, int* __restrict__ cursor,
                            MoveArgs a, const int* __restrict__ go) {
@@ -1239,409 +905,6 @@ __global__ void k_csr_slots(int ne, const int* __restrict__ offsets, int capacit
   }
 }
 
-// redistribute_particles (particle_structs/test/Distribute.h:28-89) with uniform re-draws: every live
-// particle moves with probability percentMoved to a uniformly drawn element.  The reference draws
-// from a Kokkos XorShift64 pool (not reproducible run to run); here the two draws of a slot are a
-// splitmix64 hash of (seed, slot), so the CPU oracle produces the same ids.
-__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
-  z += 0x9e3779b97f4a7c15ull;
-  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-  return z ^ (z >> 31);
-}
-// The re-draw by distribution strategy (distribute_particles' device forms, Distribute.cpp:76-253): 1 uniform,
-// 2 gaussian(ne/2, ne/8) truncated and clamped, 3 uniform -> exponential conversion (its two logarithms per
-// element come from host-made tables), 4 GITRm approximation.  Extra draws are g_j = splitmix64(h1 + j); the
-// normal variate is the Irwin-Hall sum of twelve 32-bit uniforms (exact in double: host and device agree).
-__device__ __forceinline__ int draw_element(int strat, int ne, unsigned long long h1, const int* __restrict__ exp_start,
-                                            const int* __restrict__ exp_end) {
-  if (strat == 2) {
-    double S = 0;
-    for (int j = 0; j < 12; ++j) S += (double)(splitmix64(h1 + (unsigned long long)j) >> 32);
-    const double z = S * (1.0 / 4294967296.0) - 6.0;
-    const double v = ne / 2.0 + (ne / 8.0) * z;
-    int elem = (int)v;
-    if (elem < 0) elem = 0;
-    if (elem >= ne) elem = ne - 1;
-    return elem;
-  }
-  if (strat == 3) {
-    const int uni = (int)(h1 % (unsigned long long)ne);
-    if (uni == ne - 1) return 0;
-    const int start = exp_start[uni];
-    const long long length = (long long)exp_end[uni] - start;
-    int inside = 0;
-    if (length > 1) inside = (int)(splitmix64(h1 + 1ull) % (unsigned long long)length);
-    long long e = (long long)start + inside;
-    if (e >= ne) e = (long long)(splitmix64(h1 + 2ull) % (unsigned long long)ne);
-    return (int)e;
-  }
-  if (strat == 4) {
-    const int cutoff = 2 * ne / 5;
-    const double u = (double)(splitmix64(h1 + 1ull) >> 11) * (1.0 / 9007199254740992.0);
-    const unsigned long long g = splitmix64(h1 + 2ull);
-    if (u < 0.85 && cutoff > 0) return (int)(g % (unsigned long long)cutoff);
-    return cutoff + (int)(g % (unsigned long long)(ne - cutoff));
-  }
-  return (int)(h1 % (unsigned long long)ne);
-}
-__global__ void k_redistribute(int capacity, const unsigned char* __restrict__ mask,
-                               const int* __restrict__ slot_elem, int ne, double percent_moved,
-                               unsigned long long seed, int* __restrict__ new_elems, int strat,
-                               const int* __restrict__ exp_start, const int* __restrict__ exp_end) {
-  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pid >= capacity) return;
-  const int e = slot_elem[pid];
-  if (e < 0 || !mask[pid]) {
-    new_elems[pid] = -1;
-    return;
-  }
-  const unsigned long long h0 = splitmix64(seed ^ (2ull * (unsigned long long)pid));
-  const double prob = (double)(h0 >> 11) * (1.0 / 9007199254740992.0);
-  if (prob <= percent_moved) {
-    const unsigned long long h1 = splitmix64(seed ^ (2ull * (unsigned long long)pid + 1ull));
-    new_elems[pid] = draw_element(strat, ne, h1, exp_start, exp_end);
-  } else {
-    new_elems[pid] = e;
-  }
-}
-__global__ void k_pid_count(int capacity, const unsigned char* __restrict__ mask,
-                            const int* __restrict__ slot_elem, int* __restrict__ ppe) {
-  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pid < capacity && mask[pid]) atomicAdd(&ppe[slot_elem[pid]], 1);
-}
-__global__ void k_pid_set(int capacity, const unsigned char* __restrict__ mask,
-                          const int* __restrict__ slot_elem, const int* __restrict__ offsets,
-                          int* __restrict__ cur, int* __restrict__ pids) {
-  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pid < capacity && mask[pid]) {
-    const int e = slot_elem[pid];
-    pids[offsets[e] + atomicAdd(&cur[e], 1)] = pid;
-  }
-}
-
-
-// ------------------------------------------------------------------ in-place rebuild ("reshuffle")
-// The reference first tries to keep the layout (SCS_rebuild.h:4-119, decision :160-189): when every
-// row's arrivals fit into its holes -- new count <= chunk width -- offsets / slice_to_chunk /
-// row_to_element / element_to_row stay as they are and only the particles that change element move.
-// Same decision here; the data movement is this library's own.  Rows stay prefix-compact (the hot
-// kernels rely on it: a row's live slots are its first `count` columns), so a row that shrinks
-// back-fills the holes below its new count from its own tail:
-//   k_rs_count  thread = (run of <= 32 columns, row): arrivals per element (atomics that RETURN the
-//               arrival's rank), leavers per element, the movers' records packed to aos[slot]
-//   k_rs_fit    per element: new count = old - leavers + arrivals <= chunk width ?  totals, go flag
-//   k_rs_plan   per run: holes (columns below the new count that are empty or being left) are
-//               enumerated into the row's hole list, tail stayers (columns at or above the new count)
-//               get claim numbers behind the arrivals; new mask
-//   k_rs_move   claimant k of a row takes the row's k-th hole: movers from their staged record, tail
-//               stayers slot to slot (their source slots are nobody's target)
-// About 16 % of the particles move (8 % change element per pseudoXGCm step, as many again back-fill)
-// instead of every particle twice.
-struct RsCounters {  // one int array each, num_elems long, zeroed per rebuild (n_new lives in s_ppe)
-  int *arrive, *leave, *hole_cur, *tail_cur, *removed;
-};
-template <int NQ>
-__global__ void k_rs_count(const int* __restrict__ ntiles_dev, int C, int TP, int G,
-                           const int* __restrict__ tiles, const int* __restrict__ chunk_start,
-                           const int* __restrict__ chunk_width, const int* __restrict__ r2e,
-                           const int* __restrict__ n_old, const int* __restrict__ new_element, int ne,
-                           RsCounters cn, Totals* tot, int* __restrict__ rank, uint4* __restrict__ aos,
-                           WordTable t) {
-  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int grp = (int)(g / C), r = (int)(g - (long long)grp * C);
-  const int ntiles = *ntiles_dev;
-  int cur = -1, e = -1, start = 0, run_p0 = 0, nold = 0, nl = 0, nd = 0;
-  // movers of the run that share one of the first three destinations met leave as ONE atomic each
-  // (a row's particles cross into the few neighbours of its element, see k_count_tiled)
-  int key1 = -1, key2 = -1, key3 = -1;
-  unsigned m1 = 0, m2 = 0, m3 = 0;
-  auto flush_one = [&](int key, unsigned m) {
-    if (!m) return;
-    int idx = atomicAdd(&cn.arrive[key], __popc(m));
-    while (m) {
-      const int b = __ffs(m) - 1;
-      m &= m - 1;
-      rank[start + (run_p0 + b) * C] = idx++;
-    }
-  };
-  auto flush = [&]() {
-    flush_one(key1, m1);
-    flush_one(key2, m2);
-    flush_one(key3, m3);
-    if (nl) atomicAdd(&cn.leave[e], nl);
-    if (nd) atomicAdd(&cn.removed[e], nd);
-    m1 = m2 = m3 = 0;
-    key1 = key2 = key3 = -1;
-    nl = nd = 0;
-  };
-  for (int k = 0; k < G; ++k) {
-    const int tile = grp * G + k;
-    if (tile >= ntiles) break;
-    const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
-    if (c != cur) {
-      flush();
-      cur = c;
-      start = chunk_start[c] + r;
-      e = r2e[c * C + r];
-      nold = e < ne ? n_old[e] : 0;
-      run_p0 = p0;
-    }
-    const int pend = min(min(p0 + TP, chunk_width[c]), nold);  // live columns only
-    for (int pb = p0; pb < pend; pb += 8) {
-      int nel[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) nel[j] = (pb + j < pend) ? new_element[start + (pb + j) * C] : e;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int ne_ = nel[j];
-        if (ne_ == e) continue;  // stays (or column past the live range)
-        ++nl;
-        if (ne_ == -1) {  // removed
-          ++nd;
-          continue;
-        }
-        if (ne_ < 0 || ne_ >= ne) {
-          tot->invalid = 1;
-          continue;
-        }
-        const int pid = start + (pb + j) * C;
-        {  // stage the mover: its slot may be another particle's target
-          unsigned v[NQ * 4];
-#pragma unroll
-          for (int i = 0; i < NQ * 4; ++i) v[i] = 0u;
-#pragma unroll
-          for (int i = 0; i < NQ * 2; ++i)
-            if (i < t.n8) {
-              const unsigned long long d = *(const unsigned long long*)(t.src8[i] + (long long)pid * 8);
-              v[2 * i] = (unsigned)d;
-              v[2 * i + 1] = (unsigned)(d >> 32);
-            }
-#pragma unroll
-          for (int i = 0; i < (NQ * 4 < kMax4 ? NQ * 4 : kMax4); ++i)
-            if (i < t.n4) v[NQ * 4 - 1 - i] = *(const unsigned*)(t.src4[i] + (long long)pid * 4);
-#pragma unroll
-          for (int q = 0; q < NQ; ++q)
-            aos[(long long)pid * NQ + q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-        }
-        const unsigned bit = 1u << (pb + j - run_p0);
-        if (ne_ == key1) {
-          m1 |= bit;
-        } else if (ne_ == key2) {
-          m2 |= bit;
-        } else if (ne_ == key3) {
-          m3 |= bit;
-        } else if (key1 < 0) {
-          key1 = ne_;
-          m1 = bit;
-        } else if (key2 < 0) {
-          key2 = ne_;
-          m2 = bit;
-        } else if (key3 < 0) {
-          key3 = ne_;
-          m3 = bit;
-        } else {
-          rank[pid] = atomicAdd(&cn.arrive[ne_], 1);
-        }
-      }
-    }
-  }
-  flush();
-}
-__global__ void k_rs_count_added(int n_new, const int* __restrict__ new_elems, int ne, int* __restrict__ arrive,
-                                 Totals* tot, int* __restrict__ rank_new) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_new) return;
-  const int e = new_elems[i];
-  if (e < 0 || e >= ne) {
-    tot->invalid = 1;
-    rank_new[i] = -1;
-    return;
-  }
-  rank_new[i] = atomicAdd(&arrive[e], 1);
-}
-// per element: the new count and whether it fits the row (SCS_rebuild.h:33-42: new particles of a row
-// against its holes, i.e. new count <= chunk width); totals by one atomic pair per block
-__global__ void k_rs_fit(int ne, int C, const int* __restrict__ n_old, RsCounters cn,
-                         const int* __restrict__ e2r, const int* __restrict__ chunk_width,
-                         int* __restrict__ n_new, Totals* tot) {
-  __shared__ int s_sum[4], s_nz[4];
-  int sum = 0, nz = 0;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
-    const int n = n_old[e] - cn.leave[e] + cn.arrive[e];
-    n_new[e] = n;
-    sum += n;
-    nz += n > 0;
-    // The reference counts a row's holes BEFORE its movers leave (SCS_rebuild.h:13-25: a slot is a hole
-    // when it is empty or its particle is removed; a particle that moves to another row still
-    // occupies its slot), so its test is  arrivals <= width - (old count - removed).
-    const int occupied = n_old[e] - cn.removed[e] + cn.arrive[e];
-    if (occupied > chunk_width[e2r[e] / C]) atomicAdd(&tot->n_over, 1);  // the row overflows: no in-place rebuild
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    sum += __shfl_down(sum, o);
-    nz += __shfl_down(nz, o);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    s_sum[threadIdx.x >> 6] = sum;
-    s_nz[threadIdx.x >> 6] = nz;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    sum = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
-    nz = s_nz[0] + s_nz[1] + s_nz[2] + s_nz[3];
-    if (sum) atomicAdd(&tot->active, sum);
-    if (nz) atomicAdd(&tot->nonempty, nz);
-  }
-}
-__global__ void k_rs_go(Totals* tot) {
-  tot->go = (!tot->invalid && tot->active > 0 && tot->n_over == 0) ? 1 : 0;
-}
-__global__ void k_rs_plan(const int* __restrict__ ntiles_dev, int C, int TP, int G,
-                          const int* __restrict__ tiles, const int* __restrict__ chunk_start,
-                          const int* __restrict__ chunk_width, const int* __restrict__ r2e,
-                          const int* __restrict__ n_old, const int* __restrict__ n_new,
-                          const int* __restrict__ new_element, int ne, RsCounters cn,
-                          int* __restrict__ hole_tab, int* __restrict__ rank,
-                          unsigned char* __restrict__ mask, const int* __restrict__ go) {
-  if (!*go) return;
-  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int grp = (int)(g / C), r = (int)(g - (long long)grp * C);
-  const int ntiles = *ntiles_dev;
-  int cur = -1, e = -1, start = 0, run_p0 = 0, nold = 0, nnew = 0, arr = 0;
-  unsigned hb = 0, tb = 0;  // holes / tail stayers of the run, bit = column - run_p0
-  auto flush = [&]() {
-    if (hb) {
-      int h = atomicAdd(&cn.hole_cur[e], __popc(hb));
-      while (hb) {
-        const int b = __ffs(hb) - 1;
-        hb &= hb - 1;
-        hole_tab[start + h * C] = start + (run_p0 + b) * C;
-        ++h;
-      }
-    }
-    if (tb) {
-      int tk = arr + atomicAdd(&cn.tail_cur[e], __popc(tb));  // claims of the arrivals come first
-      while (tb) {
-        const int b = __ffs(tb) - 1;
-        tb &= tb - 1;
-        rank[start + (run_p0 + b) * C] = tk++;
-      }
-    }
-  };
-  for (int k = 0; k < G; ++k) {
-    const int tile = grp * G + k;
-    if (tile >= ntiles) break;
-    const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
-    if (c != cur) {
-      flush();
-      cur = c;
-      start = chunk_start[c] + r;
-      e = r2e[c * C + r];
-      nold = nnew = arr = 0;
-      if (e < ne) {
-        nold = n_old[e];
-        nnew = n_new[e];
-        arr = cn.arrive[e];
-      }
-      run_p0 = p0;
-    }
-    const int pend = min(min(p0 + TP, chunk_width[c]), max(nold, nnew));
-    for (int p = p0; p < pend; ++p) {
-      const int pid = start + p * C;
-      const bool live = p < nold;
-      const bool stays = live && new_element[pid] == e;
-      const unsigned bit = 1u << (p - run_p0);
-      if (p < nnew) {
-        if (!stays) hb |= bit;
-      } else if (stays) {
-        tb |= bit;
-      }
-      if ((p < nnew) != live) mask[pid] = p < nnew ? 1 : 0;
-    }
-  }
-  flush();
-}
-template <int NQ>
-__global__ void k_rs_move(const int* __restrict__ ntiles_dev, int C, int TP, int G,
-                          const int* __restrict__ tiles, const int* __restrict__ chunk_start,
-                          const int* __restrict__ chunk_width, const int* __restrict__ r2e,
-                          const int* __restrict__ n_old, const int* __restrict__ n_new,
-                          const int* __restrict__ new_element, int ne, const int* __restrict__ eslot0,
-                          const int* __restrict__ hole_tab, const int* __restrict__ rank,
-                          const uint4* __restrict__ aos, WordTable t, const int* __restrict__ go) {
-  if (!*go) return;
-  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int grp = (int)(g / C), r = (int)(g - (long long)grp * C);
-  const int ntiles = *ntiles_dev;
-  int cur = -1, e = -1, start = 0, nold = 0, nnew = 0;
-  for (int k = 0; k < G; ++k) {
-    const int tile = grp * G + k;
-    if (tile >= ntiles) break;
-    const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
-    if (c != cur) {
-      cur = c;
-      start = chunk_start[c] + r;
-      e = r2e[c * C + r];
-      nold = nnew = 0;
-      if (e < ne) {
-        nold = n_old[e];
-        nnew = n_new[e];
-      }
-    }
-    const int pend = min(min(p0 + TP, chunk_width[c]), nold);
-    for (int p = p0; p < pend; ++p) {
-      const int pid = start + p * C;
-      const int ne_ = new_element[pid];
-      if (ne_ == e) {
-        if (p < nnew) continue;  // stays where it is
-        const long long tgt = hole_tab[start + rank[pid] * C];  // back-fill a hole of the own row
-#pragma unroll
-        for (int i = 0; i < NQ * 2; ++i)
-          if (i < t.n8)
-            *(unsigned long long*)(t.dst8[i] + tgt * 8) = *(const unsigned long long*)(t.dst8[i] + (long long)pid * 8);
-#pragma unroll
-        for (int i = 0; i < (NQ * 4 < kMax4 ? NQ * 4 : kMax4); ++i)
-          if (i < t.n4) *(unsigned*)(t.dst4[i] + tgt * 4) = *(const unsigned*)(t.dst4[i] + (long long)pid * 4);
-      } else if (ne_ >= 0) {
-        const long long tgt = hole_tab[eslot0[ne_] + rank[pid] * C];
-        const uint4* sp = aos + (long long)pid * NQ;
-        unsigned w[NQ * 4];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const uint4 v = sp[q];
-          w[4 * q] = v.x;
-          w[4 * q + 1] = v.y;
-          w[4 * q + 2] = v.z;
-          w[4 * q + 3] = v.w;
-        }
-#pragma unroll
-        for (int i = 0; i < NQ * 2; ++i)
-          if (i < t.n8)
-            *(unsigned long long*)(t.dst8[i] + tgt * 8) = ((unsigned long long)w[2 * i + 1] << 32) | w[2 * i];
-#pragma unroll
-        for (int i = 0; i < (NQ * 4 < kMax4 ? NQ * 4 : kMax4); ++i)
-          if (i < t.n4) *(unsigned*)(t.dst4[i] + tgt * 4) = w[NQ * 4 - 1 - i];
-      }
-    }
-  }
-}
-// new particles take the holes their arrival ranks name
-__global__ void k_rs_add(int n_new, const int* __restrict__ new_elems, const int* __restrict__ rank_new,
-                         const int* __restrict__ eslot0, const int* __restrict__ hole_tab, int C, MoveArgs a,
-                         const int* __restrict__ go) {
-  if (!*go) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_new) return;
-  const int tgt = hole_tab[eslot0[new_elems[i]] + rank_new[i] * C];
-  copy_members(a, i, tgt);
-}
-__global__ void k_zero_gated(unsigned long long* __restrict__ p, long long n, const int* __restrict__ go) {
-  if (!*go) return;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    __builtin_nontemporal_store(0ull, p + i);
-}
-
 int finish_layout_upload(pp_ps* ps, const HostLayout& L, const std::vector<int>& ppe) {
   // slot_elem + mask image on host
   std::vector<int> slot_elem((size_t)L.capacity, -1);
@@ -1659,7 +922,6 @@ int finish_layout_upload(pp_ps* ps, const HostLayout& L, const std::vector<int>&
   (void)ppe;
   // row tiles (chunk, first p) of kTileP columns for the row-major hot kernels
   std::vector<int> tiles;
-  if (getenv("PP_TILE_P")) ps->tile_p = std::min(32, std::max(1, atoi(getenv("PP_TILE_P"))));  // <= 32: stay masks
   for (int c = 0; c < L.nchunks; ++c)
     for (int p0 = 0; p0 < L.chunk_widths[c]; p0 += ps->tile_p) {
       tiles.push_back(c);
@@ -1756,10 +1018,7 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
     // the layout kernel below adds up the per-block totals (the inversely-padded layout has no such kernel)
     int* const partial_at = ps->s_hist.as<int>() + hist_words;
     et.partial = (et.totals && !(ps->pad_strat == PP_PAD_INVERSELY && ps->shuffle_padding > 0)) ? partial_at : nullptr;
-    static const bool no_fused_sort = getenv("PP_NO_FUSED_SORT") != nullptr;  // A/B knobs
-    static const bool no_rs_skip = getenv("PP_NO_RS_SKIP") != nullptr;
-    static const bool no_wide_sort = getenv("PP_NO_WIDE_SORT") != nullptr;
-    const bool fused_sort = nblk <= kFusedSortBlocks && !no_fused_sort;
+    const bool fused_sort = nblk <= kFusedSortBlocks;
     unsigned long long maxkey = (unsigned long long)(n_sigma > 0 ? n_sigma : 1) * L.base;
     int bits = 0;
     while (bits < 64 && (maxkey >> bits)) ++bits;
@@ -1770,9 +1029,7 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
     }
     // one sort window (the keys are the counts): ONE counting pass, see k_rs_pass_wide
     // (up to 64 tiles every block sweeps the digit table itself; beyond that k_wide_seg / k_wide_base prefix it)
-    static const bool no_wide_big = getenv("PP_NO_WIDE_SORT_BIG") != nullptr;
-    const bool wide_sort = (fused_sort || (!no_fused_sort && !no_wide_big)) && !no_wide_sort && allow_wide &&
-                           n_sigma <= 1 && ps->wide_skip == 0 &&
+    const bool wide_sort = allow_wide && n_sigma <= 1 && ps->wide_skip == 0 &&
                            (ps->pad_strat != PP_PAD_INVERSELY || !(ps->shuffle_padding > 0));  // (needs k_layout_fused)
     const bool wide_big = wide_sort && !fused_sort;
     L.wide = wide_sort;
@@ -1786,7 +1043,7 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
     k_make_keys<<<nblk + (ride.on ? grid_for(ride.nverts) : 0), 256, 0, st>>>(ne, ppe, sg, n_sigma, L.base,
                                                  ps->s_keys.as<unsigned long long>(),
                                                  ps->s_vals.as<int>(), tot,
-                                                 no_rs_skip, et,
+                                                 false, et,
                                                  (fused_sort || wide_big) ? FusedHist{H0, nblk, wide_sort ? 1 : 0}
                                                                           : FusedHist{nullptr, 0, 0},
                                                  nblk, ride);
@@ -1836,11 +1093,9 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
   L.tile_off = L.tile_cnt + nchunks;
   L.chunk_start = ps->s_cstart2.as<int>();
   const bool fused_layout = ps->pad_strat != PP_PAD_INVERSELY || !(ps->shuffle_padding > 0);
-  static const bool no_fused_widths = getenv("PP_NO_FUSED_WIDTHS") != nullptr;
   // one sort window: the keys are the counts, ascending -- the layout kernel reads a chunk's width off its last row
   // (after the one-pass sort it has to: the overflow digit is ordered by that kernel's prologue)
-  const bool widths_in_layout = fused_layout && L.sorted && ne > 0 && ne / std::min(ps->sigma, std::max(ne, 1)) <= 1 &&
-                                (L.wide || !no_fused_widths);
+  const bool widths_in_layout = fused_layout && L.sorted && ne > 0 && ne / std::min(ps->sigma, std::max(ne, 1)) <= 1;
   if (!widths_in_layout)
     k_chunk_widths2<<<grid_for((size_t)nchunks * 64), kBlock, 0, st>>>(
         nchunks, C_new, ne, L.keys, L.base, L.sorted ? 1 : 0, ppe, L.widths);
@@ -1908,9 +1163,8 @@ int build_word_table(const pp_ps* ps, const void* const* src, int64_t src_stride
   // scattered stores of pass 1 become read-modify-writes (measured 0.25 -> 0.40 ms per 10 M)
   int NQ = (nw + 3) / 4 == 3 ? 4 : (nw + 3) / 4;
   // the same for the 160-B ps_combo160 particle: every other 160-B record starts in the middle of a 64-B sector;
-  // padded to 192 B (whole sectors) the scattered stores of pass 1 are plain writes (PP_NO_REC_PAD=1: A/B knob)
-  static const bool no_pad = getenv("PP_NO_REC_PAD") != nullptr;
-  if (NQ == 10 && !no_pad) NQ = 12;
+  // padded to 192 B (whole sectors) the scattered stores of pass 1 are plain writes
+  if (NQ == 10) NQ = 12;
   return (NQ == 4 || NQ == 10 || NQ == 12 || (NQ >= 1 && NQ <= 3) || NQ == 6 || NQ == 8) ? NQ : 0;
 }
 
@@ -1933,8 +1187,7 @@ int totals_pin(pp_ps* ps, Totals** h_pin_out, hipEvent_t* ev_out) {
 int scs_reshuffle(pp_ps* ps, const int* new_element, int n_new, const int* new_elems,
                   const void* const* new_info, int commit_x, int commit_xt,
                   const std::function<int(const int*)>& pre_sync) {
-  static const bool off = getenv("PP_NO_RESHUFFLE") != nullptr;
-  if (off || ps->shuffle_mode <= 0) return 0;
+  if (ps->shuffle_mode <= 0) return 0;
   if (!(ps->capacity > 0 && ps->num_ptcls > 0) || !ps->elem_count_valid || ps->ntiles_max <= 0) return 0;
   if (ps->d_eslot0.bytes < sizeof(int) * (size_t)std::max(ps->num_elems, 1)) return 0;
   const bool commit = commit_x >= 0 && commit_xt >= 0;
@@ -2012,8 +1265,7 @@ int scs_reshuffle(pp_ps* ps, const int* new_element, int n_new, const int* new_e
   // x_tgt <- 0 of the fused updatePtclPositions.  Without new particles the zeros stay pending: the
   // next fused push overwrites x_tgt of every live particle (pp_push_search), anything else that
   // looks at the member materialises them first (pp::ps_ready).
-  static const bool no_lazy = getenv("PP_NO_LAZY_ZERO") != nullptr;
-  const bool lazy = commit && n_new == 0 && !no_lazy;
+  const bool lazy = commit && n_new == 0;
   if (commit && !lazy) {
     const long long nwords = (long long)ps->stride * ps->member_ncomp[commit_x];
     k_zero_gated<<<2048, kBlock, 0, st>>>((unsigned long long*)ps->data[commit_x].p, nwords, go);
@@ -2044,7 +1296,7 @@ int scs_reshuffle(pp_ps* ps, const int* new_element, int n_new, const int* new_e
   (void)scattered;
   PP_HIP_CHECK(hipEventSynchronize(ev_tot));
   const Totals h = *h_pin;
-  static const bool spec_debug_rs = getenv("PP_SPEC_DEBUG") != nullptr;
+  static const bool spec_debug_rs = PP_LAB_ENV("PP_SPEC_DEBUG") != nullptr;
   if (spec_debug_rs)
     fprintf(stderr, "rebuild in place: go %d active %d nonempty %d invalid %d overflowing rows %d\n", h.go, h.active,
             h.nonempty, h.invalid, h.n_over);
@@ -2109,10 +1361,9 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   PP_HIP_CHECK(ps->s_ranknew.reserve(sizeof(int) * (size_t)std::max(n_new, 1)));
   int* rank = ps->s_idx.as<int>();
   int* rank_new = ps->s_ranknew.as<int>();
-  static const bool no_count_merge = getenv("PP_NO_COUNT_MERGE") != nullptr;
   // (pp_ps::hot) the over-full row's own columns go through their own blocks -- in the steady state of the
   // record-fed loop, where this rebuild takes the row-major staged path again (the test at the top of this function)
-  static const bool no_hot = getenv("PP_NO_HOT_ROW") != nullptr;
+  static const bool no_hot = PP_LAB_ENV("PP_NO_HOT_ROW") != nullptr;  // (lab build: the over-full row through the common blocks)
   const bool steady = ps->lazy_rec == 2 && ps->zero_pending < 0 && (n_new == 0 || new_xt_zero) && commit_x >= 0 &&
                       commit_x == ps->lazy_x && commit_xt == ps->lazy_xt;
   const pp::HotRow hot_now =
@@ -2123,7 +1374,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
 #define PP_COUNT_ARGS                                                                                      \
   ps->d_ntiles.as<int>(), ps->C, ps->tile_p, G, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(),        \
       ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(), ps->d_mask.as<unsigned char>(), new_element, \
-      ne, ppe, tot, rank, no_count_merge ? 0 : 1, hot_now, hot_blocks
+      ne, ppe, tot, rank, 1, hot_now, hot_blocks
     if (ps->C == 64)
       k_count_tiled<3, true><<<grp_grid + hot_blocks, kBlock, 0, st>>>(PP_COUNT_ARGS);
     else
@@ -2136,9 +1387,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   // 64..256 blocks: each block ends with two atomics on the same two counters (~5 ns apiece), each
   // thread strides over ne / (blocks * 256) elements
   // the reference's reshuffle decision (mode 1), on the histogram just built
-  static const bool no_reshuffle = getenv("PP_NO_RESHUFFLE") != nullptr;
-  const bool decide_keep = try_reshuffle && ps->shuffle_mode >= 1 && have_old && ne > 0 && ps->elem_count_valid &&
-                           !no_reshuffle;
+  const bool decide_keep = try_reshuffle && ps->shuffle_mode >= 1 && have_old && ne > 0 && ps->elem_count_valid;
   // totals of the new population + the decision: in the sweep that makes the sort keys when the layout
   // is sorted (one launch instead of three), else their own kernels
   // (up to 256 key blocks: every block ends with three atomics on the same counters, ~10 ns each)
@@ -2159,8 +1408,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   // a pass that turns out to be unnecessary still costs five launches (45 us of a 0.44 ms step at
   // 1 M elements / 1 M particles)
   int bits_pred = 0;
-  static const bool no_pred = getenv("PP_NO_RS_PREDICT") != nullptr;
-  if (!no_pred && ps->last_max_key != ~0ull) {
+  if (ps->last_max_key != ~0ull) {
     // (margin: 1/16 of the last maximum.  A whole extra bit -- round 2 -- launched a third, idle, 8-bit pass
     // for the literal pseudoXGCm population, whose largest row holds 60 000 particles: 16 bits exactly)
     const unsigned long long guess = ps->last_max_key + ps->last_max_key / 16 + 16;
@@ -2215,7 +1463,8 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   bool spec_ok = false;
   long long cap_lim = 0, nsl_lim = 0;
   int64_t stride_fit = 0;
-  static const bool no_spec = getenv("PP_NO_SPEC_REBUILD") != nullptr;
+  // (lab build, PP_NO_SPEC_REBUILD=1: every rebuild takes the checked path a rebuild takes when some buffer must grow)
+  static const bool no_spec = PP_LAB_ENV("PP_NO_SPEC_REBUILD") != nullptr;
   if (!no_spec && have_old && old_grid > 0) {
     const int nchunks0 = ne / ps->C_max + (ne % ps->C_max != 0);
     cap_lim = std::min<long long>((long long)ps->s_mask2.bytes, (long long)(ps->s_slot2.bytes / 4));
@@ -2249,17 +1498,16 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   Totals* h_pin = nullptr;
   hipEvent_t ev_tot = nullptr;
   if (int rcp = totals_pin(ps, &h_pin, &ev_tot)) return rcp;
-  static const bool no_direct_totals = getenv("PP_NO_DIRECT_TOTALS") != nullptr;
   // the host polls the landing zone for this rebuild's stamp (no event in the stream); one poll that runs into
   // its time limit (the memory turned out not to be visible mid-stream) switches back to the event for good
-  static bool poll_totals = getenv("PP_NO_POLL_TOTALS") == nullptr;
-  const int stamp = (poll_totals && !no_direct_totals) ? (ps->totals_stamp = ps->totals_stamp % 1000000 + 1) : 0;
+  static bool poll_totals = true;
+  const int stamp = poll_totals ? (ps->totals_stamp = ps->totals_stamp % 1000000 + 1) : 0;
   int rc = enqueue_layout(ps, ps->C_max, ppe, tot, key_base, L, bits_pred,
                           ElemTotalsArgs{totals_in_keys ? 1 : 0, (totals_in_keys && decide_keep) ? 1 : 0, ps->C,
                                          ps->d_element_to_row.as<int>(), ps->d_chunk_width.as<int>(), nullptr},
                           SpecArgs{spec_ok ? 1 : 0, (int)cap_lim, (int)nsl_lim, ps->C_max, decide_keep ? 1 : 0,
                                    pp::search_not_found_dev()},
-                          spec_ok ? &ta_spec : nullptr, /*allow_wide=*/true, no_direct_totals ? nullptr : h_pin, stamp);
+                          spec_ok ? &ta_spec : nullptr, /*allow_wide=*/true, h_pin, stamp);
   const bool polling = stamp != 0 && L.totals_on_host;
   if (rc) return rc;
   nchunks = L.nchunks;
@@ -2268,13 +1516,11 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   int NQ = 0;
   bool lazy_zero = false, defer_unpack = false, use_rm = false;
   // today's per-element counts are not read by a re-layout that commits: its tail clears them for the next one
-  static const bool lazy_slot_elem = getenv("PP_EAGER_SLOT_ELEM") == nullptr;  // (pp::slot_elem)
-  // staging records row-major inside a chunk (pp_ps::rec_rm; PP_NO_RM_RECORDS=1: slot order, the A/B knob)
-  static const bool no_rm = getenv("PP_NO_RM_RECORDS") != nullptr;
-  const bool want_rm = !no_rm && have_old && old_grid > 0;
+  constexpr bool lazy_slot_elem = true;  // (pp::slot_elem fills the table when something asks)
+  // staging records row-major inside a chunk (pp_ps::rec_rm)
+  const bool want_rm = have_old && old_grid > 0;
   if (want_rm) PP_HIP_CHECK(ps->s_erec0.reserve(sizeof(int) * (size_t)std::max(ne, 1)));
-  static const bool no_prezero = getenv("PP_NO_PREZERO") != nullptr;
-  const bool prezero = !no_prezero && ps->d_elem_count.p && ps->d_elem_count.p != ps->s_ppe.p &&
+  const bool prezero = ps->d_elem_count.p && ps->d_elem_count.p != ps->s_ppe.p &&
                        ps->d_elem_count.bytes >= tot_off + sizeof(Totals);
   // Everything after the layout: new layout arrays, slot tables and the move of every member.
   // `cap_sz` / `nsl_sz` size the buffers and the launches; the kernels themselves read the true
@@ -2290,9 +1536,8 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
                       prezero ? ps->d_elem_count.as<int>() : nullptr,
                       prezero ? (int)((tot_off + sizeof(Totals)) / sizeof(int)) : 0,
                       want_rm ? ps->s_erec0.as<int>() : nullptr, nullptr, nullptr, nchunks, ta.sorted};
-    static const bool no_merge = getenv("PP_NO_TABLES_SLOTS_MERGE") != nullptr;
     const unsigned table_blocks = ta.b3 + grid_for(nrows);
-    if (C_new % 4 == 0 && !no_merge) {  // one launch: table blocks + slot blocks (which find tile and element themselves)
+    if (C_new % 4 == 0) {  // one launch: table blocks + slot blocks (which find tile and element themselves)
       isa.tile_off = L.tile_off;
       isa.index = L.index;
       k_layout_tables_slots<<<table_blocks + grid_for((size_t)ntiles_max * (C_new / 4)), kBlock, 0, st>>>(ta, isa,
@@ -2333,13 +1578,13 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       // x_tgt <- 0 of the fused updatePtclPositions stays pending (pp_ps::zero_pending): the next fused
       // push overwrites the member, anything else materialises the zeros first.  24 of the 60 bytes
       // pass 2 would write per particle.
-      static const bool no_lazy_zero = getenv("PP_NO_LAZY_ZERO") != nullptr;
-      lazy_zero = NQ > 0 && commit_x >= 0 && commit_xt >= 0 && (n_new == 0 || new_xt_zero) && !no_lazy_zero;
+      lazy_zero = NQ > 0 && commit_x >= 0 && commit_xt >= 0 && (n_new == 0 || new_xt_zero);
       if (lazy_zero) wt.nz8 = wt.nz4 = 0;
       // The second pass (records -> new SoA arrays) is deferred for the pseudoXGCm particle type: the
       // next fused push reads the records themselves (pp_search.hip: RECIN), anything else runs the
       // pass first (ps_ready).  One pass over the particles less per step of the pseudoXGCm loop.
-      static const bool no_defer = getenv("PP_NO_LAZY_UNPACK") != nullptr;
+      // (lab build, PP_NO_LAZY_UNPACK=1: pass 2 runs right away -- the path every other particle type takes)
+      static const bool no_defer = PP_LAB_ENV("PP_NO_LAZY_UNPACK") != nullptr;
       defer_unpack = lazy_zero && NQ == 4 && !no_defer && xgcm_shape(ps);
     }
     if (NQ > 0) {
@@ -2363,7 +1608,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       // the staging records row-major inside a chunk: the particles of a row, which carry consecutive ranks,
       // are consecutive records, and the pack's block-level transpose stores them as runs
       const RankToSlot rs_rm{new_element, ps->s_erec0.as<int>(), 1};
-      static const int rm_wide = getenv("PP_RM_WIDE") ? atoi(getenv("PP_RM_WIDE")) : 3;  // log2(columns per block)
+      constexpr int rm_wide = 3;  // log2(columns per block)
       // (only where the records stay the particle data -- the pseudoXGCm flows, where nine particles in ten keep
       // their row: c3 -3.3 %, 2dc3 -3.6 %, c5 share -3.2 %.  ps_combo160 redistributes half of its particles to
       // random elements: nothing to merge, and its second pass reads row-major records 2.5 % slower)
@@ -2495,7 +1740,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     ps->num_ptcls = 0;
     return PP_OK;
   }
-  static const bool spec_debug = getenv("PP_SPEC_DEBUG") != nullptr;
+  static const bool spec_debug = PP_LAB_ENV("PP_SPEC_DEBUG") != nullptr;
   if (spec_debug)
     fprintf(stderr, "rebuild: speculated %d go %d capacity %d (old %d) nslices %d active %d nonempty %d "
                     "key bits sorted %d max key %llu; over-full row's blocks %d (columns %d..%d)\n",
@@ -2681,7 +1926,7 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   // enqueued for that count and a one-thread kernel clears tot->go when the true count differs.
   const int guess = nold + n_new;
   bool speculated = false;
-  static const bool no_spec = getenv("PP_NO_SPEC_REBUILD") != nullptr;
+  static const bool no_spec = PP_LAB_ENV("PP_NO_SPEC_REBUILD") != nullptr;
   if (!no_spec && guess > 0) {
     k_spec_check_csr<<<1, 1, 0, st>>>(tot, guess);
     int rc = enqueue_tail(guess);

@@ -126,8 +126,7 @@ int upload_vec(pp::DevBuf& d, const std::vector<T>& h) {
 // therefore a multiple of 64 slots whose quotient is 17 mod 32: successive component arrays start
 // 17 x 512 B apart modulo 16 KiB.
 int64_t spread_stride(int64_t n) {
-  static const bool off = getenv("PP_NO_STRIDE_SPREAD") != nullptr;
-  if (off || n < 4096) return n;
+  if (n < 4096) return n;
   int64_t s = (n + 63) / 64;
   while (s % 32 != 17) ++s;
   return s * 64;
@@ -136,8 +135,7 @@ int alloc_members(pp_ps* ps, std::vector<pp::DevBuf>& bufs, int64_t stride, bool
   bufs.resize((size_t)ps->nmembers);
   for (int m = 0; m < ps->nmembers; ++m) {
     const size_t bytes = (size_t)stride * ps->member_ncomp[m] * ps->member_bytes[m];
-    static const bool no_skew = getenv("PP_NO_MEMBER_SKEW") != nullptr;
-    PP_HIP_CHECK(bufs[m].reserve(std::max<size_t>(bytes, 16), no_skew ? 0 : (size_t)((m + 1) * 5 % 32) * 512));
+    PP_HIP_CHECK(bufs[m].reserve(std::max<size_t>(bytes, 16), (size_t)((m + 1) * 5 % 32) * 512));
     if (zero && bytes) PP_HIP_CHECK(hipMemsetAsync(bufs[m].p, 0, bytes, pp::stream()));
   }
   return PP_OK;

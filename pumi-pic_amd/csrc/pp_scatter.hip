@@ -396,7 +396,7 @@ void gyro_map_invalidate(const void* dev, size_t bytes) {
 int gyro_scatter_ride(const pp_mesh* mesh, int nmaps, const int* const* v2v_dev, double* const* out_dev,
                       double rmax, int gnr, int gppr, GyroRide* ride) {
   *ride = GyroRide{};
-  static const bool off = getenv("PP_SCATTER_ATOMIC") != nullptr || getenv("PP_NO_SCATTER_RIDE") != nullptr;
+  static const bool off = PP_LAB_ENV("PP_SCATTER_ATOMIC") != nullptr || PP_LAB_ENV("PP_NO_SCATTER_RIDE") != nullptr;
   if (off || mesh->nverts <= 0 || nmaps < 1 || nmaps > 2) return PP_OK;
   const InvMap* inv = find_inverse(v2v_dev[0], mesh, gnr, gppr);
   if (!inv) return PP_OK;
@@ -439,7 +439,7 @@ int gyro_scatter_counts(const pp_mesh* mesh, const int* cnt_dev, int nmaps, cons
   k_rings_from_adjacency<<<grid_for(nverts), kBlock, 0, st>>>(
       nverts, gnr, mesh->d_vert2elems_off.as<int>(), mesh->d_vert2elems.as<int>(), cnt_dev, ringDown,
       ringUp, g_ring->as<double>());
-  static const bool no_gather = getenv("PP_SCATTER_ATOMIC") != nullptr;
+  static const bool no_gather = PP_LAB_ENV("PP_SCATTER_ATOMIC") != nullptr;  // (lab build: a map without a transpose)
   for (int k = 0; k < nmaps; ++k) {
     const InvMap* inv = no_gather ? nullptr : find_inverse(v2v_dev[k], mesh, gnr, gppr);
     if (inv) {
@@ -562,7 +562,7 @@ int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, do
   pp::DevBuf* s_ring = g_ring;
   PP_HIP_CHECK(s_cnt->reserve(sizeof(int) * (size_t)std::max(ne, 1)));
   PP_HIP_CHECK(s_ring->reserve(sizeof(double) * (size_t)std::max(nverts * gnr, 1)));
-  static const bool no_gather = getenv("PP_SCATTER_ATOMIC") != nullptr;
+  static const bool no_gather = PP_LAB_ENV("PP_SCATTER_ATOMIC") != nullptr;  // (lab build: a map without a transpose)
   const InvMap* inv = no_gather ? nullptr : find_inverse(v2v_dev, mesh, gnr, gppr);
   const bool have = ps->num_ptcls > 0 && ps->capacity > 0;
   if (!inv || !have) PP_HIP_CHECK(hipMemsetAsync(scatter_w_dev, 0, sizeof(double) * (size_t)nverts, st));
@@ -645,15 +645,14 @@ int pp_gyro_scatter_radius(const pp_mesh* mesh, const pp_ps* ps, const double* r
   const size_t er_bytes = sizeof(double) * (size_t)std::max(ne * gnr, 1);
   PP_HIP_CHECK(s_er->reserve(er_bytes + 16));
   int* clip_dev = (int*)((char*)s_er->p + er_bytes);
-  static const bool no_gather = getenv("PP_SCATTER_ATOMIC") != nullptr;
+  static const bool no_gather = PP_LAB_ENV("PP_SCATTER_ATOMIC") != nullptr;  // (lab build: a map without a transpose)
   const InvMap* inv = no_gather ? nullptr : find_inverse(v2v_dev, mesh, gnr, gppr);
   if (!inv || !have) PP_HIP_CHECK(hipMemsetAsync(scatter_w_dev, 0, sizeof(double) * (size_t)std::max(nverts, 1), st));
   if (!have) return PP_OK;
   c_ps = nullptr;  // the shared ring accumulator no longer holds the count-based rings of a structure
   PP_HIP_CHECK(hipMemsetAsync(s_er->p, 0, er_bytes + 16, st));
   const double ringWidth = rmax / gnr;
-  static const bool force_flat = getenv("PP_SCATTER_FLAT") != nullptr;
-  if (ps->kind == PP_SCS && ps->ntiles_max > 0 && !force_flat) {
+  if (ps->kind == PP_SCS && ps->ntiles_max > 0) {
     const int G = std::max(1, 32 / ps->tile_p);
     k_elem_rings_scs<<<grid_for(((size_t)ps->ntiles_max + G - 1) / G * ps->C), kBlock, 0, st>>>(
         ps->d_ntiles.as<int>(), ps->C, ps->tile_p, G, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(),

@@ -2378,8 +2378,9 @@ int pp_search_mesh(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_pi
       PP_MEMBER(ps, m_x, double), PP_MEMBER(ps, m_xtgt, double), ps->stride, elem_ids_dev,       \
       elem_ids_seeded, mesh->tol, inter_faces_dev, inter_points_dev, looplimit, g_cnt.get()
   // intersection mode: the walk on packed records (tets: k_search_mt3 with lane refill; triangles: the packed
-  // branch of k_search_tpp); PP_MT_PACKED=0 keeps the form on the Omega_h-style arrays (A/B knob)
-  static const bool mt_packed_off = getenv("PP_MT_PACKED") != nullptr && atoi(getenv("PP_MT_PACKED")) == 0;
+  // branch of k_search_tpp); a mesh whose records cannot be packed (pp_mesh::mt_packed_ok) keeps the form on the
+  // Omega_h-style arrays (lab build, PP_MT_PACKED=0: every mesh)
+  static const bool mt_packed_off = PP_LAB_ENV("PP_MT_PACKED") != nullptr && atoi(PP_LAB_ENV("PP_MT_PACKED")) == 0;
   if (mesh->dim == 2) {
     if (requireIntersection)
       k_search_tpp<2, true><<<grid, kBlock, 0, st>>>(PP_TPP_ARGS, (mesh->mt_packed_ok && !mt_packed_off) ? 1 : 0);
@@ -2387,10 +2388,8 @@ int pp_search_mesh(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_pi
       k_search_tpp<2, false><<<grid, kBlock, 0, st>>>(PP_TPP_ARGS);
   } else {
     if (requireIntersection && mesh->mt_packed_ok && !mt_packed_off) {
-      static const int per_lane_env = getenv("PP_MT_PER_LANE") ? atoi(getenv("PP_MT_PER_LANE")) : 0;
-      static const int start_batch_env = getenv("PP_MT_START_BATCH") ? atoi(getenv("PP_MT_START_BATCH")) : 0;
-      const int per_lane = per_lane_env > 0 ? per_lane_env : 2;  // (chunks of 128 slots; 1 / 2 / 4 / 8: 24.0 / 15.8 / 16.1 / 17.1 ms for c2mt)
-      const int start_batch = start_batch_env > 0 ? start_batch_env : 12;
+      const int per_lane = 2;  // (chunks of 128 slots; 1 / 2 / 4 / 8: 24.0 / 15.8 / 16.1 / 17.1 ms for c2mt)
+      const int start_batch = 12;
       // persistent blocks: as many as are resident at once (4 per CU: 112 VGPRs, 32 KB of LDS each), fewer when the
       // structure is small; the chunks of slots are drawn from a device counter
       static int resident_blocks = 0;
@@ -2627,7 +2626,8 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
     ps->zero_pending = -1;
   // Record-fed push: the last full re-layout left the particles in its staging records (pp_ps::lazy_rec)
   // and this call can read them there -- the pass that would copy them to the SoA arrays first is skipped.
-  const int wq_env = getenv("PP_WALK_QUEUE") ? atoi(getenv("PP_WALK_QUEUE")) : -1;  // per call
+  // (lab build, PP_WALK_QUEUE=0/1: the column-loop kernel / the queued kernel whatever the dimension)
+  const int wq_env = PP_LAB_ENV("PP_WALK_QUEUE") ? atoi(PP_LAB_ENV("PP_WALK_QUEUE")) : -1;  // per call
   const int wq = wq_env >= 0 ? wq_env : (mesh->dim == 3 ? 1 : 0);
   const bool recin = ((mesh->dim == 3 && wq > 0) || (mesh->dim == 2 && wq == 0)) &&
                      ps->capacity > 0 && ps->num_ptcls > 0 && ps->ntiles_max > 0 &&
@@ -2695,7 +2695,7 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
       if (mesh->dim == 2) {
         k_push_walk_rowsq<2, 4, true><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
       } else if (recin) {
-        static const int no_pairs = getenv("PP_NO_PAIR_FETCH") != nullptr ? 1 : 0;
+        static const int no_pairs = PP_LAB_ENV("PP_NO_PAIR_FETCH") != nullptr ? 1 : 0;  // (lab build: one column per fetch)
         const RecIn rin{ps->s_aos_live.as<char>(), (unsigned*)ps->data[2].p, (float*)ps->data[3].p, 0, ps->rec_rm ? 1 : 0,
                         no_pairs};
         if (ps->rec_rm && !elem_ids_seeded && (ps->tile_p & 1) == 0 && (ps->C & 1) == 0 && !no_pairs)
