@@ -625,6 +625,72 @@ def also_c4(pp, capi, a, w_main, st_main):
                     "that sweep 10^6 rows, not a stream"}
 
 
+def measure_c4ref(pp, capi, ne, nptcl, structure="scs", dist=1, k=100):
+    """ps_combo160 in the REFERENCE's own shape (performance_tests/ps_combo160.cpp:152-188, 205-232): K pseudo-pushes
+    back to back, timed; then K x (redistribute_particles + rebuild), timed, with NO member access between the
+    rebuilds -- the second pass of a re-layout (records -> member arrays) is deferred for records wider than 64 B
+    and the next rebuild moves records to records (k_move_pack_rec: 192 B read + 192 B written per particle)."""
+    import gc
+    w = build_c4(pp, capi, ne, nptcl, 0, structure, dist)
+    ps, parent = w["ps"], w["parent"]
+    gc.collect()
+    clock_prewarm(capi, float(os.environ.get("PP_BENCH_PREWARM", "0.3")))
+    for _ in range(3):
+        capi.pseudo_push160(ps, parent)
+    capi.sync()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        capi.pseudo_push160(ps, parent)
+    capi.sync()
+    push_ms = (time.perf_counter() - t0) / k * 1e3
+    new_elems = None
+
+    def round_(r):
+        nonlocal new_elems
+        new_elems = capi.redistribute_particles(ps, 0.5, seed=r, out=new_elems, strat=dist)
+        ps.rebuild(new_elems)
+        cap = max(ps.capacity(), 1)
+        if cap > new_elems.n:
+            new_elems = capi.DevArray(cap + cap // 10, np.int32)
+    for r in range(4):
+        round_(r)
+    capi.sync()
+    t0 = time.perf_counter()
+    for r in range(k):
+        round_(4 + r)
+    capi.sync()
+    loop_ms = (time.perf_counter() - t0) / k * 1e3
+    # the redistribution alone (reads the mask and the slot's element, writes 4 B per slot)
+    t0 = time.perf_counter()
+    for r in range(20):
+        new_elems = capi.redistribute_particles(ps, 0.5, seed=r, out=new_elems, strat=dist)
+    capi.sync()
+    redis_ms = (time.perf_counter() - t0) / 20 * 1e3
+    n = ps.nPtcls()
+    rebuild_ms = loop_ms - redis_ms
+    return {"workload": "%s, %d particles: %d pseudo-pushes, then %d x (redistribute 0.5 + rebuild) with no member "
+                        "access in between (performance_tests/ps_combo160.cpp:152-188, 205-232)" % (w["label"], n, k, k),
+            "particles": n, "elements": ne, "pseudo_push_ms": push_ms,
+            "pseudo_push_roofline_frac": BYTES["c4"] * n / (push_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "redistribute_plus_rebuild_ms": loop_ms, "redistribute_ms": redis_ms, "rebuild_ms": rebuild_ms,
+            "rebuild_roofline_frac": 328.0 * n / (rebuild_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "loop_roofline_frac": 328.0 * n / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "bytes_per_particle_rebuild": 328.0,
+            "note": "fractions on SURVEY 8(d)'s 328 algorithmic B per kept-or-moved particle (160 read + 160 written + "
+                    "8 index); the record-to-record pass moves 2 x 192 B of padded records for them"}
+
+
+def also_c4ref(pp, capi, a, w_main, st_main):
+    """configs[3] in the reference's two-loop shape: the stress point 1 M elements / 1 M particles and the script's
+    own point 50 k elements / 50 M particles (performance_tests/test_largeE_smallP.sh:9-19), Sell-64-ne"""
+    out = {"1Me_1Mp": measure_c4ref(pp, capi, 1_000_000, 1_000_000, "scs", 1, 100)}
+    try:
+        out["50ke_50Mp"] = measure_c4ref(pp, capi, 50_000, 50_000_000, "scs", 1, 20)
+    except Exception as e:  # noqa: BLE001 -- (memory / time on a loaded box: the stress point stands on its own)
+        out["50ke_50Mp"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
 def also_general_scatter(pp, capi, a, w_main, st_main):
     """pp_gyro_scatter_radius on the headline's structure: per-particle radius (and weight 1), the kernel the
     reference's gyroScatter would be without its constant radius (test/gyroScatter.hpp:182-204: 2*(dim+1) FP64
@@ -745,7 +811,86 @@ def also_driver_pseudoxgcm(pp, capi, a, w_main, st_main):
     return out
 
 
-ALSO = {"driver_pseudoxgcm": also_driver_pseudoxgcm, "c2": also_c2, "c2mt": also_c2mt, "c4_1Me_1Mp": also_c4, "c3_general_scatter": also_general_scatter,
+def run_virtual_ranks(pp, capi, a, V):
+    """BASELINE configs[4] at its FULL size on ONE GPU: V virtual ranks (element-block owners) of a.particles each on a
+    `local` communicator -- real migration traffic between the blocks (pack, exchange through device memory, unpack
+    into the receiver's rebuild), gyroSync over the V ranks -- all on one stream.  The time of a step divided by V
+    is the per-GPU COMPUTE of an N = V run (everything but the xGMI transfer itself): the like-for-like N = 1 point
+    of the scaling curve."""
+    from pumipic_amd import dist as ppdist
+    s = pp.synth
+    t_set = time.perf_counter()
+    ws = []
+    for r in range(V):
+        w = build_workload(pp, capi, "c5", a.particles, r, V, a.deg, a.remainder, "1m", a.sigma)
+        for k in ("elem", "info", "ppe"):  # (host copies of 32 M particles per rank: not needed again)
+            w.pop(k, None)
+        ws.append(w)
+        beat("virtual rank %d built" % r)
+    mesh, ne = ws[0]["mesh"], ws[0]["ne"]  # (every rank of a node holds the full mesh; here they share one copy)
+    owners = ppdist.element_block_owners(ne, V)
+    owners_d = capi.DevArray.from_host(owners)
+    safes = [capi.DevArray.from_host((owners == r).astype(np.uint8)) for r in range(V)]
+    comms = capi.Comm.local(V)
+    fwd, bkwd = capi.create_gyro_ring_mappings(mesh)
+    ids, wf, wb, packed = [], [], [], [None] * V
+    for w in ws:
+        cap = w["ps"].capacity()
+        ids.append(capi.DevArray.from_host(np.full(cap + cap // 4, -1, dtype=np.int32)))
+        wf.append(capi.DevArray(mesh.nverts, np.float64))
+        wb.append(capi.DevArray(mesh.nverts, np.float64))
+    t_set = time.perf_counter() - t_set
+    moved = [0]
+
+    def step():
+        for r, w in enumerate(ws):
+            ps = w["ps"]
+            capi.push_search(mesh, ps, s.XGC_H, s.XGC_K, s.XGC_D, a.deg, ids[r], seeded=False, looplimit=200,
+                             want_found=False)
+            capi.migrate_ptcls_begin(ps, ids[r], safes[r], owners_d, comms[r], commit=True,
+                                     scatter=(mesh, [fwd, bkwd], [wf[r], wb[r]]))
+        for r, w in enumerate(ws):
+            ns, _ = capi.migrate_end(w["ps"], comms[r])
+            moved[0] += ns
+            cap = w["ps"].capacity()
+            if cap > ids[r].n:
+                ids[r] = capi.DevArray(cap + cap // 4, np.int32)
+        for r in range(V):
+            packed[r] = capi.gyro_sync_pack(mesh.nverts, wf[r], wb[r], out=packed[r])
+        for r in range(V):
+            comms[r].allreduce_sum(packed[r])
+
+    import gc
+    gc.collect()
+    clock_prewarm(capi, float(os.environ.get("PP_BENCH_PREWARM", "0.3")))
+    for _ in range(a.warmup):
+        step()
+    capi.sync()
+    moved[0] = 0
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    capi.sync()
+    dt = time.perf_counter() - t0
+    n_all = sum(w["ps"].nPtcls() for w in ws)
+    per_rank_ms = dt / a.steps / V * 1e3
+    out = {"metric": METRIC["c5"], "value": n_all * a.steps / dt, "unit": "particles/s", "n_gpus": 1, "steps": a.steps,
+           "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "virtual_ranks": V, "per_rank_ms": per_rank_ms, "per_rank_value": n_all / V / (per_rank_ms * 1e-3),
+           "per_rank_roofline_frac": 194.0 * (n_all / V) / (per_rank_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "particles_total": n_all, "migrated_per_step": moved[0] / a.steps, "setup_seconds": t_set,
+           "config": {"workload": "configs[4] at full size on one GPU: %s, %d virtual ranks x %d particles = %d, element-block "
+                                  "owners, push+search+migrate(local exchange)+rebuild+gyroScatter x2+gyroSync; "
+                                  "per_rank_ms = step time / %d: the compute one GPU of an N = %d run does per step "
+                                  "(the xGMI transfer is not in it)" % (ws[0]["label"], V, a.particles, n_all, V, V),
+                      "parallelism": "%d virtual ranks on one GPU (pp_comm_create_local)" % V}}
+    for c in comms:
+        c.destroy()
+    return out
+
+
+ALSO = {"driver_pseudoxgcm": also_driver_pseudoxgcm, "c2": also_c2, "c2mt": also_c2mt, "c4_1Me_1Mp": also_c4, "c4_reference_shape": also_c4ref, "c3_general_scatter": also_general_scatter,
         "ps_parallel_for": also_parallel_for}
 
 
@@ -894,6 +1039,9 @@ def main():
     ap.add_argument("--watchdog", type=float, default=None,
                     help="seconds without progress after which a rank exits with code 3 (default: 120 on "
                          "multi-rank runs, off on one rank; 0 = off)")
+    ap.add_argument("--virtual-ranks", type=int, default=0,
+                    help="c5 on ONE GPU as this many virtual ranks of --particles each (local communicator): "
+                         "configs[4] at full size is --workload c5 --virtual-ranks 8 --particles 32000000")
     ap.add_argument("--no-scale-ref", action="store_true",
                     help="N = 1: skip the extra measurement of the multi-GPU workload's one-rank share "
                          "(c5, 998 400 tets, 32 M particles) that the line reports as `scale_ref`")
@@ -961,6 +1109,12 @@ def main():
     pp = pumipic_amd_loader.load()
     from pumipic_amd import capi
     capi.init(local_rank)  # raises when the HIP library / GPU is missing: no CPU fallback
+    if a.virtual_ranks > 1:  # configs[4] at full size on one GPU (its own, shorter, line)
+        if world != 1 or a.workload != "c5":
+            sys.stderr.write("bench.py: --virtual-ranks needs --workload c5 on one rank\n")
+            sys.exit(2)
+        print(json.dumps(run_virtual_ranks(pp, capi, a, a.virtual_ranks)))
+        return
     # PyTorch creates its HIP context lazily at the first torch.cuda call -- 50-60 ms on a fresh box, which used
     # to land inside the first timed region (the barrier's torch.cuda.synchronize()): seen as sporadic
     # 3 ms/step `cold_clocks` values in round 3's runs.  Pay it here, before anything is timed.
@@ -1098,13 +1252,50 @@ def main():
         capi.sync()
         dt5 = time.perf_counter() - t0
         n5 = w5["ps"].nPtcls()
-        return {"workload": "c5 on one rank: %s, %d particles, push+search+migrate(no peer)+rebuild+gyroScatter x2"
-                            % (w5["label"], 32_000_000),
+        out5 = {"workload": "c5 on one rank: %s, %d particles spread over the WHOLE mesh (32 per element), "
+                            "push+search+migrate(no peer)+rebuild+gyroScatter x2" % (w5["label"], 32_000_000),
                 "ms_per_step": dt5 / k5 * 1e3, "value": n5 * k5 / dt5, "unit": "particles/s", "steps": k5,
                 "warmup": 12, "setup_seconds": t_set,
                 "roofline_frac": 194.0 * n5 / (dt5 / k5) / 1e9 / HBM_PEAK_GBS,
-                "note": "the N > 1 lines of this file run exactly this workload per GPU (weak scaling); "
-                        "scaling efficiency of an N-GPU line = value / (N * scale_ref.value)"}
+                "note": "NOT the step a rank of an N = 8 run takes: there a rank's 32 M particles sit in its own "
+                        "element block (124 800 tets, 256 per element) and seven eighths of its rows are empty -- "
+                        "`rank_of_8_population` below is that population on one rank (no peer, so no pack / unpack of "
+                        "migration traffic), `virtual_ranks_8` the committed run of all eight ranks on one GPU "
+                        "(bench.py --workload c5 --virtual-ranks 8 --particles 32000000)"}
+        del st5, w5
+        # rank 0 of a world of 8: the same 32 M particles in the FIRST element block only
+        t_set = time.perf_counter()
+        w8 = build_workload(pp, capi, "c5", 32_000_000, 0, 8, a.deg, a.remainder, "1m", a.sigma)
+        w8["rank"], w8["world"] = 0, 1  # (stepped alone: leavers stay on this rank, nothing arrives)
+        w8["safe_layers"], w8["comm"], w8["origin_trust"] = 0, "rccl", w.get("origin_trust", False)
+        st8 = Stepper(pp, capi, w8, "c5", a.deg)
+        t_set = time.perf_counter() - t_set
+        clock_prewarm(capi, prewarm_s)
+        for _ in range(12):
+            st8.step()
+        capi.sync()
+        t0 = time.perf_counter()
+        for _ in range(k5):
+            st8.step()
+        capi.sync()
+        dt8 = time.perf_counter() - t0
+        n8 = w8["ps"].nPtcls()
+        out5["rank_of_8_population"] = {
+            "workload": "the population of rank 0 of 8 (32 M particles in the first 124 800 tets, 256 per element) "
+                        "stepped on one rank: the per-GPU compute of configs[4] without the exchange",
+            "ms_per_step": dt8 / k5 * 1e3, "value": n8 * k5 / dt8, "unit": "particles/s", "steps": k5, "warmup": 12,
+            "setup_seconds": t_set, "roofline_frac": 194.0 * n8 / (dt8 / k5) / 1e9 / HBM_PEAK_GBS}
+        vf = os.path.join(ROOT, "profiles", "r05_c5_virtual8.json")
+        if os.path.exists(vf):
+            try:
+                vj = json.load(open(vf))
+                out5["virtual_ranks_8"] = {k: vj.get(k) for k in ("per_rank_ms", "per_rank_value", "per_rank_roofline_frac",
+                                                                 "particles_total", "migrated_per_step", "ms_per_step")}
+                out5["virtual_ranks_8"]["provenance"] = "profiles/r05_c5_virtual8.json (committed run of this file)"
+                out5["per_rank_ms"] = {"1": dt5 / k5 * 1e3, "8": vj.get("per_rank_ms")}
+            except (ValueError, KeyError):
+                pass
+        return out5
 
     if extras_on and default_c3 and not a.no_scale_ref:
         scale_ref = guarded(measure_scale_ref)
@@ -1237,6 +1428,17 @@ def main():
                                         "source": "profiles/scale_ref.json (this workload on one rank, from a "
                                                   "driver-style N = 1 run of this file: key scale_ref)"}
                     out["efficiency_vs_scale_ref"] = out["value"] / (world * ref["value"])
+                    out["scale_ref"]["caveat"] = ("32 M particles spread over the WHOLE mesh on one rank: a rank of this "
+                                                  "run holds its 32 M in its own block of ne / %d elements" % world)
+                except (ValueError, KeyError):
+                    pass
+            v8 = os.path.join(ROOT, "profiles", "r05_c5_virtual8.json")
+            if os.path.exists(v8) and a.workload == "c5" and a.mesh == "1m" and a.scaling == "weak" and world == 8:
+                try:  # like for like: the same eight ranks as virtual ranks of ONE GPU (compute without the transfer)
+                    vj = json.load(open(v8))
+                    out["scale_ref_virtual_ranks_8"] = {"per_rank_value": vj["per_rank_value"], "per_rank_ms": vj["per_rank_ms"],
+                                                        "source": "profiles/r05_c5_virtual8.json"}
+                    out["efficiency_vs_virtual_ranks_8"] = out["value"] / (world * vj["per_rank_value"])
                 except (ValueError, KeyError):
                     pass
             out["watchdog_s"] = WATCHDOG.limit if WATCHDOG is not None and WATCHDOG.enabled else 0

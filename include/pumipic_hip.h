@@ -215,9 +215,10 @@ int pp_ps_rebuild_scatter(pp_ps* ps, int m_x, int m_xtgt, const int* new_element
  *      step), so large structures practically always take the full re-layout, as the reference does;
  * Rows stay prefix-compact in every mode (a shrinking row back-fills its holes from its own tail). */
 int pp_ps_set_shuffling(pp_ps* ps, int mode);
-/* how the rebuilds of this structure ended so far: kept layout / full re-layout (n_rows_moved: always 0,
- * kept for callers of the round-2 interface) */
-int pp_ps_rebuild_stats(const pp_ps* ps, long long* n_in_place, long long* n_full, long long* n_rows_moved);
+/* how the rebuilds of this structure ended so far: kept layout / full re-layout / full re-layouts whose first
+ * pass read the records of the re-layout before it instead of the member arrays (back-to-back rebuilds of a
+ * particle type wider than 64 B with no member access in between: performance_tests/ps_combo160.cpp:205-232) */
+int pp_ps_rebuild_stats(const pp_ps* ps, long long* n_in_place, long long* n_full, long long* n_from_records);
 /* getPIDs ps_for.hpp:65-85: offsets_dev[ne+1], pids_dev[nPtcls] */
 int pp_ps_get_pids(const pp_ps* ps, int* offsets_dev, int* pids_dev);
 /* printMetrics SellCSigma.h:465-524 */

@@ -508,7 +508,7 @@ class PS:
         check(lib().pp_ps_set_shuffling(self.p, int(v)))
 
     def rebuild_stats(self):
-        """(rebuilds that kept the layout, full re-layouts, rows that traded places)"""
+        """(rebuilds that kept the layout, full re-layouts, full re-layouts fed by the previous one's records)"""
         a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()
         check(lib().pp_ps_rebuild_stats(self.p, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value

@@ -256,6 +256,7 @@ struct pp_ps {
   // 0 = always the full re-layout (setShuffling(false)); 1 (default) = the reference's decision
   int shuffle_mode = 1;
   long long n_reshuffles = 0, n_full_rebuilds = 0;  // how the rebuilds of this structure ended
+  long long n_from_records = 0;  // full re-layouts whose first pass read the previous one's records (lazy_rec == 3)
   pp::DevBuf d_eslot0;  // first slot of every element's row in the CURRENT layout
   // a member whose content is logically all zero but has not been written yet (storage index, -1 =
   // none): x_tgt after a fused updatePtclPositions of the in-place rebuild.  Cleared without a pass
@@ -271,8 +272,12 @@ struct pp_ps {
   //   lazy_rec == 1: every travelling member is in the records, the SoA arrays are stale;
   //   lazy_rec == 2: the fused push consumed the records (pp_search.hip: RECIN) and wrote every member
   //                  but lazy_x to the SoA arrays -- only member lazy_x (the origin) is still in records.
+  //   lazy_rec == 3: any particle type whose record is wider than 64 B, after a rebuild without new particles
+  //                  and without the commit: every member is in the records (rec_nq quads each, slot order); the
+  //                  next rebuild moves records to records (round 5: the back-to-back rebuilds of ps_combo160).
   // Anything else that touches member data goes through ps_ready(), which runs the deferred pass.
   int lazy_rec = 0;
+  int rec_nq = 0;  // quads per record of the live records (lazy_rec == 3)
   int lazy_x = -1, lazy_xt = -1;  // commit members of the rebuild that left the records
   pp::DevBuf s_aos_live;
   // Position of a slot's record in s_aos_live.  rec_rm: ROW-MAJOR inside a chunk -- the record of (row r, column p)

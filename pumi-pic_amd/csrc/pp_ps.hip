@@ -1334,8 +1334,11 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   // zeros left pending by the previous in-place rebuild; records left by the previous full re-layout.
   // Exception: after the record-fed push only the ORIGIN (member lazy_x) is still in records, and a
   // rebuild that commits the same pair of members never reads it.
-  if (!(ps->lazy_rec == 2 && ps->zero_pending < 0 && (n_new == 0 || new_xt_zero) && commit_x >= 0 &&
-        commit_x == ps->lazy_x && commit_xt == ps->lazy_xt)) {
+  // Exception 2 (round 5): every member is in the previous re-layout's records (lazy_rec == 3) and this rebuild
+  // commits nothing: its first pass reads them there (k_move_pack_rec).
+  const bool from_rec = ps->lazy_rec == 3 && ps->zero_pending < 0 && commit_x < 0 && commit_xt < 0 && ps->rec_nq > 4;
+  if (!from_rec && !(ps->lazy_rec == 2 && ps->zero_pending < 0 && (n_new == 0 || new_xt_zero) && commit_x >= 0 &&
+                     commit_x == ps->lazy_x && commit_xt == ps->lazy_xt)) {
     int rc0 = pp::ps_ready(ps);
     if (rc0) return rc0;
   }
@@ -1514,7 +1517,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   nrows = L.nrows;
   const int* go = &tot->go;
   int NQ = 0;
-  bool lazy_zero = false, defer_unpack = false, use_rm = false;
+  bool lazy_zero = false, defer_unpack = false, use_rm = false, defer_wide = false;
   // today's per-element counts are not read by a re-layout that commits: its tail clears them for the next one
   constexpr bool lazy_slot_elem = true;  // (pp::slot_elem fills the table when something asks)
   // staging records row-major inside a chunk (pp_ps::rec_rm)
@@ -1586,6 +1589,11 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       // (lab build, PP_NO_LAZY_UNPACK=1: pass 2 runs right away -- the path every other particle type takes)
       static const bool no_defer = PP_LAB_ENV("PP_NO_LAZY_UNPACK") != nullptr;
       defer_unpack = lazy_zero && NQ == 4 && !no_defer && xgcm_shape(ps);
+      // Records wider than 64 B (ps_combo160's 160-B particle: 192-B records), no new particles, no commit: the
+      // second pass waits until somebody asks for a member -- a rebuild that follows reads the records
+      // (performance_tests/ps_combo160.cpp:205-232 rebuilds a hundred times without touching a member)
+      defer_wide = NQ > 4 && n_new == 0 && commit_x < 0 && commit_xt < 0 && !no_defer;
+      PP_REQUIRE(!from_rec || NQ == ps->rec_nq, "rebuild (internal): the live records have another width");
     }
     if (NQ > 0) {
       // (+ one spare column per chunk: the row-major record geometry, pp_rec_row0)
@@ -1597,12 +1605,15 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       wt, go, use_rm ? 1 : 0
 #define PP_STAGED(N)                                                                             \
   case N:                                                                                        \
-    if (use_rm)                                                                                  \
+    if (from_rec)                                                                                \
+      k_move_pack_rec<N><<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, rank, rs,      \
+                                                                    ps->s_aos_live.as<uint4>(), aos, go); \
+    else if (use_rm)                                                                             \
       k_move_pack_rm<N><<<pack_main + pack_hot, kBlock, 0, st>>>(pack_end, rank, rs_rm, aos, wt, go, \
                                                                  ps->C == 64 ? rm_wide : 0, hot_now, pack_hot); \
     else                                                                                         \
       k_move_pack<N><<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, rank, rs, aos, wt, go); \
-    if (!defer_unpack) k_move_unpack<N><<<new_grid, kBlock, 0, st>>>(PP_UNPACK_ARGS);            \
+    if (!defer_unpack && !defer_wide) k_move_unpack<N><<<new_grid, kBlock, 0, st>>>(PP_UNPACK_ARGS); \
     break;
       const RankToSlot rs{new_element, ps->s_eslot0.as<int>(), C_new};
       // the staging records row-major inside a chunk: the particles of a row, which carry consecutive ranks,
@@ -1616,7 +1627,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       // test/pseudoXGCm.cpp rebuilds without the fused commit and reads the SoA arrays right away: pass 1 358 ->
       // row-major, pass 2 reads the same records back): two records share a 128-B line, so runs are what keeps
       // the scattered stores whole lines
-      use_rm = want_rm && (defer_unpack || NQ <= 4);
+      use_rm = want_rm && (defer_unpack || NQ <= 4) && !from_rec;
       PP_REQUIRE(!hot_now.on || use_rm, "rebuild (internal): the over-full row's blocks need the row-major staged path");
       // (pp_ps::hot) the main blocks end where the columns of the over-full row begin, its own blocks follow
       const int pack_end = hot_now.on ? hot_now.start + 64 * hot_now.c1p : ps->capacity;
@@ -1711,6 +1722,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     // speculative re-layout tail did not run (k_spec_check); the in-place path does the work.  Rare at
     // scale (some row of 10^5 overflows its padding nearly every step), common for small structures.
     ps->swap_stride = swap_stride_before;
+    if (int rcm = pp::ps_ready(ps)) return rcm;  // (the in-place path moves between the member arrays)
     const int mode = ps->shuffle_mode;
     rc = scs_reshuffle(ps, new_element, n_new, new_elems, new_info, commit_x, commit_xt,
                        std::function<int(const int*)>());  // (the scatters ran behind the histogram above)
@@ -1727,6 +1739,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   }
   if (h.active == 0) {  // SCS_rebuild.h:168-182: no particle left -- resetMask, structure kept
     ps->swap_stride = swap_stride_before;
+    if (int rcm = pp::ps_ready(ps)) return rcm;
     // the fused commit still happens: the drivers call updatePtclPositions before the rebuild
     if (commit_x >= 0 && commit_xt >= 0 && ps->num_ptcls > 0) {
       rc = pp_update_positions(ps, commit_x, commit_xt);
@@ -1803,6 +1816,12 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
         ps->hot.start = h.last_chunk_start;
       }
     }
+  } else if (defer_wide && NQ > 4) {  // wide records, slot order: the particle data until a member is asked for
+    ps->s_aos.swap(ps->s_aos_live);
+    ps->lazy_rec = 3;
+    ps->rec_nq = NQ;
+    ps->rec_rm = false;
+    ps->lazy_x = ps->lazy_xt = -1;
   }
   ps->d_offsets.swap(ps->s_offsets2);
   ps->d_slice_to_chunk.swap(ps->s_s2c2);
@@ -1825,6 +1844,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   ps->elem_count_valid = true;
   ps->version = pp::next_version();
   ++ps->n_full_rebuilds;
+  if (from_rec) ++ps->n_from_records;
   ps->ntiles_max = ntiles_max;
   ps->C = C_new;
   ps->num_ptcls = h.active;
@@ -1861,6 +1881,9 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   if (n_new > 0) PP_REQUIRE(new_info != nullptr, "rebuild: new particles need new_info_dev");
   const int* go = &tot->go;
   int64_t new_stride = 0;
+  const bool from_rec = ps->lazy_rec == 3 && ps->rec_nq > 4 && nold > 0;  // (pp_ps_rebuild left the records alone)
+  bool defer_wide = false;
+  int nq_used = 0;
   // everything after the counts: swap sizing, the two move passes, the slot tables (all kernels
   // return at once when tot->go == 0)
   auto enqueue_tail = [&](int on_process) -> int {
@@ -1889,15 +1912,21 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       PP_HIP_CHECK(ps->s_aos.reserve((size_t)on_process * NQ * 16));
       uint4* aos = ps->s_aos.as<uint4>();
       const int* off2 = ps->s_offsets2.as<int>();
+      defer_wide = NQ > 4 && n_new == 0;  // (see scs_rebuild)
+      nq_used = NQ;
+      PP_REQUIRE(!from_rec || NQ == ps->rec_nq, "rebuild (internal): the live records have another width");
 #define PP_CSR_STAGED(N)                                                                         \
   case N:                                                                                        \
-    if (nold > 0)                                                                                \
+    if (nold > 0 && from_rec)                                                                    \
+      k_move_pack_rec<N><<<grid_for(nold), kBlock, 0, st>>>(                                     \
+          nold, rank, RankToSlot{new_element, off2, 1}, ps->s_aos_live.as<uint4>(), aos, go);    \
+    else if (nold > 0)                                                                           \
       k_move_pack<N><<<grid_for(nold), kBlock, 0, st>>>(                                         \
           nold, rank, RankToSlot{new_element, off2, 1}, aos, wt, go);                            \
     if (n_new > 0)                                                                               \
       k_move_pack<N><<<grid_for(n_new), kBlock, 0, st>>>(                                        \
           n_new, rank_new, RankToSlot{new_elems, off2, 1}, aos, wt_new, go);                     \
-    k_unpack_flat<N><<<grid_for(on_process), kBlock, 0, st>>>(on_process, aos, wt, go);          \
+    if (!defer_wide) k_unpack_flat<N><<<grid_for(on_process), kBlock, 0, st>>>(on_process, aos, wt, go); \
     break;
       switch (NQ) {
         PP_CSR_STAGED(1) PP_CSR_STAGED(2) PP_CSR_STAGED(3) PP_CSR_STAGED(4) PP_CSR_STAGED(6)
@@ -1905,6 +1934,7 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       }
 #undef PP_CSR_STAGED
     } else {
+      PP_REQUIRE(!from_rec, "rebuild (internal): live records but no staged path");
       if (nold > 0)
         k_move_csr<<<grid_for(nold), kBlock, 0, st>>>(nold, new_element, ps->s_rowstart.as<int>(), mv, go);
       if (n_new > 0) {
@@ -1959,6 +1989,15 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   ps->d_mask.swap(ps->s_mask2);
   ps->capacity = (int)ps->stride;
   ps->num_ptcls = on_process;
+  ps->lazy_rec = 0;
+  ++ps->n_full_rebuilds;
+  if (from_rec) ++ps->n_from_records;
+  if (defer_wide && on_process > 0) {  // the records of pass 1 are the particle data until a member is asked for
+    ps->s_aos.swap(ps->s_aos_live);
+    ps->lazy_rec = 3;
+    ps->rec_nq = nq_used;
+    ps->rec_rm = false;
+  }
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -1994,6 +2033,53 @@ bool lazy_push_ok(const pp_ps* ps, int m_x, int m_xtgt, int m_b, int m_phi) {
   return m_x == 0 && m_xtgt == 1 && m_b == 3 && m_phi == 4 && ps->lazy_x == 0 && ps->lazy_xt == 1;
 }
 int ps_materialize(pp_ps* ps) {
+  if (ps->lazy_rec == 3) {
+    // every member of every live particle is in the rec_nq-quad records of the last re-layout (slot order)
+    const int NQ = ps->rec_nq;
+    ps->lazy_rec = 0;
+    if (ps->capacity > 0 && ps->num_ptcls > 0) {
+      WordTable wt{};
+      for (int m = 0; m < ps->nmembers; ++m) {  // (the order of build_word_table)
+        const int b = ps->member_bytes[m];
+        for (int cc = 0; cc < ps->member_ncomp[m]; ++cc) {
+          char* dst = (char*)ps->data[m].p + ((size_t)cc * ps->stride) * b;
+          if (b == 8)
+            wt.dst8[wt.n8++] = dst;
+          else
+            wt.dst4[wt.n4++] = dst;
+        }
+      }
+      static int* const go_one3 = [] {
+        int* p1 = nullptr;
+        const int one = 1;
+        if (hipMalloc((void**)&p1, sizeof(int)) != hipSuccess ||
+            hipMemcpy(p1, &one, sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+          return (int*)nullptr;
+        return p1;
+      }();
+      PP_REQUIRE(go_one3 != nullptr, "ps_materialize: device allocation failed");
+      if (ps->kind == PP_SCS) {
+#define PP_MAT(N)                                                                                          \
+  case N:                                                                                                  \
+    k_move_unpack<N><<<grid_for((size_t)ps->ntiles_max * ps->C), kBlock, 0, pp::stream()>>>(               \
+        ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(),     \
+        ps->d_chunk_width.as<int>(), ps->d_mask.as<unsigned char>(), ps->s_aos_live.as<uint4>(), wt, go_one3, 0); \
+    break;
+        switch (NQ) { PP_MAT(6) PP_MAT(8) PP_MAT(10) PP_MAT(12) default: PP_REQUIRE(false, "ps_materialize: record width"); }
+#undef PP_MAT
+      } else {
+#define PP_MAT(N)                                                                                          \
+  case N:                                                                                                  \
+    k_unpack_flat<N><<<grid_for(ps->num_ptcls), kBlock, 0, pp::stream()>>>(ps->num_ptcls, ps->s_aos_live.as<uint4>(), \
+                                                                           wt, go_one3);                   \
+    break;
+        switch (NQ) { PP_MAT(6) PP_MAT(8) PP_MAT(10) PP_MAT(12) default: PP_REQUIRE(false, "ps_materialize: record width"); }
+#undef PP_MAT
+      }
+      PP_LAUNCH_CHECK();
+    }
+    return ps_zeros(ps);
+  }
   if (ps->lazy_rec) {
     // the deferred second pass of the last full re-layout: records -> SoA arrays, for every member that
     // is still only in the records (all that travelled / the origin only)
@@ -2254,11 +2340,11 @@ int pp_ps_set_shuffling(pp_ps* ps, int mode) {
   ps->shuffle_mode = mode;
   return PP_OK;
 }
-int pp_ps_rebuild_stats(const pp_ps* ps, long long* n_in_place, long long* n_full, long long* n_rows_moved) {
+int pp_ps_rebuild_stats(const pp_ps* ps, long long* n_in_place, long long* n_full, long long* n_from_records) {
   PP_REQUIRE(ps, "pp_ps_rebuild_stats: null ps");
   if (n_in_place) *n_in_place = ps->n_reshuffles;
   if (n_full) *n_full = ps->n_full_rebuilds;
-  if (n_rows_moved) *n_rows_moved = 0;  // (rows never trade places: the experimental elastic mode of round 2 is gone)
+  if (n_from_records) *n_from_records = ps->n_from_records;
   return PP_OK;
 }
 
@@ -2355,7 +2441,9 @@ int pp_ps_rebuild(pp_ps* ps, const int* new_element_dev, int n_new, const int* n
   pp::Range rg_("ps_rebuild");
   PP_REQUIRE(ps && (new_element_dev || ps->capacity == 0), "pp_ps_rebuild: null argument");
   PP_REQUIRE(n_new >= 0 && (n_new == 0 || new_elems_dev), "pp_ps_rebuild: bad new particles");
-  if (int rc = pp::ps_ready(ps)) return rc;
+  // (wide records left by the previous rebuild -- lazy_rec == 3 -- feed this one's first pass: nothing to materialise)
+  if (!(ps->lazy_rec == 3 && ps->zero_pending < 0))
+    if (int rc = pp::ps_ready(ps)) return rc;
   // storage order of members may be permuted by pp_ps_swap_members: normalise first
   for (int m = 0; m < ps->nmembers; ++m)
     if (ps->member_map[m] != m) {

@@ -281,6 +281,35 @@ __global__ void k_move_pack_rm(int capacity, const int* __restrict__ new_idx, Ra
     }
   }
 }
+// Pass 1 of a rebuild that FOLLOWS a rebuild whose second pass was deferred (pp_ps::lazy_rec == 3): the particles ARE
+// the 16*NQ-byte records of the previous re-layout, one per old slot in slot order -- nothing was asked of the member
+// arrays in between (performance_tests/ps_combo160.cpp:205-232: redistribute + rebuild, a hundred times in a row).
+// A wave takes 64 consecutive old slots: lane l computes the destination of slot l, then the NQ*64 quads of the
+// run are loaded as NQ fully coalesced instructions (1 KB each) and every quad goes to its record's new place --
+// NQ adjacent lanes store one whole record.  No staging in LDS: the destination travels by shuffle.
+// 16*NQ B read + 16*NQ B written per particle, against 2 x (16*NQ + the member bytes) for SoA -> records -> SoA.
+template <int NQ>
+__global__ void k_move_pack_rec(int capacity, const int* __restrict__ new_idx, RankToSlot rs,
+                                const uint4* __restrict__ src, uint4* __restrict__ aos,
+                                const int* __restrict__ go) {
+  if (go && !*go) return;
+  const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int l = threadIdx.x & 63;
+  const long long base = pid - l;  // first slot of the wave's run
+  const int rk = (pid < capacity) ? new_idx[pid] : -1;
+  int idx = -1;
+  if (rk >= 0) idx = rs.elem_slot0[rs.new_element[pid]] + rk * rs.step;
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int item = j * 64 + l, rec = item / NQ, part = item - rec * NQ;
+    const int d = __shfl(idx, rec);
+    if (d >= 0) {
+      const v4u q = __builtin_nontemporal_load((const v4u*)(src + (base + rec) * NQ + part));
+      __builtin_nontemporal_store(q, (v4u*)(aos + (long long)d * NQ + part));
+    }
+  }
+}
 template <int NQ>
 __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
                               const int* __restrict__ tiles, const int* __restrict__ chunk_start,

@@ -233,6 +233,13 @@ int pp_update_positions(pp_ps* ps, int m_x, int m_xtgt) {
 int pp_pseudo_push160(pp_ps* ps, const double* parent_elm_data_dev) {
   PP_REQUIRE(ps && parent_elm_data_dev, "pp_pseudo_push160: null argument");
   int rc;
+  // The pass writes every component of every member of every slot it iterates.  When the particles still sit in the
+  // records of the last rebuild (pp_ps::lazy_rec == 3) the pass that would copy them into the member arrays first is
+  // pointless: the records are simply given up.
+  if (ps->lazy_rec == 3 && ps->zero_pending < 0 && ps->nmembers == 3 && ps->member_bytes[0] == 8 &&
+      ps->member_ncomp[0] == 17 && ps->member_bytes[1] == 4 && ps->member_ncomp[1] == 4 && ps->member_bytes[2] == 8 &&
+      ps->member_ncomp[2] == 1 && ps->member_map[0] == 0 && ps->member_map[1] == 1 && ps->member_map[2] == 2)
+    ps->lazy_rec = 0;
   if ((rc = check_member(ps, 0, 8, 17, "pp_pseudo_push160 dbls"))) return rc;
   if ((rc = check_member(ps, 1, 4, 4, "pp_pseudo_push160 nums"))) return rc;
   if ((rc = check_member(ps, 2, 8, 1, "pp_pseudo_push160 lint"))) return rc;

@@ -621,3 +621,122 @@ def test_config5_share_two_virtual_ranks_full_size(pp, ppo, capi, world, per_ran
     assert np.array_equal(ppo.gyro_scatter(mo, po, fo), f)        # SUM over the ranks == the one structure's field
     for c in comms:
         c.destroy()
+
+
+@pytest.mark.skipif(not os.environ.get("PP_TEST_C5_FULL"), reason="opt-in (PP_TEST_C5_FULL=1): 256 M particles, minutes of host work")
+def test_config5_full_size_eight_virtual_ranks(pp, capi):
+    """BASELINE configs[4] at its FULL size on one GPU: the 998 400-tet mesh, 8 x 32 M = 256 M particles as the node's
+    eight element-block owners on a `local` communicator (~47 GB of device memory), three steps of what
+    `bench.py --workload c5 --virtual-ranks 8` times (pp_push_search, pp_migrate_ptcls_begin / pp_ps_migrate_end with
+    the commit and both gyroScatter maps, gyroSync).  Size-independent properties: the population is conserved BY
+    PARTICLE ID across the ranks (nobody lost, nobody duplicated; particles that leave the domain are the only ones
+    to go), every particle sits on the rank that owns its element and in the row of the element the walk gave it, its
+    position is the x_tgt the push wrote (x <- x_tgt, x_tgt <- 0) -- checked on a sample of a million -- a sample
+    passes an independent numpy barycentric test, and every rank holds the same synced scatter field, which carries
+    2 rings x 4 vertices x the mapped fraction of every particle."""
+    from pumipic_amd import dist as ppdist
+    s = pp.synth
+    world, per_rank = 8, 32_000_000
+    ws = []
+    for r in range(world):
+        w = bench.build_workload(pp, capi, "c5", per_rank, r, world, 0.5, mesh_size="1m")
+        for k in ("elem", "info", "ppe"):
+            w.pop(k, None)
+        ws.append(w)
+    ne = ws[0]["ne"]
+    assert ne == 998_400
+    mesh = ws[0]["mesh"]
+    owners = ppdist.element_block_owners(ne, world)
+    owners_d = capi.DevArray.from_host(owners)
+    safes = [capi.DevArray.from_host((owners == r).astype(np.uint8)) for r in range(world)]
+    comms = capi.Comm.local(world)
+    fwd, bkwd = capi.create_gyro_ring_mappings(mesh)
+    for r, w in enumerate(ws):  # particle ids unique across the ranks: k-th particle of rank r -> k + r * per_rank
+        ps = w["ps"]
+        tag = np.zeros((1, ps.info().stride), dtype=np.int32)
+        se, mk = ps.slot_info()
+        slots = np.flatnonzero(mk)
+        assert len(slots) == per_rank and np.all(owners[se[slots]] == r)
+        tag[0, slots] = ps.member(2)[0, slots] + r * per_rank
+        ps.set_member(2, tag)
+        del tag, se, mk, slots
+    total = world * per_rank
+    rng = np.random.default_rng(13)
+    sample = np.sort(rng.choice(total, size=1_000_000, replace=False))
+    moved = 0
+    want = None
+    for step in range(3):
+        fields = []
+        if step == 2:
+            want = {"elem": np.full(len(sample), -2, dtype=np.int64), "xt": np.zeros((3, len(sample)))}
+        for r, w in enumerate(ws):
+            ps = w["ps"]
+            cap = ps.capacity()
+            ids = capi.DevArray(cap + cap // 10, np.int32)
+            capi.push_search(mesh, ps, s.XGC_H, s.XGC_K, s.XGC_D, 0.5, ids, seeded=False, looplimit=200)
+            assert capi.push_search_counters() == (0, 0, 0)
+            if step == 2:  # what the exchange must deliver for the sampled ids
+                mk = ps.slot_info()[1].astype(bool)
+                pid = ps.member(2)[0, :cap]
+                pos = np.searchsorted(sample, pid[mk])
+                pos[pos >= len(sample)] = 0
+                hit = sample[pos] == pid[mk]
+                slots = np.flatnonzero(mk)[hit]
+                want["elem"][pos[hit]] = ids.to_host()[:cap][slots]
+                want["xt"][:, pos[hit]] = ps.member(1)[:, :cap][:, slots]
+                del mk, pid, pos, hit, slots
+            wf, wb = capi.DevArray(mesh.nverts, np.float64), capi.DevArray(mesh.nverts, np.float64)
+            capi.migrate_ptcls_begin(ps, ids, safes[r], owners_d, comms[r], commit=True,
+                                     scatter=(mesh, [fwd, bkwd], [wf, wb]))
+            fields.append((wf, wb, ids))
+        for r, w in enumerate(ws):
+            ns, nr = capi.migrate_end(w["ps"], comms[r])
+            moved += ns
+        packed = [capi.gyro_sync_pack(mesh.nverts, wf, wb) for wf, wb, _ in fields]
+        for r in range(world):
+            comms[r].allreduce_sum(packed[r])
+        alive = sum(w["ps"].nPtcls() for w in ws)
+        assert 0.999 * total <= alive <= total
+        g0 = packed[0].to_host()
+        for r in range(1, world):
+            assert np.array_equal(g0, packed[r].to_host())
+        f = g0[0::2]
+        assert np.array_equal(f, g0[1::2]) and np.isfinite(f).all() and f.min() >= 0
+        assert 0.8 * 32 * alive <= f.sum() <= 32 * alive
+    assert moved > 100_000  # particles really crossed the block boundaries
+    assert (want["elem"] != -2).all()  # every sampled id was seen before the last exchange
+    # ---- after the last step: identity of every particle, rank by rank
+    seen = np.zeros(total, dtype=bool)
+    got_elem = np.full(len(sample), -2, dtype=np.int64)
+    got_x = np.zeros((3, len(sample)))
+    n_alive = 0
+    for r, w in enumerate(ws):
+        ps = w["ps"]
+        cap = ps.capacity()
+        se, mk = ps.slot_info()
+        mk = mk.astype(bool)
+        pid = ps.member(2)[0, :cap][mk]
+        assert not seen[pid].any() and len(np.unique(pid)) == len(pid)  # nobody duplicated
+        seen[pid] = True
+        n_alive += len(pid)
+        assert np.all(owners[se[:cap][mk]] == r)  # ownership
+        x = ps.member(0)[:, :cap][:, mk]
+        assert not ps.member(1)[:, :cap][:, mk].any()  # x_tgt <- 0
+        pos = np.searchsorted(sample, pid)
+        pos[pos >= len(sample)] = 0
+        hit = sample[pos] == pid
+        got_elem[pos[hit]] = se[:cap][mk][hit]
+        got_x[:, pos[hit]] = x[:, hit]
+        samp = rng.choice(len(pid), size=50_000, replace=False)
+        lam = _tet_bcc(ws[0]["coords"], ws[0]["e2v"], se[:cap][mk][samp], x[:, samp].T)
+        assert lam.min() > -1e-9, lam.min()
+        del se, mk, pid, x, pos, hit
+    assert n_alive == sum(w["ps"].nPtcls() for w in ws)
+    kept = want["elem"] >= 0  # (-1: left the domain in the last step -> deleted)
+    assert np.array_equal(got_elem[kept], want["elem"][kept])      # everybody in the row of its new element
+    assert (got_elem[~kept] == -2).all()                            # the deleted ones are gone from every rank
+    assert np.array_equal(got_x[:, kept], want["xt"][:, kept])     # x <- x_tgt, across the exchange
+    lost = total - n_alive
+    print("configs[4] full size: %d particles on 8 virtual ranks, %d migrated in 3 steps, %d left the domain" % (n_alive, moved, lost))
+    for c in comms:
+        c.destroy()

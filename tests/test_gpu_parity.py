@@ -1357,6 +1357,89 @@ def test_ps_combo160_rounds_exact(ppo, capi, kind):
                                   np.bincount(sg[mg_.astype(bool)], minlength=ne))
 
 
+@pytest.mark.parametrize("kind", ["scs", "csr"])
+def test_consecutive_rebuilds_move_records_to_records(ppo, capi, kind):
+    """The reference's ps_combo160 rebuild loop (performance_tests/ps_combo160.cpp:205-232): rebuild after rebuild
+    with NO member access in between.  For the 160-byte particle the second pass of a re-layout is deferred and the
+    next rebuild's first pass reads the 192-byte records (k_move_pack_rec; pp_ps_rebuild_stats counts them).  The
+    destination of a particle is a function of its current ELEMENT and the round (what both sides can evaluate from
+    their own layout without touching a member), half of the elements keep their particles, one element's particles
+    are deleted; after seven rounds every member of every particle equals the oracle's by particle id, and a
+    pseudo-push + further rounds + new particles leave the records / member arrays consistent."""
+    ne, npt = 2500, 60000
+    rng = np.random.default_rng(9)
+    elems = np.sort(rng.integers(0, ne, size=npt).astype(np.int32))
+    ppe = np.bincount(elems, minlength=ne).astype(np.int32)
+    ids = np.arange(npt, dtype=np.int64)
+    info = [np.stack([ids + 0.001 * c for c in range(17)]), np.stack([4 * ids + c for c in range(4)]).astype(np.int32),
+            ids[None, :].copy()]
+    if kind == "scs":
+        po = ppo.PS.scs(ppo.PERF160, ne, ppe, C_max=64, sigma=ne, V=1024, particle_elements=elems, particle_info=info)
+        pg = capi.PS.scs(capi.PERF160, ne, ppe, C_=64, sigma=ne, V=1024, particle_elements=elems, particle_info=info)
+    else:
+        po = ppo.PS.csr(ppo.PERF160, ne, ppe, particle_elements=elems, particle_info=info)
+        pg = capi.PS.csr(capi.PERF160, ne, ppe, particle_elements=elems, particle_info=info)
+    if kind == "scs":
+        common.set_shuffling(po, pg, on=False)  # (every rebuild the full re-layout: the path under test)
+
+    def rule(ps_, rnd):
+        se, mk = ps_.slot_info()
+        mk = mk.astype(bool)
+        se = se.astype(np.int64)
+        dest = np.where((se + rnd) % 2 == 0, se, (se * 7 + 13 * rnd + 1) % ne)
+        dest = np.where(se == (17 * rnd + 3) % ne, -1, dest)  # one element's particles are deleted per round
+        return np.where(mk, dest, -1).astype(np.int32)
+
+    def compare():
+        capo, capg = po.capacity(), pg.capacity()
+        so, mko = po.slot_info()
+        sg, mkg = pg.slot_info()
+        ido, idg = po.member(2)[0, :capo], pg.member(2)[0, :capg]
+        io, eo = common.by_id(ido, mko, so[:capo])
+        ig, eg = common.by_id(idg, mkg, sg[:capg])
+        assert np.array_equal(io, ig) and np.array_equal(eo, eg)
+        for m in range(3):
+            _, a = common.by_id(ido, mko, po.member(m)[:, :capo])
+            _, b = common.by_id(idg, mkg, pg.member(m)[:, :capg])
+            assert np.array_equal(a, b), m
+
+    before = pg.rebuild_stats()
+    for rnd in range(7):
+        po.rebuild(rule(po, rnd))
+        pg.rebuild(rule(pg, rnd))  # (slot_info reads the layout only: no member is touched)
+        assert po.nPtcls() == pg.nPtcls()
+    after = pg.rebuild_stats()
+    assert after[1] - before[1] == 7 and after[2] - before[2] == 6  # the first read the member arrays, six read records
+    compare()  # (materialises the GPU's member arrays from the records)
+    assert 0 < pg.nPtcls() < npt
+    # ... and on: a round from the member arrays again, one from records, new particles (their round runs both passes)
+    po.rebuild(rule(po, 7))
+    pg.rebuild(rule(pg, 7))
+    po.rebuild(rule(po, 8))
+    pg.rebuild(rule(pg, 8))
+    n_new = 500
+    new_ids = np.arange(npt, npt + n_new, dtype=np.int64)
+    new_elems = rng.integers(0, ne, size=n_new).astype(np.int32)
+    new_info = [np.stack([new_ids + 0.001 * c for c in range(17)]),
+                np.stack([4 * new_ids + c for c in range(4)]).astype(np.int32), new_ids[None, :].copy()]
+    po.rebuild(rule(po, 9), new_elems, new_info)
+    pg.rebuild(rule(pg, 9), new_elems, new_info)
+    po.rebuild(rule(po, 10))
+    pg.rebuild(rule(pg, 10))
+    compare()
+    # a pseudo-push on live records gives them up (it overwrites every member); the rounds after it agree again
+    po.rebuild(rule(po, 11))
+    pg.rebuild(rule(pg, 11))
+    parent = np.sqrt(np.arange(ne, dtype=np.float64)) * np.arange(ne)
+    ppo.pseudo_push160(po, parent)
+    capi.pseudo_push160(pg, capi.DevArray.from_host(parent))
+    for ps_, cap in ((po, po.capacity()), (pg, pg.capacity())):
+        se, mk = ps_.slot_info()
+        mk = mk.astype(bool)
+        assert np.array_equal(ps_.member(2)[0, :cap][mk], np.flatnonzero(mk))  # lint(p) = p
+        assert np.array_equal(ps_.member(1)[0, :cap][mk], 4 * np.flatnonzero(mk))
+
+
 @pytest.mark.parametrize("strat", [2, 3, 4])
 def test_redistribute_by_strategy_matches_oracle(ppo, synth, capi, strat):
     """pp_redistribute_particles_dist: the re-draw of distribute_particles' strategies (Distribute.cpp:76-253) --
