@@ -213,7 +213,35 @@ __global__ void k_elem_rings_scs(const int* __restrict__ ntiles_dev, int C, int 
       nclip += ringUp >= gnr;
     }
   }
-  flush();
+  // LDS reduction, then one HBM atomic per (element, ring) and BLOCK: the four waves of a block are consecutive tile
+  // groups -- mostly of one chunk, i.e. the same 64 rows = the same 64 elements (as in the rebuild's histogram).  The
+  // waves whose last run lies in the same chunk hand their ring sums to the first of them through LDS, which adds
+  // them up in wave order (a fixed order: the block's contribution is reproducible) and issues the atomics: up to
+  // four times fewer of the FP64 atomics whose rate bounds this kernel (1.2 M at ~77 ps for 10 M particles: 92 us).
+  __shared__ int s_last[4];
+  __shared__ double s_part[4][64][kMaxRings];
+  const int wv = threadIdx.x >> 6;
+  if (C == 64 && blockDim.x == 256) {  // (lane == row)
+    if ((threadIdx.x & 63) == 0) s_last[wv] = cur;
+#pragma unroll
+    for (int i = 0; i < kMaxRings; ++i)
+      if (i < gnr) s_part[wv][r][i] = acc[i];
+    __syncthreads();
+    bool lead = cur >= 0;
+    for (int w = 0; w < wv; ++w) lead = lead && s_last[w] != cur;
+    if (lead && e >= 0 && e < ne) {
+#pragma unroll
+      for (int i = 0; i < kMaxRings; ++i) {
+        if (i >= gnr) continue;
+        double t = acc[i];
+        for (int w = wv + 1; w < 4; ++w)
+          if (s_last[w] == cur) t += s_part[w][r][i];
+        if (t != 0.0) atomicAdd(&elem_ring[(size_t)e * gnr + i], t);
+      }
+    }
+  } else {
+    flush();
+  }
   if (nclip) atomicAdd(clipped, nclip);
 }
 // any structure: one thread per slot (CSR, or SCS without row tiles)

@@ -2001,24 +2001,63 @@ struct MtFace {  // running state of search_findExitFace_intersect_3d over the f
   double quality;
   double t_ip;  // ray parameter of the intersection point the reference would hold now (xpoint = orig + dir * t)
   bool upd;     // ... if any face of this element wrote it
+  unsigned maybe;  // faces with dproj > -tol: the only ones the no-hit fallback looks at (bit = local face index)
 };
-// one face of the element staged at `mine`: ray_intersects_triangle (tpp:152-178) on the stored side named by
-// code byte `c`, then the reference's bookkeeping (tpp:333-348): last success wins; without a success so far
-// the face with dproj > -tol that is closest in (u, v) -- candidates overwrite the intersection point
+// One face of the element staged at `mine`: ray_intersects_triangle (tpp:152-178) on the stored side named by code
+// byte `c`, then the reference's bookkeeping (tpp:333-348): the last success wins; without ANY success the face with
+// dproj > -tol that is closest in (u, v) -- candidates overwrite the intersection point.
+// Round 5: only what the result depends on is evaluated.  A face is a success only if dproj >= tol and a candidate
+// only if dproj > -tol, so a back face costs its normal and one dot product -- not u, v, t and the IEEE divide; and
+// `closeness` (three min, two max, six abs / subtractions) is consumed only when NO face of the element succeeds
+// (then lastExit == -1 for every face, and the candidates are what the loop below makes them) -- mt_face_fallback,
+// which nearly never runs.  Every value that IS computed comes from the same operations on the same operands as
+// before: parents, exit faces and intersection points stay bit-identical (tests: test_c2_intersection_mode_full_size,
+// test_search_mesh_intersection_mode_packed_walk, tools/fuzz_search.py).
+struct MtGeom {
+  V3 f0, edge1, edge2;
+  double dproj;
+};
+__device__ __forceinline__ MtGeom mt_geom(const double2* mine, int sw, unsigned c, V3 dir) {
+  MtGeom g;
+  g.f0 = lds_rec_vertex(mine, sw, c & 3);
+  const V3 fa = lds_rec_vertex(mine, sw, (c >> 2) & 3), fb = lds_rec_vertex(mine, sw, (c >> 4) & 3);
+  g.edge1 = sub(fa, g.f0);
+  g.edge2 = sub(fb, g.f0);
+  const V3 faceNorm = cross(g.edge2, g.edge1);
+  g.dproj = dot(dir, faceNorm);
+  return g;
+}
+__device__ __forceinline__ void mt_uvt(const MtGeom& g, V3 orig, V3 dir, double& u, double& v, double& t) {
+  const V3 pvec = cross(dir, g.edge2);
+  const double invdet = 1.0 / g.dproj;
+  const V3 tvec = sub(orig, g.f0);
+  u = invdet * dot(tvec, pvec);
+  const V3 qvec = cross(tvec, g.edge1);
+  v = invdet * dot(dir, qvec);
+  t = invdet * dot(g.edge2, qvec);
+}
 __device__ __forceinline__ void mt_face(const double2* mine, int sw, unsigned c, int fi, V3 orig, V3 dir, double tol,
                                         MtFace& F) {
-  const V3 f0 = lds_rec_vertex(mine, sw, c & 3), fa = lds_rec_vertex(mine, sw, (c >> 2) & 3),
-           fb = lds_rec_vertex(mine, sw, (c >> 4) & 3);
-  const V3 edge1 = sub(fa, f0), edge2 = sub(fb, f0);
-  const V3 faceNorm = cross(edge2, edge1);
-  const V3 pvec = cross(dir, edge2);
-  const double dproj = dot(dir, faceNorm);
-  const double invdet = 1.0 / dproj;
-  const V3 tvec = sub(orig, f0);
-  const double u = invdet * dot(tvec, pvec);
-  const V3 qvec = cross(tvec, edge1);
-  const double v = invdet * dot(dir, qvec);
-  const double t = invdet * dot(edge2, qvec);
+  const MtGeom g = mt_geom(mine, sw, c, dir);
+  F.maybe |= (g.dproj > -tol) ? (1u << fi) : 0u;
+  if (g.dproj >= tol) {
+    double u, v, t;
+    mt_uvt(g, orig, dir, u, v, t);
+    const bool success = (t >= -tol) && (u >= -tol) && (v >= -tol) && (u + v <= 1.0 + 2 * tol);
+    // (the reference stores xpoint = orig + dir * t at both places; the point is a function of t alone, so t is
+    // kept and the point formed once per element, from the last t written -- the same value)
+    F.lastExit = success ? fi : F.lastExit;
+    F.t_ip = success ? t : F.t_ip;
+    F.upd = F.upd || success;
+  }
+}
+// no face of the element succeeded: the candidates of tpp:340-347 in face order (lastExit == -1 throughout)
+__device__ __forceinline__ void mt_face_fallback(const double2* mine, int sw, unsigned c, int fi, V3 orig, V3 dir,
+                                                 double tol, MtFace& F) {
+  const MtGeom g = mt_geom(mine, sw, c, dir);
+  if (!(g.dproj > -tol)) return;
+  double u, v, t;
+  mt_uvt(g, orig, dir, u, v, t);
   // Kokkos::min(a, b) = (b < a) ? b : a.  In each of the three pairs below the operands are NaN together or not
   // at all (|x| and |1 - x|; |u + v| and |1 - u - v|: inf - inf on one side is inf - inf on the other), and for
   // non-NaN operands the selection equals fmin's -- one v_min_f64 instead of compare + two selects.  The two
@@ -2028,16 +2067,11 @@ __device__ __forceinline__ void mt_face(const double2* mine, int sw, unsigned c,
   const double m3 = __builtin_fmin(fabs(u + v), fabs(1 - u - v));
   const double mm = PPG_KMAX(m1, m2);
   const double closeness = PPG_KMAX(mm, m3);
-  const bool success = (dproj >= tol) && (t >= -tol) && (u >= -tol) && (v >= -tol) && (u + v <= 1.0 + 2 * tol);
-  // (the reference stores xpoint = orig + dir * t at both places; the point is a function of t alone, so t is
-  // kept and the point formed once per element, from the last t written -- the same value)
-  F.lastExit = success ? fi : F.lastExit;
-  F.t_ip = success ? t : F.t_ip;
-  const bool cand = dproj > -tol && (F.quality < 0 || closeness < F.quality) && F.lastExit == -1;
+  const bool cand = F.quality < 0 || closeness < F.quality;
   F.quality = cand ? closeness : F.quality;
   F.bestFace = cand ? fi : F.bestFace;
   F.t_ip = cand ? t : F.t_ip;
-  F.upd = F.upd || success || cand;
+  F.upd = F.upd || cand;
 }
 __global__ void __launch_bounds__(256, 2)
     k_search_mt3(int capacity, int per_lane, int start_batch, const unsigned char* __restrict__ mask,
@@ -2138,7 +2172,7 @@ __global__ void __launch_bounds__(256, 2)
       const unsigned code = (unsigned)(__double_as_longlong(tail.y) >> 32);
       bool fin = false;
       int xf = -1;  // local index of the exposed face the ray leaves through
-      MtFace F{-1, -1, -1.0, 0.0, false};
+      MtFace F{-1, -1, -1.0, 0.0, false, 0u};
       if (start_round) {  // (wave-uniform)
         chk = false;
         V3 M[4];
@@ -2161,6 +2195,11 @@ __global__ void __launch_bounds__(256, 2)
           const int fi = j + (j >= entry ? 1 : 0);
           mt_face(mine, sw, code >> (8 * fi), fi, orig, dir, tol, F);
         }
+      }
+      if (!fin && F.lastExit == -1 && F.maybe != 0u) {  // no hit: the closest candidate among the faces just tested
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi)
+          if (F.maybe & (1u << fi)) mt_face_fallback(mine, sw, code >> (8 * fi), fi, orig, dir, tol, F);
       }
       if (!fin) {
         if (F.upd) ip = add(orig, mul(dir, F.t_ip));
