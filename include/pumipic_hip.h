@@ -186,8 +186,12 @@ int pp_ps_member_from_host(pp_ps* ps, int m, const void* in_host);
  * stream (pp_stream), so any later library call and pp_free / hipFree are safe; a caller that
  * overwrites or frees those buffers from ANOTHER stream must first wait for the library stream
  * (pp_sync, or an event recorded on pp_stream).  The same holds for the migration entry points.
- * THREADS: structures are independent (each owns its scratch, its pinned landing zone and its
- * stamps); calls on ONE structure must not overlap, and all calls share one stream. */
+ * THREADS: for pp_ps_rebuild* and the migration entry points structures are independent (each owns its
+ * scratch, its pinned landing zone and its stamps): two host threads may rebuild DIFFERENT structures, calls on
+ * ONE structure must not overlap, and all calls share one stream.  The searches (pp_push_search, pp_search_mesh*)
+ * and pp_gyro_scatter* keep process-wide scratch (the deferred-walk queue, alternating counter sets, the ring
+ * accumulator): call them from one host thread at a time -- the reference's model, one host thread per rank
+ * (SURVEY 8(b) "Threading"). */
 int pp_ps_rebuild(pp_ps* ps, const int* new_element_dev, int n_new, const int* new_elems_dev,
                   const void* const* new_info_dev);
 /* updatePtclPositions (test/pseudoXGCm.cpp:102-114: x <- x_tgt, x_tgt <- 0) fused into the

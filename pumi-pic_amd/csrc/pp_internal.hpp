@@ -135,6 +135,8 @@ struct DevBuf {
 
 constexpr int kBlock = 256;
 constexpr int kTileP = 8;  // particles per row handled by one thread of the row-tiled kernels
+static_assert(32 % kTileP == 0, "a tile group of the histogram (32 columns, the stay mask) is a whole number of tiles: "
+                                "the over-full row's own blocks start on a group boundary (pp_ps::hot)");
 inline unsigned grid_for(size_t n, int block = kBlock) {
   return (unsigned)((n + (size_t)block - 1) / (size_t)block);
 }
@@ -388,6 +390,9 @@ int ps_materialize(pp_ps* ps);
 int ps_zeros(pp_ps* ps);  // only the pending zeros of pp_ps::zero_pending
 const int* slot_elem(const pp_ps* ps);  // d_slot_elem, filled first when the last re-layout left it out (pp_ps.hip)
 const int* group_chunk(const pp_ps* ps);  // d_group_chunk (SCS, chunk height 64), else nullptr
+// pp_ps.hip: exclusive scan of n ints on the library stream (three launches beyond 16 K entries); *total_dev (may be
+// null) receives the sum
+int scan_excl_i32(DevBuf& scratch, int n, const int* in, int* out, int* total_dev);
 const int* search_not_found_dev();  // pp_search.hip: device address of the last pp_push_search's not_found counter
 inline int ps_ready(const pp_ps* ps) {
   return (ps && (ps->zero_pending >= 0 || ps->lazy_rec)) ? ps_materialize(const_cast<pp_ps*>(ps)) : PP_OK;

@@ -132,13 +132,21 @@ __global__ void k_unpack_records(int n, const unsigned* __restrict__ rec, const 
   for (int w = 0; w < t.nwords; ++w) *(unsigned*)(t.dst[w] + (long long)i * t.scale[w]) = r[2 + w];
 }
 
-// ---- routing without same-address atomics.  A per-particle atomicAdd on one of `nranks` counters
-// serialises in the L2 (~10 ns each: 3 ms for 300 k leaving particles).  Instead block b owns a fixed
-// contiguous range of slots; it counts its leavers per destination in LDS (k_route_count), one thread
-// per destination turns the per-block counts into per-block start offsets (k_route_scan), and the
-// pack pass, run with the SAME block -> slot mapping, ranks its leavers with LDS atomics only.
-constexpr int kRouteBlocks = 1024;
-constexpr int kMaxRanks = 256;
+// ---- routing.  A per-particle atomicAdd on one of `nranks` counters serialises in the L2 (~10 ns each: 3 ms for
+// 300 k leaving particles), so positions in the rank-major send buffer come from counts and a scan:
+//   k_route_mark    thread = slot, block = 1024 consecutive slots: where every slot goes as ONE BYTE (0xff = stays),
+//                   the block's leavers per destination counted in LDS -> block_cnt[dest][block]
+//   scan            ONE exclusive scan over the rank-major [dest][block] table: entry (p, b) is the first record of
+//                   block b's leavers for rank p in the send buffer (relative to rank 0's first)
+//   k_route_totals  leavers per destination (what the count exchange needs on the host)
+//   k_route_pack    the same block -> slot mapping, reads the byte per slot (not mask / element / safe / owner
+//                   again); a block without leavers -- nearly all of them: two particles in a thousand leave a
+//                   rank of configs[4] per step -- returns after 1 KB of loads; leavers take their place by LDS atomics.
+// Round 5: this replaced 1024 persistent blocks sweeping the slots twice with a one-THREAD-per-destination scan of
+// their counts in between -- 180 + 145 + 435 us per rank and step at configs[4] (a quarter of the step) for 62 000
+// leavers among 40 M slots.
+constexpr int kRouteSlots = 1024;
+constexpr int kMaxRanks = 255;  // (0xff marks a slot that stays)
 struct RankStarts {
   int v[64];  // first record of every destination rank in the send buffer (nranks <= 64 by value)
 };
@@ -158,45 +166,53 @@ __device__ __forceinline__ int route_dest(int pid, int capacity, const unsigned 
   const int p = rr.new_process ? rr.new_process[pid] : (rr.safe[e] ? rank : rr.owners[e]);
   return (p != rank && p >= 0 && p < nranks) ? p : -1;
 }
-__global__ void k_route_count(int capacity, int per_block, const unsigned char* __restrict__ mask,
-                              const int* __restrict__ new_element, const RouteRule new_process,
-                              int rank, int nranks, int* __restrict__ block_cnt) {
-  __shared__ int h[kMaxRanks];
+__global__ void k_route_mark(int capacity, const unsigned char* __restrict__ mask, const int* __restrict__ new_element,
+                             const RouteRule rr, int rank, int nranks, int nblocks,
+                             unsigned char* __restrict__ dest8, int* __restrict__ block_cnt) {
+  __shared__ int h[kMaxRanks + 1];
   for (int i = threadIdx.x; i < nranks; i += blockDim.x) h[i] = 0;
   __syncthreads();
-  const int lo = blockIdx.x * per_block, hi = min(capacity, lo + per_block);
-  for (int pid = lo + threadIdx.x; pid < hi; pid += blockDim.x) {
-    const int p = route_dest(pid, capacity, mask, new_element, new_process, rank, nranks);
-    if (p >= 0) atomicAdd(&h[p], 1);
+  const long long lo = (long long)blockIdx.x * kRouteSlots;
+#pragma unroll
+  for (int k = 0; k < kRouteSlots / 256; ++k) {
+    const long long pid = lo + k * 256 + threadIdx.x;
+    if (pid < capacity) {
+      const int p = route_dest((int)pid, capacity, mask, new_element, rr, rank, nranks);
+      dest8[pid] = p < 0 ? (unsigned char)0xff : (unsigned char)p;
+      if (p >= 0) atomicAdd(&h[p], 1);
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < nranks; i += blockDim.x) block_cnt[blockIdx.x * nranks + i] = h[i];
+  for (int i = threadIdx.x; i < nranks; i += blockDim.x) block_cnt[(size_t)i * nblocks + blockIdx.x] = h[i];
 }
-// thread p: exclusive scan over the blocks of destination p (in place), total to counts[p]
-__global__ void k_route_scan(int nblocks, int nranks, int* __restrict__ block_cnt, int* __restrict__ counts) {
+__global__ void k_route_totals(int nranks, int nblocks, const int* __restrict__ S, const int* __restrict__ total,
+                               int* __restrict__ counts) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= nranks) return;
-  int run = 0;
-  for (int b = 0; b < nblocks; ++b) {
-    const int c = block_cnt[b * nranks + p];
-    block_cnt[b * nranks + p] = run;
-    run += c;
-  }
-  counts[p] = run;
+  counts[p] = (p + 1 < nranks ? S[(size_t)(p + 1) * nblocks] : *total) - S[(size_t)p * nblocks];
 }
-__global__ void k_route_pack(int capacity, int per_block, const unsigned char* __restrict__ mask,
-                             int* new_element, const RouteRule new_process, int rank, int nranks,
-                             const int* __restrict__ block_start, RankStarts rs,
+__global__ void k_route_pack(int capacity, const unsigned char* __restrict__ dest8, int* new_element, int nranks,
+                             int nblocks, const int* __restrict__ S, RankStarts rs,
                              const int* __restrict__ rank_start_dev, const long long* __restrict__ gids,
                              unsigned* __restrict__ out, RecTable t) {
-  __shared__ int cur[kMaxRanks];
+  __shared__ int cur[kMaxRanks + 1];
+  const long long lo = (long long)blockIdx.x * kRouteSlots;
+  unsigned char d[kRouteSlots / 256];
+  bool mine = false;
+#pragma unroll
+  for (int k = 0; k < kRouteSlots / 256; ++k) {
+    const long long pid = lo + k * 256 + threadIdx.x;
+    d[k] = pid < capacity ? dest8[pid] : (unsigned char)0xff;
+    mine = mine || d[k] != 0xff;
+  }
+  if (!__syncthreads_or(mine)) return;
   for (int i = threadIdx.x; i < nranks; i += blockDim.x)
-    cur[i] = block_start[blockIdx.x * nranks + i] + (rank_start_dev ? rank_start_dev[i] : rs.v[i]);
+    cur[i] = (rank_start_dev ? rank_start_dev[i] : rs.v[i]) + S[(size_t)i * nblocks + blockIdx.x] - S[(size_t)i * nblocks];
   __syncthreads();
-  const int lo = blockIdx.x * per_block, hi = min(capacity, lo + per_block);
-  for (int pid = lo + threadIdx.x; pid < hi; pid += blockDim.x) {
-    const int p = route_dest(pid, capacity, mask, new_element, new_process, rank, nranks);
-    if (p < 0) continue;
+#pragma unroll
+  for (int k = 0; k < kRouteSlots / 256; ++k) {
+    if (d[k] == 0xff) continue;
+    const int pid = (int)(lo + k * 256 + threadIdx.x), p = d[k];
     const int e = new_element[pid];
     const int idx = atomicAdd(&cur[p], 1);  // LDS
     unsigned* r = out + (size_t)idx * t.rec_words;
@@ -334,27 +350,32 @@ int pp_ps_migrate_pack_records_commit(const pp_ps* ps, int m_x, int m_xtgt, int*
   return pack_records(ps, m_x, m_xtgt, new_element_dev, new_process_dev, comm_rank, nranks,
                       send_counts_host, send_records_dev);
 }
-// per-block leaver counts of the current routing (scratch(4): [kRouteBlocks][nranks]) and their scan;
-// totals per destination to counts_dev (nranks ints)
+// the routing of the current arrays: destination byte per slot (scratch(6)), per-block leaver counts
+// (scratch(4): [nranks][nblocks]) and their scan (scratch(5)); totals per destination to counts_dev (nranks ints)
 static int route_count(const pp_ps* ps, const int* new_element_dev, const RouteRule new_process_dev,
-                       int comm_rank, int nranks, int* counts_dev, int* per_block_out) {
-  PP_REQUIRE(nranks <= kMaxRanks, "migration: more than 256 ranks are not supported by the routing kernels");
+                       int comm_rank, int nranks, int* counts_dev, int* nblocks_out) {
+  PP_REQUIRE(nranks <= kMaxRanks, "migration: more than 255 ranks are not supported by the routing kernels");
   hipStream_t st = pp::stream();
-  pp::DevBuf& bc = scratch(4);
-  PP_HIP_CHECK(bc.reserve(sizeof(int) * (size_t)kRouteBlocks * nranks));
-  const int cap = std::max(ps->capacity, 1);
-  const int per_block = ((cap + kRouteBlocks - 1) / kRouteBlocks + 255) / 256 * 256;
-  *per_block_out = per_block;
-  k_route_count<<<kRouteBlocks, kBlock, 0, st>>>(ps->num_ptcls > 0 ? ps->capacity : 0, per_block,
-                                                 ps->d_mask.as<unsigned char>(), new_element_dev,
-                                                 new_process_dev, comm_rank, nranks, bc.as<int>());
-  k_route_scan<<<grid_for(nranks), kBlock, 0, st>>>(kRouteBlocks, nranks, bc.as<int>(), counts_dev);
+  const int cap = ps->num_ptcls > 0 ? ps->capacity : 0;
+  const int nblocks = std::max(1, (cap + kRouteSlots - 1) / kRouteSlots);
+  *nblocks_out = nblocks;
+  const size_t n = (size_t)nblocks * nranks;
+  PP_REQUIRE(n < ((size_t)1 << 31), "migration: routing table too large");
+  pp::DevBuf &bc = scratch(4), &S = scratch(5), &d8 = scratch(6);
+  PP_HIP_CHECK(bc.reserve(sizeof(int) * n));
+  PP_HIP_CHECK(S.reserve(sizeof(int) * (n + 1)));
+  PP_HIP_CHECK(d8.reserve((size_t)std::max(cap, 1)));
+  k_route_mark<<<nblocks, kBlock, 0, st>>>(cap, ps->d_mask.as<unsigned char>(), new_element_dev, new_process_dev,
+                                           comm_rank, nranks, nblocks, d8.as<unsigned char>(), bc.as<int>());
+  int rc = pp::scan_excl_i32(scratch(7), (int)n, bc.as<int>(), S.as<int>(), S.as<int>() + n);
+  if (rc) return rc;
+  k_route_totals<<<grid_for(nranks), kBlock, 0, st>>>(nranks, nblocks, S.as<int>(), S.as<int>() + n, counts_dev);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
 // pack pass of the same routing (route_count must have run on the same arrays)
 static int route_pack(const pp_ps* ps, int commit_x, int commit_xt, int* new_element_dev,
-                      const RouteRule new_process_dev, int comm_rank, int nranks, int per_block,
+                      const RouteRule /*new_process_dev*/, int /*comm_rank*/, int nranks, int nblocks,
                       const int* rank_start_host, void* send_records_dev) {
   RecTable t{};
   int rc = build_rec_table(ps, t, commit_x, commit_xt);
@@ -371,11 +392,10 @@ static int route_pack(const pp_ps* ps, int commit_x, int commit_xt, int* new_ele
     PP_HIP_CHECK(hipStreamSynchronize(st));
     rs_dev = cur.as<int>();
   }
-  k_route_pack<<<kRouteBlocks, kBlock, 0, st>>>(ps->num_ptcls > 0 ? ps->capacity : 0, per_block,
-                                                ps->d_mask.as<unsigned char>(), new_element_dev,
-                                                new_process_dev, comm_rank, nranks, scratch(4).as<int>(), rs,
-                                                rs_dev, ps->has_gids ? ps->d_gids.as<long long>() : nullptr,
-                                                (unsigned*)send_records_dev, t);
+  k_route_pack<<<nblocks, kBlock, 0, st>>>(ps->num_ptcls > 0 ? ps->capacity : 0, scratch(6).as<unsigned char>(),
+                                           new_element_dev, nranks, nblocks, scratch(5).as<int>(), rs, rs_dev,
+                                           ps->has_gids ? ps->d_gids.as<long long>() : nullptr,
+                                           (unsigned*)send_records_dev, t);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

@@ -2005,6 +2005,9 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
 }  // namespace
 
 namespace pp {
+int scan_excl_i32(DevBuf& scratch, int n, const int* in, int* out, int* total_dev) {
+  return scan_excl(scratch, n, in, out, total_dev, pp::stream());
+}
 const int* slot_elem(const pp_ps* ps) {
   if (!ps->slot_elem_valid) {
     if (ps->kind == PP_SCS && ps->capacity > 0 && ps->ntiles_max > 0)

@@ -1844,6 +1844,10 @@ __global__ void __launch_bounds__(256, OCC)
         }
         const bool live = act && s.m;
         int elem = live ? e : -1;
+        // (the one fetch above relies on rows being left-packed -- a live column implies a live first column, which
+        // every rebuild guarantees; should a row ever hold a live slot behind a dead first one, its lane loads the
+        // record itself here instead of computing on an unloaded cache: round-4 advisor)
+        if (live && cache.id != e) fetch(cache, recs, e);
         V3 dest{0, 0, 0};
         const bool need = column_math<DIM, NT>(A, s, act, live, pid, ct, cache, elem, dest);
         enqueue(need, pid, elem, dest, wq, qn, lt_mask);
