@@ -134,18 +134,18 @@ __global__ void k_unpack_records(int n, const unsigned* __restrict__ rec, const 
 
 // ---- routing.  A per-particle atomicAdd on one of `nranks` counters serialises in the L2 (~10 ns each: 3 ms for
 // 300 k leaving particles), so positions in the rank-major send buffer come from counts and a scan:
-//   k_route_mark    thread = slot, block = 1024 consecutive slots: where every slot goes as ONE BYTE (0xff = stays),
+//   k_route_mark    block = 4096 consecutive slots (a thread: 4 x 4 of them): where every slot goes as ONE BYTE (0xff = stays),
 //                   the block's leavers per destination counted in LDS -> block_cnt[dest][block]
 //   scan            ONE exclusive scan over the rank-major [dest][block] table: entry (p, b) is the first record of
 //                   block b's leavers for rank p in the send buffer (relative to rank 0's first)
 //   k_route_totals  leavers per destination (what the count exchange needs on the host)
 //   k_route_pack    the same block -> slot mapping, reads the byte per slot (not mask / element / safe / owner
 //                   again); a block without leavers -- nearly all of them: two particles in a thousand leave a
-//                   rank of configs[4] per step -- returns after 1 KB of loads; leavers take their place by LDS atomics.
+//                   rank of configs[4] per step -- returns after 4 KB of loads; leavers take their place by LDS atomics.
 // Round 5: this replaced 1024 persistent blocks sweeping the slots twice with a one-THREAD-per-destination scan of
 // their counts in between -- 180 + 145 + 435 us per rank and step at configs[4] (a quarter of the step) for 62 000
 // leavers among 40 M slots.
-constexpr int kRouteSlots = 1024;
+constexpr int kRouteSlots = 4096;  // slots per block: 4 groups of 4 consecutive slots per thread
 constexpr int kMaxRanks = 255;  // (0xff marks a slot that stays)
 struct RankStarts {
   int v[64];  // first record of every destination rank in the send buffer (nranks <= 64 by value)
@@ -166,21 +166,47 @@ __device__ __forceinline__ int route_dest(int pid, int capacity, const unsigned 
   const int p = rr.new_process ? rr.new_process[pid] : (rr.safe[e] ? rank : rr.owners[e]);
   return (p != rank && p >= 0 && p < nranks) ? p : -1;
 }
+// (thread = 4 consecutive slots: mask, new element and destination byte move as one 4-/16-/4-byte access each)
 __global__ void k_route_mark(int capacity, const unsigned char* __restrict__ mask, const int* __restrict__ new_element,
                              const RouteRule rr, int rank, int nranks, int nblocks,
                              unsigned char* __restrict__ dest8, int* __restrict__ block_cnt) {
   __shared__ int h[kMaxRanks + 1];
   for (int i = threadIdx.x; i < nranks; i += blockDim.x) h[i] = 0;
   __syncthreads();
-  const long long lo = (long long)blockIdx.x * kRouteSlots;
+  const bool aligned = ((size_t)new_element & 15) == 0 && ((size_t)mask & 3) == 0 && ((size_t)dest8 & 3) == 0 &&
+                       !rr.new_process;
 #pragma unroll
-  for (int k = 0; k < kRouteSlots / 256; ++k) {
-    const long long pid = lo + k * 256 + threadIdx.x;
-    if (pid < capacity) {
-      const int p = route_dest((int)pid, capacity, mask, new_element, rr, rank, nranks);
-      dest8[pid] = p < 0 ? (unsigned char)0xff : (unsigned char)p;
+  for (int grp = 0; grp < kRouteSlots / 1024; ++grp) {
+  const long long p0 = (long long)blockIdx.x * kRouteSlots + grp * 1024 + 4 * threadIdx.x;
+  const bool vec = aligned && p0 + 3 < capacity;
+  if (vec) {
+    const uchar4 m4 = *(const uchar4*)(mask + p0);
+    const int4 e4 = *(const int4*)(new_element + p0);
+    const unsigned char m[4] = {m4.x, m4.y, m4.z, m4.w};
+    const int e[4] = {e4.x, e4.y, e4.z, e4.w};
+    unsigned char d[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int p = -1;
+      if (m[k] && e[k] >= 0) {
+        const int q = rr.safe[e[k]] ? rank : rr.owners[e[k]];
+        p = (q != rank && q >= 0 && q < nranks) ? q : -1;
+      }
+      d[k] = p < 0 ? (unsigned char)0xff : (unsigned char)p;
       if (p >= 0) atomicAdd(&h[p], 1);
     }
+    *(uchar4*)(dest8 + p0) = make_uchar4(d[0], d[1], d[2], d[3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long long pid = p0 + k;
+      if (pid < capacity) {
+        const int p = route_dest((int)pid, capacity, mask, new_element, rr, rank, nranks);
+        dest8[pid] = p < 0 ? (unsigned char)0xff : (unsigned char)p;
+        if (p >= 0) atomicAdd(&h[p], 1);
+      }
+    }
+  }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < nranks; i += blockDim.x) block_cnt[(size_t)i * nblocks + blockIdx.x] = h[i];
@@ -196,23 +222,37 @@ __global__ void k_route_pack(int capacity, const unsigned char* __restrict__ des
                              const int* __restrict__ rank_start_dev, const long long* __restrict__ gids,
                              unsigned* __restrict__ out, RecTable t) {
   __shared__ int cur[kMaxRanks + 1];
-  const long long lo = (long long)blockIdx.x * kRouteSlots;
-  unsigned char d[kRouteSlots / 256];
-  bool mine = false;
+  constexpr int NG = kRouteSlots / 1024;
+  const long long lo = (long long)blockIdx.x * kRouteSlots + 4 * threadIdx.x;  // the mapping of k_route_mark
+  unsigned char d[4 * NG];
+  unsigned all = 0xffu;
 #pragma unroll
-  for (int k = 0; k < kRouteSlots / 256; ++k) {
-    const long long pid = lo + k * 256 + threadIdx.x;
-    d[k] = pid < capacity ? dest8[pid] : (unsigned char)0xff;
-    mine = mine || d[k] != 0xff;
+  for (int grp = 0; grp < NG; ++grp) {
+    const long long p0 = lo + grp * 1024;
+    unsigned char* dg = d + 4 * grp;
+    dg[0] = dg[1] = dg[2] = dg[3] = 0xff;
+    if (p0 + 3 < capacity && ((size_t)dest8 & 3) == 0) {
+      const uchar4 d4 = *(const uchar4*)(dest8 + p0);
+      dg[0] = d4.x;
+      dg[1] = d4.y;
+      dg[2] = d4.z;
+      dg[3] = d4.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (p0 + k < capacity) dg[k] = dest8[p0 + k];
+    }
+    all &= dg[0] & dg[1] & dg[2] & dg[3];
   }
+  const bool mine = all != 0xffu;
   if (!__syncthreads_or(mine)) return;
   for (int i = threadIdx.x; i < nranks; i += blockDim.x)
     cur[i] = (rank_start_dev ? rank_start_dev[i] : rs.v[i]) + S[(size_t)i * nblocks + blockIdx.x] - S[(size_t)i * nblocks];
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < kRouteSlots / 256; ++k) {
+  for (int k = 0; k < 4 * NG; ++k) {
     if (d[k] == 0xff) continue;
-    const int pid = (int)(lo + k * 256 + threadIdx.x), p = d[k];
+    const int pid = (int)(lo + (k >> 2) * 1024 + (k & 3)), p = d[k];
     const int e = new_element[pid];
     const int idx = atomicAdd(&cur[p], 1);  // LDS
     unsigned* r = out + (size_t)idx * t.rec_words;

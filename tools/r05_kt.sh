@@ -7,6 +7,7 @@ name=$1; shift
 cd /tmp; export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$name -o p -- python3 "$@" > $O/kt_$name.log 2>&1
 f=$(find $O/kt_$name -name "*kernel_stats.csv" | head -1); cp "$f" $O/kernel_stats_$name.csv
+if [ -n "$MARKER" ]; then t=$(find $O/kt_$name -name "*kernel_trace.csv" | head -1); python3 $R/tools/kernel_seq.py "$t" "$MARKER" > $O/seq_$name.txt 2>&1; fi
 rm -rf $O/kt_$name
 echo "== $name"; tail -1 $O/kt_$name.log | cut -c1-400
 python3 - <<PY
