@@ -324,6 +324,57 @@ __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
   const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
   const int start = chunk_start[c] + r, pend = min(p0 + TP, chunk_width[c]);
   const long long rbase = pp_rec_row0(chunk_start[c], c, r, chunk_width[c], C);  // row-major records (pp_ps::rec_rm)
+  auto put = [&](int slot, const unsigned* w) {
+#pragma unroll
+    for (int i = 0; i < NQ * 2; ++i)
+      if (i < t.n8)
+        __builtin_nontemporal_store(((unsigned long long)w[2 * i + 1] << 32) | w[2 * i],
+                                    (unsigned long long*)(t.dst8[i] + (long long)slot * 8));
+#pragma unroll
+    for (int j = 0; j < (NQ * 4 < kMax4 ? NQ * 4 : kMax4); ++j)
+      if (j < t.n4) __builtin_nontemporal_store(w[NQ * 4 - 1 - j], (unsigned*)(t.dst4[j] + (long long)slot * 4));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (i < t.nz8) __builtin_nontemporal_store(0ull, (unsigned long long*)(t.z8[i] + (long long)slot * 8));
+      if (i < t.nz4) __builtin_nontemporal_store(0u, (unsigned*)(t.z4[i] + (long long)slot * 4));
+    }
+  };
+  if (NQ <= 4 && rec_rm) {
+    // Row-major records of at most 64 B: a row's records of a tile are contiguous (columns (2j, 2j + 1) share a
+    // 128-B line).  Read one column at a time (four loads, nine stores, the next four loads), the second half of
+    // a line is asked for long after the first -- with 32 KB of lines in flight per wave the L2 has dropped it by
+    // then: the PMC counters read 1 114 MB fetched for 640 MB of records (profiles/traffic_driver.json; 662 MB
+    // now).  KC columns' records are loaded back to back, then stored.
+    // (same-box A/B of the drop-in driver, 3 x 100 steps: 1.244 against 1.252 ms with one column at a time, 1.24
+    // with four -- the pass is not bound by these bytes; the traffic is what went down)
+    constexpr int KC = 2;
+    for (int p = p0; p < pend; p += KC) {
+      bool m[KC];
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < KC; ++k) {
+        m[k] = (p + k < pend) && new_mask[start + (p + k) * C] != 0;
+        any = any || m[k];
+      }
+      if (!any) continue;
+      const uint4* sp = aos + (rbase + p) * NQ;
+      unsigned w[KC][NQ * 4];
+#pragma unroll
+      for (int k = 0; k < KC; ++k)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const uint4 v = m[k] ? sp[k * NQ + q] : make_uint4(0, 0, 0, 0);
+          w[k][4 * q] = v.x;
+          w[k][4 * q + 1] = v.y;
+          w[k][4 * q + 2] = v.z;
+          w[k][4 * q + 3] = v.w;
+        }
+#pragma unroll
+      for (int k = 0; k < KC; ++k)
+        if (m[k]) put(start + (p + k) * C, w[k]);
+    }
+    return;
+  }
   for (int p = p0; p < pend; ++p) {
     const int slot = start + p * C;
     if (!new_mask[slot]) continue;
@@ -339,19 +390,7 @@ __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
       w[4 * q + 2] = v.z;
       w[4 * q + 3] = v.w;
     }
-#pragma unroll
-    for (int i = 0; i < NQ * 2; ++i)
-      if (i < t.n8)
-        __builtin_nontemporal_store(((unsigned long long)w[2 * i + 1] << 32) | w[2 * i],
-                                    (unsigned long long*)(t.dst8[i] + (long long)slot * 8));
-#pragma unroll
-    for (int j = 0; j < (NQ * 4 < kMax4 ? NQ * 4 : kMax4); ++j)
-      if (j < t.n4) __builtin_nontemporal_store(w[NQ * 4 - 1 - j], (unsigned*)(t.dst4[j] + (long long)slot * 4));
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (i < t.nz8) __builtin_nontemporal_store(0ull, (unsigned long long*)(t.z8[i] + (long long)slot * 8));
-      if (i < t.nz4) __builtin_nontemporal_store(0u, (unsigned*)(t.z4[i] + (long long)slot * 4));
-    }
+    put(slot, w);
   }
 }
 // CSR staged move (same two passes as SCS): slot assignment by the element cursor, pack through
