@@ -798,12 +798,19 @@ def also_driver_pseudoxgcm(pp, capi, a, w_main, st_main):
     dt = _time_steps(capi, st, 6, 20)
     out["fused_2dc3_ms_per_step"] = dt * 1e3
     out["driver_over_fused"] = out["ms_per_step"] / (dt * 1e3)
-    # what the UNFUSED loop must move per slot through user lambdas on the SoA arrays (algorithmic, 2-D):
+    # what the UNFUSED loop must move per slot through user lambdas on the member arrays (algorithmic, 2-D):
     # push 8+1+4(class via element) read, 20 written; search 16+1+4 read, 4 written; updatePtclPositions 24 read, 48
-    # written; setUnsafeProcs 4+1 read, 8 written; rebuild 60+4 read, 60+1 written (in two passes through 64-B
-    # records: +128); tagParentElements 1+4
+    # written; setUnsafeProcs 4+1 read, 8 written; rebuild 60+4 read, 60+1 written (it takes two passes through 64-B
+    # records: + 128 B that are not counted here); tagParentElements 1+4
     out["unfused_bytes_per_particle"] = 33 + 25 + 72 + 13 + 125 + 5
     out["roofline_frac_on_unfused_bytes"] = out["unfused_bytes_per_particle"] * out["particles"] / (out["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    tf = os.path.join(ROOT, "profiles", "traffic_driver.json")
+    if os.path.exists(tf):
+        try:  # HBM bytes of one step of this very command from the PMC counters (tools/r05_driver_pmc.sh)
+            out["traffic_bytes_per_step"] = json.load(open(tf))["traffic_bytes_per_step"]
+            out["traffic_provenance"] = "profiles/traffic_driver.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        except (ValueError, KeyError):
+            pass
     out["workload"] = ("drivers/pseudoXGCm <100352-tri annulus> %d 12 %d %g 0: whole-loop wall clock / iterations "
                        "(Kokkos::Timer semantics: no fence per operation); `record_time_ms_per_step` is the RecordTime "
                        "table of a second run with PP_TIMER_FENCE=1 (device time per operation, one extra host wait each)"
