@@ -439,15 +439,31 @@ __device__ __forceinline__ void gyro_rings_body(int v, int nverts, int gnr, cons
 }
 // second stage, 16 lanes per target vertex (g = 16 * vertex + lane; groups of 16 do not straddle waves): the
 // lanes fetch 16 list entries at once, then every lane adds them up in list order = the sequential sum
+// (exact: every term is an integer count divided by a power of two -- the constant-radius scatter with gppr = 2^k --
+// so the sum does not depend on its order: each of the 16 lanes adds up its own entries and a four-step butterfly
+// joins them, instead of sixteen shuffles per batch of sixteen entries; bit-identical to the sequential sum)
 __device__ __forceinline__ void gyro_gather_body(int g, int nverts, int gppr, const int* __restrict__ off,
                                                  const int* __restrict__ src, const double* __restrict__ ring_accum,
-                                                 double* __restrict__ scatter_w, double* __restrict__ scatter_w2) {
+                                                 double* __restrict__ scatter_w, double* __restrict__ scatter_w2,
+                                                 bool exact = false) {
   const int t = g >> 4, sub = g & 15, lane0 = (threadIdx.x & 63) & ~15;
   const bool in = t < nverts;
   const int b = in ? off[t] : 0, e = in ? off[t + 1] : 0;
   int len = e - b;
   for (int o = 16; o < 64; o <<= 1) len = max(len, __shfl_xor(len, o));  // wave-uniform trip count
   double w = 0;
+  if (exact) {  // (wave-uniform)
+    for (int base = 0; base < len; base += 16) {
+      const int j = b + base + sub;
+      w += j < e ? ring_accum[src[j]] / gppr : 0.0;
+    }
+    for (int o = 8; o > 0; o >>= 1) w += __shfl_xor(w, o);
+    if (in && sub == 0) {
+      scatter_w[t] = w;
+      if (scatter_w2) scatter_w2[t] = w;
+    }
+    return;
+  }
   for (int base = 0; base < len; base += 16) {
     const int j = b + base + sub;
     const double val = j < e ? ring_accum[src[j]] / gppr : 0.0;

@@ -489,7 +489,7 @@ __global__ void __launch_bounds__(1024)
                    const int* __restrict__ wide_tail_start = nullptr) {
   if (blockIdx.x > 0) {  // gyroScatter's second stage riding along (pp::GyroRide; its first stage rode k_make_keys)
     pp::gyro_gather_body((blockIdx.x - 1) * 1024 + threadIdx.x, ride.nverts, ride.gppr, ride.off, ride.src, ride.ring,
-                         ride.out, ride.out2);
+                         ride.out, ride.out2, (ride.gppr & (ride.gppr - 1)) == 0);  // (the ride is the count-based scatter)
     return;
   }
   if (fix_keys) wide_fix_tail(ne, npartial, wide_hist, fix_keys, fix_vals, tot, wide_tail_start);

@@ -348,9 +348,10 @@ __global__ void k_inv_sort(int nverts, const int* __restrict__ off, int* __restr
 // then every lane adds them up in list order, so the sum is the sequential one
 __global__ void k_scatter_gathered(int nverts, int gppr, const int* __restrict__ off,
                                    const int* __restrict__ src, const double* __restrict__ ring_accum,
-                                   double* __restrict__ scatter_w, double* __restrict__ scatter_w2 = nullptr) {
+                                   double* __restrict__ scatter_w, double* __restrict__ scatter_w2 = nullptr,
+                                   bool exact = false) {
   pp::gyro_gather_body(blockIdx.x * blockDim.x + threadIdx.x, nverts, gppr, off, src, ring_accum, scatter_w,
-                       scatter_w2);  // (pp_internal.hpp: shared with the rebuild's layout kernel, pp::GyroRide)
+                       scatter_w2, exact);  // (pp_internal.hpp: shared with the rebuild's layout kernel, pp::GyroRide)
 }
 __global__ void k_sync_pack(int nverts, const double* __restrict__ f, const double* __restrict__ b,
                             double* __restrict__ out) {
@@ -492,7 +493,8 @@ int gyro_scatter_counts(const pp_mesh* mesh, const int* cnt_dev, int nmaps, cons
         if (first_same) twin = out_dev[k + 1];
       }
       k_scatter_gathered<<<grid_for((size_t)nverts * 16), kBlock, 0, st>>>(
-          nverts, gppr, inv->off.as<int>(), inv->src.as<int>(), g_ring->as<double>(), out_dev[k], twin);
+          nverts, gppr, inv->off.as<int>(), inv->src.as<int>(), g_ring->as<double>(), out_dev[k], twin,
+          (gppr & (gppr - 1)) == 0);  // (counts / 2^k: exact in any order)
     } else {
       PP_HIP_CHECK(hipMemsetAsync(out_dev[k], 0, sizeof(double) * (size_t)nverts, st));
       k_scatter_mapped<<<grid_for((size_t)nverts * gnr * gppr), kBlock, 0, st>>>(
@@ -643,7 +645,7 @@ int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, do
         PP_HIP_CHECK(s_field->reserve(sizeof(double) * (size_t)std::max(nverts, 1)));
         k_scatter_gathered<<<grid_for((size_t)nverts * 16), kBlock, 0, st>>>(
             nverts, gppr, inv->off.as<int>(), inv->src.as<int>(), s_ring->as<double>(), scatter_w_dev,
-            s_field->as<double>() == scatter_w_dev ? nullptr : s_field->as<double>());
+            s_field->as<double>() == scatter_w_dev ? nullptr : s_field->as<double>(), (gppr & (gppr - 1)) == 0);
         f_inv = inv->uid;
         f_map = v2v_dev;
         f_gppr = gppr;
