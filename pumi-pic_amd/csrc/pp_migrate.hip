@@ -259,8 +259,17 @@ __global__ void k_route_pack(int capacity, const unsigned char* __restrict__ des
     const long long g = gids ? gids[e] : (long long)e;
     r[0] = (unsigned)(g & 0xffffffffll);
     r[1] = (unsigned)((unsigned long long)g >> 32);
-    for (int w = 0; w < t.nwords; ++w)
-      r[2 + w] = t.src[w] ? *(const unsigned*)(t.src[w] + (long long)pid * t.scale[w]) : 0u;
+    // (eight member words in flight at a time: one load -> one store at a time is a chain of ~20 memory round trips
+    // per leaver, the compiler cannot reorder them across the stores to `out`)
+    for (int w0 = 0; w0 < t.nwords; w0 += 8) {
+      unsigned v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        v[k] = (w0 + k < t.nwords && t.src[w0 + k]) ? *(const unsigned*)(t.src[w0 + k] + (long long)pid * t.scale[w0 + k]) : 0u;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (w0 + k < t.nwords) r[2 + w0 + k] = v[k];
+    }
     new_element[pid] = -1;  // removeSentParticles (SCS_migrate.h:189-196)
   }
 }
