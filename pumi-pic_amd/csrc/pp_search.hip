@@ -1174,14 +1174,27 @@ __global__ void __launch_bounds__(256, OCC)
     }
   }
   if (!valid) return;
-  PState cur = load(start + p0 * C, rb + p0 * rs);
-  for (int p = p0; p < pend; ++p) {
+  // The states of TWO columns are loaded back to back, the next pair before the second column's (dependent) walk.
+  // Record-fed, row-major records: the records of columns (2j, 2j + 1) of a row are one 128-B line, and the 2-D push
+  // reads 16 B of each; asked for one column at a time -- a walk apart -- the line has left the L2 by the second
+  // request: the PMC counters read 1.32 GB fetched per step for 10 M particles (profiles/traffic_2dc3.json, round 4),
+  // every line twice.  (p0 is a multiple of the tile width and a row starts on a line: the pairs are the lines.)
+  PState sa = load(start + p0 * C, rb + p0 * rs), sb{};
+  if (p0 + 1 < pend) sb = load(start + (p0 + 1) * C, rb + (p0 + 1) * rs);
+  for (int p = p0; p < pend; p += 2) {
     const int pid = start + p * C;
-    const PState s = cur;
-    if (p + 1 < pend)  // prefetch the next particle of this row before the dependent walk
-      cur = load(pid + C, rb + (p + 1) * rs);
-    rows_particle<DIM>(s, pid, e, ct, cache, recs, nelems, xt, stride, pphi, h, k, d, tol,
+    rows_particle<DIM>(sa, pid, e, ct, cache, recs, nelems, xt, stride, pphi, h, k, d, tol,
                        unmoved_sq, elem_ids, seeded, looplimit, cnt, id_out, b_out, RECIN ? rin.zero_z : 0);
+    PState na{}, nb{};
+    if (p + 2 < pend) {
+      na = load(pid + 2 * C, rb + (p + 2) * rs);
+      if (p + 3 < pend) nb = load(pid + 3 * C, rb + (p + 3) * rs);
+    }
+    if (p + 1 < pend)
+      rows_particle<DIM>(sb, pid + C, e, ct, cache, recs, nelems, xt, stride, pphi, h, k, d, tol,
+                         unmoved_sq, elem_ids, seeded, looplimit, cnt, id_out, b_out, RECIN ? rin.zero_z : 0);
+    sa = na;
+    sb = nb;
   }
 }
 
