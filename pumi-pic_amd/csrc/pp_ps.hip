@@ -1912,7 +1912,8 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       PP_HIP_CHECK(ps->s_aos.reserve((size_t)on_process * NQ * 16));
       uint4* aos = ps->s_aos.as<uint4>();
       const int* off2 = ps->s_offsets2.as<int>();
-      defer_wide = NQ > 4 && n_new == 0;  // (see scs_rebuild)
+      static const bool no_defer = PP_LAB_ENV("PP_NO_LAZY_UNPACK") != nullptr;
+      defer_wide = NQ > 4 && n_new == 0 && !no_defer;  // (see scs_rebuild)
       nq_used = NQ;
       PP_REQUIRE(!from_rec || NQ == ps->rec_nq, "rebuild (internal): the live records have another width");
 #define PP_CSR_STAGED(N)                                                                         \

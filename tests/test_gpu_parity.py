@@ -1409,7 +1409,10 @@ def test_consecutive_rebuilds_move_records_to_records(ppo, capi, kind):
         pg.rebuild(rule(pg, rnd))  # (slot_info reads the layout only: no member is touched)
         assert po.nPtcls() == pg.nPtcls()
     after = pg.rebuild_stats()
-    assert after[1] - before[1] == 7 and after[2] - before[2] == 6  # the first read the member arrays, six read records
+    # the first read the member arrays, six read records (laboratory build with PP_NO_LAZY_UNPACK=1: pass 2 runs at
+    # once, nothing is ever fed by records)
+    fed = 0 if os.environ.get("PP_NO_LAZY_UNPACK") and "lab" in os.environ.get("PUMIPIC_HIP_LIB", "") else 6
+    assert after[1] - before[1] == 7 and after[2] - before[2] == fed
     compare()  # (materialises the GPU's member arrays from the records)
     assert 0 < pg.nPtcls() < npt
     # ... and on: a round from the member arrays again, one from records, new particles (their round runs both passes)
