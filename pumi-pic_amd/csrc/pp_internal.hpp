@@ -439,9 +439,10 @@ __device__ __forceinline__ void gyro_rings_body(int v, int nverts, int gnr, cons
 }
 // second stage, 16 lanes per target vertex (g = 16 * vertex + lane; groups of 16 do not straddle waves): the
 // lanes fetch 16 list entries at once, then every lane adds them up in list order = the sequential sum
-// (exact: every term is an integer count divided by a power of two -- the constant-radius scatter with gppr = 2^k --
-// so the sum does not depend on its order: each of the 16 lanes adds up its own entries and a four-step butterfly
-// joins them, instead of sixteen shuffles per batch of sixteen entries; bit-identical to the sequential sum)
+// (exact = the caller does not need the list order of the sum: every term is an integer count divided by a power of
+// two -- the constant-radius scatter with gppr = 2^k: the sum is exact, bit-identical to the sequential one -- or the
+// terms themselves come from unordered atomics -- the per-particle-radius scatter.  Each of the 16 lanes adds up its
+// own entries and a four-step butterfly joins them, instead of sixteen shuffles per batch of sixteen entries.)
 __device__ __forceinline__ void gyro_gather_body(int g, int nverts, int gppr, const int* __restrict__ off,
                                                  const int* __restrict__ src, const double* __restrict__ ring_accum,
                                                  double* __restrict__ scatter_w, double* __restrict__ scatter_w2,

@@ -200,17 +200,22 @@ __global__ void k_elem_rings_scs(const int* __restrict__ ntiles_dev, int C, int 
       e = r2e[c * C + r];
     }
     const int pend = min(p0 + TP, chunk_width[c]);
+#pragma unroll 4
     for (int p = p0; p < pend; ++p) {
       const int pid = start + p * C;
-      if (!mask[pid]) continue;
-      const double rad = radius[pid], w = weight ? weight[pid] : 1.0;
+      // (mask, radius and weight are asked for together: a masked-off slot's radius is read and dropped)
+      const unsigned char mk = mask[pid];
+      const double rad = radius[pid], w0 = weight ? weight[pid] : 1.0;
+      const double w = mk ? w0 : 0.0;
       int ringDown = 0;
       for (int i = 2; i <= gnr; i++) ringDown += (rad >= ringWidth * i);  // gyroScatter.hpp:186-188
       const int ringUp = ringDown + 1;
+      if (mk) {
 #pragma unroll
-      for (int i = 0; i < kMaxRings; ++i)  // static indices keep the accumulators in registers
-        if (i == ringDown || (i == ringUp && ringUp < gnr)) acc[i] += w;
-      nclip += ringUp >= gnr;
+        for (int i = 0; i < kMaxRings; ++i)  // static indices keep the accumulators in registers
+          if (i == ringDown || (i == ringUp && ringUp < gnr)) acc[i] += w;
+        nclip += ringUp >= gnr;
+      }
     }
   }
   // LDS reduction, then one HBM atomic per (element, ring) and BLOCK: the four waves of a block are consecutive tile
@@ -696,9 +701,10 @@ int pp_gyro_scatter_radius(const pp_mesh* mesh, const pp_ps* ps, const double* r
   k_rings_from_elem_rings<<<grid_for((size_t)nverts * gnr), kBlock, 0, st>>>(
       nverts, gnr, mesh->d_vert2elems_off.as<int>(), mesh->d_vert2elems.as<int>(), s_er->as<double>(),
       g_ring->as<double>());
-  if (inv)
+  if (inv)  // (any summation order: the ring sums of the first stage are sums of atomics -- their own order is not fixed)
     k_scatter_gathered<<<grid_for((size_t)nverts * 16), kBlock, 0, st>>>(nverts, gppr, inv->off.as<int>(),
-                                                           inv->src.as<int>(), g_ring->as<double>(), scatter_w_dev);
+                                                           inv->src.as<int>(), g_ring->as<double>(), scatter_w_dev,
+                                                           nullptr, true);
   else
     k_scatter_mapped<<<grid_for((size_t)nverts * gnr * gppr), kBlock, 0, st>>>(
         nverts, gnr, gppr, nvpe, g_ring->as<double>(), v2v_dev, scatter_w_dev);
