@@ -350,6 +350,8 @@ __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
     constexpr int KC = 2;
     for (int p = p0; p < pend; p += KC) {
       bool m[KC];
+      const uint4* sp = aos + (rbase + p) * NQ;
+      unsigned w[KC][NQ * 4];
       bool any = false;
 #pragma unroll
       for (int k = 0; k < KC; ++k) {
@@ -357,8 +359,6 @@ __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
         any = any || m[k];
       }
       if (!any) continue;
-      const uint4* sp = aos + (rbase + p) * NQ;
-      unsigned w[KC][NQ * 4];
 #pragma unroll
       for (int k = 0; k < KC; ++k)
 #pragma unroll
