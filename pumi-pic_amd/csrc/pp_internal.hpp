@@ -193,13 +193,21 @@ namespace pp {
 struct GyroRide;
 }
 // First record of row r of chunk c when the staging records are row-major inside a chunk (pp_ps::rec_rm).  The row
-// pitch is the chunk width rounded up to EVEN and every chunk gets one spare column (C records), so that every row
-// starts on a 128-byte line and the records of columns (2j, 2j+1) of a row are one line: the record-fed push
-// fetches them together.  The record buffer holds capacity + C * nchunks records.
+// pitch is the chunk width rounded up to a multiple of FOUR and every chunk gets three spare columns (3 C records), so
+// that every row starts on a 128-byte line and a line holds whole records of one row only: the 64-B records of columns
+// (2j, 2j+1), the 32-B records of the pseudoXGCm type (round 5) of columns (4j .. 4j+3) -- the record-fed push fetches
+// them together.  The record buffer holds capacity + 3 C * nchunks records.
+constexpr int kRecSpareCols = 3;
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-inline int pp_rec_row0(int chunk_start, int c, int r, int w, int C) { return chunk_start + C * c + r * (w + (w & 1)); }
+inline int pp_rec_pitch(int w) { return (w + 3) & ~3; }
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int pp_rec_row0(int chunk_start, int c, int r, int w, int C) {
+  return chunk_start + kRecSpareCols * C * c + r * pp_rec_pitch(w);
+}
 namespace pp {
 // (see pp_ps::hot) columns [c1p, w) of row `row` of chunk `chunk`, whose first slot is `start`, hold particles of
 // that row only
@@ -282,6 +290,8 @@ struct pp_ps {
   int rec_nq = 0;  // quads per record of the live records (lazy_rec == 3)
   int lazy_x = -1, lazy_xt = -1;  // commit members of the rebuild that left the records
   pp::DevBuf s_aos_live;
+  // the 4-byte member that travels BESIDE the 32-B records of the pseudoXGCm type (WordTable::side_*), record order
+  pp::DevBuf s_side, s_side_live;
   // Position of a slot's record in s_aos_live.  rec_rm: ROW-MAJOR inside a chunk -- the record of (row r, column p)
   // of chunk c is number pp_rec_row0(chunk_start[c], c, r, chunk_width[c], C) + p, so the particles of a row
   // (consecutive ranks of one element) are consecutive 64-B records and the re-layout's scattered stores leave as

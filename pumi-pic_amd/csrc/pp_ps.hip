@@ -104,7 +104,7 @@ __device__ __forceinline__ void init_slots_tiled4_body(const InitSlotsArgs& a, l
     if (e.z < ne) a.elem_slot0[e.z] = start + 2;
     if (e.w < ne) a.elem_slot0[e.w] = start + 3;
     if (a.elem_rec0) {  // first record of the row when the staging records are row-major inside the chunk (pp_ps::rec_rm)
-      const int w = a.chunk_width[c], q0 = pp_rec_row0(a.chunk_start[c], c, r, w, C), pt = w + (w & 1);
+      const int w = a.chunk_width[c], q0 = pp_rec_row0(a.chunk_start[c], c, r, w, C), pt = pp_rec_pitch(w);
       if (e.x < ne) a.elem_rec0[e.x] = q0;
       if (e.y < ne) a.elem_rec0[e.y] = q0 + pt;
       if (e.z < ne) a.elem_rec0[e.z] = q0 + 2 * pt;
@@ -1131,14 +1131,26 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
 // Entry table of the staged move: sources are member arrays `src[m]` with component stride
 // `src_stride` (elements), destinations the swap buffers.  Returns the number of 16-B quads per
 // record, or 0 when the members do not fit the staged path (other sizes than 4/8 bytes, too many).
+// (lab build, PP_NO_LAZY_UNPACK=1: the second pass of every re-layout runs right away)
+bool no_lazy_unpack() {
+  static const bool off = PP_LAB_ENV("PP_NO_LAZY_UNPACK") != nullptr;
+  return off;
+}
+// `side_member` >= 0: that member (one 4-byte component) travels beside the record (WordTable::side_src / side_dst).
 int build_word_table(const pp_ps* ps, const void* const* src, int64_t src_stride, int64_t dst_stride,
-                     int commit_x, int commit_xt, WordTable& wt) {
+                     int commit_x, int commit_xt, WordTable& wt, int side_member = -1) {
   wt = WordTable{};
   for (int m = 0; m < ps->nmembers; ++m) {
     const int b = ps->member_bytes[m];
     if (b != 4 && b != 8) return 0;
     for (int cc = 0; cc < ps->member_ncomp[m]; ++cc) {
       char* dst = (char*)ps->swap[m].p + ((size_t)cc * dst_stride) * b;
+      if (m == side_member) {
+        if (b != 4 || ps->member_ncomp[m] != 1 || m == commit_x || m == commit_xt) return 0;
+        wt.side_src = (const char*)src[m];
+        wt.side_dst = dst;
+        continue;
+      }
       if (m == commit_xt) {  // constant 0 after the fused updatePtclPositions
         int& nz = (b == 8) ? wt.nz8 : wt.nz4;
         if (nz >= 8) return 0;
@@ -1485,9 +1497,14 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       for (int m = 0; m < ps->nmembers; ++m) srcs[m] = ps->data[m].p;
       WordTable wt_probe{};
       const int nq = build_word_table(ps, srcs, ps->stride, stride_fit, commit_x, commit_xt, wt_probe);
-      if (nq > 0)
-        cap_lim = std::min<long long>(cap_lim, (long long)(ps->s_aos.bytes / ((size_t)nq * 16)) -
-                                                   (long long)ps->C_max * nchunks0);
+      if (nq > 0) {
+        // (the pseudoXGCm type with the commit: 32-B records + the side word, as enqueue_tail will decide)
+        const bool compact = nq == 4 && commit_x >= 0 && commit_xt >= 0 && (n_new == 0 || new_xt_zero) &&
+                             !no_lazy_unpack() && xgcm_shape(ps);
+        const long long spare = (long long)kRecSpareCols * ps->C_max * nchunks0;
+        cap_lim = std::min<long long>(cap_lim, (long long)(ps->s_aos.bytes / ((size_t)(compact ? 2 : nq) * 16)) - spare);
+        if (compact) cap_lim = std::min<long long>(cap_lim, (long long)(ps->s_side.bytes / sizeof(unsigned)) - spare);
+      }
     }
     const long long tiles_room = (long long)(ps->s_newidx.bytes / 8) - nchunks0 - 1;
     cap_lim = std::min<long long>(cap_lim, tiles_room * (long long)(ps->C_max * ps->tile_p));
@@ -1587,8 +1604,15 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       // next fused push reads the records themselves (pp_search.hip: RECIN), anything else runs the
       // pass first (ps_ready).  One pass over the particles less per step of the pseudoXGCm loop.
       // (lab build, PP_NO_LAZY_UNPACK=1: pass 2 runs right away -- the path every other particle type takes)
-      static const bool no_defer = PP_LAB_ENV("PP_NO_LAZY_UNPACK") != nullptr;
+      const bool no_defer = no_lazy_unpack();
       defer_unpack = lazy_zero && NQ == 4 && !no_defer && xgcm_shape(ps);
+      if (defer_unpack) {
+        // ... as 32-B records: origin, phi, b; the third member (4 bytes) travels beside them (WordTable::side_*) --
+        // with it the record would be 36 B, i.e. a 64-B sector per particle, written here and read by the push
+        NQ = build_word_table(ps, srcs, ps->stride, swap_stride, commit_x, commit_xt, wt, 2);
+        PP_REQUIRE(NQ == 2 && wt.side_src, "rebuild (internal): the pseudoXGCm record is not 32 bytes + one word");
+        wt.nz8 = wt.nz4 = 0;
+      }
       // Records wider than 64 B (ps_combo160's 160-B particle: 192-B records), no new particles, no commit: the
       // second pass waits until somebody asks for a member -- a rebuild that follows reads the records
       // (performance_tests/ps_combo160.cpp:205-232 rebuilds a hundred times without touching a member)
@@ -1597,8 +1621,11 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     }
     if (NQ > 0) {
       // (+ one spare column per chunk: the row-major record geometry, pp_rec_row0)
-      PP_HIP_CHECK(ps->s_aos.reserve(((size_t)std::max(cap_sz, 1) + (size_t)C_new * nchunks) * NQ * 16));
+      const size_t nrec = (size_t)std::max(cap_sz, 1) + (size_t)kRecSpareCols * C_new * nchunks;
+      PP_HIP_CHECK(ps->s_aos.reserve(nrec * NQ * 16));
+      if (defer_unpack) PP_HIP_CHECK(ps->s_side.reserve(nrec * sizeof(unsigned)));
       uint4* aos = ps->s_aos.as<uint4>();
+      unsigned* const side = defer_unpack ? ps->s_side.as<unsigned>() : nullptr;
       const unsigned new_grid = grid_for((size_t)ntiles_max * C_new);
 #define PP_UNPACK_ARGS                                                                                  \
   new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_mask2.as<unsigned char>(), aos, \
@@ -1610,16 +1637,18 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
                                                                     ps->s_aos_live.as<uint4>(), aos, go); \
     else if (use_rm)                                                                             \
       k_move_pack_rm<N><<<pack_main + pack_hot, kBlock, 0, st>>>(pack_end, rank, rs_rm, aos, wt, go, \
-                                                                 ps->C == 64 ? rm_wide : 0, hot_now, pack_hot); \
+                                                                 ps->C == 64 ? rm_wide : 0, hot_now, pack_hot, side); \
     else                                                                                         \
-      k_move_pack<N><<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, rank, rs, aos, wt, go); \
+      k_move_pack<N><<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, rank, rs, aos, wt, go, side); \
     if (!defer_unpack && !defer_wide) k_move_unpack<N><<<new_grid, kBlock, 0, st>>>(PP_UNPACK_ARGS); \
     break;
       const RankToSlot rs{new_element, ps->s_eslot0.as<int>(), C_new};
       // the staging records row-major inside a chunk: the particles of a row, which carry consecutive ranks,
       // are consecutive records, and the pack's block-level transpose stores them as runs
       const RankToSlot rs_rm{new_element, ps->s_erec0.as<int>(), 1};
-      constexpr int rm_wide = 3;  // log2(columns per block)
+      // log2(columns per block): a row's run of a block is 512 contiguous bytes -- 8 of the 64-B records, 16 of the
+      // 32-B ones (whose side words then leave as 64-B pieces)
+      const int rm_wide = NQ <= 2 ? 4 : 3;
       // (only where the records stay the particle data -- the pseudoXGCm flows, where nine particles in ten keep
       // their row: c3 -3.3 %, 2dc3 -3.6 %, c5 share -3.2 %.  ps_combo160 redistributes half of its particles to
       // random elements: nothing to merge, and its second pass reads row-major records 2.5 % slower)
@@ -1650,7 +1679,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
           n_new, new_elems, rank_new, use_rm ? ps->s_erec0.as<int>() : ps->s_eslot0.as<int>(), use_rm ? 1 : C_new,
           (const unsigned long long*)new_info[commit_x],
           (const unsigned*)new_info[2], (const unsigned*)new_info[3], (const unsigned*)new_info[4],
-          ps->s_aos.as<uint4>(), go);
+          ps->s_aos.as<uint4>(), ps->s_side.as<unsigned>(), go);
     } else if (n_new > 0) {
       MoveArgs add = mv;
       for (int m = 0; m < ps->nmembers; ++m) add.src[m] = new_info[m];
@@ -1797,8 +1826,9 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   ps->zero_pending = lazy_zero ? commit_xt : -1;
   ps->lazy_rec = 0;
   ps->hot = pp::HotRow{};
-  if (defer_unpack && NQ == 4) {  // the records of the first pass are what holds the particles now
+  if (defer_unpack) {  // the records of the first pass are what holds the particles now
     ps->s_aos.swap(ps->s_aos_live);
+    ps->s_side.swap(ps->s_side_live);
     ps->lazy_rec = 1;
     ps->lazy_x = commit_x;
     ps->lazy_xt = commit_xt;
@@ -1912,7 +1942,7 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       PP_HIP_CHECK(ps->s_aos.reserve((size_t)on_process * NQ * 16));
       uint4* aos = ps->s_aos.as<uint4>();
       const int* off2 = ps->s_offsets2.as<int>();
-      static const bool no_defer = PP_LAB_ENV("PP_NO_LAZY_UNPACK") != nullptr;
+      const bool no_defer = no_lazy_unpack();
       defer_wide = NQ > 4 && n_new == 0 && !no_defer;  // (see scs_rebuild)
       nq_used = NQ;
       PP_REQUIRE(!from_rec || NQ == ps->rec_nq, "rebuild (internal): the live records have another width");
@@ -2085,8 +2115,8 @@ int ps_materialize(pp_ps* ps) {
     return ps_zeros(ps);
   }
   if (ps->lazy_rec) {
-    // the deferred second pass of the last full re-layout: records -> SoA arrays, for every member that
-    // is still only in the records (all that travelled / the origin only)
+    // the deferred second pass of the last full re-layout: 32-B records (+ the side word) -> SoA arrays, for every
+    // member that is still only in the records (all that travelled / the origin only)
     const int state = ps->lazy_rec;
     ps->lazy_rec = 0;
     if (ps->capacity > 0 && ps->num_ptcls > 0) {
@@ -2096,7 +2126,9 @@ int ps_materialize(pp_ps* ps) {
         const int b = ps->member_bytes[m];
         for (int cc = 0; cc < ps->member_ncomp[m]; ++cc) {
           char* dst = (state == 2 && m != ps->lazy_x) ? nullptr : (char*)ps->data[m].p + ((size_t)cc * ps->stride) * b;
-          if (b == 8)
+          if (m == 2)  // (the order of build_word_table with side_member 2)
+            wt.side_dst = dst;
+          else if (b == 8)
             wt.dst8[wt.n8++] = dst;
           else
             wt.dst4[wt.n4++] = dst;
@@ -2112,10 +2144,10 @@ int ps_materialize(pp_ps* ps) {
       }();
       PP_REQUIRE(go_one != nullptr, "ps_materialize: device allocation failed");
       if (state == 2) wt.n4 = 0;  // (4-byte members were written by the push; 8-byte ones: only lazy_x has a target)
-      k_move_unpack<4><<<grid_for((size_t)ps->ntiles_max * ps->C), kBlock, 0, pp::stream()>>>(
+      k_move_unpack<2><<<grid_for((size_t)ps->ntiles_max * ps->C), kBlock, 0, pp::stream()>>>(
           ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(),
           ps->d_chunk_width.as<int>(), ps->d_mask.as<unsigned char>(), ps->s_aos_live.as<uint4>(), wt, go_one,
-          ps->rec_rm ? 1 : 0);
+          ps->rec_rm ? 1 : 0, state == 2 ? nullptr : ps->s_side_live.as<unsigned>());
       PP_LAUNCH_CHECK();
     }
   }

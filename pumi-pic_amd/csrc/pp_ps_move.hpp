@@ -66,11 +66,12 @@ __global__ void k_add_scs(int n_new, const int* __restrict__ new_elems,
   copy_members(a, i, idx);
 }
 // new particles of a rebuild whose second pass is deferred (pseudoXGCm particle type, committed layout of
-// k_move_pack: words 0-5 member commit_x, 13 / 14 / 15 the three 4-byte members from the back)
+// k_move_pack: words 0-5 member commit_x, 6 / 7 the last two 4-byte members from the back; the first one beside it)
 __global__ void k_add_rec(int n_new, const int* __restrict__ new_elems, const int* __restrict__ rank_new,
                           const int* __restrict__ elem_slot0, int C_new, const unsigned long long* __restrict__ x,
                           const unsigned* __restrict__ m2, const unsigned* __restrict__ m3,
-                          const unsigned* __restrict__ m4, uint4* __restrict__ aos, const int* __restrict__ go) {
+                          const unsigned* __restrict__ m4, uint4* __restrict__ aos, unsigned* __restrict__ side,
+                          const int* __restrict__ go) {
   if (!*go) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_new) return;
@@ -78,11 +79,10 @@ __global__ void k_add_rec(int n_new, const int* __restrict__ new_elems, const in
   // records, the row's first record and 1)
   const long long idx = elem_slot0[new_elems[i]] + (long long)rank_new[i] * C_new;
   const unsigned long long x0 = x[i], x1 = x[(size_t)n_new + i], x2 = x[2 * (size_t)n_new + i];
-  uint4* r = aos + idx * 4;
+  uint4* r = aos + idx * 2;
   r[0] = make_uint4((unsigned)x0, (unsigned)(x0 >> 32), (unsigned)x1, (unsigned)(x1 >> 32));
-  r[1] = make_uint4((unsigned)x2, (unsigned)(x2 >> 32), 0u, 0u);
-  r[2] = make_uint4(0u, 0u, 0u, 0u);
-  r[3] = make_uint4(0u, m4[i], m3[i], m2[i]);
+  r[1] = make_uint4((unsigned)x2, (unsigned)(x2 >> 32), m4[i], m3[i]);
+  side[idx] = m2[i];
 }
 // Row-tiled move (SCS): thread = (old tile, row).  Stayers of the thread reserve their slots in the
 // new row with ONE atomic (n_stay * C) and are written in a second sweep; movers take slots one
@@ -146,6 +146,12 @@ struct WordTable {
   char* dst4[kMax4];
   char* z8[8];
   char* z4[8];
+  // ONE 4-byte member that travels beside the record instead of inside it (the pseudoXGCm particle: origin + phi + b
+  // are 32 B, the third member would make it 36 -> a 64-B record).  Pass 1 reads it at side_src + old slot * 4 and
+  // stores it to `side` + record * 4 (an argument of the kernels: an array in RECORD order); pass 2 reads it there
+  // and writes side_dst + new slot * 4 (null: not wanted).
+  const char* side_src;
+  char* side_dst;
 };
 // pass 1b: one thread per old slot packs its record; the wave transposes through LDS so that
 // NQ adjacent lanes store one whole record (full 64-B sectors leave the CU already merged:
@@ -159,7 +165,8 @@ struct RankToSlot {
 };
 template <int NQ>
 __global__ void k_move_pack(int capacity, const int* __restrict__ new_idx, RankToSlot rs,
-                            uint4* __restrict__ aos, WordTable t, const int* __restrict__ go) {
+                            uint4* __restrict__ aos, WordTable t, const int* __restrict__ go,
+                            unsigned* __restrict__ side = nullptr) {
   if (go && !*go) return;
   __shared__ uint4 st[4][64][NQ + 1];
   __shared__ int sd[4][64];
@@ -188,6 +195,7 @@ __global__ void k_move_pack(int capacity, const int* __restrict__ new_idx, RankT
         v[NQ * 4 - 1 - j] = __builtin_nontemporal_load((const unsigned*)(t.src4[j] + (long long)pid * 4));
 #pragma unroll
     for (int q = 0; q < NQ; ++q) st[w][l][q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    if (side) side[idx] = __builtin_nontemporal_load((const unsigned*)(t.side_src + (long long)pid * 4));
   }
   sd[w][l] = idx;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -216,15 +224,23 @@ __global__ void k_move_pack(int capacity, const int* __restrict__ new_idx, RankT
 template <int NQ>
 __global__ void k_move_pack_rm(int capacity, const int* __restrict__ new_idx, RankToSlot rs,
                                uint4* __restrict__ aos, WordTable t, const int* __restrict__ go, int wide,
-                               pp::HotRow hot = pp::HotRow{}, unsigned hot_blocks = 0u) {
+                               pp::HotRow hot = pp::HotRow{}, unsigned hot_blocks = 0u,
+                               unsigned* __restrict__ side = nullptr) {
   if (go && !*go) return;
   __shared__ uint4 st[256][NQ + 1];
   __shared__ int sd[256];
+  __shared__ unsigned ss[256];  // the member that travels beside the record (WordTable::side_src)
   // which old slot: 4 columns x 64 rows of the block's 256 consecutive slots, or (wide: chunk height 64) 8 columns x
   // 32 rows -- block pairs share 8 columns, so a row's run is up to 8 records = 512 contiguous bytes
   const int tid = threadIdx.x;
   int pid, li;  // li = LDS index: records of one row adjacent
-  const unsigned bid = blockIdx.x - hot_blocks;  // (of the main blocks)
+  // (of the main blocks) XCD-aware: blockIdx i runs on XCD i % 8, each with an L2 of its own.  The stayers of a row
+  // leave as ONE contiguous stretch of records, written piecewise by the blocks of the row's column groups; when those
+  // blocks run on one XCD the ragged ends of neighbouring pieces meet in its L2 and leave as whole lines -- so every
+  // XCD takes a contiguous eighth of the blocks (the grid is a multiple of 16)
+  // (round 5, same box: c3 0.57 -> 0.53 ms, 2dc3 0.59 -> 0.54)
+  const unsigned nb = gridDim.x - hot_blocks;
+  const unsigned bid = (blockIdx.x & 7u) * (nb >> 3) + ((blockIdx.x - hot_blocks) >> 3);
   if (blockIdx.x < hot_blocks) {
     // (pp_ps::hot; `capacity` ends the main blocks' slots where these columns begin) 256 columns of the over-full
     // row: one run of up to 16 KB.  The first blocks of the grid, as in the histogram.
@@ -262,9 +278,14 @@ __global__ void k_move_pack_rm(int capacity, const int* __restrict__ new_idx, Ra
         v[NQ * 4 - 1 - j] = __builtin_nontemporal_load((const unsigned*)(t.src4[j] + (long long)pid * 4));
 #pragma unroll
     for (int q = 0; q < NQ; ++q) st[li][q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    if (side) ss[li] = __builtin_nontemporal_load((const unsigned*)(t.side_src + (long long)pid * 4));
   }
   sd[li] = idx;
   __syncthreads();
+  if (side) {  // thread i stores for LDS index i: the records of a row are adjacent indices, their places adjacent words
+    const int d = sd[tid];
+    if (d >= 0) side[d] = ss[tid];
+  }
 #pragma unroll
   for (int j = 0; j < NQ; ++j) {
     const int item = j * 256 + tid, rec = item / NQ, part = item % NQ;  // the records of one row are adjacent items
@@ -316,7 +337,7 @@ __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
                               const int* __restrict__ chunk_width,
                               const unsigned char* __restrict__ new_mask,
                               const uint4* __restrict__ aos, WordTable t, const int* __restrict__ go,
-                              int rec_rm = 0) {
+                              int rec_rm = 0, const unsigned* __restrict__ side = nullptr) {
   if (!*go) return;
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int tile = (int)(g / C), r = (int)(g - (long long)tile * C);
@@ -324,6 +345,7 @@ __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
   const int c = tiles[2 * tile], p0 = tiles[2 * tile + 1];
   const int start = chunk_start[c] + r, pend = min(p0 + TP, chunk_width[c]);
   const long long rbase = pp_rec_row0(chunk_start[c], c, r, chunk_width[c], C);  // row-major records (pp_ps::rec_rm)
+  const bool want_side = side != nullptr && t.side_dst != nullptr;
   auto put = [&](int slot, const unsigned* w) {
 #pragma unroll
     for (int i = 0; i < NQ * 2; ++i)
@@ -347,11 +369,12 @@ __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
     // now).  KC columns' records are loaded back to back, then stored.
     // (same-box A/B of the drop-in driver, 3 x 100 steps: 1.244 against 1.252 ms with one column at a time, 1.24
     // with four -- the pass is not bound by these bytes; the traffic is what went down)
-    constexpr int KC = 2;
+    constexpr int KC = NQ <= 2 ? 4 : 2;  // (the records of one 128-B line)
     for (int p = p0; p < pend; p += KC) {
       bool m[KC];
       const uint4* sp = aos + (rbase + p) * NQ;
       unsigned w[KC][NQ * 4];
+      unsigned sv[KC];
       bool any = false;
 #pragma unroll
       for (int k = 0; k < KC; ++k) {
@@ -369,9 +392,16 @@ __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
           w[k][4 * q + 2] = v.z;
           w[k][4 * q + 3] = v.w;
         }
+      if (want_side) {
+#pragma unroll
+        for (int k = 0; k < KC; ++k) sv[k] = m[k] ? side[rbase + p + k] : 0u;
+      }
 #pragma unroll
       for (int k = 0; k < KC; ++k)
-        if (m[k]) put(start + (p + k) * C, w[k]);
+        if (m[k]) {
+          put(start + (p + k) * C, w[k]);
+          if (want_side) __builtin_nontemporal_store(sv[k], (unsigned*)(t.side_dst + (long long)(start + (p + k) * C) * 4));
+        }
     }
     return;
   }
@@ -391,6 +421,8 @@ __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
       w[4 * q + 3] = v.w;
     }
     put(slot, w);
+    if (want_side)
+      __builtin_nontemporal_store(side[rec_rm ? rbase + p : (long long)slot], (unsigned*)(t.side_dst + (long long)slot * 4));
   }
 }
 // CSR staged move (same two passes as SCS): slot assignment by the element cursor, pack through

@@ -1000,27 +1000,27 @@ __device__ __forceinline__ PState load_state(int pid, const unsigned char* __res
   return s;
 }
 
-// Record-fed form (RECIN) of the queued kernel.  After a full re-layout with the fused updatePtclPositions
-// the particles are still in the 64-B staging records of the move's first pass (pp_ps.hip: k_move_pack;
-// words 0-5 x, 13 phi, 14 b, 15 the 4-byte third member) -- the second pass, which would copy them into
-// the SoA arrays only for this kernel to read them back, is skipped (pp_ps::lazy_rec).  The state of a
-// column is three loads from one record; the members the next rebuild packs from the SoA arrays (third
-// member, b; x_tgt and phi are written anyway) are written here.
+// Record-fed form (RECIN).  After a full re-layout with the fused updatePtclPositions the particles are still in
+// the 32-B staging records of the move's first pass (pp_ps.hip: k_move_pack; words 0-5 the origin, 6 phi, 7 b) with
+// the 4-byte third member beside them in an array in record order (WordTable::side_*) -- the second pass, which would
+// copy them into the SoA arrays only for this kernel to read them back, is skipped (pp_ps::lazy_rec).  The members
+// the next rebuild packs from the SoA arrays (third member, b; x_tgt and phi are written anyway) are written here.
 struct RecIn {
   const char* rec;  // null = SoA input
+  const unsigned* side;
   unsigned* id_out;
   float* b_out;
   int zero_z;  // 2-D: x_tgt is logically zero (pp_ps::zero_pending) -- the push writes its third component too
   int rm;      // records row-major inside a chunk (pp_ps::rec_rm): (row r, column p) of chunk c is record
                // pp_rec_row0(chunk_start[c], c, r, chunk_width[c], C) + p; else the record index is the slot
-  int no_pairs;  // PP_NO_PAIR_FETCH=1 (A/B knob): one column per fetch also on row-major records
 };
 template <int DIM = 3>
 __device__ __forceinline__ PState load_state_recin(int pid, const unsigned char* __restrict__ mask,
-                                                   const char* __restrict__ rec, long long ri) {
+                                                   const char* __restrict__ rec, const unsigned* __restrict__ side,
+                                                   long long ri) {
   PState s;
   s.m = mask[pid];
-  const char* rp = rec + ri * 64;
+  const char* rp = rec + ri * 32;
   s.x = s.y = s.z = 0;
   if (DIM == 3) {  // (the 2-D push reads no position)
     const double2 q0 = *(const double2*)rp;
@@ -1028,10 +1028,10 @@ __device__ __forceinline__ PState load_state_recin(int pid, const unsigned char*
     s.y = q0.y;
     s.z = *(const double*)(rp + 16);
   }
-  const uint4 q3 = *(const uint4*)(rp + 48);
-  s.phi = __uint_as_float(q3.y);
-  s.b = __uint_as_float(q3.z);
-  s.id = q3.w;
+  const uint2 q1 = *(const uint2*)(rp + 24);
+  s.phi = __uint_as_float(q1.x);
+  s.b = __uint_as_float(q1.y);
+  s.id = side[ri];
   s.elem = -1;
   return s;
 }
@@ -1117,7 +1117,7 @@ __global__ void __launch_bounds__(256, OCC)
   auto load = [&](int pid, long long ri) {
     PState s;
     if constexpr (RECIN) {
-      s = load_state_recin<DIM>(pid, mask, rin.rec, ri);
+      s = load_state_recin<DIM>(pid, mask, rin.rec, rin.side, ri);
       if (seeded) s.elem = elem_ids[pid];
     } else {
       s = load_state<DIM, true>(pid, mask, pphi, pb, x, stride, elem_ids, seeded != 0);
@@ -1174,27 +1174,54 @@ __global__ void __launch_bounds__(256, OCC)
     }
   }
   if (!valid) return;
-  // The states of TWO columns are loaded back to back, the next pair before the second column's (dependent) walk.
-  // Record-fed, row-major records: the records of columns (2j, 2j + 1) of a row are one 128-B line, and the 2-D push
-  // reads 16 B of each; asked for one column at a time -- a walk apart -- the line has left the L2 by the second
-  // request: the PMC counters read 1.32 GB fetched per step for 10 M particles (profiles/traffic_2dc3.json, round 4),
-  // every line twice.  (p0 is a multiple of the tile width and a row starts on a line: the pairs are the lines.)
-  PState sa = load(start + p0 * C, rb + p0 * rs), sb{};
-  if (p0 + 1 < pend) sb = load(start + (p0 + 1) * C, rb + (p0 + 1) * rs);
-  for (int p = p0; p < pend; p += 2) {
-    const int pid = start + p * C;
-    rows_particle<DIM>(sa, pid, e, ct, cache, recs, nelems, xt, stride, pphi, h, k, d, tol,
-                       unmoved_sq, elem_ids, seeded, looplimit, cnt, id_out, b_out, RECIN ? rin.zero_z : 0);
-    PState na{}, nb{};
-    if (p + 2 < pend) {
-      na = load(pid + 2 * C, rb + (p + 2) * rs);
-      if (p + 3 < pend) nb = load(pid + 3 * C, rb + (p + 3) * rs);
+  // The states of FOUR columns are loaded back to back, the next four before the second column's (dependent) walk.
+  // Record-fed, row-major records: the 32-B records of columns (4j .. 4j + 3) of a row are one 128-B line, and the 2-D
+  // push reads 8 B of each (+ the side word); asked for one column at a time -- a walk apart -- the line has left the
+  // L2 by the next request (round 4, 64-B records: 1.32 GB fetched per step for 10 M particles, every line twice).
+  // (p0 is a multiple of the tile width and a row starts on a line: the groups of four are the lines.)
+  // (the tet form, which only the lab build's PP_WALK_QUEUE=0 runs, takes two: eight states in flight spill)
+  constexpr int G = DIM == 2 ? 4 : 2;
+  // the states of columns p .. p + G - 1; record-fed 2-D on row-major records: the four third members as ONE 16-byte
+  // load (the side array is in record order, a row's group of four starts on a 16-byte boundary)
+  auto loadg = [&](int p, PState* o) {
+    if constexpr (RECIN && DIM == 2) {
+      if (rs == 1 && ((rb + p) & 3) == 0) {
+        const uint4 ids = *(const uint4*)(rin.side + rb + p);
+        const unsigned idv[4] = {ids.x, ids.y, ids.z, ids.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[j] = PState{};
+          if (p + j < pend) {
+            const int pid = start + (p + j) * C;
+            const uint2 q1 = *(const uint2*)(rin.rec + (rb + p + j) * 32 + 24);
+            o[j].m = mask[pid];
+            o[j].phi = __uint_as_float(q1.x);
+            o[j].b = __uint_as_float(q1.y);
+            o[j].id = idv[j];
+            o[j].elem = seeded ? elem_ids[pid] : -1;
+          }
+        }
+        return;
+      }
     }
-    if (p + 1 < pend)
-      rows_particle<DIM>(sb, pid + C, e, ct, cache, recs, nelems, xt, stride, pphi, h, k, d, tol,
-                         unmoved_sq, elem_ids, seeded, looplimit, cnt, id_out, b_out, RECIN ? rin.zero_z : 0);
-    sa = na;
-    sb = nb;
+#pragma unroll
+    for (int j = 0; j < G; ++j) o[j] = (p + j < pend) ? load(start + (p + j) * C, rb + (p + j) * rs) : PState{};
+  };
+  PState q[G];
+  loadg(p0, q);
+  for (int p = p0; p < pend; p += G) {
+    const int pid = start + p * C;
+    rows_particle<DIM>(q[0], pid, e, ct, cache, recs, nelems, xt, stride, pphi, h, k, d, tol,
+                       unmoved_sq, elem_ids, seeded, looplimit, cnt, id_out, b_out, RECIN ? rin.zero_z : 0);
+    PState n[G];
+    loadg(p + G, n);
+#pragma unroll
+    for (int j = 1; j < G; ++j)
+      if (p + j < pend)
+        rows_particle<DIM>(q[j], pid + j * C, e, ct, cache, recs, nelems, xt, stride, pphi, h, k, d, tol,
+                           unmoved_sq, elem_ids, seeded, looplimit, cnt, id_out, b_out, RECIN ? rin.zero_z : 0);
+#pragma unroll
+    for (int j = 0; j < G; ++j) q[j] = n[j];
   }
 }
 
@@ -1430,52 +1457,17 @@ __device__ __forceinline__ void coop_fetch(RecCache<DIM>& c, const void* __restr
   wave_lds_sync();
 }
 
-// ---- record-fed form: the wave's PARTICLE records through the LDS too.  A column's 64 records (64 B each) are
-// fetched cooperatively like the element records -- 4 lanes per record, 16 records per global_load_lds
-// instruction: 16 cache lines per instruction when the records are row-major (each record half a line of its
-// own row), against 64 lines for each of the three 16-B loads a lane-private read needs -- and land in a 4 KB
-// staging area next to a HALVED element-record area (32 records; a wave whose 64 lanes all need a new element
-// record fetches in two rounds: in the rebuilt-every-step flows this form serves that is the first column of a
-// tile).  No VGPRs hold data in flight: the state of column p + 1 is DMA'd while column p computes, into the
-// buffer column p was just read out of.
-__device__ __forceinline__ void prec_issue(const char* __restrict__ rec, int my_ri, double2* pst, int lane) {
-  const int sub = lane & 3;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int o = 16 * j + (lane >> 2);  // owner lane of the record this lane helps to fetch
-    const int ri = __shfl(my_ri, o);
-    const int piece = sub ^ (o & 3);
-    if (ri >= 0)
-      __builtin_amdgcn_global_load_lds((const void*)(rec + (long long)ri * 64 + piece * 16),
-                                       (__attribute__((address_space(3))) void*)(pst + j * 64), 16, 0, 0);
-  }
-}
-template <int DIM>
-__device__ __forceinline__ PState prec_collect(const double2* pst, int lane) {
-  const double2* mine = pst + lane * 4;
-  const int sub = lane & 3;
-  PState s;
-  s.m = 0;
-  s.x = s.y = s.z = 0;
-  if (DIM == 3) {
-    const double2 q0 = mine[0 ^ sub];
-    s.x = q0.x;
-    s.y = q0.y;
-    s.z = mine[1 ^ sub].x;
-  }
-  const uint4 q3 = *(const uint4*)(mine + (3 ^ sub));
-  s.phi = __uint_as_float(q3.y);
-  s.b = __uint_as_float(q3.z);
-  s.id = q3.w;
-  s.elem = -1;
-  return s;
-}
-// Two columns at once: with row-major records of even pitch (pp_rec_row0) the records of columns (2j, 2j + 1) of a row
-// are ONE 128-byte line; 8 lanes fetch it (as for an element record), the pair lands in the wave's whole 8 KB area.
-__device__ __forceinline__ void prec_issue_pair(const char* __restrict__ rec, int my_ri, double2* st, int lane) {
-  // One wave-uniform test instead of one exec-mask branch per instruction: the rows of a tile have their pair or
-  // none has (a wave of C = 64 rows is one tile); where a wave holds rows of two tiles (C < 64, the grid's last
-  // wave) the rows without a pair re-fetch the line of a row that has one -- into staging nobody reads.
+// ---- record-fed form: the wave's PARTICLE records through the LDS too.  With row-major records (pp_rec_row0) the
+// 32-B records of columns (4j .. 4j + 3) of a row are ONE 128-byte line: 8 lanes fetch it (as for an element record)
+// and the four columns land in the wave's whole 8 KB staging area -- 8 cache lines per global_load_lds instruction,
+// against 64 for each 16-B load a lane-private read needs.  The third member (4 bytes per particle, an array in record
+// order beside the records: RecIn::side) comes as ONE 16-byte piece per row into a 1 KB area of its own.  No VGPRs
+// hold data in flight: the four columns (p + 4 .. p + 7) are DMA'd while column p + 3 computes.
+__device__ __forceinline__ void prec_issue_quad(const char* __restrict__ rec, const unsigned* __restrict__ side,
+                                                int my_ri, double2* st, double2* ist, int lane) {
+  // One wave-uniform test instead of one exec-mask branch per instruction: the rows of a tile have their four columns
+  // or none has (a wave of C = 64 rows is one tile); where a wave holds rows of two tiles (C < 64, the grid's last
+  // wave) the rows without re-fetch the line of a row that has them -- into staging nobody reads.
   const unsigned long long have = __ballot(my_ri >= 0);
   if (have == 0ull) return;
   const int any_ri = __shfl(my_ri, (int)__builtin_ctzll(have));
@@ -1486,14 +1478,16 @@ __device__ __forceinline__ void prec_issue_pair(const char* __restrict__ rec, in
     int ri = __shfl(my_ri, o);
     ri = ri >= 0 ? ri : any_ri;
     const int piece = sub ^ (o & 7);
-    __builtin_amdgcn_global_load_lds((const void*)(rec + (long long)ri * 64 + piece * 16),
+    __builtin_amdgcn_global_load_lds((const void*)(rec + (long long)ri * 32 + piece * 16),
                                      (__attribute__((address_space(3))) void*)(st + j * 64), 16, 0, 0);
   }
+  const int mine = my_ri >= 0 ? my_ri : any_ri;
+  __builtin_amdgcn_global_load_lds((const void*)(side + mine), (__attribute__((address_space(3))) void*)ist, 16, 0, 0);
 }
 template <int DIM>
-__device__ __forceinline__ PState prec_collect_pair(const double2* st, int lane, int which) {
+__device__ __forceinline__ PState prec_collect_quad(const double2* st, const double2* ist, int lane, int which) {
   const double2* mine = st + lane * 8;
-  const int sub = lane & 7, b = 4 * which;
+  const int sub = lane & 7, b = 2 * which;
   PState s;
   s.m = 0;
   s.x = s.y = s.z = 0;
@@ -1501,40 +1495,15 @@ __device__ __forceinline__ PState prec_collect_pair(const double2* st, int lane,
     const double2 q0 = mine[(b + 0) ^ sub];
     s.x = q0.x;
     s.y = q0.y;
-    s.z = mine[(b + 1) ^ sub].x;
   }
-  const uint4 q3 = *(const uint4*)(mine + ((b + 3) ^ sub));
-  s.phi = __uint_as_float(q3.y);
-  s.b = __uint_as_float(q3.z);
-  s.id = q3.w;
+  const double2 q1 = mine[(b + 1) ^ sub];
+  if (DIM == 3) s.z = q1.x;
+  const unsigned long long pb = (unsigned long long)__double_as_longlong(q1.y);
+  s.phi = __uint_as_float((unsigned)pb);
+  s.b = __uint_as_float((unsigned)(pb >> 32));
+  s.id = ((const unsigned*)(ist + lane))[which];
   s.elem = -1;
   return s;
-}
-// element records through HALF a staging area (32 records): lanes 0-31, then lanes 32-63
-template <int DIM>
-__device__ __forceinline__ void coop_fetch_half(RecCache<DIM>& c, const void* __restrict__ recs, int want,
-                                                double2* st, int lane) {
-  constexpr int NP = DIM == 3 ? 8 : 4;
-  constexpr int RPI = 64 / NP;
-  const int sub = lane & (NP - 1);
-  for (int h = 0; h < 2; ++h) {
-    const bool mine_now = want >= 0 && (lane >> 5) == h;
-    if (__ballot(mine_now) == 0ull) continue;  // (wave-uniform)
-#pragma unroll
-    for (int j = 0; j < NP / 2; ++j) {
-      const int o = 32 * h + RPI * j + lane / NP;
-      const int eo = __shfl(want, o);
-      const int piece = sub ^ (o & (NP - 1));
-      if (eo >= 0)
-        __builtin_amdgcn_global_load_lds(
-            (const void*)((const char*)recs + (size_t)eo * (NP * 16) + piece * 16),
-            (__attribute__((address_space(3))) void*)(st + j * 64), 16, 0, 0);
-    }
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-    wave_lds_sync();
-    coop_collect<DIM>(c, mine_now, want, st - h * 32 * NP, lane);  // (lane - 32 h) * NP from the area's start
-    wave_lds_sync();
-  }
 }
 
 // per-launch constants of the fused kernel's column arithmetic
@@ -1700,9 +1669,10 @@ __device__ __forceinline__ void walk_pending(const PendEntry* __restrict__ regio
     }
   }
 }
-// RECIN: 0 SoA input; 1 record-fed, one column per fetch; 2 record-fed, unseeded search on row-major records: the
-// element record once per tile, two columns (one cache line per row) per fetch
-template <int DIM, int OCC, bool NT, int RECIN = 0>
+// RECIN: record-fed (else SoA input) -- an unseeded search on row-major 32-B records (RecIn): the element record once
+// per tile, four columns (one cache line per row) per fetch; the host materialises the members first when the
+// structure's geometry does not allow it (chunk height or tile width not a multiple of four, seeds)
+template <int DIM, int OCC, bool NT, bool RECIN = false>
 __global__ void __launch_bounds__(256, OCC)
     k_push_walk_rowsq(const int* __restrict__ ntiles_dev, int C, int TP,
                       const int* __restrict__ tiles, const int* __restrict__ chunk_start,
@@ -1795,7 +1765,7 @@ __global__ void __launch_bounds__(256, OCC)
       PState s{};
       if (act) {
         if constexpr (RECIN) {
-          s = load_state_recin<DIM>(pid, mask, rin.rec, (long long)t_rbase + (long long)p * rstride);
+          s = load_state_recin<DIM>(pid, mask, rin.rec, rin.side, (long long)t_rbase + (long long)p * rstride);
           if (read_ids) s.elem = ld<NT>(elem_ids + pid);
         } else {
           s = load_state<DIM, NT>(pid, mask, pphi, pb, x, stride, elem_ids, read_ids);
@@ -1818,108 +1788,62 @@ __global__ void __launch_bounds__(256, OCC)
   // loads of p+1 are issued and overlap the whole of column p's arithmetic.
   if constexpr (RECIN) {
     static_assert(DIM == 3, "the record-fed queued kernel is the tet form (2-D: k_push_walk_rows)");
-    // ---- record-fed form: particle records through the LDS (prec_issue / prec_collect), element records through
-    // the other half of the wave's staging area.  At the top of column p the DMA of column p has landed; the
-    // state is read out, the DMA of column p + 1 goes into the same buffer and overlaps the arithmetic of p.
-    // -- unseeded search on row-major records (the rebuilt-every-step flows): every live particle starts in its
-    // row's element, so the element record is fetched ONCE per tile, up front, and from then on the wave's whole
-    // staging area belongs to the particle records: two columns = one cache line per row per fetch
-    // (prec_issue_pair).  The pair of columns (p + 2, p + 3) is DMA'd while column p + 1 computes.
-    if constexpr (RECIN == 2) {  // (the host checks: row-major records, no seeds, an even tile width)
-      if (!thin) {
-        const int want0 = (valid && e < nelems && p0 < pend && mask[start + p0 * C] != 0) ? e : -1;
-        if (__ballot(want0 >= 0) != 0ull) coop_fetch<DIM>(cache, recs, want0, st, lane);
-      }
-      unsigned char ma = 0, mb = 0, ma_n = 0, mb_n = 0;
-      {
-        const bool first = !thin && p0 < pend;
-        prec_issue_pair(rin.rec, first ? rbase + p0 : -1, st, lane);
-        if (first) ma = mask[start + p0 * C];
-        if (first && p0 + 1 < pend) mb = mask[start + (p0 + 1) * C];
-      }
-      for (int i = 0; i < (thin ? 0 : TP); ++i) {  // wave-uniform trip count; ONE column per iteration, one fetch per two
-        const int p = p0 + i, pid = start + p * C, which = i & 1;
-        const bool act = p < pend;
-        if (which == 0) {
-          __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the pair's records (and its mask bytes)
-          wave_lds_sync();
-        }
-        PState s = prec_collect_pair<DIM>(st, lane, which);
-        s.m = act ? (which ? mb : ma) : 0;
-        if (which == 1) {
-          wave_lds_sync();  // both columns are out: the area is free for the next pair
-          const bool nxt = act && p + 1 < pend && i + 1 < TP;
-          prec_issue_pair(rin.rec, nxt ? rbase + p + 1 : -1, st, lane);
-          if (nxt) {
-            ma_n = mask[pid + C];
-            mb_n = p + 2 < pend ? mask[pid + 2 * C] : 0;
-          }
-        }
-        const bool live = act && s.m;
-        int elem = live ? e : -1;
-        // (the one fetch above relies on rows being left-packed -- a live column implies a live first column, which
-        // every rebuild guarantees; should a row ever hold a live slot behind a dead first one, its lane loads the
-        // record itself here instead of computing on an unloaded cache: round-4 advisor)
-        if (live && cache.id != e) fetch(cache, recs, e);
-        V3 dest{0, 0, 0};
-        const bool need = column_math<DIM, NT>(A, s, act, live, pid, ct, cache, elem, dest);
-        enqueue(need, pid, elem, dest, wq, qn, lt_mask);
-        if (which == 1) {
-          ma = ma_n;
-          mb = mb_n;
-        }
-      }
-      if (lane == 0) wave_cnt[gwave] = qn;
-      return;
+    // ---- record-fed form: every live particle starts in its row's element (unseeded search of a structure that
+    // was just rebuilt), so the element record is fetched ONCE per tile, up front, and from then on the wave's whole
+    // staging area belongs to the particle records: four columns = one cache line per row per fetch
+    // (prec_issue_quad).  The columns (p + 4 .. p + 7) are DMA'd while column p + 3 computes.
+    double2* const ist = lds_dyn + (size_t)(blockDim.x >> 6) * 64 * NP + (size_t)(threadIdx.x >> 6) * 64;
+    if (!thin) {
+      const int want0 = (valid && e < nelems && p0 < pend && mask[start + p0 * C] != 0) ? e : -1;
+      if (__ballot(want0 >= 0) != 0ull) coop_fetch<DIM>(cache, recs, want0, st, lane);
     }
-    double2* const pst = st + 32 * NP;  // (DIM 3: 4 KB of element records + 4 KB of particle records)
-    unsigned char m_cur = 0, m_nxt = 0;
-    int e_cur = -1, e_nxt = -1;
+    auto masks4 = [&](int p) {  // the mask bytes of columns p .. p + 3 (0 beyond the row's end)
+      unsigned m = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (p + j < pend) m |= (unsigned)mask[start + (p + j) * C] << (8 * j);
+      return m;
+    };
+    unsigned mq = 0, mq_n = 0;
     {
       const bool first = !thin && p0 < pend;
-      prec_issue(rin.rec, first ? rbase + p0 * rstride : -1, pst, lane);
-      if (first) {
-        m_cur = mask[start + p0 * C];
-        if (read_ids) e_cur = ld<NT>(elem_ids + start + p0 * C);
-      }
+      prec_issue_quad(rin.rec, rin.side, first ? rbase + p0 : -1, st, ist, lane);
+      if (first) mq = masks4(p0);
     }
-    for (int i = 0; i < (thin ? 0 : TP); ++i) {  // wave-uniform trip count
-      const int p = p0 + i;
-      const int pid = start + p * C;
+    for (int i = 0; i < (thin ? 0 : TP); ++i) {  // wave-uniform trip count; ONE column per iteration, one fetch per four
+      const int p = p0 + i, pid = start + p * C, which = i & 3;
       const bool act = p < pend;
-      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the records of column p (and its mask / seed loads)
-      wave_lds_sync();
-      PState s = prec_collect<DIM>(pst, lane);
-      s.m = act ? m_cur : 0;
-      if (read_ids) s.elem = e_cur;
-      wave_lds_sync();  // the buffer is free again
-      const bool nxt = act && p + 1 < pend;
-      prec_issue(rin.rec, nxt ? rbase + (p + 1) * rstride : -1, pst, lane);
-      if (nxt) {
-        m_nxt = mask[pid + C];
-        if (read_ids) e_nxt = ld<NT>(elem_ids + pid + C);
+      if (which == 0) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the four columns' records (and their mask bytes)
+        wave_lds_sync();
+      }
+      PState s = prec_collect_quad<DIM>(st, ist, lane, which);
+      s.m = act ? (unsigned char)(mq >> (8 * which)) : 0;
+      if (which == 3) {
+        wave_lds_sync();  // all four columns are out: the area is free for the next four
+        const bool nxt = act && p + 1 < pend && i + 1 < TP;
+        prec_issue_quad(rin.rec, rin.side, nxt ? rbase + p + 1 : -1, st, ist, lane);
+        if (nxt) mq_n = masks4(p + 1);
       }
       const bool live = act && s.m;
-      int elem = live ? seed_of<DIM>(s, e, seeded, nelems) : -1;
-      const int want = (elem >= 0 && elem != cache.id) ? elem : -1;
-      if (__ballot(want >= 0) != 0ull) coop_fetch_half<DIM>(cache, recs, want, st, lane);
+      int elem = live ? e : -1;
+      // (the one fetch above relies on rows being left-packed -- a live column implies a live first column, which
+      // every rebuild guarantees; should a row ever hold a live slot behind a dead first one, its lane loads the
+      // record itself here instead of computing on an unloaded cache: round-4 advisor)
+      if (live && cache.id != e) fetch(cache, recs, e);
       V3 dest{0, 0, 0};
       const bool need = column_math<DIM, NT>(A, s, act, live, pid, ct, cache, elem, dest);
       enqueue(need, pid, elem, dest, wq, qn, lt_mask);
-      m_cur = m_nxt;
-      e_cur = e_nxt;
+      if (which == 3) mq = mq_n;
     }
+    if (lane == 0) wave_cnt[gwave] = qn;
+    return;
   } else {
   PState cur{};
   int e1 = -1;   // raw elem_ids value of column p+1 (read two columns ahead of its use as a seed)
   int pre = -1;  // element whose record the DMA put into this lane's staging slot for column p
   if (!thin && p0 < pend) {
-    if constexpr (RECIN) {
-      cur = load_state_recin<DIM>(start + p0 * C, mask, rin.rec, (long long)rbase + (long long)p0 * rstride);
-      if (read_ids) cur.elem = ld<NT>(elem_ids + start + p0 * C);
-    } else {
-      cur = load_state<DIM, NT>(start + p0 * C, mask, pphi, pb, x, stride, elem_ids, read_ids);
-    }
+    cur = load_state<DIM, NT>(start + p0 * C, mask, pphi, pb, x, stride, elem_ids, read_ids);
     if (read_ids && p0 + 1 < pend) e1 = ld<NT>(elem_ids + start + (p0 + 1) * C);
   }
   for (int i = 0; i < (thin ? 0 : TP); ++i) {  // wave-uniform trip count: every lane reaches the wave-level ops
@@ -1946,10 +1870,7 @@ __global__ void __launch_bounds__(256, OCC)
     }
     if (__ballot(pre >= 0) != 0ull) coop_issue<DIM>(recs, pre, st, lane);
     if (act && p + 1 < pend) {
-      if constexpr (RECIN)
-        cur = load_state_recin<DIM>(pid + C, mask, rin.rec, (long long)rbase + (long long)(p + 1) * rstride);
-      else
-        cur = load_state<DIM, NT>(pid + C, mask, pphi, pb, x, stride, elem_ids, false);
+      cur = load_state<DIM, NT>(pid + C, mask, pphi, pb, x, stride, elem_ids, false);
       cur.elem = e1;
       if (read_ids && p + 2 < pend) e1 = ld<NT>(elem_ids + pid + 2 * C);
     }
@@ -2685,7 +2606,10 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
   // (lab build, PP_WALK_QUEUE=0/1: the column-loop kernel / the queued kernel whatever the dimension)
   const int wq_env = PP_LAB_ENV("PP_WALK_QUEUE") ? atoi(PP_LAB_ENV("PP_WALK_QUEUE")) : -1;  // per call
   const int wq = wq_env >= 0 ? wq_env : (mesh->dim == 3 ? 1 : 0);
-  const bool recin = ((mesh->dim == 3 && wq > 0) || (mesh->dim == 2 && wq == 0)) &&
+  // (the queued tet kernel takes the records four columns = one cache line at a time: row-major records, no seeds,
+  // chunk height and tile width multiples of four; anything else runs the deferred pass first and reads the arrays)
+  const bool quads_ok = ps->rec_rm && !elem_ids_seeded && (ps->tile_p & 3) == 0 && (ps->C & 3) == 0;
+  const bool recin = ((mesh->dim == 3 && wq > 0 && quads_ok) || (mesh->dim == 2 && wq == 0)) &&
                      ps->capacity > 0 && ps->num_ptcls > 0 && ps->ntiles_max > 0 &&
                      pp::lazy_push_ok(ps, m_x, m_xtgt, m_b, m_phi);
   int zero_z = 0;
@@ -2751,13 +2675,10 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
       if (mesh->dim == 2) {
         k_push_walk_rowsq<2, 4, true><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
       } else if (recin) {
-        static const int no_pairs = PP_LAB_ENV("PP_NO_PAIR_FETCH") != nullptr ? 1 : 0;  // (lab build: one column per fetch)
-        const RecIn rin{ps->s_aos_live.as<char>(), (unsigned*)ps->data[2].p, (float*)ps->data[3].p, 0, ps->rec_rm ? 1 : 0,
-                        no_pairs};
-        if (ps->rec_rm && !elem_ids_seeded && (ps->tile_p & 1) == 0 && (ps->C & 1) == 0 && !no_pairs)
-          k_push_walk_rowsq<3, 4, true, 2><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS, rin);
-        else
-          k_push_walk_rowsq<3, 4, true, 1><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS, rin);
+        const RecIn rin{ps->s_aos_live.as<char>(), ps->s_side_live.as<unsigned>(), (unsigned*)ps->data[2].p,
+                        (float*)ps->data[3].p, 0, 1};
+        // (+ 1 KB per wave: the four columns' third members, prec_issue_quad)
+        k_push_walk_rowsq<3, 4, true, true><<<rgrid, kBlock, lds + (size_t)(kBlock / 64) * 1024, st>>>(PP_ROWSQ_ARGS, rin);
         ps->lazy_rec = 2;  // every member but the origin is in the SoA arrays now
       } else {
         k_push_walk_rowsq<3, 4, true><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
@@ -2778,8 +2699,8 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
       g_cnt2_cur ^= 1;
     } else if (rgrid > 0) {
       if (mesh->dim == 2 && recin) {
-        const RecIn rin{ps->s_aos_live.as<char>(), (unsigned*)ps->data[2].p, (float*)ps->data[3].p, zero_z,
-                        ps->rec_rm ? 1 : 0, 0};
+        const RecIn rin{ps->s_aos_live.as<char>(), ps->s_side_live.as<unsigned>(), (unsigned*)ps->data[2].p,
+                        (float*)ps->data[3].p, zero_z, ps->rec_rm ? 1 : 0};
         k_push_walk_rows<2, 4, true><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS, rin);
         ps->lazy_rec = 2;
       } else if (mesh->dim == 2)
