@@ -1378,10 +1378,10 @@ def main():
                                     "step, calibrated; profiles/traffic_%s.json)" % a.workload,
                     "scope": "whole step: every kernel between two steps' first launches (HIP events on the "
                              "library stream)",
-                    "kernel": "whole step; its longest launches (profiles/r04_%s_kernel_stats.csv): the record-fed %s, "
-                              "then k_move_pack_rm<4> (the re-layout's one data pass: 64-B records, row-major inside a "
-                              "chunk, stored as runs)" % (
-                                  "c5_1m_32M" if a.workload == "c5" else a.workload,
+                    "kernel": "whole step; its longest launches (profiles/r05_%s_kernel_stats.csv): the record-fed %s, "
+                              "then k_move_pack_rm<2> (the re-layout's one data pass: 32-B records + the third member "
+                              "beside them, row-major inside a chunk, stored as runs)" % (
+                                  "c5_virtual8" if a.workload == "c5" else a.workload,
                                   "k_push_walk_rowsq<3> (+ k_walk_pending<3>)" if w["dim"] == 3 else "k_push_walk_rows<2>"),
                     "kernel_ms": sms, "bytes_per_particle": bpp,
                     "phases": {
