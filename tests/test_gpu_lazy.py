@@ -1,6 +1,6 @@
 """The deferred second pass of the full re-layout and the record-fed fused push (DESIGN "Rebuild: the
 record-fed push"; pp_ps::lazy_rec).  After pp_ps_rebuild_commit / _scatter the particles of a pseudoXGCm-typed
-structure stay in the move's 64-B staging records; the next pp_push_search reads them there, anything else
+structure stay in the move's 32-B staging records (+ the third member beside them); the next pp_push_search reads them there, anything else
 makes the library run the deferred pass first.  Whatever the order of calls, a caller must see exactly what
 the reference defines -- checked against the CPU oracle (test/pseudoXGCm.cpp:504-534, scs/SCS_rebuild.h:122-314)."""
 import numpy as np
@@ -161,4 +161,46 @@ def test_record_fed_push_2d(ppo, synth, capi, look, seeded):
         assert np.array_equal(ppo.gyro_scatter(mo, po, bo), wb.to_host()), step
         if look == "after_rebuild":
             _same_population(po, pg)
+    _same_population(po, pg)
+
+
+@pytest.mark.parametrize("dim", [3, 2])
+@pytest.mark.parametrize("C", [32, 12, 6, 1])
+def test_record_fed_push_other_chunk_heights(ppo, synth, capi, C, dim):
+    """The 32-B records and their side words at chunk heights other than 64: a multiple of four takes the
+    cooperative four-column fetch (tets) with rows of two tiles in one wave, the others make the library run the
+    deferred pass before the push (tets) or read the records lane by lane (triangles).  Eight steps without looking
+    at a member, deletions on the way, every member by particle id at the end."""
+    if dim == 3:
+        pop = common.population_3d(synth, n_b=4, n_theta=16, n_planes=8, num_ptcls=5000)
+    else:
+        pop = common.population_2d(synth, n_b=10, n_theta=40, num_ptcls=5000)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM, C=C)
+    mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM, C=C)
+    common.set_shuffling(po, pg, on=False)
+    rng = np.random.default_rng(C + dim)
+    for step in range(8):
+        if dim == 3:
+            ids_o = _oracle_step(ppo, mo, po, 5.0)
+        else:
+            ppo.elliptical_push(po, mo, H, K, D, 5.0, trig=1)
+            ids_o = ppo.search_mesh_2d(mo, po, looplimit=200)[1]
+        ids_g = capi.DevArray(max(pg.capacity(), 1), np.int32)
+        if dim == 2:
+            ids_g.fill_bytes(0xff)
+        capi.push_search(mg, pg, H, K, D, 5.0, ids_g, seeded=False, looplimit=200)
+        if step in (2, 5):  # delete by SLOT-independent rule: particles whose new element is in a random tenth
+            gone = rng.random(len(pop["e2v"])) < 0.1
+            ids_o = ids_o.copy()
+            live = ids_o >= 0
+            ids_o[live & gone[np.clip(ids_o, 0, None)]] = -1
+            h = ids_g.to_host()
+            live = h >= 0
+            h[live & gone[np.clip(h, 0, None)]] = -1
+            ids_g = capi.DevArray.from_host(h)
+        ppo.update_positions(po)
+        po.rebuild(ids_o)
+        pg.rebuild_commit(ids_g, 0, 1)
+        assert po.nPtcls() == pg.nPtcls() > 0
+        _layouts_equal(po, pg)
     _same_population(po, pg)
