@@ -18,6 +18,6 @@ for rep in 1 2 3; do
   done
 done
 for rep in 1 2; do
-  echo "c5 (one rank, 32 M over 998 400 tets) old"; run $1 --workload c5 --particles 32000000 --steps 8
+  echo "c5 (one rank) old"; run $1 --workload c5 --particles 32000000 --steps 8
   echo "c5 new"; run $2 --workload c5 --particles 32000000 --steps 8
 done
