@@ -277,7 +277,7 @@ struct pp_ps {
   // result of the previous search): check_initial_parents is skipped
   bool trust_origins = false;
   // Deferred second pass of the full re-layout (DESIGN "Rebuild: the record-fed push").  After a rebuild
-  // with the fused updatePtclPositions the particles sit in the 64-B staging records of the move's first
+  // with the fused updatePtclPositions the particles sit in the 32-B staging records (+ side word) of the move's first
   // pass (s_aos_live, indexed by NEW slot); the pass that copies them into the SoA arrays is not run.
   //   lazy_rec == 1: every travelling member is in the records, the SoA arrays are stale;
   //   lazy_rec == 2: the fused push consumed the records (pp_search.hip: RECIN) and wrote every member
@@ -294,7 +294,7 @@ struct pp_ps {
   pp::DevBuf s_side, s_side_live;
   // Position of a slot's record in s_aos_live.  rec_rm: ROW-MAJOR inside a chunk -- the record of (row r, column p)
   // of chunk c is number pp_rec_row0(chunk_start[c], c, r, chunk_width[c], C) + p, so the particles of a row
-  // (consecutive ranks of one element) are consecutive 64-B records and the re-layout's scattered stores leave as
+  // (consecutive ranks of one element) are consecutive records and the re-layout's scattered stores leave as
   // runs instead of single records (round 4); else the record index is the slot.  d_erec0 / s_erec0: first record
   // of every element's row in the current / the new layout.
   bool rec_rm = false;
