@@ -240,7 +240,8 @@ __global__ void k_move_pack_rm(int capacity, const int* __restrict__ new_idx, Ra
   // XCD takes a contiguous eighth of the blocks (the grid is a multiple of 16)
   // (round 5, same box: c3 0.57 -> 0.53 ms, 2dc3 0.59 -> 0.54)
   const unsigned nb = gridDim.x - hot_blocks;
-  const unsigned bid = (blockIdx.x & 7u) * (nb >> 3) + ((blockIdx.x - hot_blocks) >> 3);
+  const unsigned bid = (nb & 7u) ? blockIdx.x - hot_blocks  // (a grid that is no multiple of 8: the hardware's order)
+                                 : (blockIdx.x & 7u) * (nb >> 3) + ((blockIdx.x - hot_blocks) >> 3);
   if (blockIdx.x < hot_blocks) {
     // (pp_ps::hot; `capacity` ends the main blocks' slots where these columns begin) 256 columns of the over-full
     // row: one run of up to 16 KB.  The first blocks of the grid, as in the histogram.
