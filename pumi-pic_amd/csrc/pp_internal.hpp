@@ -272,6 +272,11 @@ struct pp_ps {
   // none): x_tgt after a fused updatePtclPositions of the in-place rebuild.  Cleared without a pass
   // when the next fused push overwrites the member; any other access materialises the zeros first.
   int zero_pending = -1;
+  // the THIRD component of member lazy_xt is logically zero and its plane holds old values: the 2-D record-fed push
+  // writes two components of x_tgt, the third one is zero since the fused updatePtclPositions and is never written --
+  // the next committing re-layout packs a zero for it, anything else writes the plane first (ps_zeros).  Round 5: the
+  // push used to write those zeros and the pack to read them back, 160 MB per step of the 2-D literal.
+  bool zero_z_pending = false;
   // pp_ps_set_origin_trust: the caller vouches that every live particle's position lies in the element
   // the fused push starts from (true when the structure was rebuilt from, or the ids are, the unmodified
   // result of the previous search): check_initial_parents is skipped
@@ -405,7 +410,7 @@ const int* group_chunk(const pp_ps* ps);  // d_group_chunk (SCS, chunk height 64
 int scan_excl_i32(DevBuf& scratch, int n, const int* in, int* out, int* total_dev);
 const int* search_not_found_dev();  // pp_search.hip: device address of the last pp_push_search's not_found counter
 inline int ps_ready(const pp_ps* ps) {
-  return (ps && (ps->zero_pending >= 0 || ps->lazy_rec)) ? ps_materialize(const_cast<pp_ps*>(ps)) : PP_OK;
+  return (ps && (ps->zero_pending >= 0 || ps->lazy_rec || ps->zero_z_pending)) ? ps_materialize(const_cast<pp_ps*>(ps)) : PP_OK;
 }
 // pp_ps_rebuild_scatter with one more promise: member m_xtgt of every NEW particle is zero (arrivals of a
 // migration that packed with the commit) -- the rebuild may then defer its second pass as if there were none

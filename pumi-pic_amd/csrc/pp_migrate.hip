@@ -285,6 +285,10 @@ int build_rec_table(const pp_ps* ps, RecTable& t, int commit_x = -1, int commit_
                                    commit_x == ps->lazy_x && commit_xt == ps->lazy_xt;
   if (!shape_only && !origin_only_missing)
     if (int rc = pp::ps_ready(ps)) return rc;
+  // (the committed record reads all three components of member commit_xt: a third one that is only logically zero --
+  // after a 2-D record-fed push -- is written now)
+  if (!shape_only && ps->zero_z_pending)
+    if (int rc = pp::ps_zeros(const_cast<pp_ps*>(ps))) return rc;
   int nw = 0;
   for (int m = 0; m < ps->nmembers; ++m) {
     const int s = ps->member_map[m == commit_x ? commit_xt : m];

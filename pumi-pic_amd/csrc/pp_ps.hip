@@ -1137,8 +1137,10 @@ bool no_lazy_unpack() {
   return off;
 }
 // `side_member` >= 0: that member (one 4-byte component) travels beside the record (WordTable::side_src / side_dst).
+// `zero_z`: component 2 of member commit_xt's arrays is logically zero (pp_ps::zero_z_pending): the word that
+// would read it gets a null source -- the pack stores 0.
 int build_word_table(const pp_ps* ps, const void* const* src, int64_t src_stride, int64_t dst_stride,
-                     int commit_x, int commit_xt, WordTable& wt, int side_member = -1) {
+                     int commit_x, int commit_xt, WordTable& wt, int side_member = -1, bool zero_z = false) {
   wt = WordTable{};
   for (int m = 0; m < ps->nmembers; ++m) {
     const int b = ps->member_bytes[m];
@@ -1159,6 +1161,7 @@ int build_word_table(const pp_ps* ps, const void* const* src, int64_t src_stride
       }
       const int sm = (m == commit_x) ? commit_xt : m;  // fused updatePtclPositions
       const char* sp = (const char*)src[sm] + ((size_t)cc * src_stride) * b;
+      if (zero_z && m == commit_x && cc == 2 && b == 8) sp = nullptr;
       if (b == 8) {
         if (wt.n8 >= kMax8) return 0;
         wt.src8[wt.n8] = sp;
@@ -1594,7 +1597,8 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     if (have_old && old_grid > 0) {
       const void* srcs[8];
       for (int m = 0; m < ps->nmembers; ++m) srcs[m] = ps->data[m].p;
-      NQ = build_word_table(ps, srcs, ps->stride, swap_stride, commit_x, commit_xt, wt);
+      const bool zero_z = ps->zero_z_pending && commit_x >= 0 && commit_x == ps->lazy_x && commit_xt == ps->lazy_xt;
+      NQ = build_word_table(ps, srcs, ps->stride, swap_stride, commit_x, commit_xt, wt, -1, zero_z);
       // x_tgt <- 0 of the fused updatePtclPositions stays pending (pp_ps::zero_pending): the next fused
       // push overwrites the member, anything else materialises the zeros first.  24 of the 60 bytes
       // pass 2 would write per particle.
@@ -1609,7 +1613,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       if (defer_unpack) {
         // ... as 32-B records: origin, phi, b; the third member (4 bytes) travels beside them (WordTable::side_*) --
         // with it the record would be 36 B, i.e. a 64-B sector per particle, written here and read by the push
-        NQ = build_word_table(ps, srcs, ps->stride, swap_stride, commit_x, commit_xt, wt, 2);
+        NQ = build_word_table(ps, srcs, ps->stride, swap_stride, commit_x, commit_xt, wt, 2, zero_z);
         PP_REQUIRE(NQ == 2 && wt.side_src, "rebuild (internal): the pseudoXGCm record is not 32 bytes + one word");
         wt.nz8 = wt.nz4 = 0;
       }
@@ -1824,6 +1828,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   ps->data.swap(ps->swap);
   std::swap(ps->stride, ps->swap_stride);
   ps->zero_pending = lazy_zero ? commit_xt : -1;
+  ps->zero_z_pending = false;  // (packed as zeros above / written by ps_ready before a non-committing re-layout)
   ps->lazy_rec = 0;
   ps->hot = pp::HotRow{};
   if (defer_unpack) {  // the records of the first pass are what holds the particles now
@@ -2154,6 +2159,14 @@ int ps_materialize(pp_ps* ps) {
   return ps_zeros(ps);
 }
 int ps_zeros(pp_ps* ps) {
+  if (ps->zero_z_pending) {  // the third component of x_tgt after a 2-D record-fed push
+    ps->zero_z_pending = false;
+    const int z = ps->lazy_xt;
+    if (z >= 0 && z < ps->nmembers && ps->member_ncomp[z] == 3 && ps->stride > 0) {
+      const size_t plane = (size_t)ps->stride * ps->member_bytes[z];
+      PP_HIP_CHECK(hipMemsetAsync((char*)ps->data[z].p + 2 * plane, 0, plane, pp::stream()));
+    }
+  }
   const int s = ps->zero_pending;
   if (s < 0) return PP_OK;
   ps->zero_pending = -1;

@@ -184,8 +184,8 @@ __global__ void k_move_pack(int capacity, const int* __restrict__ new_idx, RankT
 #pragma unroll
     for (int i = 0; i < NQ * 2; ++i)
       if (i < t.n8) {
-        const unsigned long long d =
-            __builtin_nontemporal_load((const unsigned long long*)(t.src8[i] + (long long)pid * 8));
+        const unsigned long long d =  // (a null source: a component that is logically zero, pp_ps::zero_z_pending)
+            t.src8[i] ? __builtin_nontemporal_load((const unsigned long long*)(t.src8[i] + (long long)pid * 8)) : 0ull;
         v[2 * i] = (unsigned)d;
         v[2 * i + 1] = (unsigned)(d >> 32);
       }
@@ -268,8 +268,8 @@ __global__ void k_move_pack_rm(int capacity, const int* __restrict__ new_idx, Ra
 #pragma unroll
     for (int i = 0; i < NQ * 2; ++i)
       if (i < t.n8) {
-        const unsigned long long d =
-            __builtin_nontemporal_load((const unsigned long long*)(t.src8[i] + (long long)pid * 8));
+        const unsigned long long d =  // (a null source: a component that is logically zero, pp_ps::zero_z_pending)
+            t.src8[i] ? __builtin_nontemporal_load((const unsigned long long*)(t.src8[i] + (long long)pid * 8)) : 0ull;
         v[2 * i] = (unsigned)d;
         v[2 * i + 1] = (unsigned)(d >> 32);
       }

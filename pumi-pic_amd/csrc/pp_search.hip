@@ -1010,7 +1010,6 @@ struct RecIn {
   const unsigned* side;
   unsigned* id_out;
   float* b_out;
-  int zero_z;  // 2-D: x_tgt is logically zero (pp_ps::zero_pending) -- the push writes its third component too
   int rm;      // records row-major inside a chunk (pp_ps::rec_rm): (row r, column p) of chunk c is record
                // pp_rec_row0(chunk_start[c], c, r, chunk_width[c], C) + p; else the record index is the slot
 };
@@ -1045,7 +1044,7 @@ __device__ __forceinline__ void rows_particle(const PState& s, int pid, int e,
                                               double h, double k, double d, double tol,
                                               double unmoved_sq, int* elem_ids, int seeded,
                                               int looplimit, Counters* cnt, unsigned* id_out = nullptr,
-                                              float* b_out = nullptr, int zero_z = 0) {
+                                              float* b_out = nullptr) {
   if (!s.m) {
     if (DIM == 2 || !seeded) elem_ids[pid] = -1;
     return;
@@ -1062,7 +1061,6 @@ __device__ __forceinline__ void rows_particle(const PState& s, int pid, int e,
     dest.z = 0;
     stg<true>(xt + pid, dest.x);
     stg<true>(xt + stride + pid, dest.y);
-    if (zero_z) stg<true>(xt + 2 * stride + pid, 0.0);
     stg<true>(pphi + pid, (float)rad);
     if (elem == -1) elem = e;
     if (elem == -nelems) {
@@ -1168,7 +1166,7 @@ __global__ void __launch_bounds__(256, OCC)
         const int pid = t_start + p * C;
         const PState s = load(pid, t_rb + p * t_rs);
         rows_particle<DIM>(s, pid, t_e, tct, cache, recs, nelems, xt, stride, pphi, h, k, d, tol,
-                           unmoved_sq, elem_ids, seeded, looplimit, cnt, id_out, b_out, RECIN ? rin.zero_z : 0);
+                           unmoved_sq, elem_ids, seeded, looplimit, cnt, id_out, b_out);
       }
       return;
     }
@@ -1212,14 +1210,14 @@ __global__ void __launch_bounds__(256, OCC)
   for (int p = p0; p < pend; p += G) {
     const int pid = start + p * C;
     rows_particle<DIM>(q[0], pid, e, ct, cache, recs, nelems, xt, stride, pphi, h, k, d, tol,
-                       unmoved_sq, elem_ids, seeded, looplimit, cnt, id_out, b_out, RECIN ? rin.zero_z : 0);
+                       unmoved_sq, elem_ids, seeded, looplimit, cnt, id_out, b_out);
     PState n[G];
     loadg(p + G, n);
 #pragma unroll
     for (int j = 1; j < G; ++j)
       if (p + j < pend)
         rows_particle<DIM>(q[j], pid + j * C, e, ct, cache, recs, nelems, xt, stride, pphi, h, k, d, tol,
-                           unmoved_sq, elem_ids, seeded, looplimit, cnt, id_out, b_out, RECIN ? rin.zero_z : 0);
+                           unmoved_sq, elem_ids, seeded, looplimit, cnt, id_out, b_out);
 #pragma unroll
     for (int j = 0; j < G; ++j) q[j] = n[j];
   }
@@ -2612,12 +2610,13 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
   const bool recin = ((mesh->dim == 3 && wq > 0 && quads_ok) || (mesh->dim == 2 && wq == 0)) &&
                      ps->capacity > 0 && ps->num_ptcls > 0 && ps->ntiles_max > 0 &&
                      pp::lazy_push_ok(ps, m_x, m_xtgt, m_b, m_phi);
-  int zero_z = 0;
+  bool z_stays_zero = false;
   if (recin) {
-    // (a 2-D push leaves the third component of x_tgt alone: when x_tgt is only logically zero the
-    // record-fed kernel writes that component too, for every live particle -- no fill of the member)
+    // (a 2-D push writes two components of x_tgt: when x_tgt is only logically zero the third one STAYS logically
+    // zero -- pp_ps::zero_z_pending, set behind the launch below: no fill of the member, no store per particle, and
+    // the next committing re-layout packs a zero instead of reading the plane)
     if (mesh->dim == 2 && ps->zero_pending == ps->member_map[m_xtgt]) {
-      zero_z = 1;
+      z_stays_zero = true;
       ps->zero_pending = -1;
     }
     if ((rc = pp::ps_zeros(ps))) return rc;
@@ -2676,7 +2675,7 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
         k_push_walk_rowsq<2, 4, true><<<rgrid, kBlock, lds, st>>>(PP_ROWSQ_ARGS);
       } else if (recin) {
         const RecIn rin{ps->s_aos_live.as<char>(), ps->s_side_live.as<unsigned>(), (unsigned*)ps->data[2].p,
-                        (float*)ps->data[3].p, 0, 1};
+                        (float*)ps->data[3].p, 1};
         // (+ 1 KB per wave: the four columns' third members, prec_issue_quad)
         k_push_walk_rowsq<3, 4, true, true><<<rgrid, kBlock, lds + (size_t)(kBlock / 64) * 1024, st>>>(PP_ROWSQ_ARGS, rin);
         ps->lazy_rec = 2;  // every member but the origin is in the SoA arrays now
@@ -2700,9 +2699,10 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
     } else if (rgrid > 0) {
       if (mesh->dim == 2 && recin) {
         const RecIn rin{ps->s_aos_live.as<char>(), ps->s_side_live.as<unsigned>(), (unsigned*)ps->data[2].p,
-                        (float*)ps->data[3].p, zero_z, ps->rec_rm ? 1 : 0};
+                        (float*)ps->data[3].p, ps->rec_rm ? 1 : 0};
         k_push_walk_rows<2, 4, true><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS, rin);
         ps->lazy_rec = 2;
+        ps->zero_z_pending = z_stays_zero;
       } else if (mesh->dim == 2)
         k_push_walk_rows<2, 4><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS);
       else
