@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 5: some of the PP_* switches this script sets were deleted together with the variants they selected -- the
+# script is kept as the record of how that round's numbers were taken; tools/gpu_test_matrix.sh is the live matrix)
 # Round-4 measurements (run on the GPU box): bench lines, per-kernel rocprof stats, HBM traffic counters
 # with their calibration run.  Output: gpurun_out/r04_m/ (copied to profiles/r04_*).
 set -u

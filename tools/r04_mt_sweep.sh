@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 5: some of the PP_* switches this script sets were deleted together with the variants they selected -- the
+# script is kept as the record of how that round's numbers were taken; tools/gpu_test_matrix.sh is the live matrix)
 # c2mt: the packed Moeller-Trumbore walk under its two knobs, and the unpacked form (same box)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 export PP_BENCH_NO_COLD=1

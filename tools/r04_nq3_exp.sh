@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 5: some of the PP_* switches this script sets were deleted together with the variants they selected -- the
+# script is kept as the record of how that round's numbers were taken; tools/gpu_test_matrix.sh is the live matrix)
 # EXPERIMENT: duration of the FIRST row-major pack of a c3 run with 48-B records (PP_DBG_NQ3=1; the push then reads
 # them at the wrong stride: timing of that one kernel only) against the 64-B records as shipped.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r04_nq3; mkdir -p $O

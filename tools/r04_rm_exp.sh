@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 5: some of the PP_* switches this script sets were deleted together with the variants they selected -- the
+# script is kept as the record of how that round's numbers were taken; tools/gpu_test_matrix.sh is the live matrix)
 # EXPERIMENT: duration of the FIRST k_move_pack of a c3 run with (1) row-major staging records + block-level
 # transpose, (2) block-level transpose only, (0) as shipped.  Mode 1 corrupts the structure: timing only.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r04_rm; mkdir -p $O
