@@ -35,7 +35,7 @@ void updatePtclPositions(PS* ptcls) {
   ps::parallel_for(ptcls, updatePtclPos);
 }
 
-void rebuild(p::Mesh& picparts, PS* ptcls, p::Distributor& dist, o::LOs elem_ids, const bool output) {
+void rebuild(p::Mesh& picparts, PS* ptcls, p::Distributor<>& dist, o::LOs elem_ids, const bool output) {
   (void)output;
   updatePtclPositions(ptcls);
   // (the reference's driver builds `dist` and its migrate_lb_ptcls then uses the world form; here the subset is
@@ -43,7 +43,7 @@ void rebuild(p::Mesh& picparts, PS* ptcls, p::Distributor& dist, o::LOs elem_ids
   pumipic::migrate_lb_ptcls(picparts, ptcls, elem_ids, 1.05, 0.5, &dist);
 }
 
-void search(p::Mesh& picparts, PS* ptcls, p::Distributor& dist, bool output) {
+void search(p::Mesh& picparts, PS* ptcls, p::Distributor<>& dist, bool output) {
   o::Mesh* mesh = picparts.mesh();
   Omega_h::LO maxLoops = 200;
   const auto psCapacity = ptcls->capacity();
@@ -281,7 +281,7 @@ int main(int argc, char** argv) {
   std::vector<int> dist_ranks(1, comm_rank);
   if (!getenv("PP_DIST_SELF_ONLY"))
     for (int r : picparts.bufferedRanks(picparts.dim())) dist_ranks.push_back(r);
-  p::Distributor dist((int)dist_ranks.size(), dist_ranks.data(), world);
+  p::Distributor<> dist((int)dist_ranks.size(), dist_ranks.data(), world);
 
   // Build gyro avg mappings
   const auto rmax = 0.038;

@@ -1,0 +1,3 @@
+// compat/Omega_h_array_ops.hpp -- see compat/Omega_h_mesh.hpp (not Omega_h: the names the reference drivers spell).
+#pragma once
+#include "Omega_h_mesh.hpp"

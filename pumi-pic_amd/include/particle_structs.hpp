@@ -19,6 +19,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <climits>
+#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
@@ -40,6 +41,64 @@ namespace pumipic {
 typedef int lid_t;
 typedef long int gid_t;
 
+// Memory / execution space tags (support/ppTypes.h:13-30: DefaultMemSpace = the default execution space's memory
+// space).  There is one space here -- the MI355X the library was initialised on -- so the tags carry no behaviour;
+// they exist so that `ParticleStructure<Types, MemSpace>`, `Distributor<Space>` and `PS::execution_space` spell the
+// same in user code.
+struct DeviceSpace {
+  typedef DeviceSpace memory_space;
+  typedef DeviceSpace execution_space;
+  typedef DeviceSpace device_type;
+  static const char* name() { return "HIP (gfx950)"; }
+};
+struct HostSpace {
+  typedef HostSpace memory_space;
+  typedef HostSpace execution_space;
+  typedef HostSpace device_type;
+  static const char* name() { return "Host"; }
+};
+typedef DeviceSpace DefaultMemSpace;
+
+// support/ppPrint.h:20-38, ppPrint.cpp:5-34: the library's two output streams and the printf-style writers on them
+// (printInfo is silent inside device code, as the reference's is)
+inline FILE*& pp_stdout_ref() {
+  static FILE* f = stdout;
+  return f;
+}
+inline FILE*& pp_stderr_ref() {
+  static FILE* f = stderr;
+  return f;
+}
+inline FILE* getStdout() { return pp_stdout_ref(); }
+inline FILE* getStderr() { return pp_stderr_ref(); }
+inline void setStdout(FILE* out) {
+  if (!out) abort();  // assert(out != NULL)
+  pp_stdout_ref() = out;
+}
+inline void setStderr(FILE* err) {
+  if (!err) abort();
+  pp_stderr_ref() = err;
+}
+inline void printError(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  fprintf(getStderr(), "[ERROR]");
+  vfprintf(getStderr(), fmt, ap);
+  va_end(ap);
+}
+template <class... Args>
+__host__ __device__ inline void printInfo(const char* fmt, Args... args) {  // (device code has no varargs: a pack)
+#if !defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (sizeof...(Args) == 0)
+    fputs(fmt, getStdout());
+  else
+    fprintf(getStdout(), fmt, args...);
+#else
+  (void)fmt;
+  ((void)args, ...);
+#endif
+}
+
 inline void pp_check(int rc, const char* what) {
   if (rc != PP_OK) {  // the reference aborts on unrecoverable errors (ppAssert.cpp:10-13)
     fprintf(stderr, "%s failed: %s\n", what, pp_last_error());
@@ -59,6 +118,8 @@ class View {
     alloc(n, false);
     if (n) pp_check(fill_(init), "View fill");
   }
+  View(size_t n, T init, const std::string&) : View(n, init) {}  // Omega_h::Write<T>(n, value, name)
+  View(size_t n, const std::string&) { alloc(n, true); }         // Omega_h::Write<T>(n, name)
   // Kokkos::View<T*>(Kokkos::ViewAllocateWithoutInitializing(name), n): for arrays whose every entry is written
   // before it is read (a 50 MB fill per 10 M slots otherwise)
   static View uninitialized(size_t n) {
@@ -107,6 +168,15 @@ class View {
   std::shared_ptr<void> own_;
 };
 
+// support/SupportKK.h:55-100: host array -> device view, device view -> host copy
+template <class T>
+inline void hostToDevice(View<T> view, const T* data) { view.from_host(data); }
+template <class T>
+inline std::vector<T> deviceToHost(View<T> view) {
+  pp_check(pp_sync(), "deviceToHost");
+  return view.to_host();
+}
+
 // ---------------------------------------------------------------- member type lists
 template <typename... Types>
 struct MemberTypes;
@@ -153,6 +223,19 @@ struct MemberMeta<MemberTypes<Types...>> {
 };
 
 // ---------------------------------------------------------------- Segment (ptcls->get<N>())
+// support/Segment.h:29-98.  operator()(pid), (pid,i), (pid,i,j), (pid,i,j,k) by the rank of Type, getComponents(pid)
+// -> SubSegment (Segment.h:101-176: [i], (), (i), (i,j), (i,j,k) of ONE particle).  Components of a member are
+// flattened row-major (T[A][B]: component i*B + j), each component one device array of `stride` slots.
+template <class T>
+struct ExtentsOf {
+  static constexpr int e1 = 1, e2 = 1;
+};
+template <class T, std::size_t A>
+struct ExtentsOf<T[A]> {  // size of one step of the first index = product of the remaining extents
+  static constexpr int e1 = BaseType<T>::size, e2 = ExtentsOf<T>::e1;
+};
+template <typename Type>
+class SubSegment;
 template <typename Type>
 class Segment {
  public:
@@ -161,6 +244,15 @@ class Segment {
   Segment(Base* p, long long stride, int member) : p_(p), stride_(stride), member_(member) {}
   PP_INLINE Base& operator()(const int& pid) const { return p_[pid]; }
   PP_INLINE Base& operator()(const int& pid, const int& i) const { return p_[(long long)i * stride_ + pid]; }
+  PP_INLINE Base& operator()(const int& pid, const int& i, const int& j) const {
+    return p_[(long long)(i * ExtentsOf<Type>::e1 + j) * stride_ + pid];
+  }
+  PP_INLINE Base& operator()(const int& pid, const int& i, const int& j, const int& k) const {
+    return p_[(long long)(i * ExtentsOf<Type>::e1 + j * ExtentsOf<Type>::e2 + k) * stride_ + pid];
+  }
+  PP_INLINE SubSegment<Type> getComponents(const int& particle_index) const {
+    return SubSegment<Type>(p_ + particle_index, stride_);
+  }
   int member() const { return member_; }  // which member of the structure this accessor views
   PP_INLINE Base* data() const { return p_; }
   PP_INLINE long long stride() const { return stride_; }
@@ -169,6 +261,25 @@ class Segment {
   Base* p_;
   long long stride_;
   int member_;
+};
+template <typename Type>
+class SubSegment {
+ public:
+  using Base = typename BaseType<Type>::type;
+  PP_INLINE SubSegment(Base* first, long long stride) : p_(first), stride_(stride) {}
+  PP_INLINE Base& operator[](const int& i) const { return p_[(long long)i * stride_]; }
+  PP_INLINE Base& operator()() const { return p_[0]; }
+  PP_INLINE Base& operator()(const int& i) const { return p_[(long long)i * stride_]; }
+  PP_INLINE Base& operator()(const int& i, const int& j) const {
+    return p_[(long long)(i * ExtentsOf<Type>::e1 + j) * stride_];
+  }
+  PP_INLINE Base& operator()(const int& i, const int& j, const int& k) const {
+    return p_[(long long)(i * ExtentsOf<Type>::e1 + j * ExtentsOf<Type>::e2 + k) * stride_];
+  }
+
+ private:
+  Base* p_;
+  long long stride_;
 };
 
 // MTVs: per-member device arrays [ncomp][n] used to hand new particles to a structure
@@ -228,23 +339,26 @@ inline pp_comm* comm_world() {
 // changes no message; what it keeps is the reference's contract -- index(process) is defined for the listed
 // ranks only -- which ParticleStructure::migrate checks before anything moves (a particle bound for a rank
 // outside the subset is an error here, undefined behaviour there).
+template <typename Space = DefaultMemSpace>
 class Distributor {
  public:
   Distributor() : comm_(nullptr) {}
   explicit Distributor(pp_comm* c) : comm_(c) {}
   Distributor(int nr, const int* rnks, pp_comm* c = nullptr) : comm_(c) { setRanks(nr, rnks); }
-  template <class ViewT, class = decltype(std::declval<const ViewT&>().size())>
+  template <class ViewT, class = decltype(std::declval<const ViewT&>().size()),
+            class = decltype(std::declval<const ViewT&>()[0])>
   explicit Distributor(const ViewT& rnks, pp_comm* c = nullptr) : comm_(c) {
     setRanks(rnks);
   }
+  template <class OtherSpace>
+  Distributor(const Distributor<OtherSpace>& o) : comm_(o.comm_), ranks_(o.ranks_), index_(o.index_) {}
   void setRanks(int nr, const int* rnks) {
     ranks_.assign(rnks, rnks + nr);
     buildMap();
   }
   template <class ViewT>
   void setRanks(const ViewT& rnks) {
-    ranks_.resize(rnks.size());
-    for (size_t i = 0; i < ranks_.size(); ++i) ranks_[i] = rnks[i];
+    set_from(rnks, 0);
     buildMap();
   }
   void buildMap() {
@@ -265,6 +379,19 @@ class Distributor {
   }
 
  private:
+  template <class>
+  friend class Distributor;
+  // a device View is read back; any host container with size() and operator[] is copied
+  template <class ViewT>
+  auto set_from(const ViewT& rnks, int) -> decltype(rnks.to_host(), void()) {
+    const auto h = rnks.to_host();
+    ranks_.assign(h.begin(), h.end());
+  }
+  template <class ViewT>
+  void set_from(const ViewT& rnks, long) {
+    ranks_.resize(rnks.size());
+    for (size_t i = 0; i < ranks_.size(); ++i) ranks_[i] = rnks[i];
+  }
   pp_comm* comm_;
   std::vector<int> ranks_;
   std::map<int, int> index_;
@@ -273,10 +400,13 @@ class Distributor {
 enum PaddingStrategy { PAD_EVENLY = 0, PAD_PROPORTIONALLY = 1, PAD_INVERSELY = 2 };
 
 // ---------------------------------------------------------------- ParticleStructure
-template <class DataTypes>
+template <class DataTypes, typename MemSpace = DefaultMemSpace>
 class ParticleStructure {
  public:
   typedef DataTypes Types;
+  typedef MemSpace memory_space;
+  typedef typename MemSpace::execution_space execution_space;
+  typedef typename MemSpace::device_type device_type;
   typedef View<lid_t> kkLidView;
   typedef View<gid_t> kkGidView;
   typedef MemberTypeViews MTVs;
@@ -287,6 +417,7 @@ class ParticleStructure {
 
   ParticleStructure() : h_(nullptr), name_("ptcls") {}
   virtual ~ParticleStructure() {
+    if (h_ && getenv("PP_DUMP_ON_DELETE")) dumpOnDelete(getenv("PP_DUMP_ON_DELETE"));
     if (h_) (void)pp_ps_destroy(h_);
   }
   const std::string& getName() const { return name_; }
@@ -313,7 +444,7 @@ class ParticleStructure {
   // SellCSigma::migrate / CSR::migrate (scs/SCS_migrate.h:5-222): particles whose new_process is
   // another rank are packed, exchanged over the distributor's communicator and enter the
   // receiver's rebuild as new particles; one rank -> plain rebuild (:20-25)
-  virtual void migrate(kkLidView new_element, kkLidView new_process, Distributor dist = Distributor(),
+  virtual void migrate(kkLidView new_element, kkLidView new_process, Distributor<MemSpace> dist = Distributor<MemSpace>(),
                        kkLidView new_particle_elements = kkLidView(), MTVs new_particle_info = NULL) {
     if (!dist.isWorld() && pp_comm_size(dist.comm()) > 1) {  // every leaving particle goes to a rank of the subset
       // The check is COLLECTIVE: a rank that found a violation and left alone would leave its peers waiting
@@ -437,13 +568,47 @@ class ParticleStructure {
   }
 
  protected:
+  // PP_DUMP_ON_DELETE=<prefix>: a structure writes itself to <prefix>_ps_<name>_r<rank>_<serial>_{meta.txt, mask.u8,
+  // elem.i32, m<k>.bin} when it is deleted -- how the tests read the final state of a driver whose source they
+  // must not touch (the reference's own test/pseudoXGCm.cpp, compiled unchanged: tests/test_gpu_refdrivers.py)
+  void dumpOnDelete(const char* prefix) {
+    static int serial = 0;
+    const pp_ps_info_t i = info();
+    const auto b = MemberMeta<DataTypes>::bytes();
+    const auto c = MemberMeta<DataTypes>::ncomp();
+    char base[1024];
+    snprintf(base, sizeof(base), "%s_ps_%s_r%d_%d", prefix, name_.c_str(), pp_comm_rank(comm_world()), serial++);
+    auto put = [&](const std::string& suffix, const void* data, size_t bytes) {
+      FILE* f = fopen((std::string(base) + suffix).c_str(), "wb");
+      if (!f) return;
+      fwrite(data, 1, bytes, f);
+      fclose(f);
+    };
+    const size_t cap = (size_t)std::max(i.capacity, 1);
+    std::vector<unsigned char> mask(cap);
+    std::vector<int> slot_elem(cap);
+    if (i.capacity > 0)
+      pp_check(pp_ps_layout_to_host(h_, nullptr, nullptr, nullptr, nullptr, mask.data(), slot_elem.data()), "dump");
+    put("_mask.u8", mask.data(), (size_t)i.capacity);
+    put("_elem.i32", slot_elem.data(), (size_t)i.capacity * sizeof(int));
+    for (std::size_t m = 0; m < DataTypes::size; ++m) {
+      std::vector<char> buf((size_t)std::max<int64_t>(i.stride, 1) * c[m] * b[m]);
+      if (i.capacity > 0) pp_check(pp_ps_member_to_host(h_, (int)m, buf.data()), "dump");
+      put("_m" + std::to_string(m) + ".bin", buf.data(), (size_t)i.stride * c[m] * b[m]);
+    }
+    std::stringstream meta;
+    meta << i.capacity << " " << (long long)i.stride << " " << i.num_ptcls << " " << i.num_elems << " " << DataTypes::size;
+    for (std::size_t m = 0; m < DataTypes::size; ++m) meta << " " << b[m] << " " << c[m];
+    meta << "\n";
+    put("_meta.txt", meta.str().data(), meta.str().size());
+  }
   pp_ps* h_;
   std::string name_;
 };
 
-template <class DataTypes>
+template <class DataTypes, typename MemSpace = DefaultMemSpace>
 class SellCSigma;
-template <class DataTypes>
+template <class DataTypes, typename MemSpace = DefaultMemSpace>
 class SCS_Input {
  public:
   typedef View<lid_t> kkLidView;
@@ -468,13 +633,13 @@ class SCS_Input {
   MemberTypeViews p_info;
 };
 
-template <class DataTypes>
-class SellCSigma : public ParticleStructure<DataTypes> {
+template <class DataTypes, typename MemSpace>
+class SellCSigma : public ParticleStructure<DataTypes, MemSpace> {
  public:
   typedef View<lid_t> kkLidView;
   typedef View<gid_t> kkGidView;
   typedef MemberTypeViews MTVs;
-  typedef SCS_Input<DataTypes> Input_T;
+  typedef SCS_Input<DataTypes, MemSpace> Input_T;
   SellCSigma(TeamPolicy& p, lid_t sigma, lid_t vertical_chunk_size, lid_t num_elements,
              lid_t num_particles, kkLidView particles_per_element, kkGidView element_gids,
              kkLidView particle_elements = kkLidView(), MTVs particle_info = NULL) {
@@ -489,6 +654,9 @@ class SellCSigma : public ParticleStructure<DataTypes> {
   }
   lid_t C() const { return this->info().C; }
   lid_t V() const { return this->info().V; }
+  // scs/SellCSigma.h:92: whether rebuild first tries to keep the layout and move only the particles that change
+  // element (reshuffle, SCS_rebuild.h:4-119); default on (:236)
+  void setShuffling(bool newS) { pp_check(pp_ps_set_shuffling(this->h_, newS ? 1 : 0), "setShuffling"); }
 
  private:
   void construct(int C, lid_t sigma, lid_t V, lid_t ne, lid_t np, kkLidView ppe, kkGidView gids,
@@ -515,7 +683,7 @@ class SellCSigma : public ParticleStructure<DataTypes> {
 };
 
 // csr/CSR_input.hpp:10-42
-template <class DataTypes>
+template <class DataTypes, typename MemSpace = DefaultMemSpace>
 class CSR_Input {
  public:
   typedef View<lid_t> kkLidView;
@@ -540,13 +708,13 @@ class CSR_Input {
   MTVs p_info;
 };
 
-template <class DataTypes>
-class CSR : public ParticleStructure<DataTypes> {
+template <class DataTypes, typename MemSpace = DefaultMemSpace>
+class CSR : public ParticleStructure<DataTypes, MemSpace> {
  public:
   typedef View<lid_t> kkLidView;
   typedef View<gid_t> kkGidView;
   typedef MemberTypeViews MTVs;
-  typedef CSR_Input<DataTypes> Input_T;
+  typedef CSR_Input<DataTypes, MemSpace> Input_T;
   CSR(Input_T& in) {  // csr/CSR.hpp:146-156
     this->name_ = in.name;
     construct(in.ne, in.np, in.ppe, in.e_gids, in.particle_elems, in.p_info, in.padding_amount);
@@ -603,8 +771,8 @@ __global__ void ps_parallel_for_kernel_c64(int capacity, const int* __restrict__
   const int e = row_to_element[(c << 6) + (pid & 63)];
   fn(e, pid, (int)mask[pid]);
 }
-template <typename FunctionType, typename DataTypes>
-void parallel_for(ParticleStructure<DataTypes>* ps, FunctionType& fn, std::string = "") {
+template <typename FunctionType, typename DataTypes, typename MemSpace>
+void parallel_for(ParticleStructure<DataTypes, MemSpace>* ps, FunctionType& fn, std::string = "") {
   if (!ps || !ps->handle()) {
     fprintf(stderr, "Structure does not support parallel for\n");
     throw 1;  // ps_for.hpp:28-30
@@ -627,8 +795,6 @@ void parallel_for(ParticleStructure<DataTypes>* ps, FunctionType& fn, std::strin
 // the same PS_LAMBDA on the host copy (particle_structs/test/test_structure.cpp).  Here: a HOST SNAPSHOT with the
 // same read interface (nElems / nPtcls / capacity / numRows, get<N>() -> Segment over host memory, the layout arrays,
 // ps::parallel_for on the host); rebuild / migrate stay with the device structure.
-struct HostSpace {};
-struct DeviceSpace {};
 template <class DataTypes>
 class HostParticleStructure {
  public:
@@ -637,7 +803,8 @@ class HostParticleStructure {
   using DataType = typename MemberTypeAtIndex<N, DataTypes>::type;
   template <std::size_t N>
   using Slice = Segment<DataType<N>>;
-  explicit HostParticleStructure(ParticleStructure<DataTypes>* old) : name_(old->getName()), i_(old->info()) {
+  template <class MemSpace>
+  explicit HostParticleStructure(ParticleStructure<DataTypes, MemSpace>* old) : name_(old->getName()), i_(old->info()) {
     const auto b = MemberMeta<DataTypes>::bytes();
     const auto c = MemberMeta<DataTypes>::ncomp();
     data_.resize(DataTypes::size);
@@ -677,8 +844,8 @@ class HostParticleStructure {
   pp_ps_info_t i_;
   std::vector<std::vector<char>> data_;
 };
-template <typename MSpace, typename DataTypes>
-HostParticleStructure<DataTypes>* copy(ParticleStructure<DataTypes>* old) {
+template <typename MSpace, typename DataTypes, typename MemSpace>
+HostParticleStructure<DataTypes>* copy(ParticleStructure<DataTypes, MemSpace>* old) {
   if (!old || !old->handle()) {
     fprintf(stderr, "Structure does not support copy\n");
     throw 1;  // ps_for.hpp:52-54

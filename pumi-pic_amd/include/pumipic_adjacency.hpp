@@ -28,6 +28,8 @@ typedef long GO;
 typedef double Real;
 typedef int ClassId;
 typedef int Int;
+typedef signed char Byte;
+typedef signed char I8;
 template <class T>
 using Write = pumipic::View<T>;
 template <class T>
@@ -36,9 +38,15 @@ typedef Read<LO> LOs;
 typedef Read<GO> GOs;
 typedef Read<Real> Reals;
 enum { VERT = 0, EDGE = 1, FACE = 2, REGION = 3 };
+// Omega_h::Adj as the drivers read it: a2ab (offsets; empty for a downward adjacency of fixed degree), ab2b (values)
+struct Adj {
+  Read<LO> a2ab, ab2b;
+};
 // Omega_h::parallel_for(n, OMEGA_H_LAMBDA(LO i){...}, name) over a plain index range, on the library's
 // stream (Omega_h_for.hpp); HostWrite / HostRead: a host copy of a device array
 #define OMEGA_H_LAMBDA [=] __host__ __device__
+#define OMEGA_H_DEVICE __host__ __device__ inline
+#define OMEGA_H_INLINE __host__ __device__ inline
 template <class F>
 __global__ void oh_parallel_for_kernel(int n, F f) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -64,10 +72,11 @@ class HostWrite {
   size_t size() const { return h_.size(); }
   T* data() { return h_.data(); }
   pumipic::View<T> write() const {  // Omega_h::Write<T>(HostWrite<T>)
-    pumipic::View<T> v(h_.size());
+    pumipic::View<T> v = pumipic::View<T>::uninitialized(h_.size());
     v.from_host(h_.data());
     return v;
   }
+  operator pumipic::View<T>() const { return write(); }
 
  private:
   std::vector<T> h_;
@@ -116,8 +125,23 @@ class Input {
   pp_comm* comm;
 };
 
+// Omega_h::CommPtr as the drivers use it (`picparts.comm()->rank()`, `lib.world()->size()`); converts to the
+// library's communicator handle
+struct CommPtr {
+  pp_comm* c = nullptr;
+  CommPtr() {}
+  CommPtr(pp_comm* c_) : c(c_) {}
+  operator pp_comm*() const { return c; }
+  const CommPtr* operator->() const { return this; }
+  int rank() const { return pp_comm_rank(c); }
+  int size() const { return pp_comm_size(c); }
+  pp_comm* get_impl() const { return c; }
+  void barrier() const { pp_check(pp_comm_barrier(c), "Comm::barrier"); }
+};
+
 class Mesh {
  public:
+  Mesh() {}  // an empty handle, filled by pumipic::read / move assignment
   // PICparts from an Input (Mesh::Mesh(Input&), src/pumipic_part_construct.cpp:75-118): this object is the
   // part -- its own pp_mesh unless the buffer is FULL -- with the numberings and the exchange plan of
   // reduceCommArray (pp_picpart, include/pumipic_hip.h)
@@ -148,6 +172,11 @@ class Mesh {
     }
     init_part(full_mesh, partition_vector, PP_PART_BFS, PP_PART_BFS, 0, buffer_layers, safe_layers, comm);
   }
+  // (Mesh(Omega_h::Mesh& full_mesh, Omega_h::LOs partition_vector), pumipic_mesh.hpp:27-31: owners in a device array)
+  Mesh(Mesh& full_mesh, const View<int>& partition_vector, pp_comm* comm = nullptr) {
+    pp_check(pp_sync(), "pumipic::Mesh");
+    init_part(full_mesh, partition_vector.to_host(), PP_PART_FULL, PP_PART_FULL, 0, 0, 0, comm);
+  }
   Mesh(int dim, const std::vector<double>& coords, const std::vector<int>& elem2verts,
        const std::vector<int>& class_id) {
     h_ = pp_mesh_create(dim, (int)(coords.size() / dim), coords.data(),
@@ -157,16 +186,86 @@ class Mesh {
     pp_check(pp_mesh_info(h_, &dim_, &nverts_, &nelems_, &nsides_), "pp_mesh_info");
   }
   ~Mesh() {
+    if (h_ && getenv("PP_DUMP_ON_DELETE")) {  // the real tags (scatter fields), see ParticleStructure::dumpOnDelete
+      (void)pp_sync();
+      for (auto& kv : real_tags_) {
+        std::string name = kv.first;
+        for (auto& ch : name)
+          if (ch == ':' || ch == '/') ch = '_';
+        const std::string fn = std::string(getenv("PP_DUMP_ON_DELETE")) + "_tag_" + name + "_r" + std::to_string(rank()) + ".f64";
+        const std::vector<double> h = kv.second.to_host();
+        if (FILE* f = fopen(fn.c_str(), "wb")) {
+          fwrite(h.data(), sizeof(double), h.size(), f);
+          fclose(f);
+        }
+      }
+    }
     if (bal_) (void)pp_balancer_destroy(bal_);
     if (part_) (void)pp_picpart_destroy(part_);
     if (h_ && owns_mesh_) (void)pp_mesh_destroy(h_);
   }
   Mesh(const Mesh&) = delete;
   Mesh& operator=(const Mesh&) = delete;
+  Mesh(Mesh&& o) noexcept { swap(o); }
+  Mesh& operator=(Mesh&& o) noexcept {
+    swap(o);
+    return *this;
+  }
+  void swap(Mesh& o) {
+    std::swap(h_, o.h_);
+    std::swap(owns_mesh_, o.owns_mesh_);
+    std::swap(part_, o.part_);
+    std::swap(bal_, o.bal_);
+    std::swap(dim_, o.dim_);
+    std::swap(nverts_, o.nverts_);
+    std::swap(nelems_, o.nelems_);
+    std::swap(nsides_, o.nsides_);
+    std::swap(comm_, o.comm_);
+    std::swap(owners_, o.owners_);
+    std::swap(safe_, o.safe_);
+    std::swap(gids_, o.gids_);
+    real_tags_.swap(o.real_tags_);
+    int_tags_.swap(o.int_tags_);
+    parent_.swap(o.parent_);
+  }
+  // a part cut from a full mesh that nobody else holds: the part takes the full mesh with it
+  void keep_alive(Mesh&& full_mesh) { parent_ = std::make_shared<Mesh>(std::move(full_mesh)); }
   int dim() const { return dim_; }
   int nverts() const { return nverts_; }
   int nelems() const { return nelems_; }
   int nsides() const { return nsides_; }
+  int nedges() const { return nents(1); }
+  int nfaces() const { return nents(2); }
+  int nregions() const { return dim_ == 3 ? nelems_ : 0; }
+  // Omega_h::Mesh::ask_down(high, low) / get_adj(high, low) / ask_up(low, high) for the pairs the library derives:
+  // element -> vertices / sides (/ edges of a tet), side -> vertices; vertex / side (/ tet edge) -> elements
+  o::Adj ask_down(int high, int low) const {
+    o::Adj a;
+    if (high == dim_ && low == 0) a.ab2b = view<int>(PP_MESH_ELEM2VERTS);
+    else if (high == dim_ && low == dim_ - 1) a.ab2b = view<int>(PP_MESH_ELEM2SIDES);
+    else if (high == dim_ - 1 && low == 0) a.ab2b = view<int>(PP_MESH_SIDE2VERTS);
+    else if (dim_ == 3 && high == 3 && low == 1) a.ab2b = view<int>(PP_MESH_ELEM2EDGES);
+    else if (dim_ == 3 && high == 1 && low == 0) a.ab2b = view<int>(PP_MESH_EDGE2VERTS);
+    else no_adjacency(high, low);
+    return a;
+  }
+  o::Adj get_adj(int from, int to) const { return from > to ? ask_down(from, to) : ask_up(from, to); }
+  o::Adj ask_up(int low, int high) const {
+    o::Adj a;
+    if (low == 0 && high == dim_) {
+      a.a2ab = view<int>(PP_MESH_VERT2ELEMS_OFF);
+      a.ab2b = view<int>(PP_MESH_VERT2ELEMS);
+    } else if (low == dim_ - 1 && high == dim_) {
+      a.a2ab = view<int>(PP_MESH_SIDE2ELEMS_OFF);
+      a.ab2b = view<int>(PP_MESH_SIDE2ELEMS);
+    } else if (dim_ == 3 && low == 1 && high == 3) {
+      a.a2ab = view<int>(PP_MESH_EDGE2ELEMS_OFF);
+      a.ab2b = view<int>(PP_MESH_EDGE2ELEMS);
+    } else {
+      no_adjacency(low, high);
+    }
+    return a;
+  }
   pp_mesh* handle() const { return h_; }
   // read-only device views for user kernels (Omega_h: ask_elem_verts(), coords(),
   // get_array<ClassId>(dim,"class_id"), ask_up(0,dim), measure_elements_real ...)
@@ -206,7 +305,7 @@ class Mesh {
       safe_.from_host(sf.data());
     }
   }
-  pp_comm* comm() const { return comm_ ? comm_ : comm_world(); }
+  CommPtr comm() const { return CommPtr(comm_ ? comm_ : comm_world()); }
   int rank() const { return pp_comm_rank(comm()); }
   int num_ranks() const { return pp_comm_size(comm()); }
   pp_picpart* picpart() const { return part_; }
@@ -314,6 +413,10 @@ class Mesh {
   }
   void set_tag(int edim, const std::string& name, View<double> values) { real_tags_[key(edim, name)] = values; }
   void set_tag(int edim, const std::string& name, View<int> values) { int_tags_[key(edim, name)] = values; }
+  bool has_tag(int edim, const std::string& name) const {
+    return real_tags_.count(key(edim, name)) || int_tags_.count(key(edim, name)) ||
+           (name == "class_id" && edim == dim_);
+  }
   template <class T>
   View<T> get_array(int edim, const std::string& name) {
     return get_array_impl(edim, name, (T*)nullptr);
@@ -343,6 +446,10 @@ class Mesh {
   }
   void ensure_partition(int) {
     if (owners_.size() == 0) partition(comm(), 0);
+  }
+  [[noreturn]] void no_adjacency(int a, int b) const {
+    fprintf(stderr, "pumipic::Mesh: the adjacency %d -> %d of a %d-D mesh is not derived by this library\n", a, b, dim_);
+    exit(EXIT_FAILURE);
   }
   template <class T>
   View<T> view(int which) const {
@@ -392,6 +499,7 @@ class Mesh {
   o::Write<o::GO> gids_;
   std::map<std::string, View<double>> real_tags_;
   std::map<std::string, View<int>> int_tags_;
+  std::shared_ptr<Mesh> parent_;
 };
 
 inline Input::Input(Mesh& mesh, Ownership rule, const std::vector<int>& partition_vector, Method bufferMethod_,
@@ -764,8 +872,8 @@ void setUnsafeProcs(Mesh& mesh, PS* ptcls, o::LOs elems, typename PS::kkLidView 
 // (scs/SCS_migrate.h:20-25) -- the rebuild reads `elems` itself, without the pass that would write the two routing
 // arrays (45 us and two 50 MB arrays per step at 10 M particles).
 template <class PS>
-inline bool migrate_on_one_rank(Mesh& mesh, PS* ptcls, o::LOs elems, const Distributor* dist) {
-  if (pp_comm_size(dist ? dist->comm() : mesh.comm()) != 1) return false;
+inline bool migrate_on_one_rank(Mesh& mesh, PS* ptcls, o::LOs elems, const Distributor<>* dist) {
+  if (pp_comm_size(dist ? dist->comm() : (pp_comm*)mesh.comm()) != 1) return false;
   Timer init_timer;
   RecordTime("migration_init", init_timer.seconds());
   Timer migrate_timer;
@@ -774,7 +882,7 @@ inline bool migrate_on_one_rank(Mesh& mesh, PS* ptcls, o::LOs elems, const Distr
   return true;
 }
 template <class PS>
-void migrate_ptcls(Mesh& mesh, PS* ptcls, o::LOs elems, const Distributor* dist = nullptr) {
+void migrate_ptcls(Mesh& mesh, PS* ptcls, o::LOs elems, const Distributor<>* dist = nullptr) {
   if (migrate_on_one_rank(mesh, ptcls, elems, dist)) return;
   Timer init_timer;
   const size_t cap = (size_t)std::max(ptcls->capacity(), 1);
@@ -783,12 +891,12 @@ void migrate_ptcls(Mesh& mesh, PS* ptcls, o::LOs elems, const Distributor* dist 
   setUnsafeProcs(mesh, ptcls, elems, new_elems, new_procs);
   RecordTime("migration_init", init_timer.seconds());
   Timer migrate_timer;
-  ptcls->migrate(new_elems, new_procs, dist ? *dist : Distributor(mesh.comm()));
+  ptcls->migrate(new_elems, new_procs, dist ? *dist : Distributor<>(mesh.comm()));
   RecordTime("migration", migrate_timer.seconds());
 }
 template <class PS>
 void migrate_lb_ptcls(Mesh& mesh, PS* ptcls, o::LOs elems, float tol, float step_factor = 0.5,
-                      const Distributor* dist = nullptr) {
+                      const Distributor<>* dist = nullptr) {
   pp_balancer* balancer = mesh.ptclBalancerHandle();
   if (!balancer) {
     migrate_ptcls(mesh, ptcls, elems, dist);
@@ -805,7 +913,7 @@ void migrate_lb_ptcls(Mesh& mesh, PS* ptcls, o::LOs elems, float tol, float step
            "ParticleBalancer::repartition");
   RecordTime("migration_balance", balance_timer.seconds());
   Timer migrate_timer;
-  ptcls->migrate(new_elems, new_procs, dist ? *dist : Distributor(mesh.comm()));
+  ptcls->migrate(new_elems, new_procs, dist ? *dist : Distributor<>(mesh.comm()));
   RecordTime("migration", migrate_timer.seconds());
 }
 

@@ -19,7 +19,7 @@ static int fails = 0;
 int main() {
   {  // test/pseudoXGCm.cpp:390-396: self first, then the buffered ranks
     int ranks[4] = {5, 2, 7, 11};
-    p::Distributor d(4, ranks);
+    p::Distributor<> d(4, ranks);
     CHECK(!d.isWorld());
     CHECK(d.num_ranks() == 4);
     for (int i = 0; i < 4; ++i) {
@@ -32,16 +32,16 @@ int main() {
   }
   {  // particle_structs/test/test_migrate.cpp:60-64: min(comm_size, 3) neighbours, duplicates when comm_size < 3
     int neighbors[3] = {0, 1, 1};
-    p::Distributor d(2, neighbors);
+    p::Distributor<> d(2, neighbors);
     CHECK(d.num_ranks() == 2 && d.index(1) == 1 && d.index(0) == 0);
     std::vector<int> v = {4, 9};
     d.setRanks(v);
     CHECK(d.num_ranks() == 2 && d.rank_host(1) == 9 && d.index(9) == 1 && d.index(1) < 0);
-    p::Distributor from_container(v);
+    p::Distributor<> from_container(v);
     CHECK(!from_container.isWorld() && from_container.index(4) == 0);
   }
   {  // the world form names no ranks: rank(i) = i, index(p) = p
-    p::Distributor w;
+    p::Distributor<> w;
     CHECK(w.isWorld());
     CHECK(w.rank_host(6) == 6 && w.rank(3) == 3 && w.index(12) == 12);
   }

@@ -1,0 +1,157 @@
+"""The reference's OWN drivers, compiled unchanged against this library (tools/ref_conformance.py --build, run by
+__graft_entry__.build() where /root/reference exists; the executables under tests/_refdrivers/ travel to the GPU
+box like the library's .so), run on the MI355X.
+
+test/pseudoXGCm.cpp is the reference text byte for byte: its push is the user lambda of test/ellipticalPush.hpp, its
+scatter the user lambdas of test/gyroScatter.hpp (double atomics through ps::parallel_for), its search / rebuild /
+migrate are this library.  The final state (PP_DUMP_ON_DELETE, a hook of the mirror headers -- the driver source
+cannot be touched) must equal, particle by particle, the final state of drivers/pseudoXGCm, the adaptation that
+tests/test_gpu_driver.py checks against the oracle(libm)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRV = os.path.join(ROOT, "pumi-pic_amd", "drivers")
+REFDRV = os.path.join(ROOT, "tests", "_refdrivers")
+
+
+def _need(name):
+    exe = os.path.join(REFDRV, name)
+    if not os.path.exists(exe):
+        pytest.skip("tests/_refdrivers/%s was not built (needs the reference tree at build time)" % name)
+    return exe
+
+
+def _load_ref_dump(prefix, name):
+    import glob
+    metas = sorted(glob.glob("%s_ps_%s_r0_*_meta.txt" % (prefix, name)))
+    assert metas, "no dump of structure %r" % name
+    base = metas[-1][:-len("_meta.txt")]
+    f = open(base + "_meta.txt").read().split()
+    cap, stride, nptcls, ne, nm = (int(v) for v in f[:5])
+    bytes_ncomp = [(int(f[5 + 2 * m]), int(f[6 + 2 * m])) for m in range(nm)]
+    out = dict(cap=cap, stride=stride, n=nptcls, ne=ne,
+               mask=np.fromfile(base + "_mask.u8", dtype=np.uint8)[:cap].astype(bool),
+               elem=np.fromfile(base + "_elem.i32", dtype=np.int32)[:cap], members=[])
+    for m, (b, c) in enumerate(bytes_ncomp):
+        raw = np.fromfile(base + "_m%d.bin" % m, dtype=np.uint8)
+        assert raw.size == stride * b * c
+        out["members"].append(raw.reshape(c, stride * b))
+    return out, bytes_ncomp
+
+
+def _by_id(ids, mask, values):
+    live = np.flatnonzero(mask)
+    order = np.argsort(ids[live], kind="stable")
+    return ids[live][order], np.asarray(values)[..., live[order]]
+
+
+@pytest.mark.parametrize("nptcl,steps", [(2_000_000, 8)])
+def test_reference_pseudoxgcm_source_runs_unchanged(pp, tmp_path, nptcl, steps):
+    exe = _need("pseudoXGCm")
+    s = pp.synth
+    subprocess.check_call(["make", "-C", DRV, "-s"])
+    coords, e2v, cls = s.annulus_tri()
+    mesh_file = str(tmp_path / "annulus.bin")
+    s.write_mesh_bin(mesh_file, 2, coords, e2v, cls)
+    deg, mdl = 0.5, 12
+    args = [mesh_file, str(nptcl), str(mdl), str(steps), str(deg), "0"]
+    ref_prefix, mir_prefix = str(tmp_path / "ref"), str(tmp_path / "mir")
+    r = subprocess.run([exe] + args, env=dict(os.environ, PP_DUMP_ON_DELETE=ref_prefix), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "done" in r.stderr and ("iter %d particles %d" % (steps, nptcl)) in r.stderr, r.stderr[-2000:]
+    assert re.search(r"Ptcl LB <max, min, avg, imb>: %d %d" % (nptcl, nptcl), r.stdout), r.stdout[-1500:]
+    m = subprocess.run([os.path.join(DRV, "pseudoXGCm")] + args, env=dict(os.environ, PP_DRIVER_DUMP=mir_prefix),
+                       capture_output=True, text=True, timeout=900)
+    assert m.returncode == 0, m.stderr[-2000:]
+
+    ref, bn = _load_ref_dump(ref_prefix, "ps")
+    assert bn == [(8, 3), (8, 3), (4, 1), (4, 1), (4, 1)]  # MemberTypes<Vector3d, Vector3d, int, float, float>
+    cap, stride = ref["cap"], ref["stride"]
+    x = np.stack([ref["members"][0][c].view(np.float64)[:cap] for c in range(3)])
+    xt = np.stack([ref["members"][1][c].view(np.float64)[:cap] for c in range(3)])
+    pid = ref["members"][2][0].view(np.int32)[:cap]
+    b = ref["members"][3][0].view(np.float32)[:cap]
+    phi = ref["members"][4][0].view(np.float32)[:cap]
+
+    base = "%s_r0_final" % mir_prefix
+    mcap, mstride, mn = (int(v) for v in open(base + "_meta.txt").read().split())
+    mmask = np.fromfile(base + "_mask.u8", dtype=np.uint8)[:mcap].astype(bool)
+    mx = np.fromfile(base + "_x.f64", dtype=np.float64)
+    mx = np.stack([mx[c * mstride:c * mstride + mcap] for c in range(3)])
+    melem = np.fromfile(base + "_elem.i32", dtype=np.int32)[:mcap]
+    mid = np.fromfile(base + "_id.i32", dtype=np.int32)[:mcap]
+    mb = np.fromfile(base + "_b.f32", dtype=np.float32)[:mcap]
+    mphi = np.fromfile(base + "_phi.f32", dtype=np.float32)[:mcap]
+
+    assert ref["n"] == mn == nptcl and int(ref["mask"].sum()) == nptcl
+    ir, er = _by_id(pid, ref["mask"], ref["elem"])
+    im, em = _by_id(mid, mmask, melem)
+    assert np.array_equal(ir, im), "the two drivers hold different particles"
+    assert np.array_equal(er, em), "%d particles end in another element" % int((er != em).sum())
+    for a, bb in ((x, mx), (b, mb), (phi, mphi)):
+        _, va = _by_id(pid, ref["mask"], a)
+        _, vb = _by_id(mid, mmask, bb)
+        assert np.array_equal(va, vb)
+    _, vt = _by_id(pid, ref["mask"], xt)
+    assert not vt.any()  # updatePtclPositions zeroed the targets
+    # the scatter: the reference's user lambdas (double atomics) against the library's gyro scatter kernel
+    fwd = np.fromfile(ref_prefix + "_tag_0_ptclToMeshScatterFwd_r0.f64")
+    bkwd = np.fromfile(ref_prefix + "_tag_0_ptclToMeshScatterBkwd_r0.f64")
+    sync = np.fromfile(ref_prefix + "_tag_0_ptclToMeshSync_r0.f64")
+    g_f, g_b = np.fromfile(base + "_fwd.f64"), np.fromfile(base + "_bkwd.f64")
+    assert np.array_equal(fwd, g_f) and np.array_equal(bkwd, g_b)
+    assert np.array_equal(sync[0::2], fwd) and np.array_equal(sync[1::2], bkwd)  # gyroSync on one rank
+
+
+def test_reference_pseudoxgcm_small_prints_every_particle(pp, tmp_path):
+    """<= 30 particles: the reference source prints every particle's element after every rebuild through device
+    printf (test/pseudoXGCm.cpp:121-140); particles keep their ids and every particle is reported once per step."""
+    exe = _need("pseudoXGCm")
+    s = pp.synth
+    coords, e2v, cls = s.annulus_tri(n_b=14, n_theta=64)
+    mesh_file = str(tmp_path / "small.bin")
+    s.write_mesh_bin(mesh_file, 2, coords, e2v, cls)
+    r = subprocess.run([exe, mesh_file, "24", "4", "3", "2.0", "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2000:])
+    rows = re.findall(r"Rank 0 Ptcl: (\d+) has Element (\d+) and id (\d+)", r.stdout)
+    assert len(rows) == 3 * 24
+    ids = sorted(int(i) for _, _, i in rows)
+    assert ids == sorted(list(range(24)) * 3) or len(set(ids)) == 24
+    assert all(0 <= int(e) < len(e2v) for _, e, _ in rows)
+
+
+@pytest.mark.parametrize("structure,strat", [(0, 1), (1, 2), (0, 3)])
+def test_reference_ps_combo160_source_runs_unchanged(tmp_path, structure, strat):
+    """performance_tests/ps_combo160.cpp + particle_structs/test/Distribute.cpp, unchanged: 100 pseudo-pushes and 100
+    redistribute + migrate rounds.  The pseudo-push gives every particle a unique (nums, lint) record; the records
+    must survive the 100 rebuilds as a set."""
+    exe = _need("ps_combo160")
+    ne, npt = 5000, 200000
+    prefix = str(tmp_path / "combo")
+    r = subprocess.run([exe, str(ne), str(npt), str(strat), str(structure)],
+                       env=dict(os.environ, PP_DUMP_ON_DELETE=prefix), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "Beginning migrate on structure" in r.stdout
+    name = "Sell-32-ne" if structure == 0 else "ptcls"
+    d, bn = _load_ref_dump(prefix, name)
+    assert bn == [(8, 17), (4, 4), (8, 1)]  # MemberTypes<double[17], int[4], long>
+    cap = d["cap"]
+    assert d["n"] == npt == int(d["mask"].sum())
+    live = d["mask"]
+    lint = d["members"][2][0].view(np.int64)[:cap][live]
+    nums = np.stack([d["members"][1][c].view(np.int32)[:cap][live] for c in range(4)])
+    assert len(np.unique(lint)) == npt  # every record is still there, once
+    for i in range(4):
+        assert np.array_equal(nums[i], 4 * lint.astype(np.int32) + i)
+    elem = d["elem"][live]
+    assert elem.min() >= 0 and elem.max() < ne
+    dbl0 = d["members"][0][0].view(np.float64)[:cap][live]
+    assert np.isfinite(dbl0[lint > 0]).all()

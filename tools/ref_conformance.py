@@ -1,0 +1,83 @@
+"""Compile the reference's driver sources UNCHANGED against this library's headers.
+
+The reference text is read where it lies (/root/reference); nothing of it is copied into the repo.  A translation
+unit is handed to hipcc as it is -- its quote-includes of sibling reference files (pseudoXGCmTypes.hpp,
+ellipticalPush.hpp, gyroScatter.hpp, perfTypes.hpp, Distribute.h) resolve next to it, every library header it names
+(<particle_structs.hpp>, "pumipic_adjacency.hpp", <Omega_h_mesh.hpp>, <Kokkos_Core.hpp>, ...) resolves to
+pumi-pic_amd/include[/compat].  No -I points into the reference tree.
+
+  python tools/ref_conformance.py            # syntax check of every unit, N-of-M report
+  python tools/ref_conformance.py --build    # also link executables into tests/_refdrivers/ (git-ignored; they
+                                             # travel to the GPU box like the library's .so)
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("PUMIPIC_REFERENCE", "/root/reference")
+INC = os.path.join(ROOT, "pumi-pic_amd", "include")
+OUT = os.path.join(ROOT, "tests", "_refdrivers")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-std=c++17", "-O2", "-x", "hip", "-ffp-contract=off", "-fno-fast-math",
+         "-DFP64", "-DPP_USE_HIP", "-Wno-unused-result", "-Wno-unused-value",
+         "-I", os.path.join(INC, "compat"), "-I", INC]
+
+# executable -> the reference translation units it is made of (reference-relative paths)
+UNITS = {
+    "pseudoXGCm": ["test/pseudoXGCm.cpp"],
+    "pseudoPushAndSearch": ["test/pseudoPushAndSearch.cpp"],
+    "ps_combo160": ["performance_tests/ps_combo160.cpp", "particle_structs/test/Distribute.cpp"],
+    "ps_combo264": ["performance_tests/ps_combo264.cpp", "particle_structs/test/Distribute.cpp"],
+}
+
+
+def have_reference():
+    return os.path.isdir(os.path.join(REF, "test"))
+
+
+def syntax_check(rel):
+    """(ok, diagnostics) of `hipcc -fsyntax-only` on the unchanged reference file `rel` (host and device passes)."""
+    cmd = [HIPCC] + FLAGS + ["-fsyntax-only", os.path.join(REF, rel)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    return r.returncode == 0, r.stderr
+
+
+def build(name):
+    os.makedirs(OUT, exist_ok=True)
+    exe = os.path.join(OUT, name)
+    srcs = [os.path.join(REF, rel) for rel in UNITS[name]]
+    cmd = [HIPCC] + FLAGS + srcs + ["-o", exe, "-L", os.path.join(ROOT, "pumi-pic_amd"), "-lpumipic_hip",
+                                   "-Wl,-rpath,$ORIGIN/../../pumi-pic_amd"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    return r.returncode == 0, r.stderr, exe
+
+
+def main():
+    if not have_reference():
+        print("no reference tree at", REF)
+        return 0
+    rels = sorted({rel for v in UNITS.values() for rel in v})
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]
+    if only:
+        rels = [r for r in rels if any(o in r for o in only)]
+    ok_n = 0
+    for rel in rels:
+        ok, err = syntax_check(rel)
+        ok_n += ok
+        print("%-45s %s" % (rel, "compiles unchanged" if ok else "FAILS"))
+        if not ok:
+            errs = [l for l in err.splitlines() if "error" in l]
+            print("\n".join("    " + l for l in errs[:int(os.environ.get("NERR", "25"))]))
+    print("%d of %d reference translation units compile unchanged" % (ok_n, len(rels)))
+    bad = len(rels) - ok_n
+    if "--build" in sys.argv:
+        for name in UNITS:
+            ok, err, exe = build(name)
+            print("%-24s %s" % (name, exe if ok else "LINK FAILS\n" + err[-2000:]))
+            bad += not ok
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
