@@ -223,6 +223,18 @@ int pp_ps_set_shuffling(pp_ps* ps, int mode);
  * pass read the records of the re-layout before it instead of the member arrays (back-to-back rebuilds of a
  * particle type wider than 64 B with no member access in between: performance_tests/ps_combo160.cpp:205-232) */
 int pp_ps_rebuild_stats(const pp_ps* ps, long long* n_in_place, long long* n_full, long long* n_from_records);
+/* What the structure is still holding back (DESIGN "Rebuild: the record-fed push").  A rebuild may leave members in
+ * its staging records (lazy_rec 1 / 2 / 3), a member only logically zero (zero_pending = its storage index, else
+ * -1; zero_z_pending: the third component of x_tgt after a 2-D record-fed push), slot -> element unwritten.
+ * EVERY entry point that reads or exposes member data runs the pending passes first, so none of this is
+ * observable through the API -- tests/test_gpu_state_machine.py holds every export to that, against a twin that
+ * pp_ps_materialize brought up to date before the call. */
+typedef struct pp_ps_deferred_t {
+  int lazy_rec, zero_pending, zero_z_pending, elem_count_valid, slot_elem_valid, hot_row;
+} pp_ps_deferred_t;
+int pp_ps_deferred_state(const pp_ps* ps, pp_ps_deferred_t* out);
+/* run every pending pass now (members to the SoA arrays, pending zeros, slot -> element, group -> chunk) */
+int pp_ps_materialize(pp_ps* ps);
 /* getPIDs ps_for.hpp:65-85: offsets_dev[ne+1], pids_dev[nPtcls] */
 int pp_ps_get_pids(const pp_ps* ps, int* offsets_dev, int* pids_dev);
 /* printMetrics SellCSigma.h:465-524 */
@@ -381,7 +393,13 @@ int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, do
  * pp_memset / pp_free, which drop the transpose themselves) tells the library so: the map then takes
  * the atomic form.  The two maps of one pp_create_gyro_ring_mappings call share one transpose (the
  * reference's projection is the identity, gyroScatter.hpp:125-134); forgetting either leaves the
- * other served. */
+ * other served.
+ * THE CONTRACT IS CHECKED: pp_create_gyro_ring_mappings keeps a sampled content stamp of both maps (4096 entries
+ * at a fixed stride); every 8th scatter through a transpose re-computes it on the device (one 256-thread block,
+ * no host wait) and raises a host-mapped flag when it differs; the next pp_gyro_scatter / pp_ps_rebuild_scatter /
+ * pp_ps_migrate* call that scatters then fails with PP_ESTATE and a message naming the cause -- a map rewritten
+ * wholesale by a caller kernel (what test/pseudoXGCm_scatter.cpp:58-81 does on the host) cannot go unnoticed for
+ * more than eight calls.  A single edited entry may escape the sample: the contract stands, the check is a net. */
 int pp_gyro_map_forget(const int* map_dev);
 /* gyroScatter with the particle radius the reference leaves as a TODO (test/gyroScatter.hpp:184
  * "ptclRadius = ringWidth*1.125; //TODO compute the radius") taken PER PARTICLE, and an optional

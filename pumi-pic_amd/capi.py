@@ -98,6 +98,8 @@ SYMBOLS = {
     "pp_ps_get_pids": (_I, [_V, _V, _V]),
     "pp_ps_set_shuffling": (_I, [_V, _I]),
     "pp_ps_rebuild_stats": (_I, [_V, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "pp_ps_deferred_state": (_I, [_V, C.POINTER(C.c_int * 6)]),
+    "pp_ps_materialize": (_I, [_V]),
     "pp_ps_metrics": (_I, [_V, c_int_p, c_int_p, c_int_p]),
     "pp_ps_swap_members": (_I, [_V, _I, _I]),
     "pp_elliptical_setup": (_I, [_V, _I, _I, _I, _D, _D, _D]),
@@ -515,6 +517,16 @@ class PS:
 
     def set_origin_trust(self, on):
         check(lib().pp_ps_set_origin_trust(self.p, int(bool(on))))
+
+    def deferred_state(self):
+        """dict(lazy_rec, zero_pending, zero_z_pending, elem_count_valid, slot_elem_valid, hot_row)"""
+        a = (C.c_int * 6)()
+        check(lib().pp_ps_deferred_state(self.p, C.byref(a)))
+        return dict(zip(("lazy_rec", "zero_pending", "zero_z_pending", "elem_count_valid", "slot_elem_valid",
+                         "hot_row"), list(a)))
+
+    def materialize(self):
+        check(lib().pp_ps_materialize(self.p))
 
     def get_pids(self):
         i = self.info()

@@ -2397,6 +2397,24 @@ int pp_ps_rebuild_stats(const pp_ps* ps, long long* n_in_place, long long* n_ful
   return PP_OK;
 }
 
+int pp_ps_deferred_state(const pp_ps* ps, pp_ps_deferred_t* out) {
+  PP_REQUIRE(ps && out, "pp_ps_deferred_state: null argument");
+  out->lazy_rec = ps->lazy_rec;
+  out->zero_pending = ps->zero_pending;
+  out->zero_z_pending = ps->zero_z_pending ? 1 : 0;
+  out->elem_count_valid = ps->elem_count_valid ? 1 : 0;
+  out->slot_elem_valid = ps->slot_elem_valid ? 1 : 0;
+  out->hot_row = ps->hot.on ? 1 : 0;
+  return PP_OK;
+}
+int pp_ps_materialize(pp_ps* ps) {
+  PP_REQUIRE(ps, "pp_ps_materialize: null ps");
+  if (int rc = pp::ps_ready(ps)) return rc;
+  (void)pp::slot_elem(ps);
+  (void)pp::group_chunk(ps);
+  return PP_OK;
+}
+
 int pp_ps_layout(const pp_ps* ps, pp_ps_layout_t* out) {
   PP_REQUIRE(ps && out, "pp_ps_layout: null argument");
   out->offsets = ps->d_offsets.as<int>();

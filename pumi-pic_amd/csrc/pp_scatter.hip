@@ -391,6 +391,10 @@ unsigned long long c_mesh_uid = 0;
 unsigned long long c_version = 0;
 int c_gnr = 0, c_down = -1;
 pp::DevBuf* g_ring = nullptr;  // library-lifetime scratch: ring accumulator
+// the field kept for the twin map (pp_gyro_scatter): valid only for the rings it was gathered from -- whoever
+// rewrites g_ring clears f_inv (round-5 advisor: a scatter through a map without a transpose recomputed the rings
+// and the next twin-map call copied the field of the distribution before)
+unsigned long long f_inv = 0;
 struct InvMap {
   const int* key[2];  // forward and backward map of one pp_create_gyro_ring_mappings call
   size_t bytes;
@@ -399,7 +403,56 @@ struct InvMap {
   int gnr, gppr;
   unsigned long long uid = 0;  // unique per transpose (a later one may live at the same address)
   pp::DevBuf off, src;
+  // sampled content stamp of the two maps as pp_create_gyro_ring_mappings wrote them (kStampSamples entries at a
+  // fixed stride): a map that a caller kernel rewrote in place without pp_gyro_map_forget is caught by the check
+  // kernel that rides with every kStampEvery-th scatter through the transpose (include/pumipic_hip.h: the contract)
+  unsigned long long stamp[2] = {0, 0};
+  long long entries = 0;
+  unsigned calls = 0;
 };
+constexpr int kStampSamples = 4096, kStampEvery = 8;
+// pinned, host-mapped: the check kernel raises it, the next scatter call reads it without a device wait
+int* g_map_edited = nullptr;
+__device__ inline unsigned long long stamp_mix(unsigned long long h, unsigned long long v) {
+  h ^= v + 0x9E3779B97F4A7C15ULL + (h << 6) + (h >> 2);
+  return h;
+}
+// one block: order-independent combination (sum of per-sample hashes) of the sampled entries
+__global__ void k_map_stamp(const int* __restrict__ map, long long entries, unsigned long long* __restrict__ out,
+                            unsigned long long expect, int* __restrict__ edited) {
+  __shared__ unsigned long long s_sum;
+  if (threadIdx.x == 0) s_sum = 0;
+  __syncthreads();
+  const long long n = entries < kStampSamples ? entries : kStampSamples;
+  const long long stride = entries / (n > 0 ? n : 1);
+  unsigned long long acc = 0;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x)
+    acc += stamp_mix((unsigned long long)i * 0xD6E8FEB86659FD93ULL, (unsigned long long)(unsigned)map[i * stride]);
+  atomicAdd(&s_sum, acc);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (out) *out = s_sum;
+    if (edited && s_sum != expect) *edited = 1;
+  }
+}
+int map_edit_pending(const char* who) {
+  if (g_map_edited && *(volatile int*)g_map_edited) {
+    *g_map_edited = 0;
+    pp::set_error(std::string(who) + ": a ring map was edited in place after pp_create_gyro_ring_mappings (its sampled "
+                  "content stamp changed) and scatters since then used the stale transpose -- call pp_gyro_map_forget "
+                  "(or write the map through pp_memcpy_h2d / pp_memset) after editing a map");
+    return PP_ESTATE;
+  }
+  return PP_OK;
+}
+int map_stamp_check(const InvMap* inv, const int* v2v) {
+  InvMap* m = const_cast<InvMap*>(inv);
+  if (m->calls++ % kStampEvery != 0 || !g_map_edited) return PP_OK;
+  const int k = m->key[0] == v2v ? 0 : 1;
+  k_map_stamp<<<1, 256, 0, pp::stream()>>>(v2v, m->entries, nullptr, m->stamp[k], g_map_edited);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
 std::vector<InvMap*> g_inv;
 const InvMap* find_inverse(const int* v2v, const pp_mesh* mesh, int gnr, int gppr) {
   for (const InvMap* m : g_inv)
@@ -432,8 +485,10 @@ int gyro_scatter_ride(const pp_mesh* mesh, int nmaps, const int* const* v2v_dev,
   *ride = GyroRide{};
   static const bool off = PP_LAB_ENV("PP_SCATTER_ATOMIC") != nullptr || PP_LAB_ENV("PP_NO_SCATTER_RIDE") != nullptr;
   if (off || mesh->nverts <= 0 || nmaps < 1 || nmaps > 2) return PP_OK;
+  if (int rc = map_edit_pending("gyroScatter (riding with the rebuild)")) return rc;
   const InvMap* inv = find_inverse(v2v_dev[0], mesh, gnr, gppr);
   if (!inv) return PP_OK;
+  if (int rc = map_stamp_check(inv, v2v_dev[0])) return rc;
   if (nmaps == 2 && !(find_inverse(v2v_dev[1], mesh, gnr, gppr) == inv && out_dev[1] != out_dev[0])) return PP_OK;
   const double ringWidth = rmax / gnr;
   const double ptclRadius = ringWidth * 1.125;  // gyroScatter.hpp:184-187
@@ -442,6 +497,7 @@ int gyro_scatter_ride(const pp_mesh* mesh, int nmaps, const int* const* v2v_dev,
   if (!g_ring) g_ring = new pp::DevBuf();
   PP_HIP_CHECK(g_ring->reserve(sizeof(double) * (size_t)std::max(mesh->nverts * gnr, 1)));
   c_ps = nullptr;  // the accumulator no longer belongs to a (structure, version) pair
+  f_inv = 0;
   ride->on = 1;
   ride->nverts = mesh->nverts;
   ride->gnr = gnr;
@@ -469,6 +525,7 @@ int gyro_scatter_counts(const pp_mesh* mesh, const int* cnt_dev, int nmaps, cons
   if (!g_ring) g_ring = new pp::DevBuf();
   PP_HIP_CHECK(g_ring->reserve(sizeof(double) * (size_t)std::max(nverts * gnr, 1)));
   c_ps = nullptr;  // the accumulator no longer belongs to a (structure, version) pair
+  f_inv = 0;
   if (nverts == 0) return PP_OK;
   k_rings_from_adjacency<<<grid_for(nverts), kBlock, 0, st>>>(
       nverts, gnr, mesh->d_vert2elems_off.as<int>(), mesh->d_vert2elems.as<int>(), cnt_dev, ringDown,
@@ -572,7 +629,21 @@ int pp_create_gyro_ring_mappings(const pp_mesh* mesh, double rmax, int gnr, int 
                                                             m->src.as<int>());
     k_inv_sort<<<grid_for(nv), kBlock, 0, st>>>(nv, m->off.as<int>(), m->src.as<int>());
     PP_LAUNCH_CHECK();
-    PP_HIP_CHECK(hipStreamSynchronize(st));  // cnt goes out of scope
+    if (!g_map_edited) {
+      void* hp = nullptr;
+      if (hipHostMalloc(&hp, sizeof(int), hipHostMallocMapped) == hipSuccess) {
+        g_map_edited = (int*)hp;
+        *g_map_edited = 0;
+      }
+    }
+    m->entries = entries;
+    pp::DevBuf stamps;
+    PP_HIP_CHECK(stamps.reserve(2 * sizeof(unsigned long long)));
+    k_map_stamp<<<1, 256, 0, st>>>(forward_map_dev, entries, stamps.as<unsigned long long>(), 0, nullptr);
+    k_map_stamp<<<1, 256, 0, st>>>(backward_map_dev, entries, stamps.as<unsigned long long>() + 1, 0, nullptr);
+    PP_LAUNCH_CHECK();
+    PP_HIP_CHECK(hipMemcpyAsync(m->stamp, stamps.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    PP_HIP_CHECK(hipStreamSynchronize(st));  // cnt, stamps go out of scope
     g_inv.push_back(m);
   }
   return PP_OK;
@@ -598,7 +669,10 @@ int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, do
   PP_HIP_CHECK(s_cnt->reserve(sizeof(int) * (size_t)std::max(ne, 1)));
   PP_HIP_CHECK(s_ring->reserve(sizeof(double) * (size_t)std::max(nverts * gnr, 1)));
   static const bool no_gather = PP_LAB_ENV("PP_SCATTER_ATOMIC") != nullptr;  // (lab build: a map without a transpose)
+  if (int rc = map_edit_pending("pp_gyro_scatter")) return rc;
   const InvMap* inv = no_gather ? nullptr : find_inverse(v2v_dev, mesh, gnr, gppr);
+  if (inv)
+    if (int rc = map_stamp_check(inv, v2v_dev)) return rc;
   const bool have = ps->num_ptcls > 0 && ps->capacity > 0;
   if (!inv || !have) PP_HIP_CHECK(hipMemsetAsync(scatter_w_dev, 0, sizeof(double) * (size_t)nverts, st));
   if (have) {
@@ -627,6 +701,7 @@ int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, do
       k_rings_from_adjacency<<<grid_for(nverts), kBlock, 0, st>>>(
           nverts, gnr, mesh->d_vert2elems_off.as<int>(), mesh->d_vert2elems.as<int>(), cnt, ringDown,
           ringUp, s_ring->as<double>());
+      f_inv = 0;
       c_ps = ps;
       c_mesh = mesh;
       c_mesh_uid = mesh->uid;
@@ -640,7 +715,6 @@ int pp_gyro_scatter(const pp_mesh* mesh, const pp_ps* ps, const int* v2v_dev, do
       // one's, bit for bit.  The first call leaves a copy in the library (the gather's second output), the call
       // for the twin map on the unchanged (structure, version, rings) copies it out.
       static pp::DevBuf* s_field = new pp::DevBuf();
-      static unsigned long long f_inv = 0;
       static const int* f_map = nullptr;
       static int f_gppr = 0;
       if (reuse && f_inv == inv->uid && f_map != v2v_dev && f_gppr == gppr && s_field->bytes >= sizeof(double) * (size_t)nverts) {
@@ -685,6 +759,7 @@ int pp_gyro_scatter_radius(const pp_mesh* mesh, const pp_ps* ps, const double* r
   if (!inv || !have) PP_HIP_CHECK(hipMemsetAsync(scatter_w_dev, 0, sizeof(double) * (size_t)std::max(nverts, 1), st));
   if (!have) return PP_OK;
   c_ps = nullptr;  // the shared ring accumulator no longer holds the count-based rings of a structure
+  f_inv = 0;
   PP_HIP_CHECK(hipMemsetAsync(s_er->p, 0, er_bytes + 16, st));
   const double ringWidth = rmax / gnr;
   if (ps->kind == PP_SCS && ps->ntiles_max > 0) {

@@ -41,8 +41,12 @@ using View = typename detail::ViewOf<T>::type;
 template <class... Props>
 using TeamPolicy = ::pumipic::TeamPolicy;
 
-inline void initialize(int&, char**) { ::pumipic::pp_check(pp_init(-1), "Kokkos::initialize"); }
-inline void initialize() { ::pumipic::pp_check(pp_init(-1), "Kokkos::initialize"); }
+// one process per GPU: the launcher's LOCAL_RANK picks the device (PP_DEVICE overrides)
+inline void initialize() {
+  const int device = getenv("PP_DEVICE") ? atoi(getenv("PP_DEVICE")) : (getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0);
+  ::pumipic::pp_check(pp_init(device), "Kokkos::initialize");
+}
+inline void initialize(int&, char**) { initialize(); }
 inline void finalize() {}
 inline void fence() { ::pumipic::fence(); }
 inline void fence(const std::string&) { ::pumipic::fence(); }
