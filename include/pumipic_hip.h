@@ -57,7 +57,7 @@ int pp_sync(void);
 int pp_peek_hip_error(const char** msg_out);
 int pp_device_count(void);
 /* plain device memory helpers so hosts without a HIP toolchain (ctypes, cgo, JNI) can drive it */
-/* pp_malloc / pp_free are POOLED: a freed block is kept (up to an eighth of the device memory) and handed to the
+/* pp_malloc / pp_free are POOLED: a freed block is kept (up to pp_pool_set_limit bytes) and handed to the
  * next request it fits, without hipFree's device synchronisation -- the per-step arrays of the reference's drivers
  * (Omega_h::Write<LO> elem_ids(capacity, -1) per search, test/pseudoXGCm.cpp:142-146; new_elems / new_procs per
  * migration, src/pumipic_ptcl_ops.hpp:56-60) cost a free-list lookup.  Reuse is ordered by the library stream:
@@ -65,6 +65,11 @@ int pp_device_count(void);
 void* pp_malloc(size_t bytes);
 int pp_free(void* dev);
 int pp_pool_trim(void); /* hand every cached block back to the runtime */
+/* cap of the cache in bytes (default: 1/64 of the device memory, between 1 and 4 GiB; PP_POOL_LIMIT_MB in the
+ * environment; 0 = cache nothing).  pp_malloc memory must be released with pp_free (a block released with hipFree
+ * is recognised when its address comes back and is not cached); call pp_pool_trim before handing the device to
+ * another allocator that needs the memory (torch, RCCL, the caller's own hipMalloc). */
+int pp_pool_set_limit(size_t bytes);
 int pp_pool_stats(size_t* live_bytes, size_t* cached_bytes, long long* hits, long long* misses);
 /* Kokkos::View<T*>(name, n) filled with a value / Omega_h::Write<T>(n, value): `count` items of pattern_bytes
  * (1, 2, 4, 8) each, on the library stream */
@@ -372,7 +377,9 @@ int pp_push_search_counters(int* not_found, int* not_in_elem, int* unmoved_trust
  * host wait: the full re-layout of pp_ps_rebuild* / the migration that follows the search carries the search's
  * not-found count to the host WITH ITS OWN TOTALS (the one host wait a rebuild has anyway), and this call returns
  * it without touching the device.  When the last rebuild of `ps` did not carry it (in-place rebuild, CSR) the
- * counters are read with one host sync, as pp_push_search_counters does. */
+ * structure's counters are read with one host sync.  The count is the STRUCTURE's (every Sell-C-sigma structure owns
+ * its counter sets: searching other structures in between changes nothing); a CSR structure counts in a process-wide
+ * set, and the call fails with PP_ESTATE when another structure was searched after it. */
 int pp_ps_last_search_found(const pp_ps* ps, int* found);
 
 /* ------------------------------------------------------------------ scatter / gather */

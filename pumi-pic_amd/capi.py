@@ -67,6 +67,7 @@ SYMBOLS = {
     "pp_memcpy_d2h": (_I, [_V, _V, _S]),
     "pp_memset": (_I, [_V, _I, _S]),
     "pp_pool_trim": (_I, []),
+    "pp_pool_set_limit": (_I, [_S]),
     "pp_pool_stats": (_I, [C.POINTER(_S), C.POINTER(_S), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "pp_fill": (_I, [_V, _V, _I, _S]),
     "pp_event_create": (_V, []),

@@ -503,16 +503,30 @@ int comm_exchange_records(pp_comm* c, const void* d_send, const std::vector<int>
   if (c->kind == 1) {
     RcclApi* R = rccl();
     PP_NCCL_CHECK(R->GroupStart());
-    for (int p = 0; p < n; ++p) {
+    // An error inside the group must not leave it open (every later RCCL call of the process would be queued into
+    // it and never launch -- round-5 verdict): the first failure is remembered, the group is closed, then reported.
+    ncclResult_t first = ncclSuccess;
+    const char* what = nullptr;
+    for (int p = 0; p < n && first == ncclSuccess; ++p) {
       if (p == c->rank) continue;
-      if (send_counts[(size_t)p])
-        PP_NCCL_CHECK(R->Send((const char*)d_send + sd[(size_t)p] * rec_bytes, (size_t)send_counts[(size_t)p] * rec_bytes,
-                              ncclChar, p, (ncclComm_t)c->nccl, st));
-      if (recv_counts[(size_t)p])
-        PP_NCCL_CHECK(R->Recv((char*)c->d_recv.p + rd[(size_t)p] * rec_bytes, (size_t)recv_counts[(size_t)p] * rec_bytes,
-                              ncclChar, p, (ncclComm_t)c->nccl, st));
+      if (send_counts[(size_t)p]) {
+        first = R->Send((const char*)d_send + sd[(size_t)p] * rec_bytes, (size_t)send_counts[(size_t)p] * rec_bytes,
+                        ncclChar, p, (ncclComm_t)c->nccl, st);
+        what = "ncclSend";
+      }
+      if (first == ncclSuccess && recv_counts[(size_t)p]) {
+        first = R->Recv((char*)c->d_recv.p + rd[(size_t)p] * rec_bytes, (size_t)recv_counts[(size_t)p] * rec_bytes,
+                        ncclChar, p, (ncclComm_t)c->nccl, st);
+        what = "ncclRecv";
+      }
     }
-    PP_NCCL_CHECK(R->GroupEnd());
+    const ncclResult_t end = R->GroupEnd();
+    if (first != ncclSuccess || end != ncclSuccess) {
+      const bool in_group = first != ncclSuccess;
+      set_error(std::string(in_group ? what : "ncclGroupEnd") + " of the particle exchange failed: " +
+                R->GetErrorString(in_group ? first : end) + (in_group ? " (the group was closed)" : ""));
+      return PP_EHIP;
+    }
     return PP_OK;
   }
   if (c->kind == 4) {

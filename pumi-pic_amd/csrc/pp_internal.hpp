@@ -39,6 +39,7 @@ bool initialised();
 void* pool_alloc(size_t bytes);
 int pool_free(void* dev);
 int pool_trim();
+void pool_set_limit(size_t bytes);
 void pool_stats(size_t* live_bytes, size_t* cached_bytes, long long* hits, long long* misses);
 // pp_mesh.hip: derive (once) and return the edges of a tet mesh; PP_EINVAL for a 2-D mesh
 
@@ -319,7 +320,14 @@ struct pp_ps {
   // not_found counter of the most recent pp_push_search as the last full re-layout's totals carried it to the host
   // (-1: not carried): pp_ps_last_search_found
   int search_nf = -1;
+  // the structure's own pair of search counter sets (pp_search.hip: Counters[2], used alternately), the not-found
+  // counter of its most recent pp_push_search and that search's serial number in the process
+  void* cnt2 = nullptr;
+  int cnt2_cur = 0;
+  const int* last_nf_dev = nullptr;
+  unsigned long long searched_serial = 0;
   ~pp_ps() {
+    if (cnt2) (void)hipFree(cnt2);
     if (h_totals) (void)hipHostFree(h_totals);
     if (ev_totals) (void)hipEventDestroy((hipEvent_t)ev_totals);
   }
@@ -408,7 +416,8 @@ const int* group_chunk(const pp_ps* ps);  // d_group_chunk (SCS, chunk height 64
 // pp_ps.hip: exclusive scan of n ints on the library stream (three launches beyond 16 K entries); *total_dev (may be
 // null) receives the sum
 int scan_excl_i32(DevBuf& scratch, int n, const int* in, int* out, int* total_dev);
-const int* search_not_found_dev();  // pp_search.hip: device address of the last pp_push_search's not_found counter
+const int* search_not_found_dev(const pp_ps* ps);  // pp_search.hip: device address of the not_found counter of the structure's last pp_push_search
+unsigned long long search_serial();  // pp_push_search calls of the process so far
 inline int ps_ready(const pp_ps* ps) {
   return (ps && (ps->zero_pending >= 0 || ps->lazy_rec || ps->zero_z_pending)) ? ps_materialize(const_cast<pp_ps*>(ps)) : PP_OK;
 }

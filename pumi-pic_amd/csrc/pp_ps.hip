@@ -1529,7 +1529,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
                           ElemTotalsArgs{totals_in_keys ? 1 : 0, (totals_in_keys && decide_keep) ? 1 : 0, ps->C,
                                          ps->d_element_to_row.as<int>(), ps->d_chunk_width.as<int>(), nullptr},
                           SpecArgs{spec_ok ? 1 : 0, (int)cap_lim, (int)nsl_lim, ps->C_max, decide_keep ? 1 : 0,
-                                   pp::search_not_found_dev()},
+                                   pp::search_not_found_dev(ps)},
                           spec_ok ? &ta_spec : nullptr, /*allow_wide=*/true, h_pin, stamp);
   const bool polling = stamp != 0 && L.totals_on_host;
   if (rc) return rc;
@@ -2469,7 +2469,19 @@ int pp_ps_last_search_found(const pp_ps* ps, int* found) {
     return PP_OK;
   }
   int nf = 0;  // (the rebuild did not carry it: in place, CSR, separate-kernel layout) one host sync
-  if (int rc = pp_push_search_counters(&nf, nullptr, nullptr)) return rc;
+  if (ps->last_nf_dev) {  // the structure's own counter set
+    PP_HIP_CHECK(hipMemcpyAsync(&nf, ps->last_nf_dev, sizeof(int), hipMemcpyDeviceToHost, pp::stream()));
+    PP_HIP_CHECK(hipStreamSynchronize(pp::stream()));
+  } else {
+    // the process-wide set: it is this structure's search only if nothing was searched since
+    PP_REQUIRE(ps->searched_serial != 0, "pp_ps_last_search_found: the structure was never searched with pp_push_search");
+    if (ps->searched_serial != pp::search_serial()) {
+      pp::set_error("pp_ps_last_search_found: another structure was searched since this one (CSR structures share one "
+                    "counter set) -- pass `found` to pp_push_search instead");
+      return PP_ESTATE;
+    }
+    if (int rc = pp_push_search_counters(&nf, nullptr, nullptr)) return rc;
+  }
   *found = nf == 0;
   return PP_OK;
 }

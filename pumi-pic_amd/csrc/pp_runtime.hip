@@ -128,10 +128,28 @@ int pool_free(void* dev) {
   P.live.erase(it);
   P.live_bytes -= sz;
   if (!P.limit) {
+    // Default cap of the cache: 1/64 of the device memory, at least 1 GiB, at most 4 GiB (4 GiB on a 288-GB MI355X:
+    // a hundred per-step arrays of a 10 M-particle driver).  Round 5 kept up to an eighth (36 GB), which other
+    // allocators in the process (torch, RCCL, the caller's hipMalloc) could not reclaim.  PP_POOL_LIMIT_MB in the
+    // environment or pp_pool_set_limit change it.
     size_t fr = 0, tot = 0;
-    P.limit = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot / 8 > ((size_t)1 << 30)) ? tot / 8 : ((size_t)1 << 30);
+    const size_t gib = (size_t)1 << 30;
+    P.limit = (hipMemGetInfo(&fr, &tot) == hipSuccess) ? std::min(std::max(tot / 64, gib), 4 * gib) : gib;
+    if (const char* e = getenv("PP_POOL_LIMIT_MB")) P.limit = (size_t)std::max(0ll, atoll(e)) << 20;
   }
-  if (sz > P.limit) {
+  // (a pp_malloc block that somebody released with hipFree leaves its entry behind; should the runtime hand the
+  //  address out again to ANOTHER allocator and that block come back through pp_free, the recorded size is not the
+  //  block's: ask the runtime what it is before caching it -- round-5 advisor)
+  {
+    void* base = nullptr;
+    size_t real = 0;
+    if (hipMemGetAddressRange((hipDeviceptr_t*)&base, &real, (hipDeviceptr_t)dev) != hipSuccess || base != dev || real < sz) {
+      (void)hipGetLastError();
+      PP_HIP_CHECK(hipFree(dev));
+      return PP_OK;
+    }
+  }
+  if (sz > P.limit || P.limit == 0) {
     PP_HIP_CHECK(hipFree(dev));
     return PP_OK;
   }
@@ -149,6 +167,15 @@ int pool_trim() {
   if (!P.idle.empty()) PP_HIP_CHECK(hipStreamSynchronize(g_stream));
   trim_locked(P, 0);
   return PP_OK;
+}
+void pool_set_limit(size_t bytes) {
+  Pool& P = pool();
+  std::lock_guard<std::mutex> lk(P.mu);
+  P.limit = bytes ? bytes : 1;  // (0 would mean "not chosen yet": one byte caches nothing)
+  if (P.idle_bytes > P.limit) {
+    (void)hipStreamSynchronize(g_stream);
+    trim_locked(P, P.limit / 2);
+  }
 }
 void pool_stats(size_t* live_bytes, size_t* cached_bytes, long long* hits, long long* misses) {
   Pool& P = pool();
@@ -219,6 +246,10 @@ int pp_free(void* dev) {
   return pp::pool_free(dev);
 }
 int pp_pool_trim(void) { return pp::pool_trim(); }
+int pp_pool_set_limit(size_t bytes) {
+  pp::pool_set_limit(bytes);
+  return PP_OK;
+}
 int pp_pool_stats(size_t* live_bytes, size_t* cached_bytes, long long* hits, long long* misses) {
   pp::pool_stats(live_bytes, cached_bytes, hits, misses);
   return PP_OK;

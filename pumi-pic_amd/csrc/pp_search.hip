@@ -1183,7 +1183,7 @@ __global__ void __launch_bounds__(256, OCC)
   // load (the side array is in record order, a row's group of four starts on a 16-byte boundary)
   auto loadg = [&](int p, PState* o) {
     if constexpr (RECIN && DIM == 2) {
-      if (rs == 1 && ((rb + p) & 3) == 0) {
+      if (rs == 1 && ((rb + p) & 3) == 0 && p < pend) {  // (p >= pend: the prefetch past the row -- no load at all)
         const uint4 ids = *(const uint4*)(rin.side + rb + p);
         const unsigned idv[4] = {ids.x, ids.y, ids.z, ids.w};
 #pragma unroll
@@ -2203,12 +2203,14 @@ Counters* g_last_counters = nullptr;  // the set the last pp_push_search added t
 
 // Counters of the deferred-walk kernels: two sets used alternately.  k_walk_pending zeroes the set
 // of the NEXT call, so pp_push_search needs no memset launch (8 us per step in rocprof).
-Counters* g_cnt2 = nullptr;
-int g_cnt2_cur = 0;
-int pair_counters() {
-  if (g_cnt2) return PP_OK;
-  PP_HIP_CHECK(hipMalloc((void**)&g_cnt2, 2 * sizeof(Counters)));
-  PP_HIP_CHECK(hipMemsetAsync(g_cnt2, 0, 2 * sizeof(Counters), pp::stream()));
+// The pair belongs to the STRUCTURE (pp_ps::cnt2): the rebuild that follows a search carries that structure's
+// not-found count to the host (pp_ps_last_search_found) even when other structures were searched in between (the
+// virtual ranks of one process; round-5 advisor: the pair used to be process-wide).
+unsigned long long g_search_serial = 0;  // pp_push_search calls of the process
+int pair_counters(pp_ps* ps) {
+  if (ps->cnt2) return PP_OK;
+  PP_HIP_CHECK(hipMalloc(&ps->cnt2, 2 * sizeof(Counters)));
+  PP_HIP_CHECK(hipMemsetAsync(ps->cnt2, 0, 2 * sizeof(Counters), pp::stream()));
   return PP_OK;
 }
 
@@ -2245,7 +2247,8 @@ int member_ok(const pp_ps* ps, int m, int bytes, int ncomp, const char* what) {
 }  // namespace
 
 namespace pp {
-const int* search_not_found_dev() { return g_last_counters ? &g_last_counters->not_found : nullptr; }
+const int* search_not_found_dev(const pp_ps* ps) { return ps->last_nf_dev; }
+unsigned long long search_serial() { return g_search_serial; }
 }  // namespace pp
 
 extern "C" {
@@ -2644,7 +2647,7 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
       ps->d_mask.as<unsigned char>(), mesh->d_records.p, mesh->d_class_id.as<int>(),             \
       mesh->nelems, PP_MEMBER(ps, m_x, double), PP_MEMBER(ps, m_xtgt, double), ps->stride,       \
       PP_MEMBER(ps, m_b, float), PP_MEMBER(ps, m_phi, float), h, k, d, deg, mesh->tol,           \
-      mesh->unmoved_sq, elem_ids_dev, elem_ids_seeded, looplimit, used, g_cnt2 + (g_cnt2_cur ^ 1)
+      mesh->unmoved_sq, elem_ids_dev, elem_ids_seeded, looplimit, used, (Counters*)ps->cnt2 + (ps->cnt2_cur ^ 1)
 #define PP_ROWSQ_ARGS                                                                            \
   ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(), \
       ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(),                               \
@@ -2652,7 +2655,7 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
       mesh->nelems, PP_MEMBER(ps, m_x, double), PP_MEMBER(ps, m_xtgt, double), ps->stride,       \
       PP_MEMBER(ps, m_b, float), PP_MEMBER(ps, m_phi, float), h, k, d, deg, mesh->tol,           \
       mesh->unmoved_sq, elem_ids_dev, elem_ids_seeded, looplimit, used,                          \
-      g_pending_q.as<PendEntry>(), g_wave_cnt.as<int>(), g_cnt2 + (g_cnt2_cur ^ 1), trust
+      g_pending_q.as<PendEntry>(), g_wave_cnt.as<int>(), (Counters*)ps->cnt2 + (ps->cnt2_cur ^ 1), trust
     // (kernels are built for 4 waves per SIMD: measured fastest on MI355X -- 3-D needs 126 VGPRs, a
     // 96-register build for 5 waves spills and runs 2x slower, 3 waves hide less latency)
     // Two row-tiled variants (measured on MI355X, profiles/r01_c_*):
@@ -2664,8 +2667,8 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
     // PP_WALK_QUEUE=0/1 forces one or the other (A/B knob).
     const int trust = ps->trust_origins ? 1 : 0;
     // (two counter sets used alternately: the kernels of a call clear the set of the next one -- no fill launch)
-    if ((rc = pair_counters())) return rc;
-    used = g_cnt2 + g_cnt2_cur;
+    if ((rc = pair_counters(ps))) return rc;
+    used = (Counters*)ps->cnt2 + ps->cnt2_cur;
     if (rgrid > 0 && wq > 0) {
       const size_t lds = (size_t)(kBlock / 64) * 64 * (mesh->dim == 3 ? 8 : 4) * sizeof(double2);
       const size_t nwaves = (size_t)rgrid * (kBlock / 64);
@@ -2695,7 +2698,7 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
                                                      g_wave_cnt.as<int>(), mesh->d_records.p,
                                                      elem_ids_dev, looplimit, used);
       }
-      g_cnt2_cur ^= 1;
+      ps->cnt2_cur ^= 1;
     } else if (rgrid > 0) {
       if (mesh->dim == 2 && recin) {
         const RecIn rin{ps->s_aos_live.as<char>(), ps->s_side_live.as<unsigned>(), (unsigned*)ps->data[2].p,
@@ -2707,7 +2710,7 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
         k_push_walk_rows<2, 4><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS);
       else
         k_push_walk_rows<3, 4><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS);
-      g_cnt2_cur ^= 1;
+      ps->cnt2_cur ^= 1;
     }
 #undef PP_ROWS_ARGS
 #undef PP_ROWSQ_ARGS
@@ -2733,6 +2736,10 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
   }
   PP_LAUNCH_CHECK();
   g_last_counters = used;
+  ps->searched_serial = ++g_search_serial;
+  // (the structure's own pair; the plain kernels of a CSR structure count in the process-wide set, which the next
+  //  search of ANY structure clears: nothing for a rebuild to carry)
+  ps->last_nf_dev = (ps->kind == PP_SCS && ps->cnt2) ? &used->not_found : nullptr;
   if (found) {
     Counters hc;
     PP_HIP_CHECK(hipMemcpyAsync(&hc, used, sizeof(Counters), hipMemcpyDeviceToHost, st));

@@ -664,8 +664,6 @@ RECIPES = {
     "balancer": (["pp_balancer_repartition_begin"], r_balancer, ("tet", "tri")),
 }
 EXEMPT = {
-    "pp_ps_create_scs": "constructor: no structure exists before the call",
-    "pp_ps_create_csr": "constructor",
     "pp_ps_destroy": "destructor (every test here ends with it, in every state)",
     "pp_ps_deferred_state": "the probe itself",
     "pp_ps_materialize": "the twin's reference operation",
