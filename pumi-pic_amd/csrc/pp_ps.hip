@@ -2474,7 +2474,10 @@ int pp_ps_last_search_found(const pp_ps* ps, int* found) {
     PP_HIP_CHECK(hipStreamSynchronize(pp::stream()));
   } else {
     // the process-wide set: it is this structure's search only if nothing was searched since
-    PP_REQUIRE(ps->searched_serial != 0, "pp_ps_last_search_found: the structure was never searched with pp_push_search");
+    if (ps->searched_serial == 0) {  // never searched with pp_push_search: nothing was cut off
+      *found = 1;
+      return PP_OK;
+    }
     if (ps->searched_serial != pp::search_serial()) {
       pp::set_error("pp_ps_last_search_found: another structure was searched since this one (CSR structures share one "
                     "counter set) -- pass `found` to pp_push_search instead");
