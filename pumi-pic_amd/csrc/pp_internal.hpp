@@ -417,7 +417,8 @@ const int* group_chunk(const pp_ps* ps);  // d_group_chunk (SCS, chunk height 64
 // null) receives the sum
 int scan_excl_i32(DevBuf& scratch, int n, const int* in, int* out, int* total_dev);
 const int* search_not_found_dev(const pp_ps* ps);  // pp_search.hip: device address of the not_found counter of the structure's last pp_push_search
-unsigned long long search_serial();  // pp_push_search calls of the process so far
+unsigned long long search_serial();
+void search_counters_released(const void* cnt2);  // pp_push_search calls of the process so far
 inline int ps_ready(const pp_ps* ps) {
   return (ps && (ps->zero_pending >= 0 || ps->lazy_rec || ps->zero_z_pending)) ? ps_materialize(const_cast<pp_ps*>(ps)) : PP_OK;
 }

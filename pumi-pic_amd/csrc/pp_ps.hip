@@ -2341,6 +2341,11 @@ pp_ps* pp_ps_create_csr(int num_elems, int num_ptcls, const int* ppe_host,
 }
 
 int pp_ps_destroy(pp_ps* ps) {
+  if (ps) {
+    // (queued kernels may still read the structure's buffers; the search's counter sets die with it)
+    (void)hipStreamSynchronize(pp::stream());
+    pp::search_counters_released(ps->cnt2);
+  }
   delete ps;
   return PP_OK;
 }

@@ -2249,6 +2249,10 @@ int member_ok(const pp_ps* ps, int m, int bytes, int ncomp, const char* what) {
 namespace pp {
 const int* search_not_found_dev(const pp_ps* ps) { return ps->last_nf_dev; }
 unsigned long long search_serial() { return g_search_serial; }
+void search_counters_released(const void* cnt2) {  // a structure is destroyed: pp_push_search_counters must not read its sets
+  const Counters* c = (const Counters*)cnt2;
+  if (c && g_last_counters >= c && g_last_counters < c + 2) g_last_counters = nullptr;
+}
 }  // namespace pp
 
 extern "C" {
