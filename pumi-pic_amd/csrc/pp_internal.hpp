@@ -247,6 +247,7 @@ struct pp_ps {
   // slot -> parent element: the row-tiled kernels of the time step never read it, so the SCS re-layout leaves it
   // unwritten (40 MB per 10 M slots) and pp::slot_elem() fills it when something asks
   mutable bool slot_elem_valid = true;
+  mutable bool slot_elem_used = false;  // somebody asked for the table of the CURRENT layout (pp::slot_elem)
   // 64-slot group -> chunk (chunk height 64; pp_ps_iteration): filled on first use after a re-layout
   mutable pp::DevBuf d_group_chunk;
   mutable bool group_chunk_valid = false;
@@ -337,6 +338,7 @@ struct pp_ps {
   const pp::GyroRide* ride = nullptr;  // set for the duration of a pp_ps_rebuild_scatter call (consumed by enqueue_layout)
   bool ride_done = false;
   int wide_skip = 0;  // full re-layouts left before the one-pass layout sort is tried again (it overflowed)
+  int narrow_skip = 0;  // ... before a digit narrower than 2048 is tried again (pp_ps.hip: wide_ndig)
   pp::DevBuf s_ppe, s_keys, s_keys2, s_vals, s_vals2, s_hist, s_chunkw, s_misc, s_rowstart,
       s_newidx, s_offsets2, s_s2c2, s_r2e2, s_e2r2, s_mask2, s_slot2, s_scan, s_cstart2, s_cwidth2, s_aos, s_idx, s_ranknew, s_eslot0, s_scan2;
 };

@@ -486,13 +486,13 @@ __global__ void __launch_bounds__(1024)
                    unsigned long long* fix_keys = nullptr, int* fix_vals = nullptr,
                    const int* __restrict__ wide_hist = nullptr, pp::GyroRide ride = pp::GyroRide{},
                    Totals* host_out = nullptr, int host_stamp = 0,
-                   const int* __restrict__ wide_tail_start = nullptr) {
+                   const int* __restrict__ wide_tail_start = nullptr, int wide_ndig = kWideDigits) {
   if (blockIdx.x > 0) {  // gyroScatter's second stage riding along (pp::GyroRide; its first stage rode k_make_keys)
     pp::gyro_gather_body((blockIdx.x - 1) * 1024 + threadIdx.x, ride.nverts, ride.gppr, ride.off, ride.src, ride.ring,
                          ride.out, ride.out2, (ride.gppr & (ride.gppr - 1)) == 0);  // (the ride is the count-based scatter)
     return;
   }
-  if (fix_keys) wide_fix_tail(ne, npartial, wide_hist, fix_keys, fix_vals, tot, wide_tail_start);
+  if (fix_keys) wide_fix_tail(ne, npartial, wide_hist, fix_keys, fix_vals, tot, wide_tail_start, wide_ndig);
   __shared__ int ssum[16], scnt[16];
   __shared__ int w3[16][3];
   __shared__ int carry[3];
@@ -663,6 +663,245 @@ __global__ void __launch_bounds__(1024)
       if (host_stamp) {
         __threadfence_system();
         __hip_atomic_store(&host_out->pad_[0], host_stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+}
+// k_layout_fused on NB blocks for structures of many chunks (BASELINE configs[3]: 10^6 elements = 15 625 chunks, where
+// the single block spends 51 us on ~20 dependent memory round trips; SCS_buildFns.h:47-153 does these steps with
+// parallel scans).  Block b owns the chunks [b * per, (b + 1) * per).  Two grid barriers among the NB <= 16 blocks
+// (2.2 us each at 16 blocks, profiles/r02_ub_gridbar.txt; the blocks of a launch are dispatched in index order, so
+// the first NB are resident before any rider block):
+//   phase 1  widths off the sorted keys, per-block (sum, non-zero)                      | barrier
+//   phase 2  padding from the global (sum, non-zero); LOCAL exclusive scans of slices / slots / tiles | barrier
+//   phase 3  add the totals of the blocks before; the last block writes the totals (and the host's copy)
+// Block 0 also adds up the per-tile totals of k_make_keys, the last block orders the overflow digit of the one-pass
+// sort first (its keys are the widths of the last chunks, which are that block's).
+__device__ __forceinline__ void layout_grid_barrier(unsigned* counter, unsigned target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other XCDs' stores become visible
+  }
+  __syncthreads();
+}
+__global__ void __launch_bounds__(1024)
+    k_layout_multi(int NB, int nchunks, int C, int V, int TP, int pad_strat, double pad,
+                   int* __restrict__ widths, int* __restrict__ slice_off,
+                   int* __restrict__ chunk_start, int* __restrict__ tile_off, Totals* tot,
+                   int* __restrict__ ntiles_out, SpecArgs sp, int key_bits,
+                   const int* __restrict__ partial, int npartial,
+                   const unsigned long long* keys_sorted, int ne,
+                   unsigned long long* fix_keys, int* fix_vals,
+                   const int* __restrict__ wide_hist, pp::GyroRide ride,
+                   Totals* host_out, int host_stamp,
+                   const int* __restrict__ wide_tail_start, int wide_ndig) {
+  if ((int)blockIdx.x >= NB) {  // gyroScatter's second stage riding along (pp::GyroRide)
+    pp::gyro_gather_body((blockIdx.x - NB) * 1024 + threadIdx.x, ride.nverts, ride.gppr, ride.off, ride.src, ride.ring,
+                         ride.out, ride.out2, (ride.gppr & (ride.gppr - 1)) == 0);
+    return;
+  }
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int per = (nchunks + NB - 1) / NB;
+  const int c0 = min(b * per, nchunks), c1 = min(c0 + per, nchunks);
+  __shared__ int w3[16][3];
+  __shared__ int ssum[16], scnt[16];
+  __shared__ int carry[3];
+  if (b == NB - 1 && fix_keys) wide_fix_tail(ne, npartial, wide_hist, fix_keys, fix_vals, tot, wide_tail_start, wide_ndig);
+  if (b == 0 && partial) {  // totals of the new population: the per-tile sums k_make_keys left
+    int p0 = 0, p1 = 0, p2 = 0;
+    for (int i = t; i < npartial; i += 1024) {
+      p0 += partial[3 * i];
+      p1 += partial[3 * i + 1];
+      p2 += partial[3 * i + 2];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      p0 += __shfl_down(p0, o);
+      p1 += __shfl_down(p1, o);
+      p2 += __shfl_down(p2, o);
+    }
+    if (lane == 0) {
+      w3[wave][0] = p0;
+      w3[wave][1] = p1;
+      w3[wave][2] = p2;
+    }
+    __syncthreads();
+    if (t == 0) {
+      for (int w = 1; w < 16; ++w) {
+        p0 += w3[w][0];
+        p1 += w3[w][1];
+        p2 += w3[w][2];
+      }
+      tot->nonempty += p0;
+      tot->active += p1;
+      tot->n_over += p2;
+    }
+    __syncthreads();
+  }
+  {  // ---- phase 1: the unpadded widths of the own chunks and their (sum, non-zero)
+    int s = 0, c = 0;
+    for (int i0 = c0 + t; i0 < c1; i0 += 4 * 1024) {
+      int w4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * 1024;
+        w4[k] = i < c1 ? (keys_sorted ? (int)keys_sorted[min(i * C + C - 1, ne - 1)] : widths[i]) : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * 1024;
+        if (i < c1) {
+          if (keys_sorted) widths[i] = w4[k];
+          s += w4[k];
+          c += w4[k] > 0;
+        }
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      s += __shfl_down(s, o);
+      c += __shfl_down(c, o);
+    }
+    if (lane == 0) {
+      ssum[wave] = s;
+      scnt[wave] = c;
+    }
+    __syncthreads();
+    if (t == 0) {
+      int S = 0, Cn = 0;
+      for (int w = 0; w < 16; ++w) {
+        S += ssum[w];
+        Cn += scnt[w];
+      }
+      tot->mb[b][0] = S;
+      tot->mb[b][1] = Cn;
+      carry[0] = carry[1] = carry[2] = 0;
+    }
+  }
+  layout_grid_barrier(&tot->bar, (unsigned)NB);
+  int cw_sum = 0, cw_cnt = 0;
+  for (int q = 0; q < NB; ++q) {  // (every thread: 2 * NB cached loads)
+    cw_sum += tot->mb[q][0];
+    cw_cnt += tot->mb[q][1];
+  }
+  const int avg_pad = (pad > 0 && cw_sum > 0 && pad_strat == PP_PAD_EVENLY) ? (int)(cw_sum * pad / cw_cnt) : 0;
+  // ---- phase 2: padding, then the local exclusive scans of the own range
+  constexpr int ITEMS = 4;
+  for (int base = c0; base < c1; base += 1024 * ITEMS) {
+    int v[ITEMS][3];
+    int s0 = 0, s1 = 0, s2 = 0;
+    for (int k = 0; k < ITEMS; ++k) {
+      const int i = base + t * ITEMS + k;
+      v[k][0] = v[k][1] = v[k][2] = 0;
+      if (i < c1) {
+        int w = widths[i];
+        if (pad > 0 && cw_sum > 0) {
+          if (pad_strat == PP_PAD_EVENLY) {
+            if (w > 0) w += avg_pad;
+          } else {
+            w = (int)(w + w * pad);
+          }
+          widths[i] = w;
+        }
+        v[k][0] = w / V + ((w % V) != 0);
+        v[k][1] = w * C;
+        v[k][2] = (w + TP - 1) / TP;
+      }
+      s0 += v[k][0];
+      s1 += v[k][1];
+      s2 += v[k][2];
+    }
+    int i0 = s0, i1 = s1, i2 = s2;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y0 = __shfl_up(i0, o), y1 = __shfl_up(i1, o), y2 = __shfl_up(i2, o);
+      if (lane >= o) {
+        i0 += y0;
+        i1 += y1;
+        i2 += y2;
+      }
+    }
+    if (lane == 63) {
+      w3[wave][0] = i0;
+      w3[wave][1] = i1;
+      w3[wave][2] = i2;
+    }
+    __syncthreads();
+    int o0 = carry[0], o1 = carry[1], o2 = carry[2];
+    for (int w = 0; w < wave; ++w) {
+      o0 += w3[w][0];
+      o1 += w3[w][1];
+      o2 += w3[w][2];
+    }
+    int r0 = o0 + i0 - s0, r1 = o1 + i1 - s1, r2 = o2 + i2 - s2;
+    for (int k = 0; k < ITEMS; ++k) {
+      const int i = base + t * ITEMS + k;
+      if (i < c1) {
+        slice_off[i] = r0;
+        chunk_start[i] = r1;
+        tile_off[i] = r2;
+      }
+      r0 += v[k][0];
+      r1 += v[k][1];
+      r2 += v[k][2];
+    }
+    __syncthreads();
+    if (t == 1023) {
+      carry[0] = r0;
+      carry[1] = r1;
+      carry[2] = r2;
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    tot->mb[b][2] = carry[0];
+    tot->mb[b][3] = carry[1];
+    tot->mb[b][4] = carry[2];
+  }
+  layout_grid_barrier(&tot->bar, 2u * (unsigned)NB);
+  // ---- phase 3: the totals of the blocks before this one
+  int o0 = 0, o1 = 0, o2 = 0;
+  for (int q = 0; q < b; ++q) {
+    o0 += tot->mb[q][2];
+    o1 += tot->mb[q][3];
+    o2 += tot->mb[q][4];
+  }
+  if (b > 0)
+    for (int i = c0 + t; i < c1; i += 1024) {
+      slice_off[i] += o0;
+      chunk_start[i] += o1;
+      tile_off[i] += o2;
+    }
+  if (b == NB - 1) {
+    __syncthreads();  // (chunk_start[nchunks - 1] below was written by another thread of this block)
+    if (t == 0) {
+      tot->cw_sum = cw_sum;
+      tot->cw_cnt = cw_cnt;
+      tot->nslices = o0 + carry[0];
+      tot->capacity = o1 + carry[1];
+      *ntiles_out = o2 + carry[2];
+      tot->second_key1 = (keys_sorted && ne >= 2 && nchunks >= 1 && keys_sorted[ne - 2] < (1ull << 30)) ? (int)keys_sorted[ne - 2] + 1 : 0;
+      tot->last_chunk_start = nchunks >= 1 ? chunk_start[nchunks - 1] : 0;
+      if (sp.on) spec_decide(tot, sp.cap_lim, sp.nsl_lim, sp.C_max, key_bits, sp.keep_if_fits);
+      tot->pad_[1] = sp.search_nf ? *sp.search_nf : -1;  // (pp_ps_last_search_found)
+    }
+  }
+  // every block is past both barriers once it arrives here: the last arrival puts the counters back to zero for the
+  // next launch on these totals (the re-layout's retry with another chunk height), then the totals go to the host
+  __syncthreads();
+  if (t == 0) {
+    const unsigned d = __hip_atomic_fetch_add(&tot->bar_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (d == (unsigned)NB - 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      tot->bar = 0;
+      tot->bar_done = 0;
+      if (host_out) {
+        Totals v = *tot;
+        v.pad_[0] = 0;
+        *host_out = v;
+        if (host_stamp) {
+          __threadfence_system();
+          __hip_atomic_store(&host_out->pad_[0], host_stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
       }
     }
   }
@@ -978,6 +1217,7 @@ struct LayoutPlan {
   bool wide;  // sorted by k_rs_pass_wide: the layout kernel orders the overflow digit
   bool totals_on_host;  // the layout kernel wrote the totals to the pinned landing zone itself
   const int* wide_tail_start;  // one-pass sort over many tiles: first output position of the overflow digit
+  int wide_ndig = kWideDigits;  // digits of the one pass (2048 / 256 / 64)
   unsigned long long base;
   unsigned long long* keys;
   int* index;
@@ -1031,8 +1271,20 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
     // (up to 64 tiles every block sweeps the digit table itself; beyond that k_wide_seg / k_wide_base prefix it)
     const bool wide_sort = allow_wide && n_sigma <= 1 && ps->wide_skip == 0 &&
                            (ps->pad_strat != PP_PAD_INVERSELY || !(ps->shuffle_padding > 0));  // (needs k_layout_fused)
-    const bool wide_big = wide_sort && !fused_sort;
+    // digits of the one pass, from the largest count of the previous rebuild (unknown: 2048).  A prediction that
+    // fails shows as Totals::sort_bad (more than 1 024 keys in the overflow digit): the caller re-sorts with every
+    // 8-bit pass and pp_ps::narrow_skip keeps the next rebuilds on 2048 digits.
+    int wide_ndig = kWideDigits;
+    if (wide_sort && ps->narrow_skip == 0 && ps->last_max_key != ~0ull) {
+      if (ps->last_max_key <= 44) wide_ndig = 64;
+      else if (ps->last_max_key <= 200) wide_ndig = 256;
+    }
+    static const int force_ndig = PP_LAB_ENV("PP_WIDE_NDIG") ? atoi(PP_LAB_ENV("PP_WIDE_NDIG")) : 0;  // (lab build: A/B)
+    if (wide_sort && (force_ndig == 64 || force_ndig == 256 || force_ndig == 2048)) wide_ndig = force_ndig;
+    const bool narrow = wide_sort && wide_ndig < kWideDigits;
+    const bool wide_big = wide_sort && !fused_sort && !narrow;
     L.wide = wide_sort;
+    L.wide_ndig = wide_ndig;
     L.wide_tail_start = nullptr;
     if (wide_sort) L.key_bits = 64;  // (its own check: Totals::sort_bad)
     int* const H0 = ps->s_hist.as<int>();
@@ -1044,8 +1296,8 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
                                                  ps->s_keys.as<unsigned long long>(),
                                                  ps->s_vals.as<int>(), tot,
                                                  false, et,
-                                                 (fused_sort || wide_big) ? FusedHist{H0, nblk, wide_sort ? 1 : 0}
-                                                                          : FusedHist{nullptr, 0, 0},
+                                                 (fused_sort || wide_sort) ? FusedHist{H0, nblk, wide_sort ? 1 : 0, wide_ndig}
+                                                                           : FusedHist{nullptr, 0, 0},
                                                  nblk, ride);
     unsigned long long *ka = ps->s_keys.as<unsigned long long>(),
                        *kb = ps->s_keys2.as<unsigned long long>();
@@ -1061,7 +1313,12 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
         k_wide_base<<<1, 1024, 0, st>>>(nseg, seg_base, digit_base);
         L.wide_tail_start = digit_base + kWideDigits - 1;  // first output position of the overflow digit
       }
-      k_rs_pass_wide<<<nblk, kWideThreads, 0, st>>>(ne, ka, va, nblk, H0, kb, vb, seg_base, digit_base);
+      if (wide_ndig == 64)
+        k_rs_pass_wide<64><<<nblk, kWideThreads, 0, st>>>(ne, ka, va, nblk, H0, kb, vb, nullptr, nullptr);
+      else if (wide_ndig == 256)
+        k_rs_pass_wide<256><<<nblk, kWideThreads, 0, st>>>(ne, ka, va, nblk, H0, kb, vb, nullptr, nullptr);
+      else
+        k_rs_pass_wide<kWideDigits><<<nblk, kWideThreads, 0, st>>>(ne, ka, va, nblk, H0, kb, vb, seg_base, digit_base);
       std::swap(ka, kb);
       std::swap(va, vb);
     }
@@ -1100,7 +1357,20 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
     k_chunk_widths2<<<grid_for((size_t)nchunks * 64), kBlock, 0, st>>>(
         nchunks, C_new, ne, L.keys, L.base, L.sorted ? 1 : 0, ppe, L.widths);
   PP_HIP_CHECK(ps->s_scan.reserve(sizeof(int)));
-  if (fused_layout) {
+  // many chunks (10^6 elements): the same work on up to 16 blocks with two grid barriers (k_layout_multi)
+  const int layout_blocks = nchunks >= 4096 ? std::min(kLayoutBlocksMax, (nchunks + 1023) / 1024) : 1;
+  if (fused_layout && layout_blocks > 1) {
+    k_layout_multi<<<layout_blocks + (ride.on ? (unsigned)(((size_t)ride.nverts * 16 + 1023) / 1024) : 0), 1024, 0, st>>>(
+                                       layout_blocks, nchunks, C_new, ps->V, ps->tile_p, ps->pad_strat,
+                                       ps->shuffle_padding, L.widths, L.slice_off, L.chunk_start,
+                                       L.tile_off, tot, ps->s_scan.as<int>(), sp, L.key_bits,
+                                       L.sorted ? et.partial : nullptr, (ne + RS_TILE - 1) / RS_TILE,
+                                       widths_in_layout ? L.keys : nullptr, ne, L.wide ? L.keys : nullptr,
+                                       L.wide ? L.index : nullptr, L.wide ? ps->s_hist.as<int>() : nullptr, ride,
+                                       host_out, host_stamp, L.wide ? L.wide_tail_start : nullptr, L.wide_ndig);
+    if (ride.on) ps->ride_done = true;
+    L.totals_on_host = host_out != nullptr;
+  } else if (fused_layout) {
     k_layout_fused<<<1 + (ride.on ? (unsigned)(((size_t)ride.nverts * 16 + 1023) / 1024) : 0), 1024, 0, st>>>(
                                        nchunks, C_new, ps->V, ps->tile_p, ps->pad_strat,
                                        ps->shuffle_padding, L.widths, L.slice_off, L.chunk_start,
@@ -1108,7 +1378,7 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
                                        L.sorted ? et.partial : nullptr, (ne + RS_TILE - 1) / RS_TILE,
                                        widths_in_layout ? L.keys : nullptr, ne, L.wide ? L.keys : nullptr,
                                        L.wide ? L.index : nullptr, L.wide ? ps->s_hist.as<int>() : nullptr, ride,
-                                       host_out, host_stamp, L.wide ? L.wide_tail_start : nullptr);
+                                       host_out, host_stamp, L.wide ? L.wide_tail_start : nullptr, L.wide_ndig);
     if (ride.on) ps->ride_done = true;
     L.totals_on_host = host_out != nullptr;
   } else {
@@ -1533,13 +1803,18 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
                           spec_ok ? &ta_spec : nullptr, /*allow_wide=*/true, h_pin, stamp);
   const bool polling = stamp != 0 && L.totals_on_host;
   if (rc) return rc;
+  const int sorted_ndig = L.wide_ndig;  // (a retry below re-plans L)
   nchunks = L.nchunks;
   nrows = L.nrows;
   const int* go = &tot->go;
   int NQ = 0;
   bool lazy_zero = false, defer_unpack = false, use_rm = false, defer_wide = false;
   // today's per-element counts are not read by a re-layout that commits: its tail clears them for the next one
-  constexpr bool lazy_slot_elem = true;  // (pp::slot_elem fills the table when something asks)
+  // slot -> element: left out (pp::slot_elem fills it when something asks) unless the table of the layout that is
+  // being replaced WAS asked for -- ps_combo160's loop redistributes (reads it) before every rebuild: written here by
+  // the slot blocks it costs 4 B per slot, filled on demand a launch and ~6 us per round
+  const bool lazy_slot_elem = !ps->slot_elem_used;
+  ps->slot_elem_used = false;
   // staging records row-major inside a chunk (pp_ps::rec_rm)
   const bool want_rm = have_old && old_grid > 0;
   if (want_rm) PP_HIP_CHECK(ps->s_erec0.reserve(sizeof(int) * (size_t)std::max(ne, 1)));
@@ -1818,8 +2093,14 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     if (rc) return rc;
   }
   // (a population whose rows mostly exceed the one-pass sort's digit range: the 8-bit passes for a while)
-  if (h.sort_bad) ps->wide_skip = 64;
-  else if (ps->wide_skip > 0) --ps->wide_skip;
+  // (a narrow digit that overflowed: the next rebuilds take the 2048-digit pass; the 2048-digit pass itself
+  //  overflowed: the 8-bit passes for a while)
+  if (h.sort_bad && sorted_ndig < kWideDigits) ps->narrow_skip = 64;
+  else if (h.sort_bad) ps->wide_skip = 64;
+  else {
+    if (ps->wide_skip > 0) --ps->wide_skip;
+    if (ps->narrow_skip > 0) --ps->narrow_skip;
+  }
   ps->last_max_key = h.max_key;
   const int new_capacity = h.capacity, new_nslices = h.nslices;
   ntiles_max = nchunks + new_capacity / (C_new * ps->tile_p) + 1;  // launch bound of the next calls
@@ -2045,6 +2326,7 @@ int scan_excl_i32(DevBuf& scratch, int n, const int* in, int* out, int* total_de
   return scan_excl(scratch, n, in, out, total_dev, pp::stream());
 }
 const int* slot_elem(const pp_ps* ps) {
+  ps->slot_elem_used = true;
   if (!ps->slot_elem_valid) {
     if (ps->kind == PP_SCS && ps->capacity > 0 && ps->ntiles_max > 0)
       k_fill_slot_elem<<<grid_for((size_t)ps->ntiles_max * ps->C), kBlock, 0, pp::stream()>>>(

@@ -30,7 +30,12 @@ struct Totals {  // s_misc layout
   int pad_[2];   // ([0]: the stamp the host polls for)
   int second_key1;       // 1 + the second-largest count of a one-window sort (0: not known) and the first slot of
   int last_chunk_start;  // the last chunk: what pp_ps::hot is made of
+  // the multi-block layout kernel (k_layout_multi): arrival counters of its two grid barriers (put back to zero by
+  // the kernel's last block) and the per-block partial results: widths (sum, non-zero), slices, slots, tiles
+  unsigned bar, bar_done;
+  int mb[16][5];
 };
+constexpr int kLayoutBlocksMax = 16;
 
 // ---- stable LSD radix sort (8-bit digits) of (key64, val32)
 constexpr int RS_TILE = 2048;  // keys per block
@@ -49,12 +54,16 @@ struct ElemTotalsArgs {
 // makes the keys also counts the first pass's digits per tile.
 constexpr int kWideBits = 11, kWideDigits = 1 << kWideBits;
 struct FusedHist {
-  int* h0;   // digit counts of the first pass per tile: [256][nblk], wide: [nblk][kWideDigits] (null = separate launches)
+  int* h0;   // digit counts of the first pass per tile: [256][nblk], wide: [nblk][ndig] (null = separate launches)
   int nblk;
-  int wide;  // the ONE pass over an 11-bit digit; keys of 2047 and more share the last digit (k_rs_pass_wide)
+  int wide;  // the ONE pass over one wide digit; keys of ndig - 1 and more share the last digit (k_rs_pass_wide)
+  // digits of the one pass: 2048 (11 bits), or 256 / 64 when the previous rebuild's largest count says the keys are
+  // small (round 6: at 10^6 elements the [tiles][2048] table is 4 MB that two extra kernels prefix, k_wide_seg /
+  // k_wide_base; [tiles][64] is 125 KB that every block of the pass sums itself)
+  int ndig = kWideDigits;
 };
-__device__ __forceinline__ int wide_digit(unsigned long long key) {
-  return key < (unsigned long long)(kWideDigits - 1) ? (int)key : kWideDigits - 1;
+__device__ __forceinline__ int wide_digit(unsigned long long key, int ndig = kWideDigits) {
+  return key < (unsigned long long)(ndig - 1) ? (int)key : ndig - 1;
 }
 __global__ void k_make_keys(int ne, const int* __restrict__ ppe, int sigma, int n_sigma,
                             unsigned long long base, unsigned long long* __restrict__ keys,
@@ -70,7 +79,7 @@ __global__ void k_make_keys(int ne, const int* __restrict__ ppe, int sigma, int 
   int nz = 0, sum = 0, over = 0;
   const int base_i = blockIdx.x * RS_TILE;
   __shared__ int s_h0[kWideDigits];
-  const int dmask = fh.wide ? kWideDigits - 1 : 255;  // (digits of the first pass)
+  const int dmask = fh.wide ? fh.ndig - 1 : 255;  // (digits of the first pass)
   if (fh.h0) {
     for (int d = threadIdx.x; d <= dmask; d += 256) s_h0[d] = 0;
     __syncthreads();
@@ -105,7 +114,7 @@ __global__ void k_make_keys(int ne, const int* __restrict__ ppe, int sigma, int 
     const unsigned long long key = (unsigned long long)w * base + (unsigned long long)n;
     keys[i] = key;
     vals[i] = i;
-    if (fh.h0) atomicAdd(&s_h0[fh.wide ? wide_digit(key) : (int)(key & 255ull)], 1);
+    if (fh.h0) atomicAdd(&s_h0[fh.wide ? wide_digit(key, fh.ndig) : (int)(key & 255ull)], 1);
     mx = key > mx ? key : mx;
     nz += n > 0;
     sum += n;
@@ -145,7 +154,7 @@ __global__ void k_make_keys(int ne, const int* __restrict__ ppe, int sigma, int 
   if (fh.h0) {
     __syncthreads();
     if (fh.wide)
-      for (int d = threadIdx.x; d < kWideDigits; d += 256) fh.h0[(size_t)blockIdx.x * kWideDigits + d] = s_h0[d];
+      for (int d = threadIdx.x; d < fh.ndig; d += 256) fh.h0[(size_t)blockIdx.x * fh.ndig + d] = s_h0[d];
     else
       fh.h0[threadIdx.x * fh.nblk + blockIdx.x] = s_h0[threadIdx.x];
   }
@@ -387,12 +396,15 @@ __global__ void __launch_bounds__(1024) k_wide_base(int nseg, int* __restrict__ 
 // as in k_rs_pass, with 16 waves per tile (two rounds); the per-wave counts live in a [16][2048] byte table
 // whose used entries are put back to zero by their writers.
 constexpr int kWideThreads = 1024;
+constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
+template <int DIG>
 __global__ void __launch_bounds__(kWideThreads)
     k_rs_pass_wide(int n, const unsigned long long* __restrict__ keys, const int* __restrict__ vals, int nblk,
                    const int* __restrict__ hist, unsigned long long* __restrict__ keys_out,
                    int* __restrict__ vals_out, const int* __restrict__ seg_base = nullptr,
                    const int* __restrict__ digit_base = nullptr) {
-  constexpr int NW = kWideThreads / 64, R = RS_TILE / kWideThreads, K = kWideDigits / kWideThreads;
+  constexpr int kWideDigits = DIG, kWideBits = ilog2_c(DIG);  // (shadow the 11-bit constants)
+  constexpr int NW = kWideThreads / 64, R = RS_TILE / kWideThreads, K = DIG >= kWideThreads ? DIG / kWideThreads : 1;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   __shared__ int base_d[kWideDigits];                   // next output position of this tile's keys with digit d
   __shared__ unsigned char wave_cnt[NW][kWideDigits];   // (a wave holds at most 64 keys of one digit)
@@ -408,14 +420,56 @@ __global__ void __launch_bounds__(kWideThreads)
     val[r] = i < n ? vals[i] : 0;
   }
   for (int q = t; q < NW * kWideDigits / 16; q += kWideThreads) ((uint4*)&wave_cnt[0][0])[q] = make_uint4(0, 0, 0, 0);
-  if (seg_base) {  // many tiles: the table was prefixed by k_wide_seg / k_wide_base
+  if constexpr (DIG < kWideThreads) {
+    // narrow digit: the [tiles][DIG] table is small -- every block sums it itself whatever the number of tiles.
+    // Thread t: digit t % DIG, tiles t / DIG, t / DIG + LN, ... (LN lanes of tiles per digit), then an LDS fold.
+    constexpr int LN = kWideThreads / DIG;
+    __shared__ int s_tot[LN][DIG], s_mine[LN][DIG];
+    const int d = t % DIG, l = t / DIG;
+    int total = 0, mine = 0;
+    for (int b0 = l; b0 < nblk; b0 += 8 * LN) {  // (8 independent loads in flight)
+      int h[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h[j] = b0 + j * LN < nblk ? hist[(size_t)(b0 + j * LN) * DIG + d] : 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        total += h[j];
+        mine += b0 + j * LN < (int)blockIdx.x ? h[j] : 0;
+      }
+    }
+    s_tot[l][d] = total;
+    s_mine[l][d] = mine;
+    __syncthreads();
+    if (t < DIG) {
+      total = mine = 0;
+#pragma unroll
+      for (int q = 0; q < LN; ++q) {
+        total += s_tot[q][t];
+        mine += s_mine[q][t];
+      }
+      int incl = total;  // exclusive scan over the DIG digits (DIG <= 256: up to four waves)
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+      }
+      if (lane == 63) s_part[wave] = incl;
+      s_tot[0][t] = incl - total + mine;  // (own slot: read above by this thread only)
+    }
+    __syncthreads();
+    if (t < DIG) {
+      int off = 0;
+      for (int w = 0; w < wave; ++w) off += s_part[w];
+      base_d[t] = off + s_tot[0][t];
+    }
+    __syncthreads();
+  } else if (seg_base) {  // many tiles: the table was prefixed by k_wide_seg / k_wide_base
     const int* sb = seg_base + (size_t)(blockIdx.x / kWideSeg) * kWideDigits;
     const int* hb = hist + (size_t)blockIdx.x * kWideDigits;
 #pragma unroll
     for (int k = 0; k < K; ++k)
       base_d[k * kWideThreads + t] = digit_base[k * kWideThreads + t] + sb[k * kWideThreads + t] + hb[k * kWideThreads + t];
     __syncthreads();
-  } else {
+  } else if constexpr (DIG >= kWideThreads) {
     int total[K], mine[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) total[k] = mine[k] = 0;
@@ -459,7 +513,7 @@ __global__ void __launch_bounds__(kWideThreads)
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const bool valid = tile0 + r * kWideThreads + t < n;
-    const int digit = wide_digit(key[r]);
+    const int digit = wide_digit(key[r], DIG);
     unsigned long long same = __ballot(valid);  // lanes of this wave holding the same digit
     for (int b = 0; b < kWideBits; ++b) {
       const unsigned long long bal = __ballot(valid && ((digit >> b) & 1));
@@ -625,7 +679,8 @@ __global__ void k_tile_count(int nchunks, int TP, const int* __restrict__ widths
 // digit sit at the end of the sorted arrays in element order; order them by key, ties by position (= the
 // stable order the 8-bit passes produce).
 __device__ void wide_fix_tail(int ne, int nblk, const int* __restrict__ hist, unsigned long long* keys,
-                              int* vals, Totals* tot, const int* __restrict__ tail_start = nullptr) {
+                              int* vals, Totals* tot, const int* __restrict__ tail_start = nullptr,
+                              int ndig = kWideDigits) {
   __shared__ unsigned long long fk[1024];
   __shared__ int fv[1024];
   __shared__ int s_n[16];
@@ -634,7 +689,7 @@ __device__ void wide_fix_tail(int ne, int nblk, const int* __restrict__ hist, un
   if (tail_start) {  // (many tiles: the first output position of the overflow digit is in the prefixed table)
     n = ne - *tail_start;
   } else {
-    for (int b = t; b < nblk; b += 1024) n += hist[(size_t)b * kWideDigits + kWideDigits - 1];
+    for (int b = t; b < nblk; b += 1024) n += hist[(size_t)b * ndig + ndig - 1];
     for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
     if ((t & 63) == 0) s_n[t >> 6] = n;
     __syncthreads();
