@@ -988,6 +988,32 @@ __global__ void k_layout_tables_slots(LayoutTablesArgs a, InitSlotsArgs ia, unsi
     init_slots_tiled4_body(ia, (long long)(blockIdx.x - table_blocks) * blockDim.x + threadIdx.x,
                            (long long)(gridDim.x - table_blocks) * blockDim.x);
 }
+// printMetrics (SellCSigma.h:465-524): padded cells (slots whose mask is 0) and slices that hold at least one, one
+// block per slice; out[0] += cells, out[1] += 1
+__global__ void k_slice_padding(const int* __restrict__ offsets, const unsigned char* __restrict__ mask,
+                                int* __restrict__ out) {
+  __shared__ int s_w[4];
+  const int lo = offsets[blockIdx.x], hi = offsets[blockIdx.x + 1];
+  int n = 0;
+  for (int j = lo + 4 * (int)threadIdx.x; j < hi; j += 4 * 256) {  // (slices are multiples of the chunk height: 4 | C)
+    if (j + 3 < hi && (lo & 3) == 0) {
+      const unsigned m = *(const unsigned*)(mask + j);
+      n += 4 - __popc(m & 0x01010101u);
+    } else {
+      for (int q = j; q < hi; ++q) n += !mask[q];
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    n = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (n) {
+      atomicAdd(&out[0], n);
+      atomicAdd(&out[1], 1);
+    }
+  }
+}
 // slot -> parent element of every slot of every tile (what k_init_slots_tiled leaves out, see pp::slot_elem)
 __global__ void k_fill_slot_elem(const int* __restrict__ ntiles_dev, int C, int TP, const int* __restrict__ tiles,
                                  const int* __restrict__ chunk_start, const int* __restrict__ chunk_width,
@@ -2984,20 +3010,22 @@ int pp_redistribute_particles(const pp_ps* ps, double percent_moved, unsigned lo
 int pp_ps_metrics(const pp_ps* ps, int* padded_cells, int* padded_slices, int* empty_rows) {
   PP_REQUIRE(ps, "pp_ps_metrics: null ps");
   PP_REQUIRE(ps->kind == PP_SCS, "pp_ps_metrics: SCS only (SellCSigma.h:465-524)");
-  // diagnostics, not on the hot path: evaluate on the host from the layout
-  std::vector<int> off((size_t)ps->num_slices + 1);
-  std::vector<unsigned char> mask((size_t)std::max(ps->capacity, 1));
-  int rc = pp_ps_layout_to_host(ps, off.data(), nullptr, nullptr, nullptr, mask.data(), nullptr);
-  if (rc) return rc;
-  int pc = 0, psl = 0;
-  for (int s = 0; s < ps->num_slices; ++s) {
-    int n = 0;
-    for (int j = off[s]; j < off[s + 1]; ++j) n += !mask[j];
-    pc += n;
-    psl += n > 0;
+  // The reference's drivers print the metrics in EVERY iteration of their loop (test/pseudoXGCm.cpp:505-506): counted
+  // on the device (one block per slice sums the zero bytes of its part of the mask), 8 bytes come back -- round 5
+  // copied the whole mask to the host and counted there (12 MB and a host loop per call at 10 M particles).
+  int h[2] = {0, 0};
+  if (ps->num_slices > 0 && ps->capacity > 0) {
+    static pp::DevBuf* s_m = new pp::DevBuf();
+    PP_HIP_CHECK(s_m->reserve(2 * sizeof(int)));
+    PP_HIP_CHECK(hipMemsetAsync(s_m->p, 0, 2 * sizeof(int), pp::stream()));
+    k_slice_padding<<<ps->num_slices, 256, 0, pp::stream()>>>(ps->d_offsets.as<int>(), ps->d_mask.as<unsigned char>(),
+                                                             s_m->as<int>());
+    PP_LAUNCH_CHECK();
+    PP_HIP_CHECK(hipMemcpyAsync(h, s_m->p, 2 * sizeof(int), hipMemcpyDeviceToHost, pp::stream()));
+    PP_HIP_CHECK(hipStreamSynchronize(pp::stream()));
   }
-  if (padded_cells) *padded_cells = pc;
-  if (padded_slices) *padded_slices = psl;
+  if (padded_cells) *padded_cells = h[0];
+  if (padded_slices) *padded_slices = h[1];
   if (empty_rows) *empty_rows = ps->num_empty_elements;
   return PP_OK;
 }
