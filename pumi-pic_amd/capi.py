@@ -498,7 +498,11 @@ class PS:
                 arr[i] = d.ptr
         check(lib().pp_ps_rebuild(self.p, ne.ptr, n_new, npe.ptr if npe else None,
                                   C.cast(arr, C.c_void_p) if arr is not None else None))
-        sync()
+        # (the kernels of the call may still read its inputs when it returns -- include/pumipic_hip.h, "lifetime of
+        #  the inputs": wait only when this wrapper made the device copies that die with it; a caller that passes
+        #  its own DevArray and no new particles keeps the step free of the wait, as the C++ callers are)
+        if ne is not new_element or n_new:
+            sync()
 
     def rebuild_commit(self, new_element, m_x=0, m_xtgt=1):
         """updatePtclPositions + rebuild in one pass (no new particles)"""

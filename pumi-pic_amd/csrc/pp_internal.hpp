@@ -305,6 +305,9 @@ struct pp_ps {
   // runs instead of single records (round 4); else the record index is the slot.  d_erec0 / s_erec0: first record
   // of every element's row in the current / the new layout.
   bool rec_rm = false;
+  // the live records are SPLIT (2-D loop, lazy_rec 1 / 2): s_aos_live holds (x, y) per record, s_side_live the second
+  // halves (pad, phi, b, id) as 16-B quads -- the 2-D push reads those only
+  bool rec_split = false;
   pp::DevBuf d_erec0, s_erec0;
   // One over-full row at the end of the CURRENT layout (pseudoXGCm's remainder rule puts 60 000 particles into
   // one element, pseudoXGCm.cpp:167-222): with a full sort the rows are in ascending order of their counts, so it

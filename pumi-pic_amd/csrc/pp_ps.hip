@@ -1428,6 +1428,11 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
 // `src_stride` (elements), destinations the swap buffers.  Returns the number of 16-B quads per
 // record, or 0 when the members do not fit the staged path (other sizes than 4/8 bytes, too many).
 // (lab build, PP_NO_LAZY_UNPACK=1: the second pass of every re-layout runs right away)
+// (lab build, PP_NO_REC_SPLIT=1: the 2-D loop keeps the 32-B record + side word)
+bool no_rec_split() {
+  static const bool v = PP_LAB_ENV("PP_NO_REC_SPLIT") != nullptr;
+  return v;
+}
 bool no_lazy_unpack() {
   static const bool off = PP_LAB_ENV("PP_NO_LAZY_UNPACK") != nullptr;
   return off;
@@ -1435,8 +1440,11 @@ bool no_lazy_unpack() {
 // `side_member` >= 0: that member (one 4-byte component) travels beside the record (WordTable::side_src / side_dst).
 // `zero_z`: component 2 of member commit_xt's arrays is logically zero (pp_ps::zero_z_pending): the word that
 // would read it gets a null source -- the pack stores 0.
+// `drop_z` (with zero_z): that component does not travel at all -- its destination joins the zero list (pass 2 writes
+// the zeros) and the record is one word shorter (the split 2-D record: x, y | pad, phi, b, id).
 int build_word_table(const pp_ps* ps, const void* const* src, int64_t src_stride, int64_t dst_stride,
-                     int commit_x, int commit_xt, WordTable& wt, int side_member = -1, bool zero_z = false) {
+                     int commit_x, int commit_xt, WordTable& wt, int side_member = -1, bool zero_z = false,
+                     bool drop_z = false) {
   wt = WordTable{};
   for (int m = 0; m < ps->nmembers; ++m) {
     const int b = ps->member_bytes[m];
@@ -1457,7 +1465,14 @@ int build_word_table(const pp_ps* ps, const void* const* src, int64_t src_stride
       }
       const int sm = (m == commit_x) ? commit_xt : m;  // fused updatePtclPositions
       const char* sp = (const char*)src[sm] + ((size_t)cc * src_stride) * b;
-      if (zero_z && m == commit_x && cc == 2 && b == 8) sp = nullptr;
+      if (zero_z && m == commit_x && cc == 2 && b == 8) {
+        if (drop_z) {
+          if (wt.nz8 >= 8) return 0;
+          wt.z8[wt.nz8++] = dst;
+          continue;
+        }
+        sp = nullptr;
+      }
       if (b == 8) {
         if (wt.n8 >= kMax8) return 0;
         wt.src8[wt.n8] = sp;
@@ -1834,7 +1849,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   nrows = L.nrows;
   const int* go = &tot->go;
   int NQ = 0;
-  bool lazy_zero = false, defer_unpack = false, use_rm = false, defer_wide = false;
+  bool lazy_zero = false, defer_unpack = false, use_rm = false, defer_wide = false, rec_split = false;
   // today's per-element counts are not read by a re-layout that commits: its tail clears them for the next one
   // slot -> element: left out (pp::slot_elem fills it when something asks) unless the table of the layout that is
   // being replaced WAS asked for -- ps_combo160's loop redistributes (reads it) before every rebuild: written here by
@@ -1917,6 +1932,18 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
         NQ = build_word_table(ps, srcs, ps->stride, swap_stride, commit_x, commit_xt, wt, 2, zero_z);
         PP_REQUIRE(NQ == 2 && wt.side_src, "rebuild (internal): the pseudoXGCm record is not 32 bytes + one word");
         wt.nz8 = wt.nz4 = 0;
+        // The 2-D loop (test/pseudoXGCm.cpp on triangles; zero_z: the last push was the 2-D record-fed one, the
+        // origin's third component is known to be zero): SPLIT records -- quad 0 (x, y) to one array, quad 1
+        // (pad, phi, b, id) to another.  The 2-D push reads phi, b and the id only (test/ellipticalPush.hpp:51-67 and
+        // search_mesh_2d, src/pumipic_adjacency.hpp:1045-1117, never look at the origin): 16 B per particle instead
+        // of the 32-B record + the side word (round-5 verdict: 0.70 GB read per step for 10 M particles).
+        rec_split = zero_z && n_new == 0 && want_rm && !from_rec && !no_rec_split();
+        if (rec_split) {
+          NQ = build_word_table(ps, srcs, ps->stride, swap_stride, commit_x, commit_xt, wt, -1, zero_z, /*drop_z=*/true);
+          PP_REQUIRE(NQ == 2 && wt.n8 == 2 && wt.n4 == 3 && !wt.side_src,
+                     "rebuild (internal): the split 2-D record is not (x, y | pad, phi, b, id)");
+          wt.nz8 = wt.nz4 = 0;
+        }
       }
       // Records wider than 64 B (ps_combo160's 160-B particle: 192-B records), no new particles, no commit: the
       // second pass waits until somebody asks for a member -- a rebuild that follows reads the records
@@ -1928,9 +1955,10 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       // (+ one spare column per chunk: the row-major record geometry, pp_rec_row0)
       const size_t nrec = (size_t)std::max(cap_sz, 1) + (size_t)kRecSpareCols * C_new * nchunks;
       PP_HIP_CHECK(ps->s_aos.reserve(nrec * NQ * 16));
-      if (defer_unpack) PP_HIP_CHECK(ps->s_side.reserve(nrec * sizeof(unsigned)));
+      if (defer_unpack) PP_HIP_CHECK(ps->s_side.reserve(nrec * (rec_split ? sizeof(uint4) : sizeof(unsigned))));
       uint4* aos = ps->s_aos.as<uint4>();
-      unsigned* const side = defer_unpack ? ps->s_side.as<unsigned>() : nullptr;
+      unsigned* const side = (defer_unpack && !rec_split) ? ps->s_side.as<unsigned>() : nullptr;
+      uint4* const split_hot = rec_split ? ps->s_side.as<uint4>() : nullptr;  // (the side buffer holds the second halves)
       const unsigned new_grid = grid_for((size_t)ntiles_max * C_new);
 #define PP_UNPACK_ARGS                                                                                  \
   new_ntiles, C_new, ps->tile_p, new_tiles, L.chunk_start, L.widths, ps->s_mask2.as<unsigned char>(), aos, \
@@ -1942,7 +1970,8 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
                                                                     ps->s_aos_live.as<uint4>(), aos, go); \
     else if (use_rm)                                                                             \
       k_move_pack_rm<N><<<pack_main + pack_hot, kBlock, 0, st>>>(pack_end, rank, rs_rm, aos, wt, go, \
-                                                                 ps->C == 64 ? rm_wide : 0, hot_now, pack_hot, side); \
+                                                                 ps->C == 64 ? rm_wide : 0, hot_now, pack_hot, side, \
+                                                                 N == 2 ? split_hot : nullptr);  \
     else                                                                                         \
       k_move_pack<N><<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, rank, rs, aos, wt, go, side); \
     if (!defer_unpack && !defer_wide) k_move_unpack<N><<<new_grid, kBlock, 0, st>>>(PP_UNPACK_ARGS); \
@@ -2137,6 +2166,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
   ps->zero_pending = lazy_zero ? commit_xt : -1;
   ps->zero_z_pending = false;  // (packed as zeros above / written by ps_ready before a non-committing re-layout)
   ps->lazy_rec = 0;
+  ps->rec_split = false;
   ps->hot = pp::HotRow{};
   if (defer_unpack) {  // the records of the first pass are what holds the particles now
     ps->s_aos.swap(ps->s_aos_live);
@@ -2145,6 +2175,7 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     ps->lazy_x = commit_x;
     ps->lazy_xt = commit_xt;
     ps->rec_rm = use_rm;
+    ps->rec_split = rec_split;
     if (use_rm) ps->d_erec0.swap(ps->s_erec0);
     // (pp_ps::hot) one sort window: the rows are in ascending order of their counts, the last row holds the largest
     if (use_rm && C_new == 64 && h.second_key1 > 0 && h.max_key < (1ull << 30) && !no_hot) {
@@ -2432,6 +2463,8 @@ int ps_materialize(pp_ps* ps) {
     // member that is still only in the records (all that travelled / the origin only)
     const int state = ps->lazy_rec;
     ps->lazy_rec = 0;
+    const bool split = ps->rec_split;  // (x, y) and (pad, phi, b, id) in two arrays (scs_rebuild: rec_split)
+    ps->rec_split = false;
     if (ps->capacity > 0 && ps->num_ptcls > 0) {
       WordTable wt{};
       for (int m = 0; m < ps->nmembers; ++m) {
@@ -2439,7 +2472,11 @@ int ps_materialize(pp_ps* ps) {
         const int b = ps->member_bytes[m];
         for (int cc = 0; cc < ps->member_ncomp[m]; ++cc) {
           char* dst = (state == 2 && m != ps->lazy_x) ? nullptr : (char*)ps->data[m].p + ((size_t)cc * ps->stride) * b;
-          if (m == 2)  // (the order of build_word_table with side_member 2)
+          if (split && m == ps->lazy_x && cc == 2) {  // (split 2-D records carry no third component: it is zero)
+            PP_HIP_CHECK(hipMemsetAsync(dst, 0, (size_t)ps->stride * b, pp::stream()));
+            continue;
+          }
+          if (m == 2 && !split)  // (the order of build_word_table with side_member 2)
             wt.side_dst = dst;
           else if (b == 8)
             wt.dst8[wt.n8++] = dst;
@@ -2460,7 +2497,8 @@ int ps_materialize(pp_ps* ps) {
       k_move_unpack<2><<<grid_for((size_t)ps->ntiles_max * ps->C), kBlock, 0, pp::stream()>>>(
           ps->d_ntiles.as<int>(), ps->C, ps->tile_p, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(),
           ps->d_chunk_width.as<int>(), ps->d_mask.as<unsigned char>(), ps->s_aos_live.as<uint4>(), wt, go_one,
-          ps->rec_rm ? 1 : 0, state == 2 ? nullptr : ps->s_side_live.as<unsigned>());
+          ps->rec_rm ? 1 : 0, (state == 2 || split) ? nullptr : ps->s_side_live.as<unsigned>(),
+          split ? ps->s_side_live.as<uint4>() : nullptr);
       PP_LAUNCH_CHECK();
     }
   }

@@ -225,7 +225,9 @@ template <int NQ>
 __global__ void k_move_pack_rm(int capacity, const int* __restrict__ new_idx, RankToSlot rs,
                                uint4* __restrict__ aos, WordTable t, const int* __restrict__ go, int wide,
                                pp::HotRow hot = pp::HotRow{}, unsigned hot_blocks = 0u,
-                               unsigned* __restrict__ side = nullptr) {
+                               unsigned* __restrict__ side = nullptr, uint4* __restrict__ split_hot = nullptr) {
+  // split_hot (NQ == 2 only, pp_ps::rec_split): quad 0 of a record goes to aos[record], quad 1 to split_hot[record]
+  // -- two arrays of 16-B halves instead of one of 32-B records (the 2-D push reads the second halves only)
   if (go && !*go) return;
   __shared__ uint4 st[256][NQ + 1];
   __shared__ int sd[256];
@@ -299,7 +301,10 @@ __global__ void k_move_pack_rm(int capacity, const int* __restrict__ new_idx, Ra
       y.y = x.y;
       y.z = x.z;
       y.w = x.w;
-      __builtin_nontemporal_store(y, (v4u*)(aos + (long long)d * NQ + part));
+      if (NQ == 2 && split_hot)
+        __builtin_nontemporal_store(y, (v4u*)((part ? split_hot : aos) + (long long)d));
+      else
+        __builtin_nontemporal_store(y, (v4u*)(aos + (long long)d * NQ + part));
     }
   }
 }
@@ -343,7 +348,11 @@ __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
                               const int* __restrict__ chunk_width,
                               const unsigned char* __restrict__ new_mask,
                               const uint4* __restrict__ aos, WordTable t, const int* __restrict__ go,
-                              int rec_rm = 0, const unsigned* __restrict__ side = nullptr) {
+                              int rec_rm = 0, const unsigned* __restrict__ side = nullptr,
+                              const uint4* __restrict__ split_hot = nullptr) {
+  // split_hot (NQ == 2, row-major records): quad 0 of record i is aos[i], quad 1 split_hot[i] (k_move_pack_rm);
+  // a table without 4-byte destinations (only the origin is wanted, pp_ps::lazy_rec == 2) leaves the second halves
+  // unread
   if (!*go) return;
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int tile = (int)(g / C), r = (int)(g - (long long)tile * C);
@@ -392,7 +401,12 @@ __global__ void k_move_unpack(const int* __restrict__ ntiles_dev, int C, int TP,
       for (int k = 0; k < KC; ++k)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-          const uint4 v = m[k] ? sp[k * NQ + q] : make_uint4(0, 0, 0, 0);
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (NQ == 2 && split_hot) {
+            if (m[k] && (q == 0 || t.n4 > 0)) v = (q ? split_hot : aos)[rbase + p + k];
+          } else if (m[k]) {
+            v = sp[k * NQ + q];
+          }
           w[k][4 * q] = v.x;
           w[k][4 * q + 1] = v.y;
           w[k][4 * q + 2] = v.z;

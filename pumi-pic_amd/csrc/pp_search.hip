@@ -1012,13 +1012,24 @@ struct RecIn {
   float* b_out;
   int rm;      // records row-major inside a chunk (pp_ps::rec_rm): (row r, column p) of chunk c is record
                // pp_rec_row0(chunk_start[c], c, r, chunk_width[c], C) + p; else the record index is the slot
+  // 2-D, split records (pp_ps::rec_split): record i's (pad, phi, b, id) is hot[i]; `rec` and `side` are not read
+  const uint4* hot = nullptr;
 };
 template <int DIM = 3>
 __device__ __forceinline__ PState load_state_recin(int pid, const unsigned char* __restrict__ mask,
                                                    const char* __restrict__ rec, const unsigned* __restrict__ side,
-                                                   long long ri) {
+                                                   long long ri, const uint4* __restrict__ hot = nullptr) {
   PState s;
   s.m = mask[pid];
+  if (DIM == 2 && hot) {
+    const uint4 hq = hot[ri];
+    s.x = s.y = s.z = 0;
+    s.phi = __uint_as_float(hq.y);
+    s.b = __uint_as_float(hq.z);
+    s.id = hq.w;
+    s.elem = -1;
+    return s;
+  }
   const char* rp = rec + ri * 32;
   s.x = s.y = s.z = 0;
   if (DIM == 3) {  // (the 2-D push reads no position)
@@ -1115,7 +1126,7 @@ __global__ void __launch_bounds__(256, OCC)
   auto load = [&](int pid, long long ri) {
     PState s;
     if constexpr (RECIN) {
-      s = load_state_recin<DIM>(pid, mask, rin.rec, rin.side, ri);
+      s = load_state_recin<DIM>(pid, mask, rin.rec, rin.side, ri, rin.hot);
       if (seeded) s.elem = elem_ids[pid];
     } else {
       s = load_state<DIM, true>(pid, mask, pphi, pb, x, stride, elem_ids, seeded != 0);
@@ -1183,7 +1194,23 @@ __global__ void __launch_bounds__(256, OCC)
   // load (the side array is in record order, a row's group of four starts on a 16-byte boundary)
   auto loadg = [&](int p, PState* o) {
     if constexpr (RECIN && DIM == 2) {
-      if (rs == 1 && ((rb + p) & 3) == 0 && p < pend) {  // (p >= pend: the prefetch past the row -- no load at all)
+      if (rin.hot && rs == 1 && p < pend) {  // split records: the four second halves are 64 contiguous bytes
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[j] = PState{};
+          if (p + j < pend) {
+            const int pid = start + (p + j) * C;
+            const uint4 hq = rin.hot[rb + p + j];
+            o[j].m = mask[pid];
+            o[j].phi = __uint_as_float(hq.y);
+            o[j].b = __uint_as_float(hq.z);
+            o[j].id = hq.w;
+            o[j].elem = seeded ? elem_ids[pid] : -1;
+          }
+        }
+        return;
+      }
+      if (!rin.hot && rs == 1 && ((rb + p) & 3) == 0 && p < pend) {  // (p >= pend: the prefetch past the row -- no load at all)
         const uint4 ids = *(const uint4*)(rin.side + rb + p);
         const unsigned idv[4] = {ids.x, ids.y, ids.z, ids.w};
 #pragma unroll
@@ -2616,7 +2643,8 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
   const bool quads_ok = ps->rec_rm && !elem_ids_seeded && (ps->tile_p & 3) == 0 && (ps->C & 3) == 0;
   const bool recin = ((mesh->dim == 3 && wq > 0 && quads_ok) || (mesh->dim == 2 && wq == 0)) &&
                      ps->capacity > 0 && ps->num_ptcls > 0 && ps->ntiles_max > 0 &&
-                     pp::lazy_push_ok(ps, m_x, m_xtgt, m_b, m_phi);
+                     pp::lazy_push_ok(ps, m_x, m_xtgt, m_b, m_phi) &&
+                     !(mesh->dim == 3 && ps->rec_split);  // (split records hold no third component: 2-D only)
   bool z_stays_zero = false;
   if (recin) {
     // (a 2-D push writes two components of x_tgt: when x_tgt is only logically zero the third one STAYS logically
@@ -2706,7 +2734,8 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
     } else if (rgrid > 0) {
       if (mesh->dim == 2 && recin) {
         const RecIn rin{ps->s_aos_live.as<char>(), ps->s_side_live.as<unsigned>(), (unsigned*)ps->data[2].p,
-                        (float*)ps->data[3].p, ps->rec_rm ? 1 : 0};
+                        (float*)ps->data[3].p, ps->rec_rm ? 1 : 0,
+                        ps->rec_split ? ps->s_side_live.as<uint4>() : nullptr};
         k_push_walk_rows<2, 4, true><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS, rin);
         ps->lazy_rec = 2;
         ps->zero_z_pending = z_stays_zero;
