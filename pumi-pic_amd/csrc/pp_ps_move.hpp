@@ -289,6 +289,25 @@ __global__ void k_move_pack_rm(int capacity, const int* __restrict__ new_idx, Ra
     const int d = sd[tid];
     if (d >= 0) side[d] = ss[tid];
   }
+  if (NQ == 2 && split_hot) {
+    // split records: thread i stores both halves of LDS index i -- consecutive lanes write consecutive 16-B pieces
+    // of ONE array (a row's run of 32 columns is 512 contiguous bytes in each)
+    const int d = sd[tid];
+    if (d >= 0) {
+      typedef unsigned v4u __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int part = 0; part < 2; ++part) {
+        const uint4 x = st[tid][part];
+        v4u y;
+        y.x = x.x;
+        y.y = x.y;
+        y.z = x.z;
+        y.w = x.w;
+        __builtin_nontemporal_store(y, (v4u*)((part ? split_hot : aos) + (long long)d));
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < NQ; ++j) {
     const int item = j * 256 + tid, rec = item / NQ, part = item % NQ;  // the records of one row are adjacent items
@@ -301,10 +320,7 @@ __global__ void k_move_pack_rm(int capacity, const int* __restrict__ new_idx, Ra
       y.y = x.y;
       y.z = x.z;
       y.w = x.w;
-      if (NQ == 2 && split_hot)
-        __builtin_nontemporal_store(y, (v4u*)((part ? split_hot : aos) + (long long)d));
-      else
-        __builtin_nontemporal_store(y, (v4u*)(aos + (long long)d * NQ + part));
+      __builtin_nontemporal_store(y, (v4u*)(aos + (long long)d * NQ + part));
     }
   }
 }

@@ -50,7 +50,7 @@ def _edge_distance(coords, e2v, elem, xy):
     return np.minimum(np.minimum(l1, l2), 1 - l1 - l2)
 
 
-@pytest.mark.parametrize("nptcl,steps", [(2_000_000, 12)])
+@pytest.mark.parametrize("nptcl,steps", [(2_000_000, 12), (10_000_000, 6)])
 def test_driver_pseudoxgcm_equals_oracle_libm(pp, ppo, capi, tmp_path, nptcl, steps):
     s = pp.synth
     subprocess.check_call(["make", "-C", DRV, "-s"])
