@@ -1343,6 +1343,10 @@ def main():
                         and a.mesh == "100k" and a.sigma >= 2**31 - 1 and world == 1
                         and (a.workload != "c4" or a.c4_elems == 1_000_000)):
                     traffic = tj["traffic_bytes_per_step"]
+                    # (c4's roofline object is about ONE kernel, the pseudo-push: its own bytes per launch)
+                    kp = (tj.get("kernels") or {}).get("k_pseudo_push160")
+                    if a.workload == "c4" and kp and "read_bytes_per_step" in kp:
+                        traffic = (kp["read_bytes_per_step"] + kp["write_bytes_per_step"]) / max(kp.get("launches_per_step", 1), 1)
             except (ValueError, KeyError):
                 traffic = None
         if a.workload == "c4" and a.structure != "scs":

@@ -1982,9 +1982,10 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       const RankToSlot rs_rm{new_element, ps->s_erec0.as<int>(), 1};
       // log2(columns per block): a row's run of a block is 512 contiguous bytes -- 8 of the 64-B records, 16 of the
       // 32-B ones (whose side words then leave as 64-B pieces)
-      // (split 2-D records are two arrays of 16-B halves: 32 columns per block keep a row's run at 512 B in each;
+      // (split 2-D records are two arrays of 16-B halves; 16 columns per block as for the 32-B records -- 32 columns,
+      //  512-B runs in each array, measured slower: pack 237 against 182 us, profiles/r06_ab_split_records.txt;
       //  lab build: PP_SPLIT_WIDE overrides)
-      static const int split_wide = PP_LAB_ENV("PP_SPLIT_WIDE") ? atoi(PP_LAB_ENV("PP_SPLIT_WIDE")) : 5;
+      static const int split_wide = PP_LAB_ENV("PP_SPLIT_WIDE") ? atoi(PP_LAB_ENV("PP_SPLIT_WIDE")) : 4;
       const int rm_wide = rec_split ? split_wide : NQ <= 2 ? 4 : 3;
       // (only where the records stay the particle data -- the pseudoXGCm flows, where nine particles in ten keep
       // their row: c3 -3.3 %, 2dc3 -3.6 %, c5 share -3.2 %.  ps_combo160 redistributes half of its particles to

@@ -34,7 +34,7 @@ def main(out_dir, workload, particles, nsteps, dest, pmc_dir, bytes_per_particle
     out = {"workload": workload, "particles": particles, "remainder": "last", "steps_profiled": nsteps,
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python3 bench.py --workload %s "
                      "--steps 10 --warmup 3 --no-cpu-baseline` (PP_BENCH_NO_COLD=1 PP_BENCH_PREWARM=0), "
-                     "tools/r05_measure.sh (rounds 3-4: r03_ / r04_measure.sh); every kernel that runs once per step or more, summed per step; scaled by "
+                     "tools/r06_measure.sh (rounds 3-5: r03_ / r04_ / r05_measure.sh); every kernel that runs once per step or more, summed per step; scaled by "
                      "the calibration run of tools/ub_stream.hip s_rows<8,4>: FETCH_SIZE[KiB] x 1024 x %.4f, "
                      "WRITE_SIZE[KiB] x 1024 x %.4f" % (workload, rf, wf),
            "kernels": {}}
