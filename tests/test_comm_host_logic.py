@@ -235,3 +235,32 @@ def test_mirror_distributor_rank_subset_host_logic(pp, tmp_path):
                            "-L" + libdir, "-lpumipic_hip", "-Wl,-rpath," + libdir])
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
     assert out.returncode == 0 and "all checks passed" in out.stdout, out.stdout
+
+
+def test_mpi_facade_two_processes_host_only(pp, tmp_path):
+    """pumi-pic_amd/include/pumipic_mpi.hpp: MPI_Comm_rank / size, MPI_Allreduce (every type, SUM / MAX / MIN, several
+    values), MPI_Reduce (root only), MPI_Barrier over the library's communicator -- two processes on this machine, the
+    host-staged transport, no GPU (tests/cpp/mpi_facade_host.cpp)."""
+    import shutil
+    import socket
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    libdir = os.path.join(ROOT, "pumi-pic_amd")
+    exe = str(tmp_path / "mpi_facade_host")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17",
+                           os.path.join(ROOT, "tests", "cpp", "mpi_facade_host.cpp"), "-o", exe,
+                           "-L" + libdir, "-lpumipic_hip", "-Wl,-rpath," + libdir])
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PP_COMM="tcp", PP_COMM_PORT=str(port))
+        procs.append(subprocess.Popen([exe], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("rank %d: all checks passed" % r) in o, o
+        assert ("rank %d of 2" % r) in o
