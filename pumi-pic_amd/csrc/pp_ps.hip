@@ -253,9 +253,7 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
     key[k] = -1;
     mk_[k] = 0;
   }
-  auto flush_one = [&](int dest, unsigned m) {
-    if (!m) return;
-    int idx = atomicAdd(&ppe[dest], __popc(m));
+  auto put_ranks = [&](unsigned m, int idx) {
     while (m) {
       const int b = __ffs(m) - 1;
       m &= m - 1;
@@ -263,10 +261,16 @@ __global__ void k_count_tiled(const int* __restrict__ ntiles_dev, int C, int TP,
     }
   };
   auto flush = [&]() {
-    flush_one(e, m0);
+    // every atomic of the run first (they are independent: up to 1 + NK returning atomics in flight instead of one
+    // memory round trip after the other), then the ranks they returned
+    int i0 = 0, ik[NK];
+    if (m0) i0 = atomicAdd(&ppe[e], __popc(m0));
+#pragma unroll
+    for (int k = 0; k < NK; ++k) ik[k] = mk_[k] ? atomicAdd(&ppe[key[k]], __popc(mk_[k])) : 0;
+    put_ranks(m0, i0);
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-      flush_one(key[k], mk_[k]);
+      put_ranks(mk_[k], ik[k]);
       key[k] = -1;
       mk_[k] = 0;
     }
@@ -1000,7 +1004,7 @@ __global__ void k_slice_padding(const int* __restrict__ offsets, const unsigned 
       const unsigned m = *(const unsigned*)(mask + j);
       n += 4 - __popc(m & 0x01010101u);
     } else {
-      for (int q = j; q < hi; ++q) n += !mask[q];
+      for (int q = j; q < min(j + 4, hi); ++q) n += !mask[q];
     }
   }
   for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
@@ -1699,15 +1703,22 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
       (steady && ps->rec_rm && ps->hot.on && have_old && old_grid > 0 && ps->C == 64 && !no_hot) ? ps->hot : pp::HotRow{};
   if (have_old && old_grid > 0) {
     const unsigned hot_blocks = hot_now.on ? (unsigned)((hot_now.w - hot_now.c1p + 256 * kHotCols - 1) / (256 * kHotCols)) : 0u;
+    // Thin chunks (ps_combo160 at 10^6 elements / 10^6 particles: ~5 columns, ONE tile per chunk): a thread that
+    // takes G tiles takes G different rows of G different chunks -- nothing to merge, and its returning atomics
+    // (one L2-miss line each) queue up behind one another.  One tile per thread there: four times the threads,
+    // each with one round of atomics in flight.
+    const bool thin = ps->num_chunks > 0 && (long long)ps->capacity <= (long long)ps->num_chunks * ps->C * ps->tile_p;
+    const int Gc = thin ? 1 : G;
+    const unsigned grp_grid_c = thin ? grid_for((size_t)ps->ntiles_max * ps->C) : grp_grid;
     // (three keys beside the row's own element; six: 64.3 against 60.3 us at c3, 366 against 358 at the c5 share)
 #define PP_COUNT_ARGS                                                                                      \
-  ps->d_ntiles.as<int>(), ps->C, ps->tile_p, G, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(),        \
+  ps->d_ntiles.as<int>(), ps->C, ps->tile_p, Gc, ps->d_tiles.as<int>(), ps->d_chunk_start.as<int>(),       \
       ps->d_chunk_width.as<int>(), ps->d_row_to_element.as<int>(), ps->d_mask.as<unsigned char>(), new_element, \
       ne, ppe, tot, rank, 1, hot_now, hot_blocks
     if (ps->C == 64)
-      k_count_tiled<3, true><<<grp_grid + hot_blocks, kBlock, 0, st>>>(PP_COUNT_ARGS);
+      k_count_tiled<3, true><<<grp_grid_c + hot_blocks, kBlock, 0, st>>>(PP_COUNT_ARGS);
     else
-      k_count_tiled<3, false><<<grp_grid + hot_blocks, kBlock, 0, st>>>(PP_COUNT_ARGS);
+      k_count_tiled<3, false><<<grp_grid_c + hot_blocks, kBlock, 0, st>>>(PP_COUNT_ARGS);
 #undef PP_COUNT_ARGS
   }
   if (n_new > 0) {
