@@ -778,7 +778,9 @@ def test_ring_map_edited_in_place_is_caught(capi, synth, ppo):
     assert np.array_equal(capi.gyro_scatter(mg, pg, fwd).to_host(), ppo.gyro_scatter(mo, po, fo))
     edited = fwd.to_host().copy()
     edited[edited >= 0] = (edited[edited >= 0] * 5 + 1) % mg.nverts  # every entry another vertex
-    hip = ctypes.CDLL("libamdhip64.so")
+    # (the HIP runtime the library is linked to -- a process that imported torch holds a second one under the bare
+    #  soname, which knows no device)
+    hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")
     capi.sync()
     assert hip.hipMemcpy(ctypes.c_void_p(fwd.ptr), edited.ctypes.data_as(ctypes.c_void_p),
                          ctypes.c_size_t(edited.nbytes), 1) == 0  # behind the library's back
