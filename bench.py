@@ -1308,13 +1308,15 @@ def main():
                         "stepped on one rank: the per-GPU compute of configs[4] without the exchange",
             "ms_per_step": dt8 / k5 * 1e3, "value": n8 * k5 / dt8, "unit": "particles/s", "steps": k5, "warmup": 12,
             "setup_seconds": t_set, "roofline_frac": 194.0 * n8 / (dt8 / k5) / 1e9 / HBM_PEAK_GBS}
-        vf = os.path.join(ROOT, "profiles", "r05_c5_virtual8.json")
+        vf = os.path.join(ROOT, "profiles", "r06_c5_virtual8.json")
+        if not os.path.exists(vf):
+            vf = os.path.join(ROOT, "profiles", "r05_c5_virtual8.json")
         if os.path.exists(vf):
             try:
                 vj = json.load(open(vf))
                 out5["virtual_ranks_8"] = {k: vj.get(k) for k in ("per_rank_ms", "per_rank_value", "per_rank_roofline_frac",
                                                                  "particles_total", "migrated_per_step", "ms_per_step")}
-                out5["virtual_ranks_8"]["provenance"] = "profiles/r05_c5_virtual8.json (committed run of this file)"
+                out5["virtual_ranks_8"]["provenance"] = "profiles/%s (committed run of this file)" % os.path.basename(vf)
                 out5["per_rank_ms"] = {"1": dt5 / k5 * 1e3, "8": vj.get("per_rank_ms")}
             except (ValueError, KeyError):
                 pass
@@ -1398,9 +1400,10 @@ def main():
                                     "step, calibrated; profiles/traffic_%s.json)" % a.workload,
                     "scope": "whole step: every kernel between two steps' first launches (HIP events on the "
                              "library stream)",
-                    "kernel": "whole step; its longest launches (profiles/r05_%s_kernel_stats.csv): the record-fed %s, "
+                    "kernel": "whole step; its longest launches (profiles/r06_%s_kernel_stats.csv): the record-fed %s, "
                               "then k_move_pack_rm<2> (the re-layout's one data pass: 32-B records + the third member "
-                              "beside them, row-major inside a chunk, stored as runs)" % (
+                              "beside them -- 2-D: split (x, y | pad, phi, b, id) halves in two arrays -- row-major "
+                              "inside a chunk, stored as runs)" % (
                                   "c5_virtual8" if a.workload == "c5" else a.workload,
                                   "k_push_walk_rowsq<3> (+ k_walk_pending<3>)" if w["dim"] == 3 else "k_push_walk_rows<2>"),
                     "kernel_ms": sms, "bytes_per_particle": bpp,
@@ -1459,12 +1462,14 @@ def main():
                                                   "run holds its 32 M in its own block of ne / %d elements" % world)
                 except (ValueError, KeyError):
                     pass
-            v8 = os.path.join(ROOT, "profiles", "r05_c5_virtual8.json")
+            v8 = os.path.join(ROOT, "profiles", "r06_c5_virtual8.json")
+            if not os.path.exists(v8):
+                v8 = os.path.join(ROOT, "profiles", "r05_c5_virtual8.json")
             if os.path.exists(v8) and a.workload == "c5" and a.mesh == "1m" and a.scaling == "weak" and world == 8:
                 try:  # like for like: the same eight ranks as virtual ranks of ONE GPU (compute without the transfer)
                     vj = json.load(open(v8))
                     out["scale_ref_virtual_ranks_8"] = {"per_rank_value": vj["per_rank_value"], "per_rank_ms": vj["per_rank_ms"],
-                                                        "source": "profiles/r05_c5_virtual8.json"}
+                                                        "source": "profiles/" + os.path.basename(v8)}
                     out["efficiency_vs_virtual_ranks_8"] = out["value"] / (world * vj["per_rank_value"])
                 except (ValueError, KeyError):
                     pass
