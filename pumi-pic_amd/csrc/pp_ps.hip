@@ -992,14 +992,19 @@ __global__ void k_layout_tables_slots(LayoutTablesArgs a, InitSlotsArgs ia, unsi
     init_slots_tiled4_body(ia, (long long)(blockIdx.x - table_blocks) * blockDim.x + threadIdx.x,
                            (long long)(gridDim.x - table_blocks) * blockDim.x);
 }
-// printMetrics (SellCSigma.h:465-524): padded cells (slots whose mask is 0) and slices that hold at least one, one
-// block per slice; out[0] += cells, out[1] += 1
+// printMetrics (SellCSigma.h:465-524): padded cells (slots whose mask is 0) and slices that hold at least one.  Block
+// (x, y) takes segment y (kMetricsSeg bytes) of slice x; the first block of a slice that finds a padded cell counts
+// the slice (flag[y], zeroed by the caller).  out[0] += cells, out[1] += slices
+constexpr int kMetricsSeg = 8192;
 __global__ void k_slice_padding(const int* __restrict__ offsets, const unsigned char* __restrict__ mask,
-                                int* __restrict__ out) {
+                                int* __restrict__ out, int* __restrict__ flag) {
   __shared__ int s_w[4];
-  const int lo = offsets[blockIdx.x], hi = offsets[blockIdx.x + 1];
+  const int s = blockIdx.x;
+  const int lo0 = offsets[s], hi0 = offsets[s + 1];
+  const int lo = lo0 + (int)blockIdx.y * kMetricsSeg, hi = min(hi0, lo + kMetricsSeg);
+  if (lo >= hi0) return;
   int n = 0;
-  for (int j = lo + 4 * (int)threadIdx.x; j < hi; j += 4 * 256) {  // (slices are multiples of the chunk height: 4 | C)
+  for (int j = lo + 4 * (int)threadIdx.x; j < hi; j += 4 * 256) {
     if (j + 3 < hi && (lo & 3) == 0) {
       const unsigned m = *(const unsigned*)(mask + j);
       n += 4 - __popc(m & 0x01010101u);
@@ -1014,7 +1019,7 @@ __global__ void k_slice_padding(const int* __restrict__ offsets, const unsigned 
     n = s_w[0] + s_w[1] + s_w[2] + s_w[3];
     if (n) {
       atomicAdd(&out[0], n);
-      atomicAdd(&out[1], 1);
+      if (atomicExch(&flag[s], 1) == 0) atomicAdd(&out[1], 1);
     }
   }
 }
@@ -3069,10 +3074,12 @@ int pp_ps_metrics(const pp_ps* ps, int* padded_cells, int* padded_slices, int* e
   int h[2] = {0, 0};
   if (ps->num_slices > 0 && ps->capacity > 0) {
     static pp::DevBuf* s_m = new pp::DevBuf();
-    PP_HIP_CHECK(s_m->reserve(2 * sizeof(int)));
-    PP_HIP_CHECK(hipMemsetAsync(s_m->p, 0, 2 * sizeof(int), pp::stream()));
-    k_slice_padding<<<ps->num_slices, 256, 0, pp::stream()>>>(ps->d_offsets.as<int>(), ps->d_mask.as<unsigned char>(),
-                                                             s_m->as<int>());
+    const size_t words = 2 + (size_t)ps->num_slices;
+    PP_HIP_CHECK(s_m->reserve(words * sizeof(int)));
+    PP_HIP_CHECK(hipMemsetAsync(s_m->p, 0, words * sizeof(int), pp::stream()));
+    const unsigned segs = (unsigned)(((size_t)ps->V * ps->C + kMetricsSeg - 1) / kMetricsSeg);  // (a slice is at most V x C slots)
+    k_slice_padding<<<dim3((unsigned)ps->num_slices, std::max(segs, 1u)), 256, 0, pp::stream()>>>(
+        ps->d_offsets.as<int>(), ps->d_mask.as<unsigned char>(), s_m->as<int>(), s_m->as<int>() + 2);
     PP_LAUNCH_CHECK();
     PP_HIP_CHECK(hipMemcpyAsync(h, s_m->p, 2 * sizeof(int), hipMemcpyDeviceToHost, pp::stream()));
     PP_HIP_CHECK(hipStreamSynchronize(pp::stream()));

@@ -426,8 +426,19 @@ __global__ void k_map_stamp(const int* __restrict__ map, long long entries, unsi
   const long long n = entries < kStampSamples ? entries : kStampSamples;
   const long long stride = entries / (n > 0 ? n : 1);
   unsigned long long acc = 0;
-  for (long long i = threadIdx.x; i < n; i += blockDim.x)
-    acc += stamp_mix((unsigned long long)i * 0xD6E8FEB86659FD93ULL, (unsigned long long)(unsigned)map[i * stride]);
+  for (long long i0 = threadIdx.x; i0 < n; i0 += 4ll * blockDim.x) {  // (four independent loads in flight)
+    unsigned v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long long i = i0 + (long long)q * blockDim.x;
+      v[q] = i < n ? (unsigned)map[i * stride] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long long i = i0 + (long long)q * blockDim.x;
+      if (i < n) acc += stamp_mix((unsigned long long)i * 0xD6E8FEB86659FD93ULL, (unsigned long long)v[q]);
+    }
+  }
   atomicAdd(&s_sum, acc);
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -449,7 +460,7 @@ int map_stamp_check(const InvMap* inv, const int* v2v) {
   InvMap* m = const_cast<InvMap*>(inv);
   if (m->calls++ % kStampEvery != 0 || !g_map_edited) return PP_OK;
   const int k = m->key[0] == v2v ? 0 : 1;
-  k_map_stamp<<<1, 256, 0, pp::stream()>>>(v2v, m->entries, nullptr, m->stamp[k], g_map_edited);
+  k_map_stamp<<<1, 1024, 0, pp::stream()>>>(v2v, m->entries, nullptr, m->stamp[k], g_map_edited);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -639,8 +650,8 @@ int pp_create_gyro_ring_mappings(const pp_mesh* mesh, double rmax, int gnr, int 
     m->entries = entries;
     pp::DevBuf stamps;
     PP_HIP_CHECK(stamps.reserve(2 * sizeof(unsigned long long)));
-    k_map_stamp<<<1, 256, 0, st>>>(forward_map_dev, entries, stamps.as<unsigned long long>(), 0, nullptr);
-    k_map_stamp<<<1, 256, 0, st>>>(backward_map_dev, entries, stamps.as<unsigned long long>() + 1, 0, nullptr);
+    k_map_stamp<<<1, 1024, 0, st>>>(forward_map_dev, entries, stamps.as<unsigned long long>(), 0, nullptr);
+    k_map_stamp<<<1, 1024, 0, st>>>(backward_map_dev, entries, stamps.as<unsigned long long>() + 1, 0, nullptr);
     PP_LAUNCH_CHECK();
     PP_HIP_CHECK(hipMemcpyAsync(m->stamp, stamps.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     PP_HIP_CHECK(hipStreamSynchronize(st));  // cnt, stamps go out of scope

@@ -168,3 +168,63 @@ def test_reference_ps_combo160_source_runs_unchanged(tmp_path, structure, strat)
     #  the reference)
     dbl0 = d["members"][0][0].view(np.float64)[:cap][live]
     assert np.isfinite(dbl0).mean() > 0.99 and (dbl0[np.isfinite(dbl0)] > 0).all()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def test_reference_pseudoxgcm_source_two_ranks(pp, tmp_path):
+    """The unchanged test/pseudoXGCm.cpp as TWO rank processes sharing the GPU (PP_COMM=tcp): pumipic::read cuts the
+    element-block parts, `p::Distributor<> dist(nBuffers, buffered_ranks)` lists self + the other rank,
+    migrate_lb_ptcls -> ParticleStructure::migrate moves the particles that leave a block, gyroSync ->
+    reduceCommArray sums the fields, MPI_Allreduce / MPI_Barrier / printPtclImb run over the library's communicator.
+    No particle is lost, every particle ends on the rank that owns its element, both ranks hold the same synced field."""
+    import glob
+    exe = _need("pseudoXGCm")
+    s = pp.synth
+    c, e, cl = s.annulus_tri(n_b=24, n_theta=96, b_lo=0.2, band_width=3)
+    ne = len(e)
+    mesh_file = str(tmp_path / "annulus.bin")
+    s.write_mesh_bin(mesh_file, 2, c, e, cl)
+    npt, world, steps = 40000, 2, 10
+    port = _free_port()
+    prefix = str(tmp_path / "two")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), PP_DEVICE="0",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PP_COMM="tcp", PP_COMM_PORT=str(port),
+                   PP_DUMP_ON_DELETE=prefix)
+        procs.append(subprocess.Popen([exe, mesh_file, str(npt), "6", str(steps), "2.0", "1"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, (so[-1500:], se[-3000:])
+    so0, se0 = outs[0]
+    assert "world ranks 2" in so0 and "pre-barrier enabled" in se0 and "done" in se0
+    m = re.search(r"particles created (\d+)", se0)
+    assert m
+    created = int(m.group(1))
+    assert 0 < created <= npt
+    assert ("iter %d particles %d" % (steps, created)) in se0, se0[-1500:]  # nobody lost across the migrations
+    assert re.search(r"Ptcl LB <max, min, avg, imb>: \d+ \d+", so0)
+    assert "Reduced Timing Summary with" in se0 and "migration" in se0
+    total, fields = 0, []
+    for r in range(world):
+        metas = sorted(glob.glob("%s_ps_ps_r%d_*_meta.txt" % (prefix, r)))
+        assert metas, "rank %d wrote no dump" % r
+        base = metas[-1][:-len("_meta.txt")]
+        f = open(base + "_meta.txt").read().split()
+        cap, nptcls = int(f[0]), int(f[2])
+        mask = np.fromfile(base + "_mask.u8", dtype=np.uint8)[:cap].astype(bool)
+        elem = np.fromfile(base + "_elem.i32", dtype=np.int32)[:cap]
+        assert int(mask.sum()) == nptcls
+        total += nptcls
+        owner = (elem[mask].astype(np.int64) * world) // ne
+        assert (owner == r).all(), "rank %d holds particles of another rank's elements" % r
+        fields.append(np.fromfile("%s_tag_0_ptclToMeshSync_r%d.f64" % (prefix, r)))
+    assert total == created
+    assert np.array_equal(fields[0], fields[1]) and fields[0].sum() > 0
