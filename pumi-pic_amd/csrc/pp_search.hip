@@ -2736,7 +2736,11 @@ int pp_push_search(const pp_mesh* mesh, pp_ps* ps, int m_x, int m_xtgt, int m_b,
         const RecIn rin{ps->s_aos_live.as<char>(), ps->s_side_live.as<unsigned>(), (unsigned*)ps->data[2].p,
                         (float*)ps->data[3].p, ps->rec_rm ? 1 : 0,
                         ps->rec_split ? ps->s_side_live.as<uint4>() : nullptr};
-        k_push_walk_rows<2, 4, true><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS, rin);
+        static const bool occ5 = PP_LAB_ENV("PP_PUSH2D_OCC5") != nullptr;  // (lab build: 96 VGPRs + 60 B of scratch, five waves)
+        if (occ5)
+          k_push_walk_rows<2, 5, true><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS, rin);
+        else
+          k_push_walk_rows<2, 4, true><<<rgrid, kBlock, 0, st>>>(PP_ROWS_ARGS, rin);
         ps->lazy_rec = 2;
         ps->zero_z_pending = z_stays_zero;
       } else if (mesh->dim == 2)
