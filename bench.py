@@ -1225,7 +1225,7 @@ def main():
                 "note": "the same W warm-up + K timed steps before the clock pre-warm, on the population as built: "
                         "the shader clock is still ramping AND the step gets faster as the population ages (per-element "
                         "counts even out, the layout needs less padding: 0.639 ms in the first ten steps of a fresh c3 "
-                        "structure, 0.605 after seventy, tools/r04_age_exp.py) -- ms_per_step is measured on steps "
+                        "structure, 0.605 after seventy, tools/history/r04_age_exp.py) -- ms_per_step is measured on steps "
                         "2W+K+1 .. 2W+2K of the structure's life"}
     clock_prewarm(capi, prewarm_s)
     for _ in range(a.warmup):
@@ -1334,7 +1334,7 @@ def main():
     if rank == 0:
         kms = kms_main
         # HBM bytes per launch from the PMC counters: collected with rocprofv3 in separate --pmc
-        # passes of THIS command (tools/r03_measure.sh) and calibrated as DESIGN.md section 4 says;
+        # passes of THIS command (tools/history/r03_measure.sh) and calibrated as DESIGN.md section 4 says;
         # a profiler cannot wrap itself, so the committed summary is reported with its provenance
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.workload)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/traffic_<workload>.json from a tools/r01_measure.sh output directory: FETCH_SIZE and
+"""profiles/traffic_<workload>.json from a tools/history/r01_measure.sh output directory: FETCH_SIZE and
 WRITE_SIZE per kernel, scaled by the calibration run of tools/ub_stream.hip (s_rows<8,4> moves
 exactly 37 B read + 32 B written per slot)."""
 import collections
@@ -40,7 +40,7 @@ def main(out_dir, workload, particles, dest, pmc_dir="pmc"):
     kernels, bpp = KERNELS[workload]
     out = {"workload": workload, "particles": particles, "remainder": "last",
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python3 bench.py "
-                     "--workload %s --steps 10 --warmup 3`, tools/r01_measure.sh; scaled by the calibration "
+                     "--workload %s --steps 10 --warmup 3`, tools/history/r01_measure.sh; scaled by the calibration "
                      "run of tools/ub_stream.hip s_rows<8,4>: FETCH_SIZE[KiB] x 1024 x %.4f, "
                      "WRITE_SIZE[KiB] x 1024 x %.4f" % (workload, rf, wf),
            "kernels": {}}

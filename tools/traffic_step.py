@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """profiles/traffic_<workload>.json for a WHOLE step (c3 / c5): FETCH_SIZE and WRITE_SIZE of every kernel
-a step launches, summed, per step -- from the two --pmc passes of tools/r04_measure.sh (round 3: r03_measure.sh) (`bench.py
+a step launches, summed, per step -- from the two --pmc passes of tools/history/r04_measure.sh (round 3: r03_measure.sh) (`bench.py
 --workload W --steps K --warmup W0` with PP_BENCH_NO_COLD=1 PP_BENCH_PREWARM=0, so every per-step
 kernel runs exactly K + W0 times) and scaled by the calibration run of tools/ub_stream.hip (s_rows<8,4>
 moves exactly 37 B read + 32 B written per slot; MI355X_MICROARCH.md: FETCH_SIZE tallies 128-B requests
