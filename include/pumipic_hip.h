@@ -140,6 +140,9 @@ pp_ps* pp_ps_create_csr(int num_elems, int num_ptcls, const int* ppe_host,
                         const int* member_bytes, const int* member_ncomp,
                         const int* particle_elements_host, const void* const* particle_info_host);
 int pp_ps_destroy(pp_ps* ps);
+/* SellCSigma::copy<MSpace> / CSR::copy, scs/SellCSigma.h:336-391: a deep copy -- the same layout arrays, the same
+ * slots, every member -- as a new, independent structure (ps::copy<Space>(ptcls) of ps_for.hpp:33-55 in the mirror) */
+pp_ps* pp_ps_clone(pp_ps* ps);
 typedef struct pp_ps_info_t {
   int kind, num_elems, num_ptcls, capacity, num_rows;
   int C, V, sigma, num_chunks, num_slices, nmembers;

@@ -84,6 +84,7 @@ SYMBOLS = {
     "pp_ps_create_scs": (_V, [_I, _I, _I, _I, _I, _V, _V, _I, _D, _D, _I, _V, _V, _V, _V]),
     "pp_ps_create_csr": (_V, [_I, _I, _V, _V, _D, _I, _V, _V, _V, _V]),
     "pp_ps_destroy": (_I, [_V]),
+    "pp_ps_clone": (_V, [_V]),
     "pp_ps_info": (_I, [_V, C.POINTER(PsInfo)]),
     "pp_ps_member_ptr": (_V, [_V, _I]),
     "pp_ps_member_stride": (C.c_int64, [_V]),

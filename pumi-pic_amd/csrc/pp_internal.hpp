@@ -262,7 +262,7 @@ struct pp_ps {
   // construction and rebuild, lets pp_gyro_scatter reuse the ring accumulation of the previous call
   unsigned long long version = 0;
   unsigned long long last_max_key = ~0ull;  // largest layout sort key of the previous rebuild (~0 = unknown)
-  int tile_p = pp::kTileP;  // columns per tile (PP_TILE_P overrides, tuning knob)
+  int tile_p = pp::kTileP;  // columns per tile (a constant since round 5: pp::kTileP)
   // SellCSigma::tryShuffling (SellCSigma.h:92,213,236): a rebuild keeps the layout and moves only the
   // particles that change element when every row's arrivals fit its holes (SCS_rebuild.h:4-119)
   // 0 = always the full re-layout (setShuffling(false)); 1 (default) = the reference's decision

@@ -2706,6 +2706,71 @@ pp_ps* pp_ps_create_csr(int num_elems, int num_ptcls, const int* ppe_host,
   return ps;
 }
 
+// SellCSigma::copy<MSpace> / CSR::copy (scs/SellCSigma.h:336-391): a deep copy of the structure -- the same layout
+// arrays, the same slots, every member -- as a new, independent structure (pending passes of the source run first)
+pp_ps* pp_ps_clone(pp_ps* src) {
+  if (!src) {
+    pp::set_error("pp_ps_clone: null structure");
+    return nullptr;
+  }
+  if (pp::ps_ready(src) != PP_OK) return nullptr;
+  (void)pp::slot_elem(src);
+  hipStream_t st = pp::stream();
+  pp_ps* n = new pp_ps();
+  auto dup = [&](pp::DevBuf& dst, const pp::DevBuf& from) -> bool {
+    if (!from.p || from.bytes == 0) return true;
+    if (dst.reserve(from.bytes) != hipSuccess) return false;
+    return hipMemcpyAsync(dst.p, from.p, from.bytes, hipMemcpyDeviceToDevice, st) == hipSuccess;
+  };
+  n->kind = src->kind;
+  n->num_elems = src->num_elems;
+  n->num_ptcls = src->num_ptcls;
+  n->capacity = src->capacity;
+  n->num_rows = src->num_rows;
+  n->C = src->C;
+  n->C_max = src->C_max;
+  n->V = src->V;
+  n->sigma = src->sigma;
+  n->num_chunks = src->num_chunks;
+  n->num_slices = src->num_slices;
+  n->pad_strat = src->pad_strat;
+  n->shuffle_padding = src->shuffle_padding;
+  n->extra_padding = src->extra_padding;
+  n->minimize_size = src->minimize_size;
+  n->padding_amount = src->padding_amount;
+  n->num_empty_elements = src->num_empty_elements;
+  n->nmembers = src->nmembers;
+  n->member_bytes = src->member_bytes;
+  n->member_ncomp = src->member_ncomp;
+  n->member_map = src->member_map;
+  n->stride = src->stride;
+  n->has_gids = src->has_gids;
+  n->gids_identity = src->gids_identity;
+  n->n_gid2lid = src->n_gid2lid;
+  n->ntiles_max = src->ntiles_max;
+  n->tile_p = src->tile_p;
+  n->shuffle_mode = src->shuffle_mode;
+  n->elem_count_valid = src->elem_count_valid;
+  n->slot_elem_valid = true;
+  n->version = pp::next_version();
+  bool ok = true;
+  n->data.resize(src->data.size());
+  n->swap.resize(src->swap.size());
+  for (size_t m = 0; m < src->data.size(); ++m) ok = ok && dup(n->data[m], src->data[m]);
+  ok = ok && dup(n->d_gids, src->d_gids) && dup(n->d_gid2lid, src->d_gid2lid) && dup(n->d_offsets, src->d_offsets) &&
+       dup(n->d_slice_to_chunk, src->d_slice_to_chunk) && dup(n->d_row_to_element, src->d_row_to_element) &&
+       dup(n->d_element_to_row, src->d_element_to_row) && dup(n->d_mask, src->d_mask) &&
+       dup(n->d_slot_elem, src->d_slot_elem) && dup(n->d_chunk_start, src->d_chunk_start) &&
+       dup(n->d_chunk_width, src->d_chunk_width) && dup(n->d_tiles, src->d_tiles) && dup(n->d_ntiles, src->d_ntiles) &&
+       dup(n->d_elem_count, src->d_elem_count) && dup(n->d_eslot0, src->d_eslot0);
+  if (!ok || hipStreamSynchronize(st) != hipSuccess) {
+    pp::set_error("pp_ps_clone: device allocation or copy failed");
+    delete n;
+    return nullptr;
+  }
+  return n;
+}
+
 int pp_ps_destroy(pp_ps* ps) {
   if (ps) {
     // (queued kernels may still read the structure's buffers; the search's counter sets die with it)

@@ -24,6 +24,8 @@ typedef ::pumipic::DeviceSpace DefaultExecutionSpace;
 typedef ::pumipic::HostSpace DefaultHostExecutionSpace;
 typedef ::pumipic::HostSpace HostSpace;
 typedef ::pumipic::HostSpace Serial;
+typedef ::pumipic::DeviceSpace HIPSpace;
+typedef ::pumipic::DeviceSpace HIP;
 
 // Kokkos::View<T*[, Space]>: the device array of the mirror
 namespace detail {

@@ -106,11 +106,35 @@ inline void pp_check(int rc, const char* what) {
   }
 }
 
+// ---------------------------------------------------------------- host copy of a device array
+// (what Kokkos::View<T*>::host_mirror_type is to the reference's tests: deviceToHost(view)(i), (i, j) for the [n][k]
+//  arrays of a member with k components)
+template <class T>
+class HostMirror {
+ public:
+  HostMirror() : ncomp_(1) {}
+  explicit HostMirror(size_t n, int ncomp = 1) : h_(std::make_shared<std::vector<T>>(n * (size_t)ncomp)), n_(n), ncomp_(ncomp) {}
+  T& operator()(size_t i) const { return (*h_)[i]; }
+  T& operator[](size_t i) const { return (*h_)[i]; }
+  T& operator()(size_t i, size_t j) const { return (*h_)[j * n_ + i]; }  // (component-major, like the device array)
+  size_t size() const { return n_; }
+  size_t extent(int) const { return n_; }
+  T* data() const { return h_ ? h_->data() : nullptr; }
+
+ private:
+  std::shared_ptr<std::vector<T>> h_;
+  size_t n_ = 0;
+  int ncomp_;
+};
+
 // ---------------------------------------------------------------- device array (Kokkos::View<T*>)
 template <class T>
 class View {
  public:
   typedef T value_type;
+  typedef T non_const_value_type;
+  typedef HostMirror<T> host_mirror_type;
+  typedef HostMirror<T> HostMirror;
   View() : p_(nullptr), n_(0) {}
   explicit View(size_t n) { alloc(n, true); }
   View(const std::string&, size_t n) { alloc(n, true); }
@@ -168,13 +192,29 @@ class View {
   std::shared_ptr<void> own_;
 };
 
-// support/SupportKK.h:55-100: host array -> device view, device view -> host copy
+// support/SupportKK.h:55-110: host array -> device view, device view -> host copy, the last entry of a device view
 template <class T>
 inline void hostToDevice(View<T> view, const T* data) { view.from_host(data); }
+template <class T, class U, class = typename std::enable_if<!std::is_same<T, U>::value>::type>
+inline void hostToDevice(View<T> view, const U* data) {  // (a host array of another arithmetic type: converted)
+  std::vector<T> t(view.size());
+  for (size_t i = 0; i < t.size(); ++i) t[i] = (T)data[i];
+  view.from_host(t.data());
+}
 template <class T>
-inline std::vector<T> deviceToHost(View<T> view) {
+inline HostMirror<T> deviceToHost(View<T> view) {
   pp_check(pp_sync(), "deviceToHost");
-  return view.to_host();
+  HostMirror<T> h(view.size());
+  if (view.size()) pp_check(pp_memcpy_d2h(h.data(), view.data(), view.size() * sizeof(T)), "deviceToHost");
+  return h;
+}
+template <class ViewT>
+inline typename ViewT::value_type getLastValue(ViewT view) {
+  typename ViewT::value_type v = typename ViewT::value_type();
+  if (view.size() == 0) return v;
+  pp_check(pp_sync(), "getLastValue");
+  pp_check(pp_memcpy_d2h(&v, view.data() + (view.size() - 1), sizeof(v)), "getLastValue");
+  return v;
 }
 
 // ---------------------------------------------------------------- member type lists
@@ -183,10 +223,24 @@ struct MemberTypes;
 template <>
 struct MemberTypes<> {
   static constexpr std::size_t size = 0;
+  static constexpr std::size_t memsize = 0;
+  template <std::size_t N>
+  static constexpr std::size_t sizeToIndex() {
+    return 0;
+  }
 };
 template <typename H, typename... T>
 struct MemberTypes<H, T...> {
   static constexpr std::size_t size = 1 + MemberTypes<T...>::size;
+  // bytes of one particle (support/MemberTypes.h:30-45) and of the members in front of member N
+  static constexpr std::size_t memsize = sizeof(H) + MemberTypes<T...>::memsize;
+  template <std::size_t N>
+  static constexpr std::size_t sizeToIndex() {
+    if constexpr (N == 0)
+      return 0;
+    else
+      return sizeof(H) + MemberTypes<T...>::template sizeToIndex<N - 1>();
+  }
 };
 template <std::size_t N, typename... Types>
 struct MemberTypeAtIndexImpl;
@@ -311,6 +365,29 @@ void destroyViews(MemberTypeViews v) {
   for (std::size_t m = 0; m < DataTypes::size; ++m) (void)pp_free(v[m]);
   delete[] v;
 }
+// hostToDevice / deviceToHost on a member view of an MTV (particle_structs/test/read_particles.hpp:55-61,82-88): the
+// host side is an array of n values of Type (n x k for a member with k components, particle-major), the device side
+// component-major [k][n]
+template <class Type>
+inline void hostToDevice(Segment<Type> seg, const Type* data) {
+  typedef typename BaseType<Type>::type B;
+  const size_t n = (size_t)seg.stride(), k = (size_t)BaseType<Type>::size;
+  if (n == 0) return;
+  std::vector<B> t(n * k);
+  const B* src = (const B*)data;
+  for (size_t i = 0; i < n; ++i)
+    for (size_t j = 0; j < k; ++j) t[j * n + i] = src[i * k + j];
+  pp_check(pp_memcpy_h2d(seg.data(), t.data(), t.size() * sizeof(B)), "hostToDevice");
+}
+template <class Type>
+inline HostMirror<typename BaseType<Type>::type> deviceToHost(Segment<Type> seg) {
+  typedef typename BaseType<Type>::type B;
+  const size_t n = (size_t)seg.stride(), k = (size_t)BaseType<Type>::size;
+  pp_check(pp_sync(), "deviceToHost");
+  HostMirror<B> h(n, (int)k);
+  if (n) pp_check(pp_memcpy_d2h(h.data(), seg.data(), n * k * sizeof(B)), "deviceToHost");
+  return h;
+}
 
 // ---------------------------------------------------------------- policy / distributor stand-ins
 struct TeamPolicy {
@@ -414,8 +491,15 @@ class ParticleStructure {
   using DataType = typename MemberTypeAtIndex<N, DataTypes>::type;
   template <std::size_t N>
   using Slice = Segment<DataType<N>>;
+  typedef typename kkLidView::host_mirror_type kkLidHostMirror;
+  typedef typename kkGidView::host_mirror_type kkGidHostMirror;
+  typedef ParticleStructure<DataTypes, HostSpace> HostMirror;
+  template <typename Space2>
+  using Mirror = ParticleStructure<DataTypes, Space2>;
 
   ParticleStructure() : h_(nullptr), name_("ptcls") {}
+  // adopts a library handle (ps::copy<DeviceSpace>(host copy) makes its structure this way)
+  ParticleStructure(pp_ps* adopted, const std::string& name) : h_(adopted), name_(name) {}
   virtual ~ParticleStructure() {
     if (h_ && getenv("PP_DUMP_ON_DELETE")) dumpOnDelete(getenv("PP_DUMP_ON_DELETE"));
     if (h_) (void)pp_ps_destroy(h_);
@@ -566,6 +650,9 @@ class ParticleStructure {
     pp_check(pp_ps_info(h_, &i), "pp_ps_info");
     return i;
   }
+  // structure->parallel_for(lambda, name) (scs/SellCSigma.h:110-111): the member form of ps::parallel_for
+  template <typename FunctionType>
+  void parallel_for(FunctionType& fn, std::string name = "");
 
  protected:
   // PP_DUMP_ON_DELETE=<prefix>: a structure writes itself to <prefix>_ps_<name>_r<rank>_<serial>_{meta.txt, mask.u8,
@@ -789,6 +876,12 @@ void parallel_for(ParticleStructure<DataTypes, MemSpace>* ps, FunctionType& fn, 
                        (hipStream_t)pp_stream(), it.capacity, it.slot_elem, it.mask, fn);
 }
 
+template <class DataTypes, typename MemSpace>
+template <typename FunctionType>
+void ParticleStructure<DataTypes, MemSpace>::parallel_for(FunctionType& fn, std::string name) {
+  pumipic::parallel_for(this, fn, name);
+}
+
 // ---------------------------------------------------------------- ps::copy<MSpace> (ps_for.hpp:33-55)
 // The reference copies a structure into another memory space (SellCSigma::copy<MSpace>, scs/SellCSigma.h:336-391:
 // a deep copy of every layout array and member view) -- its tests read a device structure back with it and run
@@ -796,15 +889,16 @@ void parallel_for(ParticleStructure<DataTypes, MemSpace>* ps, FunctionType& fn, 
 // same read interface (nElems / nPtcls / capacity / numRows, get<N>() -> Segment over host memory, the layout arrays,
 // ps::parallel_for on the host); rebuild / migrate stay with the device structure.
 template <class DataTypes>
-class HostParticleStructure {
+class ParticleStructure<DataTypes, HostSpace> {
  public:
   typedef DataTypes Types;
+  typedef HostSpace memory_space;
   template <std::size_t N>
   using DataType = typename MemberTypeAtIndex<N, DataTypes>::type;
   template <std::size_t N>
   using Slice = Segment<DataType<N>>;
   template <class MemSpace>
-  explicit HostParticleStructure(ParticleStructure<DataTypes, MemSpace>* old) : name_(old->getName()), i_(old->info()) {
+  explicit ParticleStructure(ParticleStructure<DataTypes, MemSpace>* old) : name_(old->getName()), i_(old->info()) {
     const auto b = MemberMeta<DataTypes>::bytes();
     const auto c = MemberMeta<DataTypes>::ncomp();
     data_.resize(DataTypes::size);
@@ -822,6 +916,11 @@ class HostParticleStructure {
     pp_check(pp_ps_layout_to_host(old->handle(), offsets.data(), scs ? slice_to_chunk.data() : nullptr,
                                   scs ? row_to_element.data() : nullptr, scs ? element_to_row.data() : nullptr,
                                   particle_mask.data(), slot_element.data()), "ps::copy (layout)");
+    // the layout of the copy as the library holds it: a deep copy on the device, which ps::copy<DeviceSpace>(this)
+    // turns into the new device structure (with the members as they are HERE at that time)
+    pp_ps* t = pp_ps_clone(old->handle());
+    if (!t) pp_check(PP_EHIP, "ps::copy (device twin)");
+    twin_ = std::shared_ptr<pp_ps>(t, [](pp_ps* q) { (void)pp_ps_destroy(q); });
   }
   const std::string& getName() const { return name_; }
   lid_t nElems() const { return i_.num_elems; }
@@ -835,6 +934,15 @@ class HostParticleStructure {
     using B = typename BaseType<DataType<N>>::type;
     return Slice<N>((B*)data_[N].data(), i_.stride, (int)N);
   }
+  // a new device structure with this copy's layout and members (SellCSigma::copy<MSpace> towards the device)
+  pp_ps* to_device() const {
+    pp_ps* n = pp_ps_clone(twin_.get());
+    if (!n) pp_check(PP_EHIP, "ps::copy (to the device)");
+    if (i_.capacity > 0)
+      for (std::size_t m = 0; m < DataTypes::size; ++m)
+        pp_check(pp_ps_member_from_host(n, (int)m, data_[m].data()), "ps::copy (members to the device)");
+    return n;
+  }
   // layout arrays of the snapshot (SellCSigma.h:186-215 / CSR.hpp:92-93), host memory
   std::vector<lid_t> offsets, slice_to_chunk, row_to_element, element_to_row, slot_element;
   std::vector<unsigned char> particle_mask;
@@ -843,22 +951,36 @@ class HostParticleStructure {
   std::string name_;
   pp_ps_info_t i_;
   std::vector<std::vector<char>> data_;
+  std::shared_ptr<pp_ps> twin_;
 };
+template <class DataTypes>
+using HostParticleStructure = ParticleStructure<DataTypes, HostSpace>;
+
+// copy<MSpace>(structure): device -> host snapshot, host snapshot -> a new device structure; the same space on both
+// sides is refused as in the reference (scs/SellCSigma.h:339-342)
 template <typename MSpace, typename DataTypes, typename MemSpace>
-HostParticleStructure<DataTypes>* copy(ParticleStructure<DataTypes, MemSpace>* old) {
-  if (!old || !old->handle()) {
+ParticleStructure<DataTypes, MSpace>* copy(ParticleStructure<DataTypes, MemSpace>* old) {
+  if (!old) {
     fprintf(stderr, "Structure does not support copy\n");
     throw 1;  // ps_for.hpp:52-54
   }
-  if (!std::is_same<MSpace, HostSpace>::value) {  // scs/SellCSigma.h:339-342
+  if constexpr (std::is_same<MSpace, MemSpace>::value) {
     fprintf(stderr, "Copy to same memory space not supported\n");
     exit(EXIT_FAILURE);
+    return nullptr;
+  } else if constexpr (std::is_same<MSpace, HostSpace>::value) {
+    if (!old->handle()) {
+      fprintf(stderr, "Structure does not support copy\n");
+      throw 1;
+    }
+    return new ParticleStructure<DataTypes, HostSpace>(old);
+  } else {
+    return new ParticleStructure<DataTypes, MSpace>(old->to_device(), old->getName());
   }
-  return new HostParticleStructure<DataTypes>(old);
 }
 // the same PS_LAMBDA on the host copy: every slot in slot order
 template <typename FunctionType, typename DataTypes>
-void parallel_for(HostParticleStructure<DataTypes>* ps, FunctionType& fn, std::string = "") {
+void parallel_for(ParticleStructure<DataTypes, HostSpace>* ps, FunctionType& fn, std::string = "") {
   if (!ps) {
     fprintf(stderr, "Structure does not support parallel for\n");
     throw 1;
@@ -874,3 +996,8 @@ void parallel_for(HostParticleStructure<DataTypes>* ps, FunctionType& fn, std::s
 }  // namespace pumipic
 
 namespace particle_structs = pumipic;
+
+// The reference's <particle_structs.hpp> brings MPI and Kokkos with it, and its own tests and drivers spell those names
+// after including nothing else (particle_structs/test/test_types.hpp:14-16): the facades over the C-ABI and HIP
+#include "pumipic_mpi.hpp"
+#include "compat/Kokkos_Core.hpp"

@@ -228,3 +228,54 @@ def test_reference_pseudoxgcm_source_two_ranks(pp, tmp_path):
         fields.append(np.fromfile("%s_tag_0_ptclToMeshSync_r%d.f64" % (prefix, r)))
     assert total == created
     assert np.array_equal(fields[0], fields[1]) and fields[0].sum() > 0
+
+
+# ---------------------------------------------------------------- the reference's OWN particle-structure tests
+# particle_structs/test/testing.cmake:1-33, unchanged sources (tools/ref_conformance.py): the programs print
+# "All tests passed" / return the number of failed checks.
+def _run_ranks(cmd, world, cwd, timeout=600, extra_env=None):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), PP_DEVICE="0",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PP_COMM="tcp", PP_COMM_PORT=str(port))
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen(cmd, env=env, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    return [(p.returncode, so, se) for p, (so, se) in zip(procs, outs)]
+
+
+@pytest.mark.parametrize("name", ["typeTest", "initParticles", "buildSCSTest", "lambdaTest", "test_scs_padding"])
+def test_reference_particle_structs_unit_programs(tmp_path, name):
+    """typeTest / initParticles / buildSCSTest / lambdaTest / scs_padding of particle_structs/test, unchanged"""
+    exe = _need(name)
+    (rc, so, se), = _run_ranks([exe], 1, str(tmp_path), timeout=300)
+    assert rc == 0, (so[-2000:], se[-2000:])
+    assert "FAIL" not in so.upper().replace("FAILS", "") or "All tests passed" in so, so[-2000:]
+
+
+@pytest.mark.parametrize("ranks,ne,npt,estrat,pstrat,tag", [
+    (1, 5, 25, 0, 0, "small_ptcls_e5_p25_r0"),
+    (1, 500, 100000, 0, 2, "medium_ptcls_e500_p10e5_r0"),
+    (4, 5, 25, 0, 2, "small_ptcls_e5_p25_r4"),
+    (4, 100, 10000, 0, 2, "small_ptcls_e100_p10k_r4"),
+    (4, 0, 0, 0, 0, "empty_ptcls"),
+    (4, 100, 0, 0, 0, "no_ptcls_e100"),
+])
+def test_reference_test_structure_passes(tmp_path, ranks, ne, npt, estrat, pstrat, tag):
+    """write_particles <ne> <np> <element strat> <particle strat> <prefix>, then test_structure <prefix>, with the rank
+    counts of the reference's ctest plan (testing.cmake:17-31): the reference's own checks of counts, parallel_for,
+    getPIDs, the five rebuild scenarios, migrateSendRight / migrateSendToOne, printMetrics, copy to the host and back,
+    getComponents, migrate-to-empty-and-refill -- on Sell-32-sigma-max, Sell-32-sigma-1-V10 and CSR -- must all pass
+    on this library."""
+    wr, ts = _need("write_particles"), _need("test_structure")
+    res = _run_ranks([wr, str(ne), str(npt), str(estrat), str(pstrat), tag], ranks, str(tmp_path))
+    for rc, so, se in res:
+        assert rc == 0, (so[-1500:], se[-1500:])
+    for r in range(ranks):
+        assert os.path.exists(os.path.join(str(tmp_path), "%s_%d.ptl" % (tag, r)))
+    res = _run_ranks([ts, tag], ranks, str(tmp_path), timeout=900)
+    for r, (rc, so, se) in enumerate(res):
+        assert rc == 0, "rank %d: %s\n%s" % (r, so[-3000:], se[-3000:])
+        assert "[ERROR]" not in so and "[ERROR]" not in se, (so[-3000:], se[-3000:])
+    assert "All tests passed" in res[0][1], res[0][1][-2000:]

@@ -22,7 +22,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -DNDEBUG: a Release build, as the reference's performance runs are (test/gyroScatter.hpp:68 asserts that every ring
 # point of the gyro map is found within 100 walk iterations, which a mesh with thin elements does not grant)
 FLAGS = ["--offload-arch=gfx950", "-std=c++17", "-O2", "-DNDEBUG", "-x", "hip", "-ffp-contract=off", "-fno-fast-math",
-         "-DFP64", "-DPP_USE_HIP", "-Wno-unused-result", "-Wno-unused-value", "-Wno-unused-variable",
+         "-DFP64", "-DPP_USE_HIP", "-DPP_USE_GPU", "-Wno-unused-result", "-Wno-unused-value", "-Wno-unused-variable",
          "-I", os.path.join(INC, "compat"), "-I", INC]
 
 # executable -> the reference translation units it is made of (reference-relative paths)
@@ -31,6 +31,16 @@ UNITS = {
     "pseudoPushAndSearch": ["test/pseudoPushAndSearch.cpp"],
     "ps_combo160": ["performance_tests/ps_combo160.cpp", "particle_structs/test/Distribute.cpp"],
     "ps_combo264": ["performance_tests/ps_combo264.cpp", "particle_structs/test/Distribute.cpp"],
+    # the reference's OWN tests of the particle-structure API (particle_structs/test/testing.cmake:1-33): the particle
+    # file writer, then test_structure -- counts, parallel_for, getPIDs, five rebuild scenarios, two migrations, copy to
+    # the host and back, SubSegment, migrate-to-empty-and-refill -- on SCS (two parameter sets) and CSR, 1 and 4 ranks
+    "write_particles": ["particle_structs/test/write_particle_file.cpp", "particle_structs/test/Distribute.cpp"],
+    "test_structure": ["particle_structs/test/test_structure.cpp"],
+    "typeTest": ["particle_structs/test/typeTest.cpp", "particle_structs/test/Distribute.cpp"],
+    "initParticles": ["particle_structs/test/initParticles.cpp", "particle_structs/test/Distribute.cpp"],
+    "buildSCSTest": ["particle_structs/test/buildSCSTest.cpp", "particle_structs/test/Distribute.cpp"],
+    "lambdaTest": ["particle_structs/test/lambdaTest.cpp", "particle_structs/test/Distribute.cpp"],
+    "test_scs_padding": ["particle_structs/test/scs_padding.cpp", "particle_structs/test/Distribute.cpp"],
 }
 
 
@@ -55,6 +65,13 @@ def build(name):
     return r.returncode == 0, r.stderr, exe
 
 
+def build_all(workers=4):
+    """every executable of UNITS, a few hipcc runs side by side -> {name: (ok, diagnostics, path)}"""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        return dict(zip(UNITS, ex.map(build, UNITS)))
+
+
 def main():
     if not have_reference():
         print("no reference tree at", REF)
@@ -74,8 +91,7 @@ def main():
     print("%d of %d reference translation units compile unchanged" % (ok_n, len(rels)))
     bad = len(rels) - ok_n
     if "--build" in sys.argv:
-        for name in UNITS:
-            ok, err, exe = build(name)
+        for name, (ok, err, exe) in build_all().items():
             print("%-24s %s" % (name, exe if ok else "LINK FAILS\n" + err[-2000:]))
             bad += not ok
     return 1 if bad else 0
