@@ -94,7 +94,26 @@ struct RecTable {
   const char* src[kRecMaxWords];
   int scale[kRecMaxWords];
   char* dst[kRecMaxWords];  // unpack: destination arrays [ncomp][n]
+  // bit w set: word w carries a member scalar of 1 or 2 bytes (scale[w]) in its low bytes -- a `short` or `char` member
+  // (particle_structs/test/test_types.hpp:12: MemberTypes<int, Vector3, short, int>) travels as one word per component
+  unsigned long long narrow;
 };
+__device__ __forceinline__ unsigned rec_load(const RecTable& t, int w, long long i) {
+  const char* p = t.src[w] + i * t.scale[w];
+  if (w < 64 && (t.narrow >> w & 1ull)) return t.scale[w] == 2 ? (unsigned)*(const unsigned short*)p : (unsigned)*(const unsigned char*)p;
+  return *(const unsigned*)p;
+}
+__device__ __forceinline__ void rec_store(const RecTable& t, int w, long long i, unsigned v) {
+  char* p = t.dst[w] + i * t.scale[w];
+  if (w < 64 && (t.narrow >> w & 1ull)) {
+    if (t.scale[w] == 2)
+      *(unsigned short*)p = (unsigned short)v;
+    else
+      *(unsigned char*)p = (unsigned char)v;
+  } else {
+    *(unsigned*)p = v;
+  }
+}
 __global__ void k_pack_records(int capacity, const unsigned char* __restrict__ mask,
                                int* new_element, const int* __restrict__ new_process, int rank,
                                int nranks, int* __restrict__ cursor,
@@ -112,7 +131,7 @@ __global__ void k_pack_records(int capacity, const unsigned char* __restrict__ m
   r[0] = (unsigned)(g & 0xffffffffll);
   r[1] = (unsigned)((unsigned long long)g >> 32);
   for (int w = 0; w < t.nwords; ++w)
-    r[2 + w] = t.src[w] ? *(const unsigned*)(t.src[w] + (long long)pid * t.scale[w]) : 0u;
+    r[2 + w] = t.src[w] ? rec_load(t, w, pid) : 0u;
   new_element[pid] = -1;  // removeSentParticles (SCS_migrate.h:189-196)
 }
 __global__ void k_unpack_records(int n, const unsigned* __restrict__ rec, const int* __restrict__ gid2lid,
@@ -129,7 +148,7 @@ __global__ void k_unpack_records(int n, const unsigned* __restrict__ rec, const 
   }
   if (lid < 0) *bad = 1;
   elems[i] = lid;
-  for (int w = 0; w < t.nwords; ++w) *(unsigned*)(t.dst[w] + (long long)i * t.scale[w]) = r[2 + w];
+  for (int w = 0; w < t.nwords; ++w) rec_store(t, w, i, r[2 + w]);
 }
 
 // ---- routing.  A per-particle atomicAdd on one of `nranks` counters serialises in the L2 (~10 ns each: 3 ms for
@@ -265,7 +284,7 @@ __global__ void k_route_pack(int capacity, const unsigned char* __restrict__ des
       unsigned v[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k)
-        v[k] = (w0 + k < t.nwords && t.src[w0 + k]) ? *(const unsigned*)(t.src[w0 + k] + (long long)pid * t.scale[w0 + k]) : 0u;
+        v[k] = (w0 + k < t.nwords && t.src[w0 + k]) ? rec_load(t, w0 + k, pid) : 0u;
 #pragma unroll
       for (int k = 0; k < 8; ++k)
         if (w0 + k < t.nwords) r[2 + w0 + k] = v[k];
@@ -293,10 +312,14 @@ int build_rec_table(const pp_ps* ps, RecTable& t, int commit_x = -1, int commit_
   for (int m = 0; m < ps->nmembers; ++m) {
     const int s = ps->member_map[m == commit_x ? commit_xt : m];
     const int b = ps->member_bytes[s];
-    PP_REQUIRE(b == 4 || b == 8, "migration records need 4- or 8-byte member scalars");
+    PP_REQUIRE(b == 1 || b == 2 || b == 4 || b == 8, "migration records need member scalars of 1, 2, 4 or 8 bytes");
     for (int c = 0; c < ps->member_ncomp[s]; ++c)
-      for (int hw = 0; hw < b / 4; ++hw) {
+      for (int hw = 0; hw < (b < 4 ? 1 : b / 4); ++hw) {
         PP_REQUIRE(nw < kRecMaxWords, "particle record too large for the migration pack");
+        if (b < 4) {
+          PP_REQUIRE(nw < 64, "a 1- or 2-byte member must lie within the first 64 words of the migration record");
+          t.narrow |= 1ull << nw;
+        }
         t.src[nw] = m == commit_xt ? nullptr : (const char*)ps->data[s].p + ((size_t)c * ps->stride) * b + hw * 4;
         t.scale[nw] = b;
         t.dst[nw] = nullptr;
@@ -518,7 +541,7 @@ static int rebuild_from_records(pp_ps* ps, int m_x, int m_xtgt, const int* new_e
     PP_HIP_CHECK(info[m].reserve((size_t)n_tot * nc * b));
     ptrs[m] = info[m].p;
     for (int c = 0; c < nc; ++c) {
-      for (int hw = 0; hw < b / 4; ++hw) t.dst[w++] = (char*)info[m].p + ((size_t)c * n_tot) * b + hw * 4;
+      for (int hw = 0; hw < (b < 4 ? 1 : b / 4); ++hw) t.dst[w++] = (char*)info[m].p + ((size_t)c * n_tot) * b + hw * 4;
       if (n_extra > 0)
         PP_HIP_CHECK(hipMemcpyAsync((char*)info[m].p + ((size_t)c * n_tot + n_recv) * b,
                                     (const char*)extra_info_dev[m] + ((size_t)c * n_extra) * b,

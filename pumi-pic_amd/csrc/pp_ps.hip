@@ -2570,7 +2570,7 @@ pp_ps* pp_ps_create_scs(int C, int sigma, int V, int num_elems, int num_ptcls,
                         double shuffle_padding, double extra_padding, int nmembers,
                         const int* member_bytes, const int* member_ncomp,
                         const int* particle_elements_host, const void* const* particle_info_host) {
-  if (C < 1 || V < 1 || num_elems < 0 || num_ptcls < 0 || !ppe_host) {
+  if (C < 1 || V < 1 || num_elems < 0 || num_ptcls < 0 || (!ppe_host && num_elems > 0)) {
     pp::set_error("pp_ps_create_scs: bad arguments");
     return nullptr;
   }
@@ -2646,7 +2646,7 @@ pp_ps* pp_ps_create_csr(int num_elems, int num_ptcls, const int* ppe_host,
                         const int64_t* gids_host, double padding_amount, int nmembers,
                         const int* member_bytes, const int* member_ncomp,
                         const int* particle_elements_host, const void* const* particle_info_host) {
-  if (num_elems < 0 || num_ptcls < 0 || !ppe_host) {
+  if (num_elems < 0 || num_ptcls < 0 || (!ppe_host && num_elems > 0)) {
     pp::set_error("pp_ps_create_csr: bad arguments");
     return nullptr;
   }
