@@ -1664,6 +1664,10 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
                 bool try_reshuffle = true, bool new_xt_zero = false) {
   hipStream_t st = pp::stream();
   const int ne = ps->num_elems;
+  if (ne == 0) {  // a structure without elements holds nothing and can take nothing (the reference's "empty_ptcls" runs)
+    PP_REQUIRE(n_new == 0, "rebuild: a structure without elements cannot take new particles");
+    return PP_OK;
+  }
   PP_REQUIRE(n_new == 0 || new_info != nullptr, "rebuild: new particles need new_info_dev");
   ps->search_nf = -1;
   // zeros left pending by the previous in-place rebuild; records left by the previous full re-layout.
@@ -2253,6 +2257,10 @@ int csr_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
                 const void* const* new_info) {
   hipStream_t st = pp::stream();
   const int ne = ps->num_elems;
+  if (ne == 0) {  // (see scs_rebuild)
+    PP_REQUIRE(n_new == 0, "rebuild: a structure without elements cannot take new particles");
+    return PP_OK;
+  }
   PP_HIP_CHECK(ps->s_ppe.reserve(sizeof(int) * ((size_t)ne + 1)));
   PP_HIP_CHECK(ps->s_misc.reserve(sizeof(Totals)));
   PP_HIP_CHECK(hipMemsetAsync(ps->s_ppe.p, 0, sizeof(int) * ((size_t)ne + 1), st));

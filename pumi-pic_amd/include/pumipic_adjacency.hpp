@@ -102,6 +102,9 @@ class Input {
   enum Ownership { PARTITION, CLASSIFICATION };
   inline Input(Mesh& mesh, Ownership rule, const std::vector<int>& partition_vector, Method bufferMethod_,
                Method safeMethod_, pp_comm* comm_ = nullptr);
+  // (the reference passes the owners as Omega_h::Write<LO>: test/search2d.cpp:193-195)
+  inline Input(Mesh& mesh, Ownership rule, const View<int>& partition_vector, Method bufferMethod_,
+               Method safeMethod_, pp_comm* comm_ = nullptr);
   Ownership getRule() const { return ownership_rule; }
   const std::vector<int>& getPartition() const { return partition; }
   static Method getMethod(std::string s) {  // pumipic_input.cpp:139-150
@@ -364,10 +367,33 @@ class Mesh {
     ensure_partition(dim);
     return owners_;
   }
-  View<unsigned char> safeTag() {
-    if (part_) return part_view<unsigned char>(PP_PART_SAFE, dim_);
+  // safeTag(): the reference hands out Omega_h::LOs (one int per element, src/pumipic_mesh.hpp:66); the library keeps
+  // the tag as bytes.  The returned object is the byte view (data(), size(), operator[]) and converts to an int view
+  // on demand (made once per mesh: `Omega_h::LOs is_safe = picparts.safeTag();`, test/search2d.cpp:60).
+  struct SafeTag {
+    View<unsigned char> bytes;
+    Mesh* owner;
+    operator View<unsigned char>() const { return bytes; }
+    operator View<int>() const { return owner->safe_as_ints(bytes); }
+    PP_INLINE unsigned char* data() const { return bytes.data(); }
+    PP_INLINE size_t size() const { return bytes.size(); }
+    PP_INLINE unsigned char& operator[](size_t i) const { return bytes[i]; }
+    std::vector<unsigned char> to_host() const { return bytes.to_host(); }
+  };
+  SafeTag safeTag() {
+    if (part_) return SafeTag{part_view<unsigned char>(PP_PART_SAFE, dim_), this};
     ensure_partition(dim_);
-    return safe_;
+    return SafeTag{safe_, this};
+  }
+  View<int> safe_as_ints(const View<unsigned char>& bytes) {
+    if (safe_ints_.size() != bytes.size() || safe_ints_src_ != bytes.data()) {
+      safe_ints_ = View<int>::uninitialized(std::max(bytes.size(), (size_t)1));
+      const unsigned char* b = bytes.data();
+      int* out = safe_ints_.data();
+      o::parallel_for((o::LO)bytes.size(), [=] __host__ __device__(o::LO i) { out[i] = b[i]; }, "safeTag");
+      safe_ints_src_ = bytes.data();
+    }
+    return View<int>::wrap(safe_ints_.data(), bytes.size());
   }
   o::GOs globalIds(int dim) {  // full-mesh replica without an Input: global id == local id
     if (part_) return part_view<o::GO>(PP_PART_GIDS, dim);
@@ -500,6 +526,8 @@ class Mesh {
   std::map<std::string, View<double>> real_tags_;
   std::map<std::string, View<int>> int_tags_;
   std::shared_ptr<Mesh> parent_;
+  View<int> safe_ints_;
+  const unsigned char* safe_ints_src_ = nullptr;
 };
 
 inline Input::Input(Mesh& mesh, Ownership rule, const std::vector<int>& partition_vector, Method bufferMethod_,
@@ -513,6 +541,11 @@ inline Input::Input(Mesh& mesh, Ownership rule, const std::vector<int>& partitio
   if (bufferMethod == MINIMUM) bufferBFSLayers = 0;  // :133-136
   if (safeMethod == MINIMUM) safeBFSLayers = 0;
 }
+
+inline Input::Input(Mesh& mesh, Ownership rule, const View<int>& partition_vector, Method bufferMethod_,
+                    Method safeMethod_, pp_comm* comm_)
+    : Input(mesh, rule, (pp_check(pp_sync(), "pumipic::Input"), partition_vector.to_host()), bufferMethod_, safeMethod_,
+            comm_) {}
 
 // ---------------------------------------------------------------- pumipic::ParticleBalancer
 // (src/pumipic_lb.hpp:33-118) over pp_balancer: sbars, weights and the selection as in the reference, the

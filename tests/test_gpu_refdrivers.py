@@ -279,3 +279,29 @@ def test_reference_test_structure_passes(tmp_path, ranks, ne, npt, estrat, pstra
         assert rc == 0, "rank %d: %s\n%s" % (r, so[-3000:], se[-3000:])
         assert "[ERROR]" not in so and "[ERROR]" not in se, (so[-3000:], se[-3000:])
     assert "All tests passed" in res[0][1], res[0][1][-2000:]
+
+
+# ---------------------------------------------------------------- the reference's OWN 2-D search test
+# test/search2d.cpp (test/CMakeLists.txt: `search2d ${TEST_DATA_DIR}`), unchanged source built WITH asserts: each of its
+# 14 walks on the 8-triangle plate ends in a device-side `assert(e == destElm || e == altDestElm)` (search2d.cpp:176).
+# Its second half reads xgc/24k.osh, a mesh of the separate pumipic-data repository that is not in the reference tree:
+# the program must get through all of testTri8 and stop exactly there.
+_SEARCH2D_DEST = [(5,), (5,), (5,), (0,), (0,), (0,), (1,), (3, 5), (7,), (0, 2), (3,), (0, 2), (1,), (4,)]
+
+
+def test_reference_search2d_tri8_asserts_hold(pp, tmp_path):
+    exe = _need("search2d")
+    s = pp.synth
+    coords, e2v, cls = s.plate_tri8_pardiag()
+    os.makedirs(os.path.join(str(tmp_path), "plate"))
+    s.write_mesh_bin(os.path.join(str(tmp_path), "plate", "tri8_parDiag.osh"), 2, coords, e2v, cls)
+    (rc, so, se), = _run_ranks([exe, str(tmp_path)], 1, str(tmp_path), timeout=300)
+    assert "Mesh loaded with <v e f r> 9 16 8 8" in so, (so[-2000:], se[-2000:])
+    import re
+    got = [int(m.group(1)) for m in re.finditer(r"pid 0 elm (\d+) \(x,y\)", so)]
+    assert len(got) == len(_SEARCH2D_DEST), (got, so[-3000:], se[-3000:])
+    for e, ok in zip(got, _SEARCH2D_DEST):
+        assert e in ok, (got, _SEARCH2D_DEST)
+    # every assert held (an abort would show as a signal, rc < 0); the only failure is the absent 24k mesh
+    assert rc == 1 and "xgc/24k.osh: not a mesh container" in se, (rc, se[-1500:])
+    assert "Assertion" not in se

@@ -41,7 +41,12 @@ UNITS = {
     "buildSCSTest": ["particle_structs/test/buildSCSTest.cpp", "particle_structs/test/Distribute.cpp"],
     "lambdaTest": ["particle_structs/test/lambdaTest.cpp", "particle_structs/test/Distribute.cpp"],
     "test_scs_padding": ["particle_structs/test/scs_padding.cpp", "particle_structs/test/Distribute.cpp"],
+    # the reference's own 2-D adjacency-search test (test/CMakeLists.txt search2d): 14 one-particle walks on the 8-triangle
+    # plate, each closed by a device-side assert on the destination element -- built WITH asserts (see ASSERTS_ON)
+    "search2d": ["test/search2d.cpp"],
 }
+# units whose checks are assert()s: compiled without -DNDEBUG so that a wrong destination element aborts the program
+ASSERTS_ON = {"search2d"}
 
 
 def have_reference():
@@ -59,7 +64,8 @@ def build(name):
     os.makedirs(OUT, exist_ok=True)
     exe = os.path.join(OUT, name)
     srcs = [os.path.join(REF, rel) for rel in UNITS[name]]
-    cmd = [HIPCC] + FLAGS + srcs + ["-o", exe, "-L", os.path.join(ROOT, "pumi-pic_amd"), "-lpumipic_hip",
+    flags = [f for f in FLAGS if not (name in ASSERTS_ON and f == "-DNDEBUG")]
+    cmd = [HIPCC] + flags + srcs + ["-o", exe, "-L", os.path.join(ROOT, "pumi-pic_amd"), "-lpumipic_hip",
                                    "-Wl,-rpath,$ORIGIN/../../pumi-pic_amd"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     return r.returncode == 0, r.stderr, exe
