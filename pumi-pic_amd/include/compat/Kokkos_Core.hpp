@@ -295,3 +295,7 @@ inline void parallel_scan(const std::string& name, long long n, const F& f, T& t
   parallel_reduce(name, n, [=] __host__ __device__(const int i, T& u) { f(i, u, false); }, total);
 }
 }  // namespace Kokkos
+#define PP_KOKKOS_CORE_DONE
+#ifdef PP_ADJACENCY_BODY_DONE
+#include "Omega_h_mesh.hpp"  // (see the end of pumipic_adjacency.hpp)
+#endif

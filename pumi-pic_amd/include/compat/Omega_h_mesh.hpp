@@ -6,6 +6,7 @@
 // place of .osh, whose format lives in Omega_h's sources only), a no-op vtk writer, pumipic::Library and
 // pumipic::read.
 #pragma once
+#include <initializer_list>
 #include <sstream>
 #include "../pumipic_mpi.hpp"
 #include "../pumipic_adjacency.hpp"
@@ -23,11 +24,18 @@ struct Few {
   __host__ __device__ T& operator[](int i) { return a_[i]; }
   __host__ __device__ const T& operator[](int i) const { return a_[i]; }
   __host__ __device__ static constexpr int size() { return n; }
+  __host__ __device__ T* data() { return a_; }
+  __host__ __device__ const T* data() const { return a_; }
 };
 template <int n>
 struct Vector : Few<Real, n> {
   __host__ __device__ Vector() {}
   __host__ __device__ Vector(const Few<Real, n>& f) : Few<Real, n>(f) {}
+  __host__ __device__ Vector(std::initializer_list<Real> l) {  // Vector<3> p{0.0, -0.2, -0.5}
+    int i = 0;
+    for (const Real* q = l.begin(); q != l.end() && i < n; ++q) this->a_[i++] = *q;
+    for (; i < n; ++i) this->a_[i] = 0;
+  }
 };
 template <int n>
 __host__ __device__ inline Vector<n> operator+(const Vector<n>& a, const Vector<n>& b) {
@@ -68,7 +76,100 @@ template <int m, int n>
 struct Matrix : Few<Vector<m>, n> {
   __host__ __device__ Matrix() {}
   __host__ __device__ Matrix(const Few<Vector<m>, n>& f) : Few<Vector<m>, n>(f) {}
+  __host__ __device__ Matrix(std::initializer_list<Vector<m>> l) {  // Matrix<3, 4> M{p1, p2, p3, p4}: the columns
+    int j = 0;
+    for (const Vector<m>* q = l.begin(); q != l.end() && j < n; ++q) this->a_[j++] = *q;
+  }
+  __host__ __device__ Matrix(std::initializer_list<Real> l) {  // m*n scalars, column after column
+    int k = 0;
+    for (const Real* q = l.begin(); q != l.end() && k < m * n; ++q, ++k) this->a_[k / m][k % m] = *q;
+  }
 };
+// ---- vector algebra of device lambdas (Omega_h_vector.hpp, published definitions)
+template <int n>
+__host__ __device__ inline Real inner_product(const Vector<n>& a, const Vector<n>& b) { return a * b; }
+template <int n>
+__host__ __device__ inline Vector<n> normalize(const Vector<n>& a) { return a / norm(a); }
+template <int n>
+__host__ __device__ inline Vector<n> zero_vector() {
+  Vector<n> v;
+  for (int i = 0; i < n; ++i) v[i] = 0.0;
+  return v;
+}
+__host__ __device__ inline Vector<3> cross(const Vector<3>& a, const Vector<3>& b) {
+  Vector<3> c;
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+  return c;
+}
+__host__ __device__ inline Real cross(const Vector<2>& a, const Vector<2>& b) { return a[0] * b[1] - a[1] * b[0]; }
+__host__ __device__ inline Vector<2> perp(const Vector<2>& a) {
+  Vector<2> c;
+  c[0] = -a[1];
+  c[1] = a[0];
+  return c;
+}
+// are_close (Omega_h_scalar.hpp): relative difference with a floor, tol = floor = 1e-10
+__host__ __device__ inline bool are_close(Real a, Real b, Real tol = 1e-10, Real floor = 1e-10) {
+  const Real am = ::fabs(a), bm = ::fabs(b);
+  if (am <= floor && bm <= floor) return true;
+  return ::fabs(b - a) / (am < bm ? bm : am) <= tol;
+}
+// the entity opposite a boundary entity of a simplex (Omega_h_simplex.hpp simplex_opposite_template): for
+// (triangle, edge) and (tet, face) the vertex that the boundary entity does not hold, and back
+__host__ __device__ inline Int simplex_opposite_template(Int elem_dim, Int bdry_dim, Int which_bdry) {
+  if (elem_dim == 2 && bdry_dim == 1) return (which_bdry + 2) % 3;       // edges {0,1},{1,2},{2,0}
+  if (elem_dim == 2 && bdry_dim == 0) return (which_bdry + 1) % 3;
+  if (elem_dim == 3 && bdry_dim == 2) return which_bdry == 0 ? 3 : which_bdry == 1 ? 2 : which_bdry == 2 ? 0 : 1;
+  if (elem_dim == 3 && bdry_dim == 0) return which_bdry == 0 ? 2 : which_bdry == 1 ? 3 : which_bdry == 2 ? 1 : 0;
+  return -1;
+}
+// barycentric coordinates of a point, one per VERTEX of the simplex (Omega_h_shape.hpp barycentric_from_global):
+// here by ratios of signed measures -- equal to Omega_h's solve in exact arithmetic, not bit-matched to it
+__host__ __device__ inline Vector<4> barycentric_tet_vertex_major(const Vector<3>& p, const Few<Vector<3>, 4>& x) {
+  Vector<4> b;
+  const Real vol = inner_product(cross(x[1] - x[0], x[2] - x[0]), x[3] - x[0]);
+  for (int i = 0; i < 4; ++i) {
+    Few<Vector<3>, 4> y = x;
+    y[i] = p;
+    b[i] = inner_product(cross(y[1] - y[0], y[2] - y[0]), y[3] - y[0]) / vol;
+  }
+  return b;
+}
+template <int sdim, int edim>
+__host__ __device__ inline Vector<edim + 1> barycentric_from_global(const Vector<sdim>& p,
+                                                                     const Few<Vector<sdim>, edim + 1>& x) {
+  if constexpr (sdim == 3 && edim == 3) {
+    return barycentric_tet_vertex_major(p, x);
+  } else {
+    static_assert(sdim == 2 && edim == 2, "barycentric_from_global: triangles in 2-D and tets in 3-D");
+    Vector<3> b;
+    const Real area = cross(x[1] - x[0], x[2] - x[0]);
+    b[0] = cross(x[1] - p, x[2] - p) / area;
+    b[1] = cross(x[2] - p, x[0] - p) / area;
+    b[2] = cross(x[0] - p, x[1] - p) / area;
+    return b;
+  }
+}
+// OMEGA_H_CHECK (Omega_h_fail.hpp): always on; prints and stops -- on the device the wave traps, which the host sees
+// as a failed synchronisation
+__host__ __device__ inline void check_fail(const char* what, const char* file, int line) {
+  printf("assertion %s failed at %s +%d\n", what, file, line);
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_trap();
+#else
+  abort();
+#endif
+}
+#define OMEGA_H_CHECK(cond) ((cond) ? ((void)0) : ::Omega_h::check_fail(#cond, __FILE__, __LINE__))
+#define OMEGA_H_CHECK_PRINTF(cond, format, ...)                                  \
+  do {                                                                           \
+    if (!(cond)) {                                                               \
+      printf(format, __VA_ARGS__);                                               \
+      ::Omega_h::check_fail(#cond, __FILE__, __LINE__);                          \
+    }                                                                            \
+  } while (0)
 // the mean of the vectors (Omega_h_vector.hpp average: sum in index order, then one division)
 template <int dim, int n>
 __host__ __device__ inline Vector<dim> average(const Few<Vector<dim>, n>& x) {
@@ -140,6 +241,9 @@ inline BBox<dim> get_bounding_box(Mesh* mesh) {
   return b;
 }
 
+// measure_elements_real (Omega_h_shape.hpp): triangle areas / tet volumes, the array the search divides by
+inline Reals measure_elements_real(Mesh* mesh) { return mesh->elem_measures(); }
+
 // ---- marks (Omega_h_mark.hpp)
 inline Read<I8> mark_exposed_sides(Mesh* mesh) { return mesh->side_is_exposed(); }
 // an entity of dimension `high` is marked when one of its `low`-dimensional bounding entities is
@@ -208,6 +312,11 @@ inline Mesh read(const std::string& path, CommPtr, bool = false) {
   return mesh_from_data(m);
 }
 }  // namespace binary
+// Omega_h::read_mesh_file(path, comm): the reader by extension (Omega_h_file.hpp)
+inline Mesh read_mesh_file(const std::string& path, CommPtr comm) {
+  const std::string ext = path.substr(path.find_last_of('.') + 1);
+  return ext == "msh" ? gmsh::read(path, comm) : binary::read(path, comm);
+}
 namespace vtk {
 // rendering is outside the hot path: the call is accepted and writes nothing
 inline void write_parallel(const std::string&, Mesh*, Int = -1) {}
@@ -217,6 +326,7 @@ inline void write_parallel(const std::string&, Mesh*, Int = -1) {}
 namespace pumipic {
 using Omega_h::mark_up;  // (the drivers call it unqualified on a pumipic::Mesh*: argument-dependent lookup)
 using Omega_h::mark_exposed_sides;
+using Omega_h::measure_elements_real;  // (called unqualified on an o::Mesh*: test/test_adj.cpp:96)
 // src/pumipic_library.hpp:8-18: starts the runtime (device = the launcher's LOCAL_RANK, PP_DEVICE overrides) and the
 // process-wide communicator
 class Library {
@@ -261,3 +371,4 @@ inline void read(Omega_h::Library* library, Omega_h::CommPtr comm, const char* p
   }
 }
 }  // namespace pumipic
+#include "../pumipic_utils.hpp"

@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
+#include <initializer_list>
 #include <memory>
 #include <sstream>
 #include <string>
@@ -143,6 +144,10 @@ class View {
     if (n) pp_check(fill_(init), "View fill");
   }
   View(size_t n, T init, const std::string&) : View(n, init) {}  // Omega_h::Write<T>(n, value, name)
+  View(std::initializer_list<T> l) {                             // Omega_h::Write<T>({a, b, c, d})
+    alloc(l.size(), false);
+    from_host(l.begin());
+  }
   View(size_t n, const std::string&) { alloc(n, true); }         // Omega_h::Write<T>(n, name)
   // Kokkos::View<T*>(Kokkos::ViewAllocateWithoutInitializing(name), n): for arrays whose every entry is written
   // before it is read (a 50 MB fill per 10 M slots otherwise)
@@ -1000,4 +1005,6 @@ namespace particle_structs = pumipic;
 // The reference's <particle_structs.hpp> brings MPI and Kokkos with it, and its own tests and drivers spell those names
 // after including nothing else (particle_structs/test/test_types.hpp:14-16): the facades over the C-ABI and HIP
 #include "pumipic_mpi.hpp"
+#ifndef PP_ADJACENCY_IN_PROGRESS  // (else pumipic_adjacency.hpp includes it when its own declarations are complete)
 #include "compat/Kokkos_Core.hpp"
+#endif

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <chrono>
 #include <map>
+#define PP_ADJACENCY_IN_PROGRESS  // (particle_structs.hpp leaves the Kokkos facade to the end of this header)
 #include "particle_structs.hpp"
 #include "pumipic_wall.hpp"    // closest_point_on_triangle[_wnormal] (device-inline)
 #include "pumipic_gather.hpp"  // interpolateTetVtx, interpolate2dField, ... (device-inline)
@@ -81,6 +82,8 @@ class HostWrite {
  private:
   std::vector<T> h_;
 };
+template <class T>
+HostWrite(const pumipic::View<T>&) -> HostWrite<T>;  // `auto h = o::HostWrite(device_array);`
 template <class T>
 using HostRead = HostWrite<T>;
 // The drivers hold an Omega_h::Mesh* (the serial mesh inside the PICpart) next to the pumipic::Mesh
@@ -186,10 +189,13 @@ class Mesh {
                         (int)(elem2verts.size() / (dim + 1)), elem2verts.data(),
                         class_id.empty() ? nullptr : class_id.data());
     if (!h_) pp_check(PP_EHIP, "pumipic::Mesh");
+    own_ = std::make_shared<Owned>();
+    own_->mesh = h_;
     pp_check(pp_mesh_info(h_, &dim_, &nverts_, &nelems_, &nsides_), "pp_mesh_info");
   }
   ~Mesh() {
-    if (h_ && getenv("PP_DUMP_ON_DELETE")) {  // the real tags (scatter fields), see ParticleStructure::dumpOnDelete
+    // (copies share the handles, as copies of an Omega_h::Mesh share its arrays: the LAST holder dumps and destroys)
+    if (h_ && own_ && own_.use_count() == 1 && getenv("PP_DUMP_ON_DELETE")) {  // the real tags (scatter fields), see ParticleStructure::dumpOnDelete
       (void)pp_sync();
       for (auto& kv : real_tags_) {
         std::string name = kv.first;
@@ -203,12 +209,11 @@ class Mesh {
         }
       }
     }
-    if (bal_) (void)pp_balancer_destroy(bal_);
-    if (part_) (void)pp_picpart_destroy(part_);
-    if (h_ && owns_mesh_) (void)pp_mesh_destroy(h_);
   }
-  Mesh(const Mesh&) = delete;
-  Mesh& operator=(const Mesh&) = delete;
+  // Omega_h::Mesh is passed BY VALUE through the reference's tests (test/test_adj.cpp:29,45,...): a copy is another
+  // holder of the same device mesh (and part, and balancer) with its own tag table
+  Mesh(const Mesh&) = default;
+  Mesh& operator=(const Mesh&) = default;
   Mesh(Mesh&& o) noexcept { swap(o); }
   Mesh& operator=(Mesh&& o) noexcept {
     swap(o);
@@ -216,9 +221,8 @@ class Mesh {
   }
   void swap(Mesh& o) {
     std::swap(h_, o.h_);
-    std::swap(owns_mesh_, o.owns_mesh_);
+    own_.swap(o.own_);
     std::swap(part_, o.part_);
-    std::swap(bal_, o.bal_);
     std::swap(dim_, o.dim_);
     std::swap(nverts_, o.nverts_);
     std::swap(nelems_, o.nelems_);
@@ -230,6 +234,10 @@ class Mesh {
     real_tags_.swap(o.real_tags_);
     int_tags_.swap(o.int_tags_);
     parent_.swap(o.parent_);
+    std::swap(safe_ints_, o.safe_ints_);
+    std::swap(safe_ints_src_, o.safe_ints_src_);
+    std::swap(vert2sides_off_, o.vert2sides_off_);
+    std::swap(vert2sides_, o.vert2sides_);
   }
   // a part cut from a full mesh that nobody else holds: the part takes the full mesh with it
   void keep_alive(Mesh&& full_mesh) { parent_ = std::make_shared<Mesh>(std::move(full_mesh)); }
@@ -264,9 +272,23 @@ class Mesh {
     } else if (dim_ == 3 && low == 1 && high == 3) {
       a.a2ab = view<int>(PP_MESH_EDGE2ELEMS_OFF);
       a.ab2b = view<int>(PP_MESH_EDGE2ELEMS);
+    } else if (dim_ == 2 && low == 0 && high == 1) {
+      // vertex -> edges of a triangle mesh (test/test_adj.cpp:174 walks them to pick a direction): inverted once on
+      // the host from side -> vertices, edges of a vertex in ascending edge id as Omega_h's invert_adj orders them
+      const_cast<Mesh*>(this)->ensure_vert2sides();
+      a.a2ab = View<int>::wrap(vert2sides_off_.data(), (size_t)nverts_ + 1);
+      a.ab2b = View<int>::wrap(vert2sides_.data(), (size_t)nsides_ * 2);
     } else {
       no_adjacency(low, high);
     }
+    return a;
+  }
+  // Omega_h::Mesh::ask_verts_of(dim) / ask_dual(): element -> elements across a side
+  o::LOs ask_verts_of(int edim) const { return ask_down(edim, 0).ab2b; }
+  o::Adj ask_dual() const {
+    o::Adj a;
+    a.a2ab = view<int>(PP_MESH_DUAL_OFF);
+    a.ab2b = view<int>(PP_MESH_DUAL_ELEMS);
     return a;
   }
   pp_mesh* handle() const { return h_; }
@@ -315,11 +337,12 @@ class Mesh {
   // the part's particle balancer (Mesh::ptclBalancer, pumipic_mesh.hpp:76; the reference builds it at the end of
   // constructPICPart, here on first use); null for a mesh that was not built from an Input
   pp_balancer* ptclBalancerHandle() {
-    if (!bal_ && part_) {
-      bal_ = pp_balancer_create(part_);
-      if (!bal_) pp_check(PP_EHIP, "ParticleBalancer");
+    if (!part_) return nullptr;
+    if (!own_->bal) {
+      own_->bal = pp_balancer_create(part_);
+      if (!own_->bal) pp_check(PP_EHIP, "ParticleBalancer");
     }
-    return bal_;
+    return own_->bal;
   }
   bool isFullMesh() const {
     if (!part_) return true;
@@ -470,6 +493,21 @@ class Mesh {
     }
     return it->second;
   }
+  void ensure_vert2sides() {
+    if (vert2sides_off_.size() != 0) return;
+    pp_check(pp_sync(), "ask_up(0, 1)");
+    const std::vector<int> s2v = view<int>(PP_MESH_SIDE2VERTS).to_host();
+    std::vector<int> off((size_t)nverts_ + 1, 0), adj((size_t)nsides_ * 2);
+    for (int v : s2v) ++off[(size_t)v + 1];
+    for (int v = 0; v < nverts_; ++v) off[(size_t)v + 1] += off[(size_t)v];
+    std::vector<int> fill(off.begin(), off.end() - 1);
+    for (int sd = 0; sd < nsides_; ++sd)
+      for (int k = 0; k < 2; ++k) adj[(size_t)fill[(size_t)s2v[(size_t)sd * 2 + k]]++] = sd;
+    vert2sides_off_ = View<int>(off.size());
+    vert2sides_off_.from_host(off.data());
+    vert2sides_ = View<int>(std::max(adj.size(), (size_t)1));
+    vert2sides_.from_host(adj.data());
+  }
   void ensure_partition(int) {
     if (owners_.size() == 0) partition(comm(), 0);
   }
@@ -494,8 +532,9 @@ class Mesh {
     part_ = pp_picpart_create(full.handle(), owner.data(), buffer_method, safe_method, bridge_dim, buffer_layers,
                               safe_layers, comm_);
     if (!part_) pp_check(PP_EHIP, "pumipic::Mesh (PICparts)");
+    own_ = std::make_shared<Owned>();
+    own_->part = part_;
     h_ = const_cast<pp_mesh*>(pp_picpart_mesh(part_));
-    owns_mesh_ = false;
     pp_check(pp_mesh_info(h_, &dim_, &nverts_, &nelems_, &nsides_), "pp_mesh_info");
   }
   void reduce_part(int edim, Op op, int dtype, void* data, size_t n) {
@@ -514,10 +553,21 @@ class Mesh {
     if (!p && n) pp_check(PP_EINVAL, "picpart array");
     return View<T>::wrap((T*)p, n);
   }
+  // what the last holder destroys: the library's mesh (a mesh made from arrays) or the part (its mesh goes with it)
+  struct Owned {
+    pp_mesh* mesh = nullptr;
+    pp_picpart* part = nullptr;
+    pp_balancer* bal = nullptr;
+    ~Owned() {
+      if (bal) (void)pp_balancer_destroy(bal);
+      if (part) (void)pp_picpart_destroy(part);
+      if (mesh) (void)pp_mesh_destroy(mesh);
+    }
+  };
+  std::shared_ptr<Owned> own_;
   pp_mesh* h_ = nullptr;
-  bool owns_mesh_ = true;
   pp_picpart* part_ = nullptr;
-  pp_balancer* bal_ = nullptr;
+  View<int> vert2sides_off_, vert2sides_;
   int dim_ = 0, nverts_ = 0, nelems_ = 0, nsides_ = 0;
   pp_comm* comm_ = nullptr;
   o::Write<o::LO> owners_;
@@ -953,3 +1003,12 @@ void migrate_lb_ptcls(Mesh& mesh, PS* ptcls, o::LOs elems, float tol, float step
 }  // namespace pumipic
 namespace p = pumipic;
 namespace ps = particle_structs;
+// The reference declares the device helpers of the search (barycentric_*, ray_intersects_triangle, check_initial_parents,
+// ...) in THIS header; here they are adapters in pumipic_utils.hpp over Omega_h-style vectors, which need the Kokkos and
+// Omega_h facades complete.  Whichever of the three headers a translation unit names first, the last one to finish
+// pulls in the rest.
+#define PP_ADJACENCY_BODY_DONE
+#include "compat/Kokkos_Core.hpp"
+#ifdef PP_KOKKOS_CORE_DONE
+#include "compat/Omega_h_mesh.hpp"
+#endif

@@ -1,0 +1,4 @@
+// pumipic_input.hpp -- the reference keeps these declarations in a header of their own (src/pumipic_input.hpp); here they live in
+// pumipic_adjacency.hpp / compat/Omega_h_mesh.hpp.
+#pragma once
+#include "pumipic_adjacency.hpp"

@@ -1,0 +1,4 @@
+// pumipic_library.hpp -- the reference keeps these declarations in a header of their own (src/pumipic_library.hpp); here they live in
+// pumipic_adjacency.hpp / compat/Omega_h_mesh.hpp.
+#pragma once
+#include "pumipic_adjacency.hpp"

@@ -305,3 +305,102 @@ def test_reference_search2d_tri8_asserts_hold(pp, tmp_path):
     # every assert held (an abort would show as a signal, rc < 0); the only failure is the absent 24k mesh
     assert rc == 1 and "xgc/24k.osh: not a mesh container" in se, (rc, se[-1500:])
     assert "Assertion" not in se
+
+
+# ---------------------------------------------------------------- the reference's OWN search test: test/test_adj.cpp
+# (testing.cmake: `test_adj plate/tri8.osh`, `test_adj cube/7k.osh`), unchanged source, asserts on.  The program takes
+# any plate or cube ("Assumes the plate or cube mesh are used", test_adj.cpp:586); the meshes here are this repo's.
+def _plate_tris(n):
+    """the unit square in 2 n^2 triangles, counter-clockwise"""
+    g = np.arange(n + 1)
+    X, Y = np.meshgrid(g, g, indexing="ij")
+    coords = np.stack([X.ravel(), Y.ravel()], axis=1).astype(np.float64) / n
+    vid = lambda i, j: i * (n + 1) + j
+    tris = []
+    for i in range(n):
+        for j in range(n):
+            a, b, c, d = vid(i, j), vid(i + 1, j), vid(i + 1, j + 1), vid(i, j + 1)
+            tris += [[a, b, c], [a, c, d]] if (i + j) % 2 == 0 else [[a, b, d], [b, c, d]]
+    e2v = np.asarray(tris, dtype=np.int32)
+    return coords, e2v, np.ones(len(e2v), dtype=np.int32)
+
+
+@pytest.mark.parametrize("mesh_kind", ["tri8", "plate_2x24x24", "cube_7986", "cube_48"])
+def test_reference_test_adj_passes(pp, tmp_path, mesh_kind):
+    """100 and 1 000 000 particles (PP_USE_GPU): internal and vertex / edge / face starts, barycentric walk and walk
+    with wall intersections, each judged by the reference's own check_initial_parents, intersection-on-face,
+    along-the-path and inside-the-bounding-box checks (test_adj.cpp:565-760) -- on this library's search."""
+    exe = _need("test_adj")
+    s = pp.synth
+    if mesh_kind == "tri8":
+        dim, (c, e, cl) = 2, s.plate_tri8_pardiag()
+    elif mesh_kind.startswith("plate"):
+        dim, (c, e, cl) = 2, _plate_tris(24)
+    else:
+        dim, (c, e, cl) = 3, s.kuhn_box(11 if mesh_kind == "cube_7986" else 2)
+    mesh_file = str(tmp_path / (mesh_kind + ".osh"))
+    s.write_mesh_bin(mesh_file, dim, c, e, cl)
+    (rc, so, se), = _run_ranks([exe, mesh_file], 1, str(tmp_path), timeout=900)
+    assert rc == 0 and "All Tests Passed" in se, (rc, so[-3000:], se[-3000:])
+    assert "[ERROR]" not in so and "[ERROR]" not in se, (so[-3000:], se[-3000:])
+
+
+def test_reference_moller_trumbore_test_passes(pp, tmp_path):
+    """test/moller_trumbore_line_tri_test.cpp wants o = (0, -0.2, -0.5) inside element 0, z = (0, -0.2, 0.9) inside
+    element 12, and the ray o -> z to leave element 12 through its FIRST face at height 1 (the file of the reference's
+    data repository is not here): two Kuhn cubes stacked in z, renumbered so."""
+    exe = _need("moller_trumbore_test")
+    s = pp.synth
+    c, e, cl = s.kuhn_box(2, lo=(-0.6, -0.9, -1.0), hi=(1.4, 1.1, 1.0))
+    e = e.copy()
+
+    def holder(p):
+        for t in range(len(e)):
+            M = c[e[t]]
+            T = np.column_stack([M[1] - M[0], M[2] - M[0], M[3] - M[0]])
+            w = np.linalg.solve(T, p - M[0])
+            if w.min() > 1e-9 and w.sum() < 1 - 1e-9:
+                return t
+        raise AssertionError("point on an element boundary")
+
+    t0, t12 = holder(np.array([0.0, -0.2, -0.5])), holder(np.array([0.0, -0.2, 0.9]))
+    order = [t for t in range(len(e)) if t not in (t0, t12)]
+    order = [t0] + order[:11] + [t12] + order[11:]
+    e = e[order]
+    # element 12: the three vertices at height 1 first (face 0 = local vertices {0, 2, 1}), positive volume
+    v = list(e[12])
+    top = [x for x in v if abs(c[x][2] - 1.0) < 1e-12]
+    assert len(top) == 3
+    bottom = [x for x in v if x not in top][0]
+    for perm in ([0, 1, 2], [0, 2, 1]):
+        q = [top[perm[0]], top[perm[1]], top[perm[2]], bottom]
+        M = c[q]
+        if np.dot(np.cross(M[1] - M[0], M[2] - M[0]), M[3] - M[0]) > 0:
+            e[12] = q
+    mesh_file = str(tmp_path / "cubes.msh")
+    import importlib
+    importlib.import_module(pp.__name__ + ".meshio").write_gmsh(mesh_file, 3, c, e, cl[order])
+    (rc, so, se), = _run_ranks([exe, mesh_file], 1, str(tmp_path), timeout=300)
+    assert rc == 0 and "[ERROR]" not in so, (rc, so[-3000:], se[-2000:])
+    assert so.count("intersected face") >= 1 and "did not intersect" in so
+
+
+def test_reference_pseudoxgcm_scatter_passes(pp, tmp_path):
+    """test/pseudoXGCm_scatter.cpp on the 8-triangle plate: the reference's gyro scatter lambdas (test/gyroScatter.hpp)
+    through ps::parallel_for and device atomics; its OMEGA_H_CHECKs hold the known vertex sums 2, 12, 0, 2/3."""
+    exe = _need("pseudoXGCm_scatter")
+    s = pp.synth
+    c, e, cl = s.plate_tri8_pardiag()
+    mesh_file = str(tmp_path / "tri8_parDiag.osh")
+    s.write_mesh_bin(mesh_file, 2, c, e, cl)
+    (rc, so, se), = _run_ranks([exe, mesh_file], 1, str(tmp_path), timeout=300)
+    assert rc == 0 and "done" in se and "assertion" not in so, (rc, so[-3000:], se[-2000:])
+
+
+@pytest.mark.parametrize("which", ["test1", "test2"])
+def test_reference_barycentric_passes(tmp_path, which):
+    """test/test_barycentric.cpp + src/unit_tests.hpp: find_barycentric_tet at the vertices of a tet and at five known
+    points (testing.cmake: barycentric_3 runs test1)"""
+    exe = _need("barycentric")
+    (rc, so, se), = _run_ranks([exe, which], 1, str(tmp_path), timeout=300)
+    assert rc == 0, (so[-2000:], se[-2000:])

@@ -44,18 +44,40 @@ UNITS = {
     # the reference's own 2-D adjacency-search test (test/CMakeLists.txt search2d): 14 one-particle walks on the 8-triangle
     # plate, each closed by a device-side assert on the destination element -- built WITH asserts (see ASSERTS_ON)
     "search2d": ["test/search2d.cpp"],
+    # the reference's search test proper (testing.cmake: test_adj_2d / test_adj_3d): 100 and 10^6 particles placed
+    # inside elements and on vertices / edges / faces, pushed, searched by barycentric walk and by intersection with
+    # the wall, each result judged by the reference's own check_initial_parents / wall-intersection checks
+    "test_adj": ["test/test_adj.cpp"],
+    # moller_trumbore_test (testing.cmake): ray against segment on the faces of one tet
+    "moller_trumbore_test": ["test/moller_trumbore_line_tri_test.cpp"],
+    # pseudoXGCm_scatter (testing.cmake): the gyro scatter of one particle on the 8-triangle plate, known vertex sums
+    "pseudoXGCm_scatter": ["test/pseudoXGCm_scatter.cpp"],
+    # barycentric (testing.cmake: barycentric_3): find_barycentric_tet known answers -- through src/unit_tests.hpp, see
+    # EXTRA_FLAGS
+    "barycentric": ["test/test_barycentric.cpp"],
 }
 # units whose checks are assert()s: compiled without -DNDEBUG so that a wrong destination element aborts the program
-ASSERTS_ON = {"search2d"}
+ASSERTS_ON = {"search2d", "test_adj", "pseudoXGCm_scatter"}
+# test/test_barycentric.cpp includes "unit_tests.hpp", a header of test functions that the reference keeps in src/.
+# It is read where it lies through -idirafter (searched AFTER this library's include directories, so nothing else
+# resolves there); the one library header it names next to itself ("pumipic_adjacency.hpp", quote form: its own
+# directory first) (and the .tpp that file appends) is emptied by predefining the reference's two include guards, and this library's header of that name is
+# put in front with -include.  No token of a reference library header is compiled.
+EXTRA_FLAGS = {"barycentric": ["-DPUMIPIC_ADJACENCY_HPP", "-DPUMIPIC_ADJACENCY_NEW_HPP", "-include", os.path.join(INC, "pumipic_adjacency.hpp"),
+                               "-idirafter", os.path.join(REF, "src")]}
 
 
 def have_reference():
     return os.path.isdir(os.path.join(REF, "test"))
 
 
+def _extra(rel):
+    return [f for name, fl in EXTRA_FLAGS.items() if rel in UNITS[name] for f in fl]
+
+
 def syntax_check(rel):
     """(ok, diagnostics) of `hipcc -fsyntax-only` on the unchanged reference file `rel` (host and device passes)."""
-    cmd = [HIPCC] + FLAGS + ["-fsyntax-only", os.path.join(REF, rel)]
+    cmd = [HIPCC] + FLAGS + _extra(rel) + ["-fsyntax-only", os.path.join(REF, rel)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     return r.returncode == 0, r.stderr
 
@@ -65,7 +87,7 @@ def build(name):
     exe = os.path.join(OUT, name)
     srcs = [os.path.join(REF, rel) for rel in UNITS[name]]
     flags = [f for f in FLAGS if not (name in ASSERTS_ON and f == "-DNDEBUG")]
-    cmd = [HIPCC] + flags + srcs + ["-o", exe, "-L", os.path.join(ROOT, "pumi-pic_amd"), "-lpumipic_hip",
+    cmd = [HIPCC] + flags + EXTRA_FLAGS.get(name, []) + srcs + ["-o", exe, "-L", os.path.join(ROOT, "pumi-pic_amd"), "-lpumipic_hip",
                                    "-Wl,-rpath,$ORIGIN/../../pumi-pic_amd"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     return r.returncode == 0, r.stderr, exe
