@@ -397,10 +397,11 @@ def test_reference_pseudoxgcm_scatter_passes(pp, tmp_path):
     assert rc == 0 and "done" in se and "assertion" not in so, (rc, so[-3000:], se[-2000:])
 
 
-@pytest.mark.parametrize("which", ["test1", "test2"])
+@pytest.mark.parametrize("which", ["test1", "test3"])
 def test_reference_barycentric_passes(tmp_path, which):
-    """test/test_barycentric.cpp + src/unit_tests.hpp: find_barycentric_tet at the vertices of a tet and at five known
-    points (testing.cmake: barycentric_3 runs test1)"""
+    """test/test_barycentric.cpp + src/unit_tests.hpp: find_barycentric_tet at the vertices of a tet
+    (testing.cmake: barycentric_3 runs test1).  `test2` is not run by the reference's plan and cannot pass anywhere:
+    unit_tests.hpp:55-63 stores the coordinates in an integer array before comparing them with 0.1, 0.15, ..."""
     exe = _need("barycentric")
     (rc, so, se), = _run_ranks([exe, which], 1, str(tmp_path), timeout=300)
     assert rc == 0, (so[-2000:], se[-2000:])
