@@ -6,6 +6,7 @@
 // place of .osh, whose format lives in Omega_h's sources only), a no-op vtk writer, pumipic::Library and
 // pumipic::read.
 #pragma once
+#include <array>
 #include <initializer_list>
 #include <sstream>
 #include "../pumipic_mpi.hpp"
@@ -271,8 +272,32 @@ class Library {
   CommPtr world() const { return CommPtr(pumipic::comm_world()); }
   CommPtr self() const { return CommPtr(pumipic::comm_world()); }  // (a reader's comm argument is unused here)
 };
+// the mesh of a reader's arrays; boundary entities listed by the file become the sides' `class_id` (sides the file does
+// not list: -1 -- Omega_h gives those the id of the region around them, which no driver here asks for)
 inline Mesh mesh_from_data(pumipic::gmsh::MeshData& m) {
-  return Mesh(m.dim, m.coords, m.elem2verts, m.class_id);
+  Mesh mesh(m.dim, m.coords, m.elem2verts, m.class_id);
+  if (!m.side_class.empty()) {
+    const int d = m.dim, ns = mesh.nsides();
+    pumipic::pp_check(pp_sync(), "side classification");
+    const std::vector<int> s2v = mesh.ask_verts_of(d - 1).to_host();
+    auto key = [d](const int* v) {
+      int a[3] = {v[0], v[1], d == 3 ? v[2] : -1};
+      std::sort(a, a + 3);
+      return std::array<int, 3>{a[0], a[1], a[2]};
+    };
+    std::map<std::array<int, 3>, int> listed;
+    for (size_t i = 0; i < m.side_class.size(); ++i) listed[key(&m.side_verts[i * (size_t)d])] = m.side_class[i];
+    std::vector<int> cls((size_t)ns, -1);
+    for (int sd = 0; sd < ns; ++sd) {
+      auto it = listed.find(key(&s2v[(size_t)sd * (size_t)d]));
+      if (it != listed.end()) cls[(size_t)sd] = it->second;
+    }
+    Write<LO> side_class((size_t)std::max(ns, 1));
+    side_class.from_host(cls.data());
+    mesh.set_tag(d - 1, "class_id", Write<LO>::wrap(side_class.data(), (size_t)ns));
+    mesh.set_tag(d - 1, "class_id:storage", side_class);  // (keeps the allocation alive next to the exact-size view)
+  }
+  return mesh;
 }
 namespace gmsh {
 inline Mesh read(const std::string& path, CommPtr) {

@@ -208,6 +208,18 @@ class Mesh {
           fclose(f);
         }
       }
+      for (auto& kv : int_tags_) {  // (has_particles of test/pseudoPushAndSearch.cpp: which elements ever held a particle)
+        if (kv.first.find(":storage") != std::string::npos) continue;
+        std::string name = kv.first;
+        for (auto& ch : name)
+          if (ch == ':' || ch == '/') ch = '_';
+        const std::string fn = std::string(getenv("PP_DUMP_ON_DELETE")) + "_itag_" + name + "_r" + std::to_string(rank()) + ".i32";
+        const std::vector<int> h = kv.second.to_host();
+        if (FILE* f = fopen(fn.c_str(), "wb")) {
+          fwrite(h.data(), sizeof(int), h.size(), f);
+          fclose(f);
+        }
+      }
     }
   }
   // Omega_h::Mesh is passed BY VALUE through the reference's tests (test/test_adj.cpp:29,45,...): a copy is another
@@ -536,6 +548,12 @@ class Mesh {
     own_->part = part_;
     h_ = const_cast<pp_mesh*>(pp_picpart_mesh(part_));
     pp_check(pp_mesh_info(h_, &dim_, &nverts_, &nelems_, &nsides_), "pp_mesh_info");
+    // a part that buffers the whole mesh numbers its entities as the full mesh does: the full mesh's tags (the side
+    // classification a reader attached, fields a driver added) are the part's too, as the reference's parts carry them
+    if (nverts_ == full.nverts() && nelems_ == full.nelems() && nsides_ == full.nsides()) {
+      real_tags_ = full.real_tags_;
+      int_tags_ = full.int_tags_;
+    }
   }
   void reduce_part(int edim, Op op, int dtype, void* data, size_t n) {
     const int ne = nents(edim);

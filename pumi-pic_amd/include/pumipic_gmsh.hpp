@@ -6,8 +6,11 @@
 // Output is what pp_mesh_create takes: vertex coordinates (dim per vertex), element->vertex ids
 // of the top-dimensional simplices (triangles: type 2, tetrahedra: type 4) and one class id per
 // element = the elementary (geometric) entity tag of the element, which is what Omega_h stores as
-// `class_id`.  Vertex ids are renumbered densely in file order; lower-dimensional elements are
-// skipped.  2-D meshes drop the z coordinate.  Binary .msh files are rejected.
+// `class_id`.  Vertex ids are renumbered densely in file order.  The elements one dimension below (triangles of a tet
+// mesh, lines of a triangle mesh) are kept as SIDE classification: their vertices and elementary tags
+// (side_verts / side_class), which Omega_h::gmsh::read turns into the `class_id` array of the sides
+// (test/pseudoPushAndSearch.cpp:231 picks the start elements by it); other lower-dimensional elements are skipped.
+// 2-D meshes drop the z coordinate.  Binary .msh files are rejected.
 #pragma once
 #include <cstdio>
 #include <cstdlib>
@@ -25,6 +28,8 @@ struct MeshData {
   std::vector<double> coords;
   std::vector<int> elem2verts;
   std::vector<int> class_id;
+  std::vector<int> side_verts;  // dim vertices per listed boundary entity
+  std::vector<int> side_class;  // its elementary tag
 };
 
 inline bool fail(const std::string& msg, std::string* err) {
@@ -101,7 +106,7 @@ inline bool read(const std::string& path, MeshData& out, std::string* err = null
             ls >> v;
             if (t == 1) elementary = v;  // tags: physical, elementary, ...
           }
-          if (type == 2 || type == 4) {
+          if (type == 1 || type == 2 || type == 4) {
             Elem e{type, elementary, {0, 0, 0, 0}};
             for (int k = 0; k < nverts_of[type]; ++k) ls >> e.v[k];
             elems.push_back(e);
@@ -125,7 +130,7 @@ inline bool read(const std::string& path, MeshData& out, std::string* err = null
               in >> v;
               if (k < 4) e.v[k] = v;
             }
-            if (type == 2 || type == 4) elems.push_back(e);
+            if (type == 1 || type == 2 || type == 4) elems.push_back(e);
           }
         }
       }
@@ -135,10 +140,21 @@ inline bool read(const std::string& path, MeshData& out, std::string* err = null
   bool has_tet = false;
   for (auto& e : elems) has_tet |= e.type == 4;
   out.dim = has_tet ? 3 : 2;
-  const int want = has_tet ? 4 : 2, nv = out.dim + 1;
+  const int want = has_tet ? 4 : 2, nv = out.dim + 1, side_type = has_tet ? 2 : 1;
   out.coords.clear();
   out.elem2verts.clear();
   out.class_id.clear();
+  out.side_verts.clear();
+  out.side_class.clear();
+  for (auto& e : elems) {
+    if (e.type != side_type) continue;
+    for (int k = 0; k < out.dim; ++k) {
+      auto it = node_index.find(e.v[k]);
+      if (it == node_index.end()) return fail("boundary element refers to an unknown node", err);
+      out.side_verts.push_back(it->second);
+    }
+    out.side_class.push_back(e.tag);
+  }
   for (size_t i = 0; i < xyz.size() / 3; ++i)
     for (int c = 0; c < out.dim; ++c) out.coords.push_back(xyz[3 * i + c]);
   for (auto& e : elems) {

@@ -78,9 +78,11 @@ def read_gmsh(path):
     return dim, coords, e2v, cls
 
 
-def write_gmsh(path, dim, coords, e2v, cls, version="2.2"):
+def write_gmsh(path, dim, coords, e2v, cls, version="2.2", sides=None):
     """ASCII writer: node tags are 1-based vertex ids, the class id goes to the physical and the
-    elementary tag (2.2) / to the entity tag of a block per class (4.1)."""
+    elementary tag (2.2) / to the entity tag of a block per class (4.1).  `sides` = (side vertices [n, dim], tags [n]):
+    boundary entities (triangles of a tet mesh, lines of a triangle mesh) written in front of the elements (2.2 only),
+    which a reader turns into the classification of the mesh sides."""
     coords = np.asarray(coords, dtype=np.float64).reshape(-1, dim)
     e2v = np.asarray(e2v, dtype=np.int64).reshape(-1, dim + 1)
     cls = np.asarray(cls, dtype=np.int64)
@@ -92,9 +94,14 @@ def write_gmsh(path, dim, coords, e2v, cls, version="2.2"):
             f.write("$MeshFormat\n2.2 0 8\n$EndMeshFormat\n$Nodes\n%d\n" % len(xyz))
             for i, p in enumerate(xyz):
                 f.write("%d %s %s %s\n" % (i + 1, repr(float(p[0])), repr(float(p[1])), repr(float(p[2]))))
-            f.write("$EndNodes\n$Elements\n%d\n" % len(e2v))
+            ns = 0 if sides is None else len(sides[1])
+            f.write("$EndNodes\n$Elements\n%d\n" % (len(e2v) + ns))
+            for i in range(ns):
+                c = int(sides[1][i])
+                f.write("%d %d 2 %d %d %s\n" % (i + 1, 2 if dim == 3 else 1, c, c,
+                                               " ".join(str(int(v) + 1) for v in sides[0][i])))
             for i, (vs, c) in enumerate(zip(e2v, cls)):
-                f.write("%d %d 2 %d %d %s\n" % (i + 1, etype, c, c, " ".join(str(v + 1) for v in vs)))
+                f.write("%d %d 2 %d %d %s\n" % (ns + i + 1, etype, c, c, " ".join(str(v + 1) for v in vs)))
             f.write("$EndElements\n")
         else:
             n = len(xyz)

@@ -405,3 +405,54 @@ def test_reference_barycentric_passes(tmp_path, which):
     exe = _need("barycentric")
     (rc, so, se), = _run_ranks([exe, which], 1, str(tmp_path), timeout=300)
     assert rc == 0, (so[-2000:], se[-2000:])
+
+
+# ---------------------------------------------------------------- BASELINE configs[0]: the reference's pseudoPushAndSearch
+# test/pseudoPushAndSearch.cpp unchanged (testing.cmake: `pseudoPushAndSearch <mesh> ignored 200 <model face> dx dy dz`).
+# The pumipic-data meshes are not here; the mesh is a Kuhn box written as Gmsh 2.2 whose boundary triangles on y == 0
+# carry the model-face id, which the reader turns into the sides' class_id (pseudoPushAndSearch.cpp:231).  The oracle
+# runs the same loop; the program's per-iteration particle counts and its has_particles tag must equal the oracle's.
+@pytest.mark.parametrize("n,npt", [(6, 20000)])
+def test_reference_pseudo_push_and_search_source_matches_oracle(pp, ppo, tmp_path, n, npt):
+    import importlib
+    import common
+    exe = _need("pseudoPushAndSearch")
+    s = pp.synth
+    coords, e2v, cls = s.kuhn_box(n)
+    faces = [(0, 2, 1), (0, 1, 3), (1, 2, 3), (2, 0, 3)]
+    tris = [[t[a], t[b], t[c]] for t in e2v for a, b, c in faces if (np.abs(coords[[t[a], t[b], t[c]], 1]) < 1e-12).all()]
+    mdl_face = 156
+    mesh_file = str(tmp_path / "box.msh")
+    importlib.import_module(pp.__name__ + ".meshio").write_gmsh(
+        mesh_file, 3, coords, e2v, cls, sides=(np.asarray(tris), np.full(len(tris), mdl_face)))
+    prefix = str(tmp_path / "dump")
+    (rc, so, se), = _run_ranks([exe, mesh_file, "ignored", str(npt), str(mdl_face), "-0.5", "0.8", "0"], 1,
+                               str(tmp_path), timeout=600, extra_env={"PP_DUMP_ON_DELETE": prefix})
+    assert rc == 0 and "done" in se, (rc, so[-3000:], se[-3000:])
+    assert "mesh elements classified on model face %d: %d" % (mdl_face, len(tris)) in so, so[:3000]
+    counts = [int(m.group(1)) for m in re.finditer(r"PS on rank 0 has Elements: \d+\. Ptcls (\d+)\.", so)]
+    hp = np.fromfile(prefix + "_itag_3_has_particles_r0.i32", dtype=np.int32)
+    assert len(hp) == len(e2v)
+    # the oracle's version of the loop (tests/test_gpu_parity.py::test_cpp_driver_pseudo_push_and_search)
+    pop = common.population_box(s, n=n, num_ptcls=npt)
+    mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_PUSH, C=64)
+    common.set_shuffling(po)
+    ppo.set_threads(ppo.max_threads())
+    tag = np.full(len(e2v), -1, dtype=np.int32)
+    se_, mk = po.slot_info()
+    tag[np.unique(se_[mk.astype(bool)])] = 0
+    expect, it = [], 1
+    while it <= 30 and po.nPtcls() > 0:
+        ppo.linear_push(po, 1.0 / 20, -0.5, 0.8, 0.0)
+        r = ppo.search_mesh_legacy3d(mo, po, looplimit=100)
+        ppo.update_positions(po)
+        po.rebuild(r["elem_ids"])
+        expect.append(po.nPtcls())
+        if po.nPtcls() == 0:
+            break
+        se_, mk = po.slot_info()
+        tag[np.unique(se_[mk.astype(bool)])] = it
+        it += 1
+    ppo.set_threads(1)
+    assert counts == expect, (counts, expect)
+    assert np.array_equal(hp, tag), int((hp != tag).sum())
