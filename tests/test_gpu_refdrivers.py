@@ -412,8 +412,8 @@ def test_reference_barycentric_passes(tmp_path, which):
 # The pumipic-data meshes are not here; the mesh is a Kuhn box written as Gmsh 2.2 whose boundary triangles on y == 0
 # carry the model-face id, which the reader turns into the sides' class_id (pseudoPushAndSearch.cpp:231).  The oracle
 # runs the same loop; the program's per-iteration particle counts and its has_particles tag must equal the oracle's.
-@pytest.mark.parametrize("n,npt", [(6, 20000)])
-def test_reference_pseudo_push_and_search_source_matches_oracle(pp, ppo, tmp_path, n, npt):
+@pytest.mark.parametrize("n,npt,ranks", [(6, 20000, 1), (6, 20000, 2)])
+def test_reference_pseudo_push_and_search_source_matches_oracle(pp, ppo, tmp_path, n, npt, ranks):
     import importlib
     import common
     exe = _need("pseudoPushAndSearch")
@@ -426,12 +426,22 @@ def test_reference_pseudo_push_and_search_source_matches_oracle(pp, ppo, tmp_pat
     importlib.import_module(pp.__name__ + ".meshio").write_gmsh(
         mesh_file, 3, coords, e2v, cls, sides=(np.asarray(tris), np.full(len(tris), mdl_face)))
     prefix = str(tmp_path / "dump")
-    (rc, so, se), = _run_ranks([exe, mesh_file, "ignored", str(npt), str(mdl_face), "-0.5", "0.8", "0"], 1,
-                               str(tmp_path), timeout=600, extra_env={"PP_DUMP_ON_DELETE": prefix})
-    assert rc == 0 and "done" in se, (rc, so[-3000:], se[-3000:])
+    # (testing.cmake pseudoPushAndSearch_t2_r2: an owner file, one rank per line of elements; all particles start on rank 0,
+    # migrate_lb_ptcls moves and balances them -- the sum over ranks and the latest visit over ranks are the serial run's)
+    owner_file = str(tmp_path / "owners.ptn")
+    with open(owner_file, "w") as f:
+        f.write("\n".join(str(int(e * ranks // len(e2v))) for e in range(len(e2v))) + "\n")
+    res = _run_ranks([exe, mesh_file, owner_file, str(npt), str(mdl_face), "-0.5", "0.8", "0"], ranks,
+                     str(tmp_path), timeout=600, extra_env={"PP_DUMP_ON_DELETE": prefix})
+    for rc, so, se in res:
+        assert rc == 0, (rc, so[-3000:], se[-3000:])
+    so, se = res[0][1], res[0][2]
+    assert "done" in se
     assert "mesh elements classified on model face %d: %d" % (mdl_face, len(tris)) in so, so[:3000]
-    counts = [int(m.group(1)) for m in re.finditer(r"PS on rank 0 has Elements: \d+\. Ptcls (\d+)\.", so)]
-    hp = np.fromfile(prefix + "_itag_3_has_particles_r0.i32", dtype=np.int32)
+    per_rank = [[int(m.group(1)) for m in re.finditer(r"PS on rank %d has Elements: \d+\. Ptcls (\d+)\." % r, res[r][1])]
+                for r in range(ranks)]
+    counts = [sum(c) for c in zip(*per_rank)]
+    hp = np.max([np.fromfile(prefix + "_itag_3_has_particles_r%d.i32" % r, dtype=np.int32) for r in range(ranks)], axis=0)
     assert len(hp) == len(e2v)
     # the oracle's version of the loop (tests/test_gpu_parity.py::test_cpp_driver_pseudo_push_and_search)
     pop = common.population_box(s, n=n, num_ptcls=npt)
