@@ -466,3 +466,39 @@ def test_reference_pseudo_push_and_search_source_matches_oracle(pp, ppo, tmp_pat
     ppo.set_threads(1)
     assert counts == expect, (counts, expect)
     assert np.array_equal(hp, tag), int((hp != tag).sum())
+
+
+# ---------------------------------------------------------------- the rows either side of the path: parts and balancer
+def _cube_with_partition(pp, tmp_path, n, ranks):
+    import importlib
+    s = pp.synth
+    coords, e2v, cls = s.kuhn_box(n)
+    mesh_file = str(tmp_path / "cube.msh")
+    importlib.import_module(pp.__name__ + ".meshio").write_gmsh(mesh_file, 3, coords, e2v, cls)
+    ptn = str(tmp_path / "cube.ptn")
+    with open(ptn, "w") as f:
+        f.write("\n".join(str(int(e * ranks // len(e2v))) for e in range(len(e2v))) + "\n")
+    return mesh_file, ptn
+
+
+def test_reference_input_construct_passes(pp, tmp_path):
+    """test/test_input_construct.cpp (testing.cmake: input_construct_cube, 4 ranks): PICparts from an Input with a FULL
+    buffer and a 3-layer BFS safe zone over the sides, and with MINIMUM / NONE"""
+    exe = _need("input_construct")
+    mesh_file, ptn = _cube_with_partition(pp, tmp_path, 4, 4)
+    res = _run_ranks([exe, mesh_file, ptn], 4, str(tmp_path), timeout=600)
+    for r, (rc, so, se) in enumerate(res):
+        assert rc == 0, "rank %d: %s\n%s" % (r, so[-2000:], se[-2000:])
+    assert "All tests passed" in res[0][1]
+
+
+@pytest.mark.parametrize("ranks", [1, 4])
+def test_reference_test_lb_passes(pp, tmp_path, ranks):
+    """test/test_lb.cpp (testing.cmake: lb_r1, lb_r4): ParticleBalancer::partition on an array of particle counts
+    (imbalance after balancing <= 1.3) and ::repartition + migrate on a structure filled on even ranks only (<= 1.5)"""
+    exe = _need("test_lb")
+    mesh_file, ptn = _cube_with_partition(pp, tmp_path, 4, ranks)
+    res = _run_ranks([exe, mesh_file, ptn if ranks > 1 else "ignored"], ranks, str(tmp_path), timeout=600)
+    for r, (rc, so, se) in enumerate(res):
+        assert rc == 0, "rank %d: %s\n%s" % (r, so[-2000:], se[-2000:])
+    assert "All Tests Passed" in res[0][2]

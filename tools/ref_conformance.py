@@ -55,6 +55,10 @@ UNITS = {
     # barycentric (testing.cmake: barycentric_3): find_barycentric_tet known answers -- through src/unit_tests.hpp, see
     # EXTRA_FLAGS
     "barycentric": ["test/test_barycentric.cpp"],
+    # the rows either side of the path: PICparts from an Input (input_construct_cube, 4 ranks) and the
+    # particle balancer on an array and on a structure (lb_r1 / lb_r4)
+    "input_construct": ["test/test_input_construct.cpp"],
+    "test_lb": ["test/test_lb.cpp"],
 }
 # units whose checks are assert()s: compiled without -DNDEBUG so that a wrong destination element aborts the program
 ASSERTS_ON = {"search2d", "test_adj", "pseudoXGCm_scatter"}
