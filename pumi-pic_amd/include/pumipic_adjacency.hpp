@@ -64,6 +64,7 @@ class HostWrite {
  public:
   HostWrite() {}
   explicit HostWrite(size_t n) : h_(n) {}
+  HostWrite(const std::vector<T>& v) : h_(v) {}  // (HostRead<LO>(picparts.nentsOffsets(dim)): already on the host)
   HostWrite(const pumipic::View<T>& v) : h_(v.size()) {
     pumipic::pp_check(pp_sync(), "HostWrite sync");
     h_ = v.to_host();
@@ -178,6 +179,10 @@ class Mesh {
     }
     init_part(full_mesh, partition_vector, PP_PART_BFS, PP_PART_BFS, 0, buffer_layers, safe_layers, comm);
   }
+  // (the same with the owners in a device array: test/test_comm_array.cpp:56)
+  Mesh(Mesh& full_mesh, const View<int>& partition_vector, int buffer_layers, int safe_layers, pp_comm* comm = nullptr)
+      : Mesh(full_mesh, (pp_check(pp_sync(), "pumipic::Mesh"), partition_vector.to_host()), buffer_layers, safe_layers,
+             comm) {}
   // (Mesh(Omega_h::Mesh& full_mesh, Omega_h::LOs partition_vector), pumipic_mesh.hpp:27-31: owners in a device array)
   Mesh(Mesh& full_mesh, const View<int>& partition_vector, pp_comm* comm = nullptr) {
     pp_check(pp_sync(), "pumipic::Mesh");
@@ -394,7 +399,8 @@ class Mesh {
   o::LOs commArrayIndex(int edim) { return part_view<o::LO>(PP_PART_COMM_INDEX, edim); }
   std::vector<int> nentsOffsets(int edim) {
     std::vector<int> off((size_t)num_ranks() + 1, 0);
-    if (part_) pp_check(pp_picpart_nents_offsets(part_, edim, off.data()), "nentsOffsets");
+    // (a dimension above the mesh's: the reference keeps an empty array there, test/test_comm_array.cpp:106 asks for 3)
+    if (part_ && edim <= dim_) pp_check(pp_picpart_nents_offsets(part_, edim, off.data()), "nentsOffsets");
     return off;
   }
   o::LOs entOwners(int dim) {

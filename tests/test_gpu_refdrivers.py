@@ -502,3 +502,27 @@ def test_reference_test_lb_passes(pp, tmp_path, ranks):
     for r, (rc, so, se) in enumerate(res):
         assert rc == 0, "rank %d: %s\n%s" % (r, so[-2000:], se[-2000:])
     assert "All Tests Passed" in res[0][2]
+
+
+@pytest.mark.parametrize("dim", [3, 2])
+def test_reference_comm_array_passes(pp, tmp_path, dim):
+    """test/test_comm_array.cpp (testing.cmake: comm_array_pisces, comm_array_2d_box; 4 ranks): reduceCommArray on parts
+    with a full buffer (SUM = number of ranks on every entity of every dimension) and on parts with one buffer layer
+    (MIN of the owners = entOwners, 1/n contributions sum to 1, a 3-component element array sums to 1).  The program
+    reports by printing; no report may appear."""
+    import importlib
+    exe = _need("comm_array")
+    s = pp.synth
+    if dim == 3:
+        coords, e2v, cls = s.kuhn_box(4)
+    else:
+        coords, e2v, cls = _plate_tris(12)
+    mesh_file = str(tmp_path / "mesh.msh")
+    importlib.import_module(pp.__name__ + ".meshio").write_gmsh(mesh_file, dim, coords, e2v, cls)
+    ptn = str(tmp_path / "mesh.ptn")
+    with open(ptn, "w") as f:
+        f.write("\n".join(str(int(e * 4 // len(e2v))) for e in range(len(e2v))) + "\n")
+    res = _run_ranks([exe, mesh_file, ptn], 4, str(tmp_path), timeout=600)
+    for r, (rc, so, se) in enumerate(res):
+        assert rc == 0, "rank %d: %s\n%s" % (r, so[-2000:], se[-2000:])
+        assert "failed" not in so and "failed" not in se, "rank %d: %s\n%s" % (r, so[-2000:], se[-2000:])

@@ -59,6 +59,9 @@ UNITS = {
     # particle balancer on an array and on a structure (lb_r1 / lb_r4)
     "input_construct": ["test/test_input_construct.cpp"],
     "test_lb": ["test/test_lb.cpp"],
+    # comm arrays of the parts (comm_array_pisces / comm_array_2d_box, 4 ranks): SUM over a full buffer, MIN of the
+    # owners, 1/n contributions summed to 1, a 3-component element array
+    "comm_array": ["test/test_comm_array.cpp"],
 }
 # units whose checks are assert()s: compiled without -DNDEBUG so that a wrong destination element aborts the program
 ASSERTS_ON = {"search2d", "test_adj", "pseudoXGCm_scatter"}
