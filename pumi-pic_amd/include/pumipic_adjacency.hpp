@@ -13,6 +13,8 @@
 // packed walk records on the device); Omega_h::Write<T>/Read<T> by pumipic::View<T>.
 #pragma once
 #include <algorithm>
+#include <fstream>
+#include <stdexcept>
 #include <chrono>
 #include <map>
 #define PP_ADJACENCY_IN_PROGRESS  // (particle_structs.hpp leaves the Kokkos facade to the end of this header)
@@ -43,6 +45,7 @@ enum { VERT = 0, EDGE = 1, FACE = 2, REGION = 3 };
 struct Adj {
   Read<LO> a2ab, ab2b;
 };
+struct TagBase {};  // (Mesh::get_tagbase: a tag's existence)
 // Omega_h::parallel_for(n, OMEGA_H_LAMBDA(LO i){...}, name) over a plain index range, on the library's
 // stream (Omega_h_for.hpp); HostWrite / HostRead: a host copy of a device array
 #define OMEGA_H_LAMBDA [=] __host__ __device__
@@ -109,6 +112,10 @@ class Input {
   // (the reference passes the owners as Omega_h::Write<LO>: test/search2d.cpp:193-195)
   inline Input(Mesh& mesh, Ownership rule, const View<int>& partition_vector, Method bufferMethod_,
                Method safeMethod_, pp_comm* comm_ = nullptr);
+  // (src/pumipic_input.cpp:23-111: the owners from a file -- `.ptn`: one owner per element; `.cpn`: the number of
+  //  classification ids, then `id owner` pairs, ownership by classification.  One rank: everything on rank 0.)
+  inline Input(Mesh& mesh, const char* partition_filename, Method bufferMethod_, Method safeMethod_,
+               pp_comm* comm_ = nullptr);
   Ownership getRule() const { return ownership_rule; }
   const std::vector<int>& getPartition() const { return partition; }
   static Method getMethod(std::string s) {  // pumipic_input.cpp:139-150
@@ -488,6 +495,15 @@ class Mesh {
   View<T> get_array(int edim, const std::string& name) {
     return get_array_impl(edim, name, (T*)nullptr);
   }
+  // Omega_h::Mesh::get_tagbase(dim, name): only its existence is asked for (test/test_full_mesh.cpp:44)
+  const o::TagBase* get_tagbase(int edim, const std::string& name) {
+    static const o::TagBase tag;
+    if (!(has_tag(edim, name) || ((name == "global" || name == "global_serial") && edim == dim_))) {
+      fprintf(stderr, "mesh has no tag %s on dimension %d\n", name.c_str(), edim);
+      exit(EXIT_FAILURE);
+    }
+    return &tag;
+  }
   Mesh* mesh() { return this; }             // picparts.mesh()
   Mesh* operator->() { return this; }       // picparts->dim()
   o::LOs ask_verts_of_elems() const { return view<int>(PP_MESH_ELEM2VERTS); }
@@ -501,6 +517,15 @@ class Mesh {
       exit(EXIT_FAILURE);
     }
     return it->second;
+  }
+  // "global" of a serial mesh / "global_serial" of a part (pumipic_part_construct.cpp renames the tag): the ids of
+  // the full mesh's entities
+  View<long> get_array_impl(int edim, const std::string& name, long*) {
+    if (name != "global" && name != "global_serial") {
+      fprintf(stderr, "mesh has no 64-bit integer tag %s on dimension %d\n", name.c_str(), edim);
+      exit(EXIT_FAILURE);
+    }
+    return globalIds(edim);
   }
   View<int> get_array_impl(int edim, const std::string& name, int*) {
     if (name == "class_id" && edim == dim_) return class_ids();
@@ -614,6 +639,40 @@ inline Input::Input(Mesh& mesh, Ownership rule, const std::vector<int>& partitio
   }
   if (bufferMethod == MINIMUM) bufferBFSLayers = 0;  // :133-136
   if (safeMethod == MINIMUM) safeBFSLayers = 0;
+}
+
+inline Input::Input(Mesh& mesh, const char* partition_filename, Method bufferMethod_, Method safeMethod_, pp_comm* comm_)
+    : Input(mesh, PARTITION, std::vector<int>((size_t)mesh.nelems(), 0), bufferMethod_, safeMethod_, comm_) {
+  pp_comm* c = comm ? comm : comm_world();
+  if (pp_comm_size(c) <= 1) return;
+  const std::string fn(partition_filename);
+  const size_t dot = fn.find_last_of('.');
+  if (dot == std::string::npos) {
+    printError("Filename provided has no extension (%s)", partition_filename);
+    throw std::runtime_error("Filename has no extension");
+  }
+  const std::string ext = fn.substr(dot + 1);
+  std::ifstream in_str(partition_filename);
+  if (ext != "ptn" && ext != "cpn") {
+    printError("Only .ptn and .cpn partitions are supported");
+    throw std::runtime_error("Invalid partition file extension");
+  }
+  if (!in_str) {
+    if (!pp_comm_rank(c)) printError("Cannot open file %s\n", partition_filename);
+    throw std::runtime_error("Cannot open file");
+  }
+  int own;
+  if (ext == "ptn") {
+    size_t index = 0;
+    while (in_str >> own && index < partition.size()) partition[index++] = own;
+  } else {
+    ownership_rule = CLASSIFICATION;
+    int size = 0, cid;
+    in_str >> size;
+    partition.assign((size_t)size + 1, 0);
+    while (in_str >> cid >> own)
+      if (cid >= 0 && cid <= size) partition[(size_t)cid] = own;
+  }
 }
 
 inline Input::Input(Mesh& mesh, Ownership rule, const View<int>& partition_vector, Method bufferMethod_,

@@ -526,3 +526,32 @@ def test_reference_comm_array_passes(pp, tmp_path, dim):
     for r, (rc, so, se) in enumerate(res):
         assert rc == 0, "rank %d: %s\n%s" % (r, so[-2000:], se[-2000:])
         assert "failed" not in so and "failed" not in se, "rank %d: %s\n%s" % (r, so[-2000:], se[-2000:])
+
+
+@pytest.mark.parametrize("ranks,dim", [(2, 3), (4, 3), (4, 2)])
+def test_reference_ptn_loading_passes(pp, tmp_path, ranks, dim):
+    """test/test_ptn_loading.cpp (testing.cmake: ptn_loading_cube / _cube_4 / _2d_box_4 `<mesh> <ptn> 1 3`): parts with 3
+    ghost layers and 1 safe layer; every element of a part has the centroid of the full-mesh element whose global id
+    it carries"""
+    import importlib
+    exe = _need("ptn_loading")
+    s = pp.synth
+    coords, e2v, cls = s.kuhn_box(5) if dim == 3 else _plate_tris(16)
+    mesh_file = str(tmp_path / "mesh.msh")
+    importlib.import_module(pp.__name__ + ".meshio").write_gmsh(mesh_file, dim, coords, e2v, cls)
+    ptn = str(tmp_path / "mesh.ptn")
+    with open(ptn, "w") as f:
+        f.write("\n".join(str(int(e * ranks // len(e2v))) for e in range(len(e2v))) + "\n")
+    res = _run_ranks([exe, mesh_file, ptn, "1", "3"], ranks, str(tmp_path), timeout=600)
+    for r, (rc, so, se) in enumerate(res):
+        assert rc == 0 and "do not match" not in so, "rank %d: %s\n%s" % (r, so[-2000:], se[-2000:])
+
+
+def test_reference_full_mesh_passes(pp, tmp_path):
+    """test/test_full_mesh.cpp (testing.cmake: full_mesh_pisces, 4 ranks): an Input that reads its owners from a .ptn
+    file, FULL buffer and safe zone: entity counts and global ids of the part are the serial mesh's"""
+    exe = _need("full_mesh")
+    mesh_file, ptn = _cube_with_partition(pp, tmp_path, 4, 4)
+    res = _run_ranks([exe, mesh_file, ptn], 4, str(tmp_path), timeout=600)
+    for r, (rc, so, se) in enumerate(res):
+        assert rc == 0 and "do not match" not in so + se, "rank %d: %s\n%s" % (r, so[-2000:], se[-2000:])

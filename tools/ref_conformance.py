@@ -62,6 +62,10 @@ UNITS = {
     # comm arrays of the parts (comm_array_pisces / comm_array_2d_box, 4 ranks): SUM over a full buffer, MIN of the
     # owners, 1/n contributions summed to 1, a 3-component element array
     "comm_array": ["test/test_comm_array.cpp"],
+    # parts with ghost / safe layers carry the full mesh's element ids (ptn_loading_cube, 2 and 4 ranks); an Input read
+    # from a .ptn file with FULL buffers reproduces the serial mesh (full_mesh_pisces, 4 ranks)
+    "ptn_loading": ["test/test_ptn_loading.cpp"],
+    "full_mesh": ["test/test_full_mesh.cpp"],
 }
 # units whose checks are assert()s: compiled without -DNDEBUG so that a wrong destination element aborts the program
 ASSERTS_ON = {"search2d", "test_adj", "pseudoXGCm_scatter"}
