@@ -1,10 +1,13 @@
 """north_star: "keeping the particle_structs SCS/CSR parallel_for operator API so it drops into pseudoXGCm and the
-performance_tests drivers UNCHANGED".  Here that is a tested statement: the reference's own driver sources --
-test/pseudoXGCm.cpp (with its test/ellipticalPush.hpp, test/gyroScatter.hpp, test/pseudoXGCmTypes.hpp),
-test/pseudoPushAndSearch.cpp, performance_tests/ps_combo160.cpp / ps_combo264.cpp (with perfTypes.hpp and
-particle_structs/test/Distribute.h) and particle_structs/test/Distribute.cpp -- are compiled where they lie, byte
-for byte, host and device passes, against pumi-pic_amd/include (tools/ref_conformance.py).  The reference text is
-read in place and never copied; the test skips where /root/reference does not exist (the GPU box)."""
+performance_tests drivers UNCHANGED".  Here that is a tested statement: the reference's own sources -- the drivers
+(test/pseudoXGCm.cpp with its three headers, test/pseudoPushAndSearch.cpp, performance_tests/ps_combo160.cpp /
+ps_combo264.cpp, particle_structs/test/Distribute.cpp) AND the reference's own tests of the path and of the rows
+either side of it (test/test_adj.cpp, search2d.cpp, moller_trumbore_line_tri_test.cpp, test_barycentric.cpp,
+pseudoXGCm_scatter.cpp; particle_structs/test/test_structure.cpp and its unit programs; test/test_input_construct.cpp,
+test_lb.cpp, test_comm_array.cpp, test_ptn_loading.cpp, test_full_mesh.cpp) -- are compiled where they lie, byte for
+byte, host and device passes, against pumi-pic_amd/include (tools/ref_conformance.py: UNITS).  The reference text is
+read in place and never copied; the test skips where /root/reference does not exist (the GPU box, where
+tests/test_gpu_refdrivers.py RUNS the executables built here)."""
 import os
 import sys
 
@@ -33,6 +36,12 @@ def test_no_include_path_points_into_the_reference():
         for i, f in enumerate(rc.FLAGS):
             if f == d:
                 assert rc.FLAGS[i + 1].startswith(ROOT)
+    # the one documented exception (tools/ref_conformance.py: EXTRA_FLAGS): src/unit_tests.hpp, a header of test
+    # functions, is found AFTER this library's directories, with the reference's library header guards predefined
+    assert set(rc.EXTRA_FLAGS) == {"barycentric"}
+    extra = rc.EXTRA_FLAGS["barycentric"]
+    assert "-idirafter" in extra and "-DPUMIPIC_ADJACENCY_HPP" in extra and "-DPUMIPIC_ADJACENCY_NEW_HPP" in extra
+    assert not any(f in ("-I", "-isystem", "-iquote") for f in extra)
 
 
 def test_operator_api_functions_are_the_reference_text():
