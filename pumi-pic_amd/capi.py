@@ -534,6 +534,10 @@ class PS:
     def materialize(self):
         check(lib().pp_ps_materialize(self.p))
 
+    def clone(self):
+        """a deep, independent copy (pp_ps_clone: SellCSigma::copy / CSR::copy on the device)"""
+        return PS(lib().pp_ps_clone(self.p), self.members)
+
     def get_pids(self):
         i = self.info()
         off = DevArray(i.num_elems + 1, np.int32)

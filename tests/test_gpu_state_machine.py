@@ -198,6 +198,21 @@ def r_members_to_host(c):
     return [common.by_id(first[c.idm][0], mk, a)[1] for a in first]
 
 
+def r_clone(c):
+    """the copy of a structure with passes pending is the copy of the structure: members by id, slots, layout"""
+    twin = c.ps.clone()
+    cap = twin.capacity()
+    assert twin.deferred_state() == 0
+    mem = [twin.member(m)[:, :cap] for m in range(len(c.members))]
+    se, mk = twin.slot_info()
+    out = [common.by_id(mem[c.idm][0], mk, a)[1] for a in mem] + [common.by_id(mem[c.idm][0], mk, se[:cap])[1]]
+    i, j = twin.info(), c.ps.info()
+    out.append(np.array([i.num_elems, i.num_ptcls, i.capacity, i.num_rows, i.num_chunks, i.num_slices]))
+    assert (i.num_ptcls, i.capacity, i.num_rows) == (j.num_ptcls, j.capacity, j.num_rows)
+    del twin
+    return out
+
+
 def r_member_ptr(c):
     capi, cap = c.capi, c.ps.capacity()
     st = capi.lib().pp_ps_member_stride(c.ps.p)
@@ -656,6 +671,7 @@ RECIPES = {
     "layout": (["pp_ps_layout", "pp_ps_layout_to_host"], r_layout, "all"),
     "member_to_host": (["pp_ps_member_to_host"], r_members_to_host, "all"),
     "member_ptr": (["pp_ps_member_ptr"], r_member_ptr, "all"),
+    "clone": (["pp_ps_clone"], r_clone, "all"),
     "member_from_host": (["pp_ps_member_from_host"], r_member_from_host, "all"),
     "swap_members": (["pp_ps_swap_members"], r_swap_members, ("tet", "tri", "push", "boris")),
     "iteration": (["pp_ps_iteration"], r_iteration, "all"),
