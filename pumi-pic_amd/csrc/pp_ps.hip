@@ -1991,14 +1991,11 @@ int scs_rebuild(pp_ps* ps, const int* new_element, int n_new, const int* new_ele
     else if (use_rm)                                                                             \
       k_move_pack_rm<N><<<pack_main + pack_hot, kBlock, 0, st>>>(pack_end, rank, rs_rm, aos, wt, go, \
                                                                  ps->C == 64 ? rm_wide : 0, hot_now, pack_hot, side, \
-                                                                 N == 2 ? split_hot : nullptr, pack_eager);  \
+                                                                 N == 2 ? split_hot : nullptr);  \
     else                                                                                         \
       k_move_pack<N><<<grid_for(ps->capacity), kBlock, 0, st>>>(ps->capacity, rank, rs, aos, wt, go, side); \
     if (!defer_unpack && !defer_wide) k_move_unpack<N><<<new_grid, kBlock, 0, st>>>(PP_UNPACK_ARGS); \
     break;
-      // (k_move_pack_rm: ask for a slot's members together with its rank when four slots in five are live)
-      static const int eager_lab = PP_LAB_ENV("PP_PACK_EAGER") ? atoi(PP_LAB_ENV("PP_PACK_EAGER")) : -1;
-      const int pack_eager = eager_lab >= 0 ? eager_lab : ((long long)ps->num_ptcls * 5 >= (long long)ps->capacity * 4);
       const RankToSlot rs{new_element, ps->s_eslot0.as<int>(), C_new};
       // the staging records row-major inside a chunk: the particles of a row, which carry consecutive ranks,
       // are consecutive records, and the pack's block-level transpose stores them as runs

@@ -225,11 +225,7 @@ template <int NQ>
 __global__ void k_move_pack_rm(int capacity, const int* __restrict__ new_idx, RankToSlot rs,
                                uint4* __restrict__ aos, WordTable t, const int* __restrict__ go, int wide,
                                pp::HotRow hot = pp::HotRow{}, unsigned hot_blocks = 0u,
-                               unsigned* __restrict__ side = nullptr, uint4* __restrict__ split_hot = nullptr,
-                               int eager = 0) {
-  // eager (a structure whose slots are mostly live): the new element and the members of a slot are asked for TOGETHER
-  // with its rank instead of after it -- the pass is a chain of dependent loads (82 % of a wave's life parked,
-  // profiles/r06_sq_c3_counters.txt), and this takes one link out of three; the loads of the few dead slots are wasted
+                               unsigned* __restrict__ side = nullptr, uint4* __restrict__ split_hot = nullptr) {
   // split_hot (NQ == 2 only, pp_ps::rec_split): quad 0 of a record goes to aos[record], quad 1 to split_hot[record]
   // -- two arrays of 16-B halves instead of one of 32-B records (the 2-D push reads the second halves only)
   if (go && !*go) return;
@@ -264,12 +260,11 @@ __global__ void k_move_pack_rm(int capacity, const int* __restrict__ new_idx, Ra
     pid = bid * 256 + tid;
     li = (tid & 63) * 4 + (tid >> 6);
   }
-  const bool inr = pid < capacity, pre = eager && inr;
-  const int rk = inr ? new_idx[pid] : -1;
-  int ne = pre ? rs.new_element[pid] : 0;
-  unsigned v[NQ * 4];
-  unsigned sv = 0u;
-  auto load_members = [&]() {
+  const int rk = (pid < capacity) ? new_idx[pid] : -1;
+  int idx = -1;
+  if (rk >= 0) {
+    idx = rs.elem_slot0[rs.new_element[pid]] + rk * rs.step;
+    unsigned v[NQ * 4];
 #pragma unroll
     for (int i = 0; i < NQ * 4; ++i) v[i] = 0u;
 #pragma unroll
@@ -284,19 +279,9 @@ __global__ void k_move_pack_rm(int capacity, const int* __restrict__ new_idx, Ra
     for (int j = 0; j < (NQ * 4 < kMax4 ? NQ * 4 : kMax4); ++j)
       if (j < t.n4)
         v[NQ * 4 - 1 - j] = __builtin_nontemporal_load((const unsigned*)(t.src4[j] + (long long)pid * 4));
-    if (side) sv = __builtin_nontemporal_load((const unsigned*)(t.side_src + (long long)pid * 4));
-  };
-  if (pre) load_members();
-  int idx = -1;
-  if (rk >= 0) {
-    if (!eager) {
-      ne = rs.new_element[pid];
-      load_members();
-    }
-    idx = rs.elem_slot0[ne] + rk * rs.step;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) st[li][q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-    if (side) ss[li] = sv;
+    if (side) ss[li] = __builtin_nontemporal_load((const unsigned*)(t.side_src + (long long)pid * 4));
   }
   sd[li] = idx;
   __syncthreads();
