@@ -1437,9 +1437,12 @@ int enqueue_layout(pp_ps* ps, int C_new, int* ppe, Totals* tot, long long key_ba
 // `src_stride` (elements), destinations the swap buffers.  Returns the number of 16-B quads per
 // record, or 0 when the members do not fit the staged path (other sizes than 4/8 bytes, too many).
 // (lab build, PP_NO_LAZY_UNPACK=1: the second pass of every re-layout runs right away)
-// (lab build, PP_NO_REC_SPLIT=1: the 2-D loop keeps the 32-B record + side word)
+// Split 2-D records -- (x, y) and (pad, phi, b, id) in two arrays, the 2-D push reads the second only -- are OFF by
+// default: the push gains 45 us per step at 10 M particles and the pack, storing two streams of 16-B pieces, loses 35 to
+// 65 depending on the box (profiles/r06_ab_split_records*.txt: four sessions, one of which had the split form ahead).
+// Lab build, PP_REC_SPLIT=1: on (the state-machine and record tests run both ways, tools/gpu_test_matrix.sh).
 bool no_rec_split() {
-  static const bool v = PP_LAB_ENV("PP_NO_REC_SPLIT") != nullptr;
+  static const bool v = PP_LAB_ENV("PP_REC_SPLIT") == nullptr || atoi(PP_LAB_ENV("PP_REC_SPLIT")) == 0;
   return v;
 }
 bool no_lazy_unpack() {

@@ -202,7 +202,8 @@ def r_clone(c):
     """the copy of a structure with passes pending is the copy of the structure: members by id, slots, layout"""
     twin = c.ps.clone()
     cap = twin.capacity()
-    assert twin.deferred_state() == 0
+    d = twin.deferred_state()
+    assert d["lazy_rec"] == 0 and d["zero_pending"] < 0 and d["zero_z_pending"] == 0, d
     mem = [twin.member(m)[:, :cap] for m in range(len(c.members))]
     se, mk = twin.slot_info()
     out = [common.by_id(mem[c.idm][0], mk, a)[1] for a in mem] + [common.by_id(mem[c.idm][0], mk, se[:cap])[1]]

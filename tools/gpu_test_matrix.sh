@@ -4,10 +4,11 @@
 # column-loop / queued walk kernel whatever the dimension, pass 2 of the re-layout run at once, gyroScatter behind the
 # rebuild instead of riding in it, the rebuild's tail after the host sync instead of speculatively, the atomic scatter
 # (a ring map without a transpose), the unpacked Moeller-Trumbore walk, one column per record fetch, the over-full
-# row through the common blocks, the reference's reshuffle decision off on both sides.
+# row through the common blocks, the reference's reshuffle decision off on both sides, the 2-D loop on split records
+# (round 6: built, measured, not the default).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export PUMIPIC_HIP_LIB=$R/pumi-pic_amd/libpumipic_hip_lab.so
 for cfg in "PP_WALK_QUEUE=1" "PP_WALK_QUEUE=0" "PP_NO_LAZY_UNPACK=1" "PP_NO_SCATTER_RIDE=1" "PP_NO_SPEC_REBUILD=1" \
-           "PP_SCATTER_ATOMIC=1" "PP_MT_PACKED=0" "PP_NO_HOT_ROW=1" "PP_TEST_SHUFFLING=0"; do
+           "PP_SCATTER_ATOMIC=1" "PP_MT_PACKED=0" "PP_NO_HOT_ROW=1" "PP_TEST_SHUFFLING=0" "PP_REC_SPLIT=1"; do
   echo "== $cfg"; env $cfg timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -2
 done
