@@ -15,24 +15,26 @@ kt() { name=$1; shift
   t=$(find $O/kt_$name -name "*kernel_trace.csv" | head -1); python3 $R/tools/gpu_gaps.py "$t" > $O/gaps_$name.txt 2>&1
   rm -rf $O/kt_$name
 }
-kt c3 --workload c3 --steps 40
-kt 2dc3 --workload 2dc3 --steps 40
-kt c2 --workload c2 --steps 40
-kt c2mt --workload c2mt --steps 6
+WLS=${WLS:-"c3 2dc3 c2 c4"}   # (WLS="2dc3" bash tools/r06_measure.sh: one workload only)
+for wl in $WLS; do
+  case $wl in c4) ;; *) kt $wl --workload $wl --steps 40;; esac
+done
+case " $WLS " in *" c2 "*) kt c2mt --workload c2mt --steps 6;; esac
 export PP_BENCH_NO_COLD=1 PP_BENCH_PREWARM=0
 passw() { wl=$1; name=$2; shift 2
   timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_$wl/$name -o p -- python3 $R/bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline > $O/pmc_${wl}_$name.log 2>&1
 }
-for wl in c3 2dc3 c2 c4; do
+for wl in $WLS; do
 passw $wl fetch FETCH_SIZE TCC_EA0_RDREQ_sum
 passw $wl write WRITE_SIZE TCC_EA0_WRREQ_sum
 done
 timeout 120 rocprofv3 --pmc FETCH_SIZE TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d $O/pmc/cal_fetch -o p -- $R/tools/_ubs > $O/pmc_cal_fetch.log 2>&1
 timeout 120 rocprofv3 --pmc WRITE_SIZE TCC_EA0_WRREQ_sum --kernel-trace --output-format csv -d $O/pmc/cal_write -o p -- $R/tools/_ubs > $O/pmc_cal_write.log 2>&1
 cd $R
-python tools/traffic_step.py $O c3 10000000 13 $O/traffic_c3.json pmc_c3 194 > $O/traffic_c3.txt 2>&1
-python tools/traffic_step.py $O 2dc3 10000000 13 $O/traffic_2dc3.json pmc_2dc3 162 > $O/traffic_2dc3.txt 2>&1
-python tools/traffic_step.py $O c2 10000000 13 $O/traffic_c2.json pmc_c2 69 > $O/traffic_c2.txt 2>&1
-python tools/traffic_step.py $O c4 1000000 13 $O/traffic_c4.json pmc_c4 489 > $O/traffic_c4.txt 2>&1
-rm -rf $O/pmc $O/pmc_c3 $O/pmc_2dc3 $O/pmc_c2 $O/pmc_c4
-for w in c3 2dc3 c2 c4; do head -14 $O/traffic_$w.txt; done
+for wl in $WLS; do
+  case $wl in c3) n=10000000; b=194;; 2dc3) n=10000000; b=162;; c2) n=10000000; b=69;; c4) n=1000000; b=489;; esac
+  python tools/traffic_step.py $O $wl $n 13 $O/traffic_$wl.json pmc_$wl $b > $O/traffic_$wl.txt 2>&1
+  rm -rf $O/pmc_$wl
+done
+rm -rf $O/pmc
+for w in $WLS; do head -14 $O/traffic_$w.txt; done
