@@ -1402,8 +1402,7 @@ def main():
                              "library stream)",
                     "kernel": "whole step; its longest launches (profiles/r06_%s_kernel_stats.csv): the record-fed %s, "
                               "then k_move_pack_rm<2> (the re-layout's one data pass: 32-B records + the third member "
-                              "beside them -- 2-D: split (x, y | pad, phi, b, id) halves in two arrays -- row-major "
-                              "inside a chunk, stored as runs)" % (
+                              "beside them, row-major inside a chunk, stored as runs)" % (
                                   "c5_virtual8" if a.workload == "c5" else a.workload,
                                   "k_push_walk_rowsq<3> (+ k_walk_pending<3>)" if w["dim"] == 3 else "k_push_walk_rows<2>"),
                     "kernel_ms": sms, "bytes_per_particle": bpp,
