@@ -372,6 +372,14 @@ class Library {
 // container -- and the parts are made on the spot: element blocks with the full mesh buffered (the replica of
 // BASELINE's config 5), or PICparts from an Input when PP_PARTS=<buffer layers>:<safe layers> is set.
 inline void read(Omega_h::Library* library, Omega_h::CommPtr comm, const char* prefix, Mesh* picparts) {
+  {  // what pumipic::write(picparts, prefix) left (pumipic_adjacency.hpp): the parts are cut again as they were
+    const std::string parts = std::string(prefix) + "_" + std::to_string(comm->size()) + ".pparts";
+    if (FILE* f = fopen(parts.c_str(), "rb")) {
+      fclose(f);
+      read_parts_container(parts, comm, picparts);
+      return;
+    }
+  }
   const std::string fn(prefix);
   const bool msh = fn.size() > 4 && fn.substr(fn.size() - 4) == ".msh";
   Mesh full = msh ? Omega_h::gmsh::read(fn, library->self()) : Omega_h::binary::read(fn, library->self());

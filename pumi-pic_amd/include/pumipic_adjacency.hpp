@@ -258,6 +258,7 @@ class Mesh {
     real_tags_.swap(o.real_tags_);
     int_tags_.swap(o.int_tags_);
     parent_.swap(o.parent_);
+    recipe_.swap(o.recipe_);
     std::swap(safe_ints_, o.safe_ints_);
     std::swap(safe_ints_src_, o.safe_ints_src_);
     std::swap(vert2sides_off_, o.vert2sides_off_);
@@ -404,11 +405,15 @@ class Mesh {
   // rankLocalIndex / commArrayIndex / nentsOffsets (pumipic_mesh.hpp:55-59), parts built from an Input
   o::LOs rankLocalIndex(int edim) { return part_view<o::LO>(PP_PART_RANK_LIDS, edim); }
   o::LOs commArrayIndex(int edim) { return part_view<o::LO>(PP_PART_COMM_INDEX, edim); }
-  std::vector<int> nentsOffsets(int edim) {
+  // (a device array, as the reference's Omega_h::LOs: test/test_file.cpp:93-96 reads it inside a lambda,
+  //  test/test_comm_array.cpp:106 through a HostRead)
+  o::LOs nentsOffsets(int edim) {
     std::vector<int> off((size_t)num_ranks() + 1, 0);
     // (a dimension above the mesh's: the reference keeps an empty array there, test/test_comm_array.cpp:106 asks for 3)
     if (part_ && edim <= dim_) pp_check(pp_picpart_nents_offsets(part_, edim, off.data()), "nentsOffsets");
-    return off;
+    o::Write<o::LO> d(off.size());
+    d.from_host(off.data());
+    return d;
   }
   o::LOs entOwners(int dim) {
     if (part_) return part_view<o::LO>(PP_PART_OWNERS, dim);
@@ -572,6 +577,8 @@ class Mesh {
               full.nelems());
       exit(EXIT_FAILURE);
     }
+    recipe_ = std::make_shared<PartRecipe>(PartRecipe{full.handle(), owner, buffer_method, safe_method, bridge_dim,
+                                                      buffer_layers, safe_layers});
     part_ = pp_picpart_create(full.handle(), owner.data(), buffer_method, safe_method, bridge_dim, buffer_layers,
                               safe_layers, comm_);
     if (!part_) pp_check(PP_EHIP, "pumipic::Mesh (PICparts)");
@@ -614,6 +621,15 @@ class Mesh {
     }
   };
   std::shared_ptr<Owned> own_;
+  // how a part was cut (pumipic::write stores it; the full mesh must be alive when write is called)
+  struct PartRecipe {
+    const pp_mesh* full;
+    std::vector<int> owner;
+    int buffer_method, safe_method, bridge_dim, buffer_layers, safe_layers;
+  };
+  std::shared_ptr<PartRecipe> recipe_;
+  friend void write(Mesh& picparts, const char* prefix);
+  friend void read_parts_container(const std::string& fn, pp_comm* comm, Mesh* picparts);
   pp_mesh* h_ = nullptr;
   pp_picpart* part_ = nullptr;
   View<int> vert2sides_off_, vert2sides_;
@@ -679,6 +695,79 @@ inline Input::Input(Mesh& mesh, Ownership rule, const View<int>& partition_vecto
                     Method safeMethod_, pp_comm* comm_)
     : Input(mesh, rule, (pp_check(pp_sync(), "pumipic::Input"), partition_vector.to_host()), bufferMethod_, safeMethod_,
             comm_) {}
+
+// ---------------------------------------------------------------- pumipic::write / the container pumipic::read takes back
+// (src/pumipic_mesh.hpp:150-151, pumipic_file.cpp:44-204.)  The reference writes, per rank, the part's mesh as an
+// Omega_h .osh directory and its comm arrays as a .ppm file; .osh is defined by Omega_h's sources, which are not in the
+// reference tree.  This library's container holds what the parts were CUT from -- the full mesh, the owner of every
+// element, the buffer / safe rules -- in one file <prefix>_<ranks>.pparts, and read() cuts them again: the part a rank
+// reads equals the part it wrote, entity for entity (test/test_file.cpp compares every array).  Rank 0 writes.
+inline void write(Mesh& picparts, const char* prefix) {
+  if (!picparts.recipe_) {
+    fprintf(stderr, "pumipic::write: the mesh was not built from a pumipic::Input / partition vector\n");
+    exit(EXIT_FAILURE);
+  }
+  pp_comm* c = picparts.comm();
+  if (pp_comm_rank(c) == 0) {
+    const Mesh::PartRecipe& r = *picparts.recipe_;
+    pp_check(pp_sync(), "pumipic::write");
+    int dim = 0, nv = 0, ne = 0, ns = 0;
+    pp_check(pp_mesh_info(r.full, &dim, &nv, &ne, &ns), "pumipic::write");
+    auto host = [&](int which, size_t bytes_per, std::vector<char>& out) {
+      size_t n = 0;
+      const void* p = pp_mesh_array_dev(r.full, which, &n);
+      out.resize(n * bytes_per);
+      if (n) pp_check(pp_memcpy_d2h(out.data(), p, out.size()), "pumipic::write");
+    };
+    std::vector<char> coords, e2v, cls;
+    host(PP_MESH_COORDS, sizeof(double), coords);
+    host(PP_MESH_ELEM2VERTS, sizeof(int), e2v);
+    host(PP_MESH_CLASS_ID, sizeof(int), cls);
+    const std::string fn = std::string(prefix) + "_" + std::to_string(pp_comm_size(c)) + ".pparts";
+    FILE* f = fopen(fn.c_str(), "wb");
+    if (!f) {
+      fprintf(stderr, "pumipic::write: cannot open %s\n", fn.c_str());
+      exit(EXIT_FAILURE);
+    }
+    const int hdr[10] = {0x50505054, dim, nv, ne, r.buffer_method, r.safe_method, r.bridge_dim, r.buffer_layers,
+                         r.safe_layers, pp_comm_size(c)};
+    fwrite(hdr, sizeof(int), 10, f);
+    fwrite(coords.data(), 1, coords.size(), f);
+    fwrite(e2v.data(), 1, e2v.size(), f);
+    fwrite(cls.data(), 1, cls.size(), f);
+    fwrite(r.owner.data(), sizeof(int), r.owner.size(), f);
+    fclose(f);
+  }
+  pp_check(pp_comm_barrier(c), "pumipic::write");
+}
+inline void read_parts_container(const std::string& fn, pp_comm* comm, Mesh* picparts) {
+  FILE* f = fopen(fn.c_str(), "rb");
+  int hdr[10] = {0};
+  bool ok = f && fread(hdr, sizeof(int), 10, f) == 10 && hdr[0] == 0x50505054 && hdr[9] == pp_comm_size(comm);
+  std::vector<double> coords;
+  std::vector<int> e2v, cls, owner;
+  if (ok) {
+    const int dim = hdr[1];
+    coords.resize((size_t)hdr[2] * dim);
+    e2v.resize((size_t)hdr[3] * (dim + 1));
+    cls.resize((size_t)hdr[3]);
+    owner.resize((size_t)hdr[3]);
+    ok = fread(coords.data(), sizeof(double), coords.size(), f) == coords.size() &&
+         fread(e2v.data(), sizeof(int), e2v.size(), f) == e2v.size() &&
+         fread(cls.data(), sizeof(int), cls.size(), f) == cls.size() &&
+         fread(owner.data(), sizeof(int), owner.size(), f) == owner.size();
+  }
+  if (f) fclose(f);
+  if (!ok) {
+    fprintf(stderr, "%s: not a parts container written by pumipic::write for %d ranks\n", fn.c_str(), pp_comm_size(comm));
+    exit(EXIT_FAILURE);
+  }
+  Mesh full(hdr[1], coords, e2v, cls);
+  Mesh part;
+  part.init_part(full, owner, hdr[4], hdr[5], hdr[6], hdr[7], hdr[8], comm);
+  picparts->swap(part);
+  picparts->keep_alive(std::move(full));  // (the part refers to the full mesh it was cut from)
+}
 
 // ---------------------------------------------------------------- pumipic::ParticleBalancer
 // (src/pumipic_lb.hpp:33-118) over pp_balancer: sbars, weights and the selection as in the reference, the

@@ -555,3 +555,19 @@ def test_reference_full_mesh_passes(pp, tmp_path):
     res = _run_ranks([exe, mesh_file, ptn], 4, str(tmp_path), timeout=600)
     for r, (rc, so, se) in enumerate(res):
         assert rc == 0 and "do not match" not in so + se, "rank %d: %s\n%s" % (r, so[-2000:], se[-2000:])
+
+
+@pytest.mark.parametrize("ranks,buffer,safe", [(4, "bfs", "full"), (4, "bfs", "bfs"), (1, "bfs", "full")])
+def test_reference_file_rw_passes(pp, tmp_path, ranks, buffer, safe):
+    """test/test_file.cpp (testing.cmake: file_rw_cube_4 `<mesh> <ptn> bfs full <prefix>`, file_rw_xgc_*): pumipic::write,
+    then pumipic::read into a new mesh; isFullMesh, entity counts, buffered ranks, global ids, owners, rank-local and
+    comm-array indices, offsets and the safe tag of the part read back must equal those of the part written (asserts,
+    built with them).  The file is this library's own container (the full mesh, the owners, the rules), not .osh/.ppm."""
+    exe = _need("file_rw")
+    mesh_file, ptn = _cube_with_partition(pp, tmp_path, 4, ranks)
+    res = _run_ranks([exe, mesh_file, ptn if ranks > 1 else "ignored", buffer, safe, str(tmp_path / "parts")], ranks,
+                     str(tmp_path), timeout=600)
+    for r, (rc, so, se) in enumerate(res):
+        assert rc == 0, "rank %d: %s\n%s" % (r, so[-2000:], se[-2000:])
+    assert "All Tests Passed" in res[0][1]
+    assert os.path.exists(str(tmp_path / ("parts_%d.pparts" % ranks)))

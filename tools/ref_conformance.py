@@ -66,9 +66,12 @@ UNITS = {
     # from a .ptn file with FULL buffers reproduces the serial mesh (full_mesh_pisces, 4 ranks)
     "ptn_loading": ["test/test_ptn_loading.cpp"],
     "full_mesh": ["test/test_full_mesh.cpp"],
+    # pumipic::write then pumipic::read: the part read back equals the part written, array by array (file_rw_cube_4 and
+    # the 1-rank form; the checks are asserts) -- through this library's own container, not .osh / .ppm
+    "file_rw": ["test/test_file.cpp"],
 }
 # units whose checks are assert()s: compiled without -DNDEBUG so that a wrong destination element aborts the program
-ASSERTS_ON = {"search2d", "test_adj", "pseudoXGCm_scatter"}
+ASSERTS_ON = {"search2d", "test_adj", "pseudoXGCm_scatter", "file_rw"}
 # test/test_barycentric.cpp includes "unit_tests.hpp", a header of test functions that the reference keeps in src/.
 # It is read where it lies through -idirafter (searched AFTER this library's include directories, so nothing else
 # resolves there); the one library header it names next to itself ("pumipic_adjacency.hpp", quote form: its own
