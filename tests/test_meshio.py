@@ -17,8 +17,12 @@ int main(int argc, char** argv) {
   double cs = 0; for (size_t i = 0; i < m.coords.size(); ++i) cs += m.coords[i] * (double)(i % 7 + 1);
   long long es = 0; for (size_t i = 0; i < m.elem2verts.size(); ++i) es += (long long)m.elem2verts[i] * (long long)(i % 5 + 1);
   long long ks = 0; for (size_t i = 0; i < m.class_id.size(); ++i) ks += (long long)m.class_id[i] * (long long)(i % 3 + 1);
-  printf("dim %d nverts %zu nelems %zu coords %.17g e2v %lld cls %lld\n", m.dim, m.coords.size() / m.dim,
-         m.class_id.size(), cs, es, ks);
+  long long ss = 0; for (size_t i = 0; i < m.side_class.size(); ++i) {
+    long long vs = 0; for (int k = 0; k < m.dim; ++k) vs += m.side_verts[i * m.dim + k];
+    ss += (long long)m.side_class[i] * 1000003ll + vs;
+  }
+  printf("dim %d nverts %zu nelems %zu coords %.17g e2v %lld cls %lld nsides %zu sides %lld\n", m.dim,
+         m.coords.size() / m.dim, m.class_id.size(), cs, es, ks, m.side_class.size(), ss);
   return 0;
 }
 """
@@ -79,3 +83,31 @@ def test_gmsh_rejects_what_it_cannot_read(reader_exe, tmp_path):
     with pytest.raises(ValueError):
         meshio.read_gmsh(str(q))
     assert subprocess.run([reader_exe, str(q)], capture_output=True, text=True).returncode == 1
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_gmsh_boundary_elements_become_side_classification(pp, reader_exe, tmp_path, dim):
+    """boundary elements of a 2.2 file (lines of a triangle mesh, triangles of a tet mesh) come back from the C++ reader as
+    (side vertices, elementary tag): what Omega_h::gmsh::read turns into the sides' class_id
+    (test/pseudoPushAndSearch.cpp:231 picks its start elements by it)"""
+    from pumipic_amd import meshio
+    synth = pp.synth
+    if dim == 3:
+        coords, e2v, cls = synth.kuhn_box(2)
+        faces = [(0, 2, 1), (0, 1, 3), (1, 2, 3), (2, 0, 3)]
+        sides = [[t[a], t[b], t[c]] for t in e2v for a, b, c in faces
+                 if (np.abs(coords[[t[a], t[b], t[c]], 1]) < 1e-12).all()]
+    else:
+        coords, e2v, cls = synth.plate_tri8_pardiag()
+        sides = [[t[a], t[(a + 1) % 3]] for t in e2v for a in range(3)
+                 if (np.abs(coords[[t[a], t[(a + 1) % 3]], 0]) < 1e-12).all()]
+    tags = np.arange(len(sides)) % 3 + 150
+    path = str(tmp_path / "m.msh")
+    meshio.write_gmsh(path, dim, coords, e2v, cls, sides=(np.asarray(sides), tags))
+    d2, c2, e2, k2 = meshio.read_gmsh(path)  # (the python reader keeps the top-dimensional elements only)
+    assert d2 == dim and np.array_equal(e2, e2v) and np.array_equal(k2, cls)
+    out = subprocess.run([reader_exe, path], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    t = out.stdout.split()
+    assert int(t[13]) == len(sides) and len(sides) > 0
+    assert int(t[15]) == int(sum(int(tag) * 1000003 + int(np.sum(sv)) for sv, tag in zip(sides, tags)))
