@@ -412,7 +412,8 @@ def test_reference_barycentric_passes(tmp_path, which):
 # The pumipic-data meshes are not here; the mesh is a Kuhn box written as Gmsh 2.2 whose boundary triangles on y == 0
 # carry the model-face id, which the reader turns into the sides' class_id (pseudoPushAndSearch.cpp:231).  The oracle
 # runs the same loop; the program's per-iteration particle counts and its has_particles tag must equal the oracle's.
-@pytest.mark.parametrize("n,npt,ranks", [(6, 20000, 1), (6, 20000, 2)])
+# (16, 100 000): BASELINE configs[0] at its size as SURVEY 8(d) restates it -- 24 576 tets, 100 000 particles, 30 steps
+@pytest.mark.parametrize("n,npt,ranks", [(6, 20000, 1), (6, 20000, 2), (16, 100000, 1)])
 def test_reference_pseudo_push_and_search_source_matches_oracle(pp, ppo, tmp_path, n, npt, ranks):
     import importlib
     import common
