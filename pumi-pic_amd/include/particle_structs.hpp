@@ -27,6 +27,7 @@
 #include <memory>
 #include <sstream>
 #include <string>
+#include <tuple>
 #include <type_traits>
 #include <utility>
 #include <map>
@@ -223,45 +224,29 @@ inline typename ViewT::value_type getLastValue(ViewT view) {
 }
 
 // ---------------------------------------------------------------- member type lists
+// MemberTypes<T0, T1, ...>: the compile-time list of a particle's members (support/MemberTypes.h:6-62 names the same
+// things: ::size, ::memsize = bytes of one particle, ::sizeToIndex<N>() = bytes of the members in front of member N,
+// MemberTypeAtIndex<N, List>::type).  C++17 pack expansions instead of recursive templates.
+
 template <typename... Types>
-struct MemberTypes;
-template <>
-struct MemberTypes<> {
-  static constexpr std::size_t size = 0;
-  static constexpr std::size_t memsize = 0;
+struct MemberTypes {
+  static constexpr std::size_t size = sizeof...(Types);
+  static constexpr std::size_t memsize = (std::size_t(0) + ... + sizeof(Types));
   template <std::size_t N>
   static constexpr std::size_t sizeToIndex() {
-    return 0;
+    static_assert(N <= sizeof...(Types), "sizeToIndex: no such member");
+    constexpr std::size_t bytes[sizeof...(Types) + 1] = {sizeof(Types)..., 0};
+    std::size_t before = 0;
+    for (std::size_t i = 0; i < N; ++i) before += bytes[i];
+    return before;
   }
-};
-template <typename H, typename... T>
-struct MemberTypes<H, T...> {
-  static constexpr std::size_t size = 1 + MemberTypes<T...>::size;
-  // bytes of one particle (support/MemberTypes.h:30-45) and of the members in front of member N
-  static constexpr std::size_t memsize = sizeof(H) + MemberTypes<T...>::memsize;
-  template <std::size_t N>
-  static constexpr std::size_t sizeToIndex() {
-    if constexpr (N == 0)
-      return 0;
-    else
-      return sizeof(H) + MemberTypes<T...>::template sizeToIndex<N - 1>();
-  }
-};
-template <std::size_t N, typename... Types>
-struct MemberTypeAtIndexImpl;
-template <typename T, typename... Types>
-struct MemberTypeAtIndexImpl<0, T, Types...> {
-  using type = T;
-};
-template <std::size_t N, typename T, typename... Types>
-struct MemberTypeAtIndexImpl<N, T, Types...> {
-  using type = typename MemberTypeAtIndexImpl<N - 1, Types...>::type;
 };
 template <std::size_t N, typename DataTypes>
 struct MemberTypeAtIndex;
 template <std::size_t N, typename... Types>
 struct MemberTypeAtIndex<N, MemberTypes<Types...>> {
-  using type = typename MemberTypeAtIndexImpl<N, Types...>::type;
+  // (std::tuple is only named, never instantiated: array members such as double[3] are fine)
+  using type = typename std::tuple_element<N, std::tuple<Types...>>::type;
 };
 template <class T>
 struct BaseType {
