@@ -287,7 +287,8 @@ def test_c2_intersection_mode_full_size(pp, ppo, capi):
     ids, faces = r["elem_ids"].to_host()[:cap], r["inter_faces"].to_host()[:cap]
     pts = r["inter_points"].to_host()[:3 * cap].reshape(cap, 3)
     steps = capi.search_walk_steps()
-    assert steps > 20 * len(live)  # tens of elements per ray
+    if os.environ.get("PP_MT_PACKED") != "0":  # (the fallback walk on the Omega_h-style arrays does not count its steps)
+        assert steps > 20 * len(live)  # tens of elements per ray
     assert (faces[~mk.astype(bool)] == -1).all() and not pts[~mk.astype(bool)].any()
     assert (ids[live] >= 0).all() and (faces[live] >= 0).all()  # every ray of this push reaches the wall
     exposed = mesh.array(capi.MESH_SIDE_EXPOSED)

@@ -120,6 +120,11 @@ class Ctx:
 
     def expect(self, state):
         d = self.ps.deferred_state()
+        # laboratory builds that force a fallback path (tools/gpu_test_matrix.sh) do not reach the deferred states at
+        # all: the second pass runs at once / the record-fed kernels are not the ones selected
+        lab_off = os.environ.get("PP_NO_LAZY_UNPACK") or os.environ.get("PP_WALK_QUEUE") is not None
+        if lab_off and state.startswith("rec") and d["lazy_rec"] != {"rec1": 1, "rec2": 2, "rec3": 3}[state]:
+            pytest.skip("a forced fallback path (lab switch) does not reach state %s" % state)
         if state == "rec1":
             assert d["lazy_rec"] == 1 and d["zero_pending"] >= 0, d
         elif state == "rec2":
@@ -787,6 +792,8 @@ def test_ring_map_edited_in_place_is_caught(capi, synth, ppo):
     see (a raw hipMemcpy here, a caller kernel in general) is caught by the sampled content stamp within eight
     scatters, the call fails with PP_ESTATE, and after pp_gyro_map_forget the edited map is served correctly."""
     import ctypes
+    if os.environ.get("PP_SCATTER_ATOMIC"):
+        pytest.skip("the atomic second stage keeps no transposed copy of the map: an edited map is simply used")
     pop = common.population_2d(synth, n_b=12, n_theta=48, num_ptcls=4000)
     mo, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_XGCM)
     mg, pg = common.gpu_pair(capi, pop, capi.PARTICLE_XGCM)

@@ -8,7 +8,7 @@
 # (round 6: built, measured, not the default).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export PUMIPIC_HIP_LIB=$R/pumi-pic_amd/libpumipic_hip_lab.so
-for cfg in "PP_WALK_QUEUE=1" "PP_WALK_QUEUE=0" "PP_NO_LAZY_UNPACK=1" "PP_NO_SCATTER_RIDE=1" "PP_NO_SPEC_REBUILD=1" \
-           "PP_SCATTER_ATOMIC=1" "PP_MT_PACKED=0" "PP_NO_HOT_ROW=1" "PP_TEST_SHUFFLING=0" "PP_REC_SPLIT=1"; do
-  echo "== $cfg"; env $cfg timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -2
+CFGS=${CFGS:-"PP_WALK_QUEUE=1 PP_WALK_QUEUE=0 PP_NO_LAZY_UNPACK=1 PP_NO_SCATTER_RIDE=1 PP_NO_SPEC_REBUILD=1 PP_SCATTER_ATOMIC=1 PP_MT_PACKED=0 PP_NO_HOT_ROW=1 PP_TEST_SHUFFLING=0 PP_REC_SPLIT=1"}
+for cfg in $CFGS; do   # (CFGS="PP_MT_PACKED=0 ..." bash tools/gpu_test_matrix.sh: some of them)
+  echo "== $cfg"; env $cfg timeout 1200 python -m pytest tests -m gpu -q 2>&1 | grep -E "^FAILED|passed|failed|error" | tail -6
 done
