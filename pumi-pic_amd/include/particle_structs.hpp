@@ -223,6 +223,10 @@ inline typename ViewT::value_type getLastValue(ViewT view) {
   return v;
 }
 
+// the timing table of the mirror (pumipic_adjacency.hpp: RecordTime / Timer; defined there, after this header)
+inline double op_timer_start();
+inline void op_timer_record(const std::string& name, double t0);
+
 // ---------------------------------------------------------------- member type lists
 // MemberTypes<T0, T1, ...>: the compile-time list of a particle's members (support/MemberTypes.h:6-62 names the same
 // things: ::size, ::memsize = bytes of one particle, ::sizeToIndex<N>() = bytes of the members in front of member N,
@@ -511,15 +515,20 @@ class ParticleStructure {
   }
   virtual void rebuild(kkLidView new_element, kkLidView new_particle_elements = kkLidView(),
                        MTVs new_particle_info = NULL) {
+    const double t0 = op_timer_start();
     pp_check(pp_ps_rebuild(h_, new_element.data(), (int)new_particle_elements.size(),
                            new_particle_elements.data(), (const void* const*)new_particle_info),
              "ParticleStructure::rebuild");
+    // (the rows the reference's structures add to the timing table: scs/SCS_rebuild.h:177,312, csr/CSR_rebuild.hpp:116)
+    op_timer_record(timing_label() + " rebuild", t0);
   }
+  std::string timing_label() const { return info().kind == PP_SCS ? name_ : std::string("CSR"); }
   // SellCSigma::migrate / CSR::migrate (scs/SCS_migrate.h:5-222): particles whose new_process is
   // another rank are packed, exchanged over the distributor's communicator and enter the
   // receiver's rebuild as new particles; one rank -> plain rebuild (:20-25)
   virtual void migrate(kkLidView new_element, kkLidView new_process, Distributor<MemSpace> dist = Distributor<MemSpace>(),
                        kkLidView new_particle_elements = kkLidView(), MTVs new_particle_info = NULL) {
+    const double t0 = op_timer_start();
     if (!dist.isWorld() && pp_comm_size(dist.comm()) > 1) {  // every leaving particle goes to a rank of the subset
       // The check is COLLECTIVE: a rank that found a violation and left alone would leave its peers waiting
       // in the exchange (round-3 advisor) -- every rank contributes its verdict to one host all-gather and
@@ -554,6 +563,9 @@ class ParticleStructure {
                                    (const void* const*)new_particle_info, nullptr, 0, nullptr, 0, nullptr,
                                    nullptr, 0.0, 2, 1),
              "ParticleStructure::migrate");
+    // (scs/SCS_migrate.h:21,122,218, csr/CSR_migrate.hpp:30,130,225 -- there without the rebuild at its end, which
+    //  has a row of its own; here the exchange and the re-layout are one call)
+    op_timer_record(timing_label() + " particle migration", t0);
   }
   virtual void printMetrics() const {
     const pp_ps_info_t i = info();

@@ -857,6 +857,20 @@ inline void RecordTime(const std::string& name, double seconds, double prebarrie
     fprintf(stderr, "%d %s (seconds) %f pre-barrier (seconds) %f\n", pp_comm_rank(comm_world()), name.c_str(),
             seconds, prebarrierTime);
 }
+// start / end of an operation a structure times itself (particle_structs.hpp: rebuild, migrate): a host clock, as the
+// reference's Kokkos::Timer is; with PP_TIMER_FENCE=1 (timer_fences(), below) the stream is drained on both sides, so
+// that the row holds the operation's device time
+inline bool timer_fences();
+inline double op_timer_start() {
+  if (!isTiming()) return 0.0;
+  if (timer_fences()) (void)pp_sync();
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline void op_timer_record(const std::string& name, double t0) {
+  if (!isTiming()) return;
+  if (timer_fences()) (void)pp_sync();
+  RecordTime(name, std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0);
+}
 enum TimingSortOption { SORT_ALPHA, SORT_ORDER, SORT_LONGEST, SORT_SHORTEST };
 inline std::vector<std::pair<std::string, TimingEntry>> sorted_timing(TimingSortOption sort) {
   std::vector<std::pair<std::string, TimingEntry>> v(timing_table().begin(), timing_table().end());
@@ -938,6 +952,7 @@ inline int& timer_fence_flag() {
   return f;
 }
 inline void SetTimerFence(bool on) { timer_fence_flag() = on ? 1 : 0; }
+inline bool timer_fences() { return timer_fence_flag() != 0; }
 struct Timer {
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   void reset() { t0 = std::chrono::steady_clock::now(); }
