@@ -152,7 +152,7 @@ def test_reference_ps_combo160_source_runs_unchanged(tmp_path, structure, strat)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "Beginning migrate on structure" in r.stdout
     # the row the reference's structures add to the timing table (scs/SCS_migrate.h:21, csr/CSR_migrate.hpp:30)
-    assert re.search(r"(Sell-32-ne|CSR) particle migration +[0-9.]+ +100 ", r.stdout), r.stdout[-1500:]
+    assert re.search(r"(Sell-32-ne|CSR) particle migration +[0-9.]+ +100 ", r.stdout + r.stderr), r.stderr[-1500:]
     name = "Sell-32-ne" if structure == 0 else "ptcls"
     d, bn = _load_ref_dump(prefix, name)
     assert bn == [(8, 17), (4, 4), (8, 1)]  # MemberTypes<double[17], int[4], long>
