@@ -991,11 +991,56 @@ bool search_mesh(Mesh& mesh, ParticleStructure<ParticleType>* ptcls, Segment3d x
     inter_points = o::Write<o::Real>((size_t)mesh.dim() * cap, 0);
     inter_faces = o::Write<o::LO>(cap, -1);
   }
+  // PP_SEARCH_DUMP=<prefix> (a hook of the mirror headers, like PP_DUMP_ON_DELETE: the reference's test programs cannot
+  // be touched): every call writes its inputs and outputs to <prefix>_call<k>_*.bin, so that a particle one of those
+  // programs complains about can be handed to the oracle (tools/replay_search_dump.py)
+  static int dump_call = 0;
+  const char* dump = getenv("PP_SEARCH_DUMP");
+  auto dump_file = [&](const char* what, const void* host, size_t bytes) {
+    const std::string fn = std::string(dump) + "_call" + std::to_string(dump_call) + "_" + what + ".bin";
+    if (FILE* f = fopen(fn.c_str(), "wb")) {
+      fwrite(host, 1, bytes, f);
+      fclose(f);
+    }
+  };
+  auto dump_member = [&](const char* what, int m, size_t bytes_per) {
+    const pp_ps_info_t inf = ptcls->info();
+    std::vector<char> h((size_t)inf.stride * bytes_per);
+    pp_check(pp_ps_member_to_host(ptcls->handle(), m, h.data()), "PP_SEARCH_DUMP");
+    dump_file(what, h.data(), h.size());
+  };
+  if (dump) {
+    pp_check(pp_sync(), "PP_SEARCH_DUMP");
+    const pp_ps_info_t inf = ptcls->info();
+    const int hdr[6] = {(int)cap, (int)inf.stride, seeded, requireIntersection ? 1 : 0, looplimit, mesh.dim()};
+    dump_file("hdr", hdr, sizeof(hdr));
+    dump_member("xo", x_ps_orig.member(), 3 * sizeof(double));
+    dump_member("xt", x_ps_tgt.member(), 3 * sizeof(double));
+    std::vector<int> slot_elem(cap), ein = elem_ids.to_host();
+    std::vector<unsigned char> mask(cap);
+    pp_check(pp_ps_layout_to_host(ptcls->handle(), nullptr, nullptr, nullptr, nullptr, mask.data(), slot_elem.data()),
+             "PP_SEARCH_DUMP");
+    dump_file("mask", mask.data(), mask.size());
+    dump_file("elem", slot_elem.data(), slot_elem.size() * sizeof(int));
+    dump_file("ein", ein.data(), ein.size() * sizeof(int));
+  }
   int found = 1, notin = 0;
   pp_check(pp_search_mesh(mesh.handle(), ptcls->handle(), x_ps_orig.member(), x_ps_tgt.member(),
                           pids.member(), elem_ids.data(), seeded, requireIntersection ? 1 : 0,
                           inter_faces.data(), inter_points.data(), looplimit, &found, &notin),
            "search_mesh");
+  if (dump) {
+    pp_check(pp_sync(), "PP_SEARCH_DUMP");
+    const std::vector<int> eout = elem_ids.to_host();
+    dump_file("eout", eout.data(), eout.size() * sizeof(int));
+    if (requireIntersection) {
+      const std::vector<int> fc = inter_faces.to_host();
+      const std::vector<double> pt = inter_points.to_host();
+      dump_file("face", fc.data(), fc.size() * sizeof(int));
+      dump_file("pts", pt.data(), pt.size() * sizeof(double));
+    }
+    ++dump_call;
+  }
   RecordTime("pumipic search_mesh", timer.seconds());
   return found != 0;
 }
