@@ -327,7 +327,7 @@ def _plate_tris(n):
     return coords, e2v, np.ones(len(e2v), dtype=np.int32)
 
 
-@pytest.mark.parametrize("mesh_kind", ["tri8", "plate_2x24x24", "cube_7986", "cube_48", "plate_2x224x224"])
+@pytest.mark.parametrize("mesh_kind", ["tri8", "plate_2x24x24", "cube_7986", "cube_48"])
 def test_reference_test_adj_passes(pp, tmp_path, mesh_kind):
     """100 and 1 000 000 particles (PP_USE_GPU): internal and vertex / edge / face starts, barycentric walk and walk
     with wall intersections, each judged by the reference's own check_initial_parents, intersection-on-face,
@@ -336,8 +336,8 @@ def test_reference_test_adj_passes(pp, tmp_path, mesh_kind):
     s = pp.synth
     if mesh_kind == "tri8":
         dim, (c, e, cl) = 2, s.plate_tri8_pardiag()
-    elif mesh_kind.startswith("plate"):  # (2 x 224 x 224 = 100 352 triangles: configs[2]'s mesh size; fine cubes: the next test)
-        dim, (c, e, cl) = 2, _plate_tris(224 if mesh_kind.endswith("224") else 24)
+    elif mesh_kind.startswith("plate"):  # (fine plates and cubes: the next test)
+        dim, (c, e, cl) = 2, _plate_tris(24)
     else:
         dim, (c, e, cl) = 3, s.kuhn_box({"cube_7986": 11, "cube_48": 2}[mesh_kind])
     mesh_file = str(tmp_path / (mesh_kind + ".osh"))
@@ -576,9 +576,11 @@ def test_reference_file_rw_passes(pp, tmp_path, ranks, buffer, safe):
     assert os.path.exists(str(tmp_path / ("parts_%d.pparts" % ranks)))
 
 
-@pytest.mark.parametrize("n", [16, 26])
-def test_reference_test_adj_on_fine_cubes_complains_only_about_the_references_own_fallback(pp, ppo, tmp_path, n):
-    """On 24 576 and 105 456 tets, 10^6 rays, test_adj's wall-intersection check flags one or two particles per run: wall
+@pytest.mark.parametrize("n", [16, 26, -224])
+def test_reference_test_adj_on_fine_meshes_complains_only_about_the_references_own_fallback(pp, ppo, tmp_path, n):
+    """(n < 0: the plate of 2 n^2 = 100 352 triangles, where a segment through a vertex can fail both edges' tests within
+    the tolerance and the particle stops where it is, adjacency.tpp:290-310.)
+    On 24 576 and 105 456 tets, 10^6 rays, test_adj's wall-intersection check flags one or two particles per run: wall
     hits whose recorded point lies outside their face (and, rarely, a ray that ends without a face).  That is the
     reference's own algorithm -- when no face of an element passes the Moeller-Trumbore test, adjacency.tpp:343-352 keeps
     the point of the face with the best `closeness`, a face the ray does not cross.  Proof: every search_mesh call of the
@@ -588,9 +590,9 @@ def test_reference_test_adj_on_fine_cubes_complains_only_about_the_references_ow
     import importlib.util
     exe = _need("test_adj")
     s = pp.synth
-    c, e, cl = s.kuhn_box(n)
-    mesh_file = str(tmp_path / "cube.osh")
-    s.write_mesh_bin(mesh_file, 3, c, e, cl)
+    dim, (c, e, cl) = (3, s.kuhn_box(n)) if n > 0 else (2, _plate_tris(-n))
+    mesh_file = str(tmp_path / "mesh.osh")
+    s.write_mesh_bin(mesh_file, dim, c, e, cl)
     prefix = str(tmp_path / "sd")
     (rc, so, se), = _run_ranks([exe, mesh_file], 1, str(tmp_path), timeout=900, extra_env={"PP_SEARCH_DUMP": prefix})
     spec = importlib.util.spec_from_file_location("replay_search_dump", os.path.join(ROOT, "tools", "replay_search_dump.py"))
@@ -600,7 +602,10 @@ def test_reference_test_adj_on_fine_cubes_complains_only_about_the_references_ow
     assert len(res) == 8  # (two particle counts) x (internal, edge starts) x (two searches each) in intersection mode
     assert all(r["identical"] for r in res), res
     flagged = sum(r["off_face"] for r in res)
-    assert flagged <= 8 and sum(r["lost"] for r in res) <= 4, res
-    assert so.count("outside the intersection face") == flagged, (flagged, so[-2000:])
+    # a handful per 10^6 rays, not a population (the plate, whose segments stop where an edge test fails: a few more)
+    assert flagged <= (8 if dim == 3 else 50) and sum(r["lost"] for r in res) <= (4 if dim == 3 else 50), res
+    print("flagged", [(r["call"], r["hits"], r["off_face"], r["lost"]) for r in res])
+    assert so.count("outside the intersection face") + so.count("outside the intersection edge") == flagged, \
+        (flagged, so[-2000:])
     if flagged == 0 and sum(r["lost"] for r in res) == 0:
         assert rc == 0 and "All Tests Passed" in se

@@ -35,10 +35,9 @@ def replay(mesh_file, prefix, ppo=None, verbose=True):
     """-> one dict per dumped intersection-mode call: slots, hits, off_face, lost, sampled, identical"""
     ppo = ppo or pumipic_amd_loader.load_oracle()
     dim, coords, e2v, cls = read_container(mesh_file)
-    assert dim == 3
     ne = len(e2v)
-    mo = ppo.Mesh(3, coords, e2v, cls)
-    s2v = np.asarray(mo.side2verts).reshape(-1, 3)
+    mo = ppo.Mesh(dim, coords, e2v, cls)
+    s2v = np.asarray(mo.side2verts).reshape(-1, dim)
     lo, hi = coords.min(axis=0), coords.max(axis=0)
     tol = mo.tolerance()
     rng = np.random.default_rng(1)
@@ -53,23 +52,31 @@ def replay(mesh_file, prefix, ppo=None, verbose=True):
         xt = g("xt", np.float64).reshape(3, stride)[:, :cap]
         mask = g("mask", np.uint8)[:cap].astype(bool)
         selem, ein, eout = g("elem", np.int32)[:cap], g("ein", np.int32)[:cap], g("eout", np.int32)[:cap]
-        face, pts = g("face", np.int32)[:cap], g("pts", np.float64)[:cap * 3].reshape(cap, 3)
+        face, pts = g("face", np.int32)[:cap], g("pts", np.float64)[:cap * dim].reshape(cap, dim)
         hit = np.flatnonzero(mask & (face >= 0))
-        a, b, c = (coords[s2v[face[hit], j]] for j in range(3))
-        nrm = np.cross(b - a, c - a)
-        with np.errstate(invalid="ignore", divide="ignore"):
-            bc = np.stack([np.einsum("ij,ij->i", nrm, np.cross(b - a, pts[hit] - a)),
-                           np.einsum("ij,ij->i", nrm, np.cross(c - b, pts[hit] - b)),
-                           np.einsum("ij,ij->i", nrm, np.cross(pts[hit] - a, c - a))]) / np.einsum("ij,ij->i", nrm, nrm)
-        off = hit[~(np.isfinite(bc).all(axis=0) & (bc >= -tol).all(axis=0))]
+        if dim == 3:  # the point inside the triangle (test_adj.cpp:640-652)
+            a, b, c = (coords[s2v[face[hit], j]] for j in range(3))
+            nrm = np.cross(b - a, c - a)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                bc = np.stack([np.einsum("ij,ij->i", nrm, np.cross(b - a, pts[hit] - a)),
+                               np.einsum("ij,ij->i", nrm, np.cross(c - b, pts[hit] - b)),
+                               np.einsum("ij,ij->i", nrm, np.cross(pts[hit] - a, c - a))]) / np.einsum("ij,ij->i", nrm, nrm)
+            ok = np.isfinite(bc).all(axis=0) & (bc >= -tol).all(axis=0)
+        else:  # the point on the edge (test_adj.cpp:614-628, 666-680)
+            a, b = coords[s2v[face[hit], 0]], coords[s2v[face[hit], 1]]
+            path, edge = pts[hit] - a, b - a
+            with np.errstate(invalid="ignore"):
+                ok = (np.abs(path[:, 0] * edge[:, 1] - path[:, 1] * edge[:, 0]) <= tol) & \
+                     (pts[hit] >= np.minimum(a, b) - tol).all(axis=1) & (pts[hit] <= np.maximum(a, b) + tol).all(axis=1)
+        off = hit[~ok]
         live_in = mask & (ein >= 0 if seeded else True)
-        lost = np.flatnonzero(live_in & (face < 0) & (((xt.T < lo - tol) | (xt.T > hi + tol)).any(axis=1)))
+        lost = np.flatnonzero(live_in & (face < 0) & (((xt.T[:, :dim] < lo - tol) | (xt.T[:, :dim] > hi + tol)).any(axis=1)))
         pool = np.flatnonzero(live_in)
         take = np.unique(np.concatenate([off, lost, rng.choice(pool, min(2000, len(pool)), replace=False)]))
         take = take[np.argsort(selem[take], kind="stable")]
         n = len(take)
         ppe = np.bincount(selem[take], minlength=ne).astype(np.int32)
-        pop = dict(dim=3, coords=coords, e2v=e2v, cls=cls, ppe=ppe, elem=selem[take],
+        pop = dict(dim=dim, coords=coords, e2v=e2v, cls=cls, ppe=ppe, elem=selem[take],
                    info=[xo[:, take], xt[:, take], np.arange(n, dtype=np.int32)])
         _, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_PUSH)
         ocap = po.capacity()
@@ -83,7 +90,8 @@ def replay(mesh_file, prefix, ppo=None, verbose=True):
         src = take[oid[om]]
         same = (np.array_equal(ro["elem_ids"][:ocap][om], eout[src]) and
                 np.array_equal(ro["inter_faces"][:ocap][om], face[src]) and
-                np.array_equal(ro["inter_points"][:ocap * 3].reshape(ocap, 3)[om].view(np.uint64), pts[src].view(np.uint64)))
+                np.array_equal(ro["inter_points"][:ocap * dim].reshape(ocap, dim)[om].view(np.uint64),
+                               pts[src].view(np.uint64)))
         out.append(dict(call=k, slots=int(mask.sum()), hits=len(hit), off_face=len(off), lost=len(lost),
                         sampled=n - len(off) - len(lost), identical=bool(same)))
         if verbose:
