@@ -179,8 +179,10 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def test_reference_pseudoxgcm_source_two_ranks(pp, tmp_path):
-    """The unchanged test/pseudoXGCm.cpp as TWO rank processes sharing the GPU (PP_COMM=tcp): pumipic::read cuts the
+@pytest.mark.parametrize("world", [2, 4])
+def test_reference_pseudoxgcm_source_two_ranks(pp, tmp_path, world):
+    """(4 ranks: testing.cmake pseudoXGCm_24kElms_4 / _120kElms_4.)
+    The unchanged test/pseudoXGCm.cpp as TWO rank processes sharing the GPU (PP_COMM=tcp): pumipic::read cuts the
     element-block parts, `p::Distributor<> dist(nBuffers, buffered_ranks)` lists self + the other rank,
     migrate_lb_ptcls -> ParticleStructure::migrate moves the particles that leave a block, gyroSync ->
     reduceCommArray sums the fields, MPI_Allreduce / MPI_Barrier / printPtclImb run over the library's communicator.
@@ -192,7 +194,7 @@ def test_reference_pseudoxgcm_source_two_ranks(pp, tmp_path):
     ne = len(e)
     mesh_file = str(tmp_path / "annulus.bin")
     s.write_mesh_bin(mesh_file, 2, c, e, cl)
-    npt, world, steps = 40000, 2, 10
+    npt, steps = 40000, 10
     port = _free_port()
     prefix = str(tmp_path / "two")
     procs = []
@@ -206,7 +208,7 @@ def test_reference_pseudoxgcm_source_two_ranks(pp, tmp_path):
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, (so[-1500:], se[-3000:])
     so0, se0 = outs[0]
-    assert "world ranks 2" in so0 and "pre-barrier enabled" in se0 and "done" in se0
+    assert ("world ranks %d" % world) in so0 and "pre-barrier enabled" in se0 and "done" in se0
     m = re.search(r"particles created (\d+)", se0)
     assert m
     created = int(m.group(1))
@@ -229,7 +231,7 @@ def test_reference_pseudoxgcm_source_two_ranks(pp, tmp_path):
         assert (owner == r).all(), "rank %d holds particles of another rank's elements" % r
         fields.append(np.fromfile("%s_tag_0_ptclToMeshSync_r%d.f64" % (prefix, r)))
     assert total == created
-    assert np.array_equal(fields[0], fields[1]) and fields[0].sum() > 0
+    assert all(np.array_equal(fields[0], f) for f in fields[1:]) and fields[0].sum() > 0
 
 
 # ---------------------------------------------------------------- the reference's OWN particle-structure tests
