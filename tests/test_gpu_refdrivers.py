@@ -578,7 +578,7 @@ def test_reference_file_rw_passes(pp, tmp_path, ranks, buffer, safe):
     assert os.path.exists(str(tmp_path / ("parts_%d.pparts" % ranks)))
 
 
-@pytest.mark.parametrize("n", [16, 26, -224])
+@pytest.mark.parametrize("n", [16, 26, -224, 0])
 def test_reference_test_adj_on_fine_meshes_complains_only_about_the_references_own_fallback(pp, ppo, tmp_path, n):
     """(n < 0: the plate of 2 n^2 = 100 352 triangles, where a segment through a vertex can fail both edges' tests within
     the tolerance and the particle stops where it is, adjacency.tpp:290-310.)
@@ -592,7 +592,9 @@ def test_reference_test_adj_on_fine_meshes_complains_only_about_the_references_o
     import importlib.util
     exe = _need("test_adj")
     s = pp.synth
-    dim, (c, e, cl) = (3, s.kuhn_box(n)) if n > 0 else (2, _plate_tris(-n))
+    # (n == 0: the 100 800-tet torus of configs[1-2] -- curved, non-convex, tets of many shapes; the program's bounding-box
+    #  check assumes a box, so only the oracle comparison and the wall-point count are asserted there)
+    dim, (c, e, cl) = (3, s.kuhn_box(n)) if n > 0 else (2, _plate_tris(-n)) if n < 0 else (3, s.torus_tet())
     mesh_file = str(tmp_path / "mesh.osh")
     s.write_mesh_bin(mesh_file, dim, c, e, cl)
     prefix = str(tmp_path / "sd")
@@ -605,7 +607,8 @@ def test_reference_test_adj_on_fine_meshes_complains_only_about_the_references_o
     assert all(r["identical"] for r in res), res
     flagged = sum(r["off_face"] for r in res)
     # a handful per 10^6 rays, not a population (the plate, whose segments stop where an edge test fails: a few more)
-    assert flagged <= (8 if dim == 3 else 50) and sum(r["lost"] for r in res) <= (4 if dim == 3 else 50), res
+    if n != 0:
+        assert flagged <= (8 if dim == 3 else 50) and sum(r["lost"] for r in res) <= (4 if dim == 3 else 50), res
     print("flagged", [(r["call"], r["hits"], r["off_face"], r["lost"]) for r in res])
     assert so.count("outside the intersection face") + so.count("outside the intersection edge") == flagged, \
         (flagged, so[-2000:])
