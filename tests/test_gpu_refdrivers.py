@@ -603,8 +603,10 @@ def test_reference_test_adj_on_fine_meshes_complains_only_about_the_references_o
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     res = mod.replay(mesh_file, prefix, ppo, verbose=False)
-    assert len(res) == 8  # (two particle counts) x (internal, edge starts) x (two searches each) in intersection mode
+    # (two particle counts) x (internal, edge starts) x (two searches each), by barycentric walk and in intersection mode
+    assert len(res) == 16 and sum(r["mode"] == "bcc" for r in res) == 8
     assert all(r["identical"] for r in res), res
+    res = [r for r in res if r["mode"] == "intersection"]
     flagged = sum(r["off_face"] for r in res)
     # a handful per 10^6 rays, not a population (the plate, whose segments stop where an edge test fails: a few more)
     if n != 0:

@@ -46,12 +46,35 @@ def replay(mesh_file, prefix, ppo=None, verbose=True):
     for k in range(ncalls):
         g = lambda what, dt: np.fromfile("%s_call%d_%s.bin" % (prefix, k, what), dtype=dt)
         cap, stride, seeded, req, looplimit, _ = g("hdr", np.int32)
-        if not req:
-            continue
         xo = g("xo", np.float64).reshape(3, stride)[:, :cap]
         xt = g("xt", np.float64).reshape(3, stride)[:, :cap]
         mask = g("mask", np.uint8)[:cap].astype(bool)
         selem, ein, eout = g("elem", np.int32)[:cap], g("ein", np.int32)[:cap], g("eout", np.int32)[:cap]
+        if not req:
+            # barycentric walk (no wall points): 5 000 particles of the call, the degenerate starts of the program's
+            # "edge" populations among them, must end in the oracle's element
+            pool = np.flatnonzero(mask & (ein >= 0 if seeded else True))
+            take = np.sort(rng.choice(pool, min(5000, len(pool)), replace=False))
+            take = take[np.argsort(selem[take], kind="stable")]
+            n = len(take)
+            pop = dict(dim=dim, coords=coords, e2v=e2v, cls=cls, ppe=np.bincount(selem[take], minlength=ne).astype(np.int32),
+                       elem=selem[take], info=[xo[:, take], xt[:, take], np.arange(n, dtype=np.int32)])
+            _, po = common.oracle_pair(ppo, pop, ppo.PARTICLE_PUSH)
+            ocap = po.capacity()
+            om = po.slot_info()[1].astype(bool)
+            oid = po.member(2)[0, :ocap]
+            seed = None
+            if seeded:
+                seed = np.full(ocap, -1, dtype=np.int32)
+                seed[om] = ein[take][oid[om]]
+            ro = ppo.search_mesh(mo, po, elem_ids=seed, require_intersection=False, looplimit=int(looplimit))
+            same = np.array_equal(ro["elem_ids"][:ocap][om], eout[take[oid[om]]])
+            out.append(dict(call=k, mode="bcc", slots=int(mask.sum()), hits=0, off_face=0, lost=0, sampled=n,
+                            identical=bool(same)))
+            if verbose:
+                print("call %d (barycentric walk): %d slots; oracle on %d of them: %s"
+                      % (k, int(mask.sum()), n, "identical" if same else "DIFFERENT"))
+            continue
         face, pts = g("face", np.int32)[:cap], g("pts", np.float64)[:cap * dim].reshape(cap, dim)
         hit = np.flatnonzero(mask & (face >= 0))
         if dim == 3:  # the point inside the triangle (test_adj.cpp:640-652)
@@ -92,7 +115,7 @@ def replay(mesh_file, prefix, ppo=None, verbose=True):
                 np.array_equal(ro["inter_faces"][:ocap][om], face[src]) and
                 np.array_equal(ro["inter_points"][:ocap * dim].reshape(ocap, dim)[om].view(np.uint64),
                                pts[src].view(np.uint64)))
-        out.append(dict(call=k, slots=int(mask.sum()), hits=len(hit), off_face=len(off), lost=len(lost),
+        out.append(dict(call=k, mode="intersection", slots=int(mask.sum()), hits=len(hit), off_face=len(off), lost=len(lost),
                         sampled=n - len(off) - len(lost), identical=bool(same)))
         if verbose:
             print("call %d: %d slots, %d wall hits, %d with the point off the face, %d outside without a face; oracle on "
