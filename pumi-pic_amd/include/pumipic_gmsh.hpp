@@ -63,7 +63,7 @@ inline bool read(const std::string& path, MeshData& out, std::string* err = null
         for (long long i = 0; i < n; ++i) {
           long long tag;
           double x, y, z;
-          in >> tag >> x >> y >> z;
+          if (!(in >> tag >> x >> y >> z)) return fail("truncated $Nodes section", err);
           node_index[tag] = (int)(xyz.size() / 3);
           xyz.insert(xyz.end(), {x, y, z});
         }
@@ -73,12 +73,12 @@ inline bool read(const std::string& path, MeshData& out, std::string* err = null
         for (long long b = 0; b < nblocks; ++b) {
           int edim, etag, parametric;
           long long nb;
-          in >> edim >> etag >> parametric >> nb;
+          if (!(in >> edim >> etag >> parametric >> nb) || nb < 0 || nb > n) return fail("bad $Nodes block", err);
           std::vector<long long> tags((size_t)nb);
           for (auto& t : tags) in >> t;
           for (long long i = 0; i < nb; ++i) {
             double x, y, z;
-            in >> x >> y >> z;
+            if (!(in >> x >> y >> z)) return fail("truncated $Nodes block", err);
             for (int k = 0; k < (parametric ? edim : 0); ++k) {
               double u;
               in >> u;
@@ -95,11 +95,13 @@ inline bool read(const std::string& path, MeshData& out, std::string* err = null
         in >> n;
         std::getline(in, line);
         for (long long i = 0; i < n; ++i) {
-          std::getline(in, line);
+          if (!std::getline(in, line)) return fail("truncated $Elements section", err);
+          if (line.rfind("$EndElements", 0) == 0) break;  // (fewer elements than announced)
           std::istringstream ls(line);
           long long id;
-          int type, ntags;
+          int type = 0, ntags = 0;
           ls >> id >> type >> ntags;
+          if (!ls || ntags < 0 || ntags > 64) return fail("bad element line in .msh", err);
           int elementary = 0;
           for (int t = 0; t < ntags; ++t) {
             int v;
@@ -118,12 +120,12 @@ inline bool read(const std::string& path, MeshData& out, std::string* err = null
         for (long long b = 0; b < nblocks; ++b) {
           int edim, etag, type;
           long long nb;
-          in >> edim >> etag >> type >> nb;
+          if (!(in >> edim >> etag >> type >> nb) || nb < 0 || nb > n) return fail("bad $Elements block", err);
           const int nv = (type > 0 && type < 16) ? nverts_of[type] : -1;
           if (nv < 0) return fail("unsupported element type in .msh", err);
           for (long long i = 0; i < nb; ++i) {
             long long id;
-            in >> id;
+            if (!(in >> id)) return fail("truncated $Elements block", err);
             Elem e{type, etag, {0, 0, 0, 0}};
             for (int k = 0; k < nv; ++k) {
               long long v;

@@ -34,8 +34,9 @@ def reader_exe(tmp_path_factory):
     src = d / "rd.cpp"
     src.write_text(_CXX)
     exe = str(d / "rd")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "pumi-pic_amd", "include"),
-                           str(src), "-o", exe])
+    # (AddressSanitizer + UBSan on this CPU build: the parser reads files it did not write)
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                           "-I", os.path.join(ROOT, "pumi-pic_amd", "include"), str(src), "-o", exe])
     return exe
 
 
@@ -111,3 +112,29 @@ def test_gmsh_boundary_elements_become_side_classification(pp, reader_exe, tmp_p
     t = out.stdout.split()
     assert int(t[13]) == len(sides) and len(sides) > 0
     assert int(t[15]) == int(sum(int(tag) * 1000003 + int(np.sum(sv)) for sv, tag in zip(sides, tags)))
+
+
+def test_gmsh_reader_survives_truncated_and_garbled_files(pp, reader_exe, tmp_path):
+    """the C++ reader under AddressSanitizer / UBSan on files cut at every tenth of their length and with a garbled
+    element section: it reports an error or reads what is there -- no crash, no out-of-bounds access"""
+    from pumipic_amd import meshio
+    coords, e2v, cls = pp.synth.kuhn_box(2)
+    path = str(tmp_path / "m.msh")
+    meshio.write_gmsh(path, 3, coords, e2v, cls)
+    text = open(path).read()
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    for k in range(1, 10):
+        cut = str(tmp_path / ("cut%d.msh" % k))
+        open(cut, "w").write(text[:len(text) * k // 10])
+        out = subprocess.run([reader_exe, cut], capture_output=True, text=True, env=env)
+        assert out.returncode in (0, 1), (k, out.stderr[-1500:])
+        assert "AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr, (k, out.stderr[-1500:])
+    bad = str(tmp_path / "bad.msh")
+    open(bad, "w").write(text.replace("$Elements\n", "$Elements\n999999999\n", 1))
+    out = subprocess.run([reader_exe, bad], capture_output=True, text=True, env=env)
+    assert out.returncode in (0, 1) and "AddressSanitizer" not in out.stderr, out.stderr[-1500:]
+    ref = str(tmp_path / "ref.msh")  # an element that names a node the file does not hold
+    open(ref, "w").write("$MeshFormat\n2.2 0 8\n$EndMeshFormat\n$Nodes\n3\n1 0 0 0\n2 1 0 0\n3 0 1 0\n$EndNodes\n"
+                         "$Elements\n1\n1 2 2 1 1 1 2 7\n$EndElements\n")
+    out = subprocess.run([reader_exe, ref], capture_output=True, text=True, env=env)
+    assert out.returncode == 1 and "unknown node" in out.stdout, (out.stdout, out.stderr[-800:])
