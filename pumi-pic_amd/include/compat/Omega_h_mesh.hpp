@@ -319,6 +319,13 @@ inline Mesh read(const std::string& path, CommPtr, bool = false) {
   int hdr[4] = {0, 0, 0, 0};
   pumipic::gmsh::MeshData m;
   bool ok = f && fread(hdr, sizeof(int), 4, f) == 4 && hdr[0] == 0x50504D31;
+  if (ok) {  // (sizes a file of this length can hold: a garbled header must not become a huge allocation)
+    fseek(f, 0, SEEK_END);
+    const long long len = ftell(f);
+    fseek(f, 4 * (long)sizeof(int), SEEK_SET);
+    ok = (hdr[1] == 2 || hdr[1] == 3) && hdr[2] >= 0 && hdr[3] >= 0 &&
+         16ll + 8ll * hdr[2] * hdr[1] + 4ll * hdr[3] * (hdr[1] + 2) <= len;
+  }
   if (ok) {
     m.dim = hdr[1];
     m.coords.resize((size_t)hdr[2] * m.dim);

@@ -746,6 +746,13 @@ inline void read_parts_container(const std::string& fn, pp_comm* comm, Mesh* pic
   bool ok = f && fread(hdr, sizeof(int), 10, f) == 10 && hdr[0] == 0x50505054 && hdr[9] == pp_comm_size(comm);
   std::vector<double> coords;
   std::vector<int> e2v, cls, owner;
+  if (ok) {  // (sizes a file of this length can hold)
+    fseek(f, 0, SEEK_END);
+    const long long len = ftell(f);
+    fseek(f, 10 * (long)sizeof(int), SEEK_SET);
+    ok = (hdr[1] == 2 || hdr[1] == 3) && hdr[2] >= 0 && hdr[3] >= 0 &&
+         40ll + 8ll * hdr[2] * hdr[1] + 4ll * hdr[3] * (hdr[1] + 3) <= len;
+  }
   if (ok) {
     const int dim = hdr[1];
     coords.resize((size_t)hdr[2] * dim);
