@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "libppo.so")
+# (PPO_LIB=<path>: another build of the same sources, e.g. the AddressSanitizer / UBSan one of `make asan`)
+_LIB_PATH = os.environ.get("PPO_LIB") or os.path.join(_HERE, "_build", "libppo.so")
 
 c_int_p = C.POINTER(C.c_int)
 c_double_p = C.POINTER(C.c_double)
