@@ -230,10 +230,15 @@ def test_mirror_distributor_rank_subset_host_logic(pp, tmp_path):
         pytest.skip("no hipcc")
     libdir = os.path.join(ROOT, "pumi-pic_amd")
     exe = str(tmp_path / "distributor_host")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17",
+    # (host code of the mirror headers under AddressSanitizer on this CPU build)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-fsanitize=address",
+                           "-fno-omit-frame-pointer",
                            os.path.join(ROOT, "tests", "cpp", "distributor_host.cpp"), "-o", exe,
                            "-L" + libdir, "-lpumipic_hip", "-Wl,-rpath," + libdir])
-    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}
+    env["ASAN_OPTIONS"] = "detect_leaks=0"
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120, env=env)
+    assert "AddressSanitizer" not in out.stdout, out.stdout[-3000:]
     assert out.returncode == 0 and "all checks passed" in out.stdout, out.stdout
 
 
@@ -249,7 +254,8 @@ def test_mpi_facade_two_processes_host_only(pp, tmp_path):
         pytest.skip("no hipcc")
     libdir = os.path.join(ROOT, "pumi-pic_amd")
     exe = str(tmp_path / "mpi_facade_host")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17",
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-fsanitize=address",
+                           "-fno-omit-frame-pointer",
                            os.path.join(ROOT, "tests", "cpp", "mpi_facade_host.cpp"), "-o", exe,
                            "-L" + libdir, "-lpumipic_hip", "-Wl,-rpath," + libdir])
     with socket.socket() as sk:
@@ -258,9 +264,11 @@ def test_mpi_facade_two_processes_host_only(pp, tmp_path):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), PP_COMM="tcp", PP_COMM_PORT=str(port))
+                   MASTER_PORT=str(port), PP_COMM="tcp", PP_COMM_PORT=str(port), ASAN_OPTIONS="detect_leaks=0")
+        env.pop("LD_PRELOAD", None)
         procs.append(subprocess.Popen([exe], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=120)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
+        assert "AddressSanitizer" not in o, o[-3000:]
         assert p.returncode == 0 and ("rank %d: all checks passed" % r) in o, o
         assert ("rank %d of 2" % r) in o
